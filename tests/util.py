@@ -1,0 +1,70 @@
+"""Helpers shared by the tests (fixture loading, option parsing)."""
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+MFCC_INT = {"remove_dc_offset", "round_to_power_of_two", "snip_edges", "num_bins", "htk_mode",
+            "num_ceps", "use_energy", "raw_energy", "htk_compat"}
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+
+
+def parse_opts(arr):
+    """['k=v', ...] -> dict with numbers converted."""
+    out = {}
+    for s in arr:
+        k, v = str(s).split("=", 1)
+        try:
+            out[k] = int(v)
+        except ValueError:
+            try:
+                out[k] = float(v)
+            except ValueError:
+                out[k] = v
+    return out
+
+
+def mfcc_kwargs(opts):
+    """Split a fixture's option dict into (struct field kwargs, vtln_warp)."""
+    o = dict(opts)
+    vtln = float(o.pop("vtln_warp", 1.0))
+    kw = {}
+    for k, v in o.items():
+        if k in MFCC_INT:
+            kw[k] = int(v)
+        elif k == "window_type":
+            kw[k] = v
+        else:
+            kw[k] = float(v)
+    return kw, vtln
+
+
+def read_htk(path):
+    """HTK parameter file: 12-byte big-endian header then big-endian float32 rows."""
+    raw = open(path, "rb").read()
+    n = int.from_bytes(raw[0:4], "big")
+    size = int.from_bytes(raw[8:10], "big")
+    d = size // 4
+    return np.frombuffer(raw[12:12 + n * size], dtype=">f4").reshape(n, d).astype(np.float32)
+
+
+def read_wav_pcm16(path):
+    """Minimal RIFF reader for the test fixtures (mono PCM-16)."""
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"RIFF" and raw[8:12] == b"WAVE"
+    pos = 12
+    sr = None
+    while pos < len(raw):
+        cid = raw[pos:pos + 4]
+        sz = int.from_bytes(raw[pos + 4:pos + 8], "little")
+        if cid == b"fmt ":
+            sr = int.from_bytes(raw[pos + 12:pos + 16], "little")
+        if cid == b"data":
+            sz = min(sz, len(raw) - pos - 8)
+            return sr, np.frombuffer(raw[pos + 8:pos + 8 + sz - sz % 2], dtype="<i2")
+        pos += 8 + sz + (sz & 1)
+    raise ValueError("no data chunk")
