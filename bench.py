@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the VoiceBridge hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic 16 kHz utterances that are
+already resident in HBM: MFCC -> CMVN+deltas+fMLLR -> all-pdf GMM log-likelihoods
+[-> lattice beam search, when the decoder is enabled].  Sizes are the DELTA+SAT sizes of
+BASELINE.md (13 MFCC -> 39 dims, 2500 pdfs / 15000 Gaussians, 39x40 per-speaker affine).
+
+    python bench.py --gpus N --steps K --warmup W
+
+For N > 1 it is launched one rank per GPU (torch.distributed.run); utterance batches are
+independent, so ranks share nothing on the data path (weak scaling) and a single all-reduce
+collects the per-rank max time and frame counts at the end.
+
+Prints ONE JSON line (rank 0).  `value` is whole-job frames/s (100 frames = 1 s of audio, so
+RTF = 100 / value).  `roofline` prices the dominant kernel from HIP-event device time
+measured here; `cpu_baseline` times the oracle (oracle/, the parity checker) on a bounded
+sample of the same workload on this host's cores -- a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per step per GPU")
+    ap.add_argument("--seconds", type=float, default=30.0, help="utterance length")
+    ap.add_argument("--pdfs", type=int, default=2500)
+    ap.add_argument("--gauss", type=int, default=15000)
+    ap.add_argument("--no-decode", action="store_true", help="stop after GMM scoring (BASELINE config 2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-seconds", type=float, default=30.0, help="audio seconds timed on the CPU baseline")
+    return ap.parse_args()
+
+
+def build_workload(args, rank):
+    from voicebridge_amd import synth
+    n_spk = max(1, args.batch // 4)
+    # a pool of distinct waveforms, reused round-robin so that host generation stays cheap
+    pool = [synth.wave(rank * 1000 + i, seconds=args.seconds) for i in range(min(args.batch, 8))]
+    waves = [pool[i % len(pool)] for i in range(args.batch)]
+    utt2spk = np.arange(args.batch, dtype=np.int32) % n_spk
+    xforms = np.stack([synth.affine(39, seed=s) for s in range(n_spk)])
+    return waves, utt2spk, n_spk, xforms
+
+
+def feature_space_model(args, sample_feats):
+    """random GMM placed in the feature space of the synthetic data (so that scores have a
+    realistic spread): per-dimension scale = std of the post-processed features."""
+    from voicebridge_amd import synth
+    std = sample_feats.std(0) + 1e-3
+    mu = sample_feats.mean(0)
+    offs, w, means, iv = synth.gmm_model(args.pdfs, args.gauss, 39, seed=1, mean_scale=0.7, dim_scale=std)
+    means = means + mu.astype(np.float32)
+    miv = (means * iv).astype(np.float32)
+    return offs, w, miv, iv
+
+
+def cpu_baseline(args, waves, utt2spk, xforms, model, decode_setup):
+    """oracle (plain C restatement of the reference, 1 thread) on a bounded sample"""
+    from oracle import vbo
+    n_utt = max(1, int(round(args.cpu_sample_seconds / args.seconds)))
+    n_utt = min(n_utt, len(waves))
+    offs, w, miv, iv = model
+    o = vbo.mfcc_opts()
+    gc = vbo.gmm_gconsts(w, miv, iv)
+    t0 = time.perf_counter()
+    frames = 0
+    for u in range(n_utt):
+        raw = vbo.mfcc(waves[u].astype(np.float32), o)
+        st = vbo.acc_cmvn_stats(raw)
+        f = vbo.transform_feats(vbo.add_deltas(vbo.apply_cmvn(raw, st)), xforms[utt2spk[u]])
+        ll = vbo.gmm_loglikes(offs, gc, miv, iv, f)
+        if decode_setup is not None:
+            fst, t2p, cfg = decode_setup
+            vbo.decode_lattice_faster(fst, ll, t2p, **cfg)
+        frames += len(raw)
+    dt = time.perf_counter() - t0
+    return dict(value=frames / dt, unit="frames/s", cores=1, kind="port",
+                sample="%d x %.0f s utterances (%d frames) through the oracle: MFCC, CMVN+deltas+fMLLR, all-pdf "
+                       "GMM scoring%s; on-demand scoring as in the reference would evaluate fewer pdfs"
+                       % (n_utt, args.seconds, frames, ", lattice search" if decode_setup is not None else ""))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from voicebridge_amd import api
+    ctx = api.Context(local_rank)
+    dev = ctx.device
+
+    waves, utt2spk, n_spk, xforms = build_workload(args, rank)
+    mf = api.Mfcc(ctx)
+    post = api.FeaturePipeline(ctx, cmvn=True, mode="delta", spk_xform_shape=(39, 40))
+    d_wave, woff, is_i16 = mf.pack(waves)
+    ctx.torch_sync()
+    raw, foff = mf.compute_packed(d_wave, woff, is_i16)
+    ctx.sync()
+    stats = post.cmvn_stats(raw, foff, utt2spk, n_spk)
+    feats = post.apply(raw, foff, utt2spk=utt2spk, cmvn_stats=stats, spk_xforms=xforms)
+    ctx.sync()
+    T = int(foff[-1])
+    model = feature_space_model(args, feats[: min(T, 20000)].cpu().numpy())
+    gmm = api.DiagGmm(ctx, *model)
+    ll = torch.empty((T, gmm.num_pdfs), dtype=torch.float32, device=dev)
+    ctx.torch_sync()
+
+    decode_setup = None   # filled in when the GPU decoder is part of the step
+
+    def step(timed):
+        if timed:
+            ctx.timer_start(1)
+        mf.compute_packed(d_wave, woff, is_i16, out=raw)
+        post.apply(raw, foff, utt2spk=utt2spk, cmvn_stats=stats, spk_xforms=xforms, out=feats)
+        if timed:
+            ctx.timer_stop(1)
+            ctx.timer_start(2)
+        gmm.loglikes(feats, out=ll)
+        if timed:
+            ctx.timer_stop(2)
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    gmm_ms, feat_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+        gmm_ms.append(ctx.timer_ms(2))      # waits for this step's GMM launch (device time)
+        feat_ms.append(ctx.timer_ms(1))
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        fr = torch.tensor([T * args.steps], dtype=torch.float64, device=dev)
+        dist.all_reduce(fr, op=dist.ReduceOp.SUM)
+        total_frames = float(fr.item())
+    else:
+        total_frames = float(T * args.steps)
+
+    if rank == 0:
+        value = total_frames / dt
+        b, f = gmm.work(T)
+        g_ms = float(np.mean(gmm_ms))
+        out = {
+            "metric": "decode frames/sec/node (RTF = 100/value), DELTA+SAT sizes",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rtf": 100.0 / value,
+            "config": {"workload": ("config2: MFCC + CMVN/deltas/fMLLR + all-pdf GMM scoring (search not in the step)"
+                                    if decode_setup is None else
+                                    "config3: DELTA+SAT full GPU decode, beam 13, lattice-beam 6, max-active 7000"),
+                       "utterances_per_step_per_gpu": args.batch, "utterance_seconds": args.seconds,
+                       "frames_per_step_per_gpu": T, "pdfs": gmm.num_pdfs, "gaussians": gmm.num_gauss, "dim": 39,
+                       "sharding": "utterances over ranks, no data-path collective"},
+            "roofline": {"kernel": "gmm_loglikes_kernel", "bound": "mfma", "achieved": f / (g_ms * 1e-3) / 1e12,
+                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": f / (g_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel_ms": g_ms, "algorithmic_flops": f, "algorithmic_bytes": b,
+                         "hbm_GBs": b / (g_ms * 1e-3) / 1e9, "hbm_frac": b / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "stage_ms": {"mfcc+featpost": float(np.mean(feat_ms)), "gmm": g_ms},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, waves, utt2spk, xforms, model, decode_setup)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

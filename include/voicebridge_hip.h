@@ -1,0 +1,206 @@
+/*
+ * voicebridge_hip.h -- C ABI of the MI355X (gfx950) implementation of VoiceBridge's
+ * acoustic-scoring + decoding hot path.  Plain C, caller-allocated buffers, int status
+ * (0 = ok, -1 = error, text via vbh_last_error()), no exceptions cross the boundary, no
+ * torch/ATen types.  One vbh_ctx per GPU and host thread; entry points taking the same ctx
+ * must not be called concurrently.
+ *
+ * "d_" parameters are DEVICE pointers (hipMalloc'ed memory of the ctx's device, e.g. from
+ * vbh_dev_alloc or a torch tensor's data_ptr()); "h_" parameters are host pointers.  All
+ * device work is enqueued on the ctx's stream (vbh_ctx_stream); entry points return after
+ * enqueueing unless documented otherwise; vbh_ctx_sync waits.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to
+ * /root/reference; K/ = kaldi-master/src/, VB/ = VoiceBridge/VoiceBridge/kaldi-win/).
+ * The argv-style bin functions and the step API of the reference (VB/src/kaldi_src.h:17-101,
+ * VB/scr/kaldi_scr.h:71-165) are re-declared in voicebridge_amd/host/voicebridge_api.h and
+ * are implemented on top of this ABI; INTEGRATION.md shows the binding a maintainer adds.
+ */
+#ifndef VOICEBRIDGE_HIP_H_
+#define VOICEBRIDGE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VBH_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ context / memory */
+typedef struct vbh_ctx vbh_ctx;
+
+int vbh_abi_version(void);
+const char *vbh_last_error(void);                 /* thread-local message of the last failure */
+int vbh_device_count(void);                       /* 0 when no HIP device is visible */
+int vbh_ctx_create(int device_id, vbh_ctx **out); /* fails (-1) when there is no such GPU */
+void vbh_ctx_destroy(vbh_ctx *ctx);
+int vbh_ctx_sync(vbh_ctx *ctx);
+void *vbh_ctx_stream(vbh_ctx *ctx);               /* hipStream_t all work is enqueued on */
+int vbh_ctx_device(vbh_ctx *ctx);
+int vbh_dev_alloc(vbh_ctx *ctx, size_t bytes, void **d_ptr);
+int vbh_dev_free(vbh_ctx *ctx, void *d_ptr);
+int vbh_copy_h2d(vbh_ctx *ctx, void *d_dst, const void *h_src, size_t bytes); /* async on the stream */
+int vbh_copy_d2h(vbh_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* synchronises */
+int vbh_memset(vbh_ctx *ctx, void *d_dst, int value, size_t bytes);
+/* HIP-event stopwatch on the ctx stream (used by bench.py for per-kernel device time) */
+int vbh_timer_start(vbh_ctx *ctx, int slot);
+int vbh_timer_stop(vbh_ctx *ctx, int slot);       /* records the stop event */
+int vbh_timer_elapsed_ms(vbh_ctx *ctx, int slot, float *ms); /* waits for the stop event */
+
+/* ------------------------------------------------------------------ MFCC
+ * replaces Mfcc::ComputeFeatures / OfflineFeatureTpl<MfccComputer>::Compute
+ * (K/feat/feature-common-inl.h:29-98) as driven by ComputeMFCCFeats
+ * (VB/src/featbin/compute-mfcc-feats.cpp:103-147).  Field meaning and defaults are those of
+ * FrameExtractionOptions (K/feat/feature-window.h:33-101), MelBanksOptions
+ * (K/feat/mel-computations.h:43-74) and MfccOptions (K/feat/feature-mfcc.h:38-78). */
+enum { VBH_WIN_HANNING = 0, VBH_WIN_HAMMING = 1, VBH_WIN_POVEY = 2, VBH_WIN_RECTANGULAR = 3,
+       VBH_WIN_BLACKMAN = 4 };
+
+typedef struct vbh_mfcc_opts {
+  float samp_freq, frame_shift_ms, frame_length_ms;
+  float dither;               /* must be 0: the reference's dither draws from libc rand() */
+  float preemph_coeff;
+  int32_t remove_dc_offset, window_type, round_to_power_of_two;
+  float blackman_coeff;
+  int32_t snip_edges;
+  int32_t num_bins;
+  float low_freq, high_freq, vtln_low, vtln_high;
+  int32_t htk_mode;
+  int32_t num_ceps, use_energy;
+  float energy_floor;
+  int32_t raw_energy;
+  float cepstral_lifter;
+  int32_t htk_compat;
+} vbh_mfcc_opts;
+
+void vbh_mfcc_opts_default(vbh_mfcc_opts *o);                    /* reference defaults, dither = 0 */
+int32_t vbh_mfcc_num_frames(const vbh_mfcc_opts *o, int64_t num_samples); /* K/feat/feature-window.cc:41-87 */
+
+typedef struct vbh_mfcc vbh_mfcc;
+/* builds window / mel filterbank / DCT / lifter tables (K/feat/feature-window.cc:109-131,
+ * mel-computations.cc:33-144, matrix-functions.cc:592-608) and uploads them */
+int vbh_mfcc_create(vbh_ctx *ctx, const vbh_mfcc_opts *opts, float vtln_warp, vbh_mfcc **out);
+void vbh_mfcc_destroy(vbh_mfcc *m);
+/* Batch of n_utt utterances.  d_wave holds the samples of all utterances back to back
+ * (int16 PCM when wave_is_int16, else float in int16 range as WaveData keeps them,
+ * K/feat/wave-reader.cc:260-310); utterance u is samples [h_wave_offsets[u], h_wave_offsets[u+1]).
+ * h_frame_offsets (n_utt+1, written by the call) gives the row range of each utterance in
+ * d_feats ([total_frames x num_ceps] row-major float32, caller sized with
+ * vbh_mfcc_num_frames). */
+int vbh_mfcc_compute(vbh_mfcc *m, const void *d_wave, int wave_is_int16,
+                     const int64_t *h_wave_offsets, int32_t n_utt, float *d_feats,
+                     int64_t *h_frame_offsets);
+
+/* ------------------------------------------------------------------ feature post-processing
+ * replaces the apply-cmvn | add-deltas | [splice-feats | transform-feats final.mat] |
+ * [transform-feats trans.JOB] pipeline that Decode() builds
+ * (VB/scr/steps/decode_gmm.cpp:201-293): ApplyCmvn (K/transform/cmvn.cc:64-113),
+ * ComputeDeltas (K/feat/feature-functions.cc:160-171), SpliceFrames (:205-226) and the
+ * body of TransformFeats (VB/src/featbin/transform-feats.cpp:89-107), fused in one pass. */
+typedef struct vbh_featpost_cfg {
+  int32_t in_dim;            /* 13 */
+  int32_t apply_cmvn;        /* 0/1 */
+  int32_t norm_vars;         /* cmvn --norm-vars */
+  int32_t mode;              /* 0 = none, 1 = deltas, 2 = splice */
+  int32_t delta_order, delta_window;   /* 2, 2 */
+  int32_t splice_left, splice_right;   /* 4, 4 */
+  int32_t lda_rows, lda_cols;          /* global transform after deltas/splice; 0 = none.
+                                          cols == dim (linear) or dim+1 (affine) */
+  int32_t spk_rows, spk_cols;          /* per-speaker (fMLLR) transform; 0 = none */
+} vbh_featpost_cfg;
+
+int32_t vbh_featpost_out_dim(const vbh_featpost_cfg *cfg);
+/* h_cmvn_stats: [n_spk][2][in_dim+1] double (K/transform/cmvn.cc:25-47); h_lda: [lda_rows][lda_cols];
+ * h_spk_xform: [n_spk][spk_rows][spk_cols]; h_utt2spk: [n_utt] speaker index of each utterance.
+ * d_in [total_frames x in_dim], d_out [total_frames x out_dim]. */
+int vbh_featpost(vbh_ctx *ctx, const vbh_featpost_cfg *cfg, const float *d_in,
+                 const int64_t *h_frame_offsets, int32_t n_utt, const int32_t *h_utt2spk,
+                 int32_t n_spk, const double *h_cmvn_stats, const float *h_lda,
+                 const float *h_spk_xform, float *d_out);
+/* CMVN statistics per speaker (ComputeCmvnStats, K/transform/cmvn.cc:30-62): h_stats_out
+ * [n_spk][2][dim+1] double, accumulated on the device, copied back (synchronises). */
+int vbh_cmvn_stats(vbh_ctx *ctx, const float *d_feats, int32_t dim, const int64_t *h_frame_offsets,
+                   int32_t n_utt, const int32_t *h_utt2spk, int32_t n_spk, double *h_stats_out);
+
+/* ------------------------------------------------------------------ diagonal GMM scoring
+ * replaces AmDiagGmm + DecodableAmDiagGmmScaled::LogLikelihood evaluated for every pdf of
+ * every frame (K/gmm/decodable-am-diag-gmm.cc:28-72, K/gmm/diag-gmm.cc:528-562,
+ * K/matrix/kaldi-vector.cc:757-775).  Model arrays are those of DiagGmm
+ * (K/gmm/diag-gmm.h: weights_, means_invvars_, inv_vars_); gconsts are recomputed as
+ * DiagGmm::Read does (K/gmm/diag-gmm.cc:114-152, :728-756). */
+typedef struct vbh_gmm vbh_gmm;
+int vbh_gmm_create(vbh_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h_pdf_offsets,
+                   const float *h_weights, const float *h_means_invvars, const float *h_inv_vars,
+                   vbh_gmm **out);
+void vbh_gmm_destroy(vbh_gmm *g);
+int32_t vbh_gmm_num_pdfs(const vbh_gmm *g);
+int32_t vbh_gmm_dim(const vbh_gmm *g);
+int vbh_gmm_get_gconsts(const vbh_gmm *g, float *h_gconsts);   /* [G] as computed at create */
+/* d_feats [T x dim] -> d_loglikes [T x num_pdfs] (unscaled log-likelihoods) */
+int vbh_gmm_loglikes(vbh_gmm *g, const float *d_feats, int64_t T, float *d_loglikes);
+/* algorithmic work of one vbh_gmm_loglikes call: bytes and flops */
+int vbh_gmm_work(const vbh_gmm *g, int64_t T, double *bytes, double *flops);
+
+/* ------------------------------------------------------------------ decoding graph + search
+ * Graph arrays are those of fst::ConstFst<StdArc> (openfst-win-1.6/src/include/fst/const-fst.h:102-110,
+ * arc.h:27-36) as read by ReadFstKaldiGeneric (K/fstext/kaldi-fst-io.cc:45-90). */
+typedef struct vbh_arc { int32_t ilabel, olabel; float weight; int32_t nextstate; } vbh_arc;
+typedef struct vbh_graph vbh_graph;
+int vbh_graph_create(vbh_ctx *ctx, int32_t num_states, int32_t start, const float *h_final,
+                     const int64_t *h_arc_offsets, const vbh_arc *h_arcs, vbh_graph **out);
+void vbh_graph_destroy(vbh_graph *g);
+
+/* LatticeFasterDecoderConfig (K/decoder/lattice-faster-decoder.h:41-92) */
+typedef struct vbh_decode_cfg {
+  float beam;            /* 13 */
+  int32_t max_active;    /* 7000 */
+  int32_t min_active;    /* 200 */
+  float lattice_beam;    /* 6 */
+  int32_t prune_interval;/* 25 */
+  float beam_delta;      /* 0.5 */
+  float acoustic_scale;  /* 0.083333 */
+} vbh_decode_cfg;
+void vbh_decode_cfg_default(vbh_decode_cfg *c);
+
+/* Result of decoding one utterance: the lattice-beam-pruned token/arc sets after
+ * FinalizeDecoding (K/decoder/lattice-faster-decoder.cc:600-615), i.e. the content of
+ * GetRawLattice (:110-192), plus the best path (GetBestPath :100-106 and
+ * GetLinearSymbolSequence).  Arrays are owned by the result object. */
+typedef struct vbh_lattice {
+  int32_t ok, reached_final, num_frames;
+  float final_relative_cost;
+  int32_t num_toks;
+  const int32_t *tok_frame, *tok_state;
+  const float *tok_cost, *tok_extra, *tok_final;
+  int32_t num_links;
+  const int32_t *link_src, *link_dst, *link_ilabel, *link_olabel;
+  const float *link_graph, *link_acoustic;
+  int32_t num_ali; const int32_t *ali;
+  int32_t num_words; const int32_t *words;
+  float best_graph, best_acoustic;
+  /* per-utterance counters of the run (decoder roofline) */
+  int64_t n_tokens_expanded, n_arcs_expanded, n_tokens_created, n_links_created;
+  int32_t n_frames_maxactive_bound, n_frames_minactive_bound;
+} vbh_lattice;
+
+typedef struct vbh_decoder vbh_decoder;
+/* max_frames bounds the longest utterance, max_batch the utterances searched concurrently */
+int vbh_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_decode_cfg *cfg,
+                       int32_t max_batch, int32_t max_frames, vbh_decoder **out);
+void vbh_decoder_destroy(vbh_decoder *d);
+/* Replaces LatticeFasterDecoder::Decode + FinalizeDecoding for a batch of utterances
+ * (DecodeUtteranceLatticeFaster, K/decoder/decoder-wrappers.cc:198-293).  d_loglikes
+ * [total_frames x num_pdfs] unscaled; h_tid2pdf [num_tids+1] = TransitionModel::id2pdf_id_
+ * (K/hmm/transition-model.h:324-328).  Synchronises; results are read with
+ * vbh_decoder_result and stay valid until the next decode call. */
+int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs,
+                     const int64_t *h_frame_offsets, int32_t n_utt, const int32_t *h_tid2pdf,
+                     int32_t num_tids);
+int vbh_decoder_result(vbh_decoder *d, int32_t utt, vbh_lattice *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOICEBRIDGE_HIP_H_ */

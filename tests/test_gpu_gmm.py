@@ -1,0 +1,78 @@
+"""GPU parity: all-pdf diagonal-GMM log-likelihoods vs the golden vectors (reference) and the oracle."""
+import numpy as np
+import pytest
+
+from tests.util import load
+
+pytestmark = pytest.mark.gpu
+
+# north_star: GMM log-likelihoods "within stated float tolerance".  Stated: 1e-4 relative
+#  with a small absolute floor for values near zero.
+RTOL, ATOL = 1e-4, 1e-3
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from voicebridge_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("name", ["gmm_p8_d39", "gmm_p64_d40"])
+def test_gmm_golden(ctx, name):
+    import torch
+    from voicebridge_amd import api
+    g = load(name)
+    m = api.DiagGmm(ctx, g["offs"], g["weights"], g["miv"], g["inv_vars"])
+    gc = m.gconsts()
+    fin = np.isfinite(g["gconsts"])
+    np.testing.assert_array_equal(np.isneginf(gc), np.isneginf(g["gconsts"]))   # zero-weight component
+    np.testing.assert_allclose(gc[fin], g["gconsts"][fin], rtol=1e-6, atol=1e-4)
+    ll = m.loglikes(torch.from_numpy(g["feats"]).to(ctx.device))
+    ctx.sync()
+    np.testing.assert_allclose(ll.cpu().numpy(), g["loglikes"], rtol=RTOL, atol=ATOL)
+    m.close()
+
+
+@pytest.mark.parametrize("P,G,D,T", [(50, 300, 39, 200), (7, 7, 13, 65), (300, 1800, 40, 130), (3, 240, 39, 5)])
+def test_gmm_vs_oracle(ctx, P, G, D, T):
+    """ragged frame counts (not multiples of the 64-frame tile), 1-Gaussian pdfs, pdfs with
+    ~100 Gaussians, tiles split over blockIdx.y"""
+    import torch
+    from oracle import vbo
+    from voicebridge_amd import api, synth
+    offs, w, means, iv = synth.gmm_model(P, G, D, seed=P + G)
+    miv = (means * iv).astype(np.float32)
+    rng = np.random.default_rng(T)
+    feats = (rng.standard_normal((T, D)) * 1.3).astype(np.float32)
+    m = api.DiagGmm(ctx, offs, w, miv, iv)
+    ll = m.loglikes(torch.from_numpy(feats).to(ctx.device))
+    ctx.sync()
+    ref = vbo.gmm_loglikes(offs, vbo.gmm_gconsts(w, miv, iv), miv, iv, feats)
+    np.testing.assert_allclose(ll.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+    m.close()
+
+
+def test_gmm_reference_sizes_property(ctx):
+    """BASELINE sizes (P=2500, G=15000, D=39): scoring a frame batch must equal scoring its
+    rows one tile at a time in any order (each output depends on its own frame only), and a
+    sample of rows must match the oracle."""
+    import torch
+    from oracle import vbo
+    from voicebridge_amd import api, synth
+    offs, w, means, iv = synth.gmm_model(2500, 15000, 39, seed=1)
+    miv = (means * iv).astype(np.float32)
+    rng = np.random.default_rng(3)
+    feats = (rng.standard_normal((2998, 39)) * 1.2).astype(np.float32)
+    m = api.DiagGmm(ctx, offs, w, miv, iv)
+    d = torch.from_numpy(feats).to(ctx.device)
+    full = m.loglikes(d)
+    perm = torch.from_numpy(rng.permutation(2998)).to(ctx.device)
+    shuf = m.loglikes(d[perm].contiguous())
+    ctx.sync()
+    assert torch.equal(full[perm], shuf)                       # bit-exact: row independence
+    rows = rng.choice(2998, 6, replace=False)
+    ref = vbo.gmm_loglikes(offs, vbo.gmm_gconsts(w, miv, iv), miv, iv, feats[rows])
+    np.testing.assert_allclose(full[torch.from_numpy(rows).to(ctx.device)].cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+    m.close()

@@ -1,0 +1,215 @@
+"""Host-side Python mirror of the reference's operator interface for the hot path, on top of
+the C ABI (include/voicebridge_hip.h).  torch is used only to own device memory; every
+compute call goes through libvoicebridge_hip.so and fails loudly when the library or the GPU
+is missing.
+
+Reference objects mirrored (paths relative to /root/reference/kaldi-master/src/):
+  Mfcc             feat/feature-mfcc.h:143      ComputeFeatures(wave, ...)
+  ComputeDeltas / ApplyCmvn / SpliceFrames / transform-feats -> FeaturePipeline
+  AmDiagGmm + DecodableAmDiagGmmScaled          gmm/am-diag-gmm.h, gmm/decodable-am-diag-gmm.h
+  LatticeFasterDecoder                          decoder/lattice-faster-decoder.h:130-155
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+WIN = {"hanning": 0, "hamming": 1, "povey": 2, "rectangular": 3, "blackman": 4}
+
+
+def _i64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def _i32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+
+
+def _f32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+class Context:
+    """One per GPU (vbh_ctx)."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        if self.lib.vbh_device_count() <= 0:
+            raise _lib.VbhError("no HIP device visible: voicebridge_amd has no CPU path")
+        h = C.c_void_p()
+        check(self.lib.vbh_ctx_create(int(device), C.byref(h)), "vbh_ctx_create")
+        self.h = h
+        self.device = torch.device("cuda", int(device))
+
+    def sync(self):
+        check(self.lib.vbh_ctx_sync(self.h), "vbh_ctx_sync")
+
+    def torch_sync(self):
+        """make work enqueued by torch (allocations, copies) visible to the ctx stream"""
+        torch.cuda.synchronize(self.device)
+
+    def timer_start(self, slot=0):
+        check(self.lib.vbh_timer_start(self.h, slot), "vbh_timer_start")
+
+    def timer_stop(self, slot=0):
+        check(self.lib.vbh_timer_stop(self.h, slot), "vbh_timer_stop")
+
+    def timer_ms(self, slot=0):
+        ms = C.c_float()
+        check(self.lib.vbh_timer_elapsed_ms(self.h, slot, C.byref(ms)), "vbh_timer_elapsed_ms")
+        return ms.value
+
+    def close(self):
+        if self.h:
+            self.lib.vbh_ctx_destroy(self.h)
+            self.h = None
+
+
+def mfcc_opts(**kw):
+    o = _lib.MfccOpts()
+    _lib.load().vbh_mfcc_opts_default(C.byref(o))
+    for k, v in kw.items():
+        if k == "window_type" and isinstance(v, str):
+            v = WIN[v]
+        if not hasattr(o, k):
+            raise KeyError(k)
+        setattr(o, k, v)
+    return o
+
+
+class Mfcc:
+    """compute-mfcc-feats for a batch of utterances (vbh_mfcc_*)."""
+
+    def __init__(self, ctx, vtln_warp=1.0, **opts):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.opts = mfcc_opts(**opts)
+        h = C.c_void_p()
+        check(self.lib.vbh_mfcc_create(ctx.h, C.byref(self.opts), C.c_float(vtln_warp), C.byref(h)), "vbh_mfcc_create")
+        self.h = h
+
+    def num_frames(self, num_samples):
+        return self.lib.vbh_mfcc_num_frames(C.byref(self.opts), int(num_samples))
+
+    def pack(self, waves):
+        """list of 1-D int16/float32 arrays -> (device tensor, int64 offsets[n+1], is_int16)"""
+        is_i16 = all(w.dtype == np.int16 for w in waves)
+        dt = np.int16 if is_i16 else np.float32
+        offs = np.zeros(len(waves) + 1, np.int64)
+        offs[1:] = np.cumsum([len(w) for w in waves])
+        flat = np.concatenate([np.asarray(w, dt) for w in waves]) if waves else np.zeros(0, dt)
+        return torch.from_numpy(flat).to(self.ctx.device), offs, is_i16
+
+    def compute_packed(self, d_wave, wave_offsets, is_int16, out=None):
+        n = len(wave_offsets) - 1
+        total = sum(self.num_frames(wave_offsets[u + 1] - wave_offsets[u]) for u in range(n))
+        if out is None:
+            out = torch.empty((total, self.opts.num_ceps), dtype=torch.float32, device=self.ctx.device)
+            self.ctx.torch_sync()
+        foff = np.zeros(n + 1, np.int64)
+        wo = np.ascontiguousarray(wave_offsets, np.int64)
+        check(self.lib.vbh_mfcc_compute(self.h, d_wave.data_ptr(), int(is_int16), _i64p(wo), n, out.data_ptr(), _i64p(foff)),
+              "vbh_mfcc_compute")
+        return out, foff
+
+    def compute(self, waves):
+        d_wave, offs, is_i16 = self.pack(waves)
+        self.ctx.torch_sync()
+        out, foff = self.compute_packed(d_wave, offs, is_i16)
+        self.ctx.sync()
+        return out, foff
+
+    def close(self):
+        if self.h:
+            self.lib.vbh_mfcc_destroy(self.h)
+            self.h = None
+
+
+class FeaturePipeline:
+    """apply-cmvn | add-deltas (or splice-feats | transform-feats final.mat) | transform-feats trans
+    (VB/scr/steps/decode_gmm.cpp:201-293) as one fused device pass (vbh_featpost)."""
+
+    def __init__(self, ctx, in_dim=13, cmvn=True, norm_vars=False, mode="delta", delta_order=2, delta_window=2,
+                 splice_left=4, splice_right=4, lda=None, spk_xform_shape=None):
+        self.ctx, self.lib = ctx, ctx.lib
+        c = _lib.FeatPostCfg()
+        c.in_dim, c.apply_cmvn, c.norm_vars = in_dim, int(cmvn), int(norm_vars)
+        c.mode = {"none": 0, "delta": 1, "splice": 2}[mode]
+        c.delta_order, c.delta_window, c.splice_left, c.splice_right = delta_order, delta_window, splice_left, splice_right
+        self.lda = None
+        if lda is not None:
+            self.lda = np.ascontiguousarray(lda, np.float32)
+            c.lda_rows, c.lda_cols = self.lda.shape
+        if spk_xform_shape is not None:
+            c.spk_rows, c.spk_cols = spk_xform_shape
+        self.cfg = c
+        self.out_dim = self.lib.vbh_featpost_out_dim(C.byref(c))
+
+    def apply(self, d_in, frame_offsets, utt2spk=None, cmvn_stats=None, spk_xforms=None, out=None):
+        n = len(frame_offsets) - 1
+        fo = np.ascontiguousarray(frame_offsets, np.int64)
+        u2s = np.ascontiguousarray(utt2spk, np.int32) if utt2spk is not None else np.zeros(n, np.int32)
+        n_spk = int(u2s.max()) + 1 if n else 1
+        st = np.ascontiguousarray(cmvn_stats, np.float64) if cmvn_stats is not None else None
+        if st is not None:
+            n_spk = st.shape[0]
+        sx = np.ascontiguousarray(spk_xforms, np.float32) if spk_xforms is not None else None
+        if sx is not None:
+            n_spk = sx.shape[0]
+        if out is None:
+            out = torch.empty((int(fo[-1]), self.out_dim), dtype=torch.float32, device=self.ctx.device)
+            self.ctx.torch_sync()
+        check(self.lib.vbh_featpost(self.ctx.h, C.byref(self.cfg), d_in.data_ptr(), _i64p(fo), n, _i32p(u2s), n_spk,
+                                    st.ctypes.data_as(C.POINTER(C.c_double)) if st is not None else None,
+                                    _f32p(self.lda), _f32p(sx), out.data_ptr()), "vbh_featpost")
+        return out
+
+    def cmvn_stats(self, d_feats, frame_offsets, utt2spk, n_spk):
+        fo = np.ascontiguousarray(frame_offsets, np.int64)
+        u2s = np.ascontiguousarray(utt2spk, np.int32)
+        dim = d_feats.shape[1]
+        out = np.zeros((n_spk, 2, dim + 1), np.float64)
+        check(self.lib.vbh_cmvn_stats(self.ctx.h, d_feats.data_ptr(), dim, _i64p(fo), len(fo) - 1, _i32p(u2s), n_spk,
+                                      out.ctypes.data_as(C.POINTER(C.c_double))), "vbh_cmvn_stats")
+        return out
+
+
+class DiagGmm:
+    """AmDiagGmm scored for every pdf of every frame (vbh_gmm_*)."""
+
+    def __init__(self, ctx, pdf_offsets, weights, means_invvars, inv_vars):
+        self.ctx, self.lib = ctx, ctx.lib
+        offs = np.ascontiguousarray(pdf_offsets, np.int32)
+        w = np.ascontiguousarray(weights, np.float32)
+        miv = np.ascontiguousarray(means_invvars, np.float32)
+        iv = np.ascontiguousarray(inv_vars, np.float32)
+        self.num_pdfs, self.dim, self.num_gauss = len(offs) - 1, miv.shape[1], miv.shape[0]
+        h = C.c_void_p()
+        check(self.lib.vbh_gmm_create(ctx.h, self.dim, self.num_pdfs, _i32p(offs), _f32p(w), _f32p(miv), _f32p(iv), C.byref(h)),
+              "vbh_gmm_create")
+        self.h = h
+
+    def gconsts(self):
+        out = np.zeros(self.num_gauss, np.float32)
+        check(self.lib.vbh_gmm_get_gconsts(self.h, _f32p(out)), "vbh_gmm_get_gconsts")
+        return out
+
+    def loglikes(self, d_feats, out=None):
+        T = d_feats.shape[0]
+        if out is None:
+            out = torch.empty((T, self.num_pdfs), dtype=torch.float32, device=self.ctx.device)
+            self.ctx.torch_sync()
+        check(self.lib.vbh_gmm_loglikes(self.h, d_feats.data_ptr(), T, out.data_ptr()), "vbh_gmm_loglikes")
+        return out
+
+    def work(self, T):
+        b, f = C.c_double(), C.c_double()
+        self.lib.vbh_gmm_work(self.h, int(T), C.byref(b), C.byref(f))
+        return b.value, f.value
+
+    def close(self):
+        if self.h:
+            self.lib.vbh_gmm_destroy(self.h)
+            self.h = None

@@ -1,0 +1,114 @@
+// vbh_ctx.hip -- context, memory and stopwatch entry points of the C ABI.
+#include "vbh_internal.h"
+
+static thread_local char g_err[1024] = "";
+
+void vbh_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" {
+
+int vbh_abi_version(void) { return VBH_ABI_VERSION; }
+const char *vbh_last_error(void) { return g_err; }
+
+int vbh_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int vbh_ctx_create(int device_id, vbh_ctx **out) {
+  VBH_CHECK(out != nullptr, "vbh_ctx_create: out is NULL");
+  int n = vbh_device_count();
+  VBH_CHECK(n > 0, "vbh_ctx_create: no HIP device visible (this library has no CPU path)");
+  VBH_CHECK(device_id >= 0 && device_id < n, "vbh_ctx_create: device %d out of range (%d devices)", device_id, n);
+  VBH_HIP(hipSetDevice(device_id));
+  vbh_ctx *c = new vbh_ctx();
+  c->device = device_id;
+  VBH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (int i = 0; i < VBH_MAX_TIMERS; i++) {
+    VBH_HIP(hipEventCreate(&c->ev_start[i]));
+    VBH_HIP(hipEventCreate(&c->ev_stop[i]));
+  }
+  hipDeviceProp_t prop;
+  VBH_HIP(hipGetDeviceProperties(&prop, device_id));
+  c->num_cus = prop.multiProcessorCount;
+  *out = c;
+  return 0;
+}
+
+void vbh_ctx_destroy(vbh_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (int i = 0; i < VBH_MAX_TIMERS; i++) {
+    (void)hipEventDestroy(c->ev_start[i]);
+    (void)hipEventDestroy(c->ev_stop[i]);
+  }
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int vbh_ctx_sync(vbh_ctx *c) {
+  if (vbh_use_device(c)) return -1;
+  VBH_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+void *vbh_ctx_stream(vbh_ctx *c) { return reinterpret_cast<void *>(c->stream); }
+int vbh_ctx_device(vbh_ctx *c) { return c->device; }
+
+int vbh_dev_alloc(vbh_ctx *c, size_t bytes, void **d_ptr) {
+  if (vbh_use_device(c)) return -1;
+  VBH_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+  return 0;
+}
+int vbh_dev_free(vbh_ctx *c, void *d_ptr) {
+  if (vbh_use_device(c)) return -1;
+  VBH_HIP(hipStreamSynchronize(c->stream));
+  VBH_HIP(hipFree(d_ptr));
+  return 0;
+}
+int vbh_copy_h2d(vbh_ctx *c, void *d_dst, const void *h_src, size_t bytes) {
+  if (vbh_use_device(c)) return -1;
+  if (bytes) VBH_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+  // pageable host memory: make the copy complete before the caller may reuse h_src
+  VBH_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int vbh_copy_d2h(vbh_ctx *c, void *h_dst, const void *d_src, size_t bytes) {
+  if (vbh_use_device(c)) return -1;
+  if (bytes) VBH_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+  VBH_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int vbh_memset(vbh_ctx *c, void *d_dst, int value, size_t bytes) {
+  if (vbh_use_device(c)) return -1;
+  if (bytes) VBH_HIP(hipMemsetAsync(d_dst, value, bytes, c->stream));
+  return 0;
+}
+
+int vbh_timer_start(vbh_ctx *c, int slot) {
+  VBH_CHECK(slot >= 0 && slot < VBH_MAX_TIMERS, "timer slot %d out of range", slot);
+  if (vbh_use_device(c)) return -1;
+  VBH_HIP(hipEventRecord(c->ev_start[slot], c->stream));
+  return 0;
+}
+int vbh_timer_stop(vbh_ctx *c, int slot) {
+  VBH_CHECK(slot >= 0 && slot < VBH_MAX_TIMERS, "timer slot %d out of range", slot);
+  if (vbh_use_device(c)) return -1;
+  VBH_HIP(hipEventRecord(c->ev_stop[slot], c->stream));
+  return 0;
+}
+int vbh_timer_elapsed_ms(vbh_ctx *c, int slot, float *ms) {
+  VBH_CHECK(slot >= 0 && slot < VBH_MAX_TIMERS, "timer slot %d out of range", slot);
+  if (vbh_use_device(c)) return -1;
+  VBH_HIP(hipEventSynchronize(c->ev_stop[slot]));
+  VBH_HIP(hipEventElapsedTime(ms, c->ev_start[slot], c->ev_stop[slot]));
+  return 0;
+}
+
+}  // extern "C"

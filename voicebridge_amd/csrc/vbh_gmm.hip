@@ -1,0 +1,285 @@
+// vbh_gmm.hip -- all-pdf diagonal-GMM log-likelihoods on gfx950.
+//
+// Replaces (paths relative to /root/reference/kaldi-master/src/):
+//   gmm/decodable-am-diag-gmm.cc:28-72  DecodableAmDiagGmmUnmapped::LogLikelihoodZeroBased
+//                                        (gconsts + means_invvars.x - 0.5 inv_vars.x^2, LogSumExp)
+//   gmm/diag-gmm.cc:546-562              DiagGmm::LogLikelihoods (matrix form: the reference
+//                                        itself evaluates a frame batch as two sgemm, K = D)
+//   gmm/diag-gmm.cc:114-152              ComputeGconsts (host, at create)
+//   matrix/kaldi-vector.cc:757-775       LogSumExp with the max + log(FLT_EPSILON) cutoff
+//
+// Formulation.  For a tile of 64 frames and up to 128 Gaussians the per-Gaussian
+// log-likelihoods are one exact-f32 MFMA contraction  C[t][g] = sum_k A[t][k] B[k][g]  with
+//   A[t] = [ x_0..x_{D-1}, x_0^2..x_{D-1}^2, 1, 0.. ]           (K = 2D+1, padded to 8)
+//   B[:,g] = [ miv_g, -0.5 iv_g, gconst_g, 0.. ]
+// (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, bit-identical to VALU f32), followed by
+// a log-sum-exp over each pdf's own Gaussians.  The model is packed once, tile-major, so a
+// workgroup streams B tiles with 16-byte coalesced loads (L2/MALL resident: 4.7 MB at
+// G = 15000, D = 39) while its 64 frames of A stay in LDS.  The accumulator tile is spilled to
+// the LDS space of the B tile it came from, and the epilogue threads walk pdfs.
+//
+// Roofline: per T frames  bytes = 4(2GD+G) + 4TD + 4TP,
+// flops = TG(4D+2) + TG + TP.  At the reference sizes this is fp32-matrix bound (AI ~ 200
+// flop/B), so bench.py prices this kernel against the 157.3 TFLOP/s f32 MFMA peak and also
+// reports its HBM fraction.
+#include "vbh_internal.h"
+
+#include <cfloat>
+#include <cmath>
+
+namespace {
+
+constexpr int TM = 64;        // frames per workgroup
+constexpr int TN = 128;       // Gaussian columns per tile
+constexpr int LDA = TM + 1;   // padded row of the A tile (k-major)
+constexpr int LDC = TN + 1;   // padded row of the spilled accumulator tile
+constexpr int MAXPRE = 16;    // float4 prefetch registers per thread: Kpad = 8*NPRE <= 128
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;   // native vector: stays in VGPRs across the tile loop
+
+struct GmmTile { int g0, ng, p0, np; };
+
+// NPRE = Kpad/8: a B tile is Kpad*TN/4 = 256*NPRE float4, i.e. exactly NPRE per thread, so
+// the prefetch registers need no predicate (a predicated register array goes to scratch).
+template <int NPRE>
+__global__ __launch_bounds__(256, 2) void gmm_loglikes_kernel(
+    const float *__restrict__ feats, long long T, int D, int P,
+    const float *__restrict__ Bp,          // [n_tiles][Kpad][TN]
+    const GmmTile *__restrict__ tiles, int n_tiles, int tiles_per_group,
+    const int *__restrict__ pdf_offsets,   // [P+1]
+    float *__restrict__ out) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int Kpad = NPRE * 8;
+  float *sA = lds;                                   // [Kpad][LDA]
+  float *sB = sA + Kpad * LDA + ((4 - (Kpad * LDA) % 4) % 4);  // 16-byte aligned, [Kpad][TN], aliased by C
+  float *sC = sB;                                    // [TM][LDC]
+  const int bc_floats = (Kpad * TN > TM * LDC) ? Kpad * TN : TM * LDC;
+  int *sOff = reinterpret_cast<int *>(sB + bc_floats);  // [TN+1] pdf column starts of the tile
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const long long t0 = (long long)blockIdx.x * TM;
+  const int j_begin = blockIdx.y * tiles_per_group;
+  int j_end = j_begin + tiles_per_group;
+  if (j_end > n_tiles) j_end = n_tiles;
+
+  // ---- A tile: [x, x^2, 1, 0...] for 64 frames, k-major
+  for (int idx = tid; idx < TM * D; idx += 256) {
+    const int t = idx / D, d = idx - t * D;
+    float x = 0.f;
+    if (t0 + t < T) x = feats[(t0 + t) * D + d];
+    sA[d * LDA + t] = x;
+    sA[(D + d) * LDA + t] = x * x;
+  }
+  for (int idx = tid; idx < (Kpad - 2 * D) * TM; idx += 256) {
+    const int k = 2 * D + idx / TM, t = idx % TM;
+    sA[k * LDA + t] = (k == 2 * D) ? 1.0f : 0.0f;
+  }
+
+  f32x4 pre[NPRE];
+  {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(Bp + (size_t)j_begin * Kpad * TN);
+#pragma unroll
+    for (int i = 0; i < NPRE; i++) pre[i] = src[tid + i * 256];
+  }
+
+  const int r = wid & 1, cpair = wid >> 1;   // wave tile: rows r*32.., column tiles 2*cpair, 2*cpair+1
+  const int khalf = lane >> 5, l31 = lane & 31;
+
+  for (int j = j_begin; j < j_end; j++) {
+    const GmmTile tile = tiles[j];
+    // ---- commit the prefetched B tile to LDS
+    {
+      f32x4 *dst = reinterpret_cast<f32x4 *>(sB);
+#pragma unroll
+      for (int i = 0; i < NPRE; i++) dst[tid + i * 256] = pre[i];
+      for (int q = tid; q <= tile.np; q += 256) sOff[q] = pdf_offsets[tile.p0 + q] - tile.g0;
+    }
+    __syncthreads();
+    {   // next tile's loads stay in flight under the MFMA loop (the tile array has one
+        // spare zero tile at the end, so the last iteration needs no branch)
+      const f32x4 *src = reinterpret_cast<const f32x4 *>(Bp + (size_t)(j + 1) * Kpad * TN);
+#pragma unroll
+      for (int i = 0; i < NPRE; i++) pre[i] = src[tid + i * 256];
+    }
+    // ---- 64 x 128 x Kpad contraction, two 32x32 accumulators per wave
+    f32x16 acc0 = {0}, acc1 = {0};
+    const float *pa = sA + khalf * LDA + r * 32 + l31;
+    const float *pb = sB + khalf * TN + cpair * 64 + l31;
+#pragma unroll 8
+    for (int kk = 0; kk < Kpad / 2; kk++) {
+      const float a = pa[kk * 2 * LDA];
+      const float b0 = pb[kk * 2 * TN], b1 = pb[kk * 2 * TN + 32];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    }
+    __syncthreads();   // every wave is done reading sB
+    // ---- spill accumulators: C/D map col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int row = r * 32 + (i & 3) + 8 * (i >> 2) + 4 * khalf;
+      sC[row * LDC + cpair * 64 + l31] = acc0[i];
+      sC[row * LDC + cpair * 64 + 32 + l31] = acc1[i];
+    }
+    __syncthreads();
+    // ---- per (frame, pdf) LogSumExp (kaldi-vector.cc:757-775)
+    const int pairs = TM * tile.np;
+    const float kMinLogDiff = -15.9423847198486328125f;   // logf(FLT_EPSILON)
+    for (int idx = tid; idx < pairs; idx += 256) {
+      const int t = idx / tile.np, q = idx - t * tile.np;
+      const int cs = sOff[q], ce = sOff[q + 1];
+      const float *row = sC + t * LDC;
+      float m = -INFINITY;
+      for (int c = cs; c < ce; c++) m = fmaxf(m, row[c]);
+      float res = m;
+      if (m > -INFINITY) {
+        const float cutoff = m + kMinLogDiff;
+        float s = 0.f;
+        for (int c = cs; c < ce; c++) {
+          const float v = row[c];
+          if (v >= cutoff) s += __expf(v - m);
+        }
+        res = m + __logf(s);
+      }
+      if (t0 + t < T) out[(t0 + t) * P + tile.p0 + q] = res;
+    }
+    __syncthreads();   // sC (= sB) is free for the next tile
+  }
+}
+
+}  // namespace
+
+struct vbh_gmm {
+  vbh_ctx *ctx;
+  int D, P, G, Kpad, n_tiles;
+  std::vector<float> gconsts;
+  std::vector<int> offs;
+  DevBuf<float> Bp;
+  DevBuf<GmmTile> tiles;
+  DevBuf<int> d_offs;
+  size_t lds_bytes;
+};
+
+extern "C" {
+
+int vbh_gmm_create(vbh_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h_pdf_offsets,
+                   const float *h_weights, const float *h_miv, const float *h_iv, vbh_gmm **out) {
+  VBH_CHECK(ctx && h_pdf_offsets && h_weights && h_miv && h_iv && out, "vbh_gmm_create: NULL argument");
+  VBH_CHECK(dim >= 1 && dim <= 63, "vbh_gmm_create: dim %d out of range [1,63]", dim);
+  VBH_CHECK(num_pdfs >= 1, "vbh_gmm_create: num_pdfs < 1");
+  VBH_CHECK(h_pdf_offsets[0] == 0, "vbh_gmm_create: pdf_offsets[0] != 0");
+  if (vbh_use_device(ctx)) return -1;
+  const int D = dim, P = num_pdfs, G = h_pdf_offsets[P];
+  for (int p = 0; p < P; p++) {
+    const int n = h_pdf_offsets[p + 1] - h_pdf_offsets[p];
+    VBH_CHECK(n >= 1 && n <= TN, "vbh_gmm_create: pdf %d has %d Gaussians (supported: 1..%d)", p, n, TN);
+  }
+  vbh_gmm *g = new vbh_gmm();
+  g->ctx = ctx; g->D = D; g->P = P; g->G = G;
+  g->offs.assign(h_pdf_offsets, h_pdf_offsets + P + 1);
+  // ---- ComputeGconsts (diag-gmm.cc:114-152): float accumulator, double right-hand sides
+  g->gconsts.resize(G);
+  const float offset = (float)(-0.5 * 1.8378770664093454835606594728112 * D);
+  for (int i = 0; i < G; i++) {
+    if (!(h_weights[i] >= 0.0f)) { vbh_set_error("vbh_gmm_create: negative weight at Gaussian %d", i); delete g; return -1; }
+    float gc = logf(h_weights[i]) + offset;
+    for (int d = 0; d < D; d++) {
+      const float iv = h_iv[(size_t)i * D + d], miv = h_miv[(size_t)i * D + d];
+      gc = (float)(gc + (0.5 * logf(iv) - 0.5 * miv * miv / iv));
+    }
+    if (gc != gc) { vbh_set_error("vbh_gmm_create: NaN gconst at Gaussian %d", i); delete g; return -1; }
+    if (std::isinf(gc) && gc > 0) gc = -gc;
+    g->gconsts[i] = gc;
+  }
+  // ---- tiles: whole pdfs, greedily filled to TN columns
+  const int K = 2 * D + 1;
+  g->Kpad = (K + 7) & ~7;
+  std::vector<GmmTile> tiles;
+  for (int p = 0; p < P;) {
+    GmmTile t{h_pdf_offsets[p], 0, p, 0};
+    while (p < P && t.ng + (h_pdf_offsets[p + 1] - h_pdf_offsets[p]) <= TN) {
+      t.ng += h_pdf_offsets[p + 1] - h_pdf_offsets[p];
+      t.np++; p++;
+    }
+    tiles.push_back(t);
+  }
+  g->n_tiles = (int)tiles.size();
+  std::vector<float> Bp((size_t)(g->n_tiles + 1) * g->Kpad * TN, 0.0f);   // + one spare tile (prefetch overrun)
+  for (int j = 0; j < g->n_tiles; j++) {
+    float *B = Bp.data() + (size_t)j * g->Kpad * TN;
+    for (int c = 0; c < tiles[j].ng; c++) {
+      const int gi = tiles[j].g0 + c;
+      for (int d = 0; d < D; d++) {
+        B[(size_t)d * TN + c] = h_miv[(size_t)gi * D + d];
+        B[(size_t)(D + d) * TN + c] = -0.5f * h_iv[(size_t)gi * D + d];
+      }
+      B[(size_t)(2 * D) * TN + c] = g->gconsts[gi];
+    }
+  }
+  hipStream_t s = ctx->stream;
+  if (g->Bp.upload(Bp.data(), Bp.size(), s) || g->tiles.upload(tiles.data(), tiles.size(), s) ||
+      g->d_offs.upload(g->offs.data(), g->offs.size(), s)) { delete g; return -1; }
+  VBH_HIP(hipStreamSynchronize(s));
+  const size_t a_floats = (size_t)g->Kpad * LDA + ((4 - (g->Kpad * LDA) % 4) % 4);
+  const size_t bc_floats = std::max((size_t)g->Kpad * TN, (size_t)TM * LDC);
+  g->lds_bytes = sizeof(float) * (a_floats + bc_floats) + sizeof(int) * (TN + 1);
+  *out = g;
+  return 0;
+}
+
+void vbh_gmm_destroy(vbh_gmm *g) {
+  if (!g) return;
+  (void)hipSetDevice(g->ctx->device);
+  (void)hipStreamSynchronize(g->ctx->stream);
+  delete g;
+}
+int32_t vbh_gmm_num_pdfs(const vbh_gmm *g) { return g->P; }
+int32_t vbh_gmm_dim(const vbh_gmm *g) { return g->D; }
+int vbh_gmm_get_gconsts(const vbh_gmm *g, float *h) {
+  memcpy(h, g->gconsts.data(), sizeof(float) * g->G);
+  return 0;
+}
+
+int vbh_gmm_work(const vbh_gmm *g, int64_t T, double *bytes, double *flops) {
+  const double G = g->G, D = g->D, P = g->P, t = (double)T;
+  if (bytes) *bytes = 4.0 * (2 * G * D + G) + 4.0 * t * D + 4.0 * t * P;
+  if (flops) *flops = t * G * (4 * D + 2) + t * G + t * P;
+  return 0;
+}
+
+int vbh_gmm_loglikes(vbh_gmm *g, const float *d_feats, int64_t T, float *d_out) {
+  VBH_CHECK(g, "vbh_gmm_loglikes: NULL model");
+  if (T == 0) return 0;
+  VBH_CHECK(T > 0 && d_feats && d_out, "vbh_gmm_loglikes: bad arguments");
+  if (vbh_use_device(g->ctx)) return -1;
+  const long long ftiles = (T + TM - 1) / TM;
+  VBH_CHECK(ftiles < 2147483647LL, "vbh_gmm_loglikes: T too large");
+  // split the Gaussian tiles over blockIdx.y only when there are too few frame tiles to fill the chip
+  int groups = 1;
+  const long long want = 4LL * g->ctx->num_cus;
+  if (ftiles < want) {
+    groups = (int)((want + ftiles - 1) / ftiles);
+    if (groups > g->n_tiles) groups = g->n_tiles;
+  }
+  const int per = (g->n_tiles + groups - 1) / groups;
+  groups = (g->n_tiles + per - 1) / per;
+#define VBH_GMM_LAUNCH(N)                                                                              \
+  case N:                                                                                              \
+    VBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gmm_loglikes_kernel<N>),               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds_bytes));       \
+    hipLaunchKernelGGL(gmm_loglikes_kernel<N>, dim3((unsigned)ftiles, groups), dim3(256), g->lds_bytes, \
+                       g->ctx->stream, d_feats, (long long)T, g->D, g->P, g->Bp.p, g->tiles.p,         \
+                       g->n_tiles, per, g->d_offs.p, d_out);                                           \
+    break;
+  switch (g->Kpad / 8) {
+    VBH_GMM_LAUNCH(1) VBH_GMM_LAUNCH(2) VBH_GMM_LAUNCH(3) VBH_GMM_LAUNCH(4) VBH_GMM_LAUNCH(5) VBH_GMM_LAUNCH(6)
+    VBH_GMM_LAUNCH(7) VBH_GMM_LAUNCH(8) VBH_GMM_LAUNCH(9) VBH_GMM_LAUNCH(10) VBH_GMM_LAUNCH(11) VBH_GMM_LAUNCH(12)
+    VBH_GMM_LAUNCH(13) VBH_GMM_LAUNCH(14) VBH_GMM_LAUNCH(15) VBH_GMM_LAUNCH(16)
+    default: vbh_set_error("vbh_gmm_loglikes: unsupported K %d", g->Kpad); return -1;
+  }
+#undef VBH_GMM_LAUNCH
+  VBH_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"
