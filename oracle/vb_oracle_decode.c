@@ -340,6 +340,13 @@ static float process_emitting(ldec *d) {
   omap_clear(&d->map);
   float adaptive_beam; int32_t best_idx;
   float cur_cutoff = get_cutoff(d, l, n, &adaptive_beam, &best_idx);
+  if (c->exact_cutoff && best_idx >= 0) {
+    /* order-independent choice among equal-cost best tokens: the smallest state id (the
+     * reference takes the first one in HashList order, lattice-faster-decoder.cc:636-641) */
+    float bw = d->toks[l[best_idx].val].tot_cost;
+    for (int32_t i = 0; i < n; i++)
+      if (d->toks[l[i].val].tot_cost == bw && l[i].state < l[best_idx].state) best_idx = i;
+  }
   /* PossiblyResizeHash :194-200 */
   size_t new_sz = (size_t)((float)n * c->hash_ratio);
   if (new_sz > d->map.hash_size) omap_set_size(&d->map, new_sz);

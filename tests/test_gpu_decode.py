@@ -1,0 +1,112 @@
+"""GPU parity: the lattice search vs the oracle's order-independent mode (bit-exact: token
+sets, float32 costs, every lattice arc, best path) and vs the reference's golden best paths."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import GOLD, load, parse_opts
+
+pytestmark = pytest.mark.gpu
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "decode_*.npz")))
+LAT_KEYS = ["tok_frame", "tok_state", "tok_cost", "tok_extra", "tok_final", "link_src", "link_dst", "link_ilabel",
+            "link_olabel", "link_graph", "link_acoustic", "ali", "words"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from voicebridge_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def arcs_of(g):
+    from voicebridge_amd import synth
+    ai = g["fst_arcs_i"]
+    arcs = np.zeros(len(ai), synth.ARC_DTYPE)
+    arcs["ilabel"], arcs["olabel"], arcs["nextstate"] = ai[:, 0], ai[:, 1], ai[:, 2]
+    arcs["weight"] = g["fst_arcs_w"]
+    return arcs
+
+
+def assert_same_lattice(got, ref):
+    for k in ("ok", "reached_final", "num_frames"):
+        assert got[k] == ref[k], k
+    for k in LAT_KEYS:
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)     # float32 arrays compared bit for bit
+    assert np.float32(got["best_graph"]) == np.float32(ref["best_graph"])
+    assert np.float32(got["best_acoustic"]) == np.float32(ref["best_acoustic"])
+    a, b = got["final_relative_cost"], ref["final_relative_cost"]
+    assert (np.isinf(a) and np.isinf(b)) or a == b
+    assert got["n_frames_maxactive_bound"] == ref["n_frames_maxactive_bound"]
+    assert got["n_frames_minactive_bound"] == ref["n_frames_minactive_bound"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_decode_golden_cases(ctx, name):
+    import torch
+    from oracle import vbo
+    from voicebridge_amd import api
+    g = load(name)
+    o = parse_opts(g["opts"])
+    arcs = arcs_of(g)
+    kw = dict(beam=o["beam"], max_active=int(o["max_active"]), min_active=int(o["min_active"]),
+              lattice_beam=o["lattice_beam"], prune_interval=int(o["prune_interval"]))
+    ref = vbo.decode_lattice_faster(vbo.make_fst(g["fst_final"], g["fst_off"], arcs, 0), g["loglikes"], g["tid2pdf"],
+                                    acwt=o["acwt"], exact_cutoff=True, **kw)
+    graph = api.Graph(ctx, g["fst_final"], g["fst_off"], arcs, 0)
+    T = g["loglikes"].shape[0]
+    dec = api.LatticeDecoder(ctx, graph, 1, T, acoustic_scale=o["acwt"], **kw)
+    ll = torch.from_numpy(g["loglikes"]).to(ctx.device)
+    ctx.torch_sync()
+    dec.decode(ll, [0, T], g["tid2pdf"])
+    got = dec.result(0)
+    assert_same_lattice(got, ref)
+    # and the reference's own best path (golden vectors from the reference build)
+    np.testing.assert_array_equal(got["words"], g["ref_lat_words"])
+    np.testing.assert_array_equal(got["ali"], g["ref_lat_ali"])
+    np.testing.assert_array_equal(np.float32([got["best_graph"], got["best_acoustic"]]), g["ref_lat_best_weight"])
+    dec.close(); graph.close()
+
+
+def make_case(S, P, T, seed, spread=30.0, **gkw):
+    from voicebridge_amd import synth
+    ntid = 3 * P
+    g = synth.decoding_graph(S, ntid, seed=seed, num_words=200, **gkw)
+    t2p = synth.tid2pdf(ntid, P, seed=seed)
+    rng = np.random.default_rng(seed + 100)
+    ll = (rng.standard_normal((T, P)) * spread - 80.0).astype(np.float32)
+    return g, t2p, ll
+
+
+@pytest.mark.parametrize("S,P,T,seed,cfg", [
+    (20000, 64, 120, 1, dict(beam=13.0, max_active=7000, min_active=200, lattice_beam=6.0)),
+    (20000, 64, 90, 2, dict(beam=13.0, max_active=300, min_active=20, lattice_beam=6.0)),       # max-active binds
+    (50000, 200, 77, 3, dict(beam=10.0, max_active=2000, min_active=200, lattice_beam=6.0, prune_interval=7)),
+    (3000, 32, 60, 4, dict(beam=8.0, max_active=2147483647, min_active=0, lattice_beam=4.0)),
+    (5000, 32, 0, 5, dict(beam=13.0, max_active=7000, min_active=200, lattice_beam=6.0)),        # empty utterance
+    (5000, 32, 1, 6, dict(beam=13.0, max_active=7000, min_active=200, lattice_beam=6.0)),
+])
+def test_decode_batch_vs_oracle(ctx, S, P, T, seed, cfg):
+    """larger graphs with epsilon chains; a ragged batch of three utterances through one call"""
+    import torch
+    from oracle import vbo
+    from voicebridge_amd import api
+    g, t2p, ll = make_case(S, P, max(T, 1), seed, eps_frac=0.3, spread=8.0 if cfg["max_active"] < 1000 else 30.0)
+    lens = [T, T // 2, max(T - 3, 0)]
+    foff = np.zeros(4, np.int64)
+    foff[1:] = np.cumsum(lens)
+    batch = np.concatenate([ll[:n] for n in lens]) if sum(lens) else np.zeros((0, P), np.float32)
+    graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
+    dec = api.LatticeDecoder(ctx, graph, 3, max(lens), **cfg)
+    d = torch.from_numpy(np.ascontiguousarray(batch)).to(ctx.device) if len(batch) else torch.zeros((1, P), device=ctx.device)
+    ctx.torch_sync()
+    dec.decode(d, foff, t2p)
+    fst = vbo.make_fst(g["final"], g["arc_offset"], g["arcs"], 0)
+    for u, n in enumerate(lens):
+        ref = vbo.decode_lattice_faster(fst, ll[:n] if n else np.zeros((0, P), np.float32), t2p, exact_cutoff=True, **cfg)
+        assert_same_lattice(dec.result(u), ref)
+    dec.close(); graph.close()

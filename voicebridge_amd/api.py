@@ -213,3 +213,78 @@ class DiagGmm:
         if self.h:
             self.lib.vbh_gmm_destroy(self.h)
             self.h = None
+
+
+class Graph:
+    """HCLG as ConstFst arrays (vbh_graph_*)."""
+
+    def __init__(self, ctx, final, arc_offset, arcs, start=0):
+        self.ctx, self.lib = ctx, ctx.lib
+        final = np.ascontiguousarray(final, np.float32)
+        off = np.ascontiguousarray(arc_offset, np.int64)
+        arcs = np.ascontiguousarray(arcs)
+        assert arcs.dtype.itemsize == 16
+        self.num_states, self.num_arcs, self.start = len(final), len(arcs), start
+        h = C.c_void_p()
+        check(self.lib.vbh_graph_create(ctx.h, len(final), int(start), _f32p(final), _i64p(off),
+                                        arcs.ctypes.data_as(C.POINTER(_lib.Arc)), C.byref(h)), "vbh_graph_create")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.vbh_graph_destroy(self.h)
+            self.h = None
+
+
+def _arr(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype).copy()
+
+
+class LatticeDecoder:
+    """LatticeFasterDecoder over a batch of utterances (vbh_decoder_*, vbh_decode_batch)."""
+
+    def __init__(self, ctx, graph, max_batch, max_frames, beam=13.0, max_active=7000, min_active=200,
+                 lattice_beam=6.0, prune_interval=25, beam_delta=0.5, acoustic_scale=0.083333):
+        self.ctx, self.lib, self.graph = ctx, ctx.lib, graph
+        c = _lib.DecodeCfg(beam, max_active, min_active, lattice_beam, prune_interval, beam_delta, acoustic_scale)
+        self.cfg = c
+        h = C.c_void_p()
+        check(self.lib.vbh_decoder_create(ctx.h, graph.h, C.byref(c), int(max_batch), int(max_frames), C.byref(h)),
+              "vbh_decoder_create")
+        self.h = h
+        self.n_utt = 0
+
+    def decode(self, d_loglikes, frame_offsets, tid2pdf):
+        fo = np.ascontiguousarray(frame_offsets, np.int64)
+        t2p = np.ascontiguousarray(tid2pdf, np.int32)
+        self.n_utt = len(fo) - 1
+        check(self.lib.vbh_decode_batch(self.h, d_loglikes.data_ptr(), int(d_loglikes.shape[1]), _i64p(fo), self.n_utt,
+                                        _i32p(t2p), len(t2p) - 1), "vbh_decode_batch")
+
+    def result(self, u, arrays=True):
+        r = _lib.Lattice()
+        check(self.lib.vbh_decoder_result(self.h, int(u), C.byref(r)), "vbh_decoder_result")
+        out = dict(ok=r.ok, reached_final=r.reached_final, num_frames=r.num_frames,
+                   final_relative_cost=r.final_relative_cost,
+                   ali=_arr(r.ali, r.num_ali, np.int32), words=_arr(r.words, r.num_words, np.int32),
+                   best_graph=r.best_graph, best_acoustic=r.best_acoustic, num_toks=r.num_toks, num_links=r.num_links,
+                   n_tokens_expanded=r.n_tokens_expanded, n_arcs_expanded=r.n_arcs_expanded,
+                   n_tokens_created=r.n_tokens_created, n_links_created=r.n_links_created,
+                   n_frames_maxactive_bound=r.n_frames_maxactive_bound,
+                   n_frames_minactive_bound=r.n_frames_minactive_bound)
+        if arrays:
+            out.update(
+                tok_frame=_arr(r.tok_frame, r.num_toks, np.int32), tok_state=_arr(r.tok_state, r.num_toks, np.int32),
+                tok_cost=_arr(r.tok_cost, r.num_toks, np.float32), tok_extra=_arr(r.tok_extra, r.num_toks, np.float32),
+                tok_final=_arr(r.tok_final, r.num_toks, np.float32),
+                link_src=_arr(r.link_src, r.num_links, np.int32), link_dst=_arr(r.link_dst, r.num_links, np.int32),
+                link_ilabel=_arr(r.link_ilabel, r.num_links, np.int32), link_olabel=_arr(r.link_olabel, r.num_links, np.int32),
+                link_graph=_arr(r.link_graph, r.num_links, np.float32), link_acoustic=_arr(r.link_acoustic, r.num_links, np.float32))
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.vbh_decoder_destroy(self.h)
+            self.h = None

@@ -1,0 +1,1147 @@
+// vbh_decode.hip -- frame-synchronous token-passing lattice search on gfx950.
+//
+// Replaces (paths relative to /root/reference/kaldi-master/src/):
+//   decoder/lattice-faster-decoder.cc:56-96    InitDecoding / Decode (frame loop)
+//   :618-685  GetCutoff            :687-777  ProcessEmitting     :796-858  ProcessNonemitting
+//   :259-295  FindOrAddToken (+ util/hash-list-inl.h)            :300-371  PruneForwardLinks
+//   :376-458  PruneForwardLinksFinal  :477-530 PruneTokensForFrame / PruneActiveTokens
+//   :532-572  ComputeFinalCosts    :600-615  FinalizeDecoding    :110-192  GetRawLattice (content)
+//   gmm/decodable-am-diag-gmm.h:142-145        acoustic_scale * loglike(frame, tid2pdf[tid])
+//
+// Execution model.  One 1024-thread workgroup owns one utterance for its whole life and
+// walks its frames; a batch runs as a persistent grid that pulls utterances from a counter,
+// so there is no inter-workgroup communication at all.  Per workgroup ("slot") HBM holds
+//   * three state-indexed arrays (key, claim, tokid) that replace the reference's per-frame
+//     hash: key[s] = (epoch | order-preserving bits of the best cost reaching s this frame)
+//     updated with 64-bit atomicMin, claim[s] = (epoch | phase) taken with one atomicCAS by the
+//     thread that creates the token, tokid[s] = token index.  The epoch (frame counter) in the
+//     high word makes entries of older frames lose every comparison, so nothing is cleared;
+//   * a raw window (W) of tokens and forward links created since the last pruning, and a
+//     history (H) holding what survived earlier prunings, with stable indices.
+// Every `prune_interval` frames the workgroup recomputes extra_costs backwards (link-parallel
+// min with atomics, iterated per frame to the fixed point when epsilon links exist), stops
+// at the first already-pruned frame whose values did not move, and compacts the survivors
+// of W into H.  The reference's final result does not depend on when intermediate pruning
+// happens (its final pass recomputes every frame with delta = 0), so this schedule yields
+// the same lattice.
+//
+// Semantics.  Costs use exactly the reference's float32 expressions and association order
+// (this file is compiled with -ffp-contract=off).  The one deliberate difference is the
+// admission rule of ProcessEmitting: the reference tightens next_cutoff while it walks its
+// hash list, so which over-the-cutoff arcs it admits depends on hash order (and on the
+// utterances decoded before by the same object); here next_cutoff takes its final value
+// (frame minimum + adaptive beam) before anything is admitted.  That is the
+// `exact_cutoff` mode of oracle/vb_oracle_decode.c, against which this kernel is bit-exact;
+// tests/test_oracle_decode.py pins how that mode relates to the reference (same best path
+// and weights; lattice = reference lattice minus the order-dependent extra arcs).
+//
+// Per-frame algorithmic traffic: N_tok(20+16) + N_arc(16+4) + N_new 16 +
+// N_link 24 bytes of random access; the counters are reported per utterance.
+#include "vbh_internal.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+
+namespace {
+
+constexpr int NT = 1024;
+constexpr int NW = NT / 64;
+constexpr int WBIT = 0x40000000;            // token id lives in the raw window
+constexpr unsigned INF_BITS = 0x7F800000u;  // +inf as float bits
+constexpr int MAX_EPS_ITERS = 4096;
+
+struct DevGraph {
+  int S, start;
+  const float *final_cost;   // [S], +inf = not final
+  const int *arc_off;        // [S+1]
+  const int *nieps;          // [S] number of input-epsilon arcs
+  const vbh_arc *arcs;       // [A]
+};
+
+struct DecCfg {
+  float beam, lattice_beam, beam_delta, acwt;
+  int max_active, min_active, prune_interval;
+};
+
+// per-slot workspace (device pointers)
+struct Slot {
+  unsigned long long *key, *claim;
+  int *tokid;
+  // raw window
+  int *w_state; float *w_cost; unsigned *w_extra, *w_tmp; int *w_flag, *w_remap;
+  int *wl_src, *wl_dst, *wl_il, *wl_ol; float *wl_gr, *wl_ac;
+  // history
+  int *h_state; float *h_cost; unsigned *h_extra, *h_tmp;
+  int *hl_src, *hl_dst, *hl_il, *hl_ol; float *hl_gr, *hl_ac;
+  // per frame_plus_one ranges: tokens, emitting links from the frame, epsilon links within it
+  int *tok_b, *tok_e, *el_b, *el_e, *pl_b, *pl_e;
+  unsigned char *tok_w, *el_w, *pl_w;      // 1 = range refers to the window
+  float *cost_offset;                      // [max_frames]
+  int *front_a, *front_b;                  // epsilon work lists
+  int *state;                              // persistent: [0] epoch base, [1] flag stamp
+  int w_tok_cap, w_link_cap, h_tok_cap, h_link_cap, front_cap;
+};
+
+struct UttDesc { long long row0; int T; int pad; };
+
+struct UttResult {   // written by the kernel, one per utterance
+  int ok, error, reached_final, num_frames;
+  float final_relative_cost, final_best_cost;
+  int final_costs_empty;
+  int n_tok, n_link;                 // alive entries written to the pool
+  long long tok_off, link_off;       // offsets into the pool
+  long long n_tokens_expanded, n_arcs_expanded, n_tokens_created, n_links_created;
+  int n_max_bound, n_min_bound;
+  long long cost_off;                // offset of this utterance's cost_offsets in the pool
+};
+
+struct Pool {   // dense per-batch output
+  int *tok_frame, *tok_state; float *tok_cost, *tok_extra, *tok_final;
+  int *link_src, *link_dst, *link_il, *link_ol; float *link_gr, *link_ac;
+  float *cost_offsets;
+  unsigned long long *counters;   // [0] tokens used, [1] links used, [2] cost offsets used
+  long long tok_cap, link_cap, cost_cap;
+};
+
+enum { ERR_NONE = 0, ERR_W_TOK = 1, ERR_W_LINK = 2, ERR_H_TOK = 3, ERR_H_LINK = 4, ERR_FRONT = 5,
+       ERR_EPS_LOOP = 6, ERR_POOL = 7 };
+
+// order-preserving map float -> uint32
+__device__ __forceinline__ unsigned f2o(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float o2f(unsigned o) {
+  unsigned u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ unsigned long long ld_u64(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_i32(const int *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_i32(int *p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct Shared {
+  unsigned long long red64[NW];
+  int red32[NW];
+  float redf[NW];
+  unsigned hist[256];
+  // broadcast / counters
+  int w_ntok, w_nlink, h_ntok, h_nlink;
+  int n_next, changed, error, flag;
+  unsigned sel_prefix, sel_mask; int sel_k;
+  float f0, f1, f2;
+  unsigned long long u0;
+  long long c_tok_exp, c_arc_exp, c_tok_new, c_link_new;
+  int n_max_bound, n_min_bound;
+  int utt;
+};
+
+__device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v, Shared &sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long w = __shfl_xor(v, o, 64);
+    v = w < v ? w : v;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh.red64[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned long long r = sh.red64[0];
+#pragma unroll
+  for (int i = 1; i < NW; i++) r = sh.red64[i] < r ? sh.red64[i] : r;
+  return r;
+}
+__device__ __forceinline__ float block_min_f(float v, Shared &sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh.redf[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = sh.redf[0];
+#pragma unroll
+  for (int i = 1; i < NW; i++) r = fminf(r, sh.redf[i]);
+  return r;
+}
+__device__ __forceinline__ int block_sum_i(int v, Shared &sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh.red32[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int r = 0;
+#pragma unroll
+  for (int i = 0; i < NW; i++) r += sh.red32[i];
+  return r;
+}
+
+// k-th smallest (0-based) of cost[0..n): exact radix select on the order-preserving keys
+// (std::nth_element value in GetCutoff, lattice-faster-decoder.cc:654-676)
+__device__ float select_kth(const float *cost, int n, int k, Shared &sh) {
+  const int tid = threadIdx.x;
+  if (tid == 0) { sh.sel_prefix = 0; sh.sel_mask = 0; sh.sel_k = k; }
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 256; i += NT) sh.hist[i] = 0;
+    __syncthreads();
+    const unsigned prefix = sh.sel_prefix, mask = sh.sel_mask;
+    for (int i = tid; i < n; i += NT) {
+      const unsigned key = f2o(cost[i]);
+      if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int kk = sh.sel_k, b = 0;
+      for (; b < 255; b++) {
+        if (kk < (int)sh.hist[b]) break;
+        kk -= (int)sh.hist[b];
+      }
+      sh.sel_k = kk;
+      sh.sel_prefix = prefix | ((unsigned)b << shift);
+      sh.sel_mask = mask | (255u << shift);
+    }
+    __syncthreads();
+  }
+  return o2f(sh.sel_prefix);
+}
+
+struct TokView { const int *state; const float *cost; int base; int n; int enc; };
+
+__device__ __forceinline__ float tok_cost(const Slot &s, int id) { return (id & WBIT) ? s.w_cost[id ^ WBIT] : s.h_cost[id]; }
+__device__ __forceinline__ unsigned tok_extra(const Slot &s, int id) { return (id & WBIT) ? s.w_extra[id ^ WBIT] : s.h_extra[id]; }
+
+// ---------------------------------------------------------------------------------------
+// PruneForwardLinks for one frame (lattice-faster-decoder.cc:300-371), evaluated to its
+// fixed point.  Returns (uniformly) whether any token's extra_cost changed.
+__device__ bool prune_frame(const Slot &s, int f, float lattice_beam, Shared &sh) {
+  const int tid = threadIdx.x;
+  const int tb = s.tok_b[f], te = s.tok_e[f];
+  const bool tw = s.tok_w[f];
+  unsigned *extra = tw ? s.w_extra : s.h_extra, *tmp = tw ? s.w_tmp : s.h_tmp;
+  const float *tcost = tw ? s.w_cost : s.h_cost;
+  const int eb = s.el_b[f], ee = s.el_e[f], pb = s.pl_b[f], pe = s.pl_e[f];
+  const bool ew = s.el_w[f], pw = s.pl_w[f];
+  bool frame_changed = false;
+  for (int iter = 0; iter < MAX_EPS_ITERS; iter++) {
+    for (int t = tb + tid; t < te; t += NT) tmp[t] = INF_BITS;
+    if (tid == 0) sh.changed = 0;
+    __syncthreads();
+    for (int pass = 0; pass < 2; pass++) {
+      const int lb = pass ? pb : eb, le_ = pass ? pe : ee;
+      const bool lw = pass ? pw : ew;
+      int *lsrc = lw ? s.wl_src : s.hl_src;
+      const int *ldst = lw ? s.wl_dst : s.hl_dst;
+      const float *lgr = lw ? s.wl_gr : s.hl_gr, *lac = lw ? s.wl_ac : s.hl_ac;
+      for (int l = lb + tid; l < le_; l += NT) {
+        const int src = lsrc[l];
+        if (src < 0) continue;   // already excised
+        const int dst = ldst[l];
+        const float nx = __uint_as_float(tok_extra(s, dst));
+        const float sc = tcost[(src & ~WBIT)];
+        // next_tok->extra_cost + ((tok->tot_cost + link->acoustic_cost + link->graph_cost) - next_tok->tot_cost)
+        float le = nx + (((sc + lac[l]) + lgr[l]) - tok_cost(s, dst));
+        if (le > lattice_beam) { lsrc[l] = -1; continue; }
+        if (le < 0.0f) le = 0.0f;
+        atomicMin(&tmp[src & ~WBIT], __float_as_uint(le));
+      }
+    }
+    __syncthreads();
+    for (int t = tb + tid; t < te; t += NT) {
+      const unsigned v = tmp[t];
+      if (v != extra[t]) { extra[t] = v; sh.changed = 1; }
+    }
+    __syncthreads();
+    const bool ch = sh.changed != 0;
+    __syncthreads();
+    frame_changed |= ch;
+    if (!ch || pe == pb) break;
+  }
+  return frame_changed;
+}
+
+// backward pass from frame `from` down; frames >= first_unpruned are always processed
+__device__ void prune_backward(const Slot &s, int from, int first_unpruned, float lattice_beam, Shared &sh) {
+  for (int f = from; f >= 0; f--) {
+    const bool ch = prune_frame(s, f, lattice_beam, sh);
+    if (!ch && f < first_unpruned) break;
+  }
+}
+
+// move the survivors of the raw window (tokens of frames (prev_front, front], links created
+// since the last compaction) into the history; returns false (uniformly) on overflow
+__device__ bool compact_window(const Slot &s, int prev_front, int front, Shared &sh) {
+  const int tid = threadIdx.x;
+  // tokens, frame by frame so that each frame stays contiguous
+  for (int f = prev_front + 1; f <= front; f++) {
+    if (!s.tok_w[f]) continue;
+    const int tb = s.tok_b[f], te = s.tok_e[f];
+    __syncthreads();
+    const int base = sh.h_ntok;
+    __syncthreads();
+    for (int t = tb + tid; t < te; t += NT) {
+      int nid = -1;
+      if (s.w_extra[t] != INF_BITS) {
+        nid = atomicAdd(&sh.h_ntok, 1);
+        if (nid < s.h_tok_cap) {
+          s.h_state[nid] = s.w_state[t]; s.h_cost[nid] = s.w_cost[t]; s.h_extra[nid] = s.w_extra[t];
+        } else { sh.error = ERR_H_TOK; nid = -1; }
+      }
+      s.w_remap[t] = nid;
+    }
+    __syncthreads();
+    if (tid == 0) { s.tok_b[f] = base; s.tok_e[f] = sh.h_ntok < s.h_tok_cap ? sh.h_ntok : s.h_tok_cap; s.tok_w[f] = 0; }
+  }
+  __syncthreads();
+  // links: emitting links from frames [prev_front, front-1], epsilon links within (prev_front, front]
+  for (int f = prev_front; f <= front; f++) {
+    for (int pass = 0; pass < 2; pass++) {
+      if (f < 0) continue;
+      const bool in_w = pass ? s.pl_w[f] : s.el_w[f];
+      if (!in_w) continue;
+      const int lb = pass ? s.pl_b[f] : s.el_b[f], le_ = pass ? s.pl_e[f] : s.el_e[f];
+      __syncthreads();
+      const int base = sh.h_nlink;
+      __syncthreads();
+      for (int l = lb + tid; l < le_; l += NT) {
+        int src = s.wl_src[l];
+        if (src < 0) continue;
+        int dst = s.wl_dst[l];
+        if (src & WBIT) src = s.w_remap[src ^ WBIT];
+        if (dst & WBIT) dst = s.w_remap[dst ^ WBIT];
+        if (src < 0 || dst < 0) continue;   // an end point died (its extra_cost is +inf)
+        const int nid = atomicAdd(&sh.h_nlink, 1);
+        if (nid < s.h_link_cap) {
+          s.hl_src[nid] = src; s.hl_dst[nid] = dst; s.hl_il[nid] = s.wl_il[l]; s.hl_ol[nid] = s.wl_ol[l];
+          s.hl_gr[nid] = s.wl_gr[l]; s.hl_ac[nid] = s.wl_ac[l];
+        } else sh.error = ERR_H_LINK;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        const int e = sh.h_nlink < s.h_link_cap ? sh.h_nlink : s.h_link_cap;
+        if (pass) { s.pl_b[f] = base; s.pl_e[f] = e; s.pl_w[f] = 0; }
+        else { s.el_b[f] = base; s.el_e[f] = e; s.el_w[f] = 0; }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) { sh.w_ntok = 0; sh.w_nlink = 0; }
+  __syncthreads();
+  return sh.error == ERR_NONE;
+}
+
+// ---------------------------------------------------------------------------------------
+// ProcessNonemitting (lattice-faster-decoder.cc:796-858) on the tokens of frame fpo, which
+// occupy window indices [nb, sh.w_ntok): iterate the frontier until no cost changes, then
+// refresh the token costs and write the epsilon links from the final costs.
+__device__ void process_nonemitting(const DevGraph &g, const Slot &s, int fpo, int nb, float cutoff,
+                                    unsigned epoch_hi, int *stamp, Shared &sh) {
+  const int tid = threadIdx.x;
+  const unsigned long long EPK = (unsigned long long)epoch_hi << 32;
+  int ncur = sh.w_ntok - nb;     // iteration 0 walks the whole new range
+  bool use_list = false;
+  int *fcur = s.front_a, *fnext = s.front_b;
+  for (int iter = 0; ncur > 0; iter++) {
+    if (iter >= MAX_EPS_ITERS) { if (tid == 0) sh.error = ERR_EPS_LOOP; break; }
+    const int my_stamp = ++(*stamp);
+    const unsigned tag = (unsigned)(iter + 1);   // claim tag of tokens created in this iteration
+    if (tid == 0) sh.n_next = 0;
+    __syncthreads();
+    for (int i = tid; i < ncur; i += NT) {
+      const int t = use_list ? fcur[i] : nb + i;
+      const int st = s.w_state[t];
+      if (g.nieps[st] == 0) continue;
+      const float c = o2f((unsigned)ld_u64(&s.key[st]));
+      if (c > cutoff) continue;
+      for (int a = g.arc_off[st]; a < g.arc_off[st + 1]; a++) {
+        const vbh_arc arc = g.arcs[a];
+        if (arc.ilabel != 0) continue;
+        const float tot = c + arc.weight;
+        if (!(tot < cutoff)) continue;
+        const int ds = arc.nextstate;
+        const unsigned long long nk = EPK | f2o(tot);
+        unsigned long long cl = ld_u64(&s.claim[ds]);
+        bool existed_before;
+        if ((unsigned)(cl >> 32) != epoch_hi) {
+          const unsigned long long old = atomicCAS(&s.claim[ds], cl, EPK | tag);
+          if (old == cl) {   // this thread creates the token
+            const int nid = atomicAdd(&sh.w_ntok, 1);
+            if (nid < s.w_tok_cap) {
+              s.w_state[nid] = ds; s.w_extra[nid] = 0u; s.w_flag[nid] = my_stamp;
+              st_i32(&s.tokid[ds], nid);
+              const int q = atomicAdd(&sh.n_next, 1);
+              if (q < s.front_cap) fnext[q] = nid; else sh.error = ERR_FRONT;
+            } else sh.error = ERR_W_TOK;
+            atomicMin(&s.key[ds], nk);
+            continue;
+          }
+          cl = old;
+        }
+        existed_before = (unsigned)cl < tag;   // created in an earlier phase: tokid is valid
+        const unsigned long long oldk = atomicMin(&s.key[ds], nk);
+        if (existed_before && nk < oldk) {   // improved an older token: it must be re-expanded
+          const int tk = ld_i32(&s.tokid[ds]);
+          if (atomicExch(&s.w_flag[tk], my_stamp) != my_stamp) {
+            const int q = atomicAdd(&sh.n_next, 1);
+            if (q < s.front_cap) fnext[q] = tk; else sh.error = ERR_FRONT;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    ncur = sh.n_next < s.front_cap ? sh.n_next : s.front_cap;
+    const bool err = sh.error != ERR_NONE;
+    __syncthreads();
+    if (err) return;
+    int *tmp = fcur; fcur = fnext; fnext = tmp;
+    use_list = true;
+  }
+  __syncthreads();
+  // final costs of the frame's tokens
+  const int ne = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap;
+  for (int t = nb + tid; t < ne; t += NT) s.w_cost[t] = o2f((unsigned)ld_u64(&s.key[s.w_state[t]]));
+  __syncthreads();
+  // epsilon links, regenerated from final costs (":824-826 delete + re-create")
+  const int lb = sh.w_nlink;
+  __syncthreads();
+  for (int t = nb + tid; t < ne; t += NT) {
+    const int st = s.w_state[t];
+    if (g.nieps[st] == 0) continue;
+    const float c = s.w_cost[t];
+    if (c > cutoff) continue;
+    for (int a = g.arc_off[st]; a < g.arc_off[st + 1]; a++) {
+      const vbh_arc arc = g.arcs[a];
+      if (arc.ilabel != 0) continue;
+      const float tot = c + arc.weight;
+      if (!(tot < cutoff)) continue;
+      const int l = atomicAdd(&sh.w_nlink, 1);
+      if (l < s.w_link_cap) {
+        s.wl_src[l] = t | WBIT; s.wl_dst[l] = ld_i32(&s.tokid[arc.nextstate]) | WBIT;
+        s.wl_il[l] = 0; s.wl_ol[l] = arc.olabel; s.wl_gr[l] = arc.weight; s.wl_ac[l] = 0.0f;
+      } else sh.error = ERR_W_LINK;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    s.pl_b[fpo] = lb; s.pl_e[fpo] = sh.w_nlink < s.w_link_cap ? sh.w_nlink : s.w_link_cap; s.pl_w[fpo] = 1;
+    sh.c_link_new += sh.w_nlink - lb;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, const Slot *slots,
+                                                     const float *__restrict__ loglikes, int P,
+                                                     const int *__restrict__ tid2pdf,
+                                                     const UttDesc *__restrict__ utts, int n_utt,
+                                                     int *work_counter, UttResult *results, Pool pool) {
+  __shared__ Shared sh;
+  const int tid = threadIdx.x;
+  const Slot s = slots[blockIdx.x];
+  const float INF = INFINITY;
+
+  while (true) {
+    __syncthreads();
+    if (tid == 0) sh.utt = atomicAdd(work_counter, 1);
+    __syncthreads();
+    const int utt = sh.utt;
+    if (utt >= n_utt) break;    // every wave of the grid reaches this exit
+    const UttDesc ud = utts[utt];
+    const int T = ud.T;
+    // epochs start at 1: the high word 0xFFFFFFFF is the cleared (memset 0xFF) state
+    int epoch_base = s.state[0] + 1;
+    int stamp = s.state[1];
+    if (tid == 0) {
+      sh.w_ntok = 0; sh.w_nlink = 0; sh.h_ntok = 0; sh.h_nlink = 0; sh.error = ERR_NONE;
+      sh.c_tok_exp = 0; sh.c_arc_exp = 0; sh.c_tok_new = 0; sh.c_link_new = 0;
+      sh.n_max_bound = 0; sh.n_min_bound = 0;
+    }
+    __syncthreads();
+
+    // ---- InitDecoding (:56-73): start token, then the epsilon closure with cutoff = beam
+    {
+      const unsigned ep = (unsigned)(0xFFFFFFFFu - (unsigned)(epoch_base + 0));
+      if (tid == 0) {
+        s.w_state[0] = g.start; s.w_cost[0] = 0.0f; s.w_extra[0] = 0u; s.w_flag[0] = 0;
+        s.key[g.start] = ((unsigned long long)ep << 32) | f2o(0.0f);
+        s.claim[g.start] = ((unsigned long long)ep << 32) | 0u;
+        s.tokid[g.start] = 0;
+        sh.w_ntok = 1; sh.c_tok_new = 1;
+        s.el_b[0] = 0; s.el_e[0] = 0; s.el_w[0] = 1;
+      }
+      __threadfence_block();
+      __syncthreads();
+      process_nonemitting(g, s, 0, 0, cfg.beam, ep, &stamp, sh);
+      if (tid == 0) { s.tok_b[0] = 0; s.tok_e[0] = sh.w_ntok; s.tok_w[0] = 1; sh.c_tok_new = sh.w_ntok; }
+      __syncthreads();
+    }
+
+    int prev_front = -1;      // frontier frame at the previous pruning (-1: none yet)
+    int frames_done = 0;
+    for (int frame = 0; frame < T && sh.error == ERR_NONE; frame++) {
+      // ---- periodic pruning (:85-87); frame 0 has nothing behind it
+      if (frame > 0 && frame % cfg.prune_interval == 0) {
+        prune_backward(s, frame - 1, prev_front < 0 ? 0 : prev_front, cfg.lattice_beam, sh);
+        if (!compact_window(s, prev_front, frame, sh)) break;
+        prev_front = frame;
+      }
+      const int tb = s.tok_b[frame], n = s.tok_e[frame] - tb;
+      const bool tw = s.tok_w[frame];
+      const int *tstate = (tw ? s.w_state : s.h_state) + tb;
+      const float *tcost = (tw ? s.w_cost : s.h_cost) + tb;
+      const int enc = tw ? WBIT : 0;
+      const float *llrow = loglikes + (ud.row0 + frame) * (long long)P;
+      const unsigned ep = (unsigned)(0xFFFFFFFFu - (unsigned)(epoch_base + frame + 1));
+      const unsigned long long EPK = (unsigned long long)ep << 32;
+
+      // ---- GetCutoff (:618-685)
+      unsigned long long bk = ~0ull;
+      for (int i = tid; i < n; i += NT) {
+        const unsigned long long k = ((unsigned long long)f2o(tcost[i]) << 32) | (unsigned)tstate[i];
+        bk = k < bk ? k : bk;
+      }
+      bk = block_min_u64(bk, sh);
+      const float best = n > 0 ? o2f((unsigned)(bk >> 32)) : INF;
+      const int best_state = (int)(unsigned)bk;
+      float cur_cutoff, adaptive_beam;
+      if (cfg.max_active == INT_MAX && cfg.min_active == 0) {
+        adaptive_beam = cfg.beam; cur_cutoff = best + cfg.beam;
+      } else {
+        const float beam_cutoff = best + cfg.beam;
+        float mac = INF, mic = INF;
+        int cnt_lt = 0, cnt_le = 0;
+        for (int i = tid; i < n; i += NT) { cnt_lt += tcost[i] < beam_cutoff; cnt_le += tcost[i] <= beam_cutoff; }
+        cnt_lt = block_sum_i(cnt_lt, sh);
+        cnt_le = block_sum_i(cnt_le, sh);
+        // the order statistic is only needed when it decides the comparison
+        if (n > cfg.max_active && cnt_lt > cfg.max_active) mac = select_kth(tcost, n, cfg.max_active, sh);
+        if (mac < beam_cutoff) {
+          adaptive_beam = mac - best + cfg.beam_delta; cur_cutoff = mac;
+          if (tid == 0) sh.n_max_bound++;
+        } else {
+          if (n > cfg.min_active) {
+            if (cfg.min_active == 0) mic = best;
+            else if (cnt_le <= cfg.min_active) mic = select_kth(tcost, n, cfg.min_active, sh);
+            else mic = beam_cutoff;   // some value <= beam_cutoff: the comparison below is false
+          }
+          if (mic > beam_cutoff) {
+            adaptive_beam = mic - best + cfg.beam_delta; cur_cutoff = mic;
+            if (tid == 0) sh.n_min_bound++;
+          } else { adaptive_beam = cfg.beam; cur_cutoff = beam_cutoff; }
+        }
+      }
+      // ---- cost_offset and the initial next_cutoff from the best token (:706-724)
+      const float cost_offset = n > 0 ? -best : 0.0f;
+      if (tid == 0) {
+        float nc = INF;
+        if (n > 0) {
+          for (int a = g.arc_off[best_state]; a < g.arc_off[best_state + 1]; a++) {
+            const vbh_arc arc = g.arcs[a];
+            if (arc.ilabel != 0) {
+              const float ll = cfg.acwt * llrow[tid2pdf[arc.ilabel]];
+              const float nw = ((arc.weight + cost_offset) - ll) + best;
+              if (nw + adaptive_beam < nc) nc = nw + adaptive_beam;
+            }
+          }
+        }
+        sh.f0 = nc;
+        s.cost_offset[frame] = cost_offset;
+      }
+      // ---- pass 1: final next_cutoff = min over every candidate of tot + adaptive_beam
+      float mymin = INF;
+      int my_tok = 0, my_arc = 0;
+      for (int i = tid; i < n; i += NT) {
+        const float c = tcost[i];
+        if (!(c <= cur_cutoff)) continue;
+        my_tok++;
+        const int st = tstate[i];
+        for (int a = g.arc_off[st]; a < g.arc_off[st + 1]; a++) {
+          const vbh_arc arc = g.arcs[a];
+          if (arc.ilabel == 0) continue;
+          my_arc++;
+          const float ac = cost_offset - cfg.acwt * llrow[tid2pdf[arc.ilabel]];
+          const float tot = (c + ac) + arc.weight;
+          mymin = fminf(mymin, tot + adaptive_beam);
+        }
+      }
+      mymin = block_min_f(mymin, sh);
+      const float next_cutoff = fminf(sh.f0, mymin);
+      my_tok = block_sum_i(my_tok, sh);
+      my_arc = block_sum_i(my_arc, sh);
+      if (tid == 0) { sh.c_tok_exp += my_tok; sh.c_arc_exp += my_arc; }
+      // ---- pass 2: admit tot <= next_cutoff; min-cost per state, one creator per new state
+      const int nb = sh.w_ntok;     // first token of frame+1
+      __syncthreads();
+      for (int i = tid; i < n; i += NT) {
+        const float c = tcost[i];
+        if (!(c <= cur_cutoff)) continue;
+        const int st = tstate[i];
+        for (int a = g.arc_off[st]; a < g.arc_off[st + 1]; a++) {
+          const vbh_arc arc = g.arcs[a];
+          if (arc.ilabel == 0) continue;
+          const float ac = cost_offset - cfg.acwt * llrow[tid2pdf[arc.ilabel]];
+          const float tot = (c + ac) + arc.weight;
+          if (tot > next_cutoff) continue;
+          const int ds = arc.nextstate;
+          atomicMin(&s.key[ds], EPK | f2o(tot));
+          const unsigned long long cl = ld_u64(&s.claim[ds]);
+          if ((unsigned)(cl >> 32) != ep && atomicCAS(&s.claim[ds], cl, EPK | 0u) == cl) {
+            const int nid = atomicAdd(&sh.w_ntok, 1);
+            if (nid < s.w_tok_cap) {
+              s.w_state[nid] = ds; s.w_extra[nid] = 0u; s.w_flag[nid] = 0;
+              st_i32(&s.tokid[ds], nid);
+            } else sh.error = ERR_W_TOK;
+          }
+        }
+      }
+      __syncthreads();
+      // ---- pass 3: forward links (:765-767)
+      const int lb = sh.w_nlink;
+      __syncthreads();
+      for (int i = tid; i < n; i += NT) {
+        const float c = tcost[i];
+        if (!(c <= cur_cutoff)) continue;
+        const int st = tstate[i];
+        for (int a = g.arc_off[st]; a < g.arc_off[st + 1]; a++) {
+          const vbh_arc arc = g.arcs[a];
+          if (arc.ilabel == 0) continue;
+          const float ac = cost_offset - cfg.acwt * llrow[tid2pdf[arc.ilabel]];
+          const float tot = (c + ac) + arc.weight;
+          if (tot > next_cutoff) continue;
+          const int l = atomicAdd(&sh.w_nlink, 1);
+          if (l < s.w_link_cap) {
+            s.wl_src[l] = (tb + i) | enc; s.wl_dst[l] = ld_i32(&s.tokid[arc.nextstate]) | WBIT;
+            s.wl_il[l] = arc.ilabel; s.wl_ol[l] = arc.olabel; s.wl_gr[l] = arc.weight; s.wl_ac[l] = ac;
+          } else sh.error = ERR_W_LINK;
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        s.el_b[frame] = lb; s.el_e[frame] = sh.w_nlink < s.w_link_cap ? sh.w_nlink : s.w_link_cap; s.el_w[frame] = 1;
+        sh.c_link_new += sh.w_nlink - lb;
+      }
+      __syncthreads();
+      if (sh.error != ERR_NONE) break;
+      // ---- ProcessNonemitting(next_cutoff)
+      process_nonemitting(g, s, frame + 1, nb, next_cutoff, ep, &stamp, sh);
+      if (tid == 0) {
+        s.tok_b[frame + 1] = nb; s.tok_e[frame + 1] = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap; s.tok_w[frame + 1] = 1;
+        sh.c_tok_new += sh.w_ntok - nb;
+      }
+      __syncthreads();
+      frames_done = frame + 1;
+    }
+    __syncthreads();
+    const bool search_ok = sh.error == ERR_NONE && frames_done == T;
+
+    // ---- FinalizeDecoding (:600-615)
+    float final_relative = INF, final_best = INF;
+    int final_empty = 1;
+    if (search_ok) {
+      const int F = T;
+      const int tb = s.tok_b[F], te = s.tok_e[F];
+      const bool tw = s.tok_w[F];
+      const int *tstate = tw ? s.w_state : s.h_state;
+      const float *tcost = tw ? s.w_cost : s.h_cost;
+      unsigned *extra = tw ? s.w_extra : s.h_extra, *tmp = tw ? s.w_tmp : s.h_tmp;
+      // ComputeFinalCosts (:532-572)
+      float bc = INF, bwf = INF; int anyfinal = 0;
+      for (int t = tb + tid; t < te; t += NT) {
+        const float fc = g.final_cost[tstate[t]], c = tcost[t];
+        bc = fminf(bc, c); bwf = fminf(bwf, c + fc);
+        anyfinal |= fc != INF;
+      }
+      bc = block_min_f(bc, sh); bwf = block_min_f(bwf, sh);
+      anyfinal = block_sum_i(anyfinal, sh);
+      final_empty = anyfinal == 0;
+      final_relative = (bc == INF && bwf == INF) ? INF : bwf - bc;
+      final_best = (bwf != INF) ? bwf : bc;
+      // PruneForwardLinksFinal (:376-458), to the fixed point
+      const int pb = s.pl_b[F], pe = s.pl_e[F];
+      const bool pw = s.pl_w[F];
+      int *lsrc = pw ? s.wl_src : s.hl_src;
+      const int *ldst = pw ? s.wl_dst : s.hl_dst;
+      const float *lgr = pw ? s.wl_gr : s.hl_gr, *lac = pw ? s.wl_ac : s.hl_ac;
+      for (int iter = 0; iter < MAX_EPS_ITERS; iter++) {
+        for (int t = tb + tid; t < te; t += NT) {
+          const float fc = final_empty ? 0.0f : g.final_cost[tstate[t]];
+          const float x = tcost[t] + fc - final_best;
+          tmp[t] = x == INF ? INF_BITS : __float_as_uint(x < 0.0f ? x : x);
+        }
+        if (tid == 0) sh.changed = 0;
+        __syncthreads();
+        for (int l = pb + tid; l < pe; l += NT) {
+          const int src = lsrc[l];
+          if (src < 0) continue;
+          const int dst = ldst[l];
+          float le = __uint_as_float(tok_extra(s, dst)) + (((tcost[src & ~WBIT] + lac[l]) + lgr[l]) - tok_cost(s, dst));
+          if (le > cfg.lattice_beam) { lsrc[l] = -1; continue; }
+          if (le < 0.0f) le = 0.0f;
+          // tmp holds a float that may be slightly negative only in theory; compare as floats
+          unsigned *p = &tmp[src & ~WBIT];
+          unsigned old = *p;
+          while (le < __uint_as_float(old)) {
+            const unsigned prev = atomicCAS(p, old, __float_as_uint(le));
+            if (prev == old) break;
+            old = prev;
+          }
+        }
+        __syncthreads();
+        for (int t = tb + tid; t < te; t += NT) {
+          float v = __uint_as_float(tmp[t]);
+          if (v > cfg.lattice_beam) v = INF;
+          const unsigned vb = __float_as_uint(v);
+          if (vb != extra[t]) { extra[t] = vb; sh.changed = 1; }
+        }
+        __syncthreads();
+        const bool ch = sh.changed != 0;
+        __syncthreads();
+        if (!ch || pe == pb) break;
+      }
+      prune_backward(s, F - 1, prev_front < 0 ? 0 : prev_front, cfg.lattice_beam, sh);
+      compact_window(s, prev_front, F, sh);
+    }
+    __syncthreads();
+
+    // ---- write the surviving lattice to the dense pool (content of GetRawLattice :110-192)
+    UttResult r;
+    r.ok = 0; r.error = sh.error; r.reached_final = 0; r.num_frames = frames_done;
+    r.final_relative_cost = final_relative; r.final_best_cost = final_best; r.final_costs_empty = final_empty;
+    r.n_tok = 0; r.n_link = 0; r.tok_off = 0; r.link_off = 0; r.cost_off = 0;
+    if (search_ok && sh.error == ERR_NONE) {
+      const int F = T;
+      // count alive tokens / links, reserve pool space
+      int na = 0, nl = 0;
+      for (int t = tid; t < sh.h_ntok; t += NT) na += s.h_extra[t] != INF_BITS;
+      na = block_sum_i(na, sh);
+      if (tid == 0) {
+        sh.u0 = atomicAdd(&pool.counters[0], (unsigned long long)na);
+        sh.flag = 0;
+      }
+      __syncthreads();
+      const long long toff = (long long)sh.u0;
+      const bool tok_fits = toff + na <= pool.tok_cap;
+      // dense index per alive history token, in h_tmp
+      if (tok_fits) {
+        for (int f = 0; f <= F; f++) {
+          for (int t = s.tok_b[f] + tid; t < s.tok_e[f]; t += NT) {
+            if (s.h_extra[t] == INF_BITS) { s.h_tmp[t] = 0xFFFFFFFFu; continue; }
+            const int d = atomicAdd(&sh.flag, 1);
+            s.h_tmp[t] = (unsigned)d;
+            const long long o = toff + d;
+            pool.tok_frame[o] = f; pool.tok_state[o] = s.h_state[t]; pool.tok_cost[o] = s.h_cost[t];
+            pool.tok_extra[o] = __uint_as_float(s.h_extra[t]);
+            float fin = INF;
+            if (f == F) fin = final_empty ? 0.0f : g.final_cost[s.h_state[t]];
+            pool.tok_final[o] = fin;
+          }
+        }
+      }
+      __syncthreads();
+      for (int l = tid; l < sh.h_nlink; l += NT) {
+        const int src = s.hl_src[l];
+        nl += src >= 0 && s.h_extra[src] != INF_BITS && s.h_extra[s.hl_dst[l]] != INF_BITS;
+      }
+      nl = block_sum_i(nl, sh);
+      if (tid == 0) { sh.u0 = atomicAdd(&pool.counters[1], (unsigned long long)nl); sh.flag = 0; }
+      __syncthreads();
+      const long long loff = (long long)sh.u0;
+      const bool link_fits = loff + nl <= pool.link_cap;
+      if (tok_fits && link_fits) {
+        for (int f = 0; f <= F; f++) {
+          for (int pass = 0; pass < 2; pass++) {
+            const int lb = pass ? s.pl_b[f] : s.el_b[f], le_ = pass ? s.pl_e[f] : s.el_e[f];
+            const float coff = (!pass && f < T) ? s.cost_offset[f] : 0.0f;
+            for (int l = lb + tid; l < le_; l += NT) {
+              const int src = s.hl_src[l];
+              if (src < 0) continue;
+              const int dst = s.hl_dst[l];
+              if (s.h_extra[src] == INF_BITS || s.h_extra[dst] == INF_BITS) continue;
+              const int d = atomicAdd(&sh.flag, 1);
+              const long long o = loff + d;
+              pool.link_src[o] = (int)s.h_tmp[src]; pool.link_dst[o] = (int)s.h_tmp[dst];
+              pool.link_il[o] = s.hl_il[l]; pool.link_ol[o] = s.hl_ol[l]; pool.link_gr[o] = s.hl_gr[l];
+              pool.link_ac[o] = s.hl_il[l] != 0 ? s.hl_ac[l] - coff : s.hl_ac[l];
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0) sh.u0 = atomicAdd(&pool.counters[2], (unsigned long long)T);
+      __syncthreads();
+      const long long coff_off = (long long)sh.u0;
+      if (coff_off + T <= pool.cost_cap)
+        for (int f = tid; f < T; f += NT) pool.cost_offsets[coff_off + f] = s.cost_offset[f];
+      if (!tok_fits || !link_fits || coff_off + T > pool.cost_cap) r.error = ERR_POOL;
+      else {
+        r.n_tok = na; r.n_link = nl; r.tok_off = toff; r.link_off = loff; r.cost_off = coff_off;
+        r.reached_final = final_relative != INF;
+        // Decode() returns whether the last frame still has tokens (:93-95)
+        int alive_last = 0;
+        for (int t = s.tok_b[F] + tid; t < s.tok_e[F]; t += NT) alive_last += s.h_extra[t] != INF_BITS;
+        alive_last = block_sum_i(alive_last, sh);
+        r.ok = alive_last > 0;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      r.n_tokens_expanded = sh.c_tok_exp; r.n_arcs_expanded = sh.c_arc_exp;
+      r.n_tokens_created = sh.c_tok_new; r.n_links_created = sh.c_link_new;
+      r.n_max_bound = sh.n_max_bound; r.n_min_bound = sh.n_min_bound;
+      results[utt] = r;
+      s.state[0] = epoch_base + T + 2;   // next utterance in this slot: disjoint epochs
+      s.state[1] = stamp;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+// ============================================================================ host side
+struct vbh_graph {
+  vbh_ctx *ctx;
+  int S, start; long long A; int max_ilabel;
+  DevBuf<float> final_cost; DevBuf<int> arc_off, nieps; DevBuf<vbh_arc> arcs;
+  std::vector<float> h_final;
+};
+
+struct HostLattice {
+  std::vector<int32_t> tok_frame, tok_state, link_src, link_dst, link_il, link_ol, ali, words;
+  std::vector<float> tok_cost, tok_extra, tok_final, link_gr, link_ac;
+  vbh_lattice view;
+};
+
+struct vbh_decoder {
+  vbh_ctx *ctx; const vbh_graph *graph; vbh_decode_cfg cfg;
+  int n_slots, max_frames;
+  Slot proto;                       // capacities
+  std::vector<Slot> h_slots;
+  std::vector<void *> allocs;
+  DevBuf<Slot> d_slots;
+  std::vector<HostLattice> results;
+  std::vector<UttResult> h_res;
+};
+
+static int slot_alloc(vbh_decoder *d, size_t bytes, void **p, int memset_val = -2) {
+  VBH_HIP(hipMalloc(p, bytes ? bytes : 8));
+  d->allocs.push_back(*p);
+  if (memset_val != -2) VBH_HIP(hipMemsetAsync(*p, memset_val, bytes, d->ctx->stream));
+  return 0;
+}
+
+extern "C" {
+
+void vbh_decode_cfg_default(vbh_decode_cfg *c) {
+  // VB/scr/kaldi_scr.h:152-157 (Decode defaults) over lattice-faster-decoder.h:59-67
+  c->beam = 13.0f; c->max_active = 7000; c->min_active = 200; c->lattice_beam = 6.0f;
+  c->prune_interval = 25; c->beam_delta = 0.5f; c->acoustic_scale = 0.083333f;
+}
+
+int vbh_graph_create(vbh_ctx *ctx, int32_t num_states, int32_t start, const float *h_final,
+                     const int64_t *h_arc_offsets, const vbh_arc *h_arcs, vbh_graph **out) {
+  VBH_CHECK(ctx && h_final && h_arc_offsets && out, "vbh_graph_create: NULL argument");
+  VBH_CHECK(num_states > 0 && start >= 0 && start < num_states, "vbh_graph_create: bad start state %d / %d states", start, num_states);
+  const long long A = h_arc_offsets[num_states];
+  VBH_CHECK(h_arc_offsets[0] == 0 && A >= 0 && A < 2147483647LL, "vbh_graph_create: bad arc offsets");
+  VBH_CHECK(A == 0 || h_arcs, "vbh_graph_create: arcs missing");
+  if (vbh_use_device(ctx)) return -1;
+  std::vector<int> off(num_states + 1), nieps(num_states, 0);
+  int max_il = 0;
+  for (int s = 0; s <= num_states; s++) {
+    VBH_CHECK(s == 0 || h_arc_offsets[s] >= h_arc_offsets[s - 1], "vbh_graph_create: arc offsets not monotone at state %d", s);
+    off[s] = (int)h_arc_offsets[s];
+  }
+  for (int s = 0; s < num_states; s++)
+    for (int a = off[s]; a < off[s + 1]; a++) {
+      VBH_CHECK(h_arcs[a].nextstate >= 0 && h_arcs[a].nextstate < num_states, "vbh_graph_create: arc %d leaves the graph", a);
+      VBH_CHECK(h_arcs[a].ilabel >= 0, "vbh_graph_create: negative ilabel on arc %d", a);
+      nieps[s] += h_arcs[a].ilabel == 0;
+      if (h_arcs[a].ilabel > max_il) max_il = h_arcs[a].ilabel;
+    }
+  vbh_graph *g = new vbh_graph();
+  g->ctx = ctx; g->S = num_states; g->start = start; g->A = A; g->max_ilabel = max_il;
+  g->h_final.assign(h_final, h_final + num_states);
+  hipStream_t st = ctx->stream;
+  if (g->final_cost.upload(h_final, num_states, st) || g->arc_off.upload(off.data(), off.size(), st) ||
+      g->nieps.upload(nieps.data(), nieps.size(), st) || g->arcs.upload(h_arcs, (size_t)A, st)) { delete g; return -1; }
+  VBH_HIP(hipStreamSynchronize(st));
+  *out = g;
+  return 0;
+}
+
+void vbh_graph_destroy(vbh_graph *g) {
+  if (!g) return;
+  (void)hipSetDevice(g->ctx->device);
+  (void)hipStreamSynchronize(g->ctx->stream);
+  delete g;
+}
+
+int vbh_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_decode_cfg *cfg, int32_t max_batch,
+                       int32_t max_frames, vbh_decoder **out) {
+  VBH_CHECK(ctx && graph && cfg && out, "vbh_decoder_create: NULL argument");
+  VBH_CHECK(cfg->beam > 0.0f && cfg->max_active > 1 && cfg->lattice_beam > 0.0f && cfg->prune_interval > 0 && cfg->beam_delta > 0.0f,
+            "vbh_decoder_create: invalid config (LatticeFasterDecoderConfig::Check)");
+  VBH_CHECK(cfg->min_active >= 0, "vbh_decoder_create: min_active < 0");
+  VBH_CHECK(max_batch >= 1 && max_frames >= 0, "vbh_decoder_create: bad batch/frames");
+  if (vbh_use_device(ctx)) return -1;
+  vbh_decoder *d = new vbh_decoder();
+  d->ctx = ctx; d->graph = graph; d->cfg = *cfg; d->max_frames = max_frames;
+  // how many utterances are searched concurrently: one workgroup each, at most one per CU here
+  d->n_slots = std::min<int>(max_batch, ctx->num_cus);
+  // capacities.  New tokens per frame are bounded by the arcs leaving the expanded tokens;
+  // with max_active binding that is ~max_active * out-degree.  Sized generously, checked at run time.
+  const long long S = graph->S;
+  const long long per_frame_tok = std::min<long long>(S, std::max<long long>(4096, 6LL * std::min<long long>(cfg->max_active, S)));
+  const long long per_frame_link = std::min<long long>(std::max<long long>(graph->A, 1), 2 * per_frame_tok);
+  const int win = cfg->prune_interval + 1;
+  Slot p{};
+  p.w_tok_cap = (int)std::min<long long>(per_frame_tok * win, 1LL << 28);
+  p.w_link_cap = (int)std::min<long long>((per_frame_link + per_frame_tok) * win, 1LL << 28);
+  // history: one unpruned frontier frame per interval plus the survivors
+  const long long n_int = max_frames / cfg->prune_interval + 2;
+  p.h_tok_cap = (int)std::min<long long>(per_frame_tok * n_int + 64LL * (max_frames + 1) + per_frame_tok, 1LL << 29);
+  p.h_link_cap = (int)std::min<long long>(per_frame_tok * n_int + 256LL * (max_frames + 1) + per_frame_link, 1LL << 29);
+  p.front_cap = (int)per_frame_tok;
+  d->proto = p;
+  d->h_slots.resize(d->n_slots);
+  const size_t F = (size_t)max_frames + 2;
+  for (int i = 0; i < d->n_slots; i++) {
+    Slot s = p;
+#define A_(field, type, count, ms) if (slot_alloc(d, sizeof(type) * (size_t)(count), reinterpret_cast<void **>(&s.field), ms)) { vbh_decoder_destroy(d); return -1; }
+    A_(key, unsigned long long, S, 0xFF) A_(claim, unsigned long long, S, 0xFF) A_(tokid, int, S, 0)
+    A_(w_state, int, p.w_tok_cap, -2) A_(w_cost, float, p.w_tok_cap, -2) A_(w_extra, unsigned, p.w_tok_cap, -2)
+    A_(w_tmp, unsigned, p.w_tok_cap, -2) A_(w_flag, int, p.w_tok_cap, 0) A_(w_remap, int, p.w_tok_cap, -2)
+    A_(wl_src, int, p.w_link_cap, -2) A_(wl_dst, int, p.w_link_cap, -2) A_(wl_il, int, p.w_link_cap, -2)
+    A_(wl_ol, int, p.w_link_cap, -2) A_(wl_gr, float, p.w_link_cap, -2) A_(wl_ac, float, p.w_link_cap, -2)
+    A_(h_state, int, p.h_tok_cap, -2) A_(h_cost, float, p.h_tok_cap, -2) A_(h_extra, unsigned, p.h_tok_cap, -2)
+    A_(h_tmp, unsigned, p.h_tok_cap, -2)
+    A_(hl_src, int, p.h_link_cap, -2) A_(hl_dst, int, p.h_link_cap, -2) A_(hl_il, int, p.h_link_cap, -2)
+    A_(hl_ol, int, p.h_link_cap, -2) A_(hl_gr, float, p.h_link_cap, -2) A_(hl_ac, float, p.h_link_cap, -2)
+    A_(tok_b, int, F, 0) A_(tok_e, int, F, 0) A_(el_b, int, F, 0) A_(el_e, int, F, 0) A_(pl_b, int, F, 0) A_(pl_e, int, F, 0)
+    A_(tok_w, unsigned char, F, 0) A_(el_w, unsigned char, F, 0) A_(pl_w, unsigned char, F, 0)
+    A_(cost_offset, float, F, 0) A_(front_a, int, p.front_cap, -2) A_(front_b, int, p.front_cap, -2)
+    A_(state, int, 4, 0)
+#undef A_
+    d->h_slots[i] = s;
+  }
+  if (d->d_slots.upload(d->h_slots.data(), d->h_slots.size(), ctx->stream)) { vbh_decoder_destroy(d); return -1; }
+  VBH_HIP(hipStreamSynchronize(ctx->stream));
+  *out = d;
+  return 0;
+}
+
+void vbh_decoder_destroy(vbh_decoder *d) {
+  if (!d) return;
+  (void)hipSetDevice(d->ctx->device);
+  (void)hipStreamSynchronize(d->ctx->stream);
+  for (void *p : d->allocs) (void)hipFree(p);
+  delete d;
+}
+
+}  // extern "C"
+
+// LatticeWeight natural order (fstext/lattice-weight.h Compare): smaller sum wins, ties on
+// the first component
+static inline bool lw_better(float a1, float a2, float b1, float b2) {
+  const float fa = a1 + a2, fb = b1 + b2;
+  if (fa < fb) return true;
+  if (fa > fb) return false;
+  return a1 < b1;
+}
+
+// canonical order (frame, state) for tokens, (src, dst, ilabel, olabel, graph, acoustic) for
+// links; best path = ShortestPath over the raw lattice + GetLinearSymbolSequence
+// (lattice-faster-decoder.cc:100-106, fstext/fstext-utils-inl.h:178-216)
+static void finish_lattice(const vbh_graph *g, const UttResult &r, const Pool &hp, HostLattice *L) {
+  const int n = r.n_tok, nl = r.n_link;
+  std::vector<int> order(n), rank(n);
+  for (int i = 0; i < n; i++) order[i] = i;
+  const int *tf = hp.tok_frame + r.tok_off, *ts = hp.tok_state + r.tok_off;
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return tf[a] != tf[b] ? tf[a] < tf[b] : ts[a] < ts[b]; });
+  L->tok_frame.resize(n); L->tok_state.resize(n); L->tok_cost.resize(n); L->tok_extra.resize(n); L->tok_final.resize(n);
+  for (int i = 0; i < n; i++) {
+    const int o = order[i];
+    rank[o] = i;
+    L->tok_frame[i] = tf[o]; L->tok_state[i] = ts[o]; L->tok_cost[i] = hp.tok_cost[r.tok_off + o];
+    L->tok_extra[i] = hp.tok_extra[r.tok_off + o]; L->tok_final[i] = hp.tok_final[r.tok_off + o];
+  }
+  struct LR { int s, d, il, ol; float g, a; };
+  std::vector<LR> recs(nl);
+  for (int i = 0; i < nl; i++) {
+    const long long o = r.link_off + i;
+    recs[i] = LR{rank[hp.link_src[o]], rank[hp.link_dst[o]], hp.link_il[o], hp.link_ol[o], hp.link_gr[o], hp.link_ac[o]};
+  }
+  std::sort(recs.begin(), recs.end(), [](const LR &x, const LR &y) {
+    if (x.s != y.s) return x.s < y.s;
+    if (x.d != y.d) return x.d < y.d;
+    if (x.il != y.il) return x.il < y.il;
+    if (x.ol != y.ol) return x.ol < y.ol;
+    if (x.g != y.g) return x.g < y.g;
+    return x.a < y.a;
+  });
+  L->link_src.resize(nl); L->link_dst.resize(nl); L->link_il.resize(nl); L->link_ol.resize(nl); L->link_gr.resize(nl); L->link_ac.resize(nl);
+  for (int i = 0; i < nl; i++) {
+    L->link_src[i] = recs[i].s; L->link_dst[i] = recs[i].d; L->link_il[i] = recs[i].il; L->link_ol[i] = recs[i].ol;
+    L->link_gr[i] = recs[i].g; L->link_ac[i] = recs[i].a;
+  }
+  // single shortest path: links are sorted by source token, i.e. by frame
+  const float INF = INFINITY;
+  std::vector<float> d1(n, INF), d2(n, INF);
+  std::vector<int> par(n, -1);
+  L->ali.clear(); L->words.clear();
+  float bg = INF, ba = INF;
+  int start = -1;
+  for (int i = 0; i < n && L->tok_frame[i] == 0; i++) if (L->tok_state[i] == g->start) start = i;
+  if (start >= 0) {
+    d1[start] = 0.0f; d2[start] = 0.0f;
+    int lo = 0;
+    while (lo < nl) {
+      const int f = L->tok_frame[recs[lo].s];
+      int hi = lo;
+      while (hi < nl && L->tok_frame[recs[hi].s] == f) hi++;
+      bool again = true;
+      while (again) {
+        again = false;
+        for (int i = lo; i < hi; i++) {
+          const int s_ = recs[i].s, t = recs[i].d;
+          if (d1[s_] == INF && d2[s_] == INF) continue;
+          const float n1 = d1[s_] + recs[i].g, n2 = d2[s_] + recs[i].a;
+          if (lw_better(n1, n2, d1[t], d2[t])) {
+            d1[t] = n1; d2[t] = n2; par[t] = i;
+            if (L->tok_frame[t] == f) again = true;
+          }
+        }
+      }
+      lo = hi;
+    }
+    int best = -1; float b1 = INF, b2 = INF;
+    for (int i = 0; i < n; i++) {
+      if (L->tok_frame[i] != r.num_frames || L->tok_final[i] == INF) continue;
+      if (d1[i] == INF && d2[i] == INF) continue;
+      const float f1 = d1[i] + L->tok_final[i], f2 = d2[i] + 0.0f;
+      if (best < 0 || lw_better(f1, f2, b1, b2)) { best = i; b1 = f1; b2 = f2; }
+    }
+    if (best >= 0) {
+      std::vector<int> path;
+      for (int t = best; par[t] >= 0; t = recs[par[t]].s) path.push_back(par[t]);
+      float t1 = 0.0f, t2 = 0.0f;
+      for (int i = (int)path.size() - 1; i >= 0; i--) {
+        const LR &x = recs[path[i]];
+        t1 = x.g + t1; t2 = x.a + t2;
+        if (x.il != 0) L->ali.push_back(x.il);
+        if (x.ol != 0) L->words.push_back(x.ol);
+      }
+      bg = L->tok_final[best] + t1; ba = 0.0f + t2;
+    }
+  }
+  vbh_lattice &v = L->view;
+  memset(&v, 0, sizeof(v));
+  v.ok = r.ok; v.reached_final = r.reached_final; v.num_frames = r.num_frames; v.final_relative_cost = r.final_relative_cost;
+  v.num_toks = n; v.tok_frame = L->tok_frame.data(); v.tok_state = L->tok_state.data(); v.tok_cost = L->tok_cost.data();
+  v.tok_extra = L->tok_extra.data(); v.tok_final = L->tok_final.data();
+  v.num_links = nl; v.link_src = L->link_src.data(); v.link_dst = L->link_dst.data(); v.link_ilabel = L->link_il.data();
+  v.link_olabel = L->link_ol.data(); v.link_graph = L->link_gr.data(); v.link_acoustic = L->link_ac.data();
+  v.num_ali = (int)L->ali.size(); v.ali = L->ali.data(); v.num_words = (int)L->words.size(); v.words = L->words.data();
+  v.best_graph = bg; v.best_acoustic = ba;
+  v.n_tokens_expanded = r.n_tokens_expanded; v.n_arcs_expanded = r.n_arcs_expanded;
+  v.n_tokens_created = r.n_tokens_created; v.n_links_created = r.n_links_created;
+  v.n_frames_maxactive_bound = r.n_max_bound; v.n_frames_minactive_bound = r.n_min_bound;
+}
+
+static const char *err_name(int e) {
+  switch (e) {
+    case ERR_W_TOK: return "raw-window token capacity exceeded";
+    case ERR_W_LINK: return "raw-window link capacity exceeded";
+    case ERR_H_TOK: return "history token capacity exceeded";
+    case ERR_H_LINK: return "history link capacity exceeded";
+    case ERR_FRONT: return "epsilon work-list capacity exceeded";
+    case ERR_EPS_LOOP: return "epsilon closure did not converge (epsilon cycle in the graph?)";
+    case ERR_POOL: return "output pool capacity exceeded";
+    default: return "unknown";
+  }
+}
+
+extern "C" {
+
+int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, const int64_t *h_frame_offsets,
+                     int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids) {
+  VBH_CHECK(d && h_frame_offsets && h_tid2pdf, "vbh_decode_batch: NULL argument");
+  VBH_CHECK(n_utt >= 0 && num_pdfs > 0 && num_tids >= 0, "vbh_decode_batch: bad sizes");
+  if (vbh_use_device(d->ctx)) return -1;
+  d->results.clear(); d->h_res.clear();
+  if (n_utt == 0) return 0;
+  const vbh_graph *g = d->graph;
+  // the graph's ilabels must be valid transition-ids ("Likely graph/model mismatch",
+  // decodable-am-diag-gmm.cc:32-33) -- checked once per batch on the tid2pdf table
+  VBH_CHECK(g->max_ilabel <= num_tids, "vbh_decode_batch: graph uses transition-id %d but the model has %d (graph/model mismatch)", g->max_ilabel, num_tids);
+  for (int t = 1; t <= num_tids; t++)
+    VBH_CHECK(h_tid2pdf[t] >= 0 && h_tid2pdf[t] < num_pdfs, "vbh_decode_batch: tid2pdf[%d] = %d out of range", t, h_tid2pdf[t]);
+  std::vector<UttDesc> utts(n_utt);
+  long long total_frames = 0;
+  for (int u = 0; u < n_utt; u++) {
+    const long long T = h_frame_offsets[u + 1] - h_frame_offsets[u];
+    VBH_CHECK(T >= 0 && T <= d->max_frames, "vbh_decode_batch: utterance %d has %lld frames (decoder built for %d)", u, T, d->max_frames);
+    utts[u] = UttDesc{h_frame_offsets[u], (int)T, 0};
+    total_frames += T;
+  }
+  VBH_CHECK(total_frames == 0 || d_loglikes, "vbh_decode_batch: NULL loglikes");
+  hipStream_t st = d->ctx->stream;
+  DevBuf<UttDesc> d_utts; DevBuf<int> d_t2p, d_counter; DevBuf<UttResult> d_res;
+  // graph labels beyond the table would read out of bounds: verify on the host copy
+  // (cheap: done in vbh_graph_create for states; here for labels)
+  std::vector<int> t2p(h_tid2pdf, h_tid2pdf + num_tids + 1);
+  t2p[0] = 0;
+  if (d_utts.upload(utts.data(), utts.size(), st) || d_t2p.upload(t2p.data(), t2p.size(), st) || d_counter.alloc(1) || d_res.alloc(n_utt)) return -1;
+  VBH_HIP(hipMemsetAsync(d_counter.p, 0, sizeof(int), st));
+  // output pool: the pruned lattice is a small multiple of the frame count
+  Pool pool{};
+  const long long tok_cap = std::max<long long>(1024, 48 * (total_frames + n_utt)), link_cap = std::max<long long>(2048, 96 * (total_frames + n_utt));
+  pool.tok_cap = tok_cap; pool.link_cap = link_cap; pool.cost_cap = total_frames + 1;
+  DevBuf<int> p_tf, p_ts, p_ls, p_ld, p_li, p_lo; DevBuf<float> p_tc, p_te, p_tfin, p_lg, p_la, p_co; DevBuf<unsigned long long> p_cnt;
+  if (p_tf.alloc(tok_cap) || p_ts.alloc(tok_cap) || p_tc.alloc(tok_cap) || p_te.alloc(tok_cap) || p_tfin.alloc(tok_cap) ||
+      p_ls.alloc(link_cap) || p_ld.alloc(link_cap) || p_li.alloc(link_cap) || p_lo.alloc(link_cap) || p_lg.alloc(link_cap) ||
+      p_la.alloc(link_cap) || p_co.alloc(pool.cost_cap) || p_cnt.alloc(4)) return -1;
+  VBH_HIP(hipMemsetAsync(p_cnt.p, 0, 4 * sizeof(unsigned long long), st));
+  pool.tok_frame = p_tf.p; pool.tok_state = p_ts.p; pool.tok_cost = p_tc.p; pool.tok_extra = p_te.p; pool.tok_final = p_tfin.p;
+  pool.link_src = p_ls.p; pool.link_dst = p_ld.p; pool.link_il = p_li.p; pool.link_ol = p_lo.p; pool.link_gr = p_lg.p; pool.link_ac = p_la.p;
+  pool.cost_offsets = p_co.p; pool.counters = p_cnt.p;
+  DevGraph dg{g->S, g->start, g->final_cost.p, g->arc_off.p, g->nieps.p, g->arcs.p};
+  DecCfg dc{d->cfg.beam, d->cfg.lattice_beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active, d->cfg.prune_interval};
+  const int grid = std::min(d->n_slots, n_utt);
+  hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(NT), 0, st, dg, dc, d->d_slots.p, d_loglikes, (int)num_pdfs, d_t2p.p,
+                     d_utts.p, n_utt, d_counter.p, d_res.p, pool);
+  VBH_HIP(hipGetLastError());
+  d->h_res.resize(n_utt);
+  VBH_HIP(hipMemcpyAsync(d->h_res.data(), d_res.p, sizeof(UttResult) * n_utt, hipMemcpyDeviceToHost, st));
+  unsigned long long used[4];
+  VBH_HIP(hipMemcpyAsync(used, p_cnt.p, sizeof(used), hipMemcpyDeviceToHost, st));
+  VBH_HIP(hipStreamSynchronize(st));
+  for (int u = 0; u < n_utt; u++)
+    VBH_CHECK(d->h_res[u].error == ERR_NONE, "vbh_decode_batch: utterance %d failed: %s", u, err_name(d->h_res[u].error));
+  // bring the used part of the pool to the host
+  const long long nt = std::min<long long>((long long)used[0], tok_cap), nl = std::min<long long>((long long)used[1], link_cap);
+  std::vector<int> tf(nt), ts(nt), ls(nl), ld(nl), li(nl), lo(nl); std::vector<float> tc(nt), te(nt), tfin(nt), lg(nl), la(nl);
+#define D2H(vec, src, cnt) if (cnt) VBH_HIP(hipMemcpyAsync(vec.data(), src.p, sizeof(vec[0]) * (cnt), hipMemcpyDeviceToHost, st));
+  D2H(tf, p_tf, nt) D2H(ts, p_ts, nt) D2H(tc, p_tc, nt) D2H(te, p_te, nt) D2H(tfin, p_tfin, nt)
+  D2H(ls, p_ls, nl) D2H(ld, p_ld, nl) D2H(li, p_li, nl) D2H(lo, p_lo, nl) D2H(lg, p_lg, nl) D2H(la, p_la, nl)
+#undef D2H
+  VBH_HIP(hipStreamSynchronize(st));
+  Pool hp{};
+  hp.tok_frame = tf.data(); hp.tok_state = ts.data(); hp.tok_cost = tc.data(); hp.tok_extra = te.data(); hp.tok_final = tfin.data();
+  hp.link_src = ls.data(); hp.link_dst = ld.data(); hp.link_il = li.data(); hp.link_ol = lo.data(); hp.link_gr = lg.data(); hp.link_ac = la.data();
+  d->results.resize(n_utt);
+  for (int u = 0; u < n_utt; u++) finish_lattice(g, d->h_res[u], hp, &d->results[u]);
+  return 0;
+}
+
+int vbh_decoder_result(vbh_decoder *d, int32_t utt, vbh_lattice *out) {
+  VBH_CHECK(d && out, "vbh_decoder_result: NULL argument");
+  VBH_CHECK(utt >= 0 && utt < (int)d->results.size(), "vbh_decoder_result: utterance %d out of range", utt);
+  *out = d->results[utt].view;
+  return 0;
+}
+
+}  // extern "C"
