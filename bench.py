@@ -42,9 +42,23 @@ def parse():
     ap.add_argument("--pdfs", type=int, default=2500)
     ap.add_argument("--gauss", type=int, default=15000)
     ap.add_argument("--no-decode", action="store_true", help="stop after GMM scoring (BASELINE config 2)")
+    ap.add_argument("--words", type=int, default=180000, help="vocabulary of the synthetic HCLG (~11 states per word)")
+    ap.add_argument("--beam", type=float, default=13.0)
+    ap.add_argument("--lattice-beam", type=float, default=6.0)
+    ap.add_argument("--max-active", type=int, default=7000)
+    ap.add_argument("--mean-scale", type=float, default=1.5, help="spread of the synthetic GMM means (search difficulty)")
+    ap.add_argument("--var-spread", type=float, default=0.2, help="sigma of the log-variances of the synthetic GMM")
+    ap.add_argument("--probe", action="store_true", help="print search statistics of the first utterances and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-seconds", type=float, default=30.0, help="audio seconds timed on the CPU baseline")
     return ap.parse_args()
+
+
+def build_graph(args):
+    """synthetic HCLG: lexicon prefix tree x 3-state HMMs x unigram loop (voicebridge_amd/synth.py);
+    ~2 M states / 4 M arcs at the default 180 k words"""
+    from voicebridge_amd import synth
+    return synth.lexicon_graph(args.words, args.pdfs, seed=11)
 
 
 def build_workload(args, rank):
@@ -64,7 +78,8 @@ def feature_space_model(args, sample_feats):
     from voicebridge_amd import synth
     std = sample_feats.std(0) + 1e-3
     mu = sample_feats.mean(0)
-    offs, w, means, iv = synth.gmm_model(args.pdfs, args.gauss, 39, seed=1, mean_scale=0.7, dim_scale=std)
+    offs, w, means, iv = synth.gmm_model(args.pdfs, args.gauss, 39, seed=1, mean_scale=args.mean_scale, dim_scale=std,
+                                         var_spread=args.var_spread)
     means = means + mu.astype(np.float32)
     miv = (means * iv).astype(np.float32)
     return offs, w, miv, iv
@@ -78,6 +93,7 @@ def cpu_baseline(args, waves, utt2spk, xforms, model, decode_setup):
     offs, w, miv, iv = model
     o = vbo.mfcc_opts()
     gc = vbo.gmm_gconsts(w, miv, iv)
+    fst = None
     t0 = time.perf_counter()
     frames = 0
     for u in range(n_utt):
@@ -86,7 +102,9 @@ def cpu_baseline(args, waves, utt2spk, xforms, model, decode_setup):
         f = vbo.transform_feats(vbo.add_deltas(vbo.apply_cmvn(raw, st)), xforms[utt2spk[u]])
         ll = vbo.gmm_loglikes(offs, gc, miv, iv, f)
         if decode_setup is not None:
-            fst, t2p, cfg = decode_setup
+            g, t2p, cfg = decode_setup
+            if fst is None:
+                fst = vbo.make_fst(g["final"], g["arc_offset"], g["arcs"], g["start"])
             vbo.decode_lattice_faster(fst, ll, t2p, **cfg)
         frames += len(raw)
     dt = time.perf_counter() - t0
@@ -126,7 +144,33 @@ def main():
     ll = torch.empty((T, gmm.num_pdfs), dtype=torch.float32, device=dev)
     ctx.torch_sync()
 
-    decode_setup = None   # filled in when the GPU decoder is part of the step
+    decode_setup = None
+    dec = None
+    if not args.no_decode:
+        g, t2p = build_graph(args)
+        graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
+        Tmax = int(np.max(np.diff(foff)))
+        dec = api.LatticeDecoder(ctx, graph, args.batch, Tmax, beam=args.beam, max_active=args.max_active,
+                                 min_active=200, lattice_beam=args.lattice_beam, acoustic_scale=0.083333)
+        decode_setup = (g, t2p, dict(acwt=0.083333, beam=args.beam, max_active=args.max_active, min_active=200,
+                                     lattice_beam=args.lattice_beam, exact_cutoff=True))
+        ctx.sync()
+
+    if args.probe and dec is not None:
+        gmm.loglikes(feats, out=ll)
+        t0 = time.perf_counter()
+        dec.decode(ll, foff, t2p)
+        dt = time.perf_counter() - t0
+        print("decode of %d utterances: %.3f s" % (args.batch, dt))
+        for u in range(min(args.batch, 4)):
+            r = dec.result(u, arrays=False)
+            nf = max(r["num_frames"], 1)
+            print("utt %d: ok=%d final=%d frames=%d tok_expanded/frame=%.0f arcs/frame=%.0f created/frame=%.0f links/frame=%.0f "
+                  "maxbound=%d minbound=%d lattice toks=%d links=%d words=%d best=(%.2f, %.2f)" % (
+                      u, r["ok"], r["reached_final"], r["num_frames"], r["n_tokens_expanded"] / nf, r["n_arcs_expanded"] / nf,
+                      r["n_tokens_created"] / nf, r["n_links_created"] / nf, r["n_frames_maxactive_bound"],
+                      r["n_frames_minactive_bound"], r["num_toks"], r["num_links"], len(r["words"]), r["best_graph"], r["best_acoustic"]))
+        return
 
     def step(timed):
         if timed:
@@ -139,6 +183,12 @@ def main():
         gmm.loglikes(feats, out=ll)
         if timed:
             ctx.timer_stop(2)
+        if dec is not None:
+            if timed:
+                ctx.timer_start(3)
+            dec.decode(ll, foff, t2p)      # synchronises: lattices are on the host when it returns
+            if timed:
+                ctx.timer_stop(3)
 
     def barrier():
         ctx.sync()
@@ -149,12 +199,15 @@ def main():
     for _ in range(args.warmup):
         step(False)
     barrier()
-    gmm_ms, feat_ms = [], []
+    gmm_ms, feat_ms, dec_ms = [], [], []
+    counters = dict(tok=0, arc=0, new=0, link=0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
         gmm_ms.append(ctx.timer_ms(2))      # waits for this step's GMM launch (device time)
         feat_ms.append(ctx.timer_ms(1))
+        if dec is not None:
+            dec_ms.append(ctx.timer_ms(3))
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -171,6 +224,38 @@ def main():
         value = total_frames / dt
         b, f = gmm.work(T)
         g_ms = float(np.mean(gmm_ms))
+        gmm_roof = {"kernel": "gmm_loglikes_kernel", "bound": "mfma", "achieved": f / (g_ms * 1e-3) / 1e12,
+                    "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f / (g_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                    "traffic": None, "kernel_ms": g_ms, "algorithmic_flops": f, "algorithmic_bytes": b,
+                    "hbm_GBs": b / (g_ms * 1e-3) / 1e9, "hbm_frac": b / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        stage_ms = {"mfcc+featpost": float(np.mean(feat_ms)), "gmm": g_ms}
+        roof = gmm_roof
+        extra = {}
+        if dec is not None:
+            d_ms = float(np.mean(dec_ms))
+            stage_ms["decode (kernel + lattice D2H + host best path)"] = d_ms
+            # algorithmic bytes of the search from the counters of the last step:
+            # N_tok*(20+16) + N_arc*(16+4) + N_new*16 + N_link*24
+            c = dict(tok=0, arc=0, new=0, link=0, maxb=0, minb=0, lat_tok=0, lat_link=0)
+            for u in range(args.batch):
+                r = dec.result(u, arrays=False)
+                c["tok"] += r["n_tokens_expanded"]; c["arc"] += r["n_arcs_expanded"]; c["new"] += r["n_tokens_created"]
+                c["link"] += r["n_links_created"]; c["maxb"] += r["n_frames_maxactive_bound"]
+                c["minb"] += r["n_frames_minactive_bound"]; c["lat_tok"] += r["num_toks"]; c["lat_link"] += r["num_links"]
+            dbytes = c["tok"] * 36.0 + c["arc"] * 20.0 + c["new"] * 16.0 + c["link"] * 24.0
+            dec_roof = {"kernel": "decode_kernel", "bound": "hbm", "achieved": dbytes / (d_ms * 1e-3) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dbytes / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None, "kernel_ms": d_ms, "algorithmic_bytes": dbytes,
+                        "note": "random-access (token/arc/atomic) traffic; time includes lattice D2H and host post-processing"}
+            extra["search"] = {"tokens_expanded_per_frame": c["tok"] / T, "arcs_per_frame": c["arc"] / T,
+                               "tokens_created_per_frame": c["new"] / T, "links_per_frame": c["link"] / T,
+                               "frames_maxactive_bound": c["maxb"], "frames_minactive_bound": c["minb"],
+                               "lattice_tokens_per_frame": c["lat_tok"] / T, "lattice_arcs_per_frame": c["lat_link"] / T,
+                               "arc_expansions_per_s": c["arc"] / (d_ms * 1e-3)}
+            if d_ms >= g_ms:
+                roof, extra["roofline_gmm"] = dec_roof, gmm_roof
+            else:
+                extra["roofline_decode"] = dec_roof
         out = {
             "metric": "decode frames/sec/node (RTF = 100/value), DELTA+SAT sizes",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -178,18 +263,16 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rtf": 100.0 / value,
             "config": {"workload": ("config2: MFCC + CMVN/deltas/fMLLR + all-pdf GMM scoring (search not in the step)"
-                                    if decode_setup is None else
-                                    "config3: DELTA+SAT full GPU decode, beam 13, lattice-beam 6, max-active 7000"),
+                                    if dec is None else
+                                    "config3: DELTA+SAT full GPU decode: MFCC, CMVN+deltas+fMLLR, GMM scoring, lattice "
+                                    "search beam %g lattice-beam %g max-active %d over a synthetic %d-state / %d-arc HCLG"
+                                    % (args.beam, args.lattice_beam, args.max_active, graph.num_states, graph.num_arcs)),
                        "utterances_per_step_per_gpu": args.batch, "utterance_seconds": args.seconds,
                        "frames_per_step_per_gpu": T, "pdfs": gmm.num_pdfs, "gaussians": gmm.num_gauss, "dim": 39,
                        "sharding": "utterances over ranks, no data-path collective"},
-            "roofline": {"kernel": "gmm_loglikes_kernel", "bound": "mfma", "achieved": f / (g_ms * 1e-3) / 1e12,
-                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": f / (g_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel_ms": g_ms, "algorithmic_flops": f, "algorithmic_bytes": b,
-                         "hbm_GBs": b / (g_ms * 1e-3) / 1e9, "hbm_frac": b / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "stage_ms": {"mfcc+featpost": float(np.mean(feat_ms)), "gmm": g_ms},
+            "roofline": roof, "stage_ms": stage_ms,
         }
+        out.update(extra)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, waves, utt2spk, xforms, model, decode_setup)
         print(json.dumps(out), flush=True)

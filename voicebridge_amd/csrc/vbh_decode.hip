@@ -902,31 +902,37 @@ int vbh_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_decode_cf
   p.w_link_cap = (int)std::min<long long>((per_frame_link + per_frame_tok) * win, 1LL << 28);
   // history: one unpruned frontier frame per interval plus the survivors
   const long long n_int = max_frames / cfg->prune_interval + 2;
-  p.h_tok_cap = (int)std::min<long long>(per_frame_tok * n_int + 64LL * (max_frames + 1) + per_frame_tok, 1LL << 29);
-  p.h_link_cap = (int)std::min<long long>(per_frame_tok * n_int + 256LL * (max_frames + 1) + per_frame_link, 1LL << 29);
+  p.h_tok_cap = (int)std::min<long long>(per_frame_tok * n_int + 1024LL * (max_frames + 1) + per_frame_tok, 1LL << 29);
+  p.h_link_cap = (int)std::min<long long>(per_frame_tok * n_int + 2048LL * (max_frames + 1) + per_frame_link, 1LL << 29);
   p.front_cap = (int)per_frame_tok;
   d->proto = p;
-  d->h_slots.resize(d->n_slots);
+  d->h_slots.assign(d->n_slots, p);
   const size_t F = (size_t)max_frames + 2;
-  for (int i = 0; i < d->n_slots; i++) {
-    Slot s = p;
-#define A_(field, type, count, ms) if (slot_alloc(d, sizeof(type) * (size_t)(count), reinterpret_cast<void **>(&s.field), ms)) { vbh_decoder_destroy(d); return -1; }
-    A_(key, unsigned long long, S, 0xFF) A_(claim, unsigned long long, S, 0xFF) A_(tokid, int, S, 0)
-    A_(w_state, int, p.w_tok_cap, -2) A_(w_cost, float, p.w_tok_cap, -2) A_(w_extra, unsigned, p.w_tok_cap, -2)
-    A_(w_tmp, unsigned, p.w_tok_cap, -2) A_(w_flag, int, p.w_tok_cap, 0) A_(w_remap, int, p.w_tok_cap, -2)
-    A_(wl_src, int, p.w_link_cap, -2) A_(wl_dst, int, p.w_link_cap, -2) A_(wl_il, int, p.w_link_cap, -2)
-    A_(wl_ol, int, p.w_link_cap, -2) A_(wl_gr, float, p.w_link_cap, -2) A_(wl_ac, float, p.w_link_cap, -2)
-    A_(h_state, int, p.h_tok_cap, -2) A_(h_cost, float, p.h_tok_cap, -2) A_(h_extra, unsigned, p.h_tok_cap, -2)
-    A_(h_tmp, unsigned, p.h_tok_cap, -2)
-    A_(hl_src, int, p.h_link_cap, -2) A_(hl_dst, int, p.h_link_cap, -2) A_(hl_il, int, p.h_link_cap, -2)
-    A_(hl_ol, int, p.h_link_cap, -2) A_(hl_gr, float, p.h_link_cap, -2) A_(hl_ac, float, p.h_link_cap, -2)
-    A_(tok_b, int, F, 0) A_(tok_e, int, F, 0) A_(el_b, int, F, 0) A_(el_e, int, F, 0) A_(pl_b, int, F, 0) A_(pl_e, int, F, 0)
-    A_(tok_w, unsigned char, F, 0) A_(el_w, unsigned char, F, 0) A_(pl_w, unsigned char, F, 0)
-    A_(cost_offset, float, F, 0) A_(front_a, int, p.front_cap, -2) A_(front_b, int, p.front_cap, -2)
-    A_(state, int, 4, 0)
-#undef A_
-    d->h_slots[i] = s;
+  // one allocation per field, covering all slots (slot i owns [i*count, (i+1)*count))
+  const size_t ns = (size_t)d->n_slots;
+#define A_(field, type, count, ms)                                                                   \
+  {                                                                                                  \
+    type *base = nullptr;                                                                            \
+    if (slot_alloc(d, sizeof(type) * (size_t)(count) * ns, reinterpret_cast<void **>(&base), ms)) {  \
+      vbh_decoder_destroy(d);                                                                        \
+      return -1;                                                                                     \
+    }                                                                                                \
+    for (size_t i = 0; i < ns; i++) d->h_slots[i].field = base + i * (size_t)(count);                \
   }
+  A_(key, unsigned long long, S, 0xFF) A_(claim, unsigned long long, S, 0xFF) A_(tokid, int, S, 0)
+  A_(w_state, int, p.w_tok_cap, -2) A_(w_cost, float, p.w_tok_cap, -2) A_(w_extra, unsigned, p.w_tok_cap, -2)
+  A_(w_tmp, unsigned, p.w_tok_cap, -2) A_(w_flag, int, p.w_tok_cap, 0) A_(w_remap, int, p.w_tok_cap, -2)
+  A_(wl_src, int, p.w_link_cap, -2) A_(wl_dst, int, p.w_link_cap, -2) A_(wl_il, int, p.w_link_cap, -2)
+  A_(wl_ol, int, p.w_link_cap, -2) A_(wl_gr, float, p.w_link_cap, -2) A_(wl_ac, float, p.w_link_cap, -2)
+  A_(h_state, int, p.h_tok_cap, -2) A_(h_cost, float, p.h_tok_cap, -2) A_(h_extra, unsigned, p.h_tok_cap, -2)
+  A_(h_tmp, unsigned, p.h_tok_cap, -2)
+  A_(hl_src, int, p.h_link_cap, -2) A_(hl_dst, int, p.h_link_cap, -2) A_(hl_il, int, p.h_link_cap, -2)
+  A_(hl_ol, int, p.h_link_cap, -2) A_(hl_gr, float, p.h_link_cap, -2) A_(hl_ac, float, p.h_link_cap, -2)
+  A_(tok_b, int, F, 0) A_(tok_e, int, F, 0) A_(el_b, int, F, 0) A_(el_e, int, F, 0) A_(pl_b, int, F, 0) A_(pl_e, int, F, 0)
+  A_(tok_w, unsigned char, F, 0) A_(el_w, unsigned char, F, 0) A_(pl_w, unsigned char, F, 0)
+  A_(cost_offset, float, F, 0) A_(front_a, int, p.front_cap, -2) A_(front_b, int, p.front_cap, -2)
+  A_(state, int, 4, 0)
+#undef A_
   if (d->d_slots.upload(d->h_slots.data(), d->h_slots.size(), ctx->stream)) { vbh_decoder_destroy(d); return -1; }
   VBH_HIP(hipStreamSynchronize(ctx->stream));
   *out = d;
@@ -1098,7 +1104,7 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
   VBH_HIP(hipMemsetAsync(d_counter.p, 0, sizeof(int), st));
   // output pool: the pruned lattice is a small multiple of the frame count
   Pool pool{};
-  const long long tok_cap = std::max<long long>(1024, 48 * (total_frames + n_utt)), link_cap = std::max<long long>(2048, 96 * (total_frames + n_utt));
+  const long long tok_cap = std::max<long long>(4096, 64 * (total_frames + n_utt)), link_cap = std::max<long long>(8192, 128 * (total_frames + n_utt));
   pool.tok_cap = tok_cap; pool.link_cap = link_cap; pool.cost_cap = total_frames + 1;
   DevBuf<int> p_tf, p_ts, p_ls, p_ld, p_li, p_lo; DevBuf<float> p_tc, p_te, p_tfin, p_lg, p_la, p_co; DevBuf<unsigned long long> p_cnt;
   if (p_tf.alloc(tok_cap) || p_ts.alloc(tok_cap) || p_tc.alloc(tok_cap) || p_te.alloc(tok_cap) || p_tfin.alloc(tok_cap) ||

@@ -26,7 +26,7 @@ def chirp(seconds=2.0, sr=16000):
     return np.round(x * 12000).astype(np.int16)
 
 
-def gmm_model(P, G, D, seed=0, mean_scale=1.0, dim_scale=None, zero_weight=False):
+def gmm_model(P, G, D, seed=0, mean_scale=1.0, dim_scale=None, zero_weight=False, var_spread=1.0):
     """Random AmDiagGmm arrays: (offs[P+1], weights[G], means[G,D], inv_vars[G,D]).
 
     Means N(0,1)*mean_scale, variances exp(N(0,1))+1e-5 (the distribution of
@@ -50,7 +50,7 @@ def gmm_model(P, G, D, seed=0, mean_scale=1.0, dim_scale=None, zero_weight=False
     offs = np.zeros(P + 1, np.int32)
     offs[1:] = np.cumsum(cnt)
     means = (rng.standard_normal((G, D)) * mean_scale).astype(np.float32)
-    var = (np.exp(rng.standard_normal((G, D))) + 1e-5).astype(np.float32)
+    var = (np.exp(rng.standard_normal((G, D)) * var_spread) + 1e-5).astype(np.float32)
     if dim_scale is not None:
         s = np.asarray(dim_scale, np.float32)
         means = means * s
@@ -124,3 +124,97 @@ def affine(D, seed=0, scale=0.05):
     A = np.eye(D, D + 1, dtype=np.float32)
     A += (rng.standard_normal((D, D + 1)) * scale).astype(np.float32)
     return A
+
+
+def lexicon_graph(num_words, num_pdfs, seed=0, n_phones=40, min_len=3, max_len=9, hmm_states=3):
+    """HCLG-shaped graph with the recombination structure of a real decoding graph: a lexicon
+    prefix tree over random phone strings, every tree node a left-to-right HMM of `hmm_states`
+    states (self-loop + forward arc), word ends returning to the root through one
+    input-epsilon arc that carries the word label and a Zipf-like unigram cost.
+
+    Returns (graph dict as decoding_graph(), tid2pdf).  Transition-ids: pdf p has the
+    self-loop tid 2p+1 and the forward tid 2p+2 (hmm/transition-model.h: two transitions per
+    emitting HMM state); each tree node draws a context-dependent phone, i.e. `hmm_states`
+    consecutive pdfs.
+    """
+    rng = np.random.default_rng(seed)
+    n_cd = num_pdfs // hmm_states
+    # ---- prefix tree: child[(node, phone)] -> node
+    lens = rng.integers(min_len, max_len + 1, size=num_words)
+    phones = rng.integers(0, n_phones, size=int(lens.sum()))
+    child = {}
+    node_cd = [0]          # node 0 = root (no HMM)
+    word_end_node = np.zeros(num_words, np.int64)
+    pos = 0
+    for w in range(num_words):
+        cur = 0
+        for k in range(lens[w]):
+            key = (cur, int(phones[pos + k]))
+            nxt = child.get(key)
+            if nxt is None:
+                nxt = len(node_cd)
+                child[key] = nxt
+                node_cd.append(0)
+            cur = nxt
+        pos += lens[w]
+        word_end_node[w] = cur
+    n_nodes = len(node_cd)
+    node_cd = rng.integers(0, n_cd, size=n_nodes)
+    # ---- states: root = 0; node n (>= 1) owns states 1 + (n-1)*H .. ; word-end states after that
+    H = hmm_states
+    first_state = lambda n: 1 + (n - 1) * H
+    n_hmm_states = (n_nodes - 1) * H
+    end_state0 = 1 + n_hmm_states
+    S = end_state0 + num_words
+    # children lists
+    kids = [[] for _ in range(n_nodes)]
+    for (parent, _ph), c in child.items():
+        kids[parent].append(c)
+    ends = [[] for _ in range(n_nodes)]
+    for w in range(num_words):
+        ends[word_end_node[w]].append(w)
+    self_w, fwd_w = np.float32(-np.log(0.6)), np.float32(-np.log(0.4))
+    lm_cost = (np.log(1.0 + rng.permutation(num_words)) * 1.1 + 1.0).astype(np.float32)   # Zipf-like
+    arc_lists = [[] for _ in range(S)]
+
+    def enter_arcs(n, from_pdf_tid):
+        """arcs that leave a state towards the first HMM state of node n's children / word ends"""
+        out = []
+        for c in kids[n]:
+            out.append((from_pdf_tid, 0, fwd_w, first_state(c)))
+        for w in ends[n]:
+            out.append((from_pdf_tid, 0, fwd_w, end_state0 + w))
+        return out
+
+    # the root enters its children through the children's own first emitting arc: model the
+    # root as a non-emitting hub: epsilon arcs root -> first state of each first phone
+    for c in kids[0]:
+        arc_lists[0].append((0, 0, np.float32(0.0), first_state(c)))
+    for n in range(1, n_nodes):
+        base = first_state(n)
+        for h in range(H):
+            pdf = int(node_cd[n]) * H + h
+            st = base + h
+            arc_lists[st].append((2 * pdf + 1, 0, self_w, st))
+            if h + 1 < H:
+                arc_lists[st].append((2 * pdf + 2, 0, fwd_w, st + 1))
+            else:
+                arc_lists[st].extend(enter_arcs(n, 2 * pdf + 2))
+    for w in range(num_words):
+        arc_lists[end_state0 + w].append((0, w + 1, lm_cost[w], 0))
+    n_arcs = np.array([len(a) for a in arc_lists], np.int64)
+    arc_offset = np.zeros(S + 1, np.int64)
+    arc_offset[1:] = np.cumsum(n_arcs)
+    arcs = np.zeros(int(arc_offset[-1]), ARC_DTYPE)
+    flat = [a for lst in arc_lists for a in lst]
+    arcs["ilabel"] = [a[0] for a in flat]
+    arcs["olabel"] = [a[1] for a in flat]
+    arcs["weight"] = [a[2] for a in flat]
+    arcs["nextstate"] = [a[3] for a in flat]
+    final = np.full(S, np.inf, np.float32)
+    final[0] = 0.0
+    num_tids = 2 * num_pdfs
+    t2p = np.empty(num_tids + 1, np.int32)
+    t2p[0] = -1
+    t2p[1:] = np.repeat(np.arange(num_pdfs, dtype=np.int32), 2)
+    return dict(final=final, arc_offset=arc_offset, arcs=arcs, start=0), t2p
