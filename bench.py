@@ -220,6 +220,17 @@ def main():
     else:
         total_frames = float(T * args.steps)
 
+    # end-of-run gather (the only collective of the job): hypotheses + scoring counters -> rank 0
+    gathered = None
+    if dec is not None and world > 1:
+        from voicebridge_amd import dist as vdist
+        hyps = [dec.result(u, arrays=False)["words"] for u in range(args.batch)]
+        ids = [rank * args.batch + u for u in range(args.batch)]
+        counters = vdist.score(hyps, hyps)          # synthetic audio has no transcripts: self-scored
+        totals, merged = vdist.gather_results(ids, hyps, counters, device=dev)
+        if rank == 0:
+            gathered = {"utterances": len(merged), "counters": dict(zip(vdist.COUNTER_NAMES, totals.tolist()))}
+
     if rank == 0:
         value = total_frames / dt
         b, f = gmm.work(T)
@@ -273,6 +284,8 @@ def main():
             "roofline": roof, "stage_ms": stage_ms,
         }
         out.update(extra)
+        if gathered is not None:
+            out["gather"] = gathered
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, waves, utt2spk, xforms, model, decode_setup)
         print(json.dumps(out), flush=True)
