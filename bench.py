@@ -170,6 +170,10 @@ def main():
                       u, r["ok"], r["reached_final"], r["num_frames"], r["n_tokens_expanded"] / nf, r["n_arcs_expanded"] / nf,
                       r["n_tokens_created"] / nf, r["n_links_created"] / nf, r["n_frames_maxactive_bound"],
                       r["n_frames_minactive_bound"], r["num_toks"], r["num_links"], len(r["words"]), r["best_graph"], r["best_acoustic"]))
+            ph = dec.phase_cycles(u)
+            tot = max(sum(ph), 1)
+            print("   phase share: " + ", ".join("%s %.1f%%" % (nm, 100.0 * c / tot) for nm, c in zip(
+                ["cutoff", "pass1", "admit+links", "eps", "prune", "compact", "output", "other"], ph)) + "  cycles/frame=%.0f" % (tot / nf))
         return
 
     def step(timed):

@@ -199,6 +199,9 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs,
                      const int64_t *h_frame_offsets, int32_t n_utt, const int32_t *h_tid2pdf,
                      int32_t num_tids);
 int vbh_decoder_result(vbh_decoder *d, int32_t utt, vbh_lattice *out);
+/* diagnostic: shader-clock cycles the utterance's workgroup spent per phase
+ * {cutoff, pass1, admit+links, epsilon closure, pruning, compaction, output, other} */
+int vbh_decoder_phase_cycles(vbh_decoder *d, int32_t utt, int64_t *out8);
 
 #ifdef __cplusplus
 }

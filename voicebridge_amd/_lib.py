@@ -18,7 +18,7 @@ SYMBOLS = [
     "vbh_gmm_create", "vbh_gmm_destroy", "vbh_gmm_num_pdfs", "vbh_gmm_dim", "vbh_gmm_get_gconsts",
     "vbh_gmm_loglikes", "vbh_gmm_work",
     "vbh_graph_create", "vbh_graph_destroy", "vbh_decode_cfg_default", "vbh_decoder_create",
-    "vbh_decoder_destroy", "vbh_decode_batch", "vbh_decoder_result",
+    "vbh_decoder_destroy", "vbh_decode_batch", "vbh_decoder_result", "vbh_decoder_phase_cycles",
 ]
 
 
@@ -124,6 +124,7 @@ def load():
         lib.vbh_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_int32,
                                          C.POINTER(C.c_int32), C.c_int32]
         lib.vbh_decoder_result.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Lattice)]
+        lib.vbh_decoder_phase_cycles.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
     _LIB = lib
     return lib
 

@@ -284,6 +284,11 @@ class LatticeDecoder:
                 link_graph=_arr(r.link_graph, r.num_links, np.float32), link_acoustic=_arr(r.link_acoustic, r.num_links, np.float32))
         return out
 
+    def phase_cycles(self, u):
+        out = (C.c_int64 * 8)()
+        check(self.lib.vbh_decoder_phase_cycles(self.h, int(u), out), "vbh_decoder_phase_cycles")
+        return list(out)
+
     def close(self):
         if self.h:
             self.lib.vbh_decoder_destroy(self.h)

@@ -51,6 +51,7 @@ constexpr int NW = NT / 64;
 constexpr int WBIT = 0x40000000;            // token id lives in the raw window
 constexpr unsigned INF_BITS = 0x7F800000u;  // +inf as float bits
 constexpr int MAX_EPS_ITERS = 4096;
+constexpr int MAX_WIN_FRAMES = 512;         // frames between two compactions (prune_interval + 1 <= this)
 
 struct DevGraph {
   int S, start;
@@ -58,6 +59,7 @@ struct DevGraph {
   const int *arc_off;        // [S+1]
   const int *nieps;          // [S] number of input-epsilon arcs
   const vbh_arc *arcs;       // [A]
+  const int *arc_pdf;        // [A] tid2pdf[ilabel], -1 for input-epsilon arcs (filled per batch)
 };
 
 struct DecCfg {
@@ -67,10 +69,10 @@ struct DecCfg {
 
 // per-slot workspace (device pointers)
 struct Slot {
-  unsigned long long *key, *claim;
-  int *tokid;
+  unsigned long long *key;                 // [S] (epoch | order-preserving cost bits)
+  int *tokid;                              // [S] window index of the state's token in the current epoch
   // raw window
-  int *w_state; float *w_cost; unsigned *w_extra, *w_tmp; int *w_flag, *w_remap;
+  int *w_state; float *w_cost; unsigned *w_extra, *w_tmp; int *w_remap;
   int *wl_src, *wl_dst, *wl_il, *wl_ol; float *wl_gr, *wl_ac;
   // history
   int *h_state; float *h_cost; unsigned *h_extra, *h_tmp;
@@ -79,9 +81,11 @@ struct Slot {
   int *tok_b, *tok_e, *el_b, *el_e, *pl_b, *pl_e;
   unsigned char *tok_w, *el_w, *pl_w;      // 1 = range refers to the window
   float *cost_offset;                      // [max_frames]
-  int *front_a, *front_b;                  // epsilon work lists
-  int *state;                              // persistent: [0] epoch base, [1] flag stamp
-  int w_tok_cap, w_link_cap, h_tok_cap, h_link_cap, front_cap;
+  // candidates of the current frame (pass 1 -> passes 2, 3)
+  float *c_tot, *c_ac; int *c_arc, *c_src, *c_dst;
+  int *front[3];                           // epsilon work lists (state ids), rotated
+  int *state;                              // persistent: [0] epoch base
+  int w_tok_cap, w_link_cap, h_tok_cap, h_link_cap, front_cap, cand_cap;
 };
 
 struct UttDesc { long long row0; int T; int pad; };
@@ -95,6 +99,7 @@ struct UttResult {   // written by the kernel, one per utterance
   long long n_tokens_expanded, n_arcs_expanded, n_tokens_created, n_links_created;
   int n_max_bound, n_min_bound;
   long long cost_off;                // offset of this utterance's cost_offsets in the pool
+  long long t_phase[8];              // shader-clock cycles per phase (thread 0): cutoff, pass1, pass2+3, eps, prune, compact, final, other
 };
 
 struct Pool {   // dense per-batch output
@@ -106,7 +111,7 @@ struct Pool {   // dense per-batch output
 };
 
 enum { ERR_NONE = 0, ERR_W_TOK = 1, ERR_W_LINK = 2, ERR_H_TOK = 3, ERR_H_LINK = 4, ERR_FRONT = 5,
-       ERR_EPS_LOOP = 6, ERR_POOL = 7 };
+       ERR_EPS_LOOP = 6, ERR_POOL = 7, ERR_CAND = 8 };
 
 // order-preserving map float -> uint32
 __device__ __forceinline__ unsigned f2o(float f) {
@@ -126,64 +131,60 @@ __device__ __forceinline__ int ld_i32(const int *p) {
 __device__ __forceinline__ void st_i32(int *p, int v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ long long clk() { return (long long)__builtin_amdgcn_s_memtime(); }
 
 struct Shared {
-  unsigned long long red64[NW];
-  int red32[NW];
-  float redf[NW];
+  unsigned long long red[2][NW];   // reduction scratch, alternated so that one barrier per reduction suffices
   unsigned hist[256];
-  // broadcast / counters
   int w_ntok, w_nlink, h_ntok, h_nlink;
-  int n_next, changed, error, flag;
+  int n_cand;
+  int fcnt[3];                     // epsilon work-list fill counts, rotated with Slot::front
+  int changed, error, flag;
   unsigned sel_prefix, sel_mask; int sel_k;
-  float f0, f1, f2;
+  float f0;
   unsigned long long u0;
-  long long c_tok_exp, c_arc_exp, c_tok_new, c_link_new;
   int n_max_bound, n_min_bound;
   int utt;
+  long long tph[8];                // phase cycle counters (thread 0)
+  int fr_cnt[3 * MAX_WIN_FRAMES];  // compaction: survivors per frame (tokens, emitting links, epsilon links)
+  int fr_base[3 * MAX_WIN_FRAMES];
 };
 
-__device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v, Shared &sh) {
+// block reductions with ONE barrier each: partials go to red[par], par flips on every call
+__device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v, Shared &sh, int &par) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     unsigned long long w = __shfl_xor(v, o, 64);
     v = w < v ? w : v;
   }
+  if ((threadIdx.x & 63) == 0) sh.red[par][threadIdx.x >> 6] = v;
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh.red64[threadIdx.x >> 6] = v;
-  __syncthreads();
-  unsigned long long r = sh.red64[0];
+  unsigned long long r = sh.red[par][0];
 #pragma unroll
-  for (int i = 1; i < NW; i++) r = sh.red64[i] < r ? sh.red64[i] : r;
+  for (int i = 1; i < NW; i++) r = sh.red[par][i] < r ? sh.red[par][i] : r;
+  par ^= 1;
   return r;
 }
-__device__ __forceinline__ float block_min_f(float v, Shared &sh) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh.redf[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float r = sh.redf[0];
-#pragma unroll
-  for (int i = 1; i < NW; i++) r = fminf(r, sh.redf[i]);
-  return r;
-}
-__device__ __forceinline__ int block_sum_i(int v, Shared &sh) {
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, Shared &sh, int &par) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sh.red[par][threadIdx.x >> 6] = v;
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh.red32[threadIdx.x >> 6] = v;
-  __syncthreads();
-  int r = 0;
+  unsigned long long r = 0;
 #pragma unroll
-  for (int i = 0; i < NW; i++) r += sh.red32[i];
+  for (int i = 0; i < NW; i++) r += sh.red[par][i];
+  par ^= 1;
   return r;
+}
+__device__ __forceinline__ float block_min_f(float v, Shared &sh, int &par) {
+  return o2f((unsigned)block_min_u64((unsigned long long)f2o(v), sh, par));
 }
 
 // k-th smallest (0-based) of cost[0..n): exact radix select on the order-preserving keys
-// (std::nth_element value in GetCutoff, lattice-faster-decoder.cc:654-676)
+// (the std::nth_element value in GetCutoff, lattice-faster-decoder.cc:654-676)
 __device__ float select_kth(const float *cost, int n, int k, Shared &sh) {
   const int tid = threadIdx.x;
+  __syncthreads();
   if (tid == 0) { sh.sel_prefix = 0; sh.sel_mask = 0; sh.sel_k = k; }
   for (int shift = 24; shift >= 0; shift -= 8) {
     for (int i = tid; i < 256; i += NT) sh.hist[i] = 0;
@@ -209,14 +210,32 @@ __device__ float select_kth(const float *cost, int n, int k, Shared &sh) {
   return o2f(sh.sel_prefix);
 }
 
-struct TokView { const int *state; const float *cost; int base; int n; int enc; };
-
 __device__ __forceinline__ float tok_cost(const Slot &s, int id) { return (id & WBIT) ? s.w_cost[id ^ WBIT] : s.h_cost[id]; }
 __device__ __forceinline__ unsigned tok_extra(const Slot &s, int id) { return (id & WBIT) ? s.w_extra[id ^ WBIT] : s.h_extra[id]; }
 
-// ---------------------------------------------------------------------------------------
-// PruneForwardLinks for one frame (lattice-faster-decoder.cc:300-371), evaluated to its
-// fixed point.  Returns (uniformly) whether any token's extra_cost changed.
+// evaluate the forward links [lb, le) of one frame: excise those over the lattice beam,
+// atomicMin the rest into tmp[src] (lattice-faster-decoder.cc:331-356)
+__device__ __forceinline__ void eval_links(const Slot &s, bool lw, int lb, int le_, const float *tcost, unsigned *tmp,
+                                           float lattice_beam) {
+  int *lsrc = lw ? s.wl_src : s.hl_src;
+  const int *ldst = lw ? s.wl_dst : s.hl_dst;
+  const float *lgr = lw ? s.wl_gr : s.hl_gr, *lac = lw ? s.wl_ac : s.hl_ac;
+  for (int l = lb + threadIdx.x; l < le_; l += NT) {
+    const int src = lsrc[l];
+    if (src < 0) continue;   // already excised
+    const int dst = ldst[l];
+    const float nx = __uint_as_float(tok_extra(s, dst));
+    // next_tok->extra_cost + ((tok->tot_cost + link->acoustic_cost + link->graph_cost) - next_tok->tot_cost)
+    float le = nx + (((tcost[src & ~WBIT] + lac[l]) + lgr[l]) - tok_cost(s, dst));
+    if (le > lattice_beam) { lsrc[l] = -1; continue; }
+    if (le < 0.0f) le = 0.0f;
+    atomicMin(&tmp[src & ~WBIT], __float_as_uint(le));
+  }
+}
+
+// PruneForwardLinks for one frame (lattice-faster-decoder.cc:300-371), evaluated to its fixed
+// point.  tmp[] of the frame's tokens must hold +inf on entry and holds +inf again on exit.
+// Returns (uniformly) whether any token's extra_cost changed.
 __device__ bool prune_frame(const Slot &s, int f, float lattice_beam, Shared &sh) {
   const int tid = threadIdx.x;
   const int tb = s.tok_b[f], te = s.tok_e[f];
@@ -227,43 +246,28 @@ __device__ bool prune_frame(const Slot &s, int f, float lattice_beam, Shared &sh
   const bool ew = s.el_w[f], pw = s.pl_w[f];
   bool frame_changed = false;
   for (int iter = 0; iter < MAX_EPS_ITERS; iter++) {
-    for (int t = tb + tid; t < te; t += NT) tmp[t] = INF_BITS;
     if (tid == 0) sh.changed = 0;
+    eval_links(s, ew, eb, ee, tcost, tmp, lattice_beam);
+    eval_links(s, pw, pb, pe, tcost, tmp, lattice_beam);
     __syncthreads();
-    for (int pass = 0; pass < 2; pass++) {
-      const int lb = pass ? pb : eb, le_ = pass ? pe : ee;
-      const bool lw = pass ? pw : ew;
-      int *lsrc = lw ? s.wl_src : s.hl_src;
-      const int *ldst = lw ? s.wl_dst : s.hl_dst;
-      const float *lgr = lw ? s.wl_gr : s.hl_gr, *lac = lw ? s.wl_ac : s.hl_ac;
-      for (int l = lb + tid; l < le_; l += NT) {
-        const int src = lsrc[l];
-        if (src < 0) continue;   // already excised
-        const int dst = ldst[l];
-        const float nx = __uint_as_float(tok_extra(s, dst));
-        const float sc = tcost[(src & ~WBIT)];
-        // next_tok->extra_cost + ((tok->tot_cost + link->acoustic_cost + link->graph_cost) - next_tok->tot_cost)
-        float le = nx + (((sc + lac[l]) + lgr[l]) - tok_cost(s, dst));
-        if (le > lattice_beam) { lsrc[l] = -1; continue; }
-        if (le < 0.0f) le = 0.0f;
-        atomicMin(&tmp[src & ~WBIT], __float_as_uint(le));
-      }
-    }
-    __syncthreads();
+    int ch = 0;
     for (int t = tb + tid; t < te; t += NT) {
       const unsigned v = tmp[t];
-      if (v != extra[t]) { extra[t] = v; sh.changed = 1; }
+      tmp[t] = INF_BITS;
+      if (v != extra[t]) { extra[t] = v; ch = 1; }
     }
+    if (ch) sh.changed = 1;
     __syncthreads();
-    const bool ch = sh.changed != 0;
-    __syncthreads();
-    frame_changed |= ch;
-    if (!ch || pe == pb) break;
+    const bool any = sh.changed != 0;
+    frame_changed |= any;
+    if (!any || pe == pb) break;
+    __syncthreads();   // sh.changed is reset at the top of the next iteration
   }
   return frame_changed;
 }
 
-// backward pass from frame `from` down; frames >= first_unpruned are always processed
+// backward pass from frame `from` down; frames >= first_unpruned are always processed,
+// older ones until a frame's extra_costs do not move (then nothing below can move)
 __device__ void prune_backward(const Slot &s, int from, int first_unpruned, float lattice_beam, Shared &sh) {
   for (int f = from; f >= 0; f--) {
     const bool ch = prune_frame(s, f, lattice_beam, sh);
@@ -271,150 +275,168 @@ __device__ void prune_backward(const Slot &s, int from, int first_unpruned, floa
   }
 }
 
-// move the survivors of the raw window (tokens of frames (prev_front, front], links created
-// since the last compaction) into the history; returns false (uniformly) on overflow
+// Move the survivors of the raw window into the history: tokens of frames (prev_front, front],
+// emitting links from frames [prev_front, front-1], epsilon links within (prev_front, front].
+// Survivors are counted per frame first so that every frame stays contiguous in H with a
+// handful of barriers in total.  Returns false (uniformly) on overflow.
 __device__ bool compact_window(const Slot &s, int prev_front, int front, Shared &sh) {
   const int tid = threadIdx.x;
-  // tokens, frame by frame so that each frame stays contiguous
-  for (int f = prev_front + 1; f <= front; f++) {
+  const int f0 = prev_front < 0 ? 0 : prev_front;
+  const int nf = front - f0 + 1;     // frames f0..front  (<= MAX_WIN_FRAMES, checked on the host)
+  for (int i = tid; i < 3 * nf; i += NT) sh.fr_cnt[i] = 0;
+  __syncthreads();
+  // ---- count
+  for (int k = 0; k < nf; k++) {
+    const int f = f0 + k;
+    if (s.tok_w[f]) {
+      int c = 0;
+      for (int t = s.tok_b[f] + tid; t < s.tok_e[f]; t += NT) c += s.w_extra[t] != INF_BITS;
+      if (c) atomicAdd(&sh.fr_cnt[k], c);
+    }
+    for (int pass = 0; pass < 2; pass++) {
+      if (!(pass ? s.pl_w[f] : s.el_w[f])) continue;
+      const int lb = pass ? s.pl_b[f] : s.el_b[f], le_ = pass ? s.pl_e[f] : s.el_e[f];
+      int c = 0;
+      for (int l = lb + tid; l < le_; l += NT) {
+        const int src = s.wl_src[l];
+        if (src < 0) continue;
+        const int dst = s.wl_dst[l];
+        const bool sa = (src & WBIT) ? s.w_extra[src ^ WBIT] != INF_BITS : true;
+        const bool da = (dst & WBIT) ? s.w_extra[dst ^ WBIT] != INF_BITS : true;
+        c += sa && da;
+      }
+      if (c) atomicAdd(&sh.fr_cnt[(1 + pass) * nf + k], c);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int tb = sh.h_ntok, lb = sh.h_nlink;
+    for (int k = 0; k < nf; k++) { sh.fr_base[k] = tb; tb += sh.fr_cnt[k]; }
+    for (int k = 0; k < nf; k++) {
+      sh.fr_base[nf + k] = lb; lb += sh.fr_cnt[nf + k];
+      sh.fr_base[2 * nf + k] = lb; lb += sh.fr_cnt[2 * nf + k];
+    }
+    if (tb > s.h_tok_cap) sh.error = ERR_H_TOK;
+    if (lb > s.h_link_cap) sh.error = ERR_H_LINK;
+    sh.h_ntok = tb; sh.h_nlink = lb;
+  }
+  __syncthreads();
+  if (sh.error != ERR_NONE) return false;
+  for (int i = tid; i < 3 * nf; i += NT) sh.fr_cnt[i] = 0;   // reused as fill counters
+  __syncthreads();
+  // ---- move tokens
+  for (int k = 0; k < nf; k++) {
+    const int f = f0 + k;
     if (!s.tok_w[f]) continue;
-    const int tb = s.tok_b[f], te = s.tok_e[f];
-    __syncthreads();
-    const int base = sh.h_ntok;
-    __syncthreads();
-    for (int t = tb + tid; t < te; t += NT) {
+    for (int t = s.tok_b[f] + tid; t < s.tok_e[f]; t += NT) {
       int nid = -1;
       if (s.w_extra[t] != INF_BITS) {
-        nid = atomicAdd(&sh.h_ntok, 1);
-        if (nid < s.h_tok_cap) {
-          s.h_state[nid] = s.w_state[t]; s.h_cost[nid] = s.w_cost[t]; s.h_extra[nid] = s.w_extra[t];
-        } else { sh.error = ERR_H_TOK; nid = -1; }
+        nid = sh.fr_base[k] + atomicAdd(&sh.fr_cnt[k], 1);
+        s.h_state[nid] = s.w_state[t]; s.h_cost[nid] = s.w_cost[t]; s.h_extra[nid] = s.w_extra[t];
+        s.h_tmp[nid] = INF_BITS;
       }
       s.w_remap[t] = nid;
     }
-    __syncthreads();
-    if (tid == 0) { s.tok_b[f] = base; s.tok_e[f] = sh.h_ntok < s.h_tok_cap ? sh.h_ntok : s.h_tok_cap; s.tok_w[f] = 0; }
   }
   __syncthreads();
-  // links: emitting links from frames [prev_front, front-1], epsilon links within (prev_front, front]
-  for (int f = prev_front; f <= front; f++) {
+  // ---- move links
+  for (int k = 0; k < nf; k++) {
+    const int f = f0 + k;
     for (int pass = 0; pass < 2; pass++) {
-      if (f < 0) continue;
-      const bool in_w = pass ? s.pl_w[f] : s.el_w[f];
-      if (!in_w) continue;
+      if (!(pass ? s.pl_w[f] : s.el_w[f])) continue;
       const int lb = pass ? s.pl_b[f] : s.el_b[f], le_ = pass ? s.pl_e[f] : s.el_e[f];
-      __syncthreads();
-      const int base = sh.h_nlink;
-      __syncthreads();
+      const int slot = (1 + pass) * nf + k;
       for (int l = lb + tid; l < le_; l += NT) {
         int src = s.wl_src[l];
         if (src < 0) continue;
         int dst = s.wl_dst[l];
         if (src & WBIT) src = s.w_remap[src ^ WBIT];
         if (dst & WBIT) dst = s.w_remap[dst ^ WBIT];
-        if (src < 0 || dst < 0) continue;   // an end point died (its extra_cost is +inf)
-        const int nid = atomicAdd(&sh.h_nlink, 1);
-        if (nid < s.h_link_cap) {
-          s.hl_src[nid] = src; s.hl_dst[nid] = dst; s.hl_il[nid] = s.wl_il[l]; s.hl_ol[nid] = s.wl_ol[l];
-          s.hl_gr[nid] = s.wl_gr[l]; s.hl_ac[nid] = s.wl_ac[l];
-        } else sh.error = ERR_H_LINK;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        const int e = sh.h_nlink < s.h_link_cap ? sh.h_nlink : s.h_link_cap;
-        if (pass) { s.pl_b[f] = base; s.pl_e[f] = e; s.pl_w[f] = 0; }
-        else { s.el_b[f] = base; s.el_e[f] = e; s.el_w[f] = 0; }
+        if (src < 0 || dst < 0) continue;
+        const int nid = sh.fr_base[slot] + atomicAdd(&sh.fr_cnt[slot], 1);
+        s.hl_src[nid] = src; s.hl_dst[nid] = dst; s.hl_il[nid] = s.wl_il[l]; s.hl_ol[nid] = s.wl_ol[l];
+        s.hl_gr[nid] = s.wl_gr[l]; s.hl_ac[nid] = s.wl_ac[l];
       }
     }
   }
   __syncthreads();
-  if (tid == 0) { sh.w_ntok = 0; sh.w_nlink = 0; }
+  if (tid == 0) {
+    for (int k = 0; k < nf; k++) {
+      const int f = f0 + k;
+      if (s.tok_w[f]) { s.tok_b[f] = sh.fr_base[k]; s.tok_e[f] = sh.fr_base[k] + sh.fr_cnt[k]; s.tok_w[f] = 0; }
+      if (s.el_w[f]) { s.el_b[f] = sh.fr_base[nf + k]; s.el_e[f] = sh.fr_base[nf + k] + sh.fr_cnt[nf + k]; s.el_w[f] = 0; }
+      if (s.pl_w[f]) { s.pl_b[f] = sh.fr_base[2 * nf + k]; s.pl_e[f] = sh.fr_base[2 * nf + k] + sh.fr_cnt[2 * nf + k]; s.pl_w[f] = 0; }
+    }
+    sh.w_ntok = 0; sh.w_nlink = 0;
+  }
+  __threadfence_block();
   __syncthreads();
-  return sh.error == ERR_NONE;
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------
-// ProcessNonemitting (lattice-faster-decoder.cc:796-858) on the tokens of frame fpo, which
-// occupy window indices [nb, sh.w_ntok): iterate the frontier until no cost changes, then
-// refresh the token costs and write the epsilon links from the final costs.
-__device__ void process_nonemitting(const DevGraph &g, const Slot &s, int fpo, int nb, float cutoff,
-                                    unsigned epoch_hi, int *stamp, Shared &sh) {
+// ProcessNonemitting (lattice-faster-decoder.cc:796-858) for the tokens of frame fpo, which
+// occupy window indices [nb, sh.w_ntok).  Work lists hold STATE ids: list `cur` (count
+// sh.fcnt[cur]) was filled by the caller with the new states that have input-epsilon arcs.
+// Iterates until no cost changes, then stores the final costs and writes the epsilon links.
+// Returns the first link index of the frame's epsilon links; on return a barrier has made all
+// writes visible.
+__device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, float cutoff, unsigned ep,
+                                   int cur, Shared &sh) {
   const int tid = threadIdx.x;
-  const unsigned long long EPK = (unsigned long long)epoch_hi << 32;
-  int ncur = sh.w_ntok - nb;     // iteration 0 walks the whole new range
-  bool use_list = false;
-  int *fcur = s.front_a, *fnext = s.front_b;
-  for (int iter = 0; ncur > 0; iter++) {
+  const unsigned long long EPK = (unsigned long long)ep << 32;
+  for (int iter = 0;; iter++) {
+    const int ncur = sh.fcnt[cur] < s.front_cap ? sh.fcnt[cur] : s.front_cap;
+    if (ncur == 0) break;
     if (iter >= MAX_EPS_ITERS) { if (tid == 0) sh.error = ERR_EPS_LOOP; break; }
-    const int my_stamp = ++(*stamp);
-    const unsigned tag = (unsigned)(iter + 1);   // claim tag of tokens created in this iteration
-    if (tid == 0) sh.n_next = 0;
-    __syncthreads();
+    const int nxt = cur == 2 ? 0 : cur + 1, spare = nxt == 2 ? 0 : nxt + 1;
+    if (tid == 0) sh.fcnt[spare] = 0;      // nobody touches the spare list during this iteration
+    const int *fcur = s.front[cur];
+    int *fnext = s.front[nxt];
     for (int i = tid; i < ncur; i += NT) {
-      const int t = use_list ? fcur[i] : nb + i;
-      const int st = s.w_state[t];
-      if (g.nieps[st] == 0) continue;
+      const int st = fcur[i];
       const float c = o2f((unsigned)ld_u64(&s.key[st]));
       if (c > cutoff) continue;
       for (int a = g.arc_off[st]; a < g.arc_off[st + 1]; a++) {
+        if (g.arc_pdf[a] >= 0) continue;     // emitting arc
         const vbh_arc arc = g.arcs[a];
-        if (arc.ilabel != 0) continue;
         const float tot = c + arc.weight;
         if (!(tot < cutoff)) continue;
         const int ds = arc.nextstate;
         const unsigned long long nk = EPK | f2o(tot);
-        unsigned long long cl = ld_u64(&s.claim[ds]);
-        bool existed_before;
-        if ((unsigned)(cl >> 32) != epoch_hi) {
-          const unsigned long long old = atomicCAS(&s.claim[ds], cl, EPK | tag);
-          if (old == cl) {   // this thread creates the token
-            const int nid = atomicAdd(&sh.w_ntok, 1);
-            if (nid < s.w_tok_cap) {
-              s.w_state[nid] = ds; s.w_extra[nid] = 0u; s.w_flag[nid] = my_stamp;
-              st_i32(&s.tokid[ds], nid);
-              const int q = atomicAdd(&sh.n_next, 1);
-              if (q < s.front_cap) fnext[q] = nid; else sh.error = ERR_FRONT;
-            } else sh.error = ERR_W_TOK;
-            atomicMin(&s.key[ds], nk);
-            continue;
-          }
-          cl = old;
-        }
-        existed_before = (unsigned)cl < tag;   // created in an earlier phase: tokid is valid
-        const unsigned long long oldk = atomicMin(&s.key[ds], nk);
-        if (existed_before && nk < oldk) {   // improved an older token: it must be re-expanded
-          const int tk = ld_i32(&s.tokid[ds]);
-          if (atomicExch(&s.w_flag[tk], my_stamp) != my_stamp) {
-            const int q = atomicAdd(&sh.n_next, 1);
-            if (q < s.front_cap) fnext[q] = tk; else sh.error = ERR_FRONT;
-          }
+        const unsigned long long old = atomicMin(&s.key[ds], nk);
+        bool push = false;
+        if ((unsigned)(old >> 32) != ep) {   // first touch of this state in this frame: create its token
+          const int nid = atomicAdd(&sh.w_ntok, 1);
+          if (nid < s.w_tok_cap) {
+            s.w_state[nid] = ds; s.w_extra[nid] = 0u; s.w_tmp[nid] = INF_BITS;
+            st_i32(&s.tokid[ds], nid);
+          } else sh.error = ERR_W_TOK;
+          push = true;
+        } else if (nk < old) push = true;     // improved: must be (re-)expanded
+        if (push && g.nieps[ds] > 0) {
+          const int q = atomicAdd(&sh.fcnt[nxt], 1);
+          if (q < s.front_cap) fnext[q] = ds; else sh.error = ERR_FRONT;
         }
       }
     }
     __syncthreads();
-    ncur = sh.n_next < s.front_cap ? sh.n_next : s.front_cap;
-    const bool err = sh.error != ERR_NONE;
-    __syncthreads();
-    if (err) return;
-    int *tmp = fcur; fcur = fnext; fnext = tmp;
-    use_list = true;
+    if (sh.error != ERR_NONE) break;
+    cur = nxt;
   }
   __syncthreads();
-  // final costs of the frame's tokens
+  // final costs of the frame's tokens + epsilon links regenerated from them (:824-845)
   const int ne = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap;
-  for (int t = nb + tid; t < ne; t += NT) s.w_cost[t] = o2f((unsigned)ld_u64(&s.key[s.w_state[t]]));
-  __syncthreads();
-  // epsilon links, regenerated from final costs (":824-826 delete + re-create")
   const int lb = sh.w_nlink;
   __syncthreads();
   for (int t = nb + tid; t < ne; t += NT) {
     const int st = s.w_state[t];
-    if (g.nieps[st] == 0) continue;
-    const float c = s.w_cost[t];
-    if (c > cutoff) continue;
+    const float c = o2f((unsigned)ld_u64(&s.key[st]));
+    s.w_cost[t] = c;
+    if (g.nieps[st] == 0 || c > cutoff) continue;
     for (int a = g.arc_off[st]; a < g.arc_off[st + 1]; a++) {
+      if (g.arc_pdf[a] >= 0) continue;
       const vbh_arc arc = g.arcs[a];
-      if (arc.ilabel != 0) continue;
       const float tot = c + arc.weight;
       if (!(tot < cutoff)) continue;
       const int l = atomicAdd(&sh.w_nlink, 1);
@@ -425,22 +447,19 @@ __device__ void process_nonemitting(const DevGraph &g, const Slot &s, int fpo, i
     }
   }
   __syncthreads();
-  if (tid == 0) {
-    s.pl_b[fpo] = lb; s.pl_e[fpo] = sh.w_nlink < s.w_link_cap ? sh.w_nlink : s.w_link_cap; s.pl_w[fpo] = 1;
-    sh.c_link_new += sh.w_nlink - lb;
-  }
-  __syncthreads();
+  return lb;
 }
 
 __global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, const Slot *slots,
                                                      const float *__restrict__ loglikes, int P,
-                                                     const int *__restrict__ tid2pdf,
                                                      const UttDesc *__restrict__ utts, int n_utt,
-                                                     int *work_counter, UttResult *results, Pool pool) {
+                                                     int *work_counter, UttResult *results, const Pool *pool_p) {
   __shared__ Shared sh;
+  const Pool &pool = *pool_p;
   const int tid = threadIdx.x;
-  const Slot s = slots[blockIdx.x];
+  const Slot &s = slots[blockIdx.x];   // pointers are fetched by scalar loads when needed (a by-value copy overflows the SGPR file)
   const float INF = INFINITY;
+  int par = 0;
 
   while (true) {
     __syncthreads();
@@ -451,47 +470,62 @@ __global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, cons
     const UttDesc ud = utts[utt];
     const int T = ud.T;
     // epochs start at 1: the high word 0xFFFFFFFF is the cleared (memset 0xFF) state
-    int epoch_base = s.state[0] + 1;
-    int stamp = s.state[1];
+    const int epoch_base = s.state[0] + 1;
+    long long c_tok_exp = 0, c_arc_exp = 0;        // per-thread counters, reduced at the end
+    long long t_last = clk();
+#define PHASE(i) { if (tid == 0) { const long long now_ = clk(); sh.tph[i] += now_ - t_last; t_last = now_; } }
     if (tid == 0) {
+      for (int i = 0; i < 8; i++) sh.tph[i] = 0;
       sh.w_ntok = 0; sh.w_nlink = 0; sh.h_ntok = 0; sh.h_nlink = 0; sh.error = ERR_NONE;
-      sh.c_tok_exp = 0; sh.c_arc_exp = 0; sh.c_tok_new = 0; sh.c_link_new = 0;
-      sh.n_max_bound = 0; sh.n_min_bound = 0;
+      sh.n_max_bound = 0; sh.n_min_bound = 0; sh.n_cand = 0;
+      sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0;
     }
     __syncthreads();
 
     // ---- InitDecoding (:56-73): start token, then the epsilon closure with cutoff = beam
+    int cur_b, cur_e;        // token range of the current frame (window or history indices)
+    bool cur_w = true;
     {
       const unsigned ep = (unsigned)(0xFFFFFFFFu - (unsigned)(epoch_base + 0));
       if (tid == 0) {
-        s.w_state[0] = g.start; s.w_cost[0] = 0.0f; s.w_extra[0] = 0u; s.w_flag[0] = 0;
+        s.w_state[0] = g.start; s.w_cost[0] = 0.0f; s.w_extra[0] = 0u; s.w_tmp[0] = INF_BITS;
         s.key[g.start] = ((unsigned long long)ep << 32) | f2o(0.0f);
-        s.claim[g.start] = ((unsigned long long)ep << 32) | 0u;
         s.tokid[g.start] = 0;
-        sh.w_ntok = 1; sh.c_tok_new = 1;
+        sh.w_ntok = 1;
+        if (g.nieps[g.start] > 0) { s.front[0][0] = g.start; sh.fcnt[0] = 1; }
         s.el_b[0] = 0; s.el_e[0] = 0; s.el_w[0] = 1;
       }
       __threadfence_block();
       __syncthreads();
-      process_nonemitting(g, s, 0, 0, cfg.beam, ep, &stamp, sh);
-      if (tid == 0) { s.tok_b[0] = 0; s.tok_e[0] = sh.w_ntok; s.tok_w[0] = 1; sh.c_tok_new = sh.w_ntok; }
+      const int plb = process_nonemitting(g, s, 0, cfg.beam, ep, 0, sh);
+      cur_b = 0; cur_e = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap;
+      if (tid == 0) {
+        s.tok_b[0] = 0; s.tok_e[0] = cur_e; s.tok_w[0] = 1;
+        s.pl_b[0] = plb; s.pl_e[0] = sh.w_nlink < s.w_link_cap ? sh.w_nlink : s.w_link_cap; s.pl_w[0] = 1;
+        sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0;
+      }
       __syncthreads();
     }
+    long long c_tok_new = cur_e, c_link_new = sh.w_nlink;
 
     int prev_front = -1;      // frontier frame at the previous pruning (-1: none yet)
     int frames_done = 0;
+    PHASE(7)
     for (int frame = 0; frame < T && sh.error == ERR_NONE; frame++) {
       // ---- periodic pruning (:85-87); frame 0 has nothing behind it
       if (frame > 0 && frame % cfg.prune_interval == 0) {
+        __syncthreads();
         prune_backward(s, frame - 1, prev_front < 0 ? 0 : prev_front, cfg.lattice_beam, sh);
+        PHASE(4)
         if (!compact_window(s, prev_front, frame, sh)) break;
         prev_front = frame;
+        cur_b = s.tok_b[frame]; cur_e = s.tok_e[frame]; cur_w = false;
+        PHASE(5)
       }
-      const int tb = s.tok_b[frame], n = s.tok_e[frame] - tb;
-      const bool tw = s.tok_w[frame];
-      const int *tstate = (tw ? s.w_state : s.h_state) + tb;
-      const float *tcost = (tw ? s.w_cost : s.h_cost) + tb;
-      const int enc = tw ? WBIT : 0;
+      const int tb = cur_b, n = cur_e - cur_b;
+      const int *tstate = (cur_w ? s.w_state : s.h_state) + tb;
+      const float *tcost = (cur_w ? s.w_cost : s.h_cost) + tb;
+      const int enc = cur_w ? WBIT : 0;
       const float *llrow = loglikes + (ud.row0 + frame) * (long long)P;
       const unsigned ep = (unsigned)(0xFFFFFFFFu - (unsigned)(epoch_base + frame + 1));
       const unsigned long long EPK = (unsigned long long)ep << 32;
@@ -502,7 +536,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, cons
         const unsigned long long k = ((unsigned long long)f2o(tcost[i]) << 32) | (unsigned)tstate[i];
         bk = k < bk ? k : bk;
       }
-      bk = block_min_u64(bk, sh);
+      bk = block_min_u64(bk, sh, par);
       const float best = n > 0 ? o2f((unsigned)(bk >> 32)) : INF;
       const int best_state = (int)(unsigned)bk;
       float cur_cutoff, adaptive_beam;
@@ -511,10 +545,10 @@ __global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, cons
       } else {
         const float beam_cutoff = best + cfg.beam;
         float mac = INF, mic = INF;
-        int cnt_lt = 0, cnt_le = 0;
-        for (int i = tid; i < n; i += NT) { cnt_lt += tcost[i] < beam_cutoff; cnt_le += tcost[i] <= beam_cutoff; }
-        cnt_lt = block_sum_i(cnt_lt, sh);
-        cnt_le = block_sum_i(cnt_le, sh);
+        unsigned long long cnt = 0;   // (#cost < beam_cutoff) << 32 | (#cost <= beam_cutoff)
+        for (int i = tid; i < n; i += NT) cnt += ((unsigned long long)(tcost[i] < beam_cutoff) << 32) | (unsigned long long)(tcost[i] <= beam_cutoff);
+        cnt = block_sum_u64(cnt, sh, par);
+        const int cnt_lt = (int)(cnt >> 32), cnt_le = (int)(unsigned)cnt;
         // the order statistic is only needed when it decides the comparison
         if (n > cfg.max_active && cnt_lt > cfg.max_active) mac = select_kth(tcost, n, cfg.max_active, sh);
         if (mac < beam_cutoff) {
@@ -538,10 +572,10 @@ __global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, cons
         float nc = INF;
         if (n > 0) {
           for (int a = g.arc_off[best_state]; a < g.arc_off[best_state + 1]; a++) {
-            const vbh_arc arc = g.arcs[a];
-            if (arc.ilabel != 0) {
-              const float ll = cfg.acwt * llrow[tid2pdf[arc.ilabel]];
-              const float nw = ((arc.weight + cost_offset) - ll) + best;
+            const int pdf = g.arc_pdf[a];
+            if (pdf >= 0) {
+              const float ll = cfg.acwt * llrow[pdf];
+              const float nw = ((g.arcs[a].weight + cost_offset) - ll) + best;
               if (nw + adaptive_beam < nc) nc = nw + adaptive_beam;
             }
           }
@@ -549,89 +583,84 @@ __global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, cons
         sh.f0 = nc;
         s.cost_offset[frame] = cost_offset;
       }
-      // ---- pass 1: final next_cutoff = min over every candidate of tot + adaptive_beam
+      PHASE(0)
+      // ---- pass 1 (token-parallel): every candidate arc -> scratch list; min of tot + adaptive_beam
       float mymin = INF;
-      int my_tok = 0, my_arc = 0;
       for (int i = tid; i < n; i += NT) {
         const float c = tcost[i];
         if (!(c <= cur_cutoff)) continue;
-        my_tok++;
+        c_tok_exp++;
         const int st = tstate[i];
         for (int a = g.arc_off[st]; a < g.arc_off[st + 1]; a++) {
+          const int pdf = g.arc_pdf[a];
+          if (pdf < 0) continue;
+          c_arc_exp++;
           const vbh_arc arc = g.arcs[a];
-          if (arc.ilabel == 0) continue;
-          my_arc++;
-          const float ac = cost_offset - cfg.acwt * llrow[tid2pdf[arc.ilabel]];
+          const float ac = cost_offset - cfg.acwt * llrow[pdf];
           const float tot = (c + ac) + arc.weight;
           mymin = fminf(mymin, tot + adaptive_beam);
+          const int q = atomicAdd(&sh.n_cand, 1);
+          if (q < s.cand_cap) { s.c_tot[q] = tot; s.c_ac[q] = ac; s.c_arc[q] = a; s.c_src[q] = i; s.c_dst[q] = arc.nextstate; }
+          else sh.error = ERR_CAND;
         }
       }
-      mymin = block_min_f(mymin, sh);
+      mymin = block_min_f(mymin, sh, par);
       const float next_cutoff = fminf(sh.f0, mymin);
-      my_tok = block_sum_i(my_tok, sh);
-      my_arc = block_sum_i(my_arc, sh);
-      if (tid == 0) { sh.c_tok_exp += my_tok; sh.c_arc_exp += my_arc; }
-      // ---- pass 2: admit tot <= next_cutoff; min-cost per state, one creator per new state
+      const int ncand = sh.n_cand < s.cand_cap ? sh.n_cand : s.cand_cap;
       const int nb = sh.w_ntok;     // first token of frame+1
-      __syncthreads();
-      for (int i = tid; i < n; i += NT) {
-        const float c = tcost[i];
-        if (!(c <= cur_cutoff)) continue;
-        const int st = tstate[i];
-        for (int a = g.arc_off[st]; a < g.arc_off[st + 1]; a++) {
-          const vbh_arc arc = g.arcs[a];
-          if (arc.ilabel == 0) continue;
-          const float ac = cost_offset - cfg.acwt * llrow[tid2pdf[arc.ilabel]];
-          const float tot = (c + ac) + arc.weight;
-          if (tot > next_cutoff) continue;
-          const int ds = arc.nextstate;
-          atomicMin(&s.key[ds], EPK | f2o(tot));
-          const unsigned long long cl = ld_u64(&s.claim[ds]);
-          if ((unsigned)(cl >> 32) != ep && atomicCAS(&s.claim[ds], cl, EPK | 0u) == cl) {
-            const int nid = atomicAdd(&sh.w_ntok, 1);
-            if (nid < s.w_tok_cap) {
-              s.w_state[nid] = ds; s.w_extra[nid] = 0u; s.w_flag[nid] = 0;
-              st_i32(&s.tokid[ds], nid);
-            } else sh.error = ERR_W_TOK;
-          }
+      PHASE(1)
+      // ---- pass 2 (candidate-parallel): admit tot <= next_cutoff; min-cost per state via one
+      //      64-bit atomicMin; the thread that meets a stale epoch creates the token
+      for (int q = tid; q < ncand; q += NT) {
+        const float tot = s.c_tot[q];
+        if (tot > next_cutoff) continue;
+        const int ds = s.c_dst[q];
+        const unsigned long long old = atomicMin(&s.key[ds], EPK | f2o(tot));
+        if ((unsigned)(old >> 32) != ep) {
+          const int nid = atomicAdd(&sh.w_ntok, 1);
+          if (nid < s.w_tok_cap) {
+            s.w_state[nid] = ds; s.w_extra[nid] = 0u; s.w_tmp[nid] = INF_BITS;
+            st_i32(&s.tokid[ds], nid);
+            if (g.nieps[ds] > 0) {
+              const int f = atomicAdd(&sh.fcnt[0], 1);
+              if (f < s.front_cap) s.front[0][f] = ds; else sh.error = ERR_FRONT;
+            }
+          } else sh.error = ERR_W_TOK;
         }
       }
       __syncthreads();
-      // ---- pass 3: forward links (:765-767)
+      // ---- pass 3 (candidate-parallel): forward links (:765-767)
       const int lb = sh.w_nlink;
-      __syncthreads();
-      for (int i = tid; i < n; i += NT) {
-        const float c = tcost[i];
-        if (!(c <= cur_cutoff)) continue;
-        const int st = tstate[i];
-        for (int a = g.arc_off[st]; a < g.arc_off[st + 1]; a++) {
-          const vbh_arc arc = g.arcs[a];
-          if (arc.ilabel == 0) continue;
-          const float ac = cost_offset - cfg.acwt * llrow[tid2pdf[arc.ilabel]];
-          const float tot = (c + ac) + arc.weight;
+      if (sh.error == ERR_NONE) {
+        for (int q = tid; q < ncand; q += NT) {
+          const float tot = s.c_tot[q];
           if (tot > next_cutoff) continue;
+          const vbh_arc arc = g.arcs[s.c_arc[q]];
           const int l = atomicAdd(&sh.w_nlink, 1);
           if (l < s.w_link_cap) {
-            s.wl_src[l] = (tb + i) | enc; s.wl_dst[l] = ld_i32(&s.tokid[arc.nextstate]) | WBIT;
-            s.wl_il[l] = arc.ilabel; s.wl_ol[l] = arc.olabel; s.wl_gr[l] = arc.weight; s.wl_ac[l] = ac;
+            s.wl_src[l] = (tb + s.c_src[q]) | enc; s.wl_dst[l] = ld_i32(&s.tokid[arc.nextstate]) | WBIT;
+            s.wl_il[l] = arc.ilabel; s.wl_ol[l] = arc.olabel; s.wl_gr[l] = arc.weight; s.wl_ac[l] = s.c_ac[q];
           } else sh.error = ERR_W_LINK;
         }
       }
       __syncthreads();
-      if (tid == 0) {
-        s.el_b[frame] = lb; s.el_e[frame] = sh.w_nlink < s.w_link_cap ? sh.w_nlink : s.w_link_cap; s.el_w[frame] = 1;
-        sh.c_link_new += sh.w_nlink - lb;
-      }
-      __syncthreads();
+      const int le_emit = sh.w_nlink < s.w_link_cap ? sh.w_nlink : s.w_link_cap;
       if (sh.error != ERR_NONE) break;
+      PHASE(2)
       // ---- ProcessNonemitting(next_cutoff)
-      process_nonemitting(g, s, frame + 1, nb, next_cutoff, ep, &stamp, sh);
+      const int plb = process_nonemitting(g, s, nb, next_cutoff, ep, 0, sh);
+      cur_b = nb; cur_e = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap; cur_w = true;
+      const int pl_end = sh.w_nlink < s.w_link_cap ? sh.w_nlink : s.w_link_cap;
       if (tid == 0) {
-        s.tok_b[frame + 1] = nb; s.tok_e[frame + 1] = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap; s.tok_w[frame + 1] = 1;
-        sh.c_tok_new += sh.w_ntok - nb;
+        s.el_b[frame] = lb; s.el_e[frame] = le_emit; s.el_w[frame] = 1;
+        s.tok_b[frame + 1] = cur_b; s.tok_e[frame + 1] = cur_e; s.tok_w[frame + 1] = 1;
+        s.pl_b[frame + 1] = plb; s.pl_e[frame + 1] = pl_end; s.pl_w[frame + 1] = 1;
+        sh.n_cand = 0; sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0;
       }
-      __syncthreads();
+      c_tok_new += cur_e - cur_b; c_link_new += pl_end - lb;
       frames_done = frame + 1;
+      __syncthreads();
+      PHASE(3)
     }
     __syncthreads();
     const bool search_ok = sh.error == ERR_NONE && frames_done == T;
@@ -641,93 +670,95 @@ __global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, cons
     int final_empty = 1;
     if (search_ok) {
       const int F = T;
+      if (tid == 0) {   // ranges of the last frame as the pruning code reads them
+        s.el_b[F] = 0; s.el_e[F] = 0; s.el_w[F] = 0;
+      }
+      __threadfence_block();
+      __syncthreads();
       const int tb = s.tok_b[F], te = s.tok_e[F];
       const bool tw = s.tok_w[F];
       const int *tstate = tw ? s.w_state : s.h_state;
       const float *tcost = tw ? s.w_cost : s.h_cost;
       unsigned *extra = tw ? s.w_extra : s.h_extra, *tmp = tw ? s.w_tmp : s.h_tmp;
       // ComputeFinalCosts (:532-572)
-      float bc = INF, bwf = INF; int anyfinal = 0;
+      float bc = INF, bwf = INF; unsigned long long anyfinal = 0;
       for (int t = tb + tid; t < te; t += NT) {
         const float fc = g.final_cost[tstate[t]], c = tcost[t];
         bc = fminf(bc, c); bwf = fminf(bwf, c + fc);
-        anyfinal |= fc != INF;
+        anyfinal += fc != INF;
       }
-      bc = block_min_f(bc, sh); bwf = block_min_f(bwf, sh);
-      anyfinal = block_sum_i(anyfinal, sh);
+      bc = block_min_f(bc, sh, par); bwf = block_min_f(bwf, sh, par);
+      anyfinal = block_sum_u64(anyfinal, sh, par);
       final_empty = anyfinal == 0;
       final_relative = (bc == INF && bwf == INF) ? INF : bwf - bc;
       final_best = (bwf != INF) ? bwf : bc;
       // PruneForwardLinksFinal (:376-458), to the fixed point
       const int pb = s.pl_b[F], pe = s.pl_e[F];
       const bool pw = s.pl_w[F];
-      int *lsrc = pw ? s.wl_src : s.hl_src;
-      const int *ldst = pw ? s.wl_dst : s.hl_dst;
-      const float *lgr = pw ? s.wl_gr : s.hl_gr, *lac = pw ? s.wl_ac : s.hl_ac;
       for (int iter = 0; iter < MAX_EPS_ITERS; iter++) {
         for (int t = tb + tid; t < te; t += NT) {
           const float fc = final_empty ? 0.0f : g.final_cost[tstate[t]];
-          const float x = tcost[t] + fc - final_best;
-          tmp[t] = x == INF ? INF_BITS : __float_as_uint(x < 0.0f ? x : x);
+          const float x = tcost[t] + fc - final_best;    // >= 0 by construction
+          tmp[t] = __float_as_uint(x);
         }
         if (tid == 0) sh.changed = 0;
         __syncthreads();
-        for (int l = pb + tid; l < pe; l += NT) {
-          const int src = lsrc[l];
-          if (src < 0) continue;
-          const int dst = ldst[l];
-          float le = __uint_as_float(tok_extra(s, dst)) + (((tcost[src & ~WBIT] + lac[l]) + lgr[l]) - tok_cost(s, dst));
-          if (le > cfg.lattice_beam) { lsrc[l] = -1; continue; }
-          if (le < 0.0f) le = 0.0f;
-          // tmp holds a float that may be slightly negative only in theory; compare as floats
-          unsigned *p = &tmp[src & ~WBIT];
-          unsigned old = *p;
-          while (le < __uint_as_float(old)) {
-            const unsigned prev = atomicCAS(p, old, __float_as_uint(le));
-            if (prev == old) break;
-            old = prev;
-          }
-        }
+        eval_links(s, pw, pb, pe, tcost, tmp, cfg.lattice_beam);
         __syncthreads();
+        int ch = 0;
         for (int t = tb + tid; t < te; t += NT) {
           float v = __uint_as_float(tmp[t]);
+          tmp[t] = INF_BITS;
           if (v > cfg.lattice_beam) v = INF;
           const unsigned vb = __float_as_uint(v);
-          if (vb != extra[t]) { extra[t] = vb; sh.changed = 1; }
+          if (vb != extra[t]) { extra[t] = vb; ch = 1; }
         }
+        if (ch) sh.changed = 1;
         __syncthreads();
-        const bool ch = sh.changed != 0;
+        const bool any = sh.changed != 0;
         __syncthreads();
-        if (!ch || pe == pb) break;
+        if (!any || pe == pb) break;
       }
       prune_backward(s, F - 1, prev_front < 0 ? 0 : prev_front, cfg.lattice_beam, sh);
+      PHASE(4)
       compact_window(s, prev_front, F, sh);
+      PHASE(5)
     }
     __syncthreads();
 
     // ---- write the surviving lattice to the dense pool (content of GetRawLattice :110-192)
-    UttResult r;
-    r.ok = 0; r.error = sh.error; r.reached_final = 0; r.num_frames = frames_done;
-    r.final_relative_cost = final_relative; r.final_best_cost = final_best; r.final_costs_empty = final_empty;
-    r.n_tok = 0; r.n_link = 0; r.tok_off = 0; r.link_off = 0; r.cost_off = 0;
+    int r_ok = 0, r_error = sh.error, r_reached_final = 0, r_n_tok = 0, r_n_link = 0;
+    long long r_tok_off = 0, r_link_off = 0, r_cost_off = 0;
     if (search_ok && sh.error == ERR_NONE) {
       const int F = T;
-      // count alive tokens / links, reserve pool space
-      int na = 0, nl = 0;
+      unsigned long long na = 0, nl = 0;
       for (int t = tid; t < sh.h_ntok; t += NT) na += s.h_extra[t] != INF_BITS;
-      na = block_sum_i(na, sh);
+      na = block_sum_u64(na, sh, par);
+      for (int l = tid; l < sh.h_nlink; l += NT) {
+        const int src = s.hl_src[l];
+        nl += src >= 0 && s.h_extra[src] != INF_BITS && s.h_extra[s.hl_dst[l]] != INF_BITS;
+      }
+      nl = block_sum_u64(nl, sh, par);
       if (tid == 0) {
-        sh.u0 = atomicAdd(&pool.counters[0], (unsigned long long)na);
+        sh.u0 = atomicAdd(&pool.counters[0], na);
         sh.flag = 0;
       }
       __syncthreads();
       const long long toff = (long long)sh.u0;
-      const bool tok_fits = toff + na <= pool.tok_cap;
-      // dense index per alive history token, in h_tmp
-      if (tok_fits) {
+      __syncthreads();
+      if (tid == 0) sh.u0 = atomicAdd(&pool.counters[1], nl);
+      __syncthreads();
+      const long long loff = (long long)sh.u0;
+      __syncthreads();
+      if (tid == 0) sh.u0 = atomicAdd(&pool.counters[2], (unsigned long long)T);
+      __syncthreads();
+      const long long coff_off = (long long)sh.u0;
+      const bool fits = toff + (long long)na <= pool.tok_cap && loff + (long long)nl <= pool.link_cap && coff_off + T <= pool.cost_cap;
+      if (fits) {
+        // dense index per alive history token, kept in h_tmp
         for (int f = 0; f <= F; f++) {
           for (int t = s.tok_b[f] + tid; t < s.tok_e[f]; t += NT) {
-            if (s.h_extra[t] == INF_BITS) { s.h_tmp[t] = 0xFFFFFFFFu; continue; }
+            if (s.h_extra[t] == INF_BITS) continue;
             const int d = atomicAdd(&sh.flag, 1);
             s.h_tmp[t] = (unsigned)d;
             const long long o = toff + d;
@@ -738,18 +769,9 @@ __global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, cons
             pool.tok_final[o] = fin;
           }
         }
-      }
-      __syncthreads();
-      for (int l = tid; l < sh.h_nlink; l += NT) {
-        const int src = s.hl_src[l];
-        nl += src >= 0 && s.h_extra[src] != INF_BITS && s.h_extra[s.hl_dst[l]] != INF_BITS;
-      }
-      nl = block_sum_i(nl, sh);
-      if (tid == 0) { sh.u0 = atomicAdd(&pool.counters[1], (unsigned long long)nl); sh.flag = 0; }
-      __syncthreads();
-      const long long loff = (long long)sh.u0;
-      const bool link_fits = loff + nl <= pool.link_cap;
-      if (tok_fits && link_fits) {
+        __syncthreads();
+        if (tid == 0) sh.flag = 0;
+        __syncthreads();
         for (int f = 0; f <= F; f++) {
           for (int pass = 0; pass < 2; pass++) {
             const int lb = pass ? s.pl_b[f] : s.el_b[f], le_ = pass ? s.pl_e[f] : s.el_e[f];
@@ -767,34 +789,46 @@ __global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, cons
             }
           }
         }
-      }
-      __syncthreads();
-      if (tid == 0) sh.u0 = atomicAdd(&pool.counters[2], (unsigned long long)T);
-      __syncthreads();
-      const long long coff_off = (long long)sh.u0;
-      if (coff_off + T <= pool.cost_cap)
         for (int f = tid; f < T; f += NT) pool.cost_offsets[coff_off + f] = s.cost_offset[f];
-      if (!tok_fits || !link_fits || coff_off + T > pool.cost_cap) r.error = ERR_POOL;
-      else {
-        r.n_tok = na; r.n_link = nl; r.tok_off = toff; r.link_off = loff; r.cost_off = coff_off;
-        r.reached_final = final_relative != INF;
+        r_n_tok = (int)na; r_n_link = (int)nl; r_tok_off = toff; r_link_off = loff; r_cost_off = coff_off;
+        r_reached_final = final_relative != INF;
         // Decode() returns whether the last frame still has tokens (:93-95)
-        int alive_last = 0;
+        unsigned long long alive_last = 0;
         for (int t = s.tok_b[F] + tid; t < s.tok_e[F]; t += NT) alive_last += s.h_extra[t] != INF_BITS;
-        alive_last = block_sum_i(alive_last, sh);
-        r.ok = alive_last > 0;
+        alive_last = block_sum_u64(alive_last, sh, par);
+        r_ok = alive_last > 0;
+        // restore the +inf invariant of h_tmp for the next utterance in this slot
+        __syncthreads();
+        for (int t = tid; t < sh.h_ntok; t += NT) s.h_tmp[t] = INF_BITS;
+      } else r_error = ERR_POOL;
+    }
+    PHASE(6)
+    {
+      const unsigned long long te_ = block_sum_u64((unsigned long long)c_tok_exp, sh, par);
+      const unsigned long long ae_ = block_sum_u64((unsigned long long)c_arc_exp, sh, par);
+      if (tid == 0) {
+        UttResult *r = &results[utt];
+        r->ok = r_ok; r->error = r_error; r->reached_final = r_reached_final; r->num_frames = frames_done;
+        r->final_relative_cost = final_relative; r->final_best_cost = final_best; r->final_costs_empty = final_empty;
+        r->n_tok = r_n_tok; r->n_link = r_n_link; r->tok_off = r_tok_off; r->link_off = r_link_off; r->cost_off = r_cost_off;
+        r->n_tokens_expanded = (long long)te_; r->n_arcs_expanded = (long long)ae_;
+        r->n_tokens_created = c_tok_new; r->n_links_created = c_link_new;
+        r->n_max_bound = sh.n_max_bound; r->n_min_bound = sh.n_min_bound;
+        for (int i = 0; i < 8; i++) r->t_phase[i] = sh.tph[i];
+        s.state[0] = epoch_base + T + 2;   // next utterance in this slot: disjoint epochs
       }
     }
     __syncthreads();
-    if (tid == 0) {
-      r.n_tokens_expanded = sh.c_tok_exp; r.n_arcs_expanded = sh.c_arc_exp;
-      r.n_tokens_created = sh.c_tok_new; r.n_links_created = sh.c_link_new;
-      r.n_max_bound = sh.n_max_bound; r.n_min_bound = sh.n_min_bound;
-      results[utt] = r;
-      s.state[0] = epoch_base + T + 2;   // next utterance in this slot: disjoint epochs
-      s.state[1] = stamp;
-    }
-    __syncthreads();
+  }
+#undef PHASE
+}
+
+// arc_pdf[a] = tid2pdf[ilabel] (-1 for input-epsilon arcs): one dependent load less per arc
+__global__ void fill_arc_pdf_kernel(const vbh_arc *__restrict__ arcs, long long A, const int *__restrict__ tid2pdf,
+                                    int *__restrict__ arc_pdf) {
+  for (long long a = blockIdx.x * (long long)blockDim.x + threadIdx.x; a < A; a += (long long)gridDim.x * blockDim.x) {
+    const int il = arcs[a].ilabel;
+    arc_pdf[a] = il == 0 ? -1 : tid2pdf[il];
   }
 }
 
@@ -804,7 +838,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, cons
 struct vbh_graph {
   vbh_ctx *ctx;
   int S, start; long long A; int max_ilabel;
-  DevBuf<float> final_cost; DevBuf<int> arc_off, nieps; DevBuf<vbh_arc> arcs;
+  DevBuf<float> final_cost; DevBuf<int> arc_off, nieps, arc_pdf; DevBuf<vbh_arc> arcs;
   std::vector<float> h_final;
 };
 
@@ -866,7 +900,8 @@ int vbh_graph_create(vbh_ctx *ctx, int32_t num_states, int32_t start, const floa
   g->h_final.assign(h_final, h_final + num_states);
   hipStream_t st = ctx->stream;
   if (g->final_cost.upload(h_final, num_states, st) || g->arc_off.upload(off.data(), off.size(), st) ||
-      g->nieps.upload(nieps.data(), nieps.size(), st) || g->arcs.upload(h_arcs, (size_t)A, st)) { delete g; return -1; }
+      g->nieps.upload(nieps.data(), nieps.size(), st) || g->arcs.upload(h_arcs, (size_t)A, st) ||
+      g->arc_pdf.alloc((size_t)(A > 0 ? A : 1))) { delete g; return -1; }
   VBH_HIP(hipStreamSynchronize(st));
   *out = g;
   return 0;
@@ -886,6 +921,7 @@ int vbh_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_decode_cf
             "vbh_decoder_create: invalid config (LatticeFasterDecoderConfig::Check)");
   VBH_CHECK(cfg->min_active >= 0, "vbh_decoder_create: min_active < 0");
   VBH_CHECK(max_batch >= 1 && max_frames >= 0, "vbh_decoder_create: bad batch/frames");
+  VBH_CHECK(cfg->prune_interval <= MAX_WIN_FRAMES - 2, "vbh_decoder_create: prune_interval %d > %d", cfg->prune_interval, MAX_WIN_FRAMES - 2);
   if (vbh_use_device(ctx)) return -1;
   vbh_decoder *d = new vbh_decoder();
   d->ctx = ctx; d->graph = graph; d->cfg = *cfg; d->max_frames = max_frames;
@@ -904,7 +940,8 @@ int vbh_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_decode_cf
   const long long n_int = max_frames / cfg->prune_interval + 2;
   p.h_tok_cap = (int)std::min<long long>(per_frame_tok * n_int + 1024LL * (max_frames + 1) + per_frame_tok, 1LL << 29);
   p.h_link_cap = (int)std::min<long long>(per_frame_tok * n_int + 2048LL * (max_frames + 1) + per_frame_link, 1LL << 29);
-  p.front_cap = (int)per_frame_tok;
+  p.front_cap = (int)(2 * per_frame_tok);
+  p.cand_cap = (int)std::min<long long>(std::max<long long>(graph->A, 1), 8 * per_frame_tok);
   d->proto = p;
   d->h_slots.assign(d->n_slots, p);
   const size_t F = (size_t)max_frames + 2;
@@ -919,9 +956,9 @@ int vbh_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_decode_cf
     }                                                                                                \
     for (size_t i = 0; i < ns; i++) d->h_slots[i].field = base + i * (size_t)(count);                \
   }
-  A_(key, unsigned long long, S, 0xFF) A_(claim, unsigned long long, S, 0xFF) A_(tokid, int, S, 0)
+  A_(key, unsigned long long, S, 0xFF) A_(tokid, int, S, 0)
   A_(w_state, int, p.w_tok_cap, -2) A_(w_cost, float, p.w_tok_cap, -2) A_(w_extra, unsigned, p.w_tok_cap, -2)
-  A_(w_tmp, unsigned, p.w_tok_cap, -2) A_(w_flag, int, p.w_tok_cap, 0) A_(w_remap, int, p.w_tok_cap, -2)
+  A_(w_tmp, unsigned, p.w_tok_cap, -2) A_(w_remap, int, p.w_tok_cap, -2)
   A_(wl_src, int, p.w_link_cap, -2) A_(wl_dst, int, p.w_link_cap, -2) A_(wl_il, int, p.w_link_cap, -2)
   A_(wl_ol, int, p.w_link_cap, -2) A_(wl_gr, float, p.w_link_cap, -2) A_(wl_ac, float, p.w_link_cap, -2)
   A_(h_state, int, p.h_tok_cap, -2) A_(h_cost, float, p.h_tok_cap, -2) A_(h_extra, unsigned, p.h_tok_cap, -2)
@@ -930,7 +967,10 @@ int vbh_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_decode_cf
   A_(hl_ol, int, p.h_link_cap, -2) A_(hl_gr, float, p.h_link_cap, -2) A_(hl_ac, float, p.h_link_cap, -2)
   A_(tok_b, int, F, 0) A_(tok_e, int, F, 0) A_(el_b, int, F, 0) A_(el_e, int, F, 0) A_(pl_b, int, F, 0) A_(pl_e, int, F, 0)
   A_(tok_w, unsigned char, F, 0) A_(el_w, unsigned char, F, 0) A_(pl_w, unsigned char, F, 0)
-  A_(cost_offset, float, F, 0) A_(front_a, int, p.front_cap, -2) A_(front_b, int, p.front_cap, -2)
+  A_(cost_offset, float, F, 0)
+  A_(c_tot, float, p.cand_cap, -2) A_(c_ac, float, p.cand_cap, -2) A_(c_arc, int, p.cand_cap, -2)
+  A_(c_src, int, p.cand_cap, -2) A_(c_dst, int, p.cand_cap, -2)
+  A_(front[0], int, p.front_cap, -2) A_(front[1], int, p.front_cap, -2) A_(front[2], int, p.front_cap, -2)
   A_(state, int, 4, 0)
 #undef A_
   if (d->d_slots.upload(d->h_slots.data(), d->h_slots.size(), ctx->stream)) { vbh_decoder_destroy(d); return -1; }
@@ -1066,6 +1106,7 @@ static const char *err_name(int e) {
     case ERR_FRONT: return "epsilon work-list capacity exceeded";
     case ERR_EPS_LOOP: return "epsilon closure did not converge (epsilon cycle in the graph?)";
     case ERR_POOL: return "output pool capacity exceeded";
+    case ERR_CAND: return "candidate list capacity exceeded";
     default: return "unknown";
   }
 }
@@ -1114,11 +1155,17 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
   pool.tok_frame = p_tf.p; pool.tok_state = p_ts.p; pool.tok_cost = p_tc.p; pool.tok_extra = p_te.p; pool.tok_final = p_tfin.p;
   pool.link_src = p_ls.p; pool.link_dst = p_ld.p; pool.link_il = p_li.p; pool.link_ol = p_lo.p; pool.link_gr = p_lg.p; pool.link_ac = p_la.p;
   pool.cost_offsets = p_co.p; pool.counters = p_cnt.p;
-  DevGraph dg{g->S, g->start, g->final_cost.p, g->arc_off.p, g->nieps.p, g->arcs.p};
+  if (g->A > 0) {
+    hipLaunchKernelGGL(fill_arc_pdf_kernel, dim3(1024), dim3(256), 0, st, g->arcs.p, g->A, d_t2p.p, g->arc_pdf.p);
+    VBH_HIP(hipGetLastError());
+  }
+  DevBuf<Pool> d_pool;
+  if (d_pool.upload(&pool, 1, st)) return -1;
+  DevGraph dg{g->S, g->start, g->final_cost.p, g->arc_off.p, g->nieps.p, g->arcs.p, g->arc_pdf.p};
   DecCfg dc{d->cfg.beam, d->cfg.lattice_beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active, d->cfg.prune_interval};
   const int grid = std::min(d->n_slots, n_utt);
-  hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(NT), 0, st, dg, dc, d->d_slots.p, d_loglikes, (int)num_pdfs, d_t2p.p,
-                     d_utts.p, n_utt, d_counter.p, d_res.p, pool);
+  hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(NT), 0, st, dg, dc, d->d_slots.p, d_loglikes, (int)num_pdfs,
+                     d_utts.p, n_utt, d_counter.p, d_res.p, d_pool.p);
   VBH_HIP(hipGetLastError());
   d->h_res.resize(n_utt);
   VBH_HIP(hipMemcpyAsync(d->h_res.data(), d_res.p, sizeof(UttResult) * n_utt, hipMemcpyDeviceToHost, st));
@@ -1140,6 +1187,13 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
   hp.link_src = ls.data(); hp.link_dst = ld.data(); hp.link_il = li.data(); hp.link_ol = lo.data(); hp.link_gr = lg.data(); hp.link_ac = la.data();
   d->results.resize(n_utt);
   for (int u = 0; u < n_utt; u++) finish_lattice(g, d->h_res[u], hp, &d->results[u]);
+  return 0;
+}
+
+int vbh_decoder_phase_cycles(vbh_decoder *d, int32_t utt, int64_t *out8) {
+  VBH_CHECK(d && out8, "vbh_decoder_phase_cycles: NULL argument");
+  VBH_CHECK(utt >= 0 && utt < (int)d->h_res.size(), "vbh_decoder_phase_cycles: utterance %d out of range", utt);
+  for (int i = 0; i < 8; i++) out8[i] = d->h_res[utt].t_phase[i];
   return 0;
 }
 
