@@ -35,9 +35,9 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="utterances per step per GPU")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="utterances per step per GPU")
     ap.add_argument("--seconds", type=float, default=30.0, help="utterance length")
     ap.add_argument("--pdfs", type=int, default=2500)
     ap.add_argument("--gauss", type=int, default=15000)
@@ -171,9 +171,9 @@ def main():
                       r["n_tokens_created"] / nf, r["n_links_created"] / nf, r["n_frames_maxactive_bound"],
                       r["n_frames_minactive_bound"], r["num_toks"], r["num_links"], len(r["words"]), r["best_graph"], r["best_acoustic"]))
             ph = dec.phase_cycles(u)
-            tot = max(sum(ph), 1)
+            tot = max(sum(ph[:7]), 1)
             print("   phase share: " + ", ".join("%s %.1f%%" % (nm, 100.0 * c / tot) for nm, c in zip(
-                ["cutoff", "pass1", "admit+links", "eps", "prune", "compact", "output", "other"], ph)) + "  cycles/frame=%.0f" % (tot / nf))
+                ["cutoff", "pass1", "admit+links", "eps", "prune", "compact", "output"], ph[:7])) + "  cycles/frame=%.0f prune-visited-frames=%d" % (tot / nf, ph[7]))
         return
 
     def step(timed):

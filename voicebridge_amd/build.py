@@ -34,7 +34,11 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
-            extra = ["-ffp-contract=off"] if s == "vbh_decode.hip" else []   # exact float32 cost expressions
+            extra = []
+            if s == "vbh_decode.hip":
+                extra = ["-ffp-contract=off"]   # exact float32 cost expressions
+                if os.environ.get("VBH_DECODE_NT"):
+                    extra.append("-DVBH_DECODE_NT=" + os.environ["VBH_DECODE_NT"])
             cmd = [hipcc] + FLAGS + extra + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)

@@ -46,7 +46,11 @@
 
 namespace {
 
-constexpr int NT = 1024;
+#ifndef VBH_DECODE_NT
+#define VBH_DECODE_NT 1024   // measured on MI355X (profiles/README.md): 256/512/1024 threads per utterance all
+                             // saturate at the same ~0.65 M frames/s once >= 256 utterances are in flight
+#endif
+constexpr int NT = VBH_DECODE_NT;    // threads per workgroup = per utterance; 1024/NT workgroups share a CU
 constexpr int NW = NT / 64;
 constexpr int WBIT = 0x40000000;            // token id lives in the raw window
 constexpr unsigned INF_BITS = 0x7F800000u;  // +inf as float bits
@@ -75,7 +79,7 @@ struct Slot {
   int *w_state; float *w_cost; unsigned *w_extra, *w_tmp; int *w_remap;
   int *wl_src, *wl_dst, *wl_il, *wl_ol; float *wl_gr, *wl_ac;
   // history
-  int *h_state; float *h_cost; unsigned *h_extra, *h_tmp;
+  int *h_state; float *h_cost; unsigned *h_extra, *h_tmp; int *h_remap;
   int *hl_src, *hl_dst, *hl_il, *hl_ol; float *hl_gr, *hl_ac;
   // per frame_plus_one ranges: tokens, emitting links from the frame, epsilon links within it
   int *tok_b, *tok_e, *el_b, *el_e, *pl_b, *pl_e;
@@ -131,6 +135,26 @@ __device__ __forceinline__ int ld_i32(const int *p) {
 __device__ __forceinline__ void st_i32(int *p, int v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// make an LDS-loaded (per-lane) pointer wave-uniform again so that it lives in SGPRs
+template <class T>
+__device__ __forceinline__ T *uptr(T *p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+}
+// One LDS atomic per wave instead of one per lane: the active lanes that want a slot elect a
+// leader, which reserves popcount slots; every lane gets base + its rank.  (Same-address LDS
+// atomics serialise per lane; with thousands of allocations per frame they dominated.)
+__device__ __forceinline__ int wave_alloc(int *counter, bool want) {
+  const unsigned long long m = __ballot(want);
+  if (m == 0) return -1;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)m) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, __popcll(m));
+  base = __shfl(base, leader, 64);
+  return want ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
 __device__ __forceinline__ long long clk() { return (long long)__builtin_amdgcn_s_memtime(); }
 
 struct Shared {
@@ -139,12 +163,16 @@ struct Shared {
   int w_ntok, w_nlink, h_ntok, h_nlink;
   int n_cand;
   int fcnt[3];                     // epsilon work-list fill counts, rotated with Slot::front
-  int changed, error, flag;
+  int changed2[2];                 // "something changed" flags, alternated per use (see prune_frame)
+  int error, flag;
   unsigned sel_prefix, sel_mask; int sel_k;
   float f0;
   unsigned long long u0;
-  int n_max_bound, n_min_bound;
+  int n_max_bound, n_min_bound, n_visited;
   int utt;
+  // the block appended to H by the previous compaction (frames (tail_f0, tail_f1]); it is
+  // re-compacted in place at the next one, once those frames have been pruned with look-ahead
+  int tail_tok_b, tail_link_b, tail_f0, tail_f1;
   long long tph[8];                // phase cycle counters (thread 0)
   int fr_cnt[3 * MAX_WIN_FRAMES];  // compaction: survivors per frame (tokens, emitting links, epsilon links)
   int fr_base[3 * MAX_WIN_FRAMES];
@@ -217,16 +245,21 @@ __device__ __forceinline__ unsigned tok_extra(const Slot &s, int id) { return (i
 // atomicMin the rest into tmp[src] (lattice-faster-decoder.cc:331-356)
 __device__ __forceinline__ void eval_links(const Slot &s, bool lw, int lb, int le_, const float *tcost, unsigned *tmp,
                                            float lattice_beam) {
-  int *lsrc = lw ? s.wl_src : s.hl_src;
-  const int *ldst = lw ? s.wl_dst : s.hl_dst;
-  const float *lgr = lw ? s.wl_gr : s.hl_gr, *lac = lw ? s.wl_ac : s.hl_ac;
+  if (le_ <= lb) return;
+  int *lsrc = uptr(lw ? s.wl_src : s.hl_src);
+  const int *ldst = uptr(lw ? s.wl_dst : s.hl_dst);
+  const float *lgr = uptr(lw ? s.wl_gr : s.hl_gr), *lac = uptr(lw ? s.wl_ac : s.hl_ac);
+  const float *wc = uptr(s.w_cost), *hc = uptr(s.h_cost);
+  const unsigned *we = uptr(s.w_extra), *he = uptr(s.h_extra);
+  tcost = uptr(tcost); tmp = uptr(tmp);
   for (int l = lb + threadIdx.x; l < le_; l += NT) {
     const int src = lsrc[l];
     if (src < 0) continue;   // already excised
     const int dst = ldst[l];
-    const float nx = __uint_as_float(tok_extra(s, dst));
+    const float nx = __uint_as_float((dst & WBIT) ? we[dst ^ WBIT] : he[dst]);
+    const float dc = (dst & WBIT) ? wc[dst ^ WBIT] : hc[dst];
     // next_tok->extra_cost + ((tok->tot_cost + link->acoustic_cost + link->graph_cost) - next_tok->tot_cost)
-    float le = nx + (((tcost[src & ~WBIT] + lac[l]) + lgr[l]) - tok_cost(s, dst));
+    float le = nx + (((tcost[src & ~WBIT] + lac[l]) + lgr[l]) - dc);
     if (le > lattice_beam) { lsrc[l] = -1; continue; }
     if (le < 0.0f) le = 0.0f;
     atomicMin(&tmp[src & ~WBIT], __float_as_uint(le));
@@ -236,7 +269,7 @@ __device__ __forceinline__ void eval_links(const Slot &s, bool lw, int lb, int l
 // PruneForwardLinks for one frame (lattice-faster-decoder.cc:300-371), evaluated to its fixed
 // point.  tmp[] of the frame's tokens must hold +inf on entry and holds +inf again on exit.
 // Returns (uniformly) whether any token's extra_cost changed.
-__device__ bool prune_frame(const Slot &s, int f, float lattice_beam, Shared &sh) {
+__device__ bool prune_frame(const Slot &s, int f, float lattice_beam, float delta, Shared &sh, int &pp) {
   const int tid = threadIdx.x;
   const int tb = s.tok_b[f], te = s.tok_e[f];
   const bool tw = s.tok_w[f];
@@ -246,33 +279,166 @@ __device__ bool prune_frame(const Slot &s, int f, float lattice_beam, Shared &sh
   const bool ew = s.el_w[f], pw = s.pl_w[f];
   bool frame_changed = false;
   for (int iter = 0; iter < MAX_EPS_ITERS; iter++) {
-    if (tid == 0) sh.changed = 0;
     eval_links(s, ew, eb, ee, tcost, tmp, lattice_beam);
     eval_links(s, pw, pb, pe, tcost, tmp, lattice_beam);
     __syncthreads();
+    // flag[pp] is written below and read after the next barrier; flag[pp^1] (read by every
+    // thread before it arrived at the barrier above) is cleared for the following use
+    if (tid == 0) sh.changed2[pp ^ 1] = 0;
     int ch = 0;
-    for (int t = tb + tid; t < te; t += NT) {
-      const unsigned v = tmp[t];
-      tmp[t] = INF_BITS;
-      if (v != extra[t]) { extra[t] = v; ch = 1; }
+    {
+      unsigned *tmp_u = uptr(tmp), *extra_u = uptr(extra);
+      for (int t = tb + tid; t < te; t += NT) {
+        const unsigned v = tmp_u[t], o = extra_u[t];
+        tmp_u[t] = INF_BITS;
+        if (v != o) {
+          extra_u[t] = v;
+          // "changed" as the reference counts it (:358): |new - old| > delta; inf vs inf is no change
+          if (fabsf(__uint_as_float(v) - __uint_as_float(o)) > delta) ch = 1;
+        }
+      }
     }
-    if (ch) sh.changed = 1;
+    if (ch) sh.changed2[pp] = 1;
     __syncthreads();
-    const bool any = sh.changed != 0;
+    const bool any = sh.changed2[pp] != 0;
+    pp ^= 1;
     frame_changed |= any;
     if (!any || pe == pb) break;
-    __syncthreads();   // sh.changed is reset at the top of the next iteration
   }
   return frame_changed;
 }
 
-// backward pass from frame `from` down; frames >= first_unpruned are always processed,
-// older ones until a frame's extra_costs do not move (then nothing below can move)
-__device__ void prune_backward(const Slot &s, int from, int first_unpruned, float lattice_beam, Shared &sh) {
-  for (int f = from; f >= 0; f--) {
-    const bool ch = prune_frame(s, f, lattice_beam, sh);
+// backward pass from frame `from` down; frames >= first_unpruned are always processed, older
+// ones until a frame's extra_costs move by no more than delta (PruneActiveTokens :503-530).
+// extra_costs only grow as the frontier advances, so values left stale by the early stop are
+// lower bounds and pruning with them never removes anything the final pass (delta = 0, every
+// frame revisited) would keep.
+__device__ void prune_backward(const Slot &s, int from, int first_unpruned, int stop_at, float lattice_beam, float delta,
+                               Shared &sh, int &pp) {
+  int visited = 0;
+  for (int f = from; f >= 0 && f >= stop_at; f--) {
+    const bool ch = prune_frame(s, f, lattice_beam, delta, sh, pp);
+    visited++;
     if (!ch && f < first_unpruned) break;
   }
+  if (threadIdx.x == 0) sh.n_visited += visited;   // diagnostic
+}
+
+// Re-compact the block that the previous compaction appended to H (frames (tail_f0, tail_f1]
+// and their links).  When it was appended its youngest frames had no look-ahead, so most of
+// their tokens and links survived; by now they have been pruned again and nearly all of them are
+// dead.  Survivors are staged in the free space behind the block and copied back to its start;
+// h_remap[] maps old to new token indices (-1 = dead) for this block.  Everything that refers to
+// these tokens is either inside the block or still in the raw window.  Returns false on overflow.
+__device__ bool recompact_tail(const Slot &s, Shared &sh) {
+  const int tid = threadIdx.x;
+  const int tf0 = sh.tail_f0, tf1 = sh.tail_f1;
+  if (tf1 < 0) return true;                       // nothing appended yet
+  const int fa = tf0 < 0 ? 0 : tf0;               // link frames fa..tf1 (emitting: fa..tf1-1), token frames tf0+1..tf1
+  const int nf = tf1 - fa + 1;
+  const int tail_tb = sh.tail_tok_b, tail_lb = sh.tail_link_b;
+  const int old_nt = sh.h_ntok, old_nl = sh.h_nlink;
+  for (int i = tid; i < 3 * nf; i += NT) sh.fr_cnt[i] = 0;
+  __syncthreads();
+  const unsigned *he = uptr(s.h_extra);
+  const int *hs = uptr(s.hl_src), *hd = uptr(s.hl_dst);
+  for (int k = 0; k < nf; k++) {
+    const int f = fa + k;
+    if (f > tf0) {
+      int c = 0;
+      for (int t = s.tok_b[f] + tid; t < s.tok_e[f]; t += NT) c += he[t] != INF_BITS;
+      if (c) atomicAdd(&sh.fr_cnt[k], c);
+    }
+    for (int pass = 0; pass < 2; pass++) {
+      if (pass == 0 && f == tf1) continue;        // emitting links of the frontier frame are still in W
+      if (pass == 1 && f <= tf0) continue;
+      const int lb = pass ? s.pl_b[f] : s.el_b[f], le_ = pass ? s.pl_e[f] : s.el_e[f];
+      int c = 0;
+      for (int l = lb + tid; l < le_; l += NT) {
+        const int src = hs[l];
+        c += src >= 0 && he[src] != INF_BITS && he[hd[l]] != INF_BITS;
+      }
+      if (c) atomicAdd(&sh.fr_cnt[(1 + pass) * nf + k], c);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int tb = tail_tb, lb = tail_lb;
+    for (int k = 0; k < nf; k++) { sh.fr_base[k] = tb; tb += sh.fr_cnt[k]; }
+    for (int k = 0; k < nf; k++) {
+      sh.fr_base[nf + k] = lb; lb += sh.fr_cnt[nf + k];
+      sh.fr_base[2 * nf + k] = lb; lb += sh.fr_cnt[2 * nf + k];
+    }
+    // staging area = [old_nt, old_nt + alive) and [old_nl, old_nl + alive)
+    if (old_nt + (tb - tail_tb) > s.h_tok_cap) sh.error = ERR_H_TOK;
+    if (old_nl + (lb - tail_lb) > s.h_link_cap) sh.error = ERR_H_LINK;
+    sh.h_ntok = tb; sh.h_nlink = lb;             // new ends of the history
+  }
+  __syncthreads();
+  if (sh.error != ERR_NONE) return false;
+  const int new_nt = sh.h_ntok, new_nl = sh.h_nlink;
+  for (int i = tid; i < 3 * nf; i += NT) sh.fr_cnt[i] = 0;
+  __syncthreads();
+  const int stage_t = old_nt - tail_tb, stage_l = old_nl - tail_lb;   // staging offset relative to the final position
+  // ---- tokens -> staging, remap table
+  for (int k = 0; k < nf; k++) {
+    const int f = fa + k;
+    if (f <= tf0) continue;
+    for (int t = s.tok_b[f] + tid; t < s.tok_e[f]; t += NT) {
+      int nid = -1;
+      if (s.h_extra[t] != INF_BITS) {
+        nid = sh.fr_base[k] + atomicAdd(&sh.fr_cnt[k], 1);
+        const int q = nid + stage_t;
+        s.h_state[q] = s.h_state[t]; s.h_cost[q] = s.h_cost[t]; s.h_extra[q] = s.h_extra[t];
+      }
+      s.h_remap[t] = nid;
+    }
+  }
+  __syncthreads();
+  // ---- links -> staging (end points remapped when they lie in the block)
+  for (int k = 0; k < nf; k++) {
+    const int f = fa + k;
+    for (int pass = 0; pass < 2; pass++) {
+      if (pass == 0 && f == tf1) continue;
+      if (pass == 1 && f <= tf0) continue;
+      const int lb = pass ? s.pl_b[f] : s.el_b[f], le_ = pass ? s.pl_e[f] : s.el_e[f];
+      const int slot = (1 + pass) * nf + k;
+      for (int l = lb + tid; l < le_; l += NT) {
+        int src = s.hl_src[l];
+        if (src < 0) continue;
+        int dst = s.hl_dst[l];
+        if (src >= tail_tb) src = s.h_remap[src];
+        if (dst >= tail_tb) dst = s.h_remap[dst];
+        if (src < 0 || dst < 0) continue;
+        if (s.h_extra[s.hl_src[l]] == INF_BITS) continue;   // source outside the block but dead
+        const int q = sh.fr_base[slot] + atomicAdd(&sh.fr_cnt[slot], 1) + stage_l;
+        s.hl_src[q] = src; s.hl_dst[q] = dst; s.hl_il[q] = s.hl_il[l]; s.hl_ol[q] = s.hl_ol[l];
+        s.hl_gr[q] = s.hl_gr[l]; s.hl_ac[q] = s.hl_ac[l];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- staging -> final position (the two regions never overlap: staging starts at the old end)
+  for (int i = tail_tb + tid; i < new_nt; i += NT) {
+    const int q = i + stage_t;
+    s.h_state[i] = s.h_state[q]; s.h_cost[i] = s.h_cost[q]; s.h_extra[i] = s.h_extra[q]; s.h_tmp[i] = INF_BITS;
+  }
+  for (int i = tail_lb + tid; i < new_nl; i += NT) {
+    const int q = i + stage_l;
+    s.hl_src[i] = s.hl_src[q]; s.hl_dst[i] = s.hl_dst[q]; s.hl_il[i] = s.hl_il[q]; s.hl_ol[i] = s.hl_ol[q];
+    s.hl_gr[i] = s.hl_gr[q]; s.hl_ac[i] = s.hl_ac[q];
+  }
+  if (tid == 0) {
+    for (int k = 0; k < nf; k++) {
+      const int f = fa + k;
+      if (f > tf0) { s.tok_b[f] = sh.fr_base[k]; s.tok_e[f] = sh.fr_base[k] + sh.fr_cnt[k]; }
+      if (f != tf1) { s.el_b[f] = sh.fr_base[nf + k]; s.el_e[f] = sh.fr_base[nf + k] + sh.fr_cnt[nf + k]; }
+      if (f > tf0) { s.pl_b[f] = sh.fr_base[2 * nf + k]; s.pl_e[f] = sh.fr_base[2 * nf + k] + sh.fr_cnt[2 * nf + k]; }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  return true;
 }
 
 // Move the survivors of the raw window into the history: tokens of frames (prev_front, front],
@@ -281,6 +447,9 @@ __device__ void prune_backward(const Slot &s, int from, int first_unpruned, floa
 // handful of barriers in total.  Returns false (uniformly) on overflow.
 __device__ bool compact_window(const Slot &s, int prev_front, int front, Shared &sh) {
   const int tid = threadIdx.x;
+  const int old_tail_tb = sh.tail_tok_b;
+  const bool had_tail = sh.tail_f1 >= 0;
+  if (!recompact_tail(s, sh)) return false;
   const int f0 = prev_front < 0 ? 0 : prev_front;
   const int nf = front - f0 + 1;     // frames f0..front  (<= MAX_WIN_FRAMES, checked on the host)
   for (int i = tid; i < 3 * nf; i += NT) sh.fr_cnt[i] = 0;
@@ -301,7 +470,8 @@ __device__ bool compact_window(const Slot &s, int prev_front, int front, Shared 
         const int src = s.wl_src[l];
         if (src < 0) continue;
         const int dst = s.wl_dst[l];
-        const bool sa = (src & WBIT) ? s.w_extra[src ^ WBIT] != INF_BITS : true;
+        const bool sa = (src & WBIT) ? s.w_extra[src ^ WBIT] != INF_BITS
+                                     : (had_tail && src >= old_tail_tb ? s.h_remap[src] >= 0 : true);
         const bool da = (dst & WBIT) ? s.w_extra[dst ^ WBIT] != INF_BITS : true;
         c += sa && da;
       }
@@ -351,6 +521,7 @@ __device__ bool compact_window(const Slot &s, int prev_front, int front, Shared 
         if (src < 0) continue;
         int dst = s.wl_dst[l];
         if (src & WBIT) src = s.w_remap[src ^ WBIT];
+        else if (had_tail && src >= old_tail_tb) src = s.h_remap[src];   // a token of the re-compacted block
         if (dst & WBIT) dst = s.w_remap[dst ^ WBIT];
         if (src < 0 || dst < 0) continue;
         const int nid = sh.fr_base[slot] + atomicAdd(&sh.fr_cnt[slot], 1);
@@ -368,6 +539,8 @@ __device__ bool compact_window(const Slot &s, int prev_front, int front, Shared 
       if (s.pl_w[f]) { s.pl_b[f] = sh.fr_base[2 * nf + k]; s.pl_e[f] = sh.fr_base[2 * nf + k] + sh.fr_cnt[2 * nf + k]; s.pl_w[f] = 0; }
     }
     sh.w_ntok = 0; sh.w_nlink = 0;
+    sh.tail_tok_b = sh.fr_base[0]; sh.tail_link_b = sh.fr_base[nf];
+    sh.tail_f0 = prev_front; sh.tail_f1 = front;
   }
   __threadfence_block();
   __syncthreads();
@@ -391,11 +564,15 @@ __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, flo
     if (iter >= MAX_EPS_ITERS) { if (tid == 0) sh.error = ERR_EPS_LOOP; break; }
     const int nxt = cur == 2 ? 0 : cur + 1, spare = nxt == 2 ? 0 : nxt + 1;
     if (tid == 0) sh.fcnt[spare] = 0;      // nobody touches the spare list during this iteration
-    const int *fcur = s.front[cur];
-    int *fnext = s.front[nxt];
+    const int *fcur = uptr(s.front[cur]);
+    int *fnext = uptr(s.front[nxt]);
+    unsigned long long *key = uptr(s.key);
+    int *tokid = uptr(s.tokid), *w_state = uptr(s.w_state);
+    unsigned *w_extra = uptr(s.w_extra), *w_tmp = uptr(s.w_tmp);
+    const int w_tok_cap = s.w_tok_cap, front_cap = s.front_cap;
     for (int i = tid; i < ncur; i += NT) {
       const int st = fcur[i];
-      const float c = o2f((unsigned)ld_u64(&s.key[st]));
+      const float c = o2f((unsigned)ld_u64(&key[st]));
       if (c > cutoff) continue;
       for (int a = g.arc_off[st]; a < g.arc_off[st + 1]; a++) {
         if (g.arc_pdf[a] >= 0) continue;     // emitting arc
@@ -404,20 +581,18 @@ __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, flo
         if (!(tot < cutoff)) continue;
         const int ds = arc.nextstate;
         const unsigned long long nk = EPK | f2o(tot);
-        const unsigned long long old = atomicMin(&s.key[ds], nk);
-        bool push = false;
-        if ((unsigned)(old >> 32) != ep) {   // first touch of this state in this frame: create its token
-          const int nid = atomicAdd(&sh.w_ntok, 1);
-          if (nid < s.w_tok_cap) {
-            s.w_state[nid] = ds; s.w_extra[nid] = 0u; s.w_tmp[nid] = INF_BITS;
-            st_i32(&s.tokid[ds], nid);
+        const unsigned long long old = atomicMin(&key[ds], nk);
+        const bool create = (unsigned)(old >> 32) != ep;   // first touch of this state in this frame
+        const int nid = wave_alloc(&sh.w_ntok, create);
+        if (create) {
+          if (nid < w_tok_cap) {
+            w_state[nid] = ds; w_extra[nid] = 0u; w_tmp[nid] = INF_BITS;
+            st_i32(&tokid[ds], nid);
           } else sh.error = ERR_W_TOK;
-          push = true;
-        } else if (nk < old) push = true;     // improved: must be (re-)expanded
-        if (push && g.nieps[ds] > 0) {
-          const int q = atomicAdd(&sh.fcnt[nxt], 1);
-          if (q < s.front_cap) fnext[q] = ds; else sh.error = ERR_FRONT;
         }
+        const bool push = (create || nk < old) && g.nieps[ds] > 0;   // new or improved: (re-)expand
+        const int q = wave_alloc(&sh.fcnt[nxt], push);
+        if (push) { if (q < front_cap) fnext[q] = ds; else sh.error = ERR_FRONT; }
       }
     }
     __syncthreads();
@@ -429,44 +604,65 @@ __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, flo
   const int ne = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap;
   const int lb = sh.w_nlink;
   __syncthreads();
-  for (int t = nb + tid; t < ne; t += NT) {
-    const int st = s.w_state[t];
-    const float c = o2f((unsigned)ld_u64(&s.key[st]));
-    s.w_cost[t] = c;
-    if (g.nieps[st] == 0 || c > cutoff) continue;
-    for (int a = g.arc_off[st]; a < g.arc_off[st + 1]; a++) {
-      if (g.arc_pdf[a] >= 0) continue;
-      const vbh_arc arc = g.arcs[a];
-      const float tot = c + arc.weight;
-      if (!(tot < cutoff)) continue;
-      const int l = atomicAdd(&sh.w_nlink, 1);
-      if (l < s.w_link_cap) {
-        s.wl_src[l] = t | WBIT; s.wl_dst[l] = ld_i32(&s.tokid[arc.nextstate]) | WBIT;
-        s.wl_il[l] = 0; s.wl_ol[l] = arc.olabel; s.wl_gr[l] = arc.weight; s.wl_ac[l] = 0.0f;
-      } else sh.error = ERR_W_LINK;
+  {
+    const unsigned long long *key = uptr(s.key);
+    const int *tokid = uptr(s.tokid), *w_state = uptr(s.w_state);
+    float *w_cost = uptr(s.w_cost);
+    int *wl_src = uptr(s.wl_src), *wl_dst = uptr(s.wl_dst), *wl_il = uptr(s.wl_il), *wl_ol = uptr(s.wl_ol);
+    float *wl_gr = uptr(s.wl_gr), *wl_ac = uptr(s.wl_ac);
+    const int w_link_cap = s.w_link_cap;
+    for (int t = nb + tid; t < ne; t += NT) {
+      const int st = w_state[t];
+      const float c = o2f((unsigned)ld_u64(&key[st]));
+      w_cost[t] = c;
+      if (g.nieps[st] == 0 || c > cutoff) continue;
+      for (int a = g.arc_off[st]; a < g.arc_off[st + 1]; a++) {
+        if (g.arc_pdf[a] >= 0) continue;
+        const vbh_arc arc = g.arcs[a];
+        const float tot = c + arc.weight;
+        if (!(tot < cutoff)) continue;
+        const int l = wave_alloc(&sh.w_nlink, true);
+        if (l < w_link_cap) {
+          wl_src[l] = t | WBIT; wl_dst[l] = ld_i32(&tokid[arc.nextstate]) | WBIT;
+          wl_il[l] = 0; wl_ol[l] = arc.olabel; wl_gr[l] = arc.weight; wl_ac[l] = 0.0f;
+        } else sh.error = ERR_W_LINK;
+      }
     }
   }
   __syncthreads();
   return lb;
 }
 
-__global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, const Slot *slots,
+__global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(DevGraph g, DecCfg cfg, const Slot *slots,
                                                      const float *__restrict__ loglikes, int P,
-                                                     const UttDesc *__restrict__ utts, int n_utt,
-                                                     int *work_counter, UttResult *results, const Pool *pool_p) {
+                                                     const UttDesc *__restrict__ utts, const int *__restrict__ work_list,
+                                                     int n_work, int *work_counter, UttResult *results, const Pool *pool_p) {
   __shared__ Shared sh;
-  const Pool &pool = *pool_p;
+  // The slot's ~45 pointers live in LDS: by value they overflow the SGPR file, and read through
+  // the global pointer the compiler re-fetches them with vector loads inside every loop.
+  __shared__ Slot s_slot;
+  __shared__ Pool s_pool;
   const int tid = threadIdx.x;
-  const Slot &s = slots[blockIdx.x];   // pointers are fetched by scalar loads when needed (a by-value copy overflows the SGPR file)
+  {
+    const int *src = reinterpret_cast<const int *>(&slots[blockIdx.x]);
+    int *dst = reinterpret_cast<int *>(&s_slot);
+    for (int i = tid; i < (int)(sizeof(Slot) / sizeof(int)); i += NT) dst[i] = src[i];
+    const int *psrc = reinterpret_cast<const int *>(pool_p);
+    int *pdst = reinterpret_cast<int *>(&s_pool);
+    for (int i = tid; i < (int)(sizeof(Pool) / sizeof(int)); i += NT) pdst[i] = psrc[i];
+  }
+  __syncthreads();
+  const Slot &s = s_slot;
+  const Pool &pool = s_pool;
   const float INF = INFINITY;
-  int par = 0;
+  int par = 0, pp = 0;
 
   while (true) {
     __syncthreads();
     if (tid == 0) sh.utt = atomicAdd(work_counter, 1);
     __syncthreads();
-    const int utt = sh.utt;
-    if (utt >= n_utt) break;    // every wave of the grid reaches this exit
+    if (sh.utt >= n_work) break;    // every wave of the grid reaches this exit
+    const int utt = work_list ? work_list[sh.utt] : sh.utt;
     const UttDesc ud = utts[utt];
     const int T = ud.T;
     // epochs start at 1: the high word 0xFFFFFFFF is the cleared (memset 0xFF) state
@@ -477,9 +673,12 @@ __global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, cons
     if (tid == 0) {
       for (int i = 0; i < 8; i++) sh.tph[i] = 0;
       sh.w_ntok = 0; sh.w_nlink = 0; sh.h_ntok = 0; sh.h_nlink = 0; sh.error = ERR_NONE;
-      sh.n_max_bound = 0; sh.n_min_bound = 0; sh.n_cand = 0;
+      sh.n_max_bound = 0; sh.n_min_bound = 0; sh.n_cand = 0; sh.n_visited = 0;
       sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0;
+      sh.changed2[0] = 0; sh.changed2[1] = 0;
+      sh.tail_tok_b = 0; sh.tail_link_b = 0; sh.tail_f0 = -1; sh.tail_f1 = -2;
     }
+    pp = 0;
     __syncthreads();
 
     // ---- InitDecoding (:56-73): start token, then the epsilon closure with cutoff = beam
@@ -510,12 +709,16 @@ __global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, cons
 
     int prev_front = -1;      // frontier frame at the previous pruning (-1: none yet)
     int frames_done = 0;
-    PHASE(7)
+    PHASE(6)
     for (int frame = 0; frame < T && sh.error == ERR_NONE; frame++) {
       // ---- periodic pruning (:85-87); frame 0 has nothing behind it
       if (frame > 0 && frame % cfg.prune_interval == 0) {
         __syncthreads();
-        prune_backward(s, frame - 1, prev_front < 0 ? 0 : prev_front, cfg.lattice_beam, sh);
+        // intermediate passes walk back at most 4 intervals beyond the unpruned frames: a bound on
+        // the work (long-lived parallel paths would otherwise drag every pass back to frame 0);
+        // whatever is left stale is a lower bound and is settled by the final pass
+        prune_backward(s, frame - 1, prev_front < 0 ? 0 : prev_front, (prev_front < 0 ? 0 : prev_front) - 4 * cfg.prune_interval,
+                       cfg.lattice_beam, cfg.lattice_beam * 0.1f, sh, pp);
         PHASE(4)
         if (!compact_window(s, prev_front, frame, sh)) break;
         prev_front = frame;
@@ -523,8 +726,11 @@ __global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, cons
         PHASE(5)
       }
       const int tb = cur_b, n = cur_e - cur_b;
-      const int *tstate = (cur_w ? s.w_state : s.h_state) + tb;
-      const float *tcost = (cur_w ? s.w_cost : s.h_cost) + tb;
+      const int *tstate = uptr(cur_w ? s.w_state : s.h_state) + tb;
+      const float *tcost = uptr(cur_w ? s.w_cost : s.h_cost) + tb;
+      float *c_tot = uptr(s.c_tot), *c_ac = uptr(s.c_ac);
+      int *c_arc = uptr(s.c_arc), *c_src = uptr(s.c_src), *c_dst = uptr(s.c_dst);
+      const int cand_cap = s.cand_cap;
       const int enc = cur_w ? WBIT : 0;
       const float *llrow = loglikes + (ud.row0 + frame) * (long long)P;
       const unsigned ep = (unsigned)(0xFFFFFFFFu - (unsigned)(epoch_base + frame + 1));
@@ -599,47 +805,59 @@ __global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, cons
           const float ac = cost_offset - cfg.acwt * llrow[pdf];
           const float tot = (c + ac) + arc.weight;
           mymin = fminf(mymin, tot + adaptive_beam);
-          const int q = atomicAdd(&sh.n_cand, 1);
-          if (q < s.cand_cap) { s.c_tot[q] = tot; s.c_ac[q] = ac; s.c_arc[q] = a; s.c_src[q] = i; s.c_dst[q] = arc.nextstate; }
+          const int q = wave_alloc(&sh.n_cand, true);
+          if (q < cand_cap) { c_tot[q] = tot; c_ac[q] = ac; c_arc[q] = a; c_src[q] = i; c_dst[q] = arc.nextstate; }
           else sh.error = ERR_CAND;
         }
       }
       mymin = block_min_f(mymin, sh, par);
       const float next_cutoff = fminf(sh.f0, mymin);
-      const int ncand = sh.n_cand < s.cand_cap ? sh.n_cand : s.cand_cap;
+      const int ncand = sh.n_cand < cand_cap ? sh.n_cand : cand_cap;
       const int nb = sh.w_ntok;     // first token of frame+1
       PHASE(1)
       // ---- pass 2 (candidate-parallel): admit tot <= next_cutoff; min-cost per state via one
       //      64-bit atomicMin; the thread that meets a stale epoch creates the token
-      for (int q = tid; q < ncand; q += NT) {
-        const float tot = s.c_tot[q];
-        if (tot > next_cutoff) continue;
-        const int ds = s.c_dst[q];
-        const unsigned long long old = atomicMin(&s.key[ds], EPK | f2o(tot));
-        if ((unsigned)(old >> 32) != ep) {
-          const int nid = atomicAdd(&sh.w_ntok, 1);
-          if (nid < s.w_tok_cap) {
-            s.w_state[nid] = ds; s.w_extra[nid] = 0u; s.w_tmp[nid] = INF_BITS;
-            st_i32(&s.tokid[ds], nid);
-            if (g.nieps[ds] > 0) {
-              const int f = atomicAdd(&sh.fcnt[0], 1);
-              if (f < s.front_cap) s.front[0][f] = ds; else sh.error = ERR_FRONT;
-            }
-          } else sh.error = ERR_W_TOK;
+      {
+        unsigned long long *key = uptr(s.key);
+        int *tokid = uptr(s.tokid), *w_state = uptr(s.w_state), *front0 = uptr(s.front[0]);
+        unsigned *w_extra = uptr(s.w_extra), *w_tmp = uptr(s.w_tmp);
+        const int w_tok_cap = s.w_tok_cap, front_cap = s.front_cap;
+        for (int q = tid; q < ncand; q += NT) {
+          const float tot = c_tot[q];
+          if (tot > next_cutoff) continue;
+          const int ds = c_dst[q];
+          const unsigned long long old = atomicMin(&key[ds], EPK | f2o(tot));
+          const bool create = (unsigned)(old >> 32) != ep;
+          const int nid = wave_alloc(&sh.w_ntok, create);
+          bool ok_tok = false;
+          if (create) {
+            if (nid < w_tok_cap) {
+              w_state[nid] = ds; w_extra[nid] = 0u; w_tmp[nid] = INF_BITS;
+              st_i32(&tokid[ds], nid);
+              ok_tok = true;
+            } else sh.error = ERR_W_TOK;
+          }
+          const bool pushf = ok_tok && g.nieps[ds] > 0;
+          const int f = wave_alloc(&sh.fcnt[0], pushf);
+          if (pushf) { if (f < front_cap) front0[f] = ds; else sh.error = ERR_FRONT; }
         }
       }
       __syncthreads();
       // ---- pass 3 (candidate-parallel): forward links (:765-767)
       const int lb = sh.w_nlink;
       if (sh.error == ERR_NONE) {
+        const int *tokid = uptr(s.tokid);
+        int *wl_src = uptr(s.wl_src), *wl_dst = uptr(s.wl_dst), *wl_il = uptr(s.wl_il), *wl_ol = uptr(s.wl_ol);
+        float *wl_gr = uptr(s.wl_gr), *wl_ac = uptr(s.wl_ac);
+        const int w_link_cap = s.w_link_cap;
         for (int q = tid; q < ncand; q += NT) {
-          const float tot = s.c_tot[q];
+          const float tot = c_tot[q];
           if (tot > next_cutoff) continue;
-          const vbh_arc arc = g.arcs[s.c_arc[q]];
-          const int l = atomicAdd(&sh.w_nlink, 1);
-          if (l < s.w_link_cap) {
-            s.wl_src[l] = (tb + s.c_src[q]) | enc; s.wl_dst[l] = ld_i32(&s.tokid[arc.nextstate]) | WBIT;
-            s.wl_il[l] = arc.ilabel; s.wl_ol[l] = arc.olabel; s.wl_gr[l] = arc.weight; s.wl_ac[l] = s.c_ac[q];
+          const vbh_arc arc = g.arcs[c_arc[q]];
+          const int l = wave_alloc(&sh.w_nlink, true);
+          if (l < w_link_cap) {
+            wl_src[l] = (tb + c_src[q]) | enc; wl_dst[l] = ld_i32(&tokid[arc.nextstate]) | WBIT;
+            wl_il[l] = arc.ilabel; wl_ol[l] = arc.olabel; wl_gr[l] = arc.weight; wl_ac[l] = c_ac[q];
           } else sh.error = ERR_W_LINK;
         }
       }
@@ -701,10 +919,10 @@ __global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, cons
           const float x = tcost[t] + fc - final_best;    // >= 0 by construction
           tmp[t] = __float_as_uint(x);
         }
-        if (tid == 0) sh.changed = 0;
         __syncthreads();
         eval_links(s, pw, pb, pe, tcost, tmp, cfg.lattice_beam);
         __syncthreads();
+        if (tid == 0) sh.changed2[pp ^ 1] = 0;
         int ch = 0;
         for (int t = tb + tid; t < te; t += NT) {
           float v = __uint_as_float(tmp[t]);
@@ -713,13 +931,13 @@ __global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, cons
           const unsigned vb = __float_as_uint(v);
           if (vb != extra[t]) { extra[t] = vb; ch = 1; }
         }
-        if (ch) sh.changed = 1;
+        if (ch) sh.changed2[pp] = 1;
         __syncthreads();
-        const bool any = sh.changed != 0;
-        __syncthreads();
+        const bool any = sh.changed2[pp] != 0;
+        pp ^= 1;
         if (!any || pe == pb) break;
       }
-      prune_backward(s, F - 1, prev_front < 0 ? 0 : prev_front, cfg.lattice_beam, sh);
+      prune_backward(s, F - 1, /*first_unpruned=*/0, /*stop_at=*/0, cfg.lattice_beam, 0.0f, sh, pp);   // every frame, delta 0 (:606-611)
       PHASE(4)
       compact_window(s, prev_front, F, sh);
       PHASE(5)
@@ -814,7 +1032,8 @@ __global__ __launch_bounds__(NT) void decode_kernel(DevGraph g, DecCfg cfg, cons
         r->n_tokens_expanded = (long long)te_; r->n_arcs_expanded = (long long)ae_;
         r->n_tokens_created = c_tok_new; r->n_links_created = c_link_new;
         r->n_max_bound = sh.n_max_bound; r->n_min_bound = sh.n_min_bound;
-        for (int i = 0; i < 8; i++) r->t_phase[i] = sh.tph[i];
+        for (int i = 0; i < 7; i++) r->t_phase[i] = sh.tph[i];
+        r->t_phase[7] = sh.n_visited;   // slot 7: frames visited by pruning (not a time)
         s.state[0] = epoch_base + T + 2;   // next utterance in this slot: disjoint epochs
       }
     }
@@ -837,7 +1056,7 @@ __global__ void fill_arc_pdf_kernel(const vbh_arc *__restrict__ arcs, long long 
 // ============================================================================ host side
 struct vbh_graph {
   vbh_ctx *ctx;
-  int S, start; long long A; int max_ilabel;
+  int S, start; long long A; int max_ilabel, max_degree;
   DevBuf<float> final_cost; DevBuf<int> arc_off, nieps, arc_pdf; DevBuf<vbh_arc> arcs;
   std::vector<float> h_final;
 };
@@ -848,21 +1067,85 @@ struct HostLattice {
   vbh_lattice view;
 };
 
+struct SlotSet {          // workspaces of one size class
+  int n = 0;
+  Slot proto{};
+  std::vector<Slot> h;
+  DevBuf<Slot> d;
+};
+
 struct vbh_decoder {
   vbh_ctx *ctx; const vbh_graph *graph; vbh_decode_cfg cfg;
-  int n_slots, max_frames;
-  Slot proto;                       // capacities
-  std::vector<Slot> h_slots;
+  int max_frames;
+  SlotSet small_set, big_set;       // big: generous capacities, allocated on first overflow
   std::vector<void *> allocs;
-  DevBuf<Slot> d_slots;
   std::vector<HostLattice> results;
   std::vector<UttResult> h_res;
+  int n_retried = 0;
 };
 
 static int slot_alloc(vbh_decoder *d, size_t bytes, void **p, int memset_val = -2) {
   VBH_HIP(hipMalloc(p, bytes ? bytes : 8));
   d->allocs.push_back(*p);
   if (memset_val != -2) VBH_HIP(hipMemsetAsync(*p, memset_val, bytes, d->ctx->stream));
+  return 0;
+}
+
+static const char *err_name(int e);
+
+static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
+  const vbh_graph *graph = d->graph;
+  const vbh_decode_cfg *cfg = &d->cfg;
+  const int max_frames = d->max_frames;
+  const long long S = graph->S;
+  const long long ma = std::min<long long>(cfg->max_active, S);
+  // new tokens per frame are bounded by the arcs leaving the expanded tokens (~max_active * out-degree)
+  const long long per_frame_tok = std::min<long long>(S, big ? std::max<long long>(8192, 8 * ma) : std::max<long long>(4096, 2 * ma));
+  const long long per_frame_link = std::min<long long>(std::max<long long>(graph->A, 1), 2 * per_frame_tok);
+  const long long surv_tok = big ? 2048 : 160, surv_link = big ? 4096 : 320;   // lattice survivors per frame
+  const int win = cfg->prune_interval + 1;
+  Slot p{};
+  p.w_tok_cap = (int)std::min<long long>(per_frame_tok * win, 1LL << 28);
+  p.w_link_cap = (int)std::min<long long>((per_frame_link + per_frame_tok) * win, 1LL << 28);
+  // history: one unpruned frontier frame per interval plus the survivors
+  const long long n_int = max_frames / cfg->prune_interval + 2;
+  const long long front_avg = big ? per_frame_tok : per_frame_tok / 2;
+  p.h_tok_cap = (int)std::min<long long>(front_avg * n_int + surv_tok * (max_frames + 1) + per_frame_tok, 1LL << 29);
+  p.h_link_cap = (int)std::min<long long>(front_avg * n_int + surv_link * (max_frames + 1) + per_frame_link, 1LL << 29);
+  p.front_cap = (int)(2 * per_frame_tok);
+  // candidates of one frame = arcs leaving the expanded tokens: at most ~max_active tokens are
+  // expanded (GetCutoff), each with at most max_degree arcs
+  p.cand_cap = (int)std::min<long long>(std::max<long long>(graph->A, 1),
+                                        std::min<long long>((ma + 256) * std::max(graph->max_degree, 1), big ? (1LL << 24) : (1LL << 21)));
+  set->proto = p; set->n = n;
+  set->h.assign(n, p);
+  const size_t F = (size_t)max_frames + 2;
+  // one allocation per field, covering all slots (slot i owns [i*count, (i+1)*count))
+  const size_t ns = (size_t)n;
+#define A_(field, type, count, ms)                                                                   \
+  {                                                                                                  \
+    type *base = nullptr;                                                                            \
+    if (slot_alloc(d, sizeof(type) * (size_t)(count) * ns, reinterpret_cast<void **>(&base), ms)) return -1; \
+    for (size_t i = 0; i < ns; i++) set->h[i].field = base + i * (size_t)(count);                    \
+  }
+  A_(key, unsigned long long, S, 0xFF) A_(tokid, int, S, 0)
+  A_(w_state, int, p.w_tok_cap, -2) A_(w_cost, float, p.w_tok_cap, -2) A_(w_extra, unsigned, p.w_tok_cap, -2)
+  A_(w_tmp, unsigned, p.w_tok_cap, -2) A_(w_remap, int, p.w_tok_cap, -2)
+  A_(wl_src, int, p.w_link_cap, -2) A_(wl_dst, int, p.w_link_cap, -2) A_(wl_il, int, p.w_link_cap, -2)
+  A_(wl_ol, int, p.w_link_cap, -2) A_(wl_gr, float, p.w_link_cap, -2) A_(wl_ac, float, p.w_link_cap, -2)
+  A_(h_state, int, p.h_tok_cap, -2) A_(h_cost, float, p.h_tok_cap, -2) A_(h_extra, unsigned, p.h_tok_cap, -2)
+  A_(h_tmp, unsigned, p.h_tok_cap, -2) A_(h_remap, int, p.h_tok_cap, -2)
+  A_(hl_src, int, p.h_link_cap, -2) A_(hl_dst, int, p.h_link_cap, -2) A_(hl_il, int, p.h_link_cap, -2)
+  A_(hl_ol, int, p.h_link_cap, -2) A_(hl_gr, float, p.h_link_cap, -2) A_(hl_ac, float, p.h_link_cap, -2)
+  A_(tok_b, int, F, 0) A_(tok_e, int, F, 0) A_(el_b, int, F, 0) A_(el_e, int, F, 0) A_(pl_b, int, F, 0) A_(pl_e, int, F, 0)
+  A_(tok_w, unsigned char, F, 0) A_(el_w, unsigned char, F, 0) A_(pl_w, unsigned char, F, 0)
+  A_(cost_offset, float, F, 0)
+  A_(c_tot, float, p.cand_cap, -2) A_(c_ac, float, p.cand_cap, -2) A_(c_arc, int, p.cand_cap, -2)
+  A_(c_src, int, p.cand_cap, -2) A_(c_dst, int, p.cand_cap, -2)
+  A_(front[0], int, p.front_cap, -2) A_(front[1], int, p.front_cap, -2) A_(front[2], int, p.front_cap, -2)
+  A_(state, int, 4, 0)
+#undef A_
+  if (set->d.upload(set->h.data(), set->h.size(), d->ctx->stream)) return -1;
   return 0;
 }
 
@@ -883,20 +1166,22 @@ int vbh_graph_create(vbh_ctx *ctx, int32_t num_states, int32_t start, const floa
   VBH_CHECK(A == 0 || h_arcs, "vbh_graph_create: arcs missing");
   if (vbh_use_device(ctx)) return -1;
   std::vector<int> off(num_states + 1), nieps(num_states, 0);
-  int max_il = 0;
+  int max_il = 0, max_deg = 0;
   for (int s = 0; s <= num_states; s++) {
     VBH_CHECK(s == 0 || h_arc_offsets[s] >= h_arc_offsets[s - 1], "vbh_graph_create: arc offsets not monotone at state %d", s);
     off[s] = (int)h_arc_offsets[s];
   }
-  for (int s = 0; s < num_states; s++)
+  for (int s = 0; s < num_states; s++) {
+    if (off[s + 1] - off[s] > max_deg) max_deg = off[s + 1] - off[s];
     for (int a = off[s]; a < off[s + 1]; a++) {
       VBH_CHECK(h_arcs[a].nextstate >= 0 && h_arcs[a].nextstate < num_states, "vbh_graph_create: arc %d leaves the graph", a);
       VBH_CHECK(h_arcs[a].ilabel >= 0, "vbh_graph_create: negative ilabel on arc %d", a);
       nieps[s] += h_arcs[a].ilabel == 0;
       if (h_arcs[a].ilabel > max_il) max_il = h_arcs[a].ilabel;
     }
+  }
   vbh_graph *g = new vbh_graph();
-  g->ctx = ctx; g->S = num_states; g->start = start; g->A = A; g->max_ilabel = max_il;
+  g->ctx = ctx; g->S = num_states; g->start = start; g->A = A; g->max_ilabel = max_il; g->max_degree = max_deg;
   g->h_final.assign(h_final, h_final + num_states);
   hipStream_t st = ctx->stream;
   if (g->final_cost.upload(h_final, num_states, st) || g->arc_off.upload(off.data(), off.size(), st) ||
@@ -925,55 +1210,11 @@ int vbh_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_decode_cf
   if (vbh_use_device(ctx)) return -1;
   vbh_decoder *d = new vbh_decoder();
   d->ctx = ctx; d->graph = graph; d->cfg = *cfg; d->max_frames = max_frames;
-  // how many utterances are searched concurrently: one workgroup each, at most one per CU here
-  d->n_slots = std::min<int>(max_batch, ctx->num_cus);
-  // capacities.  New tokens per frame are bounded by the arcs leaving the expanded tokens;
-  // with max_active binding that is ~max_active * out-degree.  Sized generously, checked at run time.
-  const long long S = graph->S;
-  const long long per_frame_tok = std::min<long long>(S, std::max<long long>(4096, 6LL * std::min<long long>(cfg->max_active, S)));
-  const long long per_frame_link = std::min<long long>(std::max<long long>(graph->A, 1), 2 * per_frame_tok);
-  const int win = cfg->prune_interval + 1;
-  Slot p{};
-  p.w_tok_cap = (int)std::min<long long>(per_frame_tok * win, 1LL << 28);
-  p.w_link_cap = (int)std::min<long long>((per_frame_link + per_frame_tok) * win, 1LL << 28);
-  // history: one unpruned frontier frame per interval plus the survivors
-  const long long n_int = max_frames / cfg->prune_interval + 2;
-  p.h_tok_cap = (int)std::min<long long>(per_frame_tok * n_int + 1024LL * (max_frames + 1) + per_frame_tok, 1LL << 29);
-  p.h_link_cap = (int)std::min<long long>(per_frame_tok * n_int + 2048LL * (max_frames + 1) + per_frame_link, 1LL << 29);
-  p.front_cap = (int)(2 * per_frame_tok);
-  p.cand_cap = (int)std::min<long long>(std::max<long long>(graph->A, 1), 8 * per_frame_tok);
-  d->proto = p;
-  d->h_slots.assign(d->n_slots, p);
-  const size_t F = (size_t)max_frames + 2;
-  // one allocation per field, covering all slots (slot i owns [i*count, (i+1)*count))
-  const size_t ns = (size_t)d->n_slots;
-#define A_(field, type, count, ms)                                                                   \
-  {                                                                                                  \
-    type *base = nullptr;                                                                            \
-    if (slot_alloc(d, sizeof(type) * (size_t)(count) * ns, reinterpret_cast<void **>(&base), ms)) {  \
-      vbh_decoder_destroy(d);                                                                        \
-      return -1;                                                                                     \
-    }                                                                                                \
-    for (size_t i = 0; i < ns; i++) d->h_slots[i].field = base + i * (size_t)(count);                \
-  }
-  A_(key, unsigned long long, S, 0xFF) A_(tokid, int, S, 0)
-  A_(w_state, int, p.w_tok_cap, -2) A_(w_cost, float, p.w_tok_cap, -2) A_(w_extra, unsigned, p.w_tok_cap, -2)
-  A_(w_tmp, unsigned, p.w_tok_cap, -2) A_(w_remap, int, p.w_tok_cap, -2)
-  A_(wl_src, int, p.w_link_cap, -2) A_(wl_dst, int, p.w_link_cap, -2) A_(wl_il, int, p.w_link_cap, -2)
-  A_(wl_ol, int, p.w_link_cap, -2) A_(wl_gr, float, p.w_link_cap, -2) A_(wl_ac, float, p.w_link_cap, -2)
-  A_(h_state, int, p.h_tok_cap, -2) A_(h_cost, float, p.h_tok_cap, -2) A_(h_extra, unsigned, p.h_tok_cap, -2)
-  A_(h_tmp, unsigned, p.h_tok_cap, -2)
-  A_(hl_src, int, p.h_link_cap, -2) A_(hl_dst, int, p.h_link_cap, -2) A_(hl_il, int, p.h_link_cap, -2)
-  A_(hl_ol, int, p.h_link_cap, -2) A_(hl_gr, float, p.h_link_cap, -2) A_(hl_ac, float, p.h_link_cap, -2)
-  A_(tok_b, int, F, 0) A_(tok_e, int, F, 0) A_(el_b, int, F, 0) A_(el_e, int, F, 0) A_(pl_b, int, F, 0) A_(pl_e, int, F, 0)
-  A_(tok_w, unsigned char, F, 0) A_(el_w, unsigned char, F, 0) A_(pl_w, unsigned char, F, 0)
-  A_(cost_offset, float, F, 0)
-  A_(c_tot, float, p.cand_cap, -2) A_(c_ac, float, p.cand_cap, -2) A_(c_arc, int, p.cand_cap, -2)
-  A_(c_src, int, p.cand_cap, -2) A_(c_dst, int, p.cand_cap, -2)
-  A_(front[0], int, p.front_cap, -2) A_(front[1], int, p.front_cap, -2) A_(front[2], int, p.front_cap, -2)
-  A_(state, int, 4, 0)
-#undef A_
-  if (d->d_slots.upload(d->h_slots.data(), d->h_slots.size(), ctx->stream)) { vbh_decoder_destroy(d); return -1; }
+  // Two size classes.  "small": sized for the common case (new tokens per frame <= 2*max_active,
+  // a few hundred lattice survivors per frame), four workgroups per CU.  "big": the generous
+  // worst-case sizes, a handful of slots, allocated only when an utterance overflows a small slot;
+  // such utterances are searched again there (vbh_decode_batch), so capacity never truncates a result.
+  if (alloc_slot_set(d, &d->small_set, std::min<int>(max_batch, (1024 / NT) * ctx->num_cus), /*big=*/false)) { vbh_decoder_destroy(d); return -1; }
   VBH_HIP(hipStreamSynchronize(ctx->stream));
   *out = d;
   return 0;
@@ -1163,12 +1404,43 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
   if (d_pool.upload(&pool, 1, st)) return -1;
   DevGraph dg{g->S, g->start, g->final_cost.p, g->arc_off.p, g->nieps.p, g->arcs.p, g->arc_pdf.p};
   DecCfg dc{d->cfg.beam, d->cfg.lattice_beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active, d->cfg.prune_interval};
-  const int grid = std::min(d->n_slots, n_utt);
-  hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(NT), 0, st, dg, dc, d->d_slots.p, d_loglikes, (int)num_pdfs,
-                     d_utts.p, n_utt, d_counter.p, d_res.p, d_pool.p);
-  VBH_HIP(hipGetLastError());
   d->h_res.resize(n_utt);
-  VBH_HIP(hipMemcpyAsync(d->h_res.data(), d_res.p, sizeof(UttResult) * n_utt, hipMemcpyDeviceToHost, st));
+  {
+    const int grid = std::min(d->small_set.n, n_utt);
+    hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(NT), 0, st, dg, dc, d->small_set.d.p, d_loglikes, (int)num_pdfs,
+                       d_utts.p, (const int *)nullptr, n_utt, d_counter.p, d_res.p, d_pool.p);
+    VBH_HIP(hipGetLastError());
+    VBH_HIP(hipMemcpyAsync(d->h_res.data(), d_res.p, sizeof(UttResult) * n_utt, hipMemcpyDeviceToHost, st));
+    VBH_HIP(hipStreamSynchronize(st));
+  }
+  // utterances that outgrew a small slot are searched again in a big one
+  std::vector<int> retry;
+  for (int u = 0; u < n_utt; u++) {
+    const int e = d->h_res[u].error;
+    if (e == ERR_W_TOK || e == ERR_W_LINK || e == ERR_H_TOK || e == ERR_H_LINK || e == ERR_FRONT || e == ERR_CAND) retry.push_back(u);
+  }
+  if (!retry.empty() && getenv("VBH_DEBUG")) {
+    int cnt[16] = {0};
+    for (int u : retry) cnt[d->h_res[u].error & 15]++;
+    fprintf(stderr, "[vbh] %zu of %d utterances overflowed a small slot:", retry.size(), n_utt);
+    for (int e = 1; e < 9; e++) if (cnt[e]) fprintf(stderr, " %s x%d;", err_name(e), cnt[e]);
+    fprintf(stderr, " (frames done of first: %d)\n", d->h_res[retry[0]].num_frames);
+  }
+  if (!retry.empty()) {
+    if (d->big_set.n == 0) {
+      if (alloc_slot_set(d, &d->big_set, std::min<int>(8, (int)retry.size()), /*big=*/true)) return -1;
+    }
+    DevBuf<int> d_list;
+    if (d_list.upload(retry.data(), retry.size(), st)) return -1;
+    VBH_HIP(hipMemsetAsync(d_counter.p, 0, sizeof(int), st));
+    const int grid = std::min<int>(d->big_set.n, (int)retry.size());
+    hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(NT), 0, st, dg, dc, d->big_set.d.p, d_loglikes, (int)num_pdfs,
+                       d_utts.p, d_list.p, (int)retry.size(), d_counter.p, d_res.p, d_pool.p);
+    VBH_HIP(hipGetLastError());
+    VBH_HIP(hipMemcpyAsync(d->h_res.data(), d_res.p, sizeof(UttResult) * n_utt, hipMemcpyDeviceToHost, st));
+    VBH_HIP(hipStreamSynchronize(st));
+  }
+  d->n_retried = (int)retry.size();
   unsigned long long used[4];
   VBH_HIP(hipMemcpyAsync(used, p_cnt.p, sizeof(used), hipMemcpyDeviceToHost, st));
   VBH_HIP(hipStreamSynchronize(st));
