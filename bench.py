@@ -288,6 +288,18 @@ def main():
             "roofline": roof, "stage_ms": stage_ms,
         }
         out.update(extra)
+        # HBM traffic of the dominant kernels from the committed rocprofv3 --pmc passes of this
+        # same command (profiles/): only attached when the batch size matches that run
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_traffic.json")))
+            if tr.get("batch") == args.batch and world == 1:
+                for ro in [out["roofline"]] + [out[k] for k in ("roofline_gmm", "roofline_decode") if k in out]:
+                    b_ = tr["bytes_per_launch"].get(ro["kernel"])
+                    if b_:
+                        ro["traffic"] = b_
+                        ro["traffic_source"] = "profiles/r01_b_pmc_fetch_write_summary.csv (FETCH_SIZE + WRITE_SIZE, raw)"
+        except Exception:
+            pass
         if gathered is not None:
             out["gather"] = gathered
         if not args.no_cpu_baseline:
