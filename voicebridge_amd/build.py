@@ -51,7 +51,27 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    build_host(force=force, verbose=verbose)
     return LIB
+
+
+HOST_LIB = os.path.join(LIBDIR, "libvoicebridge_host.so")
+HOST_SOURCES = ["kaldi_io.cc", "voicebridge_api.cc", "host_capi.cc"]
+
+
+def build_host(force=False, verbose=True):
+    """C++ host layer (file formats + the reference's argv-style bin functions) over the C ABI."""
+    hdir = os.path.join(HERE, "host")
+    srcs = [os.path.join(hdir, s) for s in HOST_SOURCES]
+    deps = srcs + [os.path.join(hdir, "kaldi_io.h"), os.path.join(hdir, "voicebridge_api.h"),
+                   os.path.join(ROOT, "include", "voicebridge_hip.h"), LIB]
+    if force or any(_newer(d, HOST_LIB) for d in deps):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + hdir,
+               "-o", HOST_LIB] + srcs + ["-L" + LIBDIR, "-lvoicebridge_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return HOST_LIB
 
 
 if __name__ == "__main__":

@@ -1,0 +1,825 @@
+// kaldi_io.cc -- see kaldi_io.h.  Formats re-implemented from their on-disk description.
+#include "kaldi_io.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <sstream>
+
+namespace vbio {
+
+static void Fail(const std::string &m) { throw IoError(m); }
+
+// ------------------------------------------------------------------ basic pieces
+bool ReadBinaryHeader(std::istream &is) {
+  if (is.peek() == '\0') {
+    is.get();
+    if (is.peek() != 'B') Fail("bad binary header");
+    is.get();
+    return true;
+  }
+  return false;
+}
+
+std::string ReadToken(std::istream &is, bool binary) {
+  std::string tok;
+  if (!binary) is >> std::ws;
+  is >> tok;
+  if (is.fail()) Fail("ReadToken: stream failure");
+  if (!isspace(is.peek())) Fail("ReadToken: expected space after token " + tok);
+  is.get();
+  return tok;
+}
+
+void ExpectToken(std::istream &is, bool binary, const char *tok) {
+  const std::string t = ReadToken(is, binary);
+  if (t != tok) Fail(std::string("expected token ") + tok + ", got " + t);
+}
+
+int32_t ReadInt32(std::istream &is, bool binary) {
+  int32_t v = 0;
+  if (binary) {
+    const int sz = is.get();
+    if (sz != 4) Fail("ReadInt32: size byte " + std::to_string(sz));
+    is.read(reinterpret_cast<char *>(&v), 4);
+  } else {
+    is >> v;
+  }
+  if (is.fail()) Fail("ReadInt32: stream failure");
+  return v;
+}
+
+float ReadFloat(std::istream &is, bool binary) {
+  if (binary) {
+    const int sz = is.get();
+    if (sz == 4) { float f; is.read(reinterpret_cast<char *>(&f), 4); return f; }
+    if (sz == 8) { double d; is.read(reinterpret_cast<char *>(&d), 8); return (float)d; }
+    Fail("ReadFloat: size byte " + std::to_string(sz));
+  }
+  float f;
+  is >> f;
+  if (is.fail()) Fail("ReadFloat: stream failure");
+  return f;
+}
+
+void ReadIntVector(std::istream &is, bool binary, std::vector<int32_t> *v) {
+  if (binary) {
+    const int sz = is.get();
+    if (sz != 4) Fail("ReadIntVector: element size " + std::to_string(sz));
+    int32_t n;
+    is.read(reinterpret_cast<char *>(&n), 4);
+    if (n < 0) Fail("ReadIntVector: negative size");
+    v->resize(n);
+    if (n) is.read(reinterpret_cast<char *>(v->data()), 4 * (size_t)n);
+  } else {
+    std::string t;
+    is >> t;
+    if (t != "[") Fail("ReadIntVector: expected [");
+    v->clear();
+    while (true) {
+      is >> std::ws;
+      if (is.peek() == ']') { is.get(); break; }
+      int32_t x; is >> x;
+      if (is.fail()) Fail("ReadIntVector: bad element");
+      v->push_back(x);
+    }
+  }
+  if (is.fail()) Fail("ReadIntVector: stream failure");
+}
+
+void WriteToken(std::ostream &os, bool, const char *tok) { os << tok << ' '; }
+void WriteInt32(std::ostream &os, bool binary, int32_t v) {
+  if (binary) { os.put(4); os.write(reinterpret_cast<const char *>(&v), 4); }
+  else os << v << ' ';
+}
+
+// ------------------------------------------------------------------ CompressedMatrix codec
+// compressed-matrix.h:212-239 headers; :347-377 float<->uint16; :457-500 float<->uint8
+namespace {
+struct CmHeader { float min_value, range; int32_t num_rows, num_cols; };   // on disk (format id is the token)
+
+inline uint16_t FloatToU16(const CmHeader &h, float value) {
+  float f = (value - h.min_value) / h.range;
+  if (f > 1.0f) f = 1.0f;
+  if (f < 0.0f) f = 0.0f;
+  return (uint16_t)(int)(f * 65535 + 0.499);
+}
+inline float U16ToFloat(const CmHeader &h, uint16_t v) { return h.min_value + h.range * 1.52590218966964e-05F * v; }
+inline uint8_t FloatToChar(float p0, float p25, float p75, float p100, float value) {
+  int ans;
+  if (value < p25) {
+    float f = (value - p0) / (p25 - p0);
+    ans = (int)(f * 64 + 0.5);
+    ans = std::min(64, std::max(0, ans));
+  } else if (value < p75) {
+    float f = (value - p25) / (p75 - p25);
+    ans = 64 + (int)(f * 128 + 0.5);
+    ans = std::min(192, std::max(64, ans));
+  } else {
+    float f = (value - p75) / (p100 - p75);
+    ans = 192 + (int)(f * 63 + 0.5);
+    ans = std::min(255, std::max(192, ans));
+  }
+  return (uint8_t)ans;
+}
+inline float CharToFloat(float p0, float p25, float p75, float p100, uint8_t v) {
+  if (v <= 64) return (float)(p0 + (p25 - p0) * v * (1 / 64.0));
+  if (v <= 192) return (float)(p25 + (p75 - p25) * (v - 64) * (1 / 128.0));
+  return (float)(p75 + (p100 - p75) * (v - 192) * (1 / 63.0));
+}
+}  // namespace
+
+void CompressMatrix(const Matrix &m, std::vector<uint8_t> *blob) {
+  if (m.rows <= 0 || m.cols <= 0) Fail("CompressMatrix: empty matrix");
+  CmHeader h;
+  float mn = m.data[0], mx = m.data[0];
+  for (float v : m.data) { mn = std::min(mn, v); mx = std::max(mx, v); }
+  if (mx == mn) mx = (float)(mn + (1.0 + std::fabs(mn)));
+  if (!(mn - mn == 0) || !(mx - mx == 0)) Fail("CompressMatrix: NaN or inf in matrix");
+  h.min_value = mn; h.range = mx - mn; h.num_rows = m.rows; h.num_cols = m.cols;
+  blob->assign(sizeof(h) + (size_t)m.cols * (8 + (size_t)m.rows), 0);
+  memcpy(blob->data(), &h, sizeof(h));
+  uint16_t *pc = reinterpret_cast<uint16_t *>(blob->data() + sizeof(h));
+  uint8_t *bytes = blob->data() + sizeof(h) + (size_t)m.cols * 8;
+  std::vector<float> col(m.rows);
+  for (int c = 0; c < m.cols; c++) {
+    for (int r = 0; r < m.rows; r++) col[r] = m.at(r, c);
+    std::vector<float> s(col);
+    std::sort(s.begin(), s.end());
+    uint16_t q0, q25, q75, q100;
+    const int n = m.rows;
+    auto u16 = [&](float v) { return FloatToU16(h, v); };
+    if (n >= 5) {
+      const int q = n / 4;
+      q0 = std::min<uint16_t>(u16(s[0]), 65532);
+      q25 = std::min<uint16_t>(std::max<uint16_t>(u16(s[q]), q0 + 1), 65533);
+      q75 = std::min<uint16_t>(std::max<uint16_t>(u16(s[3 * q]), q25 + 1), 65534);
+      q100 = std::max<uint16_t>(u16(s[n - 1]), q75 + 1);
+    } else {
+      q0 = std::min<uint16_t>(u16(s[0]), 65532);
+      q25 = n > 1 ? std::min<uint16_t>(std::max<uint16_t>(u16(s[1]), q0 + 1), 65533) : (uint16_t)(q0 + 1);
+      q75 = n > 2 ? std::min<uint16_t>(std::max<uint16_t>(u16(s[2]), q25 + 1), 65534) : (uint16_t)(q25 + 1);
+      q100 = n > 3 ? std::max<uint16_t>(u16(s[3]), q75 + 1) : (uint16_t)(q75 + 1);
+    }
+    pc[c * 4 + 0] = q0; pc[c * 4 + 1] = q25; pc[c * 4 + 2] = q75; pc[c * 4 + 3] = q100;
+    const float p0 = U16ToFloat(h, q0), p25 = U16ToFloat(h, q25), p75 = U16ToFloat(h, q75), p100 = U16ToFloat(h, q100);
+    for (int r = 0; r < n; r++) bytes[(size_t)c * n + r] = FloatToChar(p0, p25, p75, p100, col[r]);
+  }
+}
+
+void WriteCompressedMatrix(std::ostream &os, const Matrix &m) {
+  // CompressedMatrix(mat) with kAutomaticMethod: speech-feature format iff rows > 8, else
+  // two-byte (compressed-matrix.cc:60-63)
+  os.put('\0'); os.put('B');
+  if (m.rows == 0) {  // empty: written as an empty "CM " header? the reference writes "CM " + zero header
+    os << "CM ";
+    CmHeader h{0, 0, 0, 0};
+    os.write(reinterpret_cast<const char *>(&h), sizeof(h));
+    return;
+  }
+  if (m.rows > 8) {
+    std::vector<uint8_t> blob;
+    CompressMatrix(m, &blob);
+    os << "CM ";
+    os.write(reinterpret_cast<const char *>(blob.data()), blob.size());
+  } else {
+    CmHeader h;
+    float mn = m.data[0], mx = m.data[0];
+    for (float v : m.data) { mn = std::min(mn, v); mx = std::max(mx, v); }
+    if (mx == mn) mx = (float)(mn + (1.0 + std::fabs(mn)));
+    h.min_value = mn; h.range = mx - mn; h.num_rows = m.rows; h.num_cols = m.cols;
+    os << "CM2 ";
+    os.write(reinterpret_cast<const char *>(&h), sizeof(h));
+    for (float v : m.data) { uint16_t q = FloatToU16(h, v); os.write(reinterpret_cast<const char *>(&q), 2); }
+  }
+}
+
+static void ReadCompressedBody(std::istream &is, const std::string &tok, Matrix *m) {
+  CmHeader h;
+  is.read(reinterpret_cast<char *>(&h), sizeof(h));
+  if (is.fail()) Fail("compressed matrix: header read failed");
+  m->rows = h.num_rows; m->cols = h.num_cols;
+  m->data.assign((size_t)h.num_rows * h.num_cols, 0.0f);
+  if (h.num_cols == 0) return;
+  if (tok == "CM") {
+    std::vector<uint16_t> pc((size_t)h.num_cols * 4);
+    is.read(reinterpret_cast<char *>(pc.data()), pc.size() * 2);
+    std::vector<uint8_t> bytes((size_t)h.num_cols * h.num_rows);
+    is.read(reinterpret_cast<char *>(bytes.data()), bytes.size());
+    for (int c = 0; c < h.num_cols; c++) {
+      const float p0 = U16ToFloat(h, pc[c * 4]), p25 = U16ToFloat(h, pc[c * 4 + 1]), p75 = U16ToFloat(h, pc[c * 4 + 2]),
+                  p100 = U16ToFloat(h, pc[c * 4 + 3]);
+      for (int r = 0; r < h.num_rows; r++) m->at(r, c) = CharToFloat(p0, p25, p75, p100, bytes[(size_t)c * h.num_rows + r]);
+    }
+  } else if (tok == "CM2") {
+    std::vector<uint16_t> d(m->data.size());
+    is.read(reinterpret_cast<char *>(d.data()), d.size() * 2);
+    const float inc = h.range * (1.0 / 65535.0);
+    for (size_t i = 0; i < d.size(); i++) m->data[i] = h.min_value + d[i] * inc;
+  } else {  // CM3
+    std::vector<uint8_t> d(m->data.size());
+    is.read(reinterpret_cast<char *>(d.data()), d.size());
+    const float inc = h.range * (1.0 / 255.0);
+    for (size_t i = 0; i < d.size(); i++) m->data[i] = h.min_value + d[i] * inc;
+  }
+  if (is.fail()) Fail("compressed matrix: data read failed");
+}
+
+// ------------------------------------------------------------------ matrices / vectors
+static void ReadTextMatrixD(std::istream &is, int32_t *rows, int32_t *cols, std::vector<double> *data) {
+  std::string t;
+  is >> t;
+  if (t != "[") Fail("text matrix: expected [");
+  data->clear();
+  *rows = 0; *cols = 0;
+  int cur = 0;
+  std::string line;
+  while (true) {
+    is >> std::ws;
+    const int c = is.peek();
+    if (c == ']') {
+      is.get();
+      if (cur) { if (*rows && cur != *cols) Fail("text matrix: ragged rows"); *cols = cur; (*rows)++; }
+      break;
+    }
+    if (c == EOF) Fail("text matrix: unexpected end");
+    double x; is >> x;
+    if (is.fail()) Fail("text matrix: bad number");
+    data->push_back(x); cur++;
+    // a newline ends the row
+    while (is.peek() == ' ' || is.peek() == '\t') is.get();
+    if (is.peek() == '\n') {
+      is.get();
+      if (*rows && cur != *cols) Fail("text matrix: ragged rows");
+      *cols = cur; (*rows)++; cur = 0;
+    }
+  }
+}
+
+void ReadMatrix(std::istream &is, bool binary, Matrix *m) {
+  if (!binary) {
+    std::vector<double> d;
+    ReadTextMatrixD(is, &m->rows, &m->cols, &d);
+    m->data.assign(d.begin(), d.end());
+    return;
+  }
+  const std::string tok = ReadToken(is, true);
+  if (tok == "CM" || tok == "CM2" || tok == "CM3") { ReadCompressedBody(is, tok, m); return; }
+  if (tok != "FM" && tok != "DM") Fail("ReadMatrix: unexpected token " + tok);
+  m->rows = ReadInt32(is, true); m->cols = ReadInt32(is, true);
+  const size_t n = (size_t)m->rows * m->cols;
+  m->data.resize(n);
+  if (tok == "FM") is.read(reinterpret_cast<char *>(m->data.data()), n * 4);
+  else {
+    std::vector<double> d(n);
+    is.read(reinterpret_cast<char *>(d.data()), n * 8);
+    for (size_t i = 0; i < n; i++) m->data[i] = (float)d[i];
+  }
+  if (is.fail()) Fail("ReadMatrix: data read failed");
+}
+
+void ReadMatrixD(std::istream &is, bool binary, MatrixD *m) {
+  if (!binary) { ReadTextMatrixD(is, &m->rows, &m->cols, &m->data); return; }
+  const std::string tok = ReadToken(is, true);
+  if (tok != "FM" && tok != "DM") Fail("ReadMatrixD: unexpected token " + tok);
+  m->rows = ReadInt32(is, true); m->cols = ReadInt32(is, true);
+  const size_t n = (size_t)m->rows * m->cols;
+  m->data.resize(n);
+  if (tok == "DM") is.read(reinterpret_cast<char *>(m->data.data()), n * 8);
+  else {
+    std::vector<float> d(n);
+    is.read(reinterpret_cast<char *>(d.data()), n * 4);
+    for (size_t i = 0; i < n; i++) m->data[i] = d[i];
+  }
+  if (is.fail()) Fail("ReadMatrixD: data read failed");
+}
+
+void ReadVector(std::istream &is, bool binary, std::vector<float> *v) {
+  if (!binary) {
+    std::string t; is >> t;
+    if (t != "[") Fail("text vector: expected [");
+    v->clear();
+    while (true) {
+      is >> std::ws;
+      if (is.peek() == ']') { is.get(); break; }
+      float x; is >> x;
+      if (is.fail()) Fail("text vector: bad number");
+      v->push_back(x);
+    }
+    return;
+  }
+  const std::string tok = ReadToken(is, true);
+  if (tok != "FV" && tok != "DV") Fail("ReadVector: unexpected token " + tok);
+  const int32_t n = ReadInt32(is, true);
+  v->resize(n);
+  if (tok == "FV") is.read(reinterpret_cast<char *>(v->data()), (size_t)n * 4);
+  else {
+    std::vector<double> d(n);
+    is.read(reinterpret_cast<char *>(d.data()), (size_t)n * 8);
+    for (int i = 0; i < n; i++) (*v)[i] = (float)d[i];
+  }
+  if (is.fail()) Fail("ReadVector: data read failed");
+}
+
+void WriteMatrix(std::ostream &os, bool binary, const Matrix &m) {
+  if (binary) {
+    os.put('\0'); os.put('B');
+    os << "FM ";
+    WriteInt32(os, true, m.rows); WriteInt32(os, true, m.cols);
+    os.write(reinterpret_cast<const char *>(m.data.data()), m.data.size() * 4);
+  } else {
+    if (m.cols == 0) { os << " [ ]\n"; return; }
+    os << " [";
+    for (int r = 0; r < m.rows; r++) {
+      os << "\n  ";
+      for (int c = 0; c < m.cols; c++) os << m.at(r, c) << " ";
+    }
+    os << "]\n";
+  }
+}
+
+void WriteMatrixD(std::ostream &os, bool binary, const MatrixD &m) {
+  if (binary) {
+    os.put('\0'); os.put('B');
+    os << "DM ";
+    WriteInt32(os, true, m.rows); WriteInt32(os, true, m.cols);
+    os.write(reinterpret_cast<const char *>(m.data.data()), m.data.size() * 8);
+  } else {
+    os.precision(17);
+    os << " [";
+    for (int r = 0; r < m.rows; r++) {
+      os << "\n  ";
+      for (int c = 0; c < m.cols; c++) os << m.data[(size_t)r * m.cols + c] << " ";
+    }
+    os << "]\n";
+  }
+}
+
+// ------------------------------------------------------------------ tables
+static std::vector<std::string> Split(const std::string &s, char sep) {
+  std::vector<std::string> out;
+  std::string cur;
+  for (char c : s) { if (c == sep) { out.push_back(cur); cur.clear(); } else cur += c; }
+  out.push_back(cur);
+  return out;
+}
+
+Rspec ParseRspecifier(const std::string &s) {
+  const size_t p = s.find(':');
+  if (p == std::string::npos) Fail("bad rspecifier: " + s);
+  Rspec r;
+  bool ok = false;
+  for (const std::string &o : Split(s.substr(0, p), ',')) {
+    if (o == "ark") ok = true;
+    else if (o == "scp") { r.is_scp = true; ok = true; }
+    else if (o == "t") r.text = true;
+    // s, cs, p, o, ns, ncs, np, b: ordering/permissive hints with no effect on the content
+  }
+  if (!ok) Fail("bad rspecifier: " + s);
+  r.path = s.substr(p + 1);
+  return r;
+}
+
+Wspec ParseWspecifier(const std::string &s) {
+  const size_t p = s.find(':');
+  if (p == std::string::npos) Fail("bad wspecifier: " + s);
+  Wspec w;
+  std::vector<std::string> kinds;
+  for (const std::string &o : Split(s.substr(0, p), ',')) {
+    if (o == "ark" || o == "scp") kinds.push_back(o);
+    else if (o == "t") w.text = true;
+  }
+  const std::string rest = s.substr(p + 1);
+  if (kinds.size() == 1 && kinds[0] == "ark") { w.has_ark = true; w.ark_path = rest; }
+  else if (kinds.size() == 2 && kinds[0] == "ark" && kinds[1] == "scp") {
+    const size_t c = rest.find(',');
+    if (c == std::string::npos) Fail("bad wspecifier: " + s);
+    w.has_ark = true; w.has_scp = true; w.ark_path = rest.substr(0, c); w.scp_path = rest.substr(c + 1);
+  } else Fail("unsupported wspecifier: " + s);
+  return w;
+}
+
+std::vector<ScpEntry> ReadScp(const std::string &path) {
+  std::ifstream f(path);
+  if (!f) Fail("cannot open script file " + path);
+  std::vector<ScpEntry> out;
+  std::string line;
+  while (std::getline(f, line)) {
+    if (line.empty()) continue;
+    const size_t sp = line.find_first_of(" \t");
+    if (sp == std::string::npos) Fail("bad scp line: " + line);
+    ScpEntry e;
+    e.key = line.substr(0, sp);
+    std::string rest = line.substr(line.find_first_not_of(" \t", sp));
+    while (!rest.empty() && (rest.back() == '\r' || rest.back() == ' ')) rest.pop_back();
+    const size_t colon = rest.rfind(':');
+    if (colon != std::string::npos && colon + 1 < rest.size() &&
+        rest.find_first_not_of("0123456789", colon + 1) == std::string::npos && colon > 1) {
+      e.offset = std::stoll(rest.substr(colon + 1));
+      e.path = rest.substr(0, colon);
+    } else e.path = rest;
+    out.push_back(e);
+  }
+  return out;
+}
+
+static std::string ReadArkKey(std::istream &is) {
+  std::string key;
+  is >> std::ws;
+  if (is.peek() == EOF) return "";
+  is >> key;
+  if (is.fail()) return "";
+  if (is.peek() != ' ' && is.peek() != '\t' && is.peek() != '\n') Fail("archive: expected space after key " + key);
+  is.get();
+  return key;
+}
+
+MatrixReader::MatrixReader(const std::string &rspecifier) : spec_(ParseRspecifier(rspecifier)) {
+  if (spec_.is_scp) scp_ = ReadScp(spec_.path);
+  else {
+    ark_.open(spec_.path, std::ios::binary);
+    if (!ark_) Fail("cannot open archive " + spec_.path);
+  }
+}
+
+bool MatrixReader::Next(std::string *key, Matrix *m) {
+  if (spec_.is_scp) {
+    if (pos_ >= scp_.size()) return false;
+    const ScpEntry &e = scp_[pos_++];
+    std::ifstream f(e.path, std::ios::binary);
+    if (!f) Fail("cannot open " + e.path);
+    if (e.offset >= 0) f.seekg(e.offset);
+    const bool binary = ReadBinaryHeader(f);
+    ReadMatrix(f, binary, m);
+    *key = e.key;
+    return true;
+  }
+  *key = ReadArkKey(ark_);
+  if (key->empty()) return false;
+  const bool binary = ReadBinaryHeader(ark_);
+  ReadMatrix(ark_, binary, m);
+  return true;
+}
+
+std::map<std::string, Matrix> ReadMatrixTable(const std::string &rspecifier) {
+  std::map<std::string, Matrix> out;
+  MatrixReader r(rspecifier);
+  std::string k; Matrix m;
+  while (r.Next(&k, &m)) out[k] = m;
+  return out;
+}
+
+std::map<std::string, MatrixD> ReadMatrixDTable(const std::string &rspecifier) {
+  std::map<std::string, MatrixD> out;
+  const Rspec spec = ParseRspecifier(rspecifier);
+  auto read_one = [&](std::istream &is, const std::string &key) {
+    const bool binary = ReadBinaryHeader(is);
+    MatrixD m; ReadMatrixD(is, binary, &m);
+    out[key] = m;
+  };
+  if (spec.is_scp) {
+    for (const ScpEntry &e : ReadScp(spec.path)) {
+      std::ifstream f(e.path, std::ios::binary);
+      if (!f) Fail("cannot open " + e.path);
+      if (e.offset >= 0) f.seekg(e.offset);
+      read_one(f, e.key);
+    }
+  } else {
+    std::ifstream f(spec.path, std::ios::binary);
+    if (!f) Fail("cannot open archive " + spec.path);
+    while (true) {
+      const std::string key = ReadArkKey(f);
+      if (key.empty()) break;
+      read_one(f, key);
+    }
+  }
+  return out;
+}
+
+std::map<std::string, std::string> ReadStringMap(const std::string &rspecifier) {
+  const Rspec spec = ParseRspecifier(rspecifier);
+  std::ifstream f(spec.path);
+  if (!f) Fail("cannot open " + spec.path);
+  std::map<std::string, std::string> out;
+  std::string line;
+  while (std::getline(f, line)) {
+    std::istringstream ss(line);
+    std::string k, v;
+    if (ss >> k >> v) out[k] = v;
+  }
+  return out;
+}
+
+MatrixWriter::MatrixWriter(const std::string &wspecifier, bool compress) : spec_(ParseWspecifier(wspecifier)), compress_(compress) {
+  ark_.open(spec_.ark_path, std::ios::binary);
+  if (!ark_) Fail("cannot open " + spec_.ark_path + " for writing");
+  if (spec_.has_scp) {
+    scp_.open(spec_.scp_path);
+    if (!scp_) Fail("cannot open " + spec_.scp_path + " for writing");
+  }
+}
+
+void MatrixWriter::Write(const std::string &key, const Matrix &m) {
+  ark_ << key << ' ';
+  const int64_t off = (int64_t)ark_.tellp();
+  if (spec_.text) WriteMatrix(ark_, false, m);
+  else if (compress_) WriteCompressedMatrix(ark_, m);
+  else WriteMatrix(ark_, true, m);
+  if (spec_.has_scp) scp_ << key << ' ' << spec_.ark_path << ':' << off << '\n';
+  if (ark_.fail()) Fail("write failure on " + spec_.ark_path);
+}
+
+void MatrixWriter::Close() { ark_.close(); if (spec_.has_scp) scp_.close(); }
+
+void IntVectorWriter::Open(const std::string &wspecifier) {
+  spec_ = ParseWspecifier(wspecifier);
+  ark_.open(spec_.ark_path, std::ios::binary);
+  if (!ark_) Fail("cannot open " + spec_.ark_path + " for writing");
+  open_ = true;
+}
+
+void IntVectorWriter::Write(const std::string &key, const std::vector<int32_t> &v) {
+  ark_ << key << ' ';
+  if (spec_.text) {
+    for (int32_t x : v) ark_ << x << ' ';
+    ark_ << '\n';
+  } else {
+    ark_.put('\0'); ark_.put('B');
+    ark_.put(4);
+    const int32_t n = (int32_t)v.size();
+    ark_.write(reinterpret_cast<const char *>(&n), 4);
+    if (n) ark_.write(reinterpret_cast<const char *>(v.data()), 4 * (size_t)n);
+  }
+}
+
+// ------------------------------------------------------------------ wave (wave-reader.cc:137-310)
+void ReadWave(std::istream &is, Wave *w) {
+  auto rd32 = [&]() { uint32_t v = 0; is.read(reinterpret_cast<char *>(&v), 4); return v; };
+  auto rd16 = [&]() { uint16_t v = 0; is.read(reinterpret_cast<char *>(&v), 2); return v; };
+  char tag[5] = {0};
+  is.read(tag, 4);
+  if (std::string(tag) != "RIFF") Fail("wave: expected RIFF");
+  rd32();
+  is.read(tag, 4);
+  if (std::string(tag) != "WAVE") Fail("wave: expected WAVE");
+  bool have_fmt = false;
+  uint16_t fmt = 0, channels = 0, bits = 0, block_align = 0;
+  uint32_t rate = 0;
+  while (true) {
+    is.read(tag, 4);
+    if (is.fail()) Fail("wave: no data chunk");
+    uint32_t size = rd32();
+    const std::string t(tag, 4);
+    if (t == "fmt ") {
+      fmt = rd16(); channels = rd16(); rate = rd32(); rd32(); block_align = rd16(); bits = rd16();
+      uint32_t used = 16;
+      if (fmt == 0xFFFE && size >= 40) {   // WAVE_FORMAT_EXTENSIBLE: sub-format GUID starts with the real tag
+        rd16(); rd16(); rd32(); fmt = rd16(); used = 26;
+        for (int i = 0; i < 14; i++) is.get();
+        used = 40;
+      }
+      for (uint32_t i = used; i < size; i++) is.get();
+      have_fmt = true;
+    } else if (t == "data") {
+      if (!have_fmt) Fail("wave: data before fmt");
+      if (fmt != 1) Fail("wave: can read only PCM data, format tag " + std::to_string(fmt));
+      if (bits != 16) Fail("wave: unsupported bits per sample " + std::to_string(bits));
+      if (channels == 0) Fail("wave: no channels");
+      std::vector<char> raw;
+      if (size == 0xFFFFFFFFu || size == 0) {   // streamed: read to the end
+        raw.assign(std::istreambuf_iterator<char>(is), std::istreambuf_iterator<char>());
+      } else {
+        raw.resize(size);
+        is.read(raw.data(), size);
+        raw.resize((size_t)is.gcount());
+      }
+      const size_t frame = (size_t)channels * 2;
+      const size_t n = raw.size() / frame;
+      w->samp_freq = (float)rate; w->channels = channels;
+      w->data.assign(channels, std::vector<float>(n));
+      const int16_t *p = reinterpret_cast<const int16_t *>(raw.data());
+      for (size_t i = 0; i < n; i++)
+        for (int c = 0; c < channels; c++) w->data[c][i] = (float)p[i * channels + c];
+      (void)block_align;
+      return;
+    } else {
+      for (uint32_t i = 0; i < size + (size & 1); i++) is.get();
+    }
+  }
+}
+
+void ReadWaveFile(const std::string &path, int64_t offset, Wave *w) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) Fail("cannot open wave file " + path);
+  if (offset >= 0) f.seekg(offset);
+  ReadWave(f, w);
+}
+
+// ------------------------------------------------------------------ model
+namespace {
+struct HmmState { int32_t fwd, self; std::vector<std::pair<int32_t, float>> trans; };
+}
+
+void ReadModel(const std::string &path, Model *m) {
+  std::ifstream is(path, std::ios::binary);
+  if (!is) Fail("cannot open model " + path);
+  const bool binary = ReadBinaryHeader(is);
+  if (!binary) Fail("text-mode .mdl is not supported: " + path);
+  // ---- TransitionModel (transition-model.cc:383-409)
+  ExpectToken(is, binary, "<TransitionModel>");
+  ExpectToken(is, binary, "<Topology>");
+  std::vector<int32_t> phones, phone2idx;
+  ReadIntVector(is, binary, &phones);
+  ReadIntVector(is, binary, &phone2idx);
+  int32_t sz = ReadInt32(is, binary);
+  bool is_hmm = true;
+  if (sz == -1) { is_hmm = false; sz = ReadInt32(is, binary); }
+  std::vector<std::vector<HmmState>> entries(sz);
+  for (int32_t i = 0; i < sz; i++) {
+    const int32_t n = ReadInt32(is, binary);
+    entries[i].resize(n);
+    for (int32_t j = 0; j < n; j++) {
+      entries[i][j].fwd = ReadInt32(is, binary);
+      entries[i][j].self = is_hmm ? entries[i][j].fwd : ReadInt32(is, binary);
+      const int32_t nt = ReadInt32(is, binary);
+      entries[i][j].trans.resize(nt);
+      for (int32_t k = 0; k < nt; k++) {
+        entries[i][j].trans[k].first = ReadInt32(is, binary);
+        entries[i][j].trans[k].second = ReadFloat(is, binary);
+      }
+    }
+  }
+  ExpectToken(is, binary, "</Topology>");
+  const std::string tok = ReadToken(is, binary);
+  if (tok != "<Triples>" && tok != "<Tuples>") Fail("model: expected <Triples> or <Tuples>, got " + tok);
+  const int32_t ntup = ReadInt32(is, binary);
+  struct Tuple { int32_t phone, hmm_state, fwd, self; };
+  std::vector<Tuple> tuples(ntup);
+  for (int32_t i = 0; i < ntup; i++) {
+    tuples[i].phone = ReadInt32(is, binary);
+    tuples[i].hmm_state = ReadInt32(is, binary);
+    tuples[i].fwd = ReadInt32(is, binary);
+    tuples[i].self = (tok == "<Tuples>") ? ReadInt32(is, binary) : tuples[i].fwd;
+  }
+  const std::string endtok = ReadToken(is, binary);
+  if (endtok != "</Triples>" && endtok != "</Tuples>") Fail("model: bad tuple terminator " + endtok);
+  // ComputeDerived (transition-model.cc:144-177): transition-ids in tuple order, one per
+  // transition of the tuple's HMM state; a self-loop uses the self-loop pdf
+  m->tid2pdf.assign(1, -1);
+  for (const Tuple &t : tuples) {
+    if (t.phone < 0 || t.phone >= (int32_t)phone2idx.size() || phone2idx[t.phone] < 0) Fail("model: tuple phone without topology");
+    const std::vector<HmmState> &e = entries[phone2idx[t.phone]];
+    if (t.hmm_state < 0 || t.hmm_state >= (int32_t)e.size()) Fail("model: bad hmm state in tuple");
+    for (const auto &tr : e[t.hmm_state].trans) m->tid2pdf.push_back(tr.first == t.hmm_state ? t.self : t.fwd);
+  }
+  ExpectToken(is, binary, "<LogProbs>");
+  std::vector<float> logprobs;
+  ReadVector(is, binary, &logprobs);
+  ExpectToken(is, binary, "</LogProbs>");
+  ExpectToken(is, binary, "</TransitionModel>");
+  // ---- AmDiagGmm (am-diag-gmm.cc:147-161)
+  ExpectToken(is, binary, "<DIMENSION>");
+  m->dim = ReadInt32(is, binary);
+  ExpectToken(is, binary, "<NUMPDFS>");
+  m->num_pdfs = ReadInt32(is, binary);
+  m->pdf_offsets.assign(1, 0);
+  m->weights.clear(); m->means_invvars.clear(); m->inv_vars.clear(); m->gconsts_in_file.clear();
+  for (int32_t p = 0; p < m->num_pdfs; p++) {
+    std::string t = ReadToken(is, binary);
+    if (t != "<DiagGMMBegin>" && t != "<DiagGMM>") Fail("model: expected <DiagGMM>, got " + t);
+    t = ReadToken(is, binary);
+    std::vector<float> gc, w;
+    if (t == "<GCONSTS>") { ReadVector(is, binary, &gc); t = ReadToken(is, binary); }
+    if (t != "<WEIGHTS>") Fail("model: expected <WEIGHTS>, got " + t);
+    ReadVector(is, binary, &w);
+    ExpectToken(is, binary, "<MEANS_INVVARS>");
+    Matrix miv; ReadMatrix(is, binary, &miv);
+    ExpectToken(is, binary, "<INV_VARS>");
+    Matrix iv; ReadMatrix(is, binary, &iv);
+    t = ReadToken(is, binary);
+    if (t != "<DiagGMMEnd>" && t != "</DiagGMM>") Fail("model: expected </DiagGMM>, got " + t);
+    if (miv.cols != m->dim || iv.cols != m->dim || miv.rows != (int32_t)w.size() || iv.rows != miv.rows) Fail("model: inconsistent GMM sizes");
+    m->weights.insert(m->weights.end(), w.begin(), w.end());
+    m->means_invvars.insert(m->means_invvars.end(), miv.data.begin(), miv.data.end());
+    m->inv_vars.insert(m->inv_vars.end(), iv.data.begin(), iv.data.end());
+    m->gconsts_in_file.insert(m->gconsts_in_file.end(), gc.begin(), gc.end());
+    m->pdf_offsets.push_back(m->pdf_offsets.back() + (int32_t)w.size());
+  }
+}
+
+// ------------------------------------------------------------------ OpenFst binary
+namespace {
+std::string ReadFstString(std::istream &is) {
+  int32_t n = 0;
+  is.read(reinterpret_cast<char *>(&n), 4);
+  if (n < 0 || n > 1024) Fail("fst: bad string length");
+  std::string s(n, ' ');
+  if (n) is.read(&s[0], n);
+  return s;
+}
+void WriteFstString(std::ostream &os, const std::string &s) {
+  const int32_t n = (int32_t)s.size();
+  os.write(reinterpret_cast<const char *>(&n), 4);
+  os.write(s.data(), n);
+}
+constexpr int32_t kFstMagic = 2125659606;
+}  // namespace
+
+void ReadFst(const std::string &path, Graph *g) {
+  std::ifstream is(path, std::ios::binary);
+  if (!is) Fail("cannot open fst " + path);
+  int32_t magic = 0;
+  is.read(reinterpret_cast<char *>(&magic), 4);
+  if (magic != kFstMagic) Fail("fst: bad magic number in " + path);
+  const std::string fsttype = ReadFstString(is), arctype = ReadFstString(is);
+  int32_t version, flags;
+  uint64_t props;
+  int64_t start, nstates, narcs;
+  is.read(reinterpret_cast<char *>(&version), 4);
+  is.read(reinterpret_cast<char *>(&flags), 4);
+  is.read(reinterpret_cast<char *>(&props), 8);
+  is.read(reinterpret_cast<char *>(&start), 8);
+  is.read(reinterpret_cast<char *>(&nstates), 8);
+  is.read(reinterpret_cast<char *>(&narcs), 8);
+  if (is.fail()) Fail("fst: truncated header");
+  if (arctype != "standard") Fail("fst: arc type " + arctype + " not supported (need standard)");
+  if (flags & 3) Fail("fst: embedded symbol tables are not supported");
+  g->start = (int32_t)start;
+  if (fsttype == "const") {
+    const bool aligned = (flags & 4) || version == 1;
+    auto align = [&]() { while (is.tellg() % 16 != 0) is.get(); };
+    if (aligned) align();
+    struct ConstState { float final; uint32_t pos, narcs, niepsilons, noepsilons; };
+    std::vector<ConstState> st(nstates);
+    is.read(reinterpret_cast<char *>(st.data()), sizeof(ConstState) * (size_t)nstates);
+    if (aligned) align();
+    g->arcs.resize(narcs);
+    is.read(reinterpret_cast<char *>(g->arcs.data()), sizeof(Arc) * (size_t)narcs);
+    if (is.fail()) Fail("fst: truncated const fst");
+    g->final_cost.resize(nstates); g->arc_offset.resize(nstates + 1);
+    for (int64_t s = 0; s < nstates; s++) { g->final_cost[s] = st[s].final; g->arc_offset[s] = st[s].pos; }
+    g->arc_offset[nstates] = narcs;
+  } else if (fsttype == "vector") {
+    g->final_cost.clear(); g->arc_offset.assign(1, 0); g->arcs.clear();
+    for (int64_t s = 0; s < nstates; s++) {
+      float fin; int64_t na;
+      is.read(reinterpret_cast<char *>(&fin), 4);
+      is.read(reinterpret_cast<char *>(&na), 8);
+      if (is.fail() || na < 0) Fail("fst: truncated vector fst");
+      g->final_cost.push_back(fin);
+      const size_t old = g->arcs.size();
+      g->arcs.resize(old + na);
+      if (na) is.read(reinterpret_cast<char *>(g->arcs.data() + old), sizeof(Arc) * (size_t)na);
+      g->arc_offset.push_back((int64_t)g->arcs.size());
+    }
+    if (is.fail()) Fail("fst: truncated vector fst");
+  } else Fail("fst: type " + fsttype + " not supported (need const or vector)");
+}
+
+void LatticeWriter::Open(const std::string &wspecifier) {
+  spec_ = ParseWspecifier(wspecifier);
+  if (spec_.text) Fail("text-mode lattice output is not supported");
+  ark_.open(spec_.ark_path, std::ios::binary);
+  if (!ark_) Fail("cannot open " + spec_.ark_path + " for writing");
+  open_ = true;
+}
+
+// VectorFst<LatticeArc>::Write with default options inside an archive entry
+// (kaldi-lattice.cc:388-394; vector-fst.h WriteFst): header, then per state the final weight
+// (two floats), int64 arc count, arcs {ilabel, olabel, graph, acoustic, nextstate}
+void LatticeWriter::Write(const std::string &key, const LatticeOut &lat) {
+  ark_ << key << ' ';
+  const int64_t ns = (int64_t)lat.arcs.size();
+  int64_t na = 0;
+  for (const auto &a : lat.arcs) na += (int64_t)a.size();
+  ark_.write(reinterpret_cast<const char *>(&kFstMagic), 4);
+  WriteFstString(ark_, "vector");
+  WriteFstString(ark_, "lattice4");
+  const int32_t version = 2, flags = 0;
+  const uint64_t props = 3;          // kExpanded | kMutable; everything else unknown
+  const int64_t start = ns ? 0 : -1;
+  ark_.write(reinterpret_cast<const char *>(&version), 4);
+  ark_.write(reinterpret_cast<const char *>(&flags), 4);
+  ark_.write(reinterpret_cast<const char *>(&props), 8);
+  ark_.write(reinterpret_cast<const char *>(&start), 8);
+  ark_.write(reinterpret_cast<const char *>(&ns), 8);
+  ark_.write(reinterpret_cast<const char *>(&na), 8);
+  for (int64_t s = 0; s < ns; s++) {
+    const float fg = lat.final_graph[s], fa = std::isinf(fg) ? std::numeric_limits<float>::infinity() : lat.final_acoustic[s];
+    ark_.write(reinterpret_cast<const char *>(&fg), 4);
+    ark_.write(reinterpret_cast<const char *>(&fa), 4);
+    const int64_t n = (int64_t)lat.arcs[s].size();
+    ark_.write(reinterpret_cast<const char *>(&n), 8);
+    for (const LatticeArcOut &a : lat.arcs[s]) {
+      ark_.write(reinterpret_cast<const char *>(&a.ilabel), 4);
+      ark_.write(reinterpret_cast<const char *>(&a.olabel), 4);
+      ark_.write(reinterpret_cast<const char *>(&a.graph), 4);
+      ark_.write(reinterpret_cast<const char *>(&a.acoustic), 4);
+      ark_.write(reinterpret_cast<const char *>(&a.nextstate), 4);
+    }
+  }
+  if (ark_.fail()) Fail("write failure on " + spec_.ark_path);
+}
+
+}  // namespace vbio

@@ -1,0 +1,152 @@
+// kaldi_io.h -- readers/writers for the on-disk formats the hot path touches.
+// These are *formats*, re-implemented from their description; nothing of Kaldi/OpenFst is
+// linked or copied.  Reference definitions (paths relative to /root/reference):
+//   binary header "\0B", tokens, basic ints   kaldi-master/src/base/io-funcs-inl.h:34-52,291-325
+//   Matrix "FM "/"DM ", Vector "FV "/"DV "   kaldi-master/src/matrix/kaldi-matrix.cc:1375-1401, kaldi-vector.cc:1221-1227
+//   CompressedMatrix "CM"/"CM2"/"CM3"         kaldi-master/src/matrix/compressed-matrix.cc:129-187,347-600
+//   archives / script files                    kaldi-master/src/util/kaldi-table-inl.h:1055,1370-1382
+//   RIFF PCM-16                                kaldi-master/src/feat/wave-reader.cc:137-310
+//   .mdl = TransitionModel + AmDiagGmm         kaldi-master/src/hmm/transition-model.cc:383-409, hmm/hmm-topology.cc:127-160,
+//                                              gmm/am-diag-gmm.cc:147-161, gmm/diag-gmm.cc:705-756
+//   ConstFst / VectorFst<StdArc>               openfst-win-1.6/src/include/fst/const-fst.h:102-110,195-330, vector-fst.h, fst.h (FstHeader)
+//   Lattice (VectorFst<LatticeArc>)            kaldi-master/src/lat/kaldi-lattice.cc:62-90,388-413
+#ifndef VOICEBRIDGE_KALDI_IO_H_
+#define VOICEBRIDGE_KALDI_IO_H_
+
+#include <cstdint>
+#include <fstream>
+#include <istream>
+#include <map>
+#include <ostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace vbio {
+
+struct IoError : public std::runtime_error {
+  explicit IoError(const std::string &m) : std::runtime_error(m) {}
+};
+
+struct Matrix {            // row-major float32, no stride padding
+  int32_t rows = 0, cols = 0;
+  std::vector<float> data;
+  float &at(int r, int c) { return data[(size_t)r * cols + c]; }
+  float at(int r, int c) const { return data[(size_t)r * cols + c]; }
+};
+struct MatrixD { int32_t rows = 0, cols = 0; std::vector<double> data; };
+
+// ---- basic binary pieces
+bool ReadBinaryHeader(std::istream &is);                    // consumes "\0B" if present; returns binary flag
+void ExpectToken(std::istream &is, bool binary, const char *tok);
+std::string ReadToken(std::istream &is, bool binary);
+int32_t ReadInt32(std::istream &is, bool binary);
+float ReadFloat(std::istream &is, bool binary);
+void ReadIntVector(std::istream &is, bool binary, std::vector<int32_t> *v);
+void WriteToken(std::ostream &os, bool binary, const char *tok);
+void WriteInt32(std::ostream &os, bool binary, int32_t v);
+
+// ---- matrices / vectors (object body, after the optional "\0B")
+void ReadMatrix(std::istream &is, bool binary, Matrix *m);          // FM / DM / CM / CM2 / CM3 / text
+void ReadMatrixD(std::istream &is, bool binary, MatrixD *m);        // DM / FM / text (CMVN stats)
+void ReadVector(std::istream &is, bool binary, std::vector<float> *v);
+void WriteMatrix(std::ostream &os, bool binary, const Matrix &m);   // "FM "
+void WriteMatrixD(std::ostream &os, bool binary, const MatrixD &m); // "DM "
+// CompressedMatrix, speech-feature format ("CM "): bit-exact with the reference's writer
+void CompressMatrix(const Matrix &m, std::vector<uint8_t> *blob);   // header(16) + col headers + bytes
+void WriteCompressedMatrix(std::ostream &os, const Matrix &m);      // "CM " + blob; falls back to "FM " when rows <= 8? no: see .cc
+
+// ---- tables
+struct ScpEntry { std::string key, path; int64_t offset = -1; };
+std::vector<ScpEntry> ReadScp(const std::string &path);
+struct Rspec { bool is_scp = false, text = false; std::string path; };
+struct Wspec { bool has_ark = false, has_scp = false, text = false; std::string ark_path, scp_path; };
+Rspec ParseRspecifier(const std::string &s);
+Wspec ParseWspecifier(const std::string &s);
+
+// sequential reader over "ark:" or "scp:" of matrices
+class MatrixReader {
+ public:
+  explicit MatrixReader(const std::string &rspecifier);
+  bool Next(std::string *key, Matrix *m);   // false at end
+ private:
+  Rspec spec_;
+  std::ifstream ark_;
+  std::vector<ScpEntry> scp_;
+  size_t pos_ = 0;
+};
+// all entries of a table of matrices keyed by utterance/speaker (transforms, cmvn stats)
+std::map<std::string, Matrix> ReadMatrixTable(const std::string &rspecifier);
+std::map<std::string, MatrixD> ReadMatrixDTable(const std::string &rspecifier);
+std::map<std::string, std::string> ReadStringMap(const std::string &rspecifier);   // utt2spk
+
+class MatrixWriter {   // "ark:", "ark,t:", "ark,scp:a,b", "scp:"? (scp alone is not a valid wspecifier)
+ public:
+  explicit MatrixWriter(const std::string &wspecifier, bool compress = false);
+  void Write(const std::string &key, const Matrix &m);
+  void Close();
+ private:
+  Wspec spec_;
+  bool compress_;
+  std::ofstream ark_, scp_;
+};
+
+class IntVectorWriter {   // Int32VectorWriter, text or binary
+ public:
+  IntVectorWriter() {}
+  explicit IntVectorWriter(const std::string &wspecifier) { Open(wspecifier); }
+  void Open(const std::string &wspecifier);
+  bool IsOpen() const { return open_; }
+  void Write(const std::string &key, const std::vector<int32_t> &v);
+ private:
+  Wspec spec_;
+  bool open_ = false;
+  std::ofstream ark_;
+};
+
+// ---- wave
+struct Wave { float samp_freq = 0; int channels = 0; std::vector<std::vector<float>> data; };
+void ReadWave(std::istream &is, Wave *w);
+void ReadWaveFile(const std::string &path, int64_t offset, Wave *w);
+// wav.scp entries may be "key path" (plain files); pipes ("cmd |") are not supported
+
+// ---- model
+struct Model {
+  // TransitionModel: id2pdf_id_ (index 0 unused) -- K/hmm/transition-model.cc:144-177
+  std::vector<int32_t> tid2pdf;
+  int32_t num_pdfs = 0, dim = 0;
+  std::vector<int32_t> pdf_offsets;            // [num_pdfs+1]
+  std::vector<float> weights, means_invvars, inv_vars, gconsts_in_file;
+};
+void ReadModel(const std::string &path, Model *m);
+
+// ---- graphs
+struct Arc { int32_t ilabel, olabel; float weight; int32_t nextstate; };
+struct Graph {
+  int32_t start = -1;
+  std::vector<float> final_cost;               // +inf = not final
+  std::vector<int64_t> arc_offset;             // [S+1]
+  std::vector<Arc> arcs;
+};
+void ReadFst(const std::string &path, Graph *g);   // "const" or "vector", arc type "standard"
+
+// raw lattice: one state per token, as GetRawLattice builds it
+struct LatticeArcOut { int32_t ilabel, olabel; float graph, acoustic; int32_t nextstate; };
+struct LatticeOut {
+  std::vector<std::vector<LatticeArcOut>> arcs;   // per state
+  std::vector<float> final_graph, final_acoustic; // +inf graph = not final
+};
+class LatticeWriter {   // LatticeWriter ("Lattice" holder), binary archives
+ public:
+  LatticeWriter() {}
+  void Open(const std::string &wspecifier);
+  bool IsOpen() const { return open_; }
+  void Write(const std::string &key, const LatticeOut &lat);
+ private:
+  Wspec spec_;
+  bool open_ = false;
+  std::ofstream ark_;
+};
+
+}  // namespace vbio
+#endif

@@ -1,0 +1,651 @@
+// voicebridge_api.cc -- argv-style bin functions of the hot path on top of the C ABI.
+// See voicebridge_api.h for the reference declarations each one mirrors.  The bodies follow the
+// control flow of the reference wrappers (table in -> per-utterance op -> table out, counters,
+// return codes) but batch the utterances of a table through the GPU.
+#include "voicebridge_api.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "kaldi_io.h"
+#include "voicebridge_hip.h"
+
+namespace {
+
+thread_local int g_device = 0;
+thread_local vbh_ctx *g_ctx = nullptr;
+thread_local int g_ctx_device = -1;
+
+struct ApiError : public std::runtime_error {
+  explicit ApiError(const std::string &m) : std::runtime_error(m) {}
+};
+
+void Check(int rc, const char *what) {
+  if (rc != 0) throw ApiError(std::string(what) + ": " + vbh_last_error());
+}
+
+vbh_ctx *Ctx() {
+  if (g_ctx && g_ctx_device == g_device) return g_ctx;
+  if (g_ctx) { vbh_ctx_destroy(g_ctx); g_ctx = nullptr; }
+  Check(vbh_ctx_create(g_device, &g_ctx), "vbh_ctx_create");
+  g_ctx_device = g_device;
+  return g_ctx;
+}
+
+struct Log {
+  std::ofstream *f;
+  explicit Log(std::ofstream *file) : f(file) {}
+  std::ostream &os() { return (f && f->is_open()) ? static_cast<std::ostream &>(*f) : std::cerr; }
+};
+
+// ---- Kaldi command-line grammar (K/util/parse-options.cc:341-352,477-508): --name=value,
+// --flag (boolean true), --config=file with one option per line, "--" ends the options
+struct Options {
+  std::map<std::string, std::string> kv;
+  std::vector<std::string> args;
+  std::map<std::string, bool> known;
+  void Know(std::initializer_list<const char *> names) { for (const char *n : names) known[n] = true; }
+  static std::string Norm(std::string s) { for (char &c : s) if (c == '_') c = '-'; return s; }
+  void Set(const std::string &opt) {
+    const size_t eq = opt.find('=');
+    const std::string name = Norm(opt.substr(2, eq == std::string::npos ? std::string::npos : eq - 2));
+    const std::string val = eq == std::string::npos ? "true" : opt.substr(eq + 1);
+    if (name == "config") { ReadConfig(val); return; }
+    if (name == "verbose" || name == "print-args" || name == "help") return;
+    if (!known.count(name)) throw ApiError("invalid option --" + name);
+    kv[name] = val;
+  }
+  void ReadConfig(const std::string &path) {
+    std::ifstream f(path);
+    if (!f) throw ApiError("cannot open config file " + path);
+    std::string line;
+    while (std::getline(f, line)) {
+      const size_t h = line.find('#');
+      if (h != std::string::npos) line = line.substr(0, h);
+      const size_t a = line.find_first_not_of(" \t\r");
+      if (a == std::string::npos) continue;
+      const size_t b = line.find_last_not_of(" \t\r");
+      line = line.substr(a, b - a + 1);
+      if (line.compare(0, 2, "--") != 0) throw ApiError("bad line in config file " + path + ": " + line);
+      Set(line);
+    }
+  }
+  void Parse(int argc, char *argv[]) {
+    bool opts_done = false;
+    for (int i = 1; i < argc; i++) {
+      const std::string a = argv[i];
+      if (!opts_done && a == "--") { opts_done = true; continue; }
+      if (!opts_done && a.compare(0, 2, "--") == 0) Set(a);
+      else args.push_back(a);
+    }
+  }
+  bool Has(const char *n) const { return kv.count(n) != 0; }
+  std::string Str(const char *n, const std::string &d) const { auto i = kv.find(n); return i == kv.end() ? d : i->second; }
+  double Num(const char *n, double d) const { auto i = kv.find(n); return i == kv.end() ? d : atof(i->second.c_str()); }
+  bool Bool(const char *n, bool d) const {
+    auto i = kv.find(n);
+    if (i == kv.end()) return d;
+    const std::string &v = i->second;
+    if (v == "true" || v == "t" || v == "1" || v == "") return true;
+    if (v == "false" || v == "f" || v == "0") return false;
+    throw ApiError(std::string("bad boolean for --") + n + ": " + v);
+  }
+};
+
+struct DevMem {   // RAII device buffer through the ABI
+  vbh_ctx *ctx; void *p = nullptr;
+  DevMem(vbh_ctx *c, size_t bytes) : ctx(c) { Check(vbh_dev_alloc(c, bytes, &p), "vbh_dev_alloc"); }
+  ~DevMem() { if (p) vbh_dev_free(ctx, p); }
+  DevMem(const DevMem &) = delete;
+};
+
+struct Batch {   // utterances of a feature table packed row-wise
+  std::vector<std::string> keys;
+  std::vector<int64_t> offs{0};
+  std::vector<float> data;
+  int dim = -1;
+  void Add(const std::string &k, const vbio::Matrix &m) {
+    keys.push_back(k);
+    data.insert(data.end(), m.data.begin(), m.data.end());
+    offs.push_back(offs.back() + m.rows);
+  }
+  int64_t frames() const { return offs.back(); }
+  void Clear() { keys.clear(); offs.assign(1, 0); data.clear(); }
+};
+
+constexpr int64_t kBatchFrames = 1 << 20;   // rows per device pass of the table-to-table tools
+
+// runs one vbh_featpost configuration over a whole feature table
+template <class PerBatch>
+int TableToTable(const std::string &rspec, const std::string &wspec, Log &log, const char *prog, int expect_dim_multiple,
+                 PerBatch per_batch) {
+  vbio::MatrixReader reader(rspec);
+  vbio::MatrixWriter writer(wspec);
+  Batch b;
+  std::string key; vbio::Matrix m;
+  int done = 0, err = 0;
+  auto flush = [&]() {
+    if (b.keys.empty()) return;
+    std::vector<float> out; int out_dim = 0;
+    per_batch(b, &out, &out_dim);
+    for (size_t u = 0; u < b.keys.size(); u++) {
+      vbio::Matrix o;
+      o.rows = (int32_t)(b.offs[u + 1] - b.offs[u]); o.cols = out_dim;
+      o.data.assign(out.begin() + b.offs[u] * out_dim, out.begin() + b.offs[u + 1] * out_dim);
+      writer.Write(b.keys[u], o);
+      done++;
+    }
+    b.Clear();
+  };
+  while (reader.Next(&key, &m)) {
+    if (m.rows == 0) { log.os() << "WARNING (" << prog << ") Empty feature matrix for key " << key << "\n"; err++; continue; }
+    if (b.dim < 0) b.dim = m.cols;
+    if (m.cols != b.dim) { log.os() << "WARNING (" << prog << ") dimension mismatch for key " << key << "\n"; err++; continue; }
+    (void)expect_dim_multiple;
+    b.Add(key, m);
+    if (b.frames() >= kBatchFrames) flush();
+  }
+  flush();
+  writer.Close();
+  log.os() << "LOG (" << prog << ") Processed " << done << " feature matrices; " << err << " with errors.\n";
+  return done != 0 ? 0 : 1;
+}
+
+void RunFeatpost(const vbh_featpost_cfg &cfg, const Batch &b, const std::vector<int32_t> &utt2spk, int n_spk,
+                 const double *stats, const float *lda, const float *spk, std::vector<float> *out, int *out_dim) {
+  vbh_ctx *ctx = Ctx();
+  *out_dim = vbh_featpost_out_dim(&cfg);
+  const int64_t T = b.frames();
+  DevMem d_in(ctx, sizeof(float) * b.data.size()), d_out(ctx, sizeof(float) * (size_t)T * *out_dim);
+  Check(vbh_copy_h2d(ctx, d_in.p, b.data.data(), sizeof(float) * b.data.size()), "vbh_copy_h2d");
+  Check(vbh_featpost(ctx, &cfg, (const float *)d_in.p, b.offs.data(), (int32_t)b.keys.size(),
+                     utt2spk.empty() ? nullptr : utt2spk.data(), n_spk, stats, lda, spk, (float *)d_out.p), "vbh_featpost");
+  out->resize((size_t)T * *out_dim);
+  Check(vbh_copy_d2h(ctx, out->data(), d_out.p, sizeof(float) * out->size()), "vbh_copy_d2h");
+}
+
+template <class F>
+int Guard(const char *prog, std::ofstream *file_log, F body) {
+  Log log(file_log);
+  try {
+    return body(log);
+  } catch (const std::exception &e) {
+    log.os() << "ERROR (" << prog << ") " << e.what() << "\n";
+    return -1;
+  } catch (...) {
+    log.os() << "ERROR (" << prog << ") unknown exception\n";
+    return -1;
+  }
+}
+
+int WindowType(const std::string &s) {
+  if (s == "hanning") return VBH_WIN_HANNING;
+  if (s == "hamming") return VBH_WIN_HAMMING;
+  if (s == "povey") return VBH_WIN_POVEY;
+  if (s == "rectangular") return VBH_WIN_RECTANGULAR;
+  if (s == "blackman") return VBH_WIN_BLACKMAN;
+  throw ApiError("Invalid window type " + s);
+}
+
+}  // namespace
+
+// =====================================================================================
+// compute-mfcc-feats   (VB/src/featbin/compute-mfcc-feats.cpp:21-198)
+int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
+  return Guard("compute-mfcc-feats", &file_log, [&](Log &log) -> int {
+    Options po;
+    po.Know({"sample-frequency", "frame-length", "frame-shift", "preemphasis-coefficient", "remove-dc-offset", "dither",
+             "window-type", "blackman-coeff", "round-to-power-of-two", "snip-edges", "allow-downsample", "num-mel-bins",
+             "low-freq", "high-freq", "vtln-low", "vtln-high", "debug-mel", "num-ceps", "use-energy", "energy-floor",
+             "raw-energy", "cepstral-lifter", "htk-compat", "output-format", "subtract-mean", "vtln-warp", "vtln-map",
+             "utt2spk", "channel", "min-duration"});
+    po.Parse(argc, argv);
+    if (po.args.size() != 2) throw ApiError("wrong arguments.");
+    vbh_mfcc_opts o;
+    vbh_mfcc_opts_default(&o);
+    // the reference default for --dither is 1.0; it cannot be reproduced (libc rand()), so the
+    // caller has to ask for 0 explicitly -- a silent change of default would hide the difference
+    o.dither = (float)po.Num("dither", 1.0);
+    if (o.dither != 0.0f) throw ApiError("--dither=" + po.Str("dither", "1.0 (default)") + " is not supported: pass --dither=0");
+    o.samp_freq = (float)po.Num("sample-frequency", o.samp_freq);
+    o.frame_length_ms = (float)po.Num("frame-length", o.frame_length_ms);
+    o.frame_shift_ms = (float)po.Num("frame-shift", o.frame_shift_ms);
+    o.preemph_coeff = (float)po.Num("preemphasis-coefficient", o.preemph_coeff);
+    o.remove_dc_offset = po.Bool("remove-dc-offset", true);
+    o.window_type = WindowType(po.Str("window-type", "povey"));
+    o.blackman_coeff = (float)po.Num("blackman-coeff", o.blackman_coeff);
+    o.round_to_power_of_two = po.Bool("round-to-power-of-two", true);
+    o.snip_edges = po.Bool("snip-edges", true);
+    o.num_bins = (int)po.Num("num-mel-bins", 23);
+    o.low_freq = (float)po.Num("low-freq", o.low_freq); o.high_freq = (float)po.Num("high-freq", o.high_freq);
+    o.vtln_low = (float)po.Num("vtln-low", o.vtln_low); o.vtln_high = (float)po.Num("vtln-high", o.vtln_high);
+    o.num_ceps = (int)po.Num("num-ceps", 13); o.use_energy = po.Bool("use-energy", true);
+    o.energy_floor = (float)po.Num("energy-floor", 0.0); o.raw_energy = po.Bool("raw-energy", true);
+    o.cepstral_lifter = (float)po.Num("cepstral-lifter", 22.0); o.htk_compat = po.Bool("htk-compat", false);
+    if (po.Str("output-format", "kaldi") != "kaldi") throw ApiError("Invalid output_format string " + po.Str("output-format", ""));
+    if (po.Has("vtln-map") || po.Has("utt2spk")) throw ApiError("--vtln-map / --utt2spk are not supported");
+    if (po.Bool("allow-downsample", false)) throw ApiError("--allow-downsample is not supported");
+    const bool subtract_mean = po.Bool("subtract-mean", false);
+    const float vtln_warp = (float)po.Num("vtln-warp", 1.0);
+    const int channel = (int)po.Num("channel", -1);
+    const double min_duration = po.Num("min-duration", 0.0);
+
+    const vbio::Rspec rs = vbio::ParseRspecifier(po.args[0]);
+    if (!rs.is_scp) throw ApiError("wav rspecifier must be scp: (got " + po.args[0] + ")");
+    std::vector<vbio::ScpEntry> scp = vbio::ReadScp(rs.path);
+    vbio::MatrixWriter writer(po.args[1]);
+    vbh_ctx *ctx = Ctx();
+    vbh_mfcc *mf = nullptr;
+    Check(vbh_mfcc_create(ctx, &o, vtln_warp, &mf), "vbh_mfcc_create");
+    int num_utts = 0, num_success = 0;
+    // utterances are packed into batches of ~64 M samples per device pass
+    size_t i = 0;
+    while (i < scp.size()) {
+      std::vector<std::string> keys; std::vector<int64_t> woff(1, 0); std::vector<float> samples;
+      while (i < scp.size() && samples.size() < (size_t)(64 << 20)) {
+        const vbio::ScpEntry &e = scp[i++];
+        num_utts++;
+        if (!e.path.empty() && e.path.back() == '|') { log.os() << "WARNING (compute-mfcc-feats) pipe input not supported: " << e.key << "\n"; continue; }
+        vbio::Wave w;
+        try { vbio::ReadWaveFile(e.path, e.offset, &w); }
+        catch (const std::exception &ex) { log.os() << "WARNING (compute-mfcc-feats) " << e.key << ": " << ex.what() << "\n"; continue; }
+        const double dur = w.data.empty() ? 0.0 : w.data[0].size() / w.samp_freq;
+        if (dur < min_duration) { log.os() << "WARNING (compute-mfcc-feats) File: " << e.key << " is too short (" << dur << " sec): producing no output.\n"; continue; }
+        int ch = channel;
+        if (ch == -1) {
+          ch = 0;
+          if (w.channels != 1) log.os() << "WARNING (compute-mfcc-feats) Channel not specified but you have data with " << w.channels << " channels; defaulting to zero\n";
+        } else if (ch >= w.channels) { log.os() << "WARNING (compute-mfcc-feats) File with id " << e.key << " has " << w.channels << " channels but you specified channel " << channel << ", producing no output.\n"; continue; }
+        if (w.samp_freq != o.samp_freq) { log.os() << "WARNING (compute-mfcc-feats) Failed to compute features for utterance " << e.key << ": sample frequency mismatch " << w.samp_freq << " vs " << o.samp_freq << "\n"; continue; }
+        keys.push_back(e.key);
+        samples.insert(samples.end(), w.data[ch].begin(), w.data[ch].end());
+        woff.push_back((int64_t)samples.size());
+      }
+      if (keys.empty()) continue;
+      int64_t total = 0;
+      for (size_t u = 0; u < keys.size(); u++) total += vbh_mfcc_num_frames(&o, woff[u + 1] - woff[u]);
+      DevMem d_wave(ctx, sizeof(float) * samples.size()), d_feats(ctx, sizeof(float) * (size_t)total * o.num_ceps);
+      Check(vbh_copy_h2d(ctx, d_wave.p, samples.data(), sizeof(float) * samples.size()), "vbh_copy_h2d");
+      std::vector<int64_t> foff(keys.size() + 1);
+      Check(vbh_mfcc_compute(mf, d_wave.p, 0, woff.data(), (int32_t)keys.size(), (float *)d_feats.p, foff.data()), "vbh_mfcc_compute");
+      std::vector<float> feats((size_t)total * o.num_ceps);
+      Check(vbh_copy_d2h(ctx, feats.data(), d_feats.p, sizeof(float) * feats.size()), "vbh_copy_d2h");
+      for (size_t u = 0; u < keys.size(); u++) {
+        vbio::Matrix m;
+        m.rows = (int32_t)(foff[u + 1] - foff[u]); m.cols = o.num_ceps;
+        m.data.assign(feats.begin() + foff[u] * o.num_ceps, feats.begin() + foff[u + 1] * o.num_ceps);
+        if (m.rows == 0) m.cols = 0;   // too short for one frame: the reference emits a 0 x 0 matrix (feature-common-inl.h:81-84)
+        if (subtract_mean && m.rows > 0) {   // compute-mfcc-feats.cpp:153-158
+          for (int c = 0; c < m.cols; c++) {
+            double s = 0.0;
+            for (int r = 0; r < m.rows; r++) s += m.at(r, c);
+            const float mean = (float)(s / m.rows);
+            for (int r = 0; r < m.rows; r++) m.at(r, c) -= mean;
+          }
+        }
+        writer.Write(keys[u], m);
+        num_success++;
+      }
+    }
+    vbh_mfcc_destroy(mf);
+    writer.Close();
+    log.os() << "LOG (compute-mfcc-feats)  Done " << num_success << " out of " << num_utts << " utterances.\n";
+    return num_success != 0 ? 0 : 1;
+  });
+}
+
+// =====================================================================================
+// compute-cmvn-stats --spk2utt   (VB/src/featbin/compute-cmvn-stats.cpp)
+int ComputeCmvnStats(int argc, char *argv[], std::ofstream &file_log) {
+  return Guard("compute-cmvn-stats", &file_log, [&](Log &log) -> int {
+    Options po;
+    po.Know({"spk2utt", "binary", "weights"});
+    po.Parse(argc, argv);
+    if (po.args.size() != 2) throw ApiError("wrong arguments.");
+    if (po.Has("weights")) throw ApiError("--weights is not supported");
+    // spk2utt: "spk utt1 utt2 ..." lines; without it every utterance is its own speaker
+    std::map<std::string, std::string> utt2spk;
+    std::vector<std::string> spk_order;
+    if (po.Has("spk2utt")) {
+      const vbio::Rspec rs = vbio::ParseRspecifier(po.Str("spk2utt", ""));
+      std::ifstream f(rs.path);
+      if (!f) throw ApiError("cannot open " + rs.path);
+      std::string line;
+      while (std::getline(f, line)) {
+        std::istringstream ss(line);
+        std::string spk, utt;
+        if (!(ss >> spk)) continue;
+        spk_order.push_back(spk);
+        while (ss >> utt) utt2spk[utt] = spk;
+      }
+    }
+    vbio::MatrixReader reader(po.args[0]);
+    Batch b; std::string key; vbio::Matrix m;
+    std::map<std::string, int> spk_index;
+    std::vector<int32_t> u2s;
+    while (reader.Next(&key, &m)) {
+      std::string spk = key;
+      if (!utt2spk.empty()) {
+        auto it = utt2spk.find(key);
+        if (it == utt2spk.end()) { log.os() << "WARNING (compute-cmvn-stats) no speaker for utterance " << key << "\n"; continue; }
+        spk = it->second;
+      } else spk_order.push_back(key);
+      if (b.dim < 0) b.dim = m.cols;
+      if (m.cols != b.dim || m.rows == 0) continue;
+      if (!spk_index.count(spk)) { const int idx = (int)spk_index.size(); spk_index[spk] = idx; }
+      u2s.push_back(spk_index[spk]);
+      b.Add(key, m);
+    }
+    if (b.keys.empty()) { log.os() << "LOG (compute-cmvn-stats) no features\n"; return 1; }
+    vbh_ctx *ctx = Ctx();
+    const int n_spk = (int)spk_index.size(), D = b.dim;
+    DevMem d_in(ctx, sizeof(float) * b.data.size());
+    Check(vbh_copy_h2d(ctx, d_in.p, b.data.data(), sizeof(float) * b.data.size()), "vbh_copy_h2d");
+    std::vector<double> stats((size_t)n_spk * 2 * (D + 1));
+    Check(vbh_cmvn_stats(ctx, (const float *)d_in.p, D, b.offs.data(), (int32_t)b.keys.size(), u2s.data(), n_spk, stats.data()), "vbh_cmvn_stats");
+    const vbio::Wspec ws = vbio::ParseWspecifier(po.args[1]);
+    std::ofstream ark(ws.ark_path, std::ios::binary), scp;
+    if (!ark) throw ApiError("cannot open " + ws.ark_path);
+    if (ws.has_scp) scp.open(ws.scp_path);
+    int done = 0;
+    for (const std::string &spk : spk_order) {
+      auto it = spk_index.find(spk);
+      if (it == spk_index.end()) continue;
+      vbio::MatrixD sm; sm.rows = 2; sm.cols = D + 1;
+      sm.data.assign(stats.begin() + (size_t)it->second * 2 * (D + 1), stats.begin() + (size_t)(it->second + 1) * 2 * (D + 1));
+      ark << spk << ' ';
+      const int64_t off = (int64_t)ark.tellp();
+      vbio::WriteMatrixD(ark, !ws.text, sm);
+      if (ws.has_scp) scp << spk << ' ' << ws.ark_path << ':' << off << '\n';
+      done++;
+    }
+    log.os() << "LOG (compute-cmvn-stats) Done accumulating CMVN stats for " << done << " speakers.\n";
+    return done != 0 ? 0 : 1;
+  });
+}
+
+// =====================================================================================
+// apply-cmvn   (VB/src/featbin/apply-cmvn.cpp:26-187)
+int ApplyCmvn(int argc, char *argv[], std::ofstream &file_log) {
+  return Guard("apply-cmvn", &file_log, [&](Log &log) -> int {
+    Options po;
+    po.Know({"utt2spk", "norm-vars", "norm-means", "skip-dims", "reverse"});
+    po.Parse(argc, argv);
+    if (po.args.size() != 3) throw ApiError("wrong arguments.");
+    if (!po.Bool("norm-means", true) || po.Has("skip-dims") || po.Bool("reverse", false))
+      throw ApiError("--norm-means=false / --skip-dims / --reverse are not supported");
+    const bool norm_vars = po.Bool("norm-vars", false);
+    std::map<std::string, std::string> utt2spk;
+    if (po.Has("utt2spk")) utt2spk = vbio::ReadStringMap(po.Str("utt2spk", ""));
+    // per-speaker stats table ("ark:" / "scp:"); a plain rxfilename means global stats
+    std::map<std::string, vbio::MatrixD> stats;
+    vbio::MatrixD global;
+    bool use_global = false;
+    const std::string &st = po.args[0];
+    if (st.compare(0, 3, "ark") == 0 || st.compare(0, 3, "scp") == 0) stats = vbio::ReadMatrixDTable(st);
+    else {
+      std::ifstream f(st, std::ios::binary);
+      if (!f) throw ApiError("cannot open " + st);
+      const bool binary = vbio::ReadBinaryHeader(f);
+      vbio::ReadMatrixD(f, binary, &global);
+      use_global = true;
+    }
+    return TableToTable(po.args[1], po.args[2], log, "apply-cmvn", 1, [&](const Batch &b, std::vector<float> *out, int *od) {
+      std::map<std::string, int> idx; std::vector<int32_t> u2s; std::vector<double> packed;
+      const int D = b.dim;
+      for (const std::string &k : b.keys) {
+        std::string spk = k;
+        if (!utt2spk.empty()) { auto it = utt2spk.find(k); if (it != utt2spk.end()) spk = it->second; }
+        if (use_global) spk = "";
+        if (!idx.count(spk)) {
+          const vbio::MatrixD *m = use_global ? &global : nullptr;
+          if (!m) { auto it = stats.find(spk); if (it == stats.end()) throw ApiError("No normalization statistics available for key " + k); m = &it->second; }
+          if (m->cols != D + 1 || m->rows < 1 || m->rows > 2) throw ApiError("Dim mismatch: cmvn " + std::to_string(m->rows) + "x" + std::to_string(m->cols));
+          if (m->rows == 1 && norm_vars) throw ApiError("You requested variance normalization but no variance stats are supplied.");
+          const int n = (int)idx.size(); idx[spk] = n;
+          packed.insert(packed.end(), m->data.begin(), m->data.end());
+          if (m->rows == 1) packed.insert(packed.end(), (size_t)(D + 1), 0.0);
+        }
+        u2s.push_back(idx[spk]);
+      }
+      vbh_featpost_cfg cfg{};
+      cfg.in_dim = D; cfg.apply_cmvn = 1; cfg.norm_vars = norm_vars; cfg.mode = 0;
+      RunFeatpost(cfg, b, u2s, (int)idx.size(), packed.data(), nullptr, nullptr, out, od);
+    });
+  });
+}
+
+// =====================================================================================
+// add-deltas   (VB/src/featbin/add-deltas.cpp:19-72)
+int AddDeltas(int argc, char *argv[]) {
+  return Guard("add-deltas", nullptr, [&](Log &log) -> int {
+    Options po;
+    po.Know({"delta-order", "delta-window", "truncate"});
+    po.Parse(argc, argv);
+    if (po.args.size() != 2) throw ApiError("wrong arguments.");
+    if (po.Num("truncate", 0) != 0) throw ApiError("--truncate is not supported");
+    const int order = (int)po.Num("delta-order", 2), window = (int)po.Num("delta-window", 2);
+    return TableToTable(po.args[0], po.args[1], log, "add-deltas", 1, [&](const Batch &b, std::vector<float> *out, int *od) {
+      vbh_featpost_cfg cfg{};
+      cfg.in_dim = b.dim; cfg.mode = 1; cfg.delta_order = order; cfg.delta_window = window;
+      RunFeatpost(cfg, b, {}, 1, nullptr, nullptr, nullptr, out, od);
+    });
+  });
+}
+
+// =====================================================================================
+// splice-feats   (VB/src/featbin/splice-feats.cpp:20-62)
+int SpliceFeats(int argc, char *argv[]) {
+  return Guard("splice-feats", nullptr, [&](Log &log) -> int {
+    Options po;
+    po.Know({"left-context", "right-context"});
+    po.Parse(argc, argv);
+    if (po.args.size() != 2) throw ApiError("wrong arguments.");
+    const int left = (int)po.Num("left-context", 4), right = (int)po.Num("right-context", 4);
+    return TableToTable(po.args[0], po.args[1], log, "splice-feats", 1, [&](const Batch &b, std::vector<float> *out, int *od) {
+      vbh_featpost_cfg cfg{};
+      cfg.in_dim = b.dim; cfg.mode = 2; cfg.splice_left = left; cfg.splice_right = right;
+      RunFeatpost(cfg, b, {}, 1, nullptr, nullptr, nullptr, out, od);
+    });
+  });
+}
+
+// =====================================================================================
+// transform-feats   (VB/src/featbin/transform-feats.cpp:19-176)
+int TransformFeats(int argc, char *argv[], std::ofstream &file_log) {
+  return Guard("transform-feats", &file_log, [&](Log &log) -> int {
+    Options po;
+    po.Know({"utt2spk"});
+    po.Parse(argc, argv);
+    if (po.args.size() != 3) throw ApiError("wrong arguments.");
+    std::map<std::string, std::string> utt2spk;
+    if (po.Has("utt2spk")) utt2spk = vbio::ReadStringMap(po.Str("utt2spk", ""));
+    const std::string &ts = po.args[0];
+    std::map<std::string, vbio::Matrix> table;
+    vbio::Matrix global;
+    bool use_global = false;
+    if (ts.compare(0, 3, "ark") == 0 || ts.compare(0, 3, "scp") == 0) table = vbio::ReadMatrixTable(ts);
+    else {
+      std::ifstream f(ts, std::ios::binary);
+      if (!f) throw ApiError("cannot open " + ts);
+      const bool binary = vbio::ReadBinaryHeader(f);
+      vbio::ReadMatrix(f, binary, &global);
+      use_global = true;
+    }
+    return TableToTable(po.args[1], po.args[2], log, "transform-feats", 1, [&](const Batch &b, std::vector<float> *out, int *od) {
+      vbh_featpost_cfg cfg{};
+      cfg.in_dim = b.dim; cfg.mode = 0;
+      if (use_global) {
+        cfg.lda_rows = global.rows; cfg.lda_cols = global.cols;
+        RunFeatpost(cfg, b, {}, 1, nullptr, global.data.data(), nullptr, out, od);
+        return;
+      }
+      std::map<std::string, int> idx; std::vector<int32_t> u2s; std::vector<float> packed;
+      int R = -1, C = -1;
+      for (const std::string &k : b.keys) {
+        std::string spk = k;
+        if (!utt2spk.empty()) { auto it = utt2spk.find(k); if (it != utt2spk.end()) spk = it->second; }
+        if (!idx.count(spk)) {
+          auto it = table.find(spk);
+          if (it == table.end()) throw ApiError("No fMLLR transform available for utterance " + k);
+          if (R < 0) { R = it->second.rows; C = it->second.cols; }
+          if (it->second.rows != R || it->second.cols != C) throw ApiError("transform matrices of different sizes");
+          const int n = (int)idx.size(); idx[spk] = n;
+          packed.insert(packed.end(), it->second.data.begin(), it->second.data.end());
+        }
+        u2s.push_back(idx[spk]);
+      }
+      cfg.spk_rows = R; cfg.spk_cols = C;
+      RunFeatpost(cfg, b, u2s, (int)idx.size(), nullptr, nullptr, packed.data(), out, od);
+    });
+  });
+}
+
+// =====================================================================================
+// gmm-latgen-faster   (VB/src/gmmbin/gmm-latgen-faster.cpp:27-198)
+int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
+  return Guard("gmm-latgen-faster", &file_log, [&](Log &log) -> int {
+    Options po;
+    po.Know({"beam", "max-active", "min-active", "lattice-beam", "prune-interval", "determinize-lattice", "beam-delta",
+             "hash-ratio", "acoustic-scale", "word-symbol-table", "allow-partial", "max-mem", "phone-determinize",
+             "word-determinize", "minimize", "decode-batch"});
+    po.Parse(argc, argv);
+    if (po.args.size() < 4 || po.args.size() > 6) throw ApiError("wrong arguments.");
+    vbh_decode_cfg cfg;
+    vbh_decode_cfg_default(&cfg);
+    // LatticeFasterDecoderConfig defaults (K/decoder/lattice-faster-decoder.h:59-67), not Decode()'s
+    cfg.beam = (float)po.Num("beam", 16.0);
+    cfg.max_active = (int)po.Num("max-active", (double)std::numeric_limits<int32_t>::max());
+    cfg.min_active = (int)po.Num("min-active", 200);
+    cfg.lattice_beam = (float)po.Num("lattice-beam", 10.0);
+    cfg.prune_interval = (int)po.Num("prune-interval", 25);
+    cfg.beam_delta = (float)po.Num("beam-delta", 0.5);
+    cfg.acoustic_scale = (float)po.Num("acoustic-scale", 0.1);
+    const bool allow_partial = po.Bool("allow-partial", false);
+    const bool determinize = po.Bool("determinize-lattice", true);
+    const std::string &lat_wspec = po.args[3];
+    const bool want_lat = !lat_wspec.empty() && lat_wspec != "ark:/dev/null";
+    if (want_lat && determinize)
+      throw ApiError("lattice determinization is not part of this build: pass --determinize-lattice=false (raw lattices)");
+    vbio::Model model;
+    vbio::ReadModel(po.args[0], &model);
+    vbio::Graph graph;
+    vbio::ReadFst(po.args[1], &graph);
+    vbh_ctx *ctx = Ctx();
+    vbh_gmm *gmm = nullptr;
+    Check(vbh_gmm_create(ctx, model.dim, model.num_pdfs, model.pdf_offsets.data(), model.weights.data(),
+                         model.means_invvars.data(), model.inv_vars.data(), &gmm), "vbh_gmm_create");
+    vbh_graph *g = nullptr;
+    static_assert(sizeof(vbio::Arc) == sizeof(vbh_arc), "arc layout");
+    Check(vbh_graph_create(ctx, (int32_t)graph.final_cost.size(), graph.start, graph.final_cost.data(), graph.arc_offset.data(),
+                           reinterpret_cast<const vbh_arc *>(graph.arcs.data()), &g), "vbh_graph_create");
+    vbio::LatticeWriter lat_writer;
+    if (want_lat) lat_writer.Open(lat_wspec);
+    vbio::IntVectorWriter words_writer, ali_writer;
+    if (po.args.size() >= 5 && !po.args[4].empty()) words_writer.Open(po.args[4]);
+    if (po.args.size() >= 6 && !po.args[5].empty()) ali_writer.Open(po.args[5]);
+
+    const int batch_utts = (int)po.Num("decode-batch", 256);
+    vbio::MatrixReader reader(po.args[2]);
+    double tot_like = 0.0;
+    int64_t frame_count = 0;
+    int num_done = 0, num_err = 0;
+    std::string key; vbio::Matrix m;
+    bool more = true;
+    while (more) {
+      Batch b;
+      int max_T = 0;
+      while ((int)b.keys.size() < batch_utts && (more = reader.Next(&key, &m))) {
+        if (m.rows == 0) { log.os() << "WARNING (gmm-latgen-faster) Zero-length utterance: " << key << "\n"; num_err++; continue; }
+        if (m.cols != model.dim) throw ApiError("Dim mismatch: data dim = " + std::to_string(m.cols) + " vs. model dim = " + std::to_string(model.dim));
+        if (b.dim < 0) b.dim = m.cols;
+        b.Add(key, m);
+        if (m.rows > max_T) max_T = m.rows;
+      }
+      if (b.keys.empty()) break;
+      const int64_t T = b.frames();
+      DevMem d_feats(ctx, sizeof(float) * b.data.size()), d_ll(ctx, sizeof(float) * (size_t)T * model.num_pdfs);
+      Check(vbh_copy_h2d(ctx, d_feats.p, b.data.data(), sizeof(float) * b.data.size()), "vbh_copy_h2d");
+      Check(vbh_gmm_loglikes(gmm, (const float *)d_feats.p, T, (float *)d_ll.p), "vbh_gmm_loglikes");
+      vbh_decoder *dec = nullptr;
+      Check(vbh_decoder_create(ctx, g, &cfg, (int32_t)b.keys.size(), max_T, &dec), "vbh_decoder_create");
+      const int rc = vbh_decode_batch(dec, (const float *)d_ll.p, model.num_pdfs, b.offs.data(), (int32_t)b.keys.size(),
+                                      model.tid2pdf.data(), (int32_t)model.tid2pdf.size() - 1);
+      if (rc != 0) { const std::string e = vbh_last_error(); vbh_decoder_destroy(dec); throw ApiError("vbh_decode_batch: " + e); }
+      for (size_t u = 0; u < b.keys.size(); u++) {
+        vbh_lattice L;
+        Check(vbh_decoder_result(dec, (int32_t)u, &L), "vbh_decoder_result");
+        const std::string &utt = b.keys[u];
+        // DecodeUtteranceLatticeFaster (K/decoder/decoder-wrappers.cc:198-293)
+        if (!L.ok) { log.os() << "WARNING (gmm-latgen-faster) Failed to decode file " << utt << "\n"; num_err++; continue; }
+        if (!L.reached_final) {
+          if (allow_partial) log.os() << "WARNING (gmm-latgen-faster) Outputting partial output for utterance " << utt << " since no final-state reached\n";
+          else { log.os() << "WARNING (gmm-latgen-faster) Not producing output for utterance " << utt << " since no final-state reached and --allow-partial=false.\n"; num_err++; continue; }
+        }
+        std::vector<int32_t> words(L.words, L.words + L.num_words), ali(L.ali, L.ali + L.num_ali);
+        if (words_writer.IsOpen()) words_writer.Write(utt, words);
+        if (ali_writer.IsOpen()) ali_writer.Write(utt, ali);
+        const double like = -((double)L.best_graph + (double)L.best_acoustic);
+        if (want_lat) {
+          // GetRawLattice: one state per token (state 0 = start token), arc weights
+          // (graph, acoustic), acoustic un-scaled by 1/acwt before writing (:276-284)
+          vbio::LatticeOut lo;
+          const int n = L.num_toks;
+          // the start token must become state 0: tokens are sorted by (frame, HCLG state)
+          std::vector<int32_t> remap(n);
+          int start_idx = 0;
+          for (int i = 0; i < n && L.tok_frame[i] == 0; i++) if (L.tok_state[i] == graph.start) start_idx = i;
+          for (int i = 0; i < n; i++) remap[i] = i == start_idx ? 0 : (i < start_idx ? i + 1 : i);
+          lo.arcs.resize(n); lo.final_graph.assign(n, std::numeric_limits<float>::infinity()); lo.final_acoustic.assign(n, 0.0f);
+          const float inv = cfg.acoustic_scale != 0.0f ? 1.0f / cfg.acoustic_scale : 1.0f;
+          for (int i = 0; i < n; i++) lo.final_graph[remap[i]] = L.tok_final[i];
+          for (int l = 0; l < L.num_links; l++)
+            lo.arcs[remap[L.link_src[l]]].push_back(vbio::LatticeArcOut{L.link_ilabel[l], L.link_olabel[l], L.link_graph[l],
+                                                                       L.link_acoustic[l] * inv, remap[L.link_dst[l]]});
+          lat_writer.Write(utt, lo);
+        }
+        log.os() << "LOG (gmm-latgen-faster) Log-like per frame for utterance " << utt << " is " << (like / (L.num_ali ? L.num_ali : 1))
+                 << " over " << L.num_ali << " frames.\n";
+        tot_like += like;
+        frame_count += L.num_frames;
+        num_done++;
+      }
+      vbh_decoder_destroy(dec);
+    }
+    vbh_graph_destroy(g);
+    vbh_gmm_destroy(gmm);
+    log.os() << "LOG (gmm-latgen-faster) Done " << num_done << " utterances, failed for " << num_err << "\n";
+    log.os() << "LOG (gmm-latgen-faster) Overall log-likelihood per frame is " << (frame_count ? tot_like / frame_count : 0.0)
+             << " over " << frame_count << " frames.\n";
+    return num_done != 0 ? 0 : 1;
+  });
+}
+
+// =====================================================================================
+namespace {
+template <class F>
+int WithLog(const char *log_path, F f) {
+  std::ofstream log;
+  if (log_path && *log_path) log.open(log_path, std::ios::app);
+  return f(log);
+}
+}  // namespace
+
+extern "C" {
+int vb_set_device(int device_id) { g_device = device_id; return 0; }
+int vb_ComputeMFCCFeats(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return ComputeMFCCFeats(argc, argv, l); }); }
+int vb_ComputeCmvnStats(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return ComputeCmvnStats(argc, argv, l); }); }
+int vb_ApplyCmvn(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return ApplyCmvn(argc, argv, l); }); }
+int vb_AddDeltas(int argc, char *argv[]) { return AddDeltas(argc, argv); }
+int vb_SpliceFeats(int argc, char *argv[]) { return SpliceFeats(argc, argv); }
+int vb_TransformFeats(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return TransformFeats(argc, argv, l); }); }
+int vb_GmmLatgenFaster(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return GmmLatgenFaster(argc, argv, l); }); }
+}
