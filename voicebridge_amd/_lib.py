@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libvoicebridge_hip.so")
+# VBH_LIB_PATH selects another build of the same library (kernel experiments, tools/variants.py)
+LIB_PATH = os.environ.get("VBH_LIB_PATH") or os.path.join(HERE, "lib", "libvoicebridge_hip.so")
 
 # every symbol include/voicebridge_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

@@ -8,22 +8,35 @@
 //   :532-572  ComputeFinalCosts    :600-615  FinalizeDecoding    :110-192  GetRawLattice (content)
 //   gmm/decodable-am-diag-gmm.h:142-145        acoustic_scale * loglike(frame, tid2pdf[tid])
 //
-// Execution model.  One 1024-thread workgroup owns one utterance for its whole life and
-// walks its frames; a batch runs as a persistent grid that pulls utterances from a counter,
-// so there is no inter-workgroup communication at all.  Per workgroup ("slot") HBM holds
-//   * three state-indexed arrays (key, claim, tokid) that replace the reference's per-frame
-//     hash: key[s] = (epoch | order-preserving bits of the best cost reaching s this frame)
-//     updated with 64-bit atomicMin, claim[s] = (epoch | phase) taken with one atomicCAS by the
-//     thread that creates the token, tokid[s] = token index.  The epoch (frame counter) in the
-//     high word makes entries of older frames lose every comparison, so nothing is cleared;
+// Execution model.  One workgroup owns one utterance for its whole life and walks its frames;
+// a batch runs as a persistent grid that pulls utterances from a counter, so there is no
+// inter-workgroup communication at all.  The search is LATENCY bound (a frame has a few
+// thousand tokens and arcs, spread over ~25 dependent passes), so the layout and the passes
+// are built to minimise dependent memory round trips and to keep several independent loads in
+// flight per lane (profiles/README.md, r01_c):
+//   * everything an access needs sits in ONE 16-byte record: state {first arc, #eps arcs,
+//     #arcs, final cost}; arc {next state | has-eps flag, weight, pdf, olabel} (epsilon arcs
+//     first within a state); token {state, cost, extra_cost, tmp}; link {src, dst, graph,
+//     acoustic} (+ arc id, read only when the lattice is written out);
+//   * arcs are expanded by wave_expand(): a wave takes up to 64 tokens, prefix-sums their arc
+//     counts and spreads the arcs evenly over its lanes, so a state with many arcs costs a
+//     few more wave iterations instead of a serial loop on one lane;
+//   * streaming passes (candidates, links, tokens, compaction) are unrolled U times with all
+//     loads issued before the first use.
+// Per workgroup ("slot") HBM holds
+//   * ent[S] = {key, tokid}: key = (epoch | order-preserving bits of the best cost reaching
+//     the state this frame), updated with one 64-bit atomicMin whose return value tells the
+//     thread whether it is the first to reach the state (then it creates the token).  The
+//     epoch (frame counter) in the high word makes entries of older frames lose every
+//     comparison, so nothing is ever cleared;
 //   * a raw window (W) of tokens and forward links created since the last pruning, and a
-//     history (H) holding what survived earlier prunings, with stable indices.
+//     history (H) holding what survived earlier prunings.
 // Every `prune_interval` frames the workgroup recomputes extra_costs backwards (link-parallel
 // min with atomics, iterated per frame to the fixed point when epsilon links exist), stops
-// at the first already-pruned frame whose values did not move, and compacts the survivors
-// of W into H.  The reference's final result does not depend on when intermediate pruning
-// happens (its final pass recomputes every frame with delta = 0), so this schedule yields
-// the same lattice.
+// at the first already-pruned frame whose values did not move, and moves the survivors of W
+// into H (the sweeps count survivors per frame, so the move needs no counting pass).  The
+// reference's final result does not depend on when intermediate pruning happens (its final
+// pass recomputes every frame with delta = 0), so this schedule yields the same lattice.
 //
 // Semantics.  Costs use exactly the reference's float32 expressions and association order
 // (this file is compiled with -ffp-contract=off).  The one deliberate difference is the
@@ -47,8 +60,7 @@
 namespace {
 
 #ifndef VBH_DECODE_NT
-#define VBH_DECODE_NT 1024   // measured on MI355X (profiles/README.md): 256/512/1024 threads per utterance all
-                             // saturate at the same ~0.65 M frames/s once >= 256 utterances are in flight
+#define VBH_DECODE_NT 1024
 #endif
 constexpr int NT = VBH_DECODE_NT;    // threads per workgroup = per utterance; 1024/NT workgroups share a CU
 constexpr int NW = NT / 64;
@@ -56,14 +68,22 @@ constexpr int WBIT = 0x40000000;            // token id lives in the raw window
 constexpr unsigned INF_BITS = 0x7F800000u;  // +inf as float bits
 constexpr int MAX_EPS_ITERS = 4096;
 constexpr int MAX_WIN_FRAMES = 512;         // frames between two compactions (prune_interval + 1 <= this)
+constexpr int EPSBIT = (int)0x80000000;     // on an arc's next state / a token's state: that state has epsilon arcs
+constexpr int STMASK = 0x7FFFFFFF;
+constexpr int COST_CAP = 8192;              // token costs of the current frame cached in LDS
+constexpr int U = 4;                        // independent items per lane in the streaming passes
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float asf(int x) { return __int_as_float(x); }
+__device__ __forceinline__ int asi(float x) { return __float_as_int(x); }
 
 struct DevGraph {
   int S, start;
-  const float *final_cost;   // [S], +inf = not final
-  const int *arc_off;        // [S+1]
-  const int *nieps;          // [S] number of input-epsilon arcs
-  const vbh_arc *arcs;       // [A]
-  const int *arc_pdf;        // [A] tid2pdf[ilabel], -1 for input-epsilon arcs (filled per batch)
+  const i32x4 *st;      // [S] {first arc, #epsilon arcs, #arcs, final cost bits}
+  const i32x4 *arcs;    // [A] {nextstate | EPSBIT, weight bits, pdf (filled per batch), olabel}; epsilon arcs first
+  const int *arc_il;    // [A] ilabel
 };
 
 struct DecCfg {
@@ -71,22 +91,25 @@ struct DecCfg {
   int max_active, min_active, prune_interval;
 };
 
+struct Ent { unsigned long long key; int tokid; int pad; };   // per graph state
+
+struct FrameRec {
+  int tok_b, tok_e;     // tokens of this frame (frame_plus_one index)
+  int el_b, el_e;       // emitting links leaving this frame
+  int pl_b, pl_e;       // epsilon links within this frame
+  int flags;            // 1: tokens in W, 2: emitting links in W, 4: epsilon links in W
+  float cost_offset;
+  int a_tok, a_el, a_pl;  // survivors as of the last pruning sweep over the frame (upper bounds)
+  int pad;
+};
+
 // per-slot workspace (device pointers)
 struct Slot {
-  unsigned long long *key;                 // [S] (epoch | order-preserving cost bits)
-  int *tokid;                              // [S] window index of the state's token in the current epoch
-  // raw window
-  int *w_state; float *w_cost; unsigned *w_extra, *w_tmp; int *w_remap;
-  int *wl_src, *wl_dst, *wl_il, *wl_ol; float *wl_gr, *wl_ac;
-  // history
-  int *h_state; float *h_cost; unsigned *h_extra, *h_tmp; int *h_remap;
-  int *hl_src, *hl_dst, *hl_il, *hl_ol; float *hl_gr, *hl_ac;
-  // per frame_plus_one ranges: tokens, emitting links from the frame, epsilon links within it
-  int *tok_b, *tok_e, *el_b, *el_e, *pl_b, *pl_e;
-  unsigned char *tok_w, *el_w, *pl_w;      // 1 = range refers to the window
-  float *cost_offset;                      // [max_frames]
-  // candidates of the current frame (pass 1 -> passes 2, 3)
-  float *c_tot, *c_ac; int *c_arc, *c_src, *c_dst;
+  Ent *ent;                                // [S]
+  i32x4 *w_tok; int *w_remap; i32x4 *wl; int *wl_arc;    // raw window
+  i32x4 *h_tok; int *h_remap; i32x4 *hl; int *hl_arc;    // history
+  FrameRec *fr;                            // [max_frames + 2]
+  i32x4 *cand; i32x2 *cand2;               // candidates of the current frame: {tot, ac, arc, src}, {dst|EPSBIT, weight}
   int *front[3];                           // epsilon work lists (state ids), rotated
   int *state;                              // persistent: [0] epoch base
   int w_tok_cap, w_link_cap, h_tok_cap, h_link_cap, front_cap, cand_cap;
@@ -135,6 +158,17 @@ __device__ __forceinline__ int ld_i32(const int *p) {
 __device__ __forceinline__ void st_i32(int *p, int v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Read-modify-write atomics on per-utterance data: one workgroup owns an utterance, so
+// workgroup scope is all the coherence needed.
+#ifndef VBH_RMW_SCOPE
+#define VBH_RMW_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
+__device__ __forceinline__ unsigned long long rmw_min_u64(unsigned long long *p, unsigned long long v) {
+  return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, VBH_RMW_SCOPE);
+}
+__device__ __forceinline__ void rmw_min_u32(unsigned *p, unsigned v) {
+  (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, VBH_RMW_SCOPE);
+}
 // make an LDS-loaded (per-lane) pointer wave-uniform again so that it lives in SGPRs
 template <class T>
 __device__ __forceinline__ T *uptr(T *p) {
@@ -157,6 +191,41 @@ __device__ __forceinline__ int wave_alloc(int *counter, bool want) {
 }
 __device__ __forceinline__ long long clk() { return (long long)__builtin_amdgcn_s_memtime(); }
 
+// Load-balanced expansion inside a wave.  Every lane brings one item with `cnt` sub-items
+// (0 = none); body(valid, owner, j) is then called wave-uniformly with the sub-items dealt
+// out 64 at a time: lane handles sub-item j of the item that lane `owner` brought.  All 64
+// lanes must call this together.
+template <class F>
+__device__ __forceinline__ void wave_expand(int cnt, F body) {
+  const int lane = threadIdx.x & 63;
+  int incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  const int total = __shfl(incl, 63, 64);
+  const int excl = incl - cnt;
+  for (int k0 = 0; k0 < total; k0 += 64) {
+    const int k = k0 + lane;
+    int lo = 0;     // number of lanes whose inclusive sum is <= k  ==  the owner of sub-item k
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) {
+      const int v = __shfl(incl, lo + step - 1, 64);
+      if (v <= k) lo += step;
+    }
+    const bool valid = k < total;
+    const int owner = valid ? lo : 0;
+    const int j = k - __shfl(excl, owner, 64);
+    body(valid, owner, j);
+  }
+}
+// tokens/items per wave and round: spreads few items over all waves
+__device__ __forceinline__ int wave_chunk(int n) {
+  const int c = (n + NW - 1) / NW;
+  return c < 1 ? 1 : (c > 64 ? 64 : c);
+}
+
 struct Shared {
   unsigned long long red[2][NW];   // reduction scratch, alternated so that one barrier per reduction suffices
   unsigned hist[256];
@@ -164,6 +233,7 @@ struct Shared {
   int n_cand;
   int fcnt[3];                     // epsilon work-list fill counts, rotated with Slot::front
   int changed2[2];                 // "something changed" flags, alternated per use (see prune_frame)
+  int cnt_tok[2], cnt_el[2], cnt_pl[2];   // survivors seen by a pruning sweep, alternated the same way
   int error, flag;
   unsigned sel_prefix, sel_mask; int sel_k;
   float f0;
@@ -174,8 +244,12 @@ struct Shared {
   // re-compacted in place at the next one, once those frames have been pruned with look-ahead
   int tail_tok_b, tail_link_b, tail_f0, tail_f1;
   long long tph[8];                // phase cycle counters (thread 0)
-  int fr_cnt[3 * MAX_WIN_FRAMES];  // compaction: survivors per frame (tokens, emitting links, epsilon links)
-  int fr_base[3 * MAX_WIN_FRAMES];
+  float cost[COST_CAP];            // costs of the current frame's tokens (GetCutoff)
+  // compaction job: token frames and link segments in source order
+  int j_ntf, j_nseg, j_tf0, j_tdst, j_ldst;
+  int tbeg[MAX_WIN_FRAMES + 1], tbase[MAX_WIN_FRAMES], tcnt[MAX_WIN_FRAMES], tup[MAX_WIN_FRAMES];
+  int sbeg[2 * MAX_WIN_FRAMES + 1], sbase[2 * MAX_WIN_FRAMES], scnt[2 * MAX_WIN_FRAMES], sup[2 * MAX_WIN_FRAMES];
+  int sid[2 * MAX_WIN_FRAMES];     // frame << 1 | (1 = epsilon links)
 };
 
 // block reductions with ONE barrier each: partials go to red[par], par flips on every call
@@ -208,9 +282,14 @@ __device__ __forceinline__ float block_min_f(float v, Shared &sh, int &par) {
   return o2f((unsigned)block_min_u64((unsigned long long)f2o(v), sh, par));
 }
 
-// k-th smallest (0-based) of cost[0..n): exact radix select on the order-preserving keys
-// (the std::nth_element value in GetCutoff, lattice-faster-decoder.cc:654-676)
-__device__ float select_kth(const float *cost, int n, int k, Shared &sh) {
+// cost of token i of the current frame: LDS copy, or the record itself beyond the cache
+__device__ __forceinline__ float frame_cost(const Shared &sh, const i32x4 *tok, int i) {
+  return i < COST_CAP ? sh.cost[i] : asf(tok[i].y);
+}
+
+// k-th smallest (0-based) of the current frame's costs: exact radix select on the
+// order-preserving keys (the std::nth_element value in GetCutoff, lattice-faster-decoder.cc:654-676)
+__device__ float select_kth(const i32x4 *tok, int n, int k, Shared &sh) {
   const int tid = threadIdx.x;
   __syncthreads();
   if (tid == 0) { sh.sel_prefix = 0; sh.sel_mask = 0; sh.sel_k = k; }
@@ -219,91 +298,132 @@ __device__ float select_kth(const float *cost, int n, int k, Shared &sh) {
     __syncthreads();
     const unsigned prefix = sh.sel_prefix, mask = sh.sel_mask;
     for (int i = tid; i < n; i += NT) {
-      const unsigned key = f2o(cost[i]);
+      const unsigned key = f2o(frame_cost(sh, tok, i));
       if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      int kk = sh.sel_k, b = 0;
-      for (; b < 255; b++) {
-        if (kk < (int)sh.hist[b]) break;
-        kk -= (int)sh.hist[b];
+    if (tid < 64) {     // wave 0: 4 bins per lane, prefix over lanes, then the bin inside the lane
+      const int kk = sh.sel_k;
+      const int h0 = (int)sh.hist[4 * tid], h1 = (int)sh.hist[4 * tid + 1], h2 = (int)sh.hist[4 * tid + 2], h3 = (int)sh.hist[4 * tid + 3];
+      int incl = h0 + h1 + h2 + h3;
+      const int mine = incl;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (tid >= o) incl += v;
       }
-      sh.sel_k = kk;
-      sh.sel_prefix = prefix | ((unsigned)b << shift);
-      sh.sel_mask = mask | (255u << shift);
+      const unsigned long long m = __ballot(incl > kk);
+      const int owner = m ? __ffsll((long long)m) - 1 : 63;   // k < n always, so some lane qualifies
+      if (tid == owner) {
+        int r = kk - (incl - mine), b = 0;
+        if (r >= h0) { r -= h0; b = 1; if (r >= h1) { r -= h1; b = 2; if (r >= h2) { r -= h2; b = 3; } } }
+        sh.sel_k = r;
+        sh.sel_prefix = prefix | ((unsigned)(4 * tid + b) << shift);
+        sh.sel_mask = mask | (255u << shift);
+      }
     }
     __syncthreads();
   }
   return o2f(sh.sel_prefix);
 }
 
-__device__ __forceinline__ float tok_cost(const Slot &s, int id) { return (id & WBIT) ? s.w_cost[id ^ WBIT] : s.h_cost[id]; }
-__device__ __forceinline__ unsigned tok_extra(const Slot &s, int id) { return (id & WBIT) ? s.w_extra[id ^ WBIT] : s.h_extra[id]; }
+__device__ __forceinline__ i32x4 *tokp(i32x4 *wt, i32x4 *ht, int id) { return (id & WBIT) ? wt + (id ^ WBIT) : ht + id; }
 
 // evaluate the forward links [lb, le) of one frame: excise those over the lattice beam,
-// atomicMin the rest into tmp[src] (lattice-faster-decoder.cc:331-356)
-__device__ __forceinline__ void eval_links(const Slot &s, bool lw, int lb, int le_, const float *tcost, unsigned *tmp,
-                                           float lattice_beam) {
-  if (le_ <= lb) return;
-  int *lsrc = uptr(lw ? s.wl_src : s.hl_src);
-  const int *ldst = uptr(lw ? s.wl_dst : s.hl_dst);
-  const float *lgr = uptr(lw ? s.wl_gr : s.hl_gr), *lac = uptr(lw ? s.wl_ac : s.hl_ac);
-  const float *wc = uptr(s.w_cost), *hc = uptr(s.h_cost);
-  const unsigned *we = uptr(s.w_extra), *he = uptr(s.h_extra);
-  tcost = uptr(tcost); tmp = uptr(tmp);
-  for (int l = lb + threadIdx.x; l < le_; l += NT) {
-    const int src = lsrc[l];
-    if (src < 0) continue;   // already excised
-    const int dst = ldst[l];
-    const float nx = __uint_as_float((dst & WBIT) ? we[dst ^ WBIT] : he[dst]);
-    const float dc = (dst & WBIT) ? wc[dst ^ WBIT] : hc[dst];
-    // next_tok->extra_cost + ((tok->tot_cost + link->acoustic_cost + link->graph_cost) - next_tok->tot_cost)
-    float le = nx + (((tcost[src & ~WBIT] + lac[l]) + lgr[l]) - dc);
-    if (le > lattice_beam) { lsrc[l] = -1; continue; }
-    if (le < 0.0f) le = 0.0f;
-    atomicMin(&tmp[src & ~WBIT], __float_as_uint(le));
+// atomicMin the rest into the source token's tmp (lattice-faster-decoder.cc:331-356).
+// Returns (valid on lane 0 of each wave) the number of links this wave kept.
+__device__ __forceinline__ int eval_links(i32x4 *lk, int lb, int le_, i32x4 *wt, i32x4 *ht, float lattice_beam) {
+  int kept = 0;
+  for (int base = lb; base < le_; base += NT * U) {
+    i32x4 L[U]; bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int l = base + u * NT + (int)threadIdx.x;
+      ok[u] = l < le_;
+      L[u] = lk[ok[u] ? l : lb];
+      ok[u] = ok[u] && L[u].x >= 0;   // negative source: already excised
+    }
+    float sc[U]; i32x4 D[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const i32x4 *sp = ok[u] ? tokp(wt, ht, L[u].x) : ht;
+      const i32x4 *dp = ok[u] ? tokp(wt, ht, L[u].y) : ht;
+      sc[u] = asf(sp->y);
+      D[u] = *dp;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int l = base + u * NT + (int)threadIdx.x;
+      // next_tok->extra_cost + ((tok->tot_cost + link->acoustic_cost + link->graph_cost) - next_tok->tot_cost)
+      float le = asf(D[u].z) + (((sc[u] + asf(L[u].w)) + asf(L[u].z)) - asf(D[u].y));
+      const bool keep = ok[u] && !(le > lattice_beam);
+      if (ok[u] && !keep) reinterpret_cast<int *>(&lk[l])[0] = -1;
+      if (keep) {
+        if (le < 0.0f) le = 0.0f;
+        rmw_min_u32(reinterpret_cast<unsigned *>(tokp(wt, ht, L[u].x)) + 3, __float_as_uint(le));
+      }
+      kept += __popcll(__ballot(keep));
+    }
   }
+  return kept;
 }
 
 // PruneForwardLinks for one frame (lattice-faster-decoder.cc:300-371), evaluated to its fixed
-// point.  tmp[] of the frame's tokens must hold +inf on entry and holds +inf again on exit.
-// Returns (uniformly) whether any token's extra_cost changed.
+// point.  tmp of the frame's tokens must hold +inf on entry and holds +inf again on exit.
+// Leaves the frame's survivor counts in its FrameRec.  Returns (uniformly) whether any token's
+// extra_cost changed.
 __device__ bool prune_frame(const Slot &s, int f, float lattice_beam, float delta, Shared &sh, int &pp) {
   const int tid = threadIdx.x;
-  const int tb = s.tok_b[f], te = s.tok_e[f];
-  const bool tw = s.tok_w[f];
-  unsigned *extra = tw ? s.w_extra : s.h_extra, *tmp = tw ? s.w_tmp : s.h_tmp;
-  const float *tcost = tw ? s.w_cost : s.h_cost;
-  const int eb = s.el_b[f], ee = s.el_e[f], pb = s.pl_b[f], pe = s.pl_e[f];
-  const bool ew = s.el_w[f], pw = s.pl_w[f];
+  FrameRec *frp = s.fr + f;
+  const int tb = frp->tok_b, te = frp->tok_e, eb = frp->el_b, ee = frp->el_e, pb = frp->pl_b, pe = frp->pl_e;
+  const int flags = frp->flags;
+  i32x4 *wt = uptr(s.w_tok), *ht = uptr(s.h_tok);
+  i32x4 *tok = uptr((flags & 1) ? s.w_tok : s.h_tok);
+  i32x4 *elk = uptr((flags & 2) ? s.wl : s.hl), *plk = uptr((flags & 4) ? s.wl : s.hl);
   bool frame_changed = false;
   for (int iter = 0; iter < MAX_EPS_ITERS; iter++) {
-    eval_links(s, ew, eb, ee, tcost, tmp, lattice_beam);
-    eval_links(s, pw, pb, pe, tcost, tmp, lattice_beam);
+    const int ce = eval_links(elk, eb, ee, wt, ht, lattice_beam);
+    const int cp = eval_links(plk, pb, pe, wt, ht, lattice_beam);
+    if ((tid & 63) == 0) {
+      if (ce) atomicAdd(&sh.cnt_el[pp], ce);
+      if (cp) atomicAdd(&sh.cnt_pl[pp], cp);
+    }
     __syncthreads();
-    // flag[pp] is written below and read after the next barrier; flag[pp^1] (read by every
-    // thread before it arrived at the barrier above) is cleared for the following use
-    if (tid == 0) sh.changed2[pp ^ 1] = 0;
-    int ch = 0;
-    {
-      unsigned *tmp_u = uptr(tmp), *extra_u = uptr(extra);
-      for (int t = tb + tid; t < te; t += NT) {
-        const unsigned v = tmp_u[t], o = extra_u[t];
-        tmp_u[t] = INF_BITS;
-        if (v != o) {
-          extra_u[t] = v;
+    // the [pp] entries are written below / above and read after the next barrier; the [pp^1]
+    // entries (read by their consumers before they arrived at the barrier above) are cleared for
+    // the following use
+    if (tid == 0) { sh.changed2[pp ^ 1] = 0; sh.cnt_tok[pp ^ 1] = 0; sh.cnt_el[pp ^ 1] = 0; sh.cnt_pl[pp ^ 1] = 0; }
+    int ch = 0, alive = 0;
+    for (int base = tb; base < te; base += NT * U) {
+      i32x4 R[U]; bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int t = base + u * NT + tid;
+        ok[u] = t < te;
+        R[u] = tok[ok[u] ? t : tb];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int t = base + u * NT + tid;
+        const unsigned v = (unsigned)R[u].w, o = (unsigned)R[u].z;
+        if (ok[u] && (v != o || v != INF_BITS)) {
+          i32x2 nv; nv.x = (int)v; nv.y = (int)INF_BITS;
+          *reinterpret_cast<i32x2 *>(reinterpret_cast<int *>(&tok[t]) + 2) = nv;
           // "changed" as the reference counts it (:358): |new - old| > delta; inf vs inf is no change
-          if (fabsf(__uint_as_float(v) - __uint_as_float(o)) > delta) ch = 1;
+          if (v != o && fabsf(__uint_as_float(v) - __uint_as_float(o)) > delta) ch = 1;
         }
+        alive += __popcll(__ballot(ok[u] && v != INF_BITS));
       }
     }
     if (ch) sh.changed2[pp] = 1;
+    if ((tid & 63) == 0 && alive) atomicAdd(&sh.cnt_tok[pp], alive);
     __syncthreads();
     const bool any = sh.changed2[pp] != 0;
+    const bool last = !any || pe == pb;
+    if (last && tid == 0) { frp->a_tok = sh.cnt_tok[pp]; frp->a_el = sh.cnt_el[pp]; frp->a_pl = sh.cnt_pl[pp]; }
     pp ^= 1;
     frame_changed |= any;
-    if (!any || pe == pb) break;
+    if (last) break;
   }
   return frame_changed;
 }
@@ -324,6 +444,150 @@ __device__ void prune_backward(const Slot &s, int from, int first_unpruned, int 
   if (threadIdx.x == 0) sh.n_visited += visited;   // diagnostic
 }
 
+// largest j < n with beg[j] <= x (beg ascending; empty ranges repeat a value and are skipped)
+__device__ __forceinline__ int seg_find(const int *beg, int n, int x) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (beg[mid] <= x) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// Move the survivors listed by the job in LDS (token frames sh.tbeg[0..j_ntf], link segments
+// sh.sbeg[0..j_nseg], destinations sh.tbase/sh.sbase sized by the survivor counts of the last
+// pruning sweep) into H at destination + stage.  FROM_W: the source is the raw window (token
+// ids carry WBIT, remap table w_remap), else a block of H (remap table h_remap).  H token ids
+// >= remap_lo are translated through h_remap.  Flat over all frames: a survivor finds its
+// frame by binary search in LDS.
+template <bool FROM_W>
+__device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l, int remap_lo) {
+  const int tid = threadIdx.x;
+  i32x4 *wt = uptr(s.w_tok), *ht = uptr(s.h_tok);
+  int *w_remap = uptr(s.w_remap), *h_remap = uptr(s.h_remap);
+  const i32x4 *src_tok = FROM_W ? wt : ht;
+  int *remap = FROM_W ? w_remap : h_remap;
+  const int ntf = sh.j_ntf, nseg = sh.j_nseg;
+  if (ntf > 0) {
+    const int t0 = sh.tbeg[0], t1 = sh.tbeg[ntf];
+    for (int base = t0; base < t1; base += NT * U) {
+      i32x4 R[U]; bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int t = base + u * NT + tid;
+        ok[u] = t < t1;
+        R[u] = src_tok[ok[u] ? t : t0];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int t = base + u * NT + tid;
+        if (!ok[u]) continue;
+        int nid = -1;
+        if ((unsigned)R[u].z != INF_BITS) {
+          const int j = seg_find(sh.tbeg, ntf, t);
+          const int c = atomicAdd(&sh.tcnt[j], 1);
+          if (c < sh.tup[j]) {
+            nid = sh.tbase[j] + c;
+            i32x4 r = R[u]; r.w = (int)INF_BITS;
+            ht[nid + stage_t] = r;
+          } else sh.error = ERR_H_TOK;     // more survivors than the sweep counted: never expected
+        }
+        remap[t] = nid;
+      }
+    }
+  }
+  __syncthreads();
+  if (nseg > 0) {
+    const i32x4 *src_lk = uptr(FROM_W ? s.wl : s.hl);
+    const int *src_arc = uptr(FROM_W ? s.wl_arc : s.hl_arc);
+    i32x4 *hl = uptr(s.hl); int *hl_arc = uptr(s.hl_arc);
+    const int l0 = sh.sbeg[0], l1 = sh.sbeg[nseg];
+    for (int base = l0; base < l1; base += NT * U) {
+      i32x4 L[U]; int A[U]; bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int l = base + u * NT + tid;
+        ok[u] = l < l1;
+        L[u] = src_lk[ok[u] ? l : l0];
+        A[u] = src_arc[ok[u] ? l : l0];
+        ok[u] = ok[u] && L[u].x >= 0;
+      }
+      // end points: window ids and ids of the block being re-compacted go through the remap
+      // tables (-1 = dead); older history tokens keep their id if they are still alive
+      int vs[U], vd[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int a = L[u].x, b = L[u].y;
+        const int *pa = !ok[u] ? h_remap : (a & WBIT) ? w_remap + (a ^ WBIT) : (a >= remap_lo) ? h_remap + a : reinterpret_cast<const int *>(ht + a) + 2;
+        const int *pb = !ok[u] ? h_remap : (b & WBIT) ? w_remap + (b ^ WBIT) : (b >= remap_lo) ? h_remap + b : reinterpret_cast<const int *>(ht + b) + 2;
+        vs[u] = *pa; vd[u] = *pb;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int l = base + u * NT + tid;
+        if (!ok[u]) continue;
+        const int a = L[u].x, b = L[u].y;
+        const int ns = ((a & WBIT) || a >= remap_lo) ? vs[u] : ((unsigned)vs[u] != INF_BITS ? a : -1);
+        const int nd = ((b & WBIT) || b >= remap_lo) ? vd[u] : ((unsigned)vd[u] != INF_BITS ? b : -1);
+        if (ns < 0 || nd < 0) continue;
+        const int j = seg_find(sh.sbeg, nseg, l);
+        const int c = atomicAdd(&sh.scnt[j], 1);
+        if (c < sh.sup[j]) {
+          const int nid = sh.sbase[j] + c + stage_l;
+          i32x4 r = L[u]; r.x = ns; r.y = nd;
+          hl[nid] = r; hl_arc[nid] = A[u];
+        } else sh.error = ERR_H_LINK;
+      }
+    }
+  }
+  __syncthreads();
+  // slots the sweep counted but the move did not fill (an end point died without the link being
+  // re-evaluated) become dead entries, so that every frame stays one contiguous range
+  for (int j = tid; j < ntf; j += NT) {
+    const int c = sh.tcnt[j] < sh.tup[j] ? sh.tcnt[j] : sh.tup[j];
+    for (int i = sh.tbase[j] + c; i < sh.tbase[j] + sh.tup[j]; i++) {
+      i32x4 r; r.x = 0; r.y = 0; r.z = (int)INF_BITS; r.w = (int)INF_BITS;
+      s.h_tok[i + stage_t] = r;
+    }
+  }
+  for (int j = tid; j < nseg; j += NT) {
+    const int c = sh.scnt[j] < sh.sup[j] ? sh.scnt[j] : sh.sup[j];
+    for (int i = sh.sbase[j] + c; i < sh.sbase[j] + sh.sup[j]; i++) {
+      i32x4 r; r.x = -1; r.y = 0; r.z = 0; r.w = 0;
+      s.hl[i + stage_l] = r; s.hl_arc[i + stage_l] = 0;
+    }
+  }
+}
+
+// job bookkeeping shared by the two compactions (thread 0)
+__device__ __forceinline__ void job_add_tok(Shared &sh, const FrameRec &r, int f) {
+  const int j = sh.j_ntf++;
+  if (j == 0) sh.j_tf0 = f;
+  const int n = r.tok_e - r.tok_b, up = r.a_tok < n ? r.a_tok : n;
+  sh.tbeg[j] = r.tok_b; sh.tbeg[j + 1] = r.tok_e; sh.tup[j] = up; sh.tbase[j] = sh.j_tdst; sh.tcnt[j] = 0;
+  sh.j_tdst += up;
+}
+__device__ __forceinline__ void job_add_seg(Shared &sh, int b, int e, int a, int id) {
+  const int j = sh.j_nseg++;
+  const int n = e - b, up = a < n ? a : n;
+  sh.sbeg[j] = b; sh.sbeg[j + 1] = e; sh.sup[j] = up; sh.sbase[j] = sh.j_ldst; sh.scnt[j] = 0; sh.sid[j] = id;
+  sh.j_ldst += up;
+}
+// new positions -> FrameRecs (after compact_move; one thread per frame / segment)
+__device__ __forceinline__ void job_publish(const Slot &s, Shared &sh) {
+  const int tid = threadIdx.x;
+  for (int j = tid; j < sh.j_ntf; j += NT) {
+    FrameRec *r = s.fr + (sh.j_tf0 + j);
+    r->tok_b = sh.tbase[j]; r->tok_e = sh.tbase[j] + sh.tup[j]; r->a_tok = sh.tcnt[j] < sh.tup[j] ? sh.tcnt[j] : sh.tup[j];
+  }
+  for (int j = tid; j < sh.j_nseg; j += NT) {
+    FrameRec *r = s.fr + (sh.sid[j] >> 1);
+    const int c = sh.scnt[j] < sh.sup[j] ? sh.scnt[j] : sh.sup[j];
+    if (sh.sid[j] & 1) { r->pl_b = sh.sbase[j]; r->pl_e = sh.sbase[j] + sh.sup[j]; r->a_pl = c; }
+    else { r->el_b = sh.sbase[j]; r->el_e = sh.sbase[j] + sh.sup[j]; r->a_el = c; }
+  }
+}
+
 // Re-compact the block that the previous compaction appended to H (frames (tail_f0, tail_f1]
 // and their links).  When it was appended its youngest frames had no look-ahead, so most of
 // their tokens and links survived; by now they have been pruned again and nearly all of them are
@@ -335,107 +599,48 @@ __device__ bool recompact_tail(const Slot &s, Shared &sh) {
   const int tf0 = sh.tail_f0, tf1 = sh.tail_f1;
   if (tf1 < 0) return true;                       // nothing appended yet
   const int fa = tf0 < 0 ? 0 : tf0;               // link frames fa..tf1 (emitting: fa..tf1-1), token frames tf0+1..tf1
-  const int nf = tf1 - fa + 1;
   const int tail_tb = sh.tail_tok_b, tail_lb = sh.tail_link_b;
   const int old_nt = sh.h_ntok, old_nl = sh.h_nlink;
-  for (int i = tid; i < 3 * nf; i += NT) sh.fr_cnt[i] = 0;
-  __syncthreads();
-  const unsigned *he = uptr(s.h_extra);
-  const int *hs = uptr(s.hl_src), *hd = uptr(s.hl_dst);
-  for (int k = 0; k < nf; k++) {
-    const int f = fa + k;
-    if (f > tf0) {
-      int c = 0;
-      for (int t = s.tok_b[f] + tid; t < s.tok_e[f]; t += NT) c += he[t] != INF_BITS;
-      if (c) atomicAdd(&sh.fr_cnt[k], c);
-    }
-    for (int pass = 0; pass < 2; pass++) {
-      if (pass == 0 && f == tf1) continue;        // emitting links of the frontier frame are still in W
-      if (pass == 1 && f <= tf0) continue;
-      const int lb = pass ? s.pl_b[f] : s.el_b[f], le_ = pass ? s.pl_e[f] : s.el_e[f];
-      int c = 0;
-      for (int l = lb + tid; l < le_; l += NT) {
-        const int src = hs[l];
-        c += src >= 0 && he[src] != INF_BITS && he[hd[l]] != INF_BITS;
-      }
-      if (c) atomicAdd(&sh.fr_cnt[(1 + pass) * nf + k], c);
-    }
-  }
   __syncthreads();
   if (tid == 0) {
-    int tb = tail_tb, lb = tail_lb;
-    for (int k = 0; k < nf; k++) { sh.fr_base[k] = tb; tb += sh.fr_cnt[k]; }
-    for (int k = 0; k < nf; k++) {
-      sh.fr_base[nf + k] = lb; lb += sh.fr_cnt[nf + k];
-      sh.fr_base[2 * nf + k] = lb; lb += sh.fr_cnt[2 * nf + k];
+    sh.j_ntf = 0; sh.j_nseg = 0; sh.j_tf0 = 0; sh.j_tdst = tail_tb; sh.j_ldst = tail_lb;
+    for (int f = fa; f <= tf1; f++) {
+      const FrameRec r = s.fr[f];
+      if (f > tf0) job_add_tok(sh, r, f);
+      if (f > tf0) job_add_seg(sh, r.pl_b, r.pl_e, r.a_pl, (f << 1) | 1);
+      if (f < tf1) job_add_seg(sh, r.el_b, r.el_e, r.a_el, f << 1);   // emitting links of the frontier frame are still in W
     }
-    // staging area = [old_nt, old_nt + alive) and [old_nl, old_nl + alive)
-    if (old_nt + (tb - tail_tb) > s.h_tok_cap) sh.error = ERR_H_TOK;
-    if (old_nl + (lb - tail_lb) > s.h_link_cap) sh.error = ERR_H_LINK;
-    sh.h_ntok = tb; sh.h_nlink = lb;             // new ends of the history
+    // staging area = [old_nt, old_nt + survivors) and [old_nl, old_nl + survivors)
+    if (old_nt + (sh.j_tdst - tail_tb) > s.h_tok_cap) sh.error = ERR_H_TOK;
+    if (old_nl + (sh.j_ldst - tail_lb) > s.h_link_cap) sh.error = ERR_H_LINK;
+    sh.h_ntok = sh.j_tdst; sh.h_nlink = sh.j_ldst;     // new ends of the history
   }
   __syncthreads();
   if (sh.error != ERR_NONE) return false;
   const int new_nt = sh.h_ntok, new_nl = sh.h_nlink;
-  for (int i = tid; i < 3 * nf; i += NT) sh.fr_cnt[i] = 0;
-  __syncthreads();
   const int stage_t = old_nt - tail_tb, stage_l = old_nl - tail_lb;   // staging offset relative to the final position
-  // ---- tokens -> staging, remap table
-  for (int k = 0; k < nf; k++) {
-    const int f = fa + k;
-    if (f <= tf0) continue;
-    for (int t = s.tok_b[f] + tid; t < s.tok_e[f]; t += NT) {
-      int nid = -1;
-      if (s.h_extra[t] != INF_BITS) {
-        nid = sh.fr_base[k] + atomicAdd(&sh.fr_cnt[k], 1);
-        const int q = nid + stage_t;
-        s.h_state[q] = s.h_state[t]; s.h_cost[q] = s.h_cost[t]; s.h_extra[q] = s.h_extra[t];
-      }
-      s.h_remap[t] = nid;
-    }
-  }
+  compact_move<false>(s, sh, stage_t, stage_l, tail_tb);
   __syncthreads();
-  // ---- links -> staging (end points remapped when they lie in the block)
-  for (int k = 0; k < nf; k++) {
-    const int f = fa + k;
-    for (int pass = 0; pass < 2; pass++) {
-      if (pass == 0 && f == tf1) continue;
-      if (pass == 1 && f <= tf0) continue;
-      const int lb = pass ? s.pl_b[f] : s.el_b[f], le_ = pass ? s.pl_e[f] : s.el_e[f];
-      const int slot = (1 + pass) * nf + k;
-      for (int l = lb + tid; l < le_; l += NT) {
-        int src = s.hl_src[l];
-        if (src < 0) continue;
-        int dst = s.hl_dst[l];
-        if (src >= tail_tb) src = s.h_remap[src];
-        if (dst >= tail_tb) dst = s.h_remap[dst];
-        if (src < 0 || dst < 0) continue;
-        if (s.h_extra[s.hl_src[l]] == INF_BITS) continue;   // source outside the block but dead
-        const int q = sh.fr_base[slot] + atomicAdd(&sh.fr_cnt[slot], 1) + stage_l;
-        s.hl_src[q] = src; s.hl_dst[q] = dst; s.hl_il[q] = s.hl_il[l]; s.hl_ol[q] = s.hl_ol[l];
-        s.hl_gr[q] = s.hl_gr[l]; s.hl_ac[q] = s.hl_ac[l];
-      }
-    }
-  }
-  __syncthreads();
+  if (sh.error != ERR_NONE) return false;
   // ---- staging -> final position (the two regions never overlap: staging starts at the old end)
-  for (int i = tail_tb + tid; i < new_nt; i += NT) {
-    const int q = i + stage_t;
-    s.h_state[i] = s.h_state[q]; s.h_cost[i] = s.h_cost[q]; s.h_extra[i] = s.h_extra[q]; s.h_tmp[i] = INF_BITS;
-  }
-  for (int i = tail_lb + tid; i < new_nl; i += NT) {
-    const int q = i + stage_l;
-    s.hl_src[i] = s.hl_src[q]; s.hl_dst[i] = s.hl_dst[q]; s.hl_il[i] = s.hl_il[q]; s.hl_ol[i] = s.hl_ol[q];
-    s.hl_gr[i] = s.hl_gr[q]; s.hl_ac[i] = s.hl_ac[q];
-  }
-  if (tid == 0) {
-    for (int k = 0; k < nf; k++) {
-      const int f = fa + k;
-      if (f > tf0) { s.tok_b[f] = sh.fr_base[k]; s.tok_e[f] = sh.fr_base[k] + sh.fr_cnt[k]; }
-      if (f != tf1) { s.el_b[f] = sh.fr_base[nf + k]; s.el_e[f] = sh.fr_base[nf + k] + sh.fr_cnt[nf + k]; }
-      if (f > tf0) { s.pl_b[f] = sh.fr_base[2 * nf + k]; s.pl_e[f] = sh.fr_base[2 * nf + k] + sh.fr_cnt[2 * nf + k]; }
+  {
+    i32x4 *ht = uptr(s.h_tok), *hl = uptr(s.hl); int *hl_arc = uptr(s.hl_arc);
+    for (int base = tail_tb; base < new_nt; base += NT * U) {
+      i32x4 R[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) { const int i = base + u * NT + tid; R[u] = ht[(i < new_nt ? i : tail_tb) + stage_t]; }
+#pragma unroll
+      for (int u = 0; u < U; u++) { const int i = base + u * NT + tid; if (i < new_nt) ht[i] = R[u]; }
+    }
+    for (int base = tail_lb; base < new_nl; base += NT * U) {
+      i32x4 R[U]; int A[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) { const int i = base + u * NT + tid; const int q = (i < new_nl ? i : tail_lb) + stage_l; R[u] = hl[q]; A[u] = hl_arc[q]; }
+#pragma unroll
+      for (int u = 0; u < U; u++) { const int i = base + u * NT + tid; if (i < new_nl) { hl[i] = R[u]; hl_arc[i] = A[u]; } }
     }
   }
+  job_publish(s, sh);
   __threadfence_block();
   __syncthreads();
   return true;
@@ -443,8 +648,7 @@ __device__ bool recompact_tail(const Slot &s, Shared &sh) {
 
 // Move the survivors of the raw window into the history: tokens of frames (prev_front, front],
 // emitting links from frames [prev_front, front-1], epsilon links within (prev_front, front].
-// Survivors are counted per frame first so that every frame stays contiguous in H with a
-// handful of barriers in total.  Returns false (uniformly) on overflow.
+// Returns false (uniformly) on overflow.
 __device__ bool compact_window(const Slot &s, int prev_front, int front, Shared &sh) {
   const int tid = threadIdx.x;
   const int old_tail_tb = sh.tail_tok_b;
@@ -452,94 +656,29 @@ __device__ bool compact_window(const Slot &s, int prev_front, int front, Shared 
   if (!recompact_tail(s, sh)) return false;
   const int f0 = prev_front < 0 ? 0 : prev_front;
   const int nf = front - f0 + 1;     // frames f0..front  (<= MAX_WIN_FRAMES, checked on the host)
-  for (int i = tid; i < 3 * nf; i += NT) sh.fr_cnt[i] = 0;
-  __syncthreads();
-  // ---- count
-  for (int k = 0; k < nf; k++) {
-    const int f = f0 + k;
-    if (s.tok_w[f]) {
-      int c = 0;
-      for (int t = s.tok_b[f] + tid; t < s.tok_e[f]; t += NT) c += s.w_extra[t] != INF_BITS;
-      if (c) atomicAdd(&sh.fr_cnt[k], c);
-    }
-    for (int pass = 0; pass < 2; pass++) {
-      if (!(pass ? s.pl_w[f] : s.el_w[f])) continue;
-      const int lb = pass ? s.pl_b[f] : s.el_b[f], le_ = pass ? s.pl_e[f] : s.el_e[f];
-      int c = 0;
-      for (int l = lb + tid; l < le_; l += NT) {
-        const int src = s.wl_src[l];
-        if (src < 0) continue;
-        const int dst = s.wl_dst[l];
-        const bool sa = (src & WBIT) ? s.w_extra[src ^ WBIT] != INF_BITS
-                                     : (had_tail && src >= old_tail_tb ? s.h_remap[src] >= 0 : true);
-        const bool da = (dst & WBIT) ? s.w_extra[dst ^ WBIT] != INF_BITS : true;
-        c += sa && da;
-      }
-      if (c) atomicAdd(&sh.fr_cnt[(1 + pass) * nf + k], c);
-    }
-  }
-  __syncthreads();
   if (tid == 0) {
-    int tb = sh.h_ntok, lb = sh.h_nlink;
-    for (int k = 0; k < nf; k++) { sh.fr_base[k] = tb; tb += sh.fr_cnt[k]; }
-    for (int k = 0; k < nf; k++) {
-      sh.fr_base[nf + k] = lb; lb += sh.fr_cnt[nf + k];
-      sh.fr_base[2 * nf + k] = lb; lb += sh.fr_cnt[2 * nf + k];
+    sh.j_ntf = 0; sh.j_nseg = 0; sh.j_tf0 = 0; sh.j_tdst = sh.h_ntok; sh.j_ldst = sh.h_nlink;
+    for (int f = f0; f <= front; f++) {
+      const FrameRec r = s.fr[f];
+      if (r.flags & 1) job_add_tok(sh, r, f);
+      if (r.flags & 4) job_add_seg(sh, r.pl_b, r.pl_e, r.a_pl, (f << 1) | 1);   // creation order in W: eps links of f, then its emitting links
+      if (r.flags & 2) job_add_seg(sh, r.el_b, r.el_e, r.a_el, f << 1);
     }
-    if (tb > s.h_tok_cap) sh.error = ERR_H_TOK;
-    if (lb > s.h_link_cap) sh.error = ERR_H_LINK;
-    sh.h_ntok = tb; sh.h_nlink = lb;
+    if (sh.j_tdst > s.h_tok_cap) sh.error = ERR_H_TOK;
+    if (sh.j_ldst > s.h_link_cap) sh.error = ERR_H_LINK;
   }
   __syncthreads();
   if (sh.error != ERR_NONE) return false;
-  for (int i = tid; i < 3 * nf; i += NT) sh.fr_cnt[i] = 0;   // reused as fill counters
+  const int blk_tb = sh.h_ntok, blk_lb = sh.h_nlink;
+  compact_move<true>(s, sh, 0, 0, had_tail ? old_tail_tb : INT_MAX);
   __syncthreads();
-  // ---- move tokens
-  for (int k = 0; k < nf; k++) {
-    const int f = f0 + k;
-    if (!s.tok_w[f]) continue;
-    for (int t = s.tok_b[f] + tid; t < s.tok_e[f]; t += NT) {
-      int nid = -1;
-      if (s.w_extra[t] != INF_BITS) {
-        nid = sh.fr_base[k] + atomicAdd(&sh.fr_cnt[k], 1);
-        s.h_state[nid] = s.w_state[t]; s.h_cost[nid] = s.w_cost[t]; s.h_extra[nid] = s.w_extra[t];
-        s.h_tmp[nid] = INF_BITS;
-      }
-      s.w_remap[t] = nid;
-    }
-  }
-  __syncthreads();
-  // ---- move links
-  for (int k = 0; k < nf; k++) {
-    const int f = f0 + k;
-    for (int pass = 0; pass < 2; pass++) {
-      if (!(pass ? s.pl_w[f] : s.el_w[f])) continue;
-      const int lb = pass ? s.pl_b[f] : s.el_b[f], le_ = pass ? s.pl_e[f] : s.el_e[f];
-      const int slot = (1 + pass) * nf + k;
-      for (int l = lb + tid; l < le_; l += NT) {
-        int src = s.wl_src[l];
-        if (src < 0) continue;
-        int dst = s.wl_dst[l];
-        if (src & WBIT) src = s.w_remap[src ^ WBIT];
-        else if (had_tail && src >= old_tail_tb) src = s.h_remap[src];   // a token of the re-compacted block
-        if (dst & WBIT) dst = s.w_remap[dst ^ WBIT];
-        if (src < 0 || dst < 0) continue;
-        const int nid = sh.fr_base[slot] + atomicAdd(&sh.fr_cnt[slot], 1);
-        s.hl_src[nid] = src; s.hl_dst[nid] = dst; s.hl_il[nid] = s.wl_il[l]; s.hl_ol[nid] = s.wl_ol[l];
-        s.hl_gr[nid] = s.wl_gr[l]; s.hl_ac[nid] = s.wl_ac[l];
-      }
-    }
-  }
-  __syncthreads();
+  if (sh.error != ERR_NONE) return false;
+  job_publish(s, sh);
+  for (int k = tid; k < nf; k += NT) s.fr[f0 + k].flags = 0;
   if (tid == 0) {
-    for (int k = 0; k < nf; k++) {
-      const int f = f0 + k;
-      if (s.tok_w[f]) { s.tok_b[f] = sh.fr_base[k]; s.tok_e[f] = sh.fr_base[k] + sh.fr_cnt[k]; s.tok_w[f] = 0; }
-      if (s.el_w[f]) { s.el_b[f] = sh.fr_base[nf + k]; s.el_e[f] = sh.fr_base[nf + k] + sh.fr_cnt[nf + k]; s.el_w[f] = 0; }
-      if (s.pl_w[f]) { s.pl_b[f] = sh.fr_base[2 * nf + k]; s.pl_e[f] = sh.fr_base[2 * nf + k] + sh.fr_cnt[2 * nf + k]; s.pl_w[f] = 0; }
-    }
+    sh.h_ntok = sh.j_tdst; sh.h_nlink = sh.j_ldst;
     sh.w_ntok = 0; sh.w_nlink = 0;
-    sh.tail_tok_b = sh.fr_base[0]; sh.tail_link_b = sh.fr_base[nf];
+    sh.tail_tok_b = blk_tb; sh.tail_link_b = blk_lb;
     sh.tail_f0 = prev_front; sh.tail_f1 = front;
   }
   __threadfence_block();
@@ -556,44 +695,57 @@ __device__ bool compact_window(const Slot &s, int prev_front, int front, Shared 
 // writes visible.
 __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, float cutoff, unsigned ep,
                                    int cur, Shared &sh) {
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long EPK = (unsigned long long)ep << 32;
+  Ent *ent = uptr(s.ent);
+  i32x4 *wt = uptr(s.w_tok);
+  const int w_tok_cap = s.w_tok_cap, front_cap = s.front_cap;
   for (int iter = 0;; iter++) {
-    const int ncur = sh.fcnt[cur] < s.front_cap ? sh.fcnt[cur] : s.front_cap;
+    const int ncur = sh.fcnt[cur] < front_cap ? sh.fcnt[cur] : front_cap;
     if (ncur == 0) break;
     if (iter >= MAX_EPS_ITERS) { if (tid == 0) sh.error = ERR_EPS_LOOP; break; }
     const int nxt = cur == 2 ? 0 : cur + 1, spare = nxt == 2 ? 0 : nxt + 1;
     if (tid == 0) sh.fcnt[spare] = 0;      // nobody touches the spare list during this iteration
     const int *fcur = uptr(s.front[cur]);
     int *fnext = uptr(s.front[nxt]);
-    unsigned long long *key = uptr(s.key);
-    int *tokid = uptr(s.tokid), *w_state = uptr(s.w_state);
-    unsigned *w_extra = uptr(s.w_extra), *w_tmp = uptr(s.w_tmp);
-    const int w_tok_cap = s.w_tok_cap, front_cap = s.front_cap;
-    for (int i = tid; i < ncur; i += NT) {
-      const int st = fcur[i];
-      const float c = o2f((unsigned)ld_u64(&key[st]));
-      if (c > cutoff) continue;
-      for (int a = g.arc_off[st]; a < g.arc_off[st + 1]; a++) {
-        if (g.arc_pdf[a] >= 0) continue;     // emitting arc
-        const vbh_arc arc = g.arcs[a];
-        const float tot = c + arc.weight;
-        if (!(tot < cutoff)) continue;
-        const int ds = arc.nextstate;
-        const unsigned long long nk = EPK | f2o(tot);
-        const unsigned long long old = atomicMin(&key[ds], nk);
-        const bool create = (unsigned)(old >> 32) != ep;   // first touch of this state in this frame
+    int *fcnt_next = &sh.fcnt[nxt];
+    const int CH = wave_chunk(ncur);
+    for (int base = wave * CH; base < ncur; base += NW * CH) {
+      const int i = base + lane;
+      const bool have = lane < CH && i < ncur;
+      const int st = have ? fcur[i] : 0;
+      const unsigned long long k = ld_u64(&ent[st].key);
+      const i32x4 sr = g.st[st];
+      const float c = o2f((unsigned)k);
+      const bool exp = have && !(c > cutoff);
+      const int a0 = sr.x, cnt = exp ? sr.y : 0;
+      wave_expand(cnt, [&](bool valid, int owner, int j) {
+        const int a = __shfl(a0, owner, 64) + j;
+        const float cc = __shfl(c, owner, 64);
+        bool create = false, push = false;
+        int dsraw = 0, ds = 0;
+        if (valid) {
+          const i32x4 arc = g.arcs[a];
+          const float tot = cc + asf(arc.y);
+          if (tot < cutoff) {
+            dsraw = arc.x; ds = dsraw & STMASK;
+            const unsigned long long nk = EPK | f2o(tot);
+            const unsigned long long old = rmw_min_u64(&ent[ds].key, nk);
+            create = (unsigned)(old >> 32) != ep;          // first touch of this state in this frame
+            push = (create || nk < old) && dsraw < 0;      // new or improved, and it has epsilon arcs: (re-)expand
+          }
+        }
         const int nid = wave_alloc(&sh.w_ntok, create);
         if (create) {
           if (nid < w_tok_cap) {
-            w_state[nid] = ds; w_extra[nid] = 0u; w_tmp[nid] = INF_BITS;
-            st_i32(&tokid[ds], nid);
+            i32x4 r; r.x = dsraw; r.y = 0; r.z = 0; r.w = (int)INF_BITS;
+            wt[nid] = r;
+            st_i32(&ent[ds].tokid, nid);
           } else sh.error = ERR_W_TOK;
         }
-        const bool push = (create || nk < old) && g.nieps[ds] > 0;   // new or improved: (re-)expand
-        const int q = wave_alloc(&sh.fcnt[nxt], push);
+        const int q = wave_alloc(fcnt_next, push);
         if (push) { if (q < front_cap) fnext[q] = ds; else sh.error = ERR_FRONT; }
-      }
+      });
     }
     __syncthreads();
     if (sh.error != ERR_NONE) break;
@@ -601,32 +753,41 @@ __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, flo
   }
   __syncthreads();
   // final costs of the frame's tokens + epsilon links regenerated from them (:824-845)
-  const int ne = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap;
+  const int ne = sh.w_ntok < w_tok_cap ? sh.w_ntok : w_tok_cap;
   const int lb = sh.w_nlink;
   __syncthreads();
   {
-    const unsigned long long *key = uptr(s.key);
-    const int *tokid = uptr(s.tokid), *w_state = uptr(s.w_state);
-    float *w_cost = uptr(s.w_cost);
-    int *wl_src = uptr(s.wl_src), *wl_dst = uptr(s.wl_dst), *wl_il = uptr(s.wl_il), *wl_ol = uptr(s.wl_ol);
-    float *wl_gr = uptr(s.wl_gr), *wl_ac = uptr(s.wl_ac);
+    i32x4 *wl = uptr(s.wl); int *wl_arc = uptr(s.wl_arc);
     const int w_link_cap = s.w_link_cap;
-    for (int t = nb + tid; t < ne; t += NT) {
-      const int st = w_state[t];
-      const float c = o2f((unsigned)ld_u64(&key[st]));
-      w_cost[t] = c;
-      if (g.nieps[st] == 0 || c > cutoff) continue;
-      for (int a = g.arc_off[st]; a < g.arc_off[st + 1]; a++) {
-        if (g.arc_pdf[a] >= 0) continue;
-        const vbh_arc arc = g.arcs[a];
-        const float tot = c + arc.weight;
-        if (!(tot < cutoff)) continue;
-        const int l = wave_alloc(&sh.w_nlink, true);
-        if (l < w_link_cap) {
-          wl_src[l] = t | WBIT; wl_dst[l] = ld_i32(&tokid[arc.nextstate]) | WBIT;
-          wl_il[l] = 0; wl_ol[l] = arc.olabel; wl_gr[l] = arc.weight; wl_ac[l] = 0.0f;
-        } else sh.error = ERR_W_LINK;
-      }
+    const int n_new = ne - nb;
+    const int CH = wave_chunk(n_new);
+    for (int base = wave * CH; base < n_new; base += NW * CH) {
+      const int t = nb + base + lane;
+      const bool have = lane < CH && base + lane < n_new;
+      const int sx = have ? wt[t].x : 0;
+      const int st = sx & STMASK;
+      const float c = o2f((unsigned)ld_u64(&ent[st].key));
+      if (have) reinterpret_cast<int *>(&wt[t])[1] = asi(c);
+      const bool exp = have && sx < 0 && !(c > cutoff);
+      int a0 = 0, cnt = 0;
+      if (exp) { const i32x4 sr = g.st[st]; a0 = sr.x; cnt = sr.y; }
+      wave_expand(cnt, [&](bool valid, int owner, int j) {
+        const int a = __shfl(a0, owner, 64) + j;
+        const float cc = __shfl(c, owner, 64);
+        bool mk = false; int dtok = 0; i32x4 arc;
+        if (valid) {
+          arc = g.arcs[a];
+          const float tot = cc + asf(arc.y);
+          if (tot < cutoff) { mk = true; dtok = ld_i32(&ent[arc.x & STMASK].tokid); }
+        }
+        const int l = wave_alloc(&sh.w_nlink, mk);
+        if (mk) {
+          if (l < w_link_cap) {
+            i32x4 r; r.x = (nb + base + owner) | WBIT; r.y = dtok | WBIT; r.z = arc.y; r.w = 0;
+            wl[l] = r; wl_arc[l] = a;
+          } else sh.error = ERR_W_LINK;
+        }
+      });
     }
   }
   __syncthreads();
@@ -638,11 +799,11 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
                                                      const UttDesc *__restrict__ utts, const int *__restrict__ work_list,
                                                      int n_work, int *work_counter, UttResult *results, const Pool *pool_p) {
   __shared__ Shared sh;
-  // The slot's ~45 pointers live in LDS: by value they overflow the SGPR file, and read through
+  // The slot's pointers live in LDS: by value they overflow the SGPR file, and read through
   // the global pointer the compiler re-fetches them with vector loads inside every loop.
   __shared__ Slot s_slot;
   __shared__ Pool s_pool;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   {
     const int *src = reinterpret_cast<const int *>(&slots[blockIdx.x]);
     int *dst = reinterpret_cast<int *>(&s_slot);
@@ -676,6 +837,7 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
       sh.n_max_bound = 0; sh.n_min_bound = 0; sh.n_cand = 0; sh.n_visited = 0;
       sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0;
       sh.changed2[0] = 0; sh.changed2[1] = 0;
+      sh.cnt_tok[0] = 0; sh.cnt_tok[1] = 0; sh.cnt_el[0] = 0; sh.cnt_el[1] = 0; sh.cnt_pl[0] = 0; sh.cnt_pl[1] = 0;
       sh.tail_tok_b = 0; sh.tail_link_b = 0; sh.tail_f0 = -1; sh.tail_f1 = -2;
     }
     pp = 0;
@@ -687,20 +849,24 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
     {
       const unsigned ep = (unsigned)(0xFFFFFFFFu - (unsigned)(epoch_base + 0));
       if (tid == 0) {
-        s.w_state[0] = g.start; s.w_cost[0] = 0.0f; s.w_extra[0] = 0u; s.w_tmp[0] = INF_BITS;
-        s.key[g.start] = ((unsigned long long)ep << 32) | f2o(0.0f);
-        s.tokid[g.start] = 0;
+        const i32x4 sr = g.st[g.start];
+        i32x4 r; r.x = g.start | (sr.y > 0 ? EPSBIT : 0); r.y = 0; r.z = 0; r.w = (int)INF_BITS;
+        s.w_tok[0] = r;
+        s.ent[g.start].key = ((unsigned long long)ep << 32) | f2o(0.0f);
+        s.ent[g.start].tokid = 0;
         sh.w_ntok = 1;
-        if (g.nieps[g.start] > 0) { s.front[0][0] = g.start; sh.fcnt[0] = 1; }
-        s.el_b[0] = 0; s.el_e[0] = 0; s.el_w[0] = 1;
+        if (sr.y > 0) { s.front[0][0] = g.start; sh.fcnt[0] = 1; }
       }
       __threadfence_block();
       __syncthreads();
       const int plb = process_nonemitting(g, s, 0, cfg.beam, ep, 0, sh);
       cur_b = 0; cur_e = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap;
       if (tid == 0) {
-        s.tok_b[0] = 0; s.tok_e[0] = cur_e; s.tok_w[0] = 1;
-        s.pl_b[0] = plb; s.pl_e[0] = sh.w_nlink < s.w_link_cap ? sh.w_nlink : s.w_link_cap; s.pl_w[0] = 1;
+        FrameRec r;
+        r.tok_b = 0; r.tok_e = cur_e; r.el_b = 0; r.el_e = 0;
+        r.pl_b = plb; r.pl_e = sh.w_nlink < s.w_link_cap ? sh.w_nlink : s.w_link_cap;
+        r.flags = 1 | 4; r.cost_offset = 0.0f; r.a_tok = cur_e; r.a_el = 0; r.a_pl = r.pl_e - r.pl_b; r.pad = 0;
+        s.fr[0] = r;
         sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0;
       }
       __syncthreads();
@@ -714,32 +880,32 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
       // ---- periodic pruning (:85-87); frame 0 has nothing behind it
       if (frame > 0 && frame % cfg.prune_interval == 0) {
         __syncthreads();
-        // intermediate passes walk back at most 4 intervals beyond the unpruned frames: a bound on
+        // intermediate passes walk back at most one interval beyond the unpruned frames: a bound on
         // the work (long-lived parallel paths would otherwise drag every pass back to frame 0);
         // whatever is left stale is a lower bound and is settled by the final pass
-        prune_backward(s, frame - 1, prev_front < 0 ? 0 : prev_front, (prev_front < 0 ? 0 : prev_front) - 4 * cfg.prune_interval,
+        prune_backward(s, frame - 1, prev_front < 0 ? 0 : prev_front, (prev_front < 0 ? 0 : prev_front) - cfg.prune_interval,
                        cfg.lattice_beam, cfg.lattice_beam * 0.1f, sh, pp);
         PHASE(4)
         if (!compact_window(s, prev_front, frame, sh)) break;
         prev_front = frame;
-        cur_b = s.tok_b[frame]; cur_e = s.tok_e[frame]; cur_w = false;
+        cur_b = s.fr[frame].tok_b; cur_e = s.fr[frame].tok_e; cur_w = false;
         PHASE(5)
       }
       const int tb = cur_b, n = cur_e - cur_b;
-      const int *tstate = uptr(cur_w ? s.w_state : s.h_state) + tb;
-      const float *tcost = uptr(cur_w ? s.w_cost : s.h_cost) + tb;
-      float *c_tot = uptr(s.c_tot), *c_ac = uptr(s.c_ac);
-      int *c_arc = uptr(s.c_arc), *c_src = uptr(s.c_src), *c_dst = uptr(s.c_dst);
+      const i32x4 *tok = uptr(cur_w ? s.w_tok : s.h_tok) + tb;
+      i32x4 *cand = uptr(s.cand); i32x2 *cand2 = uptr(s.cand2);
       const int cand_cap = s.cand_cap;
       const int enc = cur_w ? WBIT : 0;
       const float *llrow = loglikes + (ud.row0 + frame) * (long long)P;
       const unsigned ep = (unsigned)(0xFFFFFFFFu - (unsigned)(epoch_base + frame + 1));
       const unsigned long long EPK = (unsigned long long)ep << 32;
 
-      // ---- GetCutoff (:618-685)
+      // ---- GetCutoff (:618-685); the costs go to LDS on the way
       unsigned long long bk = ~0ull;
       for (int i = tid; i < n; i += NT) {
-        const unsigned long long k = ((unsigned long long)f2o(tcost[i]) << 32) | (unsigned)tstate[i];
+        const i32x4 r = tok[i];
+        if (i < COST_CAP) sh.cost[i] = asf(r.y);
+        const unsigned long long k = ((unsigned long long)f2o(asf(r.y)) << 32) | (unsigned)(r.x & STMASK);
         bk = k < bk ? k : bk;
       }
       bk = block_min_u64(bk, sh, par);
@@ -752,18 +918,21 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
         const float beam_cutoff = best + cfg.beam;
         float mac = INF, mic = INF;
         unsigned long long cnt = 0;   // (#cost < beam_cutoff) << 32 | (#cost <= beam_cutoff)
-        for (int i = tid; i < n; i += NT) cnt += ((unsigned long long)(tcost[i] < beam_cutoff) << 32) | (unsigned long long)(tcost[i] <= beam_cutoff);
+        for (int i = tid; i < n; i += NT) {
+          const float c = frame_cost(sh, tok, i);
+          cnt += ((unsigned long long)(c < beam_cutoff) << 32) | (unsigned long long)(c <= beam_cutoff);
+        }
         cnt = block_sum_u64(cnt, sh, par);
         const int cnt_lt = (int)(cnt >> 32), cnt_le = (int)(unsigned)cnt;
         // the order statistic is only needed when it decides the comparison
-        if (n > cfg.max_active && cnt_lt > cfg.max_active) mac = select_kth(tcost, n, cfg.max_active, sh);
+        if (n > cfg.max_active && cnt_lt > cfg.max_active) mac = select_kth(tok, n, cfg.max_active, sh);
         if (mac < beam_cutoff) {
           adaptive_beam = mac - best + cfg.beam_delta; cur_cutoff = mac;
           if (tid == 0) sh.n_max_bound++;
         } else {
           if (n > cfg.min_active) {
             if (cfg.min_active == 0) mic = best;
-            else if (cnt_le <= cfg.min_active) mic = select_kth(tcost, n, cfg.min_active, sh);
+            else if (cnt_le <= cfg.min_active) mic = select_kth(tok, n, cfg.min_active, sh);
             else mic = beam_cutoff;   // some value <= beam_cutoff: the comparison below is false
           }
           if (mic > beam_cutoff) {
@@ -772,42 +941,59 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
           } else { adaptive_beam = cfg.beam; cur_cutoff = beam_cutoff; }
         }
       }
-      // ---- cost_offset and the initial next_cutoff from the best token (:706-724)
+      // ---- cost_offset and the initial next_cutoff from the best token (:706-724): wave 0,
+      //      one arc per lane; the result is first read after pass 1's reduction barrier
       const float cost_offset = n > 0 ? -best : 0.0f;
-      if (tid == 0) {
+      if (wave == 0) {
         float nc = INF;
         if (n > 0) {
-          for (int a = g.arc_off[best_state]; a < g.arc_off[best_state + 1]; a++) {
-            const int pdf = g.arc_pdf[a];
-            if (pdf >= 0) {
-              const float ll = cfg.acwt * llrow[pdf];
-              const float nw = ((g.arcs[a].weight + cost_offset) - ll) + best;
-              if (nw + adaptive_beam < nc) nc = nw + adaptive_beam;
-            }
+          const i32x4 sr = g.st[best_state];
+          const int a0 = sr.x + sr.y, ne = sr.z - sr.y;
+          for (int j = lane; j < ne; j += 64) {
+            const i32x4 arc = g.arcs[a0 + j];
+            const float ll = cfg.acwt * llrow[arc.z];
+            const float nw = ((asf(arc.y) + cost_offset) - ll) + best;
+            if (nw + adaptive_beam < nc) nc = nw + adaptive_beam;
           }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) nc = fminf(nc, __shfl_xor(nc, o, 64));
         }
-        sh.f0 = nc;
-        s.cost_offset[frame] = cost_offset;
+        if (lane == 0) { sh.f0 = nc; s.fr[frame].cost_offset = cost_offset; }
       }
       PHASE(0)
-      // ---- pass 1 (token-parallel): every candidate arc -> scratch list; min of tot + adaptive_beam
+      // ---- pass 1 (arc-parallel): every candidate arc -> scratch list; min of tot + adaptive_beam
       float mymin = INF;
-      for (int i = tid; i < n; i += NT) {
-        const float c = tcost[i];
-        if (!(c <= cur_cutoff)) continue;
-        c_tok_exp++;
-        const int st = tstate[i];
-        for (int a = g.arc_off[st]; a < g.arc_off[st + 1]; a++) {
-          const int pdf = g.arc_pdf[a];
-          if (pdf < 0) continue;
-          c_arc_exp++;
-          const vbh_arc arc = g.arcs[a];
-          const float ac = cost_offset - cfg.acwt * llrow[pdf];
-          const float tot = (c + ac) + arc.weight;
-          mymin = fminf(mymin, tot + adaptive_beam);
-          const int q = wave_alloc(&sh.n_cand, true);
-          if (q < cand_cap) { c_tot[q] = tot; c_ac[q] = ac; c_arc[q] = a; c_src[q] = i; c_dst[q] = arc.nextstate; }
-          else sh.error = ERR_CAND;
+      {
+        const int CH = wave_chunk(n);
+        for (int base = wave * CH; base < n; base += NW * CH) {
+          const int i = base + lane;
+          const bool have = lane < CH && i < n;
+          const i32x4 rec = tok[have ? i : 0];
+          const float c = asf(rec.y);
+          const bool exp = have && (c <= cur_cutoff);
+          const i32x4 sr = g.st[exp ? (rec.x & STMASK) : 0];
+          const int a0 = sr.x + sr.y, cnt = exp ? sr.z - sr.y : 0;
+          c_tok_exp += exp;
+          wave_expand(cnt, [&](bool valid, int owner, int j) {
+            const int a = __shfl(a0, owner, 64) + j;
+            const float cc = __shfl(c, owner, 64);
+            i32x4 arc; float ac = 0.0f, tot = 0.0f;
+            if (valid) {
+              arc = g.arcs[a];
+              ac = cost_offset - cfg.acwt * llrow[arc.z];
+              tot = (cc + ac) + asf(arc.y);
+              mymin = fminf(mymin, tot + adaptive_beam);
+              c_arc_exp++;
+            }
+            const int q = wave_alloc(&sh.n_cand, valid);
+            if (valid) {
+              if (q < cand_cap) {
+                i32x4 ca; ca.x = asi(tot); ca.y = asi(ac); ca.z = a; ca.w = base + owner;
+                i32x2 cb; cb.x = arc.x; cb.y = arc.y;
+                cand[q] = ca; cand2[q] = cb;
+              } else sh.error = ERR_CAND;
+            }
+          });
         }
       }
       mymin = block_min_f(mymin, sh, par);
@@ -818,47 +1004,70 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
       // ---- pass 2 (candidate-parallel): admit tot <= next_cutoff; min-cost per state via one
       //      64-bit atomicMin; the thread that meets a stale epoch creates the token
       {
-        unsigned long long *key = uptr(s.key);
-        int *tokid = uptr(s.tokid), *w_state = uptr(s.w_state), *front0 = uptr(s.front[0]);
-        unsigned *w_extra = uptr(s.w_extra), *w_tmp = uptr(s.w_tmp);
+        Ent *ent = uptr(s.ent);
+        i32x4 *wt = uptr(s.w_tok);
+        int *front0 = uptr(s.front[0]);
         const int w_tok_cap = s.w_tok_cap, front_cap = s.front_cap;
-        for (int q = tid; q < ncand; q += NT) {
-          const float tot = c_tot[q];
-          if (tot > next_cutoff) continue;
-          const int ds = c_dst[q];
-          const unsigned long long old = atomicMin(&key[ds], EPK | f2o(tot));
-          const bool create = (unsigned)(old >> 32) != ep;
-          const int nid = wave_alloc(&sh.w_ntok, create);
-          bool ok_tok = false;
-          if (create) {
-            if (nid < w_tok_cap) {
-              w_state[nid] = ds; w_extra[nid] = 0u; w_tmp[nid] = INF_BITS;
-              st_i32(&tokid[ds], nid);
-              ok_tok = true;
-            } else sh.error = ERR_W_TOK;
+        for (int base = 0; base < ncand; base += NT * U) {
+          i32x4 CA[U]; i32x2 CB[U]; bool adm[U]; unsigned long long old[U];
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const int q = base + u * NT + tid;
+            const bool ok = q < ncand;
+            CA[u] = cand[ok ? q : 0]; CB[u] = cand2[ok ? q : 0];
+            adm[u] = ok && !(asf(CA[u].x) > next_cutoff);
           }
-          const bool pushf = ok_tok && g.nieps[ds] > 0;
-          const int f = wave_alloc(&sh.fcnt[0], pushf);
-          if (pushf) { if (f < front_cap) front0[f] = ds; else sh.error = ERR_FRONT; }
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            old[u] = 0;
+            if (adm[u]) old[u] = rmw_min_u64(&ent[CB[u].x & STMASK].key, EPK | f2o(asf(CA[u].x)));
+          }
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const bool create = adm[u] && (unsigned)(old[u] >> 32) != ep;
+            const int nid = wave_alloc(&sh.w_ntok, create);
+            bool pushf = false;
+            if (create) {
+              if (nid < w_tok_cap) {
+                i32x4 r; r.x = CB[u].x; r.y = 0; r.z = 0; r.w = (int)INF_BITS;
+                wt[nid] = r;
+                st_i32(&ent[CB[u].x & STMASK].tokid, nid);
+                pushf = CB[u].x < 0;
+              } else sh.error = ERR_W_TOK;
+            }
+            const int f = wave_alloc(&sh.fcnt[0], pushf);
+            if (pushf) { if (f < front_cap) front0[f] = CB[u].x & STMASK; else sh.error = ERR_FRONT; }
+          }
         }
       }
       __syncthreads();
       // ---- pass 3 (candidate-parallel): forward links (:765-767)
       const int lb = sh.w_nlink;
       if (sh.error == ERR_NONE) {
-        const int *tokid = uptr(s.tokid);
-        int *wl_src = uptr(s.wl_src), *wl_dst = uptr(s.wl_dst), *wl_il = uptr(s.wl_il), *wl_ol = uptr(s.wl_ol);
-        float *wl_gr = uptr(s.wl_gr), *wl_ac = uptr(s.wl_ac);
+        const Ent *ent = uptr(s.ent);
+        i32x4 *wl = uptr(s.wl); int *wl_arc = uptr(s.wl_arc);
         const int w_link_cap = s.w_link_cap;
-        for (int q = tid; q < ncand; q += NT) {
-          const float tot = c_tot[q];
-          if (tot > next_cutoff) continue;
-          const vbh_arc arc = g.arcs[c_arc[q]];
-          const int l = wave_alloc(&sh.w_nlink, true);
-          if (l < w_link_cap) {
-            wl_src[l] = (tb + c_src[q]) | enc; wl_dst[l] = ld_i32(&tokid[arc.nextstate]) | WBIT;
-            wl_il[l] = arc.ilabel; wl_ol[l] = arc.olabel; wl_gr[l] = arc.weight; wl_ac[l] = c_ac[q];
-          } else sh.error = ERR_W_LINK;
+        for (int base = 0; base < ncand; base += NT * U) {
+          i32x4 CA[U]; i32x2 CB[U]; bool adm[U]; int dtok[U];
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const int q = base + u * NT + tid;
+            const bool ok = q < ncand;
+            CA[u] = cand[ok ? q : 0]; CB[u] = cand2[ok ? q : 0];
+            adm[u] = ok && !(asf(CA[u].x) > next_cutoff);
+          }
+#pragma unroll
+          for (int u = 0; u < U; u++) dtok[u] = ld_i32(&ent[adm[u] ? (CB[u].x & STMASK) : 0].tokid);
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const int l = wave_alloc(&sh.w_nlink, adm[u]);
+            if (adm[u]) {
+              if (l < w_link_cap) {
+                i32x4 r; r.x = (tb + CA[u].w) | enc; r.y = dtok[u] | WBIT; r.z = CB[u].y; r.w = CA[u].y;
+                wl[l] = r; wl_arc[l] = CA[u].z;
+              } else sh.error = ERR_W_LINK;
+            }
+          }
         }
       }
       __syncthreads();
@@ -870,9 +1079,12 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
       cur_b = nb; cur_e = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap; cur_w = true;
       const int pl_end = sh.w_nlink < s.w_link_cap ? sh.w_nlink : s.w_link_cap;
       if (tid == 0) {
-        s.el_b[frame] = lb; s.el_e[frame] = le_emit; s.el_w[frame] = 1;
-        s.tok_b[frame + 1] = cur_b; s.tok_e[frame + 1] = cur_e; s.tok_w[frame + 1] = 1;
-        s.pl_b[frame + 1] = plb; s.pl_e[frame + 1] = pl_end; s.pl_w[frame + 1] = 1;
+        FrameRec *r0 = s.fr + frame;
+        r0->el_b = lb; r0->el_e = le_emit; r0->flags |= 2; r0->a_el = le_emit - lb;
+        FrameRec r;
+        r.tok_b = cur_b; r.tok_e = cur_e; r.el_b = 0; r.el_e = 0; r.pl_b = plb; r.pl_e = pl_end;
+        r.flags = 1 | 4; r.cost_offset = 0.0f; r.a_tok = cur_e - cur_b; r.a_el = 0; r.a_pl = pl_end - plb; r.pad = 0;
+        s.fr[frame + 1] = r;
         sh.n_cand = 0; sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0;
       }
       c_tok_new += cur_e - cur_b; c_link_new += pl_end - lb;
@@ -888,20 +1100,18 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
     int final_empty = 1;
     if (search_ok) {
       const int F = T;
-      if (tid == 0) {   // ranges of the last frame as the pruning code reads them
-        s.el_b[F] = 0; s.el_e[F] = 0; s.el_w[F] = 0;
-      }
       __threadfence_block();
       __syncthreads();
-      const int tb = s.tok_b[F], te = s.tok_e[F];
-      const bool tw = s.tok_w[F];
-      const int *tstate = tw ? s.w_state : s.h_state;
-      const float *tcost = tw ? s.w_cost : s.h_cost;
-      unsigned *extra = tw ? s.w_extra : s.h_extra, *tmp = tw ? s.w_tmp : s.h_tmp;
+      const FrameRec fr = s.fr[F];
+      const int tb = fr.tok_b, te = fr.tok_e;
+      i32x4 *wt = uptr(s.w_tok), *ht = uptr(s.h_tok);
+      i32x4 *tok = uptr((fr.flags & 1) ? s.w_tok : s.h_tok);
+      i32x4 *plk = uptr((fr.flags & 4) ? s.wl : s.hl);
       // ComputeFinalCosts (:532-572)
       float bc = INF, bwf = INF; unsigned long long anyfinal = 0;
       for (int t = tb + tid; t < te; t += NT) {
-        const float fc = g.final_cost[tstate[t]], c = tcost[t];
+        const i32x4 r = tok[t];
+        const float fc = asf(g.st[r.x & STMASK].w), c = asf(r.y);
         bc = fminf(bc, c); bwf = fminf(bwf, c + fc);
         anyfinal += fc != INF;
       }
@@ -911,32 +1121,40 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
       final_relative = (bc == INF && bwf == INF) ? INF : bwf - bc;
       final_best = (bwf != INF) ? bwf : bc;
       // PruneForwardLinksFinal (:376-458), to the fixed point
-      const int pb = s.pl_b[F], pe = s.pl_e[F];
-      const bool pw = s.pl_w[F];
+      const int pb = fr.pl_b, pe = fr.pl_e;
       for (int iter = 0; iter < MAX_EPS_ITERS; iter++) {
         for (int t = tb + tid; t < te; t += NT) {
-          const float fc = final_empty ? 0.0f : g.final_cost[tstate[t]];
-          const float x = tcost[t] + fc - final_best;    // >= 0 by construction
-          tmp[t] = __float_as_uint(x);
+          const i32x4 r = tok[t];
+          const float fc = final_empty ? 0.0f : asf(g.st[r.x & STMASK].w);
+          const float x = asf(r.y) + fc - final_best;    // >= 0 by construction
+          reinterpret_cast<int *>(&tok[t])[3] = asi(x);
         }
         __syncthreads();
-        eval_links(s, pw, pb, pe, tcost, tmp, cfg.lattice_beam);
+        const int cp = eval_links(plk, pb, pe, wt, ht, cfg.lattice_beam);
+        if ((tid & 63) == 0 && cp) atomicAdd(&sh.cnt_pl[pp], cp);
         __syncthreads();
-        if (tid == 0) sh.changed2[pp ^ 1] = 0;
-        int ch = 0;
+        if (tid == 0) { sh.changed2[pp ^ 1] = 0; sh.cnt_tok[pp ^ 1] = 0; sh.cnt_el[pp ^ 1] = 0; sh.cnt_pl[pp ^ 1] = 0; }
+        int ch = 0, alive = 0;
         for (int t = tb + tid; t < te; t += NT) {
-          float v = __uint_as_float(tmp[t]);
-          tmp[t] = INF_BITS;
+          const i32x4 r = tok[t];
+          float v = asf(r.w);
           if (v > cfg.lattice_beam) v = INF;
           const unsigned vb = __float_as_uint(v);
-          if (vb != extra[t]) { extra[t] = vb; ch = 1; }
+          i32x2 nv; nv.x = (int)vb; nv.y = (int)INF_BITS;
+          *reinterpret_cast<i32x2 *>(reinterpret_cast<int *>(&tok[t]) + 2) = nv;
+          if (vb != (unsigned)r.z) ch = 1;
+          alive += vb != INF_BITS;
         }
         if (ch) sh.changed2[pp] = 1;
+        if (alive) atomicAdd(&sh.cnt_tok[pp], alive);
         __syncthreads();
         const bool any = sh.changed2[pp] != 0;
+        const bool last = !any || pe == pb;
+        if (last && tid == 0) { s.fr[F].a_tok = sh.cnt_tok[pp]; s.fr[F].a_pl = sh.cnt_pl[pp]; s.fr[F].a_el = 0; }
         pp ^= 1;
-        if (!any || pe == pb) break;
+        if (last) break;
       }
+      __syncthreads();
       prune_backward(s, F - 1, /*first_unpruned=*/0, /*stop_at=*/0, cfg.lattice_beam, 0.0f, sh, pp);   // every frame, delta 0 (:606-611)
       PHASE(4)
       compact_window(s, prev_front, F, sh);
@@ -944,23 +1162,50 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
     }
     __syncthreads();
 
-    // ---- write the surviving lattice to the dense pool (content of GetRawLattice :110-192)
+    // ---- write the surviving lattice to the dense pool (content of GetRawLattice :110-192).
+    //      One wave per frame; two traversals (number + count, then write) so that the pool
+    //      space is reserved with one atomic per utterance.
     int r_ok = 0, r_error = sh.error, r_reached_final = 0, r_n_tok = 0, r_n_link = 0;
     long long r_tok_off = 0, r_link_off = 0, r_cost_off = 0;
     if (search_ok && sh.error == ERR_NONE) {
       const int F = T;
-      unsigned long long na = 0, nl = 0;
-      for (int t = tid; t < sh.h_ntok; t += NT) na += s.h_extra[t] != INF_BITS;
-      na = block_sum_u64(na, sh, par);
-      for (int l = tid; l < sh.h_nlink; l += NT) {
-        const int src = s.hl_src[l];
-        nl += src >= 0 && s.h_extra[src] != INF_BITS && s.h_extra[s.hl_dst[l]] != INF_BITS;
+      const i32x4 *ht = uptr(s.h_tok), *hl = uptr(s.hl);
+      const int *hl_arc = uptr(s.hl_arc);
+      int *h_remap = uptr(s.h_remap);
+      if (tid == 0) sh.flag = 0;
+      __syncthreads();
+      // dense index per alive history token (h_remap; -1 = dead)
+      unsigned long long alive_last = 0;
+      for (int f = wave; f <= F; f += NW) {
+        const FrameRec fr = s.fr[f];
+        for (int b0 = fr.tok_b; b0 < fr.tok_e; b0 += 64) {
+          const int t = b0 + lane;
+          const bool in = t < fr.tok_e;
+          const bool alive = in && (unsigned)ht[in ? t : fr.tok_b].z != INF_BITS;
+          const int d = wave_alloc(&sh.flag, alive);
+          if (in) h_remap[t] = alive ? d : -1;
+          if (f == F) alive_last += alive;
+        }
+      }
+      alive_last = block_sum_u64(alive_last, sh, par);   // (barrier: h_remap and sh.flag complete)
+      const unsigned long long na = (unsigned long long)sh.flag;
+      unsigned long long nl = 0;
+      for (int f = wave; f <= F; f += NW) {
+        const FrameRec fr = s.fr[f];
+        for (int pass = 0; pass < 2; pass++) {
+          const int lb = pass ? fr.pl_b : fr.el_b, le_ = pass ? fr.pl_e : fr.el_e;
+          for (int b0 = lb; b0 < le_; b0 += 64) {
+            const int l = b0 + lane;
+            const bool in = l < le_;
+            const i32x4 L = hl[in ? l : lb];
+            const bool live = in && L.x >= 0;
+            const int a = h_remap[live ? L.x : 0], b = h_remap[live ? L.y : 0];
+            nl += live && a >= 0 && b >= 0;
+          }
+        }
       }
       nl = block_sum_u64(nl, sh, par);
-      if (tid == 0) {
-        sh.u0 = atomicAdd(&pool.counters[0], na);
-        sh.flag = 0;
-      }
+      if (tid == 0) sh.u0 = atomicAdd(&pool.counters[0], na);
       __syncthreads();
       const long long toff = (long long)sh.u0;
       __syncthreads();
@@ -968,56 +1213,54 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
       __syncthreads();
       const long long loff = (long long)sh.u0;
       __syncthreads();
-      if (tid == 0) sh.u0 = atomicAdd(&pool.counters[2], (unsigned long long)T);
+      if (tid == 0) { sh.u0 = atomicAdd(&pool.counters[2], (unsigned long long)T); sh.flag = 0; }
       __syncthreads();
       const long long coff_off = (long long)sh.u0;
       const bool fits = toff + (long long)na <= pool.tok_cap && loff + (long long)nl <= pool.link_cap && coff_off + T <= pool.cost_cap;
       if (fits) {
-        // dense index per alive history token, kept in h_tmp
-        for (int f = 0; f <= F; f++) {
-          for (int t = s.tok_b[f] + tid; t < s.tok_e[f]; t += NT) {
-            if (s.h_extra[t] == INF_BITS) continue;
-            const int d = atomicAdd(&sh.flag, 1);
-            s.h_tmp[t] = (unsigned)d;
-            const long long o = toff + d;
-            pool.tok_frame[o] = f; pool.tok_state[o] = s.h_state[t]; pool.tok_cost[o] = s.h_cost[t];
-            pool.tok_extra[o] = __uint_as_float(s.h_extra[t]);
-            float fin = INF;
-            if (f == F) fin = final_empty ? 0.0f : g.final_cost[s.h_state[t]];
-            pool.tok_final[o] = fin;
+        for (int f = wave; f <= F; f += NW) {
+          const FrameRec fr = s.fr[f];
+          for (int b0 = fr.tok_b; b0 < fr.tok_e; b0 += 64) {
+            const int t = b0 + lane;
+            const bool in = t < fr.tok_e;
+            const i32x4 r = ht[in ? t : fr.tok_b];
+            const int d = h_remap[in ? t : fr.tok_b];
+            if (in && d >= 0) {
+              const long long o = toff + d;
+              const int st = r.x & STMASK;
+              pool.tok_frame[o] = f; pool.tok_state[o] = st; pool.tok_cost[o] = asf(r.y); pool.tok_extra[o] = asf(r.z);
+              float fin = INF;
+              if (f == F) fin = final_empty ? 0.0f : asf(g.st[st].w);
+              pool.tok_final[o] = fin;
+            }
           }
-        }
-        __syncthreads();
-        if (tid == 0) sh.flag = 0;
-        __syncthreads();
-        for (int f = 0; f <= F; f++) {
           for (int pass = 0; pass < 2; pass++) {
-            const int lb = pass ? s.pl_b[f] : s.el_b[f], le_ = pass ? s.pl_e[f] : s.el_e[f];
-            const float coff = (!pass && f < T) ? s.cost_offset[f] : 0.0f;
-            for (int l = lb + tid; l < le_; l += NT) {
-              const int src = s.hl_src[l];
-              if (src < 0) continue;
-              const int dst = s.hl_dst[l];
-              if (s.h_extra[src] == INF_BITS || s.h_extra[dst] == INF_BITS) continue;
-              const int d = atomicAdd(&sh.flag, 1);
-              const long long o = loff + d;
-              pool.link_src[o] = (int)s.h_tmp[src]; pool.link_dst[o] = (int)s.h_tmp[dst];
-              pool.link_il[o] = s.hl_il[l]; pool.link_ol[o] = s.hl_ol[l]; pool.link_gr[o] = s.hl_gr[l];
-              pool.link_ac[o] = s.hl_il[l] != 0 ? s.hl_ac[l] - coff : s.hl_ac[l];
+            const int lb = pass ? fr.pl_b : fr.el_b, le_ = pass ? fr.pl_e : fr.el_e;
+            const float coff = (!pass && f < T) ? fr.cost_offset : 0.0f;
+            for (int b0 = lb; b0 < le_; b0 += 64) {
+              const int l = b0 + lane;
+              const bool in = l < le_;
+              const i32x4 L = hl[in ? l : lb];
+              const int arc_id = hl_arc[in ? l : lb];
+              const bool live = in && L.x >= 0;
+              const int a = h_remap[live ? L.x : 0], b = h_remap[live ? L.y : 0];
+              const bool w = live && a >= 0 && b >= 0;
+              const int d = wave_alloc(&sh.flag, w);
+              if (w) {
+                const long long o = loff + d;
+                const int il = g.arc_il[arc_id];
+                pool.link_src[o] = a; pool.link_dst[o] = b;
+                pool.link_il[o] = il; pool.link_ol[o] = g.arcs[arc_id].w; pool.link_gr[o] = asf(L.z);
+                pool.link_ac[o] = il != 0 ? asf(L.w) - coff : asf(L.w);
+              }
             }
           }
         }
-        for (int f = tid; f < T; f += NT) pool.cost_offsets[coff_off + f] = s.cost_offset[f];
+        for (int f = tid; f < T; f += NT) pool.cost_offsets[coff_off + f] = s.fr[f].cost_offset;
         r_n_tok = (int)na; r_n_link = (int)nl; r_tok_off = toff; r_link_off = loff; r_cost_off = coff_off;
         r_reached_final = final_relative != INF;
         // Decode() returns whether the last frame still has tokens (:93-95)
-        unsigned long long alive_last = 0;
-        for (int t = s.tok_b[F] + tid; t < s.tok_e[F]; t += NT) alive_last += s.h_extra[t] != INF_BITS;
-        alive_last = block_sum_u64(alive_last, sh, par);
         r_ok = alive_last > 0;
-        // restore the +inf invariant of h_tmp for the next utterance in this slot
-        __syncthreads();
-        for (int t = tid; t < sh.h_ntok; t += NT) s.h_tmp[t] = INF_BITS;
       } else r_error = ERR_POOL;
     }
     PHASE(6)
@@ -1042,12 +1285,12 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
 #undef PHASE
 }
 
-// arc_pdf[a] = tid2pdf[ilabel] (-1 for input-epsilon arcs): one dependent load less per arc
-__global__ void fill_arc_pdf_kernel(const vbh_arc *__restrict__ arcs, long long A, const int *__restrict__ tid2pdf,
-                                    int *__restrict__ arc_pdf) {
+// per batch: pdf of every emitting arc (arc.z = tid2pdf[ilabel]; -1 for input-epsilon arcs)
+__global__ void fill_arc_pdf_kernel(i32x4 *__restrict__ arcs, const int *__restrict__ arc_il, long long A,
+                                    const int *__restrict__ tid2pdf) {
   for (long long a = blockIdx.x * (long long)blockDim.x + threadIdx.x; a < A; a += (long long)gridDim.x * blockDim.x) {
-    const int il = arcs[a].ilabel;
-    arc_pdf[a] = il == 0 ? -1 : tid2pdf[il];
+    const int il = arc_il[a];
+    reinterpret_cast<int *>(&arcs[a])[2] = il == 0 ? -1 : tid2pdf[il];
   }
 }
 
@@ -1057,7 +1300,8 @@ __global__ void fill_arc_pdf_kernel(const vbh_arc *__restrict__ arcs, long long 
 struct vbh_graph {
   vbh_ctx *ctx;
   int S, start; long long A; int max_ilabel, max_degree;
-  DevBuf<float> final_cost; DevBuf<int> arc_off, nieps, arc_pdf; DevBuf<vbh_arc> arcs;
+  DevBuf<i32x4> st, arcs;      // device records (see DevGraph); arcs are stored epsilon-first within a state
+  DevBuf<int> arc_il;
   std::vector<float> h_final;
 };
 
@@ -1093,6 +1337,16 @@ static int slot_alloc(vbh_decoder *d, size_t bytes, void **p, int memset_val = -
 
 static const char *err_name(int e);
 
+// Frames between two intermediate prunings.  The final lattice does not depend on this schedule
+// (see the header), so the kernel is free to prune less often than cfg.prune_interval asks: every
+// visit of a frame costs the same handful of dependent passes however few links it holds, and
+// the number of re-visits per frame falls with the interval.  VBH_PRUNE_EVERY overrides (tuning).
+static int effective_prune_interval(const vbh_decode_cfg *cfg) {
+  int v = cfg->prune_interval;
+  if (const char *e = getenv("VBH_PRUNE_EVERY")) { const int x = atoi(e); if (x > 0) v = x; }
+  return std::min(v, MAX_WIN_FRAMES - 2);
+}
+
 static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
   const vbh_graph *graph = d->graph;
   const vbh_decode_cfg *cfg = &d->cfg;
@@ -1103,12 +1357,13 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
   const long long per_frame_tok = std::min<long long>(S, big ? std::max<long long>(8192, 8 * ma) : std::max<long long>(4096, 2 * ma));
   const long long per_frame_link = std::min<long long>(std::max<long long>(graph->A, 1), 2 * per_frame_tok);
   const long long surv_tok = big ? 2048 : 160, surv_link = big ? 4096 : 320;   // lattice survivors per frame
-  const int win = cfg->prune_interval + 1;
+  const int pi = effective_prune_interval(cfg);
+  const int win = pi + 1;
   Slot p{};
   p.w_tok_cap = (int)std::min<long long>(per_frame_tok * win, 1LL << 28);
   p.w_link_cap = (int)std::min<long long>((per_frame_link + per_frame_tok) * win, 1LL << 28);
   // history: one unpruned frontier frame per interval plus the survivors
-  const long long n_int = max_frames / cfg->prune_interval + 2;
+  const long long n_int = max_frames / pi + 2;
   const long long front_avg = big ? per_frame_tok : per_frame_tok / 2;
   p.h_tok_cap = (int)std::min<long long>(front_avg * n_int + surv_tok * (max_frames + 1) + per_frame_tok, 1LL << 29);
   p.h_link_cap = (int)std::min<long long>(front_avg * n_int + surv_link * (max_frames + 1) + per_frame_link, 1LL << 29);
@@ -1128,20 +1383,11 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
     if (slot_alloc(d, sizeof(type) * (size_t)(count) * ns, reinterpret_cast<void **>(&base), ms)) return -1; \
     for (size_t i = 0; i < ns; i++) set->h[i].field = base + i * (size_t)(count);                    \
   }
-  A_(key, unsigned long long, S, 0xFF) A_(tokid, int, S, 0)
-  A_(w_state, int, p.w_tok_cap, -2) A_(w_cost, float, p.w_tok_cap, -2) A_(w_extra, unsigned, p.w_tok_cap, -2)
-  A_(w_tmp, unsigned, p.w_tok_cap, -2) A_(w_remap, int, p.w_tok_cap, -2)
-  A_(wl_src, int, p.w_link_cap, -2) A_(wl_dst, int, p.w_link_cap, -2) A_(wl_il, int, p.w_link_cap, -2)
-  A_(wl_ol, int, p.w_link_cap, -2) A_(wl_gr, float, p.w_link_cap, -2) A_(wl_ac, float, p.w_link_cap, -2)
-  A_(h_state, int, p.h_tok_cap, -2) A_(h_cost, float, p.h_tok_cap, -2) A_(h_extra, unsigned, p.h_tok_cap, -2)
-  A_(h_tmp, unsigned, p.h_tok_cap, -2) A_(h_remap, int, p.h_tok_cap, -2)
-  A_(hl_src, int, p.h_link_cap, -2) A_(hl_dst, int, p.h_link_cap, -2) A_(hl_il, int, p.h_link_cap, -2)
-  A_(hl_ol, int, p.h_link_cap, -2) A_(hl_gr, float, p.h_link_cap, -2) A_(hl_ac, float, p.h_link_cap, -2)
-  A_(tok_b, int, F, 0) A_(tok_e, int, F, 0) A_(el_b, int, F, 0) A_(el_e, int, F, 0) A_(pl_b, int, F, 0) A_(pl_e, int, F, 0)
-  A_(tok_w, unsigned char, F, 0) A_(el_w, unsigned char, F, 0) A_(pl_w, unsigned char, F, 0)
-  A_(cost_offset, float, F, 0)
-  A_(c_tot, float, p.cand_cap, -2) A_(c_ac, float, p.cand_cap, -2) A_(c_arc, int, p.cand_cap, -2)
-  A_(c_src, int, p.cand_cap, -2) A_(c_dst, int, p.cand_cap, -2)
+  A_(ent, Ent, S, 0xFF)
+  A_(w_tok, i32x4, p.w_tok_cap, -2) A_(w_remap, int, p.w_tok_cap, 0) A_(wl, i32x4, p.w_link_cap, -2) A_(wl_arc, int, p.w_link_cap, -2)
+  A_(h_tok, i32x4, p.h_tok_cap, -2) A_(h_remap, int, p.h_tok_cap, 0) A_(hl, i32x4, p.h_link_cap, -2) A_(hl_arc, int, p.h_link_cap, -2)
+  A_(fr, FrameRec, F, 0)
+  A_(cand, i32x4, p.cand_cap, -2) A_(cand2, i32x2, p.cand_cap, -2)
   A_(front[0], int, p.front_cap, -2) A_(front[1], int, p.front_cap, -2) A_(front[2], int, p.front_cap, -2)
   A_(state, int, 4, 0)
 #undef A_
@@ -1180,13 +1426,29 @@ int vbh_graph_create(vbh_ctx *ctx, int32_t num_states, int32_t start, const floa
       if (h_arcs[a].ilabel > max_il) max_il = h_arcs[a].ilabel;
     }
   }
+  // device records: per state {first arc, #epsilon arcs, #arcs, final cost}; arcs re-ordered
+  // epsilon-first within a state (stable), next state tagged when it has epsilon arcs itself
+  std::vector<i32x4> h_st(num_states), h_ar((size_t)std::max<long long>(A, 1));
+  std::vector<int> h_il((size_t)std::max<long long>(A, 1), 0);
+  for (int s = 0; s < num_states; s++) {
+    int fb; memcpy(&fb, &h_final[s], 4);
+    i32x4 r; r.x = off[s]; r.y = nieps[s]; r.z = off[s + 1] - off[s]; r.w = fb;
+    h_st[s] = r;
+    int pe = off[s], pn = off[s] + nieps[s];
+    for (int a = off[s]; a < off[s + 1]; a++) {
+      const int p = h_arcs[a].ilabel == 0 ? pe++ : pn++;
+      i32x4 x; x.x = h_arcs[a].nextstate | (nieps[h_arcs[a].nextstate] > 0 ? EPSBIT : 0);
+      int wb; memcpy(&wb, &h_arcs[a].weight, 4);
+      x.y = wb; x.z = -1; x.w = h_arcs[a].olabel;
+      h_ar[p] = x; h_il[p] = h_arcs[a].ilabel;
+    }
+  }
   vbh_graph *g = new vbh_graph();
   g->ctx = ctx; g->S = num_states; g->start = start; g->A = A; g->max_ilabel = max_il; g->max_degree = max_deg;
   g->h_final.assign(h_final, h_final + num_states);
   hipStream_t st = ctx->stream;
-  if (g->final_cost.upload(h_final, num_states, st) || g->arc_off.upload(off.data(), off.size(), st) ||
-      g->nieps.upload(nieps.data(), nieps.size(), st) || g->arcs.upload(h_arcs, (size_t)A, st) ||
-      g->arc_pdf.alloc((size_t)(A > 0 ? A : 1))) { delete g; return -1; }
+  if (g->st.upload(h_st.data(), h_st.size(), st) || g->arcs.upload(h_ar.data(), h_ar.size(), st) ||
+      g->arc_il.upload(h_il.data(), h_il.size(), st)) { delete g; return -1; }
   VBH_HIP(hipStreamSynchronize(st));
   *out = g;
   return 0;
@@ -1397,13 +1659,13 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
   pool.link_src = p_ls.p; pool.link_dst = p_ld.p; pool.link_il = p_li.p; pool.link_ol = p_lo.p; pool.link_gr = p_lg.p; pool.link_ac = p_la.p;
   pool.cost_offsets = p_co.p; pool.counters = p_cnt.p;
   if (g->A > 0) {
-    hipLaunchKernelGGL(fill_arc_pdf_kernel, dim3(1024), dim3(256), 0, st, g->arcs.p, g->A, d_t2p.p, g->arc_pdf.p);
+    hipLaunchKernelGGL(fill_arc_pdf_kernel, dim3(1024), dim3(256), 0, st, g->arcs.p, g->arc_il.p, g->A, d_t2p.p);
     VBH_HIP(hipGetLastError());
   }
   DevBuf<Pool> d_pool;
   if (d_pool.upload(&pool, 1, st)) return -1;
-  DevGraph dg{g->S, g->start, g->final_cost.p, g->arc_off.p, g->nieps.p, g->arcs.p, g->arc_pdf.p};
-  DecCfg dc{d->cfg.beam, d->cfg.lattice_beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active, d->cfg.prune_interval};
+  DevGraph dg{g->S, g->start, g->st.p, g->arcs.p, g->arc_il.p};
+  DecCfg dc{d->cfg.beam, d->cfg.lattice_beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active, effective_prune_interval(&d->cfg)};
   d->h_res.resize(n_utt);
   {
     const int grid = std::min(d->small_set.n, n_utt);
