@@ -161,7 +161,7 @@ def main():
         t0 = time.perf_counter()
         dec.decode(ll, foff, t2p)
         dt = time.perf_counter() - t0
-        print("decode of %d utterances: %.3f s" % (args.batch, dt))
+        print("decode of %d utterances: %.3f s  %s" % (args.batch, dt, " ".join("%s=%.1f" % kv for kv in dec.times().items())))
         for u in range(min(args.batch, 4)):
             r = dec.result(u, arrays=False)
             nf = max(r["num_frames"], 1)

@@ -202,6 +202,9 @@ int vbh_decoder_result(vbh_decoder *d, int32_t utt, vbh_lattice *out);
 /* diagnostic: shader-clock cycles the utterance's workgroup spent per phase
  * {cutoff, pass1, admit+links, epsilon closure, pruning, compaction, output, other} */
 int vbh_decoder_phase_cycles(vbh_decoder *d, int32_t utt, int64_t *out8);
+/* diagnostic: milliseconds of the last vbh_decode_batch {search kernel(s) on the device,
+ * lattice pool device->host, host-side canonical ordering + best path, whole call} */
+int vbh_decoder_times(vbh_decoder *d, float *out4);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,7 @@ SYMBOLS = [
     "vbh_gmm_loglikes", "vbh_gmm_work",
     "vbh_graph_create", "vbh_graph_destroy", "vbh_decode_cfg_default", "vbh_decoder_create",
     "vbh_decoder_destroy", "vbh_decode_batch", "vbh_decoder_result", "vbh_decoder_phase_cycles",
+    "vbh_decoder_times",
 ]
 
 
@@ -126,6 +127,7 @@ def load():
                                          C.POINTER(C.c_int32), C.c_int32]
         lib.vbh_decoder_result.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Lattice)]
         lib.vbh_decoder_phase_cycles.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+        lib.vbh_decoder_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     _LIB = lib
     return lib
 

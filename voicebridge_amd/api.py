@@ -289,6 +289,12 @@ class LatticeDecoder:
         check(self.lib.vbh_decoder_phase_cycles(self.h, int(u), out), "vbh_decoder_phase_cycles")
         return list(out)
 
+    def times(self):
+        """ms of the last decode(): search kernel, pool copy, host lattice finishing, whole call"""
+        out = (C.c_float * 4)()
+        check(self.lib.vbh_decoder_times(self.h, out), "vbh_decoder_times")
+        return dict(kernel_ms=out[0], copy_ms=out[1], host_ms=out[2], total_ms=out[3])
+
     def close(self):
         if self.h:
             self.lib.vbh_decoder_destroy(self.h)

@@ -54,6 +54,9 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <climits>
 #include <cmath>
 
@@ -67,14 +70,29 @@ constexpr int NW = NT / 64;
 constexpr int WBIT = 0x40000000;            // token id lives in the raw window
 constexpr unsigned INF_BITS = 0x7F800000u;  // +inf as float bits
 constexpr int MAX_EPS_ITERS = 4096;
-constexpr int MAX_WIN_FRAMES = 512;         // frames between two compactions (prune_interval + 1 <= this)
+constexpr int MAX_WIN_FRAMES = NT / 2;      // frames between two compactions (prune_interval + 1 <= this)
 constexpr int EPSBIT = (int)0x80000000;     // on an arc's next state / a token's state: that state has epsilon arcs
 constexpr int STMASK = 0x7FFFFFFF;
-constexpr int COST_CAP = 8192;              // token costs of the current frame cached in LDS
-constexpr int U = 4;                        // independent items per lane in the streaming passes
+constexpr int COST_CAP = 8 * NT;            // token costs of the current frame cached in LDS
+#ifndef VBH_U
+#define VBH_U 4
+#endif
+#ifndef VBH_UL
+#define VBH_UL 4
+#endif
+constexpr int U = VBH_U;                    // independent items per lane in the streaming passes
+constexpr int UL = VBH_UL;                  // ... in the pruning sweeps over links
+constexpr int DIRTY_FRAMES = 1 << 16;       // frames covered by the dirty bitmap (8 KB of LDS)
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+// Pointers to the slot's arrays come out of LDS, where the compiler cannot know what they point
+// to and would emit FLAT instructions (they complete out of order, so every wait on one becomes
+// a full drain and nothing overlaps); cast to the global address space once, they give
+// global_load / global_store / global_atomic.
+#define VBH_GLOBAL __attribute__((address_space(1)))
+template <class T> using gp = VBH_GLOBAL T *;
 
 __device__ __forceinline__ float asf(int x) { return __int_as_float(x); }
 __device__ __forceinline__ int asi(float x) { return __float_as_int(x); }
@@ -106,8 +124,8 @@ struct FrameRec {
 // per-slot workspace (device pointers)
 struct Slot {
   Ent *ent;                                // [S]
-  i32x4 *w_tok; int *w_remap; i32x4 *wl; int *wl_arc;    // raw window
-  i32x4 *h_tok; int *h_remap; i32x4 *hl; int *hl_arc;    // history
+  i32x4 *w_tok; int *w_remap; i32x4 *wl; i32x2 *wl2;    // raw window: tokens, remap scratch, links {src, dst, tot, arc}, {graph, acoustic}
+  i32x4 *h_tok; int *h_remap; i32x4 *hl; i32x2 *hl2;    // history
   FrameRec *fr;                            // [max_frames + 2]
   i32x4 *cand; i32x2 *cand2;               // candidates of the current frame: {tot, ac, arc, src}, {dst|EPSBIT, weight}
   int *front[3];                           // epsilon work lists (state ids), rotated
@@ -149,13 +167,13 @@ __device__ __forceinline__ float o2f(unsigned o) {
   unsigned u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
   return __uint_as_float(u);
 }
-__device__ __forceinline__ unsigned long long ld_u64(const unsigned long long *p) {
+__device__ __forceinline__ unsigned long long ld_u64(gp<const unsigned long long> p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ int ld_i32(const int *p) {
+__device__ __forceinline__ int ld_i32(gp<const int> p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void st_i32(int *p, int v) {
+__device__ __forceinline__ void st_i32(gp<int> p, int v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Read-modify-write atomics on per-utterance data: one workgroup owns an utterance, so
@@ -163,18 +181,37 @@ __device__ __forceinline__ void st_i32(int *p, int v) {
 #ifndef VBH_RMW_SCOPE
 #define VBH_RMW_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
 #endif
-__device__ __forceinline__ unsigned long long rmw_min_u64(unsigned long long *p, unsigned long long v) {
+__device__ __forceinline__ unsigned long long rmw_min_u64(gp<unsigned long long> p, unsigned long long v) {
   return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, VBH_RMW_SCOPE);
 }
-__device__ __forceinline__ void rmw_min_u32(unsigned *p, unsigned v) {
+__device__ __forceinline__ void rmw_min_u32(gp<unsigned> p, unsigned v) {
   (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, VBH_RMW_SCOPE);
 }
-// make an LDS-loaded (per-lane) pointer wave-uniform again so that it lives in SGPRs
+// make an LDS-loaded (per-lane) pointer wave-uniform again so that it lives in SGPRs, and global
 template <class T>
-__device__ __forceinline__ T *uptr(T *p) {
+__device__ __forceinline__ gp<T> uptr(T *p) {
   const unsigned long long v = reinterpret_cast<unsigned long long>(p);
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+  return (gp<T>)(((unsigned long long)hi << 32) | lo);
+}
+// per-lane pointer, global
+template <class T>
+__device__ __forceinline__ gp<T> gptr(T *p) { return (gp<T>)p; }
+// FrameRec <-> global memory as three 16-byte vectors
+__device__ __forceinline__ FrameRec ld_frame(const FrameRec *p) {
+  gp<const i32x4> q = (gp<const i32x4>)p;
+  const i32x4 a = q[0], b = q[1], c = q[2];
+  FrameRec r;
+  r.tok_b = a.x; r.tok_e = a.y; r.el_b = a.z; r.el_e = a.w; r.pl_b = b.x; r.pl_e = b.y; r.flags = b.z; r.cost_offset = asf(b.w);
+  r.a_tok = c.x; r.a_el = c.y; r.a_pl = c.z; r.pad = c.w;
+  return r;
+}
+__device__ __forceinline__ void st_frame(FrameRec *p, const FrameRec &r) {
+  gp<i32x4> q = (gp<i32x4>)p;
+  i32x4 a, b, c;
+  a.x = r.tok_b; a.y = r.tok_e; a.z = r.el_b; a.w = r.el_e; b.x = r.pl_b; b.y = r.pl_e; b.z = r.flags; b.w = asi(r.cost_offset);
+  c.x = r.a_tok; c.y = r.a_el; c.z = r.a_pl; c.w = 0;
+  q[0] = a; q[1] = b; q[2] = c;
 }
 // One LDS atomic per wave instead of one per lane: the active lanes that want a slot elect a
 // leader, which reserves popcount slots; every lane gets base + its rank.  (Same-address LDS
@@ -244,6 +281,7 @@ struct Shared {
   // re-compacted in place at the next one, once those frames have been pruned with look-ahead
   int tail_tok_b, tail_link_b, tail_f0, tail_f1;
   long long tph[8];                // phase cycle counters (thread 0)
+  unsigned dirty[DIRTY_FRAMES / 32];   // see frame_dirty()
   float cost[COST_CAP];            // costs of the current frame's tokens (GetCutoff)
   // compaction job: token frames and link segments in source order
   int j_ntf, j_nseg, j_tf0, j_tdst, j_ldst;
@@ -283,13 +321,13 @@ __device__ __forceinline__ float block_min_f(float v, Shared &sh, int &par) {
 }
 
 // cost of token i of the current frame: LDS copy, or the record itself beyond the cache
-__device__ __forceinline__ float frame_cost(const Shared &sh, const i32x4 *tok, int i) {
+__device__ __forceinline__ float frame_cost(const Shared &sh, gp<const i32x4> tok, int i) {
   return i < COST_CAP ? sh.cost[i] : asf(tok[i].y);
 }
 
 // k-th smallest (0-based) of the current frame's costs: exact radix select on the
 // order-preserving keys (the std::nth_element value in GetCutoff, lattice-faster-decoder.cc:654-676)
-__device__ float select_kth(const i32x4 *tok, int n, int k, Shared &sh) {
+__device__ float select_kth(gp<const i32x4> tok, int n, int k, Shared &sh) {
   const int tid = threadIdx.x;
   __syncthreads();
   if (tid == 0) { sh.sel_prefix = 0; sh.sel_mask = 0; sh.sel_k = k; }
@@ -327,66 +365,92 @@ __device__ float select_kth(const i32x4 *tok, int n, int k, Shared &sh) {
   return o2f(sh.sel_prefix);
 }
 
-__device__ __forceinline__ i32x4 *tokp(i32x4 *wt, i32x4 *ht, int id) { return (id & WBIT) ? wt + (id ^ WBIT) : ht + id; }
+__device__ __forceinline__ gp<i32x4> tokp(gp<i32x4> wt, gp<i32x4> ht, int id) { return (id & WBIT) ? wt + (id ^ WBIT) : ht + id; }
 
 // evaluate the forward links [lb, le) of one frame: excise those over the lattice beam,
-// atomicMin the rest into the source token's tmp (lattice-faster-decoder.cc:331-356).
-// Returns (valid on lane 0 of each wave) the number of links this wave kept.
-__device__ __forceinline__ int eval_links(i32x4 *lk, int lb, int le_, i32x4 *wt, i32x4 *ht, float lattice_beam) {
-  int kept = 0;
-  for (int base = lb; base < le_; base += NT * U) {
-    i32x4 L[U]; bool ok[U];
+// atomicMin the rest into the source token's tmp (lattice-faster-decoder.cc:331-356).  A link
+// carries tot = (source cost + acoustic) + graph, so only the destination token is gathered.
+// Links at positions < split are the frame's epsilon links, the others its emitting links.
+// Returns (valid on lane 0 of each wave) the links this wave kept: epsilon << 32 | emitting.
+__device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, int le_, int split, gp<i32x4> wt, gp<i32x4> ht,
+                                                         float lattice_beam) {
+  unsigned long long kept = 0;
+  for (int base = lb; base < le_; base += NT * UL) {
+    i32x4 L[UL]; bool ok[UL];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
+    for (int u = 0; u < UL; u++) {
       const int l = base + u * NT + (int)threadIdx.x;
       ok[u] = l < le_;
       L[u] = lk[ok[u] ? l : lb];
       ok[u] = ok[u] && L[u].x >= 0;   // negative source: already excised
     }
-    float sc[U]; i32x4 D[U];
+    i32x4 D[UL];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const i32x4 *sp = ok[u] ? tokp(wt, ht, L[u].x) : ht;
-      const i32x4 *dp = ok[u] ? tokp(wt, ht, L[u].y) : ht;
-      sc[u] = asf(sp->y);
+    for (int u = 0; u < UL; u++) {
+      gp<const i32x4> dp = ok[u] ? tokp(wt, ht, L[u].y) : ht;
       D[u] = *dp;
     }
 #pragma unroll
-    for (int u = 0; u < U; u++) {
+    for (int u = 0; u < UL; u++) {
       const int l = base + u * NT + (int)threadIdx.x;
       // next_tok->extra_cost + ((tok->tot_cost + link->acoustic_cost + link->graph_cost) - next_tok->tot_cost)
-      float le = asf(D[u].z) + (((sc[u] + asf(L[u].w)) + asf(L[u].z)) - asf(D[u].y));
+      float le = asf(D[u].z) + (asf(L[u].z) - asf(D[u].y));
       const bool keep = ok[u] && !(le > lattice_beam);
-      if (ok[u] && !keep) reinterpret_cast<int *>(&lk[l])[0] = -1;
+      if (ok[u] && !keep) ((gp<int>)&lk[l])[0] = -1;
       if (keep) {
         if (le < 0.0f) le = 0.0f;
-        rmw_min_u32(reinterpret_cast<unsigned *>(tokp(wt, ht, L[u].x)) + 3, __float_as_uint(le));
+        rmw_min_u32((gp<unsigned>)tokp(wt, ht, L[u].x) + 3, __float_as_uint(le));
       }
-      kept += __popcll(__ballot(keep));
+      const unsigned long long m = __ballot(keep);
+      // a wave's 64 links are consecutive, so the split falls on a lane boundary
+      const int first = base + u * NT + ((int)threadIdx.x & ~63);
+      const int ne = split - first;   // lanes [0, ne) hold epsilon links
+      const unsigned long long em = ne <= 0 ? 0ull : (ne >= 64 ? ~0ull : ((1ull << ne) - 1ull));
+      kept += ((unsigned long long)__popcll(m & em) << 32) | (unsigned long long)__popcll(m & ~em);
     }
   }
   return kept;
 }
 
-// PruneForwardLinks for one frame (lattice-faster-decoder.cc:300-371), evaluated to its fixed
-// point.  tmp of the frame's tokens must hold +inf on entry and holds +inf again on exit.
-// Leaves the frame's survivor counts in its FrameRec.  Returns (uniformly) whether any token's
-// extra_cost changed.
-__device__ bool prune_frame(const Slot &s, int f, float lattice_beam, float delta, Shared &sh, int &pp) {
+// frames whose links must be re-evaluated because the tokens of the next frame changed since
+// they were last evaluated (or they never were).  One bit per frame in LDS; frames beyond the
+// bitmap always count as dirty.  Thread 0 writes, everybody reads after a barrier.
+__device__ __forceinline__ bool frame_dirty(const Shared &sh, int f) {
+  return f >= DIRTY_FRAMES || ((sh.dirty[f >> 5] >> (f & 31)) & 1u);
+}
+__device__ __forceinline__ void set_dirty(Shared &sh, int f, bool d) {
+  if (f < 0 || f >= DIRTY_FRAMES) return;
+  if (d) sh.dirty[f >> 5] |= 1u << (f & 31); else sh.dirty[f >> 5] &= ~(1u << (f & 31));
+}
+
+// PruneForwardLinks for one frame (lattice-faster-decoder.cc:300-371), evaluated to its exact
+// fixed point (the frame's own iteration does not use delta, so that a frame whose successor has
+// not moved since is known to be settled).  tmp of the frame's tokens must hold +inf on entry
+// and holds +inf again on exit.  Leaves the frame's survivor counts in its FrameRec.  Returns
+// (uniformly) bit 0: some extra_cost moved by more than delta (the reference's "changed", :358),
+// bit 1: some extra_cost moved at all.
+__device__ int prune_frame(const Slot &s, int f, float lattice_beam, float delta, Shared &sh, int &pp) {
   const int tid = threadIdx.x;
   FrameRec *frp = s.fr + f;
-  const int tb = frp->tok_b, te = frp->tok_e, eb = frp->el_b, ee = frp->el_e, pb = frp->pl_b, pe = frp->pl_e;
-  const int flags = frp->flags;
-  i32x4 *wt = uptr(s.w_tok), *ht = uptr(s.h_tok);
-  i32x4 *tok = uptr((flags & 1) ? s.w_tok : s.h_tok);
-  i32x4 *elk = uptr((flags & 2) ? s.wl : s.hl), *plk = uptr((flags & 4) ? s.wl : s.hl);
-  bool frame_changed = false;
+  const FrameRec fr = ld_frame(frp);
+  const int tb = fr.tok_b, te = fr.tok_e, eb = fr.el_b, ee = fr.el_e, pb = fr.pl_b, pe = fr.pl_e;
+  const int flags = fr.flags;
+  gp<i32x4> wt = uptr(s.w_tok), ht = uptr(s.h_tok);
+  gp<i32x4> tok = uptr((flags & 1) ? s.w_tok : s.h_tok);
+  gp<i32x4> elk = uptr((flags & 2) ? s.wl : s.hl), plk = uptr((flags & 4) ? s.wl : s.hl);
+  // epsilon links of a frame are created right before its emitting links: normally one range
+  const bool one_range = pe == eb && ((flags >> 1) & 1) == ((flags >> 2) & 1);
+  int result = 0;
   for (int iter = 0; iter < MAX_EPS_ITERS; iter++) {
-    const int ce = eval_links(elk, eb, ee, wt, ht, lattice_beam);
-    const int cp = eval_links(plk, pb, pe, wt, ht, lattice_beam);
+    unsigned long long kept;
+    if (one_range) kept = eval_links(elk, pb, ee, pe, wt, ht, lattice_beam);
+    else {
+      kept = eval_links(plk, pb, pe, pe, wt, ht, lattice_beam);
+      kept += eval_links(elk, eb, ee, eb, wt, ht, lattice_beam);
+    }
     if ((tid & 63) == 0) {
-      if (ce) atomicAdd(&sh.cnt_el[pp], ce);
-      if (cp) atomicAdd(&sh.cnt_pl[pp], cp);
+      if ((unsigned)kept) atomicAdd(&sh.cnt_el[pp], (int)(unsigned)kept);
+      if (kept >> 32) atomicAdd(&sh.cnt_pl[pp], (int)(kept >> 32));
     }
     __syncthreads();
     // the [pp] entries are written below / above and read after the next barrier; the [pp^1]
@@ -408,38 +472,52 @@ __device__ bool prune_frame(const Slot &s, int f, float lattice_beam, float delt
         const unsigned v = (unsigned)R[u].w, o = (unsigned)R[u].z;
         if (ok[u] && (v != o || v != INF_BITS)) {
           i32x2 nv; nv.x = (int)v; nv.y = (int)INF_BITS;
-          *reinterpret_cast<i32x2 *>(reinterpret_cast<int *>(&tok[t]) + 2) = nv;
-          // "changed" as the reference counts it (:358): |new - old| > delta; inf vs inf is no change
-          if (v != o && fabsf(__uint_as_float(v) - __uint_as_float(o)) > delta) ch = 1;
+          *(gp<i32x2>)((gp<int>)&tok[t] + 2) = nv;
+          if (v != o) {
+            ch |= 2;
+            // "changed" as the reference counts it (:358): |new - old| > delta; inf vs inf is no change
+            if (fabsf(__uint_as_float(v) - __uint_as_float(o)) > delta) ch |= 1;
+          }
         }
         alive += __popcll(__ballot(ok[u] && v != INF_BITS));
       }
     }
-    if (ch) sh.changed2[pp] = 1;
+    if (ch) atomicOr(&sh.changed2[pp], ch);
     if ((tid & 63) == 0 && alive) atomicAdd(&sh.cnt_tok[pp], alive);
     __syncthreads();
-    const bool any = sh.changed2[pp] != 0;
-    const bool last = !any || pe == pb;
-    if (last && tid == 0) { frp->a_tok = sh.cnt_tok[pp]; frp->a_el = sh.cnt_el[pp]; frp->a_pl = sh.cnt_pl[pp]; }
+    const int any = sh.changed2[pp];
+    const bool last = !(any & 2) || pe == pb;
+    if (last && tid == 0) {
+      i32x4 c; c.x = sh.cnt_tok[pp]; c.y = sh.cnt_el[pp]; c.z = sh.cnt_pl[pp]; c.w = 0;
+      ((gp<i32x4>)frp)[2] = c;
+    }
     pp ^= 1;
-    frame_changed |= any;
+    result |= any;
     if (last) break;
   }
-  return frame_changed;
+  if (tid == 0) { set_dirty(sh, f, false); if (result & 2) set_dirty(sh, f - 1, true); }
+  return result;
 }
 
-// backward pass from frame `from` down; frames >= first_unpruned are always processed, older
-// ones until a frame's extra_costs move by no more than delta (PruneActiveTokens :503-530).
-// extra_costs only grow as the frontier advances, so values left stale by the early stop are
-// lower bounds and pruning with them never removes anything the final pass (delta = 0, every
-// frame revisited) would keep.
+// backward pass from frame `from` down (PruneActiveTokens :503-530).  Intermediate passes
+// (delta > 0): frames >= first_unpruned are always processed, older ones while the frame above
+// moved by more than delta, and never below stop_at.  Whatever such a pass leaves unpropagated is
+// remembered as a dirty frame.  The final pass (delta = 0, final = true) visits exactly the
+// frames that are dirty or become so on the way down: a frame whose successor has not moved
+// since its last evaluation would be recomputed to the same values.  extra_costs only grow as
+// the frontier advances, so values left stale by an intermediate pass are lower bounds and
+// pruning with them never removes anything the final pass keeps.
 __device__ void prune_backward(const Slot &s, int from, int first_unpruned, int stop_at, float lattice_beam, float delta,
-                               Shared &sh, int &pp) {
+                               bool final, Shared &sh, int &pp) {
   int visited = 0;
+  int above = 3;   // result of the frame above: the frontier counts as changed
   for (int f = from; f >= 0 && f >= stop_at; f--) {
-    const bool ch = prune_frame(s, f, lattice_beam, delta, sh, pp);
+    if (final) {
+      if (!(above & 2) && !frame_dirty(sh, f)) { above = 0; continue; }
+    } else if (f < first_unpruned && !(above & 1)) break;
+    above = prune_frame(s, f, lattice_beam, delta, sh, pp);
+    __syncthreads();   // thread 0's dirty-bit updates before anybody tests the next frame
     visited++;
-    if (!ch && f < first_unpruned) break;
   }
   if (threadIdx.x == 0) sh.n_visited += visited;   // diagnostic
 }
@@ -463,10 +541,10 @@ __device__ __forceinline__ int seg_find(const int *beg, int n, int x) {
 template <bool FROM_W>
 __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l, int remap_lo) {
   const int tid = threadIdx.x;
-  i32x4 *wt = uptr(s.w_tok), *ht = uptr(s.h_tok);
-  int *w_remap = uptr(s.w_remap), *h_remap = uptr(s.h_remap);
-  const i32x4 *src_tok = FROM_W ? wt : ht;
-  int *remap = FROM_W ? w_remap : h_remap;
+  gp<i32x4> wt = uptr(s.w_tok), ht = uptr(s.h_tok);
+  gp<int> w_remap = uptr(s.w_remap), h_remap = uptr(s.h_remap);
+  gp<const i32x4> src_tok = FROM_W ? wt : ht;
+  gp<int> remap = FROM_W ? w_remap : h_remap;
   const int ntf = sh.j_ntf, nseg = sh.j_nseg;
   if (ntf > 0) {
     const int t0 = sh.tbeg[0], t1 = sh.tbeg[ntf];
@@ -498,18 +576,18 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
   }
   __syncthreads();
   if (nseg > 0) {
-    const i32x4 *src_lk = uptr(FROM_W ? s.wl : s.hl);
-    const int *src_arc = uptr(FROM_W ? s.wl_arc : s.hl_arc);
-    i32x4 *hl = uptr(s.hl); int *hl_arc = uptr(s.hl_arc);
+    gp<const i32x4> src_lk = uptr(FROM_W ? s.wl : s.hl);
+    gp<const i32x2> src_l2 = uptr(FROM_W ? s.wl2 : s.hl2);
+    gp<i32x4> hl = uptr(s.hl); gp<i32x2> hl2 = uptr(s.hl2);
     const int l0 = sh.sbeg[0], l1 = sh.sbeg[nseg];
     for (int base = l0; base < l1; base += NT * U) {
-      i32x4 L[U]; int A[U]; bool ok[U];
+      i32x4 L[U]; i32x2 A[U]; bool ok[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int l = base + u * NT + tid;
         ok[u] = l < l1;
         L[u] = src_lk[ok[u] ? l : l0];
-        A[u] = src_arc[ok[u] ? l : l0];
+        A[u] = src_l2[ok[u] ? l : l0];
         ok[u] = ok[u] && L[u].x >= 0;
       }
       // end points: window ids and ids of the block being re-compacted go through the remap
@@ -518,8 +596,8 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int a = L[u].x, b = L[u].y;
-        const int *pa = !ok[u] ? h_remap : (a & WBIT) ? w_remap + (a ^ WBIT) : (a >= remap_lo) ? h_remap + a : reinterpret_cast<const int *>(ht + a) + 2;
-        const int *pb = !ok[u] ? h_remap : (b & WBIT) ? w_remap + (b ^ WBIT) : (b >= remap_lo) ? h_remap + b : reinterpret_cast<const int *>(ht + b) + 2;
+        gp<const int> pa = !ok[u] ? h_remap : (a & WBIT) ? w_remap + (a ^ WBIT) : (a >= remap_lo) ? h_remap + a : (gp<const int>)(ht + a) + 2;
+        gp<const int> pb = !ok[u] ? h_remap : (b & WBIT) ? w_remap + (b ^ WBIT) : (b >= remap_lo) ? h_remap + b : (gp<const int>)(ht + b) + 2;
         vs[u] = *pa; vd[u] = *pb;
       }
 #pragma unroll
@@ -535,7 +613,7 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
         if (c < sh.sup[j]) {
           const int nid = sh.sbase[j] + c + stage_l;
           i32x4 r = L[u]; r.x = ns; r.y = nd;
-          hl[nid] = r; hl_arc[nid] = A[u];
+          hl[nid] = r; hl2[nid] = A[u];
         } else sh.error = ERR_H_LINK;
       }
     }
@@ -547,14 +625,14 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
     const int c = sh.tcnt[j] < sh.tup[j] ? sh.tcnt[j] : sh.tup[j];
     for (int i = sh.tbase[j] + c; i < sh.tbase[j] + sh.tup[j]; i++) {
       i32x4 r; r.x = 0; r.y = 0; r.z = (int)INF_BITS; r.w = (int)INF_BITS;
-      s.h_tok[i + stage_t] = r;
+      gptr(s.h_tok)[i + stage_t] = r;
     }
   }
   for (int j = tid; j < nseg; j += NT) {
     const int c = sh.scnt[j] < sh.sup[j] ? sh.scnt[j] : sh.sup[j];
     for (int i = sh.sbase[j] + c; i < sh.sbase[j] + sh.sup[j]; i++) {
       i32x4 r; r.x = -1; r.y = 0; r.z = 0; r.w = 0;
-      s.hl[i + stage_l] = r; s.hl_arc[i + stage_l] = 0;
+      gptr(s.hl)[i + stage_l] = r;
     }
   }
 }
@@ -577,16 +655,17 @@ __device__ __forceinline__ void job_add_seg(Shared &sh, int b, int e, int a, int
 __device__ __forceinline__ void job_publish(const Slot &s, Shared &sh) {
   const int tid = threadIdx.x;
   for (int j = tid; j < sh.j_ntf; j += NT) {
-    FrameRec *r = s.fr + (sh.j_tf0 + j);
-    r->tok_b = sh.tbase[j]; r->tok_e = sh.tbase[j] + sh.tup[j]; r->a_tok = sh.tcnt[j] < sh.tup[j] ? sh.tcnt[j] : sh.tup[j];
+    gp<int> r = (gp<int>)(s.fr + (sh.j_tf0 + j));
+    r[0] = sh.tbase[j]; r[1] = sh.tbase[j] + sh.tup[j]; r[8] = sh.tcnt[j] < sh.tup[j] ? sh.tcnt[j] : sh.tup[j];
   }
   for (int j = tid; j < sh.j_nseg; j += NT) {
-    FrameRec *r = s.fr + (sh.sid[j] >> 1);
+    gp<int> r = (gp<int>)(s.fr + (sh.sid[j] >> 1));
     const int c = sh.scnt[j] < sh.sup[j] ? sh.scnt[j] : sh.sup[j];
-    if (sh.sid[j] & 1) { r->pl_b = sh.sbase[j]; r->pl_e = sh.sbase[j] + sh.sup[j]; r->a_pl = c; }
-    else { r->el_b = sh.sbase[j]; r->el_e = sh.sbase[j] + sh.sup[j]; r->a_el = c; }
+    if (sh.sid[j] & 1) { r[4] = sh.sbase[j]; r[5] = sh.sbase[j] + sh.sup[j]; r[10] = c; }
+    else { r[2] = sh.sbase[j]; r[3] = sh.sbase[j] + sh.sup[j]; r[9] = c; }
   }
 }
+static_assert(sizeof(FrameRec) == 48, "FrameRec is addressed as 12 ints / 3 vectors");
 
 // Re-compact the block that the previous compaction appended to H (frames (tail_f0, tail_f1]
 // and their links).  When it was appended its youngest frames had no look-ahead, so most of
@@ -605,7 +684,7 @@ __device__ bool recompact_tail(const Slot &s, Shared &sh) {
   if (tid == 0) {
     sh.j_ntf = 0; sh.j_nseg = 0; sh.j_tf0 = 0; sh.j_tdst = tail_tb; sh.j_ldst = tail_lb;
     for (int f = fa; f <= tf1; f++) {
-      const FrameRec r = s.fr[f];
+      const FrameRec r = ld_frame(s.fr + f);
       if (f > tf0) job_add_tok(sh, r, f);
       if (f > tf0) job_add_seg(sh, r.pl_b, r.pl_e, r.a_pl, (f << 1) | 1);
       if (f < tf1) job_add_seg(sh, r.el_b, r.el_e, r.a_el, f << 1);   // emitting links of the frontier frame are still in W
@@ -624,7 +703,7 @@ __device__ bool recompact_tail(const Slot &s, Shared &sh) {
   if (sh.error != ERR_NONE) return false;
   // ---- staging -> final position (the two regions never overlap: staging starts at the old end)
   {
-    i32x4 *ht = uptr(s.h_tok), *hl = uptr(s.hl); int *hl_arc = uptr(s.hl_arc);
+    gp<i32x4> ht = uptr(s.h_tok), hl = uptr(s.hl); gp<i32x2> hl2 = uptr(s.hl2);
     for (int base = tail_tb; base < new_nt; base += NT * U) {
       i32x4 R[U];
 #pragma unroll
@@ -633,11 +712,11 @@ __device__ bool recompact_tail(const Slot &s, Shared &sh) {
       for (int u = 0; u < U; u++) { const int i = base + u * NT + tid; if (i < new_nt) ht[i] = R[u]; }
     }
     for (int base = tail_lb; base < new_nl; base += NT * U) {
-      i32x4 R[U]; int A[U];
+      i32x4 R[U]; i32x2 A[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) { const int i = base + u * NT + tid; const int q = (i < new_nl ? i : tail_lb) + stage_l; R[u] = hl[q]; A[u] = hl_arc[q]; }
+      for (int u = 0; u < U; u++) { const int i = base + u * NT + tid; const int q = (i < new_nl ? i : tail_lb) + stage_l; R[u] = hl[q]; A[u] = hl2[q]; }
 #pragma unroll
-      for (int u = 0; u < U; u++) { const int i = base + u * NT + tid; if (i < new_nl) { hl[i] = R[u]; hl_arc[i] = A[u]; } }
+      for (int u = 0; u < U; u++) { const int i = base + u * NT + tid; if (i < new_nl) { hl[i] = R[u]; hl2[i] = A[u]; } }
     }
   }
   job_publish(s, sh);
@@ -659,7 +738,7 @@ __device__ bool compact_window(const Slot &s, int prev_front, int front, Shared 
   if (tid == 0) {
     sh.j_ntf = 0; sh.j_nseg = 0; sh.j_tf0 = 0; sh.j_tdst = sh.h_ntok; sh.j_ldst = sh.h_nlink;
     for (int f = f0; f <= front; f++) {
-      const FrameRec r = s.fr[f];
+      const FrameRec r = ld_frame(s.fr + f);
       if (r.flags & 1) job_add_tok(sh, r, f);
       if (r.flags & 4) job_add_seg(sh, r.pl_b, r.pl_e, r.a_pl, (f << 1) | 1);   // creation order in W: eps links of f, then its emitting links
       if (r.flags & 2) job_add_seg(sh, r.el_b, r.el_e, r.a_el, f << 1);
@@ -674,7 +753,7 @@ __device__ bool compact_window(const Slot &s, int prev_front, int front, Shared 
   __syncthreads();
   if (sh.error != ERR_NONE) return false;
   job_publish(s, sh);
-  for (int k = tid; k < nf; k += NT) s.fr[f0 + k].flags = 0;
+  for (int k = tid; k < nf; k += NT) ((gp<int>)(s.fr + (f0 + k)))[6] = 0;
   if (tid == 0) {
     sh.h_ntok = sh.j_tdst; sh.h_nlink = sh.j_ldst;
     sh.w_ntok = 0; sh.w_nlink = 0;
@@ -697,8 +776,8 @@ __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, flo
                                    int cur, Shared &sh) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long EPK = (unsigned long long)ep << 32;
-  Ent *ent = uptr(s.ent);
-  i32x4 *wt = uptr(s.w_tok);
+  gp<Ent> ent = uptr(s.ent);
+  gp<i32x4> wt = uptr(s.w_tok);
   const int w_tok_cap = s.w_tok_cap, front_cap = s.front_cap;
   for (int iter = 0;; iter++) {
     const int ncur = sh.fcnt[cur] < front_cap ? sh.fcnt[cur] : front_cap;
@@ -706,8 +785,8 @@ __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, flo
     if (iter >= MAX_EPS_ITERS) { if (tid == 0) sh.error = ERR_EPS_LOOP; break; }
     const int nxt = cur == 2 ? 0 : cur + 1, spare = nxt == 2 ? 0 : nxt + 1;
     if (tid == 0) sh.fcnt[spare] = 0;      // nobody touches the spare list during this iteration
-    const int *fcur = uptr(s.front[cur]);
-    int *fnext = uptr(s.front[nxt]);
+    gp<const int> fcur = uptr(s.front[cur]);
+    gp<int> fnext = uptr(s.front[nxt]);
     int *fcnt_next = &sh.fcnt[nxt];
     const int CH = wave_chunk(ncur);
     for (int base = wave * CH; base < ncur; base += NW * CH) {
@@ -757,7 +836,7 @@ __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, flo
   const int lb = sh.w_nlink;
   __syncthreads();
   {
-    i32x4 *wl = uptr(s.wl); int *wl_arc = uptr(s.wl_arc);
+    gp<i32x4> wl = uptr(s.wl); gp<i32x2> wl2 = uptr(s.wl2);
     const int w_link_cap = s.w_link_cap;
     const int n_new = ne - nb;
     const int CH = wave_chunk(n_new);
@@ -767,24 +846,25 @@ __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, flo
       const int sx = have ? wt[t].x : 0;
       const int st = sx & STMASK;
       const float c = o2f((unsigned)ld_u64(&ent[st].key));
-      if (have) reinterpret_cast<int *>(&wt[t])[1] = asi(c);
+      if (have) ((gp<int>)&wt[t])[1] = asi(c);
       const bool exp = have && sx < 0 && !(c > cutoff);
       int a0 = 0, cnt = 0;
       if (exp) { const i32x4 sr = g.st[st]; a0 = sr.x; cnt = sr.y; }
       wave_expand(cnt, [&](bool valid, int owner, int j) {
         const int a = __shfl(a0, owner, 64) + j;
         const float cc = __shfl(c, owner, 64);
-        bool mk = false; int dtok = 0; i32x4 arc;
+        bool mk = false; int dtok = 0; i32x4 arc; float tot = 0.0f;
         if (valid) {
           arc = g.arcs[a];
-          const float tot = cc + asf(arc.y);
+          tot = cc + asf(arc.y);
           if (tot < cutoff) { mk = true; dtok = ld_i32(&ent[arc.x & STMASK].tokid); }
         }
         const int l = wave_alloc(&sh.w_nlink, mk);
         if (mk) {
           if (l < w_link_cap) {
-            i32x4 r; r.x = (nb + base + owner) | WBIT; r.y = dtok | WBIT; r.z = arc.y; r.w = 0;
-            wl[l] = r; wl_arc[l] = a;
+            i32x4 r; r.x = (nb + base + owner) | WBIT; r.y = dtok | WBIT; r.z = asi(tot); r.w = a;
+            i32x2 r2; r2.x = arc.y; r2.y = 0;
+            wl[l] = r; wl2[l] = r2;
           } else sh.error = ERR_W_LINK;
         }
       });
@@ -827,7 +907,7 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
     const UttDesc ud = utts[utt];
     const int T = ud.T;
     // epochs start at 1: the high word 0xFFFFFFFF is the cleared (memset 0xFF) state
-    const int epoch_base = s.state[0] + 1;
+    const int epoch_base = gptr(s.state)[0] + 1;
     long long c_tok_exp = 0, c_arc_exp = 0;        // per-thread counters, reduced at the end
     long long t_last = clk();
 #define PHASE(i) { if (tid == 0) { const long long now_ = clk(); sh.tph[i] += now_ - t_last; t_last = now_; } }
@@ -840,6 +920,7 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
       sh.cnt_tok[0] = 0; sh.cnt_tok[1] = 0; sh.cnt_el[0] = 0; sh.cnt_el[1] = 0; sh.cnt_pl[0] = 0; sh.cnt_pl[1] = 0;
       sh.tail_tok_b = 0; sh.tail_link_b = 0; sh.tail_f0 = -1; sh.tail_f1 = -2;
     }
+    for (int i = tid; i < DIRTY_FRAMES / 32; i += NT) sh.dirty[i] = ~0u;   // no frame has been evaluated yet
     pp = 0;
     __syncthreads();
 
@@ -851,11 +932,11 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
       if (tid == 0) {
         const i32x4 sr = g.st[g.start];
         i32x4 r; r.x = g.start | (sr.y > 0 ? EPSBIT : 0); r.y = 0; r.z = 0; r.w = (int)INF_BITS;
-        s.w_tok[0] = r;
-        s.ent[g.start].key = ((unsigned long long)ep << 32) | f2o(0.0f);
-        s.ent[g.start].tokid = 0;
+        gptr(s.w_tok)[0] = r;
+        gptr(s.ent)[g.start].key = ((unsigned long long)ep << 32) | f2o(0.0f);
+        gptr(s.ent)[g.start].tokid = 0;
         sh.w_ntok = 1;
-        if (sr.y > 0) { s.front[0][0] = g.start; sh.fcnt[0] = 1; }
+        if (sr.y > 0) { gptr(s.front[0])[0] = g.start; sh.fcnt[0] = 1; }
       }
       __threadfence_block();
       __syncthreads();
@@ -866,7 +947,7 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
         r.tok_b = 0; r.tok_e = cur_e; r.el_b = 0; r.el_e = 0;
         r.pl_b = plb; r.pl_e = sh.w_nlink < s.w_link_cap ? sh.w_nlink : s.w_link_cap;
         r.flags = 1 | 4; r.cost_offset = 0.0f; r.a_tok = cur_e; r.a_el = 0; r.a_pl = r.pl_e - r.pl_b; r.pad = 0;
-        s.fr[0] = r;
+        st_frame(s.fr, r);
         sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0;
       }
       __syncthreads();
@@ -884,16 +965,17 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
         // the work (long-lived parallel paths would otherwise drag every pass back to frame 0);
         // whatever is left stale is a lower bound and is settled by the final pass
         prune_backward(s, frame - 1, prev_front < 0 ? 0 : prev_front, (prev_front < 0 ? 0 : prev_front) - cfg.prune_interval,
-                       cfg.lattice_beam, cfg.lattice_beam * 0.1f, sh, pp);
+                       cfg.lattice_beam, cfg.lattice_beam * 0.1f, /*final=*/false, sh, pp);
         PHASE(4)
         if (!compact_window(s, prev_front, frame, sh)) break;
         prev_front = frame;
-        cur_b = s.fr[frame].tok_b; cur_e = s.fr[frame].tok_e; cur_w = false;
+        { const FrameRec fr = ld_frame(s.fr + frame); cur_b = fr.tok_b; cur_e = fr.tok_e; }
+        cur_w = false;
         PHASE(5)
       }
       const int tb = cur_b, n = cur_e - cur_b;
-      const i32x4 *tok = uptr(cur_w ? s.w_tok : s.h_tok) + tb;
-      i32x4 *cand = uptr(s.cand); i32x2 *cand2 = uptr(s.cand2);
+      gp<const i32x4> tok = uptr(cur_w ? s.w_tok : s.h_tok) + tb;
+      gp<i32x4> cand = uptr(s.cand); gp<i32x2> cand2 = uptr(s.cand2);
       const int cand_cap = s.cand_cap;
       const int enc = cur_w ? WBIT : 0;
       const float *llrow = loglikes + (ud.row0 + frame) * (long long)P;
@@ -958,7 +1040,7 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
 #pragma unroll
           for (int o = 32; o > 0; o >>= 1) nc = fminf(nc, __shfl_xor(nc, o, 64));
         }
-        if (lane == 0) { sh.f0 = nc; s.fr[frame].cost_offset = cost_offset; }
+        if (lane == 0) { sh.f0 = nc; ((gp<float>)(s.fr + frame))[7] = cost_offset; }
       }
       PHASE(0)
       // ---- pass 1 (arc-parallel): every candidate arc -> scratch list; min of tot + adaptive_beam
@@ -1004,9 +1086,9 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
       // ---- pass 2 (candidate-parallel): admit tot <= next_cutoff; min-cost per state via one
       //      64-bit atomicMin; the thread that meets a stale epoch creates the token
       {
-        Ent *ent = uptr(s.ent);
-        i32x4 *wt = uptr(s.w_tok);
-        int *front0 = uptr(s.front[0]);
+        gp<Ent> ent = uptr(s.ent);
+        gp<i32x4> wt = uptr(s.w_tok);
+        gp<int> front0 = uptr(s.front[0]);
         const int w_tok_cap = s.w_tok_cap, front_cap = s.front_cap;
         for (int base = 0; base < ncand; base += NT * U) {
           i32x4 CA[U]; i32x2 CB[U]; bool adm[U]; unsigned long long old[U];
@@ -1044,8 +1126,8 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
       // ---- pass 3 (candidate-parallel): forward links (:765-767)
       const int lb = sh.w_nlink;
       if (sh.error == ERR_NONE) {
-        const Ent *ent = uptr(s.ent);
-        i32x4 *wl = uptr(s.wl); int *wl_arc = uptr(s.wl_arc);
+        gp<const Ent> ent = uptr(s.ent);
+        gp<i32x4> wl = uptr(s.wl); gp<i32x2> wl2 = uptr(s.wl2);
         const int w_link_cap = s.w_link_cap;
         for (int base = 0; base < ncand; base += NT * U) {
           i32x4 CA[U]; i32x2 CB[U]; bool adm[U]; int dtok[U];
@@ -1063,8 +1145,9 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
             const int l = wave_alloc(&sh.w_nlink, adm[u]);
             if (adm[u]) {
               if (l < w_link_cap) {
-                i32x4 r; r.x = (tb + CA[u].w) | enc; r.y = dtok[u] | WBIT; r.z = CB[u].y; r.w = CA[u].y;
-                wl[l] = r; wl_arc[l] = CA[u].z;
+                i32x4 r; r.x = (tb + CA[u].w) | enc; r.y = dtok[u] | WBIT; r.z = CA[u].x; r.w = CA[u].z;
+                i32x2 r2; r2.x = CB[u].y; r2.y = CA[u].y;
+                wl[l] = r; wl2[l] = r2;
               } else sh.error = ERR_W_LINK;
             }
           }
@@ -1079,12 +1162,12 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
       cur_b = nb; cur_e = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap; cur_w = true;
       const int pl_end = sh.w_nlink < s.w_link_cap ? sh.w_nlink : s.w_link_cap;
       if (tid == 0) {
-        FrameRec *r0 = s.fr + frame;
-        r0->el_b = lb; r0->el_e = le_emit; r0->flags |= 2; r0->a_el = le_emit - lb;
+        gp<int> r0 = (gp<int>)(s.fr + frame);
+        r0[2] = lb; r0[3] = le_emit; r0[6] = r0[6] | 2; r0[9] = le_emit - lb;
         FrameRec r;
         r.tok_b = cur_b; r.tok_e = cur_e; r.el_b = 0; r.el_e = 0; r.pl_b = plb; r.pl_e = pl_end;
         r.flags = 1 | 4; r.cost_offset = 0.0f; r.a_tok = cur_e - cur_b; r.a_el = 0; r.a_pl = pl_end - plb; r.pad = 0;
-        s.fr[frame + 1] = r;
+        st_frame(s.fr + (frame + 1), r);
         sh.n_cand = 0; sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0;
       }
       c_tok_new += cur_e - cur_b; c_link_new += pl_end - lb;
@@ -1102,11 +1185,11 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
       const int F = T;
       __threadfence_block();
       __syncthreads();
-      const FrameRec fr = s.fr[F];
+      const FrameRec fr = ld_frame(s.fr + F);
       const int tb = fr.tok_b, te = fr.tok_e;
-      i32x4 *wt = uptr(s.w_tok), *ht = uptr(s.h_tok);
-      i32x4 *tok = uptr((fr.flags & 1) ? s.w_tok : s.h_tok);
-      i32x4 *plk = uptr((fr.flags & 4) ? s.wl : s.hl);
+      gp<i32x4> wt = uptr(s.w_tok), ht = uptr(s.h_tok);
+      gp<i32x4> tok = uptr((fr.flags & 1) ? s.w_tok : s.h_tok);
+      gp<i32x4> plk = uptr((fr.flags & 4) ? s.wl : s.hl);
       // ComputeFinalCosts (:532-572)
       float bc = INF, bwf = INF; unsigned long long anyfinal = 0;
       for (int t = tb + tid; t < te; t += NT) {
@@ -1127,11 +1210,11 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
           const i32x4 r = tok[t];
           const float fc = final_empty ? 0.0f : asf(g.st[r.x & STMASK].w);
           const float x = asf(r.y) + fc - final_best;    // >= 0 by construction
-          reinterpret_cast<int *>(&tok[t])[3] = asi(x);
+          ((gp<int>)&tok[t])[3] = asi(x);
         }
         __syncthreads();
-        const int cp = eval_links(plk, pb, pe, wt, ht, cfg.lattice_beam);
-        if ((tid & 63) == 0 && cp) atomicAdd(&sh.cnt_pl[pp], cp);
+        const unsigned long long cp = eval_links(plk, pb, pe, pe, wt, ht, cfg.lattice_beam);
+        if ((tid & 63) == 0 && (cp >> 32)) atomicAdd(&sh.cnt_pl[pp], (int)(cp >> 32));
         __syncthreads();
         if (tid == 0) { sh.changed2[pp ^ 1] = 0; sh.cnt_tok[pp ^ 1] = 0; sh.cnt_el[pp ^ 1] = 0; sh.cnt_pl[pp ^ 1] = 0; }
         int ch = 0, alive = 0;
@@ -1141,7 +1224,7 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
           if (v > cfg.lattice_beam) v = INF;
           const unsigned vb = __float_as_uint(v);
           i32x2 nv; nv.x = (int)vb; nv.y = (int)INF_BITS;
-          *reinterpret_cast<i32x2 *>(reinterpret_cast<int *>(&tok[t]) + 2) = nv;
+          *(gp<i32x2>)((gp<int>)&tok[t] + 2) = nv;
           if (vb != (unsigned)r.z) ch = 1;
           alive += vb != INF_BITS;
         }
@@ -1150,12 +1233,15 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
         __syncthreads();
         const bool any = sh.changed2[pp] != 0;
         const bool last = !any || pe == pb;
-        if (last && tid == 0) { s.fr[F].a_tok = sh.cnt_tok[pp]; s.fr[F].a_pl = sh.cnt_pl[pp]; s.fr[F].a_el = 0; }
+        if (last && tid == 0) {
+          i32x4 c; c.x = sh.cnt_tok[pp]; c.y = 0; c.z = sh.cnt_pl[pp]; c.w = 0;
+          ((gp<i32x4>)(s.fr + F))[2] = c;
+        }
         pp ^= 1;
         if (last) break;
       }
       __syncthreads();
-      prune_backward(s, F - 1, /*first_unpruned=*/0, /*stop_at=*/0, cfg.lattice_beam, 0.0f, sh, pp);   // every frame, delta 0 (:606-611)
+      prune_backward(s, F - 1, /*first_unpruned=*/0, /*stop_at=*/0, cfg.lattice_beam, 0.0f, /*final=*/true, sh, pp);   // delta 0 (:606-611)
       PHASE(4)
       compact_window(s, prev_front, F, sh);
       PHASE(5)
@@ -1169,15 +1255,15 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
     long long r_tok_off = 0, r_link_off = 0, r_cost_off = 0;
     if (search_ok && sh.error == ERR_NONE) {
       const int F = T;
-      const i32x4 *ht = uptr(s.h_tok), *hl = uptr(s.hl);
-      const int *hl_arc = uptr(s.hl_arc);
-      int *h_remap = uptr(s.h_remap);
+      gp<const i32x4> ht = uptr(s.h_tok), hl = uptr(s.hl);
+      gp<const i32x2> hl2 = uptr(s.hl2);
+      gp<int> h_remap = uptr(s.h_remap);
       if (tid == 0) sh.flag = 0;
       __syncthreads();
       // dense index per alive history token (h_remap; -1 = dead)
       unsigned long long alive_last = 0;
       for (int f = wave; f <= F; f += NW) {
-        const FrameRec fr = s.fr[f];
+        const FrameRec fr = ld_frame(s.fr + f);
         for (int b0 = fr.tok_b; b0 < fr.tok_e; b0 += 64) {
           const int t = b0 + lane;
           const bool in = t < fr.tok_e;
@@ -1191,7 +1277,7 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
       const unsigned long long na = (unsigned long long)sh.flag;
       unsigned long long nl = 0;
       for (int f = wave; f <= F; f += NW) {
-        const FrameRec fr = s.fr[f];
+        const FrameRec fr = ld_frame(s.fr + f);
         for (int pass = 0; pass < 2; pass++) {
           const int lb = pass ? fr.pl_b : fr.el_b, le_ = pass ? fr.pl_e : fr.el_e;
           for (int b0 = lb; b0 < le_; b0 += 64) {
@@ -1219,7 +1305,7 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
       const bool fits = toff + (long long)na <= pool.tok_cap && loff + (long long)nl <= pool.link_cap && coff_off + T <= pool.cost_cap;
       if (fits) {
         for (int f = wave; f <= F; f += NW) {
-          const FrameRec fr = s.fr[f];
+          const FrameRec fr = ld_frame(s.fr + f);
           for (int b0 = fr.tok_b; b0 < fr.tok_e; b0 += 64) {
             const int t = b0 + lane;
             const bool in = t < fr.tok_e;
@@ -1241,7 +1327,8 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
               const int l = b0 + lane;
               const bool in = l < le_;
               const i32x4 L = hl[in ? l : lb];
-              const int arc_id = hl_arc[in ? l : lb];
+              const i32x2 L2 = hl2[in ? l : lb];
+              const int arc_id = in ? L.w : 0;
               const bool live = in && L.x >= 0;
               const int a = h_remap[live ? L.x : 0], b = h_remap[live ? L.y : 0];
               const bool w = live && a >= 0 && b >= 0;
@@ -1250,13 +1337,13 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
                 const long long o = loff + d;
                 const int il = g.arc_il[arc_id];
                 pool.link_src[o] = a; pool.link_dst[o] = b;
-                pool.link_il[o] = il; pool.link_ol[o] = g.arcs[arc_id].w; pool.link_gr[o] = asf(L.z);
-                pool.link_ac[o] = il != 0 ? asf(L.w) - coff : asf(L.w);
+                pool.link_il[o] = il; pool.link_ol[o] = g.arcs[arc_id].w; pool.link_gr[o] = asf(L2.x);
+                pool.link_ac[o] = il != 0 ? asf(L2.y) - coff : asf(L2.y);
               }
             }
           }
         }
-        for (int f = tid; f < T; f += NT) pool.cost_offsets[coff_off + f] = s.fr[f].cost_offset;
+        for (int f = tid; f < T; f += NT) pool.cost_offsets[coff_off + f] = ((gp<const float>)(s.fr + f))[7];
         r_n_tok = (int)na; r_n_link = (int)nl; r_tok_off = toff; r_link_off = loff; r_cost_off = coff_off;
         r_reached_final = final_relative != INF;
         // Decode() returns whether the last frame still has tokens (:93-95)
@@ -1277,7 +1364,7 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
         r->n_max_bound = sh.n_max_bound; r->n_min_bound = sh.n_min_bound;
         for (int i = 0; i < 7; i++) r->t_phase[i] = sh.tph[i];
         r->t_phase[7] = sh.n_visited;   // slot 7: frames visited by pruning (not a time)
-        s.state[0] = epoch_base + T + 2;   // next utterance in this slot: disjoint epochs
+        gptr(s.state)[0] = epoch_base + T + 2;   // next utterance in this slot: disjoint epochs
       }
     }
     __syncthreads();
@@ -1326,6 +1413,12 @@ struct vbh_decoder {
   std::vector<HostLattice> results;
   std::vector<UttResult> h_res;
   int n_retried = 0;
+  // output pool (device) and its pinned host mirror: kept across batches, grown on demand
+  DevBuf<int> p_tf, p_ts, p_ls, p_ld, p_li, p_lo; DevBuf<float> p_tc, p_te, p_tfin, p_lg, p_la, p_co; DevBuf<unsigned long long> p_cnt;
+  DevBuf<Pool> d_pool;
+  long long pool_tok_cap = 0, pool_link_cap = 0, pool_cost_cap = 0;
+  void *pin = nullptr; size_t pin_bytes = 0;
+  float t_kernel_ms = 0, t_copy_ms = 0, t_host_ms = 0, t_total_ms = 0;   // last vbh_decode_batch
 };
 
 static int slot_alloc(vbh_decoder *d, size_t bytes, void **p, int memset_val = -2) {
@@ -1384,8 +1477,8 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
     for (size_t i = 0; i < ns; i++) set->h[i].field = base + i * (size_t)(count);                    \
   }
   A_(ent, Ent, S, 0xFF)
-  A_(w_tok, i32x4, p.w_tok_cap, -2) A_(w_remap, int, p.w_tok_cap, 0) A_(wl, i32x4, p.w_link_cap, -2) A_(wl_arc, int, p.w_link_cap, -2)
-  A_(h_tok, i32x4, p.h_tok_cap, -2) A_(h_remap, int, p.h_tok_cap, 0) A_(hl, i32x4, p.h_link_cap, -2) A_(hl_arc, int, p.h_link_cap, -2)
+  A_(w_tok, i32x4, p.w_tok_cap, -2) A_(w_remap, int, p.w_tok_cap, 0) A_(wl, i32x4, p.w_link_cap, -2) A_(wl2, i32x2, p.w_link_cap, -2)
+  A_(h_tok, i32x4, p.h_tok_cap, -2) A_(h_remap, int, p.h_tok_cap, 0) A_(hl, i32x4, p.h_link_cap, -2) A_(hl2, i32x2, p.h_link_cap, -2)
   A_(fr, FrameRec, F, 0)
   A_(cand, i32x4, p.cand_cap, -2) A_(cand2, i32x2, p.cand_cap, -2)
   A_(front[0], int, p.front_cap, -2) A_(front[1], int, p.front_cap, -2) A_(front[2], int, p.front_cap, -2)
@@ -1487,6 +1580,7 @@ void vbh_decoder_destroy(vbh_decoder *d) {
   (void)hipSetDevice(d->ctx->device);
   (void)hipStreamSynchronize(d->ctx->stream);
   for (void *p : d->allocs) (void)hipFree(p);
+  if (d->pin) (void)hipHostFree(d->pin);
   delete d;
 }
 
@@ -1622,7 +1716,12 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
   VBH_CHECK(n_utt >= 0 && num_pdfs > 0 && num_tids >= 0, "vbh_decode_batch: bad sizes");
   if (vbh_use_device(d->ctx)) return -1;
   d->results.clear(); d->h_res.clear();
+  d->t_kernel_ms = d->t_copy_ms = d->t_host_ms = d->t_total_ms = 0;
   if (n_utt == 0) return 0;
+  const auto t_begin = std::chrono::steady_clock::now();
+  hipEvent_t ev0, ev1;
+  VBH_HIP(hipEventCreate(&ev0)); VBH_HIP(hipEventCreate(&ev1));
+  struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } ev_guard{ev0, ev1};
   const vbh_graph *g = d->graph;
   // the graph's ilabels must be valid transition-ids ("Likely graph/model mismatch",
   // decodable-am-diag-gmm.cc:32-33) -- checked once per batch on the tid2pdf table
@@ -1650,10 +1749,19 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
   Pool pool{};
   const long long tok_cap = std::max<long long>(4096, 64 * (total_frames + n_utt)), link_cap = std::max<long long>(8192, 128 * (total_frames + n_utt));
   pool.tok_cap = tok_cap; pool.link_cap = link_cap; pool.cost_cap = total_frames + 1;
-  DevBuf<int> p_tf, p_ts, p_ls, p_ld, p_li, p_lo; DevBuf<float> p_tc, p_te, p_tfin, p_lg, p_la, p_co; DevBuf<unsigned long long> p_cnt;
-  if (p_tf.alloc(tok_cap) || p_ts.alloc(tok_cap) || p_tc.alloc(tok_cap) || p_te.alloc(tok_cap) || p_tfin.alloc(tok_cap) ||
-      p_ls.alloc(link_cap) || p_ld.alloc(link_cap) || p_li.alloc(link_cap) || p_lo.alloc(link_cap) || p_lg.alloc(link_cap) ||
-      p_la.alloc(link_cap) || p_co.alloc(pool.cost_cap) || p_cnt.alloc(4)) return -1;
+  DevBuf<int> &p_tf = d->p_tf, &p_ts = d->p_ts, &p_ls = d->p_ls, &p_ld = d->p_ld, &p_li = d->p_li, &p_lo = d->p_lo;
+  DevBuf<float> &p_tc = d->p_tc, &p_te = d->p_te, &p_tfin = d->p_tfin, &p_lg = d->p_lg, &p_la = d->p_la, &p_co = d->p_co;
+  DevBuf<unsigned long long> &p_cnt = d->p_cnt;
+  if (tok_cap > d->pool_tok_cap) {
+    if (p_tf.alloc(tok_cap) || p_ts.alloc(tok_cap) || p_tc.alloc(tok_cap) || p_te.alloc(tok_cap) || p_tfin.alloc(tok_cap)) return -1;
+    d->pool_tok_cap = tok_cap;
+  }
+  if (link_cap > d->pool_link_cap) {
+    if (p_ls.alloc(link_cap) || p_ld.alloc(link_cap) || p_li.alloc(link_cap) || p_lo.alloc(link_cap) || p_lg.alloc(link_cap) || p_la.alloc(link_cap)) return -1;
+    d->pool_link_cap = link_cap;
+  }
+  if (pool.cost_cap > d->pool_cost_cap) { if (p_co.alloc(pool.cost_cap)) return -1; d->pool_cost_cap = pool.cost_cap; }
+  if (!p_cnt.p && p_cnt.alloc(4)) return -1;
   VBH_HIP(hipMemsetAsync(p_cnt.p, 0, 4 * sizeof(unsigned long long), st));
   pool.tok_frame = p_tf.p; pool.tok_state = p_ts.p; pool.tok_cost = p_tc.p; pool.tok_extra = p_te.p; pool.tok_final = p_tfin.p;
   pool.link_src = p_ls.p; pool.link_dst = p_ld.p; pool.link_il = p_li.p; pool.link_ol = p_lo.p; pool.link_gr = p_lg.p; pool.link_ac = p_la.p;
@@ -1662,18 +1770,22 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
     hipLaunchKernelGGL(fill_arc_pdf_kernel, dim3(1024), dim3(256), 0, st, g->arcs.p, g->arc_il.p, g->A, d_t2p.p);
     VBH_HIP(hipGetLastError());
   }
-  DevBuf<Pool> d_pool;
-  if (d_pool.upload(&pool, 1, st)) return -1;
+  DevBuf<Pool> &d_pool = d->d_pool;
+  if (!d_pool.p && d_pool.alloc(1)) return -1;
+  VBH_HIP(hipMemcpyAsync(d_pool.p, &pool, sizeof(Pool), hipMemcpyHostToDevice, st));
   DevGraph dg{g->S, g->start, g->st.p, g->arcs.p, g->arc_il.p};
   DecCfg dc{d->cfg.beam, d->cfg.lattice_beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active, effective_prune_interval(&d->cfg)};
   d->h_res.resize(n_utt);
   {
     const int grid = std::min(d->small_set.n, n_utt);
+    VBH_HIP(hipEventRecord(ev0, st));
     hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(NT), 0, st, dg, dc, d->small_set.d.p, d_loglikes, (int)num_pdfs,
                        d_utts.p, (const int *)nullptr, n_utt, d_counter.p, d_res.p, d_pool.p);
     VBH_HIP(hipGetLastError());
+    VBH_HIP(hipEventRecord(ev1, st));
     VBH_HIP(hipMemcpyAsync(d->h_res.data(), d_res.p, sizeof(UttResult) * n_utt, hipMemcpyDeviceToHost, st));
     VBH_HIP(hipStreamSynchronize(st));
+    float ms = 0; VBH_HIP(hipEventElapsedTime(&ms, ev0, ev1)); d->t_kernel_ms += ms;
   }
   // utterances that outgrew a small slot are searched again in a big one
   std::vector<int> retry;
@@ -1696,11 +1808,14 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
     if (d_list.upload(retry.data(), retry.size(), st)) return -1;
     VBH_HIP(hipMemsetAsync(d_counter.p, 0, sizeof(int), st));
     const int grid = std::min<int>(d->big_set.n, (int)retry.size());
+    VBH_HIP(hipEventRecord(ev0, st));
     hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(NT), 0, st, dg, dc, d->big_set.d.p, d_loglikes, (int)num_pdfs,
                        d_utts.p, d_list.p, (int)retry.size(), d_counter.p, d_res.p, d_pool.p);
     VBH_HIP(hipGetLastError());
+    VBH_HIP(hipEventRecord(ev1, st));
     VBH_HIP(hipMemcpyAsync(d->h_res.data(), d_res.p, sizeof(UttResult) * n_utt, hipMemcpyDeviceToHost, st));
     VBH_HIP(hipStreamSynchronize(st));
+    float ms = 0; VBH_HIP(hipEventElapsedTime(&ms, ev0, ev1)); d->t_kernel_ms += ms;
   }
   d->n_retried = (int)retry.size();
   unsigned long long used[4];
@@ -1709,18 +1824,52 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
   for (int u = 0; u < n_utt; u++)
     VBH_CHECK(d->h_res[u].error == ERR_NONE, "vbh_decode_batch: utterance %d failed: %s", u, err_name(d->h_res[u].error));
   // bring the used part of the pool to the host
+  const auto t_copy0 = std::chrono::steady_clock::now();
   const long long nt = std::min<long long>((long long)used[0], tok_cap), nl = std::min<long long>((long long)used[1], link_cap);
-  std::vector<int> tf(nt), ts(nt), ls(nl), ld(nl), li(nl), lo(nl); std::vector<float> tc(nt), te(nt), tfin(nt), lg(nl), la(nl);
-#define D2H(vec, src, cnt) if (cnt) VBH_HIP(hipMemcpyAsync(vec.data(), src.p, sizeof(vec[0]) * (cnt), hipMemcpyDeviceToHost, st));
+  // pinned staging: [5 token arrays of nt][6 link arrays of nl], 4 bytes per entry
+  const size_t need = (size_t)(5 * nt + 6 * nl) * 4 + 64;
+  if (need > d->pin_bytes) {
+    if (d->pin) (void)hipHostFree(d->pin);
+    d->pin = nullptr; d->pin_bytes = 0;
+    const size_t want = need + need / 4;
+    VBH_HIP(hipHostMalloc(&d->pin, want, hipHostMallocDefault));
+    d->pin_bytes = want;
+  }
+  int32_t *hb = static_cast<int32_t *>(d->pin);
+  int *tf = hb, *ts = hb + nt; float *tc = reinterpret_cast<float *>(hb + 2 * nt), *te = reinterpret_cast<float *>(hb + 3 * nt), *tfin = reinterpret_cast<float *>(hb + 4 * nt);
+  int32_t *lbase = hb + 5 * nt;
+  int *ls = lbase, *ld = lbase + nl, *li = lbase + 2 * nl, *lo = lbase + 3 * nl;
+  float *lg = reinterpret_cast<float *>(lbase + 4 * nl), *la = reinterpret_cast<float *>(lbase + 5 * nl);
+#define D2H(dst, src, cnt) if (cnt) VBH_HIP(hipMemcpyAsync(dst, src.p, 4 * (size_t)(cnt), hipMemcpyDeviceToHost, st));
   D2H(tf, p_tf, nt) D2H(ts, p_ts, nt) D2H(tc, p_tc, nt) D2H(te, p_te, nt) D2H(tfin, p_tfin, nt)
   D2H(ls, p_ls, nl) D2H(ld, p_ld, nl) D2H(li, p_li, nl) D2H(lo, p_lo, nl) D2H(lg, p_lg, nl) D2H(la, p_la, nl)
 #undef D2H
   VBH_HIP(hipStreamSynchronize(st));
   Pool hp{};
-  hp.tok_frame = tf.data(); hp.tok_state = ts.data(); hp.tok_cost = tc.data(); hp.tok_extra = te.data(); hp.tok_final = tfin.data();
-  hp.link_src = ls.data(); hp.link_dst = ld.data(); hp.link_il = li.data(); hp.link_ol = lo.data(); hp.link_gr = lg.data(); hp.link_ac = la.data();
+  hp.tok_frame = tf; hp.tok_state = ts; hp.tok_cost = tc; hp.tok_extra = te; hp.tok_final = tfin;
+  hp.link_src = ls; hp.link_dst = ld; hp.link_il = li; hp.link_ol = lo; hp.link_gr = lg; hp.link_ac = la;
+  const auto t_host0 = std::chrono::steady_clock::now();
   d->results.resize(n_utt);
-  for (int u = 0; u < n_utt; u++) finish_lattice(g, d->h_res[u], hp, &d->results[u]);
+  {
+    // canonical ordering + best path per utterance: independent, spread over host threads
+    int nthr = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    if (const char *e = getenv("VBH_HOST_THREADS")) { const int x = atoi(e); if (x > 0) nthr = x; }
+    nthr = std::min(nthr, n_utt);
+    std::atomic<int> next{0};
+    auto work = [&]() {
+      for (int u = next.fetch_add(1); u < n_utt; u = next.fetch_add(1)) finish_lattice(g, d->h_res[u], hp, &d->results[u]);
+    };
+    if (nthr <= 1) work();
+    else {
+      std::vector<std::thread> pool_threads;
+      for (int i = 0; i < nthr; i++) pool_threads.emplace_back(work);
+      for (auto &t : pool_threads) t.join();
+    }
+  }
+  const auto t_end = std::chrono::steady_clock::now();
+  d->t_copy_ms = std::chrono::duration<float, std::milli>(t_host0 - t_copy0).count();
+  d->t_host_ms = std::chrono::duration<float, std::milli>(t_end - t_host0).count();
+  d->t_total_ms = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
   return 0;
 }
 
@@ -1728,6 +1877,12 @@ int vbh_decoder_phase_cycles(vbh_decoder *d, int32_t utt, int64_t *out8) {
   VBH_CHECK(d && out8, "vbh_decoder_phase_cycles: NULL argument");
   VBH_CHECK(utt >= 0 && utt < (int)d->h_res.size(), "vbh_decoder_phase_cycles: utterance %d out of range", utt);
   for (int i = 0; i < 8; i++) out8[i] = d->h_res[utt].t_phase[i];
+  return 0;
+}
+
+int vbh_decoder_times(vbh_decoder *d, float *out4) {
+  VBH_CHECK(d && out4, "vbh_decoder_times: NULL argument");
+  out4[0] = d->t_kernel_ms; out4[1] = d->t_copy_ms; out4[2] = d->t_host_ms; out4[3] = d->t_total_ms;
   return 0;
 }
 
