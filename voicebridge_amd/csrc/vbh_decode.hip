@@ -67,12 +67,17 @@ namespace {
 #endif
 constexpr int NT = VBH_DECODE_NT;    // threads per workgroup = per utterance; 1024/NT workgroups share a CU
 constexpr int NW = NT / 64;
+#ifndef VBH_WAVES_PER_EU
+#define VBH_WAVES_PER_EU 4                  // 4: 128 VGPRs, 1024 threads per CU;  8: 64 VGPRs, 2048 threads per CU
+#endif
+constexpr int WG_PER_CU = (1024 / NT) * (VBH_WAVES_PER_EU / 4);
 constexpr int WBIT = 0x40000000;            // token id lives in the raw window
 constexpr unsigned INF_BITS = 0x7F800000u;  // +inf as float bits
 constexpr int MAX_EPS_ITERS = 4096;
 constexpr int MAX_WIN_FRAMES = NT / 2;      // frames between two compactions (prune_interval + 1 <= this)
 constexpr int EPSBIT = (int)0x80000000;     // on an arc's next state / a token's state: that state has epsilon arcs
-constexpr int STMASK = 0x7FFFFFFF;
+constexpr int PLDST = 0x40000000;           // on a token's state: the token is the destination of an epsilon link of its frame
+constexpr int STMASK = 0x3FFFFFFF;
 constexpr int COST_CAP = 8 * NT;            // token costs of the current frame cached in LDS
 #ifndef VBH_U
 #define VBH_U 4
@@ -372,8 +377,9 @@ __device__ __forceinline__ gp<i32x4> tokp(gp<i32x4> wt, gp<i32x4> ht, int id) { 
 // carries tot = (source cost + acoustic) + graph, so only the destination token is gathered.
 // Links at positions < split are the frame's epsilon links, the others its emitting links.
 // Returns (valid on lane 0 of each wave) the links this wave kept: epsilon << 32 | emitting.
+template <bool LDS_TMP>
 __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, int le_, int split, gp<i32x4> wt, gp<i32x4> ht,
-                                                         float lattice_beam) {
+                                                         float lattice_beam, unsigned *lds_tmp, int tb) {
   unsigned long long kept = 0;
   for (int base = lb; base < le_; base += NT * UL) {
     i32x4 L[UL]; bool ok[UL];
@@ -399,7 +405,8 @@ __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, i
       if (ok[u] && !keep) ((gp<int>)&lk[l])[0] = -1;
       if (keep) {
         if (le < 0.0f) le = 0.0f;
-        rmw_min_u32((gp<unsigned>)tokp(wt, ht, L[u].x) + 3, __float_as_uint(le));
+        if (LDS_TMP) atomicMin(&lds_tmp[(L[u].x & ~WBIT) - tb], __float_as_uint(le));
+        else rmw_min_u32((gp<unsigned>)tokp(wt, ht, L[u].x) + 3, __float_as_uint(le));
       }
       const unsigned long long m = __ballot(keep);
       // a wave's 64 links are consecutive, so the split falls on a lane boundary
@@ -440,13 +447,31 @@ __device__ int prune_frame(const Slot &s, int f, float lattice_beam, float delta
   gp<i32x4> elk = uptr((flags & 2) ? s.wl : s.hl), plk = uptr((flags & 4) ? s.wl : s.hl);
   // epsilon links of a frame are created right before its emitting links: normally one range
   const bool one_range = pe == eb && ((flags >> 1) & 1) == ((flags >> 2) & 1);
+  // Frames of up to COST_CAP tokens accumulate the link minima in LDS (sh.cost, all +inf between
+  // sweeps) instead of the tokens' tmp fields: no global atomics to wait for, and the old
+  // extra_costs are fetched while the links are in flight.
+  const bool lds_tmp = te - tb <= COST_CAP;
+  unsigned *ltmp = reinterpret_cast<unsigned *>(sh.cost);
   int result = 0;
   for (int iter = 0; iter < MAX_EPS_ITERS; iter++) {
+    i32x4 R0[U];            // first round of the token pass, prefetched
+    if (lds_tmp) {
+#pragma unroll
+      for (int u = 0; u < U; u++) { const int t = tb + u * NT + tid; R0[u] = tok[t < te ? t : tb]; }
+    }
     unsigned long long kept;
-    if (one_range) kept = eval_links(elk, pb, ee, pe, wt, ht, lattice_beam);
-    else {
-      kept = eval_links(plk, pb, pe, pe, wt, ht, lattice_beam);
-      kept += eval_links(elk, eb, ee, eb, wt, ht, lattice_beam);
+    if (lds_tmp) {
+      if (one_range) kept = eval_links<true>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb);
+      else {
+        kept = eval_links<true>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb);
+        kept += eval_links<true>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb);
+      }
+    } else {
+      if (one_range) kept = eval_links<false>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb);
+      else {
+        kept = eval_links<false>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb);
+        kept += eval_links<false>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb);
+      }
     }
     if ((tid & 63) == 0) {
       if ((unsigned)kept) atomicAdd(&sh.cnt_el[pp], (int)(unsigned)kept);
@@ -464,20 +489,27 @@ __device__ int prune_frame(const Slot &s, int f, float lattice_beam, float delta
       for (int u = 0; u < U; u++) {
         const int t = base + u * NT + tid;
         ok[u] = t < te;
-        R[u] = tok[ok[u] ? t : tb];
+        if (lds_tmp && base == tb) R[u] = R0[u];
+        else R[u] = tok[ok[u] ? t : tb];
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int t = base + u * NT + tid;
-        const unsigned v = (unsigned)R[u].w, o = (unsigned)R[u].z;
-        if (ok[u] && (v != o || v != INF_BITS)) {
+        unsigned v = (unsigned)R[u].w;
+        const unsigned o = (unsigned)R[u].z;
+        if (lds_tmp) {
+          v = INF_BITS;
+          if (ok[u]) { v = ltmp[t - tb]; if (v != INF_BITS) ltmp[t - tb] = INF_BITS; }
+          if (ok[u] && v != o) ((gp<int>)&tok[t])[2] = (int)v;
+        } else if (ok[u] && (v != o || v != INF_BITS)) {
           i32x2 nv; nv.x = (int)v; nv.y = (int)INF_BITS;
           *(gp<i32x2>)((gp<int>)&tok[t] + 2) = nv;
-          if (v != o) {
-            ch |= 2;
-            // "changed" as the reference counts it (:358): |new - old| > delta; inf vs inf is no change
-            if (fabsf(__uint_as_float(v) - __uint_as_float(o)) > delta) ch |= 1;
-          }
+        }
+        if (ok[u] && v != o) {
+          ch |= 2;
+          if (R[u].x & PLDST) ch |= 4;
+          // "changed" as the reference counts it (:358): |new - old| > delta; inf vs inf is no change
+          if (fabsf(__uint_as_float(v) - __uint_as_float(o)) > delta) ch |= 1;
         }
         alive += __popcll(__ballot(ok[u] && v != INF_BITS));
       }
@@ -486,7 +518,8 @@ __device__ int prune_frame(const Slot &s, int f, float lattice_beam, float delta
     if ((tid & 63) == 0 && alive) atomicAdd(&sh.cnt_tok[pp], alive);
     __syncthreads();
     const int any = sh.changed2[pp];
-    const bool last = !(any & 2) || pe == pb;
+    // another sweep can only differ if a token that some epsilon link of this frame points to moved
+    const bool last = !(any & 4) || pe == pb;
     if (last && tid == 0) {
       i32x4 c; c.x = sh.cnt_tok[pp]; c.y = sh.cnt_el[pp]; c.z = sh.cnt_pl[pp]; c.w = 0;
       ((gp<i32x4>)frp)[2] = c;
@@ -511,6 +544,8 @@ __device__ void prune_backward(const Slot &s, int from, int first_unpruned, int 
                                bool final, Shared &sh, int &pp) {
   int visited = 0;
   int above = 3;   // result of the frame above: the frontier counts as changed
+  for (int i = threadIdx.x; i < COST_CAP; i += NT) reinterpret_cast<unsigned *>(sh.cost)[i] = INF_BITS;   // see prune_frame
+  __syncthreads();
   for (int f = from; f >= 0 && f >= stop_at; f--) {
     if (final) {
       if (!(above & 2) && !frame_dirty(sh, f)) { above = 0; continue; }
@@ -865,6 +900,7 @@ __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, flo
             i32x4 r; r.x = (nb + base + owner) | WBIT; r.y = dtok | WBIT; r.z = asi(tot); r.w = a;
             i32x2 r2; r2.x = arc.y; r2.y = 0;
             wl[l] = r; wl2[l] = r2;
+            (void)__hip_atomic_fetch_or((gp<int>)&wt[dtok], PLDST, __ATOMIC_RELAXED, VBH_RMW_SCOPE);
           } else sh.error = ERR_W_LINK;
         }
       });
@@ -874,7 +910,7 @@ __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, flo
   return lb;
 }
 
-__global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(DevGraph g, DecCfg cfg, const Slot *slots,
+__global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g, DecCfg cfg, const Slot *slots,
                                                      const float *__restrict__ loglikes, int P,
                                                      const UttDesc *__restrict__ utts, const int *__restrict__ work_list,
                                                      int n_work, int *work_counter, UttResult *results, const Pool *pool_p) {
@@ -1213,7 +1249,7 @@ __global__ __launch_bounds__(NT, (1024 / NT) * (NT / 256)) void decode_kernel(De
           ((gp<int>)&tok[t])[3] = asi(x);
         }
         __syncthreads();
-        const unsigned long long cp = eval_links(plk, pb, pe, pe, wt, ht, cfg.lattice_beam);
+        const unsigned long long cp = eval_links<false>(plk, pb, pe, pe, wt, ht, cfg.lattice_beam, nullptr, 0);
         if ((tid & 63) == 0 && (cp >> 32)) atomicAdd(&sh.cnt_pl[pp], (int)(cp >> 32));
         __syncthreads();
         if (tid == 0) { sh.changed2[pp ^ 1] = 0; sh.cnt_tok[pp ^ 1] = 0; sh.cnt_el[pp ^ 1] = 0; sh.cnt_pl[pp ^ 1] = 0; }
@@ -1500,6 +1536,7 @@ int vbh_graph_create(vbh_ctx *ctx, int32_t num_states, int32_t start, const floa
                      const int64_t *h_arc_offsets, const vbh_arc *h_arcs, vbh_graph **out) {
   VBH_CHECK(ctx && h_final && h_arc_offsets && out, "vbh_graph_create: NULL argument");
   VBH_CHECK(num_states > 0 && start >= 0 && start < num_states, "vbh_graph_create: bad start state %d / %d states", start, num_states);
+  VBH_CHECK(num_states <= STMASK, "vbh_graph_create: %d states, at most %d are supported (two tag bits ride on state ids)", num_states, STMASK);
   const long long A = h_arc_offsets[num_states];
   VBH_CHECK(h_arc_offsets[0] == 0 && A >= 0 && A < 2147483647LL, "vbh_graph_create: bad arc offsets");
   VBH_CHECK(A == 0 || h_arcs, "vbh_graph_create: arcs missing");
@@ -1569,7 +1606,7 @@ int vbh_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_decode_cf
   // a few hundred lattice survivors per frame), four workgroups per CU.  "big": the generous
   // worst-case sizes, a handful of slots, allocated only when an utterance overflows a small slot;
   // such utterances are searched again there (vbh_decode_batch), so capacity never truncates a result.
-  if (alloc_slot_set(d, &d->small_set, std::min<int>(max_batch, (1024 / NT) * ctx->num_cus), /*big=*/false)) { vbh_decoder_destroy(d); return -1; }
+  if (alloc_slot_set(d, &d->small_set, std::min<int>(max_batch, WG_PER_CU * ctx->num_cus), /*big=*/false)) { vbh_decoder_destroy(d); return -1; }
   VBH_HIP(hipStreamSynchronize(ctx->stream));
   *out = d;
   return 0;
