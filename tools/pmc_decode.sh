@@ -1,10 +1,10 @@
+# PMC passes over one decode of BATCH utterances (bench.py --probe); one counter set per pass.
+# usage (under gpurun): bash tools/pmc_decode.sh <tag> <batch> "<set1>" "<set2>" ...
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+tag=$1; batch=$2; shift 2
 i=0
-for set in "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCP_LATENCY_sum TCP_TOTAL_ACCESSES_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
-           "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" \
-           "TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_WRITE_REQ_LATENCY_sum GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES" \
-           "TA_TOTAL_WAVEFRONTS_sum TCP_TAGRAM0_REQ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCC_TAG_STALL_sum TCC_BUSY_sum"; do
+for set in "$@"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc_c$i -- python3 $R/bench.py --probe --batch 256 > $R/gpurun_out/pmc_c$i.log 2>&1
+  timeout 400 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc_${tag}_$i -- python3 $R/bench.py --probe --batch $batch > $R/gpurun_out/pmc_${tag}_$i.log 2>&1
 done

@@ -74,7 +74,7 @@ constexpr int WG_PER_CU = (1024 / NT) * (VBH_WAVES_PER_EU / 4);
 constexpr int WBIT = 0x40000000;            // token id lives in the raw window
 constexpr unsigned INF_BITS = 0x7F800000u;  // +inf as float bits
 constexpr int MAX_EPS_ITERS = 4096;
-constexpr int MAX_WIN_FRAMES = NT / 2;      // frames between two compactions (prune_interval + 1 <= this)
+constexpr int MAX_WIN_FRAMES = NT / 4;      // frames between two compactions (prune_interval + 1 <= this)
 constexpr int EPSBIT = (int)0x80000000;     // on an arc's next state / a token's state: that state has epsilon arcs
 constexpr int PLDST = 0x40000000;           // on a token's state: the token is the destination of an epsilon link of its frame
 constexpr int STMASK = 0x3FFFFFFF;
@@ -87,6 +87,10 @@ constexpr int COST_CAP = 8 * NT;            // token costs of the current frame 
 #endif
 constexpr int U = VBH_U;                    // independent items per lane in the streaming passes
 constexpr int UL = VBH_UL;                  // ... in the pruning sweeps over links
+constexpr int HBITS = NT >= 1024 ? 13 : (NT >= 512 ? 12 : 11);
+constexpr int HCAP = 1 << HBITS;            // slots of the per-frame state map in LDS (8 per thread)
+constexpr int HPROBE = 16;                  // probes before a state is sent to the table in HBM
+constexpr unsigned HEMPTY = 0xFFFFFFFFu;
 constexpr int DIRTY_FRAMES = 1 << 16;       // frames covered by the dirty bitmap (8 KB of LDS)
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -112,6 +116,7 @@ struct DevGraph {
 struct DecCfg {
   float beam, lattice_beam, beam_delta, acwt;
   int max_active, min_active, prune_interval;
+  int use_lds_map;      // 0: every state goes to the table in HBM (diagnostic)
 };
 
 struct Ent { unsigned long long key; int tokid; int pad; };   // per graph state
@@ -287,6 +292,9 @@ struct Shared {
   int tail_tok_b, tail_link_b, tail_f0, tail_f1;
   long long tph[8];                // phase cycle counters (thread 0)
   unsigned dirty[DIRTY_FRAMES / 32];   // see frame_dirty()
+  // state map of the frame being built (see map_relax)
+  unsigned hs[HCAP], hc[HCAP]; int ht[HCAP];
+  int use_lds_map;
   float cost[COST_CAP];            // costs of the current frame's tokens (GetCutoff)
   // compaction job: token frames and link segments in source order
   int j_ntf, j_nseg, j_tf0, j_tdst, j_ldst;
@@ -801,6 +809,68 @@ __device__ bool compact_window(const Slot &s, int prev_front, int front, Shared 
 }
 
 // ---------------------------------------------------------------------------------------
+// State map of the frame being built: state -> (best cost so far, token).  This is the
+// reference's per-frame hash (FindOrAddToken, :259-295).  First level: open addressing in LDS,
+// state tags claimed with atomicCAS, costs lowered with atomicMin on the order-preserving key,
+// cleared once per frame.  A state whose HPROBE probe slots are all taken by other states goes to
+// the second level, ent[] in HBM (epoch-stamped keys, never cleared); slots are never freed within
+// a frame, so a state always resolves to the same level.  Keeping the first level on chip removes
+// what used to be most of the kernel's HBM traffic: every state touched cost a 128-byte line
+// fetched and written back for 12 useful bytes.
+__device__ __forceinline__ unsigned map_hash(int st) { return ((unsigned)st * 2654435761u) >> (32 - HBITS); }
+__device__ __forceinline__ int map_find(const Shared &sh, int st) {     // slot, or -1: second level
+  if (!sh.use_lds_map) return -1;
+  unsigned h = map_hash(st);
+#pragma unroll 1
+  for (int p = 0; p < HPROBE; p++, h = (h + 1) & (HCAP - 1)) {
+    const unsigned cur = sh.hs[h];
+    if (cur == (unsigned)st) return (int)h;
+    if (cur == HEMPTY) return -1;
+  }
+  return -1;
+}
+// lower the cost of state ds to tot.  slot: first-level slot or -1; create: this thread is the
+// first to reach ds in this frame (it makes the token); improved: the cost went down.
+__device__ __forceinline__ void map_relax(Shared &sh, gp<Ent> ent, int ds, float tot, unsigned ep, int &slot, bool &create,
+                                          bool &improved) {
+  const unsigned ck = f2o(tot);
+  slot = -1; create = false;
+  if (sh.use_lds_map) {
+    unsigned h = map_hash(ds);
+#pragma unroll 1
+    for (int p = 0; p < HPROBE; p++, h = (h + 1) & (HCAP - 1)) {
+      unsigned cur = sh.hs[h];
+      if (cur == HEMPTY) {
+        cur = atomicCAS(&sh.hs[h], HEMPTY, (unsigned)ds);
+        if (cur == HEMPTY) { create = true; slot = (int)h; break; }
+      }
+      if (cur == (unsigned)ds) { slot = (int)h; break; }
+    }
+  }
+  if (slot >= 0) {
+    const unsigned oc = atomicMin(&sh.hc[slot], ck);
+    improved = ck < oc;
+  } else {
+    const unsigned long long nk = ((unsigned long long)ep << 32) | ck;
+    const unsigned long long old = rmw_min_u64(&ent[ds].key, nk);
+    create = (unsigned)(old >> 32) != ep;
+    improved = create || nk < old;
+  }
+}
+__device__ __forceinline__ float map_cost(const Shared &sh, gp<const Ent> ent, int slot, int st) {
+  return slot >= 0 ? o2f(sh.hc[slot]) : o2f((unsigned)ld_u64(&ent[st].key));
+}
+__device__ __forceinline__ void map_set_tok(Shared &sh, gp<Ent> ent, int slot, int st, int nid, int nb) {
+  if (slot >= 0) sh.ht[slot] = nid; else st_i32(&ent[st].tokid, nid);
+}
+__device__ __forceinline__ int map_tok(const Shared &sh, gp<const Ent> ent, int slot, int st, int nb) {
+  return slot >= 0 ? sh.ht[slot] : ld_i32(&ent[st].tokid);
+}
+__device__ __forceinline__ void map_clear(Shared &sh) {
+  for (int i = threadIdx.x; i < HCAP; i += NT) { sh.hs[i] = HEMPTY; sh.hc[i] = 0xFFFFFFFFu; }
+}
+
+// ---------------------------------------------------------------------------------------
 // ProcessNonemitting (lattice-faster-decoder.cc:796-858) for the tokens of frame fpo, which
 // occupy window indices [nb, sh.w_ntok).  Work lists hold STATE ids: list `cur` (count
 // sh.fcnt[cur]) was filled by the caller with the new states that have input-epsilon arcs.
@@ -810,7 +880,6 @@ __device__ bool compact_window(const Slot &s, int prev_front, int front, Shared 
 __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, float cutoff, unsigned ep,
                                    int cur, Shared &sh) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned long long EPK = (unsigned long long)ep << 32;
   gp<Ent> ent = uptr(s.ent);
   gp<i32x4> wt = uptr(s.w_tok);
   const int w_tok_cap = s.w_tok_cap, front_cap = s.front_cap;
@@ -828,33 +897,31 @@ __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, flo
       const int i = base + lane;
       const bool have = lane < CH && i < ncur;
       const int st = have ? fcur[i] : 0;
-      const unsigned long long k = ld_u64(&ent[st].key);
       const i32x4 sr = g.st[st];
-      const float c = o2f((unsigned)k);
+      const float c = have ? map_cost(sh, ent, map_find(sh, st), st) : 0.0f;
       const bool exp = have && !(c > cutoff);
       const int a0 = sr.x, cnt = exp ? sr.y : 0;
       wave_expand(cnt, [&](bool valid, int owner, int j) {
         const int a = __shfl(a0, owner, 64) + j;
         const float cc = __shfl(c, owner, 64);
         bool create = false, push = false;
-        int dsraw = 0, ds = 0;
+        int dsraw = 0, ds = 0, slot = -1;
         if (valid) {
           const i32x4 arc = g.arcs[a];
           const float tot = cc + asf(arc.y);
           if (tot < cutoff) {
             dsraw = arc.x; ds = dsraw & STMASK;
-            const unsigned long long nk = EPK | f2o(tot);
-            const unsigned long long old = rmw_min_u64(&ent[ds].key, nk);
-            create = (unsigned)(old >> 32) != ep;          // first touch of this state in this frame
-            push = (create || nk < old) && dsraw < 0;      // new or improved, and it has epsilon arcs: (re-)expand
+            bool improved;
+            map_relax(sh, ent, ds, tot, ep, slot, create, improved);
+            push = (create || improved) && dsraw < 0;      // new or improved, and it has epsilon arcs: (re-)expand
           }
         }
         const int nid = wave_alloc(&sh.w_ntok, create);
         if (create) {
           if (nid < w_tok_cap) {
-            i32x4 r; r.x = dsraw; r.y = 0; r.z = 0; r.w = (int)INF_BITS;
+            i32x4 r; r.x = dsraw & ~PLDST; r.y = 0; r.z = slot; r.w = (int)INF_BITS;
             wt[nid] = r;
-            st_i32(&ent[ds].tokid, nid);
+            map_set_tok(sh, ent, slot, ds, nid, nb);
           } else sh.error = ERR_W_TOK;
         }
         const int q = wave_alloc(fcnt_next, push);
@@ -866,7 +933,8 @@ __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, flo
     cur = nxt;
   }
   __syncthreads();
-  // final costs of the frame's tokens + epsilon links regenerated from them (:824-845)
+  // final costs of the frame's tokens + epsilon links regenerated from them (:824-845); until now
+  // a token's extra_cost field held its slot in the state map
   const int ne = sh.w_ntok < w_tok_cap ? sh.w_ntok : w_tok_cap;
   const int lb = sh.w_nlink;
   __syncthreads();
@@ -878,10 +946,12 @@ __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, flo
     for (int base = wave * CH; base < n_new; base += NW * CH) {
       const int t = nb + base + lane;
       const bool have = lane < CH && base + lane < n_new;
-      const int sx = have ? wt[t].x : 0;
+      i32x4 rec; rec.x = 0; rec.y = 0; rec.z = -1; rec.w = 0;
+      if (have) rec = wt[t];
+      const int sx = rec.x;
       const int st = sx & STMASK;
-      const float c = o2f((unsigned)ld_u64(&ent[st].key));
-      if (have) ((gp<int>)&wt[t])[1] = asi(c);
+      const float c = have ? map_cost(sh, ent, rec.z, st) : 0.0f;
+      if (have) { gp<int> q = (gp<int>)&wt[t]; q[1] = asi(c); q[2] = 0; }
       const bool exp = have && sx < 0 && !(c > cutoff);
       int a0 = 0, cnt = 0;
       if (exp) { const i32x4 sr = g.st[st]; a0 = sr.x; cnt = sr.y; }
@@ -892,7 +962,11 @@ __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, flo
         if (valid) {
           arc = g.arcs[a];
           tot = cc + asf(arc.y);
-          if (tot < cutoff) { mk = true; dtok = ld_i32(&ent[arc.x & STMASK].tokid); }
+          if (tot < cutoff) {
+            mk = true;
+            const int ds = arc.x & STMASK;
+            dtok = map_tok(sh, ent, map_find(sh, ds), ds, nb);
+          }
         }
         const int l = wave_alloc(&sh.w_nlink, mk);
         if (mk) {
@@ -957,6 +1031,8 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       sh.tail_tok_b = 0; sh.tail_link_b = 0; sh.tail_f0 = -1; sh.tail_f1 = -2;
     }
     for (int i = tid; i < DIRTY_FRAMES / 32; i += NT) sh.dirty[i] = ~0u;   // no frame has been evaluated yet
+    map_clear(sh);
+    if (tid == 0) sh.use_lds_map = cfg.use_lds_map;
     pp = 0;
     __syncthreads();
 
@@ -967,10 +1043,11 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       const unsigned ep = (unsigned)(0xFFFFFFFFu - (unsigned)(epoch_base + 0));
       if (tid == 0) {
         const i32x4 sr = g.st[g.start];
-        i32x4 r; r.x = g.start | (sr.y > 0 ? EPSBIT : 0); r.y = 0; r.z = 0; r.w = (int)INF_BITS;
+        int slot; bool create, improved;
+        map_relax(sh, gptr(s.ent), g.start, 0.0f, ep, slot, create, improved);
+        map_set_tok(sh, gptr(s.ent), slot, g.start, 0, 0);
+        i32x4 r; r.x = g.start | (sr.y > 0 ? EPSBIT : 0); r.y = 0; r.z = slot; r.w = (int)INF_BITS;
         gptr(s.w_tok)[0] = r;
-        gptr(s.ent)[g.start].key = ((unsigned long long)ep << 32) | f2o(0.0f);
-        gptr(s.ent)[g.start].tokid = 0;
         sh.w_ntok = 1;
         if (sr.y > 0) { gptr(s.front[0])[0] = g.start; sh.fcnt[0] = 1; }
       }
@@ -1018,7 +1095,10 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       const unsigned ep = (unsigned)(0xFFFFFFFFu - (unsigned)(epoch_base + frame + 1));
       const unsigned long long EPK = (unsigned long long)ep << 32;
 
-      // ---- GetCutoff (:618-685); the costs go to LDS on the way
+      // ---- GetCutoff (:618-685); the costs go to LDS on the way.  The state map is emptied for the
+      //      frame about to be built (its last readers finished before the barrier that ended the
+      //      previous frame; its next writers come after this phase's reduction barriers)
+      map_clear(sh);
       unsigned long long bk = ~0ull;
       for (int i = tid; i < n; i += NT) {
         const i32x4 r = tok[i];
@@ -1127,7 +1207,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         gp<int> front0 = uptr(s.front[0]);
         const int w_tok_cap = s.w_tok_cap, front_cap = s.front_cap;
         for (int base = 0; base < ncand; base += NT * U) {
-          i32x4 CA[U]; i32x2 CB[U]; bool adm[U]; unsigned long long old[U];
+          i32x4 CA[U]; i32x2 CB[U]; bool adm[U];
 #pragma unroll
           for (int u = 0; u < U; u++) {
             const int q = base + u * NT + tid;
@@ -1137,24 +1217,21 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
           }
 #pragma unroll
           for (int u = 0; u < U; u++) {
-            old[u] = 0;
-            if (adm[u]) old[u] = rmw_min_u64(&ent[CB[u].x & STMASK].key, EPK | f2o(asf(CA[u].x)));
-          }
-#pragma unroll
-          for (int u = 0; u < U; u++) {
-            const bool create = adm[u] && (unsigned)(old[u] >> 32) != ep;
+            int slot = -1; bool create = false, improved;
+            const int ds = CB[u].x & STMASK;
+            if (adm[u]) map_relax(sh, ent, ds, asf(CA[u].x), ep, slot, create, improved);
             const int nid = wave_alloc(&sh.w_ntok, create);
             bool pushf = false;
             if (create) {
               if (nid < w_tok_cap) {
-                i32x4 r; r.x = CB[u].x; r.y = 0; r.z = 0; r.w = (int)INF_BITS;
+                i32x4 r; r.x = CB[u].x; r.y = 0; r.z = slot; r.w = (int)INF_BITS;
                 wt[nid] = r;
-                st_i32(&ent[CB[u].x & STMASK].tokid, nid);
+                map_set_tok(sh, ent, slot, ds, nid, nb);
                 pushf = CB[u].x < 0;
               } else sh.error = ERR_W_TOK;
             }
             const int f = wave_alloc(&sh.fcnt[0], pushf);
-            if (pushf) { if (f < front_cap) front0[f] = CB[u].x & STMASK; else sh.error = ERR_FRONT; }
+            if (pushf) { if (f < front_cap) front0[f] = ds; else sh.error = ERR_FRONT; }
           }
         }
       }
@@ -1175,7 +1252,10 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
             adm[u] = ok && !(asf(CA[u].x) > next_cutoff);
           }
 #pragma unroll
-          for (int u = 0; u < U; u++) dtok[u] = ld_i32(&ent[adm[u] ? (CB[u].x & STMASK) : 0].tokid);
+          for (int u = 0; u < U; u++) {
+            const int ds = CB[u].x & STMASK;
+            dtok[u] = adm[u] ? map_tok(sh, ent, map_find(sh, ds), ds, nb) : 0;
+          }
 #pragma unroll
           for (int u = 0; u < U; u++) {
             const int l = wave_alloc(&sh.w_nlink, adm[u]);
@@ -1811,7 +1891,7 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
   if (!d_pool.p && d_pool.alloc(1)) return -1;
   VBH_HIP(hipMemcpyAsync(d_pool.p, &pool, sizeof(Pool), hipMemcpyHostToDevice, st));
   DevGraph dg{g->S, g->start, g->st.p, g->arcs.p, g->arc_il.p};
-  DecCfg dc{d->cfg.beam, d->cfg.lattice_beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active, effective_prune_interval(&d->cfg)};
+  DecCfg dc{d->cfg.beam, d->cfg.lattice_beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active, effective_prune_interval(&d->cfg), getenv("VBH_NO_LDS_MAP") ? 0 : 1};
   d->h_res.resize(n_utt);
   {
     const int grid = std::min(d->small_set.n, n_utt);
