@@ -110,3 +110,33 @@ def test_decode_batch_vs_oracle(ctx, S, P, T, seed, cfg):
         ref = vbo.decode_lattice_faster(fst, ll[:n] if n else np.zeros((0, P), np.float32), t2p, exact_cutoff=True, **cfg)
         assert_same_lattice(dec.result(u), ref)
     dec.close(); graph.close()
+
+
+@pytest.mark.parametrize("every", [3, 7, 25])
+@pytest.mark.parametrize("lds_map", [True, False])
+def test_decode_independent_of_pruning_schedule(ctx, monkeypatch, every, lds_map):
+    """the kernel prunes on its own schedule (at least 100 frames apart by default); the lattice must
+    not depend on it, nor on which level of the state map (LDS / HBM) holds the states"""
+    import torch
+    from oracle import vbo
+    from voicebridge_amd import api
+    monkeypatch.setenv("VBH_PRUNE_EVERY", str(every))
+    if not lds_map:
+        monkeypatch.setenv("VBH_NO_LDS_MAP", "1")
+    cfg = dict(beam=11.0, max_active=3000, min_active=100, lattice_beam=5.0)
+    S, P, T, seed = 30000, 96, 140, 11
+    g, t2p, ll = make_case(S, P, T, seed, eps_frac=0.3, spread=30.0)
+    lens = [T, 61]
+    foff = np.zeros(3, np.int64)
+    foff[1:] = np.cumsum(lens)
+    batch = np.concatenate([ll[:n] for n in lens])
+    graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
+    dec = api.LatticeDecoder(ctx, graph, 2, max(lens), **cfg)
+    d = torch.from_numpy(np.ascontiguousarray(batch)).to(ctx.device)
+    ctx.torch_sync()
+    dec.decode(d, foff, t2p)
+    fst = vbo.make_fst(g["final"], g["arc_offset"], g["arcs"], 0)
+    for u, n in enumerate(lens):
+        ref = vbo.decode_lattice_faster(fst, ll[:n], t2p, exact_cutoff=True, **cfg)
+        assert_same_lattice(dec.result(u), ref)
+    dec.close(); graph.close()

@@ -1547,11 +1547,12 @@ static int slot_alloc(vbh_decoder *d, size_t bytes, void **p, int memset_val = -
 static const char *err_name(int e);
 
 // Frames between two intermediate prunings.  The final lattice does not depend on this schedule
-// (see the header), so the kernel is free to prune less often than cfg.prune_interval asks: every
-// visit of a frame costs the same handful of dependent passes however few links it holds, and
-// the number of re-visits per frame falls with the interval.  VBH_PRUNE_EVERY overrides (tuning).
+// (see the header), so the kernel prunes no more often than every 100 frames even when
+// cfg.prune_interval asks for less: every visit of a frame costs the same handful of dependent
+// passes however few links it holds, re-visits per frame fall with the interval, and HBM has room
+// for the longer raw window.  VBH_PRUNE_EVERY overrides (tuning, and tests of the pruning paths).
 static int effective_prune_interval(const vbh_decode_cfg *cfg) {
-  int v = cfg->prune_interval;
+  int v = std::max(cfg->prune_interval, 100);
   if (const char *e = getenv("VBH_PRUNE_EVERY")) { const int x = atoi(e); if (x > 0) v = x; }
   return std::min(v, MAX_WIN_FRAMES - 2);
 }
@@ -1678,7 +1679,6 @@ int vbh_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_decode_cf
             "vbh_decoder_create: invalid config (LatticeFasterDecoderConfig::Check)");
   VBH_CHECK(cfg->min_active >= 0, "vbh_decoder_create: min_active < 0");
   VBH_CHECK(max_batch >= 1 && max_frames >= 0, "vbh_decoder_create: bad batch/frames");
-  VBH_CHECK(cfg->prune_interval <= MAX_WIN_FRAMES - 2, "vbh_decoder_create: prune_interval %d > %d", cfg->prune_interval, MAX_WIN_FRAMES - 2);
   if (vbh_use_device(ctx)) return -1;
   vbh_decoder *d = new vbh_decoder();
   d->ctx = ctx; d->graph = graph; d->cfg = *cfg; d->max_frames = max_frames;
