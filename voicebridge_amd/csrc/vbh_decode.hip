@@ -86,6 +86,10 @@ constexpr int COST_CAP = 8 * NT;            // token costs of the current frame 
 #define VBH_UL 4
 #endif
 constexpr int U = VBH_U;                    // independent items per lane in the streaming passes
+#ifndef VBH_UC
+#define VBH_UC 2
+#endif
+constexpr int UC = VBH_UC;                  // ... in the candidate passes (LDS-bound: more only costs registers)
 constexpr int UL = VBH_UL;                  // ... in the pruning sweeps over links
 constexpr int HBITS = NT >= 1024 ? 13 : (NT >= 512 ? 12 : 11);
 constexpr int HCAP = 1 << HBITS;            // slots of the per-frame state map in LDS (8 per thread)
@@ -233,8 +237,34 @@ __device__ __forceinline__ int wave_alloc(int *counter, bool want) {
   const int leader = __ffsll((long long)m) - 1;
   int base = 0;
   if (lane == leader) base = atomicAdd(counter, __popcll(m));
-  base = __shfl(base, leader, 64);
+  base = __builtin_amdgcn_readlane(base, leader);
   return want ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+// the same for N requests per lane with ONE LDS atomic; all 64 lanes must call it together
+template <int N>
+__device__ __forceinline__ void wave_alloc_n(int *counter, const bool (&want)[N], int (&idx)[N]) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  unsigned long long m[N]; int off[N]; int total = 0;
+#pragma unroll
+  for (int u = 0; u < N; u++) { m[u] = __ballot(want[u]); off[u] = total; total += __popcll(m[u]); }
+  int base = 0;
+  if (total) {
+    if (lane == 0) base = atomicAdd(counter, total);
+    base = __builtin_amdgcn_readfirstlane(base);
+  }
+#pragma unroll
+  for (int u = 0; u < N; u++) idx[u] = want[u] ? base + off[u] + __popcll(m[u] & lt) : -1;
+}
+// inclusive prefix sum over the wave on the VALU (DPP row shifts + row broadcasts; no LDS traffic)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return v;
 }
 __device__ __forceinline__ long long clk() { return (long long)__builtin_amdgcn_s_memtime(); }
 
@@ -245,13 +275,8 @@ __device__ __forceinline__ long long clk() { return (long long)__builtin_amdgcn_
 template <class F>
 __device__ __forceinline__ void wave_expand(int cnt, F body) {
   const int lane = threadIdx.x & 63;
-  int incl = cnt;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += v;
-  }
-  const int total = __shfl(incl, 63, 64);
+  const int incl = wave_incl_scan(cnt);
+  const int total = __builtin_amdgcn_readlane(incl, 63);
   const int excl = incl - cnt;
   for (int k0 = 0; k0 < total; k0 += 64) {
     const int k = k0 + lane;
@@ -356,13 +381,8 @@ __device__ float select_kth(gp<const i32x4> tok, int n, int k, Shared &sh) {
     if (tid < 64) {     // wave 0: 4 bins per lane, prefix over lanes, then the bin inside the lane
       const int kk = sh.sel_k;
       const int h0 = (int)sh.hist[4 * tid], h1 = (int)sh.hist[4 * tid + 1], h2 = (int)sh.hist[4 * tid + 2], h3 = (int)sh.hist[4 * tid + 3];
-      int incl = h0 + h1 + h2 + h3;
-      const int mine = incl;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if (tid >= o) incl += v;
-      }
+      const int mine = h0 + h1 + h2 + h3;
+      const int incl = wave_incl_scan(mine);
       const unsigned long long m = __ballot(incl > kk);
       const int owner = m ? __ffsll((long long)m) - 1 : 63;   // k < n always, so some lane qualifies
       if (tid == owner) {
@@ -866,6 +886,19 @@ __device__ __forceinline__ void map_set_tok(Shared &sh, gp<Ent> ent, int slot, i
 __device__ __forceinline__ int map_tok(const Shared &sh, gp<const Ent> ent, int slot, int st, int nb) {
   return slot >= 0 ? sh.ht[slot] : ld_i32(&ent[st].tokid);
 }
+// Epsilon work lists (state ids).  The first FCAP entries of each of the three rotating lists
+// live in LDS -- in sh.cost, which is idle between pass 1 and the next frame's cutoff -- so a
+// closure iteration reads and refills its list without a round trip to HBM; longer lists
+// continue in the slot's HBM arrays.
+constexpr int FCAP = (COST_CAP / 3) & ~63;
+__device__ __forceinline__ void front_push(Shared &sh, gp<int> glob, int glob_cap, int k, int q, int st) {
+  if (q < FCAP) reinterpret_cast<int *>(sh.cost)[k * FCAP + q] = st;
+  else if (q - FCAP < glob_cap) glob[q - FCAP] = st;
+  else sh.error = ERR_FRONT;
+}
+__device__ __forceinline__ int front_get(const Shared &sh, gp<const int> glob, int k, int i) {
+  return i < FCAP ? reinterpret_cast<const int *>(sh.cost)[k * FCAP + i] : glob[i - FCAP];
+}
 __device__ __forceinline__ void map_clear(Shared &sh) {
   for (int i = threadIdx.x; i < HCAP; i += NT) { sh.hs[i] = HEMPTY; sh.hc[i] = 0xFFFFFFFFu; }
 }
@@ -884,7 +917,7 @@ __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, flo
   gp<i32x4> wt = uptr(s.w_tok);
   const int w_tok_cap = s.w_tok_cap, front_cap = s.front_cap;
   for (int iter = 0;; iter++) {
-    const int ncur = sh.fcnt[cur] < front_cap ? sh.fcnt[cur] : front_cap;
+    const int ncur = sh.fcnt[cur] < FCAP + front_cap ? sh.fcnt[cur] : FCAP + front_cap;
     if (ncur == 0) break;
     if (iter >= MAX_EPS_ITERS) { if (tid == 0) sh.error = ERR_EPS_LOOP; break; }
     const int nxt = cur == 2 ? 0 : cur + 1, spare = nxt == 2 ? 0 : nxt + 1;
@@ -896,7 +929,7 @@ __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, flo
     for (int base = wave * CH; base < ncur; base += NW * CH) {
       const int i = base + lane;
       const bool have = lane < CH && i < ncur;
-      const int st = have ? fcur[i] : 0;
+      const int st = have ? front_get(sh, fcur, cur, i) : 0;
       const i32x4 sr = g.st[st];
       const float c = have ? map_cost(sh, ent, map_find(sh, st), st) : 0.0f;
       const bool exp = have && !(c > cutoff);
@@ -925,7 +958,7 @@ __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, flo
           } else sh.error = ERR_W_TOK;
         }
         const int q = wave_alloc(fcnt_next, push);
-        if (push) { if (q < front_cap) fnext[q] = ds; else sh.error = ERR_FRONT; }
+        if (push) front_push(sh, fnext, front_cap, nxt, q, ds);
       });
     }
     __syncthreads();
@@ -1049,7 +1082,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         i32x4 r; r.x = g.start | (sr.y > 0 ? EPSBIT : 0); r.y = 0; r.z = slot; r.w = (int)INF_BITS;
         gptr(s.w_tok)[0] = r;
         sh.w_ntok = 1;
-        if (sr.y > 0) { gptr(s.front[0])[0] = g.start; sh.fcnt[0] = 1; }
+        if (sr.y > 0) { front_push(sh, gptr(s.front[0]), s.front_cap, 0, 0, g.start); sh.fcnt[0] = 1; }
       }
       __threadfence_block();
       __syncthreads();
@@ -1206,33 +1239,40 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         gp<i32x4> wt = uptr(s.w_tok);
         gp<int> front0 = uptr(s.front[0]);
         const int w_tok_cap = s.w_tok_cap, front_cap = s.front_cap;
-        for (int base = 0; base < ncand; base += NT * U) {
-          i32x4 CA[U]; i32x2 CB[U]; bool adm[U];
+        for (int base = 0; base < ncand; base += NT * UC) {
+          i32x4 CA[UC]; i32x2 CB[UC]; bool adm[UC];
 #pragma unroll
-          for (int u = 0; u < U; u++) {
+          for (int u = 0; u < UC; u++) {
             const int q = base + u * NT + tid;
             const bool ok = q < ncand;
             CA[u] = cand[ok ? q : 0]; CB[u] = cand2[ok ? q : 0];
             adm[u] = ok && !(asf(CA[u].x) > next_cutoff);
           }
+          int slot[UC]; bool create[UC]; int nid[UC];
 #pragma unroll
-          for (int u = 0; u < U; u++) {
-            int slot = -1; bool create = false, improved;
-            const int ds = CB[u].x & STMASK;
-            if (adm[u]) map_relax(sh, ent, ds, asf(CA[u].x), ep, slot, create, improved);
-            const int nid = wave_alloc(&sh.w_ntok, create);
-            bool pushf = false;
-            if (create) {
-              if (nid < w_tok_cap) {
-                i32x4 r; r.x = CB[u].x; r.y = 0; r.z = slot; r.w = (int)INF_BITS;
-                wt[nid] = r;
-                map_set_tok(sh, ent, slot, ds, nid, nb);
-                pushf = CB[u].x < 0;
+          for (int u = 0; u < UC; u++) {
+            bool improved;
+            slot[u] = -1; create[u] = false;
+            if (adm[u]) map_relax(sh, ent, CB[u].x & STMASK, asf(CA[u].x), ep, slot[u], create[u], improved);
+          }
+          wave_alloc_n<UC>(&sh.w_ntok, create, nid);
+          bool pushf[UC]; int fq[UC];
+#pragma unroll
+          for (int u = 0; u < UC; u++) {
+            pushf[u] = false;
+            if (create[u]) {
+              const int ds = CB[u].x & STMASK;
+              if (nid[u] < w_tok_cap) {
+                i32x4 r; r.x = CB[u].x; r.y = 0; r.z = slot[u]; r.w = (int)INF_BITS;
+                wt[nid[u]] = r;
+                map_set_tok(sh, ent, slot[u], ds, nid[u], nb);
+                pushf[u] = CB[u].x < 0;
               } else sh.error = ERR_W_TOK;
             }
-            const int f = wave_alloc(&sh.fcnt[0], pushf);
-            if (pushf) { if (f < front_cap) front0[f] = ds; else sh.error = ERR_FRONT; }
           }
+          wave_alloc_n<UC>(&sh.fcnt[0], pushf, fq);
+#pragma unroll
+          for (int u = 0; u < UC; u++) if (pushf[u]) front_push(sh, front0, front_cap, 0, fq[u], CB[u].x & STMASK);
         }
       }
       __syncthreads();
@@ -1242,23 +1282,25 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         gp<const Ent> ent = uptr(s.ent);
         gp<i32x4> wl = uptr(s.wl); gp<i32x2> wl2 = uptr(s.wl2);
         const int w_link_cap = s.w_link_cap;
-        for (int base = 0; base < ncand; base += NT * U) {
-          i32x4 CA[U]; i32x2 CB[U]; bool adm[U]; int dtok[U];
+        for (int base = 0; base < ncand; base += NT * UC) {
+          i32x4 CA[UC]; i32x2 CB[UC]; bool adm[UC]; int dtok[UC];
 #pragma unroll
-          for (int u = 0; u < U; u++) {
+          for (int u = 0; u < UC; u++) {
             const int q = base + u * NT + tid;
             const bool ok = q < ncand;
             CA[u] = cand[ok ? q : 0]; CB[u] = cand2[ok ? q : 0];
             adm[u] = ok && !(asf(CA[u].x) > next_cutoff);
           }
 #pragma unroll
-          for (int u = 0; u < U; u++) {
+          for (int u = 0; u < UC; u++) {
             const int ds = CB[u].x & STMASK;
             dtok[u] = adm[u] ? map_tok(sh, ent, map_find(sh, ds), ds, nb) : 0;
           }
+          int lq[UC];
+          wave_alloc_n<UC>(&sh.w_nlink, adm, lq);
 #pragma unroll
-          for (int u = 0; u < U; u++) {
-            const int l = wave_alloc(&sh.w_nlink, adm[u]);
+          for (int u = 0; u < UC; u++) {
+            const int l = lq[u];
             if (adm[u]) {
               if (l < w_link_cap) {
                 i32x4 r; r.x = (tb + CA[u].w) | enc; r.y = dtok[u] | WBIT; r.z = CA[u].x; r.w = CA[u].z;
@@ -1836,6 +1878,14 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
   d->t_kernel_ms = d->t_copy_ms = d->t_host_ms = d->t_total_ms = 0;
   if (n_utt == 0) return 0;
   const auto t_begin = std::chrono::steady_clock::now();
+  const bool dbg_t = getenv("VBH_DEBUG_TIMES") != nullptr;
+  auto t_lap = t_begin;
+  auto lap = [&](const char *what) {
+    if (!dbg_t) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[vbh] %-28s %8.2f ms\n", what, std::chrono::duration<float, std::milli>(now - t_lap).count());
+    t_lap = now;
+  };
   hipEvent_t ev0, ev1;
   VBH_HIP(hipEventCreate(&ev0)); VBH_HIP(hipEventCreate(&ev1));
   struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } ev_guard{ev0, ev1};
@@ -1862,6 +1912,7 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
   t2p[0] = 0;
   if (d_utts.upload(utts.data(), utts.size(), st) || d_t2p.upload(t2p.data(), t2p.size(), st) || d_counter.alloc(1) || d_res.alloc(n_utt)) return -1;
   VBH_HIP(hipMemsetAsync(d_counter.p, 0, sizeof(int), st));
+  lap("checks + small uploads");
   // output pool: the pruned lattice is a small multiple of the frame count
   Pool pool{};
   const long long tok_cap = std::max<long long>(4096, 64 * (total_frames + n_utt)), link_cap = std::max<long long>(8192, 128 * (total_frames + n_utt));
@@ -1893,6 +1944,7 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
   DevGraph dg{g->S, g->start, g->st.p, g->arcs.p, g->arc_il.p};
   DecCfg dc{d->cfg.beam, d->cfg.lattice_beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active, effective_prune_interval(&d->cfg), getenv("VBH_NO_LDS_MAP") ? 0 : 1};
   d->h_res.resize(n_utt);
+  lap("pool setup");
   {
     const int grid = std::min(d->small_set.n, n_utt);
     VBH_HIP(hipEventRecord(ev0, st));
@@ -1904,6 +1956,7 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
     VBH_HIP(hipStreamSynchronize(st));
     float ms = 0; VBH_HIP(hipEventElapsedTime(&ms, ev0, ev1)); d->t_kernel_ms += ms;
   }
+  lap("search kernel + results D2H");
   // utterances that outgrew a small slot are searched again in a big one
   std::vector<int> retry;
   for (int u = 0; u < n_utt; u++) {
@@ -1941,6 +1994,7 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
   for (int u = 0; u < n_utt; u++)
     VBH_CHECK(d->h_res[u].error == ERR_NONE, "vbh_decode_batch: utterance %d failed: %s", u, err_name(d->h_res[u].error));
   // bring the used part of the pool to the host
+  lap("retries + checks");
   const auto t_copy0 = std::chrono::steady_clock::now();
   const long long nt = std::min<long long>((long long)used[0], tok_cap), nl = std::min<long long>((long long)used[1], link_cap);
   // pinned staging: [5 token arrays of nt][6 link arrays of nl], 4 bytes per entry
@@ -1965,6 +2019,7 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
   Pool hp{};
   hp.tok_frame = tf; hp.tok_state = ts; hp.tok_cost = tc; hp.tok_extra = te; hp.tok_final = tfin;
   hp.link_src = ls; hp.link_dst = ld; hp.link_il = li; hp.link_ol = lo; hp.link_gr = lg; hp.link_ac = la;
+  lap("pool D2H");
   const auto t_host0 = std::chrono::steady_clock::now();
   d->results.resize(n_utt);
   {
@@ -1983,6 +2038,7 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
       for (auto &t : pool_threads) t.join();
     }
   }
+  lap("host lattice finishing");
   const auto t_end = std::chrono::steady_clock::now();
   d->t_copy_ms = std::chrono::duration<float, std::milli>(t_host0 - t_copy0).count();
   d->t_host_ms = std::chrono::duration<float, std::milli>(t_end - t_host0).count();
