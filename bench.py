@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="utterances per step per GPU")
     ap.add_argument("--seconds", type=float, default=30.0, help="utterance length")
     ap.add_argument("--pdfs", type=int, default=2500)
@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--max-active", type=int, default=7000)
     ap.add_argument("--mean-scale", type=float, default=1.5, help="spread of the synthetic GMM means (search difficulty)")
     ap.add_argument("--var-spread", type=float, default=0.2, help="sigma of the log-variances of the synthetic GMM")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="batches in flight: 2 = two contexts/streams, the search grid of one batch drains while the "
+                         "next batch's kernels fill the freed CUs; 1 = one batch at a time")
     ap.add_argument("--probe", action="store_true", help="print search statistics of the first utterances and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-seconds", type=float, default=30.0, help="audio seconds timed on the CPU baseline")
@@ -162,6 +165,26 @@ def main():
         dec.decode(ll, foff, t2p)
         dt = time.perf_counter() - t0
         print("decode of %d utterances: %.3f s  %s" % (args.batch, dt, " ".join("%s=%.1f" % kv for kv in dec.times().items())))
+        tl = np.array([dec.timeline(u) for u in range(args.batch)], np.int64)
+        t0_, t1_ = tl[:, 0].min(), tl[:, 1].max()
+        dur = (tl[:, 1] - tl[:, 0]) / 1e5      # ms
+        n_wg = len(set(tl[:, 2].tolist()))
+        print("search grid: %d workgroups, span %.1f ms, busy %.1f%% of workgroup-time; per-utterance ms: min %.1f mean %.1f max %.1f; "
+              "last start at %.1f ms" % (n_wg, (t1_ - t0_) / 1e5, 100.0 * dur.sum() / (n_wg * (t1_ - t0_) / 1e5), dur.min(), dur.mean(),
+                                         dur.max(), (tl[:, 0].max() - t0_) / 1e5))
+        if os.environ.get("VBH_PROBE_PROXY"):
+            # does a cheap statistic of the scores predict an utterance's search time?
+            fo = torch.as_tensor(np.asarray(foff, np.int64), device=dev)
+            mx = ll.max(dim=1, keepdim=True).values
+            for theta in (30.0, 60.0, 100.0, 156.0, 300.0):
+                cnt = torch.zeros(T, device=dev)
+                for a in range(0, T, 1 << 18):
+                    cnt[a:a + (1 << 18)] = (ll[a:a + (1 << 18)] > mx[a:a + (1 << 18)] - theta).sum(1).float()
+                cs = torch.cat([torch.zeros(1, device=dev, dtype=torch.float64), cnt.double().cumsum(0)])
+                prox = ((cs[fo[1:]] - cs[fo[:-1]]) / (fo[1:] - fo[:-1]).clamp(min=1)).cpu().numpy()
+                rk = lambda x: np.argsort(np.argsort(x))
+                rho = np.corrcoef(rk(prox), rk(dur))[0, 1]
+                print("proxy theta=%g: spearman rho with per-utterance time = %.3f (pearson %.3f)" % (theta, rho, np.corrcoef(prox, dur)[0, 1]))
         for u in range(min(args.batch, 4)):
             r = dec.result(u, arrays=False)
             nf = max(r["num_frames"], 1)
@@ -176,46 +199,118 @@ def main():
                 ["cutoff", "pass1", "admit+links", "eps", "prune", "compact", "output"], ph[:7])) + "  cycles/frame=%.0f prune-visited-frames=%d" % (tot / nf, ph[7]))
         return
 
-    def step(timed):
+    # ---- pipeline (depth > 1).  Front end (MFCC, post, GMM) on its own context/stream, two
+    #      batches ahead of the search: ring of depth+1 score buffers.  Searches alternate between
+    #      `depth` decoder contexts/streams, so that while the persistent grid of batch k drains (its
+    #      last, heaviest utterances) the workgroups of batch k+1 fill the freed CUs, and the front end
+    #      of batch k+2 takes its share of them too.  depth 1 = one batch at a time on one stream.
+    class Lane:
+        pass
+    depth = max(1, args.pipeline) if dec is not None else 1
+    n_ring = depth + 1 if depth > 1 else 1
+    ring = [(raw, feats, ll)] + [(torch.empty_like(raw), torch.empty_like(feats), torch.empty_like(ll)) for _ in range(n_ring - 1)]
+    lanes = []
+    for k in range(depth):
+        L = Lane()
+        if depth == 1:
+            L.ctx, L.dec = ctx, dec
+        else:
+            L.ctx = api.Context(local_rank)
+            L.dec = dec if False else api.LatticeDecoder(L.ctx, graph, args.batch, Tmax, beam=args.beam, max_active=args.max_active,
+                                                         min_active=200, lattice_beam=args.lattice_beam, acoustic_scale=0.083333)
+        L.pending = False
+        L.timed = False
+        lanes.append(L)
+    if depth > 1 and dec is not None:
+        dec.close()          # the probe/setup decoder on the front-end context is not used by the pipeline
+        dec = lanes[0].dec
+    ctx.torch_sync()
+    gmm_ms, feat_ms, dec_ms, dec_k_ms, dec_h_ms = [], [], [], [], []
+    last_done = [lanes[0]]
+    fe_timed = []            # front-end timer slots in flight: (slot_feat, slot_gmm)
+
+    def front_end(j, timed):
+        """MFCC -> post -> GMM of batch j into ring[j % n_ring], on the front-end stream"""
+        r_, f_, l_ = ring[j % n_ring]
+        sl = 1 + 2 * (j % 4)                 # timer slots rotate: several batches may be in flight
         if timed:
-            ctx.timer_start(1)
-        mf.compute_packed(d_wave, woff, is_i16, out=raw)
-        post.apply(raw, foff, utt2spk=utt2spk, cmvn_stats=stats, spk_xforms=xforms, out=feats)
+            ctx.timer_start(sl)
+        mf.compute_packed(d_wave, woff, is_i16, out=r_)
+        post.apply(r_, foff, utt2spk=utt2spk, cmvn_stats=stats, spk_xforms=xforms, out=f_)
         if timed:
-            ctx.timer_stop(1)
-            ctx.timer_start(2)
-        gmm.loglikes(feats, out=ll)
+            ctx.timer_stop(sl)
+            ctx.timer_start(sl + 1)
+        gmm.loglikes(f_, out=l_)
         if timed:
-            ctx.timer_stop(2)
-        if dec is not None:
-            if timed:
-                ctx.timer_start(3)
-            dec.decode(ll, foff, t2p)      # synchronises: lattices are on the host when it returns
-            if timed:
-                ctx.timer_stop(3)
+            ctx.timer_stop(sl + 1)
+            fe_timed.append(sl)
+
+    def finish(L):
+        """complete the lane's search in flight: lattices on the host, times collected"""
+        if L.pending:
+            L.dec.decode_end()
+            L.pending = False
+            last_done[0] = L
+            if L.timed:
+                tm = L.dec.times()      # HIP events around the search kernel on its stream + host clocks
+                dec_ms.append(tm["total_ms"]); dec_k_ms.append(tm["kernel_ms"])
+                dec_h_ms.append(tm["copy_ms"] + tm["host_ms"])
+                L.timed = False
+
+    def run_steps(n, timed):
+        """n complete steps: n front ends and n searches, the pipeline empty before and after"""
+        if n <= 0:
+            return
+        if depth == 1:
+            L = lanes[0]
+            for j in range(n):
+                front_end(j, timed)
+                if L.dec is not None:
+                    L.timed = timed
+                    L.dec.decode_begin(ring[0][2], foff, t2p)
+                    L.pending = True
+                    finish(L)
+            return
+        front_end(0, timed)
+        lanes[0].ctx.wait_for(ctx)
+        for j in range(n):
+            L = lanes[j % depth]
+            finish(L)                                    # search j - depth
+            if j + 1 < n:
+                front_end(j + 1, timed)                  # one batch ahead of the search enqueued next
+                lanes[(j + 1) % depth].ctx.wait_for(ctx)
+            L.timed = timed
+            L.dec.decode_begin(ring[j % n_ring][2], foff, t2p)
+            L.pending = True
+        for L in lanes:
+            finish(L)
 
     def barrier():
+        for L in lanes:
+            finish(L)
+            L.ctx.sync()
         ctx.sync()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step(False)
+    run_steps(args.warmup, False)
     barrier()
-    gmm_ms, feat_ms, dec_ms, dec_k_ms, dec_h_ms = [], [], [], [], []
     counters = dict(tok=0, arc=0, new=0, link=0)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-        gmm_ms.append(ctx.timer_ms(2))      # waits for this step's GMM launch (device time)
-        feat_ms.append(ctx.timer_ms(1))
-        if dec is not None:
-            dec_ms.append(ctx.timer_ms(3))
-            tm = dec.times()        # HIP events around the search kernel on its stream + host clocks
-            dec_k_ms.append(tm["kernel_ms"]); dec_h_ms.append(tm["total_ms"] - tm["kernel_ms"])
+    run_steps(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
+    for sl in fe_timed:
+        feat_ms.append(ctx.timer_ms(sl)); gmm_ms.append(ctx.timer_ms(sl + 1))
+    if dec is not None:
+        dec = last_done[0].dec
+        tl = np.array([dec.timeline(u) for u in range(args.batch)], np.int64)
+        span = float(tl[:, 1].max() - tl[:, 0].min())
+        grid_stats = {"workgroups": len(set(tl[:, 2].tolist())), "span_ms": span / 1e5,
+                      "busy_fraction_of_span": float((tl[:, 1] - tl[:, 0]).sum()) / (len(set(tl[:, 2].tolist())) * span),
+                      "utterance_ms_min_mean_max": [float((tl[:, 1] - tl[:, 0]).min()) / 1e5, float((tl[:, 1] - tl[:, 0]).mean()) / 1e5,
+                                                    float((tl[:, 1] - tl[:, 0]).max()) / 1e5]}
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -251,9 +346,14 @@ def main():
         if dec is not None:
             d_ms = float(np.mean(dec_ms))
             k_ms = float(np.mean(dec_k_ms))
-            stage_ms["decode (kernel + lattice D2H + host best path)"] = d_ms
+            stage_ms["decode (begin to end on the host)"] = d_ms
             stage_ms["decode: search kernel only"] = k_ms
-            stage_ms["decode: uploads, lattice D2H, host ordering + best path"] = float(np.mean(dec_h_ms))
+            stage_ms["decode: lattice D2H, host ordering + best path"] = float(np.mean(dec_h_ms))
+            if depth > 1:
+                stage_ms["note"] = ("%d batches in flight on %d streams: stage times of consecutive batches overlap and are not "
+                                    "additive; a search kernel's duration includes the time its workgroups wait for CUs still held "
+                                    "by the previous batch's grid" % (depth, depth))
+            extra["search_grid_last_batch"] = grid_stats
             # algorithmic bytes of the search from the counters of the last step:
             # N_tok*(20+16) + N_arc*(16+4) + N_new*16 + N_link*24
             c = dict(tok=0, arc=0, new=0, link=0, maxb=0, minb=0, lat_tok=0, lat_link=0)
@@ -290,6 +390,7 @@ def main():
                                     % (args.beam, args.lattice_beam, args.max_active, graph.num_states, graph.num_arcs)),
                        "utterances_per_step_per_gpu": args.batch, "utterance_seconds": args.seconds,
                        "frames_per_step_per_gpu": T, "pdfs": gmm.num_pdfs, "gaussians": gmm.num_gauss, "dim": 39,
+                       "batches_in_flight": depth,
                        "sharding": "utterances over ranks, no data-path collective"},
             "roofline": roof, "stage_ms": stage_ms,
         }

@@ -37,6 +37,9 @@ int vbh_device_count(void);                       /* 0 when no HIP device is vis
 int vbh_ctx_create(int device_id, vbh_ctx **out); /* fails (-1) when there is no such GPU */
 void vbh_ctx_destroy(vbh_ctx *ctx);
 int vbh_ctx_sync(vbh_ctx *ctx);
+/* work enqueued on ctx after this call starts only when everything enqueued on other so far
+ * has completed (stages of a pipeline on different contexts of one device); does not block */
+int vbh_ctx_wait_for(vbh_ctx *ctx, vbh_ctx *other);
 void *vbh_ctx_stream(vbh_ctx *ctx);               /* hipStream_t all work is enqueued on */
 int vbh_ctx_device(vbh_ctx *ctx);
 int vbh_dev_alloc(vbh_ctx *ctx, size_t bytes, void **d_ptr);
@@ -198,10 +201,21 @@ void vbh_decoder_destroy(vbh_decoder *d);
 int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs,
                      const int64_t *h_frame_offsets, int32_t n_utt, const int32_t *h_tid2pdf,
                      int32_t num_tids);
+/* The same in two halves, so that a caller can overlap batches on different contexts/streams
+ * (the persistent search grid of one batch drains while the next one's fills the freed CUs):
+ * _begin enqueues the uploads and the search and returns; _end waits, searches overflowed
+ * utterances again in big slots, and brings the lattices to the host.  Buffers passed to _begin
+ * (log-likelihoods) must stay valid until _end returns. */
+int vbh_decode_batch_begin(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, const int64_t *h_frame_offsets,
+                           int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids);
+int vbh_decode_batch_end(vbh_decoder *d);
 int vbh_decoder_result(vbh_decoder *d, int32_t utt, vbh_lattice *out);
 /* diagnostic: shader-clock cycles the utterance's workgroup spent per phase
  * {cutoff, pass1, admit+links, epsilon closure, pruning, compaction, output, other} */
 int vbh_decoder_phase_cycles(vbh_decoder *d, int32_t utt, int64_t *out8);
+/* diagnostic: {device wall clock (100 MHz ticks) when a workgroup took the utterance, when it
+ * finished it, workgroup id} -- load balance of the persistent search grid */
+int vbh_decoder_utt_timeline(vbh_decoder *d, int32_t utt, int64_t *out3);
 /* diagnostic: milliseconds of the last vbh_decode_batch {search kernel(s) on the device,
  * lattice pool device->host, host-side canonical ordering + best path, whole call} */
 int vbh_decoder_times(vbh_decoder *d, float *out4);

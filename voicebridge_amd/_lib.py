@@ -12,15 +12,15 @@ LIB_PATH = os.environ.get("VBH_LIB_PATH") or os.path.join(HERE, "lib", "libvoice
 # every symbol include/voicebridge_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "vbh_abi_version", "vbh_last_error", "vbh_device_count", "vbh_ctx_create", "vbh_ctx_destroy",
-    "vbh_ctx_sync", "vbh_ctx_stream", "vbh_ctx_device", "vbh_dev_alloc", "vbh_dev_free", "vbh_copy_h2d",
+    "vbh_ctx_sync", "vbh_ctx_wait_for", "vbh_ctx_stream", "vbh_ctx_device", "vbh_dev_alloc", "vbh_dev_free", "vbh_copy_h2d",
     "vbh_copy_d2h", "vbh_memset", "vbh_timer_start", "vbh_timer_stop", "vbh_timer_elapsed_ms",
     "vbh_mfcc_opts_default", "vbh_mfcc_num_frames", "vbh_mfcc_create", "vbh_mfcc_destroy", "vbh_mfcc_compute",
     "vbh_featpost_out_dim", "vbh_featpost", "vbh_cmvn_stats",
     "vbh_gmm_create", "vbh_gmm_destroy", "vbh_gmm_num_pdfs", "vbh_gmm_dim", "vbh_gmm_get_gconsts",
     "vbh_gmm_loglikes", "vbh_gmm_work",
     "vbh_graph_create", "vbh_graph_destroy", "vbh_decode_cfg_default", "vbh_decoder_create",
-    "vbh_decoder_destroy", "vbh_decode_batch", "vbh_decoder_result", "vbh_decoder_phase_cycles",
-    "vbh_decoder_times",
+    "vbh_decoder_destroy", "vbh_decode_batch", "vbh_decode_batch_begin", "vbh_decode_batch_end", "vbh_decoder_result", "vbh_decoder_phase_cycles",
+    "vbh_decoder_times", "vbh_decoder_utt_timeline",
 ]
 
 
@@ -113,6 +113,7 @@ def load():
     lib.vbh_copy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.vbh_memset.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]
     lib.vbh_ctx_sync.argtypes = [C.c_void_p]
+    lib.vbh_ctx_wait_for.argtypes = [C.c_void_p, C.c_void_p]
     lib.vbh_ctx_device.argtypes = [C.c_void_p]
     lib.vbh_ctx_stream.argtypes = [C.c_void_p]
     lib.vbh_timer_start.argtypes = [C.c_void_p, C.c_int]
@@ -125,9 +126,12 @@ def load():
                                            C.POINTER(C.c_void_p)]
         lib.vbh_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_int32,
                                          C.POINTER(C.c_int32), C.c_int32]
+        lib.vbh_decode_batch_begin.argtypes = lib.vbh_decode_batch.argtypes
+        lib.vbh_decode_batch_end.argtypes = [C.c_void_p]
         lib.vbh_decoder_result.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Lattice)]
         lib.vbh_decoder_phase_cycles.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
         lib.vbh_decoder_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        lib.vbh_decoder_utt_timeline.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
     _LIB = lib
     return lib
 

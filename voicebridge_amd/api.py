@@ -47,6 +47,10 @@ class Context:
     def sync(self):
         check(self.lib.vbh_ctx_sync(self.h), "vbh_ctx_sync")
 
+    def wait_for(self, other):
+        """work enqueued here from now on starts after everything enqueued on `other` so far"""
+        check(self.lib.vbh_ctx_wait_for(self.h, other.h), "vbh_ctx_wait_for")
+
     def torch_sync(self):
         """make work enqueued by torch (allocations, copies) visible to the ctx stream"""
         torch.cuda.synchronize(self.device)
@@ -105,13 +109,16 @@ class Mfcc:
     def compute_packed(self, d_wave, wave_offsets, is_int16, out=None):
         n = len(wave_offsets) - 1
         total = sum(self.num_frames(wave_offsets[u + 1] - wave_offsets[u]) for u in range(n))
-        if out is None:
+        fresh = out is None
+        if fresh:
             out = torch.empty((total, self.opts.num_ceps), dtype=torch.float32, device=self.ctx.device)
             self.ctx.torch_sync()
         foff = np.zeros(n + 1, np.int64)
         wo = np.ascontiguousarray(wave_offsets, np.int64)
         check(self.lib.vbh_mfcc_compute(self.h, d_wave.data_ptr(), int(is_int16), _i64p(wo), n, out.data_ptr(), _i64p(foff)),
               "vbh_mfcc_compute")
+        if fresh:
+            self.ctx.sync()
         return out, foff
 
     def compute(self, waves):
@@ -158,12 +165,15 @@ class FeaturePipeline:
         sx = np.ascontiguousarray(spk_xforms, np.float32) if spk_xforms is not None else None
         if sx is not None:
             n_spk = sx.shape[0]
-        if out is None:
+        fresh = out is None
+        if fresh:
             out = torch.empty((int(fo[-1]), self.out_dim), dtype=torch.float32, device=self.ctx.device)
             self.ctx.torch_sync()
         check(self.lib.vbh_featpost(self.ctx.h, C.byref(self.cfg), d_in.data_ptr(), _i64p(fo), n, _i32p(u2s), n_spk,
                                     st.ctypes.data_as(C.POINTER(C.c_double)) if st is not None else None,
                                     _f32p(self.lda), _f32p(sx), out.data_ptr()), "vbh_featpost")
+        if fresh:
+            self.ctx.sync()     # a tensor handed out is complete; with out= the call only enqueues (ctx.sync() when needed)
         return out
 
     def cmvn_stats(self, d_feats, frame_offsets, utt2spk, n_spk):
@@ -198,10 +208,13 @@ class DiagGmm:
 
     def loglikes(self, d_feats, out=None):
         T = d_feats.shape[0]
-        if out is None:
+        fresh = out is None
+        if fresh:
             out = torch.empty((T, self.num_pdfs), dtype=torch.float32, device=self.ctx.device)
             self.ctx.torch_sync()
         check(self.lib.vbh_gmm_loglikes(self.h, d_feats.data_ptr(), T, out.data_ptr()), "vbh_gmm_loglikes")
+        if fresh:
+            self.ctx.sync()
         return out
 
     def work(self, T):
@@ -263,6 +276,19 @@ class LatticeDecoder:
         check(self.lib.vbh_decode_batch(self.h, d_loglikes.data_ptr(), int(d_loglikes.shape[1]), _i64p(fo), self.n_utt,
                                         _i32p(t2p), len(t2p) - 1), "vbh_decode_batch")
 
+    def decode_begin(self, d_loglikes, frame_offsets, tid2pdf):
+        """enqueue the search and return; d_loglikes must stay alive until decode_end()"""
+        fo = np.ascontiguousarray(frame_offsets, np.int64)
+        t2p = np.ascontiguousarray(tid2pdf, np.int32)
+        self.n_utt = len(fo) - 1
+        self._pending = d_loglikes
+        check(self.lib.vbh_decode_batch_begin(self.h, d_loglikes.data_ptr(), int(d_loglikes.shape[1]), _i64p(fo), self.n_utt,
+                                              _i32p(t2p), len(t2p) - 1), "vbh_decode_batch_begin")
+
+    def decode_end(self):
+        check(self.lib.vbh_decode_batch_end(self.h), "vbh_decode_batch_end")
+        self._pending = None
+
     def result(self, u, arrays=True):
         r = _lib.Lattice()
         check(self.lib.vbh_decoder_result(self.h, int(u), C.byref(r)), "vbh_decoder_result")
@@ -288,6 +314,12 @@ class LatticeDecoder:
         out = (C.c_int64 * 8)()
         check(self.lib.vbh_decoder_phase_cycles(self.h, int(u), out), "vbh_decoder_phase_cycles")
         return list(out)
+
+    def timeline(self, u):
+        """(start, end) of the utterance's search in 100 MHz device ticks, and the workgroup that ran it"""
+        out = (C.c_int64 * 3)()
+        check(self.lib.vbh_decoder_utt_timeline(self.h, int(u), out), "vbh_decoder_utt_timeline")
+        return int(out[0]), int(out[1]), int(out[2])
 
     def times(self):
         """ms of the last decode(): search kernel, pool copy, host lattice finishing, whole call"""

@@ -10,6 +10,39 @@ void vbh_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+vbh_arena *vbh_arena_begin(vbh_ctx *ctx, size_t bytes) {
+  vbh_arena *a = &ctx->arena[ctx->arena_next];
+  ctx->arena_next = (ctx->arena_next + 1) % VBH_ARENAS;
+  auto fail = [](hipError_t e, const char *what) { vbh_set_error("%s failed: %s", what, hipGetErrorString(e)); return (vbh_arena *)nullptr; };
+  hipError_t e;
+  if (a->pending) {
+    if ((e = hipEventSynchronize(a->done)) != hipSuccess) return fail(e, "hipEventSynchronize(arena)");
+    a->pending = false;
+  }
+  if (!a->done && (e = hipEventCreateWithFlags(&a->done, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate(arena)");
+  if (bytes > a->cap) {
+    // growth only: the previous buffers may still be read by kernels in flight, so drain first
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize(arena)");
+    if (a->h) (void)hipHostFree(a->h);
+    if (a->d) (void)hipFree(a->d);
+    a->h = a->d = nullptr; a->cap = 0;
+    const size_t want = bytes + bytes / 2 + 4096;
+    if ((e = hipHostMalloc(reinterpret_cast<void **>(&a->h), want, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(arena)");
+    if ((e = hipMalloc(reinterpret_cast<void **>(&a->d), want)) != hipSuccess) return fail(e, "hipMalloc(arena)");
+    a->cap = want;
+  }
+  a->used = 0;
+  return a;
+}
+
+int vbh_arena_commit(vbh_ctx *ctx, vbh_arena *a) {
+  if (a->used) VBH_HIP(hipMemcpyAsync(a->d, a->h, a->used, hipMemcpyHostToDevice, ctx->stream));
+  VBH_HIP(hipEventRecord(a->done, ctx->stream));
+  a->pending = true;
+  return 0;
+}
+
+
 extern "C" {
 
 int vbh_abi_version(void) { return VBH_ABI_VERSION; }
@@ -45,6 +78,11 @@ void vbh_ctx_destroy(vbh_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  for (int i = 0; i < VBH_ARENAS; i++) {
+    if (c->arena[i].h) (void)hipHostFree(c->arena[i].h);
+    if (c->arena[i].d) (void)hipFree(c->arena[i].d);
+    if (c->arena[i].done) (void)hipEventDestroy(c->arena[i].done);
+  }
   for (int i = 0; i < VBH_MAX_TIMERS; i++) {
     (void)hipEventDestroy(c->ev_start[i]);
     (void)hipEventDestroy(c->ev_stop[i]);
@@ -56,6 +94,19 @@ void vbh_ctx_destroy(vbh_ctx *c) {
 int vbh_ctx_sync(vbh_ctx *c) {
   if (vbh_use_device(c)) return -1;
   VBH_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int vbh_ctx_wait_for(vbh_ctx *c, vbh_ctx *other) {
+  VBH_CHECK(c && other, "vbh_ctx_wait_for: NULL argument");
+  VBH_CHECK(c->device == other->device, "vbh_ctx_wait_for: contexts on different devices");
+  if (vbh_use_device(c)) return -1;
+  if (c == other) return 0;
+  hipEvent_t e;
+  VBH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  hipError_t r = hipEventRecord(e, other->stream);
+  if (r == hipSuccess) r = hipStreamWaitEvent(c->stream, e, 0);
+  (void)hipEventDestroy(e);      // released once the recorded work has completed
+  VBH_HIP(r);
   return 0;
 }
 void *vbh_ctx_stream(vbh_ctx *c) { return reinterpret_cast<void *>(c->stream); }

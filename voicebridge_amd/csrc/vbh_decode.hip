@@ -159,6 +159,8 @@ struct UttResult {   // written by the kernel, one per utterance
   int n_max_bound, n_min_bound;
   long long cost_off;                // offset of this utterance's cost_offsets in the pool
   long long t_phase[8];              // shader-clock cycles per phase (thread 0): cutoff, pass1, pass2+3, eps, prune, compact, final, other
+  long long t_start, t_end;          // s_memrealtime (100 MHz) when the workgroup took the utterance / finished it
+  int wg, pad2;
 };
 
 struct Pool {   // dense per-batch output
@@ -1053,6 +1055,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
     const int epoch_base = gptr(s.state)[0] + 1;
     long long c_tok_exp = 0, c_arc_exp = 0;        // per-thread counters, reduced at the end
     long long t_last = clk();
+    const long long rt_start = (long long)__builtin_amdgcn_s_memrealtime();
 #define PHASE(i) { if (tid == 0) { const long long now_ = clk(); sh.tph[i] += now_ - t_last; t_last = now_; } }
     if (tid == 0) {
       for (int i = 0; i < 8; i++) sh.tph[i] = 0;
@@ -1522,6 +1525,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         r->n_max_bound = sh.n_max_bound; r->n_min_bound = sh.n_min_bound;
         for (int i = 0; i < 7; i++) r->t_phase[i] = sh.tph[i];
         r->t_phase[7] = sh.n_visited;   // slot 7: frames visited by pruning (not a time)
+        r->t_start = rt_start; r->t_end = (long long)__builtin_amdgcn_s_memrealtime(); r->wg = blockIdx.x; r->pad2 = 0;
         gptr(s.state)[0] = epoch_base + T + 2;   // next utterance in this slot: disjoint epochs
       }
     }
@@ -1547,6 +1551,7 @@ struct vbh_graph {
   int S, start; long long A; int max_ilabel, max_degree;
   DevBuf<i32x4> st, arcs;      // device records (see DevGraph); arcs are stored epsilon-first within a state
   DevBuf<int> arc_il;
+  mutable std::vector<int> filled_t2p;   // tid2pdf table the arcs' pdf fields currently hold (empty: none)
   std::vector<float> h_final;
 };
 
@@ -1577,6 +1582,22 @@ struct vbh_decoder {
   long long pool_tok_cap = 0, pool_link_cap = 0, pool_cost_cap = 0;
   void *pin = nullptr; size_t pin_bytes = 0;
   float t_kernel_ms = 0, t_copy_ms = 0, t_host_ms = 0, t_total_ms = 0;   // last vbh_decode_batch
+  // a batch between vbh_decode_batch_begin and vbh_decode_batch_end
+  struct Pending {
+    bool active = false;
+    int n_utt = 0, num_pdfs = 0;
+    const float *d_loglikes = nullptr;
+    long long tok_cap = 0, link_cap = 0;
+    DevGraph dg{}; DecCfg dc{};
+    std::chrono::steady_clock::time_point t_begin;
+  } pend;
+  DevBuf<UttDesc> d_utts; DevBuf<int> d_t2p, d_counter; DevBuf<UttResult> d_res;
+  size_t utts_cap = 0, t2p_cap = 0;
+  std::vector<UttDesc> h_utts; std::vector<int> h_t2p; Pool h_pool{};
+  char *stage = nullptr; size_t stage_bytes = 0;   // pinned copy of the three above: source of the (truly) asynchronous uploads
+  DevBuf<int> d_order; size_t order_cap = 0; std::vector<int> h_order;     // longest-first work order (see lpt_order)
+  float t_probe_ms = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
 static int slot_alloc(vbh_decoder *d, size_t bytes, void **p, int memset_val = -2) {
@@ -1740,6 +1761,9 @@ void vbh_decoder_destroy(vbh_decoder *d) {
   (void)hipStreamSynchronize(d->ctx->stream);
   for (void *p : d->allocs) (void)hipFree(p);
   if (d->pin) (void)hipHostFree(d->pin);
+  if (d->stage) (void)hipHostFree(d->stage);
+  if (d->ev0) (void)hipEventDestroy(d->ev0);
+  if (d->ev1) (void)hipEventDestroy(d->ev1);
   delete d;
 }
 
@@ -1869,33 +1893,29 @@ static const char *err_name(int e) {
 
 extern "C" {
 
-int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, const int64_t *h_frame_offsets,
-                     int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids) {
+int vbh_decode_batch_begin(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, const int64_t *h_frame_offsets,
+                           int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids) {
   VBH_CHECK(d && h_frame_offsets && h_tid2pdf, "vbh_decode_batch: NULL argument");
   VBH_CHECK(n_utt >= 0 && num_pdfs > 0 && num_tids >= 0, "vbh_decode_batch: bad sizes");
+  VBH_CHECK(!d->pend.active, "vbh_decode_batch_begin: the previous batch has not been ended");
   if (vbh_use_device(d->ctx)) return -1;
   d->results.clear(); d->h_res.clear();
   d->t_kernel_ms = d->t_copy_ms = d->t_host_ms = d->t_total_ms = 0;
+  d->pend = vbh_decoder::Pending();
+  d->pend.t_begin = std::chrono::steady_clock::now();
+  d->pend.n_utt = n_utt;
+  d->pend.active = true;
   if (n_utt == 0) return 0;
-  const auto t_begin = std::chrono::steady_clock::now();
-  const bool dbg_t = getenv("VBH_DEBUG_TIMES") != nullptr;
-  auto t_lap = t_begin;
-  auto lap = [&](const char *what) {
-    if (!dbg_t) return;
-    const auto now = std::chrono::steady_clock::now();
-    fprintf(stderr, "[vbh] %-28s %8.2f ms\n", what, std::chrono::duration<float, std::milli>(now - t_lap).count());
-    t_lap = now;
-  };
-  hipEvent_t ev0, ev1;
-  VBH_HIP(hipEventCreate(&ev0)); VBH_HIP(hipEventCreate(&ev1));
-  struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } ev_guard{ev0, ev1};
+  d->pend.active = false;      // set again once the launch has succeeded
+  if (!d->ev0) { VBH_HIP(hipEventCreate(&d->ev0)); VBH_HIP(hipEventCreate(&d->ev1)); }
   const vbh_graph *g = d->graph;
   // the graph's ilabels must be valid transition-ids ("Likely graph/model mismatch",
   // decodable-am-diag-gmm.cc:32-33) -- checked once per batch on the tid2pdf table
   VBH_CHECK(g->max_ilabel <= num_tids, "vbh_decode_batch: graph uses transition-id %d but the model has %d (graph/model mismatch)", g->max_ilabel, num_tids);
   for (int t = 1; t <= num_tids; t++)
     VBH_CHECK(h_tid2pdf[t] >= 0 && h_tid2pdf[t] < num_pdfs, "vbh_decode_batch: tid2pdf[%d] = %d out of range", t, h_tid2pdf[t]);
-  std::vector<UttDesc> utts(n_utt);
+  std::vector<UttDesc> &utts = d->h_utts;
+  utts.assign(n_utt, UttDesc{0, 0, 0});
   long long total_frames = 0;
   for (int u = 0; u < n_utt; u++) {
     const long long T = h_frame_offsets[u + 1] - h_frame_offsets[u];
@@ -1905,16 +1925,29 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
   }
   VBH_CHECK(total_frames == 0 || d_loglikes, "vbh_decode_batch: NULL loglikes");
   hipStream_t st = d->ctx->stream;
-  DevBuf<UttDesc> d_utts; DevBuf<int> d_t2p, d_counter; DevBuf<UttResult> d_res;
-  // graph labels beyond the table would read out of bounds: verify on the host copy
-  // (cheap: done in vbh_graph_create for states; here for labels)
-  std::vector<int> t2p(h_tid2pdf, h_tid2pdf + num_tids + 1);
+  std::vector<int> &t2p = d->h_t2p;
+  t2p.assign(h_tid2pdf, h_tid2pdf + num_tids + 1);
   t2p[0] = 0;
-  if (d_utts.upload(utts.data(), utts.size(), st) || d_t2p.upload(t2p.data(), t2p.size(), st) || d_counter.alloc(1) || d_res.alloc(n_utt)) return -1;
-  VBH_HIP(hipMemsetAsync(d_counter.p, 0, sizeof(int), st));
-  lap("checks + small uploads");
+  if ((size_t)n_utt > d->utts_cap) { if (d->d_utts.alloc(n_utt) || d->d_res.alloc(n_utt)) return -1; d->utts_cap = n_utt; }
+  if (t2p.size() > d->t2p_cap) { if (d->d_t2p.alloc(t2p.size())) return -1; d->t2p_cap = t2p.size(); }
+  if (!d->d_counter.p && d->d_counter.alloc(1)) return -1;
+  // uploads come from pinned memory: a copy from pageable memory blocks the host until the GPU
+  // has run it, i.e. behind whatever another context's search is doing to the CUs
+  const size_t utt_b = (sizeof(UttDesc) * n_utt + 255) & ~(size_t)255, t2p_b = (sizeof(int) * t2p.size() + 255) & ~(size_t)255;
+  if (utt_b + t2p_b + 256 > d->stage_bytes) {
+    if (d->stage) (void)hipHostFree(d->stage);
+    d->stage = nullptr; d->stage_bytes = 0;
+    VBH_HIP(hipHostMalloc(reinterpret_cast<void **>(&d->stage), utt_b + t2p_b + 4096, hipHostMallocDefault));
+    d->stage_bytes = utt_b + t2p_b + 4096;
+  }
+  memcpy(d->stage, utts.data(), sizeof(UttDesc) * n_utt);
+  memcpy(d->stage + utt_b, t2p.data(), sizeof(int) * t2p.size());
+  VBH_HIP(hipMemcpyAsync(d->d_utts.p, d->stage, sizeof(UttDesc) * n_utt, hipMemcpyHostToDevice, st));
+  VBH_HIP(hipMemcpyAsync(d->d_t2p.p, d->stage + utt_b, sizeof(int) * t2p.size(), hipMemcpyHostToDevice, st));
+  VBH_HIP(hipMemsetAsync(d->d_counter.p, 0, sizeof(int), st));
   // output pool: the pruned lattice is a small multiple of the frame count
-  Pool pool{};
+  Pool &pool = d->h_pool;
+  pool = Pool{};
   const long long tok_cap = std::max<long long>(4096, 64 * (total_frames + n_utt)), link_cap = std::max<long long>(8192, 128 * (total_frames + n_utt));
   pool.tok_cap = tok_cap; pool.link_cap = link_cap; pool.cost_cap = total_frames + 1;
   DevBuf<int> &p_tf = d->p_tf, &p_ts = d->p_ts, &p_ls = d->p_ls, &p_ld = d->p_ld, &p_li = d->p_li, &p_lo = d->p_lo;
@@ -1934,24 +1967,107 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
   pool.tok_frame = p_tf.p; pool.tok_state = p_ts.p; pool.tok_cost = p_tc.p; pool.tok_extra = p_te.p; pool.tok_final = p_tfin.p;
   pool.link_src = p_ls.p; pool.link_dst = p_ld.p; pool.link_il = p_li.p; pool.link_ol = p_lo.p; pool.link_gr = p_lg.p; pool.link_ac = p_la.p;
   pool.cost_offsets = p_co.p; pool.counters = p_cnt.p;
-  if (g->A > 0) {
-    hipLaunchKernelGGL(fill_arc_pdf_kernel, dim3(1024), dim3(256), 0, st, g->arcs.p, g->arc_il.p, g->A, d_t2p.p);
+  // the arcs' pdf fields depend on tid2pdf only: refill when the table changes (decoders that share
+  // a graph on different streams must therefore use one table at a time)
+  if (g->A > 0 && g->filled_t2p != t2p) {
+    hipLaunchKernelGGL(fill_arc_pdf_kernel, dim3(1024), dim3(256), 0, st, g->arcs.p, g->arc_il.p, g->A, d->d_t2p.p);
     VBH_HIP(hipGetLastError());
+    VBH_HIP(hipStreamSynchronize(st));
+    g->filled_t2p = t2p;
   }
   DevBuf<Pool> &d_pool = d->d_pool;
   if (!d_pool.p && d_pool.alloc(1)) return -1;
-  VBH_HIP(hipMemcpyAsync(d_pool.p, &pool, sizeof(Pool), hipMemcpyHostToDevice, st));
-  DevGraph dg{g->S, g->start, g->st.p, g->arcs.p, g->arc_il.p};
-  DecCfg dc{d->cfg.beam, d->cfg.lattice_beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active, effective_prune_interval(&d->cfg), getenv("VBH_NO_LDS_MAP") ? 0 : 1};
-  d->h_res.resize(n_utt);
-  lap("pool setup");
+  const DevGraph dg0{g->S, g->start, g->st.p, g->arcs.p, g->arc_il.p};
+  const DecCfg dc0{d->cfg.beam, d->cfg.lattice_beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active, effective_prune_interval(&d->cfg), getenv("VBH_NO_LDS_MAP") ? 0 : 1};
+  // Optional longest-first order for the persistent grid (VBH_LPT_PROBE_FRAMES=n, off by default).
+  // Search times differ several-fold between utterances of equal length (how well the audio matches
+  // the model decides how many tokens stay in the beam), and with a few utterances per workgroup one
+  // heavy utterance picked up late leaves CUs idle at the end (35 % of workgroup-time at 1024
+  // utterances).  With the option the grid first searches the first n frames of every utterance with
+  // the output pool closed and the real search takes the utterances in order of decreasing probe
+  // time.  Measured: 64 frames predict too little (busy 66 % -> 68 %), 128 frames help (80 %) but cost
+  // what they gain, and the probe blocks the host; overlapping consecutive batches on two streams
+  // (vbh_decode_batch_begin/_end) removes the idle tail without guessing, so that is what bench.py does.
+  const int *d_work_list = nullptr;
+  d->t_probe_ms = 0;
+  {
+    int probe_frames = 0;
+    if (const char *e = getenv("VBH_LPT_PROBE_FRAMES")) probe_frames = atoi(e);
+    if (probe_frames > 0 && n_utt > d->small_set.n) {
+      const auto tp0 = std::chrono::steady_clock::now();
+      std::vector<UttDesc> probe(utts);
+      for (auto &u : probe) u.T = std::min(u.T, probe_frames);
+      Pool closed = pool; closed.tok_cap = 0; closed.link_cap = 0; closed.cost_cap = 0;
+      VBH_HIP(hipMemcpyAsync(d->d_utts.p, probe.data(), sizeof(UttDesc) * n_utt, hipMemcpyHostToDevice, st));
+      VBH_HIP(hipMemcpyAsync(d->d_pool.p, &closed, sizeof(Pool), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(decode_kernel, dim3(std::min(d->small_set.n, n_utt)), dim3(NT), 0, st, dg0, dc0, d->small_set.d.p, d_loglikes,
+                         (int)num_pdfs, d->d_utts.p, (const int *)nullptr, n_utt, d->d_counter.p, d->d_res.p, d->d_pool.p);
+      VBH_HIP(hipGetLastError());
+      std::vector<UttResult> pr(n_utt);
+      VBH_HIP(hipMemcpyAsync(pr.data(), d->d_res.p, sizeof(UttResult) * n_utt, hipMemcpyDeviceToHost, st));
+      VBH_HIP(hipStreamSynchronize(st));
+      d->h_order.resize(n_utt);
+      for (int u = 0; u < n_utt; u++) d->h_order[u] = u;
+      // probe time per frame searched, scaled to the utterance's length
+      std::vector<double> w(n_utt);
+      for (int u = 0; u < n_utt; u++) w[u] = (double)(pr[u].t_end - pr[u].t_start) / std::max(1, probe[u].T) * std::max(1, utts[u].T);
+      std::stable_sort(d->h_order.begin(), d->h_order.end(), [&](int a, int b) { return w[a] > w[b]; });
+      if ((size_t)n_utt > d->order_cap) { if (d->d_order.alloc(n_utt)) return -1; d->order_cap = n_utt; }
+      VBH_HIP(hipMemcpyAsync(d->d_order.p, d->h_order.data(), sizeof(int) * n_utt, hipMemcpyHostToDevice, st));
+      VBH_HIP(hipMemcpyAsync(d->d_utts.p, utts.data(), sizeof(UttDesc) * n_utt, hipMemcpyHostToDevice, st));
+      VBH_HIP(hipMemsetAsync(d->d_counter.p, 0, sizeof(int), st));
+      VBH_HIP(hipMemsetAsync(p_cnt.p, 0, 4 * sizeof(unsigned long long), st));
+      d_work_list = d->d_order.p;
+      d->t_probe_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tp0).count();
+      if (getenv("VBH_DEBUG_TIMES")) fprintf(stderr, "[vbh] %-28s %8.2f ms\n", "longest-first probe", d->t_probe_ms);
+    }
+  }
+  memcpy(d->stage + utt_b + t2p_b, &pool, sizeof(Pool));
+  VBH_HIP(hipMemcpyAsync(d->d_pool.p, d->stage + utt_b + t2p_b, sizeof(Pool), hipMemcpyHostToDevice, st));
+  d->pend.dg = dg0;
+  d->pend.dc = dc0;
+  d->pend.d_loglikes = d_loglikes; d->pend.num_pdfs = num_pdfs; d->pend.tok_cap = tok_cap; d->pend.link_cap = link_cap;
   {
     const int grid = std::min(d->small_set.n, n_utt);
-    VBH_HIP(hipEventRecord(ev0, st));
-    hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(NT), 0, st, dg, dc, d->small_set.d.p, d_loglikes, (int)num_pdfs,
-                       d_utts.p, (const int *)nullptr, n_utt, d_counter.p, d_res.p, d_pool.p);
+    VBH_HIP(hipEventRecord(d->ev0, st));
+    hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(NT), 0, st, d->pend.dg, d->pend.dc, d->small_set.d.p, d_loglikes, (int)num_pdfs,
+                       d->d_utts.p, d_work_list, n_utt, d->d_counter.p, d->d_res.p, d_pool.p);
     VBH_HIP(hipGetLastError());
-    VBH_HIP(hipEventRecord(ev1, st));
+    VBH_HIP(hipEventRecord(d->ev1, st));
+  }
+  d->pend.active = true;
+  return 0;
+}
+
+int vbh_decode_batch_end(vbh_decoder *d) {
+  VBH_CHECK(d, "vbh_decode_batch_end: NULL argument");
+  VBH_CHECK(d->pend.active, "vbh_decode_batch_end: no batch has been begun");
+  if (vbh_use_device(d->ctx)) return -1;
+  d->pend.active = false;
+  const int n_utt = d->pend.n_utt;
+  if (n_utt == 0) return 0;
+  const vbh_graph *g = d->graph;
+  hipStream_t st = d->ctx->stream;
+  const long long tok_cap = d->pend.tok_cap, link_cap = d->pend.link_cap;
+  const float *d_loglikes = d->pend.d_loglikes; const int num_pdfs = d->pend.num_pdfs;
+  const DevGraph dg = d->pend.dg; const DecCfg dc = d->pend.dc;
+  const auto t_begin = d->pend.t_begin;
+  hipEvent_t ev0 = d->ev0, ev1 = d->ev1;
+  DevBuf<UttDesc> &d_utts = d->d_utts; DevBuf<int> &d_counter = d->d_counter; DevBuf<UttResult> &d_res = d->d_res;
+  DevBuf<Pool> &d_pool = d->d_pool;
+  DevBuf<int> &p_tf = d->p_tf, &p_ts = d->p_ts, &p_ls = d->p_ls, &p_ld = d->p_ld, &p_li = d->p_li, &p_lo = d->p_lo;
+  DevBuf<float> &p_tc = d->p_tc, &p_te = d->p_te, &p_tfin = d->p_tfin, &p_lg = d->p_lg, &p_la = d->p_la;
+  DevBuf<unsigned long long> &p_cnt = d->p_cnt;
+  const bool dbg_t = getenv("VBH_DEBUG_TIMES") != nullptr;
+  auto t_lap = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!dbg_t) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[vbh] %-28s %8.2f ms\n", what, std::chrono::duration<float, std::milli>(now - t_lap).count());
+    t_lap = now;
+  };
+  d->h_res.resize(n_utt);
+  {
     VBH_HIP(hipMemcpyAsync(d->h_res.data(), d_res.p, sizeof(UttResult) * n_utt, hipMemcpyDeviceToHost, st));
     VBH_HIP(hipStreamSynchronize(st));
     float ms = 0; VBH_HIP(hipEventElapsedTime(&ms, ev0, ev1)); d->t_kernel_ms += ms;
@@ -2043,6 +2159,19 @@ int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, 
   d->t_copy_ms = std::chrono::duration<float, std::milli>(t_host0 - t_copy0).count();
   d->t_host_ms = std::chrono::duration<float, std::milli>(t_end - t_host0).count();
   d->t_total_ms = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
+  return 0;
+}
+
+int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, const int64_t *h_frame_offsets,
+                     int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids) {
+  if (vbh_decode_batch_begin(d, d_loglikes, num_pdfs, h_frame_offsets, n_utt, h_tid2pdf, num_tids)) return -1;
+  return vbh_decode_batch_end(d);
+}
+
+int vbh_decoder_utt_timeline(vbh_decoder *d, int32_t utt, int64_t *out3) {
+  VBH_CHECK(d && out3, "vbh_decoder_utt_timeline: NULL argument");
+  VBH_CHECK(utt >= 0 && utt < (int)d->h_res.size(), "vbh_decoder_utt_timeline: utterance %d out of range", utt);
+  out3[0] = d->h_res[utt].t_start; out3[1] = d->h_res[utt].t_end; out3[2] = d->h_res[utt].wg;
   return 0;
 }
 

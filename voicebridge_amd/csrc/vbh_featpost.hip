@@ -299,13 +299,18 @@ int vbh_featpost(vbh_ctx *ctx, const vbh_featpost_cfg *c, const float *d_in, con
     }
   }
   hipStream_t s = ctx->stream;
-  DevBuf<long long> d_foff; DevBuf<int> d_cu, d_cf, d_u2s; DevBuf<float> d_norm, d_scales, d_lda, d_spk;
-  if (d_foff.upload(foff.data(), foff.size(), s) || d_cu.upload(cu.data(), cu.size(), s) || d_cf.upload(cf.data(), cf.size(), s) ||
-      d_u2s.upload(u2s.data(), u2s.size(), s) || d_norm.upload(norm.data(), norm.size(), s) ||
-      d_scales.upload(scales.data(), scales.size(), s))
-    return -1;
-  if (c->lda_rows && d_lda.upload(h_lda, (size_t)c->lda_rows * c->lda_cols, s)) return -1;
-  if (c->spk_rows && d_spk.upload(h_spk_xform, (size_t)n_spk * c->spk_rows * c->spk_cols, s)) return -1;
+  const size_t n_lda = c->lda_rows ? (size_t)c->lda_rows * c->lda_cols : 0, n_spkx = c->spk_rows ? (size_t)n_spk * c->spk_rows * c->spk_cols : 0;
+  vbh_arena *ar = vbh_arena_begin(ctx, vbh_arena_need(foff.size() * 8) + vbh_arena_need(cu.size() * 4) + vbh_arena_need(cf.size() * 4) +
+                                           vbh_arena_need(u2s.size() * 4) + vbh_arena_need(norm.size() * 4) + vbh_arena_need(scales.size() * 4) +
+                                           vbh_arena_need(n_lda * 4) + vbh_arena_need(n_spkx * 4));
+  if (!ar) return -1;
+  const long long *d_foff = vbh_arena_put(ar, foff.data(), foff.size());
+  const int *d_cu = vbh_arena_put(ar, cu.data(), cu.size()), *d_cf = vbh_arena_put(ar, cf.data(), cf.size());
+  const int *d_u2s = vbh_arena_put(ar, u2s.data(), u2s.size());
+  const float *d_norm = vbh_arena_put(ar, norm.data(), norm.size()), *d_scales = vbh_arena_put(ar, scales.data(), scales.size());
+  const float *d_lda = n_lda ? vbh_arena_put(ar, h_lda, n_lda) : nullptr;
+  const float *d_spk = n_spkx ? vbh_arena_put(ar, h_spk_xform, n_spkx) : nullptr;
+  if (vbh_arena_commit(ctx, ar)) return -1;
   const int raw_rows = kChunk + 2 * p.halo;
   const size_t lds_floats = (size_t)raw_rows * p.in_dim + (size_t)kChunk * (p.mid_dim | 1) +
                             (size_t)kChunk * ((p.lda_rows ? p.lda_rows : 1) | 1) + (size_t)kChunk * (p.out_dim | 1) +
@@ -318,10 +323,9 @@ int vbh_featpost(vbh_ctx *ctx, const vbh_featpost_cfg *c, const float *d_in, con
   // chunks of one speaker are contiguous, so a grid-stride walk re-stages the speaker
   // transform rarely; cap the grid at a few workgroups per CU
   const int grid = n_chunks < 4 * ctx->num_cus ? n_chunks : 4 * ctx->num_cus;
-  hipLaunchKernelGGL(featpost_kernel, dim3(grid), dim3(256), lds_bytes, s, p, d_in, d_foff.p, d_cu.p, d_cf.p, n_chunks,
-                     d_u2s.p, d_norm.p, d_scales.p, d_lda.p, d_spk.p, d_out);
+  hipLaunchKernelGGL(featpost_kernel, dim3(grid), dim3(256), lds_bytes, s, p, d_in, d_foff, d_cu, d_cf, n_chunks,
+                     d_u2s, d_norm, d_scales, d_lda, d_spk, d_out);
   VBH_HIP(hipGetLastError());
-  VBH_HIP(hipStreamSynchronize(s));   // the uploaded tables are released on return
   return 0;
 }
 

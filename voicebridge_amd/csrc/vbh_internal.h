@@ -15,12 +15,41 @@
 
 #define VBH_MAX_TIMERS 16
 
+// Per-call tables (offsets, chunk lists, per-speaker transforms ...) go to the device through a
+// small ring of staging arenas: the host fills a pinned buffer, ONE asynchronous copy moves it to
+// the arena's device buffer, kernels of that call read it there.  No allocation, no blocking copy
+// and no stream synchronisation per call, so stages enqueue without waiting for the GPU -- which
+// is what lets batches overlap on several contexts.  An arena is reused four calls later, after
+// waiting for its own copy (long done by then).
+#define VBH_ARENAS 4
+struct vbh_arena {
+  char *h = nullptr, *d = nullptr;
+  size_t cap = 0, used = 0;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+};
+
 struct vbh_ctx {
   int device;
   hipStream_t stream;
   hipEvent_t ev_start[VBH_MAX_TIMERS], ev_stop[VBH_MAX_TIMERS];
   int num_cus;
+  vbh_arena arena[VBH_ARENAS];
+  int arena_next = 0;
 };
+
+vbh_arena *vbh_arena_begin(vbh_ctx *ctx, size_t bytes);          // NULL on error
+int vbh_arena_commit(vbh_ctx *ctx, vbh_arena *a);                 // enqueue the copy on ctx->stream
+// reserve n elements in the arena, copy src there (src may be NULL: zero fill), return the device address
+template <class T>
+static inline T *vbh_arena_put(vbh_arena *a, const T *src, size_t n) {
+  const size_t off = (a->used + 255) & ~(size_t)255, bytes = n * sizeof(T);
+  if (off + bytes > a->cap) return nullptr;       // cannot happen: begin() sized the arena
+  if (src) memcpy(a->h + off, src, bytes); else memset(a->h + off, 0, bytes);
+  a->used = off + bytes;
+  return reinterpret_cast<T *>(a->d + off);
+}
+static inline size_t vbh_arena_need(size_t bytes) { return ((bytes + 255) & ~(size_t)255) + 256; }
 
 void vbh_set_error(const char *fmt, ...);
 

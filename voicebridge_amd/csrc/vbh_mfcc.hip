@@ -434,21 +434,23 @@ int vbh_mfcc_compute(vbh_mfcc *m, const void *d_wave, int wave_is_int16, const i
   if (cu.empty()) return 0;
   VBH_CHECK(d_wave && d_feats, "vbh_mfcc_compute: NULL device buffer");
   hipStream_t s = m->ctx->stream;
-  if (m->d_wave_off.upload(woff.data(), woff.size(), s) || m->d_frame_off.upload(foff.data(), foff.size(), s) ||
-      m->d_chunk_utt.upload(cu.data(), cu.size(), s) || m->d_chunk_f0.upload(cf.data(), cf.size(), s))
-    return -1;
-  VBH_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
+  vbh_arena *ar = vbh_arena_begin(m->ctx, vbh_arena_need(woff.size() * 8) + vbh_arena_need(foff.size() * 8) +
+                                              vbh_arena_need(cu.size() * 4) + vbh_arena_need(cf.size() * 4));
+  if (!ar) return -1;
+  const long long *d_wave_off = vbh_arena_put(ar, woff.data(), woff.size()), *d_frame_off = vbh_arena_put(ar, foff.data(), foff.size());
+  const int *d_chunk_utt = vbh_arena_put(ar, cu.data(), cu.size()), *d_chunk_f0 = vbh_arena_put(ar, cf.data(), cf.size());
+  if (vbh_arena_commit(m->ctx, ar)) return -1;
   vbh_mfcc_tables t{m->window.p, m->twiddle.p, m->mel_first.p, m->mel_len.p, m->mel_off.p, m->mel_w.p, m->dct.p, m->lifter.p};
   const int n_chunks = (int)cu.size();
   int grid = n_chunks < 8 * m->ctx->num_cus ? n_chunks : 8 * m->ctx->num_cus;
   if (wave_is_int16) {
     VBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes));
-    hipLaunchKernelGGL(mfcc_kernel<true>, dim3(grid), dim3(256), m->lds_bytes, s, m->p, t, d_wave, m->d_wave_off.p,
-                       m->d_frame_off.p, m->d_chunk_utt.p, m->d_chunk_f0.p, n_chunks, d_feats);
+    hipLaunchKernelGGL(mfcc_kernel<true>, dim3(grid), dim3(256), m->lds_bytes, s, m->p, t, d_wave, d_wave_off,
+                       d_frame_off, d_chunk_utt, d_chunk_f0, n_chunks, d_feats);
   } else {
     VBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes));
-    hipLaunchKernelGGL(mfcc_kernel<false>, dim3(grid), dim3(256), m->lds_bytes, s, m->p, t, d_wave, m->d_wave_off.p,
-                       m->d_frame_off.p, m->d_chunk_utt.p, m->d_chunk_f0.p, n_chunks, d_feats);
+    hipLaunchKernelGGL(mfcc_kernel<false>, dim3(grid), dim3(256), m->lds_bytes, s, m->p, t, d_wave, d_wave_off,
+                       d_frame_off, d_chunk_utt, d_chunk_f0, n_chunks, d_feats);
   }
   VBH_HIP(hipGetLastError());
   return 0;
