@@ -140,3 +140,40 @@ def test_decode_independent_of_pruning_schedule(ctx, monkeypatch, every, lds_map
         ref = vbo.decode_lattice_faster(fst, ll[:n], t2p, exact_cutoff=True, **cfg)
         assert_same_lattice(dec.result(u), ref)
     dec.close(); graph.close()
+
+
+def test_decode_begin_end_two_contexts(ctx):
+    """two batches in flight on two contexts/streams sharing one graph (what bench.py's pipeline does):
+    each must give the lattices of the one-call form"""
+    import torch
+    from oracle import vbo
+    from voicebridge_amd import api
+    cfg = dict(beam=11.0, max_active=3000, min_active=100, lattice_beam=5.0)
+    S, P, T, seed = 30000, 96, 120, 21
+    g, t2p, ll = make_case(S, P, T, seed, eps_frac=0.3, spread=30.0)
+    lens = [[T, 61, 17], [88, T]]
+    ctx2 = api.Context(0)
+    graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
+    decs = [api.LatticeDecoder(c, graph, 3, T, **cfg) for c in (ctx, ctx2)]
+    bufs, foffs = [], []
+    for ln in lens:
+        fo = np.zeros(len(ln) + 1, np.int64)
+        fo[1:] = np.cumsum(ln)
+        foffs.append(fo)
+        bufs.append(torch.from_numpy(np.ascontiguousarray(np.concatenate([ll[:n] for n in ln]))).to(ctx.device))
+    ctx.torch_sync()
+    ctx2.wait_for(ctx)                      # (nothing pending: exercises the call)
+    for d, b, fo in zip(decs, bufs, foffs):
+        d.decode_begin(b, fo, t2p)
+    with pytest.raises(Exception):
+        decs[0].decode_begin(bufs[0], foffs[0], t2p)      # a second begin before end is refused
+    for d in reversed(decs):
+        d.decode_end()
+    fst = vbo.make_fst(g["final"], g["arc_offset"], g["arcs"], 0)
+    for d, ln in zip(decs, lens):
+        for u, n in enumerate(ln):
+            ref = vbo.decode_lattice_faster(fst, ll[:n], t2p, exact_cutoff=True, **cfg)
+            assert_same_lattice(d.result(u), ref)
+    for d in decs:
+        d.close()
+    graph.close(); ctx2.close()
