@@ -40,6 +40,11 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;   // native vector: sta
 
 struct GmmTile { int g0, ng, p0, np; };
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() is a full fence: it also
+// waits for the wave's global stores to be acknowledged (vmcnt(0)), i.e. every tile paid the write
+// latency of its 84-byte output runs at the barrier that frees the tile buffer.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // NPRE = Kpad/8: a B tile is Kpad*TN/4 = 256*NPRE float4, i.e. exactly NPRE per thread, so
 // the prefetch registers need no predicate (a predicated register array goes to scratch).
 template <int NPRE>
@@ -86,16 +91,21 @@ __global__ __launch_bounds__(256, 2) void gmm_loglikes_kernel(
   const int r = wid & 1, cpair = wid >> 1;   // wave tile: rows r*32.., column tiles 2*cpair, 2*cpair+1
   const int khalf = lane >> 5, l31 = lane & 31;
 
+  // the tile's descriptor and its pdf column starts (np <= TN < 256: one per thread) are fetched one
+  // tile ahead too: loaded at the top of an iteration they were two dependent global loads in
+  // front of every tile's first barrier
+  GmmTile tile = tiles[j_begin];
+  int off = tid <= tile.np ? pdf_offsets[tile.p0 + tid] : 0;
   for (int j = j_begin; j < j_end; j++) {
-    const GmmTile tile = tiles[j];
     // ---- commit the prefetched B tile to LDS
     {
       f32x4 *dst = reinterpret_cast<f32x4 *>(sB);
 #pragma unroll
       for (int i = 0; i < NPRE; i++) dst[tid + i * 256] = pre[i];
-      for (int q = tid; q <= tile.np; q += 256) sOff[q] = pdf_offsets[tile.p0 + q] - tile.g0;
+      if (tid <= tile.np) sOff[tid] = off - tile.g0;
     }
-    __syncthreads();
+    lds_barrier();
+    const GmmTile nt = tiles[j + 1];     // (one spare descriptor at the end)
     {   // next tile's loads stay in flight under the MFMA loop (the tile array has one
         // spare zero tile at the end, so the last iteration needs no branch)
       const f32x4 *src = reinterpret_cast<const f32x4 *>(Bp + (size_t)(j + 1) * Kpad * TN);
@@ -106,14 +116,33 @@ __global__ __launch_bounds__(256, 2) void gmm_loglikes_kernel(
     f32x16 acc0 = {0}, acc1 = {0};
     const float *pa = sA + khalf * LDA + r * 32 + l31;
     const float *pb = sB + khalf * TN + cpair * 64 + l31;
-#pragma unroll 8
-    for (int kk = 0; kk < Kpad / 2; kk++) {
-      const float a = pa[kk * 2 * LDA];
-      const float b0 = pb[kk * 2 * TN], b1 = pb[kk * 2 * TN + 32];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    // operands are read from LDS one chunk (4 k-steps = 8 MFMAs) ahead of the MFMAs that use them:
+    // with the reads issued right in front of their MFMAs the loop ran at LDS latency, not MFMA rate
+    {
+      constexpr int CH = 4, NCH = Kpad / 2 / CH;      // Kpad is a multiple of 8
+      float fa[2][CH], fb0[2][CH], fb1[2][CH];
+#pragma unroll
+      for (int i = 0; i < CH; i++) { fa[0][i] = pa[i * 2 * LDA]; fb0[0][i] = pb[i * 2 * TN]; fb1[0][i] = pb[i * 2 * TN + 32]; }
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        if (c + 1 < NCH) {
+#pragma unroll
+          for (int i = 0; i < CH; i++) {
+            const int kk = (c + 1) * CH + i;
+            fa[(c + 1) & 1][i] = pa[kk * 2 * LDA]; fb0[(c + 1) & 1][i] = pb[kk * 2 * TN]; fb1[(c + 1) & 1][i] = pb[kk * 2 * TN + 32];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);     // keep the scheduler from sinking those reads to their uses
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][i], fb0[c & 1][i], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][i], fb1[c & 1][i], acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    __syncthreads();   // every wave is done reading sB
+    lds_barrier();   // every wave is done reading sB
+    const int noff = tid <= nt.np ? pdf_offsets[nt.p0 + tid] : 0;
     // ---- spill accumulators: C/D map col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -121,29 +150,63 @@ __global__ __launch_bounds__(256, 2) void gmm_loglikes_kernel(
       sC[row * LDC + cpair * 64 + l31] = acc0[i];
       sC[row * LDC + cpair * 64 + 32 + l31] = acc1[i];
     }
-    __syncthreads();
-    // ---- per (frame, pdf) LogSumExp (kaldi-vector.cc:757-775)
-    const int pairs = TM * tile.np;
-    const float kMinLogDiff = -15.9423847198486328125f;   // logf(FLT_EPSILON)
-    for (int idx = tid; idx < pairs; idx += 256) {
-      const int t = idx / tile.np, q = idx - t * tile.np;
-      const int cs = sOff[q], ce = sOff[q + 1];
-      const float *row = sC + t * LDC;
-      float m = -INFINITY;
-      for (int c = cs; c < ce; c++) m = fmaxf(m, row[c]);
-      float res = m;
-      if (m > -INFINITY) {
-        const float cutoff = m + kMinLogDiff;
-        float s = 0.f;
-        for (int c = cs; c < ce; c++) {
-          const float v = row[c];
-          if (v >= cutoff) s += __expf(v - m);
+    lds_barrier();
+    // ---- per (frame, pdf) LogSumExp (kaldi-vector.cc:757-775).  A wave takes every 4th pdf of
+    //      the tile and lane = frame: the pdf's column range is wave-uniform (scalar loop bounds,
+    //      no integer division, no divergent trip counts) and the 64 rows are read conflict-free
+    //      (LDC is odd).  The result overwrites the pdf's first column of its own row ...
+    {
+      const float kMinLogDiff = -15.9423847198486328125f;   // logf(FLT_EPSILON)
+      float *row = sC + lane * LDC;
+      for (int q = wid; q < tile.np; q += 4) {
+        const int cs = __builtin_amdgcn_readfirstlane(sOff[q]), ce = __builtin_amdgcn_readfirstlane(sOff[q + 1]);
+        // columns in chunks of 8 independent LDS reads (one read latency per chunk, not per column)
+        const int n = ce - cs;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const float x = row[cs + (i < n ? i : 0)]; v[i] = i < n ? x : -INFINITY; }
+        float m = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+        for (int c0 = cs + 8; c0 < ce; c0 += 8) {
+          const int nn = ce - c0;
+          float w[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++) { const float x = row[c0 + (i < nn ? i : 0)]; w[i] = i < nn ? x : -INFINITY; }
+          m = fmaxf(m, fmaxf(fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3])), fmaxf(fmaxf(w[4], w[5]), fmaxf(w[6], w[7]))));
         }
-        res = m + __logf(s);
+        float res = m;
+        if (m > -INFINITY) {
+          const float cutoff = m + kMinLogDiff;
+          float sum = 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; i++) if (v[i] >= cutoff) sum += __expf(v[i] - m);    // (-inf padding fails the test)
+          for (int c0 = cs + 8; c0 < ce; c0 += 8) {
+            const int nn = ce - c0;
+            float w[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const float x = row[c0 + (i < nn ? i : 0)]; w[i] = i < nn ? x : -INFINITY; }
+#pragma unroll
+            for (int i = 0; i < 8; i++) if (w[i] >= cutoff) sum += __expf(w[i] - m);
+          }
+          res = m + __logf(sum);
+        }
+        row[cs] = res;
       }
-      if (t0 + t < T) out[(t0 + t) * P + tile.p0 + q] = res;
     }
-    __syncthreads();   // sC (= sB) is free for the next tile
+    lds_barrier();
+    // ---- ... and goes out with lanes along the pdfs of a frame (84-byte runs instead of one
+    //      4-byte store per cache line)
+    {
+      const int np = tile.np;
+      const int dt = 256 / np, dq = 256 - dt * np;
+      int t = tid / np, q = tid - t * np;
+      while (t < TM) {
+        if (t0 + t < T) out[(t0 + t) * P + tile.p0 + q] = sC[t * LDC + sOff[q]];
+        t += dt; q += dq;
+        if (q >= np) { q -= np; t++; }
+      }
+    }
+    lds_barrier();   // sC (= sB) is free for the next tile
+    tile = nt; off = noff;
   }
 }
 
@@ -204,6 +267,7 @@ int vbh_gmm_create(vbh_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h
     tiles.push_back(t);
   }
   g->n_tiles = (int)tiles.size();
+  tiles.push_back(GmmTile{0, 0, 0, 0});     // spare: the kernel reads one descriptor ahead
   std::vector<float> Bp((size_t)(g->n_tiles + 1) * g->Kpad * TN, 0.0f);   // + one spare tile (prefetch overrun)
   for (int j = 0; j < g->n_tiles; j++) {
     float *B = Bp.data() + (size_t)j * g->Kpad * TN;
