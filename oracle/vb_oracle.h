@@ -181,6 +181,12 @@ int vbo_decode_lattice_faster(const vbo_fst *fst, const vbo_lat_cfg *cfg,
 /* decoder/faster-decoder.{h,cc} */
 typedef struct vbo_faster_cfg {
   float beam; int32_t max_active; int32_t min_active; float beam_delta; float hash_ratio;
+  /* 0: replay the reference's HashList order (bit-exact with it); 1: the order-independent
+   * semantics a parallel search implements: next_cutoff takes its final value before anything is
+   * admitted; per state the cheapest incoming arc wins, ties go to the smaller arc index; the
+   * epsilon closure is taken to its fixed point before tokens are made; ties between final tokens
+   * go to the smaller state id */
+  int32_t exact_cutoff;
 } vbo_faster_cfg;
 void vbo_faster_cfg_default(vbo_faster_cfg *c);
 typedef struct vbo_faster_result {

@@ -34,7 +34,7 @@ void vbo_lat_cfg_default(vbo_lat_cfg *c) {
 void vbo_faster_cfg_default(vbo_faster_cfg *c) {
   /* faster-decoder.h:38-43 */
   c->beam = 16.0f; c->max_active = INT32_MAX; c->min_active = 20;
-  c->beam_delta = 0.5f; c->hash_ratio = 2.0f;
+  c->beam_delta = 0.5f; c->hash_ratio = 2.0f; c->exact_cutoff = 0;
 }
 
 /* ------------------------------------------------------------------------------------
@@ -878,6 +878,109 @@ static double f_process_emitting(fdec *d, int32_t frame) {
   return next_cutoff;
 }
 
+/* ---- order-independent mode (cfg->exact_cutoff): one frame = entries keyed by state, each
+ * holding the cheapest way in {cost, arc index, where it comes from}; tokens are made from the
+ * entries once the epsilon closure has reached its fixed point. */
+typedef struct { int32_t state; double cost; int64_t arc; int32_t prev_tok; int32_t prev_state; int32_t tok; } fentry;
+typedef struct { fentry *e; int32_t n, cap; int32_t *slot; int32_t nslot; } fentries;   /* slot: state -> entry, open addressing */
+static void fe_init(fentries *f) { memset(f, 0, sizeof(*f)); f->nslot = 1024; f->slot = (int32_t *)malloc(sizeof(int32_t) * f->nslot); memset(f->slot, 0xFF, sizeof(int32_t) * f->nslot); }
+static void fe_free(fentries *f) { free(f->e); free(f->slot); }
+static void fe_clear(fentries *f) { f->n = 0; memset(f->slot, 0xFF, sizeof(int32_t) * f->nslot); }
+static int32_t fe_find(const fentries *f, int32_t state) {
+  uint32_t h = ((uint32_t)state * 2654435761u) & (uint32_t)(f->nslot - 1);
+  while (f->slot[h] >= 0) { if (f->e[f->slot[h]].state == state) return f->slot[h]; h = (h + 1) & (uint32_t)(f->nslot - 1); }
+  return -1;
+}
+static void fe_put_slot(fentries *f, int32_t idx) {
+  uint32_t h = ((uint32_t)f->e[idx].state * 2654435761u) & (uint32_t)(f->nslot - 1);
+  while (f->slot[h] >= 0) h = (h + 1) & (uint32_t)(f->nslot - 1);
+  f->slot[h] = idx;
+}
+/* returns 1 if the entry of `state` is new or got a lower cost (its epsilon arcs must be (re-)expanded) */
+static int fe_relax(fentries *f, int32_t state, double cost, int64_t arc, int32_t prev_tok, int32_t prev_state) {
+  int32_t i = fe_find(f, state);
+  if (i < 0) {
+    if (f->n == f->cap) { f->cap = f->cap ? 2 * f->cap : 1024; f->e = (fentry *)realloc(f->e, sizeof(fentry) * f->cap); }
+    if (2 * (f->n + 1) > f->nslot) {
+      f->nslot *= 2; f->slot = (int32_t *)realloc(f->slot, sizeof(int32_t) * f->nslot); memset(f->slot, 0xFF, sizeof(int32_t) * f->nslot);
+      for (int32_t k = 0; k < f->n; k++) fe_put_slot(f, k);
+    }
+    fentry *e = &f->e[f->n];
+    e->state = state; e->cost = cost; e->arc = arc; e->prev_tok = prev_tok; e->prev_state = prev_state; e->tok = -1;
+    fe_put_slot(f, f->n++);
+    return 1;
+  }
+  fentry *e = &f->e[i];
+  if (cost < e->cost || (cost == e->cost && arc < e->arc)) {
+    const int lower = cost < e->cost;
+    e->cost = cost; e->arc = arc; e->prev_tok = prev_tok; e->prev_state = prev_state;
+    return lower;
+  }
+  return 0;
+}
+/* closure over input-epsilon arcs to the fixed point, then one token per entry */
+static void fx_close_and_make(fdec *d, fentries *f, double cutoff) {
+  const vbo_fst *fst = d->fst;
+  int32_t qn = 0, qcap = f->n + 16;
+  int32_t *q = (int32_t *)malloc(sizeof(int32_t) * qcap);
+  for (int32_t i = 0; i < f->n; i++) q[qn++] = f->e[i].state;
+  while (qn > 0) {
+    const int32_t state = q[--qn];
+    const double c = f->e[fe_find(f, state)].cost;
+    if (c > cutoff) continue;
+    for (int64_t a = fst->arc_offset[state]; a < fst->arc_offset[state + 1]; a++) {
+      const vbo_arc *arc = &fst->arcs[a];
+      if (arc->ilabel != 0) continue;
+      const double nc = c + arc->weight;
+      if (nc > cutoff) continue;
+      if (fe_relax(f, arc->nextstate, nc, a, -1, state)) {
+        if (qn == qcap) { qcap = 2 * qcap + 16; q = (int32_t *)realloc(q, sizeof(int32_t) * qcap); }
+        q[qn++] = arc->nextstate;
+      }
+    }
+  }
+  free(q);
+  /* tokens: indices first (a token's predecessor may be any entry of the same frame), then contents */
+  for (int32_t i = 0; i < f->n; i++) {
+    if (d->ntoks == d->captoks) { d->captoks = d->captoks ? d->captoks * 2 : 4096; d->toks = (ftok *)realloc(d->toks, sizeof(ftok) * d->captoks); }
+    f->e[i].tok = d->ntoks++;
+  }
+  omap_clear(&d->map);
+  for (int32_t i = 0; i < f->n; i++) {
+    const fentry *e = &f->e[i];
+    ftok *t = &d->toks[e->tok];
+    if (e->arc >= 0) { const vbo_arc *arc = &fst->arcs[e->arc]; t->ilabel = arc->ilabel; t->olabel = arc->olabel; t->weight = arc->weight; }
+    else { t->ilabel = 0; t->olabel = 0; t->weight = 0.0f; }
+    t->nextstate = e->state; t->cost = e->cost;
+    t->prev = e->arc < 0 ? -1 : (e->prev_tok >= 0 ? e->prev_tok : f->e[fe_find(f, e->prev_state)].tok);
+    omap_insert(&d->map, e->state, e->tok);
+  }
+}
+static double fx_process_emitting(fdec *d, fentries *f, int32_t frame) {
+  const vbo_fst *fst = d->fst;
+  int32_t n; olist_item *l = omap_list(&d->map, &n);
+  float adaptive_beam; int32_t best_idx;
+  const double weight_cutoff = f_get_cutoff(d, l, n, &adaptive_beam, &best_idx);
+  double next_cutoff = INFINITY;
+  for (int pass = 0; pass < 2; pass++) {
+    if (pass == 1) fe_clear(f);
+    for (int32_t i = 0; i < n; i++) {
+      const int32_t state = l[i].state, tok = l[i].val;
+      if (!(d->toks[tok].cost < weight_cutoff)) continue;
+      for (int64_t a = fst->arc_offset[state]; a < fst->arc_offset[state + 1]; a++) {
+        const vbo_arc *arc = &fst->arcs[a];
+        if (arc->ilabel == 0) continue;
+        const float ac_cost = -(d->acwt * d->loglikes[(size_t)frame * d->P + d->tid2pdf[arc->ilabel]]);
+        const double new_weight = arc->weight + d->toks[tok].cost + ac_cost;
+        if (pass == 0) { if (new_weight + adaptive_beam < next_cutoff) next_cutoff = new_weight + adaptive_beam; }
+        else if (new_weight < next_cutoff) fe_relax(f, arc->nextstate, new_weight, a, tok, -1);
+      }
+    }
+  }
+  free(l);
+  return next_cutoff;
+}
+
 int vbo_decode_faster(const vbo_fst *fst, const vbo_faster_cfg *cfg, const float *loglikes,
                       int32_t T, int32_t P, const int32_t *tid2pdf, int32_t num_tids,
                       float acwt, vbo_faster_result *res) {
@@ -889,14 +992,26 @@ int vbo_decode_faster(const vbo_fst *fst, const vbo_faster_cfg *cfg, const float
   omap_init(&d->map, 1000);
   /* InitDecoding :36-45 */
   vbo_arc dummy = {0, 0, 0.0f, fst->start};
-  int32_t st = f_new_tok(d, &dummy, 0.0f, 0, -1);
-  omap_insert(&d->map, fst->start, st);
-  f_process_nonemitting(d, (double)FLT_MAX);
   int32_t nfd = 0;
-  while (nfd - 1 != T - 1) {
-    double wc = f_process_emitting(d, nfd);
-    nfd++;
-    f_process_nonemitting(d, wc);
+  if (!cfg->exact_cutoff) {
+    int32_t st = f_new_tok(d, &dummy, 0.0f, 0, -1);
+    omap_insert(&d->map, fst->start, st);
+    f_process_nonemitting(d, (double)FLT_MAX);
+    while (nfd - 1 != T - 1) {
+      double wc = f_process_emitting(d, nfd);
+      nfd++;
+      f_process_nonemitting(d, wc);
+    }
+  } else {
+    fentries fe; fe_init(&fe);
+    fe_relax(&fe, fst->start, 0.0, -1, -1, -1);
+    fx_close_and_make(d, &fe, (double)FLT_MAX);
+    while (nfd - 1 != T - 1) {
+      const double wc = fx_process_emitting(d, &fe, nfd);
+      nfd++;
+      fx_close_and_make(d, &fe, wc);
+    }
+    fe_free(&fe);
   }
   res->num_frames = nfd;
   /* ReachedFinal :78-85, GetBestPath :87-147 */
@@ -904,15 +1019,18 @@ int vbo_decode_faster(const vbo_fst *fst, const vbo_faster_cfg *cfg, const float
   int is_final = 0;
   for (int32_t i = 0; i < n; i++)
     if (d->toks[l[i].val].cost != INFINITY && fst->final[l[i].state] != VBO_INF) is_final = 1;
-  int32_t best = -1;
+  int32_t best = -1, best_state = -1;
   if (!is_final) {
-    for (int32_t i = 0; i < n; i++)
-      if (best < 0 || d->toks[best].cost > d->toks[l[i].val].cost) best = l[i].val;
+    for (int32_t i = 0; i < n; i++) {
+      const double c = d->toks[l[i].val].cost;
+      if (best < 0 || d->toks[best].cost > c || (cfg->exact_cutoff && d->toks[best].cost == c && l[i].state < best_state)) { best = l[i].val; best_state = l[i].state; }
+    }
   } else {
     double best_cost = INFINITY;
     for (int32_t i = 0; i < n; i++) {
       double c = d->toks[l[i].val].cost + fst->final[l[i].state];
-      if (c < best_cost && c != INFINITY) { best_cost = c; best = l[i].val; }
+      if (c == INFINITY) continue;
+      if (c < best_cost || (cfg->exact_cutoff && c == best_cost && l[i].state < best_state)) { best_cost = c; best = l[i].val; best_state = l[i].state; }
     }
   }
   free(l);

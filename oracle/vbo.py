@@ -70,7 +70,7 @@ class LatResult(C.Structure):
 
 class FasterCfg(C.Structure):
     _fields_ = [("beam", C.c_float), ("max_active", C.c_int32), ("min_active", C.c_int32),
-                ("beam_delta", C.c_float), ("hash_ratio", C.c_float)]
+                ("beam_delta", C.c_float), ("hash_ratio", C.c_float), ("exact_cutoff", C.c_int32)]
 
 
 class FasterResult(C.Structure):
@@ -281,9 +281,9 @@ def decode_lattice_faster(fst, loglikes, tid2pdf, acwt=0.083333, beam=13.0, max_
 
 
 def decode_faster(fst, loglikes, tid2pdf, acwt=0.083333, beam=13.0, max_active=7000, min_active=20,
-                  beam_delta=0.5, hash_ratio=2.0):
+                  beam_delta=0.5, hash_ratio=2.0, exact_cutoff=False):
     f, keep = fst
-    cfg = FasterCfg(beam, max_active, min_active, beam_delta, hash_ratio)
+    cfg = FasterCfg(beam, max_active, min_active, beam_delta, hash_ratio, int(bool(exact_cutoff)))
     ll = _f32(loglikes)
     T, P = ll.shape
     t2p = np.ascontiguousarray(tid2pdf, np.int32)

@@ -114,6 +114,24 @@ def test_faster_decoder_matches_reference(name):
     np.testing.assert_allclose([r["best_graph"], r["best_acoustic"]], g["ref_fast_best_weight"], rtol=2e-6)
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_faster_decoder_exact_variant_vs_reference(name):
+    """the order-independent FasterDecoder (what the GPU implements) against the reference's golden
+    vectors: same words, alignment and weights on every golden case, for any hash size"""
+    g = load(name)
+    o = parse_opts(g["opts"])
+    kw = dict(acwt=o["acwt"], beam=o["beam"], max_active=int(o["max_active"]), min_active=20)
+    ex = vbo.decode_faster(fst_from(g), g["loglikes"], g["tid2pdf"], exact_cutoff=True, **kw)
+    assert [ex["ok"], ex["reached_final"], ex["num_frames"]] == g["ref_fast_meta"].tolist()
+    np.testing.assert_array_equal(ex["words"], g["ref_fast_words"])
+    np.testing.assert_array_equal(ex["ali"], g["ref_fast_ali"])
+    np.testing.assert_allclose([ex["best_graph"], ex["best_acoustic"]], g["ref_fast_best_weight"], rtol=2e-6)
+    for hr in (1.0, 3.7):
+        ex2 = vbo.decode_faster(fst_from(g), g["loglikes"], g["tid2pdf"], exact_cutoff=True, hash_ratio=hr, **kw)
+        np.testing.assert_array_equal(ex2["ali"], ex["ali"])
+        assert (ex2["best_graph"], ex2["best_acoustic"]) == (ex["best_graph"], ex["best_acoustic"])
+
+
 def test_reference_lattice_depends_on_hash_size_but_exact_variant_does_not():
     """The reference's extra arcs depend on its hash table size (hash_ratio, and in
     gmm-latgen-faster on the utterances decoded earlier by the same decoder object); the

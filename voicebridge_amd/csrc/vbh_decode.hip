@@ -89,6 +89,10 @@ constexpr int U = VBH_U;                    // independent items per lane in the
 #ifndef VBH_UC
 #define VBH_UC 2
 #endif
+#ifndef VBH_UM
+#define VBH_UM 4
+#endif
+constexpr int UM = VBH_UM;                  // ... in the compaction moves
 constexpr int UC = VBH_UC;                  // ... in the candidate passes (LDS-bound: more only costs registers)
 constexpr int UL = VBH_UL;                  // ... in the pruning sweeps over links
 constexpr int HBITS = NT >= 1024 ? 13 : (NT >= 512 ? 12 : 11);
@@ -613,16 +617,16 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
   const int ntf = sh.j_ntf, nseg = sh.j_nseg;
   if (ntf > 0) {
     const int t0 = sh.tbeg[0], t1 = sh.tbeg[ntf];
-    for (int base = t0; base < t1; base += NT * U) {
-      i32x4 R[U]; bool ok[U];
+    for (int base = t0; base < t1; base += NT * UM) {
+      i32x4 R[UM]; bool ok[UM];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
+      for (int u = 0; u < UM; u++) {
         const int t = base + u * NT + tid;
         ok[u] = t < t1;
         R[u] = src_tok[ok[u] ? t : t0];
       }
 #pragma unroll
-      for (int u = 0; u < U; u++) {
+      for (int u = 0; u < UM; u++) {
         const int t = base + u * NT + tid;
         if (!ok[u]) continue;
         int nid = -1;
@@ -645,10 +649,10 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
     gp<const i32x2> src_l2 = uptr(FROM_W ? s.wl2 : s.hl2);
     gp<i32x4> hl = uptr(s.hl); gp<i32x2> hl2 = uptr(s.hl2);
     const int l0 = sh.sbeg[0], l1 = sh.sbeg[nseg];
-    for (int base = l0; base < l1; base += NT * U) {
-      i32x4 L[U]; i32x2 A[U]; bool ok[U];
+    for (int base = l0; base < l1; base += NT * UM) {
+      i32x4 L[UM]; i32x2 A[UM]; bool ok[UM];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
+      for (int u = 0; u < UM; u++) {
         const int l = base + u * NT + tid;
         ok[u] = l < l1;
         L[u] = src_lk[ok[u] ? l : l0];
@@ -657,16 +661,16 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
       }
       // end points: window ids and ids of the block being re-compacted go through the remap
       // tables (-1 = dead); older history tokens keep their id if they are still alive
-      int vs[U], vd[U];
+      int vs[UM], vd[UM];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
+      for (int u = 0; u < UM; u++) {
         const int a = L[u].x, b = L[u].y;
         gp<const int> pa = !ok[u] ? h_remap : (a & WBIT) ? w_remap + (a ^ WBIT) : (a >= remap_lo) ? h_remap + a : (gp<const int>)(ht + a) + 2;
         gp<const int> pb = !ok[u] ? h_remap : (b & WBIT) ? w_remap + (b ^ WBIT) : (b >= remap_lo) ? h_remap + b : (gp<const int>)(ht + b) + 2;
         vs[u] = *pa; vd[u] = *pb;
       }
 #pragma unroll
-      for (int u = 0; u < U; u++) {
+      for (int u = 0; u < UM; u++) {
         const int l = base + u * NT + tid;
         if (!ok[u]) continue;
         const int a = L[u].x, b = L[u].y;
