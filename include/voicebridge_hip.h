@@ -220,6 +220,37 @@ int vbh_decoder_utt_timeline(vbh_decoder *d, int32_t utt, int64_t *out3);
  * lattice pool device->host, host-side canonical ordering + best path, whole call} */
 int vbh_decoder_times(vbh_decoder *d, float *out4);
 
+/* ---- FasterDecoder (K/decoder/faster-decoder.{h,cc}; the search of gmm-decode-faster,
+ * VB/src/gmmbin/gmm-decode-faster.cpp): 1-best Viterbi beam search, no lattice.  Same graph and
+ * score-matrix conventions as the lattice decoder above. */
+typedef struct vbh_faster_cfg {   /* FasterDecoderOptions (faster-decoder.h:31-71) */
+  float beam;            /* 16 */
+  int32_t max_active;    /* INT32_MAX */
+  int32_t min_active;    /* 20 */
+  float beam_delta;      /* 0.5 */
+  float acoustic_scale;  /* 0.083333 */
+} vbh_faster_cfg;
+void vbh_faster_cfg_default(vbh_faster_cfg *cfg);
+typedef struct vbh_faster_decoder vbh_faster_decoder;
+int vbh_faster_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_faster_cfg *cfg, int32_t max_batch,
+                              int32_t max_frames, vbh_faster_decoder **out);
+void vbh_faster_decoder_destroy(vbh_faster_decoder *d);
+/* decodes n_utt utterances (rows h_frame_offsets[u]..[u+1] of d_loglikes [T x num_pdfs]); blocks */
+int vbh_faster_decode_batch(vbh_faster_decoder *d, const float *d_loglikes, int32_t num_pdfs,
+                            const int64_t *h_frame_offsets, int32_t n_utt, const int32_t *h_tid2pdf,
+                            int32_t num_tids);
+typedef struct vbh_best_path {    /* GetBestPath + GetLinearSymbolSequence (faster-decoder.cc:87-147) */
+  int32_t ok;                     /* a token survived the last frame (Decode's return value) */
+  int32_t reached_final;          /* ReachedFinal() */
+  int32_t num_frames;
+  int32_t num_ali; const int32_t *ali;       /* transition-ids */
+  int32_t num_words; const int32_t *words;
+  float best_graph, best_acoustic;           /* LatticeWeight of the path (acoustic still scaled) */
+  int64_t n_tokens;                          /* tokens created (diagnostic) */
+} vbh_best_path;
+/* pointers stay valid until the next vbh_faster_decode_batch / destroy on this decoder */
+int vbh_faster_decoder_result(vbh_faster_decoder *d, int32_t utt, vbh_best_path *out);
+
 #ifdef __cplusplus
 }
 #endif

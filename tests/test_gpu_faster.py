@@ -1,0 +1,86 @@
+"""GPU parity: FasterDecoder vs the oracle's order-independent mode (bit-exact best path: words,
+alignment, float32 weights) and vs the reference's golden best paths."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import GOLD, load, parse_opts
+from tests.test_gpu_decode import arcs_of, make_case
+
+pytestmark = pytest.mark.gpu
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "decode_*.npz")))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from voicebridge_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def assert_same_path(got, ref):
+    for k in ("ok", "reached_final", "num_frames"):
+        assert got[k] == ref[k], k
+    np.testing.assert_array_equal(got["words"], ref["words"])
+    np.testing.assert_array_equal(got["ali"], ref["ali"])
+    assert np.float32(got["best_graph"]) == np.float32(ref["best_graph"])
+    assert np.float32(got["best_acoustic"]) == np.float32(ref["best_acoustic"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_faster_golden_cases(ctx, name):
+    import torch
+    from oracle import vbo
+    from voicebridge_amd import api
+    g = load(name)
+    o = parse_opts(g["opts"])
+    arcs = arcs_of(g)
+    kw = dict(beam=o["beam"], max_active=int(o["max_active"]), min_active=20)
+    ref = vbo.decode_faster(vbo.make_fst(g["fst_final"], g["fst_off"], arcs, 0), g["loglikes"], g["tid2pdf"],
+                            acwt=o["acwt"], exact_cutoff=True, **kw)
+    graph = api.Graph(ctx, g["fst_final"], g["fst_off"], arcs, 0)
+    T = g["loglikes"].shape[0]
+    dec = api.FasterDecoder(ctx, graph, 1, T, acoustic_scale=o["acwt"], **kw)
+    ll = torch.from_numpy(g["loglikes"]).to(ctx.device)
+    ctx.torch_sync()
+    dec.decode(ll, [0, T], g["tid2pdf"])
+    got = dec.result(0)
+    assert_same_path(got, ref)
+    # and the reference's own best path (golden vectors from the reference build)
+    np.testing.assert_array_equal(got["words"], g["ref_fast_words"])
+    np.testing.assert_array_equal(got["ali"], g["ref_fast_ali"])
+    np.testing.assert_allclose([got["best_graph"], got["best_acoustic"]], g["ref_fast_best_weight"], rtol=2e-6)
+    dec.close(); graph.close()
+
+
+@pytest.mark.parametrize("S,P,T,seed,cfg", [
+    (20000, 64, 120, 1, dict(beam=16.0, max_active=2147483647, min_active=20)),
+    (20000, 64, 90, 2, dict(beam=13.0, max_active=300, min_active=20)),            # max-active binds
+    (50000, 200, 77, 3, dict(beam=10.0, max_active=2000, min_active=200)),
+    (3000, 32, 60, 4, dict(beam=8.0, max_active=2147483647, min_active=0)),
+    (5000, 32, 0, 5, dict(beam=16.0, max_active=7000, min_active=20)),              # empty utterance
+    (5000, 32, 1, 6, dict(beam=16.0, max_active=7000, min_active=20)),
+])
+def test_faster_batch_vs_oracle(ctx, S, P, T, seed, cfg):
+    import torch
+    from oracle import vbo
+    from voicebridge_amd import api
+    g, t2p, ll = make_case(S, P, max(T, 1), seed, eps_frac=0.3, spread=8.0 if cfg["max_active"] < 1000 else 30.0)
+    lens = [T, T // 2, max(T - 3, 0)]
+    foff = np.zeros(4, np.int64)
+    foff[1:] = np.cumsum(lens)
+    batch = np.concatenate([ll[:n] for n in lens]) if sum(lens) else np.zeros((0, P), np.float32)
+    graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
+    dec = api.FasterDecoder(ctx, graph, 3, max(lens), **cfg)
+    d = torch.from_numpy(np.ascontiguousarray(batch)).to(ctx.device) if len(batch) else torch.zeros((1, P), device=ctx.device)
+    ctx.torch_sync()
+    dec.decode(d, foff, t2p)
+    fst = vbo.make_fst(g["final"], g["arc_offset"], g["arcs"], 0)
+    for u, n in enumerate(lens):
+        ref = vbo.decode_faster(fst, ll[:n] if n else np.zeros((0, P), np.float32), t2p, exact_cutoff=True, **cfg)
+        assert_same_path(dec.result(u), ref)
+    dec.close(); graph.close()

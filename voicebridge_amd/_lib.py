@@ -21,6 +21,8 @@ SYMBOLS = [
     "vbh_graph_create", "vbh_graph_destroy", "vbh_decode_cfg_default", "vbh_decoder_create",
     "vbh_decoder_destroy", "vbh_decode_batch", "vbh_decode_batch_begin", "vbh_decode_batch_end", "vbh_decoder_result", "vbh_decoder_phase_cycles",
     "vbh_decoder_times", "vbh_decoder_utt_timeline",
+    "vbh_faster_cfg_default", "vbh_faster_decoder_create", "vbh_faster_decoder_destroy", "vbh_faster_decode_batch",
+    "vbh_faster_decoder_result",
 ]
 
 
@@ -52,6 +54,17 @@ class DecodeCfg(C.Structure):
     _fields_ = [("beam", C.c_float), ("max_active", C.c_int32), ("min_active", C.c_int32),
                 ("lattice_beam", C.c_float), ("prune_interval", C.c_int32), ("beam_delta", C.c_float),
                 ("acoustic_scale", C.c_float)]
+
+
+class FasterCfg(C.Structure):
+    _fields_ = [("beam", C.c_float), ("max_active", C.c_int32), ("min_active", C.c_int32), ("beam_delta", C.c_float),
+                ("acoustic_scale", C.c_float)]
+
+
+class BestPath(C.Structure):
+    _fields_ = [("ok", C.c_int32), ("reached_final", C.c_int32), ("num_frames", C.c_int32),
+                ("num_ali", C.c_int32), ("ali", C.POINTER(C.c_int32)), ("num_words", C.c_int32), ("words", C.POINTER(C.c_int32)),
+                ("best_graph", C.c_float), ("best_acoustic", C.c_float), ("n_tokens", C.c_int64)]
 
 
 class Lattice(C.Structure):
@@ -130,6 +143,12 @@ def load():
         lib.vbh_decode_batch_end.argtypes = [C.c_void_p]
         lib.vbh_decoder_result.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Lattice)]
         lib.vbh_decoder_phase_cycles.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+        lib.vbh_faster_decoder_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(FasterCfg), C.c_int32, C.c_int32,
+                                                  C.POINTER(C.c_void_p)]
+        lib.vbh_faster_decoder_destroy.argtypes = [C.c_void_p]
+        lib.vbh_faster_decode_batch.argtypes = lib.vbh_decode_batch.argtypes
+        lib.vbh_faster_decoder_result.argtypes = [C.c_void_p, C.c_int32, C.POINTER(BestPath)]
+        lib.vbh_faster_cfg_default.argtypes = [C.POINTER(FasterCfg)]
         lib.vbh_decoder_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         lib.vbh_decoder_utt_timeline.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
     _LIB = lib

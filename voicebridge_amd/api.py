@@ -331,3 +331,36 @@ class LatticeDecoder:
         if self.h:
             self.lib.vbh_decoder_destroy(self.h)
             self.h = None
+
+
+class FasterDecoder:
+    """FasterDecoder (1-best Viterbi beam search) over a Graph (vbh_faster_*)."""
+
+    def __init__(self, ctx, graph, max_batch, max_frames, beam=16.0, max_active=2147483647, min_active=20, beam_delta=0.5,
+                 acoustic_scale=0.083333):
+        self.ctx, self.lib, self.graph = ctx, ctx.lib, graph
+        cfg = _lib.FasterCfg(beam, int(max_active), int(min_active), beam_delta, acoustic_scale)
+        h = C.c_void_p()
+        check(self.lib.vbh_faster_decoder_create(ctx.h, graph.h, C.byref(cfg), int(max_batch), int(max_frames), C.byref(h)),
+              "vbh_faster_decoder_create")
+        self.h = h
+        self.n_utt = 0
+
+    def decode(self, d_loglikes, frame_offsets, tid2pdf):
+        fo = np.ascontiguousarray(frame_offsets, np.int64)
+        t2p = np.ascontiguousarray(tid2pdf, np.int32)
+        self.n_utt = len(fo) - 1
+        check(self.lib.vbh_faster_decode_batch(self.h, d_loglikes.data_ptr(), int(d_loglikes.shape[1]), _i64p(fo), self.n_utt,
+                                               _i32p(t2p), len(t2p) - 1), "vbh_faster_decode_batch")
+
+    def result(self, u):
+        r = _lib.BestPath()
+        check(self.lib.vbh_faster_decoder_result(self.h, int(u), C.byref(r)), "vbh_faster_decoder_result")
+        return dict(ok=r.ok, reached_final=r.reached_final, num_frames=r.num_frames,
+                    ali=_arr(r.ali, r.num_ali, np.int32), words=_arr(r.words, r.num_words, np.int32),
+                    best_graph=r.best_graph, best_acoustic=r.best_acoustic, n_tokens=r.n_tokens)
+
+    def close(self):
+        if self.h:
+            self.lib.vbh_faster_decoder_destroy(self.h)
+            self.h = None

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvoicebridge_hip.so")
-HIP_SOURCES = ["vbh_ctx.hip", "vbh_mfcc.hip", "vbh_featpost.hip", "vbh_gmm.hip", "vbh_decode.hip"]
+HIP_SOURCES = ["vbh_ctx.hip", "vbh_mfcc.hip", "vbh_featpost.hip", "vbh_gmm.hip", "vbh_decode.hip", "vbh_faster.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
@@ -35,8 +35,9 @@ def build(force=False, verbose=True):
         objs.append(obj)
         if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
             extra = []
+            if s in ("vbh_decode.hip", "vbh_faster.hip"):
+                extra = ["-ffp-contract=off"]   # exact float32 / float64 cost expressions
             if s == "vbh_decode.hip":
-                extra = ["-ffp-contract=off"]   # exact float32 cost expressions
                 if os.environ.get("VBH_DECODE_NT"):
                     extra.append("-DVBH_DECODE_NT=" + os.environ["VBH_DECODE_NT"])
             cmd = [hipcc] + FLAGS + extra + ["-c", src, "-o", obj]

@@ -1559,6 +1559,26 @@ struct vbh_graph {
   std::vector<float> h_final;
 };
 
+void vbh_graph_view_get(const vbh_graph *g, vbh_graph_view *v) {
+  v->S = g->S; v->start = g->start; v->A = g->A; v->max_ilabel = g->max_ilabel; v->max_degree = g->max_degree;
+  v->st = g->st.p; v->arcs = g->arcs.p; v->arc_il = g->arc_il.p;
+}
+
+// the arcs' pdf fields depend on tid2pdf only: refill when the table changes (decoders that share a
+// graph on different streams must therefore use one table at a time)
+int vbh_graph_fill_pdf(const vbh_graph *g, hipStream_t st, const int32_t *h_t2p, int32_t num_tids) {
+  std::vector<int> t2p(h_t2p, h_t2p + num_tids + 1);
+  t2p[0] = 0;
+  if (g->A <= 0 || g->filled_t2p == t2p) return 0;
+  DevBuf<int> d_t2p;
+  if (d_t2p.upload(t2p.data(), t2p.size(), st)) return -1;
+  hipLaunchKernelGGL(fill_arc_pdf_kernel, dim3(1024), dim3(256), 0, st, g->arcs.p, g->arc_il.p, g->A, d_t2p.p);
+  VBH_HIP(hipGetLastError());
+  VBH_HIP(hipStreamSynchronize(st));
+  g->filled_t2p = t2p;
+  return 0;
+}
+
 struct HostLattice {
   std::vector<int32_t> tok_frame, tok_state, link_src, link_dst, link_il, link_ol, ali, words;
   std::vector<float> tok_cost, tok_extra, tok_final, link_gr, link_ac;
@@ -1971,14 +1991,7 @@ int vbh_decode_batch_begin(vbh_decoder *d, const float *d_loglikes, int32_t num_
   pool.tok_frame = p_tf.p; pool.tok_state = p_ts.p; pool.tok_cost = p_tc.p; pool.tok_extra = p_te.p; pool.tok_final = p_tfin.p;
   pool.link_src = p_ls.p; pool.link_dst = p_ld.p; pool.link_il = p_li.p; pool.link_ol = p_lo.p; pool.link_gr = p_lg.p; pool.link_ac = p_la.p;
   pool.cost_offsets = p_co.p; pool.counters = p_cnt.p;
-  // the arcs' pdf fields depend on tid2pdf only: refill when the table changes (decoders that share
-  // a graph on different streams must therefore use one table at a time)
-  if (g->A > 0 && g->filled_t2p != t2p) {
-    hipLaunchKernelGGL(fill_arc_pdf_kernel, dim3(1024), dim3(256), 0, st, g->arcs.p, g->arc_il.p, g->A, d->d_t2p.p);
-    VBH_HIP(hipGetLastError());
-    VBH_HIP(hipStreamSynchronize(st));
-    g->filled_t2p = t2p;
-  }
+  if (vbh_graph_fill_pdf(g, st, h_tid2pdf, num_tids)) return -1;
   DevBuf<Pool> &d_pool = d->d_pool;
   if (!d_pool.p && d_pool.alloc(1)) return -1;
   const DevGraph dg0{g->S, g->start, g->st.p, g->arcs.p, g->arc_il.p};

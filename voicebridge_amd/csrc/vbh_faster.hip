@@ -1,0 +1,792 @@
+// vbh_faster.hip -- FasterDecoder (1-best Viterbi beam search with back pointers) on gfx950.
+//
+// Replaces (paths relative to /root/reference/kaldi-master/src/):
+//   decoder/faster-decoder.cc:36-54    InitDecoding / Decode (frame loop)
+//   :151-213  GetCutoff (double costs, nth_element for max-/min-active, adaptive beam)
+//   :224-303  ProcessEmitting          :306-346  ProcessNonemitting
+//   :78-147   ReachedFinal / GetBestPath (back-pointer trace, (graph, acoustic) totals)
+//   decoder/faster-decoder.h:116-133   Token: cost = prev->cost + arc.weight [+ ac_cost], in double
+//
+// Same execution model as vbh_decode.hip (one 1024-thread workgroup per utterance, persistent
+// grid, per-frame state map in LDS, arcs spread over lanes by wave_expand); no lattice, so no
+// links, pruning passes or compaction: a token is {previous token, arc, state} + a double cost,
+// kept for the whole utterance for the back trace.
+//
+// Semantics = oracle/vb_oracle_decode.c with exact_cutoff = 1 (bit-exact, tests/test_gpu_faster.py;
+// that mode reproduces the reference's best paths on all its golden cases,
+// tests/test_oracle_decode.py): next_cutoff takes its final value (min over all candidate arcs of
+// new_weight + adaptive_beam) before anything is admitted; per state the cheapest incoming arc
+// wins and ties go to the smaller arc index; the epsilon closure runs to its fixed point before
+// tokens are made; ties between final tokens go to the smaller state id.  The reference's own
+// choices in those three places follow its hash-list order.
+#include "vbh_internal.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+
+namespace {
+
+constexpr int NT = 1024;
+constexpr int NW = NT / 64;
+constexpr int EPSBIT = (int)0x80000000;     // on an arc's next state: that state has epsilon arcs
+constexpr int STMASK = 0x3FFFFFFF;
+constexpr int HBITS = 13;
+constexpr int HCAP = 1 << HBITS;            // states per frame the LDS map can hold
+constexpr int HPROBE = 64;
+constexpr unsigned HEMPTY = 0xFFFFFFFFu;
+constexpr int MAX_EPS_ITERS = 4096;
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#define VBH_GLOBAL __attribute__((address_space(1)))
+template <class T> using gp = VBH_GLOBAL T *;
+
+__device__ __forceinline__ float asf(int x) { return __int_as_float(x); }
+
+struct FGraph { int S, start; const i32x4 *st; const i32x4 *arcs; const int *arc_il; };
+struct FCfg { float beam, beam_delta, acwt; int max_active, min_active; };
+
+struct FSlot {
+  i32x4 *tok;              // [tok_cap] {prev token, arc (-1: start), state | EPSBIT, 0}
+  double *cost;            // [tok_cap]
+  unsigned long long *win; // [frame_cap] winner key (arc << 32 | source token) per token of the frame being built
+  double *c_w;             // [cand_cap] candidate new_weight
+  i32x4 *c_r;              // [cand_cap] {arc, source token, next state | EPSBIT, 0}
+  int *front[3];           // epsilon work lists (states), rotated
+  unsigned *g_hs; unsigned long long *g_hc; int *g_ht;   // second level of the state map, [g_cap] (power of two)
+  int tok_cap, frame_cap, cand_cap, front_cap, g_cap;
+};
+
+struct FUtt { long long row0; int T; int pad; };
+struct FResult { int ok, error, reached_final, num_frames, path_len, final_state; float final_cost; int pad; long long n_tokens; };
+
+enum { FERR_NONE = 0, FERR_TOK = 1, FERR_FRAME = 2, FERR_CAND = 3, FERR_FRONT = 4, FERR_MAP = 5, FERR_EPS = 6, FERR_PATH = 7 };
+
+// order-preserving map double -> uint64
+__device__ __forceinline__ unsigned long long d2o(double d) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(d);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double o2d(unsigned long long o) {
+  const unsigned long long u = (o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFull) : ~o;
+  return __longlong_as_double((long long)u);
+}
+template <class T>
+__device__ __forceinline__ gp<T> uptr(T *p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (gp<T>)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int wave_alloc(int *counter, bool want) {
+  const unsigned long long m = __ballot(want);
+  if (m == 0) return -1;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)m) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, __popcll(m));
+  base = __builtin_amdgcn_readlane(base, leader);
+  return want ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+// see vbh_decode.hip: sub-items of up to 64 items dealt out evenly over the lanes of a wave
+template <class F>
+__device__ __forceinline__ void wave_expand(int cnt, F body) {
+  const int lane = threadIdx.x & 63;
+  const int incl = wave_incl_scan(cnt);
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  const int excl = incl - cnt;
+  for (int k0 = 0; k0 < total; k0 += 64) {
+    const int k = k0 + lane;
+    int lo = 0;
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) {
+      const int v = __shfl(incl, lo + step - 1, 64);
+      if (v <= k) lo += step;
+    }
+    const bool valid = k < total;
+    const int owner = valid ? lo : 0;
+    const int j = k - __shfl(excl, owner, 64);
+    body(valid, owner, j);
+  }
+}
+__device__ __forceinline__ int wave_chunk(int n) {
+  const int c = (n + NW - 1) / NW;
+  return c < 1 ? 1 : (c > 64 ? 64 : c);
+}
+
+struct Shared {
+  unsigned long long red[2][NW];
+  unsigned hist[256];
+  unsigned hs[HCAP];               // state map of the frame being built: tag,
+  unsigned long long hc[HCAP];     // best cost (order-preserving key),
+  int ht[HCAP];                    // index of the state's token within the frame
+  int n_new, n_cand, fcnt[3], error, utt;
+  int g_used;                      // the second level holds entries of the frame being built
+  unsigned long long sel_prefix, sel_mask; int sel_k;
+  unsigned long long u0;
+};
+
+__device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v, Shared &sh, int &par) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
+  if ((threadIdx.x & 63) == 0) sh.red[par][threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned long long r = sh.red[par][0];
+#pragma unroll
+  for (int i = 1; i < NW; i++) r = sh.red[par][i] < r ? sh.red[par][i] : r;
+  par ^= 1;
+  return r;
+}
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, Shared &sh, int &par) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sh.red[par][threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned long long r = 0;
+#pragma unroll
+  for (int i = 0; i < NW; i++) r += sh.red[par][i];
+  par ^= 1;
+  return r;
+}
+
+// k-th smallest (0-based) of cost[0..n): radix select over the 64-bit order-preserving keys
+// (the std::nth_element value in GetCutoff, faster-decoder.cc:171-196)
+__device__ double select_kth(gp<const double> cost, int n, int k, Shared &sh) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if (tid == 0) { sh.sel_prefix = 0; sh.sel_mask = 0; sh.sel_k = k; }
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 256; i += NT) sh.hist[i] = 0;
+    __syncthreads();
+    const unsigned long long prefix = sh.sel_prefix, mask = sh.sel_mask;
+    for (int i = tid; i < n; i += NT) {
+      const unsigned long long key = d2o(cost[i]);
+      if ((key & mask) == prefix) atomicAdd(&sh.hist[(unsigned)(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int kk = sh.sel_k;
+      const int h0 = (int)sh.hist[4 * tid], h1 = (int)sh.hist[4 * tid + 1], h2 = (int)sh.hist[4 * tid + 2], h3 = (int)sh.hist[4 * tid + 3];
+      const int mine = h0 + h1 + h2 + h3;
+      const int incl = wave_incl_scan(mine);
+      const unsigned long long m = __ballot(incl > kk);
+      const int owner = m ? __ffsll((long long)m) - 1 : 63;
+      if (tid == owner) {
+        int r = kk - (incl - mine), b = 0;
+        if (r >= h0) { r -= h0; b = 1; if (r >= h1) { r -= h1; b = 2; if (r >= h2) { r -= h2; b = 3; } } }
+        sh.sel_k = r;
+        sh.sel_prefix = prefix | ((unsigned long long)(4 * tid + b) << shift);
+        sh.sel_mask = mask | (255ull << shift);
+      }
+    }
+    __syncthreads();
+  }
+  return o2d(sh.sel_prefix);
+}
+
+// ---- state map of the frame being built: state -> (best cost, index of its token in the frame).
+// First level: open addressing in LDS (tag claimed with atomicCAS, cost lowered with a 64-bit
+// atomicMin on the order-preserving key).  A state whose HPROBE probe slots are all taken goes to the
+// second level, the same table in HBM (g_cap slots, cleared only after frames that used it); slots
+// are never freed within a frame, so a state always resolves to the same level.  A slot handle is
+// >= 0 for LDS, <= -2 for HBM slot -(handle + 2), -1 for "no room".
+struct Map2 { gp<unsigned> gs; gp<unsigned long long> gc; gp<int> gt; int gmask; };
+__device__ __forceinline__ Map2 map2_of(const FSlot &s) { Map2 m; m.gs = uptr(s.g_hs); m.gc = uptr(s.g_hc); m.gt = uptr(s.g_ht); m.gmask = s.g_cap - 1; return m; }
+__device__ __forceinline__ unsigned map_hash(int st) { return ((unsigned)st * 2654435761u) >> (32 - HBITS); }
+__device__ __forceinline__ unsigned map_hash2(int st, int gmask) { return (((unsigned)st * 2246822519u) >> 7) & (unsigned)gmask; }
+__device__ __forceinline__ int map_find(const Shared &sh, const Map2 &m, int st) {
+  unsigned h = map_hash(st);
+#pragma unroll 1
+  for (int p = 0; p < HPROBE; p++, h = (h + 1) & (HCAP - 1)) {
+    const unsigned cur = sh.hs[h];
+    if (cur == (unsigned)st) return (int)h;
+    if (cur == HEMPTY) return -1;
+  }
+  if (!sh.g_used) return -1;
+  h = map_hash2(st, m.gmask);
+#pragma unroll 1
+  for (int p = 0; p <= m.gmask; p++, h = (h + 1) & (unsigned)m.gmask) {
+    const unsigned cur = __hip_atomic_load(&m.gs[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == (unsigned)st) return -(int)h - 2;
+    if (cur == HEMPTY) return -1;
+  }
+  return -1;
+}
+__device__ __forceinline__ unsigned long long map_key(const Shared &sh, const Map2 &m, int slot) {
+  return slot >= 0 ? sh.hc[slot] : __hip_atomic_load(&m.gc[-slot - 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int map_idx(const Shared &sh, const Map2 &m, int slot) {
+  return slot >= 0 ? sh.ht[slot] : __hip_atomic_load(&m.gt[-slot - 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void map_set_idx(Shared &sh, const Map2 &m, int slot, int li) {
+  if (slot >= 0) sh.ht[slot] = li; else __hip_atomic_store(&m.gt[-slot - 2], li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// lower the cost of state ds; slot == -1: no room.  create: first to reach ds; improved: cost went down
+__device__ __forceinline__ void map_relax(Shared &sh, const Map2 &m, int ds, double cost, int &slot, bool &create, bool &improved) {
+  slot = -1; create = false; improved = false;
+  const unsigned long long ck = d2o(cost);
+  unsigned h = map_hash(ds);
+#pragma unroll 1
+  for (int p = 0; p < HPROBE; p++, h = (h + 1) & (HCAP - 1)) {
+    unsigned cur = sh.hs[h];
+    if (cur == HEMPTY) {
+      cur = atomicCAS(&sh.hs[h], HEMPTY, (unsigned)ds);
+      if (cur == HEMPTY) { create = true; slot = (int)h; break; }
+    }
+    if (cur == (unsigned)ds) { slot = (int)h; break; }
+  }
+  if (slot >= 0) {
+    const unsigned long long oc = atomicMin(&sh.hc[slot], ck);
+    improved = ck < oc;
+    return;
+  }
+  sh.g_used = 1;
+  h = map_hash2(ds, m.gmask);
+#pragma unroll 1
+  for (int p = 0; p <= m.gmask; p++, h = (h + 1) & (unsigned)m.gmask) {
+    unsigned cur = __hip_atomic_load(&m.gs[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == HEMPTY) {
+      unsigned expect = HEMPTY;
+      if (__hip_atomic_compare_exchange_strong(&m.gs[h], &expect, (unsigned)ds, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+        create = true; slot = -(int)h - 2; break;
+      }
+      cur = expect;
+    }
+    if (cur == (unsigned)ds) { slot = -(int)h - 2; break; }
+  }
+  if (slot == -1) return;
+  const unsigned long long oc = __hip_atomic_fetch_min(&m.gc[-slot - 2], ck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  improved = ck < oc;
+}
+// empty map for the next frame (all threads; followed by a barrier at the caller)
+__device__ __forceinline__ void map_clear(Shared &sh, const FSlot &s) {
+  for (int i = threadIdx.x; i < HCAP; i += NT) { sh.hs[i] = HEMPTY; sh.hc[i] = ~0ull; }
+  if (sh.g_used) {
+    gp<unsigned> gs = uptr(s.g_hs); gp<unsigned long long> gc = uptr(s.g_hc);
+    for (int i = threadIdx.x; i < s.g_cap; i += NT) { gs[i] = HEMPTY; gc[i] = ~0ull; }
+  }
+}
+
+// ProcessNonemitting (faster-decoder.cc:306-346) to the fixed point: work lists hold states; a
+// state whose cost exceeds the cutoff is not expanded, an arc that would is dropped.
+__device__ void epsilon_closure(const FGraph &g, const FSlot &s, double cutoff, Shared &sh) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  gp<unsigned long long> win = uptr(s.win);
+  const Map2 m2 = map2_of(s);
+  const int frame_cap = s.frame_cap, front_cap = s.front_cap;
+  int cur = 0;
+  for (int iter = 0;; iter++) {
+    const int ncur = sh.fcnt[cur] < front_cap ? sh.fcnt[cur] : front_cap;
+    if (ncur == 0) break;
+    if (iter >= MAX_EPS_ITERS) { if (tid == 0) sh.error = FERR_EPS; break; }
+    const int nxt = cur == 2 ? 0 : cur + 1, spare = nxt == 2 ? 0 : nxt + 1;
+    if (tid == 0) sh.fcnt[spare] = 0;
+    gp<const int> fcur = uptr(s.front[cur]);
+    gp<int> fnext = uptr(s.front[nxt]);
+    const int CH = wave_chunk(ncur);
+    for (int base = wave * CH; base < ncur; base += NW * CH) {
+      const int i = base + lane;
+      const bool have = lane < CH && i < ncur;
+      const int st = have ? fcur[i] : 0;
+      const i32x4 sr = uptr(g.st)[st];
+      const int slot = have ? map_find(sh, m2, st) : -1;
+      const double c = slot != -1 ? o2d(map_key(sh, m2, slot)) : 0.0;
+      const bool exp = have && slot != -1 && !(c > cutoff);
+      const int a0 = sr.x, cnt = exp ? sr.y : 0;
+      wave_expand(cnt, [&](bool valid, int owner, int j) {
+        const int a = __shfl(a0, owner, 64) + j;
+        const double cc = __shfl(c, owner, 64);
+        bool create = false, push = false; int ds = 0, nslot = -1;   // (-1: none / no room)
+        if (valid) {
+          const i32x4 arc = uptr(g.arcs)[a];
+          const double nc = cc + (double)asf(arc.y);
+          if (!(nc > cutoff)) {
+            ds = arc.x & STMASK;
+            bool improved;
+            map_relax(sh, m2, ds, nc, nslot, create, improved);
+            if (nslot == -1) sh.error = FERR_MAP;
+            push = nslot != -1 && (create || improved) && arc.x < 0;
+          }
+        }
+        const int li = wave_alloc(&sh.n_new, create);
+        if (create) {
+          if (li < frame_cap) { map_set_idx(sh, m2, nslot, li); win[li] = ~0ull; }
+          else sh.error = FERR_FRAME;
+        }
+        const int q = wave_alloc(&sh.fcnt[nxt], push);
+        if (push) { if (q < front_cap) fnext[q] = ds; else sh.error = FERR_FRONT; }
+      });
+    }
+    __syncthreads();
+    if (sh.error != FERR_NONE) break;
+    cur = nxt;
+  }
+  __syncthreads();
+}
+
+// entry e of the frame's map: LDS slots first, then (if used) the HBM slots
+__device__ __forceinline__ bool map_entry(const Shared &sh, const Map2 &m, int e, int &state, unsigned long long &key, int &li) {
+  if (e < HCAP) {
+    const unsigned tag = sh.hs[e];
+    if (tag == HEMPTY) return false;
+    state = (int)tag; key = sh.hc[e]; li = sh.ht[e];
+    return true;
+  }
+  const unsigned tag = m.gs[e - HCAP];
+  if (tag == HEMPTY) return false;
+  state = (int)tag; key = m.gc[e - HCAP]; li = m.gt[e - HCAP];
+  return true;
+}
+
+// the winning epsilon arc of every state: all states of the frame that have epsilon arcs re-walk
+// them with the final costs; an arc that reproduces its destination's cost competes with its index
+__device__ void epsilon_winners(const FGraph &g, const FSlot &s, double cutoff, int tok_base, Shared &sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  gp<unsigned long long> win = uptr(s.win);
+  const Map2 m2 = map2_of(s);
+  const int n_ent = HCAP + (sh.g_used ? s.g_cap : 0);
+  for (int base = wave * 64; base < n_ent; base += NW * 64) {
+    int st = 0, li = 0; unsigned long long key = 0;
+    const bool have = map_entry(sh, m2, base + lane, st, key, li);
+    const double c = have ? o2d(key) : 0.0;
+    int a0 = 0, cnt = 0;
+    if (have && !(c > cutoff)) { const i32x4 sr = uptr(g.st)[st]; a0 = sr.x; cnt = sr.y; }
+    const int my_tok = have ? tok_base + li : 0;
+    wave_expand(cnt, [&](bool valid, int owner, int j) {
+      const int a = __shfl(a0, owner, 64) + j;
+      const double cc = __shfl(c, owner, 64);
+      const int src_tok = __shfl(my_tok, owner, 64);
+      if (valid) {
+        const i32x4 arc = uptr(g.arcs)[a];
+        const double nc = cc + (double)asf(arc.y);
+        if (!(nc > cutoff)) {
+          const int ds_slot = map_find(sh, m2, arc.x & STMASK);
+          if (ds_slot != -1 && d2o(nc) == map_key(sh, m2, ds_slot))
+            (void)__hip_atomic_fetch_min(&win[map_idx(sh, m2, ds_slot)], ((unsigned long long)(unsigned)a << 32) | (unsigned)src_tok,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    });
+  }
+}
+
+// one token per map entry, appended to the utterance's history at tok_base
+__device__ void make_tokens(const FSlot &s, int tok_base, Shared &sh) {
+  gp<i32x4> tok = uptr(s.tok); gp<double> cost = uptr(s.cost);
+  gp<const unsigned long long> win = uptr(s.win);
+  const Map2 m2 = map2_of(s);
+  const int n_ent = HCAP + (sh.g_used ? s.g_cap : 0);
+  for (int e = threadIdx.x; e < n_ent; e += NT) {
+    int st, li; unsigned long long key;
+    if (!map_entry(sh, m2, e, st, key, li)) continue;
+    const unsigned long long w = win[li];
+    i32x4 r; r.x = (int)(unsigned)w; r.y = (int)(unsigned)(w >> 32); r.z = st; r.w = 0;
+    if (w == ~0ull) { r.x = -1; r.y = -1; }      // the start token
+    tok[tok_base + li] = r;
+    cost[tok_base + li] = o2d(key);
+  }
+}
+
+__global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const FSlot *slots, const float *__restrict__ loglikes, int P,
+                                                       const FUtt *__restrict__ utts, int n_work, int *work_counter, FResult *results,
+                                                       i32x4 *paths, int path_cap) {   // best path per utterance, last arc first: {ilabel, olabel, weight, tot_cost}
+  __shared__ Shared sh;
+  __shared__ FSlot s_slot;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    const int *src = reinterpret_cast<const int *>(&slots[blockIdx.x]);
+    int *dst = reinterpret_cast<int *>(&s_slot);
+    for (int i = tid; i < (int)(sizeof(FSlot) / sizeof(int)); i += NT) dst[i] = src[i];
+  }
+  __syncthreads();
+  const FSlot &s = s_slot;
+  int par = 0;
+  while (true) {
+    __syncthreads();
+    if (tid == 0) sh.utt = atomicAdd(work_counter, 1);
+    __syncthreads();
+    if (sh.utt >= n_work) break;
+    const int utt = sh.utt;
+    const FUtt ud = utts[utt];
+    const int T = ud.T;
+    gp<i32x4> tok = uptr(s.tok); gp<double> cost = uptr(s.cost);
+    gp<unsigned long long> win = uptr(s.win);
+    gp<double> c_w = uptr(s.c_w); gp<i32x4> c_r = uptr(s.c_r);
+    const Map2 m2 = map2_of(s);
+    if (tid == 0) sh.g_used = 1;       // a previous utterance may have left entries in the second level
+    __syncthreads();
+    map_clear(sh, s);
+    __syncthreads();
+    if (tid == 0) { sh.n_new = 0; sh.n_cand = 0; sh.fcnt[0] = sh.fcnt[1] = sh.fcnt[2] = 0; sh.error = FERR_NONE; sh.g_used = 0; }
+    __syncthreads();
+    // ---- InitDecoding (:36-45): the start token, then the epsilon closure with cutoff FLT_MAX
+    if (tid == 0) {
+      int slot; bool create, improved;
+      map_relax(sh, m2, g.start, 0.0, slot, create, improved);
+      map_set_idx(sh, m2, slot, 0); uptr(s.win)[0] = ~0ull; sh.n_new = 1;
+      if (uptr(g.st)[g.start].y > 0) { uptr(s.front[0])[0] = g.start; sh.fcnt[0] = 1; }
+    }
+    __syncthreads();
+    epsilon_closure(g, s, (double)FLT_MAX, sh);
+    int cur_b = 0, cur_n = sh.n_new < s.frame_cap ? sh.n_new : s.frame_cap;
+    if (cur_n > s.tok_cap && tid == 0) sh.error = FERR_TOK;
+    __syncthreads();
+    if (sh.error == FERR_NONE) {
+      epsilon_winners(g, s, (double)FLT_MAX, 0, sh);
+      __syncthreads();
+      make_tokens(s, 0, sh);
+    }
+    __syncthreads();
+    int frames_done = 0;
+    for (int frame = 0; frame < T && sh.error == FERR_NONE; frame++) {
+      const float *llrow = loglikes + (ud.row0 + frame) * (long long)P;
+      gp<const double> ccost = cost + cur_b;
+      gp<const i32x4> ctok = tok + cur_b;
+      const int n = cur_n;
+      // ---- GetCutoff (:151-213), in double
+      unsigned long long bk = ~0ull;
+      for (int i = tid; i < n; i += NT) { const unsigned long long k = d2o(ccost[i]); bk = k < bk ? k : bk; }
+      bk = block_min_u64(bk, sh, par);
+      const double best = n > 0 ? o2d(bk) : (double)INFINITY;
+      double weight_cutoff; float adaptive_beam;
+      if (cfg.max_active == INT_MAX && cfg.min_active == 0) { adaptive_beam = cfg.beam; weight_cutoff = best + cfg.beam; }
+      else {
+        const double beam_cutoff = best + cfg.beam;
+        double mac = (double)INFINITY, mic = (double)INFINITY;
+        if (n > cfg.max_active) mac = select_kth(ccost, n, cfg.max_active, sh);
+        if (mac < beam_cutoff) { adaptive_beam = (float)(mac - best + cfg.beam_delta); weight_cutoff = mac; }
+        else {
+          if (n > cfg.min_active) mic = cfg.min_active == 0 ? best : select_kth(ccost, n, cfg.min_active, sh);
+          if (mic > beam_cutoff) { adaptive_beam = (float)(mic - best + cfg.beam_delta); weight_cutoff = mic; }
+          else { adaptive_beam = cfg.beam; weight_cutoff = beam_cutoff; }
+        }
+      }
+      // the map of the frame about to be built
+      map_clear(sh, s);
+      __syncthreads();
+      if (tid == 0) { sh.n_new = 0; sh.n_cand = 0; sh.fcnt[0] = sh.fcnt[1] = sh.fcnt[2] = 0; sh.g_used = 0; }
+      __syncthreads();
+      // ---- pass 1 (:224-303, arc-parallel): candidates + min of new_weight + adaptive_beam
+      unsigned long long mymin = ~0ull;
+      {
+        const int cand_cap = s.cand_cap;
+        const int CH = wave_chunk(n);
+        for (int base = wave * CH; base < n; base += NW * CH) {
+          const int i = base + lane;
+          const bool have = lane < CH && i < n;
+          const i32x4 rec = ctok[have ? i : 0];
+          const double c = ccost[have ? i : 0];
+          const bool exp = have && c < weight_cutoff;
+          const i32x4 sr = uptr(g.st)[exp ? (rec.z & STMASK) : 0];
+          const int a0 = sr.x + sr.y, cnt = exp ? sr.z - sr.y : 0;
+          wave_expand(cnt, [&](bool valid, int owner, int j) {
+            const int a = __shfl(a0, owner, 64) + j;
+            const double cc = __shfl(c, owner, 64);
+            i32x4 arc; double nw = 0.0;
+            if (valid) {
+              arc = uptr(g.arcs)[a];
+              const float ac_cost = -(cfg.acwt * llrow[arc.z]);
+              nw = ((double)asf(arc.y) + cc) + (double)ac_cost;    // arc.weight + tok->cost + ac_cost
+              const unsigned long long k = d2o(nw + (double)adaptive_beam);
+              mymin = k < mymin ? k : mymin;
+            }
+            const int q = wave_alloc(&sh.n_cand, valid);
+            if (valid) {
+              if (q < cand_cap) {
+                c_w[q] = nw;
+                i32x4 r; r.x = a; r.y = cur_b + base + owner; r.z = arc.x; r.w = 0;
+                c_r[q] = r;
+              } else sh.error = FERR_CAND;
+            }
+          });
+        }
+      }
+      mymin = block_min_u64(mymin, sh, par);
+      const double next_cutoff = mymin == ~0ull ? (double)INFINITY : o2d(mymin);
+      const int ncand = sh.n_cand < s.cand_cap ? sh.n_cand : s.cand_cap;
+      // ---- pass 2: admit new_weight < next_cutoff; cheapest per state
+      {
+        gp<int> front0 = uptr(s.front[0]);
+        const int frame_cap = s.frame_cap, front_cap = s.front_cap;
+        for (int base = 0; base < ncand; base += NT) {
+          const int q = base + tid;
+          const bool ok = q < ncand;
+          const double nw = c_w[ok ? q : 0];
+          const i32x4 r = c_r[ok ? q : 0];
+          const bool adm = ok && nw < next_cutoff;
+          int slot = -1; bool create = false, improved;
+          if (adm) { map_relax(sh, m2, r.z & STMASK, nw, slot, create, improved); if (slot == -1) sh.error = FERR_MAP; }
+          const int li = wave_alloc(&sh.n_new, create);
+          bool pushf = false;
+          if (create) {
+            if (li < frame_cap) { map_set_idx(sh, m2, slot, li); win[li] = ~0ull; pushf = r.z < 0; }
+            else sh.error = FERR_FRAME;
+          }
+          const int f = wave_alloc(&sh.fcnt[0], pushf);
+          if (pushf) { if (f < front_cap) front0[f] = r.z & STMASK; else sh.error = FERR_FRONT; }
+        }
+      }
+      __syncthreads();
+      if (sh.error != FERR_NONE) break;
+      // ---- ProcessNonemitting(next_cutoff) to the fixed point
+      epsilon_closure(g, s, next_cutoff, sh);
+      if (sh.error != FERR_NONE) break;
+      const int nb = cur_b + cur_n;
+      const int n_new = sh.n_new < s.frame_cap ? sh.n_new : s.frame_cap;
+      if (nb + n_new > s.tok_cap) { if (tid == 0) sh.error = FERR_TOK; __syncthreads(); break; }
+      // ---- winners: the emitting candidates and the epsilon arcs that reproduce a state's final cost
+      for (int base = 0; base < ncand; base += NT) {
+        const int q = base + tid;
+        const bool ok = q < ncand;
+        const double nw = c_w[ok ? q : 0];
+        const i32x4 r = c_r[ok ? q : 0];
+        if (ok && nw < next_cutoff) {
+          const int slot = map_find(sh, m2, r.z & STMASK);
+          if (slot != -1 && d2o(nw) == map_key(sh, m2, slot))
+            (void)__hip_atomic_fetch_min(&win[map_idx(sh, m2, slot)], ((unsigned long long)(unsigned)r.x << 32) | (unsigned)r.y,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      epsilon_winners(g, s, next_cutoff, nb, sh);
+      __syncthreads();
+      make_tokens(s, nb, sh);
+      __syncthreads();
+      cur_b = nb; cur_n = n_new;
+      frames_done = frame + 1;
+    }
+    __syncthreads();
+    // ---- ReachedFinal / GetBestPath (:78-147)
+    int r_ok = 0, r_final = 0, r_len = 0, r_state = -1; float r_fc = 0.0f;
+    if (sh.error == FERR_NONE && frames_done == T) {
+      gp<const double> ccost = cost + cur_b;
+      gp<const i32x4> ctok = tok + cur_b;
+      unsigned long long anyf = 0;
+      for (int i = tid; i < cur_n; i += NT) {
+        const float fc = asf(uptr(g.st)[ctok[i].z & STMASK].w);
+        anyf += (ccost[i] != (double)INFINITY && fc != INFINITY);
+      }
+      anyf = block_sum_u64(anyf, sh, par);
+      const bool is_final = anyf > 0;
+      unsigned long long bkey = ~0ull;
+      for (int i = tid; i < cur_n; i += NT) {
+        const double c = is_final ? ccost[i] + (double)asf(uptr(g.st)[ctok[i].z & STMASK].w) : ccost[i];
+        if (is_final && c == (double)INFINITY) continue;
+        const unsigned long long k = d2o(c);
+        bkey = k < bkey ? k : bkey;
+      }
+      bkey = block_min_u64(bkey, sh, par);
+      unsigned long long bsel = ~0ull;      // among the tokens at the best cost: smallest state (<< 32 | index)
+      for (int i = tid; i < cur_n; i += NT) {
+        const int st = ctok[i].z & STMASK;
+        const double c = is_final ? ccost[i] + (double)asf(uptr(g.st)[st].w) : ccost[i];
+        if (is_final && c == (double)INFINITY) continue;
+        if (d2o(c) == bkey) { const unsigned long long k = ((unsigned long long)(unsigned)st << 32) | (unsigned)i; bsel = k < bsel ? k : bsel; }
+      }
+      bsel = block_min_u64(bsel, sh, par);
+      if (bsel != ~0ull && cur_n > 0) {
+        r_ok = 1; r_final = is_final; r_state = (int)(bsel >> 32);
+        r_fc = asf(uptr(g.st)[r_state].w);
+        if (tid == 0) {     // back trace, last arc first
+          gp<i32x4> path = (gp<i32x4>)(paths + (size_t)utt * path_cap);
+          int t = cur_b + (int)(unsigned)bsel, len = 0, err = 0;
+          while (true) {
+            const i32x4 r = tok[t];
+            if (r.x < 0) break;                     // the start token
+            const double c = cost[t], pc = cost[r.x];
+            const i32x4 arc = uptr(g.arcs)[r.y];
+            if (len < path_cap) {
+              i32x4 o; o.x = uptr(g.arc_il)[r.y]; o.y = arc.w; o.z = arc.y; o.w = __float_as_int((float)(c - pc));
+              path[len] = o;
+            } else err = 1;
+            len++;
+            t = r.x;
+          }
+          sh.u0 = ((unsigned long long)(unsigned)err << 32) | (unsigned)len;
+        }
+        __syncthreads();
+        r_len = (int)(unsigned)sh.u0;
+        if (sh.u0 >> 32) { if (tid == 0) sh.error = FERR_PATH; }
+        __syncthreads();
+      }
+    }
+    if (tid == 0) {
+      FResult *r = &results[utt];
+      r->ok = r_ok; r->error = sh.error; r->reached_final = r_final; r->num_frames = frames_done; r->path_len = r_len;
+      r->final_state = r_state; r->final_cost = r_fc; r->pad = 0; r->n_tokens = cur_b + cur_n;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+// ============================================================================ host side
+struct vbh_faster_decoder {
+  vbh_ctx *ctx; const vbh_graph *graph; vbh_faster_cfg cfg;
+  int max_frames, n_slots;
+  FSlot proto{};
+  std::vector<FSlot> h_slots;
+  DevBuf<FSlot> d_slots;
+  std::vector<void *> allocs;
+  struct Out { std::vector<int32_t> ali, words; vbh_best_path view; };
+  std::vector<Out> results;
+};
+
+static const char *ferr_name(int e) {
+  switch (e) {
+    case FERR_TOK: return "token history capacity exceeded";
+    case FERR_FRAME: return "more new tokens in one frame than the slot was sized for";
+    case FERR_CAND: return "candidate list capacity exceeded";
+    case FERR_FRONT: return "epsilon work-list capacity exceeded";
+    case FERR_MAP: return "state map full (more new states in one frame than the slot was sized for)";
+    case FERR_EPS: return "epsilon closure did not converge (epsilon cycle in the graph?)";
+    case FERR_PATH: return "best path longer than the trace buffer";
+    default: return "unknown";
+  }
+}
+
+extern "C" {
+
+void vbh_faster_cfg_default(vbh_faster_cfg *c) {
+  // faster-decoder.h:38-43 (FasterDecoderOptions), acoustic scale as in VB/scr/kaldi_scr.h:152-157
+  c->beam = 16.0f; c->max_active = INT_MAX; c->min_active = 20; c->beam_delta = 0.5f; c->acoustic_scale = 0.083333f;
+}
+
+int vbh_faster_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_faster_cfg *cfg, int32_t max_batch,
+                              int32_t max_frames, vbh_faster_decoder **out) {
+  VBH_CHECK(ctx && graph && cfg && out, "vbh_faster_decoder_create: NULL argument");
+  VBH_CHECK(cfg->beam > 0.0f && cfg->max_active > 1 && cfg->min_active >= 0 && cfg->min_active < cfg->max_active && cfg->beam_delta > 0.0f,
+            "vbh_faster_decoder_create: invalid config (FasterDecoderOptions::Check)");
+  VBH_CHECK(max_batch >= 1 && max_frames >= 0, "vbh_faster_decoder_create: bad batch/frames");
+  if (vbh_use_device(ctx)) return -1;
+  vbh_graph_view gv; vbh_graph_view_get(graph, &gv);
+  vbh_faster_decoder *d = new vbh_faster_decoder();
+  d->ctx = ctx; d->graph = graph; d->cfg = *cfg; d->max_frames = max_frames;
+  d->n_slots = std::min<int>(max_batch, ctx->num_cus);
+  FSlot p{};
+  // new tokens per frame: bounded by the states; beyond the on-chip map the HBM level takes over
+  const long long ma = std::min<long long>(cfg->max_active, gv.S);
+  p.frame_cap = (int)std::min<long long>(std::max<long long>(gv.S, 1), std::max<long long>(4 * HCAP, std::min<long long>(4 * ma, 1 << 20)));
+  p.g_cap = 1;
+  while (p.g_cap < 2 * p.frame_cap) p.g_cap <<= 1;
+  const long long avg = std::min<long long>(p.frame_cap, 2048);          // tokens per frame the history is sized for
+  p.tok_cap = (int)std::min<long long>(avg * ((long long)max_frames + 2) + p.frame_cap, 1LL << 28);
+  p.cand_cap = (int)std::min<long long>(std::max<long long>(gv.A, 1), (long long)p.frame_cap * std::max(gv.max_degree, 1));
+  p.cand_cap = std::min(p.cand_cap, 1 << 22);
+  p.front_cap = 2 * p.frame_cap;
+  d->proto = p;
+  d->h_slots.assign(d->n_slots, p);
+  const size_t ns = (size_t)d->n_slots;
+#define A_(field, type, count)                                                                      \
+  {                                                                                                 \
+    type *base = nullptr;                                                                           \
+    hipError_t e_ = hipMalloc(reinterpret_cast<void **>(&base), sizeof(type) * (size_t)(count) * ns); \
+    if (e_ != hipSuccess) { vbh_set_error("vbh_faster_decoder_create: hipMalloc failed: %s", hipGetErrorString(e_)); vbh_faster_decoder_destroy(d); return -1; } \
+    d->allocs.push_back(base);                                                                      \
+    for (size_t i = 0; i < ns; i++) d->h_slots[i].field = base + i * (size_t)(count);               \
+  }
+  A_(tok, i32x4, p.tok_cap) A_(cost, double, p.tok_cap) A_(win, unsigned long long, p.frame_cap)
+  A_(c_w, double, p.cand_cap) A_(c_r, i32x4, p.cand_cap)
+  A_(front[0], int, p.front_cap) A_(front[1], int, p.front_cap) A_(front[2], int, p.front_cap)
+  A_(g_hs, unsigned, p.g_cap) A_(g_hc, unsigned long long, p.g_cap) A_(g_ht, int, p.g_cap)
+#undef A_
+  if (d->d_slots.upload(d->h_slots.data(), d->h_slots.size(), ctx->stream)) { vbh_faster_decoder_destroy(d); return -1; }
+  VBH_HIP(hipStreamSynchronize(ctx->stream));
+  *out = d;
+  return 0;
+}
+
+void vbh_faster_decoder_destroy(vbh_faster_decoder *d) {
+  if (!d) return;
+  (void)hipSetDevice(d->ctx->device);
+  (void)hipStreamSynchronize(d->ctx->stream);
+  for (void *p : d->allocs) (void)hipFree(p);
+  delete d;
+}
+
+int vbh_faster_decode_batch(vbh_faster_decoder *d, const float *d_loglikes, int32_t num_pdfs, const int64_t *h_frame_offsets,
+                            int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids) {
+  VBH_CHECK(d && h_frame_offsets && h_tid2pdf, "vbh_faster_decode_batch: NULL argument");
+  VBH_CHECK(n_utt >= 0 && num_pdfs > 0 && num_tids >= 0, "vbh_faster_decode_batch: bad sizes");
+  if (vbh_use_device(d->ctx)) return -1;
+  d->results.clear();
+  if (n_utt == 0) return 0;
+  vbh_graph_view gv; vbh_graph_view_get(d->graph, &gv);
+  VBH_CHECK(gv.max_ilabel <= num_tids, "vbh_faster_decode_batch: graph uses transition-id %d but the model has %d (graph/model mismatch)", gv.max_ilabel, num_tids);
+  for (int t = 1; t <= num_tids; t++)
+    VBH_CHECK(h_tid2pdf[t] >= 0 && h_tid2pdf[t] < num_pdfs, "vbh_faster_decode_batch: tid2pdf[%d] = %d out of range", t, h_tid2pdf[t]);
+  std::vector<FUtt> utts(n_utt);
+  long long total = 0;
+  for (int u = 0; u < n_utt; u++) {
+    const long long T = h_frame_offsets[u + 1] - h_frame_offsets[u];
+    VBH_CHECK(T >= 0 && T <= d->max_frames, "vbh_faster_decode_batch: utterance %d has %lld frames (decoder built for %d)", u, T, d->max_frames);
+    utts[u] = FUtt{h_frame_offsets[u], (int)T, 0};
+    total += T;
+  }
+  VBH_CHECK(total == 0 || d_loglikes, "vbh_faster_decode_batch: NULL loglikes");
+  hipStream_t st = d->ctx->stream;
+  if (vbh_graph_fill_pdf(d->graph, st, h_tid2pdf, num_tids)) return -1;
+  FGraph fg{gv.S, gv.start, static_cast<const i32x4 *>(gv.st), static_cast<const i32x4 *>(gv.arcs), gv.arc_il};
+  FCfg fc{d->cfg.beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active};
+  std::vector<FResult> res(n_utt);
+  d->results.resize(n_utt);
+  const int path_cap = 4 * (d->max_frames + 2) + 64;
+  DevBuf<FUtt> d_utts; DevBuf<int> d_counter; DevBuf<FResult> d_res; DevBuf<i32x4> d_paths;
+  if (d_utts.upload(utts.data(), utts.size(), st) || d_counter.alloc(1) || d_res.alloc(n_utt) || d_paths.alloc((size_t)n_utt * path_cap)) return -1;
+  VBH_HIP(hipMemsetAsync(d_counter.p, 0, sizeof(int), st));
+  hipLaunchKernelGGL(faster_kernel, dim3(std::min(d->n_slots, n_utt)), dim3(NT), 0, st, fg, fc, d->d_slots.p, d_loglikes, (int)num_pdfs,
+                     d_utts.p, n_utt, d_counter.p, d_res.p, d_paths.p, path_cap);
+  VBH_HIP(hipGetLastError());
+  VBH_HIP(hipMemcpyAsync(res.data(), d_res.p, sizeof(FResult) * n_utt, hipMemcpyDeviceToHost, st));
+  VBH_HIP(hipStreamSynchronize(st));
+  for (int u = 0; u < n_utt; u++)
+    VBH_CHECK(res[u].error == FERR_NONE, "vbh_faster_decode_batch: utterance %d failed: %s", u, ferr_name(res[u].error));
+  std::vector<std::vector<i32x4>> paths(n_utt);
+  for (int u = 0; u < n_utt; u++) {
+    paths[u].resize(res[u].path_len);
+    if (res[u].path_len)
+      VBH_HIP(hipMemcpyAsync(paths[u].data(), d_paths.p + (size_t)u * path_cap, sizeof(i32x4) * res[u].path_len, hipMemcpyDeviceToHost, st));
+  }
+  VBH_HIP(hipStreamSynchronize(st));
+  for (int u = 0; u < n_utt; u++) {
+    vbh_faster_decoder::Out &o = d->results[u];
+    // GetBestPath (:87-147): arcs from the start, (graph, acoustic) = (weight, tot - weight) summed in path order
+    float t1 = 0.0f, t2 = 0.0f;
+    for (int i = res[u].path_len - 1; i >= 0; i--) {
+      const i32x4 a = paths[u][i];
+      const int gb = a.z, tb = a.w;
+      float graph_cost, tot_cost;
+      memcpy(&graph_cost, &gb, 4); memcpy(&tot_cost, &tb, 4);
+      const float ac_cost = tot_cost - graph_cost;
+      t1 = graph_cost + t1; t2 = ac_cost + t2;
+      if (a.x != 0) o.ali.push_back(a.x);
+      if (a.y != 0) o.words.push_back(a.y);
+    }
+    if (res[u].ok && res[u].reached_final) t1 = res[u].final_cost + t1;
+    vbh_best_path &v = o.view;
+    memset(&v, 0, sizeof(v));
+    v.ok = res[u].ok; v.reached_final = res[u].reached_final; v.num_frames = res[u].num_frames;
+    v.num_ali = (int)o.ali.size(); v.ali = o.ali.data(); v.num_words = (int)o.words.size(); v.words = o.words.data();
+    v.best_graph = res[u].ok ? t1 : 0.0f; v.best_acoustic = res[u].ok ? t2 : 0.0f;
+    v.n_tokens = res[u].n_tokens;
+  }
+  return 0;
+}
+
+int vbh_faster_decoder_result(vbh_faster_decoder *d, int32_t utt, vbh_best_path *out) {
+  VBH_CHECK(d && out, "vbh_faster_decoder_result: NULL argument");
+  VBH_CHECK(utt >= 0 && utt < (int)d->results.size(), "vbh_faster_decoder_result: utterance %d out of range", utt);
+  *out = d->results[utt].view;
+  return 0;
+}
+
+}  // extern "C"

@@ -100,4 +100,15 @@ struct DevBuf {
   ~DevBuf() { free(); }
 };
 
+// what another translation unit needs of a vbh_graph (defined in vbh_decode.hip): the device
+// records described there (state {first arc, #eps arcs, #arcs, final}, arc {next | has-eps flag,
+// weight, pdf, olabel}, eps arcs first within a state) and the ilabels
+struct vbh_graph_view {
+  int S, start; long long A; int max_ilabel, max_degree;
+  const void *st; const void *arcs; const int *arc_il;
+};
+void vbh_graph_view_get(const vbh_graph *g, vbh_graph_view *v);
+// make the arcs' pdf fields hold h_t2p[ilabel] (no-op when they already do); h_t2p[0] is ignored
+int vbh_graph_fill_pdf(const vbh_graph *g, hipStream_t st, const int32_t *h_t2p, int32_t num_tids);
+
 #endif  // VBH_INTERNAL_H_
