@@ -159,6 +159,20 @@ def main():
                                      lattice_beam=args.lattice_beam, exact_cutoff=True))
         ctx.sync()
 
+    if args.probe and dec is not None and os.environ.get("VBH_PROBE_FASTER"):
+        # the 1-best search (FasterDecoder, vbh_faster_*) on the same scores
+        gmm.loglikes(feats, out=ll)
+        ctx.sync()
+        fd = api.FasterDecoder(ctx, graph, args.batch, Tmax, beam=args.beam, max_active=args.max_active, min_active=20,
+                               acoustic_scale=0.083333)
+        for rep_ in range(2):
+            t0 = time.perf_counter()
+            fd.decode(ll, foff, t2p)
+            dt = time.perf_counter() - t0
+        r0 = fd.result(0)
+        print("FasterDecoder: %d utterances in %.3f s = %.0f frames/s; utt 0: ok=%d final=%d words=%d tokens/frame=%.0f"
+              % (args.batch, dt, T / dt, r0["ok"], r0["reached_final"], len(r0["words"]), r0["n_tokens"] / max(r0["num_frames"], 1)))
+        fd.close()
     if args.probe and dec is not None:
         gmm.loglikes(feats, out=ll)
         t0 = time.perf_counter()

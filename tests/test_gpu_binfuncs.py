@@ -155,3 +155,35 @@ def test_gmm_latgen_faster_vs_reference_program(host, tmp_path):
             assert "uttA" in (d / "lat.txt").read_text()
     else:
         assert "uttA" in mine_w and "uttA" in mine_a
+
+
+def test_gmm_decode_faster_vs_reference_program(host, tmp_path):
+    """the same files through GmmDecodeFaster (FasterDecoder on the GPU) and the reference's
+    gmm-decode-faster: words and alignments must agree"""
+    d = tmp_path
+    g = load("files")
+    (d / "final.mdl").write_bytes(g["file_final_mdl"].tobytes())
+    (d / "HCLG.fst").write_bytes(g["file_HCLG_fst"].tobytes())
+    rng = np.random.default_rng(1)
+    feats = {"uttA": (rng.standard_normal((40, 39)) * 2).astype(np.float32), "uttB": (rng.standard_normal((25, 39)) * 2).astype(np.float32),
+             "uttC": (rng.standard_normal((1, 39)) * 2).astype(np.float32)}
+    with open(d / "feats.ark", "wb") as f:
+        for k, m in feats.items():
+            f.write(k.encode() + b" \0BFM " + bytes([4]) + np.int32(m.shape[0]).tobytes() + bytes([4]) + np.int32(39).tobytes() + m.tobytes())
+    opts = ["--beam=13", "--max-active=7000", "--acoustic-scale=0.083333"]
+    log = str(d / "dec.log")
+    rc = call(host.vb_GmmDecodeFaster, ["gmm-decode-faster"] + opts + [str(d / "final.mdl"), str(d / "HCLG.fst"), "ark:%s" % (d / "feats.ark"),
+                                        "ark,t:%s" % (d / "words.txt"), "ark,t:%s" % (d / "ali.txt")], log)
+    assert rc == 0, open(log).read()
+    assert "Overall log-likelihood per frame" in open(log).read()
+    # the linear-lattice output is not part of this build: refused loudly
+    assert call(host.vb_GmmDecodeFaster, ["gmm-decode-faster", str(d / "final.mdl"), str(d / "HCLG.fst"), "ark:%s" % (d / "feats.ark"),
+                                          "ark,t:%s" % (d / "w2.txt"), "ark,t:%s" % (d / "a2.txt"), "ark:%s" % (d / "lat.ark")], log) == -1
+    mine_w, mine_a = (d / "words.txt").read_text(), (d / "ali.txt").read_text()
+    if have_ref("gmm-decode-faster"):
+        ref("gmm-decode-faster", *opts, str(d / "final.mdl"), str(d / "HCLG.fst"), "ark:%s" % (d / "feats.ark"),
+            "ark,t:%s" % (d / "r_words.txt"), "ark,t:%s" % (d / "r_ali.txt"))
+        assert mine_w.split() == (d / "r_words.txt").read_text().split()
+        assert mine_a.split() == (d / "r_ali.txt").read_text().split()
+    else:
+        assert "uttA" in mine_w and "uttA" in mine_a

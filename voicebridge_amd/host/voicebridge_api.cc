@@ -629,6 +629,99 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
   });
 }
 
+// gmm-decode-faster (K/gmmbin/gmm-decode-faster.cc:67-211; the VoiceBridge DLL does not wrap this
+// program, so the upstream argv grammar and return convention are kept as they are):
+//   gmm-decode-faster [options] model-in fst-in features-rspecifier words-wspecifier [alignments-wspecifier [lattice-wspecifier]]
+// The linear-lattice output (6th argument) is not written by this build.
+int GmmDecodeFaster(int argc, char *argv[], std::ofstream &file_log) {
+  return Guard("gmm-decode-faster", &file_log, [&](Log &log) -> int {
+    Options po;
+    po.Know({"beam", "max-active", "min-active", "beam-delta", "hash-ratio", "acoustic-scale", "word-symbol-table",
+             "allow-partial", "decode-batch"});
+    po.Parse(argc, argv);
+    if (po.args.size() < 4 || po.args.size() > 6) throw ApiError("wrong arguments.");
+    if (po.args.size() == 6 && !po.args[5].empty())
+      throw ApiError("the linear-lattice output of gmm-decode-faster is not part of this build (use gmm-latgen-faster)");
+    vbh_faster_cfg cfg;
+    vbh_faster_cfg_default(&cfg);
+    // FasterDecoderOptions defaults (K/decoder/faster-decoder.h:38-43), program default acoustic scale 0.1 (:79)
+    cfg.beam = (float)po.Num("beam", 16.0);
+    cfg.max_active = (int)po.Num("max-active", (double)std::numeric_limits<int32_t>::max());
+    cfg.min_active = (int)po.Num("min-active", 20);
+    cfg.beam_delta = (float)po.Num("beam-delta", 0.5);
+    cfg.acoustic_scale = (float)po.Num("acoustic-scale", 0.1);
+    const bool allow_partial = po.Bool("allow-partial", true);
+    vbio::Model model;
+    vbio::ReadModel(po.args[0], &model);
+    vbio::Graph graph;
+    vbio::ReadFst(po.args[1], &graph);
+    vbh_ctx *ctx = Ctx();
+    vbh_gmm *gmm = nullptr;
+    Check(vbh_gmm_create(ctx, model.dim, model.num_pdfs, model.pdf_offsets.data(), model.weights.data(),
+                         model.means_invvars.data(), model.inv_vars.data(), &gmm), "vbh_gmm_create");
+    vbh_graph *g = nullptr;
+    Check(vbh_graph_create(ctx, (int32_t)graph.final_cost.size(), graph.start, graph.final_cost.data(), graph.arc_offset.data(),
+                           reinterpret_cast<const vbh_arc *>(graph.arcs.data()), &g), "vbh_graph_create");
+    vbio::IntVectorWriter words_writer(po.args[3]), ali_writer;
+    if (po.args.size() >= 5 && !po.args[4].empty()) ali_writer.Open(po.args[4]);
+    const int batch_utts = (int)po.Num("decode-batch", 256);
+    vbio::MatrixReader reader(po.args[2]);
+    double tot_like = 0.0;
+    int64_t frame_count = 0;
+    int num_success = 0, num_fail = 0;
+    std::string key; vbio::Matrix m;
+    bool more = true;
+    while (more) {
+      Batch b;
+      int max_T = 0;
+      while ((int)b.keys.size() < batch_utts && (more = reader.Next(&key, &m))) {
+        if (m.rows == 0) { log.os() << "WARNING (gmm-decode-faster) Zero-length utterance: " << key << "\n"; num_fail++; continue; }
+        if (m.cols != model.dim) throw ApiError("Dim mismatch: data dim = " + std::to_string(m.cols) + " vs. model dim = " + std::to_string(model.dim));
+        if (b.dim < 0) b.dim = m.cols;
+        b.Add(key, m);
+        if (m.rows > max_T) max_T = m.rows;
+      }
+      if (b.keys.empty()) break;
+      const int64_t T = b.frames();
+      DevMem d_feats(ctx, sizeof(float) * b.data.size()), d_ll(ctx, sizeof(float) * (size_t)T * model.num_pdfs);
+      Check(vbh_copy_h2d(ctx, d_feats.p, b.data.data(), sizeof(float) * b.data.size()), "vbh_copy_h2d");
+      Check(vbh_gmm_loglikes(gmm, (const float *)d_feats.p, T, (float *)d_ll.p), "vbh_gmm_loglikes");
+      vbh_faster_decoder *dec = nullptr;
+      Check(vbh_faster_decoder_create(ctx, g, &cfg, (int32_t)b.keys.size(), max_T, &dec), "vbh_faster_decoder_create");
+      const int rc = vbh_faster_decode_batch(dec, (const float *)d_ll.p, model.num_pdfs, b.offs.data(), (int32_t)b.keys.size(),
+                                             model.tid2pdf.data(), (int32_t)model.tid2pdf.size() - 1);
+      if (rc != 0) { const std::string e = vbh_last_error(); vbh_faster_decoder_destroy(dec); throw ApiError("vbh_faster_decode_batch: " + e); }
+      for (size_t u = 0; u < b.keys.size(); u++) {
+        vbh_best_path bp;
+        Check(vbh_faster_decoder_result(dec, (int32_t)u, &bp), "vbh_faster_decoder_result");
+        const std::string &utt = b.keys[u];
+        const int nrows = (int)(b.offs[u + 1] - b.offs[u]);
+        if ((allow_partial || bp.reached_final) && bp.ok) {      // (:154-155)
+          if (!bp.reached_final)
+            log.os() << "WARNING (gmm-decode-faster) Decoder did not reach end-state, outputting partial traceback since --allow-partial=true\n";
+          num_success++;
+          frame_count += nrows;
+          words_writer.Write(utt, std::vector<int32_t>(bp.words, bp.words + bp.num_words));
+          if (ali_writer.IsOpen()) ali_writer.Write(utt, std::vector<int32_t>(bp.ali, bp.ali + bp.num_ali));
+          const double like = -(double)bp.best_graph - (double)bp.best_acoustic;
+          tot_like += like;
+          log.os() << "LOG (gmm-decode-faster) Log-like per frame for utterance " << utt << " is " << (like / nrows) << " over " << nrows << " frames.\n";
+        } else {
+          num_fail++;
+          log.os() << "WARNING (gmm-decode-faster) Did not successfully decode utterance " << utt << ", len = " << nrows << "\n";
+        }
+      }
+      vbh_faster_decoder_destroy(dec);
+    }
+    vbh_graph_destroy(g);
+    vbh_gmm_destroy(gmm);
+    log.os() << "LOG (gmm-decode-faster) Done " << num_success << " utterances, failed for " << num_fail << "\n";
+    log.os() << "LOG (gmm-decode-faster) Overall log-likelihood per frame is " << (frame_count ? tot_like / frame_count : 0.0)
+             << " over " << frame_count << " frames.\n";
+    return num_success != 0 ? 0 : 1;
+  });
+}
+
 // =====================================================================================
 namespace {
 template <class F>
@@ -648,4 +741,5 @@ int vb_AddDeltas(int argc, char *argv[]) { return AddDeltas(argc, argv); }
 int vb_SpliceFeats(int argc, char *argv[]) { return SpliceFeats(argc, argv); }
 int vb_TransformFeats(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return TransformFeats(argc, argv, l); }); }
 int vb_GmmLatgenFaster(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return GmmLatgenFaster(argc, argv, l); }); }
+int vb_GmmDecodeFaster(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return GmmDecodeFaster(argc, argv, l); }); }
 }

@@ -35,6 +35,8 @@ int AddDeltas(int argc, char *argv[]);
 int SpliceFeats(int argc, char *argv[]);
 int TransformFeats(int argc, char *argv[], std::ofstream &file_log);
 int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log);
+// not wrapped by the reference DLL; upstream program K/gmmbin/gmm-decode-faster.cc with the same conventions
+int GmmDecodeFaster(int argc, char *argv[], std::ofstream &file_log);
 
 // plain-C shims of the above for hosts without C++ streams (ctypes, cgo ...): log_path may be NULL
 extern "C" {
@@ -45,6 +47,7 @@ int vb_AddDeltas(int argc, char *argv[]);
 int vb_SpliceFeats(int argc, char *argv[]);
 int vb_TransformFeats(int argc, char *argv[], const char *log_path);
 int vb_GmmLatgenFaster(int argc, char *argv[], const char *log_path);
+int vb_GmmDecodeFaster(int argc, char *argv[], const char *log_path);
 int vb_set_device(int device_id);   // GPU used by the calling thread's subsequent calls (default 0)
 }
 
