@@ -84,3 +84,32 @@ def test_faster_batch_vs_oracle(ctx, S, P, T, seed, cfg):
         ref = vbo.decode_faster(fst, ll[:n] if n else np.zeros((0, P), np.float32), t2p, exact_cutoff=True, **cfg)
         assert_same_path(dec.result(u), ref)
     dec.close(); graph.close()
+
+
+def test_faster_garbage_collection(ctx, monkeypatch):
+    """a history far too small for the utterance: unreachable tokens are collected on the way and the
+    best path must not change"""
+    import torch
+    from oracle import vbo
+    from voicebridge_amd import api
+    cfg = dict(beam=9.0, max_active=400, min_active=20)
+    S, P, T, seed = 60000, 96, 160, 31
+    g, t2p, ll = make_case(S, P, T, seed, eps_frac=0.3, spread=25.0)
+    fst = vbo.make_fst(g["final"], g["arc_offset"], g["arcs"], 0)
+    ref = vbo.decode_faster(fst, ll, t2p, exact_cutoff=True, **cfg)
+    graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
+    d = torch.from_numpy(ll).to(ctx.device)
+    ctx.torch_sync()
+    seen = []
+    for hist in (0, 6000, 5400):
+        if hist:
+            monkeypatch.setenv("VBH_FASTER_FRAME_CAP", "2000")
+            monkeypatch.setenv("VBH_FASTER_HISTORY", str(hist))
+        dec = api.FasterDecoder(ctx, graph, 1, T, **cfg)
+        dec.decode(d, [0, T], t2p)
+        got = dec.result(0)
+        assert_same_path(got, ref)
+        seen.append(got["n_tokens"])
+        dec.close()
+    assert seen[1] < seen[0] or seen[2] < seen[0]      # the small histories really were collected
+    graph.close()

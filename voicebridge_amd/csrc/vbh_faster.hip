@@ -55,12 +55,15 @@ struct FSlot {
   i32x4 *c_r;              // [cand_cap] {arc, source token, next state | EPSBIT, 0}
   int *front[3];           // epsilon work lists (states), rotated
   unsigned *g_hs; unsigned long long *g_hc; int *g_ht;   // second level of the state map, [g_cap] (power of two)
-  int tok_cap, frame_cap, cand_cap, front_cap, g_cap;
+  int *remap;              // [tok_cap] garbage collection: mark, then new index
+  i32x4 *stage_tok; double *stage_cost;   // [stage_cap] survivors on their way down
+  int tok_cap, frame_cap, cand_cap, front_cap, g_cap, stage_cap;
 };
 
 struct FUtt { long long row0; int T; int pad; };
 struct FResult { int ok, error, reached_final, num_frames, path_len, final_state; float final_cost; int pad; long long n_tokens; };
 
+// (FERR_TOK: even after garbage collection the history does not fit)
 enum { FERR_NONE = 0, FERR_TOK = 1, FERR_FRAME = 2, FERR_CAND = 3, FERR_FRONT = 4, FERR_MAP = 5, FERR_EPS = 6, FERR_PATH = 7 };
 
 // order-preserving map double -> uint64
@@ -396,6 +399,56 @@ __device__ void make_tokens(const FSlot &s, int tok_base, Shared &sh) {
   }
 }
 
+// Tokens no current token can reach through back pointers will never be part of a best path (the
+// reference frees them by reference counting, faster-decoder.h:136-160).  When the history is about
+// to run out, every current token marks its ancestors down to gc_base (tokens below survived an
+// earlier collection and stay), the marked tokens are packed -- through a staging buffer, order
+// kept, so the current frame stays a contiguous tail -- and back pointers are rewritten.
+// Returns the new position of the current frame; everything below it is then settled.
+__device__ int collect_garbage(const FSlot &s, int gc_base, int cur_b, int cur_n, Shared &sh) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  gp<i32x4> tok = uptr(s.tok); gp<double> cost = uptr(s.cost);
+  gp<int> remap = uptr(s.remap);
+  gp<i32x4> st_tok = uptr(s.stage_tok); gp<double> st_cost = uptr(s.stage_cost);
+  const int end = cur_b + cur_n;
+  for (int i = gc_base + tid; i < end; i += NT) remap[i] = 0;
+  __syncthreads();
+  for (int i = cur_b + tid; i < end; i += NT) {
+    int t = i;
+    while (t >= gc_base) {
+      if (__hip_atomic_exchange(&remap[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;
+      t = tok[t].x;
+    }
+  }
+  __syncthreads();
+  // survivors per thread chunk, exclusive scan over the workgroup (sh.ht is free between frames)
+  const int len = end - gc_base, per = (len + NT - 1) / NT;
+  const int lo = gc_base + tid * per, hi = lo + per < end ? lo + per : end;
+  int c = 0;
+  for (int t = lo; t < hi; t++) c += remap[t];
+  const int incl = wave_incl_scan(c);
+  if (lane == 63) sh.ht[wave] = incl;
+  __syncthreads();
+  int wbase = 0, total = 0;
+  for (int w = 0; w < NW; w++) { const int x = sh.ht[w]; if (w < wave) wbase += x; total += x; }
+  __syncthreads();
+  if (total > s.stage_cap) { if (tid == 0) sh.error = FERR_TOK; __syncthreads(); return cur_b; }
+  int idx = wbase + incl - c;
+  for (int t = lo; t < hi; t++) {
+    if (remap[t]) { st_tok[idx] = tok[t]; st_cost[idx] = cost[t]; remap[t] = gc_base + idx; idx++; }
+    else remap[t] = -1;
+  }
+  __syncthreads();
+  for (int j = tid; j < total; j += NT) {
+    i32x4 r = st_tok[j];
+    if (r.x >= gc_base) r.x = remap[r.x];
+    tok[gc_base + j] = r;
+    cost[gc_base + j] = st_cost[j];
+  }
+  __syncthreads();
+  return gc_base + total - cur_n;
+}
+
 __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const FSlot *slots, const float *__restrict__ loglikes, int P,
                                                        const FUtt *__restrict__ utts, int n_work, int *work_counter, FResult *results,
                                                        i32x4 *paths, int path_cap) {   // best path per utterance, last arc first: {ilabel, olabel, weight, tot_cost}
@@ -447,7 +500,13 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
     }
     __syncthreads();
     int frames_done = 0;
+    int gc_base = 0;
     for (int frame = 0; frame < T && sh.error == FERR_NONE; frame++) {
+      if (cur_b + cur_n + s.frame_cap > s.tok_cap) {      // make room for whatever this frame may create
+        cur_b = collect_garbage(s, gc_base, cur_b, cur_n, sh);
+        gc_base = cur_b;
+        if (sh.error != FERR_NONE) break;
+      }
       const float *llrow = loglikes + (ud.row0 + frame) * (long long)P;
       gp<const double> ccost = cost + cur_b;
       gp<const i32x4> ctok = tok + cur_b;
@@ -536,12 +595,18 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
         }
       }
       __syncthreads();
+#ifdef VBH_FASTER_DEBUG
+      if (tid == 0 && utt == 0 && frame < 12) printf("frame %d after pass2: n=%d ncand=%d n_new=%d g_used=%d err=%d fcnt0=%d\n", frame, n, ncand, sh.n_new, sh.g_used, sh.error, sh.fcnt[0]);
+#endif
       if (sh.error != FERR_NONE) break;
       // ---- ProcessNonemitting(next_cutoff) to the fixed point
       epsilon_closure(g, s, next_cutoff, sh);
       if (sh.error != FERR_NONE) break;
       const int nb = cur_b + cur_n;
       const int n_new = sh.n_new < s.frame_cap ? sh.n_new : s.frame_cap;
+#ifdef VBH_FASTER_DEBUG
+      if (tid == 0 && utt == 0 && frame < 12) printf("frame %d: n=%d ncand=%d n_new=%d g_used=%d next_cutoff=%f weight_cutoff=%f best=%f\n", frame, n, ncand, sh.n_new, sh.g_used, next_cutoff, weight_cutoff, best);
+#endif
       if (nb + n_new > s.tok_cap) { if (tid == 0) sh.error = FERR_TOK; __syncthreads(); break; }
       // ---- winners: the emitting candidates and the epsilon arcs that reproduce a state's final cost
       for (int base = 0; base < ncand; base += NT) {
@@ -643,7 +708,7 @@ struct vbh_faster_decoder {
 
 static const char *ferr_name(int e) {
   switch (e) {
-    case FERR_TOK: return "token history capacity exceeded";
+    case FERR_TOK: return "token history capacity exceeded even after garbage collection";
     case FERR_FRAME: return "more new tokens in one frame than the slot was sized for";
     case FERR_CAND: return "candidate list capacity exceeded";
     case FERR_FRONT: return "epsilon work-list capacity exceeded";
@@ -675,13 +740,24 @@ int vbh_faster_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_fa
   FSlot p{};
   // new tokens per frame: bounded by the states; beyond the on-chip map the HBM level takes over
   const long long ma = std::min<long long>(cfg->max_active, gv.S);
-  p.frame_cap = (int)std::min<long long>(std::max<long long>(gv.S, 1), std::max<long long>(4 * HCAP, std::min<long long>(4 * ma, 1 << 20)));
+  // (a frame early in an utterance can admit every arc leaving its tokens: all costs are still close)
+  p.frame_cap = (int)std::min<long long>(std::max<long long>(gv.S, 1), std::max<long long>(16 * HCAP, std::min<long long>(16 * ma, 1 << 21)));
+  if (const char *e = getenv("VBH_FASTER_FRAME_CAP")) { const int x = atoi(e); if (x > 0) p.frame_cap = std::min(p.frame_cap, x); }   // tests
   p.g_cap = 1;
   while (p.g_cap < 2 * p.frame_cap) p.g_cap <<= 1;
-  const long long avg = std::min<long long>(p.frame_cap, 2048);          // tokens per frame the history is sized for
-  p.tok_cap = (int)std::min<long long>(avg * ((long long)max_frames + 2) + p.frame_cap, 1LL << 28);
-  p.cand_cap = (int)std::min<long long>(std::max<long long>(gv.A, 1), (long long)p.frame_cap * std::max(gv.max_degree, 1));
-  p.cand_cap = std::min(p.cand_cap, 1 << 22);
+  // history: what garbage collection leaves (a few tokens per frame) + room for ~100 frames of new tokens
+  // + the frame being built; collected whenever less than one frame's worth is free
+  // (small graphs: every state every frame is the worst case and cheap to provide -- nothing to collect then)
+  const long long worst = (long long)p.frame_cap * ((long long)max_frames + 2);
+  const long long kept = 256LL * ((long long)max_frames + 2);
+  p.tok_cap = (int)std::min<long long>(std::min<long long>(worst, kept + 4LL * p.frame_cap), 1LL << 28);
+  if (const char *e = getenv("VBH_FASTER_HISTORY")) {     // tests: a small history forces garbage collections
+    const long long x = atoll(e);
+    if (x > 0) p.tok_cap = (int)std::min<long long>(p.tok_cap, std::max<long long>(x, 2LL * p.frame_cap));
+  }
+  p.stage_cap = (int)std::min<long long>(p.tok_cap, kept + 2LL * p.frame_cap);
+  p.cand_cap = (int)std::min<long long>(std::max<long long>(gv.A, 1), std::min<long long>((ma + 256) * std::max(gv.max_degree, 1), 1LL << 22));
+  p.cand_cap = std::max(p.cand_cap, std::min<int>((int)std::max<long long>(gv.A, 1), 2 * p.frame_cap));
   p.front_cap = 2 * p.frame_cap;
   d->proto = p;
   d->h_slots.assign(d->n_slots, p);
@@ -698,6 +774,7 @@ int vbh_faster_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_fa
   A_(c_w, double, p.cand_cap) A_(c_r, i32x4, p.cand_cap)
   A_(front[0], int, p.front_cap) A_(front[1], int, p.front_cap) A_(front[2], int, p.front_cap)
   A_(g_hs, unsigned, p.g_cap) A_(g_hc, unsigned long long, p.g_cap) A_(g_ht, int, p.g_cap)
+  A_(remap, int, p.tok_cap) A_(stage_tok, i32x4, p.stage_cap) A_(stage_cost, double, p.stage_cap)
 #undef A_
   if (d->d_slots.upload(d->h_slots.data(), d->h_slots.size(), ctx->stream)) { vbh_faster_decoder_destroy(d); return -1; }
   VBH_HIP(hipStreamSynchronize(ctx->stream));
@@ -749,7 +826,8 @@ int vbh_faster_decode_batch(vbh_faster_decoder *d, const float *d_loglikes, int3
   VBH_HIP(hipMemcpyAsync(res.data(), d_res.p, sizeof(FResult) * n_utt, hipMemcpyDeviceToHost, st));
   VBH_HIP(hipStreamSynchronize(st));
   for (int u = 0; u < n_utt; u++)
-    VBH_CHECK(res[u].error == FERR_NONE, "vbh_faster_decode_batch: utterance %d failed: %s", u, ferr_name(res[u].error));
+    VBH_CHECK(res[u].error == FERR_NONE, "vbh_faster_decode_batch: utterance %d failed after %d frames (%lld tokens so far; slot: %d tokens, %d per frame, %d candidates): %s",
+              u, res[u].num_frames, res[u].n_tokens, d->proto.tok_cap, d->proto.frame_cap, d->proto.cand_cap, ferr_name(res[u].error));
   std::vector<std::vector<i32x4>> paths(n_utt);
   for (int u = 0; u < n_utt; u++) {
     paths[u].resize(res[u].path_len);
