@@ -57,14 +57,14 @@ def build(force=False, verbose=True):
 
 
 HOST_LIB = os.path.join(LIBDIR, "libvoicebridge_host.so")
-HOST_SOURCES = ["kaldi_io.cc", "voicebridge_api.cc", "host_capi.cc"]
+HOST_SOURCES = ["kaldi_io.cc", "voicebridge_api.cc", "voicebridge_steps.cc", "host_capi.cc"]
 
 
 def build_host(force=False, verbose=True):
     """C++ host layer (file formats + the reference's argv-style bin functions) over the C ABI."""
     hdir = os.path.join(HERE, "host")
     srcs = [os.path.join(hdir, s) for s in HOST_SOURCES]
-    deps = srcs + [os.path.join(hdir, "kaldi_io.h"), os.path.join(hdir, "voicebridge_api.h"),
+    deps = srcs + [os.path.join(hdir, "kaldi_io.h"), os.path.join(hdir, "voicebridge_api.h"), os.path.join(hdir, "voicebridge_steps.h"),
                    os.path.join(ROOT, "include", "voicebridge_hip.h"), LIB]
     if force or any(_newer(d, HOST_LIB) for d in deps):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + hdir,

@@ -629,6 +629,39 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
   });
 }
 
+// copy-feats (VB/src/featbin/copy-feats.cpp; K/featbin/copy-feats.cc:28-170): table to table copy with
+// optional kSpeechFeature compression and a per-utterance frame count table
+int CopyFeats(int argc, char *argv[], std::ofstream &file_log) {
+  return Guard("copy-feats", &file_log, [&](Log &log) -> int {
+    Options po;
+    po.Know({"compress", "write-num-frames", "binary", "htk-in", "sphinx-in", "compression-method"});
+    po.Parse(argc, argv);
+    if (po.args.size() != 2) throw ApiError("wrong arguments.");
+    if (po.Bool("htk-in", false) || po.Bool("sphinx-in", false)) throw ApiError("--htk-in / --sphinx-in are not supported");
+    const bool compress = po.Bool("compress", false);
+    vbio::MatrixReader reader(po.args[0]);
+    vbio::MatrixWriter writer(po.args[1], compress);
+    vbio::IntVectorWriter dummy;
+    std::ofstream nf;
+    if (po.Has("write-num-frames")) {
+      const vbio::Wspec ws = vbio::ParseWspecifier(po.Str("write-num-frames", ""));
+      if (!ws.has_ark || !ws.text) throw ApiError("--write-num-frames expects ark,t:<file>");
+      nf.open(ws.ark_path);
+      if (!nf) throw ApiError("cannot open " + ws.ark_path);
+    }
+    std::string key; vbio::Matrix m;
+    int n = 0;
+    while (reader.Next(&key, &m)) {
+      writer.Write(key, m);
+      if (nf.is_open()) nf << key << " " << m.rows << "\n";
+      n++;
+    }
+    writer.Close();
+    log.os() << "LOG (copy-feats) Copied " << n << " feature matrices.\n";
+    return n != 0 ? 0 : 1;
+  });
+}
+
 // gmm-decode-faster (K/gmmbin/gmm-decode-faster.cc:67-211; the VoiceBridge DLL does not wrap this
 // program, so the upstream argv grammar and return convention are kept as they are):
 //   gmm-decode-faster [options] model-in fst-in features-rspecifier words-wspecifier [alignments-wspecifier [lattice-wspecifier]]
@@ -741,5 +774,6 @@ int vb_AddDeltas(int argc, char *argv[]) { return AddDeltas(argc, argv); }
 int vb_SpliceFeats(int argc, char *argv[]) { return SpliceFeats(argc, argv); }
 int vb_TransformFeats(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return TransformFeats(argc, argv, l); }); }
 int vb_GmmLatgenFaster(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return GmmLatgenFaster(argc, argv, l); }); }
+int vb_CopyFeats(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return CopyFeats(argc, argv, l); }); }
 int vb_GmmDecodeFaster(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return GmmDecodeFaster(argc, argv, l); }); }
 }

@@ -35,6 +35,7 @@ int AddDeltas(int argc, char *argv[]);
 int SpliceFeats(int argc, char *argv[]);
 int TransformFeats(int argc, char *argv[], std::ofstream &file_log);
 int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log);
+int CopyFeats(int argc, char *argv[], std::ofstream &file_log);          // VB/src/kaldi_src.h:20
 // not wrapped by the reference DLL; upstream program K/gmmbin/gmm-decode-faster.cc with the same conventions
 int GmmDecodeFaster(int argc, char *argv[], std::ofstream &file_log);
 
@@ -48,6 +49,7 @@ int vb_SpliceFeats(int argc, char *argv[]);
 int vb_TransformFeats(int argc, char *argv[], const char *log_path);
 int vb_GmmLatgenFaster(int argc, char *argv[], const char *log_path);
 int vb_GmmDecodeFaster(int argc, char *argv[], const char *log_path);
+int vb_CopyFeats(int argc, char *argv[], const char *log_path);
 int vb_set_device(int device_id);   // GPU used by the calling thread's subsequent calls (default 0)
 }
 

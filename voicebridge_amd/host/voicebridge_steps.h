@@ -1,0 +1,49 @@
+// voicebridge_steps.h -- the reference's step API (seam B1 of SURVEY.md §8b) for the hot path,
+// re-stated over the bin functions of voicebridge_api.h: directory conventions in, files out.
+//
+// Mirrors (paths relative to /root/reference/VoiceBridge/VoiceBridge/kaldi-win/):
+//   scr/kaldi_scr.h:71-77    VOICEBRIDGE_API int MakeMfcc(fs::path datadir, fs::path mfcc_config, int nj, bool compress,
+//                                                          bool write_utt2num_frames)       scr/steps/make_mfcc.cpp:24-327
+//   scr/kaldi_scr.h:87-94    VOICEBRIDGE_API int ComputeCmvnStats(fs::path datadir, bool fake, bool two_channel,
+//                                                                  std::string fake_dims)    scr/steps/compute_cmvn_stats.cpp:23-199
+//   scr/kaldi_scr.h:85       int SplitData(fs::path datadir, int numsplit, bool per_utt)     scr/utils/split_data.cpp:20-160
+//   scr/kaldi_scr.h:142-165  VOICEBRIDGE_API int Decode(graph_dir, data_dir, decode_dir, model, trans_dir, wer filters, iter,
+//                                                        nj, acwt, stage, max_active, beam, lattice_beam, skip_scoring, ...)
+//                                                                                             scr/steps/decode_gmm.cpp:60-390
+// Same names, argument order and meaning, return 0 / -1; std::string stands in for boost::filesystem::path.
+// The nj jobs of a step run one after the other on the calling thread's GPU (vb_set_device): they are
+// batches for one device here, not processes; the per-job file layout (JOB-numbered archives, logs,
+// split directories) is the reference's, so whatever consumes those directories keeps working.
+//
+// Not part of this build, refused with an error rather than skipped: a `segments` file in MakeMfcc
+// (extract-segments), fake / two-channel / fake-dims CMVN, and in Decode everything after the
+// lattices -- scoring must be switched off with skip_scoring = true; lattices
+// are written raw (--determinize-lattice=false, §8f row 1).
+#ifndef VOICEBRIDGE_STEPS_H_
+#define VOICEBRIDGE_STEPS_H_
+
+#include <string>
+#include <unordered_map>
+
+typedef std::unordered_map<std::string, std::string> UMAPSS;
+
+int MakeMfcc(const std::string &datadir, const std::string &mfcc_config, int nj = 4, bool compress = true,
+             bool write_utt2num_frames = false);
+int ComputeCmvnStats(const std::string &datadir, bool fake = false, bool two_channel = false, const std::string &fake_dims = "");
+int SplitData(const std::string &datadir, int numsplit, bool per_utt = false);
+int Decode(const std::string &graph_dir, const std::string &data_dir, const std::string &decode_dir, const std::string &model,
+           const std::string &trans_dir, UMAPSS &wer_ref_filter, UMAPSS &wer_hyp_filter, const std::string &iter = "", int nj = 4,
+           float acwt = 0.083333f, int stage = 0, int max_active = 7000, double beam = 13.0, double lattice_beam = 6.0,
+           bool skip_scoring = false);
+
+// plain-C shims (ctypes, cgo ...); messages of the last failure: vb_steps_last_error()
+extern "C" {
+int vb_MakeMfcc(const char *datadir, const char *mfcc_config, int nj, int compress, int write_utt2num_frames);
+int vb_ComputeCmvnStatsDir(const char *datadir);
+int vb_SplitData(const char *datadir, int numsplit, int per_utt);
+int vb_Decode(const char *graph_dir, const char *data_dir, const char *decode_dir, const char *model, int nj, float acwt,
+              int max_active, double beam, double lattice_beam, int skip_scoring);
+const char *vb_steps_last_error(void);
+}
+
+#endif
