@@ -750,12 +750,12 @@ int vbh_faster_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_fa
   // (small graphs: every state every frame is the worst case and cheap to provide -- nothing to collect then)
   const long long worst = (long long)p.frame_cap * ((long long)max_frames + 2);
   const long long kept = 256LL * ((long long)max_frames + 2);
-  p.tok_cap = (int)std::min<long long>(std::min<long long>(worst, kept + 4LL * p.frame_cap), 1LL << 28);
+  p.tok_cap = (int)std::min<long long>(std::min<long long>(worst, std::max<long long>(kept + 4LL * p.frame_cap, 2LL << 20)), 1LL << 28);
   if (const char *e = getenv("VBH_FASTER_HISTORY")) {     // tests: a small history forces garbage collections
     const long long x = atoll(e);
     if (x > 0) p.tok_cap = (int)std::min<long long>(p.tok_cap, std::max<long long>(x, 2LL * p.frame_cap));
   }
-  p.stage_cap = (int)std::min<long long>(p.tok_cap, kept + 2LL * p.frame_cap);
+  p.stage_cap = (int)std::min<long long>(p.tok_cap, std::max<long long>(kept + 2LL * p.frame_cap, 1LL << 20));
   p.cand_cap = (int)std::min<long long>(std::max<long long>(gv.A, 1), std::min<long long>((ma + 256) * std::max(gv.max_degree, 1), 1LL << 22));
   p.cand_cap = std::max(p.cand_cap, std::min<int>((int)std::max<long long>(gv.A, 1), 2 * p.frame_cap));
   p.front_cap = 2 * p.frame_cap;
