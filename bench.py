@@ -53,7 +53,7 @@ def parse():
                          "next batch's kernels fill the freed CUs; 1 = one batch at a time")
     ap.add_argument("--probe", action="store_true", help="print search statistics of the first utterances and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-seconds", type=float, default=30.0, help="audio seconds timed on the CPU baseline")
+    ap.add_argument("--cpu-sample-seconds", type=float, default=180.0, help="audio seconds timed on the CPU baseline")
     return ap.parse_args()
 
 
