@@ -99,7 +99,7 @@ constexpr int HBITS = NT >= 1024 ? 13 : (NT >= 512 ? 12 : 11);
 constexpr int HCAP = 1 << HBITS;            // slots of the per-frame state map in LDS (8 per thread)
 constexpr int HPROBE = 16;                  // probes before a state is sent to the table in HBM
 constexpr unsigned HEMPTY = 0xFFFFFFFFu;
-constexpr int DIRTY_FRAMES = 1 << 16;       // frames covered by the dirty bitmap (8 KB of LDS)
+constexpr int DIRTY_FRAMES = NT >= 1024 ? (1 << 16) : (1 << 15);   // frames covered by the dirty bitmap (8 / 4 KB of LDS)
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
