@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="utterances per step per GPU")
     ap.add_argument("--seconds", type=float, default=30.0, help="utterance length")
@@ -229,8 +229,8 @@ def main():
         if depth == 1:
             L.ctx, L.dec = ctx, dec
         else:
-            L.ctx = api.Context(local_rank)
-            L.dec = dec if False else api.LatticeDecoder(L.ctx, graph, args.batch, Tmax, beam=args.beam, max_active=args.max_active,
+            L.ctx = api.Context(local_rank, priority=int(os.environ.get("VBH_BENCH_DEC_PRIO", "0")))
+            L.dec = api.LatticeDecoder(L.ctx, graph, args.batch, Tmax, beam=args.beam, max_active=args.max_active,
                                                          min_active=200, lattice_beam=args.lattice_beam, acoustic_scale=0.083333)
         L.pending = False
         L.timed = False

@@ -35,6 +35,9 @@ int vbh_abi_version(void);
 const char *vbh_last_error(void);                 /* thread-local message of the last failure */
 int vbh_device_count(void);                       /* 0 when no HIP device is visible */
 int vbh_ctx_create(int device_id, vbh_ctx **out); /* fails (-1) when there is no such GPU */
+/* priority 0 = default; larger = this context's kernels are dispatched before those of lower
+ * priority contexts when CUs free up (clamped to what the device offers) */
+int vbh_ctx_create_with_priority(int device_id, int priority, vbh_ctx **out);
 void vbh_ctx_destroy(vbh_ctx *ctx);
 int vbh_ctx_sync(vbh_ctx *ctx);
 /* work enqueued on ctx after this call starts only when everything enqueued on other so far

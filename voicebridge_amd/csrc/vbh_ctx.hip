@@ -54,7 +54,10 @@ int vbh_device_count(void) {
   return n;
 }
 
-int vbh_ctx_create(int device_id, vbh_ctx **out) {
+static int ctx_create(int device_id, int priority, vbh_ctx **out);
+int vbh_ctx_create(int device_id, vbh_ctx **out) { return ctx_create(device_id, 0, out); }
+int vbh_ctx_create_with_priority(int device_id, int priority, vbh_ctx **out) { return ctx_create(device_id, priority, out); }
+static int ctx_create(int device_id, int priority, vbh_ctx **out) {
   VBH_CHECK(out != nullptr, "vbh_ctx_create: out is NULL");
   int n = vbh_device_count();
   VBH_CHECK(n > 0, "vbh_ctx_create: no HIP device visible (this library has no CPU path)");
@@ -62,7 +65,16 @@ int vbh_ctx_create(int device_id, vbh_ctx **out) {
   VBH_HIP(hipSetDevice(device_id));
   vbh_ctx *c = new vbh_ctx();
   c->device = device_id;
-  VBH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  {
+    // priority > 0: its kernels get CUs before those of other streams (least = 0, the default);
+    // mapped onto the device's range (numerically lower = higher priority in HIP)
+    int least = 0, greatest = 0;
+    VBH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    int p = least - priority;
+    if (p < greatest) p = greatest;
+    if (p > least) p = least;
+    VBH_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, p));
+  }
   for (int i = 0; i < VBH_MAX_TIMERS; i++) {
     VBH_HIP(hipEventCreate(&c->ev_start[i]));
     VBH_HIP(hipEventCreate(&c->ev_stop[i]));
