@@ -70,7 +70,7 @@ constexpr int NW = NT / 64;
 #ifndef VBH_WAVES_PER_EU
 #define VBH_WAVES_PER_EU 4                  // 4: 128 VGPRs, 1024 threads per CU;  8: 64 VGPRs, 2048 threads per CU
 #endif
-constexpr int WG_PER_CU = (1024 / NT) * (VBH_WAVES_PER_EU / 4);
+constexpr int WG_PER_CU = ((1024 / NT) * VBH_WAVES_PER_EU) / 4 > 0 ? ((1024 / NT) * VBH_WAVES_PER_EU) / 4 : 1;
 constexpr int WBIT = 0x40000000;            // token id lives in the raw window
 constexpr unsigned INF_BITS = 0x7F800000u;  // +inf as float bits
 constexpr int MAX_EPS_ITERS = 4096;
@@ -720,6 +720,16 @@ __device__ __forceinline__ void job_add_seg(Shared &sh, int b, int e, int a, int
   sh.sbeg[j] = b; sh.sbeg[j + 1] = e; sh.sup[j] = up; sh.sbase[j] = sh.j_ldst; sh.scnt[j] = 0; sh.sid[j] = id;
   sh.j_ldst += up;
 }
+// the FrameRecs a job is built from, fetched by everybody into LDS (sh.cost is free between the
+// pruning pass and the next frame) instead of one dependent load after the other by thread 0
+__device__ __forceinline__ const FrameRec *job_stage_frames(const Slot &s, Shared &sh, int f0, int nf) {
+  static_assert(sizeof(float) * COST_CAP >= sizeof(FrameRec) * (MAX_WIN_FRAMES + 2), "FrameRec staging aliases sh.cost");
+  int *dst = reinterpret_cast<int *>(sh.cost);
+  gp<const int> src = (gp<const int>)(s.fr + f0);
+  for (int i = threadIdx.x; i < nf * 12; i += NT) dst[i] = src[i];
+  __syncthreads();
+  return reinterpret_cast<const FrameRec *>(sh.cost);
+}
 // new positions -> FrameRecs (after compact_move; one thread per frame / segment)
 __device__ __forceinline__ void job_publish(const Slot &s, Shared &sh) {
   const int tid = threadIdx.x;
@@ -750,10 +760,11 @@ __device__ bool recompact_tail(const Slot &s, Shared &sh) {
   const int tail_tb = sh.tail_tok_b, tail_lb = sh.tail_link_b;
   const int old_nt = sh.h_ntok, old_nl = sh.h_nlink;
   __syncthreads();
+  const FrameRec *lf = job_stage_frames(s, sh, fa, tf1 - fa + 1);
   if (tid == 0) {
     sh.j_ntf = 0; sh.j_nseg = 0; sh.j_tf0 = 0; sh.j_tdst = tail_tb; sh.j_ldst = tail_lb;
     for (int f = fa; f <= tf1; f++) {
-      const FrameRec r = ld_frame(s.fr + f);
+      const FrameRec r = lf[f - fa];
       if (f > tf0) job_add_tok(sh, r, f);
       if (f > tf0) job_add_seg(sh, r.pl_b, r.pl_e, r.a_pl, (f << 1) | 1);
       if (f < tf1) job_add_seg(sh, r.el_b, r.el_e, r.a_el, f << 1);   // emitting links of the frontier frame are still in W
@@ -804,10 +815,11 @@ __device__ bool compact_window(const Slot &s, int prev_front, int front, Shared 
   if (!recompact_tail(s, sh)) return false;
   const int f0 = prev_front < 0 ? 0 : prev_front;
   const int nf = front - f0 + 1;     // frames f0..front  (<= MAX_WIN_FRAMES, checked on the host)
+  const FrameRec *lf = job_stage_frames(s, sh, f0, nf);
   if (tid == 0) {
     sh.j_ntf = 0; sh.j_nseg = 0; sh.j_tf0 = 0; sh.j_tdst = sh.h_ntok; sh.j_ldst = sh.h_nlink;
     for (int f = f0; f <= front; f++) {
-      const FrameRec r = ld_frame(s.fr + f);
+      const FrameRec r = lf[f - f0];
       if (r.flags & 1) job_add_tok(sh, r, f);
       if (r.flags & 4) job_add_seg(sh, r.pl_b, r.pl_e, r.a_pl, (f << 1) | 1);   // creation order in W: eps links of f, then its emitting links
       if (r.flags & 2) job_add_seg(sh, r.el_b, r.el_e, r.a_el, f << 1);
