@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=2,
                     help="batches in flight: 2 = two contexts/streams, the search grid of one batch drains while the "
                          "next batch's kernels fill the freed CUs; 1 = one batch at a time")
+    ap.add_argument("--search-cus", type=int, default=-1,
+                    help="confine the search contexts to this many CUs (0 = all, -1 = 7/8 of the device when batches are "
+                         "pipelined): the rest stays free for the front end of the batches ahead, which otherwise only "
+                         "runs while a search grid drains -- a persistent search workgroup owns its CU's whole LDS")
     ap.add_argument("--probe", action="store_true", help="print search statistics of the first utterances and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-seconds", type=float, default=180.0, help="audio seconds timed on the CPU baseline")
@@ -221,6 +225,9 @@ def main():
     class Lane:
         pass
     depth = max(1, args.pipeline) if dec is not None else 1
+    if args.search_cus < 0:
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        args.search_cus = (ncu * 7 // 8) if depth > 1 else 0
     n_ring = depth + 1 if depth > 1 else 1
     ring = [(raw, feats, ll)] + [(torch.empty_like(raw), torch.empty_like(feats), torch.empty_like(ll)) for _ in range(n_ring - 1)]
     lanes = []
@@ -229,7 +236,7 @@ def main():
         if depth == 1:
             L.ctx, L.dec = ctx, dec
         else:
-            L.ctx = api.Context(local_rank, priority=int(os.environ.get("VBH_BENCH_DEC_PRIO", "0")))
+            L.ctx = api.Context(local_rank, priority=int(os.environ.get("VBH_BENCH_DEC_PRIO", "0")), cus=args.search_cus)
             L.dec = api.LatticeDecoder(L.ctx, graph, args.batch, Tmax, beam=args.beam, max_active=args.max_active,
                                                          min_active=200, lattice_beam=args.lattice_beam, acoustic_scale=0.083333)
         L.pending = False
@@ -242,6 +249,7 @@ def main():
     gmm_ms, feat_ms, dec_ms, dec_k_ms, dec_h_ms = [], [], [], [], []
     last_done = [lanes[0]]
     fe_timed = []            # front-end timer slots in flight: (slot_feat, slot_gmm)
+    tl_dump = [] if os.environ.get("VBH_BENCH_TIMELINE") else None     # diagnostic: per-utterance device timelines of every timed batch
 
     def front_end(j, timed):
         """MFCC -> post -> GMM of batch j into ring[j % n_ring], on the front-end stream"""
@@ -265,6 +273,8 @@ def main():
             L.dec.decode_end()
             L.pending = False
             last_done[0] = L
+            if tl_dump is not None and L.timed:
+                tl_dump.append(np.array([L.dec.timeline(u) for u in range(args.batch)], np.int64))
             if L.timed:
                 tm = L.dec.times()      # HIP events around the search kernel on its stream + host clocks
                 dec_ms.append(tm["total_ms"]); dec_k_ms.append(tm["kernel_ms"])
@@ -325,6 +335,16 @@ def main():
                       "busy_fraction_of_span": float((tl[:, 1] - tl[:, 0]).sum()) / (len(set(tl[:, 2].tolist())) * span),
                       "utterance_ms_min_mean_max": [float((tl[:, 1] - tl[:, 0]).min()) / 1e5, float((tl[:, 1] - tl[:, 0]).mean()) / 1e5,
                                                     float((tl[:, 1] - tl[:, 0]).max()) / 1e5]}
+    if tl_dump:
+        allb = np.stack(tl_dump)                  # [batches, utterances, (start, end, workgroup)] in 100 MHz ticks
+        np.save(os.environ["VBH_BENCH_TIMELINE"], allb)
+        t_lo, t_hi = allb[:, :, 0].min(), allb[:, :, 1].max()
+        busy = float((allb[:, :, 1] - allb[:, :, 0]).sum())
+        nwg = len(set(allb[0, :, 2].tolist()))
+        print("timeline: %d batches, first start to last end %.1f ms (wall %.1f ms), search busy %.1f%% of %d workgroups; "
+              "batch starts (ms): %s; batch ends: %s" % (len(tl_dump), (t_hi - t_lo) / 1e5, dt * 1e3, 100 * busy / (nwg * (t_hi - t_lo)), nwg,
+              [round(float(b[:, 0].min() - t_lo) / 1e5) for b in allb], [round(float(b[:, 1].max() - t_lo) / 1e5) for b in allb]),
+              file=sys.stderr, flush=True)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -404,7 +424,7 @@ def main():
                                     % (args.beam, args.lattice_beam, args.max_active, graph.num_states, graph.num_arcs)),
                        "utterances_per_step_per_gpu": args.batch, "utterance_seconds": args.seconds,
                        "frames_per_step_per_gpu": T, "pdfs": gmm.num_pdfs, "gaussians": gmm.num_gauss, "dim": 39,
-                       "batches_in_flight": depth,
+                       "batches_in_flight": depth, "search_cus": args.search_cus,
                        "sharding": "utterances over ranks, no data-path collective"},
             "roofline": roof, "stage_ms": stage_ms,
         }
