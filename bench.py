@@ -231,6 +231,8 @@ def main():
     n_ring = depth + 1 if depth > 1 else 1
     ring = [(raw, feats, ll)] + [(torch.empty_like(raw), torch.empty_like(feats), torch.empty_like(ll)) for _ in range(n_ring - 1)]
     lanes = []
+    if depth > 1 and dec is not None:
+        dec.close()          # the probe/setup decoder on the front-end context is not used by the pipeline
     for k in range(depth):
         L = Lane()
         if depth == 1:
@@ -243,7 +245,6 @@ def main():
         L.timed = False
         lanes.append(L)
     if depth > 1 and dec is not None:
-        dec.close()          # the probe/setup decoder on the front-end context is not used by the pipeline
         dec = lanes[0].dec
     ctx.torch_sync()
     gmm_ms, feat_ms, dec_ms, dec_k_ms, dec_h_ms = [], [], [], [], []

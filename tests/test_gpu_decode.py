@@ -152,7 +152,7 @@ def test_decode_begin_end_two_contexts(ctx):
     S, P, T, seed = 30000, 96, 120, 21
     g, t2p, ll = make_case(S, P, T, seed, eps_frac=0.3, spread=30.0)
     lens = [[T, 61, 17], [88, T]]
-    ctx2 = api.Context(0)
+    ctx2 = api.Context(0, cus=2)            # confined to two CUs (vbh_ctx_create_on_cus): three utterances on two workgroups
     graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
     decs = [api.LatticeDecoder(c, graph, 3, T, **cfg) for c in (ctx, ctx2)]
     bufs, foffs = [], []

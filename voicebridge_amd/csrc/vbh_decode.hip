@@ -1664,7 +1664,12 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
   const long long ma = std::min<long long>(cfg->max_active, S);
   // new tokens per frame are bounded by the arcs leaving the expanded tokens (~max_active * out-degree)
   const long long per_frame_tok = std::min<long long>(S, big ? std::max<long long>(8192, 8 * ma) : std::max<long long>(4096, 2 * ma));
-  const long long per_frame_link = std::min<long long>(std::max<long long>(graph->A, 1), 2 * per_frame_tok);
+  long long per_frame_link = std::min<long long>(std::max<long long>(graph->A, 1), 2 * per_frame_tok);
+  // VBH_SLOT_SCALE (tuning): scales the raw-window link and candidate capacities of the small slots;
+  // an utterance that outgrows them is searched again in a big slot
+  double slot_scale = 1.0;
+  if (const char *e = getenv("VBH_SLOT_SCALE")) { const double x = atof(e); if (x > 0.05 && x <= 4.0) slot_scale = x; }
+  if (!big) per_frame_link = std::max<long long>(1024, (long long)(per_frame_link * slot_scale));
   const long long surv_tok = big ? 2048 : 160, surv_link = big ? 4096 : 320;   // lattice survivors per frame
   const int pi = effective_prune_interval(cfg);
   const int win = pi + 1;
@@ -1680,7 +1685,8 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
   // candidates of one frame = arcs leaving the expanded tokens: at most ~max_active tokens are
   // expanded (GetCutoff), each with at most max_degree arcs
   p.cand_cap = (int)std::min<long long>(std::max<long long>(graph->A, 1),
-                                        std::min<long long>((ma + 256) * std::max(graph->max_degree, 1), big ? (1LL << 24) : (1LL << 21)));
+                                        std::min<long long>((ma + 256) * std::max(graph->max_degree, 1),
+                                                            big ? (1LL << 24) : (long long)((1LL << 21) * slot_scale)));
   set->proto = p; set->n = n;
   set->h.assign(n, p);
   const size_t F = (size_t)max_frames + 2;
