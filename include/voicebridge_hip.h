@@ -38,10 +38,11 @@ int vbh_ctx_create(int device_id, vbh_ctx **out); /* fails (-1) when there is no
 /* priority 0 = default; larger = this context's kernels are dispatched before those of lower
  * priority contexts when CUs free up (clamped to what the device offers) */
 int vbh_ctx_create_with_priority(int device_id, int priority, vbh_ctx **out);
-/* a context whose kernels run on n_cus of the device's CUs only (spread evenly over the XCDs);
- * kernels that size their grid by the CU count (the searches) see n_cus.  Used to keep CUs free
- * for the work of other contexts while a persistent search grid is resident. */
-int vbh_ctx_create_on_cus(int device_id, int n_cus, vbh_ctx **out);
+/* a context whose kernels run only on CUs [first_cu, first_cu + n_cus) of the device's CU mask
+ * (consecutive mask bits are spread evenly over the XCDs); kernels that size their grid by the
+ * CU count (the searches) see n_cus.  Used to keep CUs free for the work of other contexts while
+ * a persistent search grid is resident. */
+int vbh_ctx_create_on_cus(int device_id, int first_cu, int n_cus, vbh_ctx **out);
 void vbh_ctx_destroy(vbh_ctx *ctx);
 int vbh_ctx_sync(vbh_ctx *ctx);
 /* work enqueued on ctx after this call starts only when everything enqueued on other so far

@@ -35,13 +35,13 @@ def _f32p(a):
 class Context:
     """One per GPU (vbh_ctx)."""
 
-    def __init__(self, device=0, priority=0, cus=0):
+    def __init__(self, device=0, priority=0, cus=0, first_cu=0):
         self.lib = _lib.load()
         if self.lib.vbh_device_count() <= 0:
             raise _lib.VbhError("no HIP device visible: voicebridge_amd has no CPU path")
         h = C.c_void_p()
         if cus > 0:       # confined to `cus` compute units (vbh_ctx_create_on_cus)
-            check(self.lib.vbh_ctx_create_on_cus(int(device), int(cus), C.byref(h)), "vbh_ctx_create_on_cus")
+            check(self.lib.vbh_ctx_create_on_cus(int(device), int(first_cu), int(cus), C.byref(h)), "vbh_ctx_create_on_cus")
         else:
             check(self.lib.vbh_ctx_create_with_priority(int(device), int(priority), C.byref(h)), "vbh_ctx_create")
         self.h = h

@@ -54,14 +54,14 @@ int vbh_device_count(void) {
   return n;
 }
 
-static int ctx_create(int device_id, int priority, int n_cus, vbh_ctx **out);
-int vbh_ctx_create(int device_id, vbh_ctx **out) { return ctx_create(device_id, 0, 0, out); }
-int vbh_ctx_create_with_priority(int device_id, int priority, vbh_ctx **out) { return ctx_create(device_id, priority, 0, out); }
-int vbh_ctx_create_on_cus(int device_id, int n_cus, vbh_ctx **out) {
-  VBH_CHECK(n_cus > 0, "vbh_ctx_create_on_cus: n_cus = %d", n_cus);
-  return ctx_create(device_id, 0, n_cus, out);
+static int ctx_create(int device_id, int priority, int first_cu, int n_cus, vbh_ctx **out);
+int vbh_ctx_create(int device_id, vbh_ctx **out) { return ctx_create(device_id, 0, 0, 0, out); }
+int vbh_ctx_create_with_priority(int device_id, int priority, vbh_ctx **out) { return ctx_create(device_id, priority, 0, 0, out); }
+int vbh_ctx_create_on_cus(int device_id, int first_cu, int n_cus, vbh_ctx **out) {
+  VBH_CHECK(n_cus > 0 && first_cu >= 0, "vbh_ctx_create_on_cus: first_cu = %d, n_cus = %d", first_cu, n_cus);
+  return ctx_create(device_id, 0, first_cu, n_cus, out);
 }
-static int ctx_create(int device_id, int priority, int n_cus, vbh_ctx **out) {
+static int ctx_create(int device_id, int priority, int first_cu, int n_cus, vbh_ctx **out) {
   VBH_CHECK(out != nullptr, "vbh_ctx_create: out is NULL");
   int n = vbh_device_count();
   VBH_CHECK(n > 0, "vbh_ctx_create: no HIP device visible (this library has no CPU path)");
@@ -72,12 +72,13 @@ static int ctx_create(int device_id, int priority, int n_cus, vbh_ctx **out) {
   hipDeviceProp_t prop;
   VBH_HIP(hipGetDeviceProperties(&prop, device_id));
   c->num_cus = prop.multiProcessorCount;
-  if (n_cus > 0 && n_cus < c->num_cus) {
-    // a stream confined to the first n_cus bits of the CU mask; the driver deals consecutive bits
-    // round-robin over the XCDs, so every XCD contributes n_cus / 8 of its CUs.  Work of other
-    // contexts keeps the remaining CUs to itself whatever this context has in flight.
+  if (n_cus > 0 && first_cu < c->num_cus && (first_cu > 0 || n_cus < c->num_cus)) {
+    // a stream confined to bits [first_cu, first_cu + n_cus) of the CU mask; the driver deals
+    // consecutive bits round-robin over the XCDs, so every XCD contributes n_cus / 8 of its CUs.
+    // Contexts on disjoint ranges never wait for each other's workgroups to leave a CU.
+    if (first_cu + n_cus > c->num_cus) n_cus = c->num_cus - first_cu;
     uint32_t mask[32] = {0};
-    for (int i = 0; i < n_cus && i < 1024; i++) mask[i >> 5] |= 1u << (i & 31);
+    for (int i = first_cu; i < first_cu + n_cus && i < 1024; i++) mask[i >> 5] |= 1u << (i & 31);
     VBH_HIP(hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)((c->num_cus + 31) / 32), mask));
     c->num_cus = n_cus;
   } else {
