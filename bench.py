@@ -433,7 +433,7 @@ def main():
         # HBM traffic of the dominant kernels from the committed rocprofv3 --pmc passes of this
         # same command (profiles/): only attached when the batch size matches that run
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")))
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")))
             if tr.get("batch") == args.batch and world == 1:
                 for ro in [out["roofline"]] + [out[k] for k in ("roofline_gmm", "roofline_decode") if k in out]:
                     b_ = tr["bytes_per_launch"].get(ro["kernel"])
@@ -447,6 +447,13 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, waves, utt2spk, xforms, model, decode_setup)
         print(json.dumps(out), flush=True)
+    # tear down in order: decoders before their contexts (and before the interpreter's own finalisation)
+    for L in lanes:
+        if L.dec is not None:
+            L.dec.close()
+    for L in lanes:
+        if L.ctx is not ctx:
+            L.ctx.close()
     if world > 1:
         dist.destroy_process_group()
 
