@@ -37,6 +37,8 @@ def build(force=False, verbose=True):
             extra = []
             if s in ("vbh_decode.hip", "vbh_faster.hip"):
                 extra = ["-ffp-contract=off"]   # exact float32 / float64 cost expressions
+            if s == "vbh_faster.hip" and os.environ.get("VBH_FASTER_PROF"):
+                extra.append("-DVBH_FASTER_PROF")
             if s == "vbh_decode.hip":
                 if os.environ.get("VBH_DECODE_NT"):
                     extra.append("-DVBH_DECODE_NT=" + os.environ["VBH_DECODE_NT"])

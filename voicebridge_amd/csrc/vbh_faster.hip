@@ -54,6 +54,7 @@ struct FSlot {
   double *c_w;             // [cand_cap] candidate new_weight
   i32x4 *c_r;              // [cand_cap] {arc, source token, next state | EPSBIT, 0}
   int *front[3];           // epsilon work lists (states), rotated
+  int *elist;              // [frame_cap] the frame's states that have epsilon arcs, each once (pushed by its creator)
   unsigned *g_hs; unsigned long long *g_hc; int *g_ht;   // second level of the state map, [g_cap] (power of two)
   int *remap;              // [tok_cap] garbage collection: mark, then new index
   i32x4 *stage_tok; double *stage_cost;   // [stage_cap] survivors on their way down
@@ -133,10 +134,19 @@ struct Shared {
   unsigned long long hc[HCAP];     // best cost (order-preserving key),
   int ht[HCAP];                    // index of the state's token within the frame
   int n_new, n_cand, fcnt[3], error, utt;
+  int n_eps;                       // fill of FSlot::elist
   int g_used;                      // the second level holds entries of the frame being built
   unsigned long long sel_prefix, sel_mask; int sel_k;
   unsigned long long u0;
+#ifdef VBH_FASTER_PROF      // build-time diagnostic: shader-clock cycles per phase, printed by thread 0 for the first utterances
+  long long tph[12], t_last;
+#endif
 };
+#ifdef VBH_FASTER_PROF
+#define FPHASE(i) { if (threadIdx.x == 0) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); sh.tph[i] += now_ - sh.t_last; sh.t_last = now_; } }
+#else
+#define FPHASE(i)
+#endif
 
 __device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v, Shared &sh, int &par) {
 #pragma unroll
@@ -284,6 +294,7 @@ __device__ __forceinline__ void map_clear(Shared &sh, const FSlot &s) {
 __device__ void epsilon_closure(const FGraph &g, const FSlot &s, double cutoff, Shared &sh) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   gp<unsigned long long> win = uptr(s.win);
+  gp<int> elist = uptr(s.elist);
   const Map2 m2 = map2_of(s);
   const int frame_cap = s.frame_cap, front_cap = s.front_cap;
   int cur = 0;
@@ -308,7 +319,7 @@ __device__ void epsilon_closure(const FGraph &g, const FSlot &s, double cutoff, 
       wave_expand(cnt, [&](bool valid, int owner, int j) {
         const int a = __shfl(a0, owner, 64) + j;
         const double cc = __shfl(c, owner, 64);
-        bool create = false, push = false; int ds = 0, nslot = -1;   // (-1: none / no room)
+        bool create = false, push = false, eps = false; int ds = 0, nslot = -1;   // (-1: none / no room)
         if (valid) {
           const i32x4 arc = uptr(g.arcs)[a];
           const double nc = cc + (double)asf(arc.y);
@@ -318,6 +329,7 @@ __device__ void epsilon_closure(const FGraph &g, const FSlot &s, double cutoff, 
             map_relax(sh, m2, ds, nc, nslot, create, improved);
             if (nslot == -1) sh.error = FERR_MAP;
             push = nslot != -1 && (create || improved) && arc.x < 0;
+            eps = create && arc.x < 0;
           }
         }
         const int li = wave_alloc(&sh.n_new, create);
@@ -325,6 +337,8 @@ __device__ void epsilon_closure(const FGraph &g, const FSlot &s, double cutoff, 
           if (li < frame_cap) { map_set_idx(sh, m2, nslot, li); win[li] = ~0ull; }
           else sh.error = FERR_FRAME;
         }
+        const int qe = wave_alloc(&sh.n_eps, eps);
+        if (eps && qe < frame_cap) elist[qe] = ds;      // (qe >= frame_cap implies li >= frame_cap: already an error)
         const int q = wave_alloc(&sh.fcnt[nxt], push);
         if (push) { if (q < front_cap) fnext[q] = ds; else sh.error = FERR_FRONT; }
       });
@@ -350,20 +364,25 @@ __device__ __forceinline__ bool map_entry(const Shared &sh, const Map2 &m, int e
   return true;
 }
 
-// the winning epsilon arc of every state: all states of the frame that have epsilon arcs re-walk
-// them with the final costs; an arc that reproduces its destination's cost competes with its index
+// the winning epsilon arc of every state: the frame's states that have epsilon arcs (FSlot::elist)
+// re-walk them with the final costs; an arc that reproduces its destination's cost competes with its index
 __device__ void epsilon_winners(const FGraph &g, const FSlot &s, double cutoff, int tok_base, Shared &sh) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   gp<unsigned long long> win = uptr(s.win);
+  gp<const int> elist = uptr(s.elist);
   const Map2 m2 = map2_of(s);
-  const int n_ent = HCAP + (sh.g_used ? s.g_cap : 0);
-  for (int base = wave * 64; base < n_ent; base += NW * 64) {
-    int st = 0, li = 0; unsigned long long key = 0;
-    const bool have = map_entry(sh, m2, base + lane, st, key, li);
-    const double c = have ? o2d(key) : 0.0;
-    int a0 = 0, cnt = 0;
-    if (have && !(c > cutoff)) { const i32x4 sr = uptr(g.st)[st]; a0 = sr.x; cnt = sr.y; }
-    const int my_tok = have ? tok_base + li : 0;
+  const int n = sh.n_eps < s.frame_cap ? sh.n_eps : s.frame_cap;
+  const int CH = wave_chunk(n);
+  for (int base = wave * CH; base < n; base += NW * CH) {
+    const int i = base + lane;
+    const bool have = lane < CH && i < n;
+    const int st = have ? elist[i] : 0;
+    const i32x4 sr = uptr(g.st)[st];
+    const int slot = have ? map_find(sh, m2, st) : -1;
+    const double c = slot != -1 ? o2d(map_key(sh, m2, slot)) : 0.0;
+    const bool exp = have && slot != -1 && !(c > cutoff);
+    const int a0 = sr.x, cnt = exp ? sr.y : 0;
+    const int my_tok = exp ? tok_base + map_idx(sh, m2, slot) : 0;
     wave_expand(cnt, [&](bool valid, int owner, int j) {
       const int a = __shfl(a0, owner, 64) + j;
       const double cc = __shfl(c, owner, 64);
@@ -382,20 +401,48 @@ __device__ void epsilon_winners(const FGraph &g, const FSlot &s, double cutoff, 
   }
 }
 
-// one token per map entry, appended to the utterance's history at tok_base
+// one token per map entry, appended to the utterance's history at tok_base.  The LDS level is
+// walked HCAP / NT entries per thread with every winner fetched before the first is used.
 __device__ void make_tokens(const FSlot &s, int tok_base, Shared &sh) {
   gp<i32x4> tok = uptr(s.tok); gp<double> cost = uptr(s.cost);
   gp<const unsigned long long> win = uptr(s.win);
   const Map2 m2 = map2_of(s);
-  const int n_ent = HCAP + (sh.g_used ? s.g_cap : 0);
-  for (int e = threadIdx.x; e < n_ent; e += NT) {
-    int st, li; unsigned long long key;
-    if (!map_entry(sh, m2, e, st, key, li)) continue;
-    const unsigned long long w = win[li];
-    i32x4 r; r.x = (int)(unsigned)w; r.y = (int)(unsigned)(w >> 32); r.z = st; r.w = 0;
-    if (w == ~0ull) { r.x = -1; r.y = -1; }      // the start token
-    tok[tok_base + li] = r;
-    cost[tok_base + li] = o2d(key);
+  constexpr int PER = HCAP / NT;
+  int st[PER], li[PER]; unsigned long long key[PER], w[PER]; bool have[PER];
+#pragma unroll
+  for (int u = 0; u < PER; u++) {
+    const int e = u * NT + threadIdx.x;
+    const unsigned tag = sh.hs[e];
+    have[u] = tag != HEMPTY;
+    st[u] = (int)tag; key[u] = sh.hc[e]; li[u] = have[u] ? sh.ht[e] : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < PER; u++) { w[u] = ~0ull; if (have[u]) w[u] = win[li[u]]; }
+#ifdef VBH_FASTER_PROF
+  { unsigned long long x = 0;
+#pragma unroll
+    for (int u = 0; u < PER; u++) x ^= w[u];
+    if (x == 0x123456789ull) sh.u0 = x; }
+  FPHASE(10)
+#endif
+#pragma unroll
+  for (int u = 0; u < PER; u++) {
+    if (!have[u]) continue;
+    i32x4 r; r.x = (int)(unsigned)w[u]; r.y = (int)(unsigned)(w[u] >> 32); r.z = st[u]; r.w = 0;
+    if (w[u] == ~0ull) { r.x = -1; r.y = -1; }      // the start token
+    tok[tok_base + li[u]] = r;
+    cost[tok_base + li[u]] = o2d(key[u]);
+  }
+  if (sh.g_used) {
+    for (int e = HCAP + threadIdx.x; e < HCAP + s.g_cap; e += NT) {
+      int st1, li1; unsigned long long key1;
+      if (!map_entry(sh, m2, e, st1, key1, li1)) continue;
+      const unsigned long long w1 = win[li1];
+      i32x4 r; r.x = (int)(unsigned)w1; r.y = (int)(unsigned)(w1 >> 32); r.z = st1; r.w = 0;
+      if (w1 == ~0ull) { r.x = -1; r.y = -1; }
+      tok[tok_base + li1] = r;
+      cost[tok_base + li1] = o2d(key1);
+    }
   }
 }
 
@@ -463,6 +510,10 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
   __syncthreads();
   const FSlot &s = s_slot;
   int par = 0;
+#ifdef VBH_FASTER_PROF
+  long long *tph = sh.tph;
+  if (tid == 0) { for (int i = 0; i < 12; i++) sh.tph[i] = 0; sh.t_last = (long long)__builtin_amdgcn_s_memtime(); }
+#endif
   while (true) {
     __syncthreads();
     if (tid == 0) sh.utt = atomicAdd(work_counter, 1);
@@ -479,14 +530,14 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
     __syncthreads();
     map_clear(sh, s);
     __syncthreads();
-    if (tid == 0) { sh.n_new = 0; sh.n_cand = 0; sh.fcnt[0] = sh.fcnt[1] = sh.fcnt[2] = 0; sh.error = FERR_NONE; sh.g_used = 0; }
+    if (tid == 0) { sh.n_new = 0; sh.n_cand = 0; sh.n_eps = 0; sh.fcnt[0] = sh.fcnt[1] = sh.fcnt[2] = 0; sh.error = FERR_NONE; sh.g_used = 0; }
     __syncthreads();
     // ---- InitDecoding (:36-45): the start token, then the epsilon closure with cutoff FLT_MAX
     if (tid == 0) {
       int slot; bool create, improved;
       map_relax(sh, m2, g.start, 0.0, slot, create, improved);
       map_set_idx(sh, m2, slot, 0); uptr(s.win)[0] = ~0ull; sh.n_new = 1;
-      if (uptr(g.st)[g.start].y > 0) { uptr(s.front[0])[0] = g.start; sh.fcnt[0] = 1; }
+      if (uptr(g.st)[g.start].y > 0) { uptr(s.front[0])[0] = g.start; sh.fcnt[0] = 1; uptr(s.elist)[0] = g.start; sh.n_eps = 1; }
     }
     __syncthreads();
     epsilon_closure(g, s, (double)FLT_MAX, sh);
@@ -501,12 +552,14 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
     __syncthreads();
     int frames_done = 0;
     int gc_base = 0;
+    FPHASE(9)
     for (int frame = 0; frame < T && sh.error == FERR_NONE; frame++) {
       if (cur_b + cur_n + s.frame_cap > s.tok_cap) {      // make room for whatever this frame may create
         cur_b = collect_garbage(s, gc_base, cur_b, cur_n, sh);
         gc_base = cur_b;
         if (sh.error != FERR_NONE) break;
       }
+      FPHASE(0)
       const float *llrow = loglikes + (ud.row0 + frame) * (long long)P;
       gp<const double> ccost = cost + cur_b;
       gp<const i32x4> ctok = tok + cur_b;
@@ -521,20 +574,36 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
       else {
         const double beam_cutoff = best + cfg.beam;
         double mac = (double)INFINITY, mic = (double)INFINITY;
-        if (n > cfg.max_active) mac = select_kth(ccost, n, cfg.max_active, sh);
+        // the order statistics are only computed when they decide the comparisons below:
+        // tmp[max_active] < beam_cutoff  <=>  more than max_active costs lie below beam_cutoff;
+        // tmp[min_active] > beam_cutoff  <=>  at most min_active costs are <= beam_cutoff
+        unsigned long long cnt = 0;   // (#cost < beam_cutoff) << 32 | (#cost <= beam_cutoff)
+        for (int i = tid; i < n; i += NT) {
+          const double c = ccost[i];
+          cnt += ((unsigned long long)(c < beam_cutoff) << 32) | (unsigned long long)(c <= beam_cutoff);
+        }
+        cnt = block_sum_u64(cnt, sh, par);
+        const int cnt_lt = (int)(cnt >> 32), cnt_le = (int)(unsigned)cnt;
+        if (n > cfg.max_active && cnt_lt > cfg.max_active) mac = select_kth(ccost, n, cfg.max_active, sh);
         if (mac < beam_cutoff) { adaptive_beam = (float)(mac - best + cfg.beam_delta); weight_cutoff = mac; }
         else {
-          if (n > cfg.min_active) mic = cfg.min_active == 0 ? best : select_kth(ccost, n, cfg.min_active, sh);
+          if (n > cfg.min_active) {
+            if (cfg.min_active == 0) mic = best;
+            else if (cnt_le <= cfg.min_active) mic = select_kth(ccost, n, cfg.min_active, sh);
+            else mic = beam_cutoff;     // some value <= beam_cutoff: the comparison below is false
+          }
           if (mic > beam_cutoff) { adaptive_beam = (float)(mic - best + cfg.beam_delta); weight_cutoff = mic; }
           else { adaptive_beam = cfg.beam; weight_cutoff = beam_cutoff; }
         }
       }
+      FPHASE(1)
       // the map of the frame about to be built
       map_clear(sh, s);
       __syncthreads();
-      if (tid == 0) { sh.n_new = 0; sh.n_cand = 0; sh.fcnt[0] = sh.fcnt[1] = sh.fcnt[2] = 0; sh.g_used = 0; }
+      if (tid == 0) { sh.n_new = 0; sh.n_cand = 0; sh.n_eps = 0; sh.fcnt[0] = sh.fcnt[1] = sh.fcnt[2] = 0; sh.g_used = 0; }
       __syncthreads();
       // ---- pass 1 (:224-303, arc-parallel): candidates + min of new_weight + adaptive_beam
+      FPHASE(2)
       unsigned long long mymin = ~0ull;
       {
         const int cand_cap = s.cand_cap;
@@ -572,9 +641,10 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
       mymin = block_min_u64(mymin, sh, par);
       const double next_cutoff = mymin == ~0ull ? (double)INFINITY : o2d(mymin);
       const int ncand = sh.n_cand < s.cand_cap ? sh.n_cand : s.cand_cap;
+      FPHASE(3)
       // ---- pass 2: admit new_weight < next_cutoff; cheapest per state
       {
-        gp<int> front0 = uptr(s.front[0]);
+        gp<int> front0 = uptr(s.front[0]); gp<int> elist0 = uptr(s.elist);
         const int frame_cap = s.frame_cap, front_cap = s.front_cap;
         for (int base = 0; base < ncand; base += NT) {
           const int q = base + tid;
@@ -591,16 +661,23 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
             else sh.error = FERR_FRAME;
           }
           const int f = wave_alloc(&sh.fcnt[0], pushf);
-          if (pushf) { if (f < front_cap) front0[f] = r.z & STMASK; else sh.error = FERR_FRONT; }
+          if (pushf) {      // (a created state with epsilon arcs: also the head of the frame's epsilon-state list)
+            if (f < front_cap) front0[f] = r.z & STMASK; else sh.error = FERR_FRONT;
+            if (f < frame_cap) elist0[f] = r.z & STMASK;
+          }
         }
       }
+      __syncthreads();
+      if (tid == 0) sh.n_eps = sh.fcnt[0];     // the closure appends the states it creates (it starts with a barrier-free read of fcnt only)
       __syncthreads();
 #ifdef VBH_FASTER_DEBUG
       if (tid == 0 && utt == 0 && frame < 12) printf("frame %d after pass2: n=%d ncand=%d n_new=%d g_used=%d err=%d fcnt0=%d\n", frame, n, ncand, sh.n_new, sh.g_used, sh.error, sh.fcnt[0]);
 #endif
       if (sh.error != FERR_NONE) break;
+      FPHASE(4)
       // ---- ProcessNonemitting(next_cutoff) to the fixed point
       epsilon_closure(g, s, next_cutoff, sh);
+      FPHASE(5)
       if (sh.error != FERR_NONE) break;
       const int nb = cur_b + cur_n;
       const int n_new = sh.n_new < s.frame_cap ? sh.n_new : s.frame_cap;
@@ -621,10 +698,14 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
+      FPHASE(6)
       epsilon_winners(g, s, next_cutoff, nb, sh);
       __syncthreads();
+      FPHASE(7)
       make_tokens(s, nb, sh);
+      FPHASE(11)
       __syncthreads();
+      FPHASE(8)
       cur_b = nb; cur_n = n_new;
       frames_done = frame + 1;
     }
@@ -683,6 +764,14 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
         __syncthreads();
       }
     }
+    FPHASE(9)
+#ifdef VBH_FASTER_PROF
+    if (tid == 0 && utt < 4) {
+      printf("faster utt %d (%d frames, %lld tokens): cycles/frame gc %lld cutoff %lld clear %lld pass1 %lld pass2 %lld closure %lld winners %lld eps-winners %lld make: loads %lld stores %lld barrier %lld; outside the frame loop %lld total\n",
+             utt, T, (long long)(cur_b + cur_n), tph[0] / T, tph[1] / T, tph[2] / T, tph[3] / T, tph[4] / T, tph[5] / T, tph[6] / T, tph[7] / T, tph[10] / T, tph[11] / T, tph[8] / T, tph[9]);
+    }
+    if (tid == 0) for (int i = 0; i < 12; i++) tph[i] = 0;
+#endif
     if (tid == 0) {
       FResult *r = &results[utt];
       r->ok = r_ok; r->error = sh.error; r->reached_final = r_final; r->num_frames = frames_done; r->path_len = r_len;
@@ -773,6 +862,7 @@ int vbh_faster_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_fa
   A_(tok, i32x4, p.tok_cap) A_(cost, double, p.tok_cap) A_(win, unsigned long long, p.frame_cap)
   A_(c_w, double, p.cand_cap) A_(c_r, i32x4, p.cand_cap)
   A_(front[0], int, p.front_cap) A_(front[1], int, p.front_cap) A_(front[2], int, p.front_cap)
+  A_(elist, int, p.frame_cap)
   A_(g_hs, unsigned, p.g_cap) A_(g_hc, unsigned long long, p.g_cap) A_(g_ht, int, p.g_cap)
   A_(remap, int, p.tok_cap) A_(stage_tok, i32x4, p.stage_cap) A_(stage_cost, double, p.stage_cap)
 #undef A_
