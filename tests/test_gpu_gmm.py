@@ -35,10 +35,12 @@ def test_gmm_golden(ctx, name):
     m.close()
 
 
-@pytest.mark.parametrize("P,G,D,T", [(50, 300, 39, 200), (7, 7, 13, 65), (300, 1800, 40, 130), (3, 240, 39, 5)])
+@pytest.mark.parametrize("P,G,D,T", [(50, 300, 39, 200), (7, 7, 13, 65), (300, 1800, 40, 130), (3, 240, 39, 5),
+                                     (3, 700, 39, 70), (2, 2100, 20, 130), (40, 6000, 39, 200)])
 def test_gmm_vs_oracle(ctx, P, G, D, T):
     """ragged frame counts (not multiples of the 64-frame tile), 1-Gaussian pdfs, pdfs with
-    ~100 Gaussians, tiles split over blockIdx.y"""
+    ~100 Gaussians, tiles split over blockIdx.y, pdfs with more Gaussians than one 128-column tile
+    (scored in parts and folded)"""
     import torch
     from oracle import vbo
     from voicebridge_amd import api, synth

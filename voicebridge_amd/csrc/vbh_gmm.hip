@@ -16,7 +16,8 @@
 // a log-sum-exp over each pdf's own Gaussians.  The model is packed once, tile-major, so a
 // workgroup streams B tiles with 16-byte coalesced loads (L2/MALL resident: 4.7 MB at
 // G = 15000, D = 39) while its 64 frames of A stay in LDS.  The accumulator tile is spilled to
-// the LDS space of the B tile it came from, and the epilogue threads walk pdfs.
+// the LDS space of the B tile it came from, and the epilogue threads walk pdfs.  A pdf with more
+// than 128 Gaussians is scored as several column groups that gmm_fold_parts_kernel combines.
 //
 // Roofline: per T frames  bytes = 4(2GD+G) + 4TD + 4TP,
 // flops = TG(4D+2) + TG + TP.  At the reference sizes this is fp32-matrix bound (AI ~ 200
@@ -24,6 +25,7 @@
 // reports its HBM fraction.
 #include "vbh_internal.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 
@@ -210,6 +212,31 @@ __global__ __launch_bounds__(256, 2) void gmm_loglikes_kernel(
   }
 }
 
+// A pdf with more than TN Gaussians is scored as several parts of <= TN columns (each part is a
+// "pdf" of the tile kernel above, written to a scratch [T x n_parts] block); this pass folds the
+// parts of every pdf with one more LogSumExp (same cutoff rule, kaldi-vector.cc:757-775).
+__global__ __launch_bounds__(256) void gmm_fold_parts_kernel(
+    const float *__restrict__ parts, long long T, int n_parts, int P,
+    const int *__restrict__ pdf_parts,     // [P+1] first part of every pdf
+    float *__restrict__ out) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= T * P) return;
+  const long long t = idx / P;
+  const int p = (int)(idx - t * P);
+  const int a = pdf_parts[p], b = pdf_parts[p + 1];
+  const float *row = parts + t * n_parts;
+  float m = row[a];
+  for (int i = a + 1; i < b; i++) m = fmaxf(m, row[i]);
+  float res = m;
+  if (b - a > 1 && m > -INFINITY) {
+    const float cutoff = m + -15.9423847198486328125f;
+    float sum = 0.f;
+    for (int i = a; i < b; i++) { const float v = row[i]; if (v >= cutoff) sum += __expf(v - m); }
+    res = m + __logf(sum);
+  }
+  out[idx] = res;
+}
+
 }  // namespace
 
 struct vbh_gmm {
@@ -221,6 +248,12 @@ struct vbh_gmm {
   DevBuf<GmmTile> tiles;
   DevBuf<int> d_offs;
   size_t lds_bytes;
+  // pdfs with more than TN Gaussians: n_parts > P column groups, folded by gmm_fold_parts_kernel
+  int n_parts;
+  std::vector<int> part_offs;     // [n_parts+1] Gaussian column starts of the parts
+  DevBuf<int> d_pdf_parts;        // [P+1] first part of every pdf
+  DevBuf<float> part_scratch;     // [part_chunk x n_parts]
+  long long part_chunk;
 };
 
 extern "C" {
@@ -235,11 +268,22 @@ int vbh_gmm_create(vbh_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h
   const int D = dim, P = num_pdfs, G = h_pdf_offsets[P];
   for (int p = 0; p < P; p++) {
     const int n = h_pdf_offsets[p + 1] - h_pdf_offsets[p];
-    VBH_CHECK(n >= 1 && n <= TN, "vbh_gmm_create: pdf %d has %d Gaussians (supported: 1..%d)", p, n, TN);
+    VBH_CHECK(n >= 1, "vbh_gmm_create: pdf %d has %d Gaussians", p, n);
   }
   vbh_gmm *g = new vbh_gmm();
   g->ctx = ctx; g->D = D; g->P = P; g->G = G;
   g->offs.assign(h_pdf_offsets, h_pdf_offsets + P + 1);
+  // parts: a pdf of n Gaussians is ceil(n/TN) column groups of near-equal size
+  std::vector<int> pdf_parts(P + 1, 0);
+  g->part_offs.assign(1, 0);
+  for (int p = 0; p < P; p++) {
+    const int n = h_pdf_offsets[p + 1] - h_pdf_offsets[p], k = (n + TN - 1) / TN;
+    for (int i = 1; i <= k; i++) g->part_offs.push_back(h_pdf_offsets[p] + (int)((long long)n * i / k));
+    pdf_parts[p + 1] = pdf_parts[p] + k;
+  }
+  g->n_parts = pdf_parts[P];
+  const int *poffs = g->part_offs.data();
+  const int NP = g->n_parts;
   // ---- ComputeGconsts (diag-gmm.cc:114-152): float accumulator, double right-hand sides
   g->gconsts.resize(G);
   const float offset = (float)(-0.5 * 1.8378770664093454835606594728112 * D);
@@ -258,10 +302,10 @@ int vbh_gmm_create(vbh_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h
   const int K = 2 * D + 1;
   g->Kpad = (K + 7) & ~7;
   std::vector<GmmTile> tiles;
-  for (int p = 0; p < P;) {
-    GmmTile t{h_pdf_offsets[p], 0, p, 0};
-    while (p < P && t.ng + (h_pdf_offsets[p + 1] - h_pdf_offsets[p]) <= TN) {
-      t.ng += h_pdf_offsets[p + 1] - h_pdf_offsets[p];
+  for (int p = 0; p < NP;) {
+    GmmTile t{poffs[p], 0, p, 0};
+    while (p < NP && t.ng + (poffs[p + 1] - poffs[p]) <= TN) {
+      t.ng += poffs[p + 1] - poffs[p];
       t.np++; p++;
     }
     tiles.push_back(t);
@@ -282,7 +326,18 @@ int vbh_gmm_create(vbh_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h
   }
   hipStream_t s = ctx->stream;
   if (g->Bp.upload(Bp.data(), Bp.size(), s) || g->tiles.upload(tiles.data(), tiles.size(), s) ||
-      g->d_offs.upload(g->offs.data(), g->offs.size(), s)) { delete g; return -1; }
+      g->d_offs.upload(g->part_offs.data(), g->part_offs.size(), s)) { delete g; return -1; }
+  g->part_chunk = 0;
+  if (NP > P) {
+    // scratch for the parts of a chunk of frames (<= 256 MB), a multiple of the frame tile
+    long long chunk = (256LL << 20) / (4LL * NP);
+    chunk = chunk / TM * TM;
+    if (chunk < TM) chunk = TM;
+    if (chunk > 65536) chunk = 65536;
+    g->part_chunk = chunk;
+    if (g->d_pdf_parts.upload(pdf_parts.data(), pdf_parts.size(), s) ||
+        g->part_scratch.alloc((size_t)chunk * NP)) { delete g; return -1; }
+  }
   VBH_HIP(hipStreamSynchronize(s));
   const size_t a_floats = (size_t)g->Kpad * LDA + ((4 - (g->Kpad * LDA) % 4) % 4);
   const size_t bc_floats = std::max((size_t)g->Kpad * TN, (size_t)TM * LDC);
@@ -311,11 +366,30 @@ int vbh_gmm_work(const vbh_gmm *g, int64_t T, double *bytes, double *flops) {
   return 0;
 }
 
-int vbh_gmm_loglikes(vbh_gmm *g, const float *d_feats, int64_t T, float *d_out) {
+static int gmm_launch_tiles(vbh_gmm *g, const float *d_feats, long long T, int n_cols, float *d_out);
+
+int vbh_gmm_loglikes(vbh_gmm *g, const float *d_feats, int64_t T, float *d_loglikes) {
   VBH_CHECK(g, "vbh_gmm_loglikes: NULL model");
   if (T == 0) return 0;
-  VBH_CHECK(T > 0 && d_feats && d_out, "vbh_gmm_loglikes: bad arguments");
+  VBH_CHECK(T > 0 && d_feats && d_loglikes, "vbh_gmm_loglikes: bad arguments");
   if (vbh_use_device(g->ctx)) return -1;
+  if (g->n_parts == g->P) return gmm_launch_tiles(g, d_feats, T, g->P, d_loglikes);
+  // some pdf spans several column groups: score the parts of a chunk of frames, fold them
+  for (long long t0 = 0; t0 < T; t0 += g->part_chunk) {
+    const long long n = std::min<long long>(g->part_chunk, T - t0);
+    if (gmm_launch_tiles(g, d_feats + t0 * g->D, n, g->n_parts, g->part_scratch.p)) return -1;
+    const long long blocks = (n * g->P + 255) / 256;
+    VBH_CHECK(blocks < 2147483647LL, "vbh_gmm_loglikes: chunk too large");
+    hipLaunchKernelGGL(gmm_fold_parts_kernel, dim3((unsigned)blocks), dim3(256), 0, g->ctx->stream,
+                       g->part_scratch.p, n, g->n_parts, g->P, g->d_pdf_parts.p, d_loglikes + t0 * g->P);
+    VBH_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+}  // extern "C"
+
+static int gmm_launch_tiles(vbh_gmm *g, const float *d_feats, long long T, int n_cols, float *d_out) {
   const long long ftiles = (T + TM - 1) / TM;
   VBH_CHECK(ftiles < 2147483647LL, "vbh_gmm_loglikes: T too large");
   // split the Gaussian tiles over blockIdx.y only when there are too few frame tiles to fill the chip
@@ -332,7 +406,7 @@ int vbh_gmm_loglikes(vbh_gmm *g, const float *d_feats, int64_t T, float *d_out) 
     VBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gmm_loglikes_kernel<N>),               \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds_bytes));       \
     hipLaunchKernelGGL(gmm_loglikes_kernel<N>, dim3((unsigned)ftiles, groups), dim3(256), g->lds_bytes, \
-                       g->ctx->stream, d_feats, (long long)T, g->D, g->P, g->Bp.p, g->tiles.p,         \
+                       g->ctx->stream, d_feats, (long long)T, g->D, n_cols, g->Bp.p, g->tiles.p,         \
                        g->n_tiles, per, g->d_offs.p, d_out);                                           \
     break;
   switch (g->Kpad / 8) {
@@ -345,5 +419,3 @@ int vbh_gmm_loglikes(vbh_gmm *g, const float *d_feats, int64_t T, float *d_out) 
   VBH_HIP(hipGetLastError());
   return 0;
 }
-
-}  // extern "C"
