@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Golden fixture for the lattice stage (tests/golden/lattices.npz), made by running the
+REFERENCE'S OWN programs (oracle/_ref/bin, built by `make -C oracle ref` from /root/reference):
+
+  gmm-latgen-faster --determinize-lattice=false   -> raw state-level lattices      (input)
+  lattice-determinize-phone-pruned / -pruned       -> determinized compact lattices (expected)
+  lattice-scale | lattice-add-penalty | lattice-best-path -> words, alignments      (expected)
+  compute-wer                                       -> the %WER / %SER lines        (expected)
+
+on a seeded synthetic model + lexicon graph written by tests/util.py.  Data only: archives as
+bytes, transcripts as text.  Run in the build container only:  python oracle/gen_golden_lat.py
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from tests import util  # noqa: E402
+from voicebridge_amd import synth  # noqa: E402
+
+B = os.path.join(HERE, "_ref", "bin")
+
+
+def ref(name, *args, stdout=None):
+    return subprocess.run([os.path.join(B, name)] + list(args), check=True, stderr=subprocess.DEVNULL, stdout=stdout,
+                          env=dict(os.environ, OPENBLAS_NUM_THREADS="1"))
+
+
+def make_case(d, seed=5, n_words=40, n_cd=12, frames=(120, 45, 260)):
+    """model + graph + features of a small decode; returns the acoustic scale used"""
+    H = 3
+    P = n_cd * H
+    g, _t2p = synth.lexicon_graph(n_words, P, seed=seed, n_phones=n_cd)
+    offs, w, means, iv = synth.gmm_model(P, P * 3, 39, seed=seed + 1)
+    miv = (means * iv).astype(np.float32)
+    util.write_mdl(os.path.join(d, "final.mdl"), n_cd, H, offs, w, miv, iv)
+    util.write_vector_fst(os.path.join(d, "HCLG.fst"), g["final"], g["arc_offset"], g["arcs"])
+    rng = np.random.default_rng(seed + 2)
+    util.write_feats_ark(os.path.join(d, "feats.ark"), {"utt%c" % (65 + i): rng.standard_normal((T, 39)) * 1.2 for i, T in enumerate(frames)})
+
+
+def run_reference_chain(d, acwt="0.083333", beam="6", lmwt="9", wip="0.5"):
+    p = lambda n: os.path.join(d, n)
+    ref("gmm-latgen-faster", "--beam=13", "--lattice-beam=" + beam, "--acoustic-scale=" + acwt, "--allow-partial=true",
+        "--determinize-lattice=false", p("final.mdl"), p("HCLG.fst"), "ark:" + p("feats.ark"), "ark:" + p("raw.ark"))
+    ref("lattice-determinize-phone-pruned", "--acoustic-scale=" + acwt, "--beam=" + beam, p("final.mdl"), "ark:" + p("raw.ark"), "ark:" + p("det_pp.ark"))
+    ref("lattice-determinize-pruned", "--acoustic-scale=" + acwt, "--beam=" + beam, "ark:" + p("raw.ark"), "ark:" + p("det_p.ark"))
+    ref("lattice-scale", "--inv-acoustic-scale=" + lmwt, "ark:" + p("det_pp.ark"), "ark:" + p("scaled.ark"))
+    ref("lattice-add-penalty", "--word-ins-penalty=" + wip, "ark:" + p("scaled.ark"), "ark:" + p("pen.ark"))
+    ref("lattice-best-path", "ark:" + p("pen.ark"), "ark,t:" + p("best_words.txt"), "ark,t:" + p("best_ali.txt"))
+    # a reference transcript that differs from the hypothesis in a known way: drop / change words
+    hyp = [l.split() for l in open(p("best_words.txt"))]
+    with open(p("ref_text.txt"), "w") as f:
+        for i, l in enumerate(hyp):
+            words = l[1:]
+            if i == 0:
+                words = words[1:] + ["777"]
+            elif i == 1:
+                words = ["5"] + words
+            f.write(" ".join([l[0]] + words) + "\n")
+    with open(p("wer.txt"), "wb") as f:
+        ref("compute-wer", "--text", "--mode=present", "ark:" + p("ref_text.txt"), "ark:" + p("best_words.txt"), stdout=f)
+
+
+def main():
+    with tempfile.TemporaryDirectory(prefix="vbgold_lat_") as d:
+        make_case(d)
+        run_reference_chain(d)
+        arrays = {}
+        for fn in ("final.mdl", "raw.ark", "det_pp.ark", "det_p.ark", "scaled.ark", "pen.ark"):
+            arrays["file_" + fn.replace(".", "_")] = np.fromfile(os.path.join(d, fn), dtype=np.uint8)
+        for fn in ("best_words.txt", "best_ali.txt", "ref_text.txt", "wer.txt"):
+            arrays["text_" + fn.replace(".", "_")] = np.array(open(os.path.join(d, fn)).read())
+        arrays["opts"] = np.array(["acwt=0.083333", "beam=6", "lmwt=9", "wip=0.5"])
+        out = os.path.join(ROOT, "tests", "golden", "lattices.npz")
+        np.savez_compressed(out, **arrays)
+        print("lattices.npz %.1f KB" % (os.path.getsize(out) / 1024.0))
+        print(open(os.path.join(d, "wer.txt")).read())
+        print(open(os.path.join(d, "best_words.txt")).read())
+
+
+if __name__ == "__main__":
+    main()

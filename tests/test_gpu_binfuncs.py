@@ -139,8 +139,8 @@ def test_gmm_latgen_faster_vs_reference_program(host, tmp_path):
     rc = call(host.vb_GmmLatgenFaster, ["gmm-latgen-faster"] + opts + [str(d / "final.mdl"), str(d / "HCLG.fst"), "ark:%s" % (d / "feats.ark"),
                                         "ark:%s" % (d / "lat.ark"), "ark,t:%s" % (d / "words.txt"), "ark,t:%s" % (d / "ali.txt")], log)
     assert rc == 0, open(log).read()
-    # default --determinize-lattice=true with a lattice output must be refused loudly
-    assert call(host.vb_GmmLatgenFaster, ["gmm-latgen-faster", str(d / "final.mdl"), str(d / "HCLG.fst"), "ark:%s" % (d / "feats.ark"),
+    # --minimize=true is not part of this build: refused loudly, not ignored
+    assert call(host.vb_GmmLatgenFaster, ["gmm-latgen-faster", "--minimize=true", str(d / "final.mdl"), str(d / "HCLG.fst"), "ark:%s" % (d / "feats.ark"),
                                           "ark:%s" % (d / "lat2.ark")], log) == -1
     mine_w, mine_a = (d / "words.txt").read_text(), (d / "ali.txt").read_text()
     if have_ref("gmm-latgen-faster"):
@@ -187,3 +187,38 @@ def test_gmm_decode_faster_vs_reference_program(host, tmp_path):
         assert mine_a.split() == (d / "r_ali.txt").read_text().split()
     else:
         assert "uttA" in mine_w and "uttA" in mine_a
+
+
+def test_gmm_latgen_faster_determinized_vs_reference_program(host, tmp_path):
+    """--determinize-lattice=true (the reference's default): GPU search + host determinization
+    (DeterminizeLatticePhonePrunedWrapper restated in host/lattice.cc) against the reference's
+    gmm-latgen-faster on a lexicon graph with words.  The beam is wide, so that the raw lattices of
+    the two searches hold the same arcs (they can only differ in arcs beyond the final
+    beam cutoff); the determinized CompactLattice archives must then have identical structure -- states, arcs,
+    word labels, transition-id strings -- and weights equal within the GMM score tolerance (the
+    acoustic costs come from two implementations of the log-likelihoods; the determinizer itself is
+    bit-exact on equal input, tests/test_host_lattice.py)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gen_golden_lat as gg
+    from tests import util
+    from tests.test_host_lattice import assert_same_archives
+    d = tmp_path
+    gg.make_case(str(d), seed=41, n_words=80, n_cd=12, frames=(150, 60, 333, 1))
+    opts = ["--beam=20", "--lattice-beam=6", "--max-active=7000", "--acoustic-scale=0.083333", "--allow-partial=true"]
+    log = str(d / "dec.log")
+    files = [str(d / "final.mdl"), str(d / "HCLG.fst"), "ark:%s" % (d / "feats.ark")]
+    rc = call(host.vb_GmmLatgenFaster, ["gmm-latgen-faster"] + opts + files + ["ark:%s" % (d / "lat.ark"), "ark,t:%s" % (d / "words.txt"),
+                                                                              "ark,t:%s" % (d / "ali.txt")], log)
+    assert rc == 0, open(log).read()
+    mine = util.read_lattice_ark(str(d / "lat.ark"))
+    assert list(mine) == ["uttA", "uttB", "uttC", "uttD"] and all(v[0] == "compactlattice44" for v in mine.values())
+    # the best path of the determinized lattice is the decoder's best path
+    assert call(host.vb_LatticeBestPath, ["lattice-best-path", "--acoustic-scale=0.083333", "ark:%s" % (d / "lat.ark"), "ark,t:%s" % (d / "bp_words.txt"),
+                                          "ark,t:%s" % (d / "bp_ali.txt")], log) == 0
+    assert (d / "bp_words.txt").read_text().split() == (d / "words.txt").read_text().split()
+    if have_ref("gmm-latgen-faster"):
+        ref("gmm-latgen-faster", *opts, *files, "ark:%s" % (d / "r_lat.ark"), "ark,t:%s" % (d / "r_words.txt"), "ark,t:%s" % (d / "r_ali.txt"))
+        assert (d / "words.txt").read_text().split() == (d / "r_words.txt").read_text().split()
+        assert (d / "ali.txt").read_text().split() == (d / "r_ali.txt").read_text().split()
+        assert_same_archives(str(d / "lat.ark"), str(d / "r_lat.ark"), rtol=1e-4, atol=0.05)

@@ -1,0 +1,178 @@
+"""Host: the lattice stage after the search (voicebridge_amd/host/lattice.cc, voicebridge_latbin.cc;
+SURVEY.md 8f rank 1 and 3) -- determinization, scaling, word insertion penalty, best path, WER --
+against golden archives produced by the reference's own programs (tests/golden/lattices.npz, made
+by oracle/gen_golden_lat.py) and, where oracle/_ref/bin is present, against those programs run on
+fresh cases.  The bar is bit-exact: same states, arcs, float32 weights and transition-id strings.
+No GPU is involved: these functions work on lattice archives."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFBIN = os.path.join(ROOT, "oracle", "_ref", "bin")
+NEEDED = ("gmm-latgen-faster", "lattice-determinize-phone-pruned", "lattice-determinize-pruned", "lattice-scale",
+          "lattice-add-penalty", "lattice-best-path", "compute-wer")
+
+
+@pytest.fixture(scope="module")
+def host():
+    from voicebridge_amd import build
+    if not os.path.exists(build.HOST_LIB):
+        build.build()
+    return C.CDLL(build.HOST_LIB)
+
+
+def call(fn, args, log=""):
+    argv = (C.c_char_p * len(args))(*[a.encode() for a in args])
+    return fn(len(args), argv, str(log).encode())
+
+
+def unpack_golden(d):
+    g = util.load("lattices")
+    for k in g.files:
+        if k.startswith("file_"):
+            name = k[5:].rsplit("_", 1)
+            (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
+        elif k.startswith("text_"):
+            name = k[5:].rsplit("_", 1)
+            (d / (name[0] + "." + name[1])).write_text(str(g[k]))
+    return util.parse_opts(g["opts"])
+
+
+def mine_chain(host, d, o, prefix="m_"):
+    """the reference's scoring chain through this build's bin functions"""
+    p = lambda n: str(d / n)
+    log = p(prefix + "log.txt")
+    acwt, beam = "--acoustic-scale=%s" % o["acwt"], "--beam=%s" % o["beam"]
+    assert call(host.vb_LatticeDeterminizePhonePruned, ["lattice-determinize-phone-pruned", acwt, beam, p("final.mdl"), "ark:" + p("raw.ark"),
+                                                        "ark:" + p(prefix + "det_pp.ark")], log) == 0, open(log).read()
+    assert call(host.vb_LatticeDeterminizePruned, ["lattice-determinize-pruned", acwt, beam, "ark:" + p("raw.ark"), "ark:" + p(prefix + "det_p.ark")], log) == 0
+    assert call(host.vb_LatticeScale, ["lattice-scale", "--inv-acoustic-scale=%s" % o["lmwt"], "ark:" + p(prefix + "det_pp.ark"),
+                                       "ark:" + p(prefix + "scaled.ark")], log) == 0
+    assert call(host.vb_LatticeAddPenalty, ["lattice-add-penalty", "--word-ins-penalty=%s" % o["wip"], "ark:" + p(prefix + "scaled.ark"),
+                                            "ark:" + p(prefix + "pen.ark")], log) == 0
+    assert call(host.vb_LatticeBestPath, ["lattice-best-path", "ark:" + p(prefix + "pen.ark"), "ark,t:" + p(prefix + "best_words.txt"),
+                                          "ark,t:" + p(prefix + "best_ali.txt")], log) == 0
+    return log
+
+
+def assert_same_archives(a, b, rtol=0.0, atol=1e-4):
+    """rtol = 0: identical, bit for bit.  rtol > 0: identical structure (states, arcs, labels,
+    transition-id strings, next states), weights within rtol -- for lattices whose acoustic costs
+    come from two implementations of the GMM scores (tolerance 1e-4 relative, tests/test_gpu_gmm.py);
+    normalised weights are differences of sums over many frames, hence the absolute floor atol"""
+    A, B = util.read_lattice_ark(a), util.read_lattice_ark(b)
+    assert list(A) == list(B)
+    for k in B:
+        assert A[k][0] == B[k][0] and A[k][1] == B[k][1], k
+        assert len(A[k][2]) == len(B[k][2]), "%s: %d vs %d states" % (k, len(A[k][2]), len(B[k][2]))
+        for s, (x, y) in enumerate(zip(A[k][2], B[k][2])):
+            if rtol == 0.0:
+                assert x == y, "%s state %d" % (k, s)
+                continue
+            (xf, xa), (yf, ya) = x, y
+            assert xf[2:] == yf[2:] and len(xa) == len(ya), "%s state %d" % (k, s)
+            np.testing.assert_allclose(xf[:2], yf[:2], rtol=rtol, atol=atol)
+            for u, v in zip(xa, ya):
+                assert (u[0], u[3], u[4]) == (v[0], v[3], v[4]), "%s state %d" % (k, s)
+                np.testing.assert_allclose(u[1:3], v[1:3], rtol=rtol, atol=atol)
+
+
+def test_chain_matches_golden(host, tmp_path):
+    d = tmp_path
+    o = unpack_golden(d)
+    mine_chain(host, d, o)
+    for fn in ("det_pp.ark", "det_p.ark", "scaled.ark", "pen.ark"):
+        assert_same_archives(str(d / ("m_" + fn)), str(d / fn))
+    assert (d / "m_best_words.txt").read_text().split() == (d / "best_words.txt").read_text().split()
+    assert (d / "m_best_ali.txt").read_text().split() == (d / "best_ali.txt").read_text().split()
+    # compute-wer: the three result lines, and the counters the multi-GPU gather sums
+    log = str(d / "wer_log.txt")
+    assert call(host.vb_ComputeWer, ["compute-wer", "--text", "--mode=present", "ark:" + str(d / "ref_text.txt"), "ark:" + str(d / "m_best_words.txt")], log) == 0
+    assert open(log).read() == (d / "wer.txt").read_text()
+    c = (C.c_longlong * 8)()
+    host.vb_ComputeWerCounts(c)
+    assert list(c)[:2] == [3, 6] and c[5] == 3
+    # strict mode with a missing hypothesis is an error (-1), "all" scores it as empty
+    (d / "hyp2.txt").write_text("uttA 27 12\n")
+    assert call(host.vb_ComputeWer, ["compute-wer", "ark:" + str(d / "ref_text.txt"), "ark:" + str(d / "hyp2.txt")], log) == -1
+    assert call(host.vb_ComputeWer, ["compute-wer", "--mode=all", "ark:" + str(d / "ref_text.txt"), "ark:" + str(d / "hyp2.txt")], log) == 0
+    assert "[PARTIAL]" in open(log).read()
+
+
+def test_determinized_lattice_properties(host, tmp_path):
+    """size-independent properties: the output is deterministic on word labels, its best path has
+    the cost of the raw lattice's best path, and every path's alignment has one transition-id per frame"""
+    d = tmp_path
+    o = unpack_golden(d)
+    mine_chain(host, d, o)
+    det = util.read_lattice_ark(str(d / "m_det_pp.ark"))
+    raw = util.read_lattice_ark(str(d / "raw.ark"))
+    acwt = float(o["acwt"])
+    for k, (_t, start, states) in det.items():
+        for fin, arcs in states:
+            labels = [a[0] for a in arcs]
+            assert len(labels) == len(set(labels)), "state with two arcs of the same word label"
+        # best cost by dynamic programming over the (top-sorted on write) compact lattice and the raw one
+        def best(states, cost_arc, cost_final, nxt):
+            n = len(states)
+            order = list(range(n))
+            INF = float("inf")
+            dist = [INF] * n
+            dist[0] = 0.0
+            # relax repeatedly (lattices are acyclic; raw ones are not numbered in order)
+            changed = True
+            while changed:
+                changed = False
+                for s in order:
+                    if dist[s] == INF:
+                        continue
+                    for a in states[s][1]:
+                        c = dist[s] + cost_arc(a)
+                        if c < dist[nxt(a)] - 1e-9:
+                            dist[nxt(a)] = c
+                            changed = True
+            return min(dist[s] + cost_final(states[s][0]) for s in range(n))
+        b_det = best(states, lambda a: a[1] + acwt * a[2], lambda f: f[0] + acwt * f[1], lambda a: a[4])
+        b_raw = best(raw[k][2], lambda a: a[2] + acwt * a[3], lambda f: f[0] + acwt * f[1], lambda a: a[4])
+        assert abs(b_det - b_raw) < 1e-3 * max(1.0, abs(b_raw))
+        # frames: follow first arcs
+        s, frames = start, 0
+        while True:
+            fin, arcs = states[s]
+            if not arcs:
+                frames += len(fin[2])
+                break
+            frames += len(arcs[0][3])
+            s = arcs[0][4]
+        n_raw_frames = sum(1 for l in open(d / "best_ali.txt") if l.split()[0] == k for _ in l.split()[1:])
+        assert frames == n_raw_frames
+
+
+def test_errors_are_reported(host, tmp_path):
+    log = str(tmp_path / "log.txt")
+    assert call(host.vb_LatticeScale, ["lattice-scale", "ark:/nonexistent/x.ark", "ark:" + str(tmp_path / "o.ark")], log) == -1
+    assert "ERROR (lattice-scale)" in open(log).read()
+    assert call(host.vb_LatticeBestPath, ["lattice-best-path", "--no-such-option=1", "ark:x"], log) == -1
+    assert call(host.vb_LatticeDeterminizePruned, ["lattice-determinize-pruned", "--acoustic-scale=0", "ark:a", "ark:b"], log) == -1
+
+
+@pytest.mark.skipif(not all(os.access(os.path.join(REFBIN, b), os.X_OK) for b in NEEDED), reason="oracle/_ref/bin not built")
+@pytest.mark.parametrize("seed,n_words,n_cd,frames,beam", [(11, 60, 10, (200, 31, 1), "6"), (23, 150, 16, (400, 90), "8"), (31, 25, 6, (300,), "4")])
+def test_fresh_cases_vs_reference_programs(host, tmp_path, seed, n_words, n_cd, frames, beam):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gen_golden_lat as gg
+    d = tmp_path
+    gg.make_case(str(d), seed=seed, n_words=n_words, n_cd=n_cd, frames=frames)
+    gg.run_reference_chain(str(d), beam=beam, lmwt="11", wip="1.0")
+    mine_chain(host, d, dict(acwt="0.083333", beam=beam, lmwt="11", wip="1.0"))
+    for fn in ("det_pp.ark", "det_p.ark", "scaled.ark", "pen.ark"):
+        assert_same_archives(str(d / ("m_" + fn)), str(d / fn))
+    assert (d / "m_best_words.txt").read_text().split() == (d / "best_words.txt").read_text().split()
+    assert (d / "m_best_ali.txt").read_text().split() == (d / "best_ali.txt").read_text().split()

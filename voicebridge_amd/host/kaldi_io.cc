@@ -667,11 +667,17 @@ void ReadModel(const std::string &path, Model *m) {
   // ComputeDerived (transition-model.cc:144-177): transition-ids in tuple order, one per
   // transition of the tuple's HMM state; a self-loop uses the self-loop pdf
   m->tid2pdf.assign(1, -1);
+  m->trans.phone.assign(1, 0); m->trans.hmm_state.assign(1, 0); m->trans.self_loop.assign(1, 0);
   for (const Tuple &t : tuples) {
     if (t.phone < 0 || t.phone >= (int32_t)phone2idx.size() || phone2idx[t.phone] < 0) Fail("model: tuple phone without topology");
     const std::vector<HmmState> &e = entries[phone2idx[t.phone]];
     if (t.hmm_state < 0 || t.hmm_state >= (int32_t)e.size()) Fail("model: bad hmm state in tuple");
-    for (const auto &tr : e[t.hmm_state].trans) m->tid2pdf.push_back(tr.first == t.hmm_state ? t.self : t.fwd);
+    for (const auto &tr : e[t.hmm_state].trans) {
+      m->tid2pdf.push_back(tr.first == t.hmm_state ? t.self : t.fwd);
+      m->trans.phone.push_back(t.phone);
+      m->trans.hmm_state.push_back(t.hmm_state);
+      m->trans.self_loop.push_back(tr.first == t.hmm_state ? 1 : 0);
+    }
   }
   ExpectToken(is, binary, "<LogProbs>");
   std::vector<float> logprobs;
@@ -820,6 +826,186 @@ void LatticeWriter::Write(const std::string &key, const LatticeOut &lat) {
     }
   }
   if (ark_.fail()) Fail("write failure on " + spec_.ark_path);
+}
+
+
+namespace {
+template <class T> void Put(std::ostream &os, const T &v) { os.write(reinterpret_cast<const char *>(&v), sizeof(T)); }
+template <class T> T Get(std::istream &is) { T v; is.read(reinterpret_cast<char *>(&v), sizeof(T)); return v; }
+void WriteFstHeader(std::ostream &os, const char *arctype, int64_t start, int64_t ns, int64_t na) {
+  Put(os, kFstMagic);
+  WriteFstString(os, "vector");
+  WriteFstString(os, arctype);
+  Put<int32_t>(os, 2); Put<int32_t>(os, 0);
+  Put<uint64_t>(os, 3);          // kExpanded | kMutable; everything else unknown
+  Put(os, start); Put(os, ns); Put(os, na);
+}
+}  // namespace
+
+void LatticeWriter::Write(const std::string &key, const vblat::Lattice &lat) {
+  ark_ << key << ' ';
+  WriteFstHeader(ark_, "lattice4", lat.start, (int64_t)lat.st.size(), (int64_t)lat.NumArcs());
+  for (const vblat::State &s : lat.st) {
+    Put(ark_, s.final.v1); Put(ark_, s.final.v2);
+    Put<int64_t>(ark_, (int64_t)s.arcs.size());
+    for (const vblat::Arc &a : s.arcs) { Put(ark_, a.ilabel); Put(ark_, a.olabel); Put(ark_, a.w.v1); Put(ark_, a.w.v2); Put(ark_, a.next); }
+  }
+  if (ark_.fail()) Fail("write failure on " + spec_.ark_path);
+}
+
+void CompactLatticeWriter::Open(const std::string &wspecifier) {
+  spec_ = ParseWspecifier(wspecifier);
+  if (spec_.text) Fail("text-mode lattice output is not supported");
+  ark_.open(spec_.ark_path, std::ios::binary);
+  if (!ark_) Fail("cannot open " + spec_.ark_path + " for writing");
+  open_ = true;
+}
+
+void CompactLatticeWriter::Write(const std::string &key, const vblat::CompactLattice &clat) {
+  ark_ << key << ' ';
+  WriteFstHeader(ark_, "compactlattice44", clat.start, (int64_t)clat.st.size(), (int64_t)clat.NumArcs());
+  auto put_w = [&](const vblat::CWeight &w) {
+    Put(ark_, w.w.v1); Put(ark_, w.w.v2);
+    Put<int32_t>(ark_, (int32_t)w.str.size());
+    if (!w.str.empty()) ark_.write(reinterpret_cast<const char *>(w.str.data()), 4 * w.str.size());
+  };
+  for (const vblat::CState &s : clat.st) {
+    put_w(s.final);
+    Put<int64_t>(ark_, (int64_t)s.arcs.size());
+    for (const vblat::CArc &a : s.arcs) { Put(ark_, a.label); Put(ark_, a.label); put_w(a.w); Put(ark_, a.next); }
+  }
+  if (ark_.fail()) Fail("write failure on " + spec_.ark_path);
+}
+
+LatticeReader::LatticeReader(const std::string &rspecifier) : spec_(ParseRspecifier(rspecifier)) {
+  if (spec_.is_scp) scp_ = ReadScp(spec_.path);
+  else {
+    ark_.open(spec_.path, std::ios::binary);
+    if (!ark_) Fail("cannot open archive " + spec_.path);
+  }
+}
+
+static void ReadLatticeBody(std::istream &is, vblat::Lattice *lat, vblat::CompactLattice *clat, bool *is_compact) {
+  const int c = is.peek();
+  if (c == EOF) Fail("lattice: unexpected end of file");
+  if (isspace(c)) Fail("text-mode lattices are not supported");
+  if (Get<int32_t>(is) != kFstMagic) Fail("lattice: bad magic number");
+  const std::string fsttype = ReadFstString(is), arctype = ReadFstString(is);
+  const int32_t version = Get<int32_t>(is), flags = Get<int32_t>(is);
+  (void)version;
+  Get<uint64_t>(is);
+  const int64_t start = Get<int64_t>(is), ns = Get<int64_t>(is);
+  Get<int64_t>(is);
+  if (is.fail()) Fail("lattice: truncated header");
+  if (fsttype != "vector") Fail("lattice: fst type " + fsttype + " not supported");
+  if (flags & 3) Fail("lattice: embedded symbol tables are not supported");
+  if (ns < 0 || ns > (1LL << 31)) Fail("lattice: bad state count");
+  if (arctype == "lattice4") {
+    *is_compact = false;
+    lat->st.assign((size_t)ns, vblat::State());
+    lat->start = (int32_t)start;
+    for (int64_t s = 0; s < ns; s++) {
+      vblat::State &st = lat->st[s];
+      st.final.v1 = Get<float>(is); st.final.v2 = Get<float>(is);
+      const int64_t na = Get<int64_t>(is);
+      if (is.fail() || na < 0) Fail("lattice: truncated");
+      st.arcs.resize((size_t)na);
+      for (vblat::Arc &a : st.arcs) { a.ilabel = Get<int32_t>(is); a.olabel = Get<int32_t>(is); a.w.v1 = Get<float>(is); a.w.v2 = Get<float>(is); a.next = Get<int32_t>(is); }
+    }
+  } else if (arctype == "compactlattice44") {
+    *is_compact = true;
+    clat->st.assign((size_t)ns, vblat::CState());
+    clat->start = (int32_t)start;
+    auto get_w = [&](vblat::CWeight *w) {
+      w->w.v1 = Get<float>(is); w->w.v2 = Get<float>(is);
+      const int32_t n = Get<int32_t>(is);
+      if (is.fail() || n < 0) Fail("lattice: bad string size");
+      w->str.resize(n);
+      if (n) is.read(reinterpret_cast<char *>(w->str.data()), 4 * (size_t)n);
+    };
+    for (int64_t s = 0; s < ns; s++) {
+      vblat::CState &st = clat->st[s];
+      get_w(&st.final);
+      const int64_t na = Get<int64_t>(is);
+      if (is.fail() || na < 0) Fail("lattice: truncated");
+      st.arcs.resize((size_t)na);
+      for (vblat::CArc &a : st.arcs) { a.label = Get<int32_t>(is); Get<int32_t>(is); get_w(&a.w); a.next = Get<int32_t>(is); }
+    }
+  } else Fail("lattice: arc type " + arctype + " not supported");
+  if (is.fail()) Fail("lattice: truncated");
+}
+
+bool LatticeReader::Next(std::string *key, vblat::Lattice *lat, vblat::CompactLattice *clat, bool *is_compact) {
+  if (spec_.is_scp) {
+    if (pos_ >= scp_.size()) return false;
+    const ScpEntry &e = scp_[pos_++];
+    std::ifstream f(e.path, std::ios::binary);
+    if (!f) Fail("cannot open " + e.path);
+    if (e.offset >= 0) f.seekg(e.offset);
+    ReadLatticeBody(f, lat, clat, is_compact);
+    *key = e.key;
+    return true;
+  }
+  *key = ReadArkKey(ark_);
+  if (key->empty()) return false;
+  ReadLatticeBody(ark_, lat, clat, is_compact);
+  return true;
+}
+bool LatticeReader::NextCompact(std::string *key, vblat::CompactLattice *clat) {
+  vblat::Lattice lat; bool compact = false;
+  if (!Next(key, &lat, clat, &compact)) return false;
+  if (!compact) Fail("expected a CompactLattice for key " + *key + ", found a state-level Lattice (conversion is not part of this build)");
+  return true;
+}
+bool LatticeReader::NextLattice(std::string *key, vblat::Lattice *lat) {
+  vblat::CompactLattice clat; bool compact = false;
+  if (!Next(key, lat, &clat, &compact)) return false;
+  if (compact) vblat::ConvertLattice(clat, lat, true);     // LatticeHolder::Read does the same (kaldi-lattice.cc:460-480)
+  return true;
+}
+
+std::vector<std::pair<std::string, std::vector<int32_t>>> ReadIntVectorTable(const std::string &rspecifier) {
+  const Rspec spec = ParseRspecifier(rspecifier);
+  if (spec.is_scp) Fail("scp: is not supported for integer-vector tables");
+  std::ifstream is(spec.path, std::ios::binary);
+  if (!is) Fail("cannot open " + spec.path);
+  std::vector<std::pair<std::string, std::vector<int32_t>>> out;
+  for (;;) {
+    const std::string key = ReadArkKey(is);
+    if (key.empty()) break;
+    std::vector<int32_t> v;
+    if (is.peek() == '\0') {
+      const bool binary = ReadBinaryHeader(is);
+      ReadIntVector(is, binary, &v);
+    } else {
+      std::string line;
+      std::getline(is, line);
+      std::istringstream ls(line);
+      long long x;
+      while (ls >> x) v.push_back((int32_t)x);
+      if (!ls.eof()) Fail("bad integer in table " + spec.path + " at key " + key);
+    }
+    out.emplace_back(key, std::move(v));
+  }
+  return out;
+}
+
+std::vector<std::pair<std::string, std::vector<std::string>>> ReadTokenTable(const std::string &rspecifier) {
+  const Rspec spec = ParseRspecifier(rspecifier);
+  if (spec.is_scp) Fail("scp: is not supported for token tables");
+  std::ifstream is(spec.path);
+  if (!is) Fail("cannot open " + spec.path);
+  std::vector<std::pair<std::string, std::vector<std::string>>> out;
+  std::string line;
+  while (std::getline(is, line)) {
+    std::istringstream ls(line);
+    std::string key, tok;
+    if (!(ls >> key)) continue;
+    std::vector<std::string> v;
+    while (ls >> tok) v.push_back(tok);
+    out.emplace_back(key, std::move(v));
+  }
+  return out;
 }
 
 }  // namespace vbio

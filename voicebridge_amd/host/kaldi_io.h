@@ -20,7 +20,10 @@
 #include <ostream>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
+
+#include "lattice.h"
 
 namespace vbio {
 
@@ -117,6 +120,9 @@ struct Model {
   int32_t num_pdfs = 0, dim = 0;
   std::vector<int32_t> pdf_offsets;            // [num_pdfs+1]
   std::vector<float> weights, means_invvars, inv_vars, gconsts_in_file;
+  // per transition-id (index 0 unused): TransitionIdToPhone / TransitionIdToHmmState / IsSelfLoop
+  // (K/hmm/transition-model.h:160-175, .cc:144-177) -- what lattice determinization asks of the model
+  vblat::TransInfo trans;
 };
 void ReadModel(const std::string &path, Model *m);
 
@@ -142,11 +148,50 @@ class LatticeWriter {   // LatticeWriter ("Lattice" holder), binary archives
   void Open(const std::string &wspecifier);
   bool IsOpen() const { return open_; }
   void Write(const std::string &key, const LatticeOut &lat);
+  void Write(const std::string &key, const vblat::Lattice &lat);
  private:
   Wspec spec_;
   bool open_ = false;
   std::ofstream ark_;
 };
+
+
+// CompactLatticeWriter ("CompactLattice" holder, kaldi-lattice.cc:62-70): binary archives of
+// VectorFst<CompactLatticeArc> (arc type "compactlattice44": weight = two floats, int32 string
+// length, int32 transition-ids)
+class CompactLatticeWriter {
+ public:
+  CompactLatticeWriter() {}
+  void Open(const std::string &wspecifier);
+  bool IsOpen() const { return open_; }
+  void Write(const std::string &key, const vblat::CompactLattice &clat);
+ private:
+  Wspec spec_;
+  bool open_ = false;
+  std::ofstream ark_;
+};
+
+// sequential reader over binary lattice archives ("ark:" or "scp:"); an entry is either a
+// Lattice ("lattice4") or a CompactLattice ("compactlattice44")
+class LatticeReader {
+ public:
+  explicit LatticeReader(const std::string &rspecifier);
+  // fills *lat or *clat according to what the entry holds (*is_compact tells which)
+  bool Next(std::string *key, vblat::Lattice *lat, vblat::CompactLattice *clat, bool *is_compact);
+  // convenience: the entry as a CompactLattice / Lattice; the other kind is an error
+  bool NextCompact(std::string *key, vblat::CompactLattice *clat);
+  bool NextLattice(std::string *key, vblat::Lattice *lat);
+ private:
+  Rspec spec_;
+  std::ifstream ark_;
+  std::vector<ScpEntry> scp_;
+  size_t pos_ = 0;
+};
+
+// Int32Vector tables in text or binary form (words, alignments): key -> ints
+std::vector<std::pair<std::string, std::vector<int32_t>>> ReadIntVectorTable(const std::string &rspecifier);
+// token tables ("key tok tok ..." text lines): reference transcripts for compute-wer
+std::vector<std::pair<std::string, std::vector<std::string>>> ReadTokenTable(const std::string &rspecifier);
 
 }  // namespace vbio
 #endif

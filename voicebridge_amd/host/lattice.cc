@@ -1,0 +1,905 @@
+// lattice.cc -- see lattice.h for what each function follows in the reference.
+#include "lattice.h"
+
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <queue>
+#include <stdexcept>
+#include <unordered_map>
+#include <utility>
+
+namespace vblat {
+
+// ------------------------------------------------------------------ LatticeWeight
+// lattice-weight.h:295-310: smaller total cost is "greater" in the semiring; ties on value1
+int Compare(const Weight &a, const Weight &b) {
+  const float f1 = a.v1 + a.v2, f2 = b.v1 + b.v2;
+  if (f1 < f2) return 1;
+  if (f1 > f2) return -1;
+  if (a.v1 < b.v1) return 1;
+  if (a.v1 > b.v1) return -1;
+  return 0;
+}
+// lattice-weight.h:343-359
+Weight Divide(const Weight &a, const Weight &b) {
+  const float x = a.v1 - b.v1, y = a.v2 - b.v2;
+  if (x != x || y != y || x == -kInf || y == -kInf) return Zero();
+  if (x == kInf || y == kInf) return Zero();
+  return Weight{x, y};
+}
+// lattice-weight.h:362-367
+bool ApproxEqual(const Weight &a, const Weight &b, float delta) {
+  if (a.v1 == b.v1 && a.v2 == b.v2) return true;
+  return std::fabs((a.v1 + a.v2) - (b.v1 + b.v2)) <= delta;
+}
+// CompactLatticeWeight comparison (lattice-weight.h:564-592): weights first, then the shorter
+// string is "greater", then lexicographic order with smaller labels "less"
+static int CompareStr(const std::vector<int32_t> &a, const std::vector<int32_t> &b) {
+  const int la = (int)a.size(), lb = (int)b.size();
+  if (la > lb) return -1;
+  if (la < lb) return 1;
+  for (int i = 0; i < la; i++) {
+    if (a[i] < b[i]) return -1;
+    if (a[i] > b[i]) return 1;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ depth-first order
+namespace {
+
+// Depth-first visit in OpenFst's order (dfs-visit.h:93-200): trees rooted at the start state,
+// then at every still unvisited state in increasing order; arcs in stored order.  Records the
+// finishing order and whether a back arc (cycle) was met (the visit stops there, as
+// TopOrderVisitor::BackArc makes it).
+template <class Fst>
+bool DfsFinishOrder(const Fst &fst, std::vector<int32_t> *finish) {
+  finish->clear();
+  const int32_t n = (int32_t)fst.st.size();
+  if (fst.start < 0) return true;
+  std::vector<uint8_t> color(n, 0);
+  std::vector<std::pair<int32_t, size_t>> stack;
+  for (int32_t root = fst.start; root < n;) {
+    color[root] = 1;
+    stack.emplace_back(root, 0);
+    while (!stack.empty()) {
+      const int32_t s = stack.back().first;
+      const size_t ai = stack.back().second;
+      if (ai >= fst.st[s].arcs.size()) {
+        color[s] = 2;
+        stack.pop_back();
+        finish->push_back(s);
+        if (!stack.empty()) stack.back().second++;
+        continue;
+      }
+      const int32_t nx = fst.st[s].arcs[ai].next;
+      if (color[nx] == 0) {
+        color[nx] = 1;
+        stack.emplace_back(nx, 0);
+      } else if (color[nx] == 1) {
+        return false;   // back arc: cyclic
+      } else {
+        stack.back().second++;
+      }
+    }
+    for (root = (root == fst.start) ? 0 : root + 1; root < n && color[root] != 0; ++root) {}
+  }
+  return true;
+}
+
+template <class Fst>
+bool TopSortImpl(Fst *fst) {
+  std::vector<int32_t> finish;
+  if (!DfsFinishOrder(*fst, &finish)) return false;
+  const int32_t n = (int32_t)fst->st.size();
+  if (fst->start < 0) return true;
+  std::vector<int32_t> order(n, -1);
+  for (size_t i = 0; i < finish.size(); i++) order[finish[finish.size() - 1 - i]] = (int32_t)i;
+  // StateSort (statesort.h): state s moves to order[s]; arcs keep their order
+  decltype(fst->st) ns(n);
+  for (int32_t s = 0; s < n; s++) {
+    auto &dst = ns[order[s]];
+    dst = std::move(fst->st[s]);
+    for (auto &a : dst.arcs) a.next = order[a.next];
+  }
+  fst->st.swap(ns);
+  fst->start = order[fst->start];
+  return true;
+}
+
+template <class Fst, class IsFinal>
+void ConnectImpl(Fst *fst, IsFinal is_final) {
+  const int32_t n = (int32_t)fst->st.size();
+  if (n == 0) return;
+  if (fst->start < 0) { fst->st.clear(); return; }
+  // accessible: reachable from the start state
+  std::vector<uint8_t> access(n, 0), coaccess(n, 0);
+  std::vector<int32_t> stack(1, fst->start);
+  access[fst->start] = 1;
+  while (!stack.empty()) {
+    const int32_t s = stack.back(); stack.pop_back();
+    for (const auto &a : fst->st[s].arcs) if (!access[a.next]) { access[a.next] = 1; stack.push_back(a.next); }
+  }
+  // coaccessible: some final state is reachable (reverse adjacency)
+  std::vector<int32_t> rhead(n + 1, 0), rlist;
+  for (int32_t s = 0; s < n; s++) for (const auto &a : fst->st[s].arcs) rhead[a.next + 1]++;
+  for (int32_t s = 0; s < n; s++) rhead[s + 1] += rhead[s];
+  rlist.resize(rhead[n]);
+  { std::vector<int32_t> fill(rhead.begin(), rhead.end() - 1);
+    for (int32_t s = 0; s < n; s++) for (const auto &a : fst->st[s].arcs) rlist[fill[a.next]++] = s; }
+  for (int32_t s = 0; s < n; s++) if (is_final(fst->st[s])) { coaccess[s] = 1; stack.push_back(s); }
+  while (!stack.empty()) {
+    const int32_t s = stack.back(); stack.pop_back();
+    for (int32_t i = rhead[s]; i < rhead[s + 1]; i++) if (!coaccess[rlist[i]]) { coaccess[rlist[i]] = 1; stack.push_back(rlist[i]); }
+  }
+  // DeleteStates (vector-fst.h): survivors keep their relative order, arcs into deleted states go
+  std::vector<int32_t> newid(n, -1);
+  int32_t m = 0;
+  for (int32_t s = 0; s < n; s++) if (access[s] && coaccess[s]) newid[s] = m++;
+  if (m == n) return;
+  if (newid[fst->start] < 0) { fst->st.clear(); fst->start = -1; return; }
+  decltype(fst->st) ns(m);
+  for (int32_t s = 0; s < n; s++) {
+    if (newid[s] < 0) continue;
+    auto &dst = ns[newid[s]];
+    dst.final = std::move(fst->st[s].final);
+    for (auto &a : fst->st[s].arcs) if (newid[a.next] >= 0) { dst.arcs.push_back(std::move(a)); dst.arcs.back().next = newid[a.next]; }
+  }
+  fst->st.swap(ns);
+  fst->start = newid[fst->start];
+}
+
+}  // namespace
+
+void Connect(Lattice *lat) { ConnectImpl(lat, [](const State &s) { return !IsZero(s.final); }); }
+void Connect(CompactLattice *clat) { ConnectImpl(clat, [](const CState &s) { return !IsZero(s.final.w); }); }
+bool TopSort(Lattice *lat) { return TopSortImpl(lat); }
+bool TopSort(CompactLattice *clat) { return TopSortImpl(clat); }
+bool IsTopSorted(const Lattice &lat) {
+  for (size_t s = 0; s < lat.st.size(); s++) for (const Arc &a : lat.st[s].arcs) if (a.next <= (int32_t)s) return false;
+  return true;
+}
+static bool IsTopSorted(const CompactLattice &lat) {
+  for (size_t s = 0; s < lat.st.size(); s++) for (const CArc &a : lat.st[s].arcs) if (a.next <= (int32_t)s) return false;
+  return true;
+}
+void Invert(Lattice *lat) { for (State &s : lat->st) for (Arc &a : s.arcs) std::swap(a.ilabel, a.olabel); }
+void ArcSortILabel(Lattice *lat) {
+  // std::sort with ILabelCompare (arcsort.h:48,170-176): the same comparison sequence, hence the
+  // same order among equal labels, as the reference built with this libstdc++
+  for (State &s : lat->st) std::sort(s.arcs.begin(), s.arcs.end(), [](const Arc &a, const Arc &b) { return a.ilabel < b.ilabel; });
+}
+
+// ------------------------------------------------------------------ string repository
+namespace {
+
+// Strings of labels stored as a trie: id 0 is the empty string, an entry is (parent, last label).
+// Entries are never freed, but the determinizer's memory check counts the entries the reference's
+// repository would hold (determinize-lattice-inl.h:186-207: Rebuild() keeps the strings still in
+// use and their prefixes, everything else is deleted and re-created on demand); `live` entries
+// are exactly those, so the check trips at the same point as in the reference.
+class StringRepo {
+ public:
+  StringRepo() { parent_.push_back(-1); label_.push_back(0); size_.push_back(0); gen_.push_back(0); }
+  int Empty() const { return 0; }
+  size_t NumEntries() const { return live_count_; }
+  int Successor(int a, int32_t l) {
+    const uint64_t key = ((uint64_t)(uint32_t)a << 32) | (uint32_t)l;
+    auto it = map_.find(key);
+    if (it != map_.end()) {
+      if (gen_[it->second] != cur_gen_) { gen_[it->second] = cur_gen_; live_count_++; }
+      return it->second;
+    }
+    const int id = (int)parent_.size();
+    parent_.push_back(a); label_.push_back(l); size_.push_back(size_[a] + 1); gen_.push_back(cur_gen_);
+    live_count_++;
+    map_.emplace(key, id);
+    return id;
+  }
+  void Rebuild(const std::vector<int> &to_keep) {
+    cur_gen_++;
+    live_count_ = 0;
+    for (int e : to_keep)
+      for (; e != 0 && gen_[e] != cur_gen_; e = parent_[e]) { gen_[e] = cur_gen_; live_count_++; }
+  }
+  int Size(int a) const { return size_[a]; }
+  void ToVector(int a, std::vector<int32_t> *out) const {
+    out->resize(size_[a]);
+    for (int i = size_[a] - 1; i >= 0; i--) { (*out)[i] = label_[a]; a = parent_[a]; }
+  }
+  int FromVector(const std::vector<int32_t> &v) { int e = 0; for (int32_t l : v) e = Successor(e, l); return e; }
+  int Concatenate(int a, int b) {
+    if (a == 0) return b;
+    if (b == 0) return a;
+    std::vector<int32_t> v; ToVector(b, &v);
+    for (int32_t l : v) a = Successor(a, l);
+    return a;
+  }
+  // shrink *b to the longest common prefix of a and *b (determinize-lattice-inl.h:96-115)
+  void ReduceToCommonPrefix(int a, std::vector<int32_t> *b) const {
+    size_t a_size = size_[a], b_size = b->size();
+    while (a_size > b_size) { a = parent_[a]; a_size--; }
+    if (b_size > a_size) b_size = a_size;
+    while (a_size != 0) {
+      if (label_[a] != (*b)[a_size - 1]) b_size = a_size - 1;
+      a = parent_[a]; a_size--;
+    }
+    if (b_size != b->size()) b->resize(b_size);
+  }
+  int RemovePrefix(int a, size_t n) {
+    if (n == 0) return a;
+    std::vector<int32_t> v; ToVector(a, &v);
+    int e = 0;
+    for (size_t i = n; i < v.size(); i++) e = Successor(e, v[i]);
+    return e;
+  }
+ private:
+  std::vector<int> parent_;
+  std::vector<int32_t> label_;
+  std::vector<int> size_;
+  std::vector<uint32_t> gen_;
+  uint32_t cur_gen_ = 0;
+  size_t live_count_ = 0;
+  std::unordered_map<uint64_t, int> map_;
+};
+
+// ------------------------------------------------------------------ the determinizer
+// LatticeDeterminizerPruned (determinize-lattice-pruned.cc:44-1190).  Same procedure, same
+// processing order (the task queue is a std::priority_queue fed in the same order, so equal
+// priorities pop in the same order as in the reference); the data structures are this file's own.
+class Determinizer {
+ public:
+  Determinizer(const Lattice &ifst, double beam, const DetOptions &opts)
+      : ifst_(ifst), beam_(beam), opts_(opts), minimal_hash_(3, SubsetKey(), SubsetEqual{opts.delta}),
+        initial_hash_(3, SubsetKey(), SubsetEqual{opts.delta}) {}
+  ~Determinizer() {
+    for (auto &kv : initial_hash_) delete kv.first;
+    for (OutputState *s : out_) delete s;
+    while (!queue_.empty()) { delete queue_.top(); queue_.pop(); }
+  }
+
+  bool Determinize(double *effective_beam) {
+    Initialize();
+    while (!queue_.empty()) {
+      Task *task = queue_.top();
+      const size_t num_states = out_.size();
+      if ((opts_.max_states > 0 && num_states > (size_t)opts_.max_states) ||
+          (opts_.max_arcs > 0 && num_arcs_ > opts_.max_arcs) ||
+          (num_states % 10 == 0 && !CheckMemoryUsage()))
+        break;
+      queue_.pop();
+      ProcessTransition(task->state, task->label, &task->subset);
+      delete task;
+    }
+    if (effective_beam) {
+      if (queue_.empty()) *effective_beam = beam_;
+      else *effective_beam = queue_.top()->priority_cost - backward_[ifst_.start];
+    }
+    return queue_.empty();
+  }
+
+  void Output(CompactLattice *ofst) {      // :54-105
+    ofst->st.clear(); ofst->start = -1;
+    const int n = (int)out_.size();
+    if (n == 0) return;
+    ofst->st.resize(n);
+    ofst->start = 0;
+    for (int s = 0; s < n; s++) {
+      for (const TempArc &t : out_[s]->arcs) {
+        CWeight w; w.w = t.weight; repo_.ToVector(t.string, &w.str);
+        if (t.next < 0) ofst->st[s].final = std::move(w);
+        else ofst->st[s].arcs.push_back(CArc{t.ilabel, std::move(w), t.next});
+      }
+    }
+  }
+  void Output(Lattice *ofst) {             // :110-180: strings become chains of extra states
+    ofst->st.clear(); ofst->start = -1;
+    const int n = (int)out_.size();
+    if (n == 0) return;
+    ofst->st.resize(n);
+    ofst->start = 0;
+    std::vector<int32_t> seq;
+    for (int s = 0; s < n; s++) {
+      for (const TempArc &t : out_[s]->arcs) {
+        repo_.ToVector(t.string, &seq);
+        if (t.next < 0) {
+          int cur = s;
+          for (size_t i = 0; i < seq.size(); i++) {
+            const int nx = (int)ofst->st.size();
+            ofst->st.emplace_back();
+            ofst->st[cur].arcs.push_back(Arc{0, seq[i], i == 0 ? t.weight : One(), nx});
+            cur = nx;
+          }
+          ofst->st[cur].final = seq.empty() ? t.weight : One();
+        } else {
+          int cur = s;
+          for (size_t i = 0; i + 1 < seq.size(); i++) {
+            const int nx = (int)ofst->st.size();
+            ofst->st.emplace_back();
+            ofst->st[cur].arcs.push_back(Arc{i == 0 ? t.ilabel : 0, seq[i], i == 0 ? t.weight : One(), nx});
+            cur = nx;
+          }
+          ofst->st[cur].arcs.push_back(Arc{seq.size() <= 1 ? t.ilabel : 0, seq.empty() ? 0 : seq.back(),
+                                           seq.size() <= 1 ? t.weight : One(), t.next});
+        }
+      }
+    }
+  }
+
+ private:
+  struct Element {
+    int32_t state; int string; Weight weight;
+    bool Differs(const Element &o) const { return state != o.state || string != o.string || !Same(weight, o.weight); }
+  };
+  struct ElemGreaterState { bool operator()(const Element &a, const Element &b) const { return a.state > b.state; } };
+  struct TempArc { int32_t ilabel; int string; int32_t next; Weight weight; };
+  struct OutputState {
+    std::vector<Element> minimal_subset;
+    std::vector<TempArc> arcs;
+    double forward_cost;
+  };
+  struct Task { int32_t state; int32_t label; std::vector<Element> subset; double priority_cost; };
+  struct TaskWorse { bool operator()(const Task *a, const Task *b) const { return a->priority_cost > b->priority_cost; } };
+  struct SubsetKey {   // states and strings only; weights are compared with a tolerance (:428-441)
+    size_t operator()(const std::vector<Element> *s) const {
+      size_t hash = 0, factor = 1;
+      for (const Element &e : *s) { hash *= factor; hash += (size_t)e.state + 103333u * (size_t)e.string; factor *= 23531; }
+      return hash;
+    }
+  };
+  struct SubsetEqual {
+    float delta;
+    bool operator()(const std::vector<Element> *a, const std::vector<Element> *b) const {
+      if (a->size() != b->size()) return false;
+      for (size_t i = 0; i < a->size(); i++)
+        if ((*a)[i].state != (*b)[i].state || (*a)[i].string != (*b)[i].string || !ApproxEqual((*a)[i].weight, (*b)[i].weight, delta)) return false;
+      return true;
+    }
+  };
+  typedef std::unordered_map<const std::vector<Element> *, int32_t, SubsetKey, SubsetEqual> MinimalHash;
+  typedef std::unordered_map<const std::vector<Element> *, Element, SubsetKey, SubsetEqual> InitialHash;
+
+  int CompareWS(const Weight &aw, int as, const Weight &bw, int bs) const {   // :583-608
+    const int c = Compare(aw, bw);
+    if (c != 0) return c;
+    if (as == bs) return 0;
+    std::vector<int32_t> av, bv;
+    repo_.ToVector(as, &av); repo_.ToVector(bs, &bv);
+    return CompareStr(av, bv);
+  }
+
+  // :252-340.  Sizes as the reference counts them on x86-64: repository entry 2 x 16 bytes,
+  // TempArc 32, Element 24.
+  bool CheckMemoryUsage() {
+    if (opts_.max_mem <= 0) return true;
+    const int32_t repo = (int32_t)(repo_.NumEntries() * 32), arcs = num_arcs_ * 32, elems = num_elems_ * 24;
+    if (repo + arcs + elems <= opts_.max_mem) return true;
+    // RebuildRepository: everything still referenced -- subsets and arcs of the output states, the
+    // queued tasks, keys and values of the initial-subset hash
+    std::vector<int> needed;
+    for (const OutputState *os : out_) {
+      for (const Element &e : os->minimal_subset) needed.push_back(e.string);
+      for (const TempArc &a : os->arcs) needed.push_back(a.string);
+    }
+    {
+      std::vector<Task *> tasks;
+      while (!queue_.empty()) { tasks.push_back(queue_.top()); queue_.pop(); }
+      for (Task *t : tasks) { for (const Element &e : t->subset) needed.push_back(e.string); }
+      for (Task *t : tasks) queue_.push(t);
+    }
+    for (const auto &kv : initial_hash_) {
+      for (const Element &e : *kv.first) needed.push_back(e.string);
+      needed.push_back(kv.second.string);
+    }
+    repo_.Rebuild(needed);
+    const int32_t new_repo = (int32_t)(repo_.NumEntries() * 32);
+    return new_repo + arcs + elems <= (int32_t)(opts_.max_mem * 0.8);
+  }
+
+  void ComputeBackward() {        // :1013-1036
+    const int n = (int)ifst_.st.size();
+    backward_.assign(n, 0.0);
+    for (int s = n - 1; s >= 0; s--) {
+      double cost = Cost(ifst_.st[s].final);
+      for (const Arc &a : ifst_.st[s].arcs) cost = std::min(cost, Cost(a.w) + backward_[a.next]);
+      backward_[s] = cost;
+    }
+    if (ifst_.start < 0) return;
+    cutoff_ = backward_[ifst_.start] + beam_;
+  }
+
+  bool IsIsymbolOrFinal(int32_t s) {    // :985-1010
+    if (isym_or_final_.size() <= (size_t)s) isym_or_final_.resize(s + 1, 0);
+    if (isym_or_final_[s] == 1) return false;
+    if (isym_or_final_[s] == 2) return true;
+    isym_or_final_[s] = 1;
+    if (!IsZero(ifst_.st[s].final)) isym_or_final_[s] = 2;
+    for (const Arc &a : ifst_.st[s].arcs) if (a.ilabel != 0 && !IsZero(a.w)) { isym_or_final_[s] = 2; break; }
+    return isym_or_final_[s] == 2;
+  }
+  void ConvertToMinimal(std::vector<Element> *subset) {
+    size_t o = 0;
+    for (size_t i = 0; i < subset->size(); i++) if (IsIsymbolOrFinal((*subset)[i].state)) (*subset)[o++] = (*subset)[i];
+    subset->resize(o);
+  }
+
+  void EpsilonClosure(std::vector<Element> *subset) {    // :614-725
+    std::priority_queue<Element, std::vector<Element>, ElemGreaterState> queue;
+    std::unordered_map<int32_t, Element> cur;
+    for (const Element &e : *subset) { queue.push(e); cur[e.state] = e; }
+    bool replaced = false;
+    int counter = 0;
+    while (!queue.empty()) {
+      const Element elem = queue.top();
+      queue.pop();
+      if (replaced && cur[elem.state].Differs(elem)) continue;
+      if (opts_.max_loop > 0 && counter++ > opts_.max_loop)
+        throw std::runtime_error("lattice determinization: looped more than max-loop times during epsilon closure");
+      for (const Arc &arc : ifst_.st[elem.state].arcs) {
+        if (arc.ilabel != 0 || IsZero(arc.w)) continue;
+        Element next;
+        next.state = arc.next;
+        next.weight = Times(elem.weight, arc.w);
+        auto it = cur.find(next.state);
+        if (it == cur.end()) {
+          next.string = arc.olabel == 0 ? elem.string : repo_.Successor(elem.string, arc.olabel);
+          cur[next.state] = next;
+          queue.push(next);
+        } else {
+          int comp = Compare(next.weight, it->second.weight);
+          if (comp == 0) {
+            next.string = arc.olabel == 0 ? elem.string : repo_.Successor(elem.string, arc.olabel);
+            comp = CompareWS(next.weight, next.string, it->second.weight, it->second.string);
+          }
+          if (comp == 1) {
+            next.string = arc.olabel == 0 ? elem.string : repo_.Successor(elem.string, arc.olabel);
+            it->second.string = next.string;
+            it->second.weight = next.weight;
+            queue.push(next);
+            replaced = true;
+          }
+        }
+      }
+    }
+    subset->clear();
+    subset->reserve(cur.size());
+    for (const auto &kv : cur) subset->push_back(kv.second);
+    std::sort(subset->begin(), subset->end(), [](const Element &a, const Element &b) { return a.state < b.state; });
+  }
+
+  void ProcessFinal(int32_t oid) {      // :733-770
+    OutputState &st = *out_[oid];
+    int final_string = repo_.Empty();
+    Weight final_weight = Zero();
+    bool is_final = false;
+    for (const Element &e : st.minimal_subset) {
+      const Weight w = Times(e.weight, ifst_.st[e.state].final);
+      if (!IsZero(w) && (!is_final || CompareWS(w, e.string, final_weight, final_string) == 1)) {
+        is_final = true; final_weight = w; final_string = e.string;
+      }
+    }
+    if (is_final && Cost(final_weight) + st.forward_cost <= cutoff_) {
+      st.arcs.push_back(TempArc{0, final_string, -1, final_weight});
+      num_arcs_++;
+    }
+  }
+
+  void NormalizeSubset(std::vector<Element> *elems, Weight *tot, int *common) {   // :775-803
+    if (elems->empty()) { *common = repo_.Empty(); *tot = Zero(); return; }
+    std::vector<int32_t> prefix;
+    repo_.ToVector((*elems)[0].string, &prefix);
+    Weight w = (*elems)[0].weight;
+    for (size_t i = 1; i < elems->size(); i++) {
+      w = Plus(w, (*elems)[i].weight);
+      repo_.ReduceToCommonPrefix((*elems)[i].string, &prefix);
+    }
+    const size_t plen = prefix.size();
+    for (Element &e : *elems) {
+      e.weight = Divide(e.weight, w);
+      e.string = repo_.RemovePrefix(e.string, plen);
+    }
+    *common = repo_.FromVector(prefix);
+    *tot = w;
+  }
+
+  void MakeSubsetUnique(std::vector<Element> *subset) {     // :808-835
+    size_t in = 0, out = 0;
+    const size_t end = subset->size();
+    while (in != end) {
+      if (in != out) (*subset)[out] = (*subset)[in];
+      in++;
+      while (in != end && (*subset)[in].state == (*subset)[out].state) {
+        if (CompareWS((*subset)[in].weight, (*subset)[in].string, (*subset)[out].weight, (*subset)[out].string) == 1) {
+          (*subset)[out].string = (*subset)[in].string;
+          (*subset)[out].weight = (*subset)[in].weight;
+        }
+        in++;
+      }
+      out++;
+    }
+    subset->resize(out);
+  }
+
+  int32_t MinimalToStateId(const std::vector<Element> &subset, double forward_cost) {    // :505-530
+    auto it = minimal_hash_.find(&subset);
+    if (it != minimal_hash_.end()) return it->second;
+    const int32_t id = (int32_t)out_.size();
+    OutputState *ns = new OutputState{subset, {}, forward_cost};
+    minimal_hash_[&ns->minimal_subset] = id;
+    out_.push_back(ns);
+    num_elems_ += (int)subset.size();
+    ProcessFinal(id);
+    ProcessTransitions(id);
+    return id;
+  }
+
+  int32_t InitialToStateId(const std::vector<Element> &subset_in, double forward_cost, Weight *remaining, int *common_prefix) {   // :535-578
+    auto it = initial_hash_.find(&subset_in);
+    if (it != initial_hash_.end()) {
+      *remaining = it->second.weight; *common_prefix = it->second.string;
+      return it->second.state;
+    }
+    std::vector<Element> subset(subset_in);
+    EpsilonClosure(&subset);
+    ConvertToMinimal(&subset);
+    Element elem;
+    NormalizeSubset(&subset, &elem.weight, &elem.string);
+    forward_cost += Cost(elem.weight);
+    const int32_t ans = MinimalToStateId(subset, forward_cost);
+    *remaining = elem.weight; *common_prefix = elem.string;
+    std::vector<Element> *key = new std::vector<Element>(subset_in);
+    elem.state = ans;
+    initial_hash_[key] = elem;
+    num_elems_ += (int)key->size();
+    return ans;
+  }
+
+  void ProcessTransition(int32_t oid, int32_t ilabel, std::vector<Element> *subset) {    // :845-875
+    double forward_cost = out_[oid]->forward_cost;
+    int common; Weight tot;
+    NormalizeSubset(subset, &tot, &common);
+    forward_cost += Cost(tot);
+    Weight next_tot; int next_common;
+    const int32_t next = InitialToStateId(*subset, forward_cost, &next_tot, &next_common);
+    common = repo_.Concatenate(common, next_common);
+    tot = Times(tot, next_tot);
+    out_[oid]->arcs.push_back(TempArc{ilabel, common, next, tot});
+    num_arcs_++;
+  }
+
+  void ProcessTransitions(int32_t oid) {     // :903-980
+    std::vector<std::pair<int32_t, Element>> &all = all_elems_tmp_;
+    // (the subset is copied: the recursion below may grow out_)
+    {
+      const std::vector<Element> &ms = out_[oid]->minimal_subset;
+      for (const Element &e : ms) {
+        for (const Arc &arc : ifst_.st[e.state].arcs) {
+          if (arc.ilabel == 0 || IsZero(arc.w)) continue;
+          Element ne;
+          ne.state = arc.next;
+          ne.weight = Times(e.weight, arc.w);
+          ne.string = arc.olabel == 0 ? e.string : repo_.Successor(e.string, arc.olabel);
+          all.emplace_back(arc.ilabel, ne);
+        }
+      }
+    }
+    std::sort(all.begin(), all.end(), [](const std::pair<int32_t, Element> &a, const std::pair<int32_t, Element> &b) {
+      if (a.first < b.first) return true;
+      if (a.first > b.first) return false;
+      return a.second.state < b.second.state;
+    });
+    size_t cur = 0;
+    const size_t end = all.size();
+    while (cur != end) {
+      Task *task = new Task;
+      const int32_t ilabel = all[cur].first;
+      task->state = oid;
+      task->priority_cost = std::numeric_limits<double>::infinity();
+      task->label = ilabel;
+      while (cur != end && all[cur].first == ilabel) {
+        const Element &e = all[cur].second;
+        task->subset.push_back(e);
+        task->priority_cost = std::min(task->priority_cost, Cost(e.weight) + backward_[e.state]);
+        cur++;
+      }
+      task->priority_cost += out_[oid]->forward_cost;
+      if (task->priority_cost > cutoff_) delete task;
+      else { MakeSubsetUnique(&task->subset); queue_.push(task); }
+    }
+    all.clear();
+  }
+
+  void Initialize() {       // :1040-1085
+    ComputeBackward();
+    minimal_hash_.rehash(ifst_.st.size() / 2 + 3);
+    initial_hash_.rehash(ifst_.st.size() / 2 + 3);
+    if (ifst_.start < 0) return;
+    std::vector<Element> subset(1);
+    subset[0].state = ifst_.start; subset[0].weight = One(); subset[0].string = repo_.Empty();
+    EpsilonClosure(&subset);
+    ConvertToMinimal(&subset);
+    OutputState *init = new OutputState{subset, {}, 0.0};
+    out_.push_back(init);
+    num_elems_ += (int)subset.size();
+    minimal_hash_[&init->minimal_subset] = 0;
+    ProcessFinal(0);
+    ProcessTransitions(0);
+  }
+
+  const Lattice &ifst_;
+  double beam_, cutoff_ = 0.0;
+  DetOptions opts_;
+  std::vector<OutputState *> out_;
+  int num_arcs_ = 0, num_elems_ = 0;
+  std::vector<double> backward_;
+  MinimalHash minimal_hash_;
+  InitialHash initial_hash_;
+  std::priority_queue<Task *, std::vector<Task *>, TaskWorse> queue_;
+  std::vector<std::pair<int32_t, Element>> all_elems_tmp_;
+  std::vector<uint8_t> isym_or_final_;
+  StringRepo repo_;
+};
+
+template <class Out>
+bool DeterminizePrunedImpl(const Lattice &ifst, double beam, Out *ofst, DetOptions opts, bool infinite_beam_skips_retry) {
+  if (ifst.st.empty()) { ofst->st.clear(); ofst->start = -1; return true; }
+  const int max_iters = 10;
+  Lattice temp;
+  for (int iter = 0; iter < max_iters; iter++) {
+    Determinizer det(iter == 0 ? ifst : temp, beam, opts);
+    double effective_beam;
+    const bool ans = det.Determinize(&effective_beam);
+    if (effective_beam >= beam * opts.retry_cutoff || (infinite_beam_skips_retry && beam == std::numeric_limits<double>::infinity()) ||
+        iter + 1 == max_iters) {
+      det.Output(ofst);
+      return ans;
+    }
+    if (effective_beam < 0.0) effective_beam = 0.0;
+    double new_beam = beam * std::sqrt(effective_beam / beam);
+    if (new_beam < 0.5 * beam) new_beam = 0.5 * beam;
+    beam = new_beam;
+    if (iter == 0) temp = ifst;
+    PruneLattice((float)beam, &temp);
+  }
+  return false;
+}
+
+}  // namespace
+
+bool DeterminizeLatticePruned(const Lattice &ifst, double beam, CompactLattice *ofst, DetOptions opts) {
+  return DeterminizePrunedImpl(ifst, beam, ofst, opts, true);
+}
+bool DeterminizeLatticePruned(const Lattice &ifst, double beam, Lattice *ofst, DetOptions opts) {
+  // (ifst and ofst may be the same object in the reference's first pass; here the result is built aside)
+  Lattice out;
+  const bool ans = DeterminizePrunedImpl(ifst, beam, &out, opts, false);
+  *ofst = std::move(out);
+  return ans;
+}
+
+// determinize-lattice-pruned.cc:1283-1340 (insert), :1342-1365 (delete), :1385-1404 (first pass),
+// :1408-1470 (both passes), :1487-1507 (wrapper)
+bool DeterminizeLatticePhonePrunedWrapper(const TransInfo &tm, Lattice *ifst, double beam, CompactLattice *ofst, PhoneDetOptions opts) {
+  bool ans = true;
+  Invert(ifst);
+  if (!IsTopSorted(*ifst)) {
+    if (!TopSort(ifst))
+      throw std::runtime_error("Topological sorting of state-level lattice failed (probably your lexicon has empty words or your LM has epsilon cycles).");
+  }
+  ArcSortILabel(ifst);
+  if (!opts.phone_determinize && !opts.word_determinize)
+    throw std::runtime_error("lattice determinization: --phone-determinize and --word-determinize both false is not supported");
+  DetOptions det;
+  det.delta = opts.delta;
+  det.max_mem = opts.max_mem;
+  if (opts.phone_determinize) {
+    // phone symbols on the word side at every phone boundary (first transition-id of a phone)
+    int32_t highest = 0;
+    for (const State &s : ifst->st) for (const Arc &a : s.arcs) highest = std::max(highest, a.ilabel);
+    const int32_t first_phone_label = highest + 1;
+    const int32_t n0 = (int32_t)ifst->st.size();
+    for (int32_t s = 0; s < n0; s++) {
+      if (s == ifst->start) continue;
+      const size_t na = ifst->st[s].arcs.size();
+      for (size_t i = 0; i < na; i++) {
+        Arc arc = ifst->st[s].arcs[i];
+        if (arc.olabel != 0) {
+          if (arc.olabel < 0 || (size_t)arc.olabel >= tm.phone.size())
+            throw std::runtime_error("lattice determinization: transition-id out of the model's range");
+          if (tm.hmm_state[arc.olabel] == 0 && !tm.self_loop[arc.olabel]) {
+            const int32_t phone = tm.phone[arc.olabel];
+            if (arc.ilabel == 0) arc.ilabel = first_phone_label + phone;
+            else {
+              const int32_t extra = (int32_t)ifst->st.size();
+              ifst->st.emplace_back();
+              ifst->st[extra].arcs.push_back(Arc{first_phone_label + phone, 0, One(), arc.next});
+              arc.next = extra;
+            }
+          }
+        }
+        ifst->st[s].arcs[i] = arc;
+      }
+    }
+    TopSort(ifst);
+    ans = DeterminizeLatticePruned(*ifst, beam, ifst, det) && ans;
+    for (State &s : ifst->st) for (Arc &a : s.arcs) if (a.ilabel >= first_phone_label) a.ilabel = 0;
+    TopSort(ifst);
+    if (!opts.word_determinize)
+      throw std::runtime_error("lattice determinization: --word-determinize=false is not supported");
+  }
+  ans = DeterminizeLatticePruned(*ifst, beam, ofst, det) && ans;
+  if (opts.minimize) throw std::runtime_error("lattice determinization: --minimize is not supported");
+  Connect(ofst);
+  return ans;
+}
+
+bool PruneLattice(float beam, Lattice *lat) {
+  if (!IsTopSorted(*lat)) { if (!TopSort(lat)) return false; }
+  const int32_t n = (int32_t)lat->st.size();
+  if (n == 0) return false;
+  const double inf = std::numeric_limits<double>::infinity();
+  std::vector<double> fwd(n, inf);
+  fwd[lat->start] = 0.0;
+  double best_final = inf;
+  for (int32_t s = 0; s < n; s++) {
+    const double f = fwd[s];
+    for (const Arc &a : lat->st[s].arcs) { const double nf = f + Cost(a.w); if (fwd[a.next] > nf) fwd[a.next] = nf; }
+    const double tf = f + Cost(lat->st[s].final);
+    if (tf < best_final) best_final = tf;
+  }
+  const int32_t bad = n;
+  lat->st.emplace_back();
+  const double cutoff = best_final + beam;
+  std::vector<double> &bwd = fwd;
+  for (int32_t s = n - 1; s >= 0; s--) {
+    const double f = fwd[s];
+    double b = Cost(lat->st[s].final);
+    if (b + f > cutoff && b != inf) lat->st[s].final = Zero();
+    for (Arc &a : lat->st[s].arcs) {
+      const double ab = Cost(a.w) + bwd[a.next];
+      if (ab < b) b = ab;
+      if (f + ab > cutoff) a.next = bad;
+    }
+    bwd[s] = b;
+  }
+  Connect(lat);
+  return !lat->st.empty();
+}
+
+// ------------------------------------------------------------------ scoring
+static inline Weight ScaleW(const Weight &w, double s00, double s01, double s10, double s11) {   // lattice-weight.h:232-242
+  if (w.v1 == kInf) return Zero();
+  return Weight{(float)(s00 * w.v1 + s01 * w.v2), (float)(s10 * w.v1 + s11 * w.v2)};
+}
+void ScaleLattice(double s00, double s01, double s10, double s11, Lattice *lat) {
+  if (s00 == 1.0 && s01 == 0.0 && s10 == 0.0 && s11 == 1.0) return;      // lattice-utils-inl.h: ScaleLattice returns early on the identity
+  for (State &s : lat->st) {
+    for (Arc &a : s.arcs) a.w = ScaleW(a.w, s00, s01, s10, s11);
+    if (!IsZero(s.final)) s.final = ScaleW(s.final, s00, s01, s10, s11);
+  }
+}
+void ScaleLattice(double s00, double s01, double s10, double s11, CompactLattice *clat) {
+  if (s00 == 1.0 && s01 == 0.0 && s10 == 0.0 && s11 == 1.0) return;
+  for (CState &s : clat->st) {
+    for (CArc &a : s.arcs) a.w.w = ScaleW(a.w.w, s00, s01, s10, s11);
+    if (!IsZero(s.final.w)) s.final.w = ScaleW(s.final.w, s00, s01, s10, s11);
+  }
+}
+void AddWordInsPen(float pen, CompactLattice *clat) {
+  for (CState &s : clat->st) for (CArc &a : s.arcs) if (a.label != 0) a.w.w.v1 = a.w.w.v1 + pen;
+}
+
+void ConvertLattice(const CompactLattice &clat, Lattice *lat, bool invert) {
+  lat->st.clear();
+  const int32_t n = (int32_t)clat.st.size();
+  lat->st.resize(n);
+  lat->start = clat.start;
+  auto add = [&](int32_t from, int32_t il, int32_t ol, Weight w, int32_t to) {
+    if (invert) std::swap(il, ol);
+    lat->st[from].arcs.push_back(Arc{il, ol, w, to});
+  };
+  for (int32_t s = 0; s < n; s++) {
+    const CWeight &fw = clat.st[s].final;
+    if (!(IsZero(fw.w) && fw.str.empty())) {
+      int32_t cur = s;
+      for (size_t k = 0; k < fw.str.size(); k++) {
+        const int32_t nx = (int32_t)lat->st.size();
+        lat->st.emplace_back();
+        add(cur, 0, fw.str[k], k == 0 ? fw.w : One(), nx);
+        cur = nx;
+      }
+      lat->st[cur].final = fw.str.empty() ? fw.w : One();
+    }
+    for (const CArc &a : clat.st[s].arcs) {
+      const size_t len = a.w.str.size();
+      int32_t cur = s;
+      for (size_t k = 0; k + 1 < len; k++) {
+        const int32_t nx = (int32_t)lat->st.size();
+        lat->st.emplace_back();
+        add(cur, k == 0 ? a.label : 0, a.w.str[k], k == 0 ? a.w.w : One(), nx);
+        cur = nx;
+      }
+      add(cur, len <= 1 ? a.label : 0, len > 0 ? a.w.str[len - 1] : 0, len <= 1 ? a.w.w : One(), a.next);
+    }
+  }
+}
+
+void CompactLatticeShortestPath(const CompactLattice &clat_in, CompactLattice *shortest) {     // lattice-functions.cc:1094-1177
+  const CompactLattice *pc = &clat_in;
+  CompactLattice copy;
+  if (!IsTopSorted(clat_in)) {
+    copy = clat_in;
+    if (!TopSort(&copy)) throw std::runtime_error("Was not able to topologically sort lattice (cycles found?)");
+    pc = &copy;
+  }
+  const CompactLattice &clat = *pc;
+  shortest->st.clear(); shortest->start = -1;
+  if (clat.start < 0) return;
+  const int32_t n = (int32_t)clat.st.size(), superfinal = n;
+  const double inf = std::numeric_limits<double>::infinity();
+  std::vector<std::pair<double, int32_t>> best(n + 1, std::make_pair(inf, -1));
+  best[0].first = 0;
+  for (int32_t s = 0; s < n; s++) {
+    const double my = best[s].first;
+    for (const CArc &a : clat.st[s].arcs) {
+      const double nc = my + Cost(a.w.w);
+      if (nc < best[a.next].first) { best[a.next].first = nc; best[a.next].second = s; }
+    }
+    const double tf = my + Cost(clat.st[s].final.w);
+    if (tf < best[superfinal].first) { best[superfinal].first = tf; best[superfinal].second = s; }
+  }
+  std::vector<int32_t> states;
+  int32_t cur = superfinal;
+  while (cur != 0) {
+    const int32_t prev = best[cur].second;
+    if (prev < 0) return;       // no path: empty result
+    states.push_back(prev);
+    cur = prev;
+  }
+  std::reverse(states.begin(), states.end());
+  shortest->st.resize(states.size());
+  shortest->start = 0;
+  for (size_t s = 0; s < states.size(); s++) {
+    if (s + 1 < states.size()) {
+      bool have = false;
+      const CArc *pick = nullptr;
+      for (const CArc &a : clat.st[states[s]].arcs)
+        if (a.next == states[s + 1] && (!have || Cost(a.w.w) < Cost(pick->w.w))) { pick = &a; have = true; }
+      CArc na = *pick;
+      na.next = (int32_t)s + 1;
+      shortest->st[s].arcs.push_back(std::move(na));
+    } else {
+      shortest->st[s].final = clat.st[states[s]].final;
+    }
+  }
+}
+
+bool GetLinearSymbolSequence(const CompactLattice &lin, std::vector<int32_t> *ali, std::vector<int32_t> *words, Weight *tot) {
+  // CompactLatticeToWordAlignment / GetLinearSymbolSequence on the converted lattice: strings in
+  // path order, words where the arc label is not 0, weights multiplied along the path
+  if (ali) ali->clear();
+  if (words) words->clear();
+  Weight w = One();
+  if (lin.start < 0) { if (tot) *tot = Zero(); return true; }   // the reference accepts the empty FST as the empty sequence
+  int32_t s = lin.start;
+  for (;;) {
+    const CState &st = lin.st[s];
+    if (!IsZero(st.final.w) || !st.final.str.empty()) {
+      if (!st.arcs.empty()) return false;
+      w = Times(w, st.final.w);
+      if (ali) ali->insert(ali->end(), st.final.str.begin(), st.final.str.end());
+      break;
+    }
+    if (st.arcs.size() != 1) return false;
+    const CArc &a = st.arcs[0];
+    w = Times(w, a.w.w);
+    if (ali) ali->insert(ali->end(), a.w.str.begin(), a.w.str.end());
+    if (words && a.label != 0) words->push_back(a.label);
+    s = a.next;
+  }
+  if (tot) *tot = w;
+  return true;
+}
+
+}  // namespace vblat

@@ -1,0 +1,110 @@
+// lattice.h -- lattices after the search: connect / sort / determinize / scale / best path.
+//
+// Host C++ written for this repository; nothing of Kaldi/OpenFst is linked or copied.  What each
+// piece follows (paths relative to /root/reference):
+//   LatticeWeight (graph, acoustic), Compare/Plus/Times/Divide/ApproxEqual/ConvertToCost
+//                                             kaldi-master/src/fstext/lattice-weight.h:225-370,786-805
+//   CompactLatticeWeight (weight + transition-id string)   lattice-weight.h:400-660
+//   Connect, TopSort (depth-first finishing order), Invert, ArcSort(ilabel)
+//                                             openfst-win-1.6/src/include/fst/{connect,dfs-visit,topsort,invert,arcsort}.h
+//   DeterminizeLatticePruned, the phone-level first pass, DeterminizeLatticePhonePrunedWrapper
+//                                             kaldi-master/src/lat/determinize-lattice-pruned.cc
+//   LatticeStringRepository                    kaldi-master/src/fstext/determinize-lattice-inl.h:37-260
+//   PruneLattice                               kaldi-master/src/lat/lattice-functions.cc (PruneLattice)
+//   ScaleLattice, AddWordInsPenToCompactLattice, CompactLatticeShortestPath, ConvertLattice
+//                                             kaldi-master/src/lat/lattice-functions.cc, fstext/lattice-utils-inl.h
+// This is the step right after the search in the reference's Decode:
+// gmm-latgen-faster determinizes every utterance's raw lattice before writing it
+// (kaldi-master/src/decoder/decoder-wrappers.cc:262-284), and scoring rescales it, adds the word
+// insertion penalty and takes the best path (VB/scr/steps/scoring/score_kaldi_wer.cpp:36-254).
+#ifndef VOICEBRIDGE_LATTICE_H_
+#define VOICEBRIDGE_LATTICE_H_
+
+#include <cstdint>
+#include <limits>
+#include <string>
+#include <vector>
+
+namespace vblat {
+
+constexpr float kInf = std::numeric_limits<float>::infinity();
+constexpr float kDelta = 1.0f / 1024.0f;     // fst::kDelta
+
+struct Weight {            // LatticeWeight: value1 = graph cost, value2 = acoustic cost
+  float v1, v2;
+};
+inline Weight Zero() { return Weight{kInf, kInf}; }
+inline Weight One() { return Weight{0.0f, 0.0f}; }
+inline bool IsZero(const Weight &w) { return w.v1 == kInf && w.v2 == kInf; }
+inline bool Same(const Weight &a, const Weight &b) { return a.v1 == b.v1 && a.v2 == b.v2; }
+int Compare(const Weight &a, const Weight &b);         // +1: a is better (smaller cost)
+inline Weight Plus(const Weight &a, const Weight &b) { return Compare(a, b) >= 0 ? a : b; }
+inline Weight Times(const Weight &a, const Weight &b) { return Weight{a.v1 + b.v1, a.v2 + b.v2}; }
+Weight Divide(const Weight &a, const Weight &b);
+bool ApproxEqual(const Weight &a, const Weight &b, float delta = kDelta);
+inline double Cost(const Weight &w) { return (double)w.v1 + (double)w.v2; }
+
+struct Arc { int32_t ilabel, olabel; Weight w; int32_t next; };
+struct State { Weight final = Zero(); std::vector<Arc> arcs; };
+struct Lattice {           // VectorFst<LatticeArc>
+  int32_t start = -1;
+  std::vector<State> st;
+  size_t NumArcs() const { size_t n = 0; for (const State &s : st) n += s.arcs.size(); return n; }
+};
+
+struct CWeight { Weight w = Zero(); std::vector<int32_t> str; };   // CompactLatticeWeight
+struct CArc { int32_t label; CWeight w; int32_t next; };          // acceptor: ilabel == olabel == word
+struct CState { CWeight final; std::vector<CArc> arcs; };
+struct CompactLattice {    // VectorFst<CompactLatticeArc>
+  int32_t start = -1;
+  std::vector<CState> st;
+  size_t NumArcs() const { size_t n = 0; for (const CState &s : st) n += s.arcs.size(); return n; }
+};
+
+// ---- graph operations (state numbering and arc order as OpenFst leaves them)
+void Connect(Lattice *lat);
+void Connect(CompactLattice *clat);
+bool IsTopSorted(const Lattice &lat);             // every arc goes to a higher-numbered state
+bool TopSort(Lattice *lat);                        // false (and unchanged) when cyclic
+bool TopSort(CompactLattice *clat);
+void Invert(Lattice *lat);
+void ArcSortILabel(Lattice *lat);
+
+// ---- determinization
+struct DetOptions {        // DeterminizeLatticePrunedOptions
+  float delta = kDelta;
+  int max_mem = -1, max_loop = -1, max_states = -1, max_arcs = -1;
+  float retry_cutoff = 0.5f;
+};
+struct PhoneDetOptions {   // DeterminizeLatticePhonePrunedOptions (gmm-latgen-faster registers max_mem 50000000)
+  float delta = kDelta;
+  int max_mem = 50000000;
+  bool phone_determinize = true, word_determinize = true, minimize = false;
+};
+// what the phone-level pass needs of the TransitionModel, indexed by transition-id (index 0 unused)
+struct TransInfo {
+  std::vector<int32_t> phone;        // TransitionIdToPhone
+  std::vector<int32_t> hmm_state;    // TransitionIdToHmmState
+  std::vector<uint8_t> self_loop;    // IsSelfLoop
+};
+// input: words on the INPUT side (i.e. after Invert), topologically sorted
+bool DeterminizeLatticePruned(const Lattice &ifst, double beam, CompactLattice *ofst, DetOptions opts = DetOptions());
+bool DeterminizeLatticePruned(const Lattice &ifst, double beam, Lattice *ofst, DetOptions opts = DetOptions());
+// raw lattice as the search leaves it (transition-ids on the input side); *ifst is consumed
+bool DeterminizeLatticePhonePrunedWrapper(const TransInfo &tm, Lattice *ifst, double beam, CompactLattice *ofst,
+                                          PhoneDetOptions opts = PhoneDetOptions());
+bool PruneLattice(float beam, Lattice *lat);
+
+// ---- what scoring uses
+void ScaleLattice(double s00, double s01, double s10, double s11, Lattice *lat);
+void ScaleLattice(double s00, double s01, double s10, double s11, CompactLattice *clat);
+void AddWordInsPen(float word_ins_penalty, CompactLattice *clat);
+void ConvertLattice(const Lattice &lat, CompactLattice *clat, bool invert = true);   // lattice-utils-inl.h:27-100
+void ConvertLattice(const CompactLattice &clat, Lattice *lat, bool invert = true);   // :102-160
+// best path of a compact lattice as a linear compact lattice; empty when there is none
+void CompactLatticeShortestPath(const CompactLattice &clat, CompactLattice *shortest);
+// words, alignment and total weight of a linear compact lattice; false if it is not linear
+bool GetLinearSymbolSequence(const CompactLattice &linear, std::vector<int32_t> *ali, std::vector<int32_t> *words, Weight *tot);
+
+}  // namespace vblat
+#endif

@@ -11,22 +11,24 @@
 #include <iostream>
 #include <limits>
 #include <map>
+#include <atomic>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
+#include "api_common.h"
 #include "kaldi_io.h"
+#include "lattice.h"
 #include "voicebridge_hip.h"
+
+using namespace vbapi;
 
 namespace {
 
 thread_local int g_device = 0;
 thread_local vbh_ctx *g_ctx = nullptr;
 thread_local int g_ctx_device = -1;
-
-struct ApiError : public std::runtime_error {
-  explicit ApiError(const std::string &m) : std::runtime_error(m) {}
-};
 
 void Check(int rc, const char *what) {
   if (rc != 0) throw ApiError(std::string(what) + ": " + vbh_last_error());
@@ -39,66 +41,6 @@ vbh_ctx *Ctx() {
   g_ctx_device = g_device;
   return g_ctx;
 }
-
-struct Log {
-  std::ofstream *f;
-  explicit Log(std::ofstream *file) : f(file) {}
-  std::ostream &os() { return (f && f->is_open()) ? static_cast<std::ostream &>(*f) : std::cerr; }
-};
-
-// ---- Kaldi command-line grammar (K/util/parse-options.cc:341-352,477-508): --name=value,
-// --flag (boolean true), --config=file with one option per line, "--" ends the options
-struct Options {
-  std::map<std::string, std::string> kv;
-  std::vector<std::string> args;
-  std::map<std::string, bool> known;
-  void Know(std::initializer_list<const char *> names) { for (const char *n : names) known[n] = true; }
-  static std::string Norm(std::string s) { for (char &c : s) if (c == '_') c = '-'; return s; }
-  void Set(const std::string &opt) {
-    const size_t eq = opt.find('=');
-    const std::string name = Norm(opt.substr(2, eq == std::string::npos ? std::string::npos : eq - 2));
-    const std::string val = eq == std::string::npos ? "true" : opt.substr(eq + 1);
-    if (name == "config") { ReadConfig(val); return; }
-    if (name == "verbose" || name == "print-args" || name == "help") return;
-    if (!known.count(name)) throw ApiError("invalid option --" + name);
-    kv[name] = val;
-  }
-  void ReadConfig(const std::string &path) {
-    std::ifstream f(path);
-    if (!f) throw ApiError("cannot open config file " + path);
-    std::string line;
-    while (std::getline(f, line)) {
-      const size_t h = line.find('#');
-      if (h != std::string::npos) line = line.substr(0, h);
-      const size_t a = line.find_first_not_of(" \t\r");
-      if (a == std::string::npos) continue;
-      const size_t b = line.find_last_not_of(" \t\r");
-      line = line.substr(a, b - a + 1);
-      if (line.compare(0, 2, "--") != 0) throw ApiError("bad line in config file " + path + ": " + line);
-      Set(line);
-    }
-  }
-  void Parse(int argc, char *argv[]) {
-    bool opts_done = false;
-    for (int i = 1; i < argc; i++) {
-      const std::string a = argv[i];
-      if (!opts_done && a == "--") { opts_done = true; continue; }
-      if (!opts_done && a.compare(0, 2, "--") == 0) Set(a);
-      else args.push_back(a);
-    }
-  }
-  bool Has(const char *n) const { return kv.count(n) != 0; }
-  std::string Str(const char *n, const std::string &d) const { auto i = kv.find(n); return i == kv.end() ? d : i->second; }
-  double Num(const char *n, double d) const { auto i = kv.find(n); return i == kv.end() ? d : atof(i->second.c_str()); }
-  bool Bool(const char *n, bool d) const {
-    auto i = kv.find(n);
-    if (i == kv.end()) return d;
-    const std::string &v = i->second;
-    if (v == "true" || v == "t" || v == "1" || v == "") return true;
-    if (v == "false" || v == "f" || v == "0") return false;
-    throw ApiError(std::string("bad boolean for --") + n + ": " + v);
-  }
-};
 
 struct DevMem {   // RAII device buffer through the ABI
   vbh_ctx *ctx; void *p = nullptr;
@@ -170,20 +112,6 @@ void RunFeatpost(const vbh_featpost_cfg &cfg, const Batch &b, const std::vector<
                      utt2spk.empty() ? nullptr : utt2spk.data(), n_spk, stats, lda, spk, (float *)d_out.p), "vbh_featpost");
   out->resize((size_t)T * *out_dim);
   Check(vbh_copy_d2h(ctx, out->data(), d_out.p, sizeof(float) * out->size()), "vbh_copy_d2h");
-}
-
-template <class F>
-int Guard(const char *prog, std::ofstream *file_log, F body) {
-  Log log(file_log);
-  try {
-    return body(log);
-  } catch (const std::exception &e) {
-    log.os() << "ERROR (" << prog << ") " << e.what() << "\n";
-    return -1;
-  } catch (...) {
-    log.os() << "ERROR (" << prog << ") unknown exception\n";
-    return -1;
-  }
 }
 
 int WindowType(const std::string &s) {
@@ -516,7 +444,7 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     Options po;
     po.Know({"beam", "max-active", "min-active", "lattice-beam", "prune-interval", "determinize-lattice", "beam-delta",
              "hash-ratio", "acoustic-scale", "word-symbol-table", "allow-partial", "max-mem", "phone-determinize",
-             "word-determinize", "minimize", "decode-batch"});
+             "word-determinize", "minimize", "decode-batch", "delta"});
     po.Parse(argc, argv);
     if (po.args.size() < 4 || po.args.size() > 6) throw ApiError("wrong arguments.");
     vbh_decode_cfg cfg;
@@ -533,8 +461,12 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     const bool determinize = po.Bool("determinize-lattice", true);
     const std::string &lat_wspec = po.args[3];
     const bool want_lat = !lat_wspec.empty() && lat_wspec != "ark:/dev/null";
-    if (want_lat && determinize)
-      throw ApiError("lattice determinization is not part of this build: pass --determinize-lattice=false (raw lattices)");
+    vblat::PhoneDetOptions det_opts;      // LatticeFasterDecoderConfig::det_opts (K/decoder/lattice-faster-decoder.h:69-92)
+    det_opts.delta = (float)po.Num("delta", vblat::kDelta);
+    det_opts.max_mem = (int)po.Num("max-mem", 50000000);
+    det_opts.phone_determinize = po.Bool("phone-determinize", true);
+    det_opts.word_determinize = po.Bool("word-determinize", true);
+    det_opts.minimize = po.Bool("minimize", false);
     vbio::Model model;
     vbio::ReadModel(po.args[0], &model);
     vbio::Graph graph;
@@ -548,7 +480,8 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     Check(vbh_graph_create(ctx, (int32_t)graph.final_cost.size(), graph.start, graph.final_cost.data(), graph.arc_offset.data(),
                            reinterpret_cast<const vbh_arc *>(graph.arcs.data()), &g), "vbh_graph_create");
     vbio::LatticeWriter lat_writer;
-    if (want_lat) lat_writer.Open(lat_wspec);
+    vbio::CompactLatticeWriter clat_writer;
+    if (want_lat) { if (determinize) clat_writer.Open(lat_wspec); else lat_writer.Open(lat_wspec); }
     vbio::IntVectorWriter words_writer, ali_writer;
     if (po.args.size() >= 5 && !po.args[4].empty()) words_writer.Open(po.args[4]);
     if (po.args.size() >= 6 && !po.args[5].empty()) ali_writer.Open(po.args[5]);
@@ -580,9 +513,55 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
       const int rc = vbh_decode_batch(dec, (const float *)d_ll.p, model.num_pdfs, b.offs.data(), (int32_t)b.keys.size(),
                                       model.tid2pdf.data(), (int32_t)model.tid2pdf.size() - 1);
       if (rc != 0) { const std::string e = vbh_last_error(); vbh_decoder_destroy(dec); throw ApiError("vbh_decode_batch: " + e); }
-      for (size_t u = 0; u < b.keys.size(); u++) {
-        vbh_lattice L;
-        Check(vbh_decoder_result(dec, (int32_t)u, &L), "vbh_decoder_result");
+      // GetRawLattice (K/decoder/lattice-faster-decoder.cc:110-192): one state per token (state 0 =
+      // the start token), arc weights (graph, acoustic - cost_offset), acoustic costs still scaled
+      const size_t nu = b.keys.size();
+      std::vector<vbh_lattice> Ls(nu);
+      for (size_t u = 0; u < nu; u++) Check(vbh_decoder_result(dec, (int32_t)u, &Ls[u]), "vbh_decoder_result");
+      auto usable = [&](const vbh_lattice &L) { return L.ok && (L.reached_final || allow_partial); };
+      auto raw_lattice = [&](const vbh_lattice &L, vblat::Lattice *lat) {
+        const int n = L.num_toks;
+        // tokens are sorted by (frame, HCLG state); the start token must become state 0
+        std::vector<int32_t> remap(n);
+        int start_idx = 0;
+        for (int i = 0; i < n && L.tok_frame[i] == 0; i++) if (L.tok_state[i] == graph.start) start_idx = i;
+        for (int i = 0; i < n; i++) remap[i] = i == start_idx ? 0 : (i < start_idx ? i + 1 : i);
+        lat->st.assign(n, vblat::State());
+        lat->start = n ? 0 : -1;
+        for (int i = 0; i < n; i++) if (!std::isinf(L.tok_final[i])) lat->st[remap[i]].final = vblat::Weight{L.tok_final[i], 0.0f};
+        for (int l = 0; l < L.num_links; l++)
+          lat->st[remap[L.link_src[l]]].arcs.push_back(vblat::Arc{L.link_ilabel[l], L.link_olabel[l], vblat::Weight{L.link_graph[l], L.link_acoustic[l]},
+                                                                  remap[L.link_dst[l]]});
+      };
+      // "We'll write the lattice without acoustic scaling" (decoder-wrappers.cc:268-284)
+      const double inv = cfg.acoustic_scale != 0.0f ? 1.0 / (double)cfg.acoustic_scale : 1.0;
+      // determinization (DeterminizeLatticePhonePrunedWrapper, decoder-wrappers.cc:262-275) is host
+      // work per utterance: the utterances of the batch are spread over the host's cores
+      std::vector<vblat::CompactLattice> clats(want_lat && determinize ? nu : 0);
+      std::vector<int> det_ok(nu, 1);
+      std::vector<std::string> det_err(nu);
+      if (want_lat && determinize) {
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+          for (size_t u = next++; u < nu; u = next++) {
+            if (!usable(Ls[u])) continue;
+            try {
+              vblat::Lattice lat;
+              raw_lattice(Ls[u], &lat);
+              vblat::Connect(&lat);
+              det_ok[u] = vblat::DeterminizeLatticePhonePrunedWrapper(model.trans, &lat, cfg.lattice_beam, &clats[u], det_opts) ? 1 : 0;
+              vblat::ScaleLattice(1.0, 0.0, 0.0, inv, &clats[u]);
+            } catch (const std::exception &e) { det_err[u] = e.what(); }
+          }
+        };
+        const unsigned nt = std::max(1u, std::min((unsigned)nu, std::min(16u, std::thread::hardware_concurrency())));
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool) t.join();
+      }
+      for (size_t u = 0; u < nu; u++) {
+        const vbh_lattice &L = Ls[u];
         const std::string &utt = b.keys[u];
         // DecodeUtteranceLatticeFaster (K/decoder/decoder-wrappers.cc:198-293)
         if (!L.ok) { log.os() << "WARNING (gmm-latgen-faster) Failed to decode file " << utt << "\n"; num_err++; continue; }
@@ -594,23 +573,17 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
         if (words_writer.IsOpen()) words_writer.Write(utt, words);
         if (ali_writer.IsOpen()) ali_writer.Write(utt, ali);
         const double like = -((double)L.best_graph + (double)L.best_acoustic);
-        if (want_lat) {
-          // GetRawLattice: one state per token (state 0 = start token), arc weights
-          // (graph, acoustic), acoustic un-scaled by 1/acwt before writing (:276-284)
-          vbio::LatticeOut lo;
-          const int n = L.num_toks;
-          // the start token must become state 0: tokens are sorted by (frame, HCLG state)
-          std::vector<int32_t> remap(n);
-          int start_idx = 0;
-          for (int i = 0; i < n && L.tok_frame[i] == 0; i++) if (L.tok_state[i] == graph.start) start_idx = i;
-          for (int i = 0; i < n; i++) remap[i] = i == start_idx ? 0 : (i < start_idx ? i + 1 : i);
-          lo.arcs.resize(n); lo.final_graph.assign(n, std::numeric_limits<float>::infinity()); lo.final_acoustic.assign(n, 0.0f);
-          const float inv = cfg.acoustic_scale != 0.0f ? 1.0f / cfg.acoustic_scale : 1.0f;
-          for (int i = 0; i < n; i++) lo.final_graph[remap[i]] = L.tok_final[i];
-          for (int l = 0; l < L.num_links; l++)
-            lo.arcs[remap[L.link_src[l]]].push_back(vbio::LatticeArcOut{L.link_ilabel[l], L.link_olabel[l], L.link_graph[l],
-                                                                       L.link_acoustic[l] * inv, remap[L.link_dst[l]]});
-          lat_writer.Write(utt, lo);
+        if (want_lat && determinize) {
+          if (!det_err[u].empty()) throw ApiError("determinization of " + utt + ": " + det_err[u]);
+          if (!det_ok[u]) log.os() << "WARNING (gmm-latgen-faster) Determinization finished earlier than the beam for utterance " << utt << "\n";
+          clat_writer.Write(utt, clats[u]);
+        } else if (want_lat) {
+          vblat::Lattice lat;
+          raw_lattice(L, &lat);
+          if (lat.st.empty()) throw ApiError("Unexpected problem getting lattice for utterance " + utt);
+          vblat::Connect(&lat);
+          vblat::ScaleLattice(1.0, 0.0, 0.0, inv, &lat);
+          lat_writer.Write(utt, lat);
         }
         log.os() << "LOG (gmm-latgen-faster) Log-like per frame for utterance " << utt << " is " << (like / (L.num_ali ? L.num_ali : 1))
                  << " over " << L.num_ali << " frames.\n";
@@ -757,12 +730,6 @@ int GmmDecodeFaster(int argc, char *argv[], std::ofstream &file_log) {
 
 // =====================================================================================
 namespace {
-template <class F>
-int WithLog(const char *log_path, F f) {
-  std::ofstream log;
-  if (log_path && *log_path) log.open(log_path, std::ios::app);
-  return f(log);
-}
 }  // namespace
 
 extern "C" {

@@ -19,10 +19,11 @@
 // Differences that a caller must know (all reported as errors, never silently ignored):
 //   * compute-mfcc-feats: --dither must be 0 (the reference default 1.0 draws from libc rand());
 //     --output-format=htk, --vtln-map, --min-duration, wav.scp pipes are not supported.
-//   * gmm-latgen-faster: lattices are written with --determinize-lattice=false only (raw state-level
-//     lattice, as DecodeFmllr's main pass does, VB/scr/steps/decode_fmllr.cpp:405-485);
-//     determinization is the next row of SURVEY.md §8f.  --word-symbol-table is accepted and ignored
-//     (it only echoes words to stderr in the reference).
+//   * gmm-latgen-faster: --determinize-lattice=true (the default) writes CompactLattices determinized
+//     by the reference's two-pass (phone level, then word level) pruned algorithm, restated in
+//     host/lattice.cc; --minimize=true is not supported.  --word-symbol-table is accepted and
+//     ignored (it only echoes words to stderr in the reference).
+//   * lattice programs read and write binary archives only (text-mode lattices are refused).
 #ifndef VOICEBRIDGE_API_H_
 #define VOICEBRIDGE_API_H_
 
@@ -39,6 +40,18 @@ int CopyFeats(int argc, char *argv[], std::ofstream &file_log);          // VB/s
 // not wrapped by the reference DLL; upstream program K/gmmbin/gmm-decode-faster.cc with the same conventions
 int GmmDecodeFaster(int argc, char *argv[], std::ofstream &file_log);
 
+// ---- lattices after the search; host code in voicebridge_latbin.cc
+//   src/kaldi_src.h:94   int LatticeDeterminizePruned(int argc, char *argv[], fs::ofstream &file_log);
+//   src/kaldi_src.h:92   int LatticeScale(...);   :89 LatticeAddPenalty(...);   :88 LatticeBestPath(...);
+//   src/kaldi_src.h:64   int ComputeWer(int argc, char *argv[], fs::ofstream &file_log);
+int LatticeDeterminizePruned(int argc, char *argv[], std::ofstream &file_log);
+int LatticeScale(int argc, char *argv[], std::ofstream &file_log);
+int LatticeAddPenalty(int argc, char *argv[], std::ofstream &file_log);
+int LatticeBestPath(int argc, char *argv[], std::ofstream &file_log);
+int ComputeWer(int argc, char *argv[], std::ofstream &file_log);           // the three result lines go to the log stream
+// upstream program K/latbin/lattice-determinize-phone-pruned.cc (what gmm-latgen-faster does per utterance)
+int LatticeDeterminizePhonePruned(int argc, char *argv[], std::ofstream &file_log);
+
 // plain-C shims of the above for hosts without C++ streams (ctypes, cgo ...): log_path may be NULL
 extern "C" {
 int vb_ComputeMFCCFeats(int argc, char *argv[], const char *log_path);
@@ -50,6 +63,13 @@ int vb_TransformFeats(int argc, char *argv[], const char *log_path);
 int vb_GmmLatgenFaster(int argc, char *argv[], const char *log_path);
 int vb_GmmDecodeFaster(int argc, char *argv[], const char *log_path);
 int vb_CopyFeats(int argc, char *argv[], const char *log_path);
+int vb_LatticeDeterminizePruned(int argc, char *argv[], const char *log_path);
+int vb_LatticeDeterminizePhonePruned(int argc, char *argv[], const char *log_path);
+int vb_LatticeScale(int argc, char *argv[], const char *log_path);
+int vb_LatticeAddPenalty(int argc, char *argv[], const char *log_path);
+int vb_LatticeBestPath(int argc, char *argv[], const char *log_path);
+int vb_ComputeWer(int argc, char *argv[], const char *log_path);
+void vb_ComputeWerCounts(long long *out8);   // {word_errs, num_words, ins, del, sub, num_sent, sent_errs, absent} of the last ComputeWer
 int vb_set_device(int device_id);   // GPU used by the calling thread's subsequent calls (default 0)
 }
 
