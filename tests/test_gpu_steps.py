@@ -20,6 +20,8 @@ def host():
     lib = C.CDLL(build.HOST_LIB)
     lib.vb_steps_last_error.restype = C.c_char_p
     lib.vb_Decode.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_float, C.c_int, C.c_double, C.c_double, C.c_int]
+    lib.vb_DecodeEx.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_float, C.c_int, C.c_double, C.c_double,
+                                C.c_int, C.c_char_p, C.c_int, C.c_int]
     return lib
 
 
@@ -87,9 +89,9 @@ def test_make_mfcc_cmvn_and_decode_steps(host, tmp_path):
     (exp / "final.mdl").write_bytes(g["file_final_mdl"].tobytes())
     (graph / "HCLG.fst").write_bytes(g["file_HCLG_fst"].tobytes())
     dec = exp / "decode_test"
-    # scoring is not part of this build: refused unless switched off
+    # scoring needs data/text and graph/words.txt: without them it is an error, not a silent skip
     assert host.vb_Decode(str(graph).encode(), str(data).encode(), str(dec).encode(), b"", 2, 0.083333, 7000, 13.0, 6.0, 0) == -1
-    assert b"scoring" in host.vb_steps_last_error()
+    assert b"text" in host.vb_steps_last_error()
     rc = host.vb_Decode(str(graph).encode(), str(data).encode(), str(dec).encode(), b"", 2, 0.083333, 7000, 13.0, 6.0, 1)
     assert rc == 0, host.vb_steps_last_error()
     assert (dec / "num_jobs").read_text().strip() == "2"
@@ -101,3 +103,96 @@ def test_make_mfcc_cmvn_and_decode_steps(host, tmp_path):
             ref("lattice-copy", "ark:%s" % (dec / ("lat.%d" % j)), "ark,t:%s" % (d / ("lat%d.txt" % j)))
         got = (d / "lat1.txt").read_text() + (d / "lat2.txt").read_text()
         assert all(u in got for u in utts)
+
+
+def test_decode_with_fmllr_transforms_and_scoring(host, tmp_path):
+    """Decode(..., trans_dir) -- the reference's "decode a SAT model with supplied fMLLR transforms"
+    path (VB/scr/steps/decode_gmm.cpp:127-172,243-267; config 3 of SURVEY.md 8d) -- followed by its
+    scoring (ScoreKaldiWER): determinized lattices, words, transcripts, one WER file per
+    (LM weight, word insertion penalty), the best of them recorded."""
+    from tests import util
+    from tests.test_host_lattice import assert_same_archives
+    from voicebridge_amd import synth
+    d = tmp_path
+    data, conf, utts = make_datadir(d, n_utt=6, n_spk=3)
+    assert host.vb_MakeMfcc(str(data).encode(), str(conf).encode(), 2, 1, 0) == 0, host.vb_steps_last_error()
+    assert host.vb_ComputeCmvnStatsDir(str(data).encode()) == 0
+    # model + lexicon graph with words; words.txt
+    H, n_cd, n_words = 3, 10, 30
+    P = n_cd * H
+    g, _ = synth.lexicon_graph(n_words, P, seed=3, n_phones=n_cd)
+    offs, w, means, iv = synth.gmm_model(P, P * 3, 39, seed=4, mean_scale=1.5, var_spread=0.3)
+    exp = d / "exp" / "tri3"
+    graph = exp / "graph"
+    graph.mkdir(parents=True)
+    util.write_mdl(str(exp / "final.mdl"), n_cd, H, offs, w, (means * iv).astype(np.float32), iv)
+    util.write_vector_fst(str(graph / "HCLG.fst"), g["final"], g["arc_offset"], g["arcs"])
+    (graph / "words.txt").write_text("<eps> 0\n" + "".join("w%d %d\n" % (i, i) for i in range(1, n_words + 2)))
+    # per-speaker fMLLR transforms written by an "earlier pass" that ran with ONE job (the decode runs with two)
+    trans = d / "exp" / "tri3" / "decode_si"
+    trans.mkdir()
+    (trans / "num_jobs").write_text("1\n")
+    with open(trans / "trans.1", "wb") as f:
+        for k in range(3):
+            m = synth.affine(39, seed=10 + k)
+            f.write(b"spk%d \0BFM " % k + bytes([4]) + np.int32(39).tobytes() + bytes([4]) + np.int32(40).tobytes() + m.astype("<f4").tobytes())
+    dec = exp / "decode_test"
+    args = [str(graph).encode(), str(data).encode(), str(dec).encode(), b"", str(trans).encode(), 2, 0.083333, 7000, 13.0, 6.0]
+    # first without scoring (no data/text yet): lattices, words, transcripts
+    assert host.vb_DecodeEx(*args, 1, b"0.0,0.5", 8, 10) == 0, host.vb_steps_last_error()
+    lats = {}
+    for j in (1, 2):
+        lats.update(util.read_lattice_ark(str(dec / ("lat.%d" % j))))
+        assert (dec / ("transcription%d.trn" % j)).exists()
+    assert sorted(lats) == utts and all(v[0] == "compactlattice44" for v in lats.values())
+    words = dict(l.split(None, 1) if " " in l.strip() else (l.strip(), "") for j in (1, 2) for l in (dec / ("w.%d" % j)).read_text().split("\n") if l.strip())
+    trn = dict(l.split(None, 1) if " " in l.strip() else (l.strip(), "") for j in (1, 2) for l in (dec / ("transcription%d.trn" % j)).read_text().split("\n") if l.strip())
+    for u in utts:
+        assert [("w" + x) for x in words[u].split()] == trn[u].split()
+    # the same features by hand through the bin functions give the same lattices (transforms really applied per speaker)
+    sd = data / "split2" / "1"
+    log = str(d / "hand.log")
+    assert call(host.vb_ApplyCmvn, ["apply-cmvn", "--utt2spk=ark:%s" % (sd / "utt2spk"), "scp:%s" % (sd / "cmvn.scp"), "scp:%s" % (sd / "feats.scp"), "ark:%s" % (d / "c.ark")], log) == 0
+    assert call(host.vb_AddDeltas, ["add-deltas", "ark:%s" % (d / "c.ark"), "ark:%s" % (d / "dl.ark")]) == 0
+    assert call(host.vb_TransformFeats, ["transform-feats", "--utt2spk=ark:%s" % (sd / "utt2spk"), "ark:%s" % (trans / "trans.1"), "ark:%s" % (d / "dl.ark"), "ark:%s" % (d / "tf.ark")], log) == 0
+    assert call(host.vb_GmmLatgenFaster, ["gmm-latgen-faster", "--max-active=7000", "--beam=13.000000", "--lattice-beam=6.000000", "--acoustic-scale=0.083333",
+                                          "--allow-partial=true", str(exp / "final.mdl"), str(graph / "HCLG.fst"), "ark:%s" % (d / "tf.ark"), "ark:%s" % (d / "hand.lat")], log) == 0
+    assert_same_archives(str(d / "hand.lat"), str(dec / "lat.1"))
+    untransformed = d / "untr.lat"
+    assert call(host.vb_GmmLatgenFaster, ["gmm-latgen-faster", "--max-active=7000", "--beam=13.000000", "--lattice-beam=6.000000", "--acoustic-scale=0.083333",
+                                          "--allow-partial=true", str(exp / "final.mdl"), str(graph / "HCLG.fst"), "ark:%s" % (d / "dl.ark"), "ark:%s" % untransformed], log) == 0
+    assert util.read_lattice_ark(str(untransformed)) != util.read_lattice_ark(str(dec / "lat.1"))
+    # ---- now with scoring: reference text = the hypotheses with two edits
+    lines = []
+    for i, u in enumerate(utts):
+        ws = trn[u].split()
+        if i == 0:
+            ws = ws[1:]
+        if i == 1:
+            ws = ws + ["w1"]
+        lines.append(" ".join([u] + ws))
+    (data / "text").write_text("\n".join(lines) + "\n")
+    assert host.vb_DecodeEx(*args, 0, b"0.0,0.5", 8, 10) == 0, host.vb_steps_last_error()
+    for wip in ("0.0", "0.5"):
+        for lmwt in (8, 9, 10):
+            f = (dec / ("wer_%d_%s" % (lmwt, wip))).read_text().split()
+            assert len(f) == 9 and int(f[8]) == len(utts)
+            assert (dec / "scoring_kaldi" / ("penalty_" + wip) / ("%d.txt" % lmwt)).exists()
+    best = (dec / "scoring_kaldi" / "best_wer").read_text().split()
+    assert (dec / "scoring_kaldi" / "wer_details" / "lmwt").read_text().strip() in ("8", "9", "10")
+    assert float(best[6]) == min(float((dec / ("wer_%d_%s" % (l, w))).read_text().split()[6]) for w in ("0.0", "0.5") for l in (8, 9, 10))
+    # one (LMWT, penalty) pair by hand through the bin functions: same hypotheses
+    with open(d / "all.lat", "wb") as f:
+        f.write((dec / "lat.1").read_bytes() + (dec / "lat.2").read_bytes())
+    assert call(host.vb_LatticeScale, ["lattice-scale", "--inv-acoustic-scale=9", "ark:%s" % (d / "all.lat"), "ark:%s" % (d / "s.lat")], log) == 0
+    assert call(host.vb_LatticeAddPenalty, ["lattice-add-penalty", "--word-ins-penalty=0.5", "ark:%s" % (d / "s.lat"), "ark:%s" % (d / "p.lat")], log) == 0
+    assert call(host.vb_LatticeBestPath, ["lattice-best-path", "ark:%s" % (d / "p.lat"), "ark,t:%s" % (d / "bp.txt")], log) == 0
+    hand = {l.split()[0]: ["w" + x for x in l.split()[1:]] for l in (d / "bp.txt").read_text().split("\n") if l.strip()}
+    got = {l.split()[0]: l.split()[1:] for l in (dec / "scoring_kaldi" / "penalty_0.5" / "9.txt").read_text().split("\n") if l.strip()}
+    assert hand == got
+    if have_ref("lattice-scale") and have_ref("lattice-best-path") and have_ref("lattice-add-penalty"):
+        # and through the reference's own programs on the lattices this build wrote
+        ref("lattice-scale", "--inv-acoustic-scale=9", "ark:%s" % (d / "all.lat"), "ark:%s" % (d / "rs.lat"))
+        ref("lattice-add-penalty", "--word-ins-penalty=0.5", "ark:%s" % (d / "rs.lat"), "ark:%s" % (d / "rp.lat"))
+        ref("lattice-best-path", "ark:%s" % (d / "rp.lat"), "ark,t:%s" % (d / "rbp.txt"))
+        assert (d / "rbp.txt").read_text().split() == (d / "bp.txt").read_text().split()

@@ -176,3 +176,34 @@ def test_fresh_cases_vs_reference_programs(host, tmp_path, seed, n_words, n_cd, 
         assert_same_archives(str(d / ("m_" + fn)), str(d / fn))
     assert (d / "m_best_words.txt").read_text().split() == (d / "best_words.txt").read_text().split()
     assert (d / "m_best_ali.txt").read_text().split() == (d / "best_ali.txt").read_text().split()
+
+
+def test_score_kaldi_wer_on_golden_lattices(host, tmp_path):
+    """ScoreKaldiWER (VB/scr/steps/scoring/score_kaldi_wer.cpp) over a decode directory holding the
+    reference's determinized lattices: the hypotheses for (LMWT 9, penalty 0.5) are the reference's
+    lattice-scale | lattice-add-penalty | lattice-best-path output, the WER file holds the counts
+    of the reference's compute-wer on them."""
+    d = tmp_path
+    unpack_golden(d)
+    dec = d / "exp" / "decode"
+    dec.mkdir(parents=True)
+    (dec / "lat.1").write_bytes((d / "det_pp.ark").read_bytes())
+    (dec / "num_jobs").write_text("1\n")
+    graph = d / "graph"
+    graph.mkdir()
+    (graph / "words.txt").write_text("<eps> 0\n" + "".join("%d %d\n" % (i, i) for i in range(1, 1000)))   # identity: symbols are the ids
+    data = d / "data"
+    data.mkdir()
+    (data / "text").write_text((d / "ref_text.txt").read_text())
+    host.vb_steps_last_error.restype = C.c_char_p
+    rc = host.vb_ScoreKaldiWER(str(data).encode(), str(graph).encode(), str(dec).encode(), 2, b"0.0, 0.5", 8, 10)
+    assert rc == 0, host.vb_steps_last_error()
+    got = (dec / "scoring_kaldi" / "penalty_0.5" / "9.txt").read_text().split()
+    assert got == (d / "best_words.txt").read_text().split()
+    # "%WER 50.00 [ 3 / 6, 1 ins, 2 del, 0 sub ]", "%SER 66.67 [ 2 / 3 ]" in the reference's one-line form
+    assert (dec / "wer_9_0.5").read_text().split() == ["50.00", "3", "6", "1", "2", "0", "66.67", "2", "3"]
+    assert len(list(dec.glob("wer_*"))) == 6
+    assert (dec / "scoring_kaldi" / "wer_details" / "wip").read_text().strip() in ("0.0", "0.5")
+    # a missing lattice file is an error
+    os.remove(dec / "lat.1")
+    assert host.vb_ScoreKaldiWER(str(data).encode(), str(graph).encode(), str(dec).encode(), 2, b"0.0", 8, 8) == -1

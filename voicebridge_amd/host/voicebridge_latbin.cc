@@ -268,7 +268,9 @@ int ComputeWer(int argc, char *argv[], std::ofstream &file_log) {
     Options po;
     po.Know({"mode", "text"});
     po.Parse(argc, argv);
-    if (po.args.size() != 2) throw ApiError("Wrong arguments.");
+    // upstream: <ref> <hyp>; the reference's wrapper adds a third argument, the file the counts are
+    // written to (VB/src/bin/compute-wer.cpp:65,141-157), which BestWer reads back
+    if (po.args.size() != 2 && po.args.size() != 3) throw ApiError("Wrong arguments.");
     const std::string mode = po.Str("mode", "strict");
     if (mode != "strict" && mode != "present" && mode != "all")
       throw ApiError("--mode option invalid: expected \"present\"|\"all\"|\"strict\", got " + mode);
@@ -299,6 +301,14 @@ int ComputeWer(int argc, char *argv[], std::ofstream &file_log) {
     o << "%SER " << std::fixed << ser << " [ " << sent_errs << " / " << num_sent << " ]\n";
     o << "Scored " << num_sent << " sentences, " << num_absent << " not present in hyp.\n";
     log.os() << o.str();
+    if (po.args.size() == 3 && !po.args[2].empty()) {
+      std::ofstream f(po.args[2], std::ios::binary);
+      if (!f) throw ApiError("Output file is not accessible " + po.args[2] + ".");
+      f << std::fixed;
+      f.precision(2);
+      f << wer << " " << word_errs << " " << num_words << " " << num_ins << " " << num_del << " " << num_sub << " " << ser << " " << sent_errs << " "
+        << num_sent << '\n';
+    }
     const long long c[8] = {word_errs, num_words, num_ins, num_del, num_sub, num_sent, sent_errs, num_absent};
     for (int i = 0; i < 8; i++) g_wer[i] = c[i];
     return 0;

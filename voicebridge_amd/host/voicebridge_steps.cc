@@ -7,13 +7,18 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <fstream>
 #include <map>
+#include <regex>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
+#include "kaldi_io.h"
+#include "lattice.h"
 #include "voicebridge_api.h"
 
 namespace {
@@ -90,6 +95,31 @@ std::vector<std::vector<std::string>> SplitLines(const std::vector<std::string> 
     pos += len;
   }
   return out;
+}
+
+// words.txt: "symbol id" per line
+std::map<int, std::string> ReadSymbolTable(const std::string &path) {
+  std::map<int, std::string> m;
+  for (const auto &l : ReadLines(path)) { std::istringstream is(l); std::string w; int id; if (is >> w >> id) m[id] = w; }
+  return m;
+}
+// int2sym.pl -f 2-: every field after the key through the table (VB/scr/utils/int2sym.cpp)
+std::string Int2SymLine(const std::map<int, std::string> &sym, const std::string &line) {
+  std::istringstream is(line);
+  std::string key, tok, out;
+  is >> key;
+  out = key;
+  while (is >> tok) {
+    const auto it = sym.find(atoi(tok.c_str()));
+    if (it == sym.end()) throw StepError("Word-id " + tok + " not in symbol table.");
+    out += " " + it->second;
+  }
+  return out;
+}
+// FilterFile (VB/scr/utils/...): every (regex -> replacement) of the map applied to the line
+std::string FilterLine(std::string line, const UMAPSS &filter) {
+  for (const auto &kv : filter) line = std::regex_replace(line, std::regex(kv.first), kv.second);
+  return line;
 }
 
 template <class F>
@@ -233,12 +263,32 @@ int SplitData(const std::string &data, int numsplit, bool per_utt) {
 
 // ------------------------------------------------------------------------------------ Decode
 int Decode(const std::string &graph_dir, const std::string &data_dir, const std::string &decode_dir, const std::string &model_in,
-           const std::string &trans_dir, UMAPSS &, UMAPSS &, const std::string &iter, int nj, float acwt, int stage, int max_active,
-           double beam, double lattice_beam, bool skip_scoring) {
-  return Run([&] {
-    if (!skip_scoring) throw StepError("scoring is not part of this build: call Decode with skip_scoring = true");
-    if (!trans_dir.empty()) throw StepError("supplying fMLLR transforms (trans_dir) goes through DecodeFmllr, which is not part of this build");
+           const std::string &trans_dir, UMAPSS &wer_ref_filter, UMAPSS &wer_hyp_filter, const std::string &iter, int nj, float acwt,
+           int stage, int max_active, double beam, double lattice_beam, bool skip_scoring, bool decode_mbr, bool stats,
+           const std::string &word_ins_penalty, int min_lmwt, int max_lmwt) {
+  const int rc_decode = Run([&] {
+    if (decode_mbr) throw StepError("MBR decoding (decode_mbr) is not part of this build");
     if (nj < 1) throw StepError("nj must be >= 1");
+    // fMLLR transforms of an earlier pass (decode_gmm.cpp:127-172): one archive per job when the job
+    // counts agree, otherwise all of them joined (binary archives concatenate)
+    std::string trans_all;
+    const bool use_trans = !trans_dir.empty() && Exists(trans_dir);
+    if (use_trans) {
+      if (!Exists(Join(trans_dir, "trans.1"))) throw StepError("Expected " + Join(trans_dir, "trans.1") + " to exist.");
+      const int nj_orig = atoi(FirstLine(Join(trans_dir, "num_jobs")).c_str());
+      if (nj_orig < 1) throw StepError("Could not read number of jobs from file " + Join(trans_dir, "num_jobs") + ".");
+      if (nj_orig != nj) {
+        MakeDirs(decode_dir);
+        trans_all = Join(decode_dir, "trans.ark");
+        std::ofstream out(trans_all, std::ios::binary);
+        if (!out) throw StepError("cannot write " + trans_all);
+        for (int n = 1; n <= nj_orig; n++) {
+          std::ifstream in(Join(trans_dir, "trans." + std::to_string(n)), std::ios::binary);
+          if (!in) throw StepError(Join(trans_dir, "trans." + std::to_string(n)) + " is required but can not be found.");
+          out << in.rdbuf();
+        }
+      }
+    }
     (void)stage;
     const std::string srcdir = Parent(decode_dir);                  // the model directory (decode_gmm.cpp:80)
     std::string model = model_in;
@@ -281,15 +331,140 @@ int Decode(const std::string &graph_dir, const std::string &data_dir, const std:
         if (TransformFeats(a3.argc(), a3.argv(), log) < 0) throw StepError("transform-feats failed for job " + J);
         unlink(t_spl.c_str());
       }
+      std::string t_in = t_feat;
+      const std::string t_trans = Join(dsn, "transformfeats_trans.temp");
+      if (use_trans) {       // decode_gmm.cpp:243-267
+        Argv a5({"transform-feats", "--utt2spk=ark:" + Join(dsn, "utt2spk"), "ark:" + (trans_all.empty() ? Join(trans_dir, "trans." + J) : trans_all),
+                 "ark:" + t_feat, "ark:" + t_trans});
+        if (TransformFeats(a5.argc(), a5.argv(), log) < 0) throw StepError("transform-feats (fMLLR) failed for job " + J);
+        t_in = t_trans;
+      }
       std::vector<std::string> g = {"gmm-latgen-faster", "--max-active=" + std::to_string(max_active), "--beam=" + std::to_string(beam),
                                     "--lattice-beam=" + std::to_string(lattice_beam), "--acoustic-scale=" + std::to_string(acwt),
-                                    "--allow-partial=true", "--determinize-lattice=false"};
-      if (Exists(Join(graph_dir, "words.txt"))) g.push_back("--word-symbol-table=" + Join(graph_dir, "words.txt"));
-      g.push_back(model); g.push_back(Join(graph_dir, "HCLG.fst")); g.push_back("ark:" + t_feat); g.push_back("ark:" + Join(decode_dir, "lat." + J));
+                                    "--allow-partial=true"};
+      const std::string symtab = Join(graph_dir, "words.txt");
+      if (Exists(symtab)) g.push_back("--word-symbol-table=" + symtab);
+      g.push_back(model); g.push_back(Join(graph_dir, "HCLG.fst")); g.push_back("ark:" + t_in); g.push_back("ark:" + Join(decode_dir, "lat." + J));
+      g.push_back("ark,t:" + Join(decode_dir, "w." + J));
       Argv a4(g);
       const int rc = GmmLatgenFaster(a4.argc(), a4.argv(), log);
-      unlink(t_cmvn.c_str()); unlink(t_feat.c_str());
+      unlink(t_cmvn.c_str()); unlink(t_feat.c_str()); unlink(t_trans.c_str());
       if (rc < 0) throw StepError("gmm-latgen-faster failed for job " + J + ", see " + Join(decode_dir, "log"));
+      // transcriptionJOB.trn: the words of w.JOB through the symbol table (decode_gmm.cpp:356-376)
+      if (Exists(symtab)) {
+        const std::map<int, std::string> sym = ReadSymbolTable(symtab);
+        std::vector<std::string> out;
+        for (const auto &l : ReadLines(Join(decode_dir, "w." + J), false)) out.push_back(Int2SymLine(sym, l));
+        WriteLines(Join(decode_dir, "transcription" + J + ".trn"), out);
+      }
+    }
+    if (!trans_all.empty()) unlink(trans_all.c_str());
+  });
+  if (rc_decode != 0 || skip_scoring) return rc_decode;
+  if (!Exists(Join(data_dir, "text"))) { g_err = "Not scoring because " + Join(data_dir, "text") + " is missing"; return -1; }
+  return ScoreKaldiWER(data_dir, graph_dir, decode_dir, wer_ref_filter, wer_hyp_filter, nj, 0, decode_mbr, stats, lattice_beam, word_ins_penalty,
+                       min_lmwt, max_lmwt, iter.empty() ? "final" : iter);
+}
+
+// ------------------------------------------------------------------------------------ ScoreKaldiWER
+// VB/scr/steps/scoring/score_kaldi_wer.cpp:36-254 (+ :256-420 the per-LMWT job, VB/scr/utils/best_wer.cpp).
+// The lattices are read once; every (word insertion penalty, LM weight) pair scales, penalises and
+// takes the best path in memory (lattice-scale --inv-acoustic-scale=LMWT | lattice-add-penalty |
+// lattice-best-path), on as many host threads as there are pairs (at most nj x 4).
+int ScoreKaldiWER(const std::string &data, const std::string &lang_or_graph, const std::string &dir, UMAPSS &wer_ref_filter,
+                  UMAPSS &wer_hyp_filter, int nj, int stage, bool decode_mbr, bool stats, double beam, const std::string &word_ins_penalty,
+                  int min_lmwt, int max_lmwt, const std::string &iter) {
+  return Run([&] {
+    (void)beam; (void)iter;
+    if (decode_mbr) throw StepError("MBR decoding (decode_mbr) is not part of this build");
+    const std::string symtab = Join(lang_or_graph, "words.txt");
+    for (const std::string &f : {symtab, Join(dir, "lat.1"), Join(data, "text")})
+      if (!Exists(f)) throw StepError(f + " is required but can not be found.");
+    if (min_lmwt > max_lmwt) throw StepError("min_lmwt > max_lmwt");
+    const std::string sk = Join(dir, "scoring_kaldi");
+    MakeDirs(sk); MakeDir(Join(sk, "log"));
+    std::ofstream slog(Join(Join(sk, "log"), "score.log"), std::ios::binary);
+    // reference transcripts through the caller's filter
+    std::vector<std::string> ref_lines;
+    for (const auto &l : ReadLines(Join(data, "text"))) ref_lines.push_back(FilterLine(l, wer_ref_filter));
+    WriteLines(Join(sk, "test_filt.txt"), ref_lines);
+    std::vector<std::string> wips;
+    { std::string w; std::istringstream is(word_ins_penalty); while (std::getline(is, w, ',')) { w.erase(0, w.find_first_not_of(" \t")); w.erase(w.find_last_not_of(" \t") + 1); if (!w.empty()) wips.push_back(w); } }
+    if (wips.empty()) throw StepError("no word insertion penalty given");
+    if (stage <= 0) {
+      // all lat.* of the directory, in job order
+      const int njobs = std::max(1, atoi(FirstLine(Join(dir, "num_jobs")).c_str()));
+      std::vector<std::pair<std::string, vblat::CompactLattice>> lats;
+      for (int j = 1; j <= njobs; j++) {
+        const std::string f = Join(dir, "lat." + std::to_string(j));
+        if (!Exists(f)) continue;
+        vbio::LatticeReader reader("ark:" + f);
+        std::string key; vblat::CompactLattice clat;
+        while (reader.NextCompact(&key, &clat)) lats.emplace_back(key, std::move(clat));
+      }
+      if (lats.empty()) throw StepError("Could not find lat.* in " + dir);
+      const std::map<int, std::string> sym = ReadSymbolTable(symtab);
+      struct Job { std::string wip; int lmwt; std::string err; };
+      std::vector<Job> jobs;
+      for (const auto &w : wips) { MakeDirs(Join(Join(sk, "penalty_" + w), "log")); for (int l = min_lmwt; l <= max_lmwt; l++) jobs.push_back(Job{w, l, ""}); }
+      std::atomic<size_t> next{0};
+      auto work = [&]() {
+        for (size_t i = next++; i < jobs.size(); i = next++) {
+          Job &jb = jobs[i];
+          try {
+            const float inv_acoustic_scale = (float)jb.lmwt, acoustic_scale = (float)(1.0 / inv_acoustic_scale);     // lattice-scale.cc:70-80
+            const float pen = (float)atof(jb.wip.c_str());
+            std::vector<std::string> hyp;
+            std::ofstream jlog(Join(Join(Join(sk, "penalty_" + jb.wip), "log"), "LMWT." + std::to_string(jb.lmwt) + ".log"), std::ios::binary);
+            for (const auto &kv : lats) {
+              vblat::CompactLattice c = kv.second;
+              vblat::ScaleLattice(1.0, 0.0, 0.0, (double)acoustic_scale, &c);
+              vblat::AddWordInsPen(pen, &c);
+              vblat::CompactLattice best;
+              vblat::CompactLatticeShortestPath(c, &best);
+              if (best.start < 0) { jlog << "WARNING (lattice-best-path) Best-path failed for key " << kv.first << "\n"; continue; }
+              std::vector<int32_t> words; vblat::Weight w;
+              if (!vblat::GetLinearSymbolSequence(best, nullptr, &words, &w)) throw StepError("best path of " + kv.first + " is not linear");
+              jlog << "LOG (lattice-best-path) For utterance " << kv.first << ", best cost " << w.v1 << " + " << w.v2 << " = " << (w.v1 + w.v2) << "\n";
+              std::string line = kv.first;
+              for (int32_t x : words) line += " " + std::to_string(x);
+              hyp.push_back(FilterLine(Int2SymLine(sym, line), wer_hyp_filter));
+            }
+            const std::string hyp_file = Join(Join(sk, "penalty_" + jb.wip), std::to_string(jb.lmwt) + ".txt");
+            WriteLines(hyp_file, hyp);
+            Argv a({"compute-wer", "--mode=present", "ark:" + Join(sk, "test_filt.txt"), "ark,p:" + hyp_file,
+                    Join(dir, "wer_" + std::to_string(jb.lmwt) + "_" + jb.wip)});
+            if (ComputeWer(a.argc(), a.argv(), jlog) < 0) throw StepError("compute-wer failed, see " + Join(Join(sk, "penalty_" + jb.wip), "log"));
+          } catch (const std::exception &e) { jb.err = e.what(); }
+        }
+      };
+      const unsigned nt = std::max(1u, std::min((unsigned)jobs.size(), std::min((unsigned)std::max(nj, 1) * 4u, std::max(1u, std::thread::hardware_concurrency()))));
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+      work();
+      for (std::thread &t : pool) t.join();
+      for (const Job &jb : jobs) if (!jb.err.empty()) throw StepError("scoring LMWT " + std::to_string(jb.lmwt) + " penalty " + jb.wip + ": " + jb.err);
+    }
+    if (stage <= 1) {
+      // BestWer (VB/scr/utils/best_wer.cpp:25-71): smallest %SER, then smallest %WER, in the order wip-major / LMWT-minor
+      double best_ser = 0, best_wer = 0; std::string best_wip; int best_lmwt = -1; std::string best_line;
+      for (const auto &w : wips)
+        for (int l = min_lmwt; l <= max_lmwt; l++) {
+          const std::string f = Join(dir, "wer_" + std::to_string(l) + "_" + w);
+          const std::vector<std::string> fields = SplitWords(FirstLine(f));
+          if (fields.size() < 9) throw StepError("Could not read WER results from " + f);
+          const double pwer = atof(fields[0].c_str()), pser = atof(fields[6].c_str());
+          if (best_lmwt < 0 || pser < best_ser || (pser == best_ser && pwer < best_wer)) { best_ser = pser; best_wer = pwer; best_wip = w; best_lmwt = l; best_line = FirstLine(f); }
+        }
+      if (best_lmwt < 0) throw StepError("Could not determine best WER.");
+      slog << "Found the best WER/SER combination: WER=" << best_wer << "%, SER=" << best_ser << "% (LMWT " << best_lmwt << ", word insertion penalty " << best_wip << ")\n";
+      WriteLines(Join(sk, "best_wer"), {best_line + " " + Join(dir, "wer_" + std::to_string(best_lmwt) + "_" + best_wip)});
+      if (stats) {
+        MakeDir(Join(sk, "wer_details"));
+        WriteLines(Join(Join(sk, "wer_details"), "lmwt"), {std::to_string(best_lmwt)});
+        WriteLines(Join(Join(sk, "wer_details"), "wip"), {best_wip});
+        slog << "WARNING per-utterance alignment statistics (wer_details/per_utt, per_spk, ops, wer_bootci) are not produced by this build\n";
+      }
     }
   });
 }
@@ -304,6 +479,18 @@ int vb_Decode(const char *graph_dir, const char *data_dir, const char *decode_di
               double beam, double lattice_beam, int skip_scoring) {
   UMAPSS a, b;
   return Decode(graph_dir, data_dir, decode_dir, model ? model : "", "", a, b, "", nj, acwt, 0, max_active, beam, lattice_beam, skip_scoring != 0);
+}
+int vb_DecodeEx(const char *graph_dir, const char *data_dir, const char *decode_dir, const char *model, const char *trans_dir, int nj,
+                float acwt, int max_active, double beam, double lattice_beam, int skip_scoring, const char *word_ins_penalty,
+                int min_lmwt, int max_lmwt) {
+  UMAPSS a, b;
+  return Decode(graph_dir, data_dir, decode_dir, model ? model : "", trans_dir ? trans_dir : "", a, b, "", nj, acwt, 0, max_active, beam, lattice_beam,
+                skip_scoring != 0, false, true, word_ins_penalty ? word_ins_penalty : "0.0,0.5,1.0", min_lmwt, max_lmwt);
+}
+int vb_ScoreKaldiWER(const char *data, const char *lang_or_graph, const char *dir, int nj, const char *word_ins_penalty, int min_lmwt,
+                     int max_lmwt) {
+  UMAPSS a, b;
+  return ScoreKaldiWER(data, lang_or_graph, dir, a, b, nj, 0, false, true, 6.0, word_ins_penalty ? word_ins_penalty : "0.0,0.5,1.0", min_lmwt, max_lmwt);
 }
 const char *vb_steps_last_error(void) { return g_err.c_str(); }
 }

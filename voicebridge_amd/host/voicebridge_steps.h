@@ -15,10 +15,20 @@
 // batches for one device here, not processes; the per-job file layout (JOB-numbered archives, logs,
 // split directories) is the reference's, so whatever consumes those directories keeps working.
 //
+//   scr/kaldi_scr.h:167-183  int ScoreKaldiWER(data, lang_or_graph, dir, wer filters, nj, stage, decode_mbr, stats, beam,
+//                                                word_ins_penalty, min_lmwt, max_lmwt, iter)  scr/steps/scoring/score_kaldi_wer.cpp:36-254
+// Decode writes what the reference's does: determinized lattices lat.JOB, words w.JOB, transcriptionJOB.trn (when
+// the graph directory has words.txt), and -- unless skip_scoring -- scores them: for every word insertion penalty
+// and LM weight the lattices are rescaled, penalised and their best path compared with data/text
+// (wer_LMWT_WIP files in the reference's "%WER errs words ins del sub %SER serrs sents" form,
+// scoring_kaldi/penalty_WIP/LMWT.txt hypotheses, scoring_kaldi/best_wer, wer_details/{lmwt,wip}).
+// Scoring works on the lattices in memory (one read, all LMWT x WIP combinations spread over host
+// threads) instead of the reference's 33 passes over temporary archives; the files it leaves are the same.
+//
 // Not part of this build, refused with an error rather than skipped: a `segments` file in MakeMfcc
-// (extract-segments), fake / two-channel / fake-dims CMVN, and in Decode everything after the
-// lattices -- scoring must be switched off with skip_scoring = true; lattices
-// are written raw (--determinize-lattice=false, §8f row 1).
+// (extract-segments), fake / two-channel / fake-dims CMVN, MBR decoding (decode_mbr).  With stats = true the
+// best LMWT/WIP are recorded, but the per-utterance alignment statistics (align-text, per_utt, per_spk, ops,
+// bootstrap confidence interval) are not produced; scoring_kaldi/log/score.log says so.
 #ifndef VOICEBRIDGE_STEPS_H_
 #define VOICEBRIDGE_STEPS_H_
 
@@ -34,7 +44,11 @@ int SplitData(const std::string &datadir, int numsplit, bool per_utt = false);
 int Decode(const std::string &graph_dir, const std::string &data_dir, const std::string &decode_dir, const std::string &model,
            const std::string &trans_dir, UMAPSS &wer_ref_filter, UMAPSS &wer_hyp_filter, const std::string &iter = "", int nj = 4,
            float acwt = 0.083333f, int stage = 0, int max_active = 7000, double beam = 13.0, double lattice_beam = 6.0,
-           bool skip_scoring = false);
+           bool skip_scoring = false, bool decode_mbr = false, bool stats = true, const std::string &word_ins_penalty = "0.0,0.5,1.0",
+           int min_lmwt = 7, int max_lmwt = 17);
+int ScoreKaldiWER(const std::string &data, const std::string &lang_or_graph, const std::string &dir, UMAPSS &wer_ref_filter,
+                  UMAPSS &wer_hyp_filter, int nj, int stage = 0, bool decode_mbr = false, bool stats = true, double beam = 6,
+                  const std::string &word_ins_penalty = "0.0,0.5,1.0", int min_lmwt = 7, int max_lmwt = 17, const std::string &iter = "final");
 
 // plain-C shims (ctypes, cgo ...); messages of the last failure: vb_steps_last_error()
 extern "C" {
@@ -43,6 +57,12 @@ int vb_ComputeCmvnStatsDir(const char *datadir);
 int vb_SplitData(const char *datadir, int numsplit, int per_utt);
 int vb_Decode(const char *graph_dir, const char *data_dir, const char *decode_dir, const char *model, int nj, float acwt,
               int max_active, double beam, double lattice_beam, int skip_scoring);
+// the full form: trans_dir ("" = none), word insertion penalties "a,b,c", LM weight range
+int vb_DecodeEx(const char *graph_dir, const char *data_dir, const char *decode_dir, const char *model, const char *trans_dir, int nj,
+                float acwt, int max_active, double beam, double lattice_beam, int skip_scoring, const char *word_ins_penalty,
+                int min_lmwt, int max_lmwt);
+int vb_ScoreKaldiWER(const char *data, const char *lang_or_graph, const char *dir, int nj, const char *word_ins_penalty, int min_lmwt,
+                     int max_lmwt);
 const char *vb_steps_last_error(void);
 }
 
