@@ -121,6 +121,38 @@ def cpu_baseline(args, waves, utt2spk, xforms, model, decode_setup):
                        % (n_utt, args.seconds, frames, ", lattice search" if decode_setup is not None else ""))
 
 
+def determinize_measurement(args, dec, T):
+    """The step after the search in the reference's Decode (gmm-latgen-faster determinizes every
+    utterance's lattice before writing it, K/decoder/decoder-wrappers.cc:262-284): host C++
+    (voicebridge_amd/host/lattice.cc) over the lattices of the last batch, on the host's cores.
+    Measured beside the GPU step, not inside it: the pipeline would hide it behind the next
+    batch's search as long as its rate stays above the search's."""
+    import ctypes as C
+    from voicebridge_amd import build
+    host = C.CDLL(build.HOST_LIB)
+    P = args.pdfs
+    # synth.lexicon_graph(): pdf p has the self-loop tid 2p+1 and the forward tid 2p+2; 3-state phones
+    n_tid = 2 * P
+    phone = np.zeros(n_tid + 1, np.int32); hmm = np.zeros(n_tid + 1, np.int32); sl = np.zeros(n_tid + 1, np.uint8)
+    for p_ in range(P):
+        for k_, tid in enumerate((2 * p_ + 1, 2 * p_ + 2)):
+            phone[tid] = p_ // 3 + 1; hmm[tid] = p_ % 3; sl[tid] = 1 - k_
+    threads = max(1, min(32, (os.cpu_count() or 1)))
+    out = (C.c_double * 6)()
+    host.vb_determinize_decoder_results.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                                    C.c_int, C.c_void_p]
+    rc = host.vb_determinize_decoder_results(dec.h, args.batch, 0, n_tid, phone.ctypes.data, hmm.ctypes.data, sl.ctypes.data,
+                                             C.c_float(args.lattice_beam), C.c_float(0.083333), threads, out)
+    if rc != 0:
+        return {"error": "vb_determinize_decoder_results failed"}
+    sec = out[0]
+    return {"what": "Connect + two-pass pruned determinization (phone level, word level) + un-scaling of the %d lattices of the last batch, "
+                    "host C++ on %d threads" % (args.batch, threads),
+            "seconds": sec, "utterances_per_s": args.batch / sec, "frames_per_s": T / sec, "threads": threads,
+            "raw_states_per_utt": out[1] / args.batch, "raw_arcs_per_utt": out[2] / args.batch,
+            "det_states_per_utt": out[3] / args.batch, "det_arcs_per_utt": out[4] / args.batch, "stopped_before_beam": int(out[5])}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -328,6 +360,17 @@ def main():
     dt = time.perf_counter() - t0
     for sl in fe_timed:
         feat_ms.append(ctx.timer_ms(sl)); gmm_ms.append(ctx.timer_ms(sl + 1))
+    # after the timed region: the GMM kernel alone on the whole chip (in the pipeline it shares the
+    # CUs with two search grids, so its in-pipeline duration says little about the kernel itself)
+    gmm_alone_ms = None
+    if depth > 1:
+        for _ in range(3):
+            ctx.timer_start(0)
+            gmm.loglikes(ring[0][1], out=ring[0][2])
+            ctx.timer_stop(0)
+            ctx.sync()
+            t_ = ctx.timer_ms(0)
+            gmm_alone_ms = t_ if gmm_alone_ms is None else min(gmm_alone_ms, t_)
     if dec is not None:
         dec = last_done[0].dec
         tl = np.array([dec.timeline(u) for u in range(args.batch)], np.int64)
@@ -375,6 +418,15 @@ def main():
                     "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f / (g_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                     "traffic": None, "kernel_ms": g_ms, "algorithmic_flops": f, "algorithmic_bytes": b,
                     "hbm_GBs": b / (g_ms * 1e-3) / 1e9, "hbm_frac": b / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if gmm_alone_ms is not None:
+            gmm_roof["in_pipeline_ms"] = g_ms
+            gmm_roof["note"] = ("kernel alone on the chip, HIP events on its stream, best of 3 after the timed region; in_pipeline_ms is its "
+                                "duration inside the timed region, where it runs beside two search grids on the CUs they leave free")
+            for k_, v_ in (("achieved", f / (gmm_alone_ms * 1e-3) / 1e12), ("kernel_ms", gmm_alone_ms),
+                           ("hbm_GBs", b / (gmm_alone_ms * 1e-3) / 1e9)):
+                gmm_roof[k_] = v_
+            gmm_roof["frac"] = gmm_roof["achieved"] / F32_MFMA_PEAK_TFLOPS
+            gmm_roof["hbm_frac"] = gmm_roof["hbm_GBs"] / HBM_PEAK_GBS
         stage_ms = {"mfcc+featpost": float(np.mean(feat_ms)), "gmm": g_ms}
         roof = gmm_roof
         extra = {}
@@ -408,6 +460,7 @@ def main():
                                "frames_maxactive_bound": c["maxb"], "frames_minactive_bound": c["minb"],
                                "lattice_tokens_per_frame": c["lat_tok"] / T, "lattice_arcs_per_frame": c["lat_link"] / T,
                                "arc_expansions_per_s": c["arc"] / (k_ms * 1e-3)}
+            extra["lattice_stage_host"] = determinize_measurement(args, dec, T)
             if d_ms >= g_ms:
                 roof, extra["roofline_gmm"] = dec_roof, gmm_roof
             else:

@@ -70,7 +70,7 @@ def build_host(force=False, verbose=True):
                    os.path.join(hdir, "lattice.h"), os.path.join(hdir, "api_common.h"),
                    os.path.join(ROOT, "include", "voicebridge_hip.h"), LIB]
     if force or any(_newer(d, HOST_LIB) for d in deps):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + hdir,
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread", "-Wl,--no-undefined", "-I" + os.path.join(ROOT, "include"), "-I" + hdir,
                "-o", HOST_LIB] + srcs + ["-L" + LIBDIR, "-lvoicebridge_hip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), flush=True)

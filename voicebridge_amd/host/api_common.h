@@ -3,6 +3,7 @@
 #ifndef VOICEBRIDGE_API_COMMON_H_
 #define VOICEBRIDGE_API_COMMON_H_
 
+#include <cstdint>
 #include <cstdlib>
 #include <fstream>
 #include <initializer_list>
@@ -100,4 +101,9 @@ int WithLog(const char *log_path, F f) {
 }
 
 }  // namespace vbapi
+
+// the raw lattice of a search result (defined in voicebridge_api.cc)
+struct vbh_lattice;
+namespace vblat { struct Lattice; }
+namespace vbapi { void RawLatticeFromResult(const vbh_lattice &L, int32_t graph_start, vblat::Lattice *lat); }
 #endif

@@ -12,6 +12,8 @@
 #include <limits>
 #include <map>
 #include <atomic>
+#include <chrono>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -126,6 +128,24 @@ int WindowType(const std::string &s) {
 }  // namespace
 
 // =====================================================================================
+// GetRawLattice (K/decoder/lattice-faster-decoder.cc:110-192) from a search result: one state per
+// token (state 0 = the start token), arc weights (graph, acoustic - cost_offset), acoustic costs
+// still scaled, final weights (final cost, 0)
+void vbapi::RawLatticeFromResult(const vbh_lattice &L, int32_t graph_start, vblat::Lattice *lat) {
+  const int n = L.num_toks;
+  // tokens are sorted by (frame, HCLG state); the start token must become state 0
+  std::vector<int32_t> remap(n);
+  int start_idx = 0;
+  for (int i = 0; i < n && L.tok_frame[i] == 0; i++) if (L.tok_state[i] == graph_start) start_idx = i;
+  for (int i = 0; i < n; i++) remap[i] = i == start_idx ? 0 : (i < start_idx ? i + 1 : i);
+  lat->st.assign(n, vblat::State());
+  lat->start = n ? 0 : -1;
+  for (int i = 0; i < n; i++) if (!std::isinf(L.tok_final[i])) lat->st[remap[i]].final = vblat::Weight{L.tok_final[i], 0.0f};
+  for (int l = 0; l < L.num_links; l++)
+    lat->st[remap[L.link_src[l]]].arcs.push_back(vblat::Arc{L.link_ilabel[l], L.link_olabel[l], vblat::Weight{L.link_graph[l], L.link_acoustic[l]},
+                                                            remap[L.link_dst[l]]});
+}
+
 // compute-mfcc-feats   (VB/src/featbin/compute-mfcc-feats.cpp:21-198)
 int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
   return Guard("compute-mfcc-feats", &file_log, [&](Log &log) -> int {
@@ -519,20 +539,7 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
       std::vector<vbh_lattice> Ls(nu);
       for (size_t u = 0; u < nu; u++) Check(vbh_decoder_result(dec, (int32_t)u, &Ls[u]), "vbh_decoder_result");
       auto usable = [&](const vbh_lattice &L) { return L.ok && (L.reached_final || allow_partial); };
-      auto raw_lattice = [&](const vbh_lattice &L, vblat::Lattice *lat) {
-        const int n = L.num_toks;
-        // tokens are sorted by (frame, HCLG state); the start token must become state 0
-        std::vector<int32_t> remap(n);
-        int start_idx = 0;
-        for (int i = 0; i < n && L.tok_frame[i] == 0; i++) if (L.tok_state[i] == graph.start) start_idx = i;
-        for (int i = 0; i < n; i++) remap[i] = i == start_idx ? 0 : (i < start_idx ? i + 1 : i);
-        lat->st.assign(n, vblat::State());
-        lat->start = n ? 0 : -1;
-        for (int i = 0; i < n; i++) if (!std::isinf(L.tok_final[i])) lat->st[remap[i]].final = vblat::Weight{L.tok_final[i], 0.0f};
-        for (int l = 0; l < L.num_links; l++)
-          lat->st[remap[L.link_src[l]]].arcs.push_back(vblat::Arc{L.link_ilabel[l], L.link_olabel[l], vblat::Weight{L.link_graph[l], L.link_acoustic[l]},
-                                                                  remap[L.link_dst[l]]});
-      };
+      auto raw_lattice = [&](const vbh_lattice &L, vblat::Lattice *lat) { RawLatticeFromResult(L, graph.start, lat); };
       // "We'll write the lattice without acoustic scaling" (decoder-wrappers.cc:268-284)
       const double inv = cfg.acoustic_scale != 0.0f ? 1.0 / (double)cfg.acoustic_scale : 1.0;
       // determinization (DeterminizeLatticePhonePrunedWrapper, decoder-wrappers.cc:262-275) is host
@@ -733,6 +740,50 @@ namespace {
 }  // namespace
 
 extern "C" {
+// Measurement hook (bench.py): determinize the lattices of the decoder's last batch exactly as
+// GmmLatgenFaster does per utterance (Connect, DeterminizeLatticePhonePrunedWrapper, un-scaling),
+// on `threads` host threads.  out6 = {seconds, input states, input arcs, output states, output arcs,
+// utterances whose determinization stopped before the beam}.
+int vb_determinize_decoder_results(void *decoder, int n_utt, int graph_start, int num_tids, const int32_t *tid_phone,
+                                   const int32_t *tid_hmm_state, const uint8_t *tid_self_loop, float lattice_beam, float acoustic_scale,
+                                   int threads, double *out6) {
+  try {
+    vblat::TransInfo tm;
+    tm.phone.assign(tid_phone, tid_phone + num_tids + 1);
+    tm.hmm_state.assign(tid_hmm_state, tid_hmm_state + num_tids + 1);
+    tm.self_loop.assign(tid_self_loop, tid_self_loop + num_tids + 1);
+    std::vector<vbh_lattice> Ls(n_utt);
+    for (int u = 0; u < n_utt; u++) Check(vbh_decoder_result((vbh_decoder *)decoder, u, &Ls[u]), "vbh_decoder_result");
+    std::atomic<int> next{0};
+    std::atomic<long long> in_s{0}, in_a{0}, out_s{0}, out_a{0}, early{0};
+    std::string err;
+    std::mutex mu;
+    const double inv = acoustic_scale != 0.0f ? 1.0 / (double)acoustic_scale : 1.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto work = [&]() {
+      for (int u = next++; u < n_utt; u = next++) {
+        if (!Ls[u].ok) continue;
+        try {
+          vblat::Lattice lat; vblat::CompactLattice clat;
+          RawLatticeFromResult(Ls[u], graph_start, &lat);
+          vblat::Connect(&lat);
+          in_s += (long long)lat.st.size(); in_a += (long long)lat.NumArcs();
+          if (!vblat::DeterminizeLatticePhonePrunedWrapper(tm, &lat, lattice_beam, &clat, vblat::PhoneDetOptions())) early++;
+          vblat::ScaleLattice(1.0, 0.0, 0.0, inv, &clat);
+          out_s += (long long)clat.st.size(); out_a += (long long)clat.NumArcs();
+        } catch (const std::exception &e) { std::lock_guard<std::mutex> g(mu); err = e.what(); }
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < std::max(threads, 1); t++) pool.emplace_back(work);
+    work();
+    for (std::thread &t : pool) t.join();
+    if (!err.empty()) throw ApiError(err);
+    out6[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    out6[1] = (double)in_s; out6[2] = (double)in_a; out6[3] = (double)out_s; out6[4] = (double)out_a; out6[5] = (double)early;
+    return 0;
+  } catch (const std::exception &e) { fprintf(stderr, "ERROR (vb_determinize_decoder_results) %s\n", e.what()); return -1; }
+}
 int vb_set_device(int device_id) { g_device = device_id; return 0; }
 int vb_ComputeMFCCFeats(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return ComputeMFCCFeats(argc, argv, l); }); }
 int vb_ComputeCmvnStats(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return ComputeCmvnStats(argc, argv, l); }); }
