@@ -67,6 +67,47 @@ def run_reference_chain(d, acwt="0.083333", beam="6", lmwt="9", wip="0.5"):
         ref("compute-wer", "--text", "--mode=present", "ark:" + p("ref_text.txt"), "ark:" + p("best_words.txt"), stdout=f)
 
 
+def run_fmllr_chain(d, run, pre, acwt="0.083333", sil="1:2", min_count="50"):
+    """the programs between the two searches of DecodeFmllr (VB/scr/steps/decode_fmllr.cpp:314-640), `run(name, *args)`
+    executing one of them; files are prefixed with `pre`"""
+    p = lambda n: os.path.join(d, n)
+    run("lattice-to-post", "--acoustic-scale=" + acwt, "ark:" + p("ldp.ark"), "ark:" + p(pre + "post.ark"))
+    run("weight-silence-post", "0.01", sil, p("final.mdl"), "ark:" + p(pre + "post.ark"), "ark:" + p(pre + "wsp.ark"))
+    run("gmm-post-to-gpost", p("final.mdl"), "ark:" + p("feats.ark"), "ark:" + p(pre + "wsp.ark"), "ark:" + p(pre + "gpost.ark"))
+    run("gmm-est-fmllr-gpost", "--fmllr-min-count=" + min_count, "--spk2utt=ark:" + p("spk2utt"), p("final.mdl"), "ark:" + p("feats.ark"),
+        "ark:" + p(pre + "gpost.ark"), "ark:" + p(pre + "pre_trans.ark"))
+    run("gmm-est-fmllr", "--fmllr-min-count=" + min_count, "--spk2utt=ark:" + p("spk2utt"), p("final.mdl"), "ark:" + p("feats.ark"),
+        "ark:" + p(pre + "wsp.ark"), "ark:" + p(pre + "trans_tmp.ark"))
+    run("compose-transforms", "--b-is-affine=true", "ark:" + p(pre + "trans_tmp.ark"), "ark:" + p(pre + "pre_trans.ark"), "ark:" + p(pre + "trans.ark"))
+    run("gmm-rescore-lattice", p("final.mdl"), "ark:" + p("raw.ark"), "ark:" + p("feats.ark"), "ark:" + p(pre + "grl.ark"))
+
+
+def make_fmllr_case(d, seed=5, frames=(150, 120, 140, 130), acwt="0.083333"):
+    make_case(d, seed=seed, frames=frames)
+    p = lambda n: os.path.join(d, n)
+    ref("gmm-latgen-faster", "--beam=13", "--lattice-beam=2.5", "--acoustic-scale=" + acwt, "--allow-partial=true",
+        "--determinize-lattice=false", p("final.mdl"), p("HCLG.fst"), "ark:" + p("feats.ark"), "ark:" + p("raw.ark"))
+    ref("lattice-determinize-pruned", "--acoustic-scale=" + acwt, "--beam=4.0", "ark:" + p("raw.ark"), "ark:" + p("ldp.ark"))
+    with open(p("spk2utt"), "w") as f:
+        f.write("spk1 uttA uttB\nspk2 uttC uttD\n")
+
+
+def main_fmllr():
+    """tests/golden/fmllr.npz: inputs (model, features, raw and pruned-determinized lattices, spk2utt) and what the
+    reference's lattice-to-post, weight-silence-post, gmm-post-to-gpost, gmm-est-fmllr-gpost, gmm-est-fmllr,
+    compose-transforms and gmm-rescore-lattice make of them"""
+    with tempfile.TemporaryDirectory(prefix="vbgold_fmllr_") as d:
+        make_fmllr_case(d)
+        run_fmllr_chain(d, ref, "")
+        arrays = {}
+        for fn in ("final.mdl", "feats.ark", "raw.ark", "ldp.ark", "post.ark", "wsp.ark", "gpost.ark", "pre_trans.ark", "trans_tmp.ark", "trans.ark", "grl.ark"):
+            arrays["file_" + fn.replace(".", "_")] = np.fromfile(os.path.join(d, fn), dtype=np.uint8)
+        arrays["text_spk2utt"] = np.array(open(os.path.join(d, "spk2utt")).read())
+        out = os.path.join(ROOT, "tests", "golden", "fmllr.npz")
+        np.savez_compressed(out, **arrays)
+        print("fmllr.npz %.1f KB" % (os.path.getsize(out) / 1024.0))
+
+
 def main():
     with tempfile.TemporaryDirectory(prefix="vbgold_lat_") as d:
         make_case(d)
@@ -86,3 +127,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    main_fmllr()

@@ -1,0 +1,161 @@
+"""Host: the programs between the two searches of DecodeFmllr (voicebridge_amd/host/voicebridge_fmllrbin.cc,
+fmllr.cc, lattice.cc) against a golden run of the reference's own programs
+(tests/golden/fmllr.npz, made by oracle/gen_golden_lat.py) and, where oracle/_ref/bin is present,
+against those programs on a fresh case.
+
+Bars: lattice posteriors and silence weighting are bit-exact (archives byte-identical).  Everything
+downstream of per-Gaussian log-likelihoods differs from the reference in float summation order
+(the reference calls BLAS sgemv) and, for the transforms, in the route to the matrix inverse (LAPACK
+there, Gauss-Jordan here): Gaussian posteriors 1e-5 absolute, fMLLR matrices 2e-4 absolute (entries
+O(1)), rescored lattices identical in structure with acoustic costs within 1e-6 relative."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests import util
+from tests.test_host_io import read_fm_ark
+from tests.test_host_lattice import REFBIN, assert_same_archives, call, host  # noqa: F401
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NEEDED = ("gmm-latgen-faster", "lattice-determinize-pruned", "lattice-to-post", "weight-silence-post", "gmm-post-to-gpost",
+          "gmm-est-fmllr-gpost", "gmm-est-fmllr", "compose-transforms", "gmm-rescore-lattice")
+
+
+def read_gpost_ark(path):
+    raw = open(path, "rb").read()
+    pos, out = 0, {}
+
+    def i32():
+        nonlocal pos
+        assert raw[pos] == 4
+        v = int(np.frombuffer(raw, "<i4", 1, pos + 1)[0])
+        pos += 5
+        return v
+    while pos < len(raw):
+        sp = raw.index(b" ", pos)
+        key = raw[pos:sp].decode()
+        pos = sp + 1
+        assert raw[pos:pos + 2] == b"\0B"
+        pos += 2
+        frames = []
+        for _ in range(i32()):
+            fr = []
+            for _ in range(i32()):
+                pdf = i32()
+                assert raw[pos:pos + 3] == b"FV "
+                pos += 3
+                n = i32()
+                fr.append((pdf, np.frombuffer(raw, "<f4", n, pos).copy()))
+                pos += 4 * n
+            frames.append(fr)
+        out[key] = frames
+    return out
+
+
+def mine_runner(host, d):
+    fns = {"lattice-to-post": host.vb_LatticeToPost, "weight-silence-post": host.vb_WeightSilencePost, "gmm-post-to-gpost": host.vb_GmmPostToGpost,
+           "gmm-est-fmllr-gpost": host.vb_GmmEstFmllrGpost, "gmm-est-fmllr": host.vb_GmmEstFmllr, "compose-transforms": host.vb_ComposeTransforms,
+           "gmm-rescore-lattice": host.vb_GmmRescoreLattice}
+
+    def run(name, *args):
+        log = str(d / "m_log.txt")
+        assert call(fns[name], [name] + list(args), log) == 0, name + ": " + open(log).read()[-600:]
+    return run
+
+
+def compare_chain(d, mine="m_", want=""):
+    p = lambda n: str(d / n)
+    assert open(p(mine + "post.ark"), "rb").read() == open(p(want + "post.ark"), "rb").read()       # bit-exact
+    assert open(p(mine + "wsp.ark"), "rb").read() == open(p(want + "wsp.ark"), "rb").read()
+    a, b = read_gpost_ark(p(mine + "gpost.ark")), read_gpost_ark(p(want + "gpost.ark"))
+    assert list(a) == list(b)
+    for k in b:
+        assert len(a[k]) == len(b[k])
+        for fa, fb in zip(a[k], b[k]):
+            assert sorted(x[0] for x in fa) == sorted(x[0] for x in fb)
+            db = dict(fb)
+            for pdf, v in fa:
+                np.testing.assert_allclose(v, db[pdf], atol=1e-5, rtol=1e-4)
+    for t in ("pre_trans", "trans_tmp", "trans"):
+        a, b = read_fm_ark(p(mine + t + ".ark")), read_fm_ark(p(want + t + ".ark"))
+        assert list(a) == list(b) == ["spk1", "spk2"]
+        for k in b:
+            assert a[k].shape == (39, 40)
+            np.testing.assert_allclose(a[k], b[k], atol=2e-4, rtol=0)
+            assert np.abs(b[k] - np.eye(39, 40)).max() > 0.05          # a real update, not the unit start
+    assert_same_archives(p(mine + "grl.ark"), p(want + "grl.ark"), rtol=1e-6, atol=1e-4)
+
+
+def test_fmllr_chain_matches_golden(host, tmp_path):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gen_golden_lat as gg
+    d = tmp_path
+    g = util.load("fmllr")
+    for k in g.files:
+        if k.startswith("file_"):
+            name = k[5:].rsplit("_", 1)
+            (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
+    (d / "spk2utt").write_text(str(g["text_spk2utt"]))
+    gg.run_fmllr_chain(str(d), mine_runner(host, d), "m_")
+    compare_chain(d)
+
+
+def test_lattice_to_compact_conversion_matches_golden(host, tmp_path):
+    """a state-level lattice read where a CompactLattice is expected is folded by Factor + TopSort
+    (K/fstext/lattice-utils-inl.h:27-100): gmm-rescore-lattice with --old-acoustic-scale=1 on features
+    of the right length adds scores but keeps the structure the reference's conversion produced"""
+    d = tmp_path
+    g = util.load("fmllr")
+    for k in ("file_final_mdl", "file_feats_ark", "file_raw_ark", "file_grl_ark"):
+        name = k[5:].rsplit("_", 1)
+        (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
+    log = str(d / "log.txt")
+    assert call(host.vb_GmmRescoreLattice, ["gmm-rescore-lattice", str(d / "final.mdl"), "ark:%s" % (d / "raw.ark"), "ark:%s" % (d / "feats.ark"),
+                                            "ark:%s" % (d / "m.ark")], log) == 0, open(log).read()
+    mine, want = util.read_lattice_ark(str(d / "m.ark")), util.read_lattice_ark(str(d / "grl.ark"))
+    for k in want:
+        assert [(len(a), [(x[0], x[3], x[4]) for x in a]) for _f, a in mine[k][2]] == [(len(a), [(x[0], x[3], x[4]) for x in a]) for _f, a in want[k][2]]
+    # features shorter than the lattice: reported, utterance skipped, return code 1 when nothing is left
+    (d / "short.ark").write_bytes(b"")
+    util.write_feats_ark(str(d / "short.ark"), {"uttA": np.zeros((5, 39), np.float32)})
+    assert call(host.vb_GmmRescoreLattice, ["gmm-rescore-lattice", str(d / "final.mdl"), "ark:%s" % (d / "raw.ark"), "ark:%s" % (d / "short.ark"),
+                                            "ark:%s" % (d / "m2.ark")], log) == 1
+
+
+def test_fmllr_update_properties(host, tmp_path):
+    """properties of the estimate that do not depend on a reference run: below --fmllr-min-count the
+    unit transform is written; the update raises the auxiliary function (logged improvement > 0)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    d = tmp_path
+    g = util.load("fmllr")
+    for k in ("file_final_mdl", "file_feats_ark", "file_wsp_ark"):
+        name = k[5:].rsplit("_", 1)
+        (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
+    (d / "spk2utt").write_text(str(g["text_spk2utt"]))
+    log = str(d / "log.txt")
+    base = ["gmm-est-fmllr", "--spk2utt=ark:%s" % (d / "spk2utt"), str(d / "final.mdl"), "ark:%s" % (d / "feats.ark"), "ark:%s" % (d / "wsp.ark")]
+    assert call(host.vb_GmmEstFmllr, base + ["ark:%s" % (d / "unit.ark")], log) == 0      # default min-count 500 > the ~270 frames per speaker
+    for m in read_fm_ark(str(d / "unit.ark")).values():
+        np.testing.assert_array_equal(m, np.eye(39, 40, dtype=np.float32))
+    assert "below min-count" in open(log).read()
+    os.remove(log)
+    assert call(host.vb_GmmEstFmllr, base[:1] + ["--fmllr-min-count=50"] + base[1:] + ["ark:%s" % (d / "t.ark")], log) == 0
+    imprs = [float(l.split("auxf-impr from fMLLR is")[1].split(",")[0]) for l in open(log) if "auxf-impr" in l]
+    assert len(imprs) == 2 and all(x > 0 for x in imprs)
+    assert call(host.vb_GmmEstFmllr, base[:1] + ["--fmllr-update-type=diag"] + base[1:] + ["ark:%s" % (d / "x.ark")], log) == -1    # refused, not ignored
+
+
+@pytest.mark.skipif(not all(os.access(os.path.join(REFBIN, b), os.X_OK) for b in NEEDED), reason="oracle/_ref/bin not built")
+def test_fresh_case_vs_reference_programs(host, tmp_path):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gen_golden_lat as gg
+    d = tmp_path
+    gg.make_fmllr_case(str(d), seed=17, frames=(210, 95, 160, 140))
+    gg.run_fmllr_chain(str(d), gg.ref, "r_")
+    gg.run_fmllr_chain(str(d), mine_runner(host, d), "m_")
+    compare_chain(d, "m_", "r_")

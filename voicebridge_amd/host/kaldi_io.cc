@@ -964,6 +964,93 @@ bool LatticeReader::NextLattice(std::string *key, vblat::Lattice *lat) {
   return true;
 }
 
+void WriteFloat(std::ostream &os, bool binary, float v) {
+  if (binary) { os.put(4); os.write(reinterpret_cast<const char *>(&v), 4); } else os << v << ' ';
+}
+
+std::ofstream OpenArkForWriting(const std::string &wspecifier) {
+  const Wspec spec = ParseWspecifier(wspecifier);
+  if (!spec.has_ark || spec.has_scp || spec.text) Fail("expected a binary ark: wspecifier, got " + wspecifier);
+  std::ofstream f(spec.ark_path, std::ios::binary);
+  if (!f) Fail("cannot open " + spec.ark_path + " for writing");
+  return f;
+}
+
+void WritePosteriorEntry(std::ostream &os, const std::string &key, const Posterior &post) {
+  os << key << ' ';
+  os.put('\0'); os.put('B');
+  WriteInt32(os, true, (int32_t)post.size());
+  for (const auto &fr : post) {
+    WriteInt32(os, true, (int32_t)fr.size());
+    for (const auto &pr : fr) { WriteInt32(os, true, pr.first); WriteFloat(os, true, pr.second); }
+  }
+}
+
+void WriteGaussPostEntry(std::ostream &os, const std::string &key, const GaussPost &gpost) {
+  os << key << ' ';
+  os.put('\0'); os.put('B');
+  WriteInt32(os, true, (int32_t)gpost.size());
+  for (const auto &fr : gpost) {
+    WriteInt32(os, true, (int32_t)fr.size());
+    for (const auto &pr : fr) {
+      WriteInt32(os, true, pr.first);
+      os << "FV ";
+      WriteInt32(os, true, (int32_t)pr.second.size());
+      if (!pr.second.empty()) os.write(reinterpret_cast<const char *>(pr.second.data()), 4 * pr.second.size());
+    }
+  }
+}
+
+std::vector<std::pair<std::string, Posterior>> ReadPosteriorTable(const std::string &rspecifier) {
+  const Rspec spec = ParseRspecifier(rspecifier);
+  if (spec.is_scp) Fail("scp: is not supported for posterior tables");
+  std::ifstream is(spec.path, std::ios::binary);
+  if (!is) Fail("cannot open " + spec.path);
+  std::vector<std::pair<std::string, Posterior>> out;
+  for (;;) {
+    const std::string key = ReadArkKey(is);
+    if (key.empty()) break;
+    if (!ReadBinaryHeader(is)) Fail("text-mode posteriors are not supported: " + spec.path);
+    const int32_t sz = ReadInt32(is, true);
+    if (sz < 0 || sz > 10000000) Fail("posterior: bad size");
+    Posterior post(sz);
+    for (auto &fr : post) {
+      const int32_t n = ReadInt32(is, true);
+      if (n < 0 || n > 1000000) Fail("posterior: bad size");
+      fr.resize(n);
+      for (auto &pr : fr) { pr.first = ReadInt32(is, true); pr.second = ReadFloat(is, true); }
+    }
+    out.emplace_back(key, std::move(post));
+  }
+  return out;
+}
+
+std::vector<std::pair<std::string, GaussPost>> ReadGaussPostTable(const std::string &rspecifier) {
+  const Rspec spec = ParseRspecifier(rspecifier);
+  if (spec.is_scp) Fail("scp: is not supported for Gaussian-posterior tables");
+  std::ifstream is(spec.path, std::ios::binary);
+  if (!is) Fail("cannot open " + spec.path);
+  std::vector<std::pair<std::string, GaussPost>> out;
+  for (;;) {
+    const std::string key = ReadArkKey(is);
+    if (key.empty()) break;
+    if (!ReadBinaryHeader(is)) Fail("text-mode Gaussian posteriors are not supported: " + spec.path);
+    const int32_t sz = ReadInt32(is, true);
+    if (sz < 0 || sz > 10000000) Fail("gpost: bad size");
+    GaussPost gp(sz);
+    for (auto &fr : gp) {
+      const int32_t n = ReadInt32(is, true);
+      if (n < 0 || n > 1000000) Fail("gpost: bad size");
+      fr.resize(n);
+      for (auto &pr : fr) { pr.first = ReadInt32(is, true); ReadVector(is, true, &pr.second); }
+    }
+    out.emplace_back(key, std::move(gp));
+  }
+  return out;
+}
+
+std::vector<std::pair<std::string, std::vector<std::string>>> ReadSpk2Utt(const std::string &rspecifier) { return ReadTokenTable(rspecifier); }
+
 std::vector<std::pair<std::string, std::vector<int32_t>>> ReadIntVectorTable(const std::string &rspecifier) {
   const Rspec spec = ParseRspecifier(rspecifier);
   if (spec.is_scp) Fail("scp: is not supported for integer-vector tables");

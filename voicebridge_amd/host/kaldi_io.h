@@ -188,6 +188,18 @@ class LatticeReader {
   size_t pos_ = 0;
 };
 
+// Posterior / GaussPost tables (K/hmm/posterior.cc:32-62,127-215), binary archives
+typedef vblat::Posterior Posterior;
+typedef std::vector<std::vector<std::pair<int32_t, std::vector<float>>>> GaussPost;    // per frame: (pdf-id, per-Gaussian posteriors)
+void WritePosteriorEntry(std::ostream &os, const std::string &key, const Posterior &post);
+void WriteGaussPostEntry(std::ostream &os, const std::string &key, const GaussPost &gpost);
+std::vector<std::pair<std::string, Posterior>> ReadPosteriorTable(const std::string &rspecifier);
+std::vector<std::pair<std::string, GaussPost>> ReadGaussPostTable(const std::string &rspecifier);
+std::ofstream OpenArkForWriting(const std::string &wspecifier);      // "ark:" only, binary
+// spk2utt: speaker -> utterances, in file order
+std::vector<std::pair<std::string, std::vector<std::string>>> ReadSpk2Utt(const std::string &rspecifier);
+void WriteFloat(std::ostream &os, bool binary, float v);
+
 // Int32Vector tables in text or binary form (words, alignments): key -> ints
 std::vector<std::pair<std::string, std::vector<int32_t>>> ReadIntVectorTable(const std::string &rspecifier);
 // token tables ("key tok tok ..." text lines): reference transcripts for compute-wer

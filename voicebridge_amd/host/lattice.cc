@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cassert>
 #include <cmath>
+#include <functional>
 #include <queue>
 #include <stdexcept>
 #include <unordered_map>
@@ -823,6 +824,200 @@ void ConvertLattice(const CompactLattice &clat, Lattice *lat, bool invert) {
       add(cur, len <= 1 ? a.label : 0, len > 0 ? a.w.str[len - 1] : 0, len <= 1 ? a.w.w : One(), a.next);
     }
   }
+}
+
+// Factor (fstext/factor-inl.h:64-140) + ConvertLattice (lattice-utils-inl.h:27-100): states with
+// exactly one arc in and one arc out (not initial, not final, no word on the arc out) disappear
+// into the arc that enters them; the transition-ids met on the way become the arc's string.
+void ConvertLattice(const Lattice &lat, CompactLattice *clat) {
+  clat->st.clear(); clat->start = -1;
+  if (lat.start < 0) return;
+  const int32_t n = (int32_t)lat.st.size();
+  // depth-first discovery order (DfsOrderVisitor::InitState), OpenFst's visiting order
+  std::vector<int32_t> order;
+  {
+    std::vector<uint8_t> color(n, 0);
+    std::vector<std::pair<int32_t, size_t>> stack;
+    for (int32_t root = lat.start; root < n;) {
+      color[root] = 1; order.push_back(root);
+      stack.emplace_back(root, 0);
+      while (!stack.empty()) {
+        const int32_t s = stack.back().first;
+        const size_t ai = stack.back().second;
+        if (ai >= lat.st[s].arcs.size()) { color[s] = 2; stack.pop_back(); if (!stack.empty()) stack.back().second++; continue; }
+        const int32_t nx = lat.st[s].arcs[ai].next;
+        if (color[nx] == 0) { color[nx] = 1; order.push_back(nx); stack.emplace_back(nx, 0); }
+        else stack.back().second++;
+      }
+      for (root = (root == lat.start) ? 0 : root + 1; root < n && color[root] != 0; ++root) {}
+    }
+  }
+  enum { kInitial = 1, kFinal = 2, kArcsIn = 4, kMultIn = 8, kArcsOut = 16, kMultOut = 32, kOlabelsOut = 64, kIlabelsOut = 128 };
+  std::vector<int> props(n, 0);
+  props[lat.start] |= kInitial;
+  for (int32_t s = 0; s < n; s++) {
+    for (const Arc &a : lat.st[s].arcs) {
+      if (a.ilabel != 0) props[s] |= kIlabelsOut;
+      if (a.olabel != 0) props[s] |= kOlabelsOut;
+      if (props[s] & kArcsOut) props[s] |= kMultOut;
+      props[s] |= kArcsOut;
+      if (props[a.next] & kArcsIn) props[a.next] |= kMultIn;
+      props[a.next] |= kArcsIn;
+    }
+    if (!IsZero(lat.st[s].final)) props[s] |= kFinal;
+  }
+  std::vector<uint8_t> remove(n);
+  for (int32_t s = 0; s < n; s++) remove[s] = props[s] == (kArcsIn | kArcsOut) || props[s] == (kArcsIn | kArcsOut | kIlabelsOut);
+  std::vector<int32_t> mapping(n, -1);
+  CompactLattice f;     // arcs carry their strings directly (the symbol table of Factor is only an indirection)
+  auto state_of = [&](int32_t s) { if (mapping[s] < 0) { mapping[s] = (int32_t)f.st.size(); f.st.emplace_back(); } return mapping[s]; };
+  for (int32_t s : order) {
+    if (remove[s]) continue;
+    const int32_t ns = state_of(s);
+    for (const Arc &a0 : lat.st[s].arcs) {
+      Arc arc = a0;
+      CArc out;
+      if (arc.ilabel != 0) out.w.str.push_back(arc.ilabel);
+      while (remove[arc.next]) {
+        const Arc &nx = lat.st[arc.next].arcs[0];
+        arc.w = Times(arc.w, nx.w);
+        if (nx.ilabel != 0) out.w.str.push_back(nx.ilabel);
+        arc.next = nx.next;
+      }
+      out.label = arc.olabel; out.w.w = arc.w; out.next = state_of(arc.next);
+      f.st[ns].arcs.push_back(std::move(out));
+    }
+    if (!IsZero(lat.st[s].final)) f.st[ns].final.w = lat.st[s].final;
+  }
+  f.start = mapping[lat.start];
+  TopSort(&f);
+  *clat = std::move(f);
+}
+
+int32_t LatticeStateTimes(const Lattice &lat, std::vector<int32_t> *times) {
+  if (!IsTopSorted(lat)) throw std::runtime_error("Input lattice must be topologically sorted.");
+  const int32_t n = (int32_t)lat.st.size();
+  times->assign(n, -1);
+  if (n == 0) return 0;
+  (*times)[0] = 0;
+  for (int32_t s = 0; s < n; s++) {
+    const int32_t t = (*times)[s];
+    for (const Arc &a : lat.st[s].arcs) {
+      const int32_t nt = a.ilabel != 0 ? t + 1 : t;
+      if ((*times)[a.next] == -1) (*times)[a.next] = nt;
+    }
+  }
+  return *std::max_element(times->begin(), times->end());
+}
+
+int32_t CompactLatticeStateTimes(const CompactLattice &clat, std::vector<int32_t> *times) {
+  if (!IsTopSorted(clat)) throw std::runtime_error("Input lattice must be topologically sorted.");
+  const int32_t n = (int32_t)clat.st.size();
+  times->assign(n, -1);
+  if (n == 0) return 0;
+  (*times)[0] = 0;
+  int32_t utt_len = -1;
+  for (int32_t s = 0; s < n; s++) {
+    const int32_t t = (*times)[s];
+    for (const CArc &a : clat.st[s].arcs) {
+      const int32_t nt = t + (int32_t)a.w.str.size();
+      if ((*times)[a.next] == -1) (*times)[a.next] = nt;
+    }
+    if (!(IsZero(clat.st[s].final.w) && clat.st[s].final.str.empty())) {
+      const int32_t len = t + (int32_t)clat.st[s].final.str.size();
+      utt_len = utt_len == -1 ? len : std::max(utt_len, len);
+    }
+  }
+  return utt_len == -1 ? 0 : utt_len;    // (no final state: the reference warns and returns 0)
+}
+
+static inline double LogAddD(double x, double y) {     // base/kaldi-math.h:186-205
+  double diff;
+  if (x < y) { diff = x - y; x = y; } else diff = y - x;
+  if (diff >= -36.04365338911715) return x + std::log1p(std::exp(diff));     // kMinLogDiffDouble = log(DBL_EPSILON)
+  return x;
+}
+
+double LatticeForwardBackward(const Lattice &lat, Posterior *post, double *acoustic_like_sum) {
+  const double kLogZero = -std::numeric_limits<double>::infinity();
+  if (acoustic_like_sum) *acoustic_like_sum = 0.0;
+  std::vector<int32_t> times;
+  const int32_t max_time = LatticeStateTimes(lat, &times);
+  const int32_t n = (int32_t)lat.st.size();
+  std::vector<double> alpha(n, kLogZero);
+  std::vector<double> &beta = alpha;
+  double tot_forward = kLogZero;
+  post->assign(max_time, {});
+  if (n == 0) return kLogZero;
+  alpha[0] = 0.0;
+  for (int32_t s = 0; s < n; s++) {
+    const double a = alpha[s];
+    for (const Arc &arc : lat.st[s].arcs) alpha[arc.next] = LogAddD(alpha[arc.next], a - Cost(arc.w));
+    const Weight &f = lat.st[s].final;
+    if (!IsZero(f)) {
+      tot_forward = LogAddD(tot_forward, a - (double)(f.v1 + f.v2));
+      if (times[s] != max_time) throw std::runtime_error("Lattice is inconsistent (final-prob not at max_time)");
+    }
+  }
+  for (int32_t s = n - 1; s >= 0; s--) {
+    const Weight &f = lat.st[s].final;
+    double this_beta = -(double)(f.v1 + f.v2);
+    for (const Arc &arc : lat.st[s].arcs) {
+      const double arc_beta = beta[arc.next] - Cost(arc.w);
+      this_beta = LogAddD(this_beta, arc_beta);
+      if (arc.ilabel != 0 || acoustic_like_sum) {
+        const double p = std::exp(alpha[s] + arc_beta - tot_forward);
+        if (arc.ilabel != 0) (*post)[times[s]].push_back(std::make_pair(arc.ilabel, (float)p));
+        if (acoustic_like_sum) *acoustic_like_sum -= p * arc.w.v2;
+      }
+    }
+    if (acoustic_like_sum && !IsZero(f)) *acoustic_like_sum -= std::exp(alpha[s] - Cost(f) - tot_forward) * f.v2;
+    beta[s] = this_beta;
+  }
+  const double tot_backward = beta[0];
+  // MergePairVectorSumming (util/stl-utils.h:289-315): sort on the transition-id, add up equal ones, drop zeros
+  for (auto &v : *post) {
+    std::sort(v.begin(), v.end(), [](const std::pair<int32_t, float> &a, const std::pair<int32_t, float> &b) { return a.first < b.first; });
+    size_t out = 0, in = 0;
+    while (in < v.size()) {
+      v[out] = v[in++];
+      while (in < v.size() && v[in].first == v[out].first) v[out].second += v[in++].second;
+      if (v[out].second != 0.0f) out++;
+    }
+    v.resize(out);
+  }
+  return tot_backward;
+}
+
+bool RescoreCompactLattice(const std::function<float(int32_t, int32_t)> &loglike, int32_t num_frames, CompactLattice *clat) {
+  if (clat->st.empty()) return false;
+  if (!IsTopSorted(*clat) && !TopSort(clat)) return false;
+  std::vector<int32_t> times;
+  const int32_t utt_len = CompactLatticeStateTimes(*clat, &times);
+  struct Tup { int32_t state, arc, tid; };
+  std::vector<std::vector<Tup>> tts(utt_len);
+  for (int32_t s = 0; s < (int32_t)clat->st.size(); s++) {
+    const int32_t t = times[s];
+    for (int32_t ai = 0; ai < (int32_t)clat->st[s].arcs.size(); ai++) {
+      const std::vector<int32_t> &str = clat->st[s].arcs[ai].w.str;
+      for (size_t off = 0; off < str.size(); off++) {
+        if (t < utt_len) tts[t + off].push_back(Tup{s, ai, str[off]});
+        else if (t != utt_len) return false;
+      }
+    }
+    const CWeight &f = clat->st[s].final;
+    if (!(IsZero(f.w) && f.str.empty()))
+      for (size_t off = 0; off < f.str.size(); off++) tts[t + off].push_back(Tup{s, -1, f.str[off]});
+  }
+  for (int32_t t = 0; t < utt_len; t++) {
+    if (t >= num_frames) return false;          // features are too short for the lattice
+    for (const Tup &x : tts[t]) {
+      const float ll = loglike(t, x.tid);
+      Weight &w = x.arc < 0 ? clat->st[x.state].final.w : clat->st[x.state].arcs[x.arc].w.w;
+      w.v2 = -ll + w.v2;
+    }
+  }
+  return true;
 }
 
 void CompactLatticeShortestPath(const CompactLattice &clat_in, CompactLattice *shortest) {     // lattice-functions.cc:1094-1177

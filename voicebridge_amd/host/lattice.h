@@ -21,8 +21,10 @@
 #define VOICEBRIDGE_LATTICE_H_
 
 #include <cstdint>
+#include <functional>
 #include <limits>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace vblat {
@@ -99,8 +101,19 @@ bool PruneLattice(float beam, Lattice *lat);
 void ScaleLattice(double s00, double s01, double s10, double s11, Lattice *lat);
 void ScaleLattice(double s00, double s01, double s10, double s11, CompactLattice *clat);
 void AddWordInsPen(float word_ins_penalty, CompactLattice *clat);
-void ConvertLattice(const Lattice &lat, CompactLattice *clat, bool invert = true);   // lattice-utils-inl.h:27-100
 void ConvertLattice(const CompactLattice &clat, Lattice *lat, bool invert = true);   // :102-160
+// state-level -> compact: chains of states are folded into one arc (fstext/factor-inl.h:64-140), then TopSort
+void ConvertLattice(const Lattice &lat, CompactLattice *clat);                        // lattice-utils-inl.h:27-100 (invert = true)
+
+// ---- times, posteriors, rescoring (what fMLLR estimation in DecodeFmllr reads)
+typedef std::vector<std::vector<std::pair<int32_t, float>>> Posterior;   // per frame: (transition-id, posterior)
+int32_t LatticeStateTimes(const Lattice &lat, std::vector<int32_t> *times);                  // lattice-functions.cc:78-110
+int32_t CompactLatticeStateTimes(const CompactLattice &clat, std::vector<int32_t> *times);   // :112-150
+// forward-backward over a top-sorted lattice (lattice-functions.cc:314-395); returns the total log-prob
+double LatticeForwardBackward(const Lattice &lat, Posterior *post, double *acoustic_like_sum);
+// adds -loglike(t, tid) to the acoustic cost of every transition-id of the lattice
+// (RescoreCompactLattice, lattice-functions.cc:1214-1345); false on lattice/feature mismatch
+bool RescoreCompactLattice(const std::function<float(int32_t, int32_t)> &loglike, int32_t num_frames, CompactLattice *clat);
 // best path of a compact lattice as a linear compact lattice; empty when there is none
 void CompactLatticeShortestPath(const CompactLattice &clat, CompactLattice *shortest);
 // words, alignment and total weight of a linear compact lattice; false if it is not linear

@@ -52,6 +52,17 @@ int ComputeWer(int argc, char *argv[], std::ofstream &file_log);           // th
 // upstream program K/latbin/lattice-determinize-phone-pruned.cc (what gmm-latgen-faster does per utterance)
 int LatticeDeterminizePhonePruned(int argc, char *argv[], std::ofstream &file_log);
 
+// ---- between the two searches of DecodeFmllr; host code in voicebridge_fmllrbin.cc
+//   src/kaldi_src.h:93 LatticeToPost, :84 WeightSilencePost, :55 GmmPostToGpost, :56 GmmEstFmllrGpost, :53 GmmEstFmllr,
+//   :34 ComposeTransforms, :57 GmmRescoreLattice  (all: int f(int argc, char *argv[], fs::ofstream &file_log))
+int LatticeToPost(int argc, char *argv[], std::ofstream &file_log);
+int WeightSilencePost(int argc, char *argv[], std::ofstream &file_log);
+int GmmPostToGpost(int argc, char *argv[], std::ofstream &file_log);
+int GmmEstFmllrGpost(int argc, char *argv[], std::ofstream &file_log);
+int GmmEstFmllr(int argc, char *argv[], std::ofstream &file_log);
+int ComposeTransforms(int argc, char *argv[], std::ofstream &file_log);
+int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log);
+
 // plain-C shims of the above for hosts without C++ streams (ctypes, cgo ...): log_path may be NULL
 extern "C" {
 int vb_ComputeMFCCFeats(int argc, char *argv[], const char *log_path);
@@ -69,6 +80,13 @@ int vb_LatticeScale(int argc, char *argv[], const char *log_path);
 int vb_LatticeAddPenalty(int argc, char *argv[], const char *log_path);
 int vb_LatticeBestPath(int argc, char *argv[], const char *log_path);
 int vb_ComputeWer(int argc, char *argv[], const char *log_path);
+int vb_LatticeToPost(int argc, char *argv[], const char *log_path);
+int vb_WeightSilencePost(int argc, char *argv[], const char *log_path);
+int vb_GmmPostToGpost(int argc, char *argv[], const char *log_path);
+int vb_GmmEstFmllrGpost(int argc, char *argv[], const char *log_path);
+int vb_GmmEstFmllr(int argc, char *argv[], const char *log_path);
+int vb_ComposeTransforms(int argc, char *argv[], const char *log_path);
+int vb_GmmRescoreLattice(int argc, char *argv[], const char *log_path);
 void vb_ComputeWerCounts(long long *out8);   // {word_errs, num_words, ins, del, sub, num_sent, sent_errs, absent} of the last ComputeWer
 int vb_set_device(int device_id);   // GPU used by the calling thread's subsequent calls (default 0)
 }

@@ -1,0 +1,387 @@
+// voicebridge_fmllrbin.cc -- the programs between the two searches of DecodeFmllr:
+// lattice posteriors, silence weighting, Gaussian-level posteriors, fMLLR estimation, transform
+// composition, lattice rescoring.  Declarations and the reference files they mirror:
+// voicebridge_api.h.  Host code this round: per frame these touch the two or three pdfs a lattice
+// holds at that time, not the whole model; the statistics accumulation is the part marked for the
+// GPU (DESIGN.md "next").
+#include <cmath>
+#include <map>
+#include <set>
+#include <sstream>
+#include <unordered_map>
+
+#include "api_common.h"
+#include "fmllr.h"
+#include "kaldi_io.h"
+#include "lattice.h"
+#include "voicebridge_api.h"
+
+using namespace vbapi;
+
+namespace {
+
+struct Gmm {       // the acoustic model as the host sees it: gconsts recomputed as DiagGmm::Read does (K/gmm/diag-gmm.cc:114-152)
+  vbio::Model m;
+  std::vector<float> gconsts;
+  explicit Gmm(const std::string &path) {
+    vbio::ReadModel(path, &m);
+    const int D = m.dim, G = m.pdf_offsets.back();
+    gconsts.resize(G);
+    const float offset = (float)(-0.5 * 1.8378770664093454835606594728112 * D);
+    for (int i = 0; i < G; i++) {
+      float gc = std::log(m.weights[i]) + offset;
+      for (int d = 0; d < D; d++) {
+        const float iv = m.inv_vars[(size_t)i * D + d], miv = m.means_invvars[(size_t)i * D + d];
+        gc = (float)(gc + (0.5 * std::log(iv) - 0.5 * miv * miv / iv));
+      }
+      if (gc != gc) throw ApiError("At component " + std::to_string(i) + ", not a number in gconst computation");
+      if (std::isinf(gc) && gc > 0) gc = -gc;
+      gconsts[i] = gc;
+    }
+  }
+  vbfmllr::PdfView Pdf(int p) const {
+    const int a = m.pdf_offsets[p], D = m.dim;
+    return vbfmllr::PdfView{m.pdf_offsets[p + 1] - a, gconsts.data() + a, m.means_invvars.data() + (size_t)a * D, m.inv_vars.data() + (size_t)a * D};
+  }
+  // DecodableAmDiagGmmUnmapped::LogLikelihoodZeroBased (K/gmm/decodable-am-diag-gmm.cc:28-72): float
+  // per-Gaussian terms, LogSumExp with a double accumulator (K/matrix/kaldi-vector.cc:757-775)
+  float LogLike(int pdf, const float *x) const {
+    std::vector<float> ll;
+    vbfmllr::GaussLogLikes(Pdf(pdf), m.dim, x, &ll);
+    float mx = ll[0];
+    for (float v : ll) if (v > mx) mx = v;
+    const float cutoff = mx + -15.9423847198486328125f;
+    double sum = 0.0;
+    for (float v : ll) if (v >= cutoff) sum += std::exp(v - mx);
+    return mx + (float)std::log(sum);
+  }
+};
+
+// ConvertPosteriorToPdfs (K/hmm/posterior.cc:322-346), pdfs of a frame in increasing order
+void PosteriorToPdfs(const std::vector<int32_t> &tid2pdf, const vbio::Posterior &in, vbio::Posterior *out) {
+  out->assign(in.size(), {});
+  for (size_t i = 0; i < in.size(); i++) {
+    std::map<int32_t, float> acc;
+    for (const auto &pr : in[i]) {
+      if (pr.first <= 0 || pr.first >= (int32_t)tid2pdf.size()) throw ApiError("posterior: transition-id out of the model's range");
+      acc[tid2pdf[pr.first]] += pr.second;
+    }
+    for (const auto &kv : acc) if (kv.second != 0.0f) (*out)[i].push_back(kv);
+  }
+}
+
+vbfmllr::FmllrOptions ReadFmllrOptions(const Options &po) {
+  vbfmllr::FmllrOptions o;
+  o.update_type = po.Str("fmllr-update-type", "full");
+  o.min_count = (float)po.Num("fmllr-min-count", 500.0);
+  o.num_iters = (int)po.Num("fmllr-num-iters", 40);
+  return o;
+}
+
+std::map<std::string, vbio::Matrix> ReadFeatureTable(const std::string &rspec) {
+  std::map<std::string, vbio::Matrix> out;
+  vbio::MatrixReader r(rspec);
+  std::string k; vbio::Matrix m;
+  while (r.Next(&k, &m)) out.emplace(k, std::move(m));
+  return out;
+}
+
+// the common body of gmm-est-fmllr and gmm-est-fmllr-gpost: per speaker (or utterance) statistics
+// -> transform.  `accumulate(utt, feats, accs)` returns false when the utterance has to be skipped.
+template <class Acc>
+int EstimateFmllr(const char *prog, const Options &po, const Gmm &gmm, const std::string &feat_rspec, const std::string &trans_wspec, Log &log, Acc accumulate) {
+  const vbfmllr::FmllrOptions opts = ReadFmllrOptions(po);
+  if (opts.update_type != "full") throw ApiError("--fmllr-update-type=" + opts.update_type + " is not supported (only full)");
+  vbio::MatrixWriter writer(trans_wspec);
+  const int D = gmm.m.dim;
+  double tot_impr = 0.0, tot_t = 0.0;
+  int num_done = 0, num_err = 0;
+  auto finish = [&](const std::string &key, vbfmllr::FmllrAccs &accs, const char *what) {
+    vbio::Matrix t; t.rows = D; t.cols = D + 1; t.data.assign((size_t)D * (D + 1), 0.0f);
+    for (int d = 0; d < D; d++) t.data[(size_t)d * (D + 1) + d] = 1.0f;
+    float count = 0.0f;
+    const float impr = accs.Update(opts, t.data.data(), &count);
+    if (!(accs.beta() > opts.min_count)) log.os() << "WARNING (" << prog << ") Not updating fMLLR since below min-count: count is " << accs.beta() << "\n";
+    writer.Write(key, t);
+    log.os() << "LOG (" << prog << ") For " << what << " " << key << ", auxf-impr from fMLLR is " << (impr / count) << ", over " << count << " frames.\n";
+    tot_impr += impr; tot_t += count;
+  };
+  if (po.Has("spk2utt")) {
+    const auto feats = ReadFeatureTable(feat_rspec);
+    for (const auto &su : vbio::ReadSpk2Utt(po.Str("spk2utt", ""))) {
+      vbfmllr::FmllrAccs accs(D);
+      for (const std::string &utt : su.second) {
+        auto it = feats.find(utt);
+        if (it == feats.end()) { log.os() << "WARNING (" << prog << ") Did not find features for utterance " << utt << "\n"; num_err++; continue; }
+        if (accumulate(utt, it->second, &accs)) num_done++; else num_err++;
+      }
+      finish(su.first, accs, "speaker");
+    }
+  } else {
+    vbio::MatrixReader r(feat_rspec);
+    std::string utt; vbio::Matrix m;
+    while (r.Next(&utt, &m)) {
+      vbfmllr::FmllrAccs accs(D);
+      if (!accumulate(utt, m, &accs)) { num_err++; continue; }
+      num_done++;
+      finish(utt, accs, "utterance");
+    }
+  }
+  writer.Close();
+  log.os() << "LOG (" << prog << ") Done " << num_done << " files, " << num_err << " with errors.\n";
+  log.os() << "LOG (" << prog << ") Overall fMLLR auxf impr per frame is " << (tot_impr / tot_t) << " over " << tot_t << " frames.\n";
+  return num_done != 0 ? 0 : 1;
+}
+
+}  // namespace
+
+// lattice-to-post   (VB/src/latbin/lattice-to-post.cpp; K/latbin/lattice-to-post.cc:28-115)
+int LatticeToPost(int argc, char *argv[], std::ofstream &file_log) {
+  return Guard("lattice-to-post", &file_log, [&](Log &log) -> int {
+    Options po;
+    po.Know({"acoustic-scale", "lm-scale"});
+    po.Parse(argc, argv);
+    if (po.args.size() < 2 || po.args.size() > 3) throw ApiError("Wrong arguments.");
+    if (po.args.size() == 3 && !po.args[2].empty()) throw ApiError("the log-likelihood output table is not supported");
+    const float acoustic_scale = (float)po.Num("acoustic-scale", 1.0), lm_scale = (float)po.Num("lm-scale", 1.0);
+    if (acoustic_scale == 0.0f) throw ApiError("Do not use a zero acoustic scale (cannot be inverted)");
+    vbio::LatticeReader reader(po.args[0]);
+    std::ofstream out = vbio::OpenArkForWriting(po.args[1]);
+    int n_done = 0;
+    double total_like = 0.0, total_ac = 0.0, total_time = 0.0;
+    std::string key; vblat::Lattice lat;
+    while (reader.NextLattice(&key, &lat)) {
+      if (acoustic_scale != 1.0f || lm_scale != 1.0f) vblat::ScaleLattice((double)lm_scale, 0.0, 0.0, (double)acoustic_scale, &lat);
+      if (!vblat::IsTopSorted(lat) && !vblat::TopSort(&lat)) throw ApiError("Cycles detected in lattice.");
+      vblat::Posterior post;
+      double ac = 0.0;
+      total_like += vblat::LatticeForwardBackward(lat, &post, &ac);
+      total_time += (double)post.size(); total_ac += ac;
+      vbio::WritePosteriorEntry(out, key, post);
+      n_done++;
+    }
+    if (out.fail()) throw ApiError("write failure on " + po.args[1]);
+    log.os() << "LOG (lattice-to-post) Overall average log-like/frame is " << (total_like / total_time) << " over " << total_time
+             << " frames.  Average acoustic like/frame is " << (total_ac / total_time) << "\n";
+    log.os() << "LOG (lattice-to-post) Done " << n_done << " lattices.\n";
+    return n_done != 0 ? 0 : 1;
+  });
+}
+
+// weight-silence-post   (VB/src/bin/weight-silence-post.cpp; K/bin/weight-silence-post.cc:28-110, K/hmm/posterior.cc:375-395)
+int WeightSilencePost(int argc, char *argv[], std::ofstream &file_log) {
+  return Guard("weight-silence-post", &file_log, [&](Log &log) -> int {
+    Options po;
+    po.Know({"distribute"});
+    po.Parse(argc, argv);
+    if (po.args.size() != 5) throw ApiError("Wrong arguments.");
+    if (po.Bool("distribute", false)) throw ApiError("--distribute=true is not supported");
+    char *end = nullptr;
+    const float w = strtof(po.args[0].c_str(), &end);
+    if (end == po.args[0].c_str() || *end) throw ApiError("Invalid silence-weight parameter: expected float, got \"" + po.args[0] + "\"");
+    std::set<int32_t> sil;
+    { std::string tok; std::istringstream is(po.args[1]); while (std::getline(is, tok, ':')) { if (tok.empty()) throw ApiError("Invalid silence-phones string " + po.args[1]); sil.insert(atoi(tok.c_str())); } }
+    vbio::Model model;
+    vbio::ReadModel(po.args[2], &model);
+    std::ofstream out = vbio::OpenArkForWriting(po.args[4]);
+    int n = 0;
+    for (auto &kv : vbio::ReadPosteriorTable(po.args[3])) {
+      for (auto &fr : kv.second) {
+        std::vector<std::pair<int32_t, float>> keep;
+        keep.reserve(fr.size());
+        for (const auto &pr : fr) {
+          if (pr.first <= 0 || pr.first >= (int32_t)model.trans.phone.size()) throw ApiError("posterior: transition-id out of the model's range");
+          if (sil.count(model.trans.phone[pr.first])) { if (w != 0.0f) keep.emplace_back(pr.first, pr.second * w); }
+          else keep.push_back(pr);
+        }
+        fr.swap(keep);
+      }
+      vbio::WritePosteriorEntry(out, kv.first, kv.second);
+      n++;
+    }
+    log.os() << "LOG (weight-silence-post) Done " << n << " posteriors.\n";
+    return n != 0 ? 0 : 1;
+  });
+}
+
+// gmm-post-to-gpost   (VB/src/gmmbin/gmm-post-to-gpost.cpp; K/gmmbin/gmm-post-to-gpost.cc:28-140)
+int GmmPostToGpost(int argc, char *argv[], std::ofstream &file_log) {
+  return Guard("gmm-post-to-gpost", &file_log, [&](Log &log) -> int {
+    Options po;
+    po.Know({"binary", "rand-prune"});
+    po.Parse(argc, argv);
+    if (po.args.size() != 4) throw ApiError("Wrong arguments.");
+    if (po.Num("rand-prune", 0.0) > 0.0) throw ApiError("--rand-prune is not supported (it draws from rand())");
+    const Gmm gmm(po.args[0]);
+    std::map<std::string, vbio::Posterior> posts;
+    for (auto &kv : vbio::ReadPosteriorTable(po.args[2])) posts.emplace(kv.first, std::move(kv.second));
+    std::ofstream out = vbio::OpenArkForWriting(po.args[3]);
+    vbio::MatrixReader r(po.args[1]);
+    int num_done = 0, num_no_post = 0, num_err = 0;
+    double tot_like = 0.0, tot_t = 0.0;
+    std::string key; vbio::Matrix mat;
+    std::vector<float> ll;
+    while (r.Next(&key, &mat)) {
+      auto it = posts.find(key);
+      if (it == posts.end()) { num_no_post++; continue; }
+      const vbio::Posterior &post = it->second;
+      if ((int)post.size() != mat.rows) { log.os() << "WARNING (gmm-post-to-gpost) Posterior vector has wrong size " << post.size() << " vs. " << mat.rows << "\n"; num_err++; continue; }
+      num_done++;
+      vbio::Posterior pdf_post;
+      PosteriorToPdfs(gmm.m.tid2pdf, post, &pdf_post);
+      vbio::GaussPost gp(post.size());
+      for (size_t i = 0; i < post.size(); i++) {
+        const float *x = &mat.data[i * (size_t)mat.cols];
+        for (const auto &pr : pdf_post[i]) {
+          vbfmllr::GaussLogLikes(gmm.Pdf(pr.first), gmm.m.dim, x, &ll);
+          float mx = ll[0];
+          for (float v : ll) if (v > mx) mx = v;
+          float sum = 0.0f;
+          for (float &v : ll) sum += (v = std::exp(v - mx));
+          const float inv = 1.0f / sum;
+          bool any = false;
+          for (float &v : ll) { v = v * inv * pr.second; any = any || v != 0.0f; }
+          if (any) gp[i].emplace_back(pr.first, ll);
+          tot_like += (double)(mx + std::log(sum)) * pr.second;
+          tot_t += pr.second;
+        }
+      }
+      vbio::WriteGaussPostEntry(out, key, gp);
+    }
+    log.os() << "LOG (gmm-post-to-gpost) Done " << num_done << " files, " << num_no_post << " with no posteriors, " << num_err << " with other errors.\n";
+    log.os() << "LOG (gmm-post-to-gpost) Overall avg like per frame (Gaussian only) = " << (tot_like / tot_t) << " over " << tot_t << " frames.\n";
+    return num_done != 0 ? 0 : 1;
+  });
+}
+
+// gmm-est-fmllr-gpost   (VB/src/gmmbin/gmm-est-fmllr-gpost.cpp; K/gmmbin/gmm-est-fmllr-gpost.cc:28-190)
+int GmmEstFmllrGpost(int argc, char *argv[], std::ofstream &file_log) {
+  return Guard("gmm-est-fmllr-gpost", &file_log, [&](Log &log) -> int {
+    Options po;
+    po.Know({"spk2utt", "fmllr-update-type", "fmllr-min-count", "fmllr-num-iters"});
+    po.Parse(argc, argv);
+    if (po.args.size() != 4) throw ApiError("Wrong arguments.");
+    const Gmm gmm(po.args[0]);
+    std::map<std::string, vbio::GaussPost> gposts;
+    for (auto &kv : vbio::ReadGaussPostTable(po.args[2])) gposts.emplace(kv.first, std::move(kv.second));
+    return EstimateFmllr("gmm-est-fmllr-gpost", po, gmm, po.args[1], po.args[3], log, [&](const std::string &utt, const vbio::Matrix &feats, vbfmllr::FmllrAccs *accs) {
+      auto it = gposts.find(utt);
+      if (it == gposts.end()) { log.os() << "WARNING (gmm-est-fmllr-gpost) Did not find posteriors for utterance " << utt << "\n"; return false; }
+      const vbio::GaussPost &gp = it->second;
+      if ((int)gp.size() != feats.rows) { log.os() << "WARNING (gmm-est-fmllr-gpost) GaussPost vector has wrong size " << gp.size() << " vs. " << feats.rows << "\n"; return false; }
+      for (size_t i = 0; i < gp.size(); i++)
+        for (const auto &pr : gp[i]) {
+          const vbfmllr::PdfView pdf = gmm.Pdf(pr.first);
+          if ((int)pr.second.size() != pdf.num_gauss) throw ApiError("Gaussian posteriors do not match the model for utterance " + utt);
+          accs->AccumulateFromPosteriors(pdf, &feats.data[i * (size_t)feats.cols], pr.second.data());
+        }
+      return true;
+    });
+  });
+}
+
+// gmm-est-fmllr   (VB/src/gmmbin/gmm-est-fmllr.cpp; K/gmmbin/gmm-est-fmllr.cc:28-200)
+int GmmEstFmllr(int argc, char *argv[], std::ofstream &file_log) {
+  return Guard("gmm-est-fmllr", &file_log, [&](Log &log) -> int {
+    Options po;
+    po.Know({"spk2utt", "fmllr-update-type", "fmllr-min-count", "fmllr-num-iters"});
+    po.Parse(argc, argv);
+    if (po.args.size() != 4) throw ApiError("Wrong arguments.");
+    const Gmm gmm(po.args[0]);
+    std::map<std::string, vbio::Posterior> posts;
+    for (auto &kv : vbio::ReadPosteriorTable(po.args[2])) posts.emplace(kv.first, std::move(kv.second));
+    return EstimateFmllr("gmm-est-fmllr", po, gmm, po.args[1], po.args[3], log, [&](const std::string &utt, const vbio::Matrix &feats, vbfmllr::FmllrAccs *accs) {
+      auto it = posts.find(utt);
+      if (it == posts.end()) { log.os() << "WARNING (gmm-est-fmllr) Did not find posteriors for utterance " << utt << "\n"; return false; }
+      if ((int)it->second.size() != feats.rows) { log.os() << "WARNING (gmm-est-fmllr) Posterior vector has wrong size " << it->second.size() << " vs. " << feats.rows << "\n"; return false; }
+      vbio::Posterior pdf_post;
+      PosteriorToPdfs(gmm.m.tid2pdf, it->second, &pdf_post);
+      for (size_t i = 0; i < pdf_post.size(); i++)
+        for (const auto &pr : pdf_post[i]) accs->AccumulateForGmm(gmm.Pdf(pr.first), &feats.data[i * (size_t)feats.cols], pr.second);
+      return true;
+    });
+  });
+}
+
+// compose-transforms   (VB/src/featbin/compose-transforms.cpp; K/featbin/compose-transforms.cc:28-165): both tables
+int ComposeTransforms(int argc, char *argv[], std::ofstream &file_log) {
+  return Guard("compose-transforms", &file_log, [&](Log &log) -> int {
+    Options po;
+    po.Know({"utt2spk", "b-is-affine", "binary"});
+    po.Parse(argc, argv);
+    if (po.args.size() != 3) throw ApiError("Wrong arguments.");
+    if (po.Has("utt2spk")) throw ApiError("--utt2spk is not supported");
+    const bool b_is_affine = po.Bool("b-is-affine", false);
+    for (int i = 0; i < 3; i++)
+      if (po.args[i].compare(0, 4, "ark:") != 0 && po.args[i].compare(0, 4, "scp:") != 0 && po.args[i].compare(0, 4, "ark,") != 0)
+        throw ApiError("only the table form (both inputs rspecifiers, output a wspecifier) is supported");
+    const std::map<std::string, vbio::Matrix> b = vbio::ReadMatrixTable(po.args[1]);
+    vbio::MatrixReader a_reader(po.args[0]);
+    vbio::MatrixWriter writer(po.args[2]);
+    std::string key; vbio::Matrix a;
+    while (a_reader.Next(&key, &a)) {
+      auto it = b.find(key);
+      if (it == b.end()) { log.os() << "WARNING (compose-transforms) Second table does not have key " << key << "\n"; continue; }
+      vbio::Matrix c;
+      if (!vbfmllr::ComposeTransforms(a.data, a.rows, a.cols, it->second.data, it->second.rows, it->second.cols, b_is_affine, &c.data, &c.rows, &c.cols)) {
+        log.os() << "WARNING (compose-transforms) Empty matrix in ComposeTransforms\n";
+        continue;
+      }
+      writer.Write(key, c);
+    }
+    writer.Close();
+    return 0;
+  });
+}
+
+// gmm-rescore-lattice   (VB/src/gmmbin/gmm-rescore-lattice.cpp; K/gmmbin/gmm-rescore-lattice.cc:28-115)
+int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
+  return Guard("gmm-rescore-lattice", &file_log, [&](Log &log) -> int {
+    Options po;
+    po.Know({"old-acoustic-scale"});
+    po.Parse(argc, argv);
+    if (po.args.size() != 4) throw ApiError("Wrong arguments.");
+    const float old_acoustic_scale = (float)po.Num("old-acoustic-scale", 0.0);
+    const Gmm gmm(po.args[0]);
+    const auto feats = ReadFeatureTable(po.args[2]);
+    vbio::LatticeReader reader(po.args[1]);
+    vbio::CompactLatticeWriter writer;
+    writer.Open(po.args[3]);
+    int num_done = 0, num_err = 0;
+    long long num_frames = 0;
+    std::string key; vblat::Lattice lat; vblat::CompactLattice clat; bool compact = false;
+    while (reader.Next(&key, &lat, &clat, &compact)) {
+      auto it = feats.find(key);
+      if (it == feats.end()) { log.os() << "WARNING (gmm-rescore-lattice) No feature found for utterance " << key << ". Skipping\n"; num_err++; continue; }
+      if (!compact) vblat::ConvertLattice(lat, &clat);          // CompactLatticeHolder::Read of a state-level lattice
+      if (old_acoustic_scale != 1.0f) vblat::ScaleLattice(1.0, 0.0, 0.0, (double)old_acoustic_scale, &clat);
+      const vbio::Matrix &f = it->second;
+      std::unordered_map<uint64_t, float> cache;       // (frame, pdf) -> log-likelihood
+      auto loglike = [&](int32_t t, int32_t tid) -> float {
+        if (tid <= 0 || tid >= (int32_t)gmm.m.tid2pdf.size()) throw ApiError("lattice: transition-id out of the model's range");
+        const int32_t pdf = gmm.m.tid2pdf[tid];
+        const uint64_t k = ((uint64_t)(uint32_t)t << 32) | (uint32_t)pdf;
+        auto c = cache.find(k);
+        if (c != cache.end()) return c->second;
+        const float v = gmm.LogLike(pdf, &f.data[(size_t)t * f.cols]);
+        cache.emplace(k, v);
+        return v;
+      };
+      if (f.cols != gmm.m.dim) throw ApiError("Dim mismatch: data dim = " + std::to_string(f.cols) + " vs. model dim = " + std::to_string(gmm.m.dim));
+      if (vblat::RescoreCompactLattice(loglike, f.rows, &clat)) { writer.Write(key, clat); num_done++; num_frames += f.rows; }
+      else { log.os() << "WARNING (gmm-rescore-lattice) lattice/feature mismatch for utterance " << key << "\n"; num_err++; }
+    }
+    log.os() << "LOG (gmm-rescore-lattice) Done " << num_done << " lattices with errors on " << num_err << ", #frames is " << num_frames << "\n";
+    return num_done != 0 ? 0 : 1;
+  });
+}
+
+extern "C" {
+int vb_LatticeToPost(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return LatticeToPost(argc, argv, l); }); }
+int vb_WeightSilencePost(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return WeightSilencePost(argc, argv, l); }); }
+int vb_GmmPostToGpost(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return GmmPostToGpost(argc, argv, l); }); }
+int vb_GmmEstFmllrGpost(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return GmmEstFmllrGpost(argc, argv, l); }); }
+int vb_GmmEstFmllr(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return GmmEstFmllr(argc, argv, l); }); }
+int vb_ComposeTransforms(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return ComposeTransforms(argc, argv, l); }); }
+int vb_GmmRescoreLattice(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return GmmRescoreLattice(argc, argv, l); }); }
+}

@@ -366,6 +366,148 @@ int Decode(const std::string &graph_dir, const std::string &data_dir, const std:
                        min_lmwt, max_lmwt, iter.empty() ? "final" : iter);
 }
 
+// ------------------------------------------------------------------------------------ DecodeFmllr
+// VB/scr/steps/decode_fmllr.cpp:91-760.  Every stage is the reference's chain of bin functions over
+// temporary archives in the job's split directory; the jobs run one after the other (they are
+// batches for one GPU here, see voicebridge_steps.h).
+int DecodeFmllr(const std::string &graphdir, const std::string &data, const std::string &dir, const std::string &alignment_model_in,
+                const std::string &adapt_model_in, const std::string &final_model_in, int nj, float acwt, int stage, int max_active, double beam,
+                double lattice_beam, double silence_weight, const std::string &si_dir_in, const std::string &fmllr_update_type, bool skip_scoring,
+                bool decode_mbr, bool stats, const std::string &word_ins_penalty, int min_lmwt, int max_lmwt) {
+  std::string si_dir = si_dir_in;
+  const int rc = Run([&] {
+    if (decode_mbr) throw StepError("MBR decoding (decode_mbr) is not part of this build");
+    if (nj < 1) throw StepError("nj must be >= 1");
+    const double first_beam = 10.0; const int first_max_active = 2000;      // decode_fmllr.cpp:116-117
+    const std::string srcdir = Parent(dir), sdata = Join(data, "split" + std::to_string(nj));
+    MakeDirs(Join(dir, "log"));
+    if (SplitData(data, nj, false) < 0) throw StepError("SplitData failed: " + g_err);
+    WriteLines(Join(dir, "num_jobs"), {std::to_string(nj)});
+    const std::string splice_opts = FirstLine(Join(srcdir, "splice_opts")), cmvn_opts = FirstLine(Join(srcdir, "cmvn_opts")),
+                      delta_opts = FirstLine(Join(srcdir, "delta_opts"));
+    const std::string silfile = Join(Join(graphdir, "phones"), "silence.csl");
+    const std::string silphonelist = FirstLine(silfile);
+    if (silphonelist.empty()) throw StepError(silfile + " is required but can not be found (or is empty).");
+    for (const std::string &f : {Join(graphdir, "HCLG.fst"), Join(data, "feats.scp")}) if (!Exists(f)) throw StepError("Failed to find " + f);
+    std::string alignment_model = alignment_model_in;
+    if (alignment_model.empty() || !Exists(alignment_model)) {
+      if (Exists(Join(srcdir, "final.alimdl"))) alignment_model = Join(srcdir, "final.alimdl");
+      else if (Exists(Join(srcdir, "final.mdl"))) alignment_model = Join(srcdir, "final.mdl");
+      else throw StepError("Failed to find alignment model.");
+    }
+    if (si_dir.empty() || !Exists(si_dir)) {
+      si_dir = dir;
+      while (si_dir.size() > 1 && si_dir.back() == '/') si_dir.pop_back();
+      si_dir += ".si";
+      if (stage <= 0) {
+        UMAPSS f1, f2;
+        if (Decode(graphdir, data, si_dir, alignment_model, "", f1, f2, "", nj, acwt, 0, first_max_active, first_beam, 6.0, skip_scoring, decode_mbr, stats,
+                   word_ins_penalty, min_lmwt, max_lmwt) < 0)
+          throw StepError("First pass speaker-independent decoding failed: " + g_err);
+      }
+    }
+    if (atoi(FirstLine(Join(si_dir, "num_jobs")).c_str()) != nj) throw StepError("Mismatch in number of jobs with si-dir.");
+    const std::string adapt_model = (adapt_model_in.empty() || !Exists(adapt_model_in)) ? Join(srcdir, "final.mdl") : adapt_model_in;
+    const std::string final_model = (final_model_in.empty() || !Exists(final_model_in)) ? Join(srcdir, "final.mdl") : final_model_in;
+    for (const std::string &f : {Join(si_dir, "lat.1"), adapt_model, final_model}) if (!Exists(f)) throw StepError("Failed to find " + f);
+    const bool lda = Exists(Join(srcdir, "final.mat"));
+    const std::string acw = "--acoustic-scale=" + std::to_string(acwt), symtab = Join(graphdir, "words.txt");
+    auto run = [&](const char *what, int (*fn)(int, char **, std::ofstream &), std::vector<std::string> a, std::ofstream &log, bool none_ok = false) {
+      Argv av(std::move(a));
+      const int r = fn(av.argc(), av.argv(), log);
+      if (r < 0 || (r != 0 && !none_ok)) throw StepError(std::string(what) + " failed (return code " + std::to_string(r) + "), see " + Join(dir, "log"));
+    };
+    for (int j = 1; j <= nj; j++) {
+      const std::string J = std::to_string(j), dsn = Join(sdata, J);
+      if (ReadLines(Join(dsn, "feats.scp"), false).empty()) continue;
+      std::ofstream log(Join(Join(dir, "log"), "fmllr." + J + ".log"), std::ios::binary);
+      // ---- speaker-independent features (decode_fmllr.cpp:275-311)
+      const std::string t_cmvn = Join(dsn, "apply_cmvn.temp"), t_si = Join(dsn, "sifeats.temp"), t_feat = Join(dsn, "transform_pass1feats.temp");
+      {
+        std::vector<std::string> c = {"apply-cmvn"};
+        for (const auto &o : SplitWords(cmvn_opts)) c.push_back(o);
+        c.insert(c.end(), {"--utt2spk=ark:" + Join(dsn, "utt2spk"), "scp:" + Join(dsn, "cmvn.scp"), "scp:" + Join(dsn, "feats.scp"), "ark:" + t_cmvn});
+        run("apply-cmvn", ApplyCmvn, c, log);
+        if (!lda) {
+          std::vector<std::string> dl = {"add-deltas"};
+          for (const auto &o : SplitWords(delta_opts)) dl.push_back(o);
+          dl.insert(dl.end(), {"ark:" + t_cmvn, "ark:" + t_si});
+          Argv a2(dl);
+          if (AddDeltas(a2.argc(), a2.argv()) < 0) throw StepError("add-deltas failed for job " + J);
+        } else {
+          const std::string t_spl = Join(dsn, "splice.temp");
+          std::vector<std::string> sp = {"splice-feats"};
+          for (const auto &o : SplitWords(splice_opts)) sp.push_back(o);
+          sp.insert(sp.end(), {"ark:" + t_cmvn, "ark:" + t_spl});
+          Argv a2(sp);
+          if (SpliceFeats(a2.argc(), a2.argv()) < 0) throw StepError("splice-feats failed for job " + J);
+          run("transform-feats", TransformFeats, {"transform-feats", Join(srcdir, "final.mat"), "ark:" + t_spl, "ark:" + t_si}, log);
+          unlink(t_spl.c_str());
+        }
+        unlink(t_cmvn.c_str());
+      }
+      const std::string pre_trans = Join(dir, "pre_trans." + J), trans = Join(dir, "trans." + J), lat_tmp = Join(dir, "lat.tmp." + J);
+      const std::string spk2utt = "--spk2utt=ark:" + Join(dsn, "spk2utt"), utt2spk = "--utt2spk=ark:" + Join(dsn, "utt2spk");
+      if (stage <= 1) {      // first-pass fMLLR from the SI lattices (:314-388)
+        const std::string t_post = Join(dsn, "post.temp"), t_wsp = Join(dsn, "wsp.temp"), t_gp = Join(dsn, "gpost.temp");
+        run("lattice-to-post", LatticeToPost, {"lattice-to-post", acw, "ark:" + Join(si_dir, "lat." + J), "ark:" + t_post}, log);
+        run("weight-silence-post", WeightSilencePost, {"weight-silence-post", std::to_string(silence_weight), silphonelist, alignment_model, "ark:" + t_post, "ark:" + t_wsp}, log);
+        run("gmm-post-to-gpost", GmmPostToGpost, {"gmm-post-to-gpost", alignment_model, "ark:" + t_si, "ark:" + t_wsp, "ark:" + t_gp}, log);
+        run("gmm-est-fmllr-gpost", GmmEstFmllrGpost, {"gmm-est-fmllr-gpost", "--fmllr-update-type=" + fmllr_update_type, spk2utt, adapt_model, "ark:" + t_si, "ark:" + t_gp, "ark:" + pre_trans}, log);
+        unlink(t_post.c_str()); unlink(t_wsp.c_str()); unlink(t_gp.c_str());
+      }
+      if (stage <= 2) {      // main search on the first-pass features (:390-489)
+        run("transform-feats", TransformFeats, {"transform-feats", utt2spk, "ark:" + pre_trans, "ark:" + t_si, "ark:" + t_feat}, log);
+        std::vector<std::string> g = {"gmm-latgen-faster", "--max-active=" + std::to_string(max_active), "--beam=" + std::to_string(beam),
+                                      "--lattice-beam=" + std::to_string(lattice_beam), acw, "--determinize-lattice=false", "--allow-partial=true"};
+        if (Exists(symtab)) g.push_back("--word-symbol-table=" + symtab);
+        g.insert(g.end(), {adapt_model, Join(graphdir, "HCLG.fst"), "ark:" + t_feat, "ark:" + lat_tmp});
+        run("gmm-latgen-faster", GmmLatgenFaster, g, log);
+      }
+      if (stage <= 3) {      // second fMLLR estimate, composed with the first (:491-566)
+        const std::string t_ldp = Join(dsn, "ldp.temp"), t_post = Join(dsn, "post.temp"), t_wsp = Join(dsn, "wsp.temp"), trans_tmp = Join(dir, "trans_tmp." + J);
+        run("transform-feats", TransformFeats, {"transform-feats", utt2spk, "ark:" + pre_trans, "ark:" + t_si, "ark:" + t_feat}, log);
+        run("lattice-determinize-pruned", LatticeDeterminizePruned, {"lattice-determinize-pruned", acw, "--beam=" + std::to_string(4.0), "ark:" + lat_tmp, "ark:" + t_ldp}, log);
+        run("lattice-to-post", LatticeToPost, {"lattice-to-post", acw, "ark:" + t_ldp, "ark:" + t_post}, log);
+        run("weight-silence-post", WeightSilencePost, {"weight-silence-post", std::to_string(silence_weight), silphonelist, adapt_model, "ark:" + t_post, "ark:" + t_wsp}, log);
+        run("gmm-est-fmllr", GmmEstFmllr, {"gmm-est-fmllr", "--fmllr-update-type=" + fmllr_update_type, spk2utt, adapt_model, "ark:" + t_feat, "ark:" + t_wsp, "ark:" + trans_tmp}, log);
+        run("compose-transforms", ComposeTransforms, {"compose-transforms", "--b-is-affine=true", "ark:" + trans_tmp, "ark:" + pre_trans, "ark:" + trans}, log);
+        unlink(t_ldp.c_str()); unlink(t_post.c_str()); unlink(t_wsp.c_str());
+      }
+      if (stage <= 4) {      // rescoring with the final model on the final features, determinization (:568-640)
+        const std::string t_grl = Join(dsn, "grl.temp");
+        run("transform-feats", TransformFeats, {"transform-feats", utt2spk, "ark:" + trans, "ark:" + t_si, "ark:" + t_feat}, log);
+        run("gmm-rescore-lattice", GmmRescoreLattice, {"gmm-rescore-lattice", final_model, "ark:" + lat_tmp, "ark:" + t_feat, "ark:" + t_grl}, log);
+        run("lattice-determinize-pruned", LatticeDeterminizePruned, {"lattice-determinize-pruned", acw, "--beam=" + std::to_string(lattice_beam), "ark:" + t_grl, "ark:" + Join(dir, "lat." + J)}, log);
+        unlink(t_grl.c_str()); unlink(lat_tmp.c_str());
+      }
+      unlink(t_si.c_str()); unlink(t_feat.c_str());
+    }
+  });
+  if (rc != 0) return rc;
+  if (!skip_scoring) {
+    UMAPSS f1, f2;
+    if (ScoreKaldiWER(data, graphdir, dir, f1, f2, nj, stage, decode_mbr, stats, beam, word_ins_penalty, min_lmwt, max_lmwt, "") < 0) return -1;
+  }
+  return Run([&] {       // words and transcripts of the final lattices (:642-745)
+    const std::string symtab = Join(graphdir, "words.txt");
+    for (int j = 1; j <= nj; j++) {
+      const std::string J = std::to_string(j);
+      if (!Exists(Join(dir, "lat." + J))) continue;
+      std::ofstream log(Join(Join(dir, "log"), "decode." + J + ".log"), std::ios::binary);
+      Argv a({"lattice-best-path", "ark:" + Join(dir, "lat." + J), "ark,t:" + Join(dir, "w." + J)});
+      if (LatticeBestPath(a.argc(), a.argv(), log) < 0) throw StepError("lattice-best-path failed for job " + J);
+      if (Exists(symtab)) {
+        const std::map<int, std::string> sym = ReadSymbolTable(symtab);
+        std::vector<std::string> out;
+        for (const auto &l : ReadLines(Join(dir, "w." + J), false)) out.push_back(Int2SymLine(sym, l));
+        WriteLines(Join(dir, "transcription" + J + ".trn"), out);
+      }
+      unlink(Join(dir, "trans_tmp." + J).c_str()); unlink(Join(dir, "pre_trans." + J).c_str());
+    }
+  });
+}
+
 // ------------------------------------------------------------------------------------ ScoreKaldiWER
 // VB/scr/steps/scoring/score_kaldi_wer.cpp:36-254 (+ :256-420 the per-LMWT job, VB/scr/utils/best_wer.cpp).
 // The lattices are read once; every (word insertion penalty, LM weight) pair scales, penalises and
@@ -486,6 +628,11 @@ int vb_DecodeEx(const char *graph_dir, const char *data_dir, const char *decode_
   UMAPSS a, b;
   return Decode(graph_dir, data_dir, decode_dir, model ? model : "", trans_dir ? trans_dir : "", a, b, "", nj, acwt, 0, max_active, beam, lattice_beam,
                 skip_scoring != 0, false, true, word_ins_penalty ? word_ins_penalty : "0.0,0.5,1.0", min_lmwt, max_lmwt);
+}
+int vb_DecodeFmllr(const char *graphdir, const char *data, const char *dir, int nj, float acwt, int max_active, double beam, double lattice_beam,
+                   double silence_weight, const char *si_dir, int skip_scoring, const char *word_ins_penalty, int min_lmwt, int max_lmwt) {
+  return DecodeFmllr(graphdir, data, dir, "", "", "", nj, acwt, 0, max_active, beam, lattice_beam, silence_weight, si_dir ? si_dir : "", "full",
+                     skip_scoring != 0, false, true, word_ins_penalty ? word_ins_penalty : "0.0,0.5,1.0", min_lmwt, max_lmwt);
 }
 int vb_ScoreKaldiWER(const char *data, const char *lang_or_graph, const char *dir, int nj, const char *word_ins_penalty, int min_lmwt,
                      int max_lmwt) {

@@ -46,6 +46,19 @@ int Decode(const std::string &graph_dir, const std::string &data_dir, const std:
            float acwt = 0.083333f, int stage = 0, int max_active = 7000, double beam = 13.0, double lattice_beam = 6.0,
            bool skip_scoring = false, bool decode_mbr = false, bool stats = true, const std::string &word_ins_penalty = "0.0,0.5,1.0",
            int min_lmwt = 7, int max_lmwt = 17);
+// scr/kaldi_scr.h:282-305  VOICEBRIDGE_API int DecodeFmllr(graphdir, data, dir, alignment_model, adapt_model, final_model, nj, acwt,
+//                          stage, max_active, beam, lattice_beam, silence_weight, si_dir, fmllr_update_type, skip_scoring, decode_mbr,
+//                          stats, word_ins_penalty, min_lmwt, max_lmwt)                     scr/steps/decode_fmllr.cpp:91-760
+// Speaker-adapted decoding: a speaker-independent pass (Decode with beam 10 / max-active 2000 into <dir>.si) -> fMLLR from its lattice
+// posteriors (pre_trans.JOB) -> main search on the transformed features (raw lattices lat.tmp.JOB) -> a second fMLLR estimate from the
+// pruned-determinized lattices, composed with the first (trans.JOB) -> acoustic rescoring with the final model on the final features ->
+// determinization (lat.JOB) -> best path (w.JOB, transcriptionJOB.trn) -> scoring.  The two searches and the feature pipeline run on
+// the GPU; posteriors, the fMLLR statistics/update, rescoring and determinization are host code this round.
+int DecodeFmllr(const std::string &graphdir, const std::string &data, const std::string &dir, const std::string &alignment_model = "",
+                const std::string &adapt_model = "", const std::string &final_model = "", int nj = 4, float acwt = 0.083333f, int stage = 0,
+                int max_active = 7000, double beam = 13.0, double lattice_beam = 6.0, double silence_weight = 0.01, const std::string &si_dir = "",
+                const std::string &fmllr_update_type = "full", bool skip_scoring = false, bool decode_mbr = false, bool stats = true,
+                const std::string &word_ins_penalty = "0.0,0.5,1.0", int min_lmwt = 7, int max_lmwt = 17);
 int ScoreKaldiWER(const std::string &data, const std::string &lang_or_graph, const std::string &dir, UMAPSS &wer_ref_filter,
                   UMAPSS &wer_hyp_filter, int nj, int stage = 0, bool decode_mbr = false, bool stats = true, double beam = 6,
                   const std::string &word_ins_penalty = "0.0,0.5,1.0", int min_lmwt = 7, int max_lmwt = 17, const std::string &iter = "final");
@@ -61,6 +74,8 @@ int vb_Decode(const char *graph_dir, const char *data_dir, const char *decode_di
 int vb_DecodeEx(const char *graph_dir, const char *data_dir, const char *decode_dir, const char *model, const char *trans_dir, int nj,
                 float acwt, int max_active, double beam, double lattice_beam, int skip_scoring, const char *word_ins_penalty,
                 int min_lmwt, int max_lmwt);
+int vb_DecodeFmllr(const char *graphdir, const char *data, const char *dir, int nj, float acwt, int max_active, double beam, double lattice_beam,
+                   double silence_weight, const char *si_dir, int skip_scoring, const char *word_ins_penalty, int min_lmwt, int max_lmwt);
 int vb_ScoreKaldiWER(const char *data, const char *lang_or_graph, const char *dir, int nj, const char *word_ins_penalty, int min_lmwt,
                      int max_lmwt);
 const char *vb_steps_last_error(void);
