@@ -20,16 +20,18 @@ def host():
     lib = C.CDLL(build.HOST_LIB)
     lib.vb_steps_last_error.restype = C.c_char_p
     lib.vb_Decode.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_float, C.c_int, C.c_double, C.c_double, C.c_int]
+    lib.vb_DecodeFmllr.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_float, C.c_int, C.c_double, C.c_double, C.c_double, C.c_char_p,
+                                   C.c_int, C.c_char_p, C.c_int, C.c_int]
     lib.vb_DecodeEx.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_float, C.c_int, C.c_double, C.c_double,
                                 C.c_int, C.c_char_p, C.c_int, C.c_int]
     return lib
 
 
-def make_datadir(d, n_utt=6, n_spk=3):
+def make_datadir(d, n_utt=6, n_spk=3, seconds=None):
     from voicebridge_amd import synth
     data = d / "data" / "test"
     data.mkdir(parents=True)
-    waves = [synth.wave(100 + i, seconds=0.6 + 0.15 * i) for i in range(n_utt)]
+    waves = [synth.wave(100 + i, seconds=(0.6 + 0.15 * i) if seconds is None else seconds + 0.1 * i) for i in range(n_utt)]
     write_wavs(data, waves)
     utts = ["utt%02d" % i for i in range(n_utt)]
     spk = ["spk%d" % (i * n_spk // n_utt) for i in range(n_utt)]
@@ -196,3 +198,67 @@ def test_decode_with_fmllr_transforms_and_scoring(host, tmp_path):
         ref("lattice-add-penalty", "--word-ins-penalty=0.5", "ark:%s" % (d / "rs.lat"), "ark:%s" % (d / "rp.lat"))
         ref("lattice-best-path", "ark:%s" % (d / "rp.lat"), "ark,t:%s" % (d / "rbp.txt"))
         assert (d / "rbp.txt").read_text().split() == (d / "bp.txt").read_text().split()
+
+
+def test_decode_fmllr_end_to_end(host, tmp_path):
+    """DecodeFmllr (VB/scr/steps/decode_fmllr.cpp:91-760; config 3 of SURVEY.md 8d end to end): SI pass,
+    fMLLR from its lattices, main search on the adapted features, second estimate, rescoring,
+    determinization, best path, scoring.  Per-stage parity with the reference's programs is
+    tests/test_host_fmllr.py; here: the files the reference leaves, transforms that are real updates,
+    and the adapted features fitting the model better than the speaker-independent ones."""
+    from tests import util
+    from voicebridge_amd import synth
+    d = tmp_path
+    data, conf, utts = make_datadir(d, n_utt=4, n_spk=2, seconds=4.5)      # well over 500 non-silence frames per speaker (fMLLR min-count)
+    assert host.vb_MakeMfcc(str(data).encode(), str(conf).encode(), 2, 1, 0) == 0, host.vb_steps_last_error()
+    assert host.vb_ComputeCmvnStatsDir(str(data).encode()) == 0
+    H, n_cd, n_words = 3, 10, 30
+    P = n_cd * H
+    g, _ = synth.lexicon_graph(n_words, P, seed=3, n_phones=n_cd)
+    offs, w, means, iv = synth.gmm_model(P, P * 3, 39, seed=4, mean_scale=1.5, var_spread=0.3)
+    exp = d / "exp" / "tri3"
+    graph = exp / "graph"
+    (graph / "phones").mkdir(parents=True)
+    util.write_mdl(str(exp / "final.mdl"), n_cd, H, offs, w, (means * iv).astype(np.float32), iv)
+    util.write_vector_fst(str(graph / "HCLG.fst"), g["final"], g["arc_offset"], g["arcs"])
+    (graph / "words.txt").write_text("<eps> 0\n" + "".join("w%d %d\n" % (i, i) for i in range(1, n_words + 2)))
+    (graph / "phones" / "silence.csl").write_text("1:2\n")
+    dec = exp / "decode_test"
+    args = [str(graph).encode(), str(data).encode(), str(dec).encode(), 2, 0.083333, 7000, 13.0, 6.0, 0.01, b""]
+    assert host.vb_DecodeFmllr(*args, 1, b"0.0,0.5", 9, 10) == 0, host.vb_steps_last_error()
+    si = exp / "decode_test.si"
+    assert (si / "lat.1").exists() and (si / "num_jobs").read_text().strip() == "2"
+    lats = {}
+    for j in (1, 2):
+        lats.update(util.read_lattice_ark(str(dec / ("lat.%d" % j))))
+        assert (dec / ("w.%d" % j)).exists() and (dec / ("transcription%d.trn" % j)).exists()
+        assert not (dec / ("lat.tmp.%d" % j)).exists() and not (dec / ("pre_trans.%d" % j)).exists()
+        assert not list((data / "split2" / str(j)).glob("*.temp"))
+    assert sorted(lats) == utts and all(v[0] == "compactlattice44" for v in lats.values())
+    from tests.test_host_io import read_fm_ark
+    trans = {}
+    for j in (1, 2):
+        trans.update(read_fm_ark(str(dec / ("trans.%d" % j))))
+    assert sorted(trans) == ["spk0", "spk1"]
+    for m in trans.values():
+        assert m.shape == (39, 40) and np.abs(m - np.eye(39, 40)).max() > 0.05 and np.isfinite(m).all()
+    # likelihood of the best path per frame: adapted pass above the speaker-independent pass
+    def like(logfile):
+        l = [x for x in open(logfile) if "Overall log-likelihood per frame is" in x][-1]
+        return float(l.split("per frame is")[1].split("over")[0])
+    si_like = np.mean([like(si / "log" / ("decode.%d.log" % j)) for j in (1, 2)])
+    ad_like = np.mean([like(dec / "log" / ("fmllr.%d.log" % j)) for j in (1, 2)])
+    assert ad_like > si_like
+    # second call with scoring, reusing the SI directory (si_dir argument): WER files of both LM weights
+    trn = dict(l.split(None, 1) if " " in l.strip() else (l.strip(), "") for j in (1, 2) for l in (dec / ("transcription%d.trn" % j)).read_text().split("\n") if l.strip())
+    (data / "text").write_text("".join("%s %s\n" % (u, trn[u].strip()) for u in utts))
+    args[-1] = str(si).encode()
+    assert host.vb_DecodeFmllr(*args, 0, b"0.0,0.5", 9, 10) == 0, host.vb_steps_last_error()
+    for wip in ("0.0", "0.5"):
+        for lmwt in (9, 10):
+            f = (dec / ("wer_%d_%s" % (lmwt, wip))).read_text().split()
+            assert len(f) == 9 and int(f[8]) == len(utts)
+    assert (dec / "scoring_kaldi" / "best_wer").exists()
+    # a missing silence list is an error
+    os.remove(graph / "phones" / "silence.csl")
+    assert host.vb_DecodeFmllr(*args, 1, b"0.0", 9, 9) == -1 and b"silence.csl" in host.vb_steps_last_error()
