@@ -228,6 +228,25 @@ int vbh_decoder_utt_timeline(vbh_decoder *d, int32_t utt, int64_t *out3);
  * lattice pool device->host, host-side canonical ordering + best path, whole call} */
 int vbh_decoder_times(vbh_decoder *d, float *out4);
 
+/* ---- fMLLR sufficient statistics.  Replaces, per batch of utterances,
+ * FmllrDiagGmmAccs::AccumulateForGmm / AccumulateFromPosteriors / CommitSingleFrameStats
+ * (K/transform/fmllr-diag-gmm.cc:30-44,100-113,562-596) as gmm-est-fmllr drives them
+ * (K/gmmbin/gmm-est-fmllr.cc:36-52): frame t of d_feats [T x dim] carries the posterior pairs
+ * [h_pair_offsets[t], h_pair_offsets[t+1]) of (pdf-id, weight) -- transition-id posteriors summed
+ * per pdf (ConvertPosteriorToPdfs, K/hmm/posterior.cc:322-346).  Component posteriors come from
+ * ali_gmm, the linear/quadratic terms from adapt_gmm (the same model twice for gmm-est-fmllr; the
+ * alignment model and the adaptation model for the gmm-post-to-gpost | gmm-est-fmllr-gpost pair of
+ * DecodeFmllr's first pass); the two models must have the same Gaussians per pdf.  h_utt2spk[u] in
+ * [0, n_spk) or -1 (utterance skipped).  Outputs on the host, double: h_beta [n_spk],
+ * h_K [n_spk][dim][dim+1], h_G [n_spk][dim][dim+1][dim+1] (full symmetric).  kernel_ms (optional):
+ * HIP-event duration of the accumulation kernel on the context's stream.  Synchronises. */
+int vbh_fmllr_accumulate(vbh_ctx *ctx, const vbh_gmm *ali_gmm, const vbh_gmm *adapt_gmm, const float *d_feats, int32_t n_utt,
+                         const int64_t *h_frame_offsets, const int32_t *h_utt2spk, int32_t n_spk, const int64_t *h_pair_offsets,
+                         const int32_t *h_pair_pdf, const float *h_pair_weight, double *h_beta, double *h_K, double *h_G,
+                         float *kernel_ms);
+/* algorithmic work of the accumulation kernel for T frames: bytes read, f64 flops issued */
+int vbh_fmllr_work(int32_t dim, int64_t T, double *bytes, double *flops);
+
 /* ---- FasterDecoder (K/decoder/faster-decoder.{h,cc}; the search of gmm-decode-faster,
  * VB/src/gmmbin/gmm-decode-faster.cpp): 1-best Viterbi beam search, no lattice.  Same graph and
  * score-matrix conventions as the lattice decoder above. */

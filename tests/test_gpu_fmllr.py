@@ -1,0 +1,138 @@
+"""GPU parity: fMLLR sufficient statistics (vbh_fmllr_accumulate, voicebridge_amd/csrc/vbh_fmllr.hip) against
+a double-precision restatement of FmllrDiagGmmAccs (K/transform/fmllr-diag-gmm.cc:30-44,100-113,562-596)
+in numpy, and -- through the bin function GmmEstFmllr, whose statistics come from this kernel -- against the
+transforms of the reference's gmm-est-fmllr (tests/golden/fmllr.npz).
+
+Tolerances: the per-frame terms a, b are float sums in a different order than the reference's BLAS calls and
+the products are accumulated in double in a different order: statistics 1e-5 relative to their scale,
+transforms 2e-4 absolute (entries O(1))."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from voicebridge_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def numpy_stats(offs, gconsts, miv, iv, feats, foff, utt2spk, n_spk, poff, ppdf, pw, ali=None):
+    D = feats.shape[1]
+    a_g, a_m, a_i = ali if ali is not None else (gconsts, miv, iv)
+    beta = np.zeros(n_spk); K = np.zeros((n_spk, D, D + 1)); G = np.zeros((n_spk, D, D + 1, D + 1))
+    for u in range(len(foff) - 1):
+        s = utt2spk[u]
+        if s < 0:
+            continue
+        for t in range(foff[u], foff[u + 1]):
+            x = feats[t].astype(np.float64)
+            xp = np.append(x, 1.0)
+            a = np.zeros(D); b = np.zeros(D); cnt = 0.0
+            for q in range(poff[t], poff[t + 1]):
+                p = ppdf[q]
+                g0, g1 = offs[p], offs[p + 1]
+                ll = a_g[g0:g1] + a_m[g0:g1].astype(np.float64) @ x - 0.5 * (a_i[g0:g1].astype(np.float64) @ (x * x))
+                post = np.exp(ll - ll.max()); post = post / post.sum() * pw[q]
+                cnt += post.sum(); a += post @ miv[g0:g1]; b += post @ iv[g0:g1]
+            beta[s] += cnt
+            K[s] += np.outer(a, xp)
+            G[s] += b[:, None, None] * np.outer(xp, xp)[None]
+    return beta, K, G
+
+
+@pytest.mark.parametrize("D,n_utt,n_spk,two_models", [(39, 5, 2, False), (40, 3, 3, True), (13, 2, 1, False)])
+def test_fmllr_stats_vs_numpy(ctx, D, n_utt, n_spk, two_models):
+    import torch
+    from voicebridge_amd import api, synth
+    rng = np.random.default_rng(D + n_utt)
+    P = 30
+    offs, w, means, iv = synth.gmm_model(P, 150, D, seed=D)
+    miv = (means * iv).astype(np.float32)
+    gmm = api.DiagGmm(ctx, offs, w, miv, iv)
+    ali, ali_arrays = None, None
+    if two_models:       # an "alignment model" with the same Gaussians per pdf and other parameters
+        means2 = means + 0.1 * rng.standard_normal(means.shape).astype(np.float32)
+        miv2 = (means2 * iv).astype(np.float32)
+        ali = api.DiagGmm(ctx, offs, w, miv2, iv)
+        ali_arrays = (ali.gconsts().astype(np.float64), miv2, iv)
+    lens = rng.integers(70, 333, n_utt)           # ragged: not multiples of the 64-frame stage or the 4-frame MFMA step
+    foff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    T = int(foff[-1])
+    feats = (rng.standard_normal((T, D)) * 1.2).astype(np.float32)
+    utt2spk = rng.integers(0, n_spk, n_utt).astype(np.int32)
+    if n_utt > 2:
+        utt2spk[1] = -1                             # a skipped utterance
+    npairs = rng.integers(0, 4, T)                 # frames without posteriors too
+    poff = np.concatenate([[0], np.cumsum(npairs)]).astype(np.int64)
+    ppdf = rng.integers(0, P, int(poff[-1])).astype(np.int32)
+    pw = rng.uniform(0.05, 1.0, int(poff[-1])).astype(np.float32)
+    beta, K, G, ms = gmm.fmllr_stats(torch.from_numpy(feats).to(ctx.device), foff, utt2spk, n_spk, poff, ppdf, pw, ali_gmm=ali)
+    rb, rK, rG = numpy_stats(offs, gmm.gconsts().astype(np.float64), miv, iv, feats, foff, utt2spk, n_spk, poff, ppdf, pw, ali=ali_arrays)
+    np.testing.assert_allclose(beta, rb, rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(K, rK, rtol=1e-5, atol=1e-5 * np.abs(rK).max())
+    np.testing.assert_allclose(G, rG, rtol=1e-5, atol=1e-5 * np.abs(rG).max())
+    assert np.array_equal(G, np.swapaxes(G, 2, 3))          # full symmetric matrices come back
+    gmm.close()
+    if ali:
+        ali.close()
+
+
+def test_gmm_est_fmllr_bin_function_vs_golden(tmp_path):
+    """GmmEstFmllr and the gmm-post-to-gpost | gmm-est-fmllr-gpost pair, both fed by the kernel: the transforms of the
+    reference's programs on the golden case"""
+    from tests.test_host_io import read_fm_ark
+    from tests.test_host_lattice import call
+    from voicebridge_amd import build
+    host = C.CDLL(build.HOST_LIB)
+    d = tmp_path
+    g = util.load("fmllr")
+    for k in ("file_final_mdl", "file_feats_ark", "file_wsp_ark", "file_trans_tmp_ark", "file_pre_trans_ark"):
+        name = k[5:].rsplit("_", 1)
+        (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
+    (d / "spk2utt").write_text(str(g["text_spk2utt"]))
+    log = str(d / "log.txt")
+    args = ["--fmllr-min-count=50", "--spk2utt=ark:%s" % (d / "spk2utt"), str(d / "final.mdl"), "ark:%s" % (d / "feats.ark"), "ark:%s" % (d / "wsp.ark")]
+    assert call(host.vb_GmmEstFmllr, ["gmm-est-fmllr"] + args + ["ark:%s" % (d / "m.ark")], log) == 0, open(log).read()
+    mine, want = read_fm_ark(str(d / "m.ark")), read_fm_ark(str(d / "trans_tmp.ark"))
+    assert list(mine) == list(want)
+    for k in want:
+        np.testing.assert_allclose(mine[k], want[k], atol=2e-4, rtol=0)
+    # per utterance (no --spk2utt)
+    assert call(host.vb_GmmEstFmllr, ["gmm-est-fmllr"] + args[:1] + args[2:] + ["ark:%s" % (d / "u.ark")], log) == 0, open(log).read()
+    assert list(read_fm_ark(str(d / "u.ark"))) == ["uttA", "uttB", "uttC", "uttD"]
+
+
+def test_fmllr_update_properties(tmp_path):
+    """properties of the estimate that do not depend on a reference run: below --fmllr-min-count the
+    unit transform is written; the update raises the auxiliary function (logged improvement > 0)"""
+    from tests.test_host_io import read_fm_ark
+    from tests.test_host_lattice import call
+    from voicebridge_amd import build
+    host = C.CDLL(build.HOST_LIB)
+    d = tmp_path
+    g = util.load("fmllr")
+    for k in ("file_final_mdl", "file_feats_ark", "file_wsp_ark"):
+        name = k[5:].rsplit("_", 1)
+        (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
+    (d / "spk2utt").write_text(str(g["text_spk2utt"]))
+    log = str(d / "log.txt")
+    base = ["gmm-est-fmllr", "--spk2utt=ark:%s" % (d / "spk2utt"), str(d / "final.mdl"), "ark:%s" % (d / "feats.ark"), "ark:%s" % (d / "wsp.ark")]
+    assert call(host.vb_GmmEstFmllr, base + ["ark:%s" % (d / "unit.ark")], log) == 0      # default min-count 500 > the ~270 frames per speaker
+    for m in read_fm_ark(str(d / "unit.ark")).values():
+        np.testing.assert_array_equal(m, np.eye(39, 40, dtype=np.float32))
+    assert "below min-count" in open(log).read()
+    os.remove(log)
+    assert call(host.vb_GmmEstFmllr, base[:1] + ["--fmllr-min-count=50"] + base[1:] + ["ark:%s" % (d / "t.ark")], log) == 0
+    imprs = [float(l.split("auxf-impr from fMLLR is")[1].split(",")[0]) for l in open(log) if "auxf-impr" in l]
+    assert len(imprs) == 2 and all(x > 0 for x in imprs)
+    assert call(host.vb_GmmEstFmllr, base[:1] + ["--fmllr-update-type=diag"] + base[1:] + ["ark:%s" % (d / "x.ark")], log) == -1    # refused, not ignored

@@ -99,7 +99,7 @@ def test_fmllr_chain_matches_golden(host, tmp_path):
             name = k[5:].rsplit("_", 1)
             (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
     (d / "spk2utt").write_text(str(g["text_spk2utt"]))
-    gg.run_fmllr_chain(str(d), mine_runner(host, d), "m_")
+    gg.run_fmllr_chain(str(d), mine_runner(host, d), "m_", trans_tmp_from="")      # gmm-est-fmllr itself: tests/test_gpu_fmllr.py
     compare_chain(d)
 
 
@@ -125,30 +125,6 @@ def test_lattice_to_compact_conversion_matches_golden(host, tmp_path):
                                             "ark:%s" % (d / "m2.ark")], log) == 1
 
 
-def test_fmllr_update_properties(host, tmp_path):
-    """properties of the estimate that do not depend on a reference run: below --fmllr-min-count the
-    unit transform is written; the update raises the auxiliary function (logged improvement > 0)"""
-    import sys
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    d = tmp_path
-    g = util.load("fmllr")
-    for k in ("file_final_mdl", "file_feats_ark", "file_wsp_ark"):
-        name = k[5:].rsplit("_", 1)
-        (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
-    (d / "spk2utt").write_text(str(g["text_spk2utt"]))
-    log = str(d / "log.txt")
-    base = ["gmm-est-fmllr", "--spk2utt=ark:%s" % (d / "spk2utt"), str(d / "final.mdl"), "ark:%s" % (d / "feats.ark"), "ark:%s" % (d / "wsp.ark")]
-    assert call(host.vb_GmmEstFmllr, base + ["ark:%s" % (d / "unit.ark")], log) == 0      # default min-count 500 > the ~270 frames per speaker
-    for m in read_fm_ark(str(d / "unit.ark")).values():
-        np.testing.assert_array_equal(m, np.eye(39, 40, dtype=np.float32))
-    assert "below min-count" in open(log).read()
-    os.remove(log)
-    assert call(host.vb_GmmEstFmllr, base[:1] + ["--fmllr-min-count=50"] + base[1:] + ["ark:%s" % (d / "t.ark")], log) == 0
-    imprs = [float(l.split("auxf-impr from fMLLR is")[1].split(",")[0]) for l in open(log) if "auxf-impr" in l]
-    assert len(imprs) == 2 and all(x > 0 for x in imprs)
-    assert call(host.vb_GmmEstFmllr, base[:1] + ["--fmllr-update-type=diag"] + base[1:] + ["ark:%s" % (d / "x.ark")], log) == -1    # refused, not ignored
-
-
 @pytest.mark.skipif(not all(os.access(os.path.join(REFBIN, b), os.X_OK) for b in NEEDED), reason="oracle/_ref/bin not built")
 def test_fresh_case_vs_reference_programs(host, tmp_path):
     import sys
@@ -157,5 +133,5 @@ def test_fresh_case_vs_reference_programs(host, tmp_path):
     d = tmp_path
     gg.make_fmllr_case(str(d), seed=17, frames=(210, 95, 160, 140))
     gg.run_fmllr_chain(str(d), gg.ref, "r_")
-    gg.run_fmllr_chain(str(d), mine_runner(host, d), "m_")
+    gg.run_fmllr_chain(str(d), mine_runner(host, d), "m_", trans_tmp_from="r_")
     compare_chain(d, "m_", "r_")

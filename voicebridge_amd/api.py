@@ -225,6 +225,24 @@ class DiagGmm:
         self.lib.vbh_gmm_work(self.h, int(T), C.byref(b), C.byref(f))
         return b.value, f.value
 
+    def fmllr_stats(self, d_feats, frame_offsets, utt2spk, n_spk, pair_offsets, pair_pdf, pair_weight, ali_gmm=None):
+        """fMLLR sufficient statistics of a batch (vbh_fmllr_accumulate): returns (beta [S], K [S, D, D+1],
+        G [S, D, D+1, D+1]) as float64 arrays and the accumulation kernel's HIP-event time in ms."""
+        foff = np.ascontiguousarray(frame_offsets, np.int64)
+        u2s = np.ascontiguousarray(utt2spk, np.int32)
+        poff = np.ascontiguousarray(pair_offsets, np.int64)
+        ppdf = np.ascontiguousarray(pair_pdf, np.int32)
+        pw = np.ascontiguousarray(pair_weight, np.float32)
+        D = self.dim
+        beta = np.zeros(n_spk, np.float64); K = np.zeros((n_spk, D, D + 1), np.float64); G = np.zeros((n_spk, D, D + 1, D + 1), np.float64)
+        ms = C.c_float()
+        fn = self.lib.vbh_fmllr_accumulate
+        fn.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 6 + [C.POINTER(C.c_float)]
+        check(fn(self.ctx.h, (ali_gmm or self).h, self.h, d_feats.data_ptr(), len(foff) - 1, foff.ctypes.data, u2s.ctypes.data, int(n_spk),
+                 poff.ctypes.data, ppdf.ctypes.data, pw.ctypes.data, beta.ctypes.data, K.ctypes.data, G.ctypes.data, C.byref(ms)),
+              "vbh_fmllr_accumulate")
+        return beta, K, G, ms.value
+
     def close(self):
         if self.h:
             self.lib.vbh_gmm_destroy(self.h)

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvoicebridge_hip.so")
-HIP_SOURCES = ["vbh_ctx.hip", "vbh_mfcc.hip", "vbh_featpost.hip", "vbh_gmm.hip", "vbh_decode.hip", "vbh_faster.hip"]
+HIP_SOURCES = ["vbh_ctx.hip", "vbh_mfcc.hip", "vbh_featpost.hip", "vbh_gmm.hip", "vbh_decode.hip", "vbh_faster.hip", "vbh_fmllr.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 

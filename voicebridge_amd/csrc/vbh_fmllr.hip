@@ -1,0 +1,268 @@
+// vbh_fmllr.hip -- fMLLR sufficient statistics on gfx950.
+//
+// Replaces (paths relative to /root/reference/kaldi-master/src/):
+//   transform/fmllr-diag-gmm.cc:100-113   FmllrDiagGmmAccs::AccumulateForGmm (component posteriors of a pdf by
+//                                          soft-max of its per-Gaussian log-likelihoods, gmm/diag-gmm.cc:528-543,601-615)
+//   transform/fmllr-diag-gmm.cc:30-44     AccumulateFromPosteriors: per frame a = sum_g gamma_g miv_g, b = sum_g gamma_g iv_g (float)
+//   transform/fmllr-diag-gmm.cc:562-596   CommitSingleFrameStats: beta += count, K += a x+^T, G_d += b[d] x+ x+^T (double)
+//   gmmbin/gmm-est-fmllr.cc:36-52         AccumulateForUtterance (posteriors on transition-ids summed per pdf)
+//
+// Two kernels.
+//   fmllr_frame_stats_kernel: one wave per frame, lane = feature dimension; the frame's (pdf, weight) pairs are
+//     walked, per-Gaussian log-likelihoods are wave reductions, a/b/count leave as [T x D] / [T] float arrays.
+//     Bytes per frame: 4D in + 8D + 4 out + the touched Gaussians (2 x 4D each, L2-resident model); HBM-bound, tiny.
+//   fmllr_accumulate_kernel: the dense part.  Per speaker  G[d][i][j] = sum_t b_t[d] x+_t[i] x+_t[j]  is the
+//     contraction  [D x T] . [T x (D+1)^2]  in double: v_mfma_f64_16x16x4_f64 with A = b (rows d), B built on the
+//     fly as x+[i] * x+[j] (the product of two floats is exact in double), only the tiles of the lower triangle
+//     (72 of 120 column tiles at D = 39).  A workgroup owns one slice of one speaker's frames and one group of 24
+//     column tiles, keeps 18 accumulator tiles per wave in registers over the whole slice and adds them to the
+//     speaker's statistics with f64 atomics once at the end.  K = sum_t a_t x+_t^T and beta = sum_t count_t ride
+//     along as one more group of column tiles.
+//     Roofline: f64 MFMA.  Flops per frame = 2 * 48 * 16 * (72 + 3) = 115 200 (padded rows included);
+//     bytes per frame = 4 * (D + 2D + 1) = 472: arithmetic intensity 244 flop/B, far above the f64 ridge (~10).
+#include "vbh_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+constexpr int TF = 64;          // frames staged in LDS per step
+constexpr int NTW = 6;          // column tiles per wave
+constexpr int XLD = 49;         // padded row of the x+ image (48 columns used: 40 real + zeros)
+constexpr int ALD = 49;         // padded row of the a / b image (48 rows of the MFMA M dimension)
+
+struct Seg { long long row0; int nrows; int pad; };
+struct Slice { int spk, seg_begin, seg_end, pad; };
+struct ColTile { int type, i, j0, pad; };      // type 0: G tile (x+[i] * x+[j0..j0+15]); 1: K tile (x+[j0..j0+15]); -1: none
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// per-Gaussian log-likelihood of the frame held one dimension per lane (lanes >= D hold zeros)
+__device__ __forceinline__ float gauss_loglike(const float *__restrict__ gconsts, const float *__restrict__ miv, const float *__restrict__ iv,
+                                               int g, int D, int lane, float x, float x2) {
+  float lin = 0.f, quad = 0.f;
+  if (lane < D) { lin = miv[(size_t)g * D + lane] * x; quad = iv[(size_t)g * D + lane] * x2; }
+  lin = wave_sum(lin); quad = wave_sum(quad);
+  return (gconsts[g] + lin) + -0.5f * quad;
+}
+
+__global__ __launch_bounds__(256) void fmllr_frame_stats_kernel(
+    const float *__restrict__ feats, long long T, int D,
+    const long long *__restrict__ pair_off, const int *__restrict__ pair_pdf, const float *__restrict__ pair_w,
+    const int *__restrict__ pdf_offs, const float *__restrict__ ali_gconsts, const float *__restrict__ ali_miv, const float *__restrict__ ali_iv,
+    const float *__restrict__ miv, const float *__restrict__ iv,
+    float *__restrict__ a_out, float *__restrict__ b_out, float *__restrict__ count_out) {
+  const int lane = threadIdx.x & 63;
+  const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const float x = lane < D ? feats[t * D + lane] : 0.f, x2 = x * x;
+  float a = 0.f, b = 0.f, count = 0.f;
+  for (long long q = pair_off[t]; q < pair_off[t + 1]; q++) {
+    const int p = pair_pdf[q];
+    const float w = pair_w[q];
+    const int g0 = pdf_offs[p], g1 = pdf_offs[p + 1];
+    float mx = -INFINITY;
+    for (int g = g0; g < g1; g++) mx = fmaxf(mx, gauss_loglike(ali_gconsts, ali_miv, ali_iv, g, D, lane, x, x2));
+    float sum = 0.f;
+    for (int g = g0; g < g1; g++) sum += expf(gauss_loglike(ali_gconsts, ali_miv, ali_iv, g, D, lane, x, x2) - mx);
+    const float inv = 1.0f / sum;
+    for (int g = g0; g < g1; g++) {
+      const float post = expf(gauss_loglike(ali_gconsts, ali_miv, ali_iv, g, D, lane, x, x2) - mx) * inv * w;
+      count += post;
+      if (lane < D) { a += post * miv[(size_t)g * D + lane]; b += post * iv[(size_t)g * D + lane]; }
+    }
+  }
+  if (lane < D) { a_out[t * D + lane] = a; b_out[t * D + lane] = b; }
+  if (lane == 0) count_out[t] = count;
+}
+
+__global__ __launch_bounds__(256) void fmllr_accumulate_kernel(
+    const float *__restrict__ feats, const float *__restrict__ a_in, const float *__restrict__ b_in, const float *__restrict__ count_in, int D,
+    const Slice *__restrict__ slices, const Seg *__restrict__ segs, const ColTile *__restrict__ tiles,
+    double *__restrict__ beta, double *__restrict__ K, double *__restrict__ G) {
+  __shared__ double sX[TF * XLD];     // x+ of the staged frames, columns >= D+1 zero
+  __shared__ double sA[TF * ALD];     // b (G tiles) or a (K tiles) of the staged frames, columns >= D zero
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n1 = D + 1;
+  const Slice sl = slices[blockIdx.x];
+  const bool kgroup = blockIdx.y == gridDim.y - 1;   // the last group of column tiles holds K (and beta)
+  const float *__restrict__ asrc = kgroup ? a_in : b_in;
+  ColTile ct[NTW];
+#pragma unroll
+  for (int q = 0; q < NTW; q++) ct[q] = tiles[(blockIdx.y * 4 + wid) * NTW + q];
+  f64x4 acc[NTW][3];
+#pragma unroll
+  for (int q = 0; q < NTW; q++)
+#pragma unroll
+    for (int m = 0; m < 3; m++) acc[q][m] = f64x4{0.0, 0.0, 0.0, 0.0};
+  double cnt = 0.0;
+  const int r = lane & 15, kk = lane >> 4;
+  for (int sg = sl.seg_begin; sg < sl.seg_end; sg++) {
+    const Seg seg = segs[sg];
+    for (int f0 = 0; f0 < seg.nrows; f0 += TF) {
+      const int nf = min(TF, seg.nrows - f0);
+      __syncthreads();        // the previous step's readers are done
+      for (int idx = tid; idx < TF * 48; idx += 256) {
+        const int f = idx / 48, c = idx - f * 48;
+        const long long row = seg.row0 + f0 + f;
+        double xv = 0.0, av = 0.0;
+        if (f < nf) {
+          if (c < D) { xv = (double)feats[row * D + c]; av = (double)asrc[row * D + c]; }
+          else if (c == D) xv = 1.0;
+        }
+        sX[f * XLD + c] = xv;
+        sA[f * ALD + c] = av;
+      }
+      if (kgroup && wid == 1) for (int f = lane; f < nf; f += 64) cnt += (double)count_in[seg.row0 + f0 + f];
+      __syncthreads();
+      for (int k0 = 0; k0 < TF; k0 += 4) {
+        if (k0 >= nf) break;                       // (uniform) the rest of the stage is zeros
+        const double *xr = &sX[(k0 + kk) * XLD], *ar = &sA[(k0 + kk) * ALD];
+        const double a0 = ar[r], a1 = ar[16 + r], a2 = ar[32 + r];
+#pragma unroll
+        for (int q = 0; q < NTW; q++) {
+          if (ct[q].type < 0) continue;            // wave-uniform
+          const double xj = xr[ct[q].j0 + r];
+          const double bv = ct[q].type == 0 ? xr[ct[q].i] * xj : xj;
+          acc[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[q][0], 0, 0, 0);
+          acc[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[q][1], 0, 0, 0);
+          acc[q][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, bv, acc[q][2], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- add this slice's tiles to the speaker's statistics.  C/D map of the f64 MFMA: col = lane & 15,
+  //      row = (lane >> 4) + 4 * reg
+  double *Gs = G + (size_t)sl.spk * D * n1 * n1, *Ks = K + (size_t)sl.spk * D * n1;
+#pragma unroll
+  for (int q = 0; q < NTW; q++) {
+    if (ct[q].type < 0) continue;
+    const int j = ct[q].j0 + r;
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int d = m * 16 + kk + 4 * v;
+        const double val = acc[q][m][v];
+        if (d >= D || j >= n1 || val == 0.0) continue;
+        if (ct[q].type == 0) { if (j <= ct[q].i) atomicAdd(&Gs[((size_t)d * n1 + ct[q].i) * n1 + j], val); }
+        else atomicAdd(&Ks[(size_t)d * n1 + j], val);
+      }
+  }
+  if (kgroup && wid == 1) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0 && cnt != 0.0) atomicAdd(&beta[sl.spk], cnt);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vbh_fmllr_work(int32_t dim, int64_t T, double *bytes, double *flops) {
+  const int n1 = dim + 1;
+  int g_tiles = 0;
+  for (int i = 0; i < n1; i++) for (int jt = 0; jt * 16 < n1; jt++) if (jt * 16 <= i) g_tiles++;
+  const int k_tiles = (n1 + 15) / 16, row_tiles = (dim + 15) / 16;
+  if (flops) *flops = (double)T * 2.0 * 16.0 * 16.0 * row_tiles * (g_tiles + k_tiles);
+  if (bytes) *bytes = (double)T * 4.0 * (3.0 * dim + 1.0);
+  return 0;
+}
+
+int vbh_fmllr_accumulate(vbh_ctx *ctx, const vbh_gmm *ali_gmm, const vbh_gmm *adapt_gmm, const float *d_feats, int32_t n_utt,
+                         const int64_t *h_frame_offsets, const int32_t *h_utt2spk, int32_t n_spk, const int64_t *h_pair_offsets,
+                         const int32_t *h_pair_pdf, const float *h_pair_weight, double *h_beta, double *h_K, double *h_G,
+                         float *kernel_ms) {
+  VBH_CHECK(ctx && ali_gmm && adapt_gmm && d_feats && h_frame_offsets && h_utt2spk && h_pair_offsets && h_beta && h_K && h_G,
+            "vbh_fmllr_accumulate: NULL argument");
+  VBH_CHECK(n_utt >= 1 && n_spk >= 1, "vbh_fmllr_accumulate: empty batch");
+  if (vbh_use_device(ctx)) return -1;
+  vbh_gmm_view va, vm;
+  vbh_gmm_view_get(ali_gmm, &va);
+  vbh_gmm_view_get(adapt_gmm, &vm);
+  VBH_CHECK(va.D == vm.D && va.P == vm.P && va.G == vm.G, "vbh_fmllr_accumulate: the two models differ in shape");
+  const int D = vm.D, n1 = D + 1;
+  VBH_CHECK(D >= 1 && D <= 47, "vbh_fmllr_accumulate: dim %d out of range [1,47]", D);
+  const long long T = h_frame_offsets[n_utt];
+  VBH_CHECK(T >= 1, "vbh_fmllr_accumulate: no frames");
+  const long long n_pairs = h_pair_offsets[T];
+  for (long long q = 0; q < n_pairs; q++) VBH_CHECK(h_pair_pdf[q] >= 0 && h_pair_pdf[q] < vm.P, "vbh_fmllr_accumulate: pdf-id out of range");
+  for (int u = 0; u < n_utt; u++) VBH_CHECK(h_utt2spk[u] >= -1 && h_utt2spk[u] < n_spk, "vbh_fmllr_accumulate: speaker index out of range");
+  // ---- column tiles: lower triangle of the (D+1) x (D+1) scatter, then K
+  std::vector<ColTile> tiles;
+  for (int i = 0; i < n1; i++) for (int jt = 0; jt * 16 < n1; jt++) if (jt * 16 <= i) tiles.push_back(ColTile{0, i, jt * 16, 0});
+  const int per_group = 4 * NTW;                  // column tiles of one workgroup (4 waves)
+  const int g_groups = ((int)tiles.size() + per_group - 1) / per_group;       // 3 at D = 39 (72 tiles), 4 up to D = 47
+  tiles.resize((size_t)g_groups * per_group, ColTile{-1, 0, 0, 0});
+  for (int jt = 0; jt * 16 < n1; jt++) tiles.push_back(ColTile{1, 0, jt * 16, 0});
+  tiles.resize((size_t)(g_groups + 1) * per_group, ColTile{-1, 0, 0, 0});
+  // ---- slices: every speaker's frames cut into pieces so that the grid fills the chip
+  std::vector<std::vector<int>> spk_utts(n_spk);
+  std::vector<long long> spk_frames(n_spk, 0);
+  for (int u = 0; u < n_utt; u++) if (h_utt2spk[u] >= 0) { spk_utts[h_utt2spk[u]].push_back(u); spk_frames[h_utt2spk[u]] += h_frame_offsets[u + 1] - h_frame_offsets[u]; }
+  const long long want_slices = 2LL * ctx->num_cus;
+  long long total = 0;
+  for (long long f : spk_frames) total += f;
+  const long long per_slice = std::max<long long>(4 * TF, ((total + want_slices - 1) / want_slices + TF - 1) / TF * TF);
+  std::vector<Seg> segs;
+  std::vector<Slice> slices;
+  for (int s = 0; s < n_spk; s++) {
+    long long in_slice = 0;
+    int seg_begin = (int)segs.size();
+    for (int u : spk_utts[s]) {
+      long long row = h_frame_offsets[u], left = h_frame_offsets[u + 1] - row;
+      while (left > 0) {
+        const long long take = std::min(left, per_slice - in_slice);
+        segs.push_back(Seg{row, (int)take, 0});
+        row += take; left -= take; in_slice += take;
+        if (in_slice == per_slice) { slices.push_back(Slice{s, seg_begin, (int)segs.size(), 0}); seg_begin = (int)segs.size(); in_slice = 0; }
+      }
+    }
+    if ((int)segs.size() > seg_begin) slices.push_back(Slice{s, seg_begin, (int)segs.size(), 0});
+  }
+  VBH_CHECK(!slices.empty(), "vbh_fmllr_accumulate: no frames assigned to a speaker");
+  hipStream_t st = ctx->stream;
+  DevBuf<long long> d_poff; DevBuf<int> d_ppdf; DevBuf<float> d_pw, d_a, d_b, d_cnt; DevBuf<Seg> d_segs; DevBuf<Slice> d_slices; DevBuf<ColTile> d_tiles;
+  DevBuf<double> d_beta, d_K, d_G;
+  static_assert(sizeof(long long) == sizeof(int64_t), "int64");
+  if (d_poff.upload(reinterpret_cast<const long long *>(h_pair_offsets), (size_t)T + 1, st) || d_ppdf.upload(h_pair_pdf, (size_t)std::max<long long>(n_pairs, 1), st) ||
+      d_pw.upload(h_pair_weight, (size_t)std::max<long long>(n_pairs, 1), st) || d_a.alloc((size_t)T * D) || d_b.alloc((size_t)T * D) || d_cnt.alloc((size_t)T) ||
+      d_segs.upload(segs.data(), segs.size(), st) || d_slices.upload(slices.data(), slices.size(), st) || d_tiles.upload(tiles.data(), tiles.size(), st) ||
+      d_beta.alloc(n_spk) || d_K.alloc((size_t)n_spk * D * n1) || d_G.alloc((size_t)n_spk * D * n1 * n1))
+    return -1;
+  VBH_HIP(hipMemsetAsync(d_beta.p, 0, sizeof(double) * n_spk, st));
+  VBH_HIP(hipMemsetAsync(d_K.p, 0, sizeof(double) * (size_t)n_spk * D * n1, st));
+  VBH_HIP(hipMemsetAsync(d_G.p, 0, sizeof(double) * (size_t)n_spk * D * n1 * n1, st));
+  const long long fblocks = (T + 3) / 4;
+  VBH_CHECK(fblocks < 2147483647LL, "vbh_fmllr_accumulate: too many frames");
+  hipLaunchKernelGGL(fmllr_frame_stats_kernel, dim3((unsigned)fblocks), dim3(256), 0, st, d_feats, T, D, d_poff.p, d_ppdf.p, d_pw.p, va.pdf_offs,
+                     va.gconsts, va.miv, va.iv, vm.miv, vm.iv, d_a.p, d_b.p, d_cnt.p);
+  VBH_HIP(hipGetLastError());
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (kernel_ms) { VBH_HIP(hipEventCreate(&e0)); VBH_HIP(hipEventCreate(&e1)); VBH_HIP(hipEventRecord(e0, st)); }
+  hipLaunchKernelGGL(fmllr_accumulate_kernel, dim3((unsigned)slices.size(), g_groups + 1), dim3(256), 0, st, d_feats, d_a.p, d_b.p, d_cnt.p, D, d_slices.p, d_segs.p,
+                     d_tiles.p, d_beta.p, d_K.p, d_G.p);
+  VBH_HIP(hipGetLastError());
+  if (kernel_ms) VBH_HIP(hipEventRecord(e1, st));
+  VBH_HIP(hipMemcpyAsync(h_beta, d_beta.p, sizeof(double) * n_spk, hipMemcpyDeviceToHost, st));
+  VBH_HIP(hipMemcpyAsync(h_K, d_K.p, sizeof(double) * (size_t)n_spk * D * n1, hipMemcpyDeviceToHost, st));
+  VBH_HIP(hipMemcpyAsync(h_G, d_G.p, sizeof(double) * (size_t)n_spk * D * n1 * n1, hipMemcpyDeviceToHost, st));
+  VBH_HIP(hipStreamSynchronize(st));
+  if (kernel_ms) { VBH_HIP(hipEventElapsedTime(kernel_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+  // the kernel fills the lower triangles (j <= i); mirror them
+  for (size_t m = 0; m < (size_t)n_spk * D; m++) {
+    double *g = h_G + m * n1 * n1;
+    for (int i = 0; i < n1; i++) for (int j = i + 1; j < n1; j++) g[(size_t)i * n1 + j] = g[(size_t)j * n1 + i];
+  }
+  return 0;
+}
+
+}  // extern "C"

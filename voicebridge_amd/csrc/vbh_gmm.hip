@@ -254,7 +254,16 @@ struct vbh_gmm {
   DevBuf<int> d_pdf_parts;        // [P+1] first part of every pdf
   DevBuf<float> part_scratch;     // [part_chunk x n_parts]
   long long part_chunk;
+  // plain row-major copies for the kernels that walk single pdfs (fMLLR statistics, vbh_fmllr.hip)
+  DevBuf<float> d_miv, d_iv, d_gconsts;   // [G x D], [G x D], [G]
+  DevBuf<int> d_pdf_offs;                 // [P+1]
 };
+
+void vbh_gmm_view_get(const vbh_gmm *g, vbh_gmm_view *v) {
+  v->D = g->D; v->P = g->P; v->G = g->G;
+  v->pdf_offs = g->d_pdf_offs.p; v->gconsts = g->d_gconsts.p; v->miv = g->d_miv.p; v->iv = g->d_iv.p;
+  v->ctx = g->ctx;
+}
 
 extern "C" {
 
@@ -327,6 +336,8 @@ int vbh_gmm_create(vbh_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h
   hipStream_t s = ctx->stream;
   if (g->Bp.upload(Bp.data(), Bp.size(), s) || g->tiles.upload(tiles.data(), tiles.size(), s) ||
       g->d_offs.upload(g->part_offs.data(), g->part_offs.size(), s)) { delete g; return -1; }
+  if (g->d_miv.upload(h_miv, (size_t)G * D, s) || g->d_iv.upload(h_iv, (size_t)G * D, s) || g->d_gconsts.upload(g->gconsts.data(), G, s) ||
+      g->d_pdf_offs.upload(g->offs.data(), g->offs.size(), s)) { delete g; return -1; }
   g->part_chunk = 0;
   if (NP > P) {
     // scratch for the parts of a chunk of frames (<= 256 MB), a multiple of the frame tile

@@ -111,4 +111,12 @@ void vbh_graph_view_get(const vbh_graph *g, vbh_graph_view *v);
 // make the arcs' pdf fields hold h_t2p[ilabel] (no-op when they already do); h_t2p[0] is ignored
 int vbh_graph_fill_pdf(const vbh_graph *g, hipStream_t st, const int32_t *h_t2p, int32_t num_tids);
 
+// what another translation unit needs of a vbh_gmm (defined in vbh_gmm.hip): row-major model arrays on the device
+struct vbh_gmm_view {
+  int D, P, G;
+  const int *pdf_offs; const float *gconsts, *miv, *iv;
+  vbh_ctx *ctx;
+};
+void vbh_gmm_view_get(const vbh_gmm *g, vbh_gmm_view *v);
+
 #endif  // VBH_INTERNAL_H_

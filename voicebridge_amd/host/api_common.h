@@ -105,5 +105,7 @@ int WithLog(const char *log_path, F f) {
 // the raw lattice of a search result (defined in voicebridge_api.cc)
 struct vbh_lattice;
 namespace vblat { struct Lattice; }
+struct vbh_ctx;
+namespace vbapi { vbh_ctx *SharedCtx(); }      // the calling thread's GPU context (vb_set_device), created on first use
 namespace vbapi { void RawLatticeFromResult(const vbh_lattice &L, int32_t graph_start, vblat::Lattice *lat); }
 #endif

@@ -94,6 +94,14 @@ void FmllrAccs::Commit() {       // CommitSingleFrameStats (fmllr-diag-gmm.cc:56
   std::fill(b_.begin(), b_.end(), 0.0f);
 }
 
+void FmllrAccs::AddStats(double beta, const double *K, const double *G) {
+  Commit();
+  const int n1 = dim_ + 1;
+  beta_ += beta;
+  for (size_t i = 0; i < K_.size(); i++) K_[i] += K[i];
+  for (int d = 0; d < dim_; d++) for (size_t i = 0; i < (size_t)n1 * n1; i++) G_[d][i] += G[(size_t)d * n1 * n1 + i];
+}
+
 void FmllrAccs::AccumulateFromPosteriors(const PdfView &pdf, const float *x, const float *post) {
   if (!have_x_ || memcmp(x, x_.data(), sizeof(float) * dim_) != 0) {     // DataHasChanged
     Commit();

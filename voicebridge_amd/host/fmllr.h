@@ -39,6 +39,8 @@ class FmllrAccs {
   float Update(const FmllrOptions &opts, float *xform, float *count);
   double beta() const { return beta_; }
   void Commit();
+  // statistics accumulated elsewhere (vbh_fmllr_accumulate): added to this object's; K [dim][dim+1], G [dim][dim+1][dim+1] full symmetric
+  void AddStats(double beta, const double *K, const double *G);
  private:
   int dim_;
   double beta_;

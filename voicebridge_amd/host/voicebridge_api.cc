@@ -128,6 +128,8 @@ int WindowType(const std::string &s) {
 }  // namespace
 
 // =====================================================================================
+vbh_ctx *vbapi::SharedCtx() { return Ctx(); }
+
 // GetRawLattice (K/decoder/lattice-faster-decoder.cc:110-192) from a search result: one state per
 // token (state 0 = the start token), arc weights (graph, acoustic - cost_offset), acoustic costs
 // still scaled, final weights (final cost, 0)

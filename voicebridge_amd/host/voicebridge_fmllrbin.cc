@@ -15,6 +15,7 @@
 #include "kaldi_io.h"
 #include "lattice.h"
 #include "voicebridge_api.h"
+#include "voicebridge_hip.h"
 
 using namespace vbapi;
 
@@ -280,26 +281,94 @@ int GmmEstFmllrGpost(int argc, char *argv[], std::ofstream &file_log) {
   });
 }
 
-// gmm-est-fmllr   (VB/src/gmmbin/gmm-est-fmllr.cpp; K/gmmbin/gmm-est-fmllr.cc:28-200)
+// gmm-est-fmllr   (VB/src/gmmbin/gmm-est-fmllr.cpp; K/gmmbin/gmm-est-fmllr.cc:28-200).  The statistics come from
+// the GPU (vbh_fmllr_accumulate: per-frame Gaussian posteriors, then the f64-MFMA contraction per speaker); the
+// row-by-row update of each speaker's 39 x 40 matrix stays on the host.
 int GmmEstFmllr(int argc, char *argv[], std::ofstream &file_log) {
   return Guard("gmm-est-fmllr", &file_log, [&](Log &log) -> int {
     Options po;
     po.Know({"spk2utt", "fmllr-update-type", "fmllr-min-count", "fmllr-num-iters"});
     po.Parse(argc, argv);
     if (po.args.size() != 4) throw ApiError("Wrong arguments.");
+    const vbfmllr::FmllrOptions opts = ReadFmllrOptions(po);
+    if (opts.update_type != "full") throw ApiError("--fmllr-update-type=" + opts.update_type + " is not supported (only full)");
     const Gmm gmm(po.args[0]);
+    const int D = gmm.m.dim, n1 = D + 1;
     std::map<std::string, vbio::Posterior> posts;
     for (auto &kv : vbio::ReadPosteriorTable(po.args[2])) posts.emplace(kv.first, std::move(kv.second));
-    return EstimateFmllr("gmm-est-fmllr", po, gmm, po.args[1], po.args[3], log, [&](const std::string &utt, const vbio::Matrix &feats, vbfmllr::FmllrAccs *accs) {
-      auto it = posts.find(utt);
-      if (it == posts.end()) { log.os() << "WARNING (gmm-est-fmllr) Did not find posteriors for utterance " << utt << "\n"; return false; }
-      if ((int)it->second.size() != feats.rows) { log.os() << "WARNING (gmm-est-fmllr) Posterior vector has wrong size " << it->second.size() << " vs. " << feats.rows << "\n"; return false; }
-      vbio::Posterior pdf_post;
-      PosteriorToPdfs(gmm.m.tid2pdf, it->second, &pdf_post);
-      for (size_t i = 0; i < pdf_post.size(); i++)
-        for (const auto &pr : pdf_post[i]) accs->AccumulateForGmm(gmm.Pdf(pr.first), &feats.data[i * (size_t)feats.cols], pr.second);
-      return true;
-    });
+    // ---- the units a transform is estimated for (speakers, or utterances without --spk2utt) and their utterances
+    std::vector<std::pair<std::string, std::vector<std::string>>> units;
+    std::map<std::string, vbio::Matrix> feats;
+    {
+      vbio::MatrixReader r(po.args[1]);
+      std::string k; vbio::Matrix m;
+      while (r.Next(&k, &m)) { if (!po.Has("spk2utt")) units.emplace_back(k, std::vector<std::string>{k}); feats.emplace(k, std::move(m)); }
+    }
+    if (po.Has("spk2utt")) units = vbio::ReadSpk2Utt(po.Str("spk2utt", ""));
+    vbh_ctx *ctx = SharedCtx();
+    vbh_gmm *dgmm = nullptr;
+    if (vbh_gmm_create(ctx, D, gmm.m.num_pdfs, gmm.m.pdf_offsets.data(), gmm.m.weights.data(), gmm.m.means_invvars.data(), gmm.m.inv_vars.data(), &dgmm) != 0)
+      throw ApiError(std::string("vbh_gmm_create: ") + vbh_last_error());
+    struct GmmGuard { vbh_gmm *g; ~GmmGuard() { vbh_gmm_destroy(g); } } guard{dgmm};
+    std::vector<vbfmllr::FmllrAccs> accs(units.size(), vbfmllr::FmllrAccs(D));
+    int num_done = 0, num_no_post = 0, num_err = 0;
+    // ---- batches of utterances through the GPU (statistics add up across batches)
+    std::vector<float> bfeats; std::vector<int64_t> foff{0}, poff{0}; std::vector<int32_t> u2s, ppdf; std::vector<float> pw;
+    auto flush = [&]() {
+      if (u2s.empty()) return;
+      const int64_t T = foff.back();
+      void *d_feats = nullptr;
+      if (vbh_dev_alloc(ctx, sizeof(float) * bfeats.size(), &d_feats) != 0) throw ApiError(std::string("vbh_dev_alloc: ") + vbh_last_error());
+      struct DevGuard { vbh_ctx *c; void *p; ~DevGuard() { vbh_dev_free(c, p); } } dg{ctx, d_feats};
+      if (vbh_copy_h2d(ctx, d_feats, bfeats.data(), sizeof(float) * bfeats.size()) != 0) throw ApiError(std::string("vbh_copy_h2d: ") + vbh_last_error());
+      const int S = (int)units.size();
+      std::vector<double> beta(S), K((size_t)S * D * n1), G((size_t)S * D * n1 * n1);
+      if (vbh_fmllr_accumulate(ctx, dgmm, dgmm, (const float *)d_feats, (int32_t)u2s.size(), foff.data(), u2s.data(), S, poff.data(), ppdf.data(), pw.data(),
+                               beta.data(), K.data(), G.data(), nullptr) != 0)
+        throw ApiError(std::string("vbh_fmllr_accumulate: ") + vbh_last_error());
+      (void)T;
+      for (int s = 0; s < S; s++) if (beta[s] != 0.0) accs[s].AddStats(beta[s], &K[(size_t)s * D * n1], &G[(size_t)s * D * n1 * n1]);
+      bfeats.clear(); foff.assign(1, 0); poff.assign(1, 0); u2s.clear(); ppdf.clear(); pw.clear();
+    };
+    for (size_t s = 0; s < units.size(); s++) {
+      for (const std::string &utt : units[s].second) {
+        auto fi = feats.find(utt);
+        if (fi == feats.end()) { log.os() << "WARNING (gmm-est-fmllr) Did not find features for utterance " << utt << "\n"; num_err++; continue; }
+        auto pi = posts.find(utt);
+        if (pi == posts.end()) { log.os() << "WARNING (gmm-est-fmllr) Did not find posteriors for utterance " << utt << "\n"; num_no_post++; continue; }
+        const vbio::Matrix &f = fi->second;
+        if ((int)pi->second.size() != f.rows) { log.os() << "WARNING (gmm-est-fmllr) Posterior vector has wrong size " << pi->second.size() << " vs. " << f.rows << "\n"; num_err++; continue; }
+        if (f.cols != D) throw ApiError("Dim mismatch: data dim = " + std::to_string(f.cols) + " vs. model dim = " + std::to_string(D));
+        vbio::Posterior pdf_post;
+        PosteriorToPdfs(gmm.m.tid2pdf, pi->second, &pdf_post);
+        bfeats.insert(bfeats.end(), f.data.begin(), f.data.end());
+        foff.push_back(foff.back() + f.rows);
+        u2s.push_back((int32_t)s);
+        for (const auto &fr : pdf_post) { for (const auto &pr : fr) { ppdf.push_back(pr.first); pw.push_back(pr.second); } poff.push_back((int64_t)ppdf.size()); }
+        num_done++;
+        if (foff.back() >= (int64_t)4 << 20) flush();
+      }
+    }
+    flush();
+    // ---- per unit: update from the unit transform, write
+    vbio::MatrixWriter writer(po.args[3]);
+    double tot_impr = 0.0, tot_t = 0.0;
+    for (size_t s = 0; s < units.size(); s++) {
+      if (!po.Has("spk2utt") && !(accs[s].beta() > 0.0) && !posts.count(units[s].first)) continue;     // per-utterance mode skips utterances without posteriors
+      vbio::Matrix t; t.rows = D; t.cols = n1; t.data.assign((size_t)D * n1, 0.0f);
+      for (int d = 0; d < D; d++) t.data[(size_t)d * n1 + d] = 1.0f;
+      float count = 0.0f;
+      const float impr = accs[s].Update(opts, t.data.data(), &count);
+      if (!(accs[s].beta() > opts.min_count)) log.os() << "WARNING (gmm-est-fmllr) Not updating fMLLR since below min-count: count is " << accs[s].beta() << "\n";
+      writer.Write(units[s].first, t);
+      log.os() << "LOG (gmm-est-fmllr) For " << (po.Has("spk2utt") ? "speaker " : "utterance ") << units[s].first << ", auxf-impr from fMLLR is " << (impr / count)
+               << ", over " << count << " frames.\n";
+      tot_impr += impr; tot_t += count;
+    }
+    writer.Close();
+    log.os() << "LOG (gmm-est-fmllr) Done " << num_done << " files, " << num_no_post << " with no posts, " << num_err << " with other errors.\n";
+    log.os() << "LOG (gmm-est-fmllr) Overall fMLLR auxf impr per frame is " << (tot_impr / tot_t) << " over " << tot_t << " frames.\n";
+    return num_done != 0 ? 0 : 1;
   });
 }
 
