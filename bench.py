@@ -153,6 +153,30 @@ def determinize_measurement(args, dec, T):
             "det_states_per_utt": out[3] / args.batch, "det_arcs_per_utt": out[4] / args.batch, "stopped_before_beam": int(out[5])}
 
 
+F64_MFMA_PEAK_TFLOPS = 78.6      # vendor figure for MI355X FP64 matrix (the micro-architecture guide lists no f64 row)
+
+
+def fmllr_measurement(args, ctx, gmm, feats, foff, utt2spk, n_spk, T):
+    """fMLLR sufficient statistics of one batch (vbh_fmllr_accumulate): every frame carries two
+    (pdf, weight) posterior pairs, as a pruned-determinized lattice typically leaves; the accumulation kernel is
+    priced against the f64 MFMA peak with its own HIP-event duration."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    poff = np.arange(T + 1, dtype=np.int64) * 2
+    ppdf = rng.integers(0, gmm.num_pdfs, 2 * T).astype(np.int32)
+    pw = np.tile(np.array([0.7, 0.3], np.float32), T)
+    best = None
+    for _ in range(2):
+        beta, K, G, ms = gmm.fmllr_stats(feats, foff, utt2spk, n_spk, poff, ppdf, pw)
+        best = ms if best is None else min(best, ms)
+    b, f = C.c_double(), C.c_double()
+    gmm.lib.vbh_fmllr_work(39, int(T), C.byref(b), C.byref(f))
+    return {"kernel": "fmllr_accumulate_kernel", "bound": "mfma (f64)", "achieved": f.value / (best * 1e-3) / 1e12, "peak": F64_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": f.value / (best * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, "kernel_ms": best, "algorithmic_flops": f.value,
+            "algorithmic_bytes": b.value, "speakers": int(n_spk), "frames": int(T), "count_check": float(beta.sum()),
+            "note": "per-speaker G_d = sum_t b_t[d] x+ x+^T (lower-triangle tiles), K, beta for the whole batch; flops count the padded 48-row tiles issued"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -461,6 +485,10 @@ def main():
                                "lattice_tokens_per_frame": c["lat_tok"] / T, "lattice_arcs_per_frame": c["lat_link"] / T,
                                "arc_expansions_per_s": c["arc"] / (k_ms * 1e-3)}
             extra["lattice_stage_host"] = determinize_measurement(args, dec, T)
+            try:
+                extra["roofline_fmllr_stats"] = fmllr_measurement(args, ctx, gmm, ring[0][1], foff, utt2spk, n_spk, T)
+            except Exception as e:        # a measurement beside the step, never a reason to lose the bench line
+                extra["roofline_fmllr_stats"] = {"error": str(e)}
             if d_ms >= g_ms:
                 roof, extra["roofline_gmm"] = dec_roof, gmm_roof
             else:

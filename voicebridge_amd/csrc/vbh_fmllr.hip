@@ -14,10 +14,11 @@
 //   fmllr_accumulate_kernel: the dense part.  Per speaker  G[d][i][j] = sum_t b_t[d] x+_t[i] x+_t[j]  is the
 //     contraction  [D x T] . [T x (D+1)^2]  in double: v_mfma_f64_16x16x4_f64 with A = b (rows d), B built on the
 //     fly as x+[i] * x+[j] (the product of two floats is exact in double), only the tiles of the lower triangle
-//     (72 of 120 column tiles at D = 39).  A workgroup owns one slice of one speaker's frames and one group of 24
-//     column tiles, keeps 18 accumulator tiles per wave in registers over the whole slice and adds them to the
-//     speaker's statistics with f64 atomics once at the end.  K = sum_t a_t x+_t^T and beta = sum_t count_t ride
-//     along as one more group of column tiles.
+//     (72 of 120 column tiles at D = 39) in groups of 4 waves x 6 tiles; K = sum_t a_t x+_t^T is three more
+//     column tiles (A = a, B = x+) in a group of their own.  A workgroup owns one slice of one speaker's frames
+//     and one group, keeps 18 accumulator tiles per wave in registers over the whole slice, fetches the next
+//     64-frame stage into registers under the MFMAs of the current one, and adds its tiles to the speaker's
+//     statistics with f64 atomics once at the end.  beta = sum_t count_t rides along in one wave.
 //     Roofline: f64 MFMA.  Flops per frame = 2 * 48 * 16 * (72 + 3) = 115 200 (padded rows included);
 //     bytes per frame = 4 * (D + 2D + 1) = 472: arithmetic intensity 244 flop/B, far above the f64 ridge (~10).
 #include "vbh_internal.h"
@@ -31,6 +32,7 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 constexpr int TF = 64;          // frames staged in LDS per step
 constexpr int NTW = 6;          // column tiles per wave
+constexpr int NWAVE = 4;        // waves per workgroup (one per SIMD: five waves put two on one SIMD and ran 1.7x slower): 24 column tiles per group
 constexpr int XLD = 49;         // padded row of the x+ image (48 columns used: 40 real + zeros)
 constexpr int ALD = 49;         // padded row of the a / b image (48 rows of the MFMA M dimension)
 
@@ -83,20 +85,22 @@ __global__ __launch_bounds__(256) void fmllr_frame_stats_kernel(
   if (lane == 0) count_out[t] = count;
 }
 
-__global__ __launch_bounds__(256) void fmllr_accumulate_kernel(
+__global__ __launch_bounds__(NWAVE * 64) void fmllr_accumulate_kernel(
     const float *__restrict__ feats, const float *__restrict__ a_in, const float *__restrict__ b_in, const float *__restrict__ count_in, int D,
     const Slice *__restrict__ slices, const Seg *__restrict__ segs, const ColTile *__restrict__ tiles,
     double *__restrict__ beta, double *__restrict__ K, double *__restrict__ G) {
   __shared__ double sX[TF * XLD];     // x+ of the staged frames, columns >= D+1 zero
-  __shared__ double sA[TF * ALD];     // b (G tiles) or a (K tiles) of the staged frames, columns >= D zero
+  __shared__ double sB[TF * ALD];     // A operand of the staged frames: b for the groups of G tiles, a for the group of K tiles; columns >= D zero
+  constexpr int NT = NWAVE * 64;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int n1 = D + 1;
   const Slice sl = slices[blockIdx.x];
-  const bool kgroup = blockIdx.y == gridDim.y - 1;   // the last group of column tiles holds K (and beta)
+  const bool kgroup = blockIdx.y == gridDim.y - 1;      // the last group holds the K tiles (its A operand is a, not b)
   const float *__restrict__ asrc = kgroup ? a_in : b_in;
+  const bool counts = kgroup && wid == 1;               // this wave also sums the frame counts (beta)
   ColTile ct[NTW];
 #pragma unroll
-  for (int q = 0; q < NTW; q++) ct[q] = tiles[(blockIdx.y * 4 + wid) * NTW + q];
+  for (int q = 0; q < NTW; q++) ct[q] = tiles[(blockIdx.y * NWAVE + wid) * NTW + q];
   f64x4 acc[NTW][3];
 #pragma unroll
   for (int q = 0; q < NTW; q++)
@@ -104,37 +108,56 @@ __global__ __launch_bounds__(256) void fmllr_accumulate_kernel(
     for (int m = 0; m < 3; m++) acc[q][m] = f64x4{0.0, 0.0, 0.0, 0.0};
   double cnt = 0.0;
   const int r = lane & 15, kk = lane >> 4;
-  for (int sg = sl.seg_begin; sg < sl.seg_end; sg++) {
-    const Seg seg = segs[sg];
-    for (int f0 = 0; f0 < seg.nrows; f0 += TF) {
-      const int nf = min(TF, seg.nrows - f0);
-      __syncthreads();        // the previous step's readers are done
-      for (int idx = tid; idx < TF * 48; idx += 256) {
-        const int f = idx / 48, c = idx - f * 48;
-        const long long row = seg.row0 + f0 + f;
-        double xv = 0.0, av = 0.0;
-        if (f < nf) {
-          if (c < D) { xv = (double)feats[row * D + c]; av = (double)asrc[row * D + c]; }
-          else if (c == D) xv = 1.0;
-        }
-        sX[f * XLD + c] = xv;
-        sA[f * ALD + c] = av;
-      }
-      if (kgroup && wid == 1) for (int f = lane; f < nf; f += 64) cnt += (double)count_in[seg.row0 + f0 + f];
-      __syncthreads();
-      for (int k0 = 0; k0 < TF; k0 += 4) {
-        if (k0 >= nf) break;                       // (uniform) the rest of the stage is zeros
-        const double *xr = &sX[(k0 + kk) * XLD], *ar = &sA[(k0 + kk) * ALD];
-        const double a0 = ar[r], a1 = ar[16 + r], a2 = ar[32 + r];
+  // the stage after the current one is fetched into registers while the MFMAs of the current one run
+  constexpr int NLD = (TF * 48 + NT - 1) / NT;     // elements of the stage per thread
+  float px[NLD], pb[NLD];
+  float pcnt = 0.f;
+  int sg = sl.seg_begin, f0 = 0;
+  Seg seg = segs[sg];
+  auto fetch = [&](const Seg &sgm, int ff0) {
+    const int nfr = min(TF, sgm.nrows - ff0);
 #pragma unroll
-        for (int q = 0; q < NTW; q++) {
-          if (ct[q].type < 0) continue;            // wave-uniform
-          const double xj = xr[ct[q].j0 + r];
-          const double bv = ct[q].type == 0 ? xr[ct[q].i] * xj : xj;
-          acc[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[q][0], 0, 0, 0);
-          acc[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[q][1], 0, 0, 0);
-          acc[q][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, bv, acc[q][2], 0, 0, 0);
-        }
+    for (int e = 0; e < NLD; e++) {
+      const int idx = tid + e * NT, f = idx / 48, c = idx - f * 48;
+      const long long row = sgm.row0 + ff0 + f;
+      px[e] = 0.f; pb[e] = 0.f;
+      if (f < nfr) {           // (f < TF follows: nfr <= TF)
+        if (c < D) { px[e] = feats[row * D + c]; pb[e] = asrc[row * D + c]; }
+        else if (c == D) px[e] = 1.0f;
+      }
+    }
+    pcnt = 0.f;
+    if (counts && lane < nfr) pcnt = count_in[sgm.row0 + ff0 + lane];      // TF == 64: one frame per lane
+  };
+  fetch(seg, 0);
+  bool more = true;
+  while (more) {
+    const int nf = min(TF, seg.nrows - f0);
+    __syncthreads();        // the previous stage's readers are done
+#pragma unroll
+    for (int e = 0; e < NLD; e++) {
+      const int idx = tid + e * NT, f = idx / 48, c = idx - f * 48;
+      if (f < TF) { sX[f * XLD + c] = (double)px[e]; sB[f * ALD + c] = (double)pb[e]; }
+    }
+    cnt += (double)pcnt;
+    __syncthreads();
+    // next stage: the rest of this segment, else the next segment of the slice
+    f0 += TF;
+    if (f0 >= seg.nrows) { sg++; f0 = 0; if (sg < sl.seg_end) seg = segs[sg]; else more = false; }
+    if (more) fetch(seg, f0);
+    for (int k0 = 0; k0 < TF; k0 += 4) {
+      if (k0 >= nf) break;                       // (uniform) the rest of the stage is zeros
+      const double *xr = &sX[(k0 + kk) * XLD], *br = &sB[(k0 + kk) * ALD];
+      const double b0 = br[r], b1 = br[16 + r], b2 = br[32 + r];
+#pragma unroll
+      for (int q = 0; q < NTW; q++) {
+        if (ct[q].type < 0) continue;            // wave-uniform
+        const double xj = xr[ct[q].j0 + r];
+        const bool kt = ct[q].type == 1;
+        const double bv = kt ? xj : xr[ct[q].i] * xj;
+        acc[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, bv, acc[q][0], 0, 0, 0);
+        acc[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, bv, acc[q][1], 0, 0, 0);
+        acc[q][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(b2, bv, acc[q][2], 0, 0, 0);
       }
     }
   }
@@ -156,7 +179,7 @@ __global__ __launch_bounds__(256) void fmllr_accumulate_kernel(
         else atomicAdd(&Ks[(size_t)d * n1 + j], val);
       }
   }
-  if (kgroup && wid == 1) {
+  if (counts) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
     if (lane == 0 && cnt != 0.0) atomicAdd(&beta[sl.spk], cnt);
@@ -199,11 +222,12 @@ int vbh_fmllr_accumulate(vbh_ctx *ctx, const vbh_gmm *ali_gmm, const vbh_gmm *ad
   // ---- column tiles: lower triangle of the (D+1) x (D+1) scatter, then K
   std::vector<ColTile> tiles;
   for (int i = 0; i < n1; i++) for (int jt = 0; jt * 16 < n1; jt++) if (jt * 16 <= i) tiles.push_back(ColTile{0, i, jt * 16, 0});
-  const int per_group = 4 * NTW;                  // column tiles of one workgroup (4 waves)
+  const int per_group = NWAVE * NTW;              // column tiles of one workgroup
   const int g_groups = ((int)tiles.size() + per_group - 1) / per_group;       // 3 at D = 39 (72 tiles), 4 up to D = 47
   tiles.resize((size_t)g_groups * per_group, ColTile{-1, 0, 0, 0});
-  for (int jt = 0; jt * 16 < n1; jt++) tiles.push_back(ColTile{1, 0, jt * 16, 0});
-  tiles.resize((size_t)(g_groups + 1) * per_group, ColTile{-1, 0, 0, 0});
+  for (int jt = 0; jt * 16 < n1; jt++) tiles.push_back(ColTile{1, 0, jt * 16, 0});       // K: a group of its own (A operand a instead of b)
+  const int n_groups = g_groups + 1;
+  tiles.resize((size_t)n_groups * per_group, ColTile{-1, 0, 0, 0});
   // ---- slices: every speaker's frames cut into pieces so that the grid fills the chip
   std::vector<std::vector<int>> spk_utts(n_spk);
   std::vector<long long> spk_frames(n_spk, 0);
@@ -248,7 +272,7 @@ int vbh_fmllr_accumulate(vbh_ctx *ctx, const vbh_gmm *ali_gmm, const vbh_gmm *ad
   VBH_HIP(hipGetLastError());
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (kernel_ms) { VBH_HIP(hipEventCreate(&e0)); VBH_HIP(hipEventCreate(&e1)); VBH_HIP(hipEventRecord(e0, st)); }
-  hipLaunchKernelGGL(fmllr_accumulate_kernel, dim3((unsigned)slices.size(), g_groups + 1), dim3(256), 0, st, d_feats, d_a.p, d_b.p, d_cnt.p, D, d_slices.p, d_segs.p,
+  hipLaunchKernelGGL(fmllr_accumulate_kernel, dim3((unsigned)slices.size(), n_groups), dim3(NWAVE * 64), 0, st, d_feats, d_a.p, d_b.p, d_cnt.p, D, d_slices.p, d_segs.p,
                      d_tiles.p, d_beta.p, d_K.p, d_G.p);
   VBH_HIP(hipGetLastError());
   if (kernel_ms) VBH_HIP(hipEventRecord(e1, st));
