@@ -55,6 +55,12 @@ def parse():
                     help="confine the search contexts to this many CUs (0 = all, -1 = 7/8 of the device when batches are "
                          "pipelined): the rest stays free for the front end of the batches ahead, which otherwise only "
                          "runs while a search grid drains -- a persistent search workgroup owns its CU's whole LDS")
+    ap.add_argument("--no-determinize", action="store_true",
+                    help="skip the second timed region, in which the host stage that follows every search in the reference's gmm-latgen-faster "
+                         "(lattice determinization) is part of the step: a pool of host threads determinizes the lattices of batch k while the GPU "
+                         "searches batch k+1")
+    ap.add_argument("--det-steps", type=int, default=6, help="steps of that second timed region")
+    ap.add_argument("--det-threads", type=int, default=0, help="host threads of the lattice stage (0: 16, the CPU share of a one-GPU box)")
     ap.add_argument("--probe", action="store_true", help="print search statistics of the first utterances and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-seconds", type=float, default=180.0, help="audio seconds timed on the CPU baseline")
@@ -121,6 +127,71 @@ def cpu_baseline(args, waves, utt2spk, xforms, model, decode_setup):
                        % (n_utt, args.seconds, frames, ", lattice search" if decode_setup is not None else ""))
 
 
+def host_threads(args):
+    """threads of the host stage: --det-threads, else the CPU share of a one-GPU box (16; more threads than cores only thrash)"""
+    if args.det_threads > 0:
+        return args.det_threads
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 16
+    return max(1, min(16, n))
+
+
+def trans_info(args):
+    """synth.lexicon_graph(): pdf p has the self-loop tid 2p+1 and the forward tid 2p+2; 3-state phones"""
+    P = args.pdfs
+    n_tid = 2 * P
+    phone = np.zeros(n_tid + 1, np.int32); hmm = np.zeros(n_tid + 1, np.int32); sl = np.zeros(n_tid + 1, np.uint8)
+    for p_ in range(P):
+        for k_, tid in enumerate((2 * p_ + 1, 2 * p_ + 2)):
+            phone[tid] = p_ // 3 + 1; hmm[tid] = p_ % 3; sl[tid] = 1 - k_
+    return n_tid, phone, hmm, sl
+
+
+class DetPool:
+    """the lattice stage as part of the step: host threads determinize the lattices of the batch just searched
+    (voicebridge_amd/host: vb_det_pool_*) while the GPU works on the next one"""
+
+    def __init__(self, args):
+        import ctypes as C
+        from voicebridge_amd import build
+        self.C = C
+        self.host = C.CDLL(build.HOST_LIB)
+        n_tid, phone, hmm, sl = trans_info(args)
+        self.threads = host_threads(args)
+        self.host.vb_det_pool_create.restype = C.c_void_p
+        self.host.vb_det_pool_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float]
+        self.host.vb_det_pool_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        self.host.vb_det_pool_wait.argtypes = [C.c_void_p, C.c_void_p]
+        self.host.vb_det_pool_destroy.argtypes = [C.c_void_p]
+        self.h = self.host.vb_det_pool_create(self.threads, n_tid, phone.ctypes.data, hmm.ctypes.data, sl.ctypes.data,
+                                              C.c_float(args.lattice_beam), C.c_float(0.083333))
+        self.submit_s = 0.0
+        self.totals = np.zeros(6)
+
+    def submit(self, dec, n_utt):
+        t0 = time.perf_counter()
+        if self.host.vb_det_pool_submit(self.h, dec.h, n_utt, 0) != 0:
+            raise RuntimeError("vb_det_pool_submit failed")
+        self.submit_s += time.perf_counter() - t0
+
+    def wait(self):
+        out = (self.C.c_double * 6)()
+        if self.host.vb_det_pool_wait(self.h, out) != 0:
+            raise RuntimeError("vb_det_pool_wait failed")
+        self.totals += np.array(list(out))
+
+    def reset(self):
+        self.submit_s = 0.0
+        self.totals[:] = 0
+
+    def close(self):
+        if self.h:
+            self.host.vb_det_pool_destroy(self.h)
+            self.h = None
+
+
 def determinize_measurement(args, dec, T):
     """The step after the search in the reference's Decode (gmm-latgen-faster determinizes every
     utterance's lattice before writing it, K/decoder/decoder-wrappers.cc:262-284): host C++
@@ -130,17 +201,16 @@ def determinize_measurement(args, dec, T):
     import ctypes as C
     from voicebridge_amd import build
     host = C.CDLL(build.HOST_LIB)
-    P = args.pdfs
-    # synth.lexicon_graph(): pdf p has the self-loop tid 2p+1 and the forward tid 2p+2; 3-state phones
-    n_tid = 2 * P
-    phone = np.zeros(n_tid + 1, np.int32); hmm = np.zeros(n_tid + 1, np.int32); sl = np.zeros(n_tid + 1, np.uint8)
-    for p_ in range(P):
-        for k_, tid in enumerate((2 * p_ + 1, 2 * p_ + 2)):
-            phone[tid] = p_ // 3 + 1; hmm[tid] = p_ % 3; sl[tid] = 1 - k_
-    threads = max(1, min(32, (os.cpu_count() or 1)))
+    n_tid, phone, hmm, sl = trans_info(args)
+    threads = host_threads(args)
     out = (C.c_double * 6)()
     host.vb_determinize_decoder_results.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                                     C.c_int, C.c_void_p]
+    if os.environ.get("VBH_DET_SWEEP"):       # diagnostic: how many host threads does the box really give us?
+        for th in (4, 8, 16, 24, 32, 48, 64):
+            host.vb_determinize_decoder_results(dec.h, args.batch, 0, n_tid, phone.ctypes.data, hmm.ctypes.data, sl.ctypes.data,
+                                                C.c_float(args.lattice_beam), C.c_float(0.083333), th, out)
+            print("determinize %d lattices on %d threads: %.3f s" % (args.batch, th, out[0]), file=sys.stderr, flush=True)
     rc = host.vb_determinize_decoder_results(dec.h, args.batch, 0, n_tid, phone.ctypes.data, hmm.ctypes.data, sl.ctypes.data,
                                              C.c_float(args.lattice_beam), C.c_float(0.083333), threads, out)
     if rc != 0:
@@ -324,12 +394,17 @@ def main():
             ctx.timer_stop(sl + 1)
             fe_timed.append(sl)
 
+    det_pool = DetPool(args) if (dec is not None and not args.no_determinize) else None
+    det_on = [False]         # the headline region times the GPU path (SURVEY.md 8 a-e); a second region adds the host lattice stage
+
     def finish(L):
         """complete the lane's search in flight: lattices on the host, times collected"""
         if L.pending:
             L.dec.decode_end()
             L.pending = False
             last_done[0] = L
+            if det_pool is not None and det_on[0]:
+                det_pool.submit(L.dec, args.batch)      # raw lattices copied out; determinized by the pool under the next search
             if tl_dump is not None and L.timed:
                 tl_dump.append(np.array([L.dec.timeline(u) for u in range(args.batch)], np.int64))
             if L.timed:
@@ -372,6 +447,8 @@ def main():
             L.ctx.sync()
         ctx.sync()
         torch.cuda.synchronize(dev)
+        if det_pool is not None and det_on[0]:
+            det_pool.wait()                             # the step is complete when its lattices are determinized
         if world > 1:
             dist.barrier()
 
@@ -384,6 +461,20 @@ def main():
     dt = time.perf_counter() - t0
     for sl in fe_timed:
         feat_ms.append(ctx.timer_ms(sl)); gmm_ms.append(ctx.timer_ms(sl + 1))
+    # second timed region: the same steps with the lattice stage of the reference's Decode inside them
+    det_dt = None
+    if det_pool is not None and args.det_steps > 0:
+        n_dec_timed = len(dec_ms)
+        det_on[0] = True
+        run_steps(1, False)
+        barrier()
+        det_pool.reset()
+        t0 = time.perf_counter()
+        run_steps(args.det_steps, False)
+        barrier()
+        det_dt = time.perf_counter() - t0
+        det_on[0] = False
+        del dec_ms[n_dec_timed:], dec_k_ms[n_dec_timed:], dec_h_ms[n_dec_timed:]
     # after the timed region: the GMM kernel alone on the whole chip (in the pipeline it shares the
     # CUs with two search grids, so its in-pipeline duration says little about the kernel itself)
     gmm_alone_ms = None
@@ -485,6 +576,16 @@ def main():
                                "lattice_tokens_per_frame": c["lat_tok"] / T, "lattice_arcs_per_frame": c["lat_link"] / T,
                                "arc_expansions_per_s": c["arc"] / (k_ms * 1e-3)}
             extra["lattice_stage_host"] = determinize_measurement(args, dec, T)
+            if det_pool is not None and det_dt is not None:
+                nb = args.det_steps * args.batch
+                tt = det_pool.totals
+                extra["lattice_stage_in_step"] = {
+                    "value": T * args.det_steps / det_dt, "unit": "frames/s", "steps": args.det_steps, "ms_per_step": 1e3 * det_dt / args.det_steps,
+                    "what": "every timed batch's lattices determinized (Connect, phone-level + word-level pruned determinization, un-scaling) by a pool "
+                            "of host threads while the GPU searches the next batch; the timed region ends when the last batch is determinized",
+                    "threads": det_pool.threads, "utterances": nb, "worker_seconds": float(tt[0]), "worker_ms_per_utterance": 1e3 * float(tt[0]) / max(nb, 1),
+                    "copy_out_seconds_on_the_step_thread": det_pool.submit_s, "raw_arcs_per_utt": float(tt[2]) / max(nb, 1),
+                    "det_arcs_per_utt": float(tt[4]) / max(nb, 1), "stopped_before_beam": int(tt[5])}
             try:
                 extra["roofline_fmllr_stats"] = fmllr_measurement(args, ctx, gmm, ring[0][1], foff, utt2spk, n_spk, T)
             except Exception as e:        # a measurement beside the step, never a reason to lose the bench line
@@ -507,6 +608,7 @@ def main():
                        "utterances_per_step_per_gpu": args.batch, "utterance_seconds": args.seconds,
                        "frames_per_step_per_gpu": T, "pdfs": gmm.num_pdfs, "gaussians": gmm.num_gauss, "dim": 39,
                        "batches_in_flight": depth, "search_cus": args.search_cus,
+                       "lattices": "raw (state level) in the headline region; determinized on the host in the second region (lattice_stage_in_step)",
                        "sharding": "utterances over ranks, no data-path collective"},
             "roofline": roof, "stage_ms": stage_ms,
         }
@@ -514,7 +616,7 @@ def main():
         # HBM traffic of the dominant kernels from the committed rocprofv3 --pmc passes of this
         # same command (profiles/): only attached when the batch size matches that run
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")))
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")))
             if tr.get("batch") == args.batch and world == 1:
                 for ro in [out["roofline"]] + [out[k] for k in ("roofline_gmm", "roofline_decode") if k in out]:
                     b_ = tr["bytes_per_launch"].get(ro["kernel"])
@@ -528,6 +630,8 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, waves, utt2spk, xforms, model, decode_setup)
         print(json.dumps(out), flush=True)
+    if det_pool is not None:
+        det_pool.close()
     # tear down in order: decoders before their contexts (and before the interpreter's own finalisation)
     for L in lanes:
         if L.dec is not None:

@@ -46,13 +46,18 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// per-Gaussian log-likelihood of the frame held one dimension per lane (lanes >= D hold zeros)
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// per-Gaussian log-likelihood of the frame held one dimension per lane (lanes >= D hold zeros): one wave reduction
 __device__ __forceinline__ float gauss_loglike(const float *__restrict__ gconsts, const float *__restrict__ miv, const float *__restrict__ iv,
                                                int g, int D, int lane, float x, float x2) {
-  float lin = 0.f, quad = 0.f;
-  if (lane < D) { lin = miv[(size_t)g * D + lane] * x; quad = iv[(size_t)g * D + lane] * x2; }
-  lin = wave_sum(lin); quad = wave_sum(quad);
-  return (gconsts[g] + lin) + -0.5f * quad;
+  float v = 0.f;
+  if (lane < D) v = miv[(size_t)g * D + lane] * x + -0.5f * (iv[(size_t)g * D + lane] * x2);
+  return gconsts[g] + wave_sum(v);
 }
 
 __global__ __launch_bounds__(256) void fmllr_frame_stats_kernel(
@@ -70,15 +75,29 @@ __global__ __launch_bounds__(256) void fmllr_frame_stats_kernel(
     const int p = pair_pdf[q];
     const float w = pair_w[q];
     const int g0 = pdf_offs[p], g1 = pdf_offs[p + 1];
-    float mx = -INFINITY;
-    for (int g = g0; g < g1; g++) mx = fmaxf(mx, gauss_loglike(ali_gconsts, ali_miv, ali_iv, g, D, lane, x, x2));
-    float sum = 0.f;
-    for (int g = g0; g < g1; g++) sum += expf(gauss_loglike(ali_gconsts, ali_miv, ali_iv, g, D, lane, x, x2) - mx);
-    const float inv = 1.0f / sum;
-    for (int g = g0; g < g1; g++) {
-      const float post = expf(gauss_loglike(ali_gconsts, ali_miv, ali_iv, g, D, lane, x, x2) - mx) * inv * w;
-      count += post;
-      if (lane < D) { a += post * miv[(size_t)g * D + lane]; b += post * iv[(size_t)g * D + lane]; }
+    if (g1 - g0 <= 64) {
+      // the usual case: lane k keeps the log-likelihood of the pdf's k-th Gaussian, so every Gaussian is evaluated once
+      float mine = -INFINITY;
+      for (int g = g0; g < g1; g++) { const float ll = gauss_loglike(ali_gconsts, ali_miv, ali_iv, g, D, lane, x, x2); if (lane == g - g0) mine = ll; }
+      const float mx = wave_max(mine);
+      const float e = lane < g1 - g0 ? expf(mine - mx) : 0.f;
+      const float post_mine = e * (1.0f / wave_sum(e)) * w;
+      count += wave_sum(post_mine);
+      for (int g = g0; g < g1; g++) {
+        const float post = __shfl(post_mine, g - g0);
+        if (lane < D) { a += post * miv[(size_t)g * D + lane]; b += post * iv[(size_t)g * D + lane]; }
+      }
+    } else {
+      float mx = -INFINITY;
+      for (int g = g0; g < g1; g++) mx = fmaxf(mx, gauss_loglike(ali_gconsts, ali_miv, ali_iv, g, D, lane, x, x2));
+      float sum = 0.f;
+      for (int g = g0; g < g1; g++) sum += expf(gauss_loglike(ali_gconsts, ali_miv, ali_iv, g, D, lane, x, x2) - mx);
+      const float inv = 1.0f / sum;
+      for (int g = g0; g < g1; g++) {
+        const float post = expf(gauss_loglike(ali_gconsts, ali_miv, ali_iv, g, D, lane, x, x2) - mx) * inv * w;
+        count += post;
+        if (lane < D) { a += post * miv[(size_t)g * D + lane]; b += post * iv[(size_t)g * D + lane]; }
+      }
     }
   }
   if (lane < D) { a_out[t * D + lane] = a; b_out[t * D + lane] = b; }

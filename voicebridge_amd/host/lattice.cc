@@ -182,20 +182,29 @@ namespace {
 // are exactly those, so the check trips at the same point as in the reference.
 class StringRepo {
  public:
-  StringRepo() { parent_.push_back(-1); label_.push_back(0); size_.push_back(0); gen_.push_back(0); }
+  StringRepo() { parent_.push_back(-1); label_.push_back(0); size_.push_back(0); gen_.push_back(0); first_.push_back(0); jump_.push_back(0); }
   int Empty() const { return 0; }
   size_t NumEntries() const { return live_count_; }
   int Successor(int a, int32_t l) {
+    // open-addressing table over (parent, label): the node ids themselves are the values, the keys live in parent_/label_
+    if ((parent_.size() + 1) * 2 > table_.size()) Grow();
+    const size_t mask = table_.size() - 1;
     const uint64_t key = ((uint64_t)(uint32_t)a << 32) | (uint32_t)l;
-    auto it = map_.find(key);
-    if (it != map_.end()) {
-      if (gen_[it->second] != cur_gen_) { gen_[it->second] = cur_gen_; live_count_++; }
-      return it->second;
+    size_t h = Hash(key) & mask;
+    for (;;) {
+      const Slot &sl = table_[h];
+      if (sl.id < 0) break;
+      if (sl.key == key) {
+        if (gen_[sl.id] != cur_gen_) { gen_[sl.id] = cur_gen_; live_count_++; }
+        return sl.id;
+      }
+      h = (h + 1) & mask;
     }
     const int id = (int)parent_.size();
-    parent_.push_back(a); label_.push_back(l); size_.push_back(size_[a] + 1); gen_.push_back(cur_gen_);
+    parent_.push_back(a); label_.push_back(l); size_.push_back(size_[a] + 1); gen_.push_back(cur_gen_); first_.push_back(a == 0 ? l : first_[a]);
+    { const int ja = jump_[a]; jump_.push_back(size_[a] - size_[ja] == size_[ja] - size_[jump_[ja]] ? jump_[ja] : a); }
     live_count_++;
-    map_.emplace(key, id);
+    table_[h] = Slot{key, id};
     return id;
   }
   void Rebuild(const std::vector<int> &to_keep) {
@@ -205,6 +214,20 @@ class StringRepo {
       for (; e != 0 && gen_[e] != cur_gen_; e = parent_[e]) { gen_[e] = cur_gen_; live_count_++; }
   }
   int Size(int a) const { return size_[a]; }
+  // the prefix of length n of string a: an ancestor in the trie (alive whenever a is: no lookup, no entry created --
+  // what the reference obtains by re-converting the prefix vector, determinize-lattice-inl.h:161-166)
+  int Prefix(int a, size_t n) const {          // level ancestor in O(log) steps through the jump pointers
+    while ((size_t)size_[a] > n) a = (size_t)size_[jump_[a]] >= n ? jump_[a] : parent_[a];
+    return a;
+  }
+  // longest common prefix of two strings = their lowest common ancestor in the trie
+  int CommonPrefix(int a, int b) const {
+    if (size_[a] > size_[b]) a = Prefix(a, size_[b]); else if (size_[b] > size_[a]) b = Prefix(b, size_[a]);
+    while (a != b) {
+      if (jump_[a] != jump_[b]) { a = jump_[a]; b = jump_[b]; } else { a = parent_[a]; b = parent_[b]; }
+    }
+    return a;
+  }
   void ToVector(int a, std::vector<int32_t> *out) const {
     out->resize(size_[a]);
     for (int i = size_[a] - 1; i >= 0; i--) { (*out)[i] = label_[a]; a = parent_[a]; }
@@ -219,6 +242,9 @@ class StringRepo {
   }
   // shrink *b to the longest common prefix of a and *b (determinize-lattice-inl.h:96-115)
   void ReduceToCommonPrefix(int a, std::vector<int32_t> *b) const {
+    if (b->empty()) return;
+    // strings that differ in their first label have no common prefix: no need to walk a's whole length to learn it
+    if (size_[a] == 0 || first_[a] != (*b)[0]) { b->clear(); return; }
     size_t a_size = size_[a], b_size = b->size();
     while (a_size > b_size) { a = parent_[a]; a_size--; }
     if (b_size > a_size) b_size = a_size;
@@ -240,9 +266,24 @@ class StringRepo {
   std::vector<int32_t> label_;
   std::vector<int> size_;
   std::vector<uint32_t> gen_;
+  std::vector<int32_t> first_;            // first label of the string (0 for the empty string)
+  std::vector<int> jump_;                 // one more ancestor per node, depths chosen so that level-ancestor queries take O(log) steps
   uint32_t cur_gen_ = 0;
   size_t live_count_ = 0;
-  std::unordered_map<uint64_t, int> map_;
+  struct Slot { uint64_t key; int id; };
+  std::vector<Slot> table_;
+  static size_t Hash(uint64_t k) { k ^= k >> 29; k *= 0x9E3779B97F4A7C15ull; return (size_t)(k >> 24); }
+  void Grow() {
+    const size_t n = table_.empty() ? (size_t)1 << 16 : table_.size() * 4;
+    table_.assign(n, Slot{0, -1});
+    const size_t mask = n - 1;
+    for (int id = 1; id < (int)parent_.size(); id++) {
+      const uint64_t key = ((uint64_t)(uint32_t)parent_[id] << 32) | (uint32_t)label_[id];
+      size_t h = Hash(key) & mask;
+      while (table_[h].id >= 0) h = (h + 1) & mask;
+      table_[h] = Slot{key, id};
+    }
+  }
 };
 
 // ------------------------------------------------------------------ the determinizer
@@ -488,19 +529,21 @@ class Determinizer {
 
   void NormalizeSubset(std::vector<Element> *elems, Weight *tot, int *common) {   // :775-803
     if (elems->empty()) { *common = repo_.Empty(); *tot = Zero(); return; }
-    std::vector<int32_t> prefix;
-    repo_.ToVector((*elems)[0].string, &prefix);
+    // the common prefix of the elements' strings is the lowest common ancestor of their trie nodes (the reference
+    // shrinks a vector against every string, determinize-lattice-inl.h:96-115: the same prefix, found without
+    // walking the strings)
+    int pre = (*elems)[0].string;
     Weight w = (*elems)[0].weight;
     for (size_t i = 1; i < elems->size(); i++) {
       w = Plus(w, (*elems)[i].weight);
-      repo_.ReduceToCommonPrefix((*elems)[i].string, &prefix);
+      if (pre != 0) pre = repo_.CommonPrefix(pre, (*elems)[i].string);
     }
-    const size_t plen = prefix.size();
+    const size_t plen = (size_t)repo_.Size(pre);
     for (Element &e : *elems) {
       e.weight = Divide(e.weight, w);
       e.string = repo_.RemovePrefix(e.string, plen);
     }
-    *common = repo_.FromVector(prefix);
+    *common = pre;
     *tot = w;
   }
 

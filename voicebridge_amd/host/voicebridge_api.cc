@@ -13,6 +13,8 @@
 #include <map>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -785,6 +787,100 @@ int vb_determinize_decoder_results(void *decoder, int n_utt, int graph_start, in
     out6[1] = (double)in_s; out6[2] = (double)in_a; out6[3] = (double)out_s; out6[4] = (double)out_a; out6[5] = (double)early;
     return 0;
   } catch (const std::exception &e) { fprintf(stderr, "ERROR (vb_determinize_decoder_results) %s\n", e.what()); return -1; }
+}
+// ---- the same as a pipeline stage: a pool of host threads that determinizes the lattices of batch k while
+// the GPU searches batch k+1.  submit() copies the decoder's results into raw lattices (they are only valid
+// until the decoder's next call) and queues one job per utterance; wait() blocks until the queue is empty and
+// returns the totals since the last wait {seconds of worker time, input states, input arcs, output states,
+// output arcs, stopped before the beam}.
+struct VbDetPool {
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cv, cv_done;
+  std::deque<vblat::Lattice> q;
+  size_t in_flight = 0;
+  bool stop = false;
+  vblat::TransInfo tm;
+  float lattice_beam = 6.0f;
+  double inv = 1.0;
+  double busy = 0.0, in_s = 0, in_a = 0, out_s = 0, out_a = 0, early = 0;
+  std::string err;
+};
+void *vb_det_pool_create(int threads, int num_tids, const int32_t *tid_phone, const int32_t *tid_hmm_state, const uint8_t *tid_self_loop,
+                         float lattice_beam, float acoustic_scale) {
+  VbDetPool *p = new VbDetPool();
+  p->tm.phone.assign(tid_phone, tid_phone + num_tids + 1);
+  p->tm.hmm_state.assign(tid_hmm_state, tid_hmm_state + num_tids + 1);
+  p->tm.self_loop.assign(tid_self_loop, tid_self_loop + num_tids + 1);
+  p->lattice_beam = lattice_beam;
+  p->inv = acoustic_scale != 0.0f ? 1.0 / (double)acoustic_scale : 1.0;
+  for (int t = 0; t < std::max(threads, 1); t++)
+    p->workers.emplace_back([p]() {
+      for (;;) {
+        vblat::Lattice lat;
+        {
+          std::unique_lock<std::mutex> lk(p->mu);
+          p->cv.wait(lk, [p] { return p->stop || !p->q.empty(); });
+          if (p->q.empty()) return;
+          lat = std::move(p->q.front());
+          p->q.pop_front();
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        double is = 0, ia = 0, os = 0, oa = 0, early = 0;
+        std::string err;
+        try {
+          vblat::CompactLattice clat;
+          vblat::Connect(&lat);
+          is = (double)lat.st.size(); ia = (double)lat.NumArcs();
+          if (!vblat::DeterminizeLatticePhonePrunedWrapper(p->tm, &lat, p->lattice_beam, &clat, vblat::PhoneDetOptions())) early = 1;
+          vblat::ScaleLattice(1.0, 0.0, 0.0, p->inv, &clat);
+          os = (double)clat.st.size(); oa = (double)clat.NumArcs();
+        } catch (const std::exception &e) { err = e.what(); }
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->busy += dt; p->in_s += is; p->in_a += ia; p->out_s += os; p->out_a += oa; p->early += early;
+        if (!err.empty()) p->err = err;
+        if (--p->in_flight == 0) p->cv_done.notify_all();
+      }
+    });
+  return p;
+}
+int vb_det_pool_submit(void *pool, void *decoder, int n_utt, int graph_start) {
+  VbDetPool *p = (VbDetPool *)pool;
+  try {
+    // the copy-out is itself spread over a few threads: it sits on the caller's critical path (the decoder's
+    // result buffers are reused by its next batch)
+    std::vector<vbh_lattice> Ls(n_utt);
+    for (int u = 0; u < n_utt; u++) Check(vbh_decoder_result((vbh_decoder *)decoder, u, &Ls[u]), "vbh_decoder_result");
+    std::vector<vblat::Lattice> lats(n_utt);
+    std::atomic<int> next{0};
+    auto work = [&]() { for (int u = next++; u < n_utt; u = next++) if (Ls[u].ok) RawLatticeFromResult(Ls[u], graph_start, &lats[u]); };
+    std::vector<std::thread> helpers;
+    const int nh = std::min<int>(8, std::max<int>(1, (int)p->workers.size()));
+    for (int t = 1; t < nh; t++) helpers.emplace_back(work);
+    work();
+    for (std::thread &t : helpers) t.join();
+    std::lock_guard<std::mutex> lk(p->mu);
+    for (int u = 0; u < n_utt; u++) if (Ls[u].ok) { p->q.push_back(std::move(lats[u])); p->in_flight++; }
+    p->cv.notify_all();
+    return 0;
+  } catch (const std::exception &e) { fprintf(stderr, "ERROR (vb_det_pool_submit) %s\n", e.what()); return -1; }
+}
+int vb_det_pool_wait(void *pool, double *out6) {
+  VbDetPool *p = (VbDetPool *)pool;
+  std::unique_lock<std::mutex> lk(p->mu);
+  p->cv_done.wait(lk, [p] { return p->in_flight == 0; });
+  out6[0] = p->busy; out6[1] = p->in_s; out6[2] = p->in_a; out6[3] = p->out_s; out6[4] = p->out_a; out6[5] = p->early;
+  p->busy = p->in_s = p->in_a = p->out_s = p->out_a = p->early = 0;
+  if (!p->err.empty()) { fprintf(stderr, "ERROR (vb_det_pool) %s\n", p->err.c_str()); p->err.clear(); return -1; }
+  return 0;
+}
+void vb_det_pool_destroy(void *pool) {
+  VbDetPool *p = (VbDetPool *)pool;
+  { std::lock_guard<std::mutex> lk(p->mu); p->stop = true; }
+  p->cv.notify_all();
+  for (std::thread &t : p->workers) t.join();
+  delete p;
 }
 int vb_set_device(int device_id) { g_device = device_id; return 0; }
 int vb_ComputeMFCCFeats(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return ComputeMFCCFeats(argc, argv, l); }); }
