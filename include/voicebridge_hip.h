@@ -244,6 +244,12 @@ int vbh_fmllr_accumulate(vbh_ctx *ctx, const vbh_gmm *ali_gmm, const vbh_gmm *ad
                          const int64_t *h_frame_offsets, const int32_t *h_utt2spk, int32_t n_spk, const int64_t *h_pair_offsets,
                          const int32_t *h_pair_pdf, const float *h_pair_weight, double *h_beta, double *h_K, double *h_G,
                          float *kernel_ms);
+/* The same from explicit Gaussian-level posteriors (gmm-est-fmllr-gpost, K/gmmbin/gmm-est-fmllr-gpost.cc:36-50): pair q carries the
+ * posteriors h_gpost[h_gpost_offsets[q] .. h_gpost_offsets[q+1]) of the Gaussians of pdf h_pair_pdf[q] (h_pdf_num_gauss[pdf] of them). */
+int vbh_fmllr_accumulate_gpost(vbh_ctx *ctx, const vbh_gmm *adapt_gmm, const float *d_feats, int32_t n_utt, const int64_t *h_frame_offsets,
+                               const int32_t *h_utt2spk, int32_t n_spk, const int64_t *h_pair_offsets, const int32_t *h_pair_pdf,
+                               const int64_t *h_gpost_offsets, const float *h_gpost, const int32_t *h_pdf_num_gauss, double *h_beta, double *h_K,
+                               double *h_G, float *kernel_ms);
 /* algorithmic work of the accumulation kernel for T frames: bytes read, f64 flops issued */
 int vbh_fmllr_work(int32_t dim, int64_t T, double *bytes, double *flops);
 

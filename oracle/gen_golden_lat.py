@@ -70,14 +70,17 @@ def run_reference_chain(d, acwt="0.083333", beam="6", lmwt="9", wip="0.5"):
 
 def run_fmllr_chain(d, run, pre, acwt="0.083333", sil="1:2", min_count="50", trans_tmp_from=None):
     """the programs between the two searches of DecodeFmllr (VB/scr/steps/decode_fmllr.cpp:314-640), `run(name, *args)`
-    executing one of them; files are prefixed with `pre`.  trans_tmp_from: take gmm-est-fmllr's output from that
-    prefix instead of running it (this build's gmm-est-fmllr needs the GPU)"""
+    executing one of them; files are prefixed with `pre`.  trans_tmp_from: take the outputs of gmm-est-fmllr-gpost and
+    gmm-est-fmllr from that prefix instead of running them (this build's take their statistics from the GPU)"""
     p = lambda n: os.path.join(d, n)
     run("lattice-to-post", "--acoustic-scale=" + acwt, "ark:" + p("ldp.ark"), "ark:" + p(pre + "post.ark"))
     run("weight-silence-post", "0.01", sil, p("final.mdl"), "ark:" + p(pre + "post.ark"), "ark:" + p(pre + "wsp.ark"))
     run("gmm-post-to-gpost", p("final.mdl"), "ark:" + p("feats.ark"), "ark:" + p(pre + "wsp.ark"), "ark:" + p(pre + "gpost.ark"))
-    run("gmm-est-fmllr-gpost", "--fmllr-min-count=" + min_count, "--spk2utt=ark:" + p("spk2utt"), p("final.mdl"), "ark:" + p("feats.ark"),
-        "ark:" + p(pre + "gpost.ark"), "ark:" + p(pre + "pre_trans.ark"))
+    if trans_tmp_from is None:
+        run("gmm-est-fmllr-gpost", "--fmllr-min-count=" + min_count, "--spk2utt=ark:" + p("spk2utt"), p("final.mdl"), "ark:" + p("feats.ark"),
+            "ark:" + p(pre + "gpost.ark"), "ark:" + p(pre + "pre_trans.ark"))
+    else:
+        shutil.copyfile(p(trans_tmp_from + "pre_trans.ark"), p(pre + "pre_trans.ark"))
     if trans_tmp_from is None:
         run("gmm-est-fmllr", "--fmllr-min-count=" + min_count, "--spk2utt=ark:" + p("spk2utt"), p("final.mdl"), "ark:" + p("feats.ark"),
             "ark:" + p(pre + "wsp.ark"), "ark:" + p(pre + "trans_tmp.ark"))

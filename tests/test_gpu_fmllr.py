@@ -96,7 +96,7 @@ def test_gmm_est_fmllr_bin_function_vs_golden(tmp_path):
     host = C.CDLL(build.HOST_LIB)
     d = tmp_path
     g = util.load("fmllr")
-    for k in ("file_final_mdl", "file_feats_ark", "file_wsp_ark", "file_trans_tmp_ark", "file_pre_trans_ark"):
+    for k in ("file_final_mdl", "file_feats_ark", "file_wsp_ark", "file_trans_tmp_ark", "file_pre_trans_ark", "file_gpost_ark"):
         name = k[5:].rsplit("_", 1)
         (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
     (d / "spk2utt").write_text(str(g["text_spk2utt"]))
@@ -104,6 +104,12 @@ def test_gmm_est_fmllr_bin_function_vs_golden(tmp_path):
     args = ["--fmllr-min-count=50", "--spk2utt=ark:%s" % (d / "spk2utt"), str(d / "final.mdl"), "ark:%s" % (d / "feats.ark"), "ark:%s" % (d / "wsp.ark")]
     assert call(host.vb_GmmEstFmllr, ["gmm-est-fmllr"] + args + ["ark:%s" % (d / "m.ark")], log) == 0, open(log).read()
     mine, want = read_fm_ark(str(d / "m.ark")), read_fm_ark(str(d / "trans_tmp.ark"))
+    assert list(mine) == list(want)
+    for k in want:
+        np.testing.assert_allclose(mine[k], want[k], atol=2e-4, rtol=0)
+    # the Gaussian-posterior form (first pass of DecodeFmllr): the reference's gpost archive in, its pre_trans out
+    assert call(host.vb_GmmEstFmllrGpost, ["gmm-est-fmllr-gpost"] + args[:4] + ["ark:%s" % (d / "gpost.ark"), "ark:%s" % (d / "g.ark")], log) == 0, open(log).read()
+    mine, want = read_fm_ark(str(d / "g.ark")), read_fm_ark(str(d / "pre_trans.ark"))
     assert list(mine) == list(want)
     for k in want:
         np.testing.assert_allclose(mine[k], want[k], atol=2e-4, rtol=0)

@@ -99,7 +99,7 @@ def test_fmllr_chain_matches_golden(host, tmp_path):
             name = k[5:].rsplit("_", 1)
             (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
     (d / "spk2utt").write_text(str(g["text_spk2utt"]))
-    gg.run_fmllr_chain(str(d), mine_runner(host, d), "m_", trans_tmp_from="")      # gmm-est-fmllr itself: tests/test_gpu_fmllr.py
+    gg.run_fmllr_chain(str(d), mine_runner(host, d), "m_", trans_tmp_from="")      # the two estimation programs: tests/test_gpu_fmllr.py
     compare_chain(d)
 
 

@@ -104,6 +104,31 @@ __global__ __launch_bounds__(256) void fmllr_frame_stats_kernel(
   if (lane == 0) count_out[t] = count;
 }
 
+// the same per-frame terms from explicit Gaussian-level posteriors (gmm-est-fmllr-gpost: FmllrDiagGmmAccs::AccumulateFromPosteriors
+// fed by gmm-post-to-gpost's output, K/gmmbin/gmm-est-fmllr-gpost.cc:36-50): pair q of a frame is a pdf and one posterior per Gaussian
+__global__ __launch_bounds__(256) void fmllr_frame_stats_gpost_kernel(
+    long long T, int D, const long long *__restrict__ pair_off, const int *__restrict__ pair_pdf, const long long *__restrict__ gpost_off,
+    const float *__restrict__ gpost, const int *__restrict__ pdf_offs, const float *__restrict__ miv, const float *__restrict__ iv,
+    float *__restrict__ a_out, float *__restrict__ b_out, float *__restrict__ count_out) {
+  const int lane = threadIdx.x & 63;
+  const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  float a = 0.f, b = 0.f, count = 0.f;
+  for (long long q = pair_off[t]; q < pair_off[t + 1]; q++) {
+    const int g0 = pdf_offs[pair_pdf[q]];
+    const long long o0 = gpost_off[q], o1 = gpost_off[q + 1];
+    float sum = 0.f;
+    for (long long o = o0; o < o1; o++) {
+      const float post = gpost[o];
+      sum += post;
+      if (lane < D && post != 0.f) { const size_t g = (size_t)(g0 + (int)(o - o0)); a += post * miv[g * D + lane]; b += post * iv[g * D + lane]; }
+    }
+    count += sum;
+  }
+  if (lane < D) { a_out[t * D + lane] = a; b_out[t * D + lane] = b; }
+  if (lane == 0) count_out[t] = count;
+}
+
 __global__ __launch_bounds__(NWAVE * 64) void fmllr_accumulate_kernel(
     const float *__restrict__ feats, const float *__restrict__ a_in, const float *__restrict__ b_in, const float *__restrict__ count_in, int D,
     const Slice *__restrict__ slices, const Seg *__restrict__ segs, const ColTile *__restrict__ tiles,
@@ -219,18 +244,14 @@ int vbh_fmllr_work(int32_t dim, int64_t T, double *bytes, double *flops) {
   return 0;
 }
 
-int vbh_fmllr_accumulate(vbh_ctx *ctx, const vbh_gmm *ali_gmm, const vbh_gmm *adapt_gmm, const float *d_feats, int32_t n_utt,
-                         const int64_t *h_frame_offsets, const int32_t *h_utt2spk, int32_t n_spk, const int64_t *h_pair_offsets,
-                         const int32_t *h_pair_pdf, const float *h_pair_weight, double *h_beta, double *h_K, double *h_G,
-                         float *kernel_ms) {
-  VBH_CHECK(ctx && ali_gmm && adapt_gmm && d_feats && h_frame_offsets && h_utt2spk && h_pair_offsets && h_beta && h_K && h_G,
-            "vbh_fmllr_accumulate: NULL argument");
+}  // extern "C"
+
+// everything both entry points share: argument checks, slices, the per-frame pass chosen by the caller, the contraction, the copy back
+template <class FrameStats>
+static int fmllr_run(vbh_ctx *ctx, const vbh_gmm_view &vm, const float *d_feats, int32_t n_utt, const int64_t *h_frame_offsets, const int32_t *h_utt2spk,
+                     int32_t n_spk, const int64_t *h_pair_offsets, const int32_t *h_pair_pdf, double *h_beta, double *h_K, double *h_G, float *kernel_ms,
+                     FrameStats frame_stats) {
   VBH_CHECK(n_utt >= 1 && n_spk >= 1, "vbh_fmllr_accumulate: empty batch");
-  if (vbh_use_device(ctx)) return -1;
-  vbh_gmm_view va, vm;
-  vbh_gmm_view_get(ali_gmm, &va);
-  vbh_gmm_view_get(adapt_gmm, &vm);
-  VBH_CHECK(va.D == vm.D && va.P == vm.P && va.G == vm.G, "vbh_fmllr_accumulate: the two models differ in shape");
   const int D = vm.D, n1 = D + 1;
   VBH_CHECK(D >= 1 && D <= 47, "vbh_fmllr_accumulate: dim %d out of range [1,47]", D);
   const long long T = h_frame_offsets[n_utt];
@@ -273,11 +294,11 @@ int vbh_fmllr_accumulate(vbh_ctx *ctx, const vbh_gmm *ali_gmm, const vbh_gmm *ad
   }
   VBH_CHECK(!slices.empty(), "vbh_fmllr_accumulate: no frames assigned to a speaker");
   hipStream_t st = ctx->stream;
-  DevBuf<long long> d_poff; DevBuf<int> d_ppdf; DevBuf<float> d_pw, d_a, d_b, d_cnt; DevBuf<Seg> d_segs; DevBuf<Slice> d_slices; DevBuf<ColTile> d_tiles;
+  DevBuf<long long> d_poff; DevBuf<int> d_ppdf; DevBuf<float> d_a, d_b, d_cnt; DevBuf<Seg> d_segs; DevBuf<Slice> d_slices; DevBuf<ColTile> d_tiles;
   DevBuf<double> d_beta, d_K, d_G;
   static_assert(sizeof(long long) == sizeof(int64_t), "int64");
   if (d_poff.upload(reinterpret_cast<const long long *>(h_pair_offsets), (size_t)T + 1, st) || d_ppdf.upload(h_pair_pdf, (size_t)std::max<long long>(n_pairs, 1), st) ||
-      d_pw.upload(h_pair_weight, (size_t)std::max<long long>(n_pairs, 1), st) || d_a.alloc((size_t)T * D) || d_b.alloc((size_t)T * D) || d_cnt.alloc((size_t)T) ||
+      d_a.alloc((size_t)T * D) || d_b.alloc((size_t)T * D) || d_cnt.alloc((size_t)T) ||
       d_segs.upload(segs.data(), segs.size(), st) || d_slices.upload(slices.data(), slices.size(), st) || d_tiles.upload(tiles.data(), tiles.size(), st) ||
       d_beta.alloc(n_spk) || d_K.alloc((size_t)n_spk * D * n1) || d_G.alloc((size_t)n_spk * D * n1 * n1))
     return -1;
@@ -286,8 +307,7 @@ int vbh_fmllr_accumulate(vbh_ctx *ctx, const vbh_gmm *ali_gmm, const vbh_gmm *ad
   VBH_HIP(hipMemsetAsync(d_G.p, 0, sizeof(double) * (size_t)n_spk * D * n1 * n1, st));
   const long long fblocks = (T + 3) / 4;
   VBH_CHECK(fblocks < 2147483647LL, "vbh_fmllr_accumulate: too many frames");
-  hipLaunchKernelGGL(fmllr_frame_stats_kernel, dim3((unsigned)fblocks), dim3(256), 0, st, d_feats, T, D, d_poff.p, d_ppdf.p, d_pw.p, va.pdf_offs,
-                     va.gconsts, va.miv, va.iv, vm.miv, vm.iv, d_a.p, d_b.p, d_cnt.p);
+  if (frame_stats(st, (unsigned)fblocks, T, n_pairs, d_poff.p, d_ppdf.p, d_a.p, d_b.p, d_cnt.p)) return -1;
   VBH_HIP(hipGetLastError());
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (kernel_ms) { VBH_HIP(hipEventCreate(&e0)); VBH_HIP(hipEventCreate(&e1)); VBH_HIP(hipEventRecord(e0, st)); }
@@ -306,6 +326,59 @@ int vbh_fmllr_accumulate(vbh_ctx *ctx, const vbh_gmm *ali_gmm, const vbh_gmm *ad
     for (int i = 0; i < n1; i++) for (int j = i + 1; j < n1; j++) g[(size_t)i * n1 + j] = g[(size_t)j * n1 + i];
   }
   return 0;
+}
+
+extern "C" {
+
+int vbh_fmllr_accumulate(vbh_ctx *ctx, const vbh_gmm *ali_gmm, const vbh_gmm *adapt_gmm, const float *d_feats, int32_t n_utt,
+                         const int64_t *h_frame_offsets, const int32_t *h_utt2spk, int32_t n_spk, const int64_t *h_pair_offsets,
+                         const int32_t *h_pair_pdf, const float *h_pair_weight, double *h_beta, double *h_K, double *h_G,
+                         float *kernel_ms) {
+  VBH_CHECK(ctx && ali_gmm && adapt_gmm && d_feats && h_frame_offsets && h_utt2spk && h_pair_offsets && h_beta && h_K && h_G,
+            "vbh_fmllr_accumulate: NULL argument");
+  if (vbh_use_device(ctx)) return -1;
+  vbh_gmm_view va, vm;
+  vbh_gmm_view_get(ali_gmm, &va);
+  vbh_gmm_view_get(adapt_gmm, &vm);
+  VBH_CHECK(va.D == vm.D && va.P == vm.P && va.G == vm.G, "vbh_fmllr_accumulate: the two models differ in shape");
+  const int D = vm.D;
+  DevBuf<float> d_pw;
+  return fmllr_run(ctx, vm, d_feats, n_utt, h_frame_offsets, h_utt2spk, n_spk, h_pair_offsets, h_pair_pdf, h_beta, h_K, h_G, kernel_ms,
+                   [&](hipStream_t st, unsigned fblocks, long long T, long long n_pairs, const long long *d_poff, const int *d_ppdf, float *d_a, float *d_b, float *d_cnt) -> int {
+                     if (d_pw.upload(h_pair_weight, (size_t)std::max<long long>(n_pairs, 1), st)) return -1;
+                     hipLaunchKernelGGL(fmllr_frame_stats_kernel, dim3(fblocks), dim3(256), 0, st, d_feats, T, D, d_poff, d_ppdf, d_pw.p, va.pdf_offs, va.gconsts,
+                                        va.miv, va.iv, vm.miv, vm.iv, d_a, d_b, d_cnt);
+                     return 0;
+                   });
+}
+
+int vbh_fmllr_accumulate_gpost(vbh_ctx *ctx, const vbh_gmm *adapt_gmm, const float *d_feats, int32_t n_utt, const int64_t *h_frame_offsets,
+                               const int32_t *h_utt2spk, int32_t n_spk, const int64_t *h_pair_offsets, const int32_t *h_pair_pdf,
+                               const int64_t *h_gpost_offsets, const float *h_gpost, const int32_t *h_pdf_num_gauss, double *h_beta, double *h_K,
+                               double *h_G, float *kernel_ms) {
+  VBH_CHECK(ctx && adapt_gmm && d_feats && h_frame_offsets && h_utt2spk && h_pair_offsets && h_gpost_offsets && h_beta && h_K && h_G,
+            "vbh_fmllr_accumulate_gpost: NULL argument");
+  if (vbh_use_device(ctx)) return -1;
+  vbh_gmm_view vm;
+  vbh_gmm_view_get(adapt_gmm, &vm);
+  const int D = vm.D;
+  if (n_utt >= 1) {        // every pair must carry exactly one posterior per Gaussian of its pdf
+    const long long n_pairs = h_pair_offsets[h_frame_offsets[n_utt]];
+    for (long long q = 0; q < n_pairs; q++) {
+      VBH_CHECK(h_pair_pdf[q] >= 0 && h_pair_pdf[q] < vm.P, "vbh_fmllr_accumulate_gpost: pdf-id out of range");
+      VBH_CHECK(h_gpost_offsets[q + 1] - h_gpost_offsets[q] == h_pdf_num_gauss[h_pair_pdf[q]], "vbh_fmllr_accumulate_gpost: posterior vector does not match the pdf");
+    }
+  }
+  DevBuf<long long> d_goff; DevBuf<float> d_gp;
+  return fmllr_run(ctx, vm, d_feats, n_utt, h_frame_offsets, h_utt2spk, n_spk, h_pair_offsets, h_pair_pdf, h_beta, h_K, h_G, kernel_ms,
+                   [&](hipStream_t st, unsigned fblocks, long long T, long long n_pairs, const long long *d_poff, const int *d_ppdf, float *d_a, float *d_b, float *d_cnt) -> int {
+                     const long long n_g = h_gpost_offsets[n_pairs];
+                     if (d_goff.upload(reinterpret_cast<const long long *>(h_gpost_offsets), (size_t)n_pairs + 1, st) ||
+                         d_gp.upload(h_gpost, (size_t)std::max<long long>(n_g, 1), st)) return -1;
+                     hipLaunchKernelGGL(fmllr_frame_stats_gpost_kernel, dim3(fblocks), dim3(256), 0, st, T, D, d_poff, d_ppdf, d_goff.p, d_gp.p, vm.pdf_offs, vm.miv,
+                                        vm.iv, d_a, d_b, d_cnt);
+                     return 0;
+                   });
 }
 
 }  // extern "C"

@@ -87,53 +87,6 @@ std::map<std::string, vbio::Matrix> ReadFeatureTable(const std::string &rspec) {
   return out;
 }
 
-// the common body of gmm-est-fmllr and gmm-est-fmllr-gpost: per speaker (or utterance) statistics
-// -> transform.  `accumulate(utt, feats, accs)` returns false when the utterance has to be skipped.
-template <class Acc>
-int EstimateFmllr(const char *prog, const Options &po, const Gmm &gmm, const std::string &feat_rspec, const std::string &trans_wspec, Log &log, Acc accumulate) {
-  const vbfmllr::FmllrOptions opts = ReadFmllrOptions(po);
-  if (opts.update_type != "full") throw ApiError("--fmllr-update-type=" + opts.update_type + " is not supported (only full)");
-  vbio::MatrixWriter writer(trans_wspec);
-  const int D = gmm.m.dim;
-  double tot_impr = 0.0, tot_t = 0.0;
-  int num_done = 0, num_err = 0;
-  auto finish = [&](const std::string &key, vbfmllr::FmllrAccs &accs, const char *what) {
-    vbio::Matrix t; t.rows = D; t.cols = D + 1; t.data.assign((size_t)D * (D + 1), 0.0f);
-    for (int d = 0; d < D; d++) t.data[(size_t)d * (D + 1) + d] = 1.0f;
-    float count = 0.0f;
-    const float impr = accs.Update(opts, t.data.data(), &count);
-    if (!(accs.beta() > opts.min_count)) log.os() << "WARNING (" << prog << ") Not updating fMLLR since below min-count: count is " << accs.beta() << "\n";
-    writer.Write(key, t);
-    log.os() << "LOG (" << prog << ") For " << what << " " << key << ", auxf-impr from fMLLR is " << (impr / count) << ", over " << count << " frames.\n";
-    tot_impr += impr; tot_t += count;
-  };
-  if (po.Has("spk2utt")) {
-    const auto feats = ReadFeatureTable(feat_rspec);
-    for (const auto &su : vbio::ReadSpk2Utt(po.Str("spk2utt", ""))) {
-      vbfmllr::FmllrAccs accs(D);
-      for (const std::string &utt : su.second) {
-        auto it = feats.find(utt);
-        if (it == feats.end()) { log.os() << "WARNING (" << prog << ") Did not find features for utterance " << utt << "\n"; num_err++; continue; }
-        if (accumulate(utt, it->second, &accs)) num_done++; else num_err++;
-      }
-      finish(su.first, accs, "speaker");
-    }
-  } else {
-    vbio::MatrixReader r(feat_rspec);
-    std::string utt; vbio::Matrix m;
-    while (r.Next(&utt, &m)) {
-      vbfmllr::FmllrAccs accs(D);
-      if (!accumulate(utt, m, &accs)) { num_err++; continue; }
-      num_done++;
-      finish(utt, accs, "utterance");
-    }
-  }
-  writer.Close();
-  log.os() << "LOG (" << prog << ") Done " << num_done << " files, " << num_err << " with errors.\n";
-  log.os() << "LOG (" << prog << ") Overall fMLLR auxf impr per frame is " << (tot_impr / tot_t) << " over " << tot_t << " frames.\n";
-  return num_done != 0 ? 0 : 1;
-}
-
 }  // namespace
 
 // lattice-to-post   (VB/src/latbin/lattice-to-post.cpp; K/latbin/lattice-to-post.cc:28-115)
@@ -255,6 +208,97 @@ int GmmPostToGpost(int argc, char *argv[], std::ofstream &file_log) {
   });
 }
 
+// The common body of gmm-est-fmllr and gmm-est-fmllr-gpost.  The statistics come from the GPU (vbh_fmllr_accumulate /
+// _gpost: per-frame terms, then the f64-MFMA contraction per speaker); the row-by-row update of each unit's matrix
+// stays on the host.  `add_utt(utt, feats, sink)` appends the utterance's posterior pairs to the batch (false: skip it).
+struct PairSink {
+  std::vector<int64_t> poff{0}, goff{0};
+  std::vector<int32_t> ppdf; std::vector<float> pw, gpost;
+  void EndFrame() { poff.push_back((int64_t)ppdf.size()); }
+  void Clear() { poff.assign(1, 0); goff.assign(1, 0); ppdf.clear(); pw.clear(); gpost.clear(); }
+};
+template <class AddUtt>
+static int EstimateOnGpu(const char *prog, bool use_gpost, const Options &po, const Gmm &gmm, const std::string &feat_rspec, const std::string &trans_wspec,
+                         Log &log, AddUtt add_utt) {
+  const vbfmllr::FmllrOptions opts = ReadFmllrOptions(po);
+  if (opts.update_type != "full") throw ApiError("--fmllr-update-type=" + opts.update_type + " is not supported (only full)");
+  const int D = gmm.m.dim, n1 = D + 1;
+  // ---- the units a transform is estimated for (speakers, or utterances without --spk2utt) and their utterances
+  std::vector<std::pair<std::string, std::vector<std::string>>> units;
+  std::map<std::string, vbio::Matrix> feats;
+  {
+    vbio::MatrixReader r(feat_rspec);
+    std::string k; vbio::Matrix m;
+    while (r.Next(&k, &m)) { if (!po.Has("spk2utt")) units.emplace_back(k, std::vector<std::string>{k}); feats.emplace(k, std::move(m)); }
+  }
+  if (po.Has("spk2utt")) units = vbio::ReadSpk2Utt(po.Str("spk2utt", ""));
+  vbh_ctx *ctx = SharedCtx();
+  vbh_gmm *dgmm = nullptr;
+  if (vbh_gmm_create(ctx, D, gmm.m.num_pdfs, gmm.m.pdf_offsets.data(), gmm.m.weights.data(), gmm.m.means_invvars.data(), gmm.m.inv_vars.data(), &dgmm) != 0)
+    throw ApiError(std::string("vbh_gmm_create: ") + vbh_last_error());
+  struct GmmGuard { vbh_gmm *g; ~GmmGuard() { vbh_gmm_destroy(g); } } guard{dgmm};
+  std::vector<int32_t> num_gauss(gmm.m.num_pdfs);
+  for (int p = 0; p < gmm.m.num_pdfs; p++) num_gauss[p] = gmm.m.pdf_offsets[p + 1] - gmm.m.pdf_offsets[p];
+  std::vector<vbfmllr::FmllrAccs> accs(units.size(), vbfmllr::FmllrAccs(D));
+  std::vector<uint8_t> unit_has_utt(units.size(), 0);
+  int num_done = 0, num_err = 0;
+  // ---- batches of utterances through the GPU (statistics add up across batches)
+  std::vector<float> bfeats; std::vector<int64_t> foff{0}; std::vector<int32_t> u2s;
+  PairSink sink;
+  auto flush = [&]() {
+    if (u2s.empty()) return;
+    void *d_feats = nullptr;
+    if (vbh_dev_alloc(ctx, sizeof(float) * bfeats.size(), &d_feats) != 0) throw ApiError(std::string("vbh_dev_alloc: ") + vbh_last_error());
+    struct DevGuard { vbh_ctx *c; void *p; ~DevGuard() { vbh_dev_free(c, p); } } dg{ctx, d_feats};
+    if (vbh_copy_h2d(ctx, d_feats, bfeats.data(), sizeof(float) * bfeats.size()) != 0) throw ApiError(std::string("vbh_copy_h2d: ") + vbh_last_error());
+    const int S = (int)units.size();
+    std::vector<double> beta(S), K((size_t)S * D * n1), G((size_t)S * D * n1 * n1);
+    const int rc = use_gpost
+        ? vbh_fmllr_accumulate_gpost(ctx, dgmm, (const float *)d_feats, (int32_t)u2s.size(), foff.data(), u2s.data(), S, sink.poff.data(), sink.ppdf.data(),
+                                     sink.goff.data(), sink.gpost.data(), num_gauss.data(), beta.data(), K.data(), G.data(), nullptr)
+        : vbh_fmllr_accumulate(ctx, dgmm, dgmm, (const float *)d_feats, (int32_t)u2s.size(), foff.data(), u2s.data(), S, sink.poff.data(), sink.ppdf.data(),
+                               sink.pw.data(), beta.data(), K.data(), G.data(), nullptr);
+    if (rc != 0) throw ApiError(std::string("vbh_fmllr_accumulate: ") + vbh_last_error());
+    for (int s = 0; s < S; s++) if (beta[s] != 0.0) accs[s].AddStats(beta[s], &K[(size_t)s * D * n1], &G[(size_t)s * D * n1 * n1]);
+    bfeats.clear(); foff.assign(1, 0); u2s.clear(); sink.Clear();
+  };
+  for (size_t s = 0; s < units.size(); s++) {
+    for (const std::string &utt : units[s].second) {
+      auto fi = feats.find(utt);
+      if (fi == feats.end()) { log.os() << "WARNING (" << prog << ") Did not find features for utterance " << utt << "\n"; num_err++; continue; }
+      const vbio::Matrix &f = fi->second;
+      if (f.cols != D) throw ApiError("Dim mismatch: data dim = " + std::to_string(f.cols) + " vs. model dim = " + std::to_string(D));
+      if (!add_utt(utt, f, &sink)) { num_err++; continue; }
+      bfeats.insert(bfeats.end(), f.data.begin(), f.data.end());
+      foff.push_back(foff.back() + f.rows);
+      u2s.push_back((int32_t)s);
+      unit_has_utt[s] = 1;
+      num_done++;
+      if (foff.back() >= (int64_t)4 << 20) flush();
+    }
+  }
+  flush();
+  // ---- per unit: update from the unit transform, write
+  vbio::MatrixWriter writer(trans_wspec);
+  double tot_impr = 0.0, tot_t = 0.0;
+  for (size_t s = 0; s < units.size(); s++) {
+    if (!po.Has("spk2utt") && !unit_has_utt[s]) continue;     // per-utterance mode writes nothing for skipped utterances
+    vbio::Matrix t; t.rows = D; t.cols = n1; t.data.assign((size_t)D * n1, 0.0f);
+    for (int d = 0; d < D; d++) t.data[(size_t)d * n1 + d] = 1.0f;
+    float count = 0.0f;
+    const float impr = accs[s].Update(opts, t.data.data(), &count);
+    if (!(accs[s].beta() > opts.min_count)) log.os() << "WARNING (" << prog << ") Not updating fMLLR since below min-count: count is " << accs[s].beta() << "\n";
+    writer.Write(units[s].first, t);
+    log.os() << "LOG (" << prog << ") For " << (po.Has("spk2utt") ? "speaker " : "utterance ") << units[s].first << ", auxf-impr from fMLLR is " << (impr / count)
+             << ", over " << count << " frames.\n";
+    tot_impr += impr; tot_t += count;
+  }
+  writer.Close();
+  log.os() << "LOG (" << prog << ") Done " << num_done << " files, " << num_err << " with errors.\n";
+  log.os() << "LOG (" << prog << ") Overall fMLLR auxf impr per frame is " << (tot_impr / tot_t) << " over " << tot_t << " frames.\n";
+  return num_done != 0 ? 0 : 1;
+}
+
 // gmm-est-fmllr-gpost   (VB/src/gmmbin/gmm-est-fmllr-gpost.cpp; K/gmmbin/gmm-est-fmllr-gpost.cc:28-190)
 int GmmEstFmllrGpost(int argc, char *argv[], std::ofstream &file_log) {
   return Guard("gmm-est-fmllr-gpost", &file_log, [&](Log &log) -> int {
@@ -265,110 +309,43 @@ int GmmEstFmllrGpost(int argc, char *argv[], std::ofstream &file_log) {
     const Gmm gmm(po.args[0]);
     std::map<std::string, vbio::GaussPost> gposts;
     for (auto &kv : vbio::ReadGaussPostTable(po.args[2])) gposts.emplace(kv.first, std::move(kv.second));
-    return EstimateFmllr("gmm-est-fmllr-gpost", po, gmm, po.args[1], po.args[3], log, [&](const std::string &utt, const vbio::Matrix &feats, vbfmllr::FmllrAccs *accs) {
+    return EstimateOnGpu("gmm-est-fmllr-gpost", true, po, gmm, po.args[1], po.args[3], log, [&](const std::string &utt, const vbio::Matrix &feats, PairSink *sink) {
       auto it = gposts.find(utt);
       if (it == gposts.end()) { log.os() << "WARNING (gmm-est-fmllr-gpost) Did not find posteriors for utterance " << utt << "\n"; return false; }
       const vbio::GaussPost &gp = it->second;
       if ((int)gp.size() != feats.rows) { log.os() << "WARNING (gmm-est-fmllr-gpost) GaussPost vector has wrong size " << gp.size() << " vs. " << feats.rows << "\n"; return false; }
-      for (size_t i = 0; i < gp.size(); i++)
-        for (const auto &pr : gp[i]) {
-          const vbfmllr::PdfView pdf = gmm.Pdf(pr.first);
-          if ((int)pr.second.size() != pdf.num_gauss) throw ApiError("Gaussian posteriors do not match the model for utterance " + utt);
-          accs->AccumulateFromPosteriors(pdf, &feats.data[i * (size_t)feats.cols], pr.second.data());
-        }
+      for (const auto &fr : gp)
+        for (const auto &pr : fr)
+          if (pr.first < 0 || pr.first >= gmm.m.num_pdfs || (int)pr.second.size() != gmm.m.pdf_offsets[pr.first + 1] - gmm.m.pdf_offsets[pr.first])
+            throw ApiError("Gaussian posteriors do not match the model for utterance " + utt);
+      for (const auto &fr : gp) {
+        for (const auto &pr : fr) { sink->ppdf.push_back(pr.first); sink->gpost.insert(sink->gpost.end(), pr.second.begin(), pr.second.end()); sink->goff.push_back((int64_t)sink->gpost.size()); }
+        sink->EndFrame();
+      }
       return true;
     });
   });
 }
 
-// gmm-est-fmllr   (VB/src/gmmbin/gmm-est-fmllr.cpp; K/gmmbin/gmm-est-fmllr.cc:28-200).  The statistics come from
-// the GPU (vbh_fmllr_accumulate: per-frame Gaussian posteriors, then the f64-MFMA contraction per speaker); the
-// row-by-row update of each speaker's 39 x 40 matrix stays on the host.
+// gmm-est-fmllr   (VB/src/gmmbin/gmm-est-fmllr.cpp; K/gmmbin/gmm-est-fmllr.cc:28-200)
 int GmmEstFmllr(int argc, char *argv[], std::ofstream &file_log) {
   return Guard("gmm-est-fmllr", &file_log, [&](Log &log) -> int {
     Options po;
     po.Know({"spk2utt", "fmllr-update-type", "fmllr-min-count", "fmllr-num-iters"});
     po.Parse(argc, argv);
     if (po.args.size() != 4) throw ApiError("Wrong arguments.");
-    const vbfmllr::FmllrOptions opts = ReadFmllrOptions(po);
-    if (opts.update_type != "full") throw ApiError("--fmllr-update-type=" + opts.update_type + " is not supported (only full)");
     const Gmm gmm(po.args[0]);
-    const int D = gmm.m.dim, n1 = D + 1;
     std::map<std::string, vbio::Posterior> posts;
     for (auto &kv : vbio::ReadPosteriorTable(po.args[2])) posts.emplace(kv.first, std::move(kv.second));
-    // ---- the units a transform is estimated for (speakers, or utterances without --spk2utt) and their utterances
-    std::vector<std::pair<std::string, std::vector<std::string>>> units;
-    std::map<std::string, vbio::Matrix> feats;
-    {
-      vbio::MatrixReader r(po.args[1]);
-      std::string k; vbio::Matrix m;
-      while (r.Next(&k, &m)) { if (!po.Has("spk2utt")) units.emplace_back(k, std::vector<std::string>{k}); feats.emplace(k, std::move(m)); }
-    }
-    if (po.Has("spk2utt")) units = vbio::ReadSpk2Utt(po.Str("spk2utt", ""));
-    vbh_ctx *ctx = SharedCtx();
-    vbh_gmm *dgmm = nullptr;
-    if (vbh_gmm_create(ctx, D, gmm.m.num_pdfs, gmm.m.pdf_offsets.data(), gmm.m.weights.data(), gmm.m.means_invvars.data(), gmm.m.inv_vars.data(), &dgmm) != 0)
-      throw ApiError(std::string("vbh_gmm_create: ") + vbh_last_error());
-    struct GmmGuard { vbh_gmm *g; ~GmmGuard() { vbh_gmm_destroy(g); } } guard{dgmm};
-    std::vector<vbfmllr::FmllrAccs> accs(units.size(), vbfmllr::FmllrAccs(D));
-    int num_done = 0, num_no_post = 0, num_err = 0;
-    // ---- batches of utterances through the GPU (statistics add up across batches)
-    std::vector<float> bfeats; std::vector<int64_t> foff{0}, poff{0}; std::vector<int32_t> u2s, ppdf; std::vector<float> pw;
-    auto flush = [&]() {
-      if (u2s.empty()) return;
-      const int64_t T = foff.back();
-      void *d_feats = nullptr;
-      if (vbh_dev_alloc(ctx, sizeof(float) * bfeats.size(), &d_feats) != 0) throw ApiError(std::string("vbh_dev_alloc: ") + vbh_last_error());
-      struct DevGuard { vbh_ctx *c; void *p; ~DevGuard() { vbh_dev_free(c, p); } } dg{ctx, d_feats};
-      if (vbh_copy_h2d(ctx, d_feats, bfeats.data(), sizeof(float) * bfeats.size()) != 0) throw ApiError(std::string("vbh_copy_h2d: ") + vbh_last_error());
-      const int S = (int)units.size();
-      std::vector<double> beta(S), K((size_t)S * D * n1), G((size_t)S * D * n1 * n1);
-      if (vbh_fmllr_accumulate(ctx, dgmm, dgmm, (const float *)d_feats, (int32_t)u2s.size(), foff.data(), u2s.data(), S, poff.data(), ppdf.data(), pw.data(),
-                               beta.data(), K.data(), G.data(), nullptr) != 0)
-        throw ApiError(std::string("vbh_fmllr_accumulate: ") + vbh_last_error());
-      (void)T;
-      for (int s = 0; s < S; s++) if (beta[s] != 0.0) accs[s].AddStats(beta[s], &K[(size_t)s * D * n1], &G[(size_t)s * D * n1 * n1]);
-      bfeats.clear(); foff.assign(1, 0); poff.assign(1, 0); u2s.clear(); ppdf.clear(); pw.clear();
-    };
-    for (size_t s = 0; s < units.size(); s++) {
-      for (const std::string &utt : units[s].second) {
-        auto fi = feats.find(utt);
-        if (fi == feats.end()) { log.os() << "WARNING (gmm-est-fmllr) Did not find features for utterance " << utt << "\n"; num_err++; continue; }
-        auto pi = posts.find(utt);
-        if (pi == posts.end()) { log.os() << "WARNING (gmm-est-fmllr) Did not find posteriors for utterance " << utt << "\n"; num_no_post++; continue; }
-        const vbio::Matrix &f = fi->second;
-        if ((int)pi->second.size() != f.rows) { log.os() << "WARNING (gmm-est-fmllr) Posterior vector has wrong size " << pi->second.size() << " vs. " << f.rows << "\n"; num_err++; continue; }
-        if (f.cols != D) throw ApiError("Dim mismatch: data dim = " + std::to_string(f.cols) + " vs. model dim = " + std::to_string(D));
-        vbio::Posterior pdf_post;
-        PosteriorToPdfs(gmm.m.tid2pdf, pi->second, &pdf_post);
-        bfeats.insert(bfeats.end(), f.data.begin(), f.data.end());
-        foff.push_back(foff.back() + f.rows);
-        u2s.push_back((int32_t)s);
-        for (const auto &fr : pdf_post) { for (const auto &pr : fr) { ppdf.push_back(pr.first); pw.push_back(pr.second); } poff.push_back((int64_t)ppdf.size()); }
-        num_done++;
-        if (foff.back() >= (int64_t)4 << 20) flush();
-      }
-    }
-    flush();
-    // ---- per unit: update from the unit transform, write
-    vbio::MatrixWriter writer(po.args[3]);
-    double tot_impr = 0.0, tot_t = 0.0;
-    for (size_t s = 0; s < units.size(); s++) {
-      if (!po.Has("spk2utt") && !(accs[s].beta() > 0.0) && !posts.count(units[s].first)) continue;     // per-utterance mode skips utterances without posteriors
-      vbio::Matrix t; t.rows = D; t.cols = n1; t.data.assign((size_t)D * n1, 0.0f);
-      for (int d = 0; d < D; d++) t.data[(size_t)d * n1 + d] = 1.0f;
-      float count = 0.0f;
-      const float impr = accs[s].Update(opts, t.data.data(), &count);
-      if (!(accs[s].beta() > opts.min_count)) log.os() << "WARNING (gmm-est-fmllr) Not updating fMLLR since below min-count: count is " << accs[s].beta() << "\n";
-      writer.Write(units[s].first, t);
-      log.os() << "LOG (gmm-est-fmllr) For " << (po.Has("spk2utt") ? "speaker " : "utterance ") << units[s].first << ", auxf-impr from fMLLR is " << (impr / count)
-               << ", over " << count << " frames.\n";
-      tot_impr += impr; tot_t += count;
-    }
-    writer.Close();
-    log.os() << "LOG (gmm-est-fmllr) Done " << num_done << " files, " << num_no_post << " with no posts, " << num_err << " with other errors.\n";
-    log.os() << "LOG (gmm-est-fmllr) Overall fMLLR auxf impr per frame is " << (tot_impr / tot_t) << " over " << tot_t << " frames.\n";
-    return num_done != 0 ? 0 : 1;
+    return EstimateOnGpu("gmm-est-fmllr", false, po, gmm, po.args[1], po.args[3], log, [&](const std::string &utt, const vbio::Matrix &feats, PairSink *sink) {
+      auto pi = posts.find(utt);
+      if (pi == posts.end()) { log.os() << "WARNING (gmm-est-fmllr) Did not find posteriors for utterance " << utt << "\n"; return false; }
+      if ((int)pi->second.size() != feats.rows) { log.os() << "WARNING (gmm-est-fmllr) Posterior vector has wrong size " << pi->second.size() << " vs. " << feats.rows << "\n"; return false; }
+      vbio::Posterior pdf_post;
+      PosteriorToPdfs(gmm.m.tid2pdf, pi->second, &pdf_post);
+      for (const auto &fr : pdf_post) { for (const auto &pr : fr) { sink->ppdf.push_back(pr.first); sink->pw.push_back(pr.second); } sink->EndFrame(); }
+      return true;
+    });
   });
 }
 
