@@ -151,6 +151,11 @@ int32_t vbh_gmm_dim(const vbh_gmm *g);
 int vbh_gmm_get_gconsts(const vbh_gmm *g, float *h_gconsts);   /* [G] as computed at create */
 /* d_feats [T x dim] -> d_loglikes [T x num_pdfs] (unscaled log-likelihoods) */
 int vbh_gmm_loglikes(vbh_gmm *g, const float *d_feats, int64_t T, float *d_loglikes);
+/* The on-demand form (the reference's semantics, K/gmm/decodable-am-diag-gmm.cc:28-72: a pdf is evaluated when the search or a
+ * lattice asks for it): log-likelihoods of the (frame, pdf) pairs [h_pair_offsets[t], h_pair_offsets[t+1]) of every frame t only;
+ * h_out [h_pair_offsets[T]] on the host.  Used by gmm-rescore-lattice.  Synchronises. */
+int vbh_gmm_loglikes_pairs(vbh_gmm *g, const float *d_feats, int64_t T, const int64_t *h_pair_offsets, const int32_t *h_pair_pdf,
+                           float *h_out);
 /* algorithmic work of one vbh_gmm_loglikes call: bytes and flops */
 int vbh_gmm_work(const vbh_gmm *g, int64_t T, double *bytes, double *flops);
 

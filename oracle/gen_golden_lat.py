@@ -70,8 +70,8 @@ def run_reference_chain(d, acwt="0.083333", beam="6", lmwt="9", wip="0.5"):
 
 def run_fmllr_chain(d, run, pre, acwt="0.083333", sil="1:2", min_count="50", trans_tmp_from=None):
     """the programs between the two searches of DecodeFmllr (VB/scr/steps/decode_fmllr.cpp:314-640), `run(name, *args)`
-    executing one of them; files are prefixed with `pre`.  trans_tmp_from: take the outputs of gmm-est-fmllr-gpost and
-    gmm-est-fmllr from that prefix instead of running them (this build's take their statistics from the GPU)"""
+    executing one of them; files are prefixed with `pre`.  trans_tmp_from: take the outputs of gmm-est-fmllr-gpost,
+    gmm-est-fmllr and gmm-rescore-lattice from that prefix instead of running them (this build's need the GPU)"""
     p = lambda n: os.path.join(d, n)
     run("lattice-to-post", "--acoustic-scale=" + acwt, "ark:" + p("ldp.ark"), "ark:" + p(pre + "post.ark"))
     run("weight-silence-post", "0.01", sil, p("final.mdl"), "ark:" + p(pre + "post.ark"), "ark:" + p(pre + "wsp.ark"))
@@ -87,7 +87,10 @@ def run_fmllr_chain(d, run, pre, acwt="0.083333", sil="1:2", min_count="50", tra
     else:
         shutil.copyfile(p(trans_tmp_from + "trans_tmp.ark"), p(pre + "trans_tmp.ark"))
     run("compose-transforms", "--b-is-affine=true", "ark:" + p(pre + "trans_tmp.ark"), "ark:" + p(pre + "pre_trans.ark"), "ark:" + p(pre + "trans.ark"))
-    run("gmm-rescore-lattice", p("final.mdl"), "ark:" + p("raw.ark"), "ark:" + p("feats.ark"), "ark:" + p(pre + "grl.ark"))
+    if trans_tmp_from is None:
+        run("gmm-rescore-lattice", p("final.mdl"), "ark:" + p("raw.ark"), "ark:" + p("feats.ark"), "ark:" + p(pre + "grl.ark"))
+    else:
+        shutil.copyfile(p(trans_tmp_from + "grl.ark"), p(pre + "grl.ark"))
 
 
 def make_fmllr_case(d, seed=5, frames=(150, 120, 140, 130), acwt="0.083333"):

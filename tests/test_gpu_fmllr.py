@@ -142,3 +142,54 @@ def test_fmllr_update_properties(tmp_path):
     imprs = [float(l.split("auxf-impr from fMLLR is")[1].split(",")[0]) for l in open(log) if "auxf-impr" in l]
     assert len(imprs) == 2 and all(x > 0 for x in imprs)
     assert call(host.vb_GmmEstFmllr, base[:1] + ["--fmllr-update-type=diag"] + base[1:] + ["ark:%s" % (d / "x.ark")], log) == -1    # refused, not ignored
+
+
+def test_rescore_and_lattice_to_compact_conversion_vs_golden(tmp_path):
+    """a state-level lattice read where a CompactLattice is expected is folded by Factor + TopSort
+    (K/fstext/lattice-utils-inl.h:27-100): gmm-rescore-lattice with --old-acoustic-scale=1 on features
+    of the right length adds scores but keeps the structure the reference's conversion produced"""
+    from tests.test_host_lattice import assert_same_archives, call
+    from voicebridge_amd import build
+    host = C.CDLL(build.HOST_LIB)
+    d = tmp_path
+    g = util.load("fmllr")
+    for k in ("file_final_mdl", "file_feats_ark", "file_raw_ark", "file_grl_ark"):
+        name = k[5:].rsplit("_", 1)
+        (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
+    log = str(d / "log.txt")
+    assert call(host.vb_GmmRescoreLattice, ["gmm-rescore-lattice", str(d / "final.mdl"), "ark:%s" % (d / "raw.ark"), "ark:%s" % (d / "feats.ark"),
+                                            "ark:%s" % (d / "m.ark")], log) == 0, open(log).read()
+    # scores from the on-demand GPU kernel: costs within float summation order of the reference's
+    assert_same_archives(str(d / "m.ark"), str(d / "grl.ark"), rtol=1e-6, atol=1e-4)
+    mine, want = util.read_lattice_ark(str(d / "m.ark")), util.read_lattice_ark(str(d / "grl.ark"))
+    for k in want:
+        assert [(len(a), [(x[0], x[3], x[4]) for x in a]) for _f, a in mine[k][2]] == [(len(a), [(x[0], x[3], x[4]) for x in a]) for _f, a in want[k][2]]
+    # features shorter than the lattice: reported, utterance skipped, return code 1 when nothing is left
+    (d / "short.ark").write_bytes(b"")
+    util.write_feats_ark(str(d / "short.ark"), {"uttA": np.zeros((5, 39), np.float32)})
+    assert call(host.vb_GmmRescoreLattice, ["gmm-rescore-lattice", str(d / "final.mdl"), "ark:%s" % (d / "raw.ark"), "ark:%s" % (d / "short.ark"),
+                                            "ark:%s" % (d / "m2.ark")], log) == 1
+
+
+@pytest.mark.parametrize("P,G,D,T", [(40, 260, 39, 150), (5, 700, 13, 70)])
+def test_gmm_loglikes_pairs_vs_all_pdf_kernel(ctx, P, G, D, T):
+    """the on-demand form (vbh_gmm_loglikes_pairs) against the batched all-pdf kernel on the same frames,
+    incl. pdfs with more than 64 Gaussians, frames without pairs and repeated pdfs"""
+    import torch
+    from voicebridge_amd import api, synth
+    offs, w, means, iv = synth.gmm_model(P, G, D, seed=G)
+    miv = (means * iv).astype(np.float32)
+    gmm = api.DiagGmm(ctx, offs, w, miv, iv)
+    rng = np.random.default_rng(T)
+    feats = torch.from_numpy((rng.standard_normal((T, D)) * 1.3).astype(np.float32)).to(ctx.device)
+    full = gmm.loglikes(feats).cpu().numpy()
+    n = rng.integers(0, 5, T)
+    poff = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+    ppdf = rng.integers(0, P, int(poff[-1])).astype(np.int32)
+    out = np.zeros(len(ppdf), np.float32)
+    fn = gmm.lib.vbh_gmm_loglikes_pairs
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert fn(gmm.h, feats.data_ptr(), T, poff.ctypes.data, ppdf.ctypes.data, out.ctypes.data) == 0
+    want = np.array([full[t, ppdf[q]] for t in range(T) for q in range(poff[t], poff[t + 1])], np.float32)
+    np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-3)
+    gmm.close()

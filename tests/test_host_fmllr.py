@@ -99,30 +99,8 @@ def test_fmllr_chain_matches_golden(host, tmp_path):
             name = k[5:].rsplit("_", 1)
             (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
     (d / "spk2utt").write_text(str(g["text_spk2utt"]))
-    gg.run_fmllr_chain(str(d), mine_runner(host, d), "m_", trans_tmp_from="")      # the two estimation programs: tests/test_gpu_fmllr.py
+    gg.run_fmllr_chain(str(d), mine_runner(host, d), "m_", trans_tmp_from="")      # the estimation programs and gmm-rescore-lattice: tests/test_gpu_fmllr.py
     compare_chain(d)
-
-
-def test_lattice_to_compact_conversion_matches_golden(host, tmp_path):
-    """a state-level lattice read where a CompactLattice is expected is folded by Factor + TopSort
-    (K/fstext/lattice-utils-inl.h:27-100): gmm-rescore-lattice with --old-acoustic-scale=1 on features
-    of the right length adds scores but keeps the structure the reference's conversion produced"""
-    d = tmp_path
-    g = util.load("fmllr")
-    for k in ("file_final_mdl", "file_feats_ark", "file_raw_ark", "file_grl_ark"):
-        name = k[5:].rsplit("_", 1)
-        (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
-    log = str(d / "log.txt")
-    assert call(host.vb_GmmRescoreLattice, ["gmm-rescore-lattice", str(d / "final.mdl"), "ark:%s" % (d / "raw.ark"), "ark:%s" % (d / "feats.ark"),
-                                            "ark:%s" % (d / "m.ark")], log) == 0, open(log).read()
-    mine, want = util.read_lattice_ark(str(d / "m.ark")), util.read_lattice_ark(str(d / "grl.ark"))
-    for k in want:
-        assert [(len(a), [(x[0], x[3], x[4]) for x in a]) for _f, a in mine[k][2]] == [(len(a), [(x[0], x[3], x[4]) for x in a]) for _f, a in want[k][2]]
-    # features shorter than the lattice: reported, utterance skipped, return code 1 when nothing is left
-    (d / "short.ark").write_bytes(b"")
-    util.write_feats_ark(str(d / "short.ark"), {"uttA": np.zeros((5, 39), np.float32)})
-    assert call(host.vb_GmmRescoreLattice, ["gmm-rescore-lattice", str(d / "final.mdl"), "ark:%s" % (d / "raw.ark"), "ark:%s" % (d / "short.ark"),
-                                            "ark:%s" % (d / "m2.ark")], log) == 1
 
 
 @pytest.mark.skipif(not all(os.access(os.path.join(REFBIN, b), os.X_OK) for b in NEEDED), reason="oracle/_ref/bin not built")

@@ -237,6 +237,65 @@ __global__ __launch_bounds__(256) void gmm_fold_parts_kernel(
   out[idx] = res;
 }
 
+// On-demand form (DecodableAmDiagGmmUnmapped::LogLikelihoodZeroBased, K/gmm/decodable-am-diag-gmm.cc:28-72): only the
+// (frame, pdf) pairs a caller asks for -- e.g. the two or three pdfs a lattice holds at a frame (gmm-rescore-lattice).
+// One wave per frame, lane = feature dimension; a Gaussian's log-likelihood is one wave reduction, lane k keeps the
+// k-th Gaussian's value, LogSumExp across lanes with the reference's cutoff.  Bytes per pair: 2 x 4D per Gaussian of
+// the pdf (model rows, L2-resident) + 4 out; the frame's 4D input is read once: HBM/L2-gather bound, AI ~ 0.5 flop/B.
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__global__ __launch_bounds__(256) void gmm_loglikes_pairs_kernel(
+    const float *__restrict__ feats, long long T, int D, const long long *__restrict__ pair_off, const int *__restrict__ pair_pdf,
+    const int *__restrict__ pdf_offs, const float *__restrict__ gconsts, const float *__restrict__ miv, const float *__restrict__ iv,
+    float *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const float x = lane < D ? feats[t * D + lane] : 0.f, x2 = x * x;
+  const float kMinLogDiff = -15.9423847198486328125f;
+  for (long long q = pair_off[t]; q < pair_off[t + 1]; q++) {
+    const int p = pair_pdf[q];
+    const int g0 = pdf_offs[p], g1 = pdf_offs[p + 1];
+    float res;
+    if (g1 - g0 <= 64) {
+      float mine = -INFINITY;
+      for (int g = g0; g < g1; g++) {
+        float v = 0.f;
+        if (lane < D) v = miv[(size_t)g * D + lane] * x + -0.5f * (iv[(size_t)g * D + lane] * x2);
+        const float ll = gconsts[g] + wsum(v);
+        if (lane == g - g0) mine = ll;
+      }
+      const float mx = wmax(mine);
+      const float e = (lane < g1 - g0 && mine >= mx + kMinLogDiff) ? expf(mine - mx) : 0.f;
+      res = mx > -INFINITY ? mx + logf(wsum(e)) : mx;
+    } else {
+      float mx = -INFINITY;
+      for (int g = g0; g < g1; g++) {
+        float v = 0.f;
+        if (lane < D) v = miv[(size_t)g * D + lane] * x + -0.5f * (iv[(size_t)g * D + lane] * x2);
+        mx = fmaxf(mx, gconsts[g] + wsum(v));
+      }
+      float sum = 0.f;
+      for (int g = g0; g < g1; g++) {
+        float v = 0.f;
+        if (lane < D) v = miv[(size_t)g * D + lane] * x + -0.5f * (iv[(size_t)g * D + lane] * x2);
+        const float ll = gconsts[g] + wsum(v);
+        if (ll >= mx + kMinLogDiff) sum += expf(ll - mx);
+      }
+      res = mx > -INFINITY ? mx + logf(sum) : mx;
+    }
+    if (lane == 0) out[q] = res;
+  }
+}
+
 }  // namespace
 
 struct vbh_gmm {
@@ -367,6 +426,29 @@ int32_t vbh_gmm_num_pdfs(const vbh_gmm *g) { return g->P; }
 int32_t vbh_gmm_dim(const vbh_gmm *g) { return g->D; }
 int vbh_gmm_get_gconsts(const vbh_gmm *g, float *h) {
   memcpy(h, g->gconsts.data(), sizeof(float) * g->G);
+  return 0;
+}
+
+int vbh_gmm_loglikes_pairs(vbh_gmm *g, const float *d_feats, int64_t T, const int64_t *h_pair_offsets, const int32_t *h_pair_pdf, float *h_out) {
+  VBH_CHECK(g && h_pair_offsets, "vbh_gmm_loglikes_pairs: NULL argument");
+  if (T == 0) return 0;
+  VBH_CHECK(T > 0 && d_feats, "vbh_gmm_loglikes_pairs: bad arguments");
+  const long long n = h_pair_offsets[T];
+  if (n == 0) return 0;
+  VBH_CHECK(h_pair_pdf && h_out, "vbh_gmm_loglikes_pairs: NULL argument");
+  for (long long q = 0; q < n; q++) VBH_CHECK(h_pair_pdf[q] >= 0 && h_pair_pdf[q] < g->P, "vbh_gmm_loglikes_pairs: pdf-id out of range");
+  if (vbh_use_device(g->ctx)) return -1;
+  hipStream_t st = g->ctx->stream;
+  DevBuf<long long> d_off; DevBuf<int> d_pdf; DevBuf<float> d_out;
+  static_assert(sizeof(long long) == sizeof(int64_t), "int64");
+  if (d_off.upload(reinterpret_cast<const long long *>(h_pair_offsets), (size_t)T + 1, st) || d_pdf.upload(h_pair_pdf, (size_t)n, st) || d_out.alloc((size_t)n)) return -1;
+  const long long blocks = (T + 3) / 4;
+  VBH_CHECK(blocks < 2147483647LL, "vbh_gmm_loglikes_pairs: T too large");
+  hipLaunchKernelGGL(gmm_loglikes_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_feats, (long long)T, g->D, d_off.p, d_pdf.p, g->d_pdf_offs.p,
+                     g->d_gconsts.p, g->d_miv.p, g->d_iv.p, d_out.p);
+  VBH_HIP(hipGetLastError());
+  VBH_HIP(hipMemcpyAsync(h_out, d_out.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
+  VBH_HIP(hipStreamSynchronize(st));
   return 0;
 }
 

@@ -4,6 +4,7 @@
 // voicebridge_api.h.  Host code this round: per frame these touch the two or three pdfs a lattice
 // holds at that time, not the whole model; the statistics accumulation is the part marked for the
 // GPU (DESIGN.md "next").
+#include <algorithm>
 #include <cmath>
 #include <map>
 #include <set>
@@ -380,7 +381,9 @@ int ComposeTransforms(int argc, char *argv[], std::ofstream &file_log) {
   });
 }
 
-// gmm-rescore-lattice   (VB/src/gmmbin/gmm-rescore-lattice.cpp; K/gmmbin/gmm-rescore-lattice.cc:28-115)
+// gmm-rescore-lattice   (VB/src/gmmbin/gmm-rescore-lattice.cpp; K/gmmbin/gmm-rescore-lattice.cc:28-115).  The scores come
+// from the GPU in the on-demand form (vbh_gmm_loglikes_pairs): for a batch of utterances, the (frame, pdf) pairs their
+// lattices hold are collected, scored in one call and added to the lattices' acoustic costs.
 int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
   return Guard("gmm-rescore-lattice", &file_log, [&](Log &log) -> int {
     Options po;
@@ -388,35 +391,88 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
     po.Parse(argc, argv);
     if (po.args.size() != 4) throw ApiError("Wrong arguments.");
     const float old_acoustic_scale = (float)po.Num("old-acoustic-scale", 0.0);
-    const Gmm gmm(po.args[0]);
+    vbio::Model model;
+    vbio::ReadModel(po.args[0], &model);
+    const int D = model.dim;
     const auto feats = ReadFeatureTable(po.args[2]);
+    vbh_ctx *ctx = SharedCtx();
+    vbh_gmm *dgmm = nullptr;
+    if (vbh_gmm_create(ctx, D, model.num_pdfs, model.pdf_offsets.data(), model.weights.data(), model.means_invvars.data(), model.inv_vars.data(), &dgmm) != 0)
+      throw ApiError(std::string("vbh_gmm_create: ") + vbh_last_error());
+    struct GmmGuard { vbh_gmm *g; ~GmmGuard() { vbh_gmm_destroy(g); } } guard{dgmm};
     vbio::LatticeReader reader(po.args[1]);
     vbio::CompactLatticeWriter writer;
     writer.Open(po.args[3]);
     int num_done = 0, num_err = 0;
     long long num_frames = 0;
+    struct Item { std::string key; vblat::CompactLattice clat; const vbio::Matrix *f; int64_t pair0; std::vector<int64_t> off; };   // off: per frame, into the batch's pairs
+    std::vector<Item> batch;
+    std::vector<float> bfeats; std::vector<int64_t> poff{0}; std::vector<int32_t> ppdf;
+    auto flush = [&]() {
+      if (batch.empty()) return;
+      const int64_t T = (int64_t)poff.size() - 1;
+      std::vector<float> scores(ppdf.size());
+      void *d_feats = nullptr;
+      if (vbh_dev_alloc(ctx, sizeof(float) * bfeats.size(), &d_feats) != 0) throw ApiError(std::string("vbh_dev_alloc: ") + vbh_last_error());
+      struct DevGuard { vbh_ctx *c; void *p; ~DevGuard() { vbh_dev_free(c, p); } } dg{ctx, d_feats};
+      if (vbh_copy_h2d(ctx, d_feats, bfeats.data(), sizeof(float) * bfeats.size()) != 0) throw ApiError(std::string("vbh_copy_h2d: ") + vbh_last_error());
+      if (vbh_gmm_loglikes_pairs(dgmm, (const float *)d_feats, T, poff.data(), ppdf.data(), scores.data()) != 0)
+        throw ApiError(std::string("vbh_gmm_loglikes_pairs: ") + vbh_last_error());
+      for (Item &it : batch) {
+        auto loglike = [&](int32_t t, int32_t tid) -> float {
+          const int32_t pdf = model.tid2pdf[tid];
+          const int64_t a = it.off[t], b = it.off[t + 1];
+          const int32_t *lo = std::lower_bound(ppdf.data() + a, ppdf.data() + b, pdf);
+          return scores[lo - ppdf.data()];
+        };
+        if (vblat::RescoreCompactLattice(loglike, it.f->rows, &it.clat)) { writer.Write(it.key, it.clat); num_done++; num_frames += it.f->rows; }
+        else { log.os() << "WARNING (gmm-rescore-lattice) lattice/feature mismatch for utterance " << it.key << "\n"; num_err++; }
+      }
+      batch.clear(); bfeats.clear(); poff.assign(1, 0); ppdf.clear();
+    };
     std::string key; vblat::Lattice lat; vblat::CompactLattice clat; bool compact = false;
     while (reader.Next(&key, &lat, &clat, &compact)) {
-      auto it = feats.find(key);
-      if (it == feats.end()) { log.os() << "WARNING (gmm-rescore-lattice) No feature found for utterance " << key << ". Skipping\n"; num_err++; continue; }
+      auto fi = feats.find(key);
+      if (fi == feats.end()) { log.os() << "WARNING (gmm-rescore-lattice) No feature found for utterance " << key << ". Skipping\n"; num_err++; continue; }
+      const vbio::Matrix &f = fi->second;
+      if (f.cols != D) throw ApiError("Dim mismatch: data dim = " + std::to_string(f.cols) + " vs. model dim = " + std::to_string(D));
       if (!compact) vblat::ConvertLattice(lat, &clat);          // CompactLatticeHolder::Read of a state-level lattice
       if (old_acoustic_scale != 1.0f) vblat::ScaleLattice(1.0, 0.0, 0.0, (double)old_acoustic_scale, &clat);
-      const vbio::Matrix &f = it->second;
-      std::unordered_map<uint64_t, float> cache;       // (frame, pdf) -> log-likelihood
-      auto loglike = [&](int32_t t, int32_t tid) -> float {
-        if (tid <= 0 || tid >= (int32_t)gmm.m.tid2pdf.size()) throw ApiError("lattice: transition-id out of the model's range");
-        const int32_t pdf = gmm.m.tid2pdf[tid];
-        const uint64_t k = ((uint64_t)(uint32_t)t << 32) | (uint32_t)pdf;
-        auto c = cache.find(k);
-        if (c != cache.end()) return c->second;
-        const float v = gmm.LogLike(pdf, &f.data[(size_t)t * f.cols]);
-        cache.emplace(k, v);
-        return v;
+      if (clat.st.empty()) { log.os() << "WARNING (gmm-rescore-lattice) Rescoring empty lattice for utterance " << key << "\n"; num_err++; continue; }
+      // the pdfs the lattice holds at every frame (the same walk as RescoreCompactLattice's time_to_state, lattice-functions.cc:1236-1270)
+      if (!vblat::TopSort(&clat)) { log.os() << "WARNING (gmm-rescore-lattice) Cycles detected in lattice " << key << "\n"; num_err++; continue; }
+      std::vector<int32_t> times;
+      const int32_t utt_len = vblat::CompactLatticeStateTimes(clat, &times);
+      if (utt_len > f.rows) { log.os() << "WARNING (gmm-rescore-lattice) Features are too short for lattice: utt-len is " << utt_len << " for utterance " << key << "\n"; num_err++; continue; }
+      std::vector<std::vector<int32_t>> pdfs(f.rows);
+      bool ok = true;
+      auto add = [&](int32_t t0, const std::vector<int32_t> &str) {
+        for (size_t o = 0; o < str.size(); o++) {
+          if (str[o] <= 0 || str[o] >= (int32_t)model.tid2pdf.size()) throw ApiError("lattice: transition-id out of the model's range");
+          if (t0 + (int32_t)o >= f.rows) { ok = false; return; }
+          pdfs[t0 + o].push_back(model.tid2pdf[str[o]]);
+        }
       };
-      if (f.cols != gmm.m.dim) throw ApiError("Dim mismatch: data dim = " + std::to_string(f.cols) + " vs. model dim = " + std::to_string(gmm.m.dim));
-      if (vblat::RescoreCompactLattice(loglike, f.rows, &clat)) { writer.Write(key, clat); num_done++; num_frames += f.rows; }
-      else { log.os() << "WARNING (gmm-rescore-lattice) lattice/feature mismatch for utterance " << key << "\n"; num_err++; }
+      for (size_t s = 0; s < clat.st.size() && ok; s++) {
+        for (const vblat::CArc &a : clat.st[s].arcs) add(times[s], a.w.str);
+        add(times[s], clat.st[s].final.str);
+      }
+      if (!ok) { log.os() << "WARNING (gmm-rescore-lattice) lattice/feature mismatch for utterance " << key << "\n"; num_err++; continue; }
+      Item it; it.key = key; it.clat = std::move(clat); it.f = &f; it.pair0 = (int64_t)ppdf.size(); it.off.reserve(f.rows + 1);
+      for (int t = 0; t < f.rows; t++) {
+        std::vector<int32_t> &v = pdfs[t];
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        it.off.push_back((int64_t)ppdf.size());
+        ppdf.insert(ppdf.end(), v.begin(), v.end());
+        poff.push_back((int64_t)ppdf.size());
+      }
+      it.off.push_back((int64_t)ppdf.size());
+      bfeats.insert(bfeats.end(), f.data.begin(), f.data.end());
+      batch.push_back(std::move(it));
+      if ((int64_t)poff.size() > ((int64_t)2 << 20)) flush();
     }
+    flush();
     log.os() << "LOG (gmm-rescore-lattice) Done " << num_done << " lattices with errors on " << num_err << ", #frames is " << num_frames << "\n";
     return num_done != 0 ? 0 : 1;
   });
