@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--det-threads", type=int, default=0, help="host threads of the lattice stage (0: 16, the CPU share of a one-GPU box)")
     ap.add_argument("--probe", action="store_true", help="print search statistics of the first utterances and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-seconds", type=float, default=180.0, help="audio seconds timed on the CPU baseline")
+    ap.add_argument("--cpu-sample-seconds", type=float, default=360.0, help="audio seconds timed on the CPU baseline (about 20 s of one core)")
     return ap.parse_args()
 
 
@@ -96,6 +96,70 @@ def feature_space_model(args, sample_feats):
     means = means + mu.astype(np.float32)
     miv = (means * iv).astype(np.float32)
     return offs, w, miv, iv
+
+
+def cpu_baseline_reference(args, waves, xforms, model, decode_setup):
+    """The reference's own programs (oracle/_ref/bin: its sources compiled as they lie, OpenBLAS single-threaded in place of MKL) on a
+    bounded sample of the bench workload, one process / one core: compute-mfcc-feats, compute-cmvn-stats, apply-cmvn, add-deltas,
+    transform-feats, gmm-latgen-faster --determinize-lattice=false (the raw-lattice search the GPU step is compared with).  Wall-clock of
+    the feature programs plus the decoder's own "Time taken" (its loop over the utterances, model and graph loading excluded).
+    Returns None when the binaries are not there."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from voicebridge_amd import refio
+    B = os.path.join(ROOT, "oracle", "_ref", "bin")
+    need = ["compute-mfcc-feats", "compute-cmvn-stats", "apply-cmvn", "add-deltas", "transform-feats", "gmm-latgen-faster"]
+    if decode_setup is None or not all(os.access(os.path.join(B, b), os.X_OK) for b in need):
+        return None
+    n_utt = max(1, min(int(round(args.cpu_sample_seconds / args.seconds)), len(waves)))
+    offs, w, miv, iv = model
+    g, _t2p, _cfg = decode_setup
+    d = tempfile.mkdtemp(prefix="vb_cpu_ref_")
+    env = dict(os.environ, OPENBLAS_NUM_THREADS="1", OMP_NUM_THREADS="1")
+    try:
+        p = lambda n: os.path.join(d, n)
+        H = 3
+        n_cd = args.pdfs // H
+        refio.write_mdl(p("final.mdl"), n_cd, H, offs, w, miv, iv)
+        refio.write_vector_fst(p("HCLG.fst"), g["final"], g["arc_offset"], g["arcs"], g["start"])
+        with open(p("wav.scp"), "w") as f, open(p("utt2spk"), "w") as fu, open(p("spk2utt"), "w") as fs:
+            for u in range(n_utt):
+                refio.write_wav(p("u%03d.wav" % u), waves[u])
+                f.write("u%03d %s\n" % (u, p("u%03d.wav" % u)))
+                fu.write("u%03d s%03d\n" % (u, u))
+                fs.write("s%03d u%03d\n" % (u, u))
+        refio.write_feats_ark(p("trans.ark"), {"s%03d" % u: xforms[u % len(xforms)] for u in range(n_utt)})
+
+        def run(name, *a):
+            t0 = time.perf_counter()
+            r = subprocess.run([os.path.join(B, name)] + list(a), env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(name + ": " + r.stderr[-300:])
+            return time.perf_counter() - t0, r.stderr
+        t_feat = 0.0
+        t_feat += run("compute-mfcc-feats", "--dither=0", "scp:" + p("wav.scp"), "ark:" + p("mfcc.ark"))[0]
+        t_feat += run("compute-cmvn-stats", "--spk2utt=ark:" + p("spk2utt"), "ark:" + p("mfcc.ark"), "ark:" + p("cmvn.ark"))[0]
+        t_feat += run("apply-cmvn", "--utt2spk=ark:" + p("utt2spk"), "ark:" + p("cmvn.ark"), "ark:" + p("mfcc.ark"), "ark:" + p("cm.ark"))[0]
+        t_feat += run("add-deltas", "ark:" + p("cm.ark"), "ark:" + p("dl.ark"))[0]
+        t_feat += run("transform-feats", "--utt2spk=ark:" + p("utt2spk"), "ark:" + p("trans.ark"), "ark:" + p("dl.ark"), "ark:" + p("feats.ark"))[0]
+        t_wall, log = run("gmm-latgen-faster", "--beam=%g" % args.beam, "--lattice-beam=%g" % args.lattice_beam, "--max-active=%d" % args.max_active,
+                          "--acoustic-scale=0.083333", "--allow-partial=true", "--determinize-lattice=false", p("final.mdl"), p("HCLG.fst"),
+                          "ark:" + p("feats.ark"), "ark:" + p("lat.ark"))
+        m = re.search(r"Time taken ([0-9.eE+-]+)s", log)
+        t_dec = float(m.group(1)) if m else t_wall
+        m = re.findall(r"Overall log-likelihood per frame is \S+ over (\d+) frames", log)
+        frames = int(m[-1]) if m else 0
+        if frames <= 0:
+            return None
+        return dict(value=frames / (t_feat + t_dec), unit="frames/s", cores=1, kind="reference",
+                    sample="%d x %.0f s utterances (%d frames) through the reference's own programs compiled from its sources (compute-mfcc-feats, "
+                           "compute-cmvn-stats, apply-cmvn, add-deltas, transform-feats, gmm-latgen-faster --determinize-lattice=false; OpenBLAS, one "
+                           "thread, MKL not available): features %.2f s, search %.2f s (its own 'Time taken'; loading the 2 M-state graph, %.1f s more, "
+                           "is left out)" % (n_utt, args.seconds, frames, t_feat, t_dec, max(t_wall - t_dec, 0.0)))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def cpu_baseline(args, waves, utt2spk, xforms, model, decode_setup):
@@ -628,7 +692,17 @@ def main():
         if gathered is not None:
             out["gather"] = gathered
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, waves, utt2spk, xforms, model, decode_setup)
+            ref_cb = None
+            try:
+                ref_cb = cpu_baseline_reference(args, waves, xforms, model, decode_setup)
+            except Exception as e:
+                print("cpu_baseline (reference programs) failed: %s" % e, file=sys.stderr, flush=True)
+            if ref_cb is not None:
+                out["cpu_baseline"] = ref_cb
+                if os.environ.get("VBH_BENCH_PORT_BASELINE"):
+                    out["cpu_baseline_port"] = cpu_baseline(args, waves, utt2spk, xforms, model, decode_setup)
+            else:
+                out["cpu_baseline"] = cpu_baseline(args, waves, utt2spk, xforms, model, decode_setup)
         print(json.dumps(out), flush=True)
     if det_pool is not None:
         det_pool.close()

@@ -71,88 +71,7 @@ def read_wav_pcm16(path):
 
 
 # ---------------------------------------------------------------- files for the lattice tests
-def _tok(s):
-    return s.encode() + b" "
-
-
-def _i32(v):
-    return b"\x04" + np.int32(v).tobytes()
-
-
-def _f32(v):
-    return b"\x04" + np.float32(v).tobytes()
-
-
-def _ivec(v):
-    v = np.asarray(v, "<i4")
-    return b"\x04" + np.int32(len(v)).tobytes() + v.tobytes()
-
-
-def _fvec(v):
-    v = np.asarray(v, "<f4")
-    return b"FV " + _i32(len(v)) + v.tobytes()
-
-
-def _fmat(m):
-    m = np.asarray(m, "<f4")
-    return b"FM " + _i32(m.shape[0]) + _i32(m.shape[1]) + m.tobytes()
-
-
-def write_mdl(path, n_cd, hmm_states, offs, weights, miv, iv, self_p=0.6):
-    """Binary .mdl: `n_cd` phones, each a left-to-right HMM of `hmm_states` emitting
-    states (self-loop then forward transition) with pdf = phone_index * hmm_states + state, i.e.
-    the transition-ids synth.lexicon_graph() uses (pdf p: self-loop 2p+1, forward 2p+2); then the
-    diagonal GMMs.  Readable by the reference (TransitionModel::Read, AmDiagGmm::Read) and by
-    vbio::ReadModel."""
-    H = hmm_states
-    out = b"\0B" + _tok("<TransitionModel>") + _tok("<Topology>")
-    phones = list(range(1, n_cd + 1))
-    out += _ivec(phones) + _ivec([-1] + [0] * n_cd)
-    out += _i32(1)                      # one topology entry shared by all phones
-    out += _i32(H + 1)
-    for k in range(H):
-        out += _i32(k) + _i32(2) + _i32(k) + _f32(self_p) + _i32(k + 1) + _f32(1.0 - self_p)
-    out += _i32(-1) + _i32(0)           # final non-emitting state
-    out += _tok("</Topology>") + _tok("<Triples>") + _i32(n_cd * H)
-    for ph in range(n_cd):
-        for k in range(H):
-            out += _i32(ph + 1) + _i32(k) + _i32(ph * H + k)
-    out += _tok("</Triples>") + _tok("<LogProbs>")
-    lp = [0.0] + [np.log(self_p), np.log(1.0 - self_p)] * (n_cd * H)
-    out += _fvec(lp) + _tok("</LogProbs>") + _tok("</TransitionModel>")
-    P = len(offs) - 1
-    D = miv.shape[1]
-    out += _tok("<DIMENSION>") + _i32(D) + _tok("<NUMPDFS>") + _i32(P)
-    for p in range(P):
-        a, b = int(offs[p]), int(offs[p + 1])
-        out += _tok("<DiagGMM>") + _tok("<WEIGHTS>") + _fvec(weights[a:b]) + _tok("<MEANS_INVVARS>") + _fmat(miv[a:b])
-        out += _tok("<INV_VARS>") + _fmat(iv[a:b]) + _tok("</DiagGMM>")
-    with open(path, "wb") as f:
-        f.write(out)
-
-
-def write_vector_fst(path, final, arc_offset, arcs, start=0):
-    """OpenFst VectorFst<StdArc> binary file from the graph arrays of synth.*_graph()."""
-    S = len(final)
-    a = np.asarray(arcs)
-
-    def s_(x):
-        return np.int32(len(x)).tobytes() + x
-    out = np.int32(2125659606).tobytes() + s_(b"vector") + s_(b"standard") + np.int32(2).tobytes() + np.int32(0).tobytes()
-    out += np.uint64(3).tobytes() + np.int64(start).tobytes() + np.int64(S).tobytes() + np.int64(len(a)).tobytes()
-    parts = [out]
-    for s in range(S):
-        lo, hi = int(arc_offset[s]), int(arc_offset[s + 1])
-        parts.append(np.float32(final[s]).tobytes() + np.int64(hi - lo).tobytes() + a[lo:hi].tobytes())
-    with open(path, "wb") as f:
-        f.write(b"".join(parts))
-
-
-def write_feats_ark(path, feats):
-    with open(path, "wb") as f:
-        for k, m in feats.items():
-            m = np.asarray(m, "<f4")
-            f.write(k.encode() + b" \0B" + _fmat(m))
+from voicebridge_amd.refio import write_feats_ark, write_mdl, write_vector_fst, write_wav  # noqa: E402,F401
 
 
 def read_lattice_ark(path):

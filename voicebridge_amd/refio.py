@@ -1,0 +1,113 @@
+"""Writers for the reference's on-disk formats from numpy arrays: .mdl (TransitionModel + AmDiagGmm), OpenFst
+VectorFst<StdArc>, feature archives, PCM-16 wav.  Used by the tests (inputs for the reference's own programs, oracle/_ref/bin)
+and by bench.py's CPU baseline, which times those programs on a sample of the bench workload."""
+import wave as _wave
+
+import numpy as np
+
+
+def _tok(s):
+    return s.encode() + b" "
+
+
+def _i32(v):
+    return b"\x04" + np.int32(v).tobytes()
+
+
+def _f32(v):
+    return b"\x04" + np.float32(v).tobytes()
+
+
+def _ivec(v):
+    v = np.asarray(v, "<i4")
+    return b"\x04" + np.int32(len(v)).tobytes() + v.tobytes()
+
+
+def _fvec(v):
+    v = np.asarray(v, "<f4")
+    return b"FV " + _i32(len(v)) + v.tobytes()
+
+
+def _fmat(m):
+    m = np.asarray(m, "<f4")
+    return b"FM " + _i32(m.shape[0]) + _i32(m.shape[1]) + m.tobytes()
+
+
+def write_mdl(path, n_cd, hmm_states, offs, weights, miv, iv, self_p=0.6):
+    """Binary .mdl: `n_cd` phones, each a left-to-right HMM of `hmm_states` emitting states (self-loop then forward
+    transition) with pdf = phone_index * hmm_states + state, i.e. the transition-ids synth.lexicon_graph() uses (pdf p:
+    self-loop 2p+1, forward 2p+2); then the diagonal GMMs of the first n_cd * hmm_states pdfs.  Readable by the reference
+    (TransitionModel::Read, AmDiagGmm::Read) and by vbio::ReadModel."""
+    H = hmm_states
+    parts = [b"\0B" + _tok("<TransitionModel>") + _tok("<Topology>")]
+    phones = list(range(1, n_cd + 1))
+    parts.append(_ivec(phones) + _ivec([-1] + [0] * n_cd))
+    parts.append(_i32(1))                      # one topology entry shared by all phones
+    parts.append(_i32(H + 1))
+    for k in range(H):
+        parts.append(_i32(k) + _i32(2) + _i32(k) + _f32(self_p) + _i32(k + 1) + _f32(1.0 - self_p))
+    parts.append(_i32(-1) + _i32(0))           # final non-emitting state
+    parts.append(_tok("</Topology>") + _tok("<Triples>") + _i32(n_cd * H))
+    trip = np.zeros((n_cd * H, 3), "<i4")
+    trip[:, 0] = np.repeat(np.arange(1, n_cd + 1), H)
+    trip[:, 1] = np.tile(np.arange(H), n_cd)
+    trip[:, 2] = np.arange(n_cd * H)
+    rec = np.zeros((n_cd * H, 3), dtype=[("s", "u1"), ("v", "<i4")])
+    rec["s"] = 4
+    rec["v"] = trip
+    parts.append(rec.tobytes())
+    parts.append(_tok("</Triples>") + _tok("<LogProbs>"))
+    lp = [0.0] + [np.log(self_p), np.log(1.0 - self_p)] * (n_cd * H)
+    parts.append(_fvec(lp) + _tok("</LogProbs>") + _tok("</TransitionModel>"))
+    P = n_cd * H
+    D = miv.shape[1]
+    parts.append(_tok("<DIMENSION>") + _i32(D) + _tok("<NUMPDFS>") + _i32(P))
+    for p in range(P):
+        a, b = int(offs[p]), int(offs[p + 1])
+        parts.append(_tok("<DiagGMM>") + _tok("<WEIGHTS>") + _fvec(weights[a:b]) + _tok("<MEANS_INVVARS>") + _fmat(miv[a:b]) +
+                     _tok("<INV_VARS>") + _fmat(iv[a:b]) + _tok("</DiagGMM>"))
+    with open(path, "wb") as f:
+        f.write(b"".join(parts))
+
+
+def write_vector_fst(path, final, arc_offset, arcs, start=0):
+    """OpenFst VectorFst<StdArc> binary file from the graph arrays of synth.*_graph() (vectorised: millions of states)."""
+    S = len(final)
+    a = np.ascontiguousarray(arcs)
+    A = len(a)
+    off = np.asarray(arc_offset, np.int64)
+    narcs = np.diff(off)
+
+    def s_(x):
+        return np.int32(len(x)).tobytes() + x
+    hdr = (np.int32(2125659606).tobytes() + s_(b"vector") + s_(b"standard") + np.int32(2).tobytes() + np.int32(0).tobytes() +
+           np.uint64(3).tobytes() + np.int64(start).tobytes() + np.int64(S).tobytes() + np.int64(A).tobytes())
+    body = np.zeros(12 * S + 16 * A, np.uint8)
+    spos = 12 * np.arange(S, dtype=np.int64) + 16 * off[:-1]          # byte position of every state's {final f32, narcs i64}
+    fin = np.asarray(final, "<f4").view(np.uint8).reshape(S, 4)
+    na = narcs.astype("<i8").view(np.uint8).reshape(S, 8)
+    idx = spos[:, None] + np.arange(12)[None, :]
+    body[idx[:, :4]] = fin
+    body[idx[:, 4:]] = na
+    if A:
+        state_of_arc = np.repeat(np.arange(S, dtype=np.int64), narcs)
+        apos = 12 * (state_of_arc + 1) + 16 * np.arange(A, dtype=np.int64)
+        ab = a.view(np.uint8).reshape(A, 16)
+        body[apos[:, None] + np.arange(16)[None, :]] = ab
+    with open(path, "wb") as f:
+        f.write(hdr)
+        f.write(body.tobytes())
+
+
+def write_feats_ark(path, feats):
+    with open(path, "wb") as f:
+        for k, m in feats.items():
+            f.write(k.encode() + b" \0B" + _fmat(np.asarray(m, "<f4")))
+
+
+def write_wav(path, samples, rate=16000):
+    with _wave.open(str(path), "wb") as f:
+        f.setnchannels(1)
+        f.setsampwidth(2)
+        f.setframerate(rate)
+        f.writeframes(np.asarray(samples, "<i2").tobytes())
