@@ -14,9 +14,9 @@
 //   fmllr_accumulate_kernel: the dense part.  Per speaker  G[d][i][j] = sum_t b_t[d] x+_t[i] x+_t[j]  is the
 //     contraction  [D x T] . [T x (D+1)^2]  in double: v_mfma_f64_16x16x4_f64 with A = b (rows d), B built on the
 //     fly as x+[i] * x+[j] (the product of two floats is exact in double), only the tiles of the lower triangle
-//     (72 of 120 column tiles at D = 39) in groups of 4 waves x 6 tiles; K = sum_t a_t x+_t^T is three more
+//     (72 of 120 column tiles at D = 39) in groups of 4 waves x 3 tiles; K = sum_t a_t x+_t^T is three more
 //     column tiles (A = a, B = x+) in a group of their own.  A workgroup owns one slice of one speaker's frames
-//     and one group, keeps 18 accumulator tiles per wave in registers over the whole slice, fetches the next
+//     and one group, keeps 9 accumulator tiles per wave in registers over the whole slice, fetches the next
 //     64-frame stage into registers under the MFMAs of the current one, and adds its tiles to the speaker's
 //     statistics with f64 atomics once at the end.  beta = sum_t count_t rides along in one wave.
 //     Roofline: f64 MFMA.  Flops per frame = 2 * 48 * 16 * (72 + 3) = 115 200 (padded rows included);
@@ -31,7 +31,7 @@ namespace {
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 constexpr int TF = 64;          // frames staged in LDS per step
-constexpr int NTW = 6;          // column tiles per wave
+constexpr int NTW = 3;          // column tiles per wave: 9 accumulator tiles, 240 registers, two workgroups per CU (6 tiles: one per CU, 9.2 ms; 4: 8.1 ms; 3: 7.6 ms; 2: 8.1 ms; three waves per SIMD spill: 10.2 ms)
 constexpr int NWAVE = 4;        // waves per workgroup (one per SIMD: five waves put two on one SIMD and ran 1.7x slower): 24 column tiles per group
 constexpr int XLD = 49;         // padded row of the x+ image (48 columns used: 40 real + zeros)
 constexpr int ALD = 49;         // padded row of the a / b image (48 rows of the MFMA M dimension)
