@@ -182,12 +182,23 @@ namespace {
 // are exactly those, so the check trips at the same point as in the reference.
 class StringRepo {
  public:
-  StringRepo() { parent_.push_back(-1); label_.push_back(0); size_.push_back(0); gen_.push_back(0); first_.push_back(0); jump_.push_back(0); }
+  StringRepo() { n_.push_back(Node{-1, 0, 0, 0, 0, 0, 0}); }
   int Empty() const { return 0; }
   size_t NumEntries() const { return live_count_; }
   int Successor(int a, int32_t l) {
-    // open-addressing table over (parent, label): the node ids themselves are the values, the keys live in parent_/label_
-    if ((parent_.size() + 1) * 2 > table_.size()) Grow();
+    // most nodes of these tries have one child (alignments are chains): the first child of a node is kept beside it and
+    // found without hashing; only further children go through the open-addressing table over (parent, label)
+    const int fc = n_[a].child;
+    if (fc == 0) {
+      const int id = NewNode(a, l);
+      n_[a].child = id;
+      return id;
+    }
+    if (n_[fc].label == l) {
+      if (n_[fc].gen != cur_gen_) { n_[fc].gen = cur_gen_; live_count_++; }
+      return fc;
+    }
+    if ((n_hashed_ + 1) * 2 > table_.size()) Grow();
     const size_t mask = table_.size() - 1;
     const uint64_t key = ((uint64_t)(uint32_t)a << 32) | (uint32_t)l;
     size_t h = Hash(key) & mask;
@@ -195,42 +206,48 @@ class StringRepo {
       const Slot &sl = table_[h];
       if (sl.id < 0) break;
       if (sl.key == key) {
-        if (gen_[sl.id] != cur_gen_) { gen_[sl.id] = cur_gen_; live_count_++; }
+        if (n_[sl.id].gen != cur_gen_) { n_[sl.id].gen = cur_gen_; live_count_++; }
         return sl.id;
       }
       h = (h + 1) & mask;
     }
-    const int id = (int)parent_.size();
-    parent_.push_back(a); label_.push_back(l); size_.push_back(size_[a] + 1); gen_.push_back(cur_gen_); first_.push_back(a == 0 ? l : first_[a]);
-    { const int ja = jump_[a]; jump_.push_back(size_[a] - size_[ja] == size_[ja] - size_[jump_[ja]] ? jump_[ja] : a); }
-    live_count_++;
+    const int id = NewNode(a, l);
     table_[h] = Slot{key, id};
+    n_hashed_++;
+    return id;
+  }
+  int NewNode(int a, int32_t l) {
+    const int id = (int)n_.size();
+    const int ja = n_[a].jump;
+    n_.push_back(Node{a, l, n_[a].size + 1, cur_gen_, a == 0 ? l : n_[a].first,
+                      n_[a].size - n_[ja].size == n_[ja].size - n_[n_[ja].jump].size ? n_[ja].jump : a, 0});
+    live_count_++;
     return id;
   }
   void Rebuild(const std::vector<int> &to_keep) {
     cur_gen_++;
     live_count_ = 0;
     for (int e : to_keep)
-      for (; e != 0 && gen_[e] != cur_gen_; e = parent_[e]) { gen_[e] = cur_gen_; live_count_++; }
+      for (; e != 0 && n_[e].gen != cur_gen_; e = n_[e].parent) { n_[e].gen = cur_gen_; live_count_++; }
   }
-  int Size(int a) const { return size_[a]; }
+  int Size(int a) const { return n_[a].size; }
   // the prefix of length n of string a: an ancestor in the trie (alive whenever a is: no lookup, no entry created --
   // what the reference obtains by re-converting the prefix vector, determinize-lattice-inl.h:161-166)
   int Prefix(int a, size_t n) const {          // level ancestor in O(log) steps through the jump pointers
-    while ((size_t)size_[a] > n) a = (size_t)size_[jump_[a]] >= n ? jump_[a] : parent_[a];
+    while ((size_t)n_[a].size > n) a = (size_t)n_[n_[a].jump].size >= n ? n_[a].jump : n_[a].parent;
     return a;
   }
   // longest common prefix of two strings = their lowest common ancestor in the trie
   int CommonPrefix(int a, int b) const {
-    if (size_[a] > size_[b]) a = Prefix(a, size_[b]); else if (size_[b] > size_[a]) b = Prefix(b, size_[a]);
+    if (n_[a].size > n_[b].size) a = Prefix(a, n_[b].size); else if (n_[b].size > n_[a].size) b = Prefix(b, n_[a].size);
     while (a != b) {
-      if (jump_[a] != jump_[b]) { a = jump_[a]; b = jump_[b]; } else { a = parent_[a]; b = parent_[b]; }
+      if (n_[a].jump != n_[b].jump) { a = n_[a].jump; b = n_[b].jump; } else { a = n_[a].parent; b = n_[b].parent; }
     }
     return a;
   }
   void ToVector(int a, std::vector<int32_t> *out) const {
-    out->resize(size_[a]);
-    for (int i = size_[a] - 1; i >= 0; i--) { (*out)[i] = label_[a]; a = parent_[a]; }
+    out->resize(n_[a].size);
+    for (int i = n_[a].size - 1; i >= 0; i--) { (*out)[i] = n_[a].label; a = n_[a].parent; }
   }
   int FromVector(const std::vector<int32_t> &v) { int e = 0; for (int32_t l : v) e = Successor(e, l); return e; }
   int Concatenate(int a, int b) {
@@ -244,41 +261,42 @@ class StringRepo {
   void ReduceToCommonPrefix(int a, std::vector<int32_t> *b) const {
     if (b->empty()) return;
     // strings that differ in their first label have no common prefix: no need to walk a's whole length to learn it
-    if (size_[a] == 0 || first_[a] != (*b)[0]) { b->clear(); return; }
-    size_t a_size = size_[a], b_size = b->size();
-    while (a_size > b_size) { a = parent_[a]; a_size--; }
+    if (n_[a].size == 0 || n_[a].first != (*b)[0]) { b->clear(); return; }
+    size_t a_size = n_[a].size, b_size = b->size();
+    while (a_size > b_size) { a = n_[a].parent; a_size--; }
     if (b_size > a_size) b_size = a_size;
     while (a_size != 0) {
-      if (label_[a] != (*b)[a_size - 1]) b_size = a_size - 1;
-      a = parent_[a]; a_size--;
+      if (n_[a].label != (*b)[a_size - 1]) b_size = a_size - 1;
+      a = n_[a].parent; a_size--;
     }
     if (b_size != b->size()) b->resize(b_size);
   }
   int RemovePrefix(int a, size_t n) {
     if (n == 0) return a;
-    std::vector<int32_t> v; ToVector(a, &v);
+    // only the suffix is walked (the reference converts the whole string, determinize-lattice-inl.h:117-126)
+    tmp_.clear();
+    for (int x = a; (size_t)n_[x].size > n; x = n_[x].parent) tmp_.push_back(n_[x].label);
     int e = 0;
-    for (size_t i = n; i < v.size(); i++) e = Successor(e, v[i]);
+    for (size_t i = tmp_.size(); i-- > 0;) e = Successor(e, tmp_[i]);
     return e;
   }
  private:
-  std::vector<int> parent_;
-  std::vector<int32_t> label_;
-  std::vector<int> size_;
-  std::vector<uint32_t> gen_;
-  std::vector<int32_t> first_;            // first label of the string (0 for the empty string)
-  std::vector<int> jump_;                 // one more ancestor per node, depths chosen so that level-ancestor queries take O(log) steps
+  struct Node { int parent; int32_t label; int size; uint32_t gen; int32_t first; int jump; int child; };   // first: first label of the string; jump: a second ancestor (level-ancestor queries in O(log)); child: first child (0: none)
+  std::vector<Node> n_;
+  std::vector<int32_t> tmp_;
   uint32_t cur_gen_ = 0;
   size_t live_count_ = 0;
   struct Slot { uint64_t key; int id; };
   std::vector<Slot> table_;
+  size_t n_hashed_ = 0;                   // nodes reachable through the table only (second and later children)
   static size_t Hash(uint64_t k) { k ^= k >> 29; k *= 0x9E3779B97F4A7C15ull; return (size_t)(k >> 24); }
   void Grow() {
-    const size_t n = table_.empty() ? (size_t)1 << 16 : table_.size() * 4;
+    const size_t n = table_.empty() ? (size_t)1 << 12 : table_.size() * 4;
     table_.assign(n, Slot{0, -1});
     const size_t mask = n - 1;
-    for (int id = 1; id < (int)parent_.size(); id++) {
-      const uint64_t key = ((uint64_t)(uint32_t)parent_[id] << 32) | (uint32_t)label_[id];
+    for (int id = 1; id < (int)n_.size(); id++) {
+      if (n_[n_[id].parent].child == id) continue;          // first children are not in the table
+      const uint64_t key = ((uint64_t)(uint32_t)n_[id].parent << 32) | (uint32_t)n_[id].label;
       size_t h = Hash(key) & mask;
       while (table_[h].id >= 0) h = (h + 1) & mask;
       table_[h] = Slot{key, id};
@@ -468,14 +486,20 @@ class Determinizer {
 
   void EpsilonClosure(std::vector<Element> *subset) {    // :614-725
     std::priority_queue<Element, std::vector<Element>, ElemGreaterState> queue;
-    std::unordered_map<int32_t, Element> cur;
-    for (const Element &e : *subset) { queue.push(e); cur[e.state] = e; }
+    // state -> position in `cur` (the reference keeps an unordered_map; only membership and the current value matter)
+    if (ec_pos_.size() < ifst_.st.size()) { ec_pos_.assign(ifst_.st.size(), 0); ec_stamp_.assign(ifst_.st.size(), 0); }
+    ec_gen_++;
+    std::vector<Element> &cur = ec_cur_;
+    cur.clear();
+    auto find = [&](int32_t st) -> Element * { return ec_stamp_[st] == ec_gen_ ? &cur[ec_pos_[st]] : nullptr; };
+    auto insert = [&](const Element &e) { ec_stamp_[e.state] = ec_gen_; ec_pos_[e.state] = (int)cur.size(); cur.push_back(e); };
+    for (const Element &e : *subset) { queue.push(e); insert(e); }
     bool replaced = false;
     int counter = 0;
     while (!queue.empty()) {
       const Element elem = queue.top();
       queue.pop();
-      if (replaced && cur[elem.state].Differs(elem)) continue;
+      if (replaced && find(elem.state)->Differs(elem)) continue;
       if (opts_.max_loop > 0 && counter++ > opts_.max_loop)
         throw std::runtime_error("lattice determinization: looped more than max-loop times during epsilon closure");
       for (const Arc &arc : ifst_.st[elem.state].arcs) {
@@ -483,30 +507,28 @@ class Determinizer {
         Element next;
         next.state = arc.next;
         next.weight = Times(elem.weight, arc.w);
-        auto it = cur.find(next.state);
-        if (it == cur.end()) {
+        Element *it = find(next.state);
+        if (it == nullptr) {
           next.string = arc.olabel == 0 ? elem.string : repo_.Successor(elem.string, arc.olabel);
-          cur[next.state] = next;
+          insert(next);
           queue.push(next);
         } else {
-          int comp = Compare(next.weight, it->second.weight);
+          int comp = Compare(next.weight, it->weight);
           if (comp == 0) {
             next.string = arc.olabel == 0 ? elem.string : repo_.Successor(elem.string, arc.olabel);
-            comp = CompareWS(next.weight, next.string, it->second.weight, it->second.string);
+            comp = CompareWS(next.weight, next.string, it->weight, it->string);
           }
           if (comp == 1) {
             next.string = arc.olabel == 0 ? elem.string : repo_.Successor(elem.string, arc.olabel);
-            it->second.string = next.string;
-            it->second.weight = next.weight;
+            it->string = next.string;
+            it->weight = next.weight;
             queue.push(next);
             replaced = true;
           }
         }
       }
     }
-    subset->clear();
-    subset->reserve(cur.size());
-    for (const auto &kv : cur) subset->push_back(kv.second);
+    *subset = cur;
     std::sort(subset->begin(), subset->end(), [](const Element &a, const Element &b) { return a.state < b.state; });
   }
 
@@ -682,6 +704,7 @@ class Determinizer {
   std::priority_queue<Task *, std::vector<Task *>, TaskWorse> queue_;
   std::vector<std::pair<int32_t, Element>> all_elems_tmp_;
   std::vector<uint8_t> isym_or_final_;
+  std::vector<int> ec_pos_; std::vector<uint32_t> ec_stamp_; uint32_t ec_gen_ = 0; std::vector<Element> ec_cur_;      // EpsilonClosure's index
   StringRepo repo_;
 };
 

@@ -758,6 +758,16 @@ int vb_determinize_decoder_results(void *decoder, int n_utt, int graph_start, in
     tm.self_loop.assign(tid_self_loop, tid_self_loop + num_tids + 1);
     std::vector<vbh_lattice> Ls(n_utt);
     for (int u = 0; u < n_utt; u++) Check(vbh_decoder_result((vbh_decoder *)decoder, u, &Ls[u]), "vbh_decoder_result");
+    if (const char *dump = getenv("VBH_DUMP_LATS")) {       // diagnostic: the first raw lattices as an archive (for profiling the host stage elsewhere)
+      vbio::LatticeWriter w;
+      w.Open(std::string("ark:") + dump);
+      for (int u = 0; u < std::min(n_utt, 8); u++) {
+        if (!Ls[u].ok) continue;
+        vblat::Lattice lat;
+        RawLatticeFromResult(Ls[u], graph_start, &lat);
+        w.Write("utt" + std::to_string(u), lat);
+      }
+    }
     std::atomic<int> next{0};
     std::atomic<long long> in_s{0}, in_a{0}, out_s{0}, out_a{0}, early{0};
     std::string err;
