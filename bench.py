@@ -59,7 +59,7 @@ def parse():
                     help="skip the second timed region, in which the host stage that follows every search in the reference's gmm-latgen-faster "
                          "(lattice determinization) is part of the step: a pool of host threads determinizes the lattices of batch k while the GPU "
                          "searches batch k+1")
-    ap.add_argument("--det-steps", type=int, default=6, help="steps of that second timed region")
+    ap.add_argument("--det-steps", type=int, default=8, help="steps of that second timed region")
     ap.add_argument("--det-threads", type=int, default=0, help="host threads of the lattice stage (0: 16, the CPU share of a one-GPU box)")
     ap.add_argument("--probe", action="store_true", help="print search statistics of the first utterances and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
