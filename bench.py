@@ -290,6 +290,39 @@ def determinize_measurement(args, dec, T):
 F64_MFMA_PEAK_TFLOPS = 78.6      # vendor figure for MI355X FP64 matrix (the micro-architecture guide lists no f64 row)
 
 
+def ondemand_gmm_measurement(args, ctx, gmm, model, feats, T):
+    """The on-demand form of the GMM scores (vbh_gmm_loglikes_pairs; the reference's semantics, SURVEY.md 8d: per frame only the pdfs
+    somebody asks for are evaluated -- here 3 per frame, what a lattice holds, and 32 per frame): wall time of the call (upload of the pair
+    lists, kernel, download of the scores) and the algorithmic gather traffic = touched Gaussians x (2D + 1) x 4 B + frames x D x 4 B."""
+    import ctypes as C
+    offs = np.asarray(model[0], np.int64)
+    ng = np.diff(offs)
+    fn = gmm.lib.vbh_gmm_loglikes_pairs
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    out = {}
+    rng = np.random.default_rng(9)
+    Tm = min(T, 1 << 20)                       # a million frames is enough to time it
+    for per in (3, 32):
+        poff = np.arange(Tm + 1, dtype=np.int64) * per
+        ppdf = rng.integers(0, gmm.num_pdfs, Tm * per).astype(np.int32)
+        res = np.zeros(Tm * per, np.float32)
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            if fn(gmm.h, feats.data_ptr(), Tm, poff.ctypes.data, ppdf.ctypes.data, res.ctypes.data) != 0:
+                return {"error": "vbh_gmm_loglikes_pairs failed"}
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        gauss = float(ng[ppdf].sum())
+        bytes_ = gauss * (2 * 39 + 1) * 4.0 + Tm * 39 * 4.0 + Tm * per * 4.0
+        out["%d_pdfs_per_frame" % per] = {"frames": int(Tm), "call_ms": 1e3 * best, "pdf_evals_per_s": Tm * per / best, "gather_GBs": bytes_ / best / 1e9,
+                                           "frac_of_hbm_peak": bytes_ / best / 1e9 / HBM_PEAK_GBS}
+    out["note"] = ("call time incl. the H2D of the pair lists and the D2H of the scores; the model (4.8 MB) is L2-resident, so this is a gather out of "
+                   "L2, not an HBM stream; compare roofline_gmm: the batched all-pdf MFMA kernel scores all %d pdfs of a frame in the time this form "
+                   "needs for a few dozen (kernel_ms / frames against call_ms / (frames x pdfs) here)" % gmm.num_pdfs)
+    return out
+
+
 def fmllr_measurement(args, ctx, gmm, feats, foff, utt2spk, n_spk, T):
     """fMLLR sufficient statistics of one batch (vbh_fmllr_accumulate): every frame carries two
     (pdf, weight) posterior pairs, as a pruned-determinized lattice typically leaves; the accumulation kernel is
@@ -650,6 +683,10 @@ def main():
                     "threads": det_pool.threads, "utterances": nb, "worker_seconds": float(tt[0]), "worker_ms_per_utterance": 1e3 * float(tt[0]) / max(nb, 1),
                     "copy_out_seconds_on_the_step_thread": det_pool.submit_s, "raw_arcs_per_utt": float(tt[2]) / max(nb, 1),
                     "det_arcs_per_utt": float(tt[4]) / max(nb, 1), "stopped_before_beam": int(tt[5])}
+            try:
+                extra["gmm_on_demand"] = ondemand_gmm_measurement(args, ctx, gmm, model, ring[0][1], T)
+            except Exception as e:
+                extra["gmm_on_demand"] = {"error": str(e)}
             try:
                 extra["roofline_fmllr_stats"] = fmllr_measurement(args, ctx, gmm, ring[0][1], foff, utt2spk, n_spk, T)
             except Exception as e:        # a measurement beside the step, never a reason to lose the bench line
