@@ -213,6 +213,9 @@ def test_gmm_latgen_faster_determinized_vs_reference_program(host, tmp_path):
     assert rc == 0, open(log).read()
     mine = util.read_lattice_ark(str(d / "lat.ark"))
     assert list(mine) == ["uttA", "uttB", "uttC", "uttD"] and all(v[0] == "compactlattice44" for v in mine.values())
+    # the table in batches of one utterance (the decoder is kept and grown across batches): the same archive, bit for bit
+    assert call(host.vb_GmmLatgenFaster, ["gmm-latgen-faster", "--decode-batch=1"] + opts + files + ["ark:%s" % (d / "lat_b1.ark")], log) == 0, open(log).read()
+    assert (d / "lat_b1.ark").read_bytes() == (d / "lat.ark").read_bytes()
     # the best path of the determinized lattice is the decoder's best path
     assert call(host.vb_LatticeBestPath, ["lattice-best-path", "--acoustic-scale=0.083333", "ark:%s" % (d / "lat.ark"), "ark,t:%s" % (d / "bp_words.txt"),
                                           "ark,t:%s" % (d / "bp_ali.txt")], log) == 0

@@ -511,6 +511,9 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     if (po.args.size() >= 6 && !po.args[5].empty()) ali_writer.Open(po.args[5]);
 
     const int batch_utts = (int)po.Num("decode-batch", 256);
+    vbh_decoder *dec = nullptr;
+    int dec_batch = 0, dec_T = 0;
+    struct DecGuard { vbh_decoder **d; ~DecGuard() { if (*d) vbh_decoder_destroy(*d); } } dec_guard{&dec};
     vbio::MatrixReader reader(po.args[2]);
     double tot_like = 0.0;
     int64_t frame_count = 0;
@@ -532,11 +535,17 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
       DevMem d_feats(ctx, sizeof(float) * b.data.size()), d_ll(ctx, sizeof(float) * (size_t)T * model.num_pdfs);
       Check(vbh_copy_h2d(ctx, d_feats.p, b.data.data(), sizeof(float) * b.data.size()), "vbh_copy_h2d");
       Check(vbh_gmm_loglikes(gmm, (const float *)d_feats.p, T, (float *)d_ll.p), "vbh_gmm_loglikes");
-      vbh_decoder *dec = nullptr;
-      Check(vbh_decoder_create(ctx, g, &cfg, (int32_t)b.keys.size(), max_T, &dec), "vbh_decoder_create");
+      // the decoder (tens of GB of search workspace at the reference's batch sizes) is kept across the batches of the table
+      // and only rebuilt when a batch needs more utterances or longer ones than it was made for
+      if (dec == nullptr || (int)b.keys.size() > dec_batch || max_T > dec_T) {
+        if (dec) vbh_decoder_destroy(dec);
+        dec = nullptr;
+        dec_batch = std::max((int)b.keys.size(), dec_batch); dec_T = std::max(max_T, dec_T);
+        Check(vbh_decoder_create(ctx, g, &cfg, dec_batch, dec_T, &dec), "vbh_decoder_create");
+      }
       const int rc = vbh_decode_batch(dec, (const float *)d_ll.p, model.num_pdfs, b.offs.data(), (int32_t)b.keys.size(),
                                       model.tid2pdf.data(), (int32_t)model.tid2pdf.size() - 1);
-      if (rc != 0) { const std::string e = vbh_last_error(); vbh_decoder_destroy(dec); throw ApiError("vbh_decode_batch: " + e); }
+      if (rc != 0) throw ApiError(std::string("vbh_decode_batch: ") + vbh_last_error());
       // GetRawLattice (K/decoder/lattice-faster-decoder.cc:110-192): one state per token (state 0 =
       // the start token), arc weights (graph, acoustic - cost_offset), acoustic costs still scaled
       const size_t nu = b.keys.size();
@@ -602,8 +611,8 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
         frame_count += L.num_frames;
         num_done++;
       }
-      vbh_decoder_destroy(dec);
     }
+    if (dec) { vbh_decoder_destroy(dec); dec = nullptr; }
     vbh_graph_destroy(g);
     vbh_gmm_destroy(gmm);
     log.os() << "LOG (gmm-latgen-faster) Done " << num_done << " utterances, failed for " << num_err << "\n";
