@@ -4,6 +4,8 @@
 // return codes) but batch the utterances of a table through the GPU.
 #include "voicebridge_api.h"
 
+#include <sys/stat.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -116,6 +118,37 @@ void RunFeatpost(const vbh_featpost_cfg &cfg, const Batch &b, const std::vector<
                      utt2spk.empty() ? nullptr : utt2spk.data(), n_spk, stats, lda, spk, (float *)d_out.p), "vbh_featpost");
   out->resize((size_t)T * *out_dim);
   Check(vbh_copy_d2h(ctx, out->data(), d_out.p, sizeof(float) * out->size()), "vbh_copy_d2h");
+}
+
+// Model, graph and search workspace of the calling thread's last gmm-latgen-faster call, kept on the device: the nj jobs of a Decode
+// step (and the passes of DecodeFmllr) name the same files again and again, and reading a 100 MB graph, building its device form and
+// allocating tens of GB of workspace per job cost more than the search of a job itself.  Keyed by path, size and modification time of
+// the two files; released by vb_release_device_cache(), by a call with other files, or when the thread's device changes.
+struct LatgenCache {
+  std::string model_path, graph_path;
+  long long model_sig = 0, graph_sig = 0;
+  vbh_ctx *ctx = nullptr;
+  vbio::Model model;
+  int32_t graph_start = 0;
+  vbh_gmm *gmm = nullptr;
+  vbh_graph *g = nullptr;
+  vbh_decoder *dec = nullptr;
+  vbh_decode_cfg dec_cfg{};
+  int dec_batch = 0, dec_T = 0;
+  void Release() {
+    if (dec) vbh_decoder_destroy(dec);
+    if (g) vbh_graph_destroy(g);
+    if (gmm) vbh_gmm_destroy(gmm);
+    dec = nullptr; g = nullptr; gmm = nullptr; dec_batch = dec_T = 0; model_path.clear(); graph_path.clear(); ctx = nullptr;
+  }
+  ~LatgenCache() { /* the process is ending or the thread is: the runtime reclaims device memory */ }
+};
+thread_local LatgenCache g_latgen;
+
+long long FileSig(const std::string &path) {
+  struct stat st;
+  if (stat(path.c_str(), &st) != 0) return -1;
+  return (long long)st.st_size * 1000003LL + (long long)st.st_mtime * 7919LL + (long long)st.st_mtim.tv_nsec;
 }
 
 int WindowType(const std::string &s) {
@@ -468,7 +501,13 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     Options po;
     po.Know({"beam", "max-active", "min-active", "lattice-beam", "prune-interval", "determinize-lattice", "beam-delta",
              "hash-ratio", "acoustic-scale", "word-symbol-table", "allow-partial", "max-mem", "phone-determinize",
-             "word-determinize", "minimize", "decode-batch", "delta"});
+             "word-determinize", "minimize", "decode-batch", "delta",
+             // extensions of this build (not in the reference's program): the feature chain of the Decode step fused in front of the
+             // scoring, on the device, so that the steps need no temporary archives between apply-cmvn, add-deltas / splice-feats +
+             // transform-feats, transform-feats(fMLLR) and this program (VB/scr/steps/decode_gmm.cpp:201-293).  With --fe-cmvn the
+             // feature rspecifier names the RAW features (e.g. the 13-dim MFCCs of feats.scp).
+             "fe-cmvn", "fe-utt2spk", "fe-norm-vars", "fe-type", "fe-delta-order", "fe-delta-window", "fe-left-context", "fe-right-context",
+             "fe-lda", "fe-trans"});
     po.Parse(argc, argv);
     if (po.args.size() < 4 || po.args.size() > 6) throw ApiError("wrong arguments.");
     vbh_decode_cfg cfg;
@@ -491,18 +530,64 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     det_opts.phone_determinize = po.Bool("phone-determinize", true);
     det_opts.word_determinize = po.Bool("word-determinize", true);
     det_opts.minimize = po.Bool("minimize", false);
-    vbio::Model model;
-    vbio::ReadModel(po.args[0], &model);
-    vbio::Graph graph;
-    vbio::ReadFst(po.args[1], &graph);
+    const bool laps = getenv("VBH_DEBUG_TIMES") != nullptr;      // diagnostic: where the host time of a job goes
+    auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+      if (!laps) return;
+      const auto now = std::chrono::steady_clock::now();
+      fprintf(stderr, "gmm-latgen-faster lap %-28s %8.1f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_lap).count());
+      t_lap = now;
+    };
     vbh_ctx *ctx = Ctx();
-    vbh_gmm *gmm = nullptr;
-    Check(vbh_gmm_create(ctx, model.dim, model.num_pdfs, model.pdf_offsets.data(), model.weights.data(),
-                         model.means_invvars.data(), model.inv_vars.data(), &gmm), "vbh_gmm_create");
-    vbh_graph *g = nullptr;
-    static_assert(sizeof(vbio::Arc) == sizeof(vbh_arc), "arc layout");
-    Check(vbh_graph_create(ctx, (int32_t)graph.final_cost.size(), graph.start, graph.final_cost.data(), graph.arc_offset.data(),
-                           reinterpret_cast<const vbh_arc *>(graph.arcs.data()), &g), "vbh_graph_create");
+    LatgenCache &cache = g_latgen;
+    {
+      const long long ms = FileSig(po.args[0]), gs = FileSig(po.args[1]);
+      if (cache.ctx != ctx || cache.model_path != po.args[0] || cache.graph_path != po.args[1] || cache.model_sig != ms || cache.graph_sig != gs || ms < 0 || gs < 0) {
+        cache.Release();
+        vbio::ReadModel(po.args[0], &cache.model);
+        lap("read model");
+        vbio::Graph graph;
+        vbio::ReadFst(po.args[1], &graph);
+        lap("read graph");
+        Check(vbh_gmm_create(ctx, cache.model.dim, cache.model.num_pdfs, cache.model.pdf_offsets.data(), cache.model.weights.data(),
+                             cache.model.means_invvars.data(), cache.model.inv_vars.data(), &cache.gmm), "vbh_gmm_create");
+        static_assert(sizeof(vbio::Arc) == sizeof(vbh_arc), "arc layout");
+        Check(vbh_graph_create(ctx, (int32_t)graph.final_cost.size(), graph.start, graph.final_cost.data(), graph.arc_offset.data(),
+                               reinterpret_cast<const vbh_arc *>(graph.arcs.data()), &cache.g), "vbh_graph_create");
+        cache.graph_start = graph.start;
+        cache.ctx = ctx; cache.model_path = po.args[0]; cache.graph_path = po.args[1]; cache.model_sig = ms; cache.graph_sig = gs;
+        lap("device model + graph");
+      }
+    }
+    const vbio::Model &model = cache.model;
+    struct { int32_t start; } graph{cache.graph_start};
+    vbh_gmm *gmm = cache.gmm;
+    vbh_graph *g = cache.g;
+    // ---- fused front end (extension, see the option list)
+    const bool fused = po.Has("fe-cmvn");
+    std::map<std::string, vbio::MatrixD> fe_stats;
+    std::map<std::string, std::string> fe_utt2spk;
+    std::map<std::string, vbio::Matrix> fe_trans;
+    vbio::Matrix fe_lda;
+    vbh_featpost_cfg fe_cfg{};
+    if (fused) {
+      fe_stats = vbio::ReadMatrixDTable(po.Str("fe-cmvn", ""));
+      if (po.Has("fe-utt2spk")) fe_utt2spk = vbio::ReadStringMap(po.Str("fe-utt2spk", ""));
+      fe_cfg.apply_cmvn = 1;
+      fe_cfg.norm_vars = po.Bool("fe-norm-vars", false);
+      const std::string type = po.Str("fe-type", "delta");
+      if (type == "delta") { fe_cfg.mode = 1; fe_cfg.delta_order = (int)po.Num("fe-delta-order", 2); fe_cfg.delta_window = (int)po.Num("fe-delta-window", 2); }
+      else if (type == "lda") {
+        fe_cfg.mode = 2; fe_cfg.splice_left = (int)po.Num("fe-left-context", 4); fe_cfg.splice_right = (int)po.Num("fe-right-context", 4);
+        if (!po.Has("fe-lda")) throw ApiError("--fe-type=lda needs --fe-lda=<final.mat>");
+        std::ifstream f(po.Str("fe-lda", ""), std::ios::binary);
+        if (!f) throw ApiError("cannot open " + po.Str("fe-lda", ""));
+        const bool binary = vbio::ReadBinaryHeader(f);
+        vbio::ReadMatrix(f, binary, &fe_lda);
+        fe_cfg.lda_rows = fe_lda.rows; fe_cfg.lda_cols = fe_lda.cols;
+      } else throw ApiError("--fe-type must be delta or lda");
+      if (po.Has("fe-trans")) fe_trans = vbio::ReadMatrixTable(po.Str("fe-trans", ""));
+    }
     vbio::LatticeWriter lat_writer;
     vbio::CompactLatticeWriter clat_writer;
     if (want_lat) { if (determinize) clat_writer.Open(lat_wspec); else lat_writer.Open(lat_wspec); }
@@ -511,9 +596,11 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     if (po.args.size() >= 6 && !po.args[5].empty()) ali_writer.Open(po.args[5]);
 
     const int batch_utts = (int)po.Num("decode-batch", 256);
-    vbh_decoder *dec = nullptr;
-    int dec_batch = 0, dec_T = 0;
-    struct DecGuard { vbh_decoder **d; ~DecGuard() { if (*d) vbh_decoder_destroy(*d); } } dec_guard{&dec};
+    // the cached workspace serves this call when it was made for the same search configuration
+    if (cache.dec && memcmp(&cache.dec_cfg, &cfg, sizeof(cfg)) != 0) { vbh_decoder_destroy(cache.dec); cache.dec = nullptr; cache.dec_batch = cache.dec_T = 0; }
+    cache.dec_cfg = cfg;
+    vbh_decoder *&dec = cache.dec;
+    int &dec_batch = cache.dec_batch, &dec_T = cache.dec_T;
     vbio::MatrixReader reader(po.args[2]);
     double tot_like = 0.0;
     int64_t frame_count = 0;
@@ -525,16 +612,54 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
       int max_T = 0;
       while ((int)b.keys.size() < batch_utts && (more = reader.Next(&key, &m))) {
         if (m.rows == 0) { log.os() << "WARNING (gmm-latgen-faster) Zero-length utterance: " << key << "\n"; num_err++; continue; }
-        if (m.cols != model.dim) throw ApiError("Dim mismatch: data dim = " + std::to_string(m.cols) + " vs. model dim = " + std::to_string(model.dim));
+        if (!fused && m.cols != model.dim) throw ApiError("Dim mismatch: data dim = " + std::to_string(m.cols) + " vs. model dim = " + std::to_string(model.dim));
         if (b.dim < 0) b.dim = m.cols;
         b.Add(key, m);
         if (m.rows > max_T) max_T = m.rows;
       }
       if (b.keys.empty()) break;
+      lap("read features of a batch");
       const int64_t T = b.frames();
-      DevMem d_feats(ctx, sizeof(float) * b.data.size()), d_ll(ctx, sizeof(float) * (size_t)T * model.num_pdfs);
-      Check(vbh_copy_h2d(ctx, d_feats.p, b.data.data(), sizeof(float) * b.data.size()), "vbh_copy_h2d");
-      Check(vbh_gmm_loglikes(gmm, (const float *)d_feats.p, T, (float *)d_ll.p), "vbh_gmm_loglikes");
+      DevMem d_in(ctx, sizeof(float) * b.data.size()), d_ll(ctx, sizeof(float) * (size_t)T * model.num_pdfs);
+      Check(vbh_copy_h2d(ctx, d_in.p, b.data.data(), sizeof(float) * b.data.size()), "vbh_copy_h2d");
+      std::unique_ptr<DevMem> d_fe;
+      const float *d_feats_p = (const float *)d_in.p;
+      if (fused) {
+        // CMVN statistics and fMLLR transforms of the batch's speakers, packed in the order the speakers appear
+        vbh_featpost_cfg cfg = fe_cfg;
+        cfg.in_dim = b.dim;
+        std::map<std::string, int> idx; std::vector<int32_t> u2s; std::vector<double> stats; std::vector<float> xf;
+        for (const std::string &k : b.keys) {
+          std::string spk = k;
+          if (!fe_utt2spk.empty()) { auto it = fe_utt2spk.find(k); if (it != fe_utt2spk.end()) spk = it->second; }
+          if (!idx.count(spk)) {
+            auto it = fe_stats.find(spk);
+            if (it == fe_stats.end()) throw ApiError("No normalization statistics available for key " + k);
+            const vbio::MatrixD &ms = it->second;
+            if (ms.cols != b.dim + 1 || ms.rows < 1 || ms.rows > 2) throw ApiError("Dim mismatch: cmvn " + std::to_string(ms.rows) + "x" + std::to_string(ms.cols));
+            if (ms.rows == 1 && cfg.norm_vars) throw ApiError("You requested variance normalization but no variance stats are supplied.");
+            stats.insert(stats.end(), ms.data.begin(), ms.data.end());
+            if (ms.rows == 1) stats.insert(stats.end(), (size_t)(b.dim + 1), 0.0);
+            if (!fe_trans.empty()) {
+              auto tt = fe_trans.find(spk);
+              if (tt == fe_trans.end()) throw ApiError("No fMLLR transform for speaker " + spk);
+              if (cfg.spk_rows == 0) { cfg.spk_rows = tt->second.rows; cfg.spk_cols = tt->second.cols; }
+              if (tt->second.rows != cfg.spk_rows || tt->second.cols != cfg.spk_cols) throw ApiError("fMLLR transforms of different sizes");
+              xf.insert(xf.end(), tt->second.data.begin(), tt->second.data.end());
+            }
+            const int n = (int)idx.size(); idx[spk] = n;
+          }
+          u2s.push_back(idx[spk]);
+        }
+        if (!fe_trans.empty() && !idx.empty()) { cfg.spk_rows = fe_trans.begin()->second.rows; cfg.spk_cols = fe_trans.begin()->second.cols; }
+        const int od = vbh_featpost_out_dim(&cfg);
+        if (od != model.dim) throw ApiError("Dim mismatch: front end gives dim " + std::to_string(od) + " vs. model dim = " + std::to_string(model.dim));
+        d_fe.reset(new DevMem(ctx, sizeof(float) * (size_t)T * od));
+        Check(vbh_featpost(ctx, &cfg, (const float *)d_in.p, b.offs.data(), (int32_t)b.keys.size(), u2s.data(), (int)idx.size(), stats.data(),
+                           fe_lda.data.empty() ? nullptr : fe_lda.data.data(), xf.empty() ? nullptr : xf.data(), (float *)d_fe->p), "vbh_featpost");
+        d_feats_p = (const float *)d_fe->p;
+      }
+      Check(vbh_gmm_loglikes(gmm, d_feats_p, T, (float *)d_ll.p), "vbh_gmm_loglikes");
       // the decoder (tens of GB of search workspace at the reference's batch sizes) is kept across the batches of the table
       // and only rebuilt when a batch needs more utterances or longer ones than it was made for
       if (dec == nullptr || (int)b.keys.size() > dec_batch || max_T > dec_T) {
@@ -542,10 +667,12 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
         dec = nullptr;
         dec_batch = std::max((int)b.keys.size(), dec_batch); dec_T = std::max(max_T, dec_T);
         Check(vbh_decoder_create(ctx, g, &cfg, dec_batch, dec_T, &dec), "vbh_decoder_create");
+        lap("front end + decoder create");
       }
       const int rc = vbh_decode_batch(dec, (const float *)d_ll.p, model.num_pdfs, b.offs.data(), (int32_t)b.keys.size(),
                                       model.tid2pdf.data(), (int32_t)model.tid2pdf.size() - 1);
       if (rc != 0) throw ApiError(std::string("vbh_decode_batch: ") + vbh_last_error());
+      lap("scores + search");
       // GetRawLattice (K/decoder/lattice-faster-decoder.cc:110-192): one state per token (state 0 =
       // the start token), arc weights (graph, acoustic - cost_offset), acoustic costs still scaled
       const size_t nu = b.keys.size();
@@ -580,6 +707,7 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
         work();
         for (std::thread &t : pool) t.join();
       }
+      lap("determinization");
       for (size_t u = 0; u < nu; u++) {
         const vbh_lattice &L = Ls[u];
         const std::string &utt = b.keys[u];
@@ -612,9 +740,7 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
         num_done++;
       }
     }
-    if (dec) { vbh_decoder_destroy(dec); dec = nullptr; }
-    vbh_graph_destroy(g);
-    vbh_gmm_destroy(gmm);
+    lap("write results");
     log.os() << "LOG (gmm-latgen-faster) Done " << num_done << " utterances, failed for " << num_err << "\n";
     log.os() << "LOG (gmm-latgen-faster) Overall log-likelihood per frame is " << (frame_count ? tot_like / frame_count : 0.0)
              << " over " << frame_count << " frames.\n";
@@ -677,10 +803,45 @@ int GmmDecodeFaster(int argc, char *argv[], std::ofstream &file_log) {
     cfg.beam_delta = (float)po.Num("beam-delta", 0.5);
     cfg.acoustic_scale = (float)po.Num("acoustic-scale", 0.1);
     const bool allow_partial = po.Bool("allow-partial", true);
+    const bool laps = getenv("VBH_DEBUG_TIMES") != nullptr;      // diagnostic: where the host time of a job goes
+    auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+      if (!laps) return;
+      const auto now = std::chrono::steady_clock::now();
+      fprintf(stderr, "gmm-latgen-faster lap %-28s %8.1f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_lap).count());
+      t_lap = now;
+    };
     vbio::Model model;
     vbio::ReadModel(po.args[0], &model);
+    lap("read model");
     vbio::Graph graph;
     vbio::ReadFst(po.args[1], &graph);
+    lap("read graph");
+    // ---- fused front end (extension, see the option list)
+    const bool fused = po.Has("fe-cmvn");
+    std::map<std::string, vbio::MatrixD> fe_stats;
+    std::map<std::string, std::string> fe_utt2spk;
+    std::map<std::string, vbio::Matrix> fe_trans;
+    vbio::Matrix fe_lda;
+    vbh_featpost_cfg fe_cfg{};
+    if (fused) {
+      fe_stats = vbio::ReadMatrixDTable(po.Str("fe-cmvn", ""));
+      if (po.Has("fe-utt2spk")) fe_utt2spk = vbio::ReadStringMap(po.Str("fe-utt2spk", ""));
+      fe_cfg.apply_cmvn = 1;
+      fe_cfg.norm_vars = po.Bool("fe-norm-vars", false);
+      const std::string type = po.Str("fe-type", "delta");
+      if (type == "delta") { fe_cfg.mode = 1; fe_cfg.delta_order = (int)po.Num("fe-delta-order", 2); fe_cfg.delta_window = (int)po.Num("fe-delta-window", 2); }
+      else if (type == "lda") {
+        fe_cfg.mode = 2; fe_cfg.splice_left = (int)po.Num("fe-left-context", 4); fe_cfg.splice_right = (int)po.Num("fe-right-context", 4);
+        if (!po.Has("fe-lda")) throw ApiError("--fe-type=lda needs --fe-lda=<final.mat>");
+        std::ifstream f(po.Str("fe-lda", ""), std::ios::binary);
+        if (!f) throw ApiError("cannot open " + po.Str("fe-lda", ""));
+        const bool binary = vbio::ReadBinaryHeader(f);
+        vbio::ReadMatrix(f, binary, &fe_lda);
+        fe_cfg.lda_rows = fe_lda.rows; fe_cfg.lda_cols = fe_lda.cols;
+      } else throw ApiError("--fe-type must be delta or lda");
+      if (po.Has("fe-trans")) fe_trans = vbio::ReadMatrixTable(po.Str("fe-trans", ""));
+    }
     vbh_ctx *ctx = Ctx();
     vbh_gmm *gmm = nullptr;
     Check(vbh_gmm_create(ctx, model.dim, model.num_pdfs, model.pdf_offsets.data(), model.weights.data(),
@@ -708,10 +869,48 @@ int GmmDecodeFaster(int argc, char *argv[], std::ofstream &file_log) {
         if (m.rows > max_T) max_T = m.rows;
       }
       if (b.keys.empty()) break;
+      lap("read features of a batch");
       const int64_t T = b.frames();
-      DevMem d_feats(ctx, sizeof(float) * b.data.size()), d_ll(ctx, sizeof(float) * (size_t)T * model.num_pdfs);
-      Check(vbh_copy_h2d(ctx, d_feats.p, b.data.data(), sizeof(float) * b.data.size()), "vbh_copy_h2d");
-      Check(vbh_gmm_loglikes(gmm, (const float *)d_feats.p, T, (float *)d_ll.p), "vbh_gmm_loglikes");
+      DevMem d_in(ctx, sizeof(float) * b.data.size()), d_ll(ctx, sizeof(float) * (size_t)T * model.num_pdfs);
+      Check(vbh_copy_h2d(ctx, d_in.p, b.data.data(), sizeof(float) * b.data.size()), "vbh_copy_h2d");
+      std::unique_ptr<DevMem> d_fe;
+      const float *d_feats_p = (const float *)d_in.p;
+      if (fused) {
+        // CMVN statistics and fMLLR transforms of the batch's speakers, packed in the order the speakers appear
+        vbh_featpost_cfg cfg = fe_cfg;
+        cfg.in_dim = b.dim;
+        std::map<std::string, int> idx; std::vector<int32_t> u2s; std::vector<double> stats; std::vector<float> xf;
+        for (const std::string &k : b.keys) {
+          std::string spk = k;
+          if (!fe_utt2spk.empty()) { auto it = fe_utt2spk.find(k); if (it != fe_utt2spk.end()) spk = it->second; }
+          if (!idx.count(spk)) {
+            auto it = fe_stats.find(spk);
+            if (it == fe_stats.end()) throw ApiError("No normalization statistics available for key " + k);
+            const vbio::MatrixD &ms = it->second;
+            if (ms.cols != b.dim + 1 || ms.rows < 1 || ms.rows > 2) throw ApiError("Dim mismatch: cmvn " + std::to_string(ms.rows) + "x" + std::to_string(ms.cols));
+            if (ms.rows == 1 && cfg.norm_vars) throw ApiError("You requested variance normalization but no variance stats are supplied.");
+            stats.insert(stats.end(), ms.data.begin(), ms.data.end());
+            if (ms.rows == 1) stats.insert(stats.end(), (size_t)(b.dim + 1), 0.0);
+            if (!fe_trans.empty()) {
+              auto tt = fe_trans.find(spk);
+              if (tt == fe_trans.end()) throw ApiError("No fMLLR transform for speaker " + spk);
+              if (cfg.spk_rows == 0) { cfg.spk_rows = tt->second.rows; cfg.spk_cols = tt->second.cols; }
+              if (tt->second.rows != cfg.spk_rows || tt->second.cols != cfg.spk_cols) throw ApiError("fMLLR transforms of different sizes");
+              xf.insert(xf.end(), tt->second.data.begin(), tt->second.data.end());
+            }
+            const int n = (int)idx.size(); idx[spk] = n;
+          }
+          u2s.push_back(idx[spk]);
+        }
+        if (!fe_trans.empty() && !idx.empty()) { cfg.spk_rows = fe_trans.begin()->second.rows; cfg.spk_cols = fe_trans.begin()->second.cols; }
+        const int od = vbh_featpost_out_dim(&cfg);
+        if (od != model.dim) throw ApiError("Dim mismatch: front end gives dim " + std::to_string(od) + " vs. model dim = " + std::to_string(model.dim));
+        d_fe.reset(new DevMem(ctx, sizeof(float) * (size_t)T * od));
+        Check(vbh_featpost(ctx, &cfg, (const float *)d_in.p, b.offs.data(), (int32_t)b.keys.size(), u2s.data(), (int)idx.size(), stats.data(),
+                           fe_lda.data.empty() ? nullptr : fe_lda.data.data(), xf.empty() ? nullptr : xf.data(), (float *)d_fe->p), "vbh_featpost");
+        d_feats_p = (const float *)d_fe->p;
+      }
+      Check(vbh_gmm_loglikes(gmm, d_feats_p, T, (float *)d_ll.p), "vbh_gmm_loglikes");
       vbh_faster_decoder *dec = nullptr;
       Check(vbh_faster_decoder_create(ctx, g, &cfg, (int32_t)b.keys.size(), max_T, &dec), "vbh_faster_decoder_create");
       const int rc = vbh_faster_decode_batch(dec, (const float *)d_ll.p, model.num_pdfs, b.offs.data(), (int32_t)b.keys.size(),
@@ -901,7 +1100,9 @@ void vb_det_pool_destroy(void *pool) {
   for (std::thread &t : p->workers) t.join();
   delete p;
 }
-int vb_set_device(int device_id) { g_device = device_id; return 0; }
+int vb_set_device(int device_id) { if (device_id != g_device) g_latgen.Release(); g_device = device_id; return 0; }
+// frees the model, graph and search workspace the calling thread's last gmm-latgen-faster call left on the device
+void vb_release_device_cache(void) { g_latgen.Release(); }
 int vb_ComputeMFCCFeats(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return ComputeMFCCFeats(argc, argv, l); }); }
 int vb_ComputeCmvnStats(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return ComputeCmvnStats(argc, argv, l); }); }
 int vb_ApplyCmvn(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return ApplyCmvn(argc, argv, l); }); }

@@ -24,6 +24,11 @@
 namespace {
 
 thread_local std::string g_err;
+thread_local int g_step_depth = 0;     // > 0 while a step runs inside another (DecodeFmllr -> Decode): the outermost one frees the device cache
+struct StepScope {
+  StepScope() { g_step_depth++; }
+  ~StepScope() { if (--g_step_depth == 0) vb_release_device_cache(); }
+};
 
 struct StepError : public std::runtime_error {
   explicit StepError(const std::string &m) : std::runtime_error(m) {}
@@ -266,6 +271,7 @@ int Decode(const std::string &graph_dir, const std::string &data_dir, const std:
            const std::string &trans_dir, UMAPSS &wer_ref_filter, UMAPSS &wer_hyp_filter, const std::string &iter, int nj, float acwt,
            int stage, int max_active, double beam, double lattice_beam, bool skip_scoring, bool decode_mbr, bool stats,
            const std::string &word_ins_penalty, int min_lmwt, int max_lmwt) {
+  StepScope scope;          // model, graph and search workspace stay on the device across the nj jobs, and go when the step returns
   const int rc_decode = Run([&] {
     if (decode_mbr) throw StepError("MBR decoding (decode_mbr) is not part of this build");
     if (nj < 1) throw StepError("nj must be >= 1");
@@ -307,48 +313,39 @@ int Decode(const std::string &graph_dir, const std::string &data_dir, const std:
       unlink(Join(decode_dir, "lat." + J).c_str());
       std::ofstream log(Join(Join(decode_dir, "log"), "decode." + J + ".log"), std::ios::binary);
       if (ReadLines(Join(dsn, "feats.scp"), false).empty()) continue;
-      const std::string t_cmvn = Join(dsn, "apply_cmvn.temp"), t_feat = Join(dsn, "feats.temp");
-      std::vector<std::string> c = {"apply-cmvn"};
-      for (const auto &o : SplitWords(cmvn_opts)) c.push_back(o);
-      c.push_back("--utt2spk=ark:" + Join(dsn, "utt2spk"));
-      c.push_back("scp:" + Join(dsn, "cmvn.scp")); c.push_back("scp:" + Join(dsn, "feats.scp")); c.push_back("ark:" + t_cmvn);
-      Argv a1(c);
-      if (ApplyCmvn(a1.argc(), a1.argv(), log) < 0) throw StepError("apply-cmvn failed for job " + J);
-      if (!lda) {
-        std::vector<std::string> dl = {"add-deltas"};
-        for (const auto &o : SplitWords(delta_opts)) dl.push_back(o);
-        dl.push_back("ark:" + t_cmvn); dl.push_back("ark:" + t_feat);
-        Argv a2(dl);
-        if (AddDeltas(a2.argc(), a2.argv()) < 0) throw StepError("add-deltas failed for job " + J);
-      } else {
-        const std::string t_spl = Join(dsn, "splice.temp");
-        std::vector<std::string> sp = {"splice-feats"};
-        for (const auto &o : SplitWords(splice_opts)) sp.push_back(o);
-        sp.push_back("ark:" + t_cmvn); sp.push_back("ark:" + t_spl);
-        Argv a2(sp);
-        if (SpliceFeats(a2.argc(), a2.argv()) < 0) throw StepError("splice-feats failed for job " + J);
-        Argv a3({"transform-feats", Join(srcdir, "final.mat"), "ark:" + t_spl, "ark:" + t_feat});
-        if (TransformFeats(a3.argc(), a3.argv(), log) < 0) throw StepError("transform-feats failed for job " + J);
-        unlink(t_spl.c_str());
-      }
-      std::string t_in = t_feat;
-      const std::string t_trans = Join(dsn, "transformfeats_trans.temp");
-      if (use_trans) {       // decode_gmm.cpp:243-267
-        Argv a5({"transform-feats", "--utt2spk=ark:" + Join(dsn, "utt2spk"), "ark:" + (trans_all.empty() ? Join(trans_dir, "trans." + J) : trans_all),
-                 "ark:" + t_feat, "ark:" + t_trans});
-        if (TransformFeats(a5.argc(), a5.argv(), log) < 0) throw StepError("transform-feats (fMLLR) failed for job " + J);
-        t_in = t_trans;
-      }
+      // The reference chains apply-cmvn | add-deltas (or splice-feats | transform-feats final.mat) [| transform-feats trans.JOB] |
+      // gmm-latgen-faster through temporary archives (decode_gmm.cpp:201-293).  Here the chain runs on the device in front of the
+      // scoring (GmmLatgenFaster's --fe-* options): the raw features of feats.scp are the only thing read.
       std::vector<std::string> g = {"gmm-latgen-faster", "--max-active=" + std::to_string(max_active), "--beam=" + std::to_string(beam),
                                     "--lattice-beam=" + std::to_string(lattice_beam), "--acoustic-scale=" + std::to_string(acwt),
-                                    "--allow-partial=true"};
+                                    "--allow-partial=true", "--fe-cmvn=scp:" + Join(dsn, "cmvn.scp"), "--fe-utt2spk=ark:" + Join(dsn, "utt2spk")};
+      for (const auto &o : SplitWords(cmvn_opts)) {
+        if (o == "--norm-vars=true" || o == "--norm-vars") g.push_back("--fe-norm-vars=true");
+        else if (o == "--norm-vars=false" || o == "--norm-means=true") continue;
+        else throw StepError("cmvn_opts option " + o + " is not supported");
+      }
+      if (!lda) {
+        g.push_back("--fe-type=delta");
+        for (const auto &o : SplitWords(delta_opts)) {
+          if (o.compare(0, 14, "--delta-order=") == 0) g.push_back("--fe-delta-order=" + o.substr(14));
+          else if (o.compare(0, 15, "--delta-window=") == 0) g.push_back("--fe-delta-window=" + o.substr(15));
+          else throw StepError("delta_opts option " + o + " is not supported");
+        }
+      } else {
+        g.push_back("--fe-type=lda"); g.push_back("--fe-lda=" + Join(srcdir, "final.mat"));
+        for (const auto &o : SplitWords(splice_opts)) {
+          if (o.compare(0, 15, "--left-context=") == 0) g.push_back("--fe-left-context=" + o.substr(15));
+          else if (o.compare(0, 16, "--right-context=") == 0) g.push_back("--fe-right-context=" + o.substr(16));
+          else throw StepError("splice_opts option " + o + " is not supported");
+        }
+      }
+      if (use_trans) g.push_back("--fe-trans=ark:" + (trans_all.empty() ? Join(trans_dir, "trans." + J) : trans_all));
       const std::string symtab = Join(graph_dir, "words.txt");
       if (Exists(symtab)) g.push_back("--word-symbol-table=" + symtab);
-      g.push_back(model); g.push_back(Join(graph_dir, "HCLG.fst")); g.push_back("ark:" + t_in); g.push_back("ark:" + Join(decode_dir, "lat." + J));
+      g.push_back(model); g.push_back(Join(graph_dir, "HCLG.fst")); g.push_back("scp:" + Join(dsn, "feats.scp")); g.push_back("ark:" + Join(decode_dir, "lat." + J));
       g.push_back("ark,t:" + Join(decode_dir, "w." + J));
       Argv a4(g);
       const int rc = GmmLatgenFaster(a4.argc(), a4.argv(), log);
-      unlink(t_cmvn.c_str()); unlink(t_feat.c_str()); unlink(t_trans.c_str());
       if (rc < 0) throw StepError("gmm-latgen-faster failed for job " + J + ", see " + Join(decode_dir, "log"));
       // transcriptionJOB.trn: the words of w.JOB through the symbol table (decode_gmm.cpp:356-376)
       if (Exists(symtab)) {
@@ -374,6 +371,7 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
                 const std::string &adapt_model_in, const std::string &final_model_in, int nj, float acwt, int stage, int max_active, double beam,
                 double lattice_beam, double silence_weight, const std::string &si_dir_in, const std::string &fmllr_update_type, bool skip_scoring,
                 bool decode_mbr, bool stats, const std::string &word_ins_penalty, int min_lmwt, int max_lmwt) {
+  StepScope scope;
   std::string si_dir = si_dir_in;
   const int rc = Run([&] {
     if (decode_mbr) throw StepError("MBR decoding (decode_mbr) is not part of this build");
