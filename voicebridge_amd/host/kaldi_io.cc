@@ -520,12 +520,20 @@ MatrixWriter::MatrixWriter(const std::string &wspecifier, bool compress) : spec_
   }
 }
 
-void MatrixWriter::Write(const std::string &key, const Matrix &m) {
+std::string SerializeMatrix(const Matrix &m, bool text, bool compress) {
+  std::ostringstream os;
+  if (text) WriteMatrix(os, false, m);
+  else if (compress) WriteCompressedMatrix(os, m);
+  else WriteMatrix(os, true, m);
+  return os.str();
+}
+
+void MatrixWriter::Write(const std::string &key, const Matrix &m) { WriteSerialized(key, SerializeMatrix(m, spec_.text, compress_)); }
+
+void MatrixWriter::WriteSerialized(const std::string &key, const std::string &object) {
   ark_ << key << ' ';
   const int64_t off = (int64_t)ark_.tellp();
-  if (spec_.text) WriteMatrix(ark_, false, m);
-  else if (compress_) WriteCompressedMatrix(ark_, m);
-  else WriteMatrix(ark_, true, m);
+  ark_.write(object.data(), (std::streamsize)object.size());
   if (spec_.has_scp) scp_ << key << ' ' << spec_.ark_path << ':' << off << '\n';
   if (ark_.fail()) Fail("write failure on " + spec_.ark_path);
 }

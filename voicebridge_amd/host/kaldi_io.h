@@ -83,10 +83,18 @@ std::map<std::string, Matrix> ReadMatrixTable(const std::string &rspecifier);
 std::map<std::string, MatrixD> ReadMatrixDTable(const std::string &rspecifier);
 std::map<std::string, std::string> ReadStringMap(const std::string &rspecifier);   // utt2spk
 
+// one matrix as a table writer stores it: text, "FM " or (compress) the speech-feature "CM " forms -- the costly part of writing a
+// compressed feature archive (a sort per column), separable from the file so that utterances can be encoded on several threads
+std::string SerializeMatrix(const Matrix &m, bool text, bool compress);
+
 class MatrixWriter {   // "ark:", "ark,t:", "ark,scp:a,b", "scp:"? (scp alone is not a valid wspecifier)
  public:
   explicit MatrixWriter(const std::string &wspecifier, bool compress = false);
   void Write(const std::string &key, const Matrix &m);
+  // the object exactly as Write would have serialised it (made with SerializeMatrix, possibly on another thread)
+  void WriteSerialized(const std::string &key, const std::string &object);
+  bool compress() const { return compress_; }
+  bool text() const { return spec_.text; }
   void Close();
  private:
   Wspec spec_;

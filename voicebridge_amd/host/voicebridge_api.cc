@@ -191,7 +191,9 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
              "window-type", "blackman-coeff", "round-to-power-of-two", "snip-edges", "allow-downsample", "num-mel-bins",
              "low-freq", "high-freq", "vtln-low", "vtln-high", "debug-mel", "num-ceps", "use-energy", "energy-floor",
              "raw-energy", "cepstral-lifter", "htk-compat", "output-format", "subtract-mean", "vtln-warp", "vtln-map",
-             "utt2spk", "channel", "min-duration"});
+             "utt2spk", "channel", "min-duration",
+             // extensions of this build: what the MakeMfcc step otherwise pipes through copy-feats (VB/scr/steps/make_mfcc.cpp:215)
+             "compress", "write-num-frames"});
     po.Parse(argc, argv);
     if (po.args.size() != 2) throw ApiError("wrong arguments.");
     vbh_mfcc_opts o;
@@ -226,7 +228,14 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
     const vbio::Rspec rs = vbio::ParseRspecifier(po.args[0]);
     if (!rs.is_scp) throw ApiError("wav rspecifier must be scp: (got " + po.args[0] + ")");
     std::vector<vbio::ScpEntry> scp = vbio::ReadScp(rs.path);
-    vbio::MatrixWriter writer(po.args[1]);
+    vbio::MatrixWriter writer(po.args[1], po.Bool("compress", false));
+    std::ofstream num_frames_out;
+    if (po.Has("write-num-frames")) {
+      const vbio::Wspec ws = vbio::ParseWspecifier(po.Str("write-num-frames", ""));
+      if (!ws.has_ark || !ws.text) throw ApiError("--write-num-frames expects ark,t:<file>");
+      num_frames_out.open(ws.ark_path);
+      if (!num_frames_out) throw ApiError("cannot open " + ws.ark_path);
+    }
     vbh_ctx *ctx = Ctx();
     vbh_mfcc *mf = nullptr;
     Check(vbh_mfcc_create(ctx, &o, vtln_warp, &mf), "vbh_mfcc_create");
@@ -235,13 +244,37 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
     size_t i = 0;
     while (i < scp.size()) {
       std::vector<std::string> keys; std::vector<int64_t> woff(1, 0); std::vector<float> samples;
-      while (i < scp.size() && samples.size() < (size_t)(64 << 20)) {
-        const vbio::ScpEntry &e = scp[i++];
+      // the files of a batch are read and parsed on several host threads (a 30 s utterance is 1 MB of PCM), then taken in table order
+      const size_t i0 = i;
+      size_t i1 = i0, est = 0;
+      while (i1 < scp.size() && est < (size_t)(64 << 20)) {
+        struct stat st;
+        est += stat(scp[i1].path.c_str(), &st) == 0 ? (size_t)st.st_size / 2 : (size_t)1 << 16;
+        i1++;
+      }
+      std::vector<vbio::Wave> waves(i1 - i0);
+      std::vector<std::string> werr(i1 - i0);
+      {
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+          for (size_t k = next++; k < i1 - i0; k = next++) {
+            const vbio::ScpEntry &e = scp[i0 + k];
+            if (!e.path.empty() && e.path.back() == '|') continue;
+            try { vbio::ReadWaveFile(e.path, e.offset, &waves[k]); } catch (const std::exception &ex) { werr[k] = ex.what(); if (werr[k].empty()) werr[k] = "read error"; }
+          }
+        };
+        const unsigned nt = std::max(1u, std::min<unsigned>(8, std::min<unsigned>((unsigned)(i1 - i0), std::thread::hardware_concurrency())));
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool) t.join();
+      }
+      for (; i < i1; i++) {
+        const vbio::ScpEntry &e = scp[i];
         num_utts++;
         if (!e.path.empty() && e.path.back() == '|') { log.os() << "WARNING (compute-mfcc-feats) pipe input not supported: " << e.key << "\n"; continue; }
-        vbio::Wave w;
-        try { vbio::ReadWaveFile(e.path, e.offset, &w); }
-        catch (const std::exception &ex) { log.os() << "WARNING (compute-mfcc-feats) " << e.key << ": " << ex.what() << "\n"; continue; }
+        vbio::Wave &w = waves[i - i0];
+        if (!werr[i - i0].empty()) { log.os() << "WARNING (compute-mfcc-feats) " << e.key << ": " << werr[i - i0] << "\n"; continue; }
         const double dur = w.data.empty() ? 0.0 : w.data[0].size() / w.samp_freq;
         if (dur < min_duration) { log.os() << "WARNING (compute-mfcc-feats) File: " << e.key << " is too short (" << dur << " sec): producing no output.\n"; continue; }
         int ch = channel;
@@ -253,6 +286,7 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
         keys.push_back(e.key);
         samples.insert(samples.end(), w.data[ch].begin(), w.data[ch].end());
         woff.push_back((int64_t)samples.size());
+        std::vector<std::vector<float>>().swap(w.data);
       }
       if (keys.empty()) continue;
       int64_t total = 0;
@@ -263,20 +297,36 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
       Check(vbh_mfcc_compute(mf, d_wave.p, 0, woff.data(), (int32_t)keys.size(), (float *)d_feats.p, foff.data()), "vbh_mfcc_compute");
       std::vector<float> feats((size_t)total * o.num_ceps);
       Check(vbh_copy_d2h(ctx, feats.data(), d_feats.p, sizeof(float) * feats.size()), "vbh_copy_d2h");
-      for (size_t u = 0; u < keys.size(); u++) {
-        vbio::Matrix m;
-        m.rows = (int32_t)(foff[u + 1] - foff[u]); m.cols = o.num_ceps;
-        m.data.assign(feats.begin() + foff[u] * o.num_ceps, feats.begin() + foff[u + 1] * o.num_ceps);
-        if (m.rows == 0) m.cols = 0;   // too short for one frame: the reference emits a 0 x 0 matrix (feature-common-inl.h:81-84)
-        if (subtract_mean && m.rows > 0) {   // compute-mfcc-feats.cpp:153-158
-          for (int c = 0; c < m.cols; c++) {
-            double s = 0.0;
-            for (int r = 0; r < m.rows; r++) s += m.at(r, c);
-            const float mean = (float)(s / m.rows);
-            for (int r = 0; r < m.rows; r++) m.at(r, c) -= mean;
+      // the utterances are encoded (compressed archives: a sort per column) on several threads, written in table order
+      std::vector<std::string> objs(keys.size());
+      {
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+          for (size_t u = next++; u < keys.size(); u = next++) {
+            vbio::Matrix m;
+            m.rows = (int32_t)(foff[u + 1] - foff[u]); m.cols = o.num_ceps;
+            m.data.assign(feats.begin() + foff[u] * o.num_ceps, feats.begin() + foff[u + 1] * o.num_ceps);
+            if (m.rows == 0) m.cols = 0;   // too short for one frame: the reference emits a 0 x 0 matrix (feature-common-inl.h:81-84)
+            if (subtract_mean && m.rows > 0) {   // compute-mfcc-feats.cpp:153-158
+              for (int c = 0; c < m.cols; c++) {
+                double s = 0.0;
+                for (int r = 0; r < m.rows; r++) s += m.at(r, c);
+                const float mean = (float)(s / m.rows);
+                for (int r = 0; r < m.rows; r++) m.at(r, c) -= mean;
+              }
+            }
+            objs[u] = vbio::SerializeMatrix(m, writer.text(), writer.compress());
           }
-        }
-        writer.Write(keys[u], m);
+        };
+        const unsigned nt = std::max(1u, std::min<unsigned>(8, std::min<unsigned>((unsigned)keys.size(), std::thread::hardware_concurrency())));
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool) t.join();
+      }
+      for (size_t u = 0; u < keys.size(); u++) {
+        writer.WriteSerialized(keys[u], objs[u]);
+        if (num_frames_out.is_open()) num_frames_out << keys[u] << ' ' << (foff[u + 1] - foff[u]) << '\n';
         num_success++;
       }
     }

@@ -159,15 +159,15 @@ int MakeMfcc(const std::string &datadir, const std::string &mfcc_config, int nj,
       WriteLines(piece, pieces[j - 1]);
       std::ofstream log(Join(logdir, "make_mfcc_" + name + "." + J + ".log"), std::ios::binary);
       if (pieces[j - 1].empty()) continue;
-      Argv a1({"compute-mfcc-feats", "--config=" + mfcc_config, "scp,p:" + piece, "ark:" + temp});
-      if (ComputeMFCCFeats(a1.argc(), a1.argv(), log) < 0) throw StepError("compute-mfcc-feats failed for job " + J + ", see " + logdir);
-      std::vector<std::string> c = {"copy-feats"};
+      // the reference pipes compute-mfcc-feats through copy-feats --compress (make_mfcc.cpp:215, a temporary archive in its
+      // port); here the program writes the final archive itself (its --compress / --write-num-frames extensions)
+      (void)temp;
+      std::vector<std::string> c = {"compute-mfcc-feats", "--config=" + mfcc_config, std::string("--compress=") + (compress ? "true" : "false")};
       if (write_utt2num_frames) c.push_back("--write-num-frames=ark,t:" + Join(logdir, "utt2num_frames." + J));
-      c.push_back(std::string("--compress=") + (compress ? "true" : "false"));
-      c.push_back("ark:" + temp);
+      c.push_back("scp,p:" + piece);
       c.push_back("ark,scp:" + Join(mfccdir, "raw_mfcc_" + name + "." + J + ".ark") + "," + Join(mfccdir, "raw_mfcc_" + name + "." + J + ".scp"));
-      Argv a2(c);
-      if (CopyFeats(a2.argc(), a2.argv(), log) < 0) throw StepError("copy-feats failed for job " + J + ", see " + logdir);
+      Argv a1(c);
+      if (ComputeMFCCFeats(a1.argc(), a1.argv(), log) < 0) throw StepError("compute-mfcc-feats failed for job " + J + ", see " + logdir);
     }
     std::vector<std::string> feats, u2n;
     for (int j = 1; j <= nj; j++) {
