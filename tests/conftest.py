@@ -15,3 +15,9 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+# torch ships its own HIP runtime (libamdhip64 inside the wheel); libvoicebridge_hip.so names the same SONAME and gets whichever copy
+# the process loaded first.  A test that loads the host library through ctypes before anything imported torch would bring in the system
+# copy, and torch's own copy, loaded later, then finds no device ("No HIP GPUs are available").  Importing torch first makes every
+# order of the test files use one runtime.
+import torch  # noqa: E402,F401
