@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--words", type=int, default=180000)
     ap.add_argument("--pdfs", type=int, default=2499)
     ap.add_argument("--gauss", type=int, default=15000)
+    ap.add_argument("--fmllr", action="store_true", help="also time DecodeFmllr (SI pass, two fMLLR estimates, main search, rescoring, determinization)")
     a = ap.parse_args()
     host = C.CDLL(build.HOST_LIB)
     host.vb_steps_last_error.restype = C.c_char_p
@@ -79,6 +80,15 @@ def main():
         host.vb_ScoreKaldiWER.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int]
         assert host.vb_ScoreKaldiWER(data.encode(), graph.encode(), dec.encode(), a.nj, b"0.0,0.5,1.0", 7, 17) == 0, host.vb_steps_last_error()
         out["ScoreKaldiWER_s (33 LMWT x penalty combinations)"] = time.perf_counter() - t0
+        if a.fmllr:
+            os.makedirs(os.path.join(graph, "phones"), exist_ok=True)
+            open(os.path.join(graph, "phones", "silence.csl"), "w").write("1:2\n")
+            host.vb_DecodeFmllr.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_float, C.c_int, C.c_double, C.c_double, C.c_double, C.c_char_p,
+                                            C.c_int, C.c_char_p, C.c_int, C.c_int]
+            dec2 = os.path.join(exp, "decode_fmllr")
+            t0 = time.perf_counter()
+            assert host.vb_DecodeFmllr(graph.encode(), data.encode(), dec2.encode(), a.nj, 0.083333, 7000, 13.0, 6.0, 0.01, b"", 1, b"0.0", 9, 9) == 0, host.vb_steps_last_error()
+            out["DecodeFmllr_s (SI pass + 2 fMLLR estimates + main search + rescoring + determinization)"] = time.perf_counter() - t0
         tot = out["MakeMfcc_s"] + out["ComputeCmvnStats_s"] + out["Decode_s (search + determinization, lattices and words written)"] + out["ScoreKaldiWER_s (33 LMWT x penalty combinations)"]
         out["total_s"] = tot
         out["frames_per_s"] = frames / tot

@@ -5,10 +5,13 @@
 // holds at that time, not the whole model; the statistics accumulation is the part marked for the
 // GPU (DESIGN.md "next").
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <functional>
 #include <map>
 #include <set>
 #include <sstream>
+#include <thread>
 #include <unordered_map>
 
 #include "api_common.h"
@@ -279,20 +282,38 @@ static int EstimateOnGpu(const char *prog, bool use_gpost, const Options &po, co
     }
   }
   flush();
-  // ---- per unit: update from the unit transform, write
+  // ---- per unit: update from the unit transform (40 row-by-row iterations, a 39 x 39 inverse per row: 0.1 s of one core per
+  //      speaker, independent per speaker -> spread over the host's threads), then written in table order
+  std::vector<vbio::Matrix> xf(units.size());
+  std::vector<float> imprs(units.size(), 0.0f), counts(units.size(), 0.0f);
+  std::vector<std::string> uerr(units.size());
+  {
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+      for (size_t s = next++; s < units.size(); s = next++) {
+        if (!po.Has("spk2utt") && !unit_has_utt[s]) continue;
+        vbio::Matrix &t = xf[s];
+        t.rows = D; t.cols = n1; t.data.assign((size_t)D * n1, 0.0f);
+        for (int d = 0; d < D; d++) t.data[(size_t)d * n1 + d] = 1.0f;
+        try { imprs[s] = accs[s].Update(opts, t.data.data(), &counts[s]); } catch (const std::exception &e) { uerr[s] = e.what(); }
+      }
+    };
+    const unsigned nt = std::max(1u, std::min<unsigned>(16, std::min<unsigned>((unsigned)units.size(), std::thread::hardware_concurrency())));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (std::thread &t : pool) t.join();
+  }
   vbio::MatrixWriter writer(trans_wspec);
   double tot_impr = 0.0, tot_t = 0.0;
   for (size_t s = 0; s < units.size(); s++) {
     if (!po.Has("spk2utt") && !unit_has_utt[s]) continue;     // per-utterance mode writes nothing for skipped utterances
-    vbio::Matrix t; t.rows = D; t.cols = n1; t.data.assign((size_t)D * n1, 0.0f);
-    for (int d = 0; d < D; d++) t.data[(size_t)d * n1 + d] = 1.0f;
-    float count = 0.0f;
-    const float impr = accs[s].Update(opts, t.data.data(), &count);
+    if (!uerr[s].empty()) throw ApiError("fMLLR update for " + units[s].first + ": " + uerr[s]);
     if (!(accs[s].beta() > opts.min_count)) log.os() << "WARNING (" << prog << ") Not updating fMLLR since below min-count: count is " << accs[s].beta() << "\n";
-    writer.Write(units[s].first, t);
-    log.os() << "LOG (" << prog << ") For " << (po.Has("spk2utt") ? "speaker " : "utterance ") << units[s].first << ", auxf-impr from fMLLR is " << (impr / count)
-             << ", over " << count << " frames.\n";
-    tot_impr += impr; tot_t += count;
+    writer.Write(units[s].first, xf[s]);
+    log.os() << "LOG (" << prog << ") For " << (po.Has("spk2utt") ? "speaker " : "utterance ") << units[s].first << ", auxf-impr from fMLLR is " << (imprs[s] / counts[s])
+             << ", over " << counts[s] << " frames.\n";
+    tot_impr += imprs[s]; tot_t += counts[s];
   }
   writer.Close();
   log.os() << "LOG (" << prog << ") Done " << num_done << " files, " << num_err << " with errors.\n";
@@ -405,74 +426,110 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
     writer.Open(po.args[3]);
     int num_done = 0, num_err = 0;
     long long num_frames = 0;
-    struct Item { std::string key; vblat::CompactLattice clat; const vbio::Matrix *f; int64_t pair0; std::vector<int64_t> off; };   // off: per frame, into the batch's pairs
-    std::vector<Item> batch;
-    std::vector<float> bfeats; std::vector<int64_t> poff{0}; std::vector<int32_t> ppdf;
-    auto flush = [&]() {
-      if (batch.empty()) return;
-      const int64_t T = (int64_t)poff.size() - 1;
+    // Per lattice: conversion to the compact form, state times, the pdfs it holds at every frame (host threads); per chunk of
+    // lattices: one call of the on-demand kernel for all their (frame, pdf) pairs; then the scores are added (host threads) and the
+    // lattices written in table order.
+    struct Item {
+      std::string key; vblat::Lattice lat; vblat::CompactLattice clat; bool compact = false; const vbio::Matrix *f = nullptr;
+      std::vector<int64_t> off; std::vector<int32_t> pdfs;      // per frame [off[t], off[t+1]) into pdfs (sorted, unique)
+      int64_t base = 0; std::string warn, err; bool ok = false;
+    };
+    std::vector<Item> items;
+    { Item it; while (reader.Next(&it.key, &it.lat, &it.clat, &it.compact)) { items.push_back(std::move(it)); it = Item(); } }
+    auto parallel_for = [&](size_t n, const std::function<void(size_t)> &fn) {
+      std::atomic<size_t> next{0};
+      auto work = [&]() { for (size_t i = next++; i < n; i = next++) fn(i); };
+      const unsigned nt = std::max(1u, std::min<unsigned>(16, std::min<unsigned>((unsigned)n, std::thread::hardware_concurrency())));
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+      work();
+      for (std::thread &t : pool) t.join();
+    };
+    parallel_for(items.size(), [&](size_t i) {
+      Item &it = items[i];
+      try {
+        auto fi = feats.find(it.key);
+        if (fi == feats.end()) { it.warn = "No feature found for utterance " + it.key + ". Skipping"; return; }
+        const vbio::Matrix &f = fi->second;
+        if (f.cols != D) throw ApiError("Dim mismatch: data dim = " + std::to_string(f.cols) + " vs. model dim = " + std::to_string(D));
+        if (!it.compact) { vblat::ConvertLattice(it.lat, &it.clat); vblat::Lattice().st.swap(it.lat.st); }      // CompactLatticeHolder::Read of a state-level lattice
+        if (old_acoustic_scale != 1.0f) vblat::ScaleLattice(1.0, 0.0, 0.0, (double)old_acoustic_scale, &it.clat);
+        if (it.clat.st.empty()) { it.warn = "Rescoring empty lattice for utterance " + it.key; return; }
+        if (!vblat::TopSort(&it.clat)) { it.warn = "Cycles detected in lattice " + it.key; return; }
+        // the pdfs the lattice holds at every frame (the same walk as RescoreCompactLattice's time_to_state, lattice-functions.cc:1236-1270)
+        std::vector<int32_t> times;
+        const int32_t utt_len = vblat::CompactLatticeStateTimes(it.clat, &times);
+        if (utt_len > f.rows) { it.warn = "Features are too short for lattice: utt-len is " + std::to_string(utt_len) + " for utterance " + it.key; return; }
+        std::vector<std::vector<int32_t>> pdfs(f.rows);
+        bool ok = true;
+        auto add = [&](int32_t t0, const std::vector<int32_t> &str) {
+          for (size_t o = 0; o < str.size(); o++) {
+            if (str[o] <= 0 || str[o] >= (int32_t)model.tid2pdf.size()) throw ApiError("lattice: transition-id out of the model's range");
+            if (t0 + (int32_t)o >= f.rows) { ok = false; return; }
+            pdfs[t0 + o].push_back(model.tid2pdf[str[o]]);
+          }
+        };
+        for (size_t s = 0; s < it.clat.st.size() && ok; s++) {
+          for (const vblat::CArc &a : it.clat.st[s].arcs) add(times[s], a.w.str);
+          add(times[s], it.clat.st[s].final.str);
+        }
+        if (!ok) { it.warn = "lattice/feature mismatch for utterance " + it.key; return; }
+        it.off.reserve(f.rows + 1);
+        for (int t = 0; t < f.rows; t++) {
+          std::vector<int32_t> &v = pdfs[t];
+          std::sort(v.begin(), v.end());
+          v.erase(std::unique(v.begin(), v.end()), v.end());
+          it.off.push_back((int64_t)it.pdfs.size());
+          it.pdfs.insert(it.pdfs.end(), v.begin(), v.end());
+        }
+        it.off.push_back((int64_t)it.pdfs.size());
+        it.f = &f;
+        it.ok = true;
+      } catch (const std::exception &e) { it.err = e.what(); if (it.err.empty()) it.err = "error"; }
+    });
+    for (const Item &it : items) if (!it.err.empty()) throw ApiError(it.err);
+    for (size_t c0 = 0; c0 < items.size();) {
+      // a chunk of lattices: up to ~2 M frames through one GPU call
+      size_t c1 = c0; int64_t frames = 0;
+      while (c1 < items.size() && (frames == 0 || frames < ((int64_t)2 << 20))) { if (items[c1].ok) frames += items[c1].f->rows; c1++; }
+      std::vector<float> bfeats; std::vector<int64_t> poff{0}; std::vector<int32_t> ppdf;
+      for (size_t i = c0; i < c1; i++) {
+        Item &it = items[i];
+        if (!it.ok) continue;
+        it.base = (int64_t)ppdf.size();
+        bfeats.insert(bfeats.end(), it.f->data.begin(), it.f->data.end());
+        for (int t = 0; t < it.f->rows; t++) poff.push_back(it.base + it.off[t + 1]);
+        ppdf.insert(ppdf.end(), it.pdfs.begin(), it.pdfs.end());
+      }
       std::vector<float> scores(ppdf.size());
-      void *d_feats = nullptr;
-      if (vbh_dev_alloc(ctx, sizeof(float) * bfeats.size(), &d_feats) != 0) throw ApiError(std::string("vbh_dev_alloc: ") + vbh_last_error());
-      struct DevGuard { vbh_ctx *c; void *p; ~DevGuard() { vbh_dev_free(c, p); } } dg{ctx, d_feats};
-      if (vbh_copy_h2d(ctx, d_feats, bfeats.data(), sizeof(float) * bfeats.size()) != 0) throw ApiError(std::string("vbh_copy_h2d: ") + vbh_last_error());
-      if (vbh_gmm_loglikes_pairs(dgmm, (const float *)d_feats, T, poff.data(), ppdf.data(), scores.data()) != 0)
-        throw ApiError(std::string("vbh_gmm_loglikes_pairs: ") + vbh_last_error());
-      for (Item &it : batch) {
+      if (!ppdf.empty()) {
+        const int64_t T = (int64_t)poff.size() - 1;
+        void *d_feats = nullptr;
+        if (vbh_dev_alloc(ctx, sizeof(float) * bfeats.size(), &d_feats) != 0) throw ApiError(std::string("vbh_dev_alloc: ") + vbh_last_error());
+        struct DevGuard { vbh_ctx *c; void *p; ~DevGuard() { vbh_dev_free(c, p); } } dg{ctx, d_feats};
+        if (vbh_copy_h2d(ctx, d_feats, bfeats.data(), sizeof(float) * bfeats.size()) != 0) throw ApiError(std::string("vbh_copy_h2d: ") + vbh_last_error());
+        if (vbh_gmm_loglikes_pairs(dgmm, (const float *)d_feats, T, poff.data(), ppdf.data(), scores.data()) != 0)
+          throw ApiError(std::string("vbh_gmm_loglikes_pairs: ") + vbh_last_error());
+      }
+      parallel_for(c1 - c0, [&](size_t k) {
+        Item &it = items[c0 + k];
+        if (!it.ok) return;
         auto loglike = [&](int32_t t, int32_t tid) -> float {
           const int32_t pdf = model.tid2pdf[tid];
-          const int64_t a = it.off[t], b = it.off[t + 1];
-          const int32_t *lo = std::lower_bound(ppdf.data() + a, ppdf.data() + b, pdf);
-          return scores[lo - ppdf.data()];
+          const int32_t *a = it.pdfs.data() + it.off[t], *b = it.pdfs.data() + it.off[t + 1];
+          return scores[it.base + (std::lower_bound(a, b, pdf) - it.pdfs.data())];
         };
-        if (vblat::RescoreCompactLattice(loglike, it.f->rows, &it.clat)) { writer.Write(it.key, it.clat); num_done++; num_frames += it.f->rows; }
-        else { log.os() << "WARNING (gmm-rescore-lattice) lattice/feature mismatch for utterance " << it.key << "\n"; num_err++; }
+        if (!vblat::RescoreCompactLattice(loglike, it.f->rows, &it.clat)) { it.ok = false; it.warn = "lattice/feature mismatch for utterance " + it.key; }
+      });
+      for (size_t i = c0; i < c1; i++) {
+        Item &it = items[i];
+        if (!it.warn.empty()) { log.os() << "WARNING (gmm-rescore-lattice) " << it.warn << "\n"; num_err++; continue; }
+        writer.Write(it.key, it.clat);
+        num_done++; num_frames += it.f->rows;
+        vblat::CompactLattice().st.swap(it.clat.st);
       }
-      batch.clear(); bfeats.clear(); poff.assign(1, 0); ppdf.clear();
-    };
-    std::string key; vblat::Lattice lat; vblat::CompactLattice clat; bool compact = false;
-    while (reader.Next(&key, &lat, &clat, &compact)) {
-      auto fi = feats.find(key);
-      if (fi == feats.end()) { log.os() << "WARNING (gmm-rescore-lattice) No feature found for utterance " << key << ". Skipping\n"; num_err++; continue; }
-      const vbio::Matrix &f = fi->second;
-      if (f.cols != D) throw ApiError("Dim mismatch: data dim = " + std::to_string(f.cols) + " vs. model dim = " + std::to_string(D));
-      if (!compact) vblat::ConvertLattice(lat, &clat);          // CompactLatticeHolder::Read of a state-level lattice
-      if (old_acoustic_scale != 1.0f) vblat::ScaleLattice(1.0, 0.0, 0.0, (double)old_acoustic_scale, &clat);
-      if (clat.st.empty()) { log.os() << "WARNING (gmm-rescore-lattice) Rescoring empty lattice for utterance " << key << "\n"; num_err++; continue; }
-      // the pdfs the lattice holds at every frame (the same walk as RescoreCompactLattice's time_to_state, lattice-functions.cc:1236-1270)
-      if (!vblat::TopSort(&clat)) { log.os() << "WARNING (gmm-rescore-lattice) Cycles detected in lattice " << key << "\n"; num_err++; continue; }
-      std::vector<int32_t> times;
-      const int32_t utt_len = vblat::CompactLatticeStateTimes(clat, &times);
-      if (utt_len > f.rows) { log.os() << "WARNING (gmm-rescore-lattice) Features are too short for lattice: utt-len is " << utt_len << " for utterance " << key << "\n"; num_err++; continue; }
-      std::vector<std::vector<int32_t>> pdfs(f.rows);
-      bool ok = true;
-      auto add = [&](int32_t t0, const std::vector<int32_t> &str) {
-        for (size_t o = 0; o < str.size(); o++) {
-          if (str[o] <= 0 || str[o] >= (int32_t)model.tid2pdf.size()) throw ApiError("lattice: transition-id out of the model's range");
-          if (t0 + (int32_t)o >= f.rows) { ok = false; return; }
-          pdfs[t0 + o].push_back(model.tid2pdf[str[o]]);
-        }
-      };
-      for (size_t s = 0; s < clat.st.size() && ok; s++) {
-        for (const vblat::CArc &a : clat.st[s].arcs) add(times[s], a.w.str);
-        add(times[s], clat.st[s].final.str);
-      }
-      if (!ok) { log.os() << "WARNING (gmm-rescore-lattice) lattice/feature mismatch for utterance " << key << "\n"; num_err++; continue; }
-      Item it; it.key = key; it.clat = std::move(clat); it.f = &f; it.pair0 = (int64_t)ppdf.size(); it.off.reserve(f.rows + 1);
-      for (int t = 0; t < f.rows; t++) {
-        std::vector<int32_t> &v = pdfs[t];
-        std::sort(v.begin(), v.end());
-        v.erase(std::unique(v.begin(), v.end()), v.end());
-        it.off.push_back((int64_t)ppdf.size());
-        ppdf.insert(ppdf.end(), v.begin(), v.end());
-        poff.push_back((int64_t)ppdf.size());
-      }
-      it.off.push_back((int64_t)ppdf.size());
-      bfeats.insert(bfeats.end(), f.data.begin(), f.data.end());
-      batch.push_back(std::move(it));
-      if ((int64_t)poff.size() > ((int64_t)2 << 20)) flush();
+      c0 = c1;
     }
-    flush();
     log.os() << "LOG (gmm-rescore-lattice) Done " << num_done << " lattices with errors on " << num_err << ", #frames is " << num_frames << "\n";
     return num_done != 0 ? 0 : 1;
   });

@@ -2,9 +2,11 @@
 // (SURVEY.md 8f rank 1 and 3): determinization, scaling, word insertion penalty, best path, WER.
 // Declarations and the reference files they mirror: voicebridge_api.h.  Host code: these run per
 // utterance on lattices of a few thousand arcs, between the GPU search and the files.
+#include <atomic>
 #include <cmath>
 #include <map>
 #include <sstream>
+#include <thread>
 
 #include "api_common.h"
 #include "kaldi_io.h"
@@ -74,26 +76,44 @@ int LatticeDeterminizePruned(int argc, char *argv[], std::ofstream &file_log) {
     writer.Open(po.args[1]);
     int n_done = 0, n_warn = 0;
     double sum_depth_in = 0.0, sum_depth_out = 0.0, sum_t = 0.0;
-    std::string key; vblat::Lattice lat;
-    while (reader.NextLattice(&key, &lat)) {
-      vblat::Invert(&lat);
-      vblat::ScaleLattice(1.0, 0.0, 0.0, (double)acoustic_scale, &lat);
-      if (!vblat::TopSort(&lat))
-        log.os() << "WARNING (lattice-determinize-pruned) Could not topologically sort lattice: this probably means it has bad properties e.g. epsilon cycles.\n";
-      vblat::ArcSortILabel(&lat);
-      vblat::CompactLattice det;
-      if (!vblat::DeterminizeLatticePruned(lat, beam, &det, opts)) {
-        log.os() << "WARNING (lattice-determinize-pruned) For key " << key << ", determinization did not succeed(partial output will be pruned tighter than the specified beam.)\n";
-        n_warn++;
-      }
-      vblat::Connect(&det);
-      if (det.st.empty()) { log.os() << "WARNING (lattice-determinize-pruned) For key " << key << ", determinized and trimmed lattice was empty.\n"; n_warn++; }
-      int32_t t;
-      TopSortCompactIfNeeded(&det);
-      const double depth = CompactLatticeDepth(det, &t);
-      sum_depth_in += (double)lat.st.size(); sum_depth_out += depth * t; sum_t += t;
-      vblat::ScaleLattice(1.0, 0.0, 0.0, 1.0 / (double)acoustic_scale, &det);
-      writer.Write(key, det);
+    // the lattices of the table are independent: read, determinized on the host's threads, written in table order
+    struct Item { std::string key; vblat::Lattice lat; vblat::CompactLattice det; bool ok = true, empty = false, unsorted = false; double depth = 0; int32_t t = 0; size_t in_states = 0; std::string err; };
+    std::vector<Item> items;
+    { Item it; while (reader.NextLattice(&it.key, &it.lat)) { items.push_back(std::move(it)); it = Item(); } }
+    {
+      std::atomic<size_t> next{0};
+      auto work = [&]() {
+        for (size_t i = next++; i < items.size(); i = next++) {
+          Item &it = items[i];
+          try {
+            vblat::Invert(&it.lat);
+            vblat::ScaleLattice(1.0, 0.0, 0.0, (double)acoustic_scale, &it.lat);
+            it.unsorted = !vblat::TopSort(&it.lat);
+            vblat::ArcSortILabel(&it.lat);
+            it.ok = vblat::DeterminizeLatticePruned(it.lat, beam, &it.det, opts);
+            vblat::Connect(&it.det);
+            it.empty = it.det.st.empty();
+            TopSortCompactIfNeeded(&it.det);
+            it.depth = CompactLatticeDepth(it.det, &it.t);
+            it.in_states = it.lat.st.size();
+            vblat::ScaleLattice(1.0, 0.0, 0.0, 1.0 / (double)acoustic_scale, &it.det);
+            vblat::Lattice().st.swap(it.lat.st);
+          } catch (const std::exception &e) { it.err = e.what(); if (it.err.empty()) it.err = "error"; }
+        }
+      };
+      const unsigned nt = std::max(1u, std::min<unsigned>(16, std::min<unsigned>((unsigned)items.size(), std::thread::hardware_concurrency())));
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+      work();
+      for (std::thread &t : pool) t.join();
+    }
+    for (Item &it : items) {
+      if (!it.err.empty()) throw ApiError("key " + it.key + ": " + it.err);
+      if (it.unsorted) log.os() << "WARNING (lattice-determinize-pruned) Could not topologically sort lattice: this probably means it has bad properties e.g. epsilon cycles.\n";
+      if (!it.ok) { log.os() << "WARNING (lattice-determinize-pruned) For key " << it.key << ", determinization did not succeed(partial output will be pruned tighter than the specified beam.)\n"; n_warn++; }
+      if (it.empty) { log.os() << "WARNING (lattice-determinize-pruned) For key " << it.key << ", determinized and trimmed lattice was empty.\n"; n_warn++; }
+      sum_depth_in += (double)it.in_states; sum_depth_out += it.depth * it.t; sum_t += it.t;
+      writer.Write(it.key, it.det);
       n_done++;
     }
     if (sum_t != 0.0)

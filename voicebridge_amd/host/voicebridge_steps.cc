@@ -8,7 +8,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <map>
 #include <regex>
@@ -410,9 +412,12 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
     for (const std::string &f : {Join(si_dir, "lat.1"), adapt_model, final_model}) if (!Exists(f)) throw StepError("Failed to find " + f);
     const bool lda = Exists(Join(srcdir, "final.mat"));
     const std::string acw = "--acoustic-scale=" + std::to_string(acwt), symtab = Join(graphdir, "words.txt");
+    const bool laps = getenv("VBH_DEBUG_TIMES") != nullptr;
     auto run = [&](const char *what, int (*fn)(int, char **, std::ofstream &), std::vector<std::string> a, std::ofstream &log, bool none_ok = false) {
       Argv av(std::move(a));
+      const auto t0 = std::chrono::steady_clock::now();
       const int r = fn(av.argc(), av.argv(), log);
+      if (laps) fprintf(stderr, "DecodeFmllr %-28s %8.1f ms\n", what, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
       if (r < 0 || (r != 0 && !none_ok)) throw StepError(std::string(what) + " failed (return code " + std::to_string(r) + "), see " + Join(dir, "log"));
     };
     for (int j = 1; j <= nj; j++) {
