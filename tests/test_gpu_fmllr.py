@@ -118,6 +118,48 @@ def test_gmm_est_fmllr_bin_function_vs_golden(tmp_path):
     assert list(read_fm_ark(str(d / "u.ark"))) == ["uttA", "uttB", "uttC", "uttD"]
 
 
+def test_gmm_est_fmllr_ali_model_vs_gpost_pair(tmp_path):
+    """--ali-model (extension; what DecodeFmllr's first pass uses): Gaussian posteriors from an alignment model, statistics
+    from the adapt model, without a gpost table -- the same transforms as gmm-post-to-gpost <alimdl> | gmm-est-fmllr-gpost
+    <adapt model> (each of which test_gmm_est_fmllr_bin_function_vs_golden / test_host_fmllr pin to the reference)"""
+    from tests.test_host_io import read_fm_ark
+    from tests.test_host_lattice import call
+    from voicebridge_amd import build, synth
+    host = C.CDLL(build.HOST_LIB)
+    d = tmp_path
+    g = util.load("fmllr")
+    for k in ("file_final_mdl", "file_feats_ark", "file_wsp_ark"):
+        name = k[5:].rsplit("_", 1)
+        (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
+    (d / "spk2utt").write_text(str(g["text_spk2utt"]))
+    # the golden case's model (oracle/gen_golden_lat.py make_case, seed 5) with other means: same topology and Gaussian counts
+    n_cd, H = 12, 3
+    P = n_cd * H
+    offs, w, means, iv = synth.gmm_model(P, P * 3, 39, seed=6)
+    rng = np.random.default_rng(0)
+    means2 = means + 0.3 * rng.standard_normal(means.shape)
+    util.write_mdl(str(d / "ali.mdl"), n_cd, H, offs, w, (means2 * iv).astype(np.float32), iv)
+    log = str(d / "log.txt")
+    common = ["--fmllr-min-count=50", "--spk2utt=ark:%s" % (d / "spk2utt")]
+    tail = ["ark:%s" % (d / "feats.ark"), "ark:%s" % (d / "wsp.ark")]
+    assert call(host.vb_GmmEstFmllr, ["gmm-est-fmllr"] + common + ["--ali-model=%s" % (d / "ali.mdl"), str(d / "final.mdl")] + tail + ["ark:%s" % (d / "fused.ark")], log) == 0, open(log).read()
+    assert call(host.vb_GmmPostToGpost, ["gmm-post-to-gpost", str(d / "ali.mdl")] + tail + ["ark:%s" % (d / "gp.ark")], log) == 0, open(log).read()
+    assert call(host.vb_GmmEstFmllrGpost, ["gmm-est-fmllr-gpost"] + common + [str(d / "final.mdl"), tail[0], "ark:%s" % (d / "gp.ark"), "ark:%s" % (d / "pair.ark")], log) == 0, open(log).read()
+    fused, pair = read_fm_ark(str(d / "fused.ark")), read_fm_ark(str(d / "pair.ark"))
+    assert list(fused) == list(pair) == ["spk1", "spk2"]
+    for k in pair:
+        np.testing.assert_allclose(fused[k], pair[k], atol=2e-4, rtol=0)
+    # and the alignment model matters: with the adapt model's own posteriors the transforms are different ones
+    assert call(host.vb_GmmEstFmllr, ["gmm-est-fmllr"] + common + [str(d / "final.mdl")] + tail + ["ark:%s" % (d / "own.ark")], log) == 0, open(log).read()
+    own = read_fm_ark(str(d / "own.ark"))
+    assert max(np.abs(own[k] - fused[k]).max() for k in own) > 1e-2
+    # a model with other Gaussian counts is refused
+    offs3, w3, means3, iv3 = synth.gmm_model(P, P * 2, 39, seed=6)
+    util.write_mdl(str(d / "bad.mdl"), n_cd, H, offs3, w3, (means3 * iv3).astype(np.float32), iv3)
+    assert call(host.vb_GmmEstFmllr, ["gmm-est-fmllr"] + common + ["--ali-model=%s" % (d / "bad.mdl"), str(d / "final.mdl")] + tail + ["ark:%s" % (d / "x.ark")], log) != 0
+    assert "--ali-model" in open(log).read()
+
+
 def test_fmllr_update_properties(tmp_path):
     """properties of the estimate that do not depend on a reference run: below --fmllr-min-count the
     unit transform is written; the update raises the auxiliary function (logged improvement > 0)"""

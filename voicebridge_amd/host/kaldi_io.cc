@@ -1,6 +1,11 @@
 // kaldi_io.cc -- see kaldi_io.h.  Formats re-implemented from their on-disk description.
 #include "kaldi_io.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -732,11 +737,6 @@ std::string ReadFstString(std::istream &is) {
   if (n) is.read(&s[0], n);
   return s;
 }
-void WriteFstString(std::ostream &os, const std::string &s) {
-  const int32_t n = (int32_t)s.size();
-  os.write(reinterpret_cast<const char *>(&n), 4);
-  os.write(s.data(), n);
-}
 constexpr int32_t kFstMagic = 2125659606;
 }  // namespace
 
@@ -799,66 +799,72 @@ void LatticeWriter::Open(const std::string &wspecifier) {
   open_ = true;
 }
 
-// VectorFst<LatticeArc>::Write with default options inside an archive entry
-// (kaldi-lattice.cc:388-394; vector-fst.h WriteFst): header, then per state the final weight
-// (two floats), int64 arc count, arcs {ilabel, olabel, graph, acoustic, nextstate}
-void LatticeWriter::Write(const std::string &key, const LatticeOut &lat) {
-  ark_ << key << ' ';
-  const int64_t ns = (int64_t)lat.arcs.size();
-  int64_t na = 0;
-  for (const auto &a : lat.arcs) na += (int64_t)a.size();
-  ark_.write(reinterpret_cast<const char *>(&kFstMagic), 4);
-  WriteFstString(ark_, "vector");
-  WriteFstString(ark_, "lattice4");
-  const int32_t version = 2, flags = 0;
-  const uint64_t props = 3;          // kExpanded | kMutable; everything else unknown
-  const int64_t start = ns ? 0 : -1;
-  ark_.write(reinterpret_cast<const char *>(&version), 4);
-  ark_.write(reinterpret_cast<const char *>(&flags), 4);
-  ark_.write(reinterpret_cast<const char *>(&props), 8);
-  ark_.write(reinterpret_cast<const char *>(&start), 8);
-  ark_.write(reinterpret_cast<const char *>(&ns), 8);
-  ark_.write(reinterpret_cast<const char *>(&na), 8);
-  for (int64_t s = 0; s < ns; s++) {
-    const float fg = lat.final_graph[s], fa = std::isinf(fg) ? std::numeric_limits<float>::infinity() : lat.final_acoustic[s];
-    ark_.write(reinterpret_cast<const char *>(&fg), 4);
-    ark_.write(reinterpret_cast<const char *>(&fa), 4);
-    const int64_t n = (int64_t)lat.arcs[s].size();
-    ark_.write(reinterpret_cast<const char *>(&n), 8);
-    for (const LatticeArcOut &a : lat.arcs[s]) {
-      ark_.write(reinterpret_cast<const char *>(&a.ilabel), 4);
-      ark_.write(reinterpret_cast<const char *>(&a.olabel), 4);
-      ark_.write(reinterpret_cast<const char *>(&a.graph), 4);
-      ark_.write(reinterpret_cast<const char *>(&a.acoustic), 4);
-      ark_.write(reinterpret_cast<const char *>(&a.nextstate), 4);
-    }
-  }
-  if (ark_.fail()) Fail("write failure on " + spec_.ark_path);
-}
-
-
+// Lattices are serialised into one buffer per entry and parsed from a mapping of the whole archive: an entry has millions of
+// 4-byte fields, and a stream call per field costs more than everything else the lattice programs do.
 namespace {
-template <class T> void Put(std::ostream &os, const T &v) { os.write(reinterpret_cast<const char *>(&v), sizeof(T)); }
-template <class T> T Get(std::istream &is) { T v; is.read(reinterpret_cast<char *>(&v), sizeof(T)); return v; }
-void WriteFstHeader(std::ostream &os, const char *arctype, int64_t start, int64_t ns, int64_t na) {
-  Put(os, kFstMagic);
-  WriteFstString(os, "vector");
-  WriteFstString(os, arctype);
-  Put<int32_t>(os, 2); Put<int32_t>(os, 0);
-  Put<uint64_t>(os, 3);          // kExpanded | kMutable; everything else unknown
-  Put(os, start); Put(os, ns); Put(os, na);
+static_assert(sizeof(LatticeArcOut) == 20 && sizeof(vblat::Arc) == 20, "arc records are written as they lie in memory");
+template <class T> void Put(std::string *b, const T &v) { b->append(reinterpret_cast<const char *>(&v), sizeof(T)); }
+void PutFstString(std::string *b, const char *s) { Put<int32_t>(b, (int32_t)strlen(s)); b->append(s); }
+void PutFstHeader(std::string *b, const char *arctype, int64_t start, int64_t ns, int64_t na) {
+  Put(b, kFstMagic);
+  PutFstString(b, "vector");
+  PutFstString(b, arctype);
+  Put<int32_t>(b, 2); Put<int32_t>(b, 0);
+  Put<uint64_t>(b, 3);          // kExpanded | kMutable; everything else unknown
+  Put(b, start); Put(b, ns); Put(b, na);
 }
 }  // namespace
 
-void LatticeWriter::Write(const std::string &key, const vblat::Lattice &lat) {
-  ark_ << key << ' ';
-  WriteFstHeader(ark_, "lattice4", lat.start, (int64_t)lat.st.size(), (int64_t)lat.NumArcs());
-  for (const vblat::State &s : lat.st) {
-    Put(ark_, s.final.v1); Put(ark_, s.final.v2);
-    Put<int64_t>(ark_, (int64_t)s.arcs.size());
-    for (const vblat::Arc &a : s.arcs) { Put(ark_, a.ilabel); Put(ark_, a.olabel); Put(ark_, a.w.v1); Put(ark_, a.w.v2); Put(ark_, a.next); }
+// VectorFst<LatticeArc>::Write with default options inside an archive entry
+// (kaldi-lattice.cc:388-394; vector-fst.h WriteFst): header, then per state the final weight
+// (two floats), int64 arc count, arcs {ilabel, olabel, graph, acoustic, nextstate}
+void SerializeLattice(const LatticeOut &lat, std::string *b) {
+  const int64_t ns = (int64_t)lat.arcs.size();
+  int64_t na = 0;
+  for (const auto &a : lat.arcs) na += (int64_t)a.size();
+  b->reserve(b->size() + 96 + 16 * (size_t)ns + 20 * (size_t)na);
+  PutFstHeader(b, "lattice4", ns ? 0 : -1, ns, na);
+  for (int64_t s = 0; s < ns; s++) {
+    const float fg = lat.final_graph[s], fa = std::isinf(fg) ? std::numeric_limits<float>::infinity() : lat.final_acoustic[s];
+    Put(b, fg); Put(b, fa);
+    Put<int64_t>(b, (int64_t)lat.arcs[s].size());
+    if (!lat.arcs[s].empty()) b->append(reinterpret_cast<const char *>(lat.arcs[s].data()), 20 * lat.arcs[s].size());
   }
+}
+void SerializeLattice(const vblat::Lattice &lat, std::string *b) {
+  const size_t na = lat.NumArcs();
+  b->reserve(b->size() + 96 + 16 * lat.st.size() + 20 * na);
+  PutFstHeader(b, "lattice4", lat.start, (int64_t)lat.st.size(), (int64_t)na);
+  for (const vblat::State &s : lat.st) {
+    Put(b, s.final.v1); Put(b, s.final.v2);
+    Put<int64_t>(b, (int64_t)s.arcs.size());
+    if (!s.arcs.empty()) b->append(reinterpret_cast<const char *>(s.arcs.data()), 20 * s.arcs.size());
+  }
+}
+void SerializeLattice(const vblat::CompactLattice &clat, std::string *b) {
+  PutFstHeader(b, "compactlattice44", clat.start, (int64_t)clat.st.size(), (int64_t)clat.NumArcs());
+  auto put_w = [&](const vblat::CWeight &w) {
+    Put(b, w.w.v1); Put(b, w.w.v2);
+    Put<int32_t>(b, (int32_t)w.str.size());
+    if (!w.str.empty()) b->append(reinterpret_cast<const char *>(w.str.data()), 4 * w.str.size());
+  };
+  for (const vblat::CState &s : clat.st) {
+    put_w(s.final);
+    Put<int64_t>(b, (int64_t)s.arcs.size());
+    for (const vblat::CArc &a : s.arcs) { Put(b, a.label); Put(b, a.label); put_w(a.w); Put(b, a.next); }
+  }
+}
+
+void LatticeWriter::WriteSerialized(const std::string &key, const std::string &object) {
+  ark_ << key << ' ';
+  ark_.write(object.data(), (std::streamsize)object.size());
   if (ark_.fail()) Fail("write failure on " + spec_.ark_path);
+}
+void LatticeWriter::Write(const std::string &key, const LatticeOut &lat) {
+  buf_.clear(); SerializeLattice(lat, &buf_); WriteSerialized(key, buf_);
+}
+void LatticeWriter::Write(const std::string &key, const vblat::Lattice &lat) {
+  buf_.clear(); SerializeLattice(lat, &buf_); WriteSerialized(key, buf_);
 }
 
 void CompactLatticeWriter::Open(const std::string &wspecifier) {
@@ -868,80 +874,149 @@ void CompactLatticeWriter::Open(const std::string &wspecifier) {
   if (!ark_) Fail("cannot open " + spec_.ark_path + " for writing");
   open_ = true;
 }
-
-void CompactLatticeWriter::Write(const std::string &key, const vblat::CompactLattice &clat) {
+void CompactLatticeWriter::WriteSerialized(const std::string &key, const std::string &object) {
   ark_ << key << ' ';
-  WriteFstHeader(ark_, "compactlattice44", clat.start, (int64_t)clat.st.size(), (int64_t)clat.NumArcs());
-  auto put_w = [&](const vblat::CWeight &w) {
-    Put(ark_, w.w.v1); Put(ark_, w.w.v2);
-    Put<int32_t>(ark_, (int32_t)w.str.size());
-    if (!w.str.empty()) ark_.write(reinterpret_cast<const char *>(w.str.data()), 4 * w.str.size());
-  };
-  for (const vblat::CState &s : clat.st) {
-    put_w(s.final);
-    Put<int64_t>(ark_, (int64_t)s.arcs.size());
-    for (const vblat::CArc &a : s.arcs) { Put(ark_, a.label); Put(ark_, a.label); put_w(a.w); Put(ark_, a.next); }
-  }
+  ark_.write(object.data(), (std::streamsize)object.size());
   if (ark_.fail()) Fail("write failure on " + spec_.ark_path);
 }
-
-LatticeReader::LatticeReader(const std::string &rspecifier) : spec_(ParseRspecifier(rspecifier)) {
-  if (spec_.is_scp) scp_ = ReadScp(spec_.path);
-  else {
-    ark_.open(spec_.path, std::ios::binary);
-    if (!ark_) Fail("cannot open archive " + spec_.path);
-  }
+void CompactLatticeWriter::Write(const std::string &key, const vblat::CompactLattice &clat) {
+  buf_.clear(); SerializeLattice(clat, &buf_); WriteSerialized(key, buf_);
 }
 
-static void ReadLatticeBody(std::istream &is, vblat::Lattice *lat, vblat::CompactLattice *clat, bool *is_compact) {
-  const int c = is.peek();
+namespace {
+struct StreamIn {            // an entry addressed through an .scp line
+  std::istream &is;
+  template <class T> T Get() { T v; is.read(reinterpret_cast<char *>(&v), sizeof(T)); if (is.fail()) Fail("lattice: truncated"); return v; }
+  void Read(void *dst, size_t n) { is.read(reinterpret_cast<char *>(dst), (std::streamsize)n); if (is.fail()) Fail("lattice: truncated"); }
+  int Peek() { return is.peek(); }
+  size_t Left() const { return std::numeric_limits<size_t>::max(); }
+};
+struct MemIn {               // cursor over an archive mapped into memory
+  const char *p, *end;
+  template <class T> T Get() { T v; Read(&v, sizeof(T)); return v; }
+  void Read(void *dst, size_t n) { if ((size_t)(end - p) < n) Fail("lattice: truncated"); memcpy(dst, p, n); p += n; }
+  int Peek() { return p < end ? (unsigned char)*p : EOF; }
+  size_t Left() const { return (size_t)(end - p); }
+};
+template <class In> std::string GetFstString(In &in) {
+  const int32_t n = in.template Get<int32_t>();
+  if (n < 0 || n > 4096) Fail("fst: bad string length in header");
+  std::string s((size_t)n, '\0');
+  if (n) in.Read(&s[0], (size_t)n);
+  return s;
+}
+template <class In>
+void ReadLatticeBody(In &in, vblat::Lattice *lat, vblat::CompactLattice *clat, bool *is_compact) {
+  const int c = in.Peek();
   if (c == EOF) Fail("lattice: unexpected end of file");
   if (isspace(c)) Fail("text-mode lattices are not supported");
-  if (Get<int32_t>(is) != kFstMagic) Fail("lattice: bad magic number");
-  const std::string fsttype = ReadFstString(is), arctype = ReadFstString(is);
-  const int32_t version = Get<int32_t>(is), flags = Get<int32_t>(is);
-  (void)version;
-  Get<uint64_t>(is);
-  const int64_t start = Get<int64_t>(is), ns = Get<int64_t>(is);
-  Get<int64_t>(is);
-  if (is.fail()) Fail("lattice: truncated header");
+  if (in.template Get<int32_t>() != kFstMagic) Fail("lattice: bad magic number");
+  const std::string fsttype = GetFstString(in), arctype = GetFstString(in);
+  in.template Get<int32_t>();                       // version
+  const int32_t flags = in.template Get<int32_t>();
+  in.template Get<uint64_t>();                      // properties
+  const int64_t start = in.template Get<int64_t>(), ns = in.template Get<int64_t>();
+  in.template Get<int64_t>();                       // arc count (not relied upon)
   if (fsttype != "vector") Fail("lattice: fst type " + fsttype + " not supported");
   if (flags & 3) Fail("lattice: embedded symbol tables are not supported");
-  if (ns < 0 || ns > (1LL << 31)) Fail("lattice: bad state count");
+  if (ns < 0 || ns > (1LL << 31) || (size_t)ns > in.Left() / 8) Fail("lattice: bad state count");
   if (arctype == "lattice4") {
     *is_compact = false;
     lat->st.assign((size_t)ns, vblat::State());
     lat->start = (int32_t)start;
     for (int64_t s = 0; s < ns; s++) {
       vblat::State &st = lat->st[s];
-      st.final.v1 = Get<float>(is); st.final.v2 = Get<float>(is);
-      const int64_t na = Get<int64_t>(is);
-      if (is.fail() || na < 0) Fail("lattice: truncated");
+      st.final.v1 = in.template Get<float>(); st.final.v2 = in.template Get<float>();
+      const int64_t na = in.template Get<int64_t>();
+      if (na < 0 || (size_t)na > in.Left() / 20) Fail("lattice: truncated");
       st.arcs.resize((size_t)na);
-      for (vblat::Arc &a : st.arcs) { a.ilabel = Get<int32_t>(is); a.olabel = Get<int32_t>(is); a.w.v1 = Get<float>(is); a.w.v2 = Get<float>(is); a.next = Get<int32_t>(is); }
+      if (na) in.Read(st.arcs.data(), 20 * (size_t)na);
     }
   } else if (arctype == "compactlattice44") {
     *is_compact = true;
     clat->st.assign((size_t)ns, vblat::CState());
     clat->start = (int32_t)start;
     auto get_w = [&](vblat::CWeight *w) {
-      w->w.v1 = Get<float>(is); w->w.v2 = Get<float>(is);
-      const int32_t n = Get<int32_t>(is);
-      if (is.fail() || n < 0) Fail("lattice: bad string size");
+      w->w.v1 = in.template Get<float>(); w->w.v2 = in.template Get<float>();
+      const int32_t n = in.template Get<int32_t>();
+      if (n < 0 || (size_t)n > in.Left() / 4) Fail("lattice: bad string size");
       w->str.resize(n);
-      if (n) is.read(reinterpret_cast<char *>(w->str.data()), 4 * (size_t)n);
+      if (n) in.Read(w->str.data(), 4 * (size_t)n);
     };
     for (int64_t s = 0; s < ns; s++) {
       vblat::CState &st = clat->st[s];
       get_w(&st.final);
-      const int64_t na = Get<int64_t>(is);
-      if (is.fail() || na < 0) Fail("lattice: truncated");
+      const int64_t na = in.template Get<int64_t>();
+      if (na < 0 || (size_t)na > in.Left() / 20) Fail("lattice: truncated");
       st.arcs.resize((size_t)na);
-      for (vblat::CArc &a : st.arcs) { a.label = Get<int32_t>(is); Get<int32_t>(is); get_w(&a.w); a.next = Get<int32_t>(is); }
+      for (vblat::CArc &a : st.arcs) { a.label = in.template Get<int32_t>(); in.template Get<int32_t>(); get_w(&a.w); a.next = in.template Get<int32_t>(); }
     }
   } else Fail("lattice: arc type " + arctype + " not supported");
-  if (is.fail()) Fail("lattice: truncated");
 }
+}  // namespace
+
+namespace {
+// the end of the entry that starts at in.p, without building anything
+void SkimLatticeBody(MemIn &in) {
+  auto skip = [&](size_t n) { if (in.Left() < n) Fail("lattice: truncated"); in.p += n; };
+  const int c = in.Peek();
+  if (c == EOF) Fail("lattice: unexpected end of file");
+  if (isspace(c)) Fail("text-mode lattices are not supported");
+  if (in.Get<int32_t>() != kFstMagic) Fail("lattice: bad magic number");
+  const std::string fsttype = GetFstString(in), arctype = GetFstString(in);
+  skip(4 + 4 + 8 + 8);
+  const int64_t ns = in.Get<int64_t>();
+  skip(8);
+  if (ns < 0 || (size_t)ns > in.Left() / 8) Fail("lattice: bad state count");
+  if (arctype == "lattice4") {
+    for (int64_t s = 0; s < ns; s++) {
+      skip(8);
+      const int64_t na = in.Get<int64_t>();
+      if (na < 0 || (size_t)na > in.Left() / 20) Fail("lattice: truncated");
+      skip(20 * (size_t)na);
+    }
+  } else if (arctype == "compactlattice44") {
+    auto skip_w = [&]() {
+      skip(8);
+      const int32_t n = in.Get<int32_t>();
+      if (n < 0 || (size_t)n > in.Left() / 4) Fail("lattice: bad string size");
+      skip(4 * (size_t)n);
+    };
+    for (int64_t s = 0; s < ns; s++) {
+      skip_w();
+      const int64_t na = in.Get<int64_t>();
+      if (na < 0 || (size_t)na > in.Left() / 20) Fail("lattice: truncated");
+      for (int64_t k = 0; k < na; k++) { skip(8); skip_w(); skip(4); }
+    }
+  } else Fail("lattice: arc type " + arctype + " not supported");
+}
+}  // namespace
+
+void ParseLatticeBytes(const char *p, size_t n, vblat::Lattice *lat, vblat::CompactLattice *clat, bool *is_compact) {
+  MemIn in{p, p + n};
+  ReadLatticeBody(in, lat, clat, is_compact);
+}
+void ParseLatticeBytes(const char *p, size_t n, vblat::Lattice *lat) {
+  vblat::CompactLattice clat; bool compact = false;
+  ParseLatticeBytes(p, n, lat, &clat, &compact);
+  if (compact) vblat::ConvertLattice(clat, lat, true);
+}
+
+LatticeReader::LatticeReader(const std::string &rspecifier) : spec_(ParseRspecifier(rspecifier)) {
+  if (spec_.is_scp) { scp_ = ReadScp(spec_.path); return; }
+  const int fd = ::open(spec_.path.c_str(), O_RDONLY);
+  if (fd < 0) Fail("cannot open archive " + spec_.path);
+  struct stat sb;
+  if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { ::close(fd); Fail("archive " + spec_.path + " is not a regular file"); }
+  map_len_ = (size_t)sb.st_size;
+  if (map_len_) {
+    void *m = mmap(nullptr, map_len_, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) { ::close(fd); Fail("cannot map archive " + spec_.path); }
+    map_ = static_cast<const char *>(m);
+  }
+  ::close(fd);
+}
+LatticeReader::~LatticeReader() { if (map_) munmap(const_cast<char *>(map_), map_len_); }
 
 bool LatticeReader::Next(std::string *key, vblat::Lattice *lat, vblat::CompactLattice *clat, bool *is_compact) {
   if (spec_.is_scp) {
@@ -950,13 +1025,45 @@ bool LatticeReader::Next(std::string *key, vblat::Lattice *lat, vblat::CompactLa
     std::ifstream f(e.path, std::ios::binary);
     if (!f) Fail("cannot open " + e.path);
     if (e.offset >= 0) f.seekg(e.offset);
-    ReadLatticeBody(f, lat, clat, is_compact);
+    StreamIn in{f};
+    ReadLatticeBody(in, lat, clat, is_compact);
     *key = e.key;
     return true;
   }
-  *key = ReadArkKey(ark_);
-  if (key->empty()) return false;
-  ReadLatticeBody(ark_, lat, clat, is_compact);
+  const char *p = map_ + pos_, *end = map_ + map_len_;
+  while (p < end && isspace((unsigned char)*p)) p++;
+  if (p == end) { pos_ = map_len_; return false; }
+  const char *k = p;
+  while (p < end && !isspace((unsigned char)*p)) p++;
+  key->assign(k, p);
+  if (p == end) Fail("archive: expected space after key " + *key);
+  p++;
+  MemIn in{p, end};
+  ReadLatticeBody(in, lat, clat, is_compact);
+  pos_ = (size_t)(in.p - map_);
+  return true;
+}
+bool LatticeReader::NextBytes(std::string *key, const char **bytes, size_t *n) {
+  if (spec_.is_scp) {
+    vblat::Lattice lat; vblat::CompactLattice clat; bool compact = false;
+    if (!Next(key, &lat, &clat, &compact)) return false;
+    held_.emplace_back();
+    if (compact) SerializeLattice(clat, &held_.back()); else SerializeLattice(lat, &held_.back());
+    *bytes = held_.back().data(); *n = held_.back().size();
+    return true;
+  }
+  const char *p = map_ + pos_, *end = map_ + map_len_;
+  while (p < end && isspace((unsigned char)*p)) p++;
+  if (p == end) { pos_ = map_len_; return false; }
+  const char *k = p;
+  while (p < end && !isspace((unsigned char)*p)) p++;
+  key->assign(k, p);
+  if (p == end) Fail("archive: expected space after key " + *key);
+  p++;
+  MemIn in{p, end};
+  SkimLatticeBody(in);
+  *bytes = p; *n = (size_t)(in.p - p);
+  pos_ = (size_t)(in.p - map_);
   return true;
 }
 bool LatticeReader::NextCompact(std::string *key, vblat::CompactLattice *clat) {

@@ -14,6 +14,7 @@
 #define VOICEBRIDGE_KALDI_IO_H_
 
 #include <cstdint>
+#include <deque>
 #include <fstream>
 #include <istream>
 #include <map>
@@ -157,11 +158,17 @@ class LatticeWriter {   // LatticeWriter ("Lattice" holder), binary archives
   bool IsOpen() const { return open_; }
   void Write(const std::string &key, const LatticeOut &lat);
   void Write(const std::string &key, const vblat::Lattice &lat);
+  void WriteSerialized(const std::string &key, const std::string &object);   // object: what SerializeLattice made
  private:
   Wspec spec_;
   bool open_ = false;
   std::ofstream ark_;
+  std::string buf_;
 };
+// the bytes of one archive entry (after the key); callers serialise on their own threads and hand the result to WriteSerialized
+void SerializeLattice(const LatticeOut &lat, std::string *b);
+void SerializeLattice(const vblat::Lattice &lat, std::string *b);
+void SerializeLattice(const vblat::CompactLattice &clat, std::string *b);
 
 
 // CompactLatticeWriter ("CompactLattice" holder, kaldi-lattice.cc:62-70): binary archives of
@@ -173,10 +180,12 @@ class CompactLatticeWriter {
   void Open(const std::string &wspecifier);
   bool IsOpen() const { return open_; }
   void Write(const std::string &key, const vblat::CompactLattice &clat);
+  void WriteSerialized(const std::string &key, const std::string &object);
  private:
   Wspec spec_;
   bool open_ = false;
   std::ofstream ark_;
+  std::string buf_;
 };
 
 // sequential reader over binary lattice archives ("ark:" or "scp:"); an entry is either a
@@ -184,17 +193,26 @@ class CompactLatticeWriter {
 class LatticeReader {
  public:
   explicit LatticeReader(const std::string &rspecifier);
+  ~LatticeReader();
+  LatticeReader(const LatticeReader &) = delete;
+  LatticeReader &operator=(const LatticeReader &) = delete;
   // fills *lat or *clat according to what the entry holds (*is_compact tells which)
   bool Next(std::string *key, vblat::Lattice *lat, vblat::CompactLattice *clat, bool *is_compact);
   // convenience: the entry as a CompactLattice / Lattice; the other kind is an error
   bool NextCompact(std::string *key, vblat::CompactLattice *clat);
   bool NextLattice(std::string *key, vblat::Lattice *lat);
+  // the entry's bytes only (valid while the reader lives): callers parse them on their own threads with ParseLatticeBytes
+  bool NextBytes(std::string *key, const char **bytes, size_t *n);
  private:
   Rspec spec_;
-  std::ifstream ark_;
+  const char *map_ = nullptr;      // "ark:": the whole archive, mapped
+  size_t map_len_ = 0;
   std::vector<ScpEntry> scp_;
-  size_t pos_ = 0;
+  size_t pos_ = 0;                 // scp: next line; ark: offset into the mapping
+  std::deque<std::string> held_;   // scp: the entries NextBytes handed out
 };
+void ParseLatticeBytes(const char *p, size_t n, vblat::Lattice *lat, vblat::CompactLattice *clat, bool *is_compact);
+void ParseLatticeBytes(const char *p, size_t n, vblat::Lattice *lat);     // a compact entry is converted (LatticeHolder::Read)
 
 // Posterior / GaussPost tables (K/hmm/posterior.cc:32-62,127-215), binary archives
 typedef vblat::Posterior Posterior;

@@ -734,10 +734,11 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
       const double inv = cfg.acoustic_scale != 0.0f ? 1.0 / (double)cfg.acoustic_scale : 1.0;
       // determinization (DeterminizeLatticePhonePrunedWrapper, decoder-wrappers.cc:262-275) is host
       // work per utterance: the utterances of the batch are spread over the host's cores
-      std::vector<vblat::CompactLattice> clats(want_lat && determinize ? nu : 0);
+      // Both are done here, with the entry's bytes, so that the writing loop below only appends to the archives.
+      std::vector<std::string> entry(want_lat ? nu : 0);
       std::vector<int> det_ok(nu, 1);
       std::vector<std::string> det_err(nu);
-      if (want_lat && determinize) {
+      if (want_lat) {
         std::atomic<size_t> next{0};
         auto work = [&]() {
           for (size_t u = next++; u < nu; u = next++) {
@@ -745,10 +746,18 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
             try {
               vblat::Lattice lat;
               raw_lattice(Ls[u], &lat);
+              if (lat.st.empty()) throw ApiError("Unexpected problem getting lattice");
               vblat::Connect(&lat);
-              det_ok[u] = vblat::DeterminizeLatticePhonePrunedWrapper(model.trans, &lat, cfg.lattice_beam, &clats[u], det_opts) ? 1 : 0;
-              vblat::ScaleLattice(1.0, 0.0, 0.0, inv, &clats[u]);
-            } catch (const std::exception &e) { det_err[u] = e.what(); }
+              if (determinize) {
+                vblat::CompactLattice clat;
+                det_ok[u] = vblat::DeterminizeLatticePhonePrunedWrapper(model.trans, &lat, cfg.lattice_beam, &clat, det_opts) ? 1 : 0;
+                vblat::ScaleLattice(1.0, 0.0, 0.0, inv, &clat);
+                vbio::SerializeLattice(clat, &entry[u]);
+              } else {
+                vblat::ScaleLattice(1.0, 0.0, 0.0, inv, &lat);
+                vbio::SerializeLattice(lat, &entry[u]);
+              }
+            } catch (const std::exception &e) { det_err[u] = e.what(); if (det_err[u].empty()) det_err[u] = "error"; }
           }
         };
         const unsigned nt = std::max(1u, std::min((unsigned)nu, std::min(16u, std::thread::hardware_concurrency())));
@@ -771,17 +780,11 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
         if (words_writer.IsOpen()) words_writer.Write(utt, words);
         if (ali_writer.IsOpen()) ali_writer.Write(utt, ali);
         const double like = -((double)L.best_graph + (double)L.best_acoustic);
-        if (want_lat && determinize) {
-          if (!det_err[u].empty()) throw ApiError("determinization of " + utt + ": " + det_err[u]);
+        if (want_lat) {
+          if (!det_err[u].empty()) throw ApiError("lattice of " + utt + ": " + det_err[u]);
           if (!det_ok[u]) log.os() << "WARNING (gmm-latgen-faster) Determinization finished earlier than the beam for utterance " << utt << "\n";
-          clat_writer.Write(utt, clats[u]);
-        } else if (want_lat) {
-          vblat::Lattice lat;
-          raw_lattice(L, &lat);
-          if (lat.st.empty()) throw ApiError("Unexpected problem getting lattice for utterance " + utt);
-          vblat::Connect(&lat);
-          vblat::ScaleLattice(1.0, 0.0, 0.0, inv, &lat);
-          lat_writer.Write(utt, lat);
+          if (determinize) clat_writer.WriteSerialized(utt, entry[u]); else lat_writer.WriteSerialized(utt, entry[u]);
+          std::string().swap(entry[u]);
         }
         log.os() << "LOG (gmm-latgen-faster) Log-like per frame for utterance " << utt << " is " << (like / (L.num_ali ? L.num_ali : 1))
                  << " over " << L.num_ali << " frames.\n";

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <functional>
 #include <map>
+#include <memory>
 #include <set>
 #include <sstream>
 #include <thread>
@@ -222,8 +223,8 @@ struct PairSink {
   void Clear() { poff.assign(1, 0); goff.assign(1, 0); ppdf.clear(); pw.clear(); gpost.clear(); }
 };
 template <class AddUtt>
-static int EstimateOnGpu(const char *prog, bool use_gpost, const Options &po, const Gmm &gmm, const std::string &feat_rspec, const std::string &trans_wspec,
-                         Log &log, AddUtt add_utt) {
+static int EstimateOnGpu(const char *prog, bool use_gpost, const Options &po, const Gmm &gmm, const Gmm *ali_gmm, const std::string &feat_rspec,
+                         const std::string &trans_wspec, Log &log, AddUtt add_utt) {
   const vbfmllr::FmllrOptions opts = ReadFmllrOptions(po);
   if (opts.update_type != "full") throw ApiError("--fmllr-update-type=" + opts.update_type + " is not supported (only full)");
   const int D = gmm.m.dim, n1 = D + 1;
@@ -240,7 +241,17 @@ static int EstimateOnGpu(const char *prog, bool use_gpost, const Options &po, co
   vbh_gmm *dgmm = nullptr;
   if (vbh_gmm_create(ctx, D, gmm.m.num_pdfs, gmm.m.pdf_offsets.data(), gmm.m.weights.data(), gmm.m.means_invvars.data(), gmm.m.inv_vars.data(), &dgmm) != 0)
     throw ApiError(std::string("vbh_gmm_create: ") + vbh_last_error());
-  struct GmmGuard { vbh_gmm *g; ~GmmGuard() { vbh_gmm_destroy(g); } } guard{dgmm};
+  struct GmmGuard { vbh_gmm *g; ~GmmGuard() { if (g) vbh_gmm_destroy(g); } } guard{dgmm}, ali_guard{nullptr};
+  // --ali-model (extension): the Gaussian posteriors come from that model, the statistics from `gmm` -- what the reference gets
+  // by piping gmm-post-to-gpost into gmm-est-fmllr-gpost (VB/scr/steps/decode_fmllr.cpp first pass), without the gpost table
+  vbh_gmm *dali = dgmm;
+  if (ali_gmm) {
+    if (ali_gmm->m.dim != D || ali_gmm->m.pdf_offsets != gmm.m.pdf_offsets || ali_gmm->m.tid2pdf != gmm.m.tid2pdf) throw ApiError("--ali-model: the alignment model's Gaussians do not match the model's");
+    if (vbh_gmm_create(ctx, D, ali_gmm->m.num_pdfs, ali_gmm->m.pdf_offsets.data(), ali_gmm->m.weights.data(), ali_gmm->m.means_invvars.data(),
+                       ali_gmm->m.inv_vars.data(), &ali_guard.g) != 0)
+      throw ApiError(std::string("vbh_gmm_create: ") + vbh_last_error());
+    dali = ali_guard.g;
+  }
   std::vector<int32_t> num_gauss(gmm.m.num_pdfs);
   for (int p = 0; p < gmm.m.num_pdfs; p++) num_gauss[p] = gmm.m.pdf_offsets[p + 1] - gmm.m.pdf_offsets[p];
   std::vector<vbfmllr::FmllrAccs> accs(units.size(), vbfmllr::FmllrAccs(D));
@@ -260,7 +271,7 @@ static int EstimateOnGpu(const char *prog, bool use_gpost, const Options &po, co
     const int rc = use_gpost
         ? vbh_fmllr_accumulate_gpost(ctx, dgmm, (const float *)d_feats, (int32_t)u2s.size(), foff.data(), u2s.data(), S, sink.poff.data(), sink.ppdf.data(),
                                      sink.goff.data(), sink.gpost.data(), num_gauss.data(), beta.data(), K.data(), G.data(), nullptr)
-        : vbh_fmllr_accumulate(ctx, dgmm, dgmm, (const float *)d_feats, (int32_t)u2s.size(), foff.data(), u2s.data(), S, sink.poff.data(), sink.ppdf.data(),
+        : vbh_fmllr_accumulate(ctx, dali, dgmm, (const float *)d_feats, (int32_t)u2s.size(), foff.data(), u2s.data(), S, sink.poff.data(), sink.ppdf.data(),
                                sink.pw.data(), beta.data(), K.data(), G.data(), nullptr);
     if (rc != 0) throw ApiError(std::string("vbh_fmllr_accumulate: ") + vbh_last_error());
     for (int s = 0; s < S; s++) if (beta[s] != 0.0) accs[s].AddStats(beta[s], &K[(size_t)s * D * n1], &G[(size_t)s * D * n1 * n1]);
@@ -331,7 +342,7 @@ int GmmEstFmllrGpost(int argc, char *argv[], std::ofstream &file_log) {
     const Gmm gmm(po.args[0]);
     std::map<std::string, vbio::GaussPost> gposts;
     for (auto &kv : vbio::ReadGaussPostTable(po.args[2])) gposts.emplace(kv.first, std::move(kv.second));
-    return EstimateOnGpu("gmm-est-fmllr-gpost", true, po, gmm, po.args[1], po.args[3], log, [&](const std::string &utt, const vbio::Matrix &feats, PairSink *sink) {
+    return EstimateOnGpu("gmm-est-fmllr-gpost", true, po, gmm, nullptr, po.args[1], po.args[3], log, [&](const std::string &utt, const vbio::Matrix &feats, PairSink *sink) {
       auto it = gposts.find(utt);
       if (it == gposts.end()) { log.os() << "WARNING (gmm-est-fmllr-gpost) Did not find posteriors for utterance " << utt << "\n"; return false; }
       const vbio::GaussPost &gp = it->second;
@@ -353,13 +364,15 @@ int GmmEstFmllrGpost(int argc, char *argv[], std::ofstream &file_log) {
 int GmmEstFmllr(int argc, char *argv[], std::ofstream &file_log) {
   return Guard("gmm-est-fmllr", &file_log, [&](Log &log) -> int {
     Options po;
-    po.Know({"spk2utt", "fmllr-update-type", "fmllr-min-count", "fmllr-num-iters"});
+    po.Know({"spk2utt", "fmllr-update-type", "fmllr-min-count", "fmllr-num-iters", "ali-model"});
     po.Parse(argc, argv);
     if (po.args.size() != 4) throw ApiError("Wrong arguments.");
     const Gmm gmm(po.args[0]);
+    std::unique_ptr<Gmm> ali;
+    if (po.Has("ali-model")) ali.reset(new Gmm(po.Str("ali-model", "")));
     std::map<std::string, vbio::Posterior> posts;
     for (auto &kv : vbio::ReadPosteriorTable(po.args[2])) posts.emplace(kv.first, std::move(kv.second));
-    return EstimateOnGpu("gmm-est-fmllr", false, po, gmm, po.args[1], po.args[3], log, [&](const std::string &utt, const vbio::Matrix &feats, PairSink *sink) {
+    return EstimateOnGpu("gmm-est-fmllr", false, po, gmm, ali.get(), po.args[1], po.args[3], log, [&](const std::string &utt, const vbio::Matrix &feats, PairSink *sink) {
       auto pi = posts.find(utt);
       if (pi == posts.end()) { log.os() << "WARNING (gmm-est-fmllr) Did not find posteriors for utterance " << utt << "\n"; return false; }
       if ((int)pi->second.size() != feats.rows) { log.os() << "WARNING (gmm-est-fmllr) Posterior vector has wrong size " << pi->second.size() << " vs. " << feats.rows << "\n"; return false; }
@@ -430,12 +443,12 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
     // lattices: one call of the on-demand kernel for all their (frame, pdf) pairs; then the scores are added (host threads) and the
     // lattices written in table order.
     struct Item {
-      std::string key; vblat::Lattice lat; vblat::CompactLattice clat; bool compact = false; const vbio::Matrix *f = nullptr;
+      std::string key; const char *bytes = nullptr; size_t nbytes = 0; vblat::CompactLattice clat; std::string entry; const vbio::Matrix *f = nullptr;
       std::vector<int64_t> off; std::vector<int32_t> pdfs;      // per frame [off[t], off[t+1]) into pdfs (sorted, unique)
       int64_t base = 0; std::string warn, err; bool ok = false;
     };
     std::vector<Item> items;
-    { Item it; while (reader.Next(&it.key, &it.lat, &it.clat, &it.compact)) { items.push_back(std::move(it)); it = Item(); } }
+    { Item it; while (reader.NextBytes(&it.key, &it.bytes, &it.nbytes)) { items.push_back(std::move(it)); it = Item(); } }
     auto parallel_for = [&](size_t n, const std::function<void(size_t)> &fn) {
       std::atomic<size_t> next{0};
       auto work = [&]() { for (size_t i = next++; i < n; i = next++) fn(i); };
@@ -452,7 +465,11 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
         if (fi == feats.end()) { it.warn = "No feature found for utterance " + it.key + ". Skipping"; return; }
         const vbio::Matrix &f = fi->second;
         if (f.cols != D) throw ApiError("Dim mismatch: data dim = " + std::to_string(f.cols) + " vs. model dim = " + std::to_string(D));
-        if (!it.compact) { vblat::ConvertLattice(it.lat, &it.clat); vblat::Lattice().st.swap(it.lat.st); }      // CompactLatticeHolder::Read of a state-level lattice
+        {
+          vblat::Lattice lat; bool compact = false;
+          vbio::ParseLatticeBytes(it.bytes, it.nbytes, &lat, &it.clat, &compact);
+          if (!compact) vblat::ConvertLattice(lat, &it.clat);      // CompactLatticeHolder::Read of a state-level lattice
+        }
         if (old_acoustic_scale != 1.0f) vblat::ScaleLattice(1.0, 0.0, 0.0, (double)old_acoustic_scale, &it.clat);
         if (it.clat.st.empty()) { it.warn = "Rescoring empty lattice for utterance " + it.key; return; }
         if (!vblat::TopSort(&it.clat)) { it.warn = "Cycles detected in lattice " + it.key; return; }
@@ -519,14 +536,16 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
           const int32_t *a = it.pdfs.data() + it.off[t], *b = it.pdfs.data() + it.off[t + 1];
           return scores[it.base + (std::lower_bound(a, b, pdf) - it.pdfs.data())];
         };
-        if (!vblat::RescoreCompactLattice(loglike, it.f->rows, &it.clat)) { it.ok = false; it.warn = "lattice/feature mismatch for utterance " + it.key; }
+        if (!vblat::RescoreCompactLattice(loglike, it.f->rows, &it.clat)) { it.ok = false; it.warn = "lattice/feature mismatch for utterance " + it.key; return; }
+        vbio::SerializeLattice(it.clat, &it.entry);
+        vblat::CompactLattice().st.swap(it.clat.st);
       });
       for (size_t i = c0; i < c1; i++) {
         Item &it = items[i];
         if (!it.warn.empty()) { log.os() << "WARNING (gmm-rescore-lattice) " << it.warn << "\n"; num_err++; continue; }
-        writer.Write(it.key, it.clat);
+        writer.WriteSerialized(it.key, it.entry);
         num_done++; num_frames += it.f->rows;
-        vblat::CompactLattice().st.swap(it.clat.st);
+        std::string().swap(it.entry);
       }
       c0 = c1;
     }

@@ -77,15 +77,17 @@ int LatticeDeterminizePruned(int argc, char *argv[], std::ofstream &file_log) {
     int n_done = 0, n_warn = 0;
     double sum_depth_in = 0.0, sum_depth_out = 0.0, sum_t = 0.0;
     // the lattices of the table are independent: read, determinized on the host's threads, written in table order
-    struct Item { std::string key; vblat::Lattice lat; vblat::CompactLattice det; bool ok = true, empty = false, unsorted = false; double depth = 0; int32_t t = 0; size_t in_states = 0; std::string err; };
+    struct Item { std::string key; const char *bytes = nullptr; size_t nbytes = 0; vblat::Lattice lat; vblat::CompactLattice det; std::string entry;
+                  bool ok = true, empty = false, unsorted = false; double depth = 0; int32_t t = 0; size_t in_states = 0; std::string err; };
     std::vector<Item> items;
-    { Item it; while (reader.NextLattice(&it.key, &it.lat)) { items.push_back(std::move(it)); it = Item(); } }
+    { Item it; while (reader.NextBytes(&it.key, &it.bytes, &it.nbytes)) { items.push_back(std::move(it)); it = Item(); } }
     {
       std::atomic<size_t> next{0};
       auto work = [&]() {
         for (size_t i = next++; i < items.size(); i = next++) {
           Item &it = items[i];
           try {
+            vbio::ParseLatticeBytes(it.bytes, it.nbytes, &it.lat);
             vblat::Invert(&it.lat);
             vblat::ScaleLattice(1.0, 0.0, 0.0, (double)acoustic_scale, &it.lat);
             it.unsorted = !vblat::TopSort(&it.lat);
@@ -98,6 +100,8 @@ int LatticeDeterminizePruned(int argc, char *argv[], std::ofstream &file_log) {
             it.in_states = it.lat.st.size();
             vblat::ScaleLattice(1.0, 0.0, 0.0, 1.0 / (double)acoustic_scale, &it.det);
             vblat::Lattice().st.swap(it.lat.st);
+            vbio::SerializeLattice(it.det, &it.entry);
+            vblat::CompactLattice().st.swap(it.det.st);
           } catch (const std::exception &e) { it.err = e.what(); if (it.err.empty()) it.err = "error"; }
         }
       };
@@ -113,7 +117,8 @@ int LatticeDeterminizePruned(int argc, char *argv[], std::ofstream &file_log) {
       if (!it.ok) { log.os() << "WARNING (lattice-determinize-pruned) For key " << it.key << ", determinization did not succeed(partial output will be pruned tighter than the specified beam.)\n"; n_warn++; }
       if (it.empty) { log.os() << "WARNING (lattice-determinize-pruned) For key " << it.key << ", determinized and trimmed lattice was empty.\n"; n_warn++; }
       sum_depth_in += (double)it.in_states; sum_depth_out += it.depth * it.t; sum_t += it.t;
-      writer.Write(it.key, it.det);
+      writer.WriteSerialized(it.key, it.entry);
+      std::string().swap(it.entry);
       n_done++;
     }
     if (sum_t != 0.0)

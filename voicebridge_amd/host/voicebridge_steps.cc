@@ -452,12 +452,14 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
       const std::string pre_trans = Join(dir, "pre_trans." + J), trans = Join(dir, "trans." + J), lat_tmp = Join(dir, "lat.tmp." + J);
       const std::string spk2utt = "--spk2utt=ark:" + Join(dsn, "spk2utt"), utt2spk = "--utt2spk=ark:" + Join(dsn, "utt2spk");
       if (stage <= 1) {      // first-pass fMLLR from the SI lattices (:314-388)
-        const std::string t_post = Join(dsn, "post.temp"), t_wsp = Join(dsn, "wsp.temp"), t_gp = Join(dsn, "gpost.temp");
+        const std::string t_post = Join(dsn, "post.temp"), t_wsp = Join(dsn, "wsp.temp");
         run("lattice-to-post", LatticeToPost, {"lattice-to-post", acw, "ark:" + Join(si_dir, "lat." + J), "ark:" + t_post}, log);
         run("weight-silence-post", WeightSilencePost, {"weight-silence-post", std::to_string(silence_weight), silphonelist, alignment_model, "ark:" + t_post, "ark:" + t_wsp}, log);
-        run("gmm-post-to-gpost", GmmPostToGpost, {"gmm-post-to-gpost", alignment_model, "ark:" + t_si, "ark:" + t_wsp, "ark:" + t_gp}, log);
-        run("gmm-est-fmllr-gpost", GmmEstFmllrGpost, {"gmm-est-fmllr-gpost", "--fmllr-update-type=" + fmllr_update_type, spk2utt, adapt_model, "ark:" + t_si, "ark:" + t_gp, "ark:" + pre_trans}, log);
-        unlink(t_post.c_str()); unlink(t_wsp.c_str()); unlink(t_gp.c_str());
+        // the reference pipes gmm-post-to-gpost (alignment model) into gmm-est-fmllr-gpost (adapt model); here the Gaussian
+        // posteriors never leave the GPU: gmm-est-fmllr takes them from --ali-model and the statistics from the adapt model
+        run("gmm-est-fmllr", GmmEstFmllr, {"gmm-est-fmllr", "--fmllr-update-type=" + fmllr_update_type, spk2utt, "--ali-model=" + alignment_model, adapt_model,
+                                           "ark:" + t_si, "ark:" + t_wsp, "ark:" + pre_trans}, log);
+        unlink(t_post.c_str()); unlink(t_wsp.c_str());
       }
       if (stage <= 2) {      // main search on the first-pass features (:390-489)
         run("transform-feats", TransformFeats, {"transform-feats", utt2spk, "ark:" + pre_trans, "ark:" + t_si, "ark:" + t_feat}, log);
