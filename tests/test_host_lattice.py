@@ -162,6 +162,43 @@ def test_errors_are_reported(host, tmp_path):
     assert call(host.vb_LatticeDeterminizePruned, ["lattice-determinize-pruned", "--acoustic-scale=0", "ark:a", "ark:b"], log) == -1
 
 
+def test_damaged_and_script_addressed_archives(host, tmp_path):
+    """the archive readers parse a mapping of the file: a truncated or corrupt entry is an error message, never a read past
+    the end; entries addressed through an .scp (key path:offset) give the same lattices as the archive itself"""
+    d = tmp_path
+    o = unpack_golden(d)
+    p = lambda n: str(d / n)
+    log = p("log.txt")
+    acwt, beam = "--acoustic-scale=%s" % o["acwt"], "--beam=%s" % o["beam"]
+    raw = open(p("raw.ark"), "rb").read()
+    assert call(host.vb_LatticeDeterminizePruned, ["lattice-determinize-pruned", acwt, beam, "ark:" + p("raw.ark"), "ark:" + p("whole.ark")], log) == 0
+    det = open(p("whole.ark"), "rb").read()
+    rng = np.random.default_rng(0)
+    for name, blob, fn, pre in (("raw", raw, host.vb_LatticeDeterminizePruned, ["lattice-determinize-pruned", acwt, beam]),
+                                ("det", det, host.vb_LatticeScale, ["lattice-scale", "--inv-acoustic-scale=9"])):
+        cuts = sorted(set([5, 9, 20, 40, 60, 90, len(blob) - 1, len(blob) - 7] + [int(x) for x in rng.integers(10, len(blob) - 1, 12)]))
+        for cut in cuts:
+            open(p("cut.ark"), "wb").write(blob[:cut])
+            rc = call(fn, pre + ["ark:" + p("cut.ark"), "ark:" + p("cut_out.ark")], log)
+            assert rc != 0 or cut < 6, "%s truncated at %d of %d accepted" % (name, cut, len(blob))      # a cut inside the first key reads as an empty table
+        # sizes that claim more than the file holds (state count, arc count, string length fields set to huge values)
+        for pos in [int(x) for x in rng.integers(40, len(blob) - 8, 40)]:
+            bad = bytearray(blob)
+            bad[pos:pos + 4] = (0x7fffff00).to_bytes(4, "little")
+            open(p("bad.ark"), "wb").write(bytes(bad))
+            call(fn, pre + ["ark:" + p("bad.ark"), "ark:" + p("bad_out.ark")], log)       # any return code; must not crash
+    # script-addressed entries: offsets of the objects right after "key "
+    offs, pos = [], 0
+    lats = util.read_lattice_ark(p("raw.ark"))
+    for key in lats:
+        at = raw.index(key.encode() + b" ", pos)
+        offs.append((key, at + len(key) + 1))
+        pos = at + len(key) + 1
+    open(p("raw.scp"), "w").write("".join("%s %s:%d\n" % (k, p("raw.ark"), off) for k, off in offs))
+    assert call(host.vb_LatticeDeterminizePruned, ["lattice-determinize-pruned", acwt, beam, "scp:" + p("raw.scp"), "ark:" + p("via_scp.ark")], log) == 0, open(log).read()
+    assert open(p("via_scp.ark"), "rb").read() == det
+
+
 @pytest.mark.skipif(not all(os.access(os.path.join(REFBIN, b), os.X_OK) for b in NEEDED), reason="oracle/_ref/bin not built")
 @pytest.mark.parametrize("seed,n_words,n_cd,frames,beam", [(11, 60, 10, (200, 31, 1), "6"), (23, 150, 16, (400, 90), "8"), (31, 25, 6, (300,), "4")])
 def test_fresh_cases_vs_reference_programs(host, tmp_path, seed, n_words, n_cd, frames, beam):

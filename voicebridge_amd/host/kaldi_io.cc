@@ -931,6 +931,8 @@ void ReadLatticeBody(In &in, vblat::Lattice *lat, vblat::CompactLattice *clat, b
       if (na < 0 || (size_t)na > in.Left() / 20) Fail("lattice: truncated");
       st.arcs.resize((size_t)na);
       if (na) in.Read(st.arcs.data(), 20 * (size_t)na);
+      for (const vblat::Arc &a : st.arcs)
+        if (a.next < 0 || a.next >= ns || a.ilabel < 0 || a.olabel < 0) Fail("lattice: arc with a label or destination state out of range");
     }
   } else if (arctype == "compactlattice44") {
     *is_compact = true;
@@ -942,6 +944,7 @@ void ReadLatticeBody(In &in, vblat::Lattice *lat, vblat::CompactLattice *clat, b
       if (n < 0 || (size_t)n > in.Left() / 4) Fail("lattice: bad string size");
       w->str.resize(n);
       if (n) in.Read(w->str.data(), 4 * (size_t)n);
+      for (int32_t t : w->str) if (t <= 0) Fail("lattice: transition-id out of range");
     };
     for (int64_t s = 0; s < ns; s++) {
       vblat::CState &st = clat->st[s];
@@ -949,9 +952,13 @@ void ReadLatticeBody(In &in, vblat::Lattice *lat, vblat::CompactLattice *clat, b
       const int64_t na = in.template Get<int64_t>();
       if (na < 0 || (size_t)na > in.Left() / 20) Fail("lattice: truncated");
       st.arcs.resize((size_t)na);
-      for (vblat::CArc &a : st.arcs) { a.label = in.template Get<int32_t>(); in.template Get<int32_t>(); get_w(&a.w); a.next = in.template Get<int32_t>(); }
+      for (vblat::CArc &a : st.arcs) {
+        a.label = in.template Get<int32_t>(); in.template Get<int32_t>(); get_w(&a.w); a.next = in.template Get<int32_t>();
+        if (a.next < 0 || a.next >= ns || a.label < 0) Fail("lattice: arc with a label or destination state out of range");
+      }
     }
   } else Fail("lattice: arc type " + arctype + " not supported");
+  if (start < -1 || start >= ns) Fail("lattice: start state out of range");
 }
 }  // namespace
 
