@@ -351,12 +351,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
+    # VBH_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share the
+    # devices round-robin, the few scalars and the end gather go through CPU tensors); the driver's runs use RCCL
+    backend = os.environ.get("VBH_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= max(torch.cuda.device_count(), 1)
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from voicebridge_amd import api
     ctx = api.Context(local_rank)
     dev = ctx.device
+    cdev = torch.device("cpu") if backend == "gloo" else dev        # where the tensors of the collectives live
 
     waves, utt2spk, n_spk, xforms = build_workload(args, rank)
     mf = api.Mfcc(ctx)
@@ -602,10 +611,10 @@ def main():
               [round(float(b[:, 0].min() - t_lo) / 1e5) for b in allb], [round(float(b[:, 1].max() - t_lo) / 1e5) for b in allb]),
               file=sys.stderr, flush=True)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        fr = torch.tensor([T * args.steps], dtype=torch.float64, device=dev)
+        fr = torch.tensor([T * args.steps], dtype=torch.float64, device=cdev)
         dist.all_reduce(fr, op=dist.ReduceOp.SUM)
         total_frames = float(fr.item())
     else:
@@ -618,7 +627,7 @@ def main():
         hyps = [dec.result(u, arrays=False)["words"] for u in range(args.batch)]
         ids = [rank * args.batch + u for u in range(args.batch)]
         counters = vdist.score(hyps, hyps)          # synthetic audio has no transcripts: self-scored
-        totals, merged = vdist.gather_results(ids, hyps, counters, device=dev)
+        totals, merged = vdist.gather_results(ids, hyps, counters, device=cdev)
         if rank == 0:
             gathered = {"utterances": len(merged), "counters": dict(zip(vdist.COUNTER_NAMES, totals.tolist()))}
 
