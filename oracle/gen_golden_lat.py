@@ -119,6 +119,25 @@ def main_fmllr():
         print("fmllr.npz %.1f KB" % (os.path.getsize(out) / 1024.0))
 
 
+def main_fmllr_types():
+    """tests/golden/fmllr_types.npz: the reference's gmm-est-fmllr with --fmllr-update-type=diag / offset / none on the inputs
+    of fmllr.npz (model, features, silence-weighted posteriors, spk2utt)"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "fmllr.npz"))
+    with tempfile.TemporaryDirectory(prefix="vbgold_fmllr_") as d:
+        p = lambda n: os.path.join(d, n)
+        for k, fn in (("file_final_mdl", "final.mdl"), ("file_feats_ark", "feats.ark"), ("file_wsp_ark", "wsp.ark")):
+            g[k].tofile(p(fn))
+        open(p("spk2utt"), "w").write(str(g["text_spk2utt"]))
+        arrays = {}
+        for t in ("diag", "offset", "none"):
+            ref("gmm-est-fmllr", "--fmllr-min-count=50", "--fmllr-update-type=" + t, "--spk2utt=ark:" + p("spk2utt"), p("final.mdl"),
+                "ark:" + p("feats.ark"), "ark:" + p("wsp.ark"), "ark:" + p("trans_%s.ark" % t))
+            arrays["file_trans_%s_ark" % t] = np.fromfile(p("trans_%s.ark" % t), dtype=np.uint8)
+        out = os.path.join(ROOT, "tests", "golden", "fmllr_types.npz")
+        np.savez_compressed(out, **arrays)
+        print("fmllr_types.npz %.1f KB" % (os.path.getsize(out) / 1024.0))
+
+
 def main():
     with tempfile.TemporaryDirectory(prefix="vbgold_lat_") as d:
         make_case(d)
@@ -137,5 +156,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
-    main_fmllr()
+    import sys
+    if sys.argv[1:] == ["fmllr_types"]:
+        main_fmllr_types()
+    else:
+        main()
+        main_fmllr()
+        main_fmllr_types()

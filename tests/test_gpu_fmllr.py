@@ -160,6 +160,36 @@ def test_gmm_est_fmllr_ali_model_vs_gpost_pair(tmp_path):
     assert "--ali-model" in open(log).read()
 
 
+@pytest.mark.parametrize("update_type", ["diag", "offset", "none"])
+def test_gmm_est_fmllr_update_types_vs_golden(tmp_path, update_type):
+    """--fmllr-update-type=diag | offset | none (FmllrDiagGmmAccs::Update, K/transform/fmllr-diag-gmm.cc:131-167,275-379) against
+    the transforms of the reference's gmm-est-fmllr on the golden case (tests/golden/fmllr_types.npz, oracle/gen_golden_lat.py
+    main_fmllr_types)"""
+    from tests.test_host_io import read_fm_ark
+    from tests.test_host_lattice import call
+    from voicebridge_amd import build
+    host = C.CDLL(build.HOST_LIB)
+    d = tmp_path
+    g, gt = util.load("fmllr"), util.load("fmllr_types")
+    for k in ("file_final_mdl", "file_feats_ark", "file_wsp_ark"):
+        name = k[5:].rsplit("_", 1)
+        (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
+    (d / "want.ark").write_bytes(gt["file_trans_%s_ark" % update_type].tobytes())
+    (d / "spk2utt").write_text(str(g["text_spk2utt"]))
+    log = str(d / "log.txt")
+    assert call(host.vb_GmmEstFmllr, ["gmm-est-fmllr", "--fmllr-min-count=50", "--fmllr-update-type=" + update_type, "--spk2utt=ark:%s" % (d / "spk2utt"),
+                                      str(d / "final.mdl"), "ark:%s" % (d / "feats.ark"), "ark:%s" % (d / "wsp.ark"), "ark:%s" % (d / "m.ark")], log) == 0, open(log).read()
+    mine, want = read_fm_ark(str(d / "m.ark")), read_fm_ark(str(d / "want.ark"))
+    assert list(mine) == list(want) == ["spk1", "spk2"]
+    for k in want:
+        np.testing.assert_allclose(mine[k], want[k], atol=2e-4, rtol=0)
+        if update_type != "none":
+            assert np.abs(want[k] - np.eye(39, 40)).max() > 0.05
+    assert call(host.vb_GmmEstFmllr, ["gmm-est-fmllr", "--fmllr-update-type=banana", str(d / "final.mdl"), "ark:%s" % (d / "feats.ark"), "ark:%s" % (d / "wsp.ark"),
+                                      "ark:%s" % (d / "x.ark")], log) != 0
+    assert "fmllr-update-type must be one of" in open(log).read()
+
+
 def test_fmllr_update_properties(tmp_path):
     """properties of the estimate that do not depend on a reference run: below --fmllr-min-count the
     unit transform is written; the update raises the auxiliary function (logged improvement > 0)"""
@@ -183,7 +213,7 @@ def test_fmllr_update_properties(tmp_path):
     assert call(host.vb_GmmEstFmllr, base[:1] + ["--fmllr-min-count=50"] + base[1:] + ["ark:%s" % (d / "t.ark")], log) == 0
     imprs = [float(l.split("auxf-impr from fMLLR is")[1].split(",")[0]) for l in open(log) if "auxf-impr" in l]
     assert len(imprs) == 2 and all(x > 0 for x in imprs)
-    assert call(host.vb_GmmEstFmllr, base[:1] + ["--fmllr-update-type=diag"] + base[1:] + ["ark:%s" % (d / "x.ark")], log) == -1    # refused, not ignored
+    assert call(host.vb_GmmEstFmllr, base[:1] + ["--fmllr-update-type=banana"] + base[1:] + ["ark:%s" % (d / "x.ark")], log) == -1    # refused, not ignored
 
 
 def test_rescore_and_lattice_to_compact_conversion_vs_golden(tmp_path):

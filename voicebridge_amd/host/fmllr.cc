@@ -139,9 +139,50 @@ float FmllrAccs::AccumulateForGmm(const PdfView &pdf, const float *x, float weig
 float FmllrAccs::Update(const FmllrOptions &opts, float *xform, float *count) {
   Commit();
   if (count) *count = (float)beta_;
-  if (opts.update_type != "full") throw std::runtime_error("fMLLR update type " + opts.update_type + " is not supported (only \"full\")");
+  if (opts.update_type != "full" && opts.update_type != "diag" && opts.update_type != "offset" && opts.update_type != "none")
+    throw std::runtime_error("Unknown fMLLR update type " + opts.update_type + ", fmllr-update-type must be one of \"full\"|\"diag\"|\"offset\"|\"none\"");
   if (!(beta_ > opts.min_count)) return 0.0f;        // "Not updating fMLLR since below min-count"
   const int dim = dim_, n1 = dim + 1;
+  if (opts.update_type == "none") return 0.0f;
+  if (opts.update_type != "full") {
+    // ComputeFmllrMatrixDiagGmmDiagonal (fmllr-diag-gmm.cc:275-348) / ...Offset (:350-379): closed forms per row from K(i,i), K(i,dim) and
+    // G_i(i,i), G_i(dim,i), G_i(dim,dim).  The reference accumulates only those elements of G for these update types, with the product
+    // b_i x_i x_i rounded to float per frame (:583-590); here they are read out of the full statistics (double products): same values to
+    // ~1e-7 relative.
+    for (int r = 0; r < dim; r++) for (int c = 0; c < dim; c++)
+      if (r != c && xform[(size_t)r * n1 + c] != 0.0f) throw std::runtime_error("fMLLR " + opts.update_type + " update: the initial transform must be diagonal");
+    auto g = [&](int i, int r, int c) { return G_[i][(size_t)r * n1 + c]; };      // lower triangle: r >= c
+    if (opts.update_type == "offset") {
+      for (int i = 0; i < dim; i++) if (xform[(size_t)i * n1 + i] != 1.0f) throw std::runtime_error("fMLLR offset update: the initial transform must be the unit transform");
+      float impr = 0.0f;
+      for (int i = 0; i < dim; i++) {
+        const double gdd = g(i, dim, dim), gid = g(i, dim, i), kid = K_[(size_t)i * n1 + dim];
+        float b = xform[(size_t)i * n1 + dim];
+        const float before = (float)(-0.5 * b * b * gdd - b * gid + b * kid);
+        b = (float)((kid - gid) / gdd);
+        xform[(size_t)i * n1 + dim] = b;
+        const float after = (float)(-0.5 * b * b * gdd - b * gid + b * kid);
+        impr += after - before;
+      }
+      return impr;
+    }
+    std::vector<std::vector<double>> G = G_;
+    for (int d = 0; d < dim; d++) for (int i = 0; i < n1; i++) for (int j = i + 1; j < n1; j++) G[d][(size_t)i * n1 + j] = G[d][(size_t)j * n1 + i];
+    std::vector<double> W((size_t)dim * n1);
+    for (size_t i = 0; i < W.size(); i++) W[i] = xform[i];
+    const float old_objf = (float)AuxFunc(W, dim, beta_, K_, G);
+    for (int i = 0; i < dim; i++) {
+      const double kii = K_[(size_t)i * n1 + i], kid = K_[(size_t)i * n1 + dim], giii = g(i, i, i), gidd = g(i, dim, dim), gidi = g(i, dim, i);
+      const double a = gidi * gidi / gidd - giii, b = kii - gidi * kid / gidd, c = beta_;
+      const double sc = (-b - std::sqrt(b * b - 4 * a * c)) / (2 * a);
+      if (!(sc > 0.0)) throw std::runtime_error("fMLLR diag update: non-positive scale");
+      const double o = (kid - sc * gidi) / gidd;
+      xform[(size_t)i * n1 + i] = (float)sc;
+      xform[(size_t)i * n1 + dim] = (float)o;
+    }
+    for (size_t i = 0; i < W.size(); i++) W[i] = xform[i];        // the reference evaluates the float matrix it stored
+    return (float)AuxFunc(W, dim, beta_, K_, G) - old_objf;
+  }
   // the symmetric halves of G were accumulated in the lower triangle only
   std::vector<std::vector<double>> G = G_, invG(dim);
   for (int d = 0; d < dim; d++) {

@@ -226,7 +226,6 @@ template <class AddUtt>
 static int EstimateOnGpu(const char *prog, bool use_gpost, const Options &po, const Gmm &gmm, const Gmm *ali_gmm, const std::string &feat_rspec,
                          const std::string &trans_wspec, Log &log, AddUtt add_utt) {
   const vbfmllr::FmllrOptions opts = ReadFmllrOptions(po);
-  if (opts.update_type != "full") throw ApiError("--fmllr-update-type=" + opts.update_type + " is not supported (only full)");
   const int D = gmm.m.dim, n1 = D + 1;
   // ---- the units a transform is estimated for (speakers, or utterances without --spk2utt) and their utterances
   std::vector<std::pair<std::string, std::vector<std::string>>> units;
