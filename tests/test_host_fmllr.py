@@ -113,3 +113,74 @@ def test_fresh_case_vs_reference_programs(host, tmp_path):
     gg.run_fmllr_chain(str(d), gg.ref, "r_")
     gg.run_fmllr_chain(str(d), mine_runner(host, d), "m_", trans_tmp_from="r_")
     compare_chain(d, "m_", "r_")
+
+
+def _np_fmllr_full(beta, K, G, iters=40):
+    """ComputeFmllrMatrixDiagGmmFull (K/transform/fmllr-diag-gmm.cc:236-273) with FmllrInnerUpdate (:195-231), double,
+    the cofactor row from a fresh inverse of A^T for every row of every iteration -- as the reference does it"""
+    D = K.shape[0]
+    W = np.eye(D, D + 1)
+    invG = [np.linalg.inv(G[d]) for d in range(D)]
+
+    def auxf(W):
+        return beta * np.log(abs(np.linalg.det(W[:, :D]))) + (W * K).sum() - 0.5 * sum(W[d] @ G[d] @ W[d] for d in range(D))
+    old = auxf(W)
+    for _ in range(iters):
+        for d in range(D):
+            cof = np.linalg.inv(W[:, :D].T)
+            row = np.concatenate([cof[d], [0.0]])
+            rig = invG[d] @ row
+            e1, e2 = rig @ row, rig @ K[d]
+            disc = np.sqrt(e2 * e2 + 4 * e1 * beta)
+            a1, a2 = (-e2 + disc) / (2 * e1), (-e2 - disc) / (2 * e1)
+            f1 = beta * np.log(abs(a1 * e1 + e2)) - 0.5 * a1 * a1 * e1
+            f2 = beta * np.log(abs(a2 * e1 + e2)) - 0.5 * a2 * a2 * e1
+            alpha = a1 if f1 > f2 else a2
+            W[d] = invG[d] @ (row * alpha + K[d])
+    return W, auxf(W) - old
+
+
+@pytest.mark.parametrize("D,T,seed", [(39, 4000, 0), (13, 900, 1), (40, 6000, 2), (5, 300, 3)])
+def test_fmllr_update_from_statistics(host, D, T, seed):
+    """the row-by-row update (inverse(A) carried along by rank-one updates) against the restatement above that inverts for
+    every row, on statistics of synthetic frames; and the closed forms of the diag / offset types against their formulas"""
+    rng = np.random.default_rng(seed)
+    A0 = np.eye(D) + 0.25 * rng.standard_normal((D, D))
+    x = rng.standard_normal((T, D)) @ A0.T + rng.standard_normal(D)                # frames that want a real transform
+    xp = np.concatenate([x, np.ones((T, 1))], 1)
+    iv = np.exp(0.3 * rng.standard_normal((T, D)))                                  # b_t: posterior-weighted inverse variances
+    mu = 0.5 * rng.standard_normal((T, D))
+    a = mu * iv                                                                     # a_t: posterior-weighted means * inverse variances
+    beta = float(T)
+    K = a.T @ xp
+    G = np.einsum("td,ti,tj->dij", iv, xp, xp)
+    want, want_impr = _np_fmllr_full(beta, K, G)
+    host.vb_fmllr_update.argtypes = [C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_char_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+    host.vb_fmllr_update.restype = C.c_int
+
+    def update(kind, iters=40, min_count=50.0):
+        xf = np.eye(D, D + 1, dtype=np.float32)
+        impr = np.zeros(1, np.float32)
+        Kc, Gc = np.ascontiguousarray(K), np.ascontiguousarray(G)
+        assert host.vb_fmllr_update(D, beta, Kc.ctypes.data, Gc.ctypes.data, kind.encode(), min_count, iters, xf.ctypes.data, impr.ctypes.data) == 0
+        return xf, float(impr[0])
+    got, impr = update("full")
+    np.testing.assert_allclose(got, want, atol=2e-6 * max(1.0, np.abs(want).max()), rtol=1e-5)
+    assert impr > 0 and abs(impr - want_impr) <= 1e-4 * abs(want_impr) + 1e-2
+    # below the count: the unit transform stays
+    same, z = update("full", min_count=2.0 * T)
+    assert z == 0.0 and np.array_equal(same, np.eye(D, D + 1, dtype=np.float32))
+    # diag: s from a s^2 + b s + beta = 0 (the negative root), o = (k_id - s g_idi) / g_idd   (fmllr-diag-gmm.cc:331-343)
+    got, impr = update("diag")
+    for i in range(D):
+        aa = G[i][D, i] ** 2 / G[i][D, D] - G[i][i, i]
+        bb = K[i, i] - G[i][D, i] * K[i, D] / G[i][D, D]
+        s_ = (-bb - np.sqrt(bb * bb - 4 * aa * beta)) / (2 * aa)
+        assert abs(got[i, i] - s_) < 1e-5 * max(1, abs(s_)) and abs(got[i, D] - (K[i, D] - s_ * G[i][D, i]) / G[i][D, D]) < 1e-5
+    assert impr > 0 and np.count_nonzero(got[:, :D] - np.diag(np.diag(got[:, :D]))) == 0
+    # offset: b_i = (K(i,dim) - G_i(i,dim)) / G_i(dim,dim)   (:359-376)
+    got, impr = update("offset")
+    np.testing.assert_allclose(got[:, D], [(K[i, D] - G[i][i, D]) / G[i][D, D] for i in range(D)], rtol=1e-5, atol=1e-6)
+    assert impr > 0 and np.array_equal(got[:, :D], np.eye(D, dtype=np.float32))
+    got, impr = update("none")
+    assert impr == 0.0 and np.array_equal(got, np.eye(D, D + 1, dtype=np.float32))

@@ -193,12 +193,17 @@ float FmllrAccs::Update(const FmllrOptions &opts, float *xform, float *count) {
   std::vector<double> oldW((size_t)dim * n1), W((size_t)dim * n1);
   for (size_t i = 0; i < W.size(); i++) oldW[i] = W[i] = xform[i];
   const float old_objf = (float)AuxFunc(oldW, dim, beta_, K_, G);
-  std::vector<double> cof((size_t)dim * dim), row(n1), row_invg(n1);
+  // FmllrInnerUpdate (fmllr-diag-gmm.cc:195-231) takes row d of inverse(A^T) -- column d of inverse(A) -- for every row of every
+  // iteration, i.e. 40 x 39 inversions of a 39 x 39 matrix per transform in the reference.  Replacing row d of A is a rank-one
+  // change, so inverse(A) is carried along by the Sherman-Morrison formula (O(dim^2) per row) and recomputed from scratch once
+  // per iteration, which bounds the drift to 39 updates in double; same transforms (tests/test_host_fmllr.py compares with a
+  // restatement that inverts every time).
+  std::vector<double> M((size_t)dim * dim), row(n1), row_invg(n1), u(dim), v(dim), delta(dim);
   for (int iter = 0; iter < opts.num_iters; iter++) {
-    for (int d = 0; d < dim; d++) {        // FmllrInnerUpdate (fmllr-diag-gmm.cc:195-231)
-      for (int r = 0; r < dim; r++) for (int c = 0; c < dim; c++) cof[(size_t)r * dim + c] = W[(size_t)c * n1 + r];    // transpose of A
-      InvertGeneral(cof, dim);
-      for (int c = 0; c < dim; c++) row[c] = cof[(size_t)d * dim + c];
+    for (int r = 0; r < dim; r++) for (int c = 0; c < dim; c++) M[(size_t)r * dim + c] = W[(size_t)r * n1 + c];
+    InvertGeneral(M, dim);
+    for (int d = 0; d < dim; d++) {
+      for (int c = 0; c < dim; c++) row[c] = M[(size_t)c * dim + d];
       row[dim] = 0.0;
       const std::vector<double> &ig = invG[d];
       for (int i = 0; i < n1; i++) { double s = 0.0; for (int j = 0; j < n1; j++) s += ig[(size_t)i * n1 + j] * row[j]; row_invg[i] = s; }
@@ -211,7 +216,18 @@ float FmllrAccs::Update(const FmllrOptions &opts, float *xform, float *count) {
       const double auxf2 = beta_ * std::log(std::fabs(alpha2 * e1 + e2)) - 0.5 * alpha2 * alpha2 * e1;
       const double alpha = auxf1 > auxf2 ? alpha1 : alpha2;
       for (int i = 0; i < n1; i++) row[i] = row[i] * alpha + k[i];
-      for (int i = 0; i < n1; i++) { double s = 0.0; for (int j = 0; j < n1; j++) s += ig[(size_t)i * n1 + j] * row[j]; W[(size_t)d * n1 + i] = s; }
+      for (int i = 0; i < n1; i++) {
+        double s = 0.0;
+        for (int j = 0; j < n1; j++) s += ig[(size_t)i * n1 + j] * row[j];
+        if (i < dim) delta[i] = s - W[(size_t)d * n1 + i];
+        W[(size_t)d * n1 + i] = s;
+      }
+      // A' = A + e_d delta^T  ->  inverse(A') = M - (M e_d)(delta^T M) / (1 + delta^T M e_d)
+      double denom = 1.0;
+      for (int r = 0; r < dim; r++) { u[r] = M[(size_t)r * dim + d]; denom += delta[r] * u[r]; }
+      if (denom == 0.0 || !std::isfinite(denom)) throw std::runtime_error("fMLLR: singular matrix");
+      for (int c = 0; c < dim; c++) { double sv = 0.0; for (int r = 0; r < dim; r++) sv += delta[r] * M[(size_t)r * dim + c]; v[c] = sv / denom; }
+      for (int r = 0; r < dim; r++) { const double ur = u[r]; double *mr = &M[(size_t)r * dim]; for (int c = 0; c < dim; c++) mr[c] -= ur * v[c]; }
     }
   }
   const float new_objf = (float)AuxFunc(W, dim, beta_, K_, G);

@@ -2,6 +2,7 @@
 #include <cstring>
 #include <string>
 
+#include "fmllr.h"
 #include "kaldi_io.h"
 
 namespace {
@@ -65,6 +66,21 @@ int vbio_fst_get(float *final_cost, long long *arc_offset, void *arcs16) {
   for (size_t i = 0; i < g_graph.arc_offset.size(); i++) arc_offset[i] = g_graph.arc_offset[i];
   memcpy(arcs16, g_graph.arcs.data(), 16 * g_graph.arcs.size());
   return 0;
+}
+
+
+// FmllrDiagGmmAccs::Update from given statistics (K [dim][dim+1], G [dim][dim+1][dim+1] full symmetric): the estimate without the
+// accumulation, for tests that bring their own statistics.  xform holds the starting value on entry.
+int vb_fmllr_update(int dim, double beta, const double *K, const double *G, const char *update_type, float min_count, int num_iters,
+                    float *xform, float *impr) {
+  return Try([&] {
+    vbfmllr::FmllrAccs accs(dim);
+    accs.AddStats(beta, K, G);
+    vbfmllr::FmllrOptions o;
+    o.update_type = update_type; o.min_count = min_count; o.num_iters = num_iters;
+    float count = 0.0f;
+    *impr = accs.Update(o, xform, &count);
+  });
 }
 
 }  // extern "C"

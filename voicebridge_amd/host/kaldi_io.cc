@@ -1098,14 +1098,24 @@ std::ofstream OpenArkForWriting(const std::string &wspecifier) {
   return f;
 }
 
-void WritePosteriorEntry(std::ostream &os, const std::string &key, const Posterior &post) {
-  os << key << ' ';
-  os.put('\0'); os.put('B');
-  WriteInt32(os, true, (int32_t)post.size());
+// One buffer per entry, one stream call (a job's table has a few million 5-byte fields)
+void SerializePosterior(const Posterior &post, std::string *b) {
+  size_t n = 0;
+  for (const auto &fr : post) n += fr.size();
+  b->reserve(b->size() + 7 + 5 * post.size() + 10 * n);
+  auto put_i32 = [&](int32_t v) { b->push_back(4); b->append(reinterpret_cast<const char *>(&v), 4); };
+  b->push_back('\0'); b->push_back('B');
+  put_i32((int32_t)post.size());
   for (const auto &fr : post) {
-    WriteInt32(os, true, (int32_t)fr.size());
-    for (const auto &pr : fr) { WriteInt32(os, true, pr.first); WriteFloat(os, true, pr.second); }
+    put_i32((int32_t)fr.size());
+    for (const auto &pr : fr) { put_i32(pr.first); b->push_back(4); b->append(reinterpret_cast<const char *>(&pr.second), 4); }
   }
+}
+void WritePosteriorEntry(std::ostream &os, const std::string &key, const Posterior &post) {
+  std::string b;
+  SerializePosterior(post, &b);
+  os << key << ' ';
+  os.write(b.data(), (std::streamsize)b.size());
 }
 
 void WriteGaussPostEntry(std::ostream &os, const std::string &key, const GaussPost &gpost) {
@@ -1126,21 +1136,43 @@ void WriteGaussPostEntry(std::ostream &os, const std::string &key, const GaussPo
 std::vector<std::pair<std::string, Posterior>> ReadPosteriorTable(const std::string &rspecifier) {
   const Rspec spec = ParseRspecifier(rspecifier);
   if (spec.is_scp) Fail("scp: is not supported for posterior tables");
-  std::ifstream is(spec.path, std::ios::binary);
-  if (!is) Fail("cannot open " + spec.path);
+  std::string buf;
+  {
+    std::ifstream is(spec.path, std::ios::binary | std::ios::ate);
+    if (!is) Fail("cannot open " + spec.path);
+    const std::streamoff n = is.tellg();
+    is.seekg(0);
+    buf.resize((size_t)std::max<std::streamoff>(n, 0));
+    if (n > 0) is.read(&buf[0], n);
+    if (is.fail()) Fail("read failure on " + spec.path);
+  }
+  const char *p = buf.data(), *end = p + buf.size();
+  auto need = [&](size_t n) { if ((size_t)(end - p) < n) Fail("posterior: truncated table " + spec.path); };
+  auto get_i32 = [&]() { need(5); if (*p != 4) Fail("posterior: expected a 4-byte integer in " + spec.path); int32_t v; memcpy(&v, p + 1, 4); p += 5; return v; };
   std::vector<std::pair<std::string, Posterior>> out;
   for (;;) {
-    const std::string key = ReadArkKey(is);
-    if (key.empty()) break;
-    if (!ReadBinaryHeader(is)) Fail("text-mode posteriors are not supported: " + spec.path);
-    const int32_t sz = ReadInt32(is, true);
-    if (sz < 0 || sz > 10000000) Fail("posterior: bad size");
+    while (p < end && isspace((unsigned char)*p)) p++;
+    if (p == end) break;
+    const char *k = p;
+    while (p < end && !isspace((unsigned char)*p)) p++;
+    const std::string key(k, p);
+    need(3);
+    p++;
+    if (p[0] != '\0' || p[1] != 'B') Fail("text-mode posteriors are not supported: " + spec.path);
+    p += 2;
+    const int32_t sz = get_i32();
+    if (sz < 0 || (size_t)sz > (size_t)(end - p) / 5) Fail("posterior: bad size");
     Posterior post(sz);
     for (auto &fr : post) {
-      const int32_t n = ReadInt32(is, true);
-      if (n < 0 || n > 1000000) Fail("posterior: bad size");
+      const int32_t n = get_i32();
+      if (n < 0 || (size_t)n > (size_t)(end - p) / 10) Fail("posterior: bad size");
       fr.resize(n);
-      for (auto &pr : fr) { pr.first = ReadInt32(is, true); pr.second = ReadFloat(is, true); }
+      for (auto &pr : fr) {
+        need(10);
+        if (p[0] != 4 || p[5] != 4) Fail("posterior: bad field size in " + spec.path);
+        memcpy(&pr.first, p + 1, 4); memcpy(&pr.second, p + 6, 4);
+        p += 10;
+      }
     }
     out.emplace_back(key, std::move(post));
   }

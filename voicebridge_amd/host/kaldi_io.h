@@ -218,6 +218,7 @@ void ParseLatticeBytes(const char *p, size_t n, vblat::Lattice *lat);     // a c
 typedef vblat::Posterior Posterior;
 typedef std::vector<std::vector<std::pair<int32_t, std::vector<float>>>> GaussPost;    // per frame: (pdf-id, per-Gaussian posteriors)
 void WritePosteriorEntry(std::ostream &os, const std::string &key, const Posterior &post);
+void SerializePosterior(const Posterior &post, std::string *b);      // the entry's bytes after "key "
 void WriteGaussPostEntry(std::ostream &os, const std::string &key, const GaussPost &gpost);
 std::vector<std::pair<std::string, Posterior>> ReadPosteriorTable(const std::string &rspecifier);
 std::vector<std::pair<std::string, GaussPost>> ReadGaussPostTable(const std::string &rspecifier);

@@ -108,15 +108,40 @@ int LatticeToPost(int argc, char *argv[], std::ofstream &file_log) {
     std::ofstream out = vbio::OpenArkForWriting(po.args[1]);
     int n_done = 0;
     double total_like = 0.0, total_ac = 0.0, total_time = 0.0;
-    std::string key; vblat::Lattice lat;
-    while (reader.NextLattice(&key, &lat)) {
-      if (acoustic_scale != 1.0f || lm_scale != 1.0f) vblat::ScaleLattice((double)lm_scale, 0.0, 0.0, (double)acoustic_scale, &lat);
-      if (!vblat::IsTopSorted(lat) && !vblat::TopSort(&lat)) throw ApiError("Cycles detected in lattice.");
-      vblat::Posterior post;
-      double ac = 0.0;
-      total_like += vblat::LatticeForwardBackward(lat, &post, &ac);
-      total_time += (double)post.size(); total_ac += ac;
-      vbio::WritePosteriorEntry(out, key, post);
+    // the lattices of the table are independent: parsed, scaled, forward-backward and the entry's bytes on the host's threads;
+    // written (and the totals added up) in table order
+    struct Item { std::string key; const char *bytes = nullptr; size_t nbytes = 0; std::string entry, err; double like = 0, ac = 0; size_t frames = 0; };
+    std::vector<Item> items;
+    { Item it; while (reader.NextBytes(&it.key, &it.bytes, &it.nbytes)) { items.push_back(std::move(it)); it = Item(); } }
+    {
+      std::atomic<size_t> next{0};
+      auto work = [&]() {
+        for (size_t i = next++; i < items.size(); i = next++) {
+          Item &it = items[i];
+          try {
+            vblat::Lattice lat;
+            vbio::ParseLatticeBytes(it.bytes, it.nbytes, &lat);
+            if (acoustic_scale != 1.0f || lm_scale != 1.0f) vblat::ScaleLattice((double)lm_scale, 0.0, 0.0, (double)acoustic_scale, &lat);
+            if (!vblat::IsTopSorted(lat) && !vblat::TopSort(&lat)) throw ApiError("Cycles detected in lattice.");
+            vblat::Posterior post;
+            it.like = vblat::LatticeForwardBackward(lat, &post, &it.ac);
+            it.frames = post.size();
+            vbio::SerializePosterior(post, &it.entry);
+          } catch (const std::exception &e) { it.err = e.what(); if (it.err.empty()) it.err = "error"; }
+        }
+      };
+      const unsigned nt = std::max(1u, std::min<unsigned>(16, std::min<unsigned>((unsigned)items.size(), std::thread::hardware_concurrency())));
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+      work();
+      for (std::thread &t : pool) t.join();
+    }
+    for (Item &it : items) {
+      if (!it.err.empty()) throw ApiError(it.err);
+      total_like += it.like; total_time += (double)it.frames; total_ac += it.ac;
+      out << it.key << ' ';
+      out.write(it.entry.data(), (std::streamsize)it.entry.size());
+      std::string().swap(it.entry);
       n_done++;
     }
     if (out.fail()) throw ApiError("write failure on " + po.args[1]);
