@@ -1064,11 +1064,44 @@ int vb_determinize_decoder_results(void *decoder, int n_utt, int graph_start, in
 // until the decoder's next call) and queues one job per utterance; wait() blocks until the queue is empty and
 // returns the totals since the last wait {seconds of worker time, input states, input arcs, output states,
 // output arcs, stopped before the beam}.
+// what RawLatticeFromResult reads of a search result, copied out of the decoder's buffers (which its next batch reuses): flat
+// arrays, one allocation per utterance -- the state-level lattice with its vector per state is built by the worker that
+// determinizes it, off the caller's critical path
+struct RawSnap {
+  std::vector<int32_t> i32;     // tok_frame prefix (frame 0, then a sentinel) | tok_state prefix | link src, dst, ilabel, olabel
+  std::vector<float> f32;       // tok_final | link graph, acoustic
+  int32_t n = 0, nl = 0, k0 = 0;
+  void Take(const vbh_lattice &L) {
+    n = L.num_toks; nl = L.num_links; k0 = 0;
+    while (k0 < n && L.tok_frame[k0] == 0) k0++;
+    i32.resize((size_t)2 * (k0 + 1) + (size_t)4 * nl);
+    f32.resize((size_t)n + (size_t)2 * nl);
+    int32_t *pi = i32.data();
+    memcpy(pi, L.tok_frame, sizeof(int32_t) * k0); pi[k0] = 1; pi += k0 + 1;
+    memcpy(pi, L.tok_state, sizeof(int32_t) * k0); pi[k0] = -1; pi += k0 + 1;
+    for (const int32_t *src : {L.link_src, L.link_dst, L.link_ilabel, L.link_olabel}) { memcpy(pi, src, sizeof(int32_t) * nl); pi += nl; }
+    float *pf = f32.data();
+    memcpy(pf, L.tok_final, sizeof(float) * n); pf += n;
+    memcpy(pf, L.link_graph, sizeof(float) * nl); pf += nl;
+    memcpy(pf, L.link_acoustic, sizeof(float) * nl);
+  }
+  vbh_lattice View() const {
+    vbh_lattice L{};
+    L.ok = 1; L.num_toks = n; L.num_links = nl;
+    const int32_t *pi = i32.data();
+    L.tok_frame = pi; pi += k0 + 1;
+    L.tok_state = pi; pi += k0 + 1;
+    L.link_src = pi; L.link_dst = pi + nl; L.link_ilabel = pi + 2 * (size_t)nl; L.link_olabel = pi + 3 * (size_t)nl;
+    const float *pf = f32.data();
+    L.tok_final = pf; L.link_graph = pf + n; L.link_acoustic = pf + n + nl;
+    return L;
+  }
+};
 struct VbDetPool {
   std::vector<std::thread> workers;
   std::mutex mu;
   std::condition_variable cv, cv_done;
-  std::deque<vblat::Lattice> q;
+  std::deque<std::pair<RawSnap, int>> q;       // (result, the graph's start state)
   size_t in_flight = 0;
   bool stop = false;
   vblat::TransInfo tm;
@@ -1088,18 +1121,21 @@ void *vb_det_pool_create(int threads, int num_tids, const int32_t *tid_phone, co
   for (int t = 0; t < std::max(threads, 1); t++)
     p->workers.emplace_back([p]() {
       for (;;) {
-        vblat::Lattice lat;
+        std::pair<RawSnap, int> job;
         {
           std::unique_lock<std::mutex> lk(p->mu);
           p->cv.wait(lk, [p] { return p->stop || !p->q.empty(); });
           if (p->q.empty()) return;
-          lat = std::move(p->q.front());
+          job = std::move(p->q.front());
           p->q.pop_front();
         }
         const auto t0 = std::chrono::steady_clock::now();
         double is = 0, ia = 0, os = 0, oa = 0, early = 0;
         std::string err;
         try {
+          vblat::Lattice lat;
+          RawLatticeFromResult(job.first.View(), job.second, &lat);
+          RawSnap().i32.swap(job.first.i32); RawSnap().f32.swap(job.first.f32);
           vblat::CompactLattice clat;
           vblat::Connect(&lat);
           is = (double)lat.st.size(); ia = (double)lat.NumArcs();
@@ -1123,16 +1159,16 @@ int vb_det_pool_submit(void *pool, void *decoder, int n_utt, int graph_start) {
     // result buffers are reused by its next batch)
     std::vector<vbh_lattice> Ls(n_utt);
     for (int u = 0; u < n_utt; u++) Check(vbh_decoder_result((vbh_decoder *)decoder, u, &Ls[u]), "vbh_decoder_result");
-    std::vector<vblat::Lattice> lats(n_utt);
+    std::vector<RawSnap> lats(n_utt);
     std::atomic<int> next{0};
-    auto work = [&]() { for (int u = next++; u < n_utt; u = next++) if (Ls[u].ok) RawLatticeFromResult(Ls[u], graph_start, &lats[u]); };
+    auto work = [&]() { for (int u = next++; u < n_utt; u = next++) if (Ls[u].ok) lats[u].Take(Ls[u]); };
     std::vector<std::thread> helpers;
     const int nh = std::min<int>(8, std::max<int>(1, (int)p->workers.size()));
     for (int t = 1; t < nh; t++) helpers.emplace_back(work);
     work();
     for (std::thread &t : helpers) t.join();
     std::lock_guard<std::mutex> lk(p->mu);
-    for (int u = 0; u < n_utt; u++) if (Ls[u].ok) { p->q.push_back(std::move(lats[u])); p->in_flight++; }
+    for (int u = 0; u < n_utt; u++) if (Ls[u].ok) { p->q.emplace_back(std::move(lats[u]), graph_start); p->in_flight++; }
     p->cv.notify_all();
     return 0;
   } catch (const std::exception &e) { fprintf(stderr, "ERROR (vb_det_pool_submit) %s\n", e.what()); return -1; }
