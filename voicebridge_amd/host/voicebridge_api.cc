@@ -135,7 +135,20 @@ struct LatgenCache {
   vbh_decoder *dec = nullptr;
   vbh_decode_cfg dec_cfg{};
   int dec_batch = 0, dec_T = 0;
+  void *d_ll = nullptr;            // the batch's scores [frames x pdfs]: gigabytes per job, kept (grow-only) like the search workspace
+  size_t d_ll_bytes = 0;
+  void *Scores(vbh_ctx *c, size_t bytes) {
+    if (bytes > d_ll_bytes) {
+      if (d_ll) vbh_dev_free(c, d_ll);
+      d_ll = nullptr; d_ll_bytes = 0;
+      Check(vbh_dev_alloc(c, bytes, &d_ll), "vbh_dev_alloc");
+      d_ll_bytes = bytes;
+    }
+    return d_ll;
+  }
   void Release() {
+    if (d_ll && ctx) vbh_dev_free(ctx, d_ll);
+    d_ll = nullptr; d_ll_bytes = 0;
     if (dec) vbh_decoder_destroy(dec);
     if (g) vbh_graph_destroy(g);
     if (gmm) vbh_gmm_destroy(gmm);
@@ -670,7 +683,8 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
       if (b.keys.empty()) break;
       lap("read features of a batch");
       const int64_t T = b.frames();
-      DevMem d_in(ctx, sizeof(float) * b.data.size()), d_ll(ctx, sizeof(float) * (size_t)T * model.num_pdfs);
+      DevMem d_in(ctx, sizeof(float) * b.data.size());
+      struct { void *p; } d_ll{g_latgen.Scores(ctx, sizeof(float) * (size_t)T * model.num_pdfs)};
       Check(vbh_copy_h2d(ctx, d_in.p, b.data.data(), sizeof(float) * b.data.size()), "vbh_copy_h2d");
       std::unique_ptr<DevMem> d_fe;
       const float *d_feats_p = (const float *)d_in.p;
