@@ -184,3 +184,27 @@ def test_fmllr_update_from_statistics(host, D, T, seed):
     assert impr > 0 and np.array_equal(got[:, :D], np.eye(D, dtype=np.float32))
     got, impr = update("none")
     assert impr == 0.0 and np.array_equal(got, np.eye(D, D + 1, dtype=np.float32))
+
+
+def test_damaged_posterior_tables_are_errors(host, tmp_path):
+    """the posterior reader parses the table from memory: a truncated or corrupt table is an error message, never a read past the end"""
+    d = tmp_path
+    g = util.load("fmllr")
+    for k in ("file_final_mdl", "file_post_ark"):
+        name = k[5:].rsplit("_", 1)
+        (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
+    blob = (d / "post.ark").read_bytes()
+    log = str(d / "log.txt")
+    args = ["weight-silence-post", "0.01", "1:2", str(d / "final.mdl")]
+    assert call(host.vb_WeightSilencePost, args + ["ark:%s" % (d / "post.ark"), "ark:%s" % (d / "ok.ark")], log) == 0
+    rng = np.random.default_rng(1)
+    for cut in sorted(set([7, 8, 12, 30, len(blob) - 1, len(blob) - 9] + [int(x) for x in rng.integers(10, len(blob) - 1, 20)])):
+        (d / "cut.ark").write_bytes(blob[:cut])
+        rc = call(host.vb_WeightSilencePost, args + ["ark:%s" % (d / "cut.ark"), "ark:%s" % (d / "o.ark")], log)
+        assert rc != 0 or cut < 5, "truncated at %d of %d accepted" % (cut, len(blob))
+        assert rc == 0 or "ERROR (weight-silence-post)" in open(log).read()
+    for pos in [int(x) for x in rng.integers(8, len(blob) - 8, 60)]:
+        bad = bytearray(blob)
+        bad[pos:pos + 4] = (0x7fffff00).to_bytes(4, "little")
+        (d / "bad.ark").write_bytes(bytes(bad))
+        call(host.vb_WeightSilencePost, args + ["ark:%s" % (d / "bad.ark"), "ark:%s" % (d / "o.ark")], log)       # any return code; must not crash
