@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--pdfs", type=int, default=2500)
     ap.add_argument("--gauss", type=int, default=15000)
     ap.add_argument("--no-decode", action="store_true", help="stop after GMM scoring (BASELINE config 2)")
+    ap.add_argument("--feat", choices=("delta", "lda"), default="delta",
+                    help="delta: CMVN + deltas (39) + per-speaker fMLLR 39x40 (DELTA+SAT, config 3); lda: CMVN + splice +-4 (117) + LDA 40x117 + "
+                         "per-speaker fMLLR 40x41 (LDA+MLLT+SAT, config 4)")
     ap.add_argument("--words", type=int, default=180000, help="vocabulary of the synthetic HCLG (~11 states per word)")
     ap.add_argument("--beam", type=float, default=13.0)
     ap.add_argument("--lattice-beam", type=float, default=6.0)
@@ -74,15 +77,41 @@ def build_graph(args):
     return synth.lexicon_graph(args.words, args.pdfs, seed=11)
 
 
-def build_workload(args, rank):
+UTT_PER_SPK = 4
+
+
+def build_workload(args, rank, world, device):
+    """The job = world x batch utterances of world x batch/4 speakers (speakers of 4 utterances),
+    sharded by speaker over the ranks as voicebridge_amd/dist.py does for a data directory (longest-processing-time
+    assignment; all utterances have the same length here, so every rank gets batch/4 speakers).  Every utterance of the
+    job is a distinct waveform, synthesised on the rank's device (synth.wave_batch_device).  Returns the packed int16
+    samples on the device, the sample offsets, the rank-local utt2spk, the speaker count and the speakers' transforms."""
+    import torch
     from voicebridge_amd import synth
-    n_spk = max(1, args.batch // 4)
-    # a pool of distinct waveforms, reused round-robin so that host generation stays cheap
-    pool = [synth.wave(rank * 1000 + i, seconds=args.seconds) for i in range(min(args.batch, 8))]
-    waves = [pool[i % len(pool)] for i in range(args.batch)]
-    utt2spk = np.arange(args.batch, dtype=np.int32) % n_spk
-    xforms = np.stack([synth.affine(39, seed=s) for s in range(n_spk)])
-    return waves, utt2spk, n_spk, xforms
+    from voicebridge_amd import dist as vdist
+    n_spk = max(1, args.batch // UTT_PER_SPK)
+    upk = -(-args.batch // n_spk)
+    frames_per_utt = 1 + (int(round(args.seconds * 16000)) - 400) // 160
+    rank_of = vdist.shard_speakers(np.full(world * n_spk, upk * frames_per_utt, np.int64), world)
+    my_spk = np.flatnonzero(rank_of == rank)
+    assert len(my_spk) == n_spk
+    utt2spk = np.arange(args.batch, dtype=np.int32) % n_spk            # rank-local speaker index
+    gid = my_spk[utt2spk] * upk + np.arange(args.batch) // n_spk          # job-wide utterance id
+    n = int(round(args.seconds * 16000))
+    d_wave = torch.empty(args.batch * n, dtype=torch.int16, device=device)
+    for a in range(0, args.batch, 64):
+        b_ = min(a + 64, args.batch)
+        d_wave[a * n:b_ * n] = synth.wave_batch_device(gid[a:b_], args.seconds, device).reshape(-1)
+    woff = np.arange(args.batch + 1, dtype=np.int64) * n
+    xforms = np.stack([synth.affine(args.feat_dim, seed=int(s)) for s in my_spk])
+    return d_wave, woff, utt2spk, n_spk, xforms, gid
+
+
+def synth_lda(args):
+    """a 40 x 117 LDA+MLLT-like matrix (final.mat): orthonormal rows from a seeded Gaussian"""
+    rng = np.random.default_rng(77)
+    q, _ = np.linalg.qr(rng.standard_normal((117, 40)))
+    return np.ascontiguousarray(q.T, np.float32)
 
 
 def feature_space_model(args, sample_feats):
@@ -91,29 +120,45 @@ def feature_space_model(args, sample_feats):
     from voicebridge_amd import synth
     std = sample_feats.std(0) + 1e-3
     mu = sample_feats.mean(0)
-    offs, w, means, iv = synth.gmm_model(args.pdfs, args.gauss, 39, seed=1, mean_scale=args.mean_scale, dim_scale=std,
+    offs, w, means, iv = synth.gmm_model(args.pdfs, args.gauss, args.feat_dim, seed=1, mean_scale=args.mean_scale, dim_scale=std,
                                          var_spread=args.var_spread)
     means = means + mu.astype(np.float32)
     miv = (means * iv).astype(np.float32)
     return offs, w, miv, iv
 
 
-def cpu_baseline_reference(args, waves, xforms, model, decode_setup):
+def cpu_sample(args, utt2spk, n_spk):
+    """utterances of the bounded CPU sample: whole speakers (CMVN statistics are per speaker), split into <= 4 jobs of whole
+    speakers as the reference's split_data does (VB/scr/utils/split_data.cpp:20-100)"""
+    per = max(1, int(round(args.cpu_sample_seconds / args.seconds)))          # utterances one process decodes (about 10-20 s of one core)
+    upk = max(1, int(np.sum(np.asarray(utt2spk) == 0)))
+    spk_per_job = max(1, per // upk)
+    n_jobs = max(1, min(4, n_spk // spk_per_job))
+    jobs = []
+    for j in range(n_jobs):
+        spk = list(range(j * spk_per_job, (j + 1) * spk_per_job))
+        jobs.append([int(u) for u in np.flatnonzero(np.isin(utt2spk, spk))])
+    return jobs
+
+
+def cpu_baseline_reference(args, jobs, waves, utt2spk, xforms, lda, model, decode_setup):
     """The reference's own programs (oracle/_ref/bin: its sources compiled as they lie, OpenBLAS single-threaded in place of MKL) on a
-    bounded sample of the bench workload, one process / one core: compute-mfcc-feats, compute-cmvn-stats, apply-cmvn, add-deltas,
-    transform-feats, gmm-latgen-faster --determinize-lattice=false (the raw-lattice search the GPU step is compared with).  Wall-clock of
-    the feature programs plus the decoder's own "Time taken" (its loop over the utterances, model and graph loading excluded).
+    bounded sample of the bench workload: compute-mfcc-feats, compute-cmvn-stats, apply-cmvn, add-deltas (or splice-feats | transform-feats
+    final.mat), transform-feats trans, gmm-latgen-faster --determinize-lattice=false (the raw-lattice search the GPU step is compared with).
+    Two figures: len(jobs) processes side by side, one job each (the reference's nj jobs, VB/scr/steps/decode_gmm.cpp:300-324), and job 0
+    alone on one core.  A process's time = wall-clock of its feature programs + the decoder's own "Time taken" (its loop over the
+    utterances; model and graph loading excluded).  Also returns the words the reference decoded, per utterance, for the parity line.
     Returns None when the binaries are not there."""
     import re
     import shutil
     import subprocess
     import tempfile
+    from concurrent.futures import ThreadPoolExecutor
     from voicebridge_amd import refio
     B = os.path.join(ROOT, "oracle", "_ref", "bin")
-    need = ["compute-mfcc-feats", "compute-cmvn-stats", "apply-cmvn", "add-deltas", "transform-feats", "gmm-latgen-faster"]
+    need = ["compute-mfcc-feats", "compute-cmvn-stats", "apply-cmvn", "add-deltas", "splice-feats", "transform-feats", "gmm-latgen-faster"]
     if decode_setup is None or not all(os.access(os.path.join(B, b), os.X_OK) for b in need):
         return None
-    n_utt = max(1, min(int(round(args.cpu_sample_seconds / args.seconds)), len(waves)))
     offs, w, miv, iv = model
     g, _t2p, _cfg = decode_setup
     d = tempfile.mkdtemp(prefix="vb_cpu_ref_")
@@ -124,13 +169,21 @@ def cpu_baseline_reference(args, waves, xforms, model, decode_setup):
         n_cd = args.pdfs // H
         refio.write_mdl(p("final.mdl"), n_cd, H, offs, w, miv, iv)
         refio.write_vector_fst(p("HCLG.fst"), g["final"], g["arc_offset"], g["arcs"], g["start"])
-        with open(p("wav.scp"), "w") as f, open(p("utt2spk"), "w") as fu, open(p("spk2utt"), "w") as fs:
-            for u in range(n_utt):
-                refio.write_wav(p("u%03d.wav" % u), waves[u])
-                f.write("u%03d %s\n" % (u, p("u%03d.wav" % u)))
-                fu.write("u%03d s%03d\n" % (u, u))
-                fs.write("s%03d u%03d\n" % (u, u))
-        refio.write_feats_ark(p("trans.ark"), {"s%03d" % u: xforms[u % len(xforms)] for u in range(n_utt)})
+        if lda is not None:
+            refio.write_feats_ark(p("final.mat.ark"), {"lda": lda})
+            # a bare matrix file = the archive entry without its key
+            blob = open(p("final.mat.ark"), "rb").read()
+            open(p("final.mat"), "wb").write(blob[blob.index(b"\0B"):])
+        for j, utts in enumerate(jobs):
+            spks = sorted(set(int(utt2spk[u]) for u in utts))
+            with open(p("wav.%d.scp" % j), "w") as f, open(p("utt2spk.%d" % j), "w") as fu, open(p("spk2utt.%d" % j), "w") as fs:
+                for u in sorted(utts, key=lambda u_: "s%04d-u%05d" % (utt2spk[u_], u_)):
+                    refio.write_wav(p("u%05d.wav" % u), waves[u])
+                    f.write("s%04d-u%05d %s\n" % (utt2spk[u], u, p("u%05d.wav" % u)))
+                    fu.write("s%04d-u%05d s%04d\n" % (utt2spk[u], u, utt2spk[u]))
+                for s_ in spks:
+                    fs.write("s%04d %s\n" % (s_, " ".join("s%04d-u%05d" % (s_, u) for u in sorted(utts) if utt2spk[u] == s_)))
+            refio.write_feats_ark(p("trans.%d.ark" % j), {"s%04d" % s_: xforms[s_] for s_ in spks})
 
         def run(name, *a):
             t0 = time.perf_counter()
@@ -138,57 +191,93 @@ def cpu_baseline_reference(args, waves, xforms, model, decode_setup):
             if r.returncode != 0:
                 raise RuntimeError(name + ": " + r.stderr[-300:])
             return time.perf_counter() - t0, r.stderr
-        t_feat = 0.0
-        t_feat += run("compute-mfcc-feats", "--dither=0", "scp:" + p("wav.scp"), "ark:" + p("mfcc.ark"))[0]
-        t_feat += run("compute-cmvn-stats", "--spk2utt=ark:" + p("spk2utt"), "ark:" + p("mfcc.ark"), "ark:" + p("cmvn.ark"))[0]
-        t_feat += run("apply-cmvn", "--utt2spk=ark:" + p("utt2spk"), "ark:" + p("cmvn.ark"), "ark:" + p("mfcc.ark"), "ark:" + p("cm.ark"))[0]
-        t_feat += run("add-deltas", "ark:" + p("cm.ark"), "ark:" + p("dl.ark"))[0]
-        t_feat += run("transform-feats", "--utt2spk=ark:" + p("utt2spk"), "ark:" + p("trans.ark"), "ark:" + p("dl.ark"), "ark:" + p("feats.ark"))[0]
-        t_wall, log = run("gmm-latgen-faster", "--beam=%g" % args.beam, "--lattice-beam=%g" % args.lattice_beam, "--max-active=%d" % args.max_active,
-                          "--acoustic-scale=0.083333", "--allow-partial=true", "--determinize-lattice=false", p("final.mdl"), p("HCLG.fst"),
-                          "ark:" + p("feats.ark"), "ark:" + p("lat.ark"))
-        m = re.search(r"Time taken ([0-9.eE+-]+)s", log)
-        t_dec = float(m.group(1)) if m else t_wall
-        m = re.findall(r"Overall log-likelihood per frame is \S+ over (\d+) frames", log)
-        frames = int(m[-1]) if m else 0
-        if frames <= 0:
+
+        def job(j, tag):
+            """one job's program chain, as Decode() of the reference builds it (VB/scr/steps/decode_gmm.cpp:201-293)"""
+            q = lambda n: p("%s.%d.%s" % (n, j, tag))
+            t_feat = run("compute-mfcc-feats", "--dither=0", "scp:" + p("wav.%d.scp" % j), "ark:" + q("mfcc"))[0]
+            t_feat += run("compute-cmvn-stats", "--spk2utt=ark:" + p("spk2utt.%d" % j), "ark:" + q("mfcc"), "ark:" + q("cmvn"))[0]
+            t_feat += run("apply-cmvn", "--utt2spk=ark:" + p("utt2spk.%d" % j), "ark:" + q("cmvn"), "ark:" + q("mfcc"), "ark:" + q("cm"))[0]
+            if lda is None:
+                t_feat += run("add-deltas", "ark:" + q("cm"), "ark:" + q("dl"))[0]
+            else:
+                t_feat += run("splice-feats", "--left-context=4", "--right-context=4", "ark:" + q("cm"), "ark:" + q("sp"))[0]
+                t_feat += run("transform-feats", p("final.mat"), "ark:" + q("sp"), "ark:" + q("dl"))[0]
+            t_feat += run("transform-feats", "--utt2spk=ark:" + p("utt2spk.%d" % j), "ark:" + p("trans.%d.ark" % j), "ark:" + q("dl"), "ark:" + q("feats"))[0]
+            t_wall, log = run("gmm-latgen-faster", "--beam=%g" % args.beam, "--lattice-beam=%g" % args.lattice_beam, "--max-active=%d" % args.max_active,
+                              "--acoustic-scale=0.083333", "--allow-partial=true", "--determinize-lattice=false", p("final.mdl"), p("HCLG.fst"),
+                              "ark:" + q("feats"), "ark:" + q("lat"), "ark,t:" + q("words"))
+            m = re.search(r"Time taken ([0-9.eE+-]+)s", log)
+            t_dec = float(m.group(1)) if m else t_wall
+            m = re.findall(r"Overall log-likelihood per frame is \S+ over (\d+) frames", log)
+            frames = int(m[-1]) if m else 0
+            words = {}
+            for line in open(q("words")):
+                f_ = line.split()
+                if f_:
+                    words[int(f_[0].split("-u")[1])] = [int(x) for x in f_[1:]]
+            for n in ("mfcc", "cm", "dl", "sp", "feats", "lat"):
+                if os.path.exists(q(n)):
+                    os.remove(q(n))
+            return t_feat, t_dec, frames, max(t_wall - t_dec, 0.0), words
+
+        with ThreadPoolExecutor(len(jobs)) as ex:
+            par = list(ex.map(lambda j: job(j, "par"), range(len(jobs))))
+        one = job(0, "one")
+        if one[2] <= 0 or any(r[2] <= 0 for r in par):
             return None
-        return dict(value=frames / (t_feat + t_dec), unit="frames/s", cores=1, kind="reference",
-                    sample="%d x %.0f s utterances (%d frames) through the reference's own programs compiled from its sources (compute-mfcc-feats, "
-                           "compute-cmvn-stats, apply-cmvn, add-deltas, transform-feats, gmm-latgen-faster --determinize-lattice=false; OpenBLAS, one "
-                           "thread, MKL not available): features %.2f s, search %.2f s (its own 'Time taken'; loading the 2 M-state graph, %.1f s more, "
-                           "is left out)" % (n_utt, args.seconds, frames, t_feat, t_dec, max(t_wall - t_dec, 0.0)))
+        words = {}
+        for r in par:
+            words.update(r[4])
+        chain = ("compute-mfcc-feats, compute-cmvn-stats, apply-cmvn, %s, transform-feats, gmm-latgen-faster --determinize-lattice=false; OpenBLAS, "
+                 "one thread per process, MKL not available" % ("add-deltas" if lda is None else "splice-feats, transform-feats final.mat"))
+        t_par = max(r[0] + r[1] for r in par)
+        out_par = dict(value=sum(r[2] for r in par) / t_par, unit="frames/s", cores=len(jobs), kind="reference",
+                       sample="%d x %.0f s utterances (%d frames) in %d jobs of whole speakers run side by side, one process per job, through the "
+                              "reference's own programs compiled from its sources (%s): slowest job %.2f s = features %.2f s + search %.2f s (its own "
+                              "'Time taken'; loading the graph, %.1f s more per process, is left out)"
+                              % (sum(len(j_) for j_ in jobs), args.seconds, sum(r[2] for r in par), len(jobs), chain, t_par,
+                                 max(par, key=lambda r: r[0] + r[1])[0], max(par, key=lambda r: r[0] + r[1])[1], par[0][3]))
+        out_one = dict(value=one[2] / (one[0] + one[1]), unit="frames/s", cores=1, kind="reference",
+                       sample="job 0 of that sample alone (%d utterances, %d frames), one process: features %.2f s, search %.2f s" % (len(jobs[0]), one[2], one[0], one[1]))
+        return out_par, out_one, words
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
 
-def cpu_baseline(args, waves, utt2spk, xforms, model, decode_setup):
-    """oracle (plain C restatement of the reference, 1 thread) on a bounded sample"""
+def cpu_baseline(args, utts, waves, utt2spk, xforms, lda, model, decode_setup):
+    """oracle (plain C restatement of the reference, 1 thread) on job 0 of the bounded sample; the fallback where the
+    reference's programs are not there.  Returns the figure and the words it decoded."""
     from oracle import vbo
-    n_utt = max(1, int(round(args.cpu_sample_seconds / args.seconds)))
-    n_utt = min(n_utt, len(waves))
     offs, w, miv, iv = model
     o = vbo.mfcc_opts()
     gc = vbo.gmm_gconsts(w, miv, iv)
     fst = None
     t0 = time.perf_counter()
     frames = 0
-    for u in range(n_utt):
-        raw = vbo.mfcc(waves[u].astype(np.float32), o)
-        st = vbo.acc_cmvn_stats(raw)
-        f = vbo.transform_feats(vbo.add_deltas(vbo.apply_cmvn(raw, st)), xforms[utt2spk[u]])
+    raws = {u: vbo.mfcc(waves[u].astype(np.float32), o) for u in utts}
+    stats = {}
+    for u in utts:
+        st = vbo.acc_cmvn_stats(raws[u])
+        stats[utt2spk[u]] = st if utt2spk[u] not in stats else stats[utt2spk[u]] + st
+    words = {}
+    for u in utts:
+        f = vbo.apply_cmvn(raws[u], stats[utt2spk[u]])
+        f = vbo.add_deltas(f) if lda is None else vbo.transform_feats(vbo.splice(f), lda)
+        f = vbo.transform_feats(f, xforms[utt2spk[u]])
         ll = vbo.gmm_loglikes(offs, gc, miv, iv, f)
         if decode_setup is not None:
             g, t2p, cfg = decode_setup
             if fst is None:
                 fst = vbo.make_fst(g["final"], g["arc_offset"], g["arcs"], g["start"])
-            vbo.decode_lattice_faster(fst, ll, t2p, **cfg)
-        frames += len(raw)
+            words[u] = [int(x) for x in vbo.decode_lattice_faster(fst, ll, t2p, **cfg)["words"]]
+        frames += len(raws[u])
     dt = time.perf_counter() - t0
     return dict(value=frames / dt, unit="frames/s", cores=1, kind="port",
-                sample="%d x %.0f s utterances (%d frames) through the oracle: MFCC, CMVN+deltas+fMLLR, all-pdf "
+                sample="%d x %.0f s utterances (%d frames) through the oracle: MFCC, CMVN+%s+fMLLR, all-pdf "
                        "GMM scoring%s; on-demand scoring as in the reference would evaluate fewer pdfs"
-                       % (n_utt, args.seconds, frames, ", lattice search" if decode_setup is not None else ""))
+                       % (len(utts), args.seconds, frames, "deltas" if lda is None else "splice+LDA",
+                          ", lattice search" if decode_setup is not None else "")), words
 
 
 def host_threads(args):
@@ -314,7 +403,7 @@ def ondemand_gmm_measurement(args, ctx, gmm, model, feats, T):
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         gauss = float(ng[ppdf].sum())
-        bytes_ = gauss * (2 * 39 + 1) * 4.0 + Tm * 39 * 4.0 + Tm * per * 4.0
+        bytes_ = gauss * (2 * gmm.dim + 1) * 4.0 + Tm * gmm.dim * 4.0 + Tm * per * 4.0
         out["%d_pdfs_per_frame" % per] = {"frames": int(Tm), "call_ms": 1e3 * best, "pdf_evals_per_s": Tm * per / best, "gather_GBs": bytes_ / best / 1e9,
                                            "frac_of_hbm_peak": bytes_ / best / 1e9 / HBM_PEAK_GBS}
     out["note"] = ("call time incl. the H2D of the pair lists and the D2H of the scores; the model (4.8 MB) is L2-resident, so this is a gather out of "
@@ -337,18 +426,39 @@ def fmllr_measurement(args, ctx, gmm, feats, foff, utt2spk, n_spk, T):
         beta, K, G, ms = gmm.fmllr_stats(feats, foff, utt2spk, n_spk, poff, ppdf, pw)
         best = ms if best is None else min(best, ms)
     b, f = C.c_double(), C.c_double()
-    gmm.lib.vbh_fmllr_work(39, int(T), C.byref(b), C.byref(f))
+    gmm.lib.vbh_fmllr_work(gmm.dim, int(T), C.byref(b), C.byref(f))
     return {"kernel": "fmllr_accumulate_kernel", "bound": "mfma (f64)", "achieved": f.value / (best * 1e-3) / 1e12, "peak": F64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": f.value / (best * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, "kernel_ms": best, "algorithmic_flops": f.value,
             "algorithmic_bytes": b.value, "speakers": int(n_spk), "frames": int(T), "count_check": float(beta.sum()),
             "note": "per-speaker G_d = sum_t b_t[d] x+ x+^T (lower-triangle tiles), K, beta for the whole batch; flops count the padded 48-row tiles issued"}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start one rank per GPU as children of a process that has
+    not touched the GPU (torch.distributed.run, rendezvous on 127.0.0.1), forward their output and exit code.  Nothing is
+    re-executed in place: a process that has initialised HIP must never be replaced by another program."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = str(s_.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    args.feat_dim = 40 if args.feat == "lda" else 39
+    if world != max(args.gpus, 1):
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or plain `python bench.py --gpus N`)" % (args.gpus, world))
     import torch
     import torch.distributed as dist
     # VBH_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share the
@@ -367,10 +477,15 @@ def main():
     dev = ctx.device
     cdev = torch.device("cpu") if backend == "gloo" else dev        # where the tensors of the collectives live
 
-    waves, utt2spk, n_spk, xforms = build_workload(args, rank)
+    d_wave, woff, utt2spk, n_spk, xforms, gid = build_workload(args, rank, world, dev)
+    is_i16 = True
     mf = api.Mfcc(ctx)
-    post = api.FeaturePipeline(ctx, cmvn=True, mode="delta", spk_xform_shape=(39, 40))
-    d_wave, woff, is_i16 = mf.pack(waves)
+    if args.feat == "lda":
+        lda = synth_lda(args)
+        post = api.FeaturePipeline(ctx, cmvn=True, mode="splice", splice_left=4, splice_right=4, lda=lda, spk_xform_shape=(40, 41))
+    else:
+        lda = None
+        post = api.FeaturePipeline(ctx, cmvn=True, mode="delta", spk_xform_shape=(39, 40))
     ctx.torch_sync()
     raw, foff = mf.compute_packed(d_wave, woff, is_i16)
     ctx.sync()
@@ -625,7 +740,7 @@ def main():
     if dec is not None and world > 1:
         from voicebridge_amd import dist as vdist
         hyps = [dec.result(u, arrays=False)["words"] for u in range(args.batch)]
-        ids = [rank * args.batch + u for u in range(args.batch)]
+        ids = [int(x) for x in gid]
         counters = vdist.score(hyps, hyps)          # synthetic audio has no transcripts: self-scored
         totals, merged = vdist.gather_results(ids, hyps, counters, device=cdev)
         if rank == 0:
@@ -716,7 +831,7 @@ def main():
                                     "search beam %g lattice-beam %g max-active %d over a synthetic %d-state / %d-arc HCLG"
                                     % (args.beam, args.lattice_beam, args.max_active, graph.num_states, graph.num_arcs)),
                        "utterances_per_step_per_gpu": args.batch, "utterance_seconds": args.seconds,
-                       "frames_per_step_per_gpu": T, "pdfs": gmm.num_pdfs, "gaussians": gmm.num_gauss, "dim": 39,
+                       "frames_per_step_per_gpu": T, "pdfs": gmm.num_pdfs, "gaussians": gmm.num_gauss, "dim": gmm.dim, "features": args.feat,
                        "batches_in_flight": depth, "search_cus": args.search_cus,
                        "lattices": "raw (state level) in the headline region; determinized on the host in the second region (lattice_stage_in_step)",
                        "sharding": "utterances over ranks, no data-path collective"},
@@ -738,17 +853,26 @@ def main():
         if gathered is not None:
             out["gather"] = gathered
         if not args.no_cpu_baseline:
-            ref_cb = None
+            jobs = cpu_sample(args, utt2spk, n_spk)
+            n_smp = int(round(args.seconds * 16000))
+            waves = {u: d_wave[u * n_smp:(u + 1) * n_smp].cpu().numpy() for j_ in jobs for u in j_}
+            ref_cb, cpu_words = None, {}
             try:
-                ref_cb = cpu_baseline_reference(args, waves, xforms, model, decode_setup)
+                ref_cb = cpu_baseline_reference(args, jobs, waves, utt2spk, xforms, lda, model, decode_setup)
             except Exception as e:
                 print("cpu_baseline (reference programs) failed: %s" % e, file=sys.stderr, flush=True)
             if ref_cb is not None:
-                out["cpu_baseline"] = ref_cb
+                out["cpu_baseline"], out["cpu_baseline_1proc"], cpu_words = ref_cb
                 if os.environ.get("VBH_BENCH_PORT_BASELINE"):
-                    out["cpu_baseline_port"] = cpu_baseline(args, waves, utt2spk, xforms, model, decode_setup)
+                    out["cpu_baseline_port"] = cpu_baseline(args, jobs[0], waves, utt2spk, xforms, lda, model, decode_setup)[0]
             else:
-                out["cpu_baseline"] = cpu_baseline(args, waves, utt2spk, xforms, model, decode_setup)
+                out["cpu_baseline"], cpu_words = cpu_baseline(args, jobs[0], waves, utt2spk, xforms, lda, model, decode_setup)
+            if dec is not None and cpu_words:
+                # the utterances the CPU leg decoded anyway: are the GPU step's hypotheses the same words?
+                same = sum(1 for u, w_ in cpu_words.items() if list(dec.result(u, arrays=False)["words"]) == list(w_))
+                out["parity_words_equal"] = "%d/%d" % (same, len(cpu_words))
+                out["parity_note"] = ("best-path words of the GPU step against the %s's for the utterances of the CPU sample (same waveforms, model, "
+                                      "graph, transforms)" % ("reference programs" if ref_cb is not None else "oracle"))
         print(json.dumps(out), flush=True)
     if det_pool is not None:
         det_pool.close()

@@ -223,6 +223,11 @@ int vbh_decode_batch_begin(vbh_decoder *d, const float *d_loglikes, int32_t num_
                            int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids);
 int vbh_decode_batch_end(vbh_decoder *d);
 int vbh_decoder_result(vbh_decoder *d, int32_t utt, vbh_lattice *out);
+/* Capacities inside the search are estimates and never decide a result: {utterances of the last batch that outgrew a
+ * regular search slot and were searched again in a big one, times the output pool had to be enlarged, utterances given
+ * up (reported with ok = 0 and a warning on stderr; the rest of the batch is delivered, as the reference fails one
+ * utterance at a time, K/decoder/decoder-wrappers.cc:227-231)} */
+int vbh_decoder_batch_stats(vbh_decoder *d, int32_t *out3);
 /* diagnostic: shader-clock cycles the utterance's workgroup spent per phase
  * {cutoff, pass1, admit+links, epsilon closure, pruning, compaction, output, other} */
 int vbh_decoder_phase_cycles(vbh_decoder *d, int32_t utt, int64_t *out8);

@@ -21,6 +21,26 @@ def test_edit_counts():
     assert i + d + s == 3
 
 
+def test_edit_counts_split_is_the_reference_one(tmp_path):
+    """the ins/del/sub split of dist.edit_counts = the host ComputeWer's (the reference's tie order,
+    K/util/edit-distance-inl.h:104-120): what the multi-GPU gather sums must be what single-GPU scoring prints"""
+    import ctypes as C
+    from voicebridge_amd import build
+    assert vdist.edit_counts([0, 2, 3, 0, 2], [2, 1, 3]) == (1, 3, 0)
+    host = C.CDLL(build.HOST_LIB)
+    rng = np.random.default_rng(5)
+    refs = [rng.integers(1, 5, size=rng.integers(0, 8)).tolist() for _ in range(300)]
+    hyps = [rng.integers(1, 5, size=rng.integers(0, 8)).tolist() for _ in range(300)]
+    (tmp_path / "ref.txt").write_text("".join("u%03d %s\n" % (i, " ".join(map(str, r))) for i, r in enumerate(refs)))
+    (tmp_path / "hyp.txt").write_text("".join("u%03d %s\n" % (i, " ".join(map(str, h))) for i, h in enumerate(hyps)))
+    args = ["compute-wer", "--text", "--mode=present", "ark:" + str(tmp_path / "ref.txt"), "ark:" + str(tmp_path / "hyp.txt")]
+    argv = (C.c_char_p * len(args))(*[a.encode() for a in args])
+    assert host.vb_ComputeWer(len(args), argv, str(tmp_path / "log.txt").encode()) == 0
+    c = (C.c_longlong * 8)()
+    host.vb_ComputeWerCounts(c)
+    assert list(c)[:7] == vdist.score(refs, hyps).tolist()
+
+
 def test_shard_speakers_balances_frames():
     frames = [1000, 10, 900, 20, 500, 480, 30, 5]
     rank_of = vdist.shard_speakers(frames, 2)

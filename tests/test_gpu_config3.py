@@ -1,0 +1,122 @@
+"""GPU parity at the size the bench runs the search: utterances of 30 s (T = 2998) on the
+180 k-word lexicon graph (~2 M states), P = 2500 / G = 15000 / D = 39, beam 13, lattice-beam 6, max-active 7000 -- the whole
+GPU path from PCM to lattices, checked
+
+  * against the oracle's order-independent mode on the GPU's own scores: bit-exact token sets, float32 costs, every arc,
+    best path (what only exists at this size is exercised here: ~30 compactions per utterance, the dirty-frame bitmap, the
+    HBM level of the state map, frames bound by max-active and by min-active);
+  * against tests/golden/config3_refpaths.npz: words, alignment and weights the REFERENCE's own programs decode for the same
+    seeded inputs (oracle/gen_golden_config3.py, made in the build container -- the GPU box has no reference binary);
+  * with the small search slots shrunk (VBH_SLOT_SCALE) so that utterances overflow them and are searched again in big
+    slots, and with the output pool too small for the batch: identical lattices, and the retry counters say it happened.
+"""
+import numpy as np
+import pytest
+
+from tests.util import load
+
+pytestmark = pytest.mark.gpu
+
+LAT_KEYS = ["tok_frame", "tok_state", "tok_cost", "tok_extra", "tok_final", "link_src", "link_dst", "link_ilabel",
+            "link_olabel", "link_graph", "link_acoustic", "ali", "words"]
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import torch
+    from oracle import gen_golden_config3 as c3
+    from voicebridge_amd import api, synth
+    fx = load("config3_refpaths")
+    assert int(fx["n_utt"]) == c3.N_UTT and int(fx["words_in_graph"]) == c3.WORDS
+    ctx = api.Context(0)
+    waves, utt2spk, xforms = c3.workload()
+    mf = api.Mfcc(ctx)
+    raw, foff = mf.compute(waves)
+    post = api.FeaturePipeline(ctx, cmvn=True, mode="delta", spk_xform_shape=(c3.D, c3.D + 1))
+    stats = post.cmvn_stats(raw, foff, utt2spk, c3.N_SPK)
+    feats = post.apply(raw, foff, utt2spk=utt2spk, cmvn_stats=stats, spk_xforms=xforms)
+    ctx.sync()
+    offs, w, miv, iv = c3.model_from(fx["mu"], fx["std"])
+    gmm = api.DiagGmm(ctx, offs, w, miv, iv)
+    ll = gmm.loglikes(feats)
+    ctx.sync()
+    g, t2p = synth.lexicon_graph(c3.WORDS, c3.P, seed=11)
+    graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
+    cfg = dict(beam=c3.CFG["beam"], max_active=c3.CFG["max_active"], min_active=c3.CFG["min_active"], lattice_beam=c3.CFG["lattice_beam"])
+    dec = api.LatticeDecoder(ctx, graph, c3.N_UTT, int(np.diff(foff).max()), acoustic_scale=c3.CFG["acwt"], **cfg)
+    dec.decode(ll, foff, t2p)
+    res = [dec.result(u) for u in range(c3.N_UTT)]
+    stats0 = dec.batch_stats()
+    dec.close()
+    yield dict(ctx=ctx, fx=fx, foff=foff, ll=ll, ll_host=ll.cpu().numpy(), g=g, t2p=t2p, graph=graph, cfg=cfg, res=res, stats0=stats0,
+               acwt=c3.CFG["acwt"], n=c3.N_UTT, torch=torch)
+    graph.close(); gmm.close(); ctx.close()
+
+
+def test_search_at_bench_scale_is_bit_exact_with_the_oracle(setup):
+    from oracle import vbo
+    s = setup
+    assert all(int(d) == 2998 for d in np.diff(s["foff"]))
+    fst = vbo.make_fst(s["g"]["final"], s["g"]["arc_offset"], s["g"]["arcs"], 0)
+    bound = 0
+    for u in range(s["n"]):
+        ref = vbo.decode_lattice_faster(fst, s["ll_host"][s["foff"][u]:s["foff"][u + 1]], s["t2p"], acwt=s["acwt"], exact_cutoff=True, **s["cfg"])
+        got = s["res"][u]
+        for k in ("ok", "reached_final", "num_frames", "n_frames_maxactive_bound", "n_frames_minactive_bound"):
+            assert got[k] == ref[k], (u, k)
+        for k in LAT_KEYS:
+            np.testing.assert_array_equal(got[k], ref[k], err_msg="utt %d %s" % (u, k))
+        assert np.float32(got["best_graph"]) == np.float32(ref["best_graph"]) and np.float32(got["best_acoustic"]) == np.float32(ref["best_acoustic"])
+        bound += got["n_frames_maxactive_bound"] + got["n_frames_minactive_bound"]
+    assert bound > 1000          # the sample does contain frames where max-/min-active decide the cutoff
+    assert s["stats0"]["failed"] == 0
+
+
+def test_best_paths_equal_the_reference_programs(setup):
+    """end to end against the reference's compute-mfcc-feats ... gmm-latgen-faster on the same waveforms, model, graph and
+    transforms: same words and alignments; weights within the tolerance of the feature/score chain (MFCC 2e-3 abs, scores 1e-4 rel)"""
+    s = setup
+    fx = s["fx"]
+    for u in range(s["n"]):
+        got = s["res"][u]
+        assert got["ok"] == 1 and got["reached_final"] == 1
+        np.testing.assert_array_equal(got["words"], fx["ref_words_%d" % u], err_msg="words of utterance %d" % u)
+        np.testing.assert_array_equal(got["ali"], fx["ref_ali_%d" % u], err_msg="alignment of utterance %d" % u)
+        # gmm-latgen-faster logs (graph + acoustic) / (acwt * frames) hmm: "Log-like per frame" = -(total cost) / frames
+        like = -(got["best_graph"] + got["best_acoustic"]) / got["num_frames"]
+        np.testing.assert_allclose(like, float(fx["ref_like_per_frame_%d" % u]), rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("scale", ["0.12", "0.02"])
+def test_slot_overflow_is_searched_again_with_the_same_result(setup, monkeypatch, scale):
+    """the small-slot -> big-slot retry: some (0.12) or all (0.02) utterances outgrow their slot"""
+    from voicebridge_amd import api
+    s = setup
+    monkeypatch.setenv("VBH_SLOT_SCALE", scale)
+    dec = api.LatticeDecoder(s["ctx"], s["graph"], s["n"], 2998, acoustic_scale=s["acwt"], **s["cfg"])
+    dec.decode(s["ll"], s["foff"], s["t2p"])
+    st = dec.batch_stats()
+    assert st["failed"] == 0 and st["retried_in_big_slot"] > 0
+    if scale == "0.02":
+        assert st["retried_in_big_slot"] == s["n"]
+    for u in range(s["n"]):
+        got = dec.result(u)
+        for k in LAT_KEYS:
+            np.testing.assert_array_equal(got[k], s["res"][u][k], err_msg="utt %d %s" % (u, k))
+    dec.close()
+
+
+def test_output_pool_grows_instead_of_failing_the_batch(setup, monkeypatch):
+    """a batch whose lattices outgrow the output pool used to fail as a whole"""
+    from voicebridge_amd import api
+    s = setup
+    monkeypatch.setenv("VBH_POOL_SCALE", "0.01")          # pool sized for ~0.6 tokens per frame: too small for these lattices
+    dec = api.LatticeDecoder(s["ctx"], s["graph"], s["n"], 2998, acoustic_scale=s["acwt"], **s["cfg"])
+    dec.decode(s["ll"], s["foff"], s["t2p"])
+    st = dec.batch_stats()
+    assert st["failed"] == 0 and st["pool_grown"] > 0
+    for u in range(s["n"]):
+        got = dec.result(u)
+        for k in LAT_KEYS:
+            np.testing.assert_array_equal(got[k], s["res"][u][k], err_msg="utt %d %s" % (u, k))
+    dec.close()

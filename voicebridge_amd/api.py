@@ -348,6 +348,13 @@ class LatticeDecoder:
         check(self.lib.vbh_decoder_times(self.h, out), "vbh_decoder_times")
         return dict(kernel_ms=out[0], copy_ms=out[1], host_ms=out[2], total_ms=out[3])
 
+    def batch_stats(self):
+        """of the last decode(): utterances searched again in a big slot, output pool enlargements, utterances given up (ok = 0)"""
+        out = (C.c_int32 * 3)()
+        self.lib.vbh_decoder_batch_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        check(self.lib.vbh_decoder_batch_stats(self.h, out), "vbh_decoder_batch_stats")
+        return dict(retried_in_big_slot=out[0], pool_grown=out[1], failed=out[2])
+
     def close(self):
         if self.h:
             self.lib.vbh_decoder_destroy(self.h)

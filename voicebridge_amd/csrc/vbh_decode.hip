@@ -59,6 +59,7 @@
 #include <thread>
 #include <climits>
 #include <cmath>
+#include <mutex>
 
 namespace {
 
@@ -1567,7 +1568,11 @@ struct vbh_graph {
   int S, start; long long A; int max_ilabel, max_degree;
   DevBuf<i32x4> st, arcs;      // device records (see DevGraph); arcs are stored epsilon-first within a state
   DevBuf<int> arc_il;
-  mutable std::vector<int> filled_t2p;   // tid2pdf table the arcs' pdf fields currently hold (empty: none)
+  // tid2pdf table the arcs' pdf fields currently hold (empty: none) and the searches in flight that read them: decoders on
+  // several host threads / streams may share a graph as long as they use the same transition model at the same time
+  mutable std::vector<int> filled_t2p;
+  mutable std::mutex pdf_mu;
+  mutable int pdf_users = 0;
   std::vector<float> h_final;
 };
 
@@ -1576,19 +1581,27 @@ void vbh_graph_view_get(const vbh_graph *g, vbh_graph_view *v) {
   v->st = g->st.p; v->arcs = g->arcs.p; v->arc_il = g->arc_il.p;
 }
 
-// the arcs' pdf fields depend on tid2pdf only: refill when the table changes (decoders that share a
-// graph on different streams must therefore use one table at a time)
+// The arcs' pdf fields depend on tid2pdf only: refill when the table changes.  A search that reads them holds a use count
+// from vbh_graph_fill_pdf until vbh_graph_release_pdf; a different table is refused while another search is in flight.
 int vbh_graph_fill_pdf(const vbh_graph *g, hipStream_t st, const int32_t *h_t2p, int32_t num_tids) {
   std::vector<int> t2p(h_t2p, h_t2p + num_tids + 1);
   t2p[0] = 0;
-  if (g->A <= 0 || g->filled_t2p == t2p) return 0;
+  std::lock_guard<std::mutex> lk(g->pdf_mu);
+  if (g->A <= 0 || g->filled_t2p == t2p) { g->pdf_users++; return 0; }
+  VBH_CHECK(g->pdf_users == 0, "the decoding graph is being searched with another transition model (tid2pdf table): decoders that share a "
+                               "vbh_graph must use one table at a time");
   DevBuf<int> d_t2p;
   if (d_t2p.upload(t2p.data(), t2p.size(), st)) return -1;
   hipLaunchKernelGGL(fill_arc_pdf_kernel, dim3(1024), dim3(256), 0, st, g->arcs.p, g->arc_il.p, g->A, d_t2p.p);
   VBH_HIP(hipGetLastError());
   VBH_HIP(hipStreamSynchronize(st));
   g->filled_t2p = t2p;
+  g->pdf_users++;
   return 0;
+}
+void vbh_graph_release_pdf(const vbh_graph *g) {
+  std::lock_guard<std::mutex> lk(g->pdf_mu);
+  if (g->pdf_users > 0) g->pdf_users--;
 }
 
 struct HostLattice {
@@ -1611,7 +1624,7 @@ struct vbh_decoder {
   std::vector<void *> allocs;
   std::vector<HostLattice> results;
   std::vector<UttResult> h_res;
-  int n_retried = 0;
+  int n_retried = 0, n_pool_grown = 0, n_failed = 0;   // last batch: searched again in a big slot / pool enlargements / given up
   // output pool (device) and its pinned host mirror: kept across batches, grown on demand
   DevBuf<int> p_tf, p_ts, p_ls, p_ld, p_li, p_lo; DevBuf<float> p_tc, p_te, p_tfin, p_lg, p_la, p_co; DevBuf<unsigned long long> p_cnt;
   DevBuf<Pool> d_pool;
@@ -1621,6 +1634,7 @@ struct vbh_decoder {
   // a batch between vbh_decode_batch_begin and vbh_decode_batch_end
   struct Pending {
     bool active = false;
+    bool holds_pdf = false;           // a use count on the graph's pdf fields (vbh_graph_fill_pdf)
     int n_utt = 0, num_pdfs = 0;
     const float *d_loglikes = nullptr;
     long long tok_cap = 0, link_cap = 0;
@@ -1665,17 +1679,21 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
   // new tokens per frame are bounded by the arcs leaving the expanded tokens (~max_active * out-degree)
   const long long per_frame_tok = std::min<long long>(S, big ? std::max<long long>(8192, 8 * ma) : std::max<long long>(4096, 2 * ma));
   long long per_frame_link = std::min<long long>(std::max<long long>(graph->A, 1), 2 * per_frame_tok);
-  // VBH_SLOT_SCALE (tuning): scales the raw-window link and candidate capacities of the small slots;
-  // an utterance that outgrows them is searched again in a big slot
+  // VBH_SLOT_SCALE (tuning, and the tests of the retry path): scales the per-frame token, link and candidate capacities of
+  // the small slots; an utterance that outgrows them is searched again in a big slot
   double slot_scale = 1.0;
-  if (const char *e = getenv("VBH_SLOT_SCALE")) { const double x = atof(e); if (x > 0.05 && x <= 4.0) slot_scale = x; }
-  if (!big) per_frame_link = std::max<long long>(1024, (long long)(per_frame_link * slot_scale));
+  if (const char *e = getenv("VBH_SLOT_SCALE")) { const double x = atof(e); if (x >= 0.01 && x <= 4.0) slot_scale = x; }
+  long long per_frame_tok_s = per_frame_tok;
+  if (!big) {
+    per_frame_link = std::max<long long>(1024, (long long)(per_frame_link * slot_scale));
+    if (slot_scale < 1.0) per_frame_tok_s = std::max<long long>(256, (long long)(per_frame_tok * slot_scale));
+  }
   const long long surv_tok = big ? 2048 : 160, surv_link = big ? 4096 : 320;   // lattice survivors per frame
   const int pi = effective_prune_interval(cfg);
   const int win = pi + 1;
   Slot p{};
-  p.w_tok_cap = (int)std::min<long long>(per_frame_tok * win, 1LL << 28);
-  p.w_link_cap = (int)std::min<long long>((per_frame_link + per_frame_tok) * win, 1LL << 28);
+  p.w_tok_cap = (int)std::min<long long>(per_frame_tok_s * win, 1LL << 28);
+  p.w_link_cap = (int)std::min<long long>((per_frame_link + per_frame_tok_s) * win, 1LL << 28);
   // history: one unpruned frontier frame per interval plus the survivors
   const long long n_int = max_frames / pi + 2;
   const long long front_avg = big ? per_frame_tok : per_frame_tok / 2;
@@ -1935,8 +1953,8 @@ static const char *err_name(int e) {
 
 extern "C" {
 
-int vbh_decode_batch_begin(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, const int64_t *h_frame_offsets,
-                           int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids) {
+static int decode_batch_begin_impl(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, const int64_t *h_frame_offsets,
+                                   int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids) {
   VBH_CHECK(d && h_frame_offsets && h_tid2pdf, "vbh_decode_batch: NULL argument");
   VBH_CHECK(n_utt >= 0 && num_pdfs > 0 && num_tids >= 0, "vbh_decode_batch: bad sizes");
   VBH_CHECK(!d->pend.active, "vbh_decode_batch_begin: the previous batch has not been ended");
@@ -1990,7 +2008,11 @@ int vbh_decode_batch_begin(vbh_decoder *d, const float *d_loglikes, int32_t num_
   // output pool: the pruned lattice is a small multiple of the frame count
   Pool &pool = d->h_pool;
   pool = Pool{};
-  const long long tok_cap = std::max<long long>(4096, 64 * (total_frames + n_utt)), link_cap = std::max<long long>(8192, 128 * (total_frames + n_utt));
+  // (an estimate: a batch that needs more gets an enlarged pool in vbh_decode_batch_end; VBH_POOL_SCALE shrinks it for the tests of that path)
+  double pool_scale = 1.0;
+  if (const char *e = getenv("VBH_POOL_SCALE")) { const double x = atof(e); if (x > 0.0 && x <= 16.0) pool_scale = x; }
+  const long long tok_cap = std::max<long long>(4096, (long long)(pool_scale * 64 * (total_frames + n_utt))),
+                  link_cap = std::max<long long>(8192, (long long)(pool_scale * 128 * (total_frames + n_utt)));
   pool.tok_cap = tok_cap; pool.link_cap = link_cap; pool.cost_cap = total_frames + 1;
   DevBuf<int> &p_tf = d->p_tf, &p_ts = d->p_ts, &p_ls = d->p_ls, &p_ld = d->p_ld, &p_li = d->p_li, &p_lo = d->p_lo;
   DevBuf<float> &p_tc = d->p_tc, &p_te = d->p_te, &p_tfin = d->p_tfin, &p_lg = d->p_lg, &p_la = d->p_la, &p_co = d->p_co;
@@ -2010,6 +2032,7 @@ int vbh_decode_batch_begin(vbh_decoder *d, const float *d_loglikes, int32_t num_
   pool.link_src = p_ls.p; pool.link_dst = p_ld.p; pool.link_il = p_li.p; pool.link_ol = p_lo.p; pool.link_gr = p_lg.p; pool.link_ac = p_la.p;
   pool.cost_offsets = p_co.p; pool.counters = p_cnt.p;
   if (vbh_graph_fill_pdf(g, st, h_tid2pdf, num_tids)) return -1;
+  d->pend.holds_pdf = true;
   DevBuf<Pool> &d_pool = d->d_pool;
   if (!d_pool.p && d_pool.alloc(1)) return -1;
   const DevGraph dg0{g->S, g->start, g->st.p, g->arcs.p, g->arc_il.p};
@@ -2074,7 +2097,21 @@ int vbh_decode_batch_begin(vbh_decoder *d, const float *d_loglikes, int32_t num_
   return 0;
 }
 
+int vbh_decode_batch_begin(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, const int64_t *h_frame_offsets,
+                           int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids) {
+  const int rc = decode_batch_begin_impl(d, d_loglikes, num_pdfs, h_frame_offsets, n_utt, h_tid2pdf, num_tids);
+  if (rc != 0 && d && d->pend.holds_pdf) { vbh_graph_release_pdf(d->graph); d->pend.holds_pdf = false; }
+  return rc;
+}
+
+static int decode_batch_end_impl(vbh_decoder *d);
 int vbh_decode_batch_end(vbh_decoder *d) {
+  const int rc = decode_batch_end_impl(d);
+  if (d && d->pend.holds_pdf) { vbh_graph_release_pdf(d->graph); d->pend.holds_pdf = false; }
+  return rc;
+}
+
+static int decode_batch_end_impl(vbh_decoder *d) {
   VBH_CHECK(d, "vbh_decode_batch_end: NULL argument");
   VBH_CHECK(d->pend.active, "vbh_decode_batch_end: no batch has been begun");
   if (vbh_use_device(d->ctx)) return -1;
@@ -2108,46 +2145,107 @@ int vbh_decode_batch_end(vbh_decoder *d) {
     float ms = 0; VBH_HIP(hipEventElapsedTime(&ms, ev0, ev1)); d->t_kernel_ms += ms;
   }
   lap("search kernel + results D2H");
-  // utterances that outgrew a small slot are searched again in a big one
-  std::vector<int> retry;
-  for (int u = 0; u < n_utt; u++) {
-    const int e = d->h_res[u].error;
-    if (e == ERR_W_TOK || e == ERR_W_LINK || e == ERR_H_TOK || e == ERR_H_LINK || e == ERR_FRONT || e == ERR_CAND) retry.push_back(u);
-  }
-  if (!retry.empty() && getenv("VBH_DEBUG")) {
-    int cnt[16] = {0};
-    for (int u : retry) cnt[d->h_res[u].error & 15]++;
-    fprintf(stderr, "[vbh] %zu of %d utterances overflowed a small slot:", retry.size(), n_utt);
-    for (int e = 1; e < 9; e++) if (cnt[e]) fprintf(stderr, " %s x%d;", err_name(e), cnt[e]);
-    fprintf(stderr, " (frames done of first: %d)\n", d->h_res[retry[0]].num_frames);
-  }
-  if (!retry.empty()) {
-    if (d->big_set.n == 0) {
-      if (alloc_slot_set(d, &d->big_set, std::min<int>(8, (int)retry.size()), /*big=*/true)) return -1;
+  // Capacities are estimates, results are not: an utterance that outgrew a small slot is searched again in a big one, and
+  // when the lattices of a batch outgrow the output pool the pool is enlarged (its content kept) and the utterances that
+  // did not fit are searched again.  What still fails after that -- a big slot too small, an epsilon cycle -- fails alone:
+  // the utterance is reported with ok = 0 / error set and the rest of the batch is delivered (the reference logs
+  // "Failed to decode" for one utterance and goes on, K/decoder/decoder-wrappers.cc:227-231).
+  auto is_cap = [](int e) { return e == ERR_W_TOK || e == ERR_W_LINK || e == ERR_H_TOK || e == ERR_H_LINK || e == ERR_FRONT || e == ERR_CAND; };
+  long long tok_cap_now = tok_cap, link_cap_now = link_cap;
+  std::vector<char> tried_big(n_utt, 0);
+  d->n_retried = 0; d->n_pool_grown = 0; d->n_failed = 0;
+  for (int round = 0; round < 6; round++) {
+    std::vector<int> retry;
+    bool pool_short = false, need_big = false;
+    for (int u = 0; u < n_utt; u++) {
+      const int e = d->h_res[u].error;
+      if (e == ERR_POOL) { retry.push_back(u); pool_short = true; }
+      else if (is_cap(e) && !tried_big[u]) { retry.push_back(u); need_big = true; }
     }
-    DevBuf<int> d_list;
-    if (d_list.upload(retry.data(), retry.size(), st)) return -1;
-    VBH_HIP(hipMemsetAsync(d_counter.p, 0, sizeof(int), st));
-    const int grid = std::min<int>(d->big_set.n, (int)retry.size());
-    VBH_HIP(hipEventRecord(ev0, st));
-    hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(NT), 0, st, dg, dc, d->big_set.d.p, d_loglikes, (int)num_pdfs,
-                       d_utts.p, d_list.p, (int)retry.size(), d_counter.p, d_res.p, d_pool.p);
-    VBH_HIP(hipGetLastError());
-    VBH_HIP(hipEventRecord(ev1, st));
+    if (retry.empty()) break;
+    if (getenv("VBH_DEBUG")) {
+      int cnt[16] = {0};
+      for (int u : retry) cnt[d->h_res[u].error & 15]++;
+      fprintf(stderr, "[vbh] round %d: %zu of %d utterances are searched again:", round, retry.size(), n_utt);
+      for (int e = 1; e < 9; e++) if (cnt[e]) fprintf(stderr, " %s x%d;", err_name(e), cnt[e]);
+      fprintf(stderr, " (frames done of first: %d)\n", d->h_res[retry[0]].num_frames);
+    }
+    if (pool_short) {
+      // counters hold the demand so far, including the reservations that did not fit; the utterances searched again
+      // reserve once more, so twice the demand is enough for this round
+      unsigned long long used[4];
+      VBH_HIP(hipMemcpyAsync(used, p_cnt.p, sizeof(used), hipMemcpyDeviceToHost, st));
+      VBH_HIP(hipStreamSynchronize(st));
+      const long long want_t = std::max<long long>(2 * (long long)used[0] + 4096, tok_cap_now), want_l = std::max<long long>(2 * (long long)used[1] + 8192, link_cap_now);
+      auto grow = [&](auto &buf, long long old_cap, long long new_cap) -> int {
+        if (new_cap <= old_cap) return 0;
+        typename std::remove_reference<decltype(buf)>::type nb;
+        if (nb.alloc((size_t)new_cap)) return -1;
+        VBH_HIP(hipMemcpyAsync(nb.p, buf.p, sizeof(*buf.p) * (size_t)old_cap, hipMemcpyDeviceToDevice, st));
+        VBH_HIP(hipStreamSynchronize(st));
+        std::swap(buf.p, nb.p); std::swap(buf.n, nb.n);
+        return 0;
+      };
+      if (grow(p_tf, tok_cap_now, want_t) || grow(p_ts, tok_cap_now, want_t) || grow(p_tc, tok_cap_now, want_t) || grow(p_te, tok_cap_now, want_t) ||
+          grow(p_tfin, tok_cap_now, want_t)) return -1;
+      if (grow(p_ls, link_cap_now, want_l) || grow(p_ld, link_cap_now, want_l) || grow(p_li, link_cap_now, want_l) || grow(p_lo, link_cap_now, want_l) ||
+          grow(p_lg, link_cap_now, want_l) || grow(p_la, link_cap_now, want_l)) return -1;
+      tok_cap_now = std::max(tok_cap_now, want_t); link_cap_now = std::max(link_cap_now, want_l);
+      d->pool_tok_cap = std::max(d->pool_tok_cap, tok_cap_now); d->pool_link_cap = std::max(d->pool_link_cap, link_cap_now);
+      Pool &pool = d->h_pool;
+      pool.tok_cap = tok_cap_now; pool.link_cap = link_cap_now;
+      pool.tok_frame = p_tf.p; pool.tok_state = p_ts.p; pool.tok_cost = p_tc.p; pool.tok_extra = p_te.p; pool.tok_final = p_tfin.p;
+      pool.link_src = p_ls.p; pool.link_dst = p_ld.p; pool.link_il = p_li.p; pool.link_ol = p_lo.p; pool.link_gr = p_lg.p; pool.link_ac = p_la.p;
+      VBH_HIP(hipMemcpyAsync(d_pool.p, &pool, sizeof(Pool), hipMemcpyHostToDevice, st));
+      VBH_HIP(hipStreamSynchronize(st));
+      d->n_pool_grown++;
+    }
+    // capacity overflows go to the big slots; utterances that only lacked pool space run where they ran before
+    for (int pass = 0; pass < 2; pass++) {
+      std::vector<int> list;
+      for (int u : retry) {
+        const bool cap_err = is_cap(d->h_res[u].error);
+        if ((pass == 0) == (cap_err || tried_big[u])) list.push_back(u);
+      }
+      if (list.empty()) continue;
+      const bool big = pass == 0;
+      if (big && d->big_set.n == 0) {
+        if (alloc_slot_set(d, &d->big_set, std::min<int>(8, (int)list.size()), /*big=*/true)) return -1;
+      }
+      SlotSet &set = big ? d->big_set : d->small_set;
+      DevBuf<int> d_list;
+      if (d_list.upload(list.data(), list.size(), st)) return -1;
+      VBH_HIP(hipMemsetAsync(d_counter.p, 0, sizeof(int), st));
+      const int grid = std::min<int>(set.n, (int)list.size());
+      VBH_HIP(hipEventRecord(ev0, st));
+      hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(NT), 0, st, dg, dc, set.d.p, d_loglikes, (int)num_pdfs,
+                         d_utts.p, d_list.p, (int)list.size(), d_counter.p, d_res.p, d_pool.p);
+      VBH_HIP(hipGetLastError());
+      VBH_HIP(hipEventRecord(ev1, st));
+      VBH_HIP(hipStreamSynchronize(st));
+      float ms = 0; VBH_HIP(hipEventElapsedTime(&ms, ev0, ev1)); d->t_kernel_ms += ms;
+      if (big) for (int u : list) { if (!tried_big[u]) d->n_retried++; tried_big[u] = 1; }
+    }
+    (void)need_big;
     VBH_HIP(hipMemcpyAsync(d->h_res.data(), d_res.p, sizeof(UttResult) * n_utt, hipMemcpyDeviceToHost, st));
     VBH_HIP(hipStreamSynchronize(st));
-    float ms = 0; VBH_HIP(hipEventElapsedTime(&ms, ev0, ev1)); d->t_kernel_ms += ms;
   }
-  d->n_retried = (int)retry.size();
   unsigned long long used[4];
   VBH_HIP(hipMemcpyAsync(used, p_cnt.p, sizeof(used), hipMemcpyDeviceToHost, st));
   VBH_HIP(hipStreamSynchronize(st));
-  for (int u = 0; u < n_utt; u++)
-    VBH_CHECK(d->h_res[u].error == ERR_NONE, "vbh_decode_batch: utterance %d failed: %s", u, err_name(d->h_res[u].error));
+  for (int u = 0; u < n_utt; u++) {
+    UttResult &r = d->h_res[u];
+    if (r.error == ERR_NONE) continue;
+    d->n_failed++;
+    fprintf(stderr, "WARNING (vbh_decode_batch) utterance %d failed: %s (frame %d of %d); it is reported with ok = 0\n", u, err_name(r.error),
+            r.num_frames, (int)d->h_utts[u].T);
+    r.ok = 0; r.reached_final = 0; r.n_tok = 0; r.n_link = 0; r.tok_off = 0; r.link_off = 0;
+  }
+  const long long tok_cap_final = tok_cap_now, link_cap_final = link_cap_now;
   // bring the used part of the pool to the host
   lap("retries + checks");
   const auto t_copy0 = std::chrono::steady_clock::now();
-  const long long nt = std::min<long long>((long long)used[0], tok_cap), nl = std::min<long long>((long long)used[1], link_cap);
+  const long long nt = std::min<long long>((long long)used[0], tok_cap_final), nl = std::min<long long>((long long)used[1], link_cap_final);
   // pinned staging: [5 token arrays of nt][6 link arrays of nl], 4 bytes per entry
   const size_t need = (size_t)(5 * nt + 6 * nl) * 4 + 64;
   if (need > d->pin_bytes) {
@@ -2220,6 +2318,12 @@ int vbh_decoder_phase_cycles(vbh_decoder *d, int32_t utt, int64_t *out8) {
 int vbh_decoder_times(vbh_decoder *d, float *out4) {
   VBH_CHECK(d && out4, "vbh_decoder_times: NULL argument");
   out4[0] = d->t_kernel_ms; out4[1] = d->t_copy_ms; out4[2] = d->t_host_ms; out4[3] = d->t_total_ms;
+  return 0;
+}
+
+int vbh_decoder_batch_stats(vbh_decoder *d, int32_t *out3) {
+  VBH_CHECK(d && out3, "vbh_decoder_batch_stats: NULL argument");
+  out3[0] = d->n_retried; out3[1] = d->n_pool_grown; out3[2] = d->n_failed;
   return 0;
 }
 

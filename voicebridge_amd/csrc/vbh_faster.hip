@@ -880,8 +880,8 @@ void vbh_faster_decoder_destroy(vbh_faster_decoder *d) {
   delete d;
 }
 
-int vbh_faster_decode_batch(vbh_faster_decoder *d, const float *d_loglikes, int32_t num_pdfs, const int64_t *h_frame_offsets,
-                            int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids) {
+static int faster_decode_batch_impl(vbh_faster_decoder *d, const float *d_loglikes, int32_t num_pdfs, const int64_t *h_frame_offsets,
+                                    int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids, bool *holds_pdf) {
   VBH_CHECK(d && h_frame_offsets && h_tid2pdf, "vbh_faster_decode_batch: NULL argument");
   VBH_CHECK(n_utt >= 0 && num_pdfs > 0 && num_tids >= 0, "vbh_faster_decode_batch: bad sizes");
   if (vbh_use_device(d->ctx)) return -1;
@@ -902,6 +902,7 @@ int vbh_faster_decode_batch(vbh_faster_decoder *d, const float *d_loglikes, int3
   VBH_CHECK(total == 0 || d_loglikes, "vbh_faster_decode_batch: NULL loglikes");
   hipStream_t st = d->ctx->stream;
   if (vbh_graph_fill_pdf(d->graph, st, h_tid2pdf, num_tids)) return -1;
+  *holds_pdf = true;
   FGraph fg{gv.S, gv.start, static_cast<const i32x4 *>(gv.st), static_cast<const i32x4 *>(gv.arcs), gv.arc_il};
   FCfg fc{d->cfg.beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active};
   std::vector<FResult> res(n_utt);
@@ -915,9 +916,15 @@ int vbh_faster_decode_batch(vbh_faster_decoder *d, const float *d_loglikes, int3
   VBH_HIP(hipGetLastError());
   VBH_HIP(hipMemcpyAsync(res.data(), d_res.p, sizeof(FResult) * n_utt, hipMemcpyDeviceToHost, st));
   VBH_HIP(hipStreamSynchronize(st));
-  for (int u = 0; u < n_utt; u++)
-    VBH_CHECK(res[u].error == FERR_NONE, "vbh_faster_decode_batch: utterance %d failed after %d frames (%lld tokens so far; slot: %d tokens, %d per frame, %d candidates): %s",
-              u, res[u].num_frames, res[u].n_tokens, d->proto.tok_cap, d->proto.frame_cap, d->proto.cand_cap, ferr_name(res[u].error));
+  // an utterance that outgrows the search workspace fails alone (ok = 0), as the reference fails one utterance at a time
+  // (K/gmmbin/gmm-decode-faster.cc:150-178: "Did not successfully decode utterance"); the rest of the batch is delivered
+  for (int u = 0; u < n_utt; u++) {
+    if (res[u].error == FERR_NONE) continue;
+    fprintf(stderr, "WARNING (vbh_faster_decode_batch) utterance %d failed after %d frames (%lld tokens so far; slot: %d tokens, %d per frame, %d candidates): %s; "
+                    "it is reported with ok = 0\n", u, res[u].num_frames, res[u].n_tokens, d->proto.tok_cap, d->proto.frame_cap, d->proto.cand_cap,
+            ferr_name(res[u].error));
+    res[u].ok = 0; res[u].reached_final = 0; res[u].path_len = 0;
+  }
   std::vector<std::vector<i32x4>> paths(n_utt);
   for (int u = 0; u < n_utt; u++) {
     paths[u].resize(res[u].path_len);
@@ -948,6 +955,14 @@ int vbh_faster_decode_batch(vbh_faster_decoder *d, const float *d_loglikes, int3
     v.n_tokens = res[u].n_tokens;
   }
   return 0;
+}
+
+int vbh_faster_decode_batch(vbh_faster_decoder *d, const float *d_loglikes, int32_t num_pdfs, const int64_t *h_frame_offsets,
+                            int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids) {
+  bool holds_pdf = false;
+  const int rc = faster_decode_batch_impl(d, d_loglikes, num_pdfs, h_frame_offsets, n_utt, h_tid2pdf, num_tids, &holds_pdf);
+  if (holds_pdf) vbh_graph_release_pdf(d->graph);
+  return rc;
 }
 
 int vbh_faster_decoder_result(vbh_faster_decoder *d, int32_t utt, vbh_best_path *out) {

@@ -110,6 +110,8 @@ struct vbh_graph_view {
 void vbh_graph_view_get(const vbh_graph *g, vbh_graph_view *v);
 // make the arcs' pdf fields hold h_t2p[ilabel] (no-op when they already do); h_t2p[0] is ignored
 int vbh_graph_fill_pdf(const vbh_graph *g, hipStream_t st, const int32_t *h_t2p, int32_t num_tids);
+// every successful vbh_graph_fill_pdf is paired with one release once the search that reads the pdf fields has finished
+void vbh_graph_release_pdf(const vbh_graph *g);
 
 // what another translation unit needs of a vbh_gmm (defined in vbh_gmm.hip): row-major model arrays on the device
 struct vbh_gmm_view {

@@ -33,31 +33,30 @@ def shard_speakers(spk_frames, world):
 
 
 def edit_counts(ref, hyp):
-    """(ins, del, sub) of the minimum edit distance alignment of hyp against ref
-    (LevenshteinEditDistance as used by compute-wer, VB/src/bin/compute-wer.cpp:95-110)."""
+    """(ins, del, sub) of the minimum edit distance alignment of hyp against ref, with the tie order of the
+    reference's LevenshteinEditDistance (K/util/edit-distance-inl.h:78-122, as compute-wer calls it,
+    VB/src/bin/compute-wer.cpp:95-110): a substitution/match only when it is strictly cheaper than both other
+    moves, else a deletion when it is strictly cheaper than an insertion, else an insertion.  The total is the
+    same under any order; the split into ins/del/sub is not, and this is the one the host ComputeWer prints."""
     ref, hyp = list(ref), list(hyp)
-    R, H = len(ref), len(hyp)
-    # cost, ins, del, sub per cell; row by row
-    prev = [(j, j, 0, 0) for j in range(H + 1)]
-    for i in range(1, R + 1):
-        cur = [(i, 0, i, 0)]
-        for j in range(1, H + 1):
-            c_sub = prev[j - 1]
-            if ref[i - 1] == hyp[j - 1]:
-                best = c_sub
+    R = len(ref)
+    # column r of a row: (cost, ins, del, sub) of the best alignment of the hypothesis prefix with ref[:r]
+    row = [(r, 0, r, 0) for r in range(R + 1)]
+    for h in hyp:
+        c0 = row[0]
+        cur = [(c0[0] + 1, c0[1] + 1, c0[2], c0[3])]
+        for r in range(1, R + 1):
+            up, left, diag = row[r], cur[r - 1], row[r - 1]
+            miss = int(h != ref[r - 1])
+            c_ins, c_del, c_sub = up[0] + 1, left[0] + 1, diag[0] + miss
+            if c_sub < c_ins and c_sub < c_del:
+                cur.append((c_sub, diag[1], diag[2], diag[3] + miss))
+            elif c_del < c_ins:
+                cur.append((c_del, left[1], left[2] + 1, left[3]))
             else:
-                best = (c_sub[0] + 1, c_sub[1], c_sub[2], c_sub[3] + 1)
-            c_del = prev[j]
-            cand = (c_del[0] + 1, c_del[1], c_del[2] + 1, c_del[3])
-            if cand[0] < best[0]:
-                best = cand
-            c_ins = cur[j - 1]
-            cand = (c_ins[0] + 1, c_ins[1] + 1, c_ins[2], c_ins[3])
-            if cand[0] < best[0]:
-                best = cand
-            cur.append(best)
-        prev = cur
-    return prev[H][1], prev[H][2], prev[H][3]
+                cur.append((c_ins, up[1] + 1, up[2], up[3]))
+        row = cur
+    return row[R][1], row[R][2], row[R][3]
 
 
 def score(refs, hyps):

@@ -111,3 +111,47 @@ def write_wav(path, samples, rate=16000):
         f.setsampwidth(2)
         f.setframerate(rate)
         f.writeframes(np.asarray(samples, "<i2").tobytes())
+
+
+def write_raw_lattice_ark(path, lattices, graph_start=0):
+    """Binary archive of state-level lattices (OpenFst VectorFst<LatticeArc>, arc type "lattice4") from search results in the
+    canonical form of vbh_lattice / the oracle (tokens sorted by (frame, HCLG state); links by source): one state per
+    token, the start token becomes state 0, arcs (ilabel, olabel, (graph, acoustic)), final weights (final cost, 0) --
+    what GetRawLattice builds (K/decoder/lattice-faster-decoder.cc:110-192).  lattices: {key: result dict}."""
+    def s_(x):
+        return np.int32(len(x)).tobytes() + x
+    with open(path, "wb") as f:
+        for key, r in lattices.items():
+            tf, ts = np.asarray(r["tok_frame"]), np.asarray(r["tok_state"])
+            n = len(tf)
+            start_idx = 0
+            for i in range(n):
+                if tf[i] != 0:
+                    break
+                if ts[i] == graph_start:
+                    start_idx = i
+            remap = np.arange(n)
+            remap[:start_idx] += 1
+            if n:
+                remap[start_idx] = 0
+            src = remap[np.asarray(r["link_src"], np.int64)]
+            dst = remap[np.asarray(r["link_dst"], np.int64)]
+            order = np.argsort(src, kind="stable")
+            cnt = np.bincount(src, minlength=n)
+            fin = np.full(n, np.inf, np.float32)
+            fin[remap] = np.asarray(r["tok_final"], np.float32)
+            arcs = np.zeros(len(src), dtype=[("il", "<i4"), ("ol", "<i4"), ("g", "<f4"), ("a", "<f4"), ("nx", "<i4")])
+            arcs["il"] = np.asarray(r["link_ilabel"])[order]
+            arcs["ol"] = np.asarray(r["link_olabel"])[order]
+            arcs["g"] = np.asarray(r["link_graph"], np.float32)[order]
+            arcs["a"] = np.asarray(r["link_acoustic"], np.float32)[order]
+            arcs["nx"] = dst[order]
+            f.write(key.encode() + b" ")
+            f.write(np.int32(2125659606).tobytes() + s_(b"vector") + s_(b"lattice4") + np.int32(2).tobytes() + np.int32(0).tobytes() +
+                    np.uint64(3).tobytes() + np.int64(0 if n else -1).tobytes() + np.int64(n).tobytes() + np.int64(len(src)).tobytes())
+            pos = 0
+            for s in range(n):
+                w0 = fin[s]
+                f.write(np.float32(w0).tobytes() + np.float32(0.0 if np.isfinite(w0) else np.inf).tobytes() + np.int64(cnt[s]).tobytes())
+                f.write(arcs[pos:pos + cnt[s]].tobytes())
+                pos += int(cnt[s])

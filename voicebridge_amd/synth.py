@@ -19,6 +19,26 @@ def wave(i, seconds=30.0, sr=16000, seed=1234):
     return np.clip(np.round(x * 8000.0), -32768, 32767).astype(np.int16)
 
 
+def wave_batch_device(ids, seconds, device, sr=16000, seed=1234):
+    """The same family of utterances as wave(), synthesised on the device (torch), one distinct waveform per id: tone
+    frequency, modulation rate and the noise stream all depend on the id.  Returns an int16 tensor [len(ids) x n] on
+    `device`.  The noise comes from the device's Philox generator seeded per utterance, so a given (id, device type)
+    always yields the same samples; they are not the samples wave() draws with numpy for that id."""
+    import torch
+    n = int(round(seconds * sr))
+    out = torch.empty((len(ids), n), dtype=torch.int16, device=device)
+    t = torch.arange(n, dtype=torch.float64, device=device) / sr
+    g = torch.Generator(device=device)
+    for k, i in enumerate(ids):
+        i = int(i)
+        g.manual_seed(seed + 7919 * i)
+        f0 = 200.0 + 5.0 * (i % 400) + 0.37 * ((i // 400) % 13)
+        x = 0.3 * torch.sin(2 * np.pi * f0 * t) + 0.1 * torch.randn(n, generator=g, device=device, dtype=torch.float32).double()
+        x = x * (0.6 + 0.4 * torch.sin(2 * np.pi * (0.7 + 0.01 * (i % 50) + 0.003 * ((i // 50) % 17)) * t))
+        out[k] = torch.clamp(torch.round(x * 8000.0), -32768, 32767).to(torch.int16)
+    return out
+
+
 def chirp(seconds=2.0, sr=16000):
     n = int(seconds * sr)
     t = np.arange(n) / sr
