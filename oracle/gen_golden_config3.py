@@ -188,6 +188,23 @@ def main():
         assert A == R, "host determinizer differs from the reference's program on the reference's raw lattices"
         det_equal = np.array([int(A[k] == B[k]) for k in sorted(A)], np.int32)
         det_sizes = np.array([[len(A[k][2]), sum(len(s[1]) for s in A[k][2]), len(B[k][2]), sum(len(s[1]) for s in B[k][2])] for k in sorted(A)], np.int32)
+        # what differs where they are not identical: word labels / structure, transition-id strings, or weights only
+        det_diff = []
+        for k in sorted(A):
+            if A[k] == B[k]:
+                det_diff.append("identical")
+                continue
+            sa, sb = A[k][2], B[k][2]
+            if len(sa) != len(sb) or any(len(x[1]) != len(y[1]) for x, y in zip(sa, sb)):
+                det_diff.append("structure")
+                continue
+            labels = all([(a[0], a[4]) for a in x[1]] == [(a[0], a[4]) for a in y[1]] for x, y in zip(sa, sb))
+            tids = all([a[3] for a in x[1]] == [a[3] for a in y[1]] and x[0][2] == y[0][2] for x, y in zip(sa, sb))
+            wmax = max([abs(a[1] - b[1]) + abs(a[2] - b[2]) for x, y in zip(sa, sb) for a, b in zip(x[1], y[1])] +
+                       [abs(x[0][0] - y[0][0]) + abs(x[0][1] - y[0][1]) for x, y in zip(sa, sb) if np.isfinite(x[0][0]) and np.isfinite(y[0][0])] + [0.0])
+            det_diff.append("same words and next states: %s; same transition-id strings: %s; max weight difference %.3g" % (labels, tids, wmax))
+        out["determinized_difference"] = np.array(det_diff)
+        print("\n".join("  %s: %s" % kv for kv in zip(sorted(A), det_diff)), flush=True)
         out["determinized_equal"] = det_equal
         out["determinized_sizes"] = det_sizes      # ref states, ref arcs, our states, our arcs
         print("determinized lattices identical: %d / %d; sizes %s" % (det_equal.sum(), len(det_equal), det_sizes.tolist()), flush=True)
