@@ -707,6 +707,15 @@ def main():
             ctx.sync()
             t_ = ctx.timer_ms(0)
             gmm_alone_ms = t_ if gmm_alone_ms is None else min(gmm_alone_ms, t_)
+    # the MFCC kernel alone on the whole chip, the same way (its share of the pipelined step says little about the kernel)
+    mfcc_alone_ms = None
+    for _ in range(3):
+        ctx.timer_start(0)
+        mf.compute_packed(d_wave, woff, is_i16, out=ring[0][0])
+        ctx.timer_stop(0)
+        ctx.sync()
+        t_ = ctx.timer_ms(0)
+        mfcc_alone_ms = t_ if mfcc_alone_ms is None else min(mfcc_alone_ms, t_)
     if dec is not None:
         dec = last_done[0].dec
         tl = np.array([dec.timeline(u) for u in range(args.batch)], np.int64)
@@ -763,6 +772,15 @@ def main():
                 gmm_roof[k_] = v_
             gmm_roof["frac"] = gmm_roof["achieved"] / F32_MFMA_PEAK_TFLOPS
             gmm_roof["hbm_frac"] = gmm_roof["hbm_GBs"] / HBM_PEAK_GBS
+        # MFCC: SURVEY.md 8d: 160 new int16 samples in + 13 floats out = 372 B and ~15 kflop per frame
+        m_bytes, m_flops = 372.0 * T, 15.0e3 * T
+        extra_mfcc = {"kernel": "mfcc512_kernel", "bound": "hbm", "achieved": m_bytes / (mfcc_alone_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                      "unit": "GB/s", "frac": m_bytes / (mfcc_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": mfcc_alone_ms,
+                      "algorithmic_bytes": m_bytes, "algorithmic_flops": m_flops, "gflops": m_flops / (mfcc_alone_ms * 1e-3) / 1e9,
+                      "frames_per_s": T / (mfcc_alone_ms * 1e-3),
+                      "note": "kernel alone on the chip, HIP events on its stream, best of 3 after the timed region; HBM-bound by its arithmetic intensity "
+                              "(40 flop/B) only in principle: a frame is a 512-point FFT plus three small dot-product stages through LDS, so the kernel "
+                              "is bound by LDS/VALU issue, and the fraction of the HBM roof is small by construction"}
         stage_ms = {"mfcc+featpost": float(np.mean(feat_ms)), "gmm": g_ms}
         roof = gmm_roof
         extra = {}
@@ -838,6 +856,7 @@ def main():
             "roofline": roof, "stage_ms": stage_ms,
         }
         out.update(extra)
+        out["roofline_mfcc"] = extra_mfcc
         # HBM traffic of the dominant kernels from the committed rocprofv3 --pmc passes of this
         # same command (profiles/): only attached when the batch size matches that run
         try:

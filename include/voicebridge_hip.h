@@ -71,7 +71,7 @@ enum { VBH_WIN_HANNING = 0, VBH_WIN_HAMMING = 1, VBH_WIN_POVEY = 2, VBH_WIN_RECT
 
 typedef struct vbh_mfcc_opts {
   float samp_freq, frame_shift_ms, frame_length_ms;
-  float dither;               /* must be 0: the reference's dither draws from libc rand() */
+  float dither;               /* reference default 1.0; here drawn from a counter-based generator, see vbh_mfcc_set_dither_stream */
   float preemph_coeff;
   int32_t remove_dc_offset, window_type, round_to_power_of_two;
   float blackman_coeff;
@@ -86,7 +86,7 @@ typedef struct vbh_mfcc_opts {
   int32_t htk_compat;
 } vbh_mfcc_opts;
 
-void vbh_mfcc_opts_default(vbh_mfcc_opts *o);                    /* reference defaults, dither = 0 */
+void vbh_mfcc_opts_default(vbh_mfcc_opts *o);                    /* reference defaults except dither = 0 (bit parity needs it) */
 int32_t vbh_mfcc_num_frames(const vbh_mfcc_opts *o, int64_t num_samples); /* K/feat/feature-window.cc:41-87 */
 
 typedef struct vbh_mfcc vbh_mfcc;
@@ -103,6 +103,12 @@ void vbh_mfcc_destroy(vbh_mfcc *m);
 int vbh_mfcc_compute(vbh_mfcc *m, const void *d_wave, int wave_is_int16,
                      const int64_t *h_wave_offsets, int32_t n_utt, float *d_feats,
                      int64_t *h_frame_offsets);
+/* Dither (Dither(), K/feat/feature-window.cc:90-98: dither * N(0,1) added to every sample of the extracted window).  The
+ * reference draws from libc rand(), a sequential stream no parallel code can replay; here the normal of (utterance, frame,
+ * window sample) comes from a counter-based generator (Philox2x32-10 + Box-Muller): same distribution, NOT the same bits --
+ * parity tests use dither = 0.  The noise is a pure function of (seed, first_utt_index + position of the utterance in the
+ * call, frame, sample), so a job gets the same features however it is cut into calls.  Defaults: a fixed seed, index 0. */
+int vbh_mfcc_set_dither_stream(vbh_mfcc *m, uint64_t seed, int64_t first_utt_index);
 
 /* ------------------------------------------------------------------ feature post-processing
  * replaces the apply-cmvn | add-deltas | [splice-feats | transform-feats final.mat] |

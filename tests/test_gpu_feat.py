@@ -23,9 +23,13 @@ def ctx():
     c.close()
 
 
+@pytest.mark.parametrize("generic", [False, True])
 @pytest.mark.parametrize("name", MFCC_CASES)
-def test_mfcc_golden(ctx, name):
+def test_mfcc_golden(ctx, name, generic, monkeypatch):
+    """both kernels: the wave-per-frame radix-4 one for 512-point windows and the general radix-2 one"""
     from voicebridge_amd import api
+    if generic:
+        monkeypatch.setenv("VBH_MFCC_GENERIC", "1")
     g = load(name)
     kw, vtln = mfcc_kwargs(parse_opts(g["opts"]))
     m = api.Mfcc(ctx, vtln_warp=vtln, **kw)
@@ -66,10 +70,62 @@ def test_mfcc_empty_batch(ctx):
     m.close()
 
 
-def test_mfcc_rejects_dither(ctx):
-    from voicebridge_amd import api, _lib
-    with pytest.raises(_lib.VbhError):
-        api.Mfcc(ctx, dither=1.0)
+def test_mfcc_odd_offsets_and_float_input_vs_oracle(ctx):
+    """utterances of odd length put their successors at odd sample offsets (the fast kernel's paired 32-bit loads need the
+    16-bit path there); float input takes the same code with other loads"""
+    from oracle import vbo
+    from voicebridge_amd import api, synth
+    waves = [synth.wave(0, 0.5)[:-1], synth.wave(1, 0.4)[:-3], synth.wave(2, 0.3)]
+    o = vbo.mfcc_opts()
+    for cast in (np.int16, np.float32):
+        m = api.Mfcc(ctx)
+        feats, foff = m.compute([w.astype(cast) for w in waves])
+        feats = feats.cpu().numpy()
+        for u, w in enumerate(waves):
+            np.testing.assert_allclose(feats[foff[u]:foff[u + 1]], vbo.mfcc(w.astype(np.float32), o), atol=MFCC_ATOL, rtol=1e-5)
+        m.close()
+
+
+@pytest.mark.parametrize("generic", [False, True])
+def test_mfcc_dither_is_standard_normal_noise(ctx, generic, monkeypatch):
+    """Dither (K/feat/feature-window.cc:90-98): dither * N(0,1) on every window sample.  The reference's libc rand() stream
+    cannot be replayed, so the check is statistical: on a silent wave the raw log-energy of a frame is log of a
+    chi-square(399)-distributed sum (window of 400 samples, mean removed), frames and utterances get different noise, a seed
+    reproduces it, and the stream does not depend on how a job is cut into calls."""
+    from voicebridge_amd import api
+    if generic:
+        monkeypatch.setenv("VBH_MFCC_GENERIC", "1")
+    silent = [np.zeros(16000 * 4, np.int16), np.zeros(16000 * 4, np.int16)]
+    m = api.Mfcc(ctx, dither=1.0)
+    a, foff = m.compute(silent)
+    a = a.cpu().numpy()
+    e = np.exp(a[:, 0].astype(np.float64))                 # column 0 = raw log-energy (use_energy default)
+    n = len(e)
+    assert n == 2 * 398
+    # chi-square with 399 degrees of freedom: mean 399, variance 798
+    assert abs(e.mean() - 399.0) < 5 * np.sqrt(798.0 / n)
+    assert 0.8 * 798.0 < e.var() < 1.25 * 798.0
+    assert not np.allclose(a[foff[0]:foff[1]], a[foff[1]:foff[2]])      # utterances differ
+    assert np.abs(np.diff(a[:, 0])).min() > 0                           # frames differ
+    b, _ = m.compute(silent)
+    np.testing.assert_array_equal(a, b.cpu().numpy())                   # reproducible
+    # the second utterance alone, announced as utterance 1 of the job: the same features as inside the batch
+    m.set_dither_stream(first_utt_index=1)
+    c, _ = m.compute(silent[1:])
+    np.testing.assert_array_equal(c.cpu().numpy(), a[foff[1]:foff[2]])
+    m.set_dither_stream(seed=1234)
+    d, _ = m.compute(silent)
+    assert not np.allclose(d.cpu().numpy(), a)
+    # scaling: dither = 3 -> variance 9 times larger
+    m3 = api.Mfcc(ctx, dither=3.0)
+    e3 = np.exp(m3.compute(silent)[0].cpu().numpy()[:, 0].astype(np.float64))
+    assert abs(e3.mean() / 9.0 - 399.0) < 5 * np.sqrt(798.0 / n)
+    # a loud signal is hardly changed by dither 1.0 (that is its purpose: only digital silence is affected)
+    from voicebridge_amd import synth
+    w = [synth.wave(5, 1.0)]
+    x0 = api.Mfcc(ctx).compute(w)[0].cpu().numpy()
+    x1 = api.Mfcc(ctx, dither=1.0).compute(w)[0].cpu().numpy()
+    assert 0 < np.abs(x0 - x1).max() < 0.05
 
 
 @pytest.mark.parametrize("name", ["post_13", "post_9_lda"])

@@ -100,6 +100,13 @@ class Mfcc:
     def num_frames(self, num_samples):
         return self.lib.vbh_mfcc_num_frames(C.byref(self.opts), int(num_samples))
 
+    def set_dither_stream(self, seed=None, first_utt_index=0):
+        """noise stream of the dither (vbh_mfcc_set_dither_stream): a seed and the job-wide index of the next call's first utterance"""
+        if seed is not None:
+            self._seed = int(seed)
+        self.lib.vbh_mfcc_set_dither_stream.argtypes = [C.c_void_p, C.c_uint64, C.c_int64]
+        check(self.lib.vbh_mfcc_set_dither_stream(self.h, getattr(self, "_seed", 0x4F6CDD1D2545F491), int(first_utt_index)), "vbh_mfcc_set_dither_stream")
+
     def pack(self, waves):
         """list of 1-D int16/float32 arrays -> (device tensor, int64 offsets[n+1], is_int16)"""
         is_i16 = all(w.dtype == np.int16 for w in waves)

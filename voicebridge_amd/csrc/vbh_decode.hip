@@ -2190,6 +2190,12 @@ static int decode_batch_end_impl(vbh_decoder *d) {
           grow(p_tfin, tok_cap_now, want_t)) return -1;
       if (grow(p_ls, link_cap_now, want_l) || grow(p_ld, link_cap_now, want_l) || grow(p_li, link_cap_now, want_l) || grow(p_lo, link_cap_now, want_l) ||
           grow(p_lg, link_cap_now, want_l) || grow(p_la, link_cap_now, want_l)) return -1;
+      // the per-frame cost offsets are reserved per attempt as well
+      {
+        const long long want_c = 2 * (long long)used[2] + 1;
+        if (want_c > d->pool_cost_cap) { if (grow(d->p_co, d->pool_cost_cap, want_c)) return -1; d->pool_cost_cap = want_c; }
+        d->h_pool.cost_cap = d->pool_cost_cap; d->h_pool.cost_offsets = d->p_co.p;
+      }
       tok_cap_now = std::max(tok_cap_now, want_t); link_cap_now = std::max(link_cap_now, want_l);
       d->pool_tok_cap = std::max(d->pool_tok_cap, tok_cap_now); d->pool_link_cap = std::max(d->pool_link_cap, link_cap_now);
       Pool &pool = d->h_pool;

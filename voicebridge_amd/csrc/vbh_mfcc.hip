@@ -14,6 +14,20 @@
 // Tables follow feature-window.cc:109-131, mel-computations.cc:33-144,255-261 and
 // matrix/matrix-functions.cc:592-608 (computed on the host in the same float/double mix).
 //
+// Two kernels.  mfcc512_kernel is the path of the reference's own configuration (25 ms windows at
+// 16 kHz -> N = 512; up to 32 mel bins): one wavefront per frame with NO workgroup barrier in the
+// frame loop -- a lane keeps four complex points of the 256-point FFT in registers, the four
+// radix-4 Stockham passes exchange them through a per-wave LDS buffer (in-order LDS, wave-level
+// fences only), sums are DPP reductions.  mfcc_kernel is the general one (any power-of-two
+// window up to 4096, radix-2).
+//
+// Dither (feature-window.cc:90-98, applied to the extracted window before DC removal): the
+// reference adds dither * N(0,1) drawn from libc rand(), which no parallel code can replay.
+// Here every window sample gets an independent standard normal from a counter-based generator
+// (Philox2x32-10 keyed by a seed, counter = utterance, frame, sample pair; Box-Muller): the same
+// distribution, reproducible for a given seed and independent of batching, not the reference's
+// bit stream.
+//
 // Algorithmic traffic per frame: 160 new int16 samples in, num_ceps floats
 // out = 372 B at the defaults; ~15 kflop.
 #include "vbh_internal.h"
@@ -33,6 +47,9 @@ struct MfccParams {
   int snip_edges, remove_dc, use_energy, raw_energy, htk_compat, htk_mode, use_lifter;
   float preemph, energy_floor, log_energy_floor;
   int melw_total;                   // total packed mel weights
+  float dither;                     // 0 = off
+  unsigned seed_lo, seed_hi;        // dither stream
+  long long utt_base;               // job-wide index of the call's first utterance (noise independent of batching)
 };
 
 struct vbh_mfcc_tables {
@@ -56,6 +73,266 @@ template <bool kInt16>
 __device__ __forceinline__ float load_sample(const void *wave, long long i) {
   if (kInt16) return (float)reinterpret_cast<const short *>(wave)[i];
   return reinterpret_cast<const float *>(wave)[i];
+}
+
+
+// ---- dither noise: two independent N(0,1) for window samples (2p, 2p+1) of frame f of utterance u
+__device__ __forceinline__ void dither_pair(const MfccParams &p, long long utt, int frame, int pair, float &n0, float &n1) {
+  unsigned c0 = (unsigned)frame, c1 = ((unsigned)pair & 0xFFFu) | ((unsigned)utt << 12);
+  unsigned key = p.seed_lo ^ (unsigned)((unsigned long long)utt >> 20) * 0x9E3779B9u ^ p.seed_hi * 0x85EBCA6Bu;
+#pragma unroll
+  for (int r = 0; r < 10; r++) {      // Philox2x32-10
+    const unsigned hi = __umulhi(0xD256D193u, c0), lo = 0xD256D193u * c0;
+    c0 = hi ^ key ^ c1; c1 = lo;
+    key += 0x9E3779B9u;
+  }
+  const float u1 = (float)((c0 >> 8) + 1u) * (1.0f / 16777216.0f);      // (0, 1]
+  const float u2 = (float)(c1 >> 8) * (1.0f / 16777216.0f);             // [0, 1)
+  const float r = sqrtf(-2.0f * __logf(u1));
+  float sn, cs;
+  __sincosf(6.283185307179586f * u2, &sn, &cs);
+  n0 = r * cs; n1 = r * sn;
+}
+
+// sum over the wave on the VALU (DPP row shifts + row broadcasts), result on every lane
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define VBH_DPPF(x, ctrl, rm, bc) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rm, 0xf, bc))
+  v += VBH_DPPF(v, 0x111, 0xf, true);
+  v += VBH_DPPF(v, 0x112, 0xf, true);
+  v += VBH_DPPF(v, 0x114, 0xf, true);
+  v += VBH_DPPF(v, 0x118, 0xf, true);
+  v += VBH_DPPF(v, 0x142, 0xa, false);
+  v += VBH_DPPF(v, 0x143, 0xc, false);
+#undef VBH_DPPF
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // the LDS queue of a wave is in order; this only keeps the compiler from moving LDS accesses of
+  // different lanes' data across each other
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// padded index of the per-wave FFT buffer (one extra slot per 16: spreads the stride-4 writes over the banks)
+__device__ __forceinline__ int fpad(int i) { return i + (i >> 4); }
+
+constexpr int kFastN = 512, kFastM = 256;
+constexpr int kFastBuf = kFastM + (kFastM >> 4);    // float2 slots
+
+// dynamic LDS layout (floats): window[512] | t256[2*256] | t512[2*132] | dct[nceps*nbins] | lifter[nceps] | melw[melw_total] |
+//   mel meta ints [3*nbins] | per wave: buf[2*kFastBuf] ps[260] mel[32]
+template <bool kInt16, bool kDither>
+__global__ __launch_bounds__(256) void mfcc512_kernel(MfccParams p, vbh_mfcc_tables t, const float *t256, const float *t512, const void *wave,
+                                                      const long long *wave_offsets, const long long *frame_offsets, const int *chunk_utt,
+                                                      const int *chunk_f0, int n_chunks, float *feats) {
+  extern __shared__ __align__(16) float lds[];
+  float *s_window = lds;
+  float2 *s_t256 = reinterpret_cast<float2 *>(s_window + kFastN);
+  float2 *s_t512 = s_t256 + 256;
+  float *s_dct = reinterpret_cast<float *>(s_t512 + 132);
+  float *s_lifter = s_dct + p.nceps * p.nbins;
+  float *s_melw = s_lifter + p.nceps;
+  int *s_melmeta = reinterpret_cast<int *>(s_melw + p.melw_total);
+  float *s_wave0 = reinterpret_cast<float *>(s_melmeta + 3 * p.nbins);
+  constexpr int per_wave = 2 * kFastBuf + 260 + 32;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int i = tid; i < kFastN; i += 256) s_window[i] = i < p.flen ? t.window[i] : 0.0f;
+  for (int i = tid; i < 256; i += 256) s_t256[i] = make_float2(t256[2 * i], t256[2 * i + 1]);
+  for (int i = tid; i < 129; i += 256) s_t512[i] = make_float2(t512[2 * i], t512[2 * i + 1]);
+  for (int i = tid; i < p.nceps * p.nbins; i += 256) s_dct[i] = t.dct[i];
+  for (int i = tid; i < p.nceps; i += 256) s_lifter[i] = t.lifter[i];
+  for (int i = tid; i < p.melw_total; i += 256) s_melw[i] = t.mel_w[i];
+  for (int i = tid; i < p.nbins; i += 256) {
+    s_melmeta[i] = t.mel_first[i];
+    s_melmeta[p.nbins + i] = t.mel_len[i];
+    s_melmeta[2 * p.nbins + i] = t.mel_off[i];
+  }
+  __syncthreads();
+  float2 *buf = reinterpret_cast<float2 *>(s_wave0 + wid * per_wave);
+  float *s_ps = reinterpret_cast<float *>(buf + kFastBuf);
+  float *s_mel = s_ps + 260;
+  const int flen = p.flen;
+  // mel: two lanes per filter when they fit
+  const int mel_parts = 2 * p.nbins <= 64 ? 2 : 1;
+  const int mel_b = mel_parts == 2 ? lane >> 1 : lane, mel_h = mel_parts == 2 ? lane & 1 : 0;
+  int m_first = 0, m_len = 0, m_off = 0;
+  if (mel_b < p.nbins) { m_first = s_melmeta[mel_b]; m_len = s_melmeta[p.nbins + mel_b]; m_off = s_melmeta[2 * p.nbins + mel_b]; }
+
+  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const int utt = chunk_utt[chunk], f0 = chunk_f0[chunk];
+    const long long w0 = wave_offsets[utt], nsamp = wave_offsets[utt + 1] - w0;
+    const long long row0 = frame_offsets[utt];
+    const int T = (int)(frame_offsets[utt + 1] - row0);
+    int f_end = f0 + kChunkFrames;
+    if (f_end > T) f_end = T;
+    for (int f = f0 + wid; f < f_end; f += kWaves) {
+      // ---- ExtractWindow (feature-window.cc:162-220): lane l holds the sample pairs p = l + 64 k, k < 4,
+      //      i.e. the complex points z[l + 64 k] of the N/2-point FFT -- the inputs of radix-4 butterfly l
+      long long start;
+      if (p.snip_edges) start = (long long)f * p.shift;
+      else start = (long long)p.shift * f + p.shift / 2 - flen / 2;
+      const bool edge = start < 0 || start + flen > nsamp;
+      float xe[4], xo[4];
+      if (!edge && kInt16 && (((w0 + start) & 1) == 0)) {
+        const unsigned *wp = reinterpret_cast<const unsigned *>(reinterpret_cast<const short *>(wave) + (w0 + start));
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int i0 = 2 * (lane + 64 * k);
+          unsigned v = 0;
+          if (i0 + 1 < flen) v = wp[lane + 64 * k];
+          xe[k] = (float)(short)(v & 0xFFFFu); xo[k] = (float)(short)(v >> 16);
+          if (i0 + 1 >= flen && i0 < flen) { xe[k] = load_sample<kInt16>(wave, w0 + start + i0); xo[k] = 0.0f; }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int i0 = 2 * (lane + 64 * k);
+          float a = 0.0f, b = 0.0f;
+          if (i0 < flen) {
+            long long s0 = start + i0;
+            while (s0 < 0 || s0 >= nsamp) s0 = (s0 < 0) ? (-s0 - 1) : (2 * nsamp - 1 - s0);
+            a = load_sample<kInt16>(wave, w0 + s0);
+          }
+          if (i0 + 1 < flen) {
+            long long s1 = start + i0 + 1;
+            while (s1 < 0 || s1 >= nsamp) s1 = (s1 < 0) ? (-s1 - 1) : (2 * nsamp - 1 - s1);
+            b = load_sample<kInt16>(wave, w0 + s1);
+          }
+          xe[k] = a; xo[k] = b;
+        }
+      }
+      // ---- ProcessWindow (feature-window.cc:133-156)
+      if (kDither) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int pr = lane + 64 * k;
+          if (2 * pr < flen) {
+            float n0, n1;
+            dither_pair(p, p.utt_base + utt, f, pr, n0, n1);
+            xe[k] += p.dither * n0;
+            if (2 * pr + 1 < flen) xo[k] += p.dither * n1;
+          }
+        }
+      }
+      if (p.remove_dc) {
+        const float mean = wave_sum_dpp((xe[0] + xo[0]) + (xe[1] + xo[1]) + (xe[2] + xo[2]) + (xe[3] + xo[3])) / (float)flen;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int i0 = 2 * (lane + 64 * k);
+          if (i0 < flen) xe[k] -= mean;
+          if (i0 + 1 < flen) xo[k] -= mean;
+        }
+      }
+      float log_energy = 0.f;
+      if (p.use_energy && p.raw_energy) {
+        float e = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) e += xe[k] * xe[k] + xo[k] * xo[k];
+        log_energy = logf(fmaxf(wave_sum_dpp(e), FLT_EPSILON));
+      }
+      float2 a[4];
+      {
+        // pre-emphasis reads the un-emphasised left neighbour; sample 0 uses itself
+        float prev[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          float up = __shfl_up(xo[k], 1, 64);
+          if (lane == 0) up = k > 0 ? 0.0f : xe[0];
+          prev[k] = up;
+        }
+#pragma unroll
+        for (int k = 1; k < 4; k++) {
+          const float last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xo[k - 1]), 63));
+          if (lane == 0) prev[k] = last;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int i0 = 2 * (lane + 64 * k);
+          float ye = xe[k], yo = xo[k];
+          if (p.preemph != 0.f) { ye -= p.preemph * prev[k]; yo -= p.preemph * xe[k]; }
+          const float2 w = *reinterpret_cast<const float2 *>(s_window + i0);
+          a[k] = make_float2(ye * w.x, yo * w.y);
+        }
+      }
+      if (p.use_energy && !p.raw_energy) {  // feature-mfcc.cc:39-41
+        float e2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) e2 += a[k].x * a[k].x + a[k].y * a[k].y;
+        log_energy = logf(fmaxf(wave_sum_dpp(e2), FLT_MIN));
+      }
+      // ---- 256-point complex FFT: four radix-4 Stockham passes, butterfly j = lane
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const int Ns = 1 << (2 * s);
+        const int k = lane & (Ns - 1);
+        if (s > 0) {
+          wave_lds_fence();
+#pragma unroll
+          for (int q = 0; q < 4; q++) a[q] = buf[fpad(lane + 64 * q)];
+          const int m = k * (64 >> (2 * s));
+          const float2 w1 = s_t256[m], w2 = s_t256[2 * m];
+          const float2 w3 = cmul(w1, w2);
+          a[1] = cmul(a[1], w1); a[2] = cmul(a[2], w2); a[3] = cmul(a[3], w3);
+          wave_lds_fence();
+        }
+        const float2 t0 = make_float2(a[0].x + a[2].x, a[0].y + a[2].y), t1 = make_float2(a[0].x - a[2].x, a[0].y - a[2].y);
+        const float2 t2 = make_float2(a[1].x + a[3].x, a[1].y + a[3].y), d = make_float2(a[1].x - a[3].x, a[1].y - a[3].y);
+        const float2 t3 = make_float2(d.y, -d.x);      // -i (b1 - b3)
+        const int o = ((lane - k) << 2) + k;
+        buf[fpad(o)] = make_float2(t0.x + t2.x, t0.y + t2.y);
+        buf[fpad(o + Ns)] = make_float2(t1.x + t3.x, t1.y + t3.y);
+        buf[fpad(o + 2 * Ns)] = make_float2(t0.x - t2.x, t0.y - t2.y);
+        buf[fpad(o + 3 * Ns)] = make_float2(t1.x - t3.x, t1.y - t3.y);
+      }
+      wave_lds_fence();
+      // ---- real-FFT split + ComputePowerSpectrum (feature-functions.cc:29-51): bins k and N/2 - k from one pair
+      {
+        auto split = [&](int kk) {
+          const float2 zk = buf[fpad(kk)], zm = buf[fpad((kFastM - kk) & (kFastM - 1))];
+          const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
+          const float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
+          const float2 c = s_t512[kk];
+          const float tr = orr * c.x - oi * c.y, ti = orr * c.y + oi * c.x;
+          s_ps[kk] = (er + tr) * (er + tr) + (ei + ti) * (ei + ti);
+          s_ps[kFastM - kk] = (er - tr) * (er - tr) + (ei - ti) * (ei - ti);
+        };
+        split(lane); split(lane + 64);
+        if (lane == 0) split(128);
+      }
+      wave_lds_fence();
+      // ---- MelBanks::Compute + floor + log (mel-computations.cc:228-253, feature-mfcc.cc:54-55)
+      {
+        float e = 0.f;
+        for (int i = mel_h; i < m_len; i += mel_parts) e = fmaf(s_melw[m_off + i], s_ps[m_first + i], e);
+        if (mel_parts == 2) e += __shfl_xor(e, 1, 64);
+        if (p.htk_mode && e < 1.0f) e = 1.0f;
+        if (mel_b < p.nbins && mel_h == 0) s_mel[mel_b] = logf(fmaxf(e, FLT_EPSILON));
+      }
+      wave_lds_fence();
+      // ---- DCT, lifter, energy / C0, htk reorder (feature-mfcc.cc:57-79)
+      if (lane < p.nceps) {
+        float v = 0.f;
+        for (int b = 0; b < p.nbins; b++) v = fmaf(s_dct[lane * p.nbins + b], s_mel[b], v);
+        if (p.use_lifter) v *= s_lifter[lane];
+        if (p.use_energy && lane == 0) {
+          float le = log_energy;
+          if (p.energy_floor > 0.f && le < p.log_energy_floor) le = p.log_energy_floor;
+          v = le;
+        }
+        int col = lane;
+        if (p.htk_compat) {
+          if (lane == 0) {
+            col = p.nceps - 1;
+            if (!p.use_energy) v *= 1.41421356237309504880f;
+          } else col = lane - 1;
+        }
+        feats[(row0 + f) * p.nceps + col] = v;
+      }
+      wave_lds_fence();
+    }
+  }
 }
 
 // dynamic LDS layout (floats):
@@ -122,6 +399,11 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccParams p, vbh_mfcc_tables
               while (s < 0 || s >= nsamp) s = (s < 0) ? (-s - 1) : (2 * nsamp - 1 - s);
             }
             v = load_sample<kInt16>(wave, w0 + s);
+            if (p.dither != 0.0f) {
+              float n0, n1;
+              dither_pair(p, p.utt_base + utt, f, i >> 1, n0, n1);
+              v += p.dither * ((i & 1) ? n1 : n0);
+            }
             part += v;
           }
           bufA[i] = v;
@@ -240,6 +522,8 @@ struct vbh_mfcc {
   vbh_mfcc_opts opts;
   MfccParams p;
   DevBuf<float> window, twiddle, mel_w, dct, lifter;
+  DevBuf<float> t256, t512;        // fast kernel: exp(-2 pi i m / 256), m < 256; exp(-2 pi i k / 512), k <= 128
+  bool fast = false; size_t fast_lds = 0;
   DevBuf<int> mel_first, mel_len, mel_off;
   DevBuf<long long> d_wave_off, d_frame_off;
   DevBuf<int> d_chunk_utt, d_chunk_f0;
@@ -296,7 +580,7 @@ int32_t vbh_mfcc_num_frames(const vbh_mfcc_opts *o, int64_t num_samples) {
 
 int vbh_mfcc_create(vbh_ctx *ctx, const vbh_mfcc_opts *o, float vtln_warp, vbh_mfcc **out) {
   VBH_CHECK(ctx && o && out, "vbh_mfcc_create: NULL argument");
-  VBH_CHECK(o->dither == 0.0f, "vbh_mfcc_create: dither must be 0 (the reference's dither uses libc rand())");
+  VBH_CHECK(o->dither >= 0.0f, "vbh_mfcc_create: negative dither");
   const int flen = win_size(o), N = padded_size(o), shift = win_shift(o);
   VBH_CHECK(flen > 1 && shift > 0, "vbh_mfcc_create: bad frame length/shift");
   VBH_CHECK((N & (N - 1)) == 0 && N >= 64 && N <= 4096, "vbh_mfcc_create: padded window %d must be a power of two in [64, 4096]", N);
@@ -392,7 +676,17 @@ int vbh_mfcc_create(vbh_ctx *ctx, const vbh_mfcc_opts *o, float vtln_warp, vbh_m
   p.use_lifter = o->cepstral_lifter != 0.0f; p.preemph = o->preemph_coeff;
   p.energy_floor = o->energy_floor; p.log_energy_floor = o->energy_floor > 0.0f ? logf(o->energy_floor) : 0.0f;
   p.melw_total = (int)melw.size();
+  p.dither = o->dither; p.seed_lo = 0x2545F491u; p.seed_hi = 0x4F6CDD1Du; p.utt_base = 0;
   hipStream_t s = ctx->stream;
+  m->fast = N == kFastN && flen <= kFastN && nb <= 32 && o->num_ceps <= 32 && !getenv("VBH_MFCC_GENERIC");
+  if (m->fast) {
+    std::vector<float> t256(512), t512(2 * 129);
+    for (int i = 0; i < 256; i++) { const double ang = 6.283185307179586476925286766559005 * i / 256.0; t256[2 * i] = (float)cos(ang); t256[2 * i + 1] = (float)-sin(ang); }
+    for (int i = 0; i <= 128; i++) { const double ang = 6.283185307179586476925286766559005 * i / 512.0; t512[2 * i] = (float)cos(ang); t512[2 * i + 1] = (float)-sin(ang); }
+    if (m->t256.upload(t256.data(), t256.size(), s) || m->t512.upload(t512.data(), t512.size(), s)) { delete m; return -1; }
+    m->fast_lds = sizeof(float) * (kFastN + 2 * 256 + 2 * 132 + (size_t)o->num_ceps * nb + o->num_ceps + melw.size() + 3 * nb +
+                                   kWaves * (2 * (size_t)kFastBuf + 260 + 32));
+  }
   if (m->window.upload(window.data(), window.size(), s) || m->twiddle.upload(tw.data(), tw.size(), s) ||
       m->mel_w.upload(melw.data(), melw.size(), s) || m->dct.upload(dct.data(), dct.size(), s) ||
       m->lifter.upload(lifter.data(), lifter.size(), s) || m->mel_first.upload(first.data(), nb, s) ||
@@ -414,6 +708,13 @@ void vbh_mfcc_destroy(vbh_mfcc *m) {
   (void)hipSetDevice(m->ctx->device);
   (void)hipStreamSynchronize(m->ctx->stream);
   delete m;
+}
+
+int vbh_mfcc_set_dither_stream(vbh_mfcc *m, uint64_t seed, int64_t first_utt_index) {
+  VBH_CHECK(m, "vbh_mfcc_set_dither_stream: NULL argument");
+  m->p.seed_lo = (unsigned)seed; m->p.seed_hi = (unsigned)(seed >> 32);
+  m->p.utt_base = first_utt_index;
+  return 0;
 }
 
 int vbh_mfcc_compute(vbh_mfcc *m, const void *d_wave, int wave_is_int16, const int64_t *h_wave_offsets,
@@ -443,7 +744,19 @@ int vbh_mfcc_compute(vbh_mfcc *m, const void *d_wave, int wave_is_int16, const i
   vbh_mfcc_tables t{m->window.p, m->twiddle.p, m->mel_first.p, m->mel_len.p, m->mel_off.p, m->mel_w.p, m->dct.p, m->lifter.p};
   const int n_chunks = (int)cu.size();
   int grid = n_chunks < 8 * m->ctx->num_cus ? n_chunks : 8 * m->ctx->num_cus;
-  if (wave_is_int16) {
+  if (m->fast) {
+#define VBH_LAUNCH_FAST(I16, DIT)                                                                                                       \
+    {                                                                                                                                   \
+      VBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc512_kernel<I16, DIT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)m->fast_lds));                                                                                   \
+      hipLaunchKernelGGL((mfcc512_kernel<I16, DIT>), dim3(grid), dim3(256), m->fast_lds, s, m->p, t, m->t256.p, m->t512.p, d_wave,      \
+                         d_wave_off, d_frame_off, d_chunk_utt, d_chunk_f0, n_chunks, d_feats);                                          \
+    }
+    const bool dit = m->p.dither != 0.0f;
+    if (wave_is_int16) { if (dit) VBH_LAUNCH_FAST(true, true) else VBH_LAUNCH_FAST(true, false) }
+    else { if (dit) VBH_LAUNCH_FAST(false, true) else VBH_LAUNCH_FAST(false, false) }
+#undef VBH_LAUNCH_FAST
+  } else if (wave_is_int16) {
     VBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes));
     hipLaunchKernelGGL(mfcc_kernel<true>, dim3(grid), dim3(256), m->lds_bytes, s, m->p, t, d_wave, d_wave_off,
                        d_frame_off, d_chunk_utt, d_chunk_f0, n_chunks, d_feats);

@@ -206,15 +206,18 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
              "raw-energy", "cepstral-lifter", "htk-compat", "output-format", "subtract-mean", "vtln-warp", "vtln-map",
              "utt2spk", "channel", "min-duration",
              // extensions of this build: what the MakeMfcc step otherwise pipes through copy-feats (VB/scr/steps/make_mfcc.cpp:215)
-             "compress", "write-num-frames"});
+             "compress", "write-num-frames", "dither-seed"});
     po.Parse(argc, argv);
     if (po.args.size() != 2) throw ApiError("wrong arguments.");
     vbh_mfcc_opts o;
     vbh_mfcc_opts_default(&o);
-    // the reference default for --dither is 1.0; it cannot be reproduced (libc rand()), so the
-    // caller has to ask for 0 explicitly -- a silent change of default would hide the difference
+    // --dither: the reference's default 1.0 (K/feat/feature-window.h:55), so that a stock mfcc.conf runs.  The noise has the
+    // reference's distribution but comes from a counter-based generator, not from libc rand() (include/voicebridge_hip.h,
+    // vbh_mfcc_set_dither_stream): features equal the reference's statistically, bit for bit only with --dither=0.
+    // --dither-seed (extension) selects the stream; an utterance's noise depends on the seed and on its position in the table.
     o.dither = (float)po.Num("dither", 1.0);
-    if (o.dither != 0.0f) throw ApiError("--dither=" + po.Str("dither", "1.0 (default)") + " is not supported: pass --dither=0");
+    if (o.dither < 0.0f) throw ApiError("--dither must not be negative");
+    const uint64_t dither_seed = (uint64_t)po.Num("dither-seed", 0.0);
     o.samp_freq = (float)po.Num("sample-frequency", o.samp_freq);
     o.frame_length_ms = (float)po.Num("frame-length", o.frame_length_ms);
     o.frame_shift_ms = (float)po.Num("frame-shift", o.frame_shift_ms);
@@ -253,6 +256,7 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
     vbh_mfcc *mf = nullptr;
     Check(vbh_mfcc_create(ctx, &o, vtln_warp, &mf), "vbh_mfcc_create");
     int num_utts = 0, num_success = 0;
+    size_t num_success_batches_base = 0;      // utterances handed to the device so far: the dither stream's utterance index
     // utterances are packed into batches of ~64 M samples per device pass
     size_t i = 0;
     while (i < scp.size()) {
@@ -307,6 +311,9 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
       DevMem d_wave(ctx, sizeof(float) * samples.size()), d_feats(ctx, sizeof(float) * (size_t)total * o.num_ceps);
       Check(vbh_copy_h2d(ctx, d_wave.p, samples.data(), sizeof(float) * samples.size()), "vbh_copy_h2d");
       std::vector<int64_t> foff(keys.size() + 1);
+      if (o.dither != 0.0f)
+        Check(vbh_mfcc_set_dither_stream(mf, dither_seed ? dither_seed : 0x4F6CDD1D2545F491ull, (int64_t)num_success_batches_base), "vbh_mfcc_set_dither_stream");
+      num_success_batches_base += keys.size();
       Check(vbh_mfcc_compute(mf, d_wave.p, 0, woff.data(), (int32_t)keys.size(), (float *)d_feats.p, foff.data()), "vbh_mfcc_compute");
       std::vector<float> feats((size_t)total * o.num_ceps);
       Check(vbh_copy_d2h(ctx, feats.data(), d_feats.p, sizeof(float) * feats.size()), "vbh_copy_d2h");
