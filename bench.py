@@ -65,8 +65,14 @@ def parse():
     ap.add_argument("--det-steps", type=int, default=8, help="steps of that second timed region")
     ap.add_argument("--det-threads", type=int, default=0, help="host threads of the lattice stage (0: 16, the CPU share of a one-GPU box)")
     ap.add_argument("--probe", action="store_true", help="print search statistics of the first utterances and exit")
+    ap.add_argument("--sweep-mean-scale", default="",
+                    help="comma-separated --mean-scale values: for each, one batch is scored and searched (one batch at a time, no pipeline) and a JSON "
+                         "line with the search's difficulty (tokens, arcs per frame, share of frames bound by max-/min-active) and its rate is printed; "
+                         "then exit.  RTF as a function of search difficulty")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-seconds", type=float, default=360.0, help="audio seconds timed on the CPU baseline (about 20 s of one core)")
+    ap.add_argument("--cpu-sample-seconds", type=float, default=120.0,
+                    help="audio seconds one process of the CPU baseline decodes (whole speakers; the default is one speaker of four 30 s utterances, "
+                         "about 10-30 s of one core depending on how hard the search is)")
     return ap.parse_args()
 
 
@@ -493,7 +499,9 @@ def main():
     feats = post.apply(raw, foff, utt2spk=utt2spk, cmvn_stats=stats, spk_xforms=xforms)
     ctx.sync()
     T = int(foff[-1])
-    model = feature_space_model(args, feats[: min(T, 20000)].cpu().numpy())
+    # the random GMM is placed in the feature space of the whole batch: a sample of frames spread over all utterances
+    sample_idx = torch.linspace(0, T - 1, min(T, 20000), device=dev).long()
+    model = feature_space_model(args, feats[sample_idx].cpu().numpy())
     gmm = api.DiagGmm(ctx, *model)
     ll = torch.empty((T, gmm.num_pdfs), dtype=torch.float32, device=dev)
     ctx.torch_sync()
@@ -510,6 +518,29 @@ def main():
                                      lattice_beam=args.lattice_beam, exact_cutoff=True))
         ctx.sync()
 
+    if args.sweep_mean_scale and dec is not None:
+        for ms_ in [float(x) for x in args.sweep_mean_scale.split(",") if x]:
+            args.mean_scale = ms_
+            gm = api.DiagGmm(ctx, *feature_space_model(args, feats[sample_idx].cpu().numpy()))
+            gm.loglikes(feats, out=ll)
+            ctx.sync()
+            best = None
+            for _ in range(2):
+                dec.decode(ll, foff, t2p)
+                tm = dec.times()
+                best = tm["kernel_ms"] if best is None else min(best, tm["kernel_ms"])
+            c = dict(tok=0, arc=0, new=0, link=0, maxb=0, minb=0, lat=0, words=0)
+            for u in range(args.batch):
+                r = dec.result(u, arrays=False)
+                c["tok"] += r["n_tokens_expanded"]; c["arc"] += r["n_arcs_expanded"]; c["new"] += r["n_tokens_created"]; c["link"] += r["n_links_created"]
+                c["maxb"] += r["n_frames_maxactive_bound"]; c["minb"] += r["n_frames_minactive_bound"]; c["lat"] += r["num_links"]; c["words"] += len(r["words"])
+            print(json.dumps({"mean_scale": ms_, "utterances": args.batch, "frames": T, "search_kernel_ms": best, "frames_per_s_search_only": T / (best * 1e-3),
+                              "rtf_search_only": 100.0 * best * 1e-3 / T, "tokens_expanded_per_frame": c["tok"] / T, "arcs_per_frame": c["arc"] / T,
+                              "tokens_created_per_frame": c["new"] / T, "links_per_frame": c["link"] / T, "share_frames_maxactive_bound": c["maxb"] / T,
+                              "share_frames_minactive_bound": c["minb"] / T, "lattice_arcs_per_frame": c["lat"] / T, "words_per_utterance": c["words"] / args.batch,
+                              "batch_stats": dec.batch_stats()}), flush=True)
+            gm.close()
+        return
     if args.probe and dec is not None and os.environ.get("VBH_PROBE_FASTER"):
         # the 1-best search (FasterDecoder, vbh_faster_*) on the same scores
         gmm.loglikes(feats, out=ll)
@@ -550,6 +581,13 @@ def main():
                 rk = lambda x: np.argsort(np.argsort(x))
                 rho = np.corrcoef(rk(prox), rk(dur))[0, 1]
                 print("proxy theta=%g: spearman rho with per-utterance time = %.3f (pearson %.3f)" % (theta, rho, np.corrcoef(prox, dur)[0, 1]))
+        agg = np.zeros(6)
+        for u in range(args.batch):
+            r = dec.result(u, arrays=False)
+            agg += [r["n_tokens_expanded"], r["n_arcs_expanded"], r["n_tokens_created"], r["n_links_created"], r["n_frames_maxactive_bound"], r["n_frames_minactive_bound"]]
+        print("all utterances: tok_expanded/frame=%.0f arcs/frame=%.0f created/frame=%.0f links/frame=%.0f maxbound %.1f%% minbound %.1f%% of frames; %s; "
+              "search kernel %.0f frames/s" % (agg[0] / T, agg[1] / T, agg[2] / T, agg[3] / T, 100 * agg[4] / T, 100 * agg[5] / T, dec.batch_stats(),
+                                             T / (dec.times()["kernel_ms"] * 1e-3)))
         for u in range(min(args.batch, 4)):
             r = dec.result(u, arrays=False)
             nf = max(r["num_frames"], 1)
@@ -586,8 +624,10 @@ def main():
             L.ctx, L.dec = ctx, dec
         else:
             L.ctx = api.Context(local_rank, priority=int(os.environ.get("VBH_BENCH_DEC_PRIO", "0")), cus=args.search_cus)
+            # the lanes' decoders draw their search workspaces from one pool (vbh_decoder_create_shared)
             L.dec = api.LatticeDecoder(L.ctx, graph, args.batch, Tmax, beam=args.beam, max_active=args.max_active,
-                                                         min_active=200, lattice_beam=args.lattice_beam, acoustic_scale=0.083333)
+                                       min_active=200, lattice_beam=args.lattice_beam, acoustic_scale=0.083333,
+                                       share_slots_with=lanes[0].dec if lanes else None)
         L.pending = False
         L.timed = False
         lanes.append(L)
@@ -795,6 +835,7 @@ def main():
                                     "additive; a search kernel's duration includes the time its workgroups wait for CUs still held "
                                     "by the previous batch's grid" % (depth, depth))
             extra["search_grid_last_batch"] = grid_stats
+            extra["search_retries_last_batch"] = dec.batch_stats()
             # algorithmic bytes of the search from the counters of the last step:
             # N_tok*(20+16) + N_arc*(16+4) + N_new*16 + N_link*24
             c = dict(tok=0, arc=0, new=0, link=0, maxb=0, minb=0, lat_tok=0, lat_link=0)

@@ -211,6 +211,12 @@ typedef struct vbh_decoder vbh_decoder;
 /* max_frames bounds the longest utterance, max_batch the utterances searched concurrently */
 int vbh_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_decode_cfg *cfg,
                        int32_t max_batch, int32_t max_frames, vbh_decoder **out);
+/* The same, drawing its search workspaces from the pool of another decoder of the same device, graph size and capacity
+ * settings (share_slots_with; NULL = a pool of its own): decoders on several contexts/streams of one device then keep
+ * several batches in flight out of ONE set of workspaces -- the workgroups of whatever grids are resident claim and return
+ * slots -- instead of one set per decoder.  The pool lives as long as any decoder that uses it. */
+int vbh_decoder_create_shared(vbh_ctx *ctx, const vbh_graph *graph, const vbh_decode_cfg *cfg,
+                              int32_t max_batch, int32_t max_frames, vbh_decoder *share_slots_with, vbh_decoder **out);
 void vbh_decoder_destroy(vbh_decoder *d);
 /* Replaces LatticeFasterDecoder::Decode + FinalizeDecoding for a batch of utterances
  * (DecodeUtteranceLatticeFaster, K/decoder/decoder-wrappers.cc:198-293).  d_loglikes

@@ -125,7 +125,7 @@ def test_mfcc_dither_is_standard_normal_noise(ctx, generic, monkeypatch):
     w = [synth.wave(5, 1.0)]
     x0 = api.Mfcc(ctx).compute(w)[0].cpu().numpy()
     x1 = api.Mfcc(ctx, dither=1.0).compute(w)[0].cpu().numpy()
-    assert 0 < np.abs(x0 - x1).max() < 0.05
+    assert 0 < np.abs(x0 - x1).max() < 0.5
 
 
 @pytest.mark.parametrize("name", ["post_13", "post_9_lda"])

@@ -262,3 +262,80 @@ def test_decode_fmllr_end_to_end(host, tmp_path):
     # a missing silence list is an error
     os.remove(graph / "phones" / "silence.csl")
     assert host.vb_DecodeFmllr(*args, 1, b"0.0", 9, 9) == -1 and b"silence.csl" in host.vb_steps_last_error()
+
+
+def test_decode_lda_mllt_sat_model_against_the_reference_chain(host, tmp_path):
+    """Config 4 of SURVEY.md 8d: an LDA+MLLT+SAT model directory (final.mat 40 x 117, splice_opts, D = 40, per-speaker 40 x 41
+    transforms from trans_dir).  Decode() must build apply-cmvn | splice-feats | transform-feats final.mat | transform-feats
+    trans.JOB | gmm-latgen-faster (VB/scr/steps/decode_gmm.cpp:102-106, 243-267): checked against this build's bin functions
+    run by hand (identical lattices) and against the reference's own programs run on the same files (features within float
+    tolerance, same best-path words)."""
+    from tests import util
+    from tests.test_host_lattice import assert_same_archives
+    from voicebridge_amd import synth
+    d = tmp_path
+    data, conf, utts = make_datadir(d, n_utt=6, n_spk=3, seconds=1.2)
+    assert host.vb_MakeMfcc(str(data).encode(), str(conf).encode(), 2, 0, 0) == 0, host.vb_steps_last_error()      # uncompressed: same inputs for both sides
+    assert host.vb_ComputeCmvnStatsDir(str(data).encode()) == 0
+    H, n_cd, n_words, D = 3, 10, 30, 40
+    P = n_cd * H
+    g, _ = synth.lexicon_graph(n_words, P, seed=3, n_phones=n_cd)
+    rng = np.random.default_rng(12)
+    q, _r = np.linalg.qr(rng.standard_normal((117, D)))
+    lda = np.ascontiguousarray(q.T, np.float32)                      # final.mat: 40 x 117, orthonormal rows
+    # place the model in the space of the spliced + projected features of this data
+    assert call(host.vb_ApplyCmvn, ["apply-cmvn", "--utt2spk=ark:%s" % (data / "utt2spk"), "scp:%s" % (data / "cmvn.scp"), "scp:%s" % (data / "feats.scp"),
+                                    "ark:%s" % (d / "all_c.ark")], "") == 0
+    sample = np.concatenate([np.concatenate([np.pad(m, ((4, 4), (0, 0)), mode="edge")[k:k + len(m)] for k in range(9)], 1) @ lda.T
+                             for m in read_fm_ark(str(d / "all_c.ark")).values()])
+    offs, w, means, iv = synth.gmm_model(P, P * 3, D, seed=4, mean_scale=1.5, dim_scale=sample.std(0) + 1e-3, var_spread=0.3)
+    means = means + sample.mean(0).astype(np.float32)
+    exp = d / "exp" / "tri3b"
+    graph = exp / "graph"
+    graph.mkdir(parents=True)
+    util.write_mdl(str(exp / "final.mdl"), n_cd, H, offs, w, (means * iv).astype(np.float32), iv)
+    util.write_vector_fst(str(graph / "HCLG.fst"), g["final"], g["arc_offset"], g["arcs"])
+    (graph / "words.txt").write_text("<eps> 0\n" + "".join("w%d %d\n" % (i, i) for i in range(1, n_words + 2)))
+    with open(exp / "final.mat", "wb") as f:
+        f.write(b"\0BFM " + bytes([4]) + np.int32(D).tobytes() + bytes([4]) + np.int32(117).tobytes() + lda.astype("<f4").tobytes())
+    (exp / "splice_opts").write_text("--left-context=4 --right-context=4\n")
+    trans = exp / "decode_si"
+    trans.mkdir()
+    (trans / "num_jobs").write_text("1\n")
+    with open(trans / "trans.1", "wb") as f:
+        for k in range(3):
+            m = synth.affine(D, seed=20 + k)
+            f.write(b"spk%d \0BFM " % k + bytes([4]) + np.int32(D).tobytes() + bytes([4]) + np.int32(D + 1).tobytes() + m.astype("<f4").tobytes())
+    dec = exp / "decode_test"
+    assert host.vb_DecodeEx(str(graph).encode(), str(data).encode(), str(dec).encode(), b"", str(trans).encode(), 2, 0.083333, 7000, 13.0, 6.0,
+                            1, b"0.0", 9, 9) == 0, host.vb_steps_last_error()
+    words = {l.split()[0]: l.split()[1:] for j in (1, 2) for l in (dec / ("w.%d" % j)).read_text().split("\n") if l.strip()}
+    assert sorted(words) == utts
+    log = str(d / "hand.log")
+    latgen = ["--max-active=7000", "--beam=13.000000", "--lattice-beam=6.000000", "--acoustic-scale=0.083333", "--allow-partial=true",
+              str(exp / "final.mdl"), str(graph / "HCLG.fst")]
+    for j in (1, 2):
+        sd = data / "split2" / str(j)
+        # ---- this build's bin functions, archive to archive
+        assert call(host.vb_ApplyCmvn, ["apply-cmvn", "--utt2spk=ark:%s" % (sd / "utt2spk"), "scp:%s" % (sd / "cmvn.scp"), "scp:%s" % (sd / "feats.scp"), "ark:%s" % (d / "c.ark")], log) == 0
+        assert call(host.vb_SpliceFeats, ["splice-feats", "--left-context=4", "--right-context=4", "ark:%s" % (d / "c.ark"), "ark:%s" % (d / "sp.ark")]) == 0
+        assert call(host.vb_TransformFeats, ["transform-feats", str(exp / "final.mat"), "ark:%s" % (d / "sp.ark"), "ark:%s" % (d / "ld.ark")], log) == 0
+        assert call(host.vb_TransformFeats, ["transform-feats", "--utt2spk=ark:%s" % (sd / "utt2spk"), "ark:%s" % (trans / "trans.1"), "ark:%s" % (d / "ld.ark"), "ark:%s" % (d / "tf.ark")], log) == 0
+        assert call(host.vb_GmmLatgenFaster, ["gmm-latgen-faster"] + latgen + ["ark:%s" % (d / "tf.ark"), "ark:%s" % (d / "hand.lat")], log) == 0
+        assert_same_archives(str(d / "hand.lat"), str(dec / ("lat.%d" % j)))
+        mine = read_fm_ark(str(d / "tf.ark"))
+        assert all(m.shape[1] == D for m in mine.values())
+        if have_ref("splice-feats") and have_ref("gmm-latgen-faster"):
+            # ---- the reference's programs on the same split directory
+            ref("apply-cmvn", "--utt2spk=ark:%s" % (sd / "utt2spk"), "scp:%s" % (sd / "cmvn.scp"), "scp:%s" % (sd / "feats.scp"), "ark:%s" % (d / "r_c.ark"))
+            ref("splice-feats", "--left-context=4", "--right-context=4", "ark:%s" % (d / "r_c.ark"), "ark:%s" % (d / "r_sp.ark"))
+            ref("transform-feats", str(exp / "final.mat"), "ark:%s" % (d / "r_sp.ark"), "ark:%s" % (d / "r_ld.ark"))
+            ref("transform-feats", "--utt2spk=ark:%s" % (sd / "utt2spk"), "ark:%s" % (trans / "trans.1"), "ark:%s" % (d / "r_ld.ark"), "ark:%s" % (d / "r_tf.ark"))
+            theirs = read_fm_ark(str(d / "r_tf.ark"))
+            assert list(theirs) == list(mine)
+            for u in mine:
+                np.testing.assert_allclose(mine[u], theirs[u], rtol=1e-5, atol=2e-4)
+            ref("gmm-latgen-faster", *latgen, "ark:%s" % (d / "r_tf.ark"), "ark:%s" % (d / "r.lat"), "ark,t:%s" % (d / "r_w.txt"))
+            rw = {l.split()[0]: l.split()[1:] for l in (d / "r_w.txt").read_text().split("\n") if l.strip()}
+            for u in rw:
+                assert rw[u] == words[u], u

@@ -59,6 +59,7 @@
 #include <thread>
 #include <climits>
 #include <cmath>
+#include <memory>
 #include <mutex>
 
 namespace {
@@ -100,7 +101,30 @@ constexpr int HBITS = NT >= 1024 ? 13 : (NT >= 512 ? 12 : 11);
 constexpr int HCAP = 1 << HBITS;            // slots of the per-frame state map in LDS (8 per thread)
 constexpr int HPROBE = 16;                  // probes before a state is sent to the table in HBM
 constexpr unsigned HEMPTY = 0xFFFFFFFFu;
-constexpr int DIRTY_FRAMES = NT >= 1024 ? (1 << 16) : (1 << 15);   // frames covered by the dirty bitmap (8 / 4 KB of LDS)
+// VBH_LL_LDS: the frame's row of acoustic scores (P floats, fetched coalesced at the start of the frame) is kept in LDS, so
+// that the per-arc score lookup of pass 1 is an LDS read instead of a third dependent global access (token -> state -> arc
+// -> score); models of more than LLCAP pdfs read the row from global memory as before
+#ifndef VBH_LL_LDS
+#define VBH_LL_LDS 0           // measured (r02): 1 is 15 % slower at 1024 threads -- see DESIGN.md (register allocation of the frame loop)
+#endif
+constexpr int LLCAP = VBH_LL_LDS ? 2560 : 1;
+constexpr int DIRTY_FRAMES = VBH_LL_LDS ? (1 << 14) : (NT >= 1024 ? (1 << 16) : (1 << 15));   // frames covered by the dirty bitmap (2 KB of LDS); later frames count as dirty
+
+// The pruning and compaction passes run once per pruning interval; as functions of their own they get their own register
+// allocation instead of competing with the per-frame passes for the kernel's 128 VGPRs (VBH_OUTLINE=0: inlined, as before)
+#ifndef VBH_OUTLINE
+#define VBH_OUTLINE 0          // measured (r02, tools/variants.py): 1 and 2 are 15 % slower -- the call sites cost the hot loop more registers than the callees free
+#endif
+#if VBH_OUTLINE
+#define VBH_COLD __attribute__((noinline))
+#else
+#define VBH_COLD
+#endif
+#if VBH_OUTLINE >= 2
+#define VBH_WARM __attribute__((noinline))
+#else
+#define VBH_WARM
+#endif
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
@@ -177,7 +201,7 @@ struct Pool {   // dense per-batch output
 };
 
 enum { ERR_NONE = 0, ERR_W_TOK = 1, ERR_W_LINK = 2, ERR_H_TOK = 3, ERR_H_LINK = 4, ERR_FRONT = 5,
-       ERR_EPS_LOOP = 6, ERR_POOL = 7, ERR_CAND = 8 };
+       ERR_EPS_LOOP = 6, ERR_POOL = 7, ERR_CAND = 8, ERR_NOT_RUN = 9 };
 
 // order-preserving map float -> uint32
 __device__ __forceinline__ unsigned f2o(float f) {
@@ -328,6 +352,7 @@ struct Shared {
   unsigned hs[HCAP], hc[HCAP]; int ht[HCAP];
   int use_lds_map;
   float cost[COST_CAP];            // costs of the current frame's tokens (GetCutoff)
+  float ll[LLCAP];                 // the frame's acoustic scores (VBH_LL_LDS)
   // compaction job: token frames and link segments in source order
   int j_ntf, j_nseg, j_tf0, j_tdst, j_ldst;
   int tbeg[MAX_WIN_FRAMES + 1], tbase[MAX_WIN_FRAMES], tcnt[MAX_WIN_FRAMES], tup[MAX_WIN_FRAMES];
@@ -372,7 +397,7 @@ __device__ __forceinline__ float frame_cost(const Shared &sh, gp<const i32x4> to
 
 // k-th smallest (0-based) of the current frame's costs: exact radix select on the
 // order-preserving keys (the std::nth_element value in GetCutoff, lattice-faster-decoder.cc:654-676)
-__device__ float select_kth(gp<const i32x4> tok, int n, int k, Shared &sh) {
+__device__ VBH_WARM float select_kth(gp<const i32x4> tok, int n, int k, Shared &sh) {
   const int tid = threadIdx.x;
   __syncthreads();
   if (tid == 0) { sh.sel_prefix = 0; sh.sel_mask = 0; sh.sel_k = k; }
@@ -575,7 +600,7 @@ __device__ int prune_frame(const Slot &s, int f, float lattice_beam, float delta
 // since its last evaluation would be recomputed to the same values.  extra_costs only grow as
 // the frontier advances, so values left stale by an intermediate pass are lower bounds and
 // pruning with them never removes anything the final pass keeps.
-__device__ void prune_backward(const Slot &s, int from, int first_unpruned, int stop_at, float lattice_beam, float delta,
+__device__ VBH_COLD void prune_backward(const Slot &s, int from, int first_unpruned, int stop_at, float lattice_beam, float delta,
                                bool final, Shared &sh, int &pp) {
   int visited = 0;
   int above = 3;   // result of the frame above: the frontier counts as changed
@@ -809,7 +834,7 @@ __device__ bool recompact_tail(const Slot &s, Shared &sh) {
 // Move the survivors of the raw window into the history: tokens of frames (prev_front, front],
 // emitting links from frames [prev_front, front-1], epsilon links within (prev_front, front].
 // Returns false (uniformly) on overflow.
-__device__ bool compact_window(const Slot &s, int prev_front, int front, Shared &sh) {
+__device__ VBH_COLD bool compact_window(const Slot &s, int prev_front, int front, Shared &sh) {
   const int tid = threadIdx.x;
   const int old_tail_tb = sh.tail_tok_b;
   const bool had_tail = sh.tail_f1 >= 0;
@@ -929,7 +954,7 @@ __device__ __forceinline__ void map_clear(Shared &sh) {
 // Iterates until no cost changes, then stores the final costs and writes the epsilon links.
 // Returns the first link index of the frame's epsilon links; on return a barrier has made all
 // writes visible.
-__device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, float cutoff, unsigned ep,
+__device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, int nb, float cutoff, unsigned ep,
                                    int cur, Shared &sh) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   gp<Ent> ent = uptr(s.ent);
@@ -1036,7 +1061,40 @@ __device__ int process_nonemitting(const DevGraph &g, const Slot &s, int nb, flo
   return lb;
 }
 
-__global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g, DecCfg cfg, const Slot *slots,
+// Search workspaces ("slots") of one device are a pool shared by every decoder created on it with
+// vbh_decoder_create_shared: the persistent grids of several batches are resident at the same time (the grid of batch k
+// drains while those of batches k+1, k+2 fill the freed CUs), so a workgroup cannot own slot blockIdx.x; it claims a free
+// slot when it starts and gives it back when it leaves.  At most WG_PER_CU workgroups per CU are resident, the pool holds
+// that many slots, so a resident workgroup always finds one.  The pool is partitioned by XCD (HW_REG_XCC_ID) and a
+// workgroup looks in its own XCD's partition first: the slot's working set then stays in that XCD's L2.  That is a speed
+// matter only -- hand-over is an agent-scope release by the leaving workgroup and an agent-scope acquire by the claiming
+// one, and the only data a new owner reads before writing it are the epoch-stamped state-map entries (older versions carry
+// older epochs and lose every comparison) and the slot's epoch counter (an agent-scope atomic).
+struct SlotPoolDev { int *flags; int n_per_xcd, n_xcd; };
+
+__device__ __forceinline__ int claim_slot(const SlotPoolDev &sp) {
+  const int n = sp.n_per_xcd, nx = sp.n_xcd;
+  int x = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF);     // HW_REG_XCC_ID[3:0]
+  if (x >= nx) x %= nx;
+  const int start = (int)((blockIdx.x / 8u) % (unsigned)n);
+  for (int round = 0; round < 4096; round++) {
+    // own partition first, then the others
+    for (int dx = 0; dx < (round == 0 ? 1 : nx); dx++) {
+      const int part = (x + dx) % nx;
+      for (int k = 0; k < n; k++) {
+        int i = start + k; if (i >= n) i -= n;
+        int *f = sp.flags + part * n + i;
+        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) continue;
+        int expected = 0;
+        if (__hip_atomic_compare_exchange_strong(f, &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return part * n + i;
+      }
+    }
+    __builtin_amdgcn_s_sleep(64);
+  }
+  return -1;      // never expected (the pool holds a slot for every resident workgroup): the utterances are taken by the others
+}
+
+__global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g, DecCfg cfg, const Slot *slots, SlotPoolDev spool,
                                                      const float *__restrict__ loglikes, int P,
                                                      const UttDesc *__restrict__ utts, const int *__restrict__ work_list,
                                                      int n_work, int *work_counter, UttResult *results, const Pool *pool_p) {
@@ -1046,8 +1104,17 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
   __shared__ Slot s_slot;
   __shared__ Pool s_pool;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int my_slot = blockIdx.x;
+  if (spool.flags) {
+    if (tid == 0) sh.utt = claim_slot(spool);
+    __syncthreads();
+    my_slot = sh.utt;
+    __syncthreads();
+    if (my_slot < 0) return;       // (uniform)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
   {
-    const int *src = reinterpret_cast<const int *>(&slots[blockIdx.x]);
+    const int *src = reinterpret_cast<const int *>(&slots[my_slot]);
     int *dst = reinterpret_cast<int *>(&s_slot);
     for (int i = tid; i < (int)(sizeof(Slot) / sizeof(int)); i += NT) dst[i] = src[i];
     const int *psrc = reinterpret_cast<const int *>(pool_p);
@@ -1068,8 +1135,12 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
     const int utt = work_list ? work_list[sh.utt] : sh.utt;
     const UttDesc ud = utts[utt];
     const int T = ud.T;
-    // epochs start at 1: the high word 0xFFFFFFFF is the cleared (memset 0xFF) state
-    const int epoch_base = gptr(s.state)[0] + 1;
+    // epochs start at 1: the high word 0xFFFFFFFF is the cleared (memset 0xFF) state.  The slot's epoch counter is advanced
+    // with an agent-scope atomic: the next owner of the slot (maybe on another XCD) continues after this utterance's epochs
+    if (tid == 0) sh.flag = __hip_atomic_fetch_add(gptr(s.state), T + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int epoch_base = sh.flag + 1;
+    __syncthreads();
     long long c_tok_exp = 0, c_arc_exp = 0;        // per-thread counters, reduced at the end
     long long t_last = clk();
     const long long rt_start = (long long)__builtin_amdgcn_s_memrealtime();
@@ -1152,12 +1223,22 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       //      frame about to be built (its last readers finished before the barrier that ended the
       //      previous frame; its next writers come after this phase's reduction barriers)
       map_clear(sh);
+      const bool ll_lds = VBH_LL_LDS && P <= LLCAP;
+      float llr[(LLCAP + NT - 1) / NT];
+      if (ll_lds) {
+#pragma unroll
+        for (int u = 0; u < (LLCAP + NT - 1) / NT; u++) { const int i = u * NT + tid; llr[u] = i < P ? llrow[i] : 0.0f; }
+      }
       unsigned long long bk = ~0ull;
       for (int i = tid; i < n; i += NT) {
         const i32x4 r = tok[i];
         if (i < COST_CAP) sh.cost[i] = asf(r.y);
         const unsigned long long k = ((unsigned long long)f2o(asf(r.y)) << 32) | (unsigned)(r.x & STMASK);
         bk = k < bk ? k : bk;
+      }
+      if (ll_lds) {      // (its readers come after the reduction barrier below; its last readers were pass 1 of the previous frame)
+#pragma unroll
+        for (int u = 0; u < (LLCAP + NT - 1) / NT; u++) { const int i = u * NT + tid; if (i < P) sh.ll[i] = llr[u]; }
       }
       bk = block_min_u64(bk, sh, par);
       const float best = n > 0 ? o2f((unsigned)(bk >> 32)) : INF;
@@ -1202,7 +1283,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
           const int a0 = sr.x + sr.y, ne = sr.z - sr.y;
           for (int j = lane; j < ne; j += 64) {
             const i32x4 arc = g.arcs[a0 + j];
-            const float ll = cfg.acwt * llrow[arc.z];
+            const float ll = cfg.acwt * (ll_lds ? sh.ll[arc.z] : llrow[arc.z]);
             const float nw = ((asf(arc.y) + cost_offset) - ll) + best;
             if (nw + adaptive_beam < nc) nc = nw + adaptive_beam;
           }
@@ -1231,7 +1312,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
             i32x4 arc; float ac = 0.0f, tot = 0.0f;
             if (valid) {
               arc = g.arcs[a];
-              ac = cost_offset - cfg.acwt * llrow[arc.z];
+              ac = cost_offset - cfg.acwt * (ll_lds ? sh.ll[arc.z] : llrow[arc.z]);
               tot = (cc + ac) + asf(arc.y);
               mymin = fminf(mymin, tot + adaptive_beam);
               c_arc_exp++;
@@ -1543,12 +1624,18 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         for (int i = 0; i < 7; i++) r->t_phase[i] = sh.tph[i];
         r->t_phase[7] = sh.n_visited;   // slot 7: frames visited by pruning (not a time)
         r->t_start = rt_start; r->t_end = (long long)__builtin_amdgcn_s_memrealtime(); r->wg = blockIdx.x; r->pad2 = 0;
-        gptr(s.state)[0] = epoch_base + T + 2;   // next utterance in this slot: disjoint epochs
       }
     }
     __syncthreads();
   }
 #undef PHASE
+  if (spool.flags) {
+    __syncthreads();               // every wave's stores have left for L2
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_store(spool.flags + my_slot, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // per batch: pdf of every emitting arc (arc.z = tid2pdf[ilabel]; -1 for input-epsilon arcs)
@@ -1615,13 +1702,26 @@ struct SlotSet {          // workspaces of one size class
   Slot proto{};
   std::vector<Slot> h;
   DevBuf<Slot> d;
+  // the pool form (see claim_slot): n = n_xcd * n_per_xcd slots claimed through flags; flags.p == nullptr: slot = blockIdx.x
+  DevBuf<int> flags;
+  int n_per_xcd = 0, n_xcd = 1;
+  int device = 0, max_frames = 0, graph_states = 0;
+  vbh_decode_cfg cfg{};
+  std::vector<void *> allocs;
+  SlotPoolDev dev() const { return SlotPoolDev{flags.p, n_per_xcd, n_xcd}; }
+  ~SlotSet() {
+    if (allocs.empty()) return;
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    for (void *p : allocs) (void)hipFree(p);
+  }
 };
 
 struct vbh_decoder {
   vbh_ctx *ctx; const vbh_graph *graph; vbh_decode_cfg cfg;
   int max_frames;
-  SlotSet small_set, big_set;       // big: generous capacities, allocated on first overflow
-  std::vector<void *> allocs;
+  std::shared_ptr<SlotSet> small_set;   // the device's slot pool (shared by the decoders created with vbh_decoder_create_shared)
+  SlotSet big_set;                      // generous capacities, private, allocated on first overflow
   std::vector<HostLattice> results;
   std::vector<UttResult> h_res;
   int n_retried = 0, n_pool_grown = 0, n_failed = 0;   // last batch: searched again in a big slot / pool enlargements / given up
@@ -1650,9 +1750,9 @@ struct vbh_decoder {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
-static int slot_alloc(vbh_decoder *d, size_t bytes, void **p, int memset_val = -2) {
+static int slot_alloc(vbh_decoder *d, SlotSet *set, size_t bytes, void **p, int memset_val = -2) {
   VBH_HIP(hipMalloc(p, bytes ? bytes : 8));
-  d->allocs.push_back(*p);
+  set->allocs.push_back(*p);
   if (memset_val != -2) VBH_HIP(hipMemsetAsync(*p, memset_val, bytes, d->ctx->stream));
   return 0;
 }
@@ -1670,6 +1770,15 @@ static int effective_prune_interval(const vbh_decode_cfg *cfg) {
   return std::min(v, MAX_WIN_FRAMES - 2);
 }
 
+// Regular slots are sized for the common case, not for the worst one: the raw window of forward links is cut to
+// VBH_DEFAULT_LINK_SCALE of its worst-case size (a frame may leave 2 links per new token and 2 x max_active new tokens; over a
+// pruning interval the bench's heaviest utterances stay under a sixth of that), the token window keeps its full size (it is
+// the smaller array and the one heavy utterances do fill).  What outgrows a regular slot is searched again in a big slot,
+// which costs that utterance a second search -- rare by construction; the memory saved is what lets a pool of two slots per
+// CU and several batches of scores be resident on one device.
+#ifndef VBH_DEFAULT_LINK_SCALE
+#define VBH_DEFAULT_LINK_SCALE 0.35
+#endif
 static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
   const vbh_graph *graph = d->graph;
   const vbh_decode_cfg *cfg = &d->cfg;
@@ -1685,7 +1794,7 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
   if (const char *e = getenv("VBH_SLOT_SCALE")) { const double x = atof(e); if (x >= 0.01 && x <= 4.0) slot_scale = x; }
   long long per_frame_tok_s = per_frame_tok;
   if (!big) {
-    per_frame_link = std::max<long long>(1024, (long long)(per_frame_link * slot_scale));
+    per_frame_link = std::max<long long>(1024, (long long)(per_frame_link * slot_scale * VBH_DEFAULT_LINK_SCALE));
     if (slot_scale < 1.0) per_frame_tok_s = std::max<long long>(256, (long long)(per_frame_tok * slot_scale));
   }
   const long long surv_tok = big ? 2048 : 160, surv_link = big ? 4096 : 320;   // lattice survivors per frame
@@ -1704,8 +1813,9 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
   // expanded (GetCutoff), each with at most max_degree arcs
   p.cand_cap = (int)std::min<long long>(std::max<long long>(graph->A, 1),
                                         std::min<long long>((ma + 256) * std::max(graph->max_degree, 1),
-                                                            big ? (1LL << 24) : (long long)((1LL << 21) * slot_scale)));
+                                                            big ? (1LL << 24) : (long long)((1LL << 21) * std::min(1.0, slot_scale))));
   set->proto = p; set->n = n;
+  set->device = d->ctx->device; set->max_frames = max_frames; set->graph_states = graph->S; set->cfg = *cfg;
   set->h.assign(n, p);
   const size_t F = (size_t)max_frames + 2;
   // one allocation per field, covering all slots (slot i owns [i*count, (i+1)*count))
@@ -1713,7 +1823,7 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
 #define A_(field, type, count, ms)                                                                   \
   {                                                                                                  \
     type *base = nullptr;                                                                            \
-    if (slot_alloc(d, sizeof(type) * (size_t)(count) * ns, reinterpret_cast<void **>(&base), ms)) return -1; \
+    if (slot_alloc(d, set, sizeof(type) * (size_t)(count) * ns, reinterpret_cast<void **>(&base), ms)) return -1; \
     for (size_t i = 0; i < ns; i++) set->h[i].field = base + i * (size_t)(count);                    \
   }
   A_(ent, Ent, S, 0xFF)
@@ -1725,6 +1835,11 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
   A_(state, int, 4, 0)
 #undef A_
   if (set->d.upload(set->h.data(), set->h.size(), d->ctx->stream)) return -1;
+  if (!big) {
+    set->n_xcd = 8; set->n_per_xcd = n / 8;       // (n is a multiple of 8, see vbh_decoder_create_shared)
+    if (set->flags.alloc((size_t)n)) return -1;
+    VBH_HIP(hipMemsetAsync(set->flags.p, 0, sizeof(int) * (size_t)n, d->ctx->stream));
+  }
   return 0;
 }
 
@@ -1795,8 +1910,8 @@ void vbh_graph_destroy(vbh_graph *g) {
   delete g;
 }
 
-int vbh_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_decode_cfg *cfg, int32_t max_batch,
-                       int32_t max_frames, vbh_decoder **out) {
+int vbh_decoder_create_shared(vbh_ctx *ctx, const vbh_graph *graph, const vbh_decode_cfg *cfg, int32_t max_batch,
+                              int32_t max_frames, vbh_decoder *share_slots_with, vbh_decoder **out) {
   VBH_CHECK(ctx && graph && cfg && out, "vbh_decoder_create: NULL argument");
   VBH_CHECK(cfg->beam > 0.0f && cfg->max_active > 1 && cfg->lattice_beam > 0.0f && cfg->prune_interval > 0 && cfg->beam_delta > 0.0f,
             "vbh_decoder_create: invalid config (LatticeFasterDecoderConfig::Check)");
@@ -1805,21 +1920,40 @@ int vbh_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_decode_cf
   if (vbh_use_device(ctx)) return -1;
   vbh_decoder *d = new vbh_decoder();
   d->ctx = ctx; d->graph = graph; d->cfg = *cfg; d->max_frames = max_frames;
-  // Two size classes.  "small": sized for the common case (new tokens per frame <= 2*max_active,
-  // a few hundred lattice survivors per frame), four workgroups per CU.  "big": the generous
-  // worst-case sizes, a handful of slots, allocated only when an utterance overflows a small slot;
-  // such utterances are searched again there (vbh_decode_batch), so capacity never truncates a result.
-  if (alloc_slot_set(d, &d->small_set, std::min<int>(max_batch, WG_PER_CU * ctx->num_cus), /*big=*/false)) { vbh_decoder_destroy(d); return -1; }
+  if (share_slots_with) {
+    const SlotSet *o = share_slots_with->small_set.get();
+    const bool ok = o && o->device == ctx->device && o->graph_states == graph->S && o->max_frames >= max_frames &&
+                    o->cfg.max_active >= cfg->max_active && effective_prune_interval(&o->cfg) == effective_prune_interval(cfg);
+    if (!ok) { delete d; vbh_set_error("vbh_decoder_create_shared: the other decoder's search slots do not fit (device, graph size, max_frames, max_active or pruning interval differ)"); return -1; }
+    d->small_set = share_slots_with->small_set;
+    *out = d;
+    return 0;
+  }
+  // Two size classes.  Regular slots: sized for the common case, one per workgroup that can be resident on the device (the
+  // pool claim_slot() draws from), or fewer for small batches.  "big": the generous worst-case sizes, a handful of slots,
+  // allocated only when an utterance overflows a regular slot; such utterances are searched again there (vbh_decode_batch),
+  // so capacity never truncates a result.
+  int dev_cus = ctx->num_cus;
+  { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) dev_cus = prop.multiProcessorCount; }
+  int n = std::min<int>(max_batch, WG_PER_CU * dev_cus);
+  n = (n + 7) & ~7;
+  d->small_set = std::make_shared<SlotSet>();
+  if (alloc_slot_set(d, d->small_set.get(), n, /*big=*/false)) { vbh_decoder_destroy(d); return -1; }
   VBH_HIP(hipStreamSynchronize(ctx->stream));
   *out = d;
   return 0;
+}
+
+int vbh_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_decode_cfg *cfg, int32_t max_batch,
+                       int32_t max_frames, vbh_decoder **out) {
+  return vbh_decoder_create_shared(ctx, graph, cfg, max_batch, max_frames, nullptr, out);
 }
 
 void vbh_decoder_destroy(vbh_decoder *d) {
   if (!d) return;
   (void)hipSetDevice(d->ctx->device);
   (void)hipStreamSynchronize(d->ctx->stream);
-  for (void *p : d->allocs) (void)hipFree(p);
+  d->small_set.reset();
   if (d->pin) (void)hipHostFree(d->pin);
   if (d->stage) (void)hipHostFree(d->stage);
   if (d->ev0) (void)hipEventDestroy(d->ev0);
@@ -1947,6 +2081,7 @@ static const char *err_name(int e) {
     case ERR_EPS_LOOP: return "epsilon closure did not converge (epsilon cycle in the graph?)";
     case ERR_POOL: return "output pool capacity exceeded";
     case ERR_CAND: return "candidate list capacity exceeded";
+    case ERR_NOT_RUN: return "no workgroup searched the utterance";
     default: return "unknown";
   }
 }
@@ -2051,14 +2186,14 @@ static int decode_batch_begin_impl(vbh_decoder *d, const float *d_loglikes, int3
   {
     int probe_frames = 0;
     if (const char *e = getenv("VBH_LPT_PROBE_FRAMES")) probe_frames = atoi(e);
-    if (probe_frames > 0 && n_utt > d->small_set.n) {
+    if (probe_frames > 0 && n_utt > d->small_set->n) {
       const auto tp0 = std::chrono::steady_clock::now();
       std::vector<UttDesc> probe(utts);
       for (auto &u : probe) u.T = std::min(u.T, probe_frames);
       Pool closed = pool; closed.tok_cap = 0; closed.link_cap = 0; closed.cost_cap = 0;
       VBH_HIP(hipMemcpyAsync(d->d_utts.p, probe.data(), sizeof(UttDesc) * n_utt, hipMemcpyHostToDevice, st));
       VBH_HIP(hipMemcpyAsync(d->d_pool.p, &closed, sizeof(Pool), hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(decode_kernel, dim3(std::min(d->small_set.n, n_utt)), dim3(NT), 0, st, dg0, dc0, d->small_set.d.p, d_loglikes,
+      hipLaunchKernelGGL(decode_kernel, dim3(std::min(WG_PER_CU * d->ctx->num_cus, n_utt)), dim3(NT), 0, st, dg0, dc0, d->small_set->d.p, d->small_set->dev(), d_loglikes,
                          (int)num_pdfs, d->d_utts.p, (const int *)nullptr, n_utt, d->d_counter.p, d->d_res.p, d->d_pool.p);
       VBH_HIP(hipGetLastError());
       std::vector<UttResult> pr(n_utt);
@@ -2086,9 +2221,11 @@ static int decode_batch_begin_impl(vbh_decoder *d, const float *d_loglikes, int3
   d->pend.dc = dc0;
   d->pend.d_loglikes = d_loglikes; d->pend.num_pdfs = num_pdfs; d->pend.tok_cap = tok_cap; d->pend.link_cap = link_cap;
   {
-    const int grid = std::min(d->small_set.n, n_utt);
+    // one workgroup per slot the context's CUs can hold (a CU-masked context counts its own CUs), never more than the pool has
+    const int grid = std::min(std::min(d->small_set->n, WG_PER_CU * d->ctx->num_cus), n_utt);
+    VBH_HIP(hipMemsetAsync(d->d_res.p, 0xFF, sizeof(UttResult) * (size_t)n_utt, st));     // error = -1: "no workgroup searched it" until one does
     VBH_HIP(hipEventRecord(d->ev0, st));
-    hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(NT), 0, st, d->pend.dg, d->pend.dc, d->small_set.d.p, d_loglikes, (int)num_pdfs,
+    hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(NT), 0, st, d->pend.dg, d->pend.dc, d->small_set->d.p, d->small_set->dev(), d_loglikes, (int)num_pdfs,
                        d->d_utts.p, d_work_list, n_utt, d->d_counter.p, d->d_res.p, d_pool.p);
     VBH_HIP(hipGetLastError());
     VBH_HIP(hipEventRecord(d->ev1, st));
@@ -2150,7 +2287,8 @@ static int decode_batch_end_impl(vbh_decoder *d) {
   // did not fit are searched again.  What still fails after that -- a big slot too small, an epsilon cycle -- fails alone:
   // the utterance is reported with ok = 0 / error set and the rest of the batch is delivered (the reference logs
   // "Failed to decode" for one utterance and goes on, K/decoder/decoder-wrappers.cc:227-231).
-  auto is_cap = [](int e) { return e == ERR_W_TOK || e == ERR_W_LINK || e == ERR_H_TOK || e == ERR_H_LINK || e == ERR_FRONT || e == ERR_CAND; };
+  auto is_cap = [](int e) { return e == ERR_W_TOK || e == ERR_W_LINK || e == ERR_H_TOK || e == ERR_H_LINK || e == ERR_FRONT || e == ERR_CAND || e == ERR_NOT_RUN; };
+  for (int u = 0; u < n_utt; u++) if (d->h_res[u].error < 0) { d->h_res[u] = UttResult{}; d->h_res[u].error = ERR_NOT_RUN; }
   long long tok_cap_now = tok_cap, link_cap_now = link_cap;
   std::vector<char> tried_big(n_utt, 0);
   d->n_retried = 0; d->n_pool_grown = 0; d->n_failed = 0;
@@ -2216,15 +2354,15 @@ static int decode_batch_end_impl(vbh_decoder *d) {
       if (list.empty()) continue;
       const bool big = pass == 0;
       if (big && d->big_set.n == 0) {
-        if (alloc_slot_set(d, &d->big_set, std::min<int>(8, (int)list.size()), /*big=*/true)) return -1;
+        if (alloc_slot_set(d, &d->big_set, std::min<int>(16, (int)list.size()), /*big=*/true)) return -1;
       }
-      SlotSet &set = big ? d->big_set : d->small_set;
+      SlotSet &set = big ? d->big_set : *d->small_set;
       DevBuf<int> d_list;
       if (d_list.upload(list.data(), list.size(), st)) return -1;
       VBH_HIP(hipMemsetAsync(d_counter.p, 0, sizeof(int), st));
-      const int grid = std::min<int>(set.n, (int)list.size());
+      const int grid = std::min<int>(big ? set.n : std::min(set.n, WG_PER_CU * d->ctx->num_cus), (int)list.size());
       VBH_HIP(hipEventRecord(ev0, st));
-      hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(NT), 0, st, dg, dc, set.d.p, d_loglikes, (int)num_pdfs,
+      hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(NT), 0, st, dg, dc, set.d.p, set.dev(), d_loglikes, (int)num_pdfs,
                          d_utts.p, d_list.p, (int)list.size(), d_counter.p, d_res.p, d_pool.p);
       VBH_HIP(hipGetLastError());
       VBH_HIP(hipEventRecord(ev1, st));

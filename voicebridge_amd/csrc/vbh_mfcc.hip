@@ -121,44 +121,61 @@ __device__ __forceinline__ int fpad(int i) { return i + (i >> 4); }
 constexpr int kFastN = 512, kFastM = 256;
 constexpr int kFastBuf = kFastM + (kFastM >> 4);    // float2 slots
 
-// dynamic LDS layout (floats): window[512] | t256[2*256] | t512[2*132] | dct[nceps*nbins] | lifter[nceps] | melw[melw_total] |
-//   mel meta ints [3*nbins] | per wave: buf[2*kFastBuf] ps[260] mel[32]
+// dynamic LDS layout (floats): t256[2*256] | per wave: buf[2*kFastBuf] mel[32]
+// Per-lane constants live in registers for the whole kernel: the window values of the lane's eight samples, the split
+// twiddles and mel weights of its five spectrum bins, its eight DCT coefficients.
+//   mel: a spectrum bin lies under at most two (adjacent) triangular filters, so bin k carries {lower filter, weight in it,
+//   weight in the next one} (binw, built at create time) and the filter energies are accumulated with LDS float adds straight
+//   from the registers that hold the power spectrum -- no per-filter loop, no spectrum in LDS;
+//   DCT: lane = (cepstral index c = lane & 15, quarter q = lane >> 4) sums the mel bins q, q + 4, ... and two shuffles add
+//   the quarters.
+struct FastTables {
+  const float *t256;      // [256] x (cos, -sin)(2 pi m / 256)
+  const float *t512;      // [129] x (cos, -sin)(2 pi k / 512)
+  const float *binw;      // [257] x {lower filter (as float), weight there, weight in the next filter, 0}
+};
+
 template <bool kInt16, bool kDither>
-__global__ __launch_bounds__(256) void mfcc512_kernel(MfccParams p, vbh_mfcc_tables t, const float *t256, const float *t512, const void *wave,
+__global__ __launch_bounds__(256) void mfcc512_kernel(MfccParams p, vbh_mfcc_tables t, FastTables ft, const void *wave,
                                                       const long long *wave_offsets, const long long *frame_offsets, const int *chunk_utt,
                                                       const int *chunk_f0, int n_chunks, float *feats) {
   extern __shared__ __align__(16) float lds[];
-  float *s_window = lds;
-  float2 *s_t256 = reinterpret_cast<float2 *>(s_window + kFastN);
-  float2 *s_t512 = s_t256 + 256;
-  float *s_dct = reinterpret_cast<float *>(s_t512 + 132);
-  float *s_lifter = s_dct + p.nceps * p.nbins;
-  float *s_melw = s_lifter + p.nceps;
-  int *s_melmeta = reinterpret_cast<int *>(s_melw + p.melw_total);
-  float *s_wave0 = reinterpret_cast<float *>(s_melmeta + 3 * p.nbins);
-  constexpr int per_wave = 2 * kFastBuf + 260 + 32;
+  float2 *s_t256 = reinterpret_cast<float2 *>(lds);
+  float *s_wave0 = lds + 512;
+  constexpr int per_wave = 2 * kFastBuf + 32;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  for (int i = tid; i < kFastN; i += 256) s_window[i] = i < p.flen ? t.window[i] : 0.0f;
-  for (int i = tid; i < 256; i += 256) s_t256[i] = make_float2(t256[2 * i], t256[2 * i + 1]);
-  for (int i = tid; i < 129; i += 256) s_t512[i] = make_float2(t512[2 * i], t512[2 * i + 1]);
-  for (int i = tid; i < p.nceps * p.nbins; i += 256) s_dct[i] = t.dct[i];
-  for (int i = tid; i < p.nceps; i += 256) s_lifter[i] = t.lifter[i];
-  for (int i = tid; i < p.melw_total; i += 256) s_melw[i] = t.mel_w[i];
-  for (int i = tid; i < p.nbins; i += 256) {
-    s_melmeta[i] = t.mel_first[i];
-    s_melmeta[p.nbins + i] = t.mel_len[i];
-    s_melmeta[2 * p.nbins + i] = t.mel_off[i];
-  }
+  for (int i = tid; i < 256; i += 256) s_t256[i] = make_float2(ft.t256[2 * i], ft.t256[2 * i + 1]);
   __syncthreads();
   float2 *buf = reinterpret_cast<float2 *>(s_wave0 + wid * per_wave);
-  float *s_ps = reinterpret_cast<float *>(buf + kFastBuf);
-  float *s_mel = s_ps + 260;
+  float *s_mel = reinterpret_cast<float *>(buf + kFastBuf);
   const int flen = p.flen;
-  // mel: two lanes per filter when they fit
-  const int mel_parts = 2 * p.nbins <= 64 ? 2 : 1;
-  const int mel_b = mel_parts == 2 ? lane >> 1 : lane, mel_h = mel_parts == 2 ? lane & 1 : 0;
-  int m_first = 0, m_len = 0, m_off = 0;
-  if (mel_b < p.nbins) { m_first = s_melmeta[mel_b]; m_len = s_melmeta[p.nbins + mel_b]; m_off = s_melmeta[2 * p.nbins + mel_b]; }
+  // ---- per-lane constants
+  float2 win[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int i0 = 2 * (lane + 64 * k);
+    win[k] = make_float2(i0 < flen ? t.window[i0] : 0.0f, i0 + 1 < flen ? t.window[i0 + 1] : 0.0f);
+  }
+  // spectrum bins of this lane: lane, lane + 64 (split index kk) and their mirrors 256 - kk; lane 0 also owns bin 128
+  float2 tw5[2];
+  float4 bw[5];
+#pragma unroll
+  for (int m = 0; m < 2; m++) {
+    const int kk = lane + 64 * m;
+    tw5[m] = make_float2(ft.t512[2 * kk], ft.t512[2 * kk + 1]);
+    bw[2 * m] = reinterpret_cast<const float4 *>(ft.binw)[kk];
+    bw[2 * m + 1] = reinterpret_cast<const float4 *>(ft.binw)[kFastM - kk];
+  }
+  bw[4] = reinterpret_cast<const float4 *>(ft.binw)[128];
+  const float2 tw128 = make_float2(ft.t512[256], ft.t512[257]);
+  const int dc = lane & 15, dq = lane >> 4;
+  float dctc[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int b = dq + 4 * j;
+    dctc[j] = (dc < p.nceps && b < p.nbins) ? t.dct[dc * p.nbins + b] : 0.0f;
+  }
+  const float lift = (p.use_lifter && dc < p.nceps) ? t.lifter[dc] : 1.0f;
 
   for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const int utt = chunk_utt[chunk], f0 = chunk_f0[chunk];
@@ -177,12 +194,16 @@ __global__ __launch_bounds__(256) void mfcc512_kernel(MfccParams p, vbh_mfcc_tab
       float xe[4], xo[4];
       if (!edge && kInt16 && (((w0 + start) & 1) == 0)) {
         const unsigned *wp = reinterpret_cast<const unsigned *>(reinterpret_cast<const short *>(wave) + (w0 + start));
+        unsigned v[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const int i0 = 2 * (lane + 64 * k);
-          unsigned v = 0;
-          if (i0 + 1 < flen) v = wp[lane + 64 * k];
-          xe[k] = (float)(short)(v & 0xFFFFu); xo[k] = (float)(short)(v >> 16);
+          v[k] = (i0 + 1 < flen) ? wp[lane + 64 * k] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int i0 = 2 * (lane + 64 * k);
+          xe[k] = (float)(short)(v[k] & 0xFFFFu); xo[k] = (float)(short)(v[k] >> 16);
           if (i0 + 1 >= flen && i0 < flen) { xe[k] = load_sample<kInt16>(wave, w0 + start + i0); xo[k] = 0.0f; }
         }
       } else {
@@ -249,11 +270,9 @@ __global__ __launch_bounds__(256) void mfcc512_kernel(MfccParams p, vbh_mfcc_tab
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const int i0 = 2 * (lane + 64 * k);
           float ye = xe[k], yo = xo[k];
           if (p.preemph != 0.f) { ye -= p.preemph * prev[k]; yo -= p.preemph * xe[k]; }
-          const float2 w = *reinterpret_cast<const float2 *>(s_window + i0);
-          a[k] = make_float2(ye * w.x, yo * w.y);
+          a[k] = make_float2(ye * win[k].x, yo * win[k].y);
         }
       }
       if (p.use_energy && !p.raw_energy) {  // feature-mfcc.cc:39-41
@@ -262,6 +281,7 @@ __global__ __launch_bounds__(256) void mfcc512_kernel(MfccParams p, vbh_mfcc_tab
         for (int k = 0; k < 4; k++) e2 += a[k].x * a[k].x + a[k].y * a[k].y;
         log_energy = logf(fmaxf(wave_sum_dpp(e2), FLT_MIN));
       }
+      if (lane < 32) s_mel[lane] = 0.0f;
       // ---- 256-point complex FFT: four radix-4 Stockham passes, butterfly j = lane
 #pragma unroll
       for (int s = 0; s < 4; s++) {
@@ -269,10 +289,10 @@ __global__ __launch_bounds__(256) void mfcc512_kernel(MfccParams p, vbh_mfcc_tab
         const int k = lane & (Ns - 1);
         if (s > 0) {
           wave_lds_fence();
-#pragma unroll
-          for (int q = 0; q < 4; q++) a[q] = buf[fpad(lane + 64 * q)];
           const int m = k * (64 >> (2 * s));
           const float2 w1 = s_t256[m], w2 = s_t256[2 * m];
+#pragma unroll
+          for (int q = 0; q < 4; q++) a[q] = buf[fpad(lane + 64 * q)];
           const float2 w3 = cmul(w1, w2);
           a[1] = cmul(a[1], w1); a[2] = cmul(a[2], w2); a[3] = cmul(a[3], w3);
           wave_lds_fence();
@@ -287,48 +307,63 @@ __global__ __launch_bounds__(256) void mfcc512_kernel(MfccParams p, vbh_mfcc_tab
         buf[fpad(o + 3 * Ns)] = make_float2(t1.x - t3.x, t1.y - t3.y);
       }
       wave_lds_fence();
-      // ---- real-FFT split + ComputePowerSpectrum (feature-functions.cc:29-51): bins k and N/2 - k from one pair
+      // ---- real-FFT split + ComputePowerSpectrum (feature-functions.cc:29-51): bins kk and N/2 - kk from one pair of
+      //      points, then MelBanks::Compute (mel-computations.cc:228-253) as float adds into the filters' LDS cells
       {
-        auto split = [&](int kk) {
-          const float2 zk = buf[fpad(kk)], zm = buf[fpad((kFastM - kk) & (kFastM - 1))];
+        float pw[5];
+        const float2 z0 = buf[fpad(lane)], z0m = buf[fpad((kFastM - lane) & (kFastM - 1))];
+        const float2 z1 = buf[fpad(lane + 64)], z1m = buf[fpad(kFastM - lane - 64)];
+        const float2 z128 = buf[fpad(128)];
+        auto split = [](float2 zk, float2 zm, float2 c, float &p_lo, float &p_hi) {
           const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
           const float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
-          const float2 c = s_t512[kk];
           const float tr = orr * c.x - oi * c.y, ti = orr * c.y + oi * c.x;
-          s_ps[kk] = (er + tr) * (er + tr) + (ei + ti) * (ei + ti);
-          s_ps[kFastM - kk] = (er - tr) * (er - tr) + (ei - ti) * (ei - ti);
+          p_lo = (er + tr) * (er + tr) + (ei + ti) * (ei + ti);
+          p_hi = (er - tr) * (er - tr) + (ei - ti) * (ei - ti);
         };
-        split(lane); split(lane + 64);
-        if (lane == 0) split(128);
+        split(z0, z0m, tw5[0], pw[0], pw[1]);
+        split(z1, z1m, tw5[1], pw[2], pw[3]);
+        float dummy;
+        split(z128, z128, tw128, pw[4], dummy);
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+          if (j == 4 && lane != 0) break;
+          const int fl = (int)bw[j].x;
+          if (bw[j].y != 0.0f) atomicAdd(&s_mel[fl], bw[j].y * pw[j]);
+          if (bw[j].z != 0.0f) atomicAdd(&s_mel[fl + 1], bw[j].z * pw[j]);
+        }
       }
       wave_lds_fence();
-      // ---- MelBanks::Compute + floor + log (mel-computations.cc:228-253, feature-mfcc.cc:54-55)
-      {
-        float e = 0.f;
-        for (int i = mel_h; i < m_len; i += mel_parts) e = fmaf(s_melw[m_off + i], s_ps[m_first + i], e);
-        if (mel_parts == 2) e += __shfl_xor(e, 1, 64);
+      // floor + log (feature-mfcc.cc:54-55)
+      if (lane < p.nbins) {
+        float e = s_mel[lane];
         if (p.htk_mode && e < 1.0f) e = 1.0f;
-        if (mel_b < p.nbins && mel_h == 0) s_mel[mel_b] = logf(fmaxf(e, FLT_EPSILON));
+        s_mel[lane] = logf(fmaxf(e, FLT_EPSILON));
       }
       wave_lds_fence();
       // ---- DCT, lifter, energy / C0, htk reorder (feature-mfcc.cc:57-79)
-      if (lane < p.nceps) {
+      {
         float v = 0.f;
-        for (int b = 0; b < p.nbins; b++) v = fmaf(s_dct[lane * p.nbins + b], s_mel[b], v);
-        if (p.use_lifter) v *= s_lifter[lane];
-        if (p.use_energy && lane == 0) {
-          float le = log_energy;
-          if (p.energy_floor > 0.f && le < p.log_energy_floor) le = p.log_energy_floor;
-          v = le;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v = fmaf(dctc[j], s_mel[(dq + 4 * j) & 31], v);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < p.nceps) {
+          v *= lift;
+          if (p.use_energy && lane == 0) {
+            float le = log_energy;
+            if (p.energy_floor > 0.f && le < p.log_energy_floor) le = p.log_energy_floor;
+            v = le;
+          }
+          int col = lane;
+          if (p.htk_compat) {
+            if (lane == 0) {
+              col = p.nceps - 1;
+              if (!p.use_energy) v *= 1.41421356237309504880f;
+            } else col = lane - 1;
+          }
+          feats[(row0 + f) * p.nceps + col] = v;
         }
-        int col = lane;
-        if (p.htk_compat) {
-          if (lane == 0) {
-            col = p.nceps - 1;
-            if (!p.use_energy) v *= 1.41421356237309504880f;
-          } else col = lane - 1;
-        }
-        feats[(row0 + f) * p.nceps + col] = v;
       }
       wave_lds_fence();
     }
@@ -522,7 +557,7 @@ struct vbh_mfcc {
   vbh_mfcc_opts opts;
   MfccParams p;
   DevBuf<float> window, twiddle, mel_w, dct, lifter;
-  DevBuf<float> t256, t512;        // fast kernel: exp(-2 pi i m / 256), m < 256; exp(-2 pi i k / 512), k <= 128
+  DevBuf<float> t256, t512, binw;  // fast kernel: exp(-2 pi i m / 256), m < 256; exp(-2 pi i k / 512), k <= 128; per-bin mel weights
   bool fast = false; size_t fast_lds = 0;
   DevBuf<int> mel_first, mel_len, mel_off;
   DevBuf<long long> d_wave_off, d_frame_off;
@@ -678,14 +713,29 @@ int vbh_mfcc_create(vbh_ctx *ctx, const vbh_mfcc_opts *o, float vtln_warp, vbh_m
   p.melw_total = (int)melw.size();
   p.dither = o->dither; p.seed_lo = 0x2545F491u; p.seed_hi = 0x4F6CDD1Du; p.utt_base = 0;
   hipStream_t s = ctx->stream;
-  m->fast = N == kFastN && flen <= kFastN && nb <= 32 && o->num_ceps <= 32 && !getenv("VBH_MFCC_GENERIC");
+  m->fast = N == kFastN && flen <= kFastN && nb <= 32 && o->num_ceps <= 16 && !getenv("VBH_MFCC_GENERIC");
   if (m->fast) {
+    // per spectrum bin: the (at most two, adjacent) filters it lies under; anything else takes the general kernel
+    std::vector<float> binw(4 * 257, 0.0f);
+    std::vector<int> cnt(257, 0);
+    for (int b = 0; b < nb && m->fast; b++)
+      for (int i = 0; i < len[b]; i++) {
+        const int k = first[b] + i;
+        const float w = melw[off[b] + i];
+        if (w == 0.0f) continue;
+        if (k > 256) { m->fast = false; break; }
+        if (cnt[k] == 0) { binw[4 * k] = (float)b; binw[4 * k + 1] = w; }
+        else if (cnt[k] == 1 && (int)binw[4 * k] == b - 1) binw[4 * k + 2] = w;
+        else { m->fast = false; break; }
+        cnt[k]++;
+      }
     std::vector<float> t256(512), t512(2 * 129);
     for (int i = 0; i < 256; i++) { const double ang = 6.283185307179586476925286766559005 * i / 256.0; t256[2 * i] = (float)cos(ang); t256[2 * i + 1] = (float)-sin(ang); }
     for (int i = 0; i <= 128; i++) { const double ang = 6.283185307179586476925286766559005 * i / 512.0; t512[2 * i] = (float)cos(ang); t512[2 * i + 1] = (float)-sin(ang); }
-    if (m->t256.upload(t256.data(), t256.size(), s) || m->t512.upload(t512.data(), t512.size(), s)) { delete m; return -1; }
-    m->fast_lds = sizeof(float) * (kFastN + 2 * 256 + 2 * 132 + (size_t)o->num_ceps * nb + o->num_ceps + melw.size() + 3 * nb +
-                                   kWaves * (2 * (size_t)kFastBuf + 260 + 32));
+    if (m->fast && (m->t256.upload(t256.data(), t256.size(), s) || m->t512.upload(t512.data(), t512.size(), s) || m->binw.upload(binw.data(), binw.size(), s))) {
+      delete m; return -1;
+    }
+    m->fast_lds = sizeof(float) * (512 + kWaves * (2 * (size_t)kFastBuf + 32));
   }
   if (m->window.upload(window.data(), window.size(), s) || m->twiddle.upload(tw.data(), tw.size(), s) ||
       m->mel_w.upload(melw.data(), melw.size(), s) || m->dct.upload(dct.data(), dct.size(), s) ||
@@ -749,10 +799,11 @@ int vbh_mfcc_compute(vbh_mfcc *m, const void *d_wave, int wave_is_int16, const i
     {                                                                                                                                   \
       VBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc512_kernel<I16, DIT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)m->fast_lds));                                                                                   \
-      hipLaunchKernelGGL((mfcc512_kernel<I16, DIT>), dim3(grid), dim3(256), m->fast_lds, s, m->p, t, m->t256.p, m->t512.p, d_wave,      \
+      hipLaunchKernelGGL((mfcc512_kernel<I16, DIT>), dim3(grid), dim3(256), m->fast_lds, s, m->p, t, ft, d_wave,                        \
                          d_wave_off, d_frame_off, d_chunk_utt, d_chunk_f0, n_chunks, d_feats);                                          \
     }
     const bool dit = m->p.dither != 0.0f;
+    const FastTables ft{m->t256.p, m->t512.p, m->binw.p};
     if (wave_is_int16) { if (dit) VBH_LAUNCH_FAST(true, true) else VBH_LAUNCH_FAST(true, false) }
     else { if (dit) VBH_LAUNCH_FAST(false, true) else VBH_LAUNCH_FAST(false, false) }
 #undef VBH_LAUNCH_FAST

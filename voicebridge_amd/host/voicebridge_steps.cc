@@ -36,6 +36,43 @@ struct StepError : public std::runtime_error {
   explicit StepError(const std::string &m) : std::runtime_error(m) {}
 };
 
+// Devices the jobs of a step are spread over (vb_set_step_devices / VB_STEP_DEVICES, default: the calling thread's device
+// only).  The reference starts its nj jobs as nj threads (VB/scr/steps/decode_gmm.cpp:300-324); here a job is a batch for a
+// GPU, so the jobs are dealt round-robin to the listed devices, one host thread per device, each running its jobs in order.
+std::vector<int> g_step_devices;
+std::vector<int> StepDevices() {
+  if (!g_step_devices.empty()) return g_step_devices;
+  std::vector<int> d;
+  if (const char *e = getenv("VB_STEP_DEVICES")) {
+    std::string w; std::istringstream is(e);
+    while (std::getline(is, w, ',')) if (!w.empty()) d.push_back(atoi(w.c_str()));
+  }
+  return d;
+}
+// fn(j) for j = 1..nj; an exception of any job is rethrown (the first one) after all threads have finished
+template <class F>
+void ForEachJob(int nj, F fn) {
+  const std::vector<int> devs = StepDevices();
+  if (devs.size() <= 1 || nj <= 1) {
+    if (devs.size() == 1) vb_set_device(devs[0]);
+    for (int j = 1; j <= nj; j++) fn(j);
+    return;
+  }
+  const int nt = (int)std::min<size_t>(devs.size(), (size_t)nj);
+  std::vector<std::string> errs(nt);
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; t++)
+    th.emplace_back([&, t]() {
+      try {
+        vb_set_device(devs[t]);
+        StepScope scope;                     // the thread's device cache is released when its last job is done
+        for (int j = 1 + t; j <= nj; j += nt) fn(j);
+      } catch (const std::exception &e) { errs[t] = e.what(); if (errs[t].empty()) errs[t] = "error"; }
+    });
+  for (auto &x : th) x.join();
+  for (const auto &e : errs) if (!e.empty()) throw StepError(e);
+}
+
 bool Exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
 bool IsDir(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
 void MakeDir(const std::string &p) {
@@ -155,12 +192,12 @@ int MakeMfcc(const std::string &datadir, const std::string &mfcc_config, int nj,
     if (Exists(Join(datadir, "segments"))) throw StepError("a segments file (extract-segments) is not part of this build");
     if (Exists(Join(datadir, "spk2warp")) || Exists(Join(datadir, "utt2warp"))) throw StepError("VTLN warp maps are not part of this build");
     const auto pieces = SplitLines(wav, nj);
-    for (int j = 1; j <= nj; j++) {
+    ForEachJob(nj, [&](int j) {
       const std::string J = std::to_string(j);
       const std::string piece = Join(logdir, "wav_" + name + "." + J + ".scp"), temp = Join(logdir, "wav_" + name + "." + J + ".mfctemp");
       WriteLines(piece, pieces[j - 1]);
       std::ofstream log(Join(logdir, "make_mfcc_" + name + "." + J + ".log"), std::ios::binary);
-      if (pieces[j - 1].empty()) continue;
+      if (pieces[j - 1].empty()) return;
       // the reference pipes compute-mfcc-feats through copy-feats --compress (make_mfcc.cpp:215, a temporary archive in its
       // port); here the program writes the final archive itself (its --compress / --write-num-frames extensions)
       (void)temp;
@@ -170,7 +207,7 @@ int MakeMfcc(const std::string &datadir, const std::string &mfcc_config, int nj,
       c.push_back("ark,scp:" + Join(mfccdir, "raw_mfcc_" + name + "." + J + ".ark") + "," + Join(mfccdir, "raw_mfcc_" + name + "." + J + ".scp"));
       Argv a1(c);
       if (ComputeMFCCFeats(a1.argc(), a1.argv(), log) < 0) throw StepError("compute-mfcc-feats failed for job " + J + ", see " + logdir);
-    }
+    });
     std::vector<std::string> feats, u2n;
     for (int j = 1; j <= nj; j++) {
       const std::string J = std::to_string(j);
@@ -310,11 +347,11 @@ int Decode(const std::string &graph_dir, const std::string &data_dir, const std:
     WriteLines(Join(decode_dir, "num_jobs"), {std::to_string(nj)});
     if (SplitData(data_dir, nj, false) < 0) throw StepError("SplitData failed: " + g_err);
     const std::string sdata = Join(data_dir, "split" + std::to_string(nj));
-    for (int j = 1; j <= nj; j++) {
+    ForEachJob(nj, [&](int j) {
       const std::string J = std::to_string(j), dsn = Join(sdata, J);
       unlink(Join(decode_dir, "lat." + J).c_str());
       std::ofstream log(Join(Join(decode_dir, "log"), "decode." + J + ".log"), std::ios::binary);
-      if (ReadLines(Join(dsn, "feats.scp"), false).empty()) continue;
+      if (ReadLines(Join(dsn, "feats.scp"), false).empty()) return;
       // The reference chains apply-cmvn | add-deltas (or splice-feats | transform-feats final.mat) [| transform-feats trans.JOB] |
       // gmm-latgen-faster through temporary archives (decode_gmm.cpp:201-293).  Here the chain runs on the device in front of the
       // scoring (GmmLatgenFaster's --fe-* options): the raw features of feats.scp are the only thing read.
@@ -356,7 +393,7 @@ int Decode(const std::string &graph_dir, const std::string &data_dir, const std:
         for (const auto &l : ReadLines(Join(decode_dir, "w." + J), false)) out.push_back(Int2SymLine(sym, l));
         WriteLines(Join(decode_dir, "transcription" + J + ".trn"), out);
       }
-    }
+    });
     if (!trans_all.empty()) unlink(trans_all.c_str());
   });
   if (rc_decode != 0 || skip_scoring) return rc_decode;
@@ -420,9 +457,9 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
       if (laps) fprintf(stderr, "DecodeFmllr %-28s %8.1f ms\n", what, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
       if (r < 0 || (r != 0 && !none_ok)) throw StepError(std::string(what) + " failed (return code " + std::to_string(r) + "), see " + Join(dir, "log"));
     };
-    for (int j = 1; j <= nj; j++) {
+    ForEachJob(nj, [&](int j) {
       const std::string J = std::to_string(j), dsn = Join(sdata, J);
-      if (ReadLines(Join(dsn, "feats.scp"), false).empty()) continue;
+      if (ReadLines(Join(dsn, "feats.scp"), false).empty()) return;
       std::ofstream log(Join(Join(dir, "log"), "fmllr." + J + ".log"), std::ios::binary);
       // ---- speaker-independent features (decode_fmllr.cpp:275-311)
       const std::string t_cmvn = Join(dsn, "apply_cmvn.temp"), t_si = Join(dsn, "sifeats.temp"), t_feat = Join(dsn, "transform_pass1feats.temp");
@@ -487,7 +524,7 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
         unlink(t_grl.c_str()); unlink(lat_tmp.c_str());
       }
       unlink(t_si.c_str()); unlink(t_feat.c_str());
-    }
+    });
   });
   if (rc != 0) return rc;
   if (!skip_scoring) {
@@ -645,4 +682,9 @@ int vb_ScoreKaldiWER(const char *data, const char *lang_or_graph, const char *di
   return ScoreKaldiWER(data, lang_or_graph, dir, a, b, nj, 0, false, true, 6.0, word_ins_penalty ? word_ins_penalty : "0.0,0.5,1.0", min_lmwt, max_lmwt);
 }
 const char *vb_steps_last_error(void) { return g_err.c_str(); }
+int vb_set_step_devices(const int *devices, int n) {
+  g_step_devices.clear();
+  for (int i = 0; i < n; i++) { if (devices[i] < 0) return -1; g_step_devices.push_back(devices[i]); }
+  return 0;
+}
 }

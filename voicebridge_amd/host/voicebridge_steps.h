@@ -11,8 +11,10 @@
 //                                                        nj, acwt, stage, max_active, beam, lattice_beam, skip_scoring, ...)
 //                                                                                             scr/steps/decode_gmm.cpp:60-390
 // Same names, argument order and meaning, return 0 / -1; std::string stands in for boost::filesystem::path.
-// The nj jobs of a step run one after the other on the calling thread's GPU (vb_set_device): they are
-// batches for one device here, not processes; the per-job file layout (JOB-numbered archives, logs,
+// The nj jobs of a step are batches for a GPU here, not processes.  By default they run one after the other on the calling
+// thread's GPU (vb_set_device); vb_set_step_devices (or VB_STEP_DEVICES=0,1,...) names the GPUs of the node to use: the jobs
+// are then dealt round-robin to them, one host thread per device -- the reference's nj concurrent job threads
+// (scr/steps/decode_gmm.cpp:300-324), with a device behind each.  The per-job file layout (JOB-numbered archives, logs,
 // split directories) is the reference's, so whatever consumes those directories keeps working.
 //
 //   scr/kaldi_scr.h:167-183  int ScoreKaldiWER(data, lang_or_graph, dir, wer filters, nj, stage, decode_mbr, stats, beam,
@@ -79,6 +81,7 @@ int vb_DecodeFmllr(const char *graphdir, const char *data, const char *dir, int 
 int vb_ScoreKaldiWER(const char *data, const char *lang_or_graph, const char *dir, int nj, const char *word_ins_penalty, int min_lmwt,
                      int max_lmwt);
 const char *vb_steps_last_error(void);
+int vb_set_step_devices(const int *devices, int n);    // GPUs the jobs of the steps are spread over (n = 0: the calling thread's device only)
 }
 
 #endif
