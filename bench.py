@@ -51,9 +51,13 @@ def parse():
     ap.add_argument("--max-active", type=int, default=7000)
     ap.add_argument("--mean-scale", type=float, default=1.5, help="spread of the synthetic GMM means (search difficulty)")
     ap.add_argument("--var-spread", type=float, default=0.2, help="sigma of the log-variances of the synthetic GMM")
+    ap.add_argument("--sub-batches", type=int, default=1,
+                    help="a step's utterances go through the pipeline as this many slices of whole speakers (front end and search per slice): more, "
+                         "smaller persistent search grids in flight, whose drains overlap; the step stays --batch utterances")
+    ap.add_argument("--ahead", type=int, default=1, help="items the front end runs ahead of the search that is enqueued next (ring of pipeline + ahead score buffers)")
     ap.add_argument("--pipeline", type=int, default=2,
-                    help="batches in flight: 2 = two contexts/streams, the search grid of one batch drains while the "
-                         "next batch's kernels fill the freed CUs; 1 = one batch at a time")
+                    help="search grids in flight: n contexts/streams whose decoders share one pool of search workspaces; the grid of one "
+                         "batch drains while the next ones' workgroups fill the freed slots; 1 = one batch at a time")
     ap.add_argument("--search-cus", type=int, default=-1,
                     help="confine the search contexts to this many CUs (0 = all, -1 = 7/8 of the device when batches are "
                          "pipelined): the rest stays free for the front end of the batches ahead, which otherwise only "
@@ -101,8 +105,8 @@ def build_workload(args, rank, world, device):
     rank_of = vdist.shard_speakers(np.full(world * n_spk, upk * frames_per_utt, np.int64), world)
     my_spk = np.flatnonzero(rank_of == rank)
     assert len(my_spk) == n_spk
-    utt2spk = np.arange(args.batch, dtype=np.int32) % n_spk            # rank-local speaker index
-    gid = my_spk[utt2spk] * upk + np.arange(args.batch) // n_spk          # job-wide utterance id
+    utt2spk = (np.arange(args.batch, dtype=np.int32) // upk).astype(np.int32)      # rank-local speaker index: a speaker's utterances are adjacent
+    gid = my_spk[utt2spk] * upk + np.arange(args.batch) % upk             # job-wide utterance id
     n = int(round(args.seconds * 16000))
     d_wave = torch.empty(args.batch * n, dtype=torch.int16, device=device)
     for a in range(0, args.batch, 64):
@@ -351,7 +355,7 @@ class DetPool:
             self.h = None
 
 
-def determinize_measurement(args, dec, T):
+def determinize_measurement(args, dec, n_utt, T):
     """The step after the search in the reference's Decode (gmm-latgen-faster determinizes every
     utterance's lattice before writing it, K/decoder/decoder-wrappers.cc:262-284): host C++
     (voicebridge_amd/host/lattice.cc) over the lattices of the last batch, on the host's cores.
@@ -367,19 +371,19 @@ def determinize_measurement(args, dec, T):
                                                     C.c_int, C.c_void_p]
     if os.environ.get("VBH_DET_SWEEP"):       # diagnostic: how many host threads does the box really give us?
         for th in (4, 8, 16, 24, 32, 48, 64):
-            host.vb_determinize_decoder_results(dec.h, args.batch, 0, n_tid, phone.ctypes.data, hmm.ctypes.data, sl.ctypes.data,
+            host.vb_determinize_decoder_results(dec.h, n_utt, 0, n_tid, phone.ctypes.data, hmm.ctypes.data, sl.ctypes.data,
                                                 C.c_float(args.lattice_beam), C.c_float(0.083333), th, out)
-            print("determinize %d lattices on %d threads: %.3f s" % (args.batch, th, out[0]), file=sys.stderr, flush=True)
-    rc = host.vb_determinize_decoder_results(dec.h, args.batch, 0, n_tid, phone.ctypes.data, hmm.ctypes.data, sl.ctypes.data,
+            print("determinize %d lattices on %d threads: %.3f s" % (n_utt, th, out[0]), file=sys.stderr, flush=True)
+    rc = host.vb_determinize_decoder_results(dec.h, n_utt, 0, n_tid, phone.ctypes.data, hmm.ctypes.data, sl.ctypes.data,
                                              C.c_float(args.lattice_beam), C.c_float(0.083333), threads, out)
     if rc != 0:
         return {"error": "vb_determinize_decoder_results failed"}
     sec = out[0]
     return {"what": "Connect + two-pass pruned determinization (phone level, word level) + un-scaling of the %d lattices of the last batch, "
-                    "host C++ on %d threads" % (args.batch, threads),
-            "seconds": sec, "utterances_per_s": args.batch / sec, "frames_per_s": T / sec, "threads": threads,
-            "raw_states_per_utt": out[1] / args.batch, "raw_arcs_per_utt": out[2] / args.batch,
-            "det_states_per_utt": out[3] / args.batch, "det_arcs_per_utt": out[4] / args.batch, "stopped_before_beam": int(out[5])}
+                    "host C++ on %d threads" % (n_utt, threads),
+            "seconds": sec, "utterances_per_s": n_utt / sec, "frames_per_s": T / sec, "threads": threads,
+            "raw_states_per_utt": out[1] / n_utt, "raw_arcs_per_utt": out[2] / n_utt,
+            "det_states_per_utt": out[3] / n_utt, "det_arcs_per_utt": out[4] / n_utt, "stopped_before_beam": int(out[5])}
 
 
 F64_MFMA_PEAK_TFLOPS = 78.6      # vendor figure for MI355X FP64 matrix (the micro-architecture guide lists no f64 row)
@@ -518,6 +522,7 @@ def main():
                                      lattice_beam=args.lattice_beam, exact_cutoff=True))
         ctx.sync()
 
+    dec_enabled = dec is not None
     if args.sweep_mean_scale and dec is not None:
         for ms_ in [float(x) for x in args.sweep_mean_scale.split(",") if x]:
             args.mean_scale = ms_
@@ -613,49 +618,114 @@ def main():
     if args.search_cus < 0:
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
         args.search_cus = (ncu * 7 // 8) if depth > 1 else 0
-    n_ring = depth + 1 if depth > 1 else 1
-    ring = [(raw, feats, ll)] + [(torch.empty_like(raw), torch.empty_like(feats), torch.empty_like(ll)) for _ in range(n_ring - 1)]
+    # ---- slices of a step: contiguous ranges of whole speakers
+    S = max(1, args.sub_batches)
+    if args.batch % (S * UTT_PER_SPK) != 0:
+        sys.exit("bench.py: --batch must be a multiple of --sub-batches x %d (slices hold whole speakers)" % UTT_PER_SPK)
+    per = args.batch // S
+
+    class Slice:
+        pass
+    slices = []
+    for k in range(S):
+        sl = Slice()
+        sl.a, sl.b = k * per, (k + 1) * per
+        sl.wave = d_wave[int(woff[sl.a]):int(woff[sl.b])]
+        sl.woff = np.ascontiguousarray(woff[sl.a:sl.b + 1] - woff[sl.a])
+        sl.r0, sl.r1 = int(foff[sl.a]), int(foff[sl.b])
+        sl.foff = np.ascontiguousarray(foff[sl.a:sl.b + 1] - foff[sl.a])
+        s0, s1 = int(utt2spk[sl.a]), int(utt2spk[sl.b - 1]) + 1
+        sl.u2s = np.ascontiguousarray(utt2spk[sl.a:sl.b] - s0)
+        sl.stats, sl.xforms = np.ascontiguousarray(stats[s0:s1]), np.ascontiguousarray(xforms[s0:s1])
+        slices.append(sl)
+    Ts = max(sl.r1 - sl.r0 for sl in slices)
+    ahead = max(1, args.ahead) if depth > 1 else 1
+    n_ring = depth + ahead if depth > 1 else 1
+    if S == 1:
+        ring = [(raw, feats, ll)] + [(torch.empty_like(raw), torch.empty_like(feats), torch.empty_like(ll)) for _ in range(n_ring - 1)]
+    else:
+        del ll
+        ring = [(torch.empty((Ts, raw.shape[1]), dtype=torch.float32, device=dev), torch.empty((Ts, feats.shape[1]), dtype=torch.float32, device=dev),
+                 torch.empty((Ts, gmm.num_pdfs), dtype=torch.float32, device=dev)) for _ in range(n_ring)]
     lanes = []
-    if depth > 1 and dec is not None:
+    if dec is not None and (depth > 1 or S > 1):
         dec.close()          # the probe/setup decoder on the front-end context is not used by the pipeline
+        dec = None
     for k in range(depth):
         L = Lane()
-        if depth == 1:
+        if depth == 1 and S == 1:
             L.ctx, L.dec = ctx, dec
-        else:
-            L.ctx = api.Context(local_rank, priority=int(os.environ.get("VBH_BENCH_DEC_PRIO", "0")), cus=args.search_cus)
+        elif dec_enabled:
+            L.ctx = api.Context(local_rank, priority=int(os.environ.get("VBH_BENCH_DEC_PRIO", "0")), cus=args.search_cus) if depth > 1 else ctx
             # the lanes' decoders draw their search workspaces from one pool (vbh_decoder_create_shared)
-            L.dec = api.LatticeDecoder(L.ctx, graph, args.batch, Tmax, beam=args.beam, max_active=args.max_active,
+            L.dec = api.LatticeDecoder(L.ctx, graph, per, Tmax, beam=args.beam, max_active=args.max_active,
                                        min_active=200, lattice_beam=args.lattice_beam, acoustic_scale=0.083333,
                                        share_slots_with=lanes[0].dec if lanes else None)
+        else:
+            L.ctx, L.dec = ctx, None
         L.pending = False
         L.timed = False
+        L.slice = None
         lanes.append(L)
-    if depth > 1 and dec is not None:
-        dec = lanes[0].dec
     ctx.torch_sync()
     gmm_ms, feat_ms, dec_ms, dec_k_ms, dec_h_ms = [], [], [], [], []
-    last_done = [lanes[0]]
     fe_timed = []            # front-end timer slots in flight: (slot_feat, slot_gmm)
-    tl_dump = [] if os.environ.get("VBH_BENCH_TIMELINE") else None     # diagnostic: per-utterance device timelines of every timed batch
+    # per-utterance results of one complete step, gathered by an untimed pass after the timed regions (collect[0]):
+    # words, search counters, device timeline
+    collect = [False]
+    col_words = [None] * args.batch
+    col_cnt = np.zeros((args.batch, 8), np.float64)
+    col_tl = np.zeros((args.batch, 3), np.int64)
+    col_stats = dict(retried_in_big_slot=0, pool_grown=0, failed=0)
 
-    def front_end(j, timed):
-        """MFCC -> post -> GMM of batch j into ring[j % n_ring], on the front-end stream"""
-        r_, f_, l_ = ring[j % n_ring]
-        sl = 1 + 2 * (j % 4)                 # timer slots rotate: several batches may be in flight
+    def front_end(i, timed):
+        """MFCC -> post -> GMM of item i (slice i % S of a step) into ring[i % n_ring], on the front-end stream"""
+        sl_ = slices[i % S]
+        r_, f_, l_ = ring[i % n_ring]
+        n_rows = sl_.r1 - sl_.r0
+        tsl = 1 + 2 * (i % 7)                # timer slots rotate: several items may be in flight
         if timed:
-            ctx.timer_start(sl)
-        mf.compute_packed(d_wave, woff, is_i16, out=r_)
-        post.apply(r_, foff, utt2spk=utt2spk, cmvn_stats=stats, spk_xforms=xforms, out=f_)
+            ctx.timer_start(tsl)
+        dbg_ = os.environ.get("VBH_BENCH_STAGE_SYNC")
+        mf.compute_packed(sl_.wave, sl_.woff, is_i16, out=r_[:n_rows])
+        if dbg_:
+            ctx.sync(); print("item %d: mfcc done" % i, file=sys.stderr, flush=True)
+        post.apply(r_[:n_rows], sl_.foff, utt2spk=sl_.u2s, cmvn_stats=sl_.stats, spk_xforms=sl_.xforms, out=f_[:n_rows])
+        if dbg_:
+            ctx.sync(); print("item %d: featpost done" % i, file=sys.stderr, flush=True)
         if timed:
-            ctx.timer_stop(sl)
-            ctx.timer_start(sl + 1)
-        gmm.loglikes(f_, out=l_)
+            ctx.timer_stop(tsl)
+            ctx.timer_start(tsl + 1)
+        gmm.loglikes(f_[:n_rows], out=l_[:n_rows])
+        if dbg_:
+            ctx.sync(); print("item %d: gmm done" % i, file=sys.stderr, flush=True)
+        if os.environ.get("VBH_BENCH_CHECK_LL"):     # diagnostic: are the scores sane while search grids are running beside the kernel?
+            ctx.sync()
+            bad = int((~torch.isfinite(l_[:n_rows])).sum().item())
+            mn, mx = float(l_[:n_rows].min().item()), float(l_[:n_rows].max().item())
+            print("item %d: scores non-finite %d, min %.1f max %.1f" % (i, bad, mn, mx), file=sys.stderr, flush=True)
+            if check_gmm[0] is not None:
+                worst = 0.0
+                for a_ in range(0, n_rows, 1 << 18):
+                    b_ = min(n_rows, a_ + (1 << 18))
+                    ref_ = check_gmm[0].loglikes(f_[a_:b_])
+                    ctx.sync()
+                    worst = max(worst, float((ref_ - l_[a_:b_]).abs().max().item()))
+                    del ref_
+                print("   vs the other GMM kernel: max abs diff %.3g" % worst, file=sys.stderr, flush=True)
         if timed:
-            ctx.timer_stop(sl + 1)
-            fe_timed.append(sl)
+            ctx.timer_stop(tsl + 1)
+            fe_timed.append(tsl)
+            if len(fe_timed) >= 7:           # read the oldest before its slot comes round again
+                o_ = fe_timed.pop(0)
+                feat_ms.append(ctx.timer_ms(o_)); gmm_ms.append(ctx.timer_ms(o_ + 1))
 
-    det_pool = DetPool(args) if (dec is not None and not args.no_determinize) else None
+    check_gmm = [None]
+    if os.environ.get("VBH_BENCH_CHECK_LL") and not os.environ.get("VBH_GMM_V1"):
+        os.environ["VBH_GMM_V1"] = "1"
+        check_gmm[0] = api.DiagGmm(ctx, *model)
+        del os.environ["VBH_GMM_V1"]
+    det_pool = DetPool(args) if (dec_enabled and not args.no_determinize) else None
     det_on = [False]         # the headline region times the GPU path (SURVEY.md 8 a-e); a second region adds the host lattice stage
 
     def finish(L):
@@ -663,11 +733,18 @@ def main():
         if L.pending:
             L.dec.decode_end()
             L.pending = False
-            last_done[0] = L
             if det_pool is not None and det_on[0]:
-                det_pool.submit(L.dec, args.batch)      # raw lattices copied out; determinized by the pool under the next search
-            if tl_dump is not None and L.timed:
-                tl_dump.append(np.array([L.dec.timeline(u) for u in range(args.batch)], np.int64))
+                det_pool.submit(L.dec, per)             # raw lattices copied out; determinized by the pool under the next search
+            if collect[0]:
+                sl_ = slices[L.slice]
+                for u in range(per):
+                    r = L.dec.result(u, arrays=False)
+                    col_words[sl_.a + u] = r["words"]
+                    col_cnt[sl_.a + u] = [r["n_tokens_expanded"], r["n_arcs_expanded"], r["n_tokens_created"], r["n_links_created"],
+                                          r["n_frames_maxactive_bound"], r["n_frames_minactive_bound"], r["num_toks"], r["num_links"]]
+                    col_tl[sl_.a + u] = L.dec.timeline(u)
+                for k_, v_ in L.dec.batch_stats().items():
+                    col_stats[k_] += v_
             if L.timed:
                 tm = L.dec.times()      # HIP events around the search kernel on its stream + host clocks
                 dec_ms.append(tm["total_ms"]); dec_k_ms.append(tm["kernel_ms"])
@@ -675,29 +752,35 @@ def main():
                 L.timed = False
 
     def run_steps(n, timed):
-        """n complete steps: n front ends and n searches, the pipeline empty before and after"""
-        if n <= 0:
+        """n complete steps = n x S items (front end + search each), the pipeline empty before and after"""
+        items = n * S
+        if items <= 0:
             return
         if depth == 1:
             L = lanes[0]
-            for j in range(n):
-                front_end(j, timed)
+            for i in range(items):
+                front_end(i, timed)
                 if L.dec is not None:
                     L.timed = timed
-                    L.dec.decode_begin(ring[0][2], foff, t2p)
+                    L.slice = i % S
+                    L.dec.decode_begin(ring[0][2], slices[i % S].foff, t2p)
                     L.pending = True
                     finish(L)
             return
-        front_end(0, timed)
-        lanes[0].ctx.wait_for(ctx)
-        for j in range(n):
-            L = lanes[j % depth]
-            finish(L)                                    # search j - depth
-            if j + 1 < n:
-                front_end(j + 1, timed)                  # one batch ahead of the search enqueued next
-                lanes[(j + 1) % depth].ctx.wait_for(ctx)
+        # the front end runs `ahead` items in front of the search enqueued next; a search waits (on the device) for the front
+        # end of its own item only: an event recorded on the front-end stream right after that item's scores
+        n_fe = 0
+        for i in range(items):
+            L = lanes[i % depth]
+            finish(L)                                    # search i - depth
+            while n_fe < items and n_fe <= i + ahead - 1:
+                front_end(n_fe, timed)
+                ctx.mark(n_fe % n_ring)                  # "scores of item n_fe are complete" on the front-end stream
+                n_fe += 1
+            L.ctx.wait_mark(ctx, i % n_ring)
             L.timed = timed
-            L.dec.decode_begin(ring[j % n_ring][2], foff, t2p)
+            L.slice = i % S
+            L.dec.decode_begin(ring[i % n_ring][2], slices[i % S].foff, t2p)
             L.pending = True
         for L in lanes:
             finish(L)
@@ -715,13 +798,13 @@ def main():
 
     run_steps(args.warmup, False)
     barrier()
-    counters = dict(tok=0, arc=0, new=0, link=0)
     t0 = time.perf_counter()
     run_steps(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
-    for sl in fe_timed:
-        feat_ms.append(ctx.timer_ms(sl)); gmm_ms.append(ctx.timer_ms(sl + 1))
+    for o_ in fe_timed:
+        feat_ms.append(ctx.timer_ms(o_)); gmm_ms.append(ctx.timer_ms(o_ + 1))
+    del fe_timed[:]
     # second timed region: the same steps with the lattice stage of the reference's Decode inside them
     det_dt = None
     if det_pool is not None and args.det_steps > 0:
@@ -736,44 +819,40 @@ def main():
         det_dt = time.perf_counter() - t0
         det_on[0] = False
         del dec_ms[n_dec_timed:], dec_k_ms[n_dec_timed:], dec_h_ms[n_dec_timed:]
+    # one more (untimed) step through the same pipeline to gather every utterance's words, counters and timeline
+    if dec_enabled:
+        collect[0] = True
+        run_steps(1, False)
+        barrier()
+        collect[0] = False
     # after the timed region: the GMM kernel alone on the whole chip (in the pipeline it shares the
-    # CUs with two search grids, so its in-pipeline duration says little about the kernel itself)
+    # CUs with the search grids, so its in-pipeline duration says little about the kernel itself)
+    n_rows0 = slices[0].r1 - slices[0].r0
     gmm_alone_ms = None
-    if depth > 1:
-        for _ in range(3):
-            ctx.timer_start(0)
-            gmm.loglikes(ring[0][1], out=ring[0][2])
-            ctx.timer_stop(0)
-            ctx.sync()
-            t_ = ctx.timer_ms(0)
-            gmm_alone_ms = t_ if gmm_alone_ms is None else min(gmm_alone_ms, t_)
+    for _ in range(3):
+        ctx.timer_start(0)
+        gmm.loglikes(ring[0][1][:n_rows0], out=ring[0][2][:n_rows0])
+        ctx.timer_stop(0)
+        ctx.sync()
+        t_ = ctx.timer_ms(0) * (T / float(n_rows0))          # (scaled to the step's frame count when the step runs in slices)
+        gmm_alone_ms = t_ if gmm_alone_ms is None else min(gmm_alone_ms, t_)
     # the MFCC kernel alone on the whole chip, the same way (its share of the pipelined step says little about the kernel)
     mfcc_alone_ms = None
     for _ in range(3):
         ctx.timer_start(0)
-        mf.compute_packed(d_wave, woff, is_i16, out=ring[0][0])
+        mf.compute_packed(slices[0].wave, slices[0].woff, is_i16, out=ring[0][0][:n_rows0])
         ctx.timer_stop(0)
         ctx.sync()
-        t_ = ctx.timer_ms(0)
+        t_ = ctx.timer_ms(0) * (T / float(n_rows0))
         mfcc_alone_ms = t_ if mfcc_alone_ms is None else min(mfcc_alone_ms, t_)
-    if dec is not None:
-        dec = last_done[0].dec
-        tl = np.array([dec.timeline(u) for u in range(args.batch)], np.int64)
-        span = float(tl[:, 1].max() - tl[:, 0].min())
-        grid_stats = {"workgroups": len(set(tl[:, 2].tolist())), "span_ms": span / 1e5,
-                      "busy_fraction_of_span": float((tl[:, 1] - tl[:, 0]).sum()) / (len(set(tl[:, 2].tolist())) * span),
-                      "utterance_ms_min_mean_max": [float((tl[:, 1] - tl[:, 0]).min()) / 1e5, float((tl[:, 1] - tl[:, 0]).mean()) / 1e5,
-                                                    float((tl[:, 1] - tl[:, 0]).max()) / 1e5]}
-    if tl_dump:
-        allb = np.stack(tl_dump)                  # [batches, utterances, (start, end, workgroup)] in 100 MHz ticks
-        np.save(os.environ["VBH_BENCH_TIMELINE"], allb)
-        t_lo, t_hi = allb[:, :, 0].min(), allb[:, :, 1].max()
-        busy = float((allb[:, :, 1] - allb[:, :, 0]).sum())
-        nwg = len(set(allb[0, :, 2].tolist()))
-        print("timeline: %d batches, first start to last end %.1f ms (wall %.1f ms), search busy %.1f%% of %d workgroups; "
-              "batch starts (ms): %s; batch ends: %s" % (len(tl_dump), (t_hi - t_lo) / 1e5, dt * 1e3, 100 * busy / (nwg * (t_hi - t_lo)), nwg,
-              [round(float(b[:, 0].min() - t_lo) / 1e5) for b in allb], [round(float(b[:, 1].max() - t_lo) / 1e5) for b in allb]),
-              file=sys.stderr, flush=True)
+    if dec_enabled:
+        dec = lanes[(S - 1) % depth].dec                 # holds the lattices of the collection step's last slice
+        dur = (col_tl[:, 1] - col_tl[:, 0]).astype(np.float64)
+        span = float(col_tl[:, 1].max() - col_tl[:, 0].min())
+        grid_stats = {"what": "the %d utterances of one step (searched as %d slice(s), %d search grid(s) in flight)" % (args.batch, S, depth),
+                      "workgroups": len(set(col_tl[:, 2].tolist())), "span_ms": span / 1e5,
+                      "mean_utterances_in_search": float(dur.sum()) / span,
+                      "utterance_ms_min_mean_max": [float(dur.min()) / 1e5, float(dur.mean()) / 1e5, float(dur.max()) / 1e5]}
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -788,7 +867,7 @@ def main():
     gathered = None
     if dec is not None and world > 1:
         from voicebridge_amd import dist as vdist
-        hyps = [dec.result(u, arrays=False)["words"] for u in range(args.batch)]
+        hyps = col_words
         ids = [int(x) for x in gid]
         counters = vdist.score(hyps, hyps)          # synthetic audio has no transcripts: self-scored
         totals, merged = vdist.gather_results(ids, hyps, counters, device=cdev)
@@ -831,31 +910,27 @@ def main():
             stage_ms["decode: search kernel only"] = k_ms
             stage_ms["decode: lattice D2H, host ordering + best path"] = float(np.mean(dec_h_ms))
             if depth > 1:
-                stage_ms["note"] = ("%d batches in flight on %d streams: stage times of consecutive batches overlap and are not "
-                                    "additive; a search kernel's duration includes the time its workgroups wait for CUs still held "
-                                    "by the previous batch's grid" % (depth, depth))
+                stage_ms["note"] = ("per pipeline item (a step = %d slice(s) of %d utterances); %d items in flight on %d streams: stage times of "
+                                    "consecutive items overlap and are not additive; a search kernel's duration includes the time its "
+                                    "workgroups wait for CUs still held by the grids launched before it" % (S, per, depth, depth))
             extra["search_grid_last_batch"] = grid_stats
-            extra["search_retries_last_batch"] = dec.batch_stats()
-            # algorithmic bytes of the search from the counters of the last step:
-            # N_tok*(20+16) + N_arc*(16+4) + N_new*16 + N_link*24
-            c = dict(tok=0, arc=0, new=0, link=0, maxb=0, minb=0, lat_tok=0, lat_link=0)
-            for u in range(args.batch):
-                r = dec.result(u, arrays=False)
-                c["tok"] += r["n_tokens_expanded"]; c["arc"] += r["n_arcs_expanded"]; c["new"] += r["n_tokens_created"]
-                c["link"] += r["n_links_created"]; c["maxb"] += r["n_frames_maxactive_bound"]
-                c["minb"] += r["n_frames_minactive_bound"]; c["lat_tok"] += r["num_toks"]; c["lat_link"] += r["num_links"]
-            dbytes = c["tok"] * 36.0 + c["arc"] * 20.0 + c["new"] * 16.0 + c["link"] * 24.0
+            extra["search_retries_last_batch"] = col_stats
+            # algorithmic bytes of the search from the counters of one step:
+            # N_tok*(20+16) + N_arc*(16+4) + N_new*16 + N_link*24; one launch searches one slice, i.e. 1/S of them
+            cs = col_cnt.sum(0)
+            c = dict(tok=cs[0], arc=cs[1], new=cs[2], link=cs[3], maxb=int(cs[4]), minb=int(cs[5]), lat_tok=cs[6], lat_link=cs[7])
+            dbytes = (c["tok"] * 36.0 + c["arc"] * 20.0 + c["new"] * 16.0 + c["link"] * 24.0) / S
             dec_roof = {"kernel": "decode_kernel", "bound": "hbm", "achieved": dbytes / (k_ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "traffic": None, "kernel_ms": k_ms, "algorithmic_bytes": dbytes,
+                        "traffic": None, "kernel_ms": k_ms, "algorithmic_bytes": dbytes, "launches_per_step": S,
                         "note": "random-access (token/arc/link) bytes of SURVEY.md 8d over the kernel's own duration (HIP events "
                                 "on its stream); the search is bound by dependent-access latency, not by bandwidth (DESIGN.md)"}
             extra["search"] = {"tokens_expanded_per_frame": c["tok"] / T, "arcs_per_frame": c["arc"] / T,
                                "tokens_created_per_frame": c["new"] / T, "links_per_frame": c["link"] / T,
                                "frames_maxactive_bound": c["maxb"], "frames_minactive_bound": c["minb"],
                                "lattice_tokens_per_frame": c["lat_tok"] / T, "lattice_arcs_per_frame": c["lat_link"] / T,
-                               "arc_expansions_per_s": c["arc"] / (k_ms * 1e-3)}
-            extra["lattice_stage_host"] = determinize_measurement(args, dec, T)
+                               "arc_expansions_per_s": c["arc"] / S / (k_ms * 1e-3)}
+            extra["lattice_stage_host"] = determinize_measurement(args, dec, per, slices[(S - 1) % S].r1 - slices[(S - 1) % S].r0)
             if det_pool is not None and det_dt is not None:
                 nb = args.det_steps * args.batch
                 tt = det_pool.totals
@@ -867,11 +942,12 @@ def main():
                     "copy_out_seconds_on_the_step_thread": det_pool.submit_s, "raw_arcs_per_utt": float(tt[2]) / max(nb, 1),
                     "det_arcs_per_utt": float(tt[4]) / max(nb, 1), "stopped_before_beam": int(tt[5])}
             try:
-                extra["gmm_on_demand"] = ondemand_gmm_measurement(args, ctx, gmm, model, ring[0][1], T)
+                extra["gmm_on_demand"] = ondemand_gmm_measurement(args, ctx, gmm, model, ring[0][1][:n_rows0], n_rows0)
             except Exception as e:
                 extra["gmm_on_demand"] = {"error": str(e)}
             try:
-                extra["roofline_fmllr_stats"] = fmllr_measurement(args, ctx, gmm, ring[0][1], foff, utt2spk, n_spk, T)
+                extra["roofline_fmllr_stats"] = fmllr_measurement(args, ctx, gmm, ring[0][1][:n_rows0], slices[0].foff, slices[0].u2s,
+                                                                  int(slices[0].u2s.max()) + 1, n_rows0)
             except Exception as e:        # a measurement beside the step, never a reason to lose the bench line
                 extra["roofline_fmllr_stats"] = {"error": str(e)}
             if d_ms >= g_ms:
@@ -891,7 +967,7 @@ def main():
                                     % (args.beam, args.lattice_beam, args.max_active, graph.num_states, graph.num_arcs)),
                        "utterances_per_step_per_gpu": args.batch, "utterance_seconds": args.seconds,
                        "frames_per_step_per_gpu": T, "pdfs": gmm.num_pdfs, "gaussians": gmm.num_gauss, "dim": gmm.dim, "features": args.feat,
-                       "batches_in_flight": depth, "search_cus": args.search_cus,
+                       "batches_in_flight": depth, "slices_per_step": S, "search_cus": args.search_cus,
                        "lattices": "raw (state level) in the headline region; determinized on the host in the second region (lattice_stage_in_step)",
                        "sharding": "utterances over ranks, no data-path collective"},
             "roofline": roof, "stage_ms": stage_ms,
@@ -929,7 +1005,7 @@ def main():
                 out["cpu_baseline"], cpu_words = cpu_baseline(args, jobs[0], waves, utt2spk, xforms, lda, model, decode_setup)
             if dec is not None and cpu_words:
                 # the utterances the CPU leg decoded anyway: are the GPU step's hypotheses the same words?
-                same = sum(1 for u, w_ in cpu_words.items() if list(dec.result(u, arrays=False)["words"]) == list(w_))
+                same = sum(1 for u, w_ in cpu_words.items() if list(col_words[u]) == list(w_))
                 out["parity_words_equal"] = "%d/%d" % (same, len(cpu_words))
                 out["parity_note"] = ("best-path words of the GPU step against the %s's for the utterances of the CPU sample (same waveforms, model, "
                                       "graph, transforms)" % ("reference programs" if ref_cb is not None else "oracle"))

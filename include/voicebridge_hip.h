@@ -48,6 +48,11 @@ int vbh_ctx_sync(vbh_ctx *ctx);
 /* work enqueued on ctx after this call starts only when everything enqueued on other so far
  * has completed (stages of a pipeline on different contexts of one device); does not block */
 int vbh_ctx_wait_for(vbh_ctx *ctx, vbh_ctx *other);
+/* finer than vbh_ctx_wait_for: vbh_ctx_mark records "everything enqueued on ctx so far" under a slot number (0..15; a slot is
+ * overwritten by its next mark), vbh_ctx_wait_mark makes ctx wait for that point of other's stream -- a consumer stream
+ * waits for its own item of a producer stream that is already working on later items */
+int vbh_ctx_mark(vbh_ctx *ctx, int slot);
+int vbh_ctx_wait_mark(vbh_ctx *ctx, vbh_ctx *other, int slot);
 void *vbh_ctx_stream(vbh_ctx *ctx);               /* hipStream_t all work is enqueued on */
 int vbh_ctx_device(vbh_ctx *ctx);
 int vbh_dev_alloc(vbh_ctx *ctx, size_t bytes, void **d_ptr);
@@ -217,6 +222,10 @@ int vbh_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_decode_cf
  * slots -- instead of one set per decoder.  The pool lives as long as any decoder that uses it. */
 int vbh_decoder_create_shared(vbh_ctx *ctx, const vbh_graph *graph, const vbh_decode_cfg *cfg,
                               int32_t max_batch, int32_t max_frames, vbh_decoder *share_slots_with, vbh_decoder **out);
+/* Another search configuration for the batches that follow (beams, min_active, acoustic scale; max_active up to the value the
+ * decoder's workspaces were made for): DecodeFmllr's speaker-independent pass (beam 10, max-active 2000) and its main pass
+ * (beam 13, max-active 7000) then share one decoder and one set of workspaces. */
+int vbh_decoder_set_cfg(vbh_decoder *d, const vbh_decode_cfg *cfg);
 void vbh_decoder_destroy(vbh_decoder *d);
 /* Replaces LatticeFasterDecoder::Decode + FinalizeDecoding for a batch of utterances
  * (DecodeUtteranceLatticeFaster, K/decoder/decoder-wrappers.cc:198-293).  d_loglikes

@@ -54,6 +54,15 @@ class Context:
         """work enqueued here from now on starts after everything enqueued on `other` so far"""
         check(self.lib.vbh_ctx_wait_for(self.h, other.h), "vbh_ctx_wait_for")
 
+    def mark(self, slot):
+        self.lib.vbh_ctx_mark.argtypes = [C.c_void_p, C.c_int]
+        check(self.lib.vbh_ctx_mark(self.h, int(slot)), "vbh_ctx_mark")
+
+    def wait_mark(self, other, slot):
+        """work enqueued here from now on starts after `other` has reached its mark `slot`"""
+        self.lib.vbh_ctx_wait_mark.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        check(self.lib.vbh_ctx_wait_mark(self.h, other.h, int(slot)), "vbh_ctx_wait_mark")
+
     def torch_sync(self):
         """make work enqueued by torch (allocations, copies) visible to the ctx stream"""
         torch.cuda.synchronize(self.device)

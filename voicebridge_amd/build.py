@@ -59,7 +59,7 @@ def build(force=False, verbose=True):
 
 
 HOST_LIB = os.path.join(LIBDIR, "libvoicebridge_host.so")
-HOST_SOURCES = ["kaldi_io.cc", "lattice.cc", "voicebridge_api.cc", "voicebridge_latbin.cc", "voicebridge_fmllrbin.cc", "fmllr.cc", "voicebridge_steps.cc", "host_capi.cc"]
+HOST_SOURCES = ["kaldi_io.cc", "lattice.cc", "device_feats.cc", "voicebridge_api.cc", "voicebridge_latbin.cc", "voicebridge_fmllrbin.cc", "fmllr.cc", "voicebridge_steps.cc", "host_capi.cc"]
 
 
 def build_host(force=False, verbose=True):
@@ -67,7 +67,7 @@ def build_host(force=False, verbose=True):
     hdir = os.path.join(HERE, "host")
     srcs = [os.path.join(hdir, s) for s in HOST_SOURCES]
     deps = srcs + [os.path.join(hdir, "kaldi_io.h"), os.path.join(hdir, "voicebridge_api.h"), os.path.join(hdir, "voicebridge_steps.h"),
-                   os.path.join(hdir, "lattice.h"), os.path.join(hdir, "fmllr.h"), os.path.join(hdir, "api_common.h"),
+                   os.path.join(hdir, "lattice.h"), os.path.join(hdir, "fmllr.h"), os.path.join(hdir, "api_common.h"), os.path.join(hdir, "device_feats.h"),
                    os.path.join(ROOT, "include", "voicebridge_hip.h"), LIB]
     if force or any(_newer(d, HOST_LIB) for d in deps):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread", "-Wl,--no-undefined", "-I" + os.path.join(ROOT, "include"), "-I" + hdir,

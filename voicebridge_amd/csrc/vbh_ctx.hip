@@ -109,6 +109,7 @@ void vbh_ctx_destroy(vbh_ctx *c) {
     if (c->arena[i].done) (void)hipEventDestroy(c->arena[i].done);
   }
   for (int i = 0; i < VBH_MAX_TIMERS; i++) {
+    if (c->marks[i]) (void)hipEventDestroy(c->marks[i]);
     (void)hipEventDestroy(c->ev_start[i]);
     (void)hipEventDestroy(c->ev_stop[i]);
   }
@@ -132,6 +133,22 @@ int vbh_ctx_wait_for(vbh_ctx *c, vbh_ctx *other) {
   if (r == hipSuccess) r = hipStreamWaitEvent(c->stream, e, 0);
   (void)hipEventDestroy(e);      // released once the recorded work has completed
   VBH_HIP(r);
+  return 0;
+}
+int vbh_ctx_mark(vbh_ctx *c, int slot) {
+  VBH_CHECK(c && slot >= 0 && slot < VBH_MAX_TIMERS, "vbh_ctx_mark: bad argument");
+  if (vbh_use_device(c)) return -1;
+  if (!c->marks[slot]) VBH_HIP(hipEventCreateWithFlags(&c->marks[slot], hipEventDisableTiming));
+  VBH_HIP(hipEventRecord(c->marks[slot], c->stream));
+  return 0;
+}
+int vbh_ctx_wait_mark(vbh_ctx *c, vbh_ctx *other, int slot) {
+  VBH_CHECK(c && other && slot >= 0 && slot < VBH_MAX_TIMERS, "vbh_ctx_wait_mark: bad argument");
+  VBH_CHECK(c->device == other->device, "vbh_ctx_wait_mark: contexts on different devices");
+  VBH_CHECK(other->marks[slot], "vbh_ctx_wait_mark: mark %d was never set", slot);
+  if (vbh_use_device(c)) return -1;
+  if (c == other) return 0;
+  VBH_HIP(hipStreamWaitEvent(c->stream, other->marks[slot], 0));
   return 0;
 }
 void *vbh_ctx_stream(vbh_ctx *c) { return reinterpret_cast<void *>(c->stream); }

@@ -64,6 +64,11 @@
 
 namespace {
 
+// Threads per utterance.  1024 (one utterance per CU: its 155 KB of LDS leave room for no other workgroup) is the default.
+// 512 (two utterances per CU) searched 10 % more frames per second in r02's measurements, but a 512-thread search workgroup
+// shares its CU with workgroups of other kernels, and beside gmm_rows_kernel it faulted (memory access fault inside the
+// search's own slot memory, 5 of 7 runs; never beside the older GMM kernel, never with 1024 threads, never alone; not
+// explained -- see DESIGN.md): not shipped until that is understood.
 #ifndef VBH_DECODE_NT
 #define VBH_DECODE_NT 1024
 #endif
@@ -1781,7 +1786,8 @@ static int effective_prune_interval(const vbh_decode_cfg *cfg) {
 #endif
 static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
   const vbh_graph *graph = d->graph;
-  const vbh_decode_cfg *cfg = &d->cfg;
+  // (big slots follow the pool's configuration, which vbh_decoder_set_cfg cannot exceed)
+  const vbh_decode_cfg *cfg = (big && d->small_set && d->small_set->n > 0) ? &d->small_set->cfg : &d->cfg;
   const int max_frames = d->max_frames;
   const long long S = graph->S;
   const long long ma = std::min<long long>(cfg->max_active, S);
@@ -2462,6 +2468,19 @@ int vbh_decoder_phase_cycles(vbh_decoder *d, int32_t utt, int64_t *out8) {
 int vbh_decoder_times(vbh_decoder *d, float *out4) {
   VBH_CHECK(d && out4, "vbh_decoder_times: NULL argument");
   out4[0] = d->t_kernel_ms; out4[1] = d->t_copy_ms; out4[2] = d->t_host_ms; out4[3] = d->t_total_ms;
+  return 0;
+}
+
+int vbh_decoder_set_cfg(vbh_decoder *d, const vbh_decode_cfg *cfg) {
+  VBH_CHECK(d && cfg, "vbh_decoder_set_cfg: NULL argument");
+  VBH_CHECK(!d->pend.active, "vbh_decoder_set_cfg: a batch is in flight");
+  VBH_CHECK(cfg->beam > 0.0f && cfg->max_active > 1 && cfg->lattice_beam > 0.0f && cfg->prune_interval > 0 && cfg->beam_delta > 0.0f && cfg->min_active >= 0,
+            "vbh_decoder_set_cfg: invalid config (LatticeFasterDecoderConfig::Check)");
+  const SlotSet *o = d->small_set.get();
+  VBH_CHECK(o && cfg->max_active <= o->cfg.max_active && effective_prune_interval(cfg) == effective_prune_interval(&o->cfg),
+            "vbh_decoder_set_cfg: the search workspaces were made for max_active %d / pruning interval %d: a configuration that needs larger ones "
+            "needs a new decoder", o ? o->cfg.max_active : 0, o ? effective_prune_interval(&o->cfg) : 0);
+  d->cfg = *cfg;
   return 0;
 }
 

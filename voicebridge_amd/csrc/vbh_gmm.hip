@@ -212,6 +212,138 @@ __global__ __launch_bounds__(256, 2) void gmm_loglikes_kernel(
   }
 }
 
+
+// =====================================================================================
+// gmm_rows_kernel -- the same contraction with the roles of the MFMA operands swapped: the MODEL is the A operand (32
+// Gaussians = rows of a 32 x 32 block), the FRAMES are the B operand (columns).  What that buys:
+//   * the accumulator layout puts a frame in a lane (column = lane & 31) and 16 Gaussians of the block in its registers;
+//     one v_permlane32_swap per register pair hands each of the 64 lanes all 32 Gaussians of ONE of the tile's 64 frames,
+//     so the LogSumExp of a pdf is a register loop (online form: one running maximum and one rescaled sum per pdf) -- the
+//     accumulator tile never goes through LDS;
+//   * a wave's model operand is a strip nobody else reads (32 Gaussians x K), so it comes straight from global memory
+//     (L2/MALL resident) into registers, one row-block ahead; LDS holds only the 64 frames (read-only after the first
+//     barrier) and a small per-wave staging area for the output runs;
+//   * the four waves of a workgroup work on different row-blocks and never meet: NO barrier in the block loop.
+// The model is packed once (vbh_gmm_create): pdfs never straddle a 32-row block (the gap rows are Gaussians with
+// gconst = -inf, which add exp(-inf) = 0), a block holds at most 16 pdfs, a pdf with more than 32 Gaussians is scored in
+// parts of <= 32 that gmm_fold_parts_kernel combines.  Per block: {bit r set = row r starts a pdf, first pdf, #pdfs}.
+struct RbMeta { unsigned mask; int p0; int np; int pad; };
+constexpr int LDP = 17;       // padded row of a wave's staging area: [64 frames][<= 16 pdfs]
+
+template <int NC>             // NC = Kpad / 8: a lane's strip of a row-block is NC float4 (4 k-steps each)
+__global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
+    const float *__restrict__ feats, long long T, int D, int P,
+    const f32x4 *__restrict__ Mp,            // [n_rb][NC][64 lanes]: Mp[(rb*NC + c)*64 + lane][j] = row (lane & 31), k = 2(4c + j) + (lane >> 5)
+    const RbMeta *__restrict__ meta, int n_rb, int rb_per_group,
+    float *__restrict__ out) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int Kpad = NC * 8;
+  float *sA = lds;                                   // [Kpad][LDA]: [x, x^2, 1, 0..] of 64 frames, k-major
+  float *sStage = sA + Kpad * LDA + ((4 - (Kpad * LDA) % 4) % 4);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const long long t0 = (long long)blockIdx.x * TM;
+  const int j_begin = blockIdx.y * rb_per_group;
+  int j_end = j_begin + rb_per_group;
+  if (j_end > n_rb) j_end = n_rb;
+  for (int idx = tid; idx < TM * D; idx += 256) {
+    const int t = idx / D, d = idx - t * D;
+    float x = 0.f;
+    if (t0 + t < T) x = feats[(t0 + t) * D + d];
+    sA[d * LDA + t] = x;
+    sA[(D + d) * LDA + t] = x * x;
+  }
+  for (int idx = tid; idx < (Kpad - 2 * D) * TM; idx += 256) {
+    const int k = 2 * D + idx / TM, t = idx % TM;
+    sA[k * LDA + t] = (k == 2 * D) ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  const int khalf = lane >> 5, l31 = lane & 31;
+  float *stage = sStage + wid * (TM * LDP);
+  const float *pb = sA + khalf * LDA + l31;
+  int rb = j_begin + wid;
+  f32x4 cur[NC];
+  if (rb < j_end) {
+#pragma unroll
+    for (int c = 0; c < NC; c++) cur[c] = Mp[((size_t)rb * NC + c) * 64 + lane];
+  }
+  for (; rb < j_end; rb += 4) {
+    // next row-block's strip: in flight under this block's MFMAs
+    f32x4 nxt[NC];
+    {
+      const int rbn = rb + 4 < j_end ? rb + 4 : rb;
+#pragma unroll
+      for (int c = 0; c < NC; c++) nxt[c] = Mp[((size_t)rbn * NC + c) * 64 + lane];
+    }
+    const RbMeta mt = meta[rb];
+    const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)mt.mask);
+    const int p0 = __builtin_amdgcn_readfirstlane(mt.p0), np = __builtin_amdgcn_readfirstlane(mt.np);
+    // ---- 32 Gaussians x 64 frames x Kpad: two 32 x 32 accumulators (frames 0-31, 32-63)
+    f32x16 acc0 = {0}, acc1 = {0};
+    {
+      float b0[2][4], b1[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { b0[0][j] = pb[j * 2 * LDA]; b1[0][j] = pb[j * 2 * LDA + 32]; }
+#pragma unroll
+      for (int c = 0; c < NC; c++) {
+        if (c + 1 < NC) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) { const int kk = (c + 1) * 4 + j; b0[(c + 1) & 1][j] = pb[kk * 2 * LDA]; b1[(c + 1) & 1][j] = pb[kk * 2 * LDA + 32]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[c][j], b0[c & 1][j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[c][j], b1[c & 1][j], acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- every lane gets the 32 rows of its own frame (frame = lane): lanes 0-31 give away their share of frames 32-63
+    //      and take the rows 4-7, 12-15, ... of frames 0-31 from lanes 32-63, and the other way round
+    float v0[16], v1[16];     // v0[i]: row (i&3) + 8(i>>2), v1[i]: that row + 4
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[i]), __float_as_uint(acc1[i]), false, false);
+      v0[i] = __uint_as_float(r[0]); v1[i] = __uint_as_float(r[1]);
+    }
+    // ---- LogSumExp per pdf (kaldi-vector.cc:757-775), online: m = running maximum, s = sum of exp(x - m).  The terms the
+    //      reference drops (below max + log FLT_EPSILON) are below 1.2e-7 of the sum each: inside the stated tolerance.
+    {
+      float m = -3.0e38f, sum = 0.0f;
+      float *so = stage + lane * LDP;
+      int q = 0;
+#pragma unroll
+      for (int r = 0; r < 32; r++) {
+        const float x = ((r >> 2) & 1) ? v1[(r & 3) + 4 * (r >> 3)] : v0[(r & 3) + 4 * (r >> 3)];
+        if (r > 0 && ((mask >> r) & 1u)) {      // (wave-uniform) row r starts the next pdf
+          so[q] = sum > 0.0f ? m + __logf(sum) : -INFINITY;
+          q++;
+          m = -3.0e38f; sum = 0.0f;
+        }
+        const float m2 = fmaxf(m, x);
+        sum = sum * __expf(m - m2) + __expf(x - m2);
+        m = m2;
+      }
+      so[q] = sum > 0.0f ? m + __logf(sum) : -INFINITY;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- out: runs of np pdfs per frame, lanes along (frame, pdf)
+    {
+      const unsigned inv = (65536u + (unsigned)np - 1u) / (unsigned)np;
+      const int total = TM * np;
+      for (int idx = lane; idx < total; idx += 64) {
+        const int f = (int)(((unsigned)idx * inv) >> 16), q = idx - f * np;
+        if (t0 + f < T) out[(t0 + f) * P + p0 + q] = stage[f * LDP + q];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < NC; c++) cur[c] = nxt[c];
+  }
+}
+
 // A pdf with more than TN Gaussians is scored as several parts of <= TN columns (each part is a
 // "pdf" of the tile kernel above, written to a scratch [T x n_parts] block); this pass folds the
 // parts of every pdf with one more LogSumExp (same cutoff rule, kaldi-vector.cc:757-775).
@@ -313,6 +445,12 @@ struct vbh_gmm {
   DevBuf<int> d_pdf_parts;        // [P+1] first part of every pdf
   DevBuf<float> part_scratch;     // [part_chunk x n_parts]
   long long part_chunk;
+  // gmm_rows_kernel's form of the model (row-blocks of 32 Gaussians, see there); its own parts (a pdf of more than 32 Gaussians)
+  bool rows = false;
+  int n_rb = 0, n_parts2 = 0;
+  DevBuf<f32x4> Mp; DevBuf<RbMeta> rb_meta;
+  DevBuf<int> d_pdf_parts2; DevBuf<float> part_scratch2; long long part_chunk2 = 0;
+  size_t lds_bytes2 = 0;
   // plain row-major copies for the kernels that walk single pdfs (fMLLR statistics, vbh_fmllr.hip)
   DevBuf<float> d_miv, d_iv, d_gconsts;   // [G x D], [G x D], [G]
   DevBuf<int> d_pdf_offs;                 // [P+1]
@@ -408,6 +546,62 @@ int vbh_gmm_create(vbh_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h
     if (g->d_pdf_parts.upload(pdf_parts.data(), pdf_parts.size(), s) ||
         g->part_scratch.alloc((size_t)chunk * NP)) { delete g; return -1; }
   }
+  // ---- gmm_rows_kernel: parts of <= 32 Gaussians, row-blocks of whole parts (<= 16 of them), gap rows with gconst = -inf
+  g->rows = !getenv("VBH_GMM_V1");
+  if (g->rows) {
+    std::vector<int> part2(1, 0), pdf_parts2(P + 1, 0);
+    for (int p = 0; p < P; p++) {
+      const int n = h_pdf_offsets[p + 1] - h_pdf_offsets[p], k = (n + 31) / 32;
+      for (int i = 1; i <= k; i++) part2.push_back(h_pdf_offsets[p] + (int)((long long)n * i / k));
+      pdf_parts2[p + 1] = pdf_parts2[p] + k;
+    }
+    const int NP2 = pdf_parts2[P];
+    g->n_parts2 = NP2;
+    std::vector<RbMeta> meta;
+    std::vector<int> row_gauss;       // Gaussian of every packed row (-1 = gap)
+    for (int p = 0; p < NP2;) {
+      RbMeta m{0u, p, 0, 0};
+      int rows_used = 0;
+      while (p < NP2 && m.np < 16 && rows_used + (part2[p + 1] - part2[p]) <= 32) {
+        m.mask |= 1u << rows_used;
+        for (int gi = part2[p]; gi < part2[p + 1]; gi++) row_gauss.push_back(gi);
+        rows_used += part2[p + 1] - part2[p];
+        m.np++; p++;
+      }
+      for (; rows_used < 32; rows_used++) row_gauss.push_back(-1);
+      meta.push_back(m);
+    }
+    g->n_rb = (int)meta.size();
+    const int NC = g->Kpad / 8;
+    std::vector<f32x4> Mp((size_t)g->n_rb * NC * 64);
+    for (int rb = 0; rb < g->n_rb; rb++)
+      for (int c = 0; c < NC; c++)
+        for (int lane = 0; lane < 64; lane++) {
+          const int gi = row_gauss[(size_t)rb * 32 + (lane & 31)];
+          f32x4 v;
+          for (int j = 0; j < 4; j++) {
+            const int k = 2 * (4 * c + j) + (lane >> 5);
+            float x = 0.0f;
+            if (gi < 0) x = k == 2 * D ? -INFINITY : 0.0f;
+            else if (k < D) x = h_miv[(size_t)gi * D + k];
+            else if (k < 2 * D) x = -0.5f * h_iv[(size_t)gi * D + (k - D)];
+            else if (k == 2 * D) x = g->gconsts[gi];
+            v[j] = x;
+          }
+          Mp[((size_t)rb * NC + c) * 64 + lane] = v;
+        }
+    if (g->Mp.upload(Mp.data(), Mp.size(), s) || g->rb_meta.upload(meta.data(), meta.size(), s)) { delete g; return -1; }
+    if (NP2 > P) {
+      long long chunk = (256LL << 20) / (4LL * NP2);
+      chunk = chunk / TM * TM;
+      if (chunk < TM) chunk = TM;
+      if (chunk > 65536) chunk = 65536;
+      g->part_chunk2 = chunk;
+      if (g->d_pdf_parts2.upload(pdf_parts2.data(), pdf_parts2.size(), s) || g->part_scratch2.alloc((size_t)chunk * NP2)) { delete g; return -1; }
+    }
+    g->lds_bytes2 = sizeof(float) * ((size_t)g->Kpad * LDA + ((4 - (g->Kpad * LDA) % 4) % 4) + 4 * (size_t)TM * LDP);
+    if (const char *e = getenv("VBH_GMM_LDS_PAD")) g->lds_bytes2 += (size_t)atoi(e) * 1024;       // diagnostic: keeps the kernel off CUs whose LDS is mostly taken
+  }
   VBH_HIP(hipStreamSynchronize(s));
   const size_t a_floats = (size_t)g->Kpad * LDA + ((4 - (g->Kpad * LDA) % 4) % 4);
   const size_t bc_floats = std::max((size_t)g->Kpad * TN, (size_t)TM * LDC);
@@ -460,12 +654,26 @@ int vbh_gmm_work(const vbh_gmm *g, int64_t T, double *bytes, double *flops) {
 }
 
 static int gmm_launch_tiles(vbh_gmm *g, const float *d_feats, long long T, int n_cols, float *d_out);
+static int gmm_launch_rows(vbh_gmm *g, const float *d_feats, long long T, int n_cols, float *d_out);
 
 int vbh_gmm_loglikes(vbh_gmm *g, const float *d_feats, int64_t T, float *d_loglikes) {
   VBH_CHECK(g, "vbh_gmm_loglikes: NULL model");
   if (T == 0) return 0;
   VBH_CHECK(T > 0 && d_feats && d_loglikes, "vbh_gmm_loglikes: bad arguments");
   if (vbh_use_device(g->ctx)) return -1;
+  if (g->rows) {
+    if (g->n_parts2 == g->P) return gmm_launch_rows(g, d_feats, T, g->P, d_loglikes);
+    for (long long t0 = 0; t0 < T; t0 += g->part_chunk2) {
+      const long long n = std::min<long long>(g->part_chunk2, T - t0);
+      if (gmm_launch_rows(g, d_feats + t0 * g->D, n, g->n_parts2, g->part_scratch2.p)) return -1;
+      const long long blocks = (n * g->P + 255) / 256;
+      VBH_CHECK(blocks < 2147483647LL, "vbh_gmm_loglikes: chunk too large");
+      hipLaunchKernelGGL(gmm_fold_parts_kernel, dim3((unsigned)blocks), dim3(256), 0, g->ctx->stream,
+                         g->part_scratch2.p, n, g->n_parts2, g->P, g->d_pdf_parts2.p, d_loglikes + t0 * g->P);
+      VBH_HIP(hipGetLastError());
+    }
+    return 0;
+  }
   if (g->n_parts == g->P) return gmm_launch_tiles(g, d_feats, T, g->P, d_loglikes);
   // some pdf spans several column groups: score the parts of a chunk of frames, fold them
   for (long long t0 = 0; t0 < T; t0 += g->part_chunk) {
@@ -501,6 +709,38 @@ static int gmm_launch_tiles(vbh_gmm *g, const float *d_feats, long long T, int n
     hipLaunchKernelGGL(gmm_loglikes_kernel<N>, dim3((unsigned)ftiles, groups), dim3(256), g->lds_bytes, \
                        g->ctx->stream, d_feats, (long long)T, g->D, n_cols, g->Bp.p, g->tiles.p,         \
                        g->n_tiles, per, g->d_offs.p, d_out);                                           \
+    break;
+  switch (g->Kpad / 8) {
+    VBH_GMM_LAUNCH(1) VBH_GMM_LAUNCH(2) VBH_GMM_LAUNCH(3) VBH_GMM_LAUNCH(4) VBH_GMM_LAUNCH(5) VBH_GMM_LAUNCH(6)
+    VBH_GMM_LAUNCH(7) VBH_GMM_LAUNCH(8) VBH_GMM_LAUNCH(9) VBH_GMM_LAUNCH(10) VBH_GMM_LAUNCH(11) VBH_GMM_LAUNCH(12)
+    VBH_GMM_LAUNCH(13) VBH_GMM_LAUNCH(14) VBH_GMM_LAUNCH(15) VBH_GMM_LAUNCH(16)
+    default: vbh_set_error("vbh_gmm_loglikes: unsupported K %d", g->Kpad); return -1;
+  }
+#undef VBH_GMM_LAUNCH
+  VBH_HIP(hipGetLastError());
+  return 0;
+}
+
+static int gmm_launch_rows(vbh_gmm *g, const float *d_feats, long long T, int n_cols, float *d_out) {
+  const long long ftiles = (T + TM - 1) / TM;
+  VBH_CHECK(ftiles < 2147483647LL, "vbh_gmm_loglikes: T too large");
+  // split the row-blocks over blockIdx.y only when there are too few frame tiles to fill the chip
+  int groups = 1;
+  const long long want = 6LL * g->ctx->num_cus;
+  if (ftiles < want) {
+    groups = (int)((want + ftiles - 1) / ftiles);
+    if (groups > (g->n_rb + 3) / 4) groups = (g->n_rb + 3) / 4;
+  }
+  int per = (g->n_rb + groups - 1) / groups;
+  per = (per + 3) & ~3;
+  groups = (g->n_rb + per - 1) / per;
+#define VBH_GMM_LAUNCH(N)                                                                              \
+  case N:                                                                                              \
+    VBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gmm_rows_kernel<N>),                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds_bytes2));      \
+    hipLaunchKernelGGL(gmm_rows_kernel<N>, dim3((unsigned)ftiles, groups), dim3(256), g->lds_bytes2,   \
+                       g->ctx->stream, d_feats, (long long)T, g->D, n_cols, g->Mp.p, g->rb_meta.p,      \
+                       g->n_rb, per, d_out);                                                           \
     break;
   switch (g->Kpad / 8) {
     VBH_GMM_LAUNCH(1) VBH_GMM_LAUNCH(2) VBH_GMM_LAUNCH(3) VBH_GMM_LAUNCH(4) VBH_GMM_LAUNCH(5) VBH_GMM_LAUNCH(6)

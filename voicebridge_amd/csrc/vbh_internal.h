@@ -36,6 +36,7 @@ struct vbh_ctx {
   int num_cus;
   vbh_arena arena[VBH_ARENAS];
   int arena_next = 0;
+  hipEvent_t marks[VBH_MAX_TIMERS] = {};      // vbh_ctx_mark / vbh_ctx_wait_mark
 };
 
 vbh_arena *vbh_arena_begin(vbh_ctx *ctx, size_t bytes);          // NULL on error

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "api_common.h"
+#include "device_feats.h"
 #include "kaldi_io.h"
 #include "lattice.h"
 #include "voicebridge_hip.h"
@@ -157,6 +158,7 @@ struct LatgenCache {
   ~LatgenCache() { /* the process is ending or the thread is: the runtime reclaims device memory */ }
 };
 thread_local LatgenCache g_latgen;
+thread_local int g_workspace_max_active = 0;      // vb_set_workspace_max_active: see GmmLatgenFaster
 
 long long FileSig(const std::string &path) {
   struct stat st;
@@ -571,7 +573,7 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     Options po;
     po.Know({"beam", "max-active", "min-active", "lattice-beam", "prune-interval", "determinize-lattice", "beam-delta",
              "hash-ratio", "acoustic-scale", "word-symbol-table", "allow-partial", "max-mem", "phone-determinize",
-             "word-determinize", "minimize", "decode-batch", "delta",
+             "word-determinize", "minimize", "decode-batch", "workspace-max-active", "delta",
              // extensions of this build (not in the reference's program): the feature chain of the Decode step fused in front of the
              // scoring, on the device, so that the steps need no temporary archives between apply-cmvn, add-deltas / splice-feats +
              // transform-feats, transform-feats(fMLLR) and this program (VB/scr/steps/decode_gmm.cpp:201-293).  With --fe-cmvn the
@@ -612,52 +614,39 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     LatgenCache &cache = g_latgen;
     {
       const long long ms = FileSig(po.args[0]), gs = FileSig(po.args[1]);
-      if (cache.ctx != ctx || cache.model_path != po.args[0] || cache.graph_path != po.args[1] || cache.model_sig != ms || cache.graph_sig != gs || ms < 0 || gs < 0) {
-        cache.Release();
-        vbio::ReadModel(po.args[0], &cache.model);
-        lap("read model");
+      if (cache.ctx != ctx) cache.Release();
+      // the graph (and with it the search workspace) and the model are kept independently: DecodeFmllr's passes use two or
+      // three models over one graph
+      if (cache.g == nullptr || cache.graph_path != po.args[1] || cache.graph_sig != gs || gs < 0) {
+        if (cache.dec) { vbh_decoder_destroy(cache.dec); cache.dec = nullptr; cache.dec_batch = cache.dec_T = 0; }
+        if (cache.g) { vbh_graph_destroy(cache.g); cache.g = nullptr; }
         vbio::Graph graph;
         vbio::ReadFst(po.args[1], &graph);
         lap("read graph");
-        Check(vbh_gmm_create(ctx, cache.model.dim, cache.model.num_pdfs, cache.model.pdf_offsets.data(), cache.model.weights.data(),
-                             cache.model.means_invvars.data(), cache.model.inv_vars.data(), &cache.gmm), "vbh_gmm_create");
         static_assert(sizeof(vbio::Arc) == sizeof(vbh_arc), "arc layout");
         Check(vbh_graph_create(ctx, (int32_t)graph.final_cost.size(), graph.start, graph.final_cost.data(), graph.arc_offset.data(),
                                reinterpret_cast<const vbh_arc *>(graph.arcs.data()), &cache.g), "vbh_graph_create");
         cache.graph_start = graph.start;
-        cache.ctx = ctx; cache.model_path = po.args[0]; cache.graph_path = po.args[1]; cache.model_sig = ms; cache.graph_sig = gs;
-        lap("device model + graph");
+        cache.ctx = ctx; cache.graph_path = po.args[1]; cache.graph_sig = gs;
+        lap("device graph");
+      }
+      if (cache.gmm == nullptr || cache.model_path != po.args[0] || cache.model_sig != ms || ms < 0) {
+        if (cache.gmm) { vbh_gmm_destroy(cache.gmm); cache.gmm = nullptr; }
+        vbio::ReadModel(po.args[0], &cache.model);
+        lap("read model");
+        Check(vbh_gmm_create(ctx, cache.model.dim, cache.model.num_pdfs, cache.model.pdf_offsets.data(), cache.model.weights.data(),
+                             cache.model.means_invvars.data(), cache.model.inv_vars.data(), &cache.gmm), "vbh_gmm_create");
+        cache.ctx = ctx; cache.model_path = po.args[0]; cache.model_sig = ms;
+        lap("device model");
       }
     }
     const vbio::Model &model = cache.model;
     struct { int32_t start; } graph{cache.graph_start};
     vbh_gmm *gmm = cache.gmm;
     vbh_graph *g = cache.g;
-    // ---- fused front end (extension, see the option list)
-    const bool fused = po.Has("fe-cmvn");
-    std::map<std::string, vbio::MatrixD> fe_stats;
-    std::map<std::string, std::string> fe_utt2spk;
-    std::map<std::string, vbio::Matrix> fe_trans;
-    vbio::Matrix fe_lda;
-    vbh_featpost_cfg fe_cfg{};
-    if (fused) {
-      fe_stats = vbio::ReadMatrixDTable(po.Str("fe-cmvn", ""));
-      if (po.Has("fe-utt2spk")) fe_utt2spk = vbio::ReadStringMap(po.Str("fe-utt2spk", ""));
-      fe_cfg.apply_cmvn = 1;
-      fe_cfg.norm_vars = po.Bool("fe-norm-vars", false);
-      const std::string type = po.Str("fe-type", "delta");
-      if (type == "delta") { fe_cfg.mode = 1; fe_cfg.delta_order = (int)po.Num("fe-delta-order", 2); fe_cfg.delta_window = (int)po.Num("fe-delta-window", 2); }
-      else if (type == "lda") {
-        fe_cfg.mode = 2; fe_cfg.splice_left = (int)po.Num("fe-left-context", 4); fe_cfg.splice_right = (int)po.Num("fe-right-context", 4);
-        if (!po.Has("fe-lda")) throw ApiError("--fe-type=lda needs --fe-lda=<final.mat>");
-        std::ifstream f(po.Str("fe-lda", ""), std::ios::binary);
-        if (!f) throw ApiError("cannot open " + po.Str("fe-lda", ""));
-        const bool binary = vbio::ReadBinaryHeader(f);
-        vbio::ReadMatrix(f, binary, &fe_lda);
-        fe_cfg.lda_rows = fe_lda.rows; fe_cfg.lda_cols = fe_lda.cols;
-      } else throw ApiError("--fe-type must be delta or lda");
-      if (po.Has("fe-trans")) fe_trans = vbio::ReadMatrixTable(po.Str("fe-trans", ""));
-    }
+    // ---- fused front end (extension, device_feats.h)
+    FrontEnd fe;
+    fe.Parse(po);
     vbio::LatticeWriter lat_writer;
     vbio::CompactLatticeWriter clat_writer;
     if (want_lat) { if (determinize) clat_writer.Open(lat_wspec); else lat_writer.Open(lat_wspec); }
@@ -666,70 +655,43 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     if (po.args.size() >= 6 && !po.args[5].empty()) ali_writer.Open(po.args[5]);
 
     const int batch_utts = (int)po.Num("decode-batch", 256);
-    // the cached workspace serves this call when it was made for the same search configuration
-    if (cache.dec && memcmp(&cache.dec_cfg, &cfg, sizeof(cfg)) != 0) { vbh_decoder_destroy(cache.dec); cache.dec = nullptr; cache.dec_batch = cache.dec_T = 0; }
+    // the cached workspace serves this call when its capacities cover the search configuration (vbh_decoder_set_cfg: beams and
+    // scales are free, max_active up to what the workspaces were made for); --workspace-max-active (extension) asks for workspaces
+    // that also cover a later call with a larger max_active (DecodeFmllr: first pass 2000, main pass 7000)
+    vbh_decode_cfg ws_cfg = cfg;
+    ws_cfg.max_active = std::max(cfg.max_active, (int)po.Num("workspace-max-active", 0.0));
+    if (g_workspace_max_active > ws_cfg.max_active) ws_cfg.max_active = g_workspace_max_active;
+    if (cache.dec && memcmp(&cache.dec_cfg, &cfg, sizeof(cfg)) != 0 && vbh_decoder_set_cfg(cache.dec, &cfg) != 0) {
+      vbh_decoder_destroy(cache.dec); cache.dec = nullptr; cache.dec_batch = cache.dec_T = 0;
+    }
     cache.dec_cfg = cfg;
     vbh_decoder *&dec = cache.dec;
     int &dec_batch = cache.dec_batch, &dec_T = cache.dec_T;
-    vbio::MatrixReader reader(po.args[2]);
+    // the feature table on the device: read and uploaded once per job (the thread's cached copy serves the job's other programs)
+    const RawTable &tab = CachedRawTable(po.args[2]);
+    lap("features to the device");
     double tot_like = 0.0;
     int64_t frame_count = 0;
     int num_done = 0, num_err = 0;
-    std::string key; vbio::Matrix m;
-    bool more = true;
-    while (more) {
-      Batch b;
+    for (size_t u0 = 0; u0 < tab.keys.size();) {
+      const size_t u1 = std::min(tab.keys.size(), u0 + (size_t)std::max(batch_utts, 1));
+      Batch b;        // keys and row offsets of the batch (the rows themselves stay on the device)
       int max_T = 0;
-      while ((int)b.keys.size() < batch_utts && (more = reader.Next(&key, &m))) {
-        if (m.rows == 0) { log.os() << "WARNING (gmm-latgen-faster) Zero-length utterance: " << key << "\n"; num_err++; continue; }
-        if (!fused && m.cols != model.dim) throw ApiError("Dim mismatch: data dim = " + std::to_string(m.cols) + " vs. model dim = " + std::to_string(model.dim));
-        if (b.dim < 0) b.dim = m.cols;
-        b.Add(key, m);
-        if (m.rows > max_T) max_T = m.rows;
+      for (size_t u = u0; u < u1; u++) {
+        b.keys.push_back(tab.keys[u]);
+        b.offs.push_back(tab.offs[u + 1] - tab.offs[u0]);
+        max_T = std::max(max_T, tab.rows(u));
       }
-      if (b.keys.empty()) break;
-      lap("read features of a batch");
+      u0 = u1;
       const int64_t T = b.frames();
-      DevMem d_in(ctx, sizeof(float) * b.data.size());
+      if (T == 0) { for (const auto &k : b.keys) { log.os() << "WARNING (gmm-latgen-faster) Zero-length utterance: " << k << "\n"; num_err++; } continue; }
+      int fdim = 0;
+      std::unique_ptr<DevBuffer> d_fe;
+      const float *d_feats_p = DeviceFeatures(fe, tab, u1 - b.keys.size(), u1, &fdim, &d_fe);
+      if (fdim != model.dim)
+        throw ApiError(fe.fused ? "Dim mismatch: front end gives dim " + std::to_string(fdim) + " vs. model dim = " + std::to_string(model.dim)
+                                : "Dim mismatch: data dim = " + std::to_string(fdim) + " vs. model dim = " + std::to_string(model.dim));
       struct { void *p; } d_ll{g_latgen.Scores(ctx, sizeof(float) * (size_t)T * model.num_pdfs)};
-      Check(vbh_copy_h2d(ctx, d_in.p, b.data.data(), sizeof(float) * b.data.size()), "vbh_copy_h2d");
-      std::unique_ptr<DevMem> d_fe;
-      const float *d_feats_p = (const float *)d_in.p;
-      if (fused) {
-        // CMVN statistics and fMLLR transforms of the batch's speakers, packed in the order the speakers appear
-        vbh_featpost_cfg cfg = fe_cfg;
-        cfg.in_dim = b.dim;
-        std::map<std::string, int> idx; std::vector<int32_t> u2s; std::vector<double> stats; std::vector<float> xf;
-        for (const std::string &k : b.keys) {
-          std::string spk = k;
-          if (!fe_utt2spk.empty()) { auto it = fe_utt2spk.find(k); if (it != fe_utt2spk.end()) spk = it->second; }
-          if (!idx.count(spk)) {
-            auto it = fe_stats.find(spk);
-            if (it == fe_stats.end()) throw ApiError("No normalization statistics available for key " + k);
-            const vbio::MatrixD &ms = it->second;
-            if (ms.cols != b.dim + 1 || ms.rows < 1 || ms.rows > 2) throw ApiError("Dim mismatch: cmvn " + std::to_string(ms.rows) + "x" + std::to_string(ms.cols));
-            if (ms.rows == 1 && cfg.norm_vars) throw ApiError("You requested variance normalization but no variance stats are supplied.");
-            stats.insert(stats.end(), ms.data.begin(), ms.data.end());
-            if (ms.rows == 1) stats.insert(stats.end(), (size_t)(b.dim + 1), 0.0);
-            if (!fe_trans.empty()) {
-              auto tt = fe_trans.find(spk);
-              if (tt == fe_trans.end()) throw ApiError("No fMLLR transform for speaker " + spk);
-              if (cfg.spk_rows == 0) { cfg.spk_rows = tt->second.rows; cfg.spk_cols = tt->second.cols; }
-              if (tt->second.rows != cfg.spk_rows || tt->second.cols != cfg.spk_cols) throw ApiError("fMLLR transforms of different sizes");
-              xf.insert(xf.end(), tt->second.data.begin(), tt->second.data.end());
-            }
-            const int n = (int)idx.size(); idx[spk] = n;
-          }
-          u2s.push_back(idx[spk]);
-        }
-        if (!fe_trans.empty() && !idx.empty()) { cfg.spk_rows = fe_trans.begin()->second.rows; cfg.spk_cols = fe_trans.begin()->second.cols; }
-        const int od = vbh_featpost_out_dim(&cfg);
-        if (od != model.dim) throw ApiError("Dim mismatch: front end gives dim " + std::to_string(od) + " vs. model dim = " + std::to_string(model.dim));
-        d_fe.reset(new DevMem(ctx, sizeof(float) * (size_t)T * od));
-        Check(vbh_featpost(ctx, &cfg, (const float *)d_in.p, b.offs.data(), (int32_t)b.keys.size(), u2s.data(), (int)idx.size(), stats.data(),
-                           fe_lda.data.empty() ? nullptr : fe_lda.data.data(), xf.empty() ? nullptr : xf.data(), (float *)d_fe->p), "vbh_featpost");
-        d_feats_p = (const float *)d_fe->p;
-      }
       Check(vbh_gmm_loglikes(gmm, d_feats_p, T, (float *)d_ll.p), "vbh_gmm_loglikes");
       // the decoder (tens of GB of search workspace at the reference's batch sizes) is kept across the batches of the table
       // and only rebuilt when a batch needs more utterances or longer ones than it was made for
@@ -737,7 +699,8 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
         if (dec) vbh_decoder_destroy(dec);
         dec = nullptr;
         dec_batch = std::max((int)b.keys.size(), dec_batch); dec_T = std::max(max_T, dec_T);
-        Check(vbh_decoder_create(ctx, g, &cfg, dec_batch, dec_T, &dec), "vbh_decoder_create");
+        Check(vbh_decoder_create(ctx, g, &ws_cfg, dec_batch, dec_T, &dec), "vbh_decoder_create");
+        if (ws_cfg.max_active != cfg.max_active) Check(vbh_decoder_set_cfg(dec, &cfg), "vbh_decoder_set_cfg");
         lap("front end + decoder create");
       }
       const int rc = vbh_decode_batch(dec, (const float *)d_ll.p, model.num_pdfs, b.offs.data(), (int32_t)b.keys.size(),
@@ -791,6 +754,7 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
       for (size_t u = 0; u < nu; u++) {
         const vbh_lattice &L = Ls[u];
         const std::string &utt = b.keys[u];
+        if (b.offs[u + 1] == b.offs[u]) { log.os() << "WARNING (gmm-latgen-faster) Zero-length utterance: " << utt << "\n"; num_err++; continue; }
         // DecodeUtteranceLatticeFaster (K/decoder/decoder-wrappers.cc:198-293)
         if (!L.ok) { log.os() << "WARNING (gmm-latgen-faster) Failed to decode file " << utt << "\n"; num_err++; continue; }
         if (!L.reached_final) {
@@ -1210,9 +1174,11 @@ void vb_det_pool_destroy(void *pool) {
   for (std::thread &t : p->workers) t.join();
   delete p;
 }
+// the calling thread's following gmm-latgen-faster calls make their search workspaces large enough for this max_active as well
+int vb_set_workspace_max_active(int max_active) { g_workspace_max_active = max_active > 0 ? max_active : 0; return 0; }
 int vb_set_device(int device_id) { if (device_id != g_device) g_latgen.Release(); g_device = device_id; return 0; }
 // frees the model, graph and search workspace the calling thread's last gmm-latgen-faster call left on the device
-void vb_release_device_cache(void) { g_latgen.Release(); }
+void vb_release_device_cache(void) { g_latgen.Release(); ReleaseRawTableCache(); }
 int vb_ComputeMFCCFeats(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return ComputeMFCCFeats(argc, argv, l); }); }
 int vb_ComputeCmvnStats(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return ComputeCmvnStats(argc, argv, l); }); }
 int vb_ApplyCmvn(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return ApplyCmvn(argc, argv, l); }); }

@@ -16,6 +16,7 @@
 #include <unordered_map>
 
 #include "api_common.h"
+#include "device_feats.h"
 #include "fmllr.h"
 #include "kaldi_io.h"
 #include "lattice.h"
@@ -82,14 +83,6 @@ vbfmllr::FmllrOptions ReadFmllrOptions(const Options &po) {
   o.min_count = (float)po.Num("fmllr-min-count", 500.0);
   o.num_iters = (int)po.Num("fmllr-num-iters", 40);
   return o;
-}
-
-std::map<std::string, vbio::Matrix> ReadFeatureTable(const std::string &rspec) {
-  std::map<std::string, vbio::Matrix> out;
-  vbio::MatrixReader r(rspec);
-  std::string k; vbio::Matrix m;
-  while (r.Next(&k, &m)) out.emplace(k, std::move(m));
-  return out;
 }
 
 }  // namespace
@@ -252,15 +245,16 @@ static int EstimateOnGpu(const char *prog, bool use_gpost, const Options &po, co
                          const std::string &trans_wspec, Log &log, AddUtt add_utt) {
   const vbfmllr::FmllrOptions opts = ReadFmllrOptions(po);
   const int D = gmm.m.dim, n1 = D + 1;
+  // ---- the features: the table on the device (the thread's cached copy when this job's previous program read it), behind
+  //      the fused front end when --fe-* options are given
+  FrontEnd fe;
+  fe.Parse(po);
+  const RawTable &tab = CachedRawTable(feat_rspec);
+  const size_t NU = tab.keys.size();
   // ---- the units a transform is estimated for (speakers, or utterances without --spk2utt) and their utterances
   std::vector<std::pair<std::string, std::vector<std::string>>> units;
-  std::map<std::string, vbio::Matrix> feats;
-  {
-    vbio::MatrixReader r(feat_rspec);
-    std::string k; vbio::Matrix m;
-    while (r.Next(&k, &m)) { if (!po.Has("spk2utt")) units.emplace_back(k, std::vector<std::string>{k}); feats.emplace(k, std::move(m)); }
-  }
   if (po.Has("spk2utt")) units = vbio::ReadSpk2Utt(po.Str("spk2utt", ""));
+  else for (const std::string &k : tab.keys) units.emplace_back(k, std::vector<std::string>{k});
   vbh_ctx *ctx = SharedCtx();
   vbh_gmm *dgmm = nullptr;
   if (vbh_gmm_create(ctx, D, gmm.m.num_pdfs, gmm.m.pdf_offsets.data(), gmm.m.weights.data(), gmm.m.means_invvars.data(), gmm.m.inv_vars.data(), &dgmm) != 0)
@@ -281,42 +275,41 @@ static int EstimateOnGpu(const char *prog, bool use_gpost, const Options &po, co
   std::vector<vbfmllr::FmllrAccs> accs(units.size(), vbfmllr::FmllrAccs(D));
   std::vector<uint8_t> unit_has_utt(units.size(), 0);
   int num_done = 0, num_err = 0;
-  // ---- batches of utterances through the GPU (statistics add up across batches)
-  std::vector<float> bfeats; std::vector<int64_t> foff{0}; std::vector<int32_t> u2s;
+  // ---- the table's utterances in table order: unit of each (-1: not part of any unit, or skipped), its posterior pairs per frame
+  std::vector<int32_t> u2s(NU, -1);
+  for (size_t s_ = 0; s_ < units.size(); s_++)
+    for (const std::string &utt : units[s_].second) {
+      auto it = tab.index.find(utt);
+      if (it == tab.index.end() || tab.rows((size_t)it->second) == 0) { log.os() << "WARNING (" << prog << ") Did not find features for utterance " << utt << "\n"; num_err++; continue; }
+      u2s[(size_t)it->second] = (int32_t)s_;
+    }
   PairSink sink;
-  auto flush = [&]() {
-    if (u2s.empty()) return;
-    void *d_feats = nullptr;
-    if (vbh_dev_alloc(ctx, sizeof(float) * bfeats.size(), &d_feats) != 0) throw ApiError(std::string("vbh_dev_alloc: ") + vbh_last_error());
-    struct DevGuard { vbh_ctx *c; void *p; ~DevGuard() { vbh_dev_free(c, p); } } dg{ctx, d_feats};
-    if (vbh_copy_h2d(ctx, d_feats, bfeats.data(), sizeof(float) * bfeats.size()) != 0) throw ApiError(std::string("vbh_copy_h2d: ") + vbh_last_error());
+  for (size_t u = 0; u < NU; u++) {
+    const int rows = tab.rows(u);
+    if (u2s[u] >= 0) {
+      const size_t before = sink.poff.size();
+      if (add_utt(tab.keys[u], rows, &sink)) { unit_has_utt[(size_t)u2s[u]] = 1; num_done++; continue; }
+      if (sink.poff.size() != before) throw ApiError("internal: a skipped utterance left posterior frames behind");
+      num_err++;
+      u2s[u] = -1;
+    }
+    for (int t = 0; t < rows; t++) sink.EndFrame();      // an utterance without statistics: frames without pairs
+  }
+  if (num_done > 0) {
+    int fdim = 0;
+    std::unique_ptr<DevBuffer> hold;
+    const float *d_feats = DeviceFeatures(fe, tab, 0, NU, &fdim, &hold);
+    if (fdim != D) throw ApiError("Dim mismatch: data dim = " + std::to_string(fdim) + " vs. model dim = " + std::to_string(D));
     const int S = (int)units.size();
     std::vector<double> beta(S), K((size_t)S * D * n1), G((size_t)S * D * n1 * n1);
     const int rc = use_gpost
-        ? vbh_fmllr_accumulate_gpost(ctx, dgmm, (const float *)d_feats, (int32_t)u2s.size(), foff.data(), u2s.data(), S, sink.poff.data(), sink.ppdf.data(),
+        ? vbh_fmllr_accumulate_gpost(ctx, dgmm, d_feats, (int32_t)NU, tab.offs.data(), u2s.data(), S, sink.poff.data(), sink.ppdf.data(),
                                      sink.goff.data(), sink.gpost.data(), num_gauss.data(), beta.data(), K.data(), G.data(), nullptr)
-        : vbh_fmllr_accumulate(ctx, dali, dgmm, (const float *)d_feats, (int32_t)u2s.size(), foff.data(), u2s.data(), S, sink.poff.data(), sink.ppdf.data(),
+        : vbh_fmllr_accumulate(ctx, dali, dgmm, d_feats, (int32_t)NU, tab.offs.data(), u2s.data(), S, sink.poff.data(), sink.ppdf.data(),
                                sink.pw.data(), beta.data(), K.data(), G.data(), nullptr);
     if (rc != 0) throw ApiError(std::string("vbh_fmllr_accumulate: ") + vbh_last_error());
-    for (int s = 0; s < S; s++) if (beta[s] != 0.0) accs[s].AddStats(beta[s], &K[(size_t)s * D * n1], &G[(size_t)s * D * n1 * n1]);
-    bfeats.clear(); foff.assign(1, 0); u2s.clear(); sink.Clear();
-  };
-  for (size_t s = 0; s < units.size(); s++) {
-    for (const std::string &utt : units[s].second) {
-      auto fi = feats.find(utt);
-      if (fi == feats.end()) { log.os() << "WARNING (" << prog << ") Did not find features for utterance " << utt << "\n"; num_err++; continue; }
-      const vbio::Matrix &f = fi->second;
-      if (f.cols != D) throw ApiError("Dim mismatch: data dim = " + std::to_string(f.cols) + " vs. model dim = " + std::to_string(D));
-      if (!add_utt(utt, f, &sink)) { num_err++; continue; }
-      bfeats.insert(bfeats.end(), f.data.begin(), f.data.end());
-      foff.push_back(foff.back() + f.rows);
-      u2s.push_back((int32_t)s);
-      unit_has_utt[s] = 1;
-      num_done++;
-      if (foff.back() >= (int64_t)4 << 20) flush();
-    }
+    for (int s_ = 0; s_ < S; s_++) if (beta[s_] != 0.0) accs[s_].AddStats(beta[s_], &K[(size_t)s_ * D * n1], &G[(size_t)s_ * D * n1 * n1]);
   }
-  flush();
   // ---- per unit: update from the unit transform (40 row-by-row iterations, a 39 x 39 inverse per row: 0.1 s of one core per
   //      speaker, independent per speaker -> spread over the host's threads), then written in table order
   std::vector<vbio::Matrix> xf(units.size());
@@ -361,16 +354,17 @@ int GmmEstFmllrGpost(int argc, char *argv[], std::ofstream &file_log) {
   return Guard("gmm-est-fmllr-gpost", &file_log, [&](Log &log) -> int {
     Options po;
     po.Know({"spk2utt", "fmllr-update-type", "fmllr-min-count", "fmllr-num-iters"});
+    FrontEnd::Know(&po);
     po.Parse(argc, argv);
     if (po.args.size() != 4) throw ApiError("Wrong arguments.");
     const Gmm gmm(po.args[0]);
     std::map<std::string, vbio::GaussPost> gposts;
     for (auto &kv : vbio::ReadGaussPostTable(po.args[2])) gposts.emplace(kv.first, std::move(kv.second));
-    return EstimateOnGpu("gmm-est-fmllr-gpost", true, po, gmm, nullptr, po.args[1], po.args[3], log, [&](const std::string &utt, const vbio::Matrix &feats, PairSink *sink) {
+    return EstimateOnGpu("gmm-est-fmllr-gpost", true, po, gmm, nullptr, po.args[1], po.args[3], log, [&](const std::string &utt, int feat_rows, PairSink *sink) {
       auto it = gposts.find(utt);
       if (it == gposts.end()) { log.os() << "WARNING (gmm-est-fmllr-gpost) Did not find posteriors for utterance " << utt << "\n"; return false; }
       const vbio::GaussPost &gp = it->second;
-      if ((int)gp.size() != feats.rows) { log.os() << "WARNING (gmm-est-fmllr-gpost) GaussPost vector has wrong size " << gp.size() << " vs. " << feats.rows << "\n"; return false; }
+      if ((int)gp.size() != feat_rows) { log.os() << "WARNING (gmm-est-fmllr-gpost) GaussPost vector has wrong size " << gp.size() << " vs. " << feat_rows << "\n"; return false; }
       for (const auto &fr : gp)
         for (const auto &pr : fr)
           if (pr.first < 0 || pr.first >= gmm.m.num_pdfs || (int)pr.second.size() != gmm.m.pdf_offsets[pr.first + 1] - gmm.m.pdf_offsets[pr.first])
@@ -389,6 +383,7 @@ int GmmEstFmllr(int argc, char *argv[], std::ofstream &file_log) {
   return Guard("gmm-est-fmllr", &file_log, [&](Log &log) -> int {
     Options po;
     po.Know({"spk2utt", "fmllr-update-type", "fmllr-min-count", "fmllr-num-iters", "ali-model"});
+    FrontEnd::Know(&po);
     po.Parse(argc, argv);
     if (po.args.size() != 4) throw ApiError("Wrong arguments.");
     const Gmm gmm(po.args[0]);
@@ -396,10 +391,10 @@ int GmmEstFmllr(int argc, char *argv[], std::ofstream &file_log) {
     if (po.Has("ali-model")) ali.reset(new Gmm(po.Str("ali-model", "")));
     std::map<std::string, vbio::Posterior> posts;
     for (auto &kv : vbio::ReadPosteriorTable(po.args[2])) posts.emplace(kv.first, std::move(kv.second));
-    return EstimateOnGpu("gmm-est-fmllr", false, po, gmm, ali.get(), po.args[1], po.args[3], log, [&](const std::string &utt, const vbio::Matrix &feats, PairSink *sink) {
+    return EstimateOnGpu("gmm-est-fmllr", false, po, gmm, ali.get(), po.args[1], po.args[3], log, [&](const std::string &utt, int feat_rows, PairSink *sink) {
       auto pi = posts.find(utt);
       if (pi == posts.end()) { log.os() << "WARNING (gmm-est-fmllr) Did not find posteriors for utterance " << utt << "\n"; return false; }
-      if ((int)pi->second.size() != feats.rows) { log.os() << "WARNING (gmm-est-fmllr) Posterior vector has wrong size " << pi->second.size() << " vs. " << feats.rows << "\n"; return false; }
+      if ((int)pi->second.size() != feat_rows) { log.os() << "WARNING (gmm-est-fmllr) Posterior vector has wrong size " << pi->second.size() << " vs. " << feat_rows << "\n"; return false; }
       vbio::Posterior pdf_post;
       PosteriorToPdfs(gmm.m.tid2pdf, pi->second, &pdf_post);
       for (const auto &fr : pdf_post) { for (const auto &pr : fr) { sink->ppdf.push_back(pr.first); sink->pw.push_back(pr.second); } sink->EndFrame(); }
@@ -446,13 +441,16 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
   return Guard("gmm-rescore-lattice", &file_log, [&](Log &log) -> int {
     Options po;
     po.Know({"old-acoustic-scale"});
+    FrontEnd::Know(&po);
     po.Parse(argc, argv);
     if (po.args.size() != 4) throw ApiError("Wrong arguments.");
     const float old_acoustic_scale = (float)po.Num("old-acoustic-scale", 0.0);
     vbio::Model model;
     vbio::ReadModel(po.args[0], &model);
     const int D = model.dim;
-    const auto feats = ReadFeatureTable(po.args[2]);
+    FrontEnd fe;
+    fe.Parse(po);
+    const RawTable &tab = CachedRawTable(po.args[2]);
     vbh_ctx *ctx = SharedCtx();
     vbh_gmm *dgmm = nullptr;
     if (vbh_gmm_create(ctx, D, model.num_pdfs, model.pdf_offsets.data(), model.weights.data(), model.means_invvars.data(), model.inv_vars.data(), &dgmm) != 0)
@@ -463,11 +461,11 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
     writer.Open(po.args[3]);
     int num_done = 0, num_err = 0;
     long long num_frames = 0;
-    // Per lattice: conversion to the compact form, state times, the pdfs it holds at every frame (host threads); per chunk of
-    // lattices: one call of the on-demand kernel for all their (frame, pdf) pairs; then the scores are added (host threads) and the
-    // lattices written in table order.
+    // Per lattice: conversion to the compact form, state times, the pdfs it holds at every frame (host threads); then ONE call of
+    // the on-demand kernel for the (frame, pdf) pairs of all lattices over the table's features on the device; then the scores are
+    // added (host threads) and the lattices written in table order.
     struct Item {
-      std::string key; const char *bytes = nullptr; size_t nbytes = 0; vblat::CompactLattice clat; std::string entry; const vbio::Matrix *f = nullptr;
+      std::string key; const char *bytes = nullptr; size_t nbytes = 0; vblat::CompactLattice clat; std::string entry; int utt = -1, rows = 0;
       std::vector<int64_t> off; std::vector<int32_t> pdfs;      // per frame [off[t], off[t+1]) into pdfs (sorted, unique)
       int64_t base = 0; std::string warn, err; bool ok = false;
     };
@@ -485,10 +483,9 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
     parallel_for(items.size(), [&](size_t i) {
       Item &it = items[i];
       try {
-        auto fi = feats.find(it.key);
-        if (fi == feats.end()) { it.warn = "No feature found for utterance " + it.key + ". Skipping"; return; }
-        const vbio::Matrix &f = fi->second;
-        if (f.cols != D) throw ApiError("Dim mismatch: data dim = " + std::to_string(f.cols) + " vs. model dim = " + std::to_string(D));
+        auto fi = tab.index.find(it.key);
+        if (fi == tab.index.end() || tab.rows((size_t)fi->second) == 0) { it.warn = "No feature found for utterance " + it.key + ". Skipping"; return; }
+        it.utt = fi->second; it.rows = tab.rows((size_t)it.utt);
         {
           vblat::Lattice lat; bool compact = false;
           vbio::ParseLatticeBytes(it.bytes, it.nbytes, &lat, &it.clat, &compact);
@@ -500,13 +497,13 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
         // the pdfs the lattice holds at every frame (the same walk as RescoreCompactLattice's time_to_state, lattice-functions.cc:1236-1270)
         std::vector<int32_t> times;
         const int32_t utt_len = vblat::CompactLatticeStateTimes(it.clat, &times);
-        if (utt_len > f.rows) { it.warn = "Features are too short for lattice: utt-len is " + std::to_string(utt_len) + " for utterance " + it.key; return; }
-        std::vector<std::vector<int32_t>> pdfs(f.rows);
+        if (utt_len > it.rows) { it.warn = "Features are too short for lattice: utt-len is " + std::to_string(utt_len) + " for utterance " + it.key; return; }
+        std::vector<std::vector<int32_t>> pdfs(it.rows);
         bool ok = true;
         auto add = [&](int32_t t0, const std::vector<int32_t> &str) {
           for (size_t o = 0; o < str.size(); o++) {
             if (str[o] <= 0 || str[o] >= (int32_t)model.tid2pdf.size()) throw ApiError("lattice: transition-id out of the model's range");
-            if (t0 + (int32_t)o >= f.rows) { ok = false; return; }
+            if (t0 + (int32_t)o >= it.rows) { ok = false; return; }
             pdfs[t0 + o].push_back(model.tid2pdf[str[o]]);
           }
         };
@@ -515,8 +512,8 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
           add(times[s], it.clat.st[s].final.str);
         }
         if (!ok) { it.warn = "lattice/feature mismatch for utterance " + it.key; return; }
-        it.off.reserve(f.rows + 1);
-        for (int t = 0; t < f.rows; t++) {
+        it.off.reserve(it.rows + 1);
+        for (int t = 0; t < it.rows; t++) {
           std::vector<int32_t> &v = pdfs[t];
           std::sort(v.begin(), v.end());
           v.erase(std::unique(v.begin(), v.end()), v.end());
@@ -524,54 +521,55 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
           it.pdfs.insert(it.pdfs.end(), v.begin(), v.end());
         }
         it.off.push_back((int64_t)it.pdfs.size());
-        it.f = &f;
         it.ok = true;
       } catch (const std::exception &e) { it.err = e.what(); if (it.err.empty()) it.err = "error"; }
     });
     for (const Item &it : items) if (!it.err.empty()) throw ApiError(it.err);
-    for (size_t c0 = 0; c0 < items.size();) {
-      // a chunk of lattices: up to ~2 M frames through one GPU call
-      size_t c1 = c0; int64_t frames = 0;
-      while (c1 < items.size() && (frames == 0 || frames < ((int64_t)2 << 20))) { if (items[c1].ok) frames += items[c1].f->rows; c1++; }
-      std::vector<float> bfeats; std::vector<int64_t> poff{0}; std::vector<int32_t> ppdf;
-      for (size_t i = c0; i < c1; i++) {
-        Item &it = items[i];
-        if (!it.ok) continue;
-        it.base = (int64_t)ppdf.size();
-        bfeats.insert(bfeats.end(), it.f->data.begin(), it.f->data.end());
-        for (int t = 0; t < it.f->rows; t++) poff.push_back(it.base + it.off[t + 1]);
-        ppdf.insert(ppdf.end(), it.pdfs.begin(), it.pdfs.end());
-      }
-      std::vector<float> scores(ppdf.size());
-      if (!ppdf.empty()) {
-        const int64_t T = (int64_t)poff.size() - 1;
-        void *d_feats = nullptr;
-        if (vbh_dev_alloc(ctx, sizeof(float) * bfeats.size(), &d_feats) != 0) throw ApiError(std::string("vbh_dev_alloc: ") + vbh_last_error());
-        struct DevGuard { vbh_ctx *c; void *p; ~DevGuard() { vbh_dev_free(c, p); } } dg{ctx, d_feats};
-        if (vbh_copy_h2d(ctx, d_feats, bfeats.data(), sizeof(float) * bfeats.size()) != 0) throw ApiError(std::string("vbh_copy_h2d: ") + vbh_last_error());
-        if (vbh_gmm_loglikes_pairs(dgmm, (const float *)d_feats, T, poff.data(), ppdf.data(), scores.data()) != 0)
-          throw ApiError(std::string("vbh_gmm_loglikes_pairs: ") + vbh_last_error());
-      }
-      parallel_for(c1 - c0, [&](size_t k) {
-        Item &it = items[c0 + k];
-        if (!it.ok) return;
-        auto loglike = [&](int32_t t, int32_t tid) -> float {
-          const int32_t pdf = model.tid2pdf[tid];
-          const int32_t *a = it.pdfs.data() + it.off[t], *b = it.pdfs.data() + it.off[t + 1];
-          return scores[it.base + (std::lower_bound(a, b, pdf) - it.pdfs.data())];
-        };
-        if (!vblat::RescoreCompactLattice(loglike, it.f->rows, &it.clat)) { it.ok = false; it.warn = "lattice/feature mismatch for utterance " + it.key; return; }
+    // ---- the pairs of every frame of the table, in table order (frames of utterances without a usable lattice: none)
+    std::vector<int> item_of(tab.keys.size(), -1);
+    for (size_t i = 0; i < items.size(); i++) if (items[i].ok && item_of[(size_t)items[i].utt] < 0) item_of[(size_t)items[i].utt] = (int)i;
+    std::vector<int64_t> poff{0}; std::vector<int32_t> ppdf;
+    poff.reserve((size_t)tab.frames() + 1);
+    for (size_t u = 0; u < tab.keys.size(); u++) {
+      const int rows = tab.rows(u);
+      if (item_of[u] < 0) { for (int t = 0; t < rows; t++) poff.push_back((int64_t)ppdf.size()); continue; }
+      Item &it = items[(size_t)item_of[u]];
+      it.base = (int64_t)ppdf.size();
+      for (int t = 0; t < rows; t++) poff.push_back(it.base + it.off[t + 1]);
+      ppdf.insert(ppdf.end(), it.pdfs.begin(), it.pdfs.end());
+    }
+    std::vector<float> scores(ppdf.size());
+    if (!ppdf.empty()) {
+      int fdim = 0;
+      std::unique_ptr<DevBuffer> hold;
+      const float *d_feats = DeviceFeatures(fe, tab, 0, tab.keys.size(), &fdim, &hold);
+      if (fdim != D) throw ApiError("Dim mismatch: data dim = " + std::to_string(fdim) + " vs. model dim = " + std::to_string(D));
+      if (vbh_gmm_loglikes_pairs(dgmm, d_feats, tab.frames(), poff.data(), ppdf.data(), scores.data()) != 0)
+        throw ApiError(std::string("vbh_gmm_loglikes_pairs: ") + vbh_last_error());
+    }
+    parallel_for(items.size(), [&](size_t k) {
+      Item &it = items[k];
+      if (!it.ok) return;
+      const Item &src = items[(size_t)item_of[(size_t)it.utt]];       // (a key met twice in the lattice table shares the first one's scores)
+      auto loglike = [&](int32_t t, int32_t tid) -> float {
+        const int32_t pdf = model.tid2pdf[tid];
+        const int32_t *a = src.pdfs.data() + src.off[t], *b = src.pdfs.data() + src.off[t + 1];
+        const int32_t *f = std::lower_bound(a, b, pdf);
+        if (f == b || *f != pdf) throw ApiError("internal: pdf of a lattice arc was not scored");
+        return scores[src.base + (f - src.pdfs.data())];
+      };
+      try {
+        if (!vblat::RescoreCompactLattice(loglike, it.rows, &it.clat)) { it.ok = false; it.warn = "lattice/feature mismatch for utterance " + it.key; return; }
         vbio::SerializeLattice(it.clat, &it.entry);
         vblat::CompactLattice().st.swap(it.clat.st);
-      });
-      for (size_t i = c0; i < c1; i++) {
-        Item &it = items[i];
-        if (!it.warn.empty()) { log.os() << "WARNING (gmm-rescore-lattice) " << it.warn << "\n"; num_err++; continue; }
-        writer.WriteSerialized(it.key, it.entry);
-        num_done++; num_frames += it.f->rows;
-        std::string().swap(it.entry);
-      }
-      c0 = c1;
+      } catch (const std::exception &e) { it.err = e.what(); }
+    });
+    for (Item &it : items) {
+      if (!it.err.empty()) throw ApiError(it.err);
+      if (!it.warn.empty()) { log.os() << "WARNING (gmm-rescore-lattice) " << it.warn << "\n"; num_err++; continue; }
+      writer.WriteSerialized(it.key, it.entry);
+      num_done++; num_frames += it.rows;
+      std::string().swap(it.entry);
     }
     log.os() << "LOG (gmm-rescore-lattice) Done " << num_done << " lattices with errors on " << num_err << ", #frames is " << num_frames << "\n";
     return num_done != 0 ? 0 : 1;

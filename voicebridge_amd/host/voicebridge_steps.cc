@@ -305,6 +305,35 @@ int SplitData(const std::string &data, int numsplit, bool per_utt) {
   });
 }
 
+// The reference's feature pipeline of a decoding job -- apply-cmvn | add-deltas (or splice-feats | transform-feats final.mat)
+// (VB/scr/steps/decode_gmm.cpp:201-293) -- as the --fe-* options of the program that consumes the features (device_feats.h):
+// the job's raw feats.scp is the only feature table any program of the job reads.
+std::vector<std::string> FrontEndOptions(const std::string &srcdir, const std::string &dsn, bool lda, const std::string &cmvn_opts,
+                                         const std::string &delta_opts, const std::string &splice_opts) {
+  std::vector<std::string> g = {"--fe-cmvn=scp:" + Join(dsn, "cmvn.scp"), "--fe-utt2spk=ark:" + Join(dsn, "utt2spk")};
+  for (const auto &o : SplitWords(cmvn_opts)) {
+    if (o == "--norm-vars=true" || o == "--norm-vars") g.push_back("--fe-norm-vars=true");
+    else if (o == "--norm-vars=false" || o == "--norm-means=true") continue;
+    else throw StepError("cmvn_opts option " + o + " is not supported");
+  }
+  if (!lda) {
+    g.push_back("--fe-type=delta");
+    for (const auto &o : SplitWords(delta_opts)) {
+      if (o.compare(0, 14, "--delta-order=") == 0) g.push_back("--fe-delta-order=" + o.substr(14));
+      else if (o.compare(0, 15, "--delta-window=") == 0) g.push_back("--fe-delta-window=" + o.substr(15));
+      else throw StepError("delta_opts option " + o + " is not supported");
+    }
+  } else {
+    g.push_back("--fe-type=lda"); g.push_back("--fe-lda=" + Join(srcdir, "final.mat"));
+    for (const auto &o : SplitWords(splice_opts)) {
+      if (o.compare(0, 15, "--left-context=") == 0) g.push_back("--fe-left-context=" + o.substr(15));
+      else if (o.compare(0, 16, "--right-context=") == 0) g.push_back("--fe-right-context=" + o.substr(16));
+      else throw StepError("splice_opts option " + o + " is not supported");
+    }
+  }
+  return g;
+}
+
 // ------------------------------------------------------------------------------------ Decode
 int Decode(const std::string &graph_dir, const std::string &data_dir, const std::string &decode_dir, const std::string &model_in,
            const std::string &trans_dir, UMAPSS &wer_ref_filter, UMAPSS &wer_hyp_filter, const std::string &iter, int nj, float acwt,
@@ -357,27 +386,8 @@ int Decode(const std::string &graph_dir, const std::string &data_dir, const std:
       // scoring (GmmLatgenFaster's --fe-* options): the raw features of feats.scp are the only thing read.
       std::vector<std::string> g = {"gmm-latgen-faster", "--max-active=" + std::to_string(max_active), "--beam=" + std::to_string(beam),
                                     "--lattice-beam=" + std::to_string(lattice_beam), "--acoustic-scale=" + std::to_string(acwt),
-                                    "--allow-partial=true", "--fe-cmvn=scp:" + Join(dsn, "cmvn.scp"), "--fe-utt2spk=ark:" + Join(dsn, "utt2spk")};
-      for (const auto &o : SplitWords(cmvn_opts)) {
-        if (o == "--norm-vars=true" || o == "--norm-vars") g.push_back("--fe-norm-vars=true");
-        else if (o == "--norm-vars=false" || o == "--norm-means=true") continue;
-        else throw StepError("cmvn_opts option " + o + " is not supported");
-      }
-      if (!lda) {
-        g.push_back("--fe-type=delta");
-        for (const auto &o : SplitWords(delta_opts)) {
-          if (o.compare(0, 14, "--delta-order=") == 0) g.push_back("--fe-delta-order=" + o.substr(14));
-          else if (o.compare(0, 15, "--delta-window=") == 0) g.push_back("--fe-delta-window=" + o.substr(15));
-          else throw StepError("delta_opts option " + o + " is not supported");
-        }
-      } else {
-        g.push_back("--fe-type=lda"); g.push_back("--fe-lda=" + Join(srcdir, "final.mat"));
-        for (const auto &o : SplitWords(splice_opts)) {
-          if (o.compare(0, 15, "--left-context=") == 0) g.push_back("--fe-left-context=" + o.substr(15));
-          else if (o.compare(0, 16, "--right-context=") == 0) g.push_back("--fe-right-context=" + o.substr(16));
-          else throw StepError("splice_opts option " + o + " is not supported");
-        }
-      }
+                                    "--allow-partial=true"};
+      for (const auto &o : FrontEndOptions(srcdir, dsn, lda, cmvn_opts, delta_opts, splice_opts)) g.push_back(o);
       if (use_trans) g.push_back("--fe-trans=ark:" + (trans_all.empty() ? Join(trans_dir, "trans." + J) : trans_all));
       const std::string symtab = Join(graph_dir, "words.txt");
       if (Exists(symtab)) g.push_back("--word-symbol-table=" + symtab);
@@ -438,6 +448,8 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
       si_dir += ".si";
       if (stage <= 0) {
         UMAPSS f1, f2;
+        // the first pass searches with max-active 2000, the main pass below with max_active: one set of search workspaces for both
+        vb_set_workspace_max_active(std::max(first_max_active, max_active));
         if (Decode(graphdir, data, si_dir, alignment_model, "", f1, f2, "", nj, acwt, 0, first_max_active, first_beam, 6.0, skip_scoring, decode_mbr, stats,
                    word_ins_penalty, min_lmwt, max_lmwt) < 0)
           throw StepError("First pass speaker-independent decoding failed: " + g_err);
@@ -461,70 +473,54 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
       const std::string J = std::to_string(j), dsn = Join(sdata, J);
       if (ReadLines(Join(dsn, "feats.scp"), false).empty()) return;
       std::ofstream log(Join(Join(dir, "log"), "fmllr." + J + ".log"), std::ios::binary);
-      // ---- speaker-independent features (decode_fmllr.cpp:275-311)
-      const std::string t_cmvn = Join(dsn, "apply_cmvn.temp"), t_si = Join(dsn, "sifeats.temp"), t_feat = Join(dsn, "transform_pass1feats.temp");
-      {
-        std::vector<std::string> c = {"apply-cmvn"};
-        for (const auto &o : SplitWords(cmvn_opts)) c.push_back(o);
-        c.insert(c.end(), {"--utt2spk=ark:" + Join(dsn, "utt2spk"), "scp:" + Join(dsn, "cmvn.scp"), "scp:" + Join(dsn, "feats.scp"), "ark:" + t_cmvn});
-        run("apply-cmvn", ApplyCmvn, c, log);
-        if (!lda) {
-          std::vector<std::string> dl = {"add-deltas"};
-          for (const auto &o : SplitWords(delta_opts)) dl.push_back(o);
-          dl.insert(dl.end(), {"ark:" + t_cmvn, "ark:" + t_si});
-          Argv a2(dl);
-          if (AddDeltas(a2.argc(), a2.argv()) < 0) throw StepError("add-deltas failed for job " + J);
-        } else {
-          const std::string t_spl = Join(dsn, "splice.temp");
-          std::vector<std::string> sp = {"splice-feats"};
-          for (const auto &o : SplitWords(splice_opts)) sp.push_back(o);
-          sp.insert(sp.end(), {"ark:" + t_cmvn, "ark:" + t_spl});
-          Argv a2(sp);
-          if (SpliceFeats(a2.argc(), a2.argv()) < 0) throw StepError("splice-feats failed for job " + J);
-          run("transform-feats", TransformFeats, {"transform-feats", Join(srcdir, "final.mat"), "ark:" + t_spl, "ark:" + t_si}, log);
-          unlink(t_spl.c_str());
-        }
-        unlink(t_cmvn.c_str());
-      }
+      // ---- the features of every program below: the job's raw feats.scp behind the fused front end (the reference writes
+      //      sifeats / transform_pass1feats / final feature archives: decode_fmllr.cpp:275-311, 390-402, 491-500, 568-580); the raw
+      //      rows are uploaded once per job (the thread's table cache) and the transforms applied on the device
+      const std::vector<std::string> fe = FrontEndOptions(srcdir, dsn, lda, cmvn_opts, delta_opts, splice_opts);
+      const std::string raw = "scp:" + Join(dsn, "feats.scp");
+      auto with_fe = [&](std::vector<std::string> a, const std::string &trans_file) {
+        std::vector<std::string> r{a[0]};
+        for (const auto &o : fe) r.push_back(o);
+        if (!trans_file.empty()) r.push_back("--fe-trans=ark:" + trans_file);
+        r.insert(r.end(), a.begin() + 1, a.end());
+        return r;
+      };
       const std::string pre_trans = Join(dir, "pre_trans." + J), trans = Join(dir, "trans." + J), lat_tmp = Join(dir, "lat.tmp." + J);
-      const std::string spk2utt = "--spk2utt=ark:" + Join(dsn, "spk2utt"), utt2spk = "--utt2spk=ark:" + Join(dsn, "utt2spk");
+      const std::string spk2utt = "--spk2utt=ark:" + Join(dsn, "spk2utt");
       if (stage <= 1) {      // first-pass fMLLR from the SI lattices (:314-388)
         const std::string t_post = Join(dsn, "post.temp"), t_wsp = Join(dsn, "wsp.temp");
         run("lattice-to-post", LatticeToPost, {"lattice-to-post", acw, "ark:" + Join(si_dir, "lat." + J), "ark:" + t_post}, log);
         run("weight-silence-post", WeightSilencePost, {"weight-silence-post", std::to_string(silence_weight), silphonelist, alignment_model, "ark:" + t_post, "ark:" + t_wsp}, log);
         // the reference pipes gmm-post-to-gpost (alignment model) into gmm-est-fmllr-gpost (adapt model); here the Gaussian
         // posteriors never leave the GPU: gmm-est-fmllr takes them from --ali-model and the statistics from the adapt model
-        run("gmm-est-fmllr", GmmEstFmllr, {"gmm-est-fmllr", "--fmllr-update-type=" + fmllr_update_type, spk2utt, "--ali-model=" + alignment_model, adapt_model,
-                                           "ark:" + t_si, "ark:" + t_wsp, "ark:" + pre_trans}, log);
+        run("gmm-est-fmllr", GmmEstFmllr, with_fe({"gmm-est-fmllr", "--fmllr-update-type=" + fmllr_update_type, spk2utt, "--ali-model=" + alignment_model, adapt_model,
+                                                   raw, "ark:" + t_wsp, "ark:" + pre_trans}, ""), log);
         unlink(t_post.c_str()); unlink(t_wsp.c_str());
       }
       if (stage <= 2) {      // main search on the first-pass features (:390-489)
-        run("transform-feats", TransformFeats, {"transform-feats", utt2spk, "ark:" + pre_trans, "ark:" + t_si, "ark:" + t_feat}, log);
         std::vector<std::string> g = {"gmm-latgen-faster", "--max-active=" + std::to_string(max_active), "--beam=" + std::to_string(beam),
                                       "--lattice-beam=" + std::to_string(lattice_beam), acw, "--determinize-lattice=false", "--allow-partial=true"};
         if (Exists(symtab)) g.push_back("--word-symbol-table=" + symtab);
-        g.insert(g.end(), {adapt_model, Join(graphdir, "HCLG.fst"), "ark:" + t_feat, "ark:" + lat_tmp});
-        run("gmm-latgen-faster", GmmLatgenFaster, g, log);
+        g.insert(g.end(), {adapt_model, Join(graphdir, "HCLG.fst"), raw, "ark:" + lat_tmp});
+        run("gmm-latgen-faster", GmmLatgenFaster, with_fe(g, pre_trans), log);
       }
       if (stage <= 3) {      // second fMLLR estimate, composed with the first (:491-566)
         const std::string t_ldp = Join(dsn, "ldp.temp"), t_post = Join(dsn, "post.temp"), t_wsp = Join(dsn, "wsp.temp"), trans_tmp = Join(dir, "trans_tmp." + J);
-        run("transform-feats", TransformFeats, {"transform-feats", utt2spk, "ark:" + pre_trans, "ark:" + t_si, "ark:" + t_feat}, log);
         run("lattice-determinize-pruned", LatticeDeterminizePruned, {"lattice-determinize-pruned", acw, "--beam=" + std::to_string(4.0), "ark:" + lat_tmp, "ark:" + t_ldp}, log);
         run("lattice-to-post", LatticeToPost, {"lattice-to-post", acw, "ark:" + t_ldp, "ark:" + t_post}, log);
         run("weight-silence-post", WeightSilencePost, {"weight-silence-post", std::to_string(silence_weight), silphonelist, adapt_model, "ark:" + t_post, "ark:" + t_wsp}, log);
-        run("gmm-est-fmllr", GmmEstFmllr, {"gmm-est-fmllr", "--fmllr-update-type=" + fmllr_update_type, spk2utt, adapt_model, "ark:" + t_feat, "ark:" + t_wsp, "ark:" + trans_tmp}, log);
+        run("gmm-est-fmllr", GmmEstFmllr, with_fe({"gmm-est-fmllr", "--fmllr-update-type=" + fmllr_update_type, spk2utt, adapt_model, raw, "ark:" + t_wsp, "ark:" + trans_tmp}, pre_trans), log);
         run("compose-transforms", ComposeTransforms, {"compose-transforms", "--b-is-affine=true", "ark:" + trans_tmp, "ark:" + pre_trans, "ark:" + trans}, log);
         unlink(t_ldp.c_str()); unlink(t_post.c_str()); unlink(t_wsp.c_str());
       }
       if (stage <= 4) {      // rescoring with the final model on the final features, determinization (:568-640)
         const std::string t_grl = Join(dsn, "grl.temp");
-        run("transform-feats", TransformFeats, {"transform-feats", utt2spk, "ark:" + trans, "ark:" + t_si, "ark:" + t_feat}, log);
-        run("gmm-rescore-lattice", GmmRescoreLattice, {"gmm-rescore-lattice", final_model, "ark:" + lat_tmp, "ark:" + t_feat, "ark:" + t_grl}, log);
+        run("gmm-rescore-lattice", GmmRescoreLattice, with_fe({"gmm-rescore-lattice", final_model, "ark:" + lat_tmp, raw, "ark:" + t_grl}, trans), log);
         run("lattice-determinize-pruned", LatticeDeterminizePruned, {"lattice-determinize-pruned", acw, "--beam=" + std::to_string(lattice_beam), "ark:" + t_grl, "ark:" + Join(dir, "lat." + J)}, log);
         unlink(t_grl.c_str()); unlink(lat_tmp.c_str());
       }
-      unlink(t_si.c_str()); unlink(t_feat.c_str());
     });
+
   });
   if (rc != 0) return rc;
   if (!skip_scoring) {
