@@ -74,6 +74,9 @@ def parse():
                          "line with the search's difficulty (tokens, arcs per frame, share of frames bound by max-/min-active) and its rate is printed; "
                          "then exit.  RTF as a function of search difficulty")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-step-api", action="store_true", help="skip the step-API measurement (MakeMfcc / Decode / DecodeFmllr on a data directory, in a child process)")
+    ap.add_argument("--step-api-utts", type=int, default=256)
+    ap.add_argument("--step-api-threads", type=int, default=1)
     ap.add_argument("--cpu-sample-seconds", type=float, default=120.0,
                     help="audio seconds one process of the CPU baseline decodes (whole speakers; the default is one speaker of four 30 s utterances, "
                          "about 10-30 s of one core depending on how hard the search is)")
@@ -202,6 +205,8 @@ def cpu_baseline_reference(args, jobs, waves, utt2spk, xforms, lda, model, decod
                 raise RuntimeError(name + ": " + r.stderr[-300:])
             return time.perf_counter() - t0, r.stderr
 
+        ref_like = {}
+
         def job(j, tag):
             """one job's program chain, as Decode() of the reference builds it (VB/scr/steps/decode_gmm.cpp:201-293)"""
             q = lambda n: p("%s.%d.%s" % (n, j, tag))
@@ -226,6 +231,8 @@ def cpu_baseline_reference(args, jobs, waves, utt2spk, xforms, lda, model, decod
                 f_ = line.split()
                 if f_:
                     words[int(f_[0].split("-u")[1])] = [int(x) for x in f_[1:]]
+            for m_ in re.finditer(r"Log-like per frame for utterance \S+-u(\d+) is (\S+) over", log):
+                ref_like[int(m_.group(1))] = float(m_.group(2))
             for n in ("mfcc", "cm", "dl", "sp", "feats", "lat"):
                 if os.path.exists(q(n)):
                     os.remove(q(n))
@@ -250,7 +257,7 @@ def cpu_baseline_reference(args, jobs, waves, utt2spk, xforms, lda, model, decod
                                  max(par, key=lambda r: r[0] + r[1])[0], max(par, key=lambda r: r[0] + r[1])[1], par[0][3]))
         out_one = dict(value=one[2] / (one[0] + one[1]), unit="frames/s", cores=1, kind="reference",
                        sample="job 0 of that sample alone (%d utterances, %d frames), one process: features %.2f s, search %.2f s" % (len(jobs[0]), one[2], one[0], one[1]))
-        return out_par, out_one, words
+        return out_par, out_one, words, ref_like
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
@@ -674,6 +681,7 @@ def main():
     # words, search counters, device timeline
     collect = [False]
     col_words = [None] * args.batch
+    col_like = np.zeros(args.batch)
     col_cnt = np.zeros((args.batch, 8), np.float64)
     col_tl = np.zeros((args.batch, 3), np.int64)
     col_stats = dict(retried_in_big_slot=0, pool_grown=0, failed=0)
@@ -740,6 +748,7 @@ def main():
                 for u in range(per):
                     r = L.dec.result(u, arrays=False)
                     col_words[sl_.a + u] = r["words"]
+                    col_like[sl_.a + u] = -(r["best_graph"] + r["best_acoustic"]) / max(r["num_frames"], 1)
                     col_cnt[sl_.a + u] = [r["n_tokens_expanded"], r["n_arcs_expanded"], r["n_tokens_created"], r["n_links_created"],
                                           r["n_frames_maxactive_bound"], r["n_frames_minactive_bound"], r["num_toks"], r["num_links"]]
                     col_tl[sl_.a + u] = L.dec.timeline(u)
@@ -992,13 +1001,13 @@ def main():
             jobs = cpu_sample(args, utt2spk, n_spk)
             n_smp = int(round(args.seconds * 16000))
             waves = {u: d_wave[u * n_smp:(u + 1) * n_smp].cpu().numpy() for j_ in jobs for u in j_}
-            ref_cb, cpu_words = None, {}
+            ref_cb, cpu_words, cpu_like = None, {}, {}
             try:
                 ref_cb = cpu_baseline_reference(args, jobs, waves, utt2spk, xforms, lda, model, decode_setup)
             except Exception as e:
                 print("cpu_baseline (reference programs) failed: %s" % e, file=sys.stderr, flush=True)
             if ref_cb is not None:
-                out["cpu_baseline"], out["cpu_baseline_1proc"], cpu_words = ref_cb
+                out["cpu_baseline"], out["cpu_baseline_1proc"], cpu_words, cpu_like = ref_cb
                 if os.environ.get("VBH_BENCH_PORT_BASELINE"):
                     out["cpu_baseline_port"] = cpu_baseline(args, jobs[0], waves, utt2spk, xforms, lda, model, decode_setup)[0]
             else:
@@ -1007,9 +1016,15 @@ def main():
                 # the utterances the CPU leg decoded anyway: are the GPU step's hypotheses the same words?
                 same = sum(1 for u, w_ in cpu_words.items() if list(col_words[u]) == list(w_))
                 out["parity_words_equal"] = "%d/%d" % (same, len(cpu_words))
+                # where the words differ: the two best paths' log-likelihood per frame (a difference at the level of the front end's float
+                # tolerance means two hypotheses of nearly equal score, which MFCC differences of 1e-3 are enough to swap)
+                diff = [{"utt": int(u), "reference_words": list(w_), "gpu_words": [int(x) for x in col_words[u]],
+                         "reference_like_per_frame": cpu_like.get(u), "gpu_like_per_frame": float(col_like[u])}
+                        for u, w_ in cpu_words.items() if list(col_words[u]) != list(w_)]
+                if diff:
+                    out["parity_words_differ"] = diff
                 out["parity_note"] = ("best-path words of the GPU step against the %s's for the utterances of the CPU sample (same waveforms, model, "
                                       "graph, transforms)" % ("reference programs" if ref_cb is not None else "oracle"))
-        print(json.dumps(out), flush=True)
     if det_pool is not None:
         det_pool.close()
     # tear down in order: decoders before their contexts (and before the interpreter's own finalisation)
@@ -1019,6 +1034,29 @@ def main():
     for L in lanes:
         if L.ctx is not ctx:
             L.ctx.close()
+    if rank == 0:
+        if dec_enabled and world == 1 and not args.no_step_api:
+            # The reference's own entry points on a data directory (MakeMfcc, ComputeCmvnStats, Decode, DecodeFmllr: wav files in, archives /
+            # lattices / transforms / WER files out, per-job set-up and file I/O included), in a child process once this one has given its
+            # GPU memory back: what an application that calls the step API sees, beside the kernels' own rate above
+            try:
+                ring = gmm = raw = feats = ll = d_wave = None      # (the tensors of this process: the child needs the memory)
+                slices[:] = []
+                torch.cuda.empty_cache()
+                import subprocess
+                r_ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_steps.py"), "--utts", str(args.step_api_utts), "--nj", "4", "--fmllr",
+                                     "--job-threads", str(args.step_api_threads), "--words", str(args.words)], capture_output=True, text=True, timeout=600)
+                st_ = json.loads([l_ for l_ in r_.stdout.splitlines() if l_.startswith("{")][-1])
+                fr_ = float(st_["frames"])
+                k_dec = [k_ for k_ in st_ if k_.startswith("Decode_s")][0]
+                k_fm = [k_ for k_ in st_ if k_.startswith("DecodeFmllr_s")][0]
+                out["step_api"] = {"what": "tools/bench_steps.py: %d utterances of 30 s in a data directory, nj = 4 jobs on %d host thread(s), one GPU; seconds per step "
+                                           "of the reference's API and frames/s of the two decoding steps" % (args.step_api_utts, args.step_api_threads),
+                                   "MakeMfcc_s": st_["MakeMfcc_s"], "ComputeCmvnStats_s": st_["ComputeCmvnStats_s"], "Decode_s": st_[k_dec],
+                                   "DecodeFmllr_s": st_[k_fm], "Decode_step_frames_per_s": fr_ / st_[k_dec], "DecodeFmllr_step_frames_per_s": fr_ / st_[k_fm]}
+            except Exception as e:
+                out["step_api"] = {"error": str(e)[:300]}
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -93,6 +93,7 @@ def test_slot_overflow_is_searched_again_with_the_same_result(setup, monkeypatch
     from voicebridge_amd import api
     s = setup
     monkeypatch.setenv("VBH_SLOT_SCALE", scale)
+    monkeypatch.setenv("VBH_PRIVATE_SLOTS", "1")          # (a decoder would otherwise share the module's full-size pool)
     dec = api.LatticeDecoder(s["ctx"], s["graph"], s["n"], 2998, acoustic_scale=s["acwt"], **s["cfg"])
     dec.decode(s["ll"], s["foff"], s["t2p"])
     st = dec.batch_stats()

@@ -265,3 +265,50 @@ def test_gmm_loglikes_pairs_vs_all_pdf_kernel(ctx, P, G, D, T):
     want = np.array([full[t, ppdf[q]] for t in range(T) for q in range(poff[t], poff[t + 1])], np.float32)
     np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-3)
     gmm.close()
+
+
+def test_fused_front_end_equals_feature_archives(tmp_path):
+    """--fe-* on gmm-est-fmllr and gmm-rescore-lattice (device_feats.h; what DecodeFmllr uses instead of the reference's
+    sifeats / pass-1 / final feature archives): the same transforms and the same rescored lattices as the programs fed with
+    features that apply-cmvn | add-deltas | transform-feats wrote to an archive first"""
+    from tests.test_host_io import read_fm_ark
+    from tests.test_host_lattice import assert_same_archives, call
+    from voicebridge_amd import build, synth
+    host = C.CDLL(build.HOST_LIB)
+    d = tmp_path
+    g = util.load("fmllr")
+    for k in ("file_final_mdl", "file_feats_ark", "file_wsp_ark", "file_raw_ark"):
+        name = k[5:].rsplit("_", 1)
+        (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
+    (d / "spk2utt").write_text(str(g["text_spk2utt"]))
+    spk2utt = {l.split()[0]: l.split()[1:] for l in str(g["text_spk2utt"]).split("\n") if l.strip()}
+    (d / "utt2spk").write_text("".join("%s %s\n" % (u, s) for s, us in spk2utt.items() for u in us))
+    # raw 13-dim features with the golden utterances' keys and lengths; per-speaker CMVN statistics and transforms
+    rng = np.random.default_rng(3)
+    golden = read_fm_ark(str(d / "feats.ark"))
+    raw = {k: (rng.standard_normal((v.shape[0], 13)) * np.linspace(5, 1, 13) + np.linspace(-2, 2, 13)).astype(np.float32) for k, v in golden.items()}
+    util.write_feats_ark(str(d / "raw13.ark"), raw)
+    log = str(d / "log.txt")
+    assert call(host.vb_ComputeCmvnStats, ["compute-cmvn-stats", "--spk2utt=ark:%s" % (d / "spk2utt"), "ark:%s" % (d / "raw13.ark"), "ark:%s" % (d / "cmvn.ark")], log) == 0, open(log).read()
+    util.write_feats_ark(str(d / "pre.ark"), {s: synth.affine(39, seed=40 + i) for i, s in enumerate(sorted(spk2utt))})
+    u2s = "--utt2spk=ark:%s" % (d / "utt2spk")
+    assert call(host.vb_ApplyCmvn, ["apply-cmvn", u2s, "ark:%s" % (d / "cmvn.ark"), "ark:%s" % (d / "raw13.ark"), "ark:%s" % (d / "c.ark")], log) == 0
+    assert call(host.vb_AddDeltas, ["add-deltas", "ark:%s" % (d / "c.ark"), "ark:%s" % (d / "dl.ark")]) == 0
+    assert call(host.vb_TransformFeats, ["transform-feats", u2s, "ark:%s" % (d / "pre.ark"), "ark:%s" % (d / "dl.ark"), "ark:%s" % (d / "proc.ark")], log) == 0
+    fe = ["--fe-cmvn=ark:%s" % (d / "cmvn.ark"), "--fe-utt2spk=ark:%s" % (d / "utt2spk"), "--fe-type=delta", "--fe-trans=ark:%s" % (d / "pre.ark")]
+    common = ["--fmllr-min-count=50", "--spk2utt=ark:%s" % (d / "spk2utt")]
+    # ---- gmm-est-fmllr
+    assert call(host.vb_GmmEstFmllr, ["gmm-est-fmllr"] + common + [str(d / "final.mdl"), "ark:%s" % (d / "proc.ark"), "ark:%s" % (d / "wsp.ark"), "ark:%s" % (d / "t_arch.ark")], log) == 0, open(log).read()
+    assert call(host.vb_GmmEstFmllr, ["gmm-est-fmllr"] + common + fe + [str(d / "final.mdl"), "ark:%s" % (d / "raw13.ark"), "ark:%s" % (d / "wsp.ark"), "ark:%s" % (d / "t_fused.ark")], log) == 0, open(log).read()
+    a, b = read_fm_ark(str(d / "t_arch.ark")), read_fm_ark(str(d / "t_fused.ark"))
+    assert list(a) == list(b) and len(a) == len(spk2utt)
+    for k in a:
+        np.testing.assert_allclose(b[k], a[k], atol=2e-5, rtol=0)
+        assert np.abs(a[k] - np.eye(39, 40)).max() > 1e-3          # real updates, not the unit transform of a skipped speaker
+    # ---- gmm-rescore-lattice
+    assert call(host.vb_GmmRescoreLattice, ["gmm-rescore-lattice", str(d / "final.mdl"), "ark:%s" % (d / "raw.ark"), "ark:%s" % (d / "proc.ark"), "ark:%s" % (d / "r_arch.ark")], log) == 0, open(log).read()
+    assert call(host.vb_GmmRescoreLattice, ["gmm-rescore-lattice"] + fe + [str(d / "final.mdl"), "ark:%s" % (d / "raw.ark"), "ark:%s" % (d / "raw13.ark"), "ark:%s" % (d / "r_fused.ark")], log) == 0, open(log).read()
+    assert_same_archives(str(d / "r_fused.ark"), str(d / "r_arch.ark"), rtol=1e-6, atol=1e-4)
+    # the options only make sense together
+    assert call(host.vb_GmmRescoreLattice, ["gmm-rescore-lattice", "--fe-type=delta", str(d / "final.mdl"), "ark:%s" % (d / "raw.ark"), "ark:%s" % (d / "raw13.ark"), "ark:%s" % (d / "x.ark")], log) == -1
+    assert "--fe-cmvn" in open(log).read()

@@ -1755,6 +1755,10 @@ struct vbh_decoder {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
+// the pools of this process (weak: a pool lives as long as a decoder uses it), see vbh_decoder_create_shared
+static std::mutex g_pool_mu;
+static std::vector<std::weak_ptr<SlotSet>> g_pools;
+
 static int slot_alloc(vbh_decoder *d, SlotSet *set, size_t bytes, void **p, int memset_val = -2) {
   VBH_HIP(hipMalloc(p, bytes ? bytes : 8));
   set->allocs.push_back(*p);
@@ -1935,6 +1939,26 @@ int vbh_decoder_create_shared(vbh_ctx *ctx, const vbh_graph *graph, const vbh_de
     *out = d;
     return 0;
   }
+  // Decoders of one process share the device's pool whenever an existing one fits (same graph size, capacities that cover
+  // this configuration, at least as many slots): the jobs of a step running on several host threads, or a caller's decoders
+  // on several streams, then hold ONE set of workspaces between them.  VBH_PRIVATE_SLOTS=1: every decoder its own.
+  if (!getenv("VBH_PRIVATE_SLOTS")) {
+    int dev_cus0 = ctx->num_cus;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) dev_cus0 = prop.multiProcessorCount; }
+    const int want_n = (std::min<int>(max_batch, WG_PER_CU * dev_cus0) + 7) & ~7;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto it = g_pools.begin(); it != g_pools.end();) {
+      std::shared_ptr<SlotSet> o = it->lock();
+      if (!o) { it = g_pools.erase(it); continue; }
+      if (o->device == ctx->device && o->graph_states == graph->S && o->max_frames >= max_frames && o->cfg.max_active >= cfg->max_active &&
+          effective_prune_interval(&o->cfg) == effective_prune_interval(cfg) && o->n >= want_n) {
+        d->small_set = o;
+        *out = d;
+        return 0;
+      }
+      ++it;
+    }
+  }
   // Two size classes.  Regular slots: sized for the common case, one per workgroup that can be resident on the device (the
   // pool claim_slot() draws from), or fewer for small batches.  "big": the generous worst-case sizes, a handful of slots,
   // allocated only when an utterance overflows a regular slot; such utterances are searched again there (vbh_decode_batch),
@@ -1946,6 +1970,7 @@ int vbh_decoder_create_shared(vbh_ctx *ctx, const vbh_graph *graph, const vbh_de
   d->small_set = std::make_shared<SlotSet>();
   if (alloc_slot_set(d, d->small_set.get(), n, /*big=*/false)) { vbh_decoder_destroy(d); return -1; }
   VBH_HIP(hipStreamSynchronize(ctx->stream));
+  if (!getenv("VBH_PRIVATE_SLOTS")) { std::lock_guard<std::mutex> lk(g_pool_mu); g_pools.push_back(d->small_set); }
   *out = d;
   return 0;
 }

@@ -125,6 +125,35 @@ void RunFeatpost(const vbh_featpost_cfg &cfg, const Batch &b, const std::vector<
 // step (and the passes of DecodeFmllr) name the same files again and again, and reading a 100 MB graph, building its device form and
 // allocating tens of GB of workspace per job cost more than the search of a job itself.  Keyed by path, size and modification time of
 // the two files; released by vb_release_device_cache(), by a call with other files, or when the thread's device changes.
+// The decoding graph on a device, shared by the threads of the process (the jobs of a step run on threads of their own when
+// several are allowed): the file is read and its device form built once per (file, device); searches of different threads
+// use it at the same time (they must name the same transition model, which the jobs of a step do).
+struct GraphHolder {
+  vbh_graph *g = nullptr;
+  int32_t start = 0;
+  ~GraphHolder() { if (g) vbh_graph_destroy(g); }
+};
+std::mutex g_graph_mu;
+std::map<std::string, std::weak_ptr<GraphHolder>> g_graphs;
+template <class Lap>
+std::shared_ptr<GraphHolder> SharedGraph(vbh_ctx *ctx, int device, const std::string &path, long long sig, Lap lap) {
+  const std::string key = std::to_string(device) + "|" + std::to_string(sig) + "|" + path;
+  std::lock_guard<std::mutex> lk(g_graph_mu);          // (a second thread asking for the same graph waits for the first one's load)
+  auto it = g_graphs.find(key);
+  if (it != g_graphs.end()) { if (auto sp = it->second.lock()) return sp; }
+  vbio::Graph graph;
+  vbio::ReadFst(path, &graph);
+  lap("read graph");
+  static_assert(sizeof(vbio::Arc) == sizeof(vbh_arc), "arc layout");
+  auto sp = std::make_shared<GraphHolder>();
+  Check(vbh_graph_create(ctx, (int32_t)graph.final_cost.size(), graph.start, graph.final_cost.data(), graph.arc_offset.data(),
+                         reinterpret_cast<const vbh_arc *>(graph.arcs.data()), &sp->g), "vbh_graph_create");
+  sp->start = graph.start;
+  g_graphs[key] = sp;
+  lap("device graph");
+  return sp;
+}
+
 struct LatgenCache {
   std::string model_path, graph_path;
   long long model_sig = 0, graph_sig = 0;
@@ -132,7 +161,7 @@ struct LatgenCache {
   vbio::Model model;
   int32_t graph_start = 0;
   vbh_gmm *gmm = nullptr;
-  vbh_graph *g = nullptr;
+  std::shared_ptr<GraphHolder> gh;
   vbh_decoder *dec = nullptr;
   vbh_decode_cfg dec_cfg{};
   int dec_batch = 0, dec_T = 0;
@@ -151,14 +180,14 @@ struct LatgenCache {
     if (d_ll && ctx) vbh_dev_free(ctx, d_ll);
     d_ll = nullptr; d_ll_bytes = 0;
     if (dec) vbh_decoder_destroy(dec);
-    if (g) vbh_graph_destroy(g);
+    gh.reset();
     if (gmm) vbh_gmm_destroy(gmm);
-    dec = nullptr; g = nullptr; gmm = nullptr; dec_batch = dec_T = 0; model_path.clear(); graph_path.clear(); ctx = nullptr;
+    dec = nullptr; gmm = nullptr; dec_batch = dec_T = 0; model_path.clear(); graph_path.clear(); ctx = nullptr;
   }
   ~LatgenCache() { /* the process is ending or the thread is: the runtime reclaims device memory */ }
 };
 thread_local LatgenCache g_latgen;
-thread_local int g_workspace_max_active = 0;      // vb_set_workspace_max_active: see GmmLatgenFaster
+std::atomic<int> g_workspace_max_active{0};       // vb_set_workspace_max_active (process-wide: a step's jobs run on threads of their own): see GmmLatgenFaster
 
 long long FileSig(const std::string &path) {
   struct stat st;
@@ -617,18 +646,12 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
       if (cache.ctx != ctx) cache.Release();
       // the graph (and with it the search workspace) and the model are kept independently: DecodeFmllr's passes use two or
       // three models over one graph
-      if (cache.g == nullptr || cache.graph_path != po.args[1] || cache.graph_sig != gs || gs < 0) {
+      if (!cache.gh || cache.graph_path != po.args[1] || cache.graph_sig != gs || gs < 0) {
         if (cache.dec) { vbh_decoder_destroy(cache.dec); cache.dec = nullptr; cache.dec_batch = cache.dec_T = 0; }
-        if (cache.g) { vbh_graph_destroy(cache.g); cache.g = nullptr; }
-        vbio::Graph graph;
-        vbio::ReadFst(po.args[1], &graph);
-        lap("read graph");
-        static_assert(sizeof(vbio::Arc) == sizeof(vbh_arc), "arc layout");
-        Check(vbh_graph_create(ctx, (int32_t)graph.final_cost.size(), graph.start, graph.final_cost.data(), graph.arc_offset.data(),
-                               reinterpret_cast<const vbh_arc *>(graph.arcs.data()), &cache.g), "vbh_graph_create");
-        cache.graph_start = graph.start;
+        cache.gh.reset();
+        cache.gh = SharedGraph(ctx, g_device, po.args[1], gs, lap);
+        cache.graph_start = cache.gh->start;
         cache.ctx = ctx; cache.graph_path = po.args[1]; cache.graph_sig = gs;
-        lap("device graph");
       }
       if (cache.gmm == nullptr || cache.model_path != po.args[0] || cache.model_sig != ms || ms < 0) {
         if (cache.gmm) { vbh_gmm_destroy(cache.gmm); cache.gmm = nullptr; }
@@ -643,7 +666,7 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     const vbio::Model &model = cache.model;
     struct { int32_t start; } graph{cache.graph_start};
     vbh_gmm *gmm = cache.gmm;
-    vbh_graph *g = cache.g;
+    vbh_graph *g = cache.gh->g;
     // ---- fused front end (extension, device_feats.h)
     FrontEnd fe;
     fe.Parse(po);
@@ -660,7 +683,7 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     // that also cover a later call with a larger max_active (DecodeFmllr: first pass 2000, main pass 7000)
     vbh_decode_cfg ws_cfg = cfg;
     ws_cfg.max_active = std::max(cfg.max_active, (int)po.Num("workspace-max-active", 0.0));
-    if (g_workspace_max_active > ws_cfg.max_active) ws_cfg.max_active = g_workspace_max_active;
+    if (g_workspace_max_active.load() > ws_cfg.max_active) ws_cfg.max_active = g_workspace_max_active.load();
     if (cache.dec && memcmp(&cache.dec_cfg, &cfg, sizeof(cfg)) != 0 && vbh_decoder_set_cfg(cache.dec, &cfg) != 0) {
       vbh_decoder_destroy(cache.dec); cache.dec = nullptr; cache.dec_batch = cache.dec_T = 0;
     }
@@ -1175,7 +1198,7 @@ void vb_det_pool_destroy(void *pool) {
   delete p;
 }
 // the calling thread's following gmm-latgen-faster calls make their search workspaces large enough for this max_active as well
-int vb_set_workspace_max_active(int max_active) { g_workspace_max_active = max_active > 0 ? max_active : 0; return 0; }
+int vb_set_workspace_max_active(int max_active) { g_workspace_max_active.store(max_active > 0 ? max_active : 0); return 0; }
 int vb_set_device(int device_id) { if (device_id != g_device) g_latgen.Release(); g_device = device_id; return 0; }
 // frees the model, graph and search workspace the calling thread's last gmm-latgen-faster call left on the device
 void vb_release_device_cache(void) { g_latgen.Release(); ReleaseRawTableCache(); }
