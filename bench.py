@@ -45,7 +45,9 @@ def parse():
     ap.add_argument("--feat", choices=("delta", "lda"), default="delta",
                     help="delta: CMVN + deltas (39) + per-speaker fMLLR 39x40 (DELTA+SAT, config 3); lda: CMVN + splice +-4 (117) + LDA 40x117 + "
                          "per-speaker fMLLR 40x41 (LDA+MLLT+SAT, config 4)")
-    ap.add_argument("--words", type=int, default=180000, help="vocabulary of the synthetic HCLG (~11 states per word)")
+    ap.add_argument("--words", type=int, default=228000,
+                    help="vocabulary of the synthetic HCLG (~11 states and ~22 arcs per word: 228 k words = 2.5 M states / 5.0 M arcs, the graph size of "
+                         "SURVEY.md 8d config 3)")
     ap.add_argument("--beam", type=float, default=13.0)
     ap.add_argument("--lattice-beam", type=float, default=6.0)
     ap.add_argument("--max-active", type=int, default=7000)
@@ -68,6 +70,9 @@ def parse():
                          "searches batch k+1")
     ap.add_argument("--det-steps", type=int, default=8, help="steps of that second timed region")
     ap.add_argument("--det-threads", type=int, default=0, help="host threads of the lattice stage (0: 16, the CPU share of a one-GPU box)")
+    ap.add_argument("--save-waves", default="", help="write the rank's synthesised PCM (int16 .npy) to this file and go on")
+    ap.add_argument("--load-waves", default="", help="read the PCM a --save-waves run of the same --batch / --seconds wrote instead of synthesising it "
+                                                      "on the device (profiling runs: rocprofv3 --pmc does not survive torch's generator kernels)")
     ap.add_argument("--probe", action="store_true", help="print search statistics of the first utterances and exit")
     ap.add_argument("--sweep-mean-scale", default="",
                     help="comma-separated --mean-scale values: for each, one batch is scored and searched (one batch at a time, no pipeline) and a JSON "
@@ -85,7 +90,7 @@ def parse():
 
 def build_graph(args):
     """synthetic HCLG: lexicon prefix tree x 3-state HMMs x unigram loop (voicebridge_amd/synth.py);
-    ~2 M states / 4 M arcs at the default 180 k words"""
+    ~2.5 M states / 5 M arcs at the default 228 k words"""
     from voicebridge_amd import synth
     return synth.lexicon_graph(args.words, args.pdfs, seed=11)
 
@@ -111,10 +116,18 @@ def build_workload(args, rank, world, device):
     utt2spk = (np.arange(args.batch, dtype=np.int32) // upk).astype(np.int32)      # rank-local speaker index: a speaker's utterances are adjacent
     gid = my_spk[utt2spk] * upk + np.arange(args.batch) % upk             # job-wide utterance id
     n = int(round(args.seconds * 16000))
-    d_wave = torch.empty(args.batch * n, dtype=torch.int16, device=device)
-    for a in range(0, args.batch, 64):
-        b_ = min(a + 64, args.batch)
-        d_wave[a * n:b_ * n] = synth.wave_batch_device(gid[a:b_], args.seconds, device).reshape(-1)
+    if args.load_waves:
+        h_wave = np.load(args.load_waves)
+        if h_wave.dtype != np.int16 or h_wave.size != args.batch * n:
+            sys.exit("bench.py: %s does not hold %d x %d int16 samples" % (args.load_waves, args.batch, n))
+        d_wave = torch.from_numpy(h_wave.reshape(-1)).to(device)
+    else:
+        d_wave = torch.empty(args.batch * n, dtype=torch.int16, device=device)
+        for a in range(0, args.batch, 64):
+            b_ = min(a + 64, args.batch)
+            d_wave[a * n:b_ * n] = synth.wave_batch_device(gid[a:b_], args.seconds, device).reshape(-1)
+    if args.save_waves:
+        np.save(args.save_waves, d_wave.cpu().numpy())
     woff = np.arange(args.batch + 1, dtype=np.int64) * n
     xforms = np.stack([synth.affine(args.feat_dim, seed=int(s)) for s in my_spk])
     return d_wave, woff, utt2spk, n_spk, xforms, gid
@@ -986,7 +999,7 @@ def main():
         # HBM traffic of the dominant kernels from the committed rocprofv3 --pmc passes of this
         # same command (profiles/): only attached when the batch size matches that run
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_i_pmc_traffic.json")))
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_a_pmc_traffic.json")))
             if tr.get("batch") == args.batch and world == 1:
                 for ro in [out["roofline"]] + [out[k] for k in ("roofline_gmm", "roofline_decode") if k in out]:
                     b_ = tr["bytes_per_launch"].get(ro["kernel"])

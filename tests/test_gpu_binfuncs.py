@@ -237,3 +237,46 @@ def test_gmm_latgen_faster_determinized_vs_reference_program(host, tmp_path):
         assert (d / "words.txt").read_text().split() == (d / "r_words.txt").read_text().split()
         assert (d / "ali.txt").read_text().split() == (d / "r_ali.txt").read_text().split()
         assert_same_archives(str(d / "lat.ark"), str(d / "r_lat.ark"), rtol=1e-4, atol=0.05)
+
+
+def test_compute_mfcc_feats_with_segments(host, tmp_path):
+    """--segments (extension: the reference's MakeMfcc pipes extract-segments into compute-mfcc-feats when the data directory has
+    a segments file, VB/scr/steps/make_mfcc.cpp:93-190): the pieces of the recordings, with extract-segments' rules for bad
+    lines, overshoot and short segments (K/featbin/extract-segments.cc:60-195)"""
+    from oracle import vbo
+    from voicebridge_amd import synth
+    d = tmp_path
+    recs = [synth.wave(20, 3.0), synth.wave(21, 2.0)]
+    write_wavs(d, recs)                                  # utt00, utt01 are the recordings
+    (d / "segments").write_text(
+        "segA utt00 0.50 1.75\n"
+        "segB utt00 1.75 -1\n"                          # to the end of the recording
+        "segC utt01 0.10 2.30\n"                        # 0.3 s beyond the end: truncated (max-overshoot 0.5)
+        "segD utt01 0.10 2.90\n"                        # 0.9 s beyond: skipped
+        "segE utt01 1.00 1.05\n"                        # shorter than 0.1 s: skipped
+        "segF nosuchrec 0.0 1.0\n"                      # unknown recording: skipped
+        "segG utt01 1.2 0.4\n"                          # start after end: invalid line
+        "segH utt00 0.25 0.95 0\n")                     # explicit channel
+    log = str(d / "log.txt")
+    assert call(host.vb_ComputeMFCCFeats, ["compute-mfcc-feats", "--dither=0", "--segments=%s" % (d / "segments"), "scp:%s" % (d / "wav.scp"),
+                                           "ark:%s" % (d / "seg.ark")], log) == 0, open(log).read()
+    got = read_fm_ark(d / "seg.ark")
+    assert list(got) == ["segA", "segB", "segC", "segH"]
+    text = open(log).read()
+    for needle in ("too far out of range", "too short", "Could not find recording nosuchrec", "empty or invalid segment"):
+        assert needle in text, needle
+    sr = 16000
+    cuts = {"segA": recs[0][int(0.50 * sr):int(1.75 * sr)], "segB": recs[0][int(1.75 * sr):], "segC": recs[1][int(0.10 * sr):],
+            "segH": recs[0][int(0.25 * sr):int(0.95 * sr)]}
+    for k, w in cuts.items():
+        ref_ = vbo.mfcc(w.astype(np.float32), vbo.mfcc_opts())
+        assert got[k].shape == ref_.shape, k
+        np.testing.assert_allclose(got[k], ref_, atol=2e-3, rtol=1e-5)
+    if have_ref("extract-segments") and have_ref("compute-mfcc-feats"):
+        ref("extract-segments", "scp:%s" % (d / "wav.scp"), str(d / "segments"), "ark:%s" % (d / "r_seg_wav.ark"))
+        ref("compute-mfcc-feats", "--dither=0", "ark:%s" % (d / "r_seg_wav.ark"), "ark:%s" % (d / "r_seg.ark"))
+        want = read_fm_ark(d / "r_seg.ark")
+        assert list(want) == list(got)
+        for k in want:
+            assert want[k].shape == got[k].shape
+            np.testing.assert_allclose(got[k], want[k], atol=2e-3, rtol=1e-5)

@@ -57,7 +57,7 @@ if rows:
         for r in rows:
             f.write("%s,%s,%d,%.1f,%.1f\n" % r)
     fe, wr = per.get("FETCH_SIZE", {}), per.get("WRITE_SIZE", {})
-    out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
+    out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-step-api --no-determinize",
            "batch": 1024, "source": "profiles/%s_pmc_fetch_write_summary.csv (FETCH_SIZE + WRITE_SIZE, raw KiB x 1024)" % name,
            "note": "raw counter values x 1024 B; MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced streaming reads by 2x "
                    "and is uncalibrated for scattered access",

@@ -155,6 +155,7 @@ struct DecCfg {
   float beam, lattice_beam, beam_delta, acwt;
   int max_active, min_active, prune_interval;
   int use_lds_map;      // 0: every state goes to the table in HBM (diagnostic)
+  int prune_back;       // frames an intermediate pruning pass may walk back beyond the unpruned window
 };
 
 struct Ent { unsigned long long key; int tokid; int pad; };   // per graph state
@@ -206,7 +207,7 @@ struct Pool {   // dense per-batch output
 };
 
 enum { ERR_NONE = 0, ERR_W_TOK = 1, ERR_W_LINK = 2, ERR_H_TOK = 3, ERR_H_LINK = 4, ERR_FRONT = 5,
-       ERR_EPS_LOOP = 6, ERR_POOL = 7, ERR_CAND = 8, ERR_NOT_RUN = 9 };
+       ERR_EPS_LOOP = 6, ERR_POOL = 7, ERR_CAND = 8, ERR_NOT_RUN = 9, ERR_LDS = 10 };
 
 // order-preserving map float -> uint32
 __device__ __forceinline__ unsigned f2o(float f) {
@@ -335,6 +336,9 @@ __device__ __forceinline__ int wave_chunk(int n) {
 }
 
 struct Shared {
+#ifdef VBH_LDS_CANARY
+  unsigned canary_lo[4];
+#endif
   unsigned long long red[2][NW];   // reduction scratch, alternated so that one barrier per reduction suffices
   unsigned hist[256];
   int w_ntok, w_nlink, h_ntok, h_nlink;
@@ -363,6 +367,9 @@ struct Shared {
   int tbeg[MAX_WIN_FRAMES + 1], tbase[MAX_WIN_FRAMES], tcnt[MAX_WIN_FRAMES], tup[MAX_WIN_FRAMES];
   int sbeg[2 * MAX_WIN_FRAMES + 1], sbase[2 * MAX_WIN_FRAMES], scnt[2 * MAX_WIN_FRAMES], sup[2 * MAX_WIN_FRAMES];
   int sid[2 * MAX_WIN_FRAMES];     // frame << 1 | (1 = epsilon links)
+#ifdef VBH_LDS_CANARY
+  unsigned canary_hi[4];
+#endif
 };
 
 // block reductions with ONE barrier each: partials go to red[par], par flips on every call
@@ -1126,6 +1133,10 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
     int *pdst = reinterpret_cast<int *>(&s_pool);
     for (int i = tid; i < (int)(sizeof(Pool) / sizeof(int)); i += NT) pdst[i] = psrc[i];
   }
+#ifdef VBH_LDS_CANARY
+  if (tid < 4) { sh.canary_lo[tid] = 0xC0FFEE00u + tid; sh.canary_hi[tid] = 0xFACADE00u + tid; }
+  const unsigned long long slot_sum0 = (unsigned long long)slots[my_slot].ent ^ (unsigned long long)slots[my_slot].w_tok ^ (unsigned long long)slots[my_slot].hl;
+#endif
   __syncthreads();
   const Slot &s = s_slot;
   const Pool &pool = s_pool;
@@ -1200,13 +1211,23 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
     int frames_done = 0;
     PHASE(6)
     for (int frame = 0; frame < T && sh.error == ERR_NONE; frame++) {
+#ifdef VBH_LDS_CANARY
+      if (tid == 0) {
+        bool bad = false;
+        for (int i = 0; i < 4; i++) bad |= sh.canary_lo[i] != 0xC0FFEE00u + i || sh.canary_hi[i] != 0xFACADE00u + i;
+        const unsigned long long sum = (unsigned long long)s_slot.ent ^ (unsigned long long)s_slot.w_tok ^ (unsigned long long)s_slot.hl;
+        if (bad || sum != slot_sum0) sh.error = ERR_LDS;
+      }
+      __syncthreads();
+      if (sh.error != ERR_NONE) break;
+#endif
       // ---- periodic pruning (:85-87); frame 0 has nothing behind it
       if (frame > 0 && frame % cfg.prune_interval == 0) {
         __syncthreads();
         // intermediate passes walk back at most one interval beyond the unpruned frames: a bound on
         // the work (long-lived parallel paths would otherwise drag every pass back to frame 0);
         // whatever is left stale is a lower bound and is settled by the final pass
-        prune_backward(s, frame - 1, prev_front < 0 ? 0 : prev_front, (prev_front < 0 ? 0 : prev_front) - cfg.prune_interval,
+        prune_backward(s, frame - 1, prev_front < 0 ? 0 : prev_front, (prev_front < 0 ? 0 : prev_front) - cfg.prune_back,
                        cfg.lattice_beam, cfg.lattice_beam * 0.1f, /*final=*/false, sh, pp);
         PHASE(4)
         if (!compact_window(s, prev_front, frame, sh)) break;
@@ -2113,6 +2134,7 @@ static const char *err_name(int e) {
     case ERR_POOL: return "output pool capacity exceeded";
     case ERR_CAND: return "candidate list capacity exceeded";
     case ERR_NOT_RUN: return "no workgroup searched the utterance";
+    case ERR_LDS: return "the workgroup's LDS was overwritten from outside (canary, diagnostic build)";
     default: return "unknown";
   }
 }
@@ -2202,7 +2224,8 @@ static int decode_batch_begin_impl(vbh_decoder *d, const float *d_loglikes, int3
   DevBuf<Pool> &d_pool = d->d_pool;
   if (!d_pool.p && d_pool.alloc(1)) return -1;
   const DevGraph dg0{g->S, g->start, g->st.p, g->arcs.p, g->arc_il.p};
-  const DecCfg dc0{d->cfg.beam, d->cfg.lattice_beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active, effective_prune_interval(&d->cfg), getenv("VBH_NO_LDS_MAP") ? 0 : 1};
+  const DecCfg dc0{d->cfg.beam, d->cfg.lattice_beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active, effective_prune_interval(&d->cfg), getenv("VBH_NO_LDS_MAP") ? 0 : 1,
+                      getenv("VBH_PRUNE_BACK") ? std::max(0, atoi(getenv("VBH_PRUNE_BACK"))) : effective_prune_interval(&d->cfg)};
   // Optional longest-first order for the persistent grid (VBH_LPT_PROBE_FRAMES=n, off by default).
   // Search times differ several-fold between utterances of equal length (how well the audio matches
   // the model decides how many tokens stay in the beam), and with a few utterances per workgroup one

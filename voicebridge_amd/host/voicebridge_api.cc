@@ -237,7 +237,7 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
              "raw-energy", "cepstral-lifter", "htk-compat", "output-format", "subtract-mean", "vtln-warp", "vtln-map",
              "utt2spk", "channel", "min-duration",
              // extensions of this build: what the MakeMfcc step otherwise pipes through copy-feats (VB/scr/steps/make_mfcc.cpp:215)
-             "compress", "write-num-frames", "dither-seed"});
+             "compress", "write-num-frames", "dither-seed", "segments", "min-segment-length", "max-overshoot"});
     po.Parse(argc, argv);
     if (po.args.size() != 2) throw ApiError("wrong arguments.");
     vbh_mfcc_opts o;
@@ -275,6 +275,42 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
     const vbio::Rspec rs = vbio::ParseRspecifier(po.args[0]);
     if (!rs.is_scp) throw ApiError("wav rspecifier must be scp: (got " + po.args[0] + ")");
     std::vector<vbio::ScpEntry> scp = vbio::ReadScp(rs.path);
+    // --segments=<file> (extension): what the reference's MakeMfcc pipes through extract-segments when the data directory has a
+    // segments file (VB/scr/steps/make_mfcc.cpp:93-190; K/featbin/extract-segments.cc:60-195): the table holds recordings, an
+    // utterance is the piece <segment-id> <recording-id> <start> <end> [channel] of one, with that program's checks and warnings
+    struct Segment { std::string id; size_t rec = 0; double start = 0, end = 0; int channel = -1; };
+    std::vector<Segment> segments;
+    const bool use_segments = po.Has("segments");
+    if (use_segments) {
+      std::map<std::string, size_t> rec_index;
+      for (size_t k = 0; k < scp.size(); k++) rec_index[scp[k].key] = k;
+      std::ifstream sf(po.Str("segments", ""));
+      if (!sf) throw ApiError("cannot open " + po.Str("segments", ""));
+      std::string line;
+      while (std::getline(sf, line)) {
+        std::vector<std::string> f; { std::istringstream is(line); std::string w; while (is >> w) f.push_back(w); }
+        if (f.empty()) continue;
+        if (f.size() != 4 && f.size() != 5) { log.os() << "WARNING (extract-segments) Invalid line in segments file: " << line << "\n"; continue; }
+        char *e1 = nullptr, *e2 = nullptr;
+        Segment sg; sg.id = f[0];
+        sg.start = strtod(f[2].c_str(), &e1); sg.end = strtod(f[3].c_str(), &e2);
+        if (e1 == f[2].c_str() || *e1) { log.os() << "WARNING (extract-segments) Invalid line in segments file [bad start]: " << line << "\n"; continue; }
+        if (e2 == f[3].c_str() || *e2) { log.os() << "WARNING (extract-segments) Invalid line in segments file [bad end]: " << line << "\n"; continue; }
+        if (sg.start < 0 || (sg.end != -1.0 && sg.end <= 0) || (sg.start >= sg.end && sg.end > 0)) {
+          log.os() << "WARNING (extract-segments) Invalid line in segments file [empty or invalid segment]: " << line << "\n"; continue;
+        }
+        if (f.size() == 5) {
+          char *e3 = nullptr; const long c = strtol(f[4].c_str(), &e3, 10);
+          if (e3 == f[4].c_str() || *e3 || c < 0) { log.os() << "WARNING (extract-segments) Invalid line in segments file [bad channel]: " << line << "\n"; continue; }
+          sg.channel = (int)c;
+        }
+        auto it = rec_index.find(f[1]);
+        if (it == rec_index.end()) { log.os() << "WARNING (extract-segments) Could not find recording " << f[1] << ", skipping segment " << sg.id << "\n"; continue; }
+        sg.rec = it->second;
+        segments.push_back(sg);
+      }
+    }
+    const double min_segment_length = po.Num("min-segment-length", 0.1), max_overshoot = po.Num("max-overshoot", 0.5);
     vbio::MatrixWriter writer(po.args[1], po.Bool("compress", false));
     std::ofstream num_frames_out;
     if (po.Has("write-num-frames")) {
@@ -289,53 +325,90 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
     int num_utts = 0, num_success = 0;
     size_t num_success_batches_base = 0;      // utterances handed to the device so far: the dither stream's utterance index
     // utterances are packed into batches of ~64 M samples per device pass
+    // the units of work: the table's entries, or the pieces of them a segments file names
+    struct Unit { std::string key; size_t rec; int seg; };
+    std::vector<Unit> units;
+    if (use_segments) for (size_t k = 0; k < segments.size(); k++) units.push_back(Unit{segments[k].id, segments[k].rec, (int)k});
+    else for (size_t k = 0; k < scp.size(); k++) units.push_back(Unit{scp[k].key, k, -1});
     size_t i = 0;
-    while (i < scp.size()) {
+    while (i < units.size()) {
       std::vector<std::string> keys; std::vector<int64_t> woff(1, 0); std::vector<float> samples;
-      // the files of a batch are read and parsed on several host threads (a 30 s utterance is 1 MB of PCM), then taken in table order
+      // the files of a batch are read and parsed on several host threads (a 30 s utterance is 1 MB of PCM), then taken in table order;
+      // a recording that several segments of the batch cut from is read once
       const size_t i0 = i;
       size_t i1 = i0, est = 0;
-      while (i1 < scp.size() && est < (size_t)(64 << 20)) {
-        struct stat st;
-        est += stat(scp[i1].path.c_str(), &st) == 0 ? (size_t)st.st_size / 2 : (size_t)1 << 16;
+      std::vector<size_t> recs; std::map<size_t, size_t> rec_slot;
+      while (i1 < units.size() && est < (size_t)(64 << 20)) {
+        if (!rec_slot.count(units[i1].rec)) {
+          struct stat st;
+          est += stat(scp[units[i1].rec].path.c_str(), &st) == 0 ? (size_t)st.st_size / 2 : (size_t)1 << 16;
+          rec_slot[units[i1].rec] = recs.size(); recs.push_back(units[i1].rec);
+        }
         i1++;
       }
-      std::vector<vbio::Wave> waves(i1 - i0);
-      std::vector<std::string> werr(i1 - i0);
+      std::vector<vbio::Wave> waves(recs.size());
+      std::vector<std::string> werr(recs.size());
       {
         std::atomic<size_t> next{0};
         auto work = [&]() {
-          for (size_t k = next++; k < i1 - i0; k = next++) {
-            const vbio::ScpEntry &e = scp[i0 + k];
+          for (size_t k = next++; k < recs.size(); k = next++) {
+            const vbio::ScpEntry &e = scp[recs[k]];
             if (!e.path.empty() && e.path.back() == '|') continue;
             try { vbio::ReadWaveFile(e.path, e.offset, &waves[k]); } catch (const std::exception &ex) { werr[k] = ex.what(); if (werr[k].empty()) werr[k] = "read error"; }
           }
         };
-        const unsigned nt = std::max(1u, std::min<unsigned>(8, std::min<unsigned>((unsigned)(i1 - i0), std::thread::hardware_concurrency())));
+        const unsigned nt = std::max(1u, std::min<unsigned>(8, std::min<unsigned>((unsigned)recs.size(), std::thread::hardware_concurrency())));
         std::vector<std::thread> pool;
         for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
         work();
         for (std::thread &t : pool) t.join();
       }
       for (; i < i1; i++) {
-        const vbio::ScpEntry &e = scp[i];
+        const Unit &un = units[i];
+        const vbio::ScpEntry &e = scp[un.rec];
         num_utts++;
         if (!e.path.empty() && e.path.back() == '|') { log.os() << "WARNING (compute-mfcc-feats) pipe input not supported: " << e.key << "\n"; continue; }
-        vbio::Wave &w = waves[i - i0];
-        if (!werr[i - i0].empty()) { log.os() << "WARNING (compute-mfcc-feats) " << e.key << ": " << werr[i - i0] << "\n"; continue; }
-        const double dur = w.data.empty() ? 0.0 : w.data[0].size() / w.samp_freq;
-        if (dur < min_duration) { log.os() << "WARNING (compute-mfcc-feats) File: " << e.key << " is too short (" << dur << " sec): producing no output.\n"; continue; }
+        vbio::Wave &w = waves[rec_slot[un.rec]];
+        if (!werr[rec_slot[un.rec]].empty()) { log.os() << "WARNING (compute-mfcc-feats) " << e.key << ": " << werr[rec_slot[un.rec]] << "\n"; continue; }
+        // the samples of the unit: the whole recording, or the segment's piece of it (extract-segments.cc:126-190)
+        size_t s0 = 0, s1 = w.data.empty() ? 0 : w.data[0].size();
         int ch = channel;
-        if (ch == -1) {
-          ch = 0;
-          if (w.channels != 1) log.os() << "WARNING (compute-mfcc-feats) Channel not specified but you have data with " << w.channels << " channels; defaulting to zero\n";
-        } else if (ch >= w.channels) { log.os() << "WARNING (compute-mfcc-feats) File with id " << e.key << " has " << w.channels << " channels but you specified channel " << channel << ", producing no output.\n"; continue; }
-        if (w.samp_freq != o.samp_freq) { log.os() << "WARNING (compute-mfcc-feats) Failed to compute features for utterance " << e.key << ": sample frequency mismatch " << w.samp_freq << " vs " << o.samp_freq << "\n"; continue; }
-        keys.push_back(e.key);
-        samples.insert(samples.end(), w.data[ch].begin(), w.data[ch].end());
+        if (un.seg >= 0) {
+          const Segment &sg = segments[(size_t)un.seg];
+          const int32_t num_samp = (int32_t)s1;
+          const int32_t start_samp = (int32_t)(sg.start * w.samp_freq);
+          int32_t end_samp = sg.end != -1.0 ? (int32_t)(sg.end * w.samp_freq) : num_samp;
+          if (start_samp < 0 || start_samp >= num_samp) {
+            log.os() << "WARNING (extract-segments) Start sample out of range " << start_samp << " [length:] " << num_samp << ", skipping segment " << sg.id << "\n"; continue;
+          }
+          if (end_samp > num_samp) {
+            if (end_samp >= num_samp + (int32_t)(max_overshoot * w.samp_freq)) {
+              log.os() << "WARNING (extract-segments) End sample too far out of range " << end_samp << " [length:] " << num_samp << ", skipping segment " << sg.id << "\n"; continue;
+            }
+            end_samp = num_samp;
+          }
+          if (end_samp <= start_samp + (int32_t)(min_segment_length * w.samp_freq)) { log.os() << "WARNING (extract-segments) Segment " << sg.id << " too short, skipping it.\n"; continue; }
+          if (sg.channel == -1) {
+            if (w.channels != 1) throw ApiError("If your data has multiple channels, you must specify the channel in the segments file.  Processing segment " + sg.id);
+            ch = 0;
+          } else if (sg.channel >= w.channels) { log.os() << "WARNING (extract-segments) Invalid channel " << sg.channel << " >= " << w.channels << ", processing segment " << sg.id << "\n"; continue; }
+          else ch = sg.channel;
+          s0 = (size_t)start_samp; s1 = (size_t)end_samp;
+        }
+        const double dur = (double)(s1 - s0) / w.samp_freq;
+        if (dur < min_duration) { log.os() << "WARNING (compute-mfcc-feats) File: " << un.key << " is too short (" << dur << " sec): producing no output.\n"; continue; }
+        if (un.seg < 0) {
+          if (ch == -1) {
+            ch = 0;
+            if (w.channels != 1) log.os() << "WARNING (compute-mfcc-feats) Channel not specified but you have data with " << w.channels << " channels; defaulting to zero\n";
+          } else if (ch >= w.channels) { log.os() << "WARNING (compute-mfcc-feats) File with id " << un.key << " has " << w.channels << " channels but you specified channel " << channel << ", producing no output.\n"; continue; }
+        }
+        if (w.samp_freq != o.samp_freq) { log.os() << "WARNING (compute-mfcc-feats) Failed to compute features for utterance " << un.key << ": sample frequency mismatch " << w.samp_freq << " vs " << o.samp_freq << "\n"; continue; }
+        keys.push_back(un.key);
+        samples.insert(samples.end(), w.data[ch].begin() + (std::ptrdiff_t)s0, w.data[ch].begin() + (std::ptrdiff_t)s1);
         woff.push_back((int64_t)samples.size());
-        std::vector<std::vector<float>>().swap(w.data);
       }
+      std::vector<vbio::Wave>().swap(waves);
       if (keys.empty()) continue;
       int64_t total = 0;
       for (size_t u = 0; u < keys.size(); u++) total += vbh_mfcc_num_frames(&o, woff[u + 1] - woff[u]);

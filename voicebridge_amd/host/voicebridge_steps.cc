@@ -189,9 +189,12 @@ int MakeMfcc(const std::string &datadir, const std::string &mfcc_config, int nj,
     const std::string scp = Join(datadir, "wav.scp");
     const std::vector<std::string> wav = ReadLines(scp);
     if (wav.empty()) throw StepError(scp + " is empty.");
-    if (Exists(Join(datadir, "segments"))) throw StepError("a segments file (extract-segments) is not part of this build");
+    // a segments file: the table holds recordings and the utterances are pieces of them (make_mfcc.cpp:93-190 pipes through
+    // extract-segments; here compute-mfcc-feats takes the job's share of the segments file itself, --segments)
+    const bool use_segments = Exists(Join(datadir, "segments"));
+    const std::vector<std::string> seg_lines = use_segments ? ReadLines(Join(datadir, "segments")) : std::vector<std::string>();
     if (Exists(Join(datadir, "spk2warp")) || Exists(Join(datadir, "utt2warp"))) throw StepError("VTLN warp maps are not part of this build");
-    const auto pieces = SplitLines(wav, nj);
+    const auto pieces = SplitLines(use_segments ? seg_lines : wav, nj);
     ForEachJob(nj, [&](int j) {
       const std::string J = std::to_string(j);
       const std::string piece = Join(logdir, "wav_" + name + "." + J + ".scp"), temp = Join(logdir, "wav_" + name + "." + J + ".mfctemp");
@@ -203,7 +206,8 @@ int MakeMfcc(const std::string &datadir, const std::string &mfcc_config, int nj,
       (void)temp;
       std::vector<std::string> c = {"compute-mfcc-feats", "--config=" + mfcc_config, std::string("--compress=") + (compress ? "true" : "false")};
       if (write_utt2num_frames) c.push_back("--write-num-frames=ark,t:" + Join(logdir, "utt2num_frames." + J));
-      c.push_back("scp,p:" + piece);
+      if (use_segments) { c.push_back("--segments=" + piece); c.push_back("scp,p:" + scp); }
+      else c.push_back("scp,p:" + piece);
       c.push_back("ark,scp:" + Join(mfccdir, "raw_mfcc_" + name + "." + J + ".ark") + "," + Join(mfccdir, "raw_mfcc_" + name + "." + J + ".scp"));
       Argv a1(c);
       if (ComputeMFCCFeats(a1.argc(), a1.argv(), log) < 0) throw StepError("compute-mfcc-feats failed for job " + J + ", see " + logdir);
