@@ -51,7 +51,14 @@ def parse():
     ap.add_argument("--beam", type=float, default=13.0)
     ap.add_argument("--lattice-beam", type=float, default=6.0)
     ap.add_argument("--max-active", type=int, default=7000)
-    ap.add_argument("--mean-scale", type=float, default=1.5, help="spread of the synthetic GMM means (search difficulty)")
+    ap.add_argument("--workload", choices=("speech", "tones"), default="speech",
+                    help="speech: utterances are word sequences of the graph's lexicon, every HMM state a noise burst with its pdf's spectral "
+                         "envelope, acoustic model fit to such data through the product's front end (voicebridge_amd/synth_speech.py); hypotheses are "
+                         "scored against the transcripts.  tones: round 1's tone-plus-noise waveforms under a randomly placed GMM")
+    ap.add_argument("--depth", type=float, default=0.25,
+                    help="speech workload: standard deviation (nats) of the pdfs' cepstral envelopes = how far apart the pdfs sound (search difficulty)")
+    ap.add_argument("--train-utts", type=int, default=128, help="speech workload: utterances (uniformly drawn words) the acoustic model is fit to")
+    ap.add_argument("--mean-scale", type=float, default=1.5, help="tones workload: spread of the synthetic GMM means (search difficulty)")
     ap.add_argument("--var-spread", type=float, default=0.2, help="sigma of the log-variances of the synthetic GMM")
     ap.add_argument("--sub-batches", type=int, default=1,
                     help="a step's utterances go through the pipeline as this many slices of whole speakers (front end and search per slice): more, "
@@ -74,6 +81,10 @@ def parse():
     ap.add_argument("--load-waves", default="", help="read the PCM a --save-waves run of the same --batch / --seconds wrote instead of synthesising it "
                                                       "on the device (profiling runs: rocprofv3 --pmc does not survive torch's generator kernels)")
     ap.add_argument("--probe", action="store_true", help="print search statistics of the first utterances and exit")
+    ap.add_argument("--sweep-depth", default="",
+                    help="speech workload: comma-separated --depth values: for each, the batch is synthesised, the model fit, one batch scored and "
+                         "searched (no pipeline) and a JSON line printed (search rate, tokens per frame, bound shares, WER against the transcripts); "
+                         "then exit")
     ap.add_argument("--sweep-mean-scale", default="",
                     help="comma-separated --mean-scale values: for each, one batch is scored and searched (one batch at a time, no pipeline) and a JSON "
                          "line with the search's difficulty (tokens, arcs per frame, share of frames bound by max-/min-active) and its rate is printed; "
@@ -88,17 +99,18 @@ def parse():
     return ap.parse_args()
 
 
-def build_graph(args):
+def build_graph(args, lexicon=False):
     """synthetic HCLG: lexicon prefix tree x 3-state HMMs x unigram loop (voicebridge_amd/synth.py);
     ~2.5 M states / 5 M arcs at the default 228 k words"""
     from voicebridge_amd import synth
-    return synth.lexicon_graph(args.words, args.pdfs, seed=11)
+    return synth.lexicon_graph(args.words, args.pdfs, seed=11, return_lexicon=lexicon)
 
 
 UTT_PER_SPK = 4
+SPEECH_XFORM_SCALE = 0.005
 
 
-def build_workload(args, rank, world, device):
+def build_workload(args, rank, world, device, lex=None):
     """The job = world x batch utterances of world x batch/4 speakers (speakers of 4 utterances),
     sharded by speaker over the ranks as voicebridge_amd/dist.py does for a data directory (longest-processing-time
     assignment; all utterances have the same length here, so every rank gets batch/4 speakers).  Every utterance of the
@@ -116,6 +128,11 @@ def build_workload(args, rank, world, device):
     utt2spk = (np.arange(args.batch, dtype=np.int32) // upk).astype(np.int32)      # rank-local speaker index: a speaker's utterances are adjacent
     gid = my_spk[utt2spk] * upk + np.arange(args.batch) % upk             # job-wide utterance id
     n = int(round(args.seconds * 16000))
+    truth = None
+    if lex is not None:
+        from voicebridge_amd import synth_speech as ss
+        n = (n // ss.HOP) * ss.HOP
+        hop_pdf, truth = ss.transcripts(lex, gid, n // ss.HOP)
     if args.load_waves:
         h_wave = np.load(args.load_waves)
         if h_wave.dtype != np.int16 or h_wave.size != args.batch * n:
@@ -123,14 +140,56 @@ def build_workload(args, rank, world, device):
         d_wave = torch.from_numpy(h_wave.reshape(-1)).to(device)
     else:
         d_wave = torch.empty(args.batch * n, dtype=torch.int16, device=device)
+        if lex is not None:
+            gains = torch.from_numpy(ss.pdf_gains(args.pdfs, args.depth)).to(device)
+            sgain = torch.from_numpy(ss.speaker_gains(my_spk)).to(device)
         for a in range(0, args.batch, 64):
             b_ = min(a + 64, args.batch)
-            d_wave[a * n:b_ * n] = synth.wave_batch_device(gid[a:b_], args.seconds, device).reshape(-1)
+            if lex is not None:
+                d_wave[a * n:b_ * n] = ss.waves_device(hop_pdf[a:b_], gains, gid[a:b_], device, spk_gain=sgain[utt2spk[a:b_]]).reshape(-1)
+            else:
+                d_wave[a * n:b_ * n] = synth.wave_batch_device(gid[a:b_], args.seconds, device).reshape(-1)
     if args.save_waves:
         np.save(args.save_waves, d_wave.cpu().numpy())
     woff = np.arange(args.batch + 1, dtype=np.int64) * n
-    xforms = np.stack([synth.affine(args.feat_dim, seed=int(s)) for s in my_spk])
-    return d_wave, woff, utt2spk, n_spk, xforms, gid
+    # the speakers' fMLLR-like transforms: for the speech workload close to the identity (an adaptation transform that scrambled the
+    # features by as much as the pdfs differ would make the model useless for every speaker but its own)
+    xforms = np.stack([synth.affine(args.feat_dim, seed=int(s), scale=SPEECH_XFORM_SCALE if lex is not None else 0.05) for s in my_spk])
+    return d_wave, woff, utt2spk, n_spk, xforms, gid, truth
+
+
+def speech_model(args, lex, mf, post, ctx, device):
+    """The acoustic model of the speech workload: --train-utts utterances of uniformly drawn words (so that every phone is
+    heard), spoken by speakers of their own and taken through the bench's front end (MFCC, per-speaker CMVN, deltas or
+    splice + LDA, the speakers' transforms); per-pdf mean / variance of the labelled frames, spread over the pdf's
+    mixture components (synth_speech.GmmFit).  Every rank fits the same model (the seeds do not depend on the rank)."""
+    import torch
+    from voicebridge_amd import synth, synth_speech as ss
+    n = (int(round(args.seconds * 16000)) // ss.HOP) * ss.HOP
+    gains = torch.from_numpy(ss.pdf_gains(args.pdfs, args.depth)).to(device)
+    fit = ss.GmmFit(args.pdfs, args.feat_dim, device)
+    first_id, first_spk = 1 << 24, 1 << 20          # ids no job utterance / speaker has
+    for a in range(0, args.train_utts, 64):
+        b_ = min(a + 64, args.train_utts)
+        ids = first_id + np.arange(a, b_)
+        spk = first_spk + np.arange(a, b_) // UTT_PER_SPK
+        u2s = (np.arange(a, b_) // UTT_PER_SPK - a // UTT_PER_SPK).astype(np.int32)
+        hop_pdf, _w = ss.transcripts(lex, ids, n // ss.HOP, uniform=True)
+        sg = torch.from_numpy(ss.speaker_gains(spk)).to(device)
+        w = ss.waves_device(hop_pdf, gains, ids, device, spk_gain=sg).reshape(-1)
+        woff = np.arange(b_ - a + 1, dtype=np.int64) * n
+        ctx.torch_sync()
+        raw, foff = mf.compute_packed(w, woff, True)
+        ctx.sync()
+        n_spk = int(u2s.max()) + 1
+        xf = np.stack([synth.affine(args.feat_dim, seed=int(s_), scale=SPEECH_XFORM_SCALE) for s_ in np.unique(spk)])
+        st = post.cmvn_stats(raw, foff, u2s, n_spk)
+        f = post.apply(raw, foff, utt2spk=u2s, cmvn_stats=st, spk_xforms=xf)
+        ctx.sync()
+        nf = int(foff[1] - foff[0])
+        fit.add(f, ss.frame_labels(hop_pdf, nf))
+    model, n_unseen = fit.model(args.gauss)
+    return model, n_unseen
 
 
 def synth_lda(args):
@@ -507,7 +566,10 @@ def main():
     dev = ctx.device
     cdev = torch.device("cpu") if backend == "gloo" else dev        # where the tensors of the collectives live
 
-    d_wave, woff, utt2spk, n_spk, xforms, gid = build_workload(args, rank, world, dev)
+    lex = None
+    if args.workload == "speech":
+        g, t2p, lex = build_graph(args, lexicon=True)
+    d_wave, woff, utt2spk, n_spk, xforms, gid, truth = build_workload(args, rank, world, dev, lex)
     is_i16 = True
     mf = api.Mfcc(ctx)
     if args.feat == "lda":
@@ -525,7 +587,11 @@ def main():
     T = int(foff[-1])
     # the random GMM is placed in the feature space of the whole batch: a sample of frames spread over all utterances
     sample_idx = torch.linspace(0, T - 1, min(T, 20000), device=dev).long()
-    model = feature_space_model(args, feats[sample_idx].cpu().numpy())
+    n_unseen_pdfs = None
+    if lex is not None:
+        model, n_unseen_pdfs = speech_model(args, lex, mf, post, ctx, dev)
+    else:
+        model = feature_space_model(args, feats[sample_idx].cpu().numpy())
     gmm = api.DiagGmm(ctx, *model)
     ll = torch.empty((T, gmm.num_pdfs), dtype=torch.float32, device=dev)
     ctx.torch_sync()
@@ -533,7 +599,8 @@ def main():
     decode_setup = None
     dec = None
     if not args.no_decode:
-        g, t2p = build_graph(args)
+        if lex is None:
+            g, t2p = build_graph(args)
         graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
         Tmax = int(np.max(np.diff(foff)))
         dec = api.LatticeDecoder(ctx, graph, args.batch, Tmax, beam=args.beam, max_active=args.max_active,
@@ -543,6 +610,53 @@ def main():
         ctx.sync()
 
     dec_enabled = dec is not None
+    if args.sweep_depth and dec is not None and lex is not None:
+        from voicebridge_amd import dist as vdist
+        for dp in [float(x) for x in args.sweep_depth.split(",") if x]:
+            args.depth = dp
+            gmm.close()
+            d_wave = raw = feats = None
+            d_wave, woff, utt2spk, n_spk, xforms, gid, truth = build_workload(args, rank, world, dev, lex)
+            ctx.torch_sync()
+            raw, foff = mf.compute_packed(d_wave, woff, is_i16)
+            ctx.sync()
+            stats = post.cmvn_stats(raw, foff, utt2spk, n_spk)
+            feats = post.apply(raw, foff, utt2spk=utt2spk, cmvn_stats=stats, spk_xforms=xforms)
+            ctx.sync()
+            model, n_unseen_pdfs = speech_model(args, lex, mf, post, ctx, dev)
+            gmm = api.DiagGmm(ctx, *model)
+            gmm.loglikes(feats, out=ll)
+            ctx.sync()
+            # frame accuracy of the model: is the spoken pdf the best-scoring one?
+            from voicebridge_amd import synth_speech as ss
+            n_hops = (int(round(args.seconds * 16000)) // ss.HOP)
+            hop_pdf, _tw = ss.transcripts(lex, gid, n_hops)
+            lab = torch.as_tensor(np.concatenate([ss.frame_labels(hop_pdf[u:u + 1], int(foff[u + 1] - foff[u]))[0] for u in range(args.batch)]), device=dev).long()
+            acc = 0
+            for a_ in range(0, T, 1 << 18):
+                acc += int((ll[a_:a_ + (1 << 18)].argmax(1) == lab[a_:a_ + (1 << 18)]).sum())
+            best = None
+            for _ in range(2):
+                dec.decode(ll, foff, t2p)
+                tm = dec.times()
+                best = tm["kernel_ms"] if best is None else min(best, tm["kernel_ms"])
+            c = dict(tok=0, arc=0, new=0, link=0, maxb=0, minb=0, lat=0, words=0, fin=0)
+            hyps = []
+            for u in range(args.batch):
+                r = dec.result(u, arrays=False)
+                c["tok"] += r["n_tokens_expanded"]; c["arc"] += r["n_arcs_expanded"]; c["new"] += r["n_tokens_created"]; c["link"] += r["n_links_created"]
+                c["maxb"] += r["n_frames_maxactive_bound"]; c["minb"] += r["n_frames_minactive_bound"]; c["lat"] += r["num_links"]; c["words"] += len(r["words"])
+                c["fin"] += int(r["reached_final"])
+                hyps.append(r["words"])
+            wc = dict(zip(vdist.COUNTER_NAMES, [int(x) for x in vdist.score(truth, hyps)]))
+            print(json.dumps({"depth": dp, "utterances": args.batch, "frames": T, "search_kernel_ms": best, "frames_per_s_search_only": T / (best * 1e-3),
+                              "tokens_expanded_per_frame": c["tok"] / T, "arcs_per_frame": c["arc"] / T,
+                              "tokens_created_per_frame": c["new"] / T, "links_per_frame": c["link"] / T, "share_frames_maxactive_bound": c["maxb"] / T,
+                              "share_frames_minactive_bound": c["minb"] / T, "lattice_arcs_per_frame": c["lat"] / T, "words_per_utterance": c["words"] / args.batch,
+                              "reached_final": c["fin"], "frame_accuracy_of_the_model": acc / T, "pdfs_unseen_in_training": n_unseen_pdfs,
+                              "wer_percent": 100.0 * wc["word_errs"] / max(wc["num_words"], 1), "ref_words_per_utterance": wc["num_words"] / args.batch,
+                              "ins_del_sub": [wc["ins"], wc["del"], wc["sub"]], "batch_stats": dec.batch_stats()}), flush=True)
+        return
     if args.sweep_mean_scale and dec is not None:
         for ms_ in [float(x) for x in args.sweep_mean_scale.split(",") if x]:
             args.mean_scale = ms_
@@ -625,6 +739,14 @@ def main():
             tot = max(sum(ph[:7]), 1)
             print("   phase share: " + ", ".join("%s %.1f%%" % (nm, 100.0 * c / tot) for nm, c in zip(
                 ["cutoff", "pass1", "admit+links", "eps", "prune", "compact", "output"], ph[:7])) + "  cycles/frame=%.0f prune-visited-frames=%d" % (tot / nf, ph[7]))
+            dg = dec.diag(u)
+            if any(dg[8:]):
+                tot += dg[8] + dg[9]
+                print("   VBH_DIAG: admit %.1f%% links %.1f%% cutoff-up-to-first-reduction %.1f%% rest-of-cutoff %.1f%%; admissions/frame %.0f, to the HBM map %.1f%%; "
+                      "frames creating > 3/4 of the LDS map %d, frames with > 2 candidates per slot %d"
+                      % (100.0 * dg[8] / tot, 100.0 * dg[2] / tot, 100.0 * dg[9] / tot, 100.0 * dg[0] / tot, dg[11] / nf, 100.0 * dg[10] / max(dg[11], 1), dg[12], dg[13]))
+                print("   frames by tokens at their start (< 512, < 2048, < 6144, more): frames %s, kilocycles per frame %s"
+                      % ([(dg[15] >> (16 * i)) & 0xFFFF for i in range(4)], [(dg[14] >> (16 * i)) & 0xFFFF for i in range(4)]))
         return
 
     # ---- pipeline (depth > 1).  Front end (MFCC, post, GMM) on its own context/stream, two
@@ -891,7 +1013,7 @@ def main():
         from voicebridge_amd import dist as vdist
         hyps = col_words
         ids = [int(x) for x in gid]
-        counters = vdist.score(hyps, hyps)          # synthetic audio has no transcripts: self-scored
+        counters = vdist.score(truth if truth is not None else hyps, hyps)     # (tones have no transcripts: self-scored)
         totals, merged = vdist.gather_results(ids, hyps, counters, device=cdev)
         if rank == 0:
             gathered = {"utterances": len(merged), "counters": dict(zip(vdist.COUNTER_NAMES, totals.tolist()))}
@@ -935,6 +1057,18 @@ def main():
                 stage_ms["note"] = ("per pipeline item (a step = %d slice(s) of %d utterances); %d items in flight on %d streams: stage times of "
                                     "consecutive items overlap and are not additive; a search kernel's duration includes the time its "
                                     "workgroups wait for CUs still held by the grids launched before it" % (S, per, depth, depth))
+            if truth is not None:
+                from voicebridge_amd import dist as vdist
+                if gathered is not None:
+                    wc = dict(gathered["counters"])
+                else:
+                    wc = dict(zip(vdist.COUNTER_NAMES, [int(x) for x in vdist.score(truth, col_words)]))
+                extra["wer_vs_transcripts"] = {
+                    "wer_percent": 100.0 * wc["word_errs"] / max(wc["num_words"], 1), "words": wc["num_words"], "ins": wc["ins"], "del": wc["del"],
+                    "sub": wc["sub"], "utterances": wc["num_sent"], "words_per_utterance": wc["num_words"] / max(wc["num_sent"], 1),
+                    "what": "best path of the raw lattice (acoustic scale 1/12, no LM-weight search) of the last timed step's utterances against "
+                            "the word sequences the waveforms were synthesised from; the acoustic model was fit to other utterances by other speakers"
+                            + (", %d pdfs unseen in the training data" % n_unseen_pdfs if n_unseen_pdfs else "")}
             extra["search_grid_last_batch"] = grid_stats
             extra["search_retries_last_batch"] = col_stats
             # algorithmic bytes of the search from the counters of one step:
@@ -980,7 +1114,9 @@ def main():
             "metric": "decode frames/sec/node (RTF = 100/value), DELTA+SAT sizes",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32",
+            "data": ("synthetic speech: word sequences of the graph's lexicon, one spectral envelope per pdf (depth %g), model fit to %d other utterances"
+                     % (args.depth, args.train_utts)) if lex is not None else "synthetic",
             "rtf": 100.0 / value,
             "config": {"workload": ("config2: MFCC + CMVN/deltas/fMLLR + all-pdf GMM scoring (search not in the step)"
                                     if dec is None else
@@ -1035,9 +1171,20 @@ def main():
                          "reference_like_per_frame": cpu_like.get(u), "gpu_like_per_frame": float(col_like[u])}
                         for u, w_ in cpu_words.items() if list(col_words[u]) != list(w_)]
                 if diff:
-                    out["parity_words_differ"] = diff
+                    out["parity_words_differ"] = [{k_: (v_ if "words" not in k_ else "%d words" % len(v_)) for k_, v_ in d_.items()} for d_ in diff]
                 out["parity_note"] = ("best-path words of the GPU step against the %s's for the utterances of the CPU sample (same waveforms, model, "
-                                      "graph, transforms)" % ("reference programs" if ref_cb is not None else "oracle"))
+                                      "graph, transforms).  Where they differ the two pipelines' scores differ within their float tolerance (MFCC 2e-3 abs, "
+                                      "log-likelihoods 1e-4 rel) and the search, with max-active deciding the cutoff in every sixth frame, keeps or loses a "
+                                      "hypothesis on that margin -- in either direction (like_per_frame is the best path's own score: the higher one "
+                                      "found the better path).  On IDENTICAL scores the GPU search reproduces the reference's best paths bit for bit "
+                                      "(tests/test_gpu_config3.py, tests/golden/speech_refpaths.npz)" % ("reference programs" if ref_cb is not None else "oracle"))
+                if truth is not None:
+                    from voicebridge_amd import dist as vdist
+                    us_ = sorted(cpu_words)
+                    wr_ = vdist.score([truth[u] for u in us_], [cpu_words[u] for u in us_])
+                    wg_ = vdist.score([truth[u] for u in us_], [col_words[u] for u in us_])
+                    out["parity_wer_on_the_cpu_sample"] = {"reference_percent": 100.0 * wr_[0] / max(wr_[1], 1), "gpu_percent": 100.0 * wg_[0] / max(wg_[1], 1),
+                                                           "words": int(wr_[1]), "utterances": len(us_)}
     if det_pool is not None:
         det_pool.close()
     # tear down in order: decoders before their contexts (and before the interpreter's own finalisation)
@@ -1058,7 +1205,8 @@ def main():
                 torch.cuda.empty_cache()
                 import subprocess
                 r_ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_steps.py"), "--utts", str(args.step_api_utts), "--nj", "4", "--fmllr",
-                                     "--job-threads", str(args.step_api_threads), "--words", str(args.words)], capture_output=True, text=True, timeout=600)
+                                     "--job-threads", str(args.step_api_threads), "--words", str(args.words), "--depth", str(args.depth),
+                                     "--train-utts", str(args.train_utts)], capture_output=True, text=True, timeout=600)
                 st_ = json.loads([l_ for l_ in r_.stdout.splitlines() if l_.startswith("{")][-1])
                 fr_ = float(st_["frames"])
                 k_dec = [k_ for k_ in st_ if k_.startswith("Decode_s")][0]
@@ -1066,7 +1214,8 @@ def main():
                 out["step_api"] = {"what": "tools/bench_steps.py: %d utterances of 30 s in a data directory, nj = 4 jobs on %d host thread(s), one GPU; seconds per step "
                                            "of the reference's API and frames/s of the two decoding steps" % (args.step_api_utts, args.step_api_threads),
                                    "MakeMfcc_s": st_["MakeMfcc_s"], "ComputeCmvnStats_s": st_["ComputeCmvnStats_s"], "Decode_s": st_[k_dec],
-                                   "DecodeFmllr_s": st_[k_fm], "Decode_step_frames_per_s": fr_ / st_[k_dec], "DecodeFmllr_step_frames_per_s": fr_ / st_[k_fm]}
+                                   "DecodeFmllr_s": st_[k_fm], "Decode_step_frames_per_s": fr_ / st_[k_dec], "DecodeFmllr_step_frames_per_s": fr_ / st_[k_fm],
+                                   "Decode_best_wer": st_.get("Decode_best_wer"), "DecodeFmllr_best_wer": st_.get("DecodeFmllr_best_wer")}
             except Exception as e:
                 out["step_api"] = {"error": str(e)[:300]}
         print(json.dumps(out), flush=True)

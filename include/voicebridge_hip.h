@@ -252,6 +252,10 @@ int vbh_decoder_batch_stats(vbh_decoder *d, int32_t *out3);
 /* diagnostic: shader-clock cycles the utterance's workgroup spent per phase
  * {cutoff, pass1, admit+links, epsilon closure, pruning, compaction, output, other} */
 int vbh_decoder_phase_cycles(vbh_decoder *d, int32_t utt, int64_t *out8);
+/* diagnostic: the same 8 values, then -- in libraries built with -DVBH_DIAG, zeros otherwise -- {cycles admitting candidates (pass 2;
+ * [2] is then the forward links alone), cycles of the cutoff phase up to the first reduction, admissions that went to the HBM level of
+ * the state map, admissions, frames that created more than 3/4 of the LDS map's slots, frames with more than two candidates per slot, 0, 0} */
+int vbh_decoder_diag(vbh_decoder *d, int32_t utt, int64_t *out16);
 /* diagnostic: {device wall clock (100 MHz ticks) when a workgroup took the utterance, when it
  * finished it, workgroup id} -- load balance of the persistent search grid */
 int vbh_decoder_utt_timeline(vbh_decoder *d, int32_t utt, int64_t *out3);

@@ -10,6 +10,8 @@ GPU path from PCM to lattices, checked
   * with the small search slots shrunk (VBH_SLOT_SCALE) so that utterances overflow them and are searched again in big
     slots, and with the output pool too small for the batch: identical lattices, and the retry counters say it happened.
 """
+import functools
+
 import numpy as np
 import pytest
 
@@ -19,6 +21,14 @@ pytestmark = pytest.mark.gpu
 
 LAT_KEYS = ["tok_frame", "tok_state", "tok_cost", "tok_extra", "tok_final", "link_src", "link_dst", "link_ilabel",
             "link_olabel", "link_graph", "link_acoustic", "ali", "words"]
+
+
+@functools.lru_cache(maxsize=1)
+def lexicon_graph():
+    """the 180 k-word graph both fixtures were made with, and its lexicon (about a minute of Python: built once per run)"""
+    from oracle import gen_golden_config3 as c3
+    from voicebridge_amd import synth
+    return synth.lexicon_graph(c3.WORDS, c3.P, seed=11, return_lexicon=True)
 
 
 @pytest.fixture(scope="module")
@@ -40,7 +50,7 @@ def setup():
     gmm = api.DiagGmm(ctx, offs, w, miv, iv)
     ll = gmm.loglikes(feats)
     ctx.sync()
-    g, t2p = synth.lexicon_graph(c3.WORDS, c3.P, seed=11)
+    g, t2p, _lex = lexicon_graph()
     graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
     cfg = dict(beam=c3.CFG["beam"], max_active=c3.CFG["max_active"], min_active=c3.CFG["min_active"], lattice_beam=c3.CFG["lattice_beam"])
     dec = api.LatticeDecoder(ctx, graph, c3.N_UTT, int(np.diff(foff).max()), acoustic_scale=c3.CFG["acwt"], **cfg)
@@ -120,4 +130,46 @@ def test_output_pool_grows_instead_of_failing_the_batch(setup, monkeypatch):
         got = dec.result(u)
         for k in LAT_KEYS:
             np.testing.assert_array_equal(got[k], s["res"][u][k], err_msg="utt %d %s" % (u, k))
+    dec.close()
+
+
+def test_speech_workload_equals_the_reference_decoder_on_identical_scores(setup):
+    """The regime the bench's headline is measured in (synth_speech: ~50 words per 30 s utterance, max-active deciding the cutoff in
+    every sixth frame, WER about 1 % with this graph): the GPU search on the ORACLE's scores must give the best paths the REFERENCE's
+    own LatticeFasterDecoder gave on the same scores (oracle/gen_golden_speech.py ran it in the build container) -- words, alignment
+    and float32 weights, bit for bit -- and the lattice the oracle's order-independent mode gives."""
+    from oracle import gen_golden_speech as sp
+    from oracle import vbo
+    from voicebridge_amd import api, synth_speech as ss
+    s = setup
+    fx = load("speech_refpaths")
+    assert int(fx["n_utt"]) == sp.N_UTT and int(fx["words_in_graph"]) == sp.WORDS and float(fx["depth"]) == sp.DEPTH
+    g, t2p, lex = lexicon_graph()
+    ids, spk, waves, hop, truth = sp.test_set(lex)
+    crc = [int(np.bitwise_xor.reduce(w.view(np.uint16).astype(np.uint64) * (np.arange(w.size, dtype=np.uint64) % 65521 + 1))) for w in waves]
+    same_waves = crc == [int(x) for x in fx["waves_crc"]]
+    F = sp.oracle_features(waves, spk)
+    offs, w, miv, iv = ss.mixture_from_stats(fx["mu"], fx["var"], sp.G)
+    gc = vbo.gmm_gconsts(w, miv, iv)
+    ll = np.concatenate([vbo.gmm_loglikes(offs, gc, miv, iv, F[u]) for u in range(sp.N_UTT)])
+    foff = np.zeros(sp.N_UTT + 1, np.int64)
+    foff[1:] = np.cumsum([f.shape[0] for f in F])
+    dec = api.LatticeDecoder(s["ctx"], s["graph"], sp.N_UTT, int(np.diff(foff).max()), acoustic_scale=sp.CFG["acwt"], **s["cfg"])
+    dec.decode(s["torch"].from_numpy(ll).to(s["ctx"].device), foff, t2p)
+    fst = vbo.make_fst(g["final"], g["arc_offset"], g["arcs"], 0)
+    bound = 0
+    for u in range(sp.N_UTT):
+        got = dec.result(u)
+        msg = "utt %d (regenerated waveforms %s the fixture's)" % (u, "equal" if same_waves else "DIFFER from")
+        np.testing.assert_array_equal(got["words"], fx["ref_words_%d" % u], err_msg=msg)
+        np.testing.assert_array_equal(got["ali"], fx["ref_ali_%d" % u], err_msg=msg)
+        np.testing.assert_array_equal(np.float32([got["best_graph"], got["best_acoustic"]]), fx["ref_best_weight_%d" % u], err_msg=msg)
+        assert len(got["words"]) > 30
+        if u < 2:        # (the oracle's search of one such utterance takes a few seconds)
+            ref = vbo.decode_lattice_faster(fst, ll[foff[u]:foff[u + 1]], t2p, acwt=sp.CFG["acwt"], exact_cutoff=True, **s["cfg"])
+            for k in LAT_KEYS:
+                np.testing.assert_array_equal(got[k], ref[k], err_msg="utt %d %s" % (u, k))
+        bound += got["n_frames_maxactive_bound"]
+    assert bound > 8 * 300
+    assert dec.batch_stats()["failed"] == 0
     dec.close()

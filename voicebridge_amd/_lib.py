@@ -19,7 +19,7 @@ SYMBOLS = [
     "vbh_gmm_create", "vbh_gmm_destroy", "vbh_gmm_num_pdfs", "vbh_gmm_dim", "vbh_gmm_get_gconsts",
     "vbh_gmm_loglikes", "vbh_gmm_loglikes_pairs", "vbh_gmm_work",
     "vbh_graph_create", "vbh_graph_destroy", "vbh_decode_cfg_default", "vbh_decoder_create", "vbh_decoder_create_shared", "vbh_decoder_set_cfg",
-    "vbh_decoder_destroy", "vbh_decode_batch", "vbh_decode_batch_begin", "vbh_decode_batch_end", "vbh_decoder_result", "vbh_decoder_phase_cycles",
+    "vbh_decoder_destroy", "vbh_decode_batch", "vbh_decode_batch_begin", "vbh_decode_batch_end", "vbh_decoder_result", "vbh_decoder_phase_cycles", "vbh_decoder_diag",
     "vbh_decoder_times", "vbh_decoder_utt_timeline", "vbh_decoder_batch_stats",
     "vbh_faster_cfg_default", "vbh_faster_decoder_create", "vbh_faster_decoder_destroy", "vbh_faster_decode_batch",
     "vbh_faster_decoder_result",
@@ -144,6 +144,7 @@ def load():
         lib.vbh_decode_batch_end.argtypes = [C.c_void_p]
         lib.vbh_decoder_result.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Lattice)]
         lib.vbh_decoder_phase_cycles.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+        lib.vbh_decoder_diag.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
         lib.vbh_faster_decoder_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(FasterCfg), C.c_int32, C.c_int32,
                                                   C.POINTER(C.c_void_p)]
         lib.vbh_faster_decoder_destroy.argtypes = [C.c_void_p]

@@ -356,6 +356,11 @@ class LatticeDecoder:
         check(self.lib.vbh_decoder_phase_cycles(self.h, int(u), out), "vbh_decoder_phase_cycles")
         return list(out)
 
+    def diag(self, u):
+        out = (C.c_int64 * 16)()
+        check(self.lib.vbh_decoder_diag(self.h, int(u), out), "vbh_decoder_diag")
+        return list(out)
+
     def timeline(self, u):
         """(start, end) of the utterance's search in 100 MHz device ticks, and the workgroup that ran it"""
         out = (C.c_int64 * 3)()

@@ -85,7 +85,6 @@ constexpr int MAX_WIN_FRAMES = NT / 4;      // frames between two compactions (p
 constexpr int EPSBIT = (int)0x80000000;     // on an arc's next state / a token's state: that state has epsilon arcs
 constexpr int PLDST = 0x40000000;           // on a token's state: the token is the destination of an epsilon link of its frame
 constexpr int STMASK = 0x3FFFFFFF;
-constexpr int COST_CAP = 8 * NT;            // token costs of the current frame cached in LDS
 #ifndef VBH_U
 #define VBH_U 4
 #endif
@@ -102,10 +101,14 @@ constexpr int U = VBH_U;                    // independent items per lane in the
 constexpr int UM = VBH_UM;                  // ... in the compaction moves
 constexpr int UC = VBH_UC;                  // ... in the candidate passes (LDS-bound: more only costs registers)
 constexpr int UL = VBH_UL;                  // ... in the pruning sweeps over links
-constexpr int HBITS = NT >= 1024 ? 13 : (NT >= 512 ? 12 : 11);
-constexpr int HCAP = 1 << HBITS;            // slots of the per-frame state map in LDS (8 per thread)
-constexpr int HPROBE = 16;                  // probes before a state is sent to the table in HBM
+constexpr int HBITS = NT >= 1024 ? 14 : (NT >= 512 ? 12 : 11);
+constexpr int HCAP = 1 << HBITS;            // slots of the per-frame state map in LDS (16 per thread at 1024 threads)
+constexpr int HPROBE = 24;                  // probes before a state is sent to the table in HBM
 constexpr unsigned HEMPTY = 0xFFFFFFFFu;
+constexpr int SPT = HCAP / NT;              // slots a thread numbers in the slot scan
+constexpr int COST_CAP = 2 * HCAP;          // token costs of the current frame cached in LDS (the map's memory, idle at that time)
+constexpr int FCAP = NT >= 1024 ? 1024 : 512;   // entries of each epsilon work list kept in LDS
+static_assert(SPT >= 4 && SPT <= 32 && (SPT & (SPT - 1)) == 0, "slot scan: a 32-slot group is shared by 32 / SPT adjacent lanes");
 // VBH_LL_LDS: the frame's row of acoustic scores (P floats, fetched coalesced at the start of the frame) is kept in LDS, so
 // that the per-arc score lookup of pass 1 is an LDS read instead of a third dependent global access (token -> state -> arc
 // -> score); models of more than LLCAP pdfs read the row from global memory as before
@@ -113,7 +116,7 @@ constexpr unsigned HEMPTY = 0xFFFFFFFFu;
 #define VBH_LL_LDS 0           // measured (r02): 1 is 15 % slower at 1024 threads -- see DESIGN.md (register allocation of the frame loop)
 #endif
 constexpr int LLCAP = VBH_LL_LDS ? 2560 : 1;
-constexpr int DIRTY_FRAMES = VBH_LL_LDS ? (1 << 14) : (NT >= 1024 ? (1 << 16) : (1 << 15));   // frames covered by the dirty bitmap (2 KB of LDS); later frames count as dirty
+constexpr int DIRTY_FRAMES = 1 << 13;       // frames covered by the dirty bitmap (1 KB of LDS); later frames count as dirty
 
 // The pruning and compaction passes run once per pruning interval; as functions of their own they get their own register
 // allocation instead of competing with the per-frame passes for the kernel's 128 VGPRs (VBH_OUTLINE=0: inlined, as before)
@@ -193,7 +196,8 @@ struct UttResult {   // written by the kernel, one per utterance
   long long n_tokens_expanded, n_arcs_expanded, n_tokens_created, n_links_created;
   int n_max_bound, n_min_bound;
   long long cost_off;                // offset of this utterance's cost_offsets in the pool
-  long long t_phase[8];              // shader-clock cycles per phase (thread 0): cutoff, pass1, pass2+3, eps, prune, compact, final, other
+  long long t_phase[16];             // shader-clock cycles per phase (thread 0): cutoff, pass1, pass2+3, eps, prune, compact, final; [7] frames
+                                     // visited by pruning; [8..] only in -DVBH_DIAG builds (see vbh_decoder_diag)
   long long t_start, t_end;          // s_memrealtime (100 MHz) when the workgroup took the utterance / finished it
   int wg, pad2;
 };
@@ -355,22 +359,44 @@ struct Shared {
   // the block appended to H by the previous compaction (frames (tail_f0, tail_f1]); it is
   // re-compacted in place at the next one, once those frames have been pruned with look-ahead
   int tail_tok_b, tail_link_b, tail_f0, tail_f1;
-  long long tph[8];                // phase cycle counters (thread 0)
+  long long tph[12];               // phase cycle counters (thread 0)
+#ifdef VBH_DIAG
+  int diag[8];
+  long long fcl[8];                // cycles / frames by class of frame (tokens at its start: < 512, < 2048, < 6144, more)
+  long long hph[12];               // phase cycles of the frames of the last class alone
+#endif
   unsigned dirty[DIRTY_FRAMES / 32];   // see frame_dirty()
-  // state map of the frame being built (see map_relax)
-  unsigned hs[HCAP], hc[HCAP]; int ht[HCAP];
   int use_lds_map;
-  float cost[COST_CAP];            // costs of the current frame's tokens (GetCutoff)
+  int scan_part[NW], scan_base;    // slot scan: occupied slots per wave, first token index it hands out
   float ll[LLCAP];                 // the frame's acoustic scores (VBH_LL_LDS)
-  // compaction job: token frames and link segments in source order
-  int j_ntf, j_nseg, j_tf0, j_tdst, j_ldst;
-  int tbeg[MAX_WIN_FRAMES + 1], tbase[MAX_WIN_FRAMES], tcnt[MAX_WIN_FRAMES], tup[MAX_WIN_FRAMES];
-  int sbeg[2 * MAX_WIN_FRAMES + 1], sbase[2 * MAX_WIN_FRAMES], scnt[2 * MAX_WIN_FRAMES], sup[2 * MAX_WIN_FRAMES];
-  int sid[2 * MAX_WIN_FRAMES];     // frame << 1 | (1 = epsilon links)
+  int j_ntf, j_nseg, j_tf0, j_tdst, j_ldst;   // compaction job (its arrays: struct Job, in the arena)
+  int front_lds[3 * FCAP];         // the first FCAP entries of the three rotating epsilon work lists
+  // token index of a map slot: {occupancy of the group's 32 slots, index of the group's first token relative to the frame's first}
+  uint2 grp[HCAP / 32];
+  // The arena.  While a frame is built (pass 2 to the end of the frame): the state map, tags [0, HCAP) and cost keys
+  // [HCAP, 2 HCAP) (see map_relax).  In the cutoff phase: the frame's token costs (lds_cost).  During pruning: the link
+  // minima per token (prune_frame).  During compaction: FrameRec staging and the job arrays (struct Job).
+  unsigned arena[2 * HCAP];
 #ifdef VBH_LDS_CANARY
   unsigned canary_hi[4];
 #endif
 };
+
+// compaction job: token frames and link segments in source order (lives in the arena behind the FrameRec staging area)
+struct Job {
+  int tbeg[MAX_WIN_FRAMES + 1], tbase[MAX_WIN_FRAMES], tcnt[MAX_WIN_FRAMES], tup[MAX_WIN_FRAMES];
+  int sbeg[2 * MAX_WIN_FRAMES + 1], sbase[2 * MAX_WIN_FRAMES], scnt[2 * MAX_WIN_FRAMES], sup[2 * MAX_WIN_FRAMES];
+  int sid[2 * MAX_WIN_FRAMES];     // frame << 1 | (1 = epsilon links)
+};
+constexpr int JOB_OFF_WORDS = ((MAX_WIN_FRAMES + 2) * 12 + 63) & ~63;
+static_assert(JOB_OFF_WORDS * 4 + sizeof(Job) <= sizeof(unsigned) * 2 * HCAP, "FrameRec staging + job arrays must fit in the arena");
+__device__ __forceinline__ Job &job_of(Shared &sh) { return *reinterpret_cast<Job *>(sh.arena + JOB_OFF_WORDS); }
+__device__ __forceinline__ float *lds_cost(Shared &sh) { return reinterpret_cast<float *>(sh.arena); }
+__device__ __forceinline__ const float *lds_cost(const Shared &sh) { return reinterpret_cast<const float *>(sh.arena); }
+__device__ __forceinline__ unsigned *map_tag(Shared &sh) { return sh.arena; }
+__device__ __forceinline__ const unsigned *map_tag(const Shared &sh) { return sh.arena; }
+__device__ __forceinline__ unsigned *map_key(Shared &sh) { return sh.arena + HCAP; }
+__device__ __forceinline__ const unsigned *map_key(const Shared &sh) { return sh.arena + HCAP; }
 
 // block reductions with ONE barrier each: partials go to red[par], par flips on every call
 __device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v, Shared &sh, int &par) {
@@ -404,7 +430,7 @@ __device__ __forceinline__ float block_min_f(float v, Shared &sh, int &par) {
 
 // cost of token i of the current frame: LDS copy, or the record itself beyond the cache
 __device__ __forceinline__ float frame_cost(const Shared &sh, gp<const i32x4> tok, int i) {
-  return i < COST_CAP ? sh.cost[i] : asf(tok[i].y);
+  return i < COST_CAP ? lds_cost(sh)[i] : asf(tok[i].y);
 }
 
 // k-th smallest (0-based) of the current frame's costs: exact radix select on the
@@ -523,7 +549,7 @@ __device__ int prune_frame(const Slot &s, int f, float lattice_beam, float delta
   // sweeps) instead of the tokens' tmp fields: no global atomics to wait for, and the old
   // extra_costs are fetched while the links are in flight.
   const bool lds_tmp = te - tb <= COST_CAP;
-  unsigned *ltmp = reinterpret_cast<unsigned *>(sh.cost);
+  unsigned *ltmp = sh.arena;
   int result = 0;
   for (int iter = 0; iter < MAX_EPS_ITERS; iter++) {
     i32x4 R0[U];            // first round of the token pass, prefetched
@@ -616,7 +642,7 @@ __device__ VBH_COLD void prune_backward(const Slot &s, int from, int first_unpru
                                bool final, Shared &sh, int &pp) {
   int visited = 0;
   int above = 3;   // result of the frame above: the frontier counts as changed
-  for (int i = threadIdx.x; i < COST_CAP; i += NT) reinterpret_cast<unsigned *>(sh.cost)[i] = INF_BITS;   // see prune_frame
+  for (int i = threadIdx.x; i < COST_CAP; i += NT) sh.arena[i] = INF_BITS;   // see prune_frame
   __syncthreads();
   for (int f = from; f >= 0 && f >= stop_at; f--) {
     if (final) {
@@ -653,8 +679,9 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
   gp<const i32x4> src_tok = FROM_W ? wt : ht;
   gp<int> remap = FROM_W ? w_remap : h_remap;
   const int ntf = sh.j_ntf, nseg = sh.j_nseg;
+  Job &J = job_of(sh);
   if (ntf > 0) {
-    const int t0 = sh.tbeg[0], t1 = sh.tbeg[ntf];
+    const int t0 = J.tbeg[0], t1 = J.tbeg[ntf];
     for (int base = t0; base < t1; base += NT * UM) {
       i32x4 R[UM]; bool ok[UM];
 #pragma unroll
@@ -669,10 +696,10 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
         if (!ok[u]) continue;
         int nid = -1;
         if ((unsigned)R[u].z != INF_BITS) {
-          const int j = seg_find(sh.tbeg, ntf, t);
-          const int c = atomicAdd(&sh.tcnt[j], 1);
-          if (c < sh.tup[j]) {
-            nid = sh.tbase[j] + c;
+          const int j = seg_find(J.tbeg, ntf, t);
+          const int c = atomicAdd(&J.tcnt[j], 1);
+          if (c < J.tup[j]) {
+            nid = J.tbase[j] + c;
             i32x4 r = R[u]; r.w = (int)INF_BITS;
             ht[nid + stage_t] = r;
           } else sh.error = ERR_H_TOK;     // more survivors than the sweep counted: never expected
@@ -686,7 +713,7 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
     gp<const i32x4> src_lk = uptr(FROM_W ? s.wl : s.hl);
     gp<const i32x2> src_l2 = uptr(FROM_W ? s.wl2 : s.hl2);
     gp<i32x4> hl = uptr(s.hl); gp<i32x2> hl2 = uptr(s.hl2);
-    const int l0 = sh.sbeg[0], l1 = sh.sbeg[nseg];
+    const int l0 = J.sbeg[0], l1 = J.sbeg[nseg];
     for (int base = l0; base < l1; base += NT * UM) {
       i32x4 L[UM]; i32x2 A[UM]; bool ok[UM];
 #pragma unroll
@@ -715,10 +742,10 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
         const int ns = ((a & WBIT) || a >= remap_lo) ? vs[u] : ((unsigned)vs[u] != INF_BITS ? a : -1);
         const int nd = ((b & WBIT) || b >= remap_lo) ? vd[u] : ((unsigned)vd[u] != INF_BITS ? b : -1);
         if (ns < 0 || nd < 0) continue;
-        const int j = seg_find(sh.sbeg, nseg, l);
-        const int c = atomicAdd(&sh.scnt[j], 1);
-        if (c < sh.sup[j]) {
-          const int nid = sh.sbase[j] + c + stage_l;
+        const int j = seg_find(J.sbeg, nseg, l);
+        const int c = atomicAdd(&J.scnt[j], 1);
+        if (c < J.sup[j]) {
+          const int nid = J.sbase[j] + c + stage_l;
           i32x4 r = L[u]; r.x = ns; r.y = nd;
           hl[nid] = r; hl2[nid] = A[u];
         } else sh.error = ERR_H_LINK;
@@ -729,15 +756,15 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
   // slots the sweep counted but the move did not fill (an end point died without the link being
   // re-evaluated) become dead entries, so that every frame stays one contiguous range
   for (int j = tid; j < ntf; j += NT) {
-    const int c = sh.tcnt[j] < sh.tup[j] ? sh.tcnt[j] : sh.tup[j];
-    for (int i = sh.tbase[j] + c; i < sh.tbase[j] + sh.tup[j]; i++) {
+    const int c = J.tcnt[j] < J.tup[j] ? J.tcnt[j] : J.tup[j];
+    for (int i = J.tbase[j] + c; i < J.tbase[j] + J.tup[j]; i++) {
       i32x4 r; r.x = 0; r.y = 0; r.z = (int)INF_BITS; r.w = (int)INF_BITS;
       gptr(s.h_tok)[i + stage_t] = r;
     }
   }
   for (int j = tid; j < nseg; j += NT) {
-    const int c = sh.scnt[j] < sh.sup[j] ? sh.scnt[j] : sh.sup[j];
-    for (int i = sh.sbase[j] + c; i < sh.sbase[j] + sh.sup[j]; i++) {
+    const int c = J.scnt[j] < J.sup[j] ? J.scnt[j] : J.sup[j];
+    for (int i = J.sbase[j] + c; i < J.sbase[j] + J.sup[j]; i++) {
       i32x4 r; r.x = -1; r.y = 0; r.z = 0; r.w = 0;
       gptr(s.hl)[i + stage_l] = r;
     }
@@ -746,40 +773,42 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
 
 // job bookkeeping shared by the two compactions (thread 0)
 __device__ __forceinline__ void job_add_tok(Shared &sh, const FrameRec &r, int f) {
+  Job &J = job_of(sh);
   const int j = sh.j_ntf++;
   if (j == 0) sh.j_tf0 = f;
   const int n = r.tok_e - r.tok_b, up = r.a_tok < n ? r.a_tok : n;
-  sh.tbeg[j] = r.tok_b; sh.tbeg[j + 1] = r.tok_e; sh.tup[j] = up; sh.tbase[j] = sh.j_tdst; sh.tcnt[j] = 0;
+  J.tbeg[j] = r.tok_b; J.tbeg[j + 1] = r.tok_e; J.tup[j] = up; J.tbase[j] = sh.j_tdst; J.tcnt[j] = 0;
   sh.j_tdst += up;
 }
 __device__ __forceinline__ void job_add_seg(Shared &sh, int b, int e, int a, int id) {
+  Job &J = job_of(sh);
   const int j = sh.j_nseg++;
   const int n = e - b, up = a < n ? a : n;
-  sh.sbeg[j] = b; sh.sbeg[j + 1] = e; sh.sup[j] = up; sh.sbase[j] = sh.j_ldst; sh.scnt[j] = 0; sh.sid[j] = id;
+  J.sbeg[j] = b; J.sbeg[j + 1] = e; J.sup[j] = up; J.sbase[j] = sh.j_ldst; J.scnt[j] = 0; J.sid[j] = id;
   sh.j_ldst += up;
 }
 // the FrameRecs a job is built from, fetched by everybody into LDS (sh.cost is free between the
 // pruning pass and the next frame) instead of one dependent load after the other by thread 0
 __device__ __forceinline__ const FrameRec *job_stage_frames(const Slot &s, Shared &sh, int f0, int nf) {
-  static_assert(sizeof(float) * COST_CAP >= sizeof(FrameRec) * (MAX_WIN_FRAMES + 2), "FrameRec staging aliases sh.cost");
-  int *dst = reinterpret_cast<int *>(sh.cost);
+  int *dst = reinterpret_cast<int *>(sh.arena);
   gp<const int> src = (gp<const int>)(s.fr + f0);
   for (int i = threadIdx.x; i < nf * 12; i += NT) dst[i] = src[i];
   __syncthreads();
-  return reinterpret_cast<const FrameRec *>(sh.cost);
+  return reinterpret_cast<const FrameRec *>(sh.arena);
 }
 // new positions -> FrameRecs (after compact_move; one thread per frame / segment)
 __device__ __forceinline__ void job_publish(const Slot &s, Shared &sh) {
   const int tid = threadIdx.x;
+  Job &J = job_of(sh);
   for (int j = tid; j < sh.j_ntf; j += NT) {
     gp<int> r = (gp<int>)(s.fr + (sh.j_tf0 + j));
-    r[0] = sh.tbase[j]; r[1] = sh.tbase[j] + sh.tup[j]; r[8] = sh.tcnt[j] < sh.tup[j] ? sh.tcnt[j] : sh.tup[j];
+    r[0] = J.tbase[j]; r[1] = J.tbase[j] + J.tup[j]; r[8] = J.tcnt[j] < J.tup[j] ? J.tcnt[j] : J.tup[j];
   }
   for (int j = tid; j < sh.j_nseg; j += NT) {
-    gp<int> r = (gp<int>)(s.fr + (sh.sid[j] >> 1));
-    const int c = sh.scnt[j] < sh.sup[j] ? sh.scnt[j] : sh.sup[j];
-    if (sh.sid[j] & 1) { r[4] = sh.sbase[j]; r[5] = sh.sbase[j] + sh.sup[j]; r[10] = c; }
-    else { r[2] = sh.sbase[j]; r[3] = sh.sbase[j] + sh.sup[j]; r[9] = c; }
+    gp<int> r = (gp<int>)(s.fr + (J.sid[j] >> 1));
+    const int c = J.scnt[j] < J.sup[j] ? J.scnt[j] : J.sup[j];
+    if (J.sid[j] & 1) { r[4] = J.sbase[j]; r[5] = J.sbase[j] + J.sup[j]; r[10] = c; }
+    else { r[2] = J.sbase[j]; r[3] = J.sbase[j] + J.sup[j]; r[9] = c; }
   }
 }
 static_assert(sizeof(FrameRec) == 48, "FrameRec is addressed as 12 ints / 3 vectors");
@@ -887,44 +916,51 @@ __device__ VBH_COLD bool compact_window(const Slot &s, int prev_front, int front
 // ---------------------------------------------------------------------------------------
 // State map of the frame being built: state -> (best cost so far, token).  This is the
 // reference's per-frame hash (FindOrAddToken, :259-295).  First level: open addressing in LDS,
-// state tags claimed with atomicCAS, costs lowered with atomicMin on the order-preserving key,
-// cleared once per frame.  A state whose HPROBE probe slots are all taken by other states goes to
-// the second level, ent[] in HBM (epoch-stamped keys, never cleared); slots are never freed within
-// a frame, so a state always resolves to the same level.  Keeping the first level on chip removes
-// what used to be most of the kernel's HBM traffic: every state touched cost a 128-byte line
-// fetched and written back for 12 useful bytes.
+// tags (state | EPSBIT when the state has epsilon arcs) claimed with atomicCAS, costs lowered with
+// atomicMin on the order-preserving key.  A state whose HPROBE probe slots are all taken by other
+// states goes to the second level, ent[] in HBM (epoch-stamped keys, never cleared); slots are
+// never freed within a frame, so a state always resolves to the same level.
+// First-level states get their tokens when the frame is complete (slot_scan): token index =
+// frame's first + number of occupied slots before the state's slot, kept per 32-slot group in
+// sh.grp, so the map holds 8 bytes per state (16384 states at 1024 threads) and a token's record is
+// written once, with its final cost.  Second-level states get a token when they are first reached
+// (its index goes to ent[].tokid).
 __device__ __forceinline__ unsigned map_hash(int st) { return ((unsigned)st * 2654435761u) >> (32 - HBITS); }
 __device__ __forceinline__ int map_find(const Shared &sh, int st) {     // slot, or -1: second level
   if (!sh.use_lds_map) return -1;
+  const unsigned *tag = map_tag(sh);
   unsigned h = map_hash(st);
 #pragma unroll 1
   for (int p = 0; p < HPROBE; p++, h = (h + 1) & (HCAP - 1)) {
-    const unsigned cur = sh.hs[h];
-    if (cur == (unsigned)st) return (int)h;
+    const unsigned cur = tag[h];
+    if ((cur & STMASK) == (unsigned)st) return (int)h;      // (an empty slot's low bits are no state id)
     if (cur == HEMPTY) return -1;
   }
   return -1;
 }
-// lower the cost of state ds to tot.  slot: first-level slot or -1; create: this thread is the
-// first to reach ds in this frame (it makes the token); improved: the cost went down.
-__device__ __forceinline__ void map_relax(Shared &sh, gp<Ent> ent, int ds, float tot, unsigned ep, int &slot, bool &create,
+// lower the cost of the state dsraw & STMASK to tot (dsraw: the arc's next-state field, EPSBIT included).  slot: first-level
+// slot or -1; create: this thread is the first to reach the state in this frame; improved: the cost went down.
+__device__ __forceinline__ void map_relax(Shared &sh, gp<Ent> ent, int dsraw, float tot, unsigned ep, int &slot, bool &create,
                                           bool &improved) {
   const unsigned ck = f2o(tot);
+  const int ds = dsraw & STMASK;
   slot = -1; create = false;
   if (sh.use_lds_map) {
+    unsigned *tag = map_tag(sh);
+    const unsigned want = (unsigned)(dsraw & ~PLDST);
     unsigned h = map_hash(ds);
 #pragma unroll 1
     for (int p = 0; p < HPROBE; p++, h = (h + 1) & (HCAP - 1)) {
-      unsigned cur = sh.hs[h];
+      unsigned cur = tag[h];
       if (cur == HEMPTY) {
-        cur = atomicCAS(&sh.hs[h], HEMPTY, (unsigned)ds);
+        cur = atomicCAS(&tag[h], HEMPTY, want);
         if (cur == HEMPTY) { create = true; slot = (int)h; break; }
       }
-      if (cur == (unsigned)ds) { slot = (int)h; break; }
+      if ((cur & STMASK) == (unsigned)ds) { slot = (int)h; break; }
     }
   }
   if (slot >= 0) {
-    const unsigned oc = atomicMin(&sh.hc[slot], ck);
+    const unsigned oc = atomicMin(&map_key(sh)[slot], ck);
     improved = ck < oc;
   } else {
     const unsigned long long nk = ((unsigned long long)ep << 32) | ck;
@@ -934,40 +970,46 @@ __device__ __forceinline__ void map_relax(Shared &sh, gp<Ent> ent, int ds, float
   }
 }
 __device__ __forceinline__ float map_cost(const Shared &sh, gp<const Ent> ent, int slot, int st) {
-  return slot >= 0 ? o2f(sh.hc[slot]) : o2f((unsigned)ld_u64(&ent[st].key));
+  return slot >= 0 ? o2f(map_key(sh)[slot]) : o2f((unsigned)ld_u64(&ent[st].key));
 }
-__device__ __forceinline__ void map_set_tok(Shared &sh, gp<Ent> ent, int slot, int st, int nid, int nb) {
-  if (slot >= 0) sh.ht[slot] = nid; else st_i32(&ent[st].tokid, nid);
-}
+// token of a state, frame-relative for first-level states (valid after slot_scan), absolute window index for second-level ones
 __device__ __forceinline__ int map_tok(const Shared &sh, gp<const Ent> ent, int slot, int st, int nb) {
-  return slot >= 0 ? sh.ht[slot] : ld_i32(&ent[st].tokid);
+  if (slot < 0) return ld_i32(&ent[st].tokid);
+  const uint2 gq = sh.grp[slot >> 5];
+  return nb + (int)gq.y + __popc(gq.x & ((1u << (slot & 31)) - 1u));
 }
 // Epsilon work lists (state ids).  The first FCAP entries of each of the three rotating lists
-// live in LDS -- in sh.cost, which is idle between pass 1 and the next frame's cutoff -- so a
-// closure iteration reads and refills its list without a round trip to HBM; longer lists
-// continue in the slot's HBM arrays.
-constexpr int FCAP = (COST_CAP / 3) & ~63;
+// live in LDS, so a closure iteration reads and refills its list without a round trip to HBM;
+// longer lists continue in the slot's HBM arrays.
 __device__ __forceinline__ void front_push(Shared &sh, gp<int> glob, int glob_cap, int k, int q, int st) {
-  if (q < FCAP) reinterpret_cast<int *>(sh.cost)[k * FCAP + q] = st;
+  if (q < FCAP) sh.front_lds[k * FCAP + q] = st;
   else if (q - FCAP < glob_cap) glob[q - FCAP] = st;
   else sh.error = ERR_FRONT;
 }
 __device__ __forceinline__ int front_get(const Shared &sh, gp<const int> glob, int k, int i) {
-  return i < FCAP ? reinterpret_cast<const int *>(sh.cost)[k * FCAP + i] : glob[i - FCAP];
+  return i < FCAP ? sh.front_lds[k * FCAP + i] : glob[i - FCAP];
 }
 __device__ __forceinline__ void map_clear(Shared &sh) {
-  for (int i = threadIdx.x; i < HCAP; i += NT) { sh.hs[i] = HEMPTY; sh.hc[i] = 0xFFFFFFFFu; }
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 *a = reinterpret_cast<u32x4 *>(sh.arena);
+  const u32x4 e = {HEMPTY, HEMPTY, HEMPTY, HEMPTY};        // (an empty tag; as a cost key: larger than any cost)
+  for (int i = threadIdx.x; i < 2 * HCAP / 4; i += NT) a[i] = e;
 }
 
 // ---------------------------------------------------------------------------------------
-// ProcessNonemitting (lattice-faster-decoder.cc:796-858) for the tokens of frame fpo, which
-// occupy window indices [nb, sh.w_ntok).  Work lists hold STATE ids: list `cur` (count
-// sh.fcnt[cur]) was filled by the caller with the new states that have input-epsilon arcs.
-// Iterates until no cost changes, then stores the final costs and writes the epsilon links.
-// Returns the first link index of the frame's epsilon links; on return a barrier has made all
-// writes visible.
+// The second half of a frame: ProcessNonemitting (lattice-faster-decoder.cc:796-858) for the tokens of frame fpo, then
+// the tokens themselves.  On entry the map holds the states the emitting arcs reached (first level: tag + cost; second level:
+// token records [nb, sh.w_ntok) already written by whoever reached them first), work list `cur` (count sh.fcnt[cur]) the
+// new states that have input-epsilon arcs, and the emitting links [el_b, el_e) carry a provisional destination (map slot, or
+// -1 - state for second-level states).
+//   1. closure: iterate over the work lists until no cost changes (arcs through wave_expand);
+//   2. slot scan: first-level states are numbered in slot order behind the second-level tokens and their records written
+//      with the final cost; second-level tokens get their final cost;
+//   3. emitting links get their destination token; the epsilon links are regenerated from the final costs (:824-845) and
+//      the tokens they point to tagged (PLDST).
+// Returns the first link index of the frame's epsilon links; on return a barrier has made all writes visible.
 __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, int nb, float cutoff, unsigned ep,
-                                   int cur, Shared &sh) {
+                                   int cur, Shared &sh, int el_b, int el_e) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   gp<Ent> ent = uptr(s.ent);
   gp<i32x4> wt = uptr(s.w_tok);
@@ -1001,16 +1043,17 @@ __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, in
           if (tot < cutoff) {
             dsraw = arc.x; ds = dsraw & STMASK;
             bool improved;
-            map_relax(sh, ent, ds, tot, ep, slot, create, improved);
+            map_relax(sh, ent, dsraw, tot, ep, slot, create, improved);
             push = (create || improved) && dsraw < 0;      // new or improved, and it has epsilon arcs: (re-)expand
           }
         }
-        const int nid = wave_alloc(&sh.w_ntok, create);
-        if (create) {
+        const bool mk = create && slot < 0;                 // second-level state: it gets its token now
+        const int nid = wave_alloc(&sh.w_ntok, mk);
+        if (mk) {
           if (nid < w_tok_cap) {
-            i32x4 r; r.x = dsraw & ~PLDST; r.y = 0; r.z = slot; r.w = (int)INF_BITS;
+            i32x4 r; r.x = dsraw & ~PLDST; r.y = 0; r.z = 0; r.w = (int)INF_BITS;
             wt[nid] = r;
-            map_set_tok(sh, ent, slot, ds, nid, nb);
+            st_i32(&ent[ds].tokid, nid);
           } else sh.error = ERR_W_TOK;
         }
         const int q = wave_alloc(fcnt_next, push);
@@ -1022,51 +1065,124 @@ __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, in
     cur = nxt;
   }
   __syncthreads();
-  // final costs of the frame's tokens + epsilon links regenerated from them (:824-845); until now
-  // a token's extra_cost field held its slot in the state map
-  const int ne = sh.w_ntok < w_tok_cap ? sh.w_ntok : w_tok_cap;
-  const int lb = sh.w_nlink;
-  __syncthreads();
+  // ---- slot scan: thread t numbers the occupied ones of slots [t SPT, (t+1) SPT)
+  const int n2 = sh.w_ntok < w_tok_cap ? sh.w_ntok : w_tok_cap;      // second-level tokens: [nb, n2)
+  unsigned occ = 0;
+  unsigned tg[SPT];
   {
-    gp<i32x4> wl = uptr(s.wl); gp<i32x2> wl2 = uptr(s.wl2);
-    const int w_link_cap = s.w_link_cap;
-    const int n_new = ne - nb;
-    const int CH = wave_chunk(n_new);
-    for (int base = wave * CH; base < n_new; base += NW * CH) {
-      const int t = nb + base + lane;
-      const bool have = lane < CH && base + lane < n_new;
-      i32x4 rec; rec.x = 0; rec.y = 0; rec.z = -1; rec.w = 0;
+    const unsigned *tag = map_tag(sh);
+#pragma unroll
+    for (int j = 0; j < SPT; j++) { tg[j] = sh.use_lds_map ? tag[tid * SPT + j] : HEMPTY; occ |= (unsigned)(tg[j] != HEMPTY) << j; }
+  }
+  const int mine = __popc(occ);
+  const int incl = wave_incl_scan(mine);
+  if (lane == 63) sh.scan_part[wave] = incl;
+  if (tid == 0) { sh.scan_base = n2; sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0; }
+  __syncthreads();
+  int first = sh.scan_base - nb + incl - mine, total = 0;     // frame-relative index of this thread's first token
+#pragma unroll
+  for (int i = 0; i < NW; i++) { const int v = sh.scan_part[i]; total += v; if (i < wave) first += v; }
+  const int ne_all = sh.scan_base + total;
+  if (ne_all > w_tok_cap) { if (tid == 0) sh.error = ERR_W_TOK; }
+  else {
+    // group words: the lanes that share a 32-slot group combine their occupancy bits; the group's first lane knows its base
+    {
+      constexpr int LPG = 32 / SPT;                      // lanes per group
+      unsigned m = occ << ((lane % LPG) * SPT);
+#pragma unroll
+      for (int o = 1; o < LPG; o <<= 1) m |= __shfl_xor(m, o, 64);
+      const int gfirst = __shfl(first, lane & ~(LPG - 1), 64);
+      if ((lane % LPG) == 0) { uint2 gq; gq.x = m; gq.y = (unsigned)gfirst; sh.grp[(tid * SPT) >> 5] = gq; }
+    }
+    // token records of the first-level states, final cost included; those with epsilon arcs and a cost within the cutoff go
+    // on work list 0 (as slots) for the regeneration of the epsilon links
+    const unsigned *key = map_key(sh);
+    int k = nb + first;
+#pragma unroll
+    for (int j = 0; j < SPT; j++) {
+      bool want = false;
+      if ((occ >> j) & 1u) {
+        const float c = o2f(key[tid * SPT + j]);
+        i32x4 r; r.x = (int)tg[j]; r.y = asi(c); r.z = 0; r.w = (int)INF_BITS;
+        wt[k++] = r;
+        want = (int)tg[j] < 0 && !(c > cutoff);
+      }
+      if (__ballot(want)) {       // (uniform per wave)
+        const int q = wave_alloc(&sh.fcnt[0], want);
+        if (want) front_push(sh, uptr(s.front[0]), front_cap, 0, q, tid * SPT + j);
+      }
+    }
+    // second-level tokens: final cost; the ones to expand go on work list 1 (as token indices)
+    for (int t0 = nb + wave * 64; t0 < n2; t0 += NT) {
+      const int t = t0 + lane;
+      const bool have = t < n2;
+      i32x4 rec; rec.x = 0; rec.y = 0; rec.z = 0; rec.w = 0;
       if (have) rec = wt[t];
-      const int sx = rec.x;
-      const int st = sx & STMASK;
-      const float c = have ? map_cost(sh, ent, rec.z, st) : 0.0f;
+      const float c = have ? o2f((unsigned)ld_u64(&ent[rec.x & STMASK].key)) : 0.0f;
       if (have) { gp<int> q = (gp<int>)&wt[t]; q[1] = asi(c); q[2] = 0; }
-      const bool exp = have && sx < 0 && !(c > cutoff);
-      int a0 = 0, cnt = 0;
-      if (exp) { const i32x4 sr = g.st[st]; a0 = sr.x; cnt = sr.y; }
-      wave_expand(cnt, [&](bool valid, int owner, int j) {
-        const int a = __shfl(a0, owner, 64) + j;
-        const float cc = __shfl(c, owner, 64);
-        bool mk = false; int dtok = 0; i32x4 arc; float tot = 0.0f;
-        if (valid) {
-          arc = g.arcs[a];
-          tot = cc + asf(arc.y);
-          if (tot < cutoff) {
-            mk = true;
-            const int ds = arc.x & STMASK;
-            dtok = map_tok(sh, ent, map_find(sh, ds), ds, nb);
+      const bool want = have && rec.x < 0 && !(c > cutoff);
+      const int q = wave_alloc(&sh.fcnt[1], want);
+      if (want) front_push(sh, uptr(s.front[1]), front_cap, 1, q, t);
+    }
+  }
+  if (tid == 0) sh.w_ntok = ne_all < w_tok_cap ? ne_all : w_tok_cap;
+  __syncthreads();
+  const int lb = sh.w_nlink;
+  if (sh.error != ERR_NONE) return lb;
+  __syncthreads();        // (everybody has read w_nlink before the links below move it)
+  gp<i32x4> wl = uptr(s.wl); gp<i32x2> wl2 = uptr(s.wl2);
+  // ---- the emitting links' destinations
+  for (int l = el_b + tid; l < el_e; l += NT) {
+    gp<int> py = (gp<int>)&wl[l] + 1;
+    const int y = *py;
+    const int d = y >= 0 ? map_tok(sh, ent, y, 0, nb) : ld_i32(&ent[-1 - y].tokid);
+    *py = d | WBIT;
+  }
+  // ---- epsilon links regenerated from the final costs; what they point to is tagged
+  {
+    const int w_link_cap = s.w_link_cap;
+    const unsigned *tag = map_tag(sh);
+    const unsigned *key = map_key(sh);
+    for (int pass = 0; pass < 2; pass++) {
+      const int n_list = sh.fcnt[pass] < FCAP + front_cap ? sh.fcnt[pass] : FCAP + front_cap;
+      gp<const int> fl = uptr(s.front[pass]);
+      const int CH = wave_chunk(n_list);
+      for (int base = wave * CH; base < n_list; base += NW * CH) {
+        const int i = base + lane;
+        const bool have = lane < CH && i < n_list;
+        const int e = have ? front_get(sh, fl, pass, i) : 0;
+        int st = 0, src = 0; float c = 0.0f;
+        if (have) {
+          if (pass == 0) { st = (int)(tag[e] & STMASK); c = o2f(key[e]); src = map_tok(sh, ent, e, 0, nb); }
+          else { const i32x4 rec = wt[e]; st = rec.x & STMASK; c = asf(rec.y); src = e; }
+        }
+        int a0 = 0, cnt = 0;
+        if (have) { const i32x4 sr = g.st[st]; a0 = sr.x; cnt = sr.y; }
+        wave_expand(cnt, [&](bool valid, int owner, int j) {
+          const int a = __shfl(a0, owner, 64) + j;
+          const float cc = __shfl(c, owner, 64);
+          const int so = __shfl(src, owner, 64);
+          bool mk = false; int dtok = 0; i32x4 arc; float tot = 0.0f;
+          if (valid) {
+            arc = g.arcs[a];
+            tot = cc + asf(arc.y);
+            if (tot < cutoff) {
+              mk = true;
+              const int ds = arc.x & STMASK;
+              dtok = map_tok(sh, ent, map_find(sh, ds), ds, nb);
+            }
           }
-        }
-        const int l = wave_alloc(&sh.w_nlink, mk);
-        if (mk) {
-          if (l < w_link_cap) {
-            i32x4 r; r.x = (nb + base + owner) | WBIT; r.y = dtok | WBIT; r.z = asi(tot); r.w = a;
-            i32x2 r2; r2.x = arc.y; r2.y = 0;
-            wl[l] = r; wl2[l] = r2;
-            (void)__hip_atomic_fetch_or((gp<int>)&wt[dtok], PLDST, __ATOMIC_RELAXED, VBH_RMW_SCOPE);
-          } else sh.error = ERR_W_LINK;
-        }
-      });
+          const int l = wave_alloc(&sh.w_nlink, mk);
+          if (mk) {
+            if (l < w_link_cap) {
+              i32x4 r; r.x = so | WBIT; r.y = dtok | WBIT; r.z = asi(tot); r.w = a;
+              i32x2 r2; r2.x = arc.y; r2.y = 0;
+              wl[l] = r; wl2[l] = r2;
+              (void)__hip_atomic_fetch_or((gp<int>)&wt[dtok], PLDST, __ATOMIC_RELAXED, VBH_RMW_SCOPE);
+            } else sh.error = ERR_W_LINK;
+          }
+        });
+      }
     }
   }
   __syncthreads();
@@ -1160,9 +1276,23 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
     long long c_tok_exp = 0, c_arc_exp = 0;        // per-thread counters, reduced at the end
     long long t_last = clk();
     const long long rt_start = (long long)__builtin_amdgcn_s_memrealtime();
+#ifdef VBH_DIAG
+    int f_heavy = 0;
+#define PHASE(i) { if (tid == 0) { const long long now_ = clk(); sh.tph[i] += now_ - t_last; if (f_heavy) sh.hph[i] += now_ - t_last; t_last = now_; } }
+#else
 #define PHASE(i) { if (tid == 0) { const long long now_ = clk(); sh.tph[i] += now_ - t_last; t_last = now_; } }
+#endif
+#ifdef VBH_DIAG
+#define PHASE_D(i) PHASE(i)
+#define DIAG_ADD(i, pred) { const int c_ = __popcll(__ballot(pred)); if (lane == 0 && c_) atomicAdd(&sh.diag[i], c_); }
+    if (tid < 8) { sh.diag[tid] = 0; sh.fcl[tid] = 0; }
+    if (tid < 12) sh.hph[tid] = 0;
+#else
+#define PHASE_D(i)
+#define DIAG_ADD(i, pred)
+#endif
     if (tid == 0) {
-      for (int i = 0; i < 8; i++) sh.tph[i] = 0;
+      for (int i = 0; i < 12; i++) sh.tph[i] = 0;
       sh.w_ntok = 0; sh.w_nlink = 0; sh.h_ntok = 0; sh.h_nlink = 0; sh.error = ERR_NONE;
       sh.n_max_bound = 0; sh.n_min_bound = 0; sh.n_cand = 0; sh.n_visited = 0;
       sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0;
@@ -1184,16 +1314,19 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       if (tid == 0) {
         const i32x4 sr = g.st[g.start];
         int slot; bool create, improved;
-        map_relax(sh, gptr(s.ent), g.start, 0.0f, ep, slot, create, improved);
-        map_set_tok(sh, gptr(s.ent), slot, g.start, 0, 0);
-        i32x4 r; r.x = g.start | (sr.y > 0 ? EPSBIT : 0); r.y = 0; r.z = slot; r.w = (int)INF_BITS;
-        gptr(s.w_tok)[0] = r;
-        sh.w_ntok = 1;
+        const int sraw = g.start | (sr.y > 0 ? EPSBIT : 0);
+        map_relax(sh, gptr(s.ent), sraw, 0.0f, ep, slot, create, improved);
+        if (slot < 0) {        // second-level state: its token is made here (first-level ones by the slot scan)
+          i32x4 r; r.x = sraw; r.y = 0; r.z = 0; r.w = (int)INF_BITS;
+          gptr(s.w_tok)[0] = r;
+          st_i32(&gptr(s.ent)[g.start].tokid, 0);
+          sh.w_ntok = 1;
+        }
         if (sr.y > 0) { front_push(sh, gptr(s.front[0]), s.front_cap, 0, 0, g.start); sh.fcnt[0] = 1; }
       }
       __threadfence_block();
       __syncthreads();
-      const int plb = process_nonemitting(g, s, 0, cfg.beam, ep, 0, sh);
+      const int plb = process_nonemitting(g, s, 0, cfg.beam, ep, 0, sh, 0, 0);
       cur_b = 0; cur_e = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap;
       if (tid == 0) {
         FrameRec r;
@@ -1211,6 +1344,13 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
     int frames_done = 0;
     PHASE(6)
     for (int frame = 0; frame < T && sh.error == ERR_NONE; frame++) {
+#ifdef VBH_DIAG
+      const long long f_t0 = clk(); const int f_n0 = cur_e - cur_b;
+#ifndef VBH_DIAG_CLASS
+#define VBH_DIAG_CLASS 3
+#endif
+      f_heavy = (f_n0 < 512 ? 0 : f_n0 < 2048 ? 1 : f_n0 < 6144 ? 2 : 3) == VBH_DIAG_CLASS;
+#endif
 #ifdef VBH_LDS_CANARY
       if (tid == 0) {
         bool bad = false;
@@ -1248,7 +1388,6 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       // ---- GetCutoff (:618-685); the costs go to LDS on the way.  The state map is emptied for the
       //      frame about to be built (its last readers finished before the barrier that ended the
       //      previous frame; its next writers come after this phase's reduction barriers)
-      map_clear(sh);
       const bool ll_lds = VBH_LL_LDS && P <= LLCAP;
       float llr[(LLCAP + NT - 1) / NT];
       if (ll_lds) {
@@ -1258,7 +1397,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       unsigned long long bk = ~0ull;
       for (int i = tid; i < n; i += NT) {
         const i32x4 r = tok[i];
-        if (i < COST_CAP) sh.cost[i] = asf(r.y);
+        if (i < COST_CAP) lds_cost(sh)[i] = asf(r.y);
         const unsigned long long k = ((unsigned long long)f2o(asf(r.y)) << 32) | (unsigned)(r.x & STMASK);
         bk = k < bk ? k : bk;
       }
@@ -1267,6 +1406,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         for (int u = 0; u < (LLCAP + NT - 1) / NT; u++) { const int i = u * NT + tid; if (i < P) sh.ll[i] = llr[u]; }
       }
       bk = block_min_u64(bk, sh, par);
+      PHASE_D(9)
       const float best = n > 0 ? o2f((unsigned)(bk >> 32)) : INF;
       const int best_state = (int)(unsigned)bk;
       float cur_cutoff, adaptive_beam;
@@ -1319,6 +1459,9 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         if (lane == 0) { sh.f0 = nc; ((gp<float>)(s.fr + frame))[7] = cost_offset; }
       }
       PHASE(0)
+      // ---- the state map is emptied for the frame about to be built (the costs the cutoff phase kept in its memory were last
+      //      read before that phase's last reduction barrier; the map's first writers come after pass 1's reduction barrier)
+      map_clear(sh);
       // ---- pass 1 (arc-parallel): every candidate arc -> scratch list; min of tot + adaptive_beam
       float mymin = INF;
       {
@@ -1359,13 +1502,17 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       const int ncand = sh.n_cand < cand_cap ? sh.n_cand : cand_cap;
       const int nb = sh.w_ntok;     // first token of frame+1
       PHASE(1)
-      // ---- pass 2 (candidate-parallel): admit tot <= next_cutoff; min-cost per state via one
-      //      64-bit atomicMin; the thread that meets a stale epoch creates the token
+      // ---- pass 2 (candidate-parallel): admit tot <= next_cutoff: the state's cost in the map is lowered (the thread whose
+      //      compare-and-swap claims a first-level slot, or that meets a stale epoch in the second level, is the first to reach
+      //      the state), and the forward link (:765-767) is written with a provisional destination -- map slot, or -1 - state
+      //      for a second-level state -- that process_nonemitting replaces by the token once tokens are numbered
+      const int lb = sh.w_nlink;
       {
         gp<Ent> ent = uptr(s.ent);
         gp<i32x4> wt = uptr(s.w_tok);
         gp<int> front0 = uptr(s.front[0]);
-        const int w_tok_cap = s.w_tok_cap, front_cap = s.front_cap;
+        gp<i32x4> wl = uptr(s.wl); gp<i32x2> wl2 = uptr(s.wl2);
+        const int w_tok_cap = s.w_tok_cap, front_cap = s.front_cap, w_link_cap = s.w_link_cap;
         for (int base = 0; base < ncand; base += NT * UC) {
           i32x4 CA[UC]; i32x2 CB[UC]; bool adm[UC];
 #pragma unroll
@@ -1375,75 +1522,51 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
             CA[u] = cand[ok ? q : 0]; CB[u] = cand2[ok ? q : 0];
             adm[u] = ok && !(asf(CA[u].x) > next_cutoff);
           }
-          int slot[UC]; bool create[UC]; int nid[UC];
+          int slot[UC]; bool create[UC], mk2[UC]; int nid[UC];
 #pragma unroll
           for (int u = 0; u < UC; u++) {
             bool improved;
             slot[u] = -1; create[u] = false;
-            if (adm[u]) map_relax(sh, ent, CB[u].x & STMASK, asf(CA[u].x), ep, slot[u], create[u], improved);
+            if (adm[u]) map_relax(sh, ent, CB[u].x, asf(CA[u].x), ep, slot[u], create[u], improved);
+            mk2[u] = create[u] && slot[u] < 0;
+            DIAG_ADD(0, adm[u] && slot[u] < 0)
+            DIAG_ADD(1, adm[u])
           }
-          wave_alloc_n<UC>(&sh.w_ntok, create, nid);
-          bool pushf[UC]; int fq[UC];
+          wave_alloc_n<UC>(&sh.w_ntok, mk2, nid);
+          bool pushf[UC]; int fq[UC], lq[UC];
 #pragma unroll
           for (int u = 0; u < UC; u++) {
-            pushf[u] = false;
-            if (create[u]) {
-              const int ds = CB[u].x & STMASK;
+            pushf[u] = create[u] && CB[u].x < 0;
+            if (mk2[u]) {       // second-level state: its token is made now
               if (nid[u] < w_tok_cap) {
-                i32x4 r; r.x = CB[u].x; r.y = 0; r.z = slot[u]; r.w = (int)INF_BITS;
+                i32x4 r; r.x = CB[u].x & ~PLDST; r.y = 0; r.z = 0; r.w = (int)INF_BITS;
                 wt[nid[u]] = r;
-                map_set_tok(sh, ent, slot[u], ds, nid[u], nb);
-                pushf[u] = CB[u].x < 0;
-              } else sh.error = ERR_W_TOK;
+                st_i32(&ent[CB[u].x & STMASK].tokid, nid[u]);
+              } else { sh.error = ERR_W_TOK; pushf[u] = false; }
             }
           }
           wave_alloc_n<UC>(&sh.fcnt[0], pushf, fq);
-#pragma unroll
-          for (int u = 0; u < UC; u++) if (pushf[u]) front_push(sh, front0, front_cap, 0, fq[u], CB[u].x & STMASK);
-        }
-      }
-      __syncthreads();
-      // ---- pass 3 (candidate-parallel): forward links (:765-767)
-      const int lb = sh.w_nlink;
-      if (sh.error == ERR_NONE) {
-        gp<const Ent> ent = uptr(s.ent);
-        gp<i32x4> wl = uptr(s.wl); gp<i32x2> wl2 = uptr(s.wl2);
-        const int w_link_cap = s.w_link_cap;
-        for (int base = 0; base < ncand; base += NT * UC) {
-          i32x4 CA[UC]; i32x2 CB[UC]; bool adm[UC]; int dtok[UC];
-#pragma unroll
-          for (int u = 0; u < UC; u++) {
-            const int q = base + u * NT + tid;
-            const bool ok = q < ncand;
-            CA[u] = cand[ok ? q : 0]; CB[u] = cand2[ok ? q : 0];
-            adm[u] = ok && !(asf(CA[u].x) > next_cutoff);
-          }
-#pragma unroll
-          for (int u = 0; u < UC; u++) {
-            const int ds = CB[u].x & STMASK;
-            dtok[u] = adm[u] ? map_tok(sh, ent, map_find(sh, ds), ds, nb) : 0;
-          }
-          int lq[UC];
           wave_alloc_n<UC>(&sh.w_nlink, adm, lq);
 #pragma unroll
           for (int u = 0; u < UC; u++) {
-            const int l = lq[u];
+            if (pushf[u]) front_push(sh, front0, front_cap, 0, fq[u], CB[u].x & STMASK);
             if (adm[u]) {
-              if (l < w_link_cap) {
-                i32x4 r; r.x = (tb + CA[u].w) | enc; r.y = dtok[u] | WBIT; r.z = CA[u].x; r.w = CA[u].z;
+              if (lq[u] < w_link_cap) {
+                i32x4 r; r.x = (tb + CA[u].w) | enc; r.y = slot[u] >= 0 ? slot[u] : -1 - (CB[u].x & STMASK); r.z = CA[u].x; r.w = CA[u].z;
                 i32x2 r2; r2.x = CB[u].y; r2.y = CA[u].y;
-                wl[l] = r; wl2[l] = r2;
+                wl[lq[u]] = r; wl2[lq[u]] = r2;
               } else sh.error = ERR_W_LINK;
             }
           }
         }
       }
       __syncthreads();
+      PHASE_D(8)
       const int le_emit = sh.w_nlink < s.w_link_cap ? sh.w_nlink : s.w_link_cap;
       if (sh.error != ERR_NONE) break;
       PHASE(2)
       // ---- ProcessNonemitting(next_cutoff)
-      const int plb = process_nonemitting(g, s, nb, next_cutoff, ep, 0, sh);
+      const int plb = process_nonemitting(g, s, nb, next_cutoff, ep, 0, sh, lb, le_emit);
       cur_b = nb; cur_e = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap; cur_w = true;
       const int pl_end = sh.w_nlink < s.w_link_cap ? sh.w_nlink : s.w_link_cap;
       if (tid == 0) {
@@ -1455,6 +1578,14 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         st_frame(s.fr + (frame + 1), r);
         sh.n_cand = 0; sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0;
       }
+#ifdef VBH_DIAG
+      if (tid == 0) {
+        if (cur_e - cur_b > (HCAP * 3) / 4) sh.diag[2]++;
+        if (ncand > 2 * HCAP) sh.diag[3]++;
+        const int cl = f_n0 < 512 ? 0 : f_n0 < 2048 ? 1 : f_n0 < 6144 ? 2 : 3;
+        sh.fcl[cl] += clk() - f_t0; sh.fcl[4 + cl] += 1;
+      }
+#endif
       c_tok_new += cur_e - cur_b; c_link_new += pl_end - lb;
       frames_done = frame + 1;
       __syncthreads();
@@ -1649,12 +1780,31 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         r->n_max_bound = sh.n_max_bound; r->n_min_bound = sh.n_min_bound;
         for (int i = 0; i < 7; i++) r->t_phase[i] = sh.tph[i];
         r->t_phase[7] = sh.n_visited;   // slot 7: frames visited by pruning (not a time)
+        for (int i = 8; i < 16; i++) r->t_phase[i] = 0;
+#ifdef VBH_DIAG
+        r->t_phase[8] = sh.tph[8]; r->t_phase[9] = sh.tph[9];
+        for (int i = 0; i < 4; i++) r->t_phase[10 + i] = sh.diag[i];
+        // [14], [15]: cycles and frames of the four frame classes, 16 bits of kilocycles-per-frame / frames each
+        r->t_phase[14] = 0; r->t_phase[15] = 0;
+        // heavy frames' phase cycles replace [0..6], [8], [9] when VBH_DIAG_HEAVY is defined
+#ifdef VBH_DIAG_HEAVY
+        for (int i = 0; i < 7; i++) r->t_phase[i] = sh.hph[i];
+        r->t_phase[8] = sh.hph[8]; r->t_phase[9] = sh.hph[9];
+#endif
+        for (int i = 0; i < 4; i++) {
+          const long long kc = sh.fcl[4 + i] ? sh.fcl[i] / sh.fcl[4 + i] / 1000 : 0;
+          r->t_phase[14] |= (kc > 65535 ? 65535 : kc) << (16 * i);
+          r->t_phase[15] |= (sh.fcl[4 + i] > 65535 ? 65535 : sh.fcl[4 + i]) << (16 * i);
+        }
+#endif
         r->t_start = rt_start; r->t_end = (long long)__builtin_amdgcn_s_memrealtime(); r->wg = blockIdx.x; r->pad2 = 0;
       }
     }
     __syncthreads();
   }
 #undef PHASE
+#undef PHASE_D
+#undef DIAG_ADD
   if (spool.flags) {
     __syncthreads();               // every wave's stores have left for L2
     if (tid == 0) {
@@ -2506,6 +2656,12 @@ int vbh_decoder_utt_timeline(vbh_decoder *d, int32_t utt, int64_t *out3) {
   return 0;
 }
 
+int vbh_decoder_diag(vbh_decoder *d, int32_t utt, int64_t *out16) {
+  VBH_CHECK(d && out16, "vbh_decoder_diag: NULL argument");
+  VBH_CHECK(utt >= 0 && utt < (int)d->h_res.size(), "vbh_decoder_diag: utterance %d out of range", utt);
+  for (int i = 0; i < 16; i++) out16[i] = d->h_res[utt].t_phase[i];
+  return 0;
+}
 int vbh_decoder_phase_cycles(vbh_decoder *d, int32_t utt, int64_t *out8) {
   VBH_CHECK(d && out8, "vbh_decoder_phase_cycles: NULL argument");
   VBH_CHECK(utt >= 0 && utt < (int)d->h_res.size(), "vbh_decoder_phase_cycles: utterance %d out of range", utt);

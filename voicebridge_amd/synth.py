@@ -146,7 +146,7 @@ def affine(D, seed=0, scale=0.05):
     return A
 
 
-def lexicon_graph(num_words, num_pdfs, seed=0, n_phones=40, min_len=3, max_len=9, hmm_states=3):
+def lexicon_graph(num_words, num_pdfs, seed=0, n_phones=40, min_len=3, max_len=9, hmm_states=3, return_lexicon=False):
     """HCLG-shaped graph with the recombination structure of a real decoding graph: a lexicon
     prefix tree over random phone strings, every tree node a left-to-right HMM of `hmm_states`
     states (self-loop + forward arc), word ends returning to the root through one
@@ -156,6 +156,9 @@ def lexicon_graph(num_words, num_pdfs, seed=0, n_phones=40, min_len=3, max_len=9
     self-loop tid 2p+1 and the forward tid 2p+2 (hmm/transition-model.h: two transitions per
     emitting HMM state); each tree node draws a context-dependent phone, i.e. `hmm_states`
     consecutive pdfs.
+
+    return_lexicon: also return dict(word_off[W+1], word_pdf[...], lm_cost[W]): the pdf sequence a word's path through
+    the graph emits (one entry per HMM state), for synth_speech's utterances; the graph is the same either way.
     """
     rng = np.random.default_rng(seed)
     n_cd = num_pdfs // hmm_states
@@ -165,6 +168,7 @@ def lexicon_graph(num_words, num_pdfs, seed=0, n_phones=40, min_len=3, max_len=9
     child = {}
     node_cd = [0]          # node 0 = root (no HMM)
     word_end_node = np.zeros(num_words, np.int64)
+    word_nodes = np.zeros(int(lens.sum()), np.int64) if return_lexicon else None
     pos = 0
     for w in range(num_words):
         cur = 0
@@ -176,6 +180,8 @@ def lexicon_graph(num_words, num_pdfs, seed=0, n_phones=40, min_len=3, max_len=9
                 child[key] = nxt
                 node_cd.append(0)
             cur = nxt
+            if word_nodes is not None:
+                word_nodes[pos + k] = cur
         pos += lens[w]
         word_end_node[w] = cur
     n_nodes = len(node_cd)
@@ -237,4 +243,10 @@ def lexicon_graph(num_words, num_pdfs, seed=0, n_phones=40, min_len=3, max_len=9
     t2p = np.empty(num_tids + 1, np.int32)
     t2p[0] = -1
     t2p[1:] = np.repeat(np.arange(num_pdfs, dtype=np.int32), 2)
-    return dict(final=final, arc_offset=arc_offset, arcs=arcs, start=0), t2p
+    g = dict(final=final, arc_offset=arc_offset, arcs=arcs, start=0)
+    if not return_lexicon:
+        return g, t2p
+    word_off = np.zeros(num_words + 1, np.int64)
+    word_off[1:] = np.cumsum(lens) * H
+    word_pdf = (node_cd[word_nodes][:, None] * H + np.arange(H)[None, :]).reshape(-1).astype(np.int32)
+    return g, t2p, dict(word_off=word_off, word_pdf=word_pdf, lm_cost=lm_cost, hmm_states=H)
