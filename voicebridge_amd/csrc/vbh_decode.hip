@@ -58,24 +58,26 @@
 #include <chrono>
 #include <thread>
 #include <climits>
+#include <cstddef>
 #include <cmath>
 #include <memory>
 #include <mutex>
 
 namespace {
 
-// Threads per utterance.  1024 (one utterance per CU: its 155 KB of LDS leave room for no other workgroup) is the default.
-// 512 (two utterances per CU) searched 10 % more frames per second in r02's measurements, but a 512-thread search workgroup
-// shares its CU with workgroups of other kernels, and beside gmm_rows_kernel it faulted (memory access fault inside the
-// search's own slot memory, 5 of 7 runs; never beside the older GMM kernel, never with 1024 threads, never alone; not
-// explained -- see DESIGN.md): not shipped until that is understood.
+// Threads per utterance.  One utterance per CU (the workgroup's ~150 KB of LDS leave room for no other workgroup), so the
+// thread count decides how many registers a thread gets: 1024 threads = 4 waves per SIMD = 128 VGPRs, 768 = 3 waves = 168
+// VGPRs, 512 = 2 waves = 256 VGPRs.  The frame loop wants about 250; at 128 it spills ~230 registers to scratch and the
+// spill code sits in the hot loops (small edits moved the kernel's speed by 20 % either way, r01/r02).  Measured on the
+// bench's speech workload (r02, one box, per-utterance search time): 1024 threads 376 ms, 768 threads 301 ms (58 spills),
+// 512 threads 330 ms (no spills, but only 8 waves to hide latency with).
 #ifndef VBH_DECODE_NT
-#define VBH_DECODE_NT 1024
+#define VBH_DECODE_NT 768
 #endif
 constexpr int NT = VBH_DECODE_NT;    // threads per workgroup = per utterance; 1024/NT workgroups share a CU
 constexpr int NW = NT / 64;
 #ifndef VBH_WAVES_PER_EU
-#define VBH_WAVES_PER_EU 4                  // 4: 128 VGPRs, 1024 threads per CU;  8: 64 VGPRs, 2048 threads per CU
+#define VBH_WAVES_PER_EU (VBH_DECODE_NT / 256)    // one workgroup per CU: 4 waves per SIMD (128 VGPRs) at 1024 threads, 3 (168) at 768, 2 (256) at 512
 #endif
 constexpr int WG_PER_CU = ((1024 / NT) * VBH_WAVES_PER_EU) / 4 > 0 ? ((1024 / NT) * VBH_WAVES_PER_EU) / 4 : 1;
 constexpr int WBIT = 0x40000000;            // token id lives in the raw window
@@ -98,17 +100,24 @@ constexpr int U = VBH_U;                    // independent items per lane in the
 #ifndef VBH_UM
 #define VBH_UM 4
 #endif
+#ifndef VBH_UA
+#define VBH_UA 2
+#endif
+constexpr int UA = VBH_UA;                  // x 64 arcs a wave has in flight in pass 1
 constexpr int UM = VBH_UM;                  // ... in the compaction moves
 constexpr int UC = VBH_UC;                  // ... in the candidate passes (LDS-bound: more only costs registers)
 constexpr int UL = VBH_UL;                  // ... in the pruning sweeps over links
-constexpr int HBITS = NT >= 1024 ? 14 : (NT >= 512 ? 12 : 11);
-constexpr int HCAP = 1 << HBITS;            // slots of the per-frame state map in LDS (16 per thread at 1024 threads)
+#ifndef VBH_HBITS
+#define VBH_HBITS (VBH_DECODE_NT >= 512 ? 14 : 11)
+#endif
+constexpr int HBITS = VBH_HBITS;
+constexpr int HCAP = 1 << HBITS;            // slots of the per-frame state map in LDS
 constexpr int HPROBE = 24;                  // probes before a state is sent to the table in HBM
 constexpr unsigned HEMPTY = 0xFFFFFFFFu;
-constexpr int SPT = HCAP / NT;              // slots a thread numbers in the slot scan
+constexpr int SPT = 32;                     // slots a thread numbers in the slot scan: one group (threads 0 .. HCAP / 32 - 1 take part)
 constexpr int COST_CAP = 2 * HCAP;          // token costs of the current frame cached in LDS (the map's memory, idle at that time)
 constexpr int FCAP = NT >= 1024 ? 1024 : 512;   // entries of each epsilon work list kept in LDS
-static_assert(SPT >= 4 && SPT <= 32 && (SPT & (SPT - 1)) == 0, "slot scan: a 32-slot group is shared by 32 / SPT adjacent lanes");
+static_assert(HCAP / SPT <= NT, "slot scan: one thread per 32-slot group");
 // VBH_LL_LDS: the frame's row of acoustic scores (P floats, fetched coalesced at the start of the frame) is kept in LDS, so
 // that the per-arc score lookup of pass 1 is an LDS read instead of a third dependent global access (token -> state -> arc
 // -> score); models of more than LLCAP pdfs read the row from global memory as before
@@ -211,7 +220,7 @@ struct Pool {   // dense per-batch output
 };
 
 enum { ERR_NONE = 0, ERR_W_TOK = 1, ERR_W_LINK = 2, ERR_H_TOK = 3, ERR_H_LINK = 4, ERR_FRONT = 5,
-       ERR_EPS_LOOP = 6, ERR_POOL = 7, ERR_CAND = 8, ERR_NOT_RUN = 9, ERR_LDS = 10 };
+       ERR_EPS_LOOP = 6, ERR_POOL = 7, ERR_CAND = 8, ERR_NOT_RUN = 9, ERR_LDS = 10, ERR_INTERNAL = 11 };
 
 // order-preserving map float -> uint32
 __device__ __forceinline__ unsigned f2o(float f) {
@@ -333,6 +342,34 @@ __device__ __forceinline__ void wave_expand(int cnt, F body) {
     body(valid, owner, j);
   }
 }
+// the same, UA x 64 sub-items per round: body(valid[UA], owner[UA], j[UA]) can issue the loads of all of them before it uses any
+template <int UA, class F>
+__device__ __forceinline__ void wave_expand_n(int cnt, F body) {
+  const int lane = threadIdx.x & 63;
+  const int incl = wave_incl_scan(cnt);
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  const int excl = incl - cnt;
+  for (int k0 = 0; k0 < total; k0 += 64 * UA) {
+    bool valid[UA]; int owner[UA], j[UA];
+#pragma unroll
+    for (int u = 0; u < UA; u++) {
+      valid[u] = false; owner[u] = 0; j[u] = 0;
+      if (k0 + u * 64 < total) {      // (uniform)
+        const int k = k0 + u * 64 + lane;
+        int lo = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+          const int v = __shfl(incl, lo + step - 1, 64);
+          if (v <= k) lo += step;
+        }
+        valid[u] = k < total;
+        owner[u] = valid[u] ? lo : 0;
+        j[u] = k - __shfl(excl, owner[u], 64);
+      }
+    }
+    body(valid, owner, j);
+  }
+}
 // tokens/items per wave and round: spreads few items over all waves
 __device__ __forceinline__ int wave_chunk(int n) {
   const int c = (n + NW - 1) / NW;
@@ -368,6 +405,7 @@ struct Shared {
   unsigned dirty[DIRTY_FRAMES / 32];   // see frame_dirty()
   int use_lds_map;
   int scan_part[NW], scan_base;    // slot scan: occupied slots per wave, first token index it hands out
+  int chk[4];                      // first failed consistency check: {where, frame, value, bound}
   float ll[LLCAP];                 // the frame's acoustic scores (VBH_LL_LDS)
   int j_ntf, j_nseg, j_tf0, j_tdst, j_ldst;   // compaction job (its arrays: struct Job, in the arena)
   int front_lds[3 * FCAP];         // the first FCAP entries of the three rotating epsilon work lists
@@ -388,6 +426,7 @@ struct Job {
   int sbeg[2 * MAX_WIN_FRAMES + 1], sbase[2 * MAX_WIN_FRAMES], scnt[2 * MAX_WIN_FRAMES], sup[2 * MAX_WIN_FRAMES];
   int sid[2 * MAX_WIN_FRAMES];     // frame << 1 | (1 = epsilon links)
 };
+static_assert(offsetof(Shared, arena) % 16 == 0, "the arena is cleared and read with 16-byte LDS accesses");
 constexpr int JOB_OFF_WORDS = ((MAX_WIN_FRAMES + 2) * 12 + 63) & ~63;
 static_assert(JOB_OFF_WORDS * 4 + sizeof(Job) <= sizeof(unsigned) * 2 * HCAP, "FrameRec staging + job arrays must fit in the arena");
 __device__ __forceinline__ Job &job_of(Shared &sh) { return *reinterpret_cast<Job *>(sh.arena + JOB_OFF_WORDS); }
@@ -470,6 +509,25 @@ __device__ VBH_WARM float select_kth(gp<const i32x4> tok, int n, int k, Shared &
 
 __device__ __forceinline__ gp<i32x4> tokp(gp<i32x4> wt, gp<i32x4> ht, int id) { return (id & WBIT) ? wt + (id ^ WBIT) : ht + id; }
 
+// Consistency checks on indices that are about to address memory: a violation is recorded (first one wins), the utterance
+// fails with ERR_INTERNAL instead of the device faulting.
+#ifndef VBH_CHECKS
+#define VBH_CHECKS 0           // (diagnostic builds: -DVBH_CHECKS=1; measured r02: 20 % slower, the compares cost registers the frame loop does not have)
+#endif
+__device__ __forceinline__ bool chk_fail(Shared &sh, int where, int value, int bound) {
+  if (atomicCAS(&sh.chk[0], 0, where) == 0) { sh.chk[2] = value; sh.chk[3] = bound; }
+  sh.error = ERR_INTERNAL;
+  return false;
+}
+#if VBH_CHECKS
+#define VBH_CHK(sh, where, value, bound) (((unsigned)(value) < (unsigned)(bound)) ? true : chk_fail(sh, where, value, bound))
+#else
+#define VBH_CHK(sh, where, value, bound) true
+#endif
+__device__ __forceinline__ bool chk_tok_id(Shared &sh, const Slot &s, int where, int id) {
+  return (id & WBIT) ? VBH_CHK(sh, where, id ^ WBIT, s.w_tok_cap) : VBH_CHK(sh, where + 1, id, s.h_tok_cap);
+}
+
 // evaluate the forward links [lb, le) of one frame: excise those over the lattice beam,
 // atomicMin the rest into the source token's tmp (lattice-faster-decoder.cc:331-356).  A link
 // carries tot = (source cost + acoustic) + graph, so only the destination token is gathered.
@@ -477,7 +535,7 @@ __device__ __forceinline__ gp<i32x4> tokp(gp<i32x4> wt, gp<i32x4> ht, int id) { 
 // Returns (valid on lane 0 of each wave) the links this wave kept: epsilon << 32 | emitting.
 template <bool LDS_TMP>
 __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, int le_, int split, gp<i32x4> wt, gp<i32x4> ht,
-                                                         float lattice_beam, unsigned *lds_tmp, int tb) {
+                                                         float lattice_beam, unsigned *lds_tmp, int tb, Shared &sh, const Slot &s) {
   unsigned long long kept = 0;
   for (int base = lb; base < le_; base += NT * UL) {
     i32x4 L[UL]; bool ok[UL];
@@ -487,6 +545,10 @@ __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, i
       ok[u] = l < le_;
       L[u] = lk[ok[u] ? l : lb];
       ok[u] = ok[u] && L[u].x >= 0;   // negative source: already excised
+      if (ok[u]) {
+        ok[u] = chk_tok_id(sh, s, 10, L[u].y) && chk_tok_id(sh, s, 12, L[u].x);
+        if (LDS_TMP && ok[u]) ok[u] = VBH_CHK(sh, 14, (L[u].x & ~WBIT) - tb, COST_CAP);
+      }
     }
     i32x4 D[UL];
 #pragma unroll
@@ -545,6 +607,13 @@ __device__ int prune_frame(const Slot &s, int f, float lattice_beam, float delta
   gp<i32x4> elk = uptr((flags & 2) ? s.wl : s.hl), plk = uptr((flags & 4) ? s.wl : s.hl);
   // epsilon links of a frame are created right before its emitting links: normally one range
   const bool one_range = pe == eb && ((flags >> 1) & 1) == ((flags >> 2) & 1);
+#if VBH_CHECKS
+  {   // (uniform: everybody read the same record)
+    const int tcap = (flags & 1) ? s.w_tok_cap : s.h_tok_cap, ecap = (flags & 2) ? s.w_link_cap : s.h_link_cap, pcap = (flags & 4) ? s.w_link_cap : s.h_link_cap;
+    const bool good = tb >= 0 && tb <= te && te <= tcap && eb >= 0 && eb <= ee && ee <= ecap && pb >= 0 && pb <= pe && pe <= pcap;
+    if (!good) { if (threadIdx.x == 0) { chk_fail(sh, 20, f, te); } __syncthreads(); return 0; }
+  }
+#endif
   // Frames of up to COST_CAP tokens accumulate the link minima in LDS (sh.cost, all +inf between
   // sweeps) instead of the tokens' tmp fields: no global atomics to wait for, and the old
   // extra_costs are fetched while the links are in flight.
@@ -559,16 +628,16 @@ __device__ int prune_frame(const Slot &s, int f, float lattice_beam, float delta
     }
     unsigned long long kept;
     if (lds_tmp) {
-      if (one_range) kept = eval_links<true>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb);
+      if (one_range) kept = eval_links<true>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s);
       else {
-        kept = eval_links<true>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb);
-        kept += eval_links<true>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb);
+        kept = eval_links<true>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb, sh, s);
+        kept += eval_links<true>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s);
       }
     } else {
-      if (one_range) kept = eval_links<false>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb);
+      if (one_range) kept = eval_links<false>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s);
       else {
-        kept = eval_links<false>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb);
-        kept += eval_links<false>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb);
+        kept = eval_links<false>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb, sh, s);
+        kept += eval_links<false>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s);
       }
     }
     if ((tid & 63) == 0) {
@@ -1068,11 +1137,15 @@ __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, in
   // ---- slot scan: thread t numbers the occupied ones of slots [t SPT, (t+1) SPT)
   const int n2 = sh.w_ntok < w_tok_cap ? sh.w_ntok : w_tok_cap;      // second-level tokens: [nb, n2)
   unsigned occ = 0;
-  unsigned tg[SPT];
-  {
-    const unsigned *tag = map_tag(sh);
+  const bool scans = tid < HCAP / SPT && sh.use_lds_map;
+  if (scans) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 *tag4 = reinterpret_cast<const u32x4 *>(map_tag(sh) + tid * SPT);
 #pragma unroll
-    for (int j = 0; j < SPT; j++) { tg[j] = sh.use_lds_map ? tag[tid * SPT + j] : HEMPTY; occ |= (unsigned)(tg[j] != HEMPTY) << j; }
+    for (int j = 0; j < SPT / 4; j++) {
+      const u32x4 t4 = tag4[j];
+      occ |= ((unsigned)(t4.x != HEMPTY) | ((unsigned)(t4.y != HEMPTY) << 1) | ((unsigned)(t4.z != HEMPTY) << 2) | ((unsigned)(t4.w != HEMPTY) << 3)) << (4 * j);
+    }
   }
   const int mine = __popc(occ);
   const int incl = wave_incl_scan(mine);
@@ -1085,32 +1158,24 @@ __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, in
   const int ne_all = sh.scan_base + total;
   if (ne_all > w_tok_cap) { if (tid == 0) sh.error = ERR_W_TOK; }
   else {
-    // group words: the lanes that share a 32-slot group combine their occupancy bits; the group's first lane knows its base
-    {
-      constexpr int LPG = 32 / SPT;                      // lanes per group
-      unsigned m = occ << ((lane % LPG) * SPT);
-#pragma unroll
-      for (int o = 1; o < LPG; o <<= 1) m |= __shfl_xor(m, o, 64);
-      const int gfirst = __shfl(first, lane & ~(LPG - 1), 64);
-      if ((lane % LPG) == 0) { uint2 gq; gq.x = m; gq.y = (unsigned)gfirst; sh.grp[(tid * SPT) >> 5] = gq; }
-    }
+    if (scans) { uint2 gq; gq.x = occ; gq.y = (unsigned)first; sh.grp[tid] = gq; }
     // token records of the first-level states, final cost included; those with epsilon arcs and a cost within the cutoff go
     // on work list 0 (as slots) for the regeneration of the epsilon links
+    const unsigned *tag = map_tag(sh);
     const unsigned *key = map_key(sh);
     int k = nb + first;
-#pragma unroll
-    for (int j = 0; j < SPT; j++) {
-      bool want = false;
-      if ((occ >> j) & 1u) {
-        const float c = o2f(key[tid * SPT + j]);
-        i32x4 r; r.x = (int)tg[j]; r.y = asi(c); r.z = 0; r.w = (int)INF_BITS;
+    for (unsigned m = occ; __ballot(m != 0) != 0; m &= m - 1) {       // (a wave goes on until its last lane is done)
+      bool want = false; int slot = 0;
+      if (m) {
+        slot = tid * SPT + (__ffs((int)m) - 1);
+        const unsigned tg = tag[slot];
+        const float c = o2f(key[slot]);
+        i32x4 r; r.x = (int)tg; r.y = asi(c); r.z = 0; r.w = (int)INF_BITS;
         wt[k++] = r;
-        want = (int)tg[j] < 0 && !(c > cutoff);
+        want = (int)tg < 0 && !(c > cutoff);
       }
-      if (__ballot(want)) {       // (uniform per wave)
-        const int q = wave_alloc(&sh.fcnt[0], want);
-        if (want) front_push(sh, uptr(s.front[0]), front_cap, 0, q, tid * SPT + j);
-      }
+      const int q = wave_alloc(&sh.fcnt[0], want);
+      if (want) front_push(sh, uptr(s.front[0]), front_cap, 0, q, slot);
     }
     // second-level tokens: final cost; the ones to expand go on work list 1 (as token indices)
     for (int t0 = nb + wave * 64; t0 < n2; t0 += NT) {
@@ -1136,6 +1201,7 @@ __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, in
     gp<int> py = (gp<int>)&wl[l] + 1;
     const int y = *py;
     const int d = y >= 0 ? map_tok(sh, ent, y, 0, nb) : ld_i32(&ent[-1 - y].tokid);
+    (void)VBH_CHK(sh, 30, d - nb, ne_all - nb);
     *py = d | WBIT;
   }
   // ---- epsilon links regenerated from the final costs; what they point to is tagged
@@ -1170,6 +1236,7 @@ __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, in
               mk = true;
               const int ds = arc.x & STMASK;
               dtok = map_tok(sh, ent, map_find(sh, ds), ds, nb);
+              mk = VBH_CHK(sh, 31, dtok - nb, ne_all - nb) && VBH_CHK(sh, 32, so - nb, ne_all - nb);
             }
           }
           const int l = wave_alloc(&sh.w_nlink, mk);
@@ -1299,6 +1366,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       sh.changed2[0] = 0; sh.changed2[1] = 0;
       sh.cnt_tok[0] = 0; sh.cnt_tok[1] = 0; sh.cnt_el[0] = 0; sh.cnt_el[1] = 0; sh.cnt_pl[0] = 0; sh.cnt_pl[1] = 0;
       sh.tail_tok_b = 0; sh.tail_link_b = 0; sh.tail_f0 = -1; sh.tail_f1 = -2;
+      sh.chk[0] = 0; sh.chk[1] = 0; sh.chk[2] = 0; sh.chk[3] = 0;
     }
     for (int i = tid; i < DIRTY_FRAMES / 32; i += NT) sh.dirty[i] = ~0u;   // no frame has been evaluated yet
     map_clear(sh);
@@ -1439,25 +1507,10 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
           } else { adaptive_beam = cfg.beam; cur_cutoff = beam_cutoff; }
         }
       }
-      // ---- cost_offset and the initial next_cutoff from the best token (:706-724): wave 0,
-      //      one arc per lane; the result is first read after pass 1's reduction barrier
+      // ---- cost_offset (:706-711).  The initial next_cutoff from the best token's arcs (:712-724) is taken in pass 1 by the lanes
+      //      that expand that token: min over arcs of (new_weight + adaptive_beam), in the reference's own association order
       const float cost_offset = n > 0 ? -best : 0.0f;
-      if (wave == 0) {
-        float nc = INF;
-        if (n > 0) {
-          const i32x4 sr = g.st[best_state];
-          const int a0 = sr.x + sr.y, ne = sr.z - sr.y;
-          for (int j = lane; j < ne; j += 64) {
-            const i32x4 arc = g.arcs[a0 + j];
-            const float ll = cfg.acwt * (ll_lds ? sh.ll[arc.z] : llrow[arc.z]);
-            const float nw = ((asf(arc.y) + cost_offset) - ll) + best;
-            if (nw + adaptive_beam < nc) nc = nw + adaptive_beam;
-          }
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) nc = fminf(nc, __shfl_xor(nc, o, 64));
-        }
-        if (lane == 0) { sh.f0 = nc; ((gp<float>)(s.fr + frame))[7] = cost_offset; }
-      }
+      if (tid == 0) ((gp<float>)(s.fr + frame))[7] = cost_offset;
       PHASE(0)
       // ---- the state map is emptied for the frame about to be built (the costs the cutoff phase kept in its memory were last
       //      read before that phase's last reduction barrier; the map's first writers come after pass 1's reduction barrier)
@@ -1473,32 +1526,49 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
           const float c = asf(rec.y);
           const bool exp = have && (c <= cur_cutoff);
           const i32x4 sr = g.st[exp ? (rec.x & STMASK) : 0];
-          const int a0 = sr.x + sr.y, cnt = exp ? sr.z - sr.y : 0;
+          // (the sign bit of the first-arc index marks the frame's best token)
+          const int a0 = (sr.x + sr.y) | ((exp && (rec.x & STMASK) == best_state) ? EPSBIT : 0), cnt = exp ? sr.z - sr.y : 0;
           c_tok_exp += exp;
-          wave_expand(cnt, [&](bool valid, int owner, int j) {
-            const int a = __shfl(a0, owner, 64) + j;
-            const float cc = __shfl(c, owner, 64);
-            i32x4 arc; float ac = 0.0f, tot = 0.0f;
-            if (valid) {
-              arc = g.arcs[a];
-              ac = cost_offset - cfg.acwt * (ll_lds ? sh.ll[arc.z] : llrow[arc.z]);
-              tot = (cc + ac) + asf(arc.y);
-              mymin = fminf(mymin, tot + adaptive_beam);
-              c_arc_exp++;
+          wave_expand_n<UA>(cnt, [&](const bool (&valid)[UA], const int (&owner)[UA], const int (&j)[UA]) {
+            int a[UA]; float cc[UA]; bool isb[UA]; i32x4 arc[UA]; float sc[UA];
+#pragma unroll
+            for (int u = 0; u < UA; u++) {
+              const int ao = __shfl(a0, owner[u], 64);
+              a[u] = (ao & ~EPSBIT) + j[u]; isb[u] = ao < 0;
+              cc[u] = __shfl(c, owner[u], 64);
             }
-            const int q = wave_alloc(&sh.n_cand, valid);
-            if (valid) {
-              if (q < cand_cap) {
-                i32x4 ca; ca.x = asi(tot); ca.y = asi(ac); ca.z = a; ca.w = base + owner;
-                i32x2 cb; cb.x = arc.x; cb.y = arc.y;
-                cand[q] = ca; cand2[q] = cb;
-              } else sh.error = ERR_CAND;
+#pragma unroll
+            for (int u = 0; u < UA; u++) arc[u] = g.arcs[valid[u] ? a[u] : 0];
+#pragma unroll
+            for (int u = 0; u < UA; u++) sc[u] = cfg.acwt * (ll_lds ? sh.ll[valid[u] ? arc[u].z : 0] : llrow[valid[u] ? arc[u].z : 0]);
+            float ac[UA], tot[UA];
+#pragma unroll
+            for (int u = 0; u < UA; u++) {
+              ac[u] = cost_offset - sc[u];
+              tot[u] = (cc[u] + ac[u]) + asf(arc[u].y);
+              if (valid[u]) {
+                mymin = fminf(mymin, tot[u] + adaptive_beam);
+                if (isb[u]) mymin = fminf(mymin, (((asf(arc[u].y) + cost_offset) - sc[u]) + best) + adaptive_beam);
+                c_arc_exp++;
+              }
+            }
+            int q[UA];
+            wave_alloc_n<UA>(&sh.n_cand, valid, q);
+#pragma unroll
+            for (int u = 0; u < UA; u++) {
+              if (valid[u]) {
+                if (q[u] < cand_cap) {
+                  i32x4 ca; ca.x = asi(tot[u]); ca.y = asi(ac[u]); ca.z = a[u]; ca.w = base + owner[u];
+                  i32x2 cb; cb.x = arc[u].x; cb.y = arc[u].y;
+                  cand[q[u]] = ca; cand2[q[u]] = cb;
+                } else sh.error = ERR_CAND;
+              }
             }
           });
         }
       }
       mymin = block_min_f(mymin, sh, par);
-      const float next_cutoff = fminf(sh.f0, mymin);
+      const float next_cutoff = mymin;
       const int ncand = sh.n_cand < cand_cap ? sh.n_cand : cand_cap;
       const int nb = sh.w_ntok;     // first token of frame+1
       PHASE(1)
@@ -1629,7 +1699,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
           ((gp<int>)&tok[t])[3] = asi(x);
         }
         __syncthreads();
-        const unsigned long long cp = eval_links<false>(plk, pb, pe, pe, wt, ht, cfg.lattice_beam, nullptr, 0);
+        const unsigned long long cp = eval_links<false>(plk, pb, pe, pe, wt, ht, cfg.lattice_beam, nullptr, 0, sh, s);
         if ((tid & 63) == 0 && (cp >> 32)) atomicAdd(&sh.cnt_pl[pp], (int)(cp >> 32));
         __syncthreads();
         if (tid == 0) { sh.changed2[pp ^ 1] = 0; sh.cnt_tok[pp ^ 1] = 0; sh.cnt_el[pp ^ 1] = 0; sh.cnt_pl[pp ^ 1] = 0; }
@@ -1781,6 +1851,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         for (int i = 0; i < 7; i++) r->t_phase[i] = sh.tph[i];
         r->t_phase[7] = sh.n_visited;   // slot 7: frames visited by pruning (not a time)
         for (int i = 8; i < 16; i++) r->t_phase[i] = 0;
+        if (r_error == ERR_INTERNAL) { r->t_phase[8] = sh.chk[0]; r->t_phase[9] = sh.chk[1]; r->t_phase[10] = sh.chk[2]; r->t_phase[11] = sh.chk[3]; }
 #ifdef VBH_DIAG
         r->t_phase[8] = sh.tph[8]; r->t_phase[9] = sh.tph[9];
         for (int i = 0; i < 4; i++) r->t_phase[10 + i] = sh.diag[i];
@@ -2285,6 +2356,7 @@ static const char *err_name(int e) {
     case ERR_CAND: return "candidate list capacity exceeded";
     case ERR_NOT_RUN: return "no workgroup searched the utterance";
     case ERR_LDS: return "the workgroup's LDS was overwritten from outside (canary, diagnostic build)";
+    case ERR_INTERNAL: return "internal consistency check failed (an index out of its array)";
     default: return "unknown";
   }
 }
@@ -2587,6 +2659,8 @@ static int decode_batch_end_impl(vbh_decoder *d) {
     d->n_failed++;
     fprintf(stderr, "WARNING (vbh_decode_batch) utterance %d failed: %s (frame %d of %d); it is reported with ok = 0\n", u, err_name(r.error),
             r.num_frames, (int)d->h_utts[u].T);
+    if (r.error == ERR_INTERNAL)
+      fprintf(stderr, "        check %lld failed: value %lld, bound %lld\n", r.t_phase[8], r.t_phase[10], r.t_phase[11]);
     r.ok = 0; r.reached_final = 0; r.n_tok = 0; r.n_link = 0; r.tok_off = 0; r.link_off = 0;
   }
   const long long tok_cap_final = tok_cap_now, link_cap_final = link_cap_now;

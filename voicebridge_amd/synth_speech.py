@@ -106,13 +106,23 @@ def waves_device(hop_pdf, gains, ids, device, spk_gain=None, seed=4321, level=22
     lab = torch.as_tensor(hop_pdf, device=device).long()
     out = torch.empty((B, H * HOP), dtype=torch.int16, device=device)
     g = torch.Generator(device=device)
+    # the inverse real FFT of a hop as two matrix products (x = Re Z . C - Im Z . S): plain GEMMs instead of an FFT library call
+    n = torch.arange(HOP, device=device, dtype=torch.float64)[None, :]
+    kk = torch.arange(NBIN, device=device, dtype=torch.float64)[:, None]
+    wgt = torch.full((NBIN, 1), 2.0 / HOP, device=device, dtype=torch.float64)
+    wgt[0, 0] = 1.0 / HOP
+    wgt[NBIN - 1, 0] = 1.0 / HOP
+    Cm = (wgt * torch.cos(2.0 * np.pi * kk * n / HOP)).float()
+    Sm = (wgt * torch.sin(2.0 * np.pi * kk * n / HOP)).float()
+    Sm[0] = 0.0
+    Sm[NBIN - 1] = 0.0
     for k in range(B):
         g.manual_seed(seed + 7919 * int(ids[k]))
         z = torch.randn((H, NBIN, 2), generator=g, device=device, dtype=torch.float32)
         amp = gains[lab[k]]
         if spk_gain is not None:
             amp = amp * spk_gain[k][None, :]
-        x = torch.fft.irfft(torch.view_as_complex(z) * amp, n=HOP, dim=1).reshape(-1)
+        x = ((z[..., 0] * amp) @ Cm - (z[..., 1] * amp) @ Sm).reshape(-1)
         out[k] = torch.clamp(torch.round(x * level), -32768, 32767).to(torch.int16)
     return out
 
