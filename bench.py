@@ -740,7 +740,10 @@ def main():
             print("   phase share: " + ", ".join("%s %.1f%%" % (nm, 100.0 * c / tot) for nm, c in zip(
                 ["cutoff", "pass1", "admit+links", "eps", "prune", "compact", "output"], ph[:7])) + "  cycles/frame=%.0f prune-visited-frames=%d" % (tot / nf, ph[7]))
             dg = dec.diag(u)
-            if any(dg[8:]):
+            if os.environ.get("VBH_PROBE_P1"):
+                print("   pass 1 of wave 0, kilocycles per frame: round top (token/state wait) %.1f, owner search %.1f, arc wait %.1f, score wait %.1f, "
+                      "compute + alloc %.1f, stores %.1f, loop exit %.1f, reduction barrier %.1f" % tuple(x / nf / 1e3 for x in dg[:8]))
+            elif any(dg[8:]):
                 tot += dg[8] + dg[9]
                 print("   VBH_DIAG: admit %.1f%% links %.1f%% cutoff-up-to-first-reduction %.1f%% rest-of-cutoff %.1f%%; admissions/frame %.0f, to the HBM map %.1f%%; "
                       "frames creating > 3/4 of the LDS map %d, frames with > 2 candidates per slot %d"

@@ -91,7 +91,7 @@ constexpr int STMASK = 0x3FFFFFFF;
 #define VBH_U 4
 #endif
 #ifndef VBH_UL
-#define VBH_UL 4
+#define VBH_UL 2                // (r02, 768 threads: 4 costs 35 more spilled registers in the pruning sweep and 5 % of the search rate)
 #endif
 constexpr int U = VBH_U;                    // independent items per lane in the streaming passes
 #ifndef VBH_UC
@@ -1345,7 +1345,11 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
     const long long rt_start = (long long)__builtin_amdgcn_s_memrealtime();
 #ifdef VBH_DIAG
     int f_heavy = 0;
+#ifdef VBH_DIAG_P1
+#define PHASE(i) { if (tid == 0) { const long long now_ = clk(); sh.tph[i] += now_ - t_last; t_last = now_; } }
+#else
 #define PHASE(i) { if (tid == 0) { const long long now_ = clk(); sh.tph[i] += now_ - t_last; if (f_heavy) sh.hph[i] += now_ - t_last; t_last = now_; } }
+#endif
 #else
 #define PHASE(i) { if (tid == 0) { const long long now_ = clk(); sh.tph[i] += now_ - t_last; t_last = now_; } }
 #endif
@@ -1516,20 +1520,42 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       //      read before that phase's last reduction barrier; the map's first writers come after pass 1's reduction barrier)
       map_clear(sh);
       // ---- pass 1 (arc-parallel): every candidate arc -> scratch list; min of tot + adaptive_beam
+#ifdef VBH_DIAG_P1
+#define P1STAMP(i) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (tid == 0) { const long long now_ = clk(); sh.hph[i] += now_ - p1_t; p1_t = now_; } }
+      long long p1_t = clk();
+#else
+#define P1STAMP(i)
+#endif
       float mymin = INF;
       {
-        const int CH = wave_chunk(n);
-        for (int base = wave * CH; base < n; base += NW * CH) {
-          const int i = base + lane;
-          const bool have = lane < CH && i < n;
-          const i32x4 rec = tok[have ? i : 0];
+        // Rounds of <= 64 tokens per wave, software-pipelined: while the arcs of round r are expanded, the state records of round
+        // r + 1 and the token records of round r + 2 are already on their way (a round is otherwise a chain of four dependent
+        // loads: token, state, arc, score).
+        const int CH = wave_chunk(n), RS = NW * CH;
+        auto ld_tok = [&](int b) -> i32x2 {      // {state | flags, cost} of this lane's token of the round starting at b
+          const int i_ = b + lane;
+          i32x2 r_; r_.x = 0; r_.y = 0x7FC00000;      // (no token: a NaN cost fails every comparison)
+          if (b < n) { const i32x4 t_ = tok[(lane < CH && i_ < n) ? i_ : 0]; if (lane < CH && i_ < n) { r_.x = t_.x; r_.y = t_.y; } }
+          return r_;
+        };
+        auto ld_st = [&](const i32x2 &r_) -> i32x4 { return g.st[(asf(r_.y) <= cur_cutoff) ? (r_.x & STMASK) : 0]; };
+        const int b0 = wave * CH;
+        i32x2 recC = ld_tok(b0), recB = ld_tok(b0 + RS);
+        i32x4 srC = ld_st(recC);
+        for (int base = b0; base < n; base += RS) {
+          P1STAMP(0)
+          const i32x4 srB = ld_st(recB);
+          const i32x2 recA = ld_tok(base + 2 * RS);
+          const i32x2 rec = recC;
+          const i32x4 sr = srC;
+          recC = recB; srC = srB; recB = recA;
           const float c = asf(rec.y);
-          const bool exp = have && (c <= cur_cutoff);
-          const i32x4 sr = g.st[exp ? (rec.x & STMASK) : 0];
+          const bool exp = c <= cur_cutoff;       // (false for lanes without a token)
           // (the sign bit of the first-arc index marks the frame's best token)
           const int a0 = (sr.x + sr.y) | ((exp && (rec.x & STMASK) == best_state) ? EPSBIT : 0), cnt = exp ? sr.z - sr.y : 0;
           c_tok_exp += exp;
           wave_expand_n<UA>(cnt, [&](const bool (&valid)[UA], const int (&owner)[UA], const int (&j)[UA]) {
+            P1STAMP(1)
             int a[UA]; float cc[UA]; bool isb[UA]; i32x4 arc[UA]; float sc[UA];
 #pragma unroll
             for (int u = 0; u < UA; u++) {
@@ -1539,8 +1565,10 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
             }
 #pragma unroll
             for (int u = 0; u < UA; u++) arc[u] = g.arcs[valid[u] ? a[u] : 0];
+            P1STAMP(2)
 #pragma unroll
-            for (int u = 0; u < UA; u++) sc[u] = cfg.acwt * (ll_lds ? sh.ll[valid[u] ? arc[u].z : 0] : llrow[valid[u] ? arc[u].z : 0]);
+            for (int u = 0; u < UA; u++) sc[u] = cfg.acwt * llrow[valid[u] ? arc[u].z : 0];
+            P1STAMP(3)
             float ac[UA], tot[UA];
 #pragma unroll
             for (int u = 0; u < UA; u++) {
@@ -1554,6 +1582,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
             }
             int q[UA];
             wave_alloc_n<UA>(&sh.n_cand, valid, q);
+            P1STAMP(4)
 #pragma unroll
             for (int u = 0; u < UA; u++) {
               if (valid[u]) {
@@ -1564,10 +1593,13 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
                 } else sh.error = ERR_CAND;
               }
             }
+            P1STAMP(5)
           });
         }
       }
+      P1STAMP(6)
       mymin = block_min_f(mymin, sh, par);
+      P1STAMP(7)
       const float next_cutoff = mymin;
       const int ncand = sh.n_cand < cand_cap ? sh.n_cand : cand_cap;
       const int nb = sh.w_ntok;     // first token of frame+1
@@ -1861,6 +1893,10 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
 #ifdef VBH_DIAG_HEAVY
         for (int i = 0; i < 7; i++) r->t_phase[i] = sh.hph[i];
         r->t_phase[8] = sh.hph[8]; r->t_phase[9] = sh.hph[9];
+#endif
+#ifdef VBH_DIAG_P1
+        for (int i = 0; i < 7; i++) r->t_phase[i] = sh.hph[i];
+        r->t_phase[7] = sh.hph[7];
 #endif
         for (int i = 0; i < 4; i++) {
           const long long kc = sh.fcl[4 + i] ? sh.fcl[i] / sh.fcl[4 + i] / 1000 : 0;
