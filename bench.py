@@ -1233,4 +1233,5 @@ if __name__ == "__main__":
     # of an otherwise complete run), and nothing of this process is needed any more.
     sys.stdout.flush()
     sys.stderr.flush()
-    os._exit(0)
+    if not os.environ.get("VBH_BENCH_SOFT_EXIT"):      # (a profiler writes its files from an exit handler: tools/profile_bench.sh sets this)
+        os._exit(0)
