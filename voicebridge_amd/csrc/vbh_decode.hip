@@ -994,16 +994,23 @@ __device__ VBH_COLD bool compact_window(const Slot &s, int prev_front, int front
 // sh.grp, so the map holds 8 bytes per state (16384 states at 1024 threads) and a token's record is
 // written once, with its final cost.  Second-level states get a token when they are first reached
 // (its index goes to ent[].tokid).
-__device__ __forceinline__ unsigned map_hash(int st) { return ((unsigned)st * 2654435761u) >> (32 - HBITS); }
+// Probing goes by buckets of four adjacent slots, one 16-byte LDS read each: the probe sequence of a state is its home
+// bucket and the HPROBE / 4 - 1 buckets behind it, the slots of a bucket in order.  (A wave's probe loop lasts as long as its
+// unluckiest lane's; with one slot per read that was 10-15 dependent LDS round trips per admission in the heavy frames.)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned map_hash(int st) { return (((unsigned)st * 2654435761u) >> (32 - HBITS)) & ~3u; }
 __device__ __forceinline__ int map_find(const Shared &sh, int st) {     // slot, or -1: second level
   if (!sh.use_lds_map) return -1;
   const unsigned *tag = map_tag(sh);
-  unsigned h = map_hash(st);
+  unsigned b = map_hash(st);
 #pragma unroll 1
-  for (int p = 0; p < HPROBE; p++, h = (h + 1) & (HCAP - 1)) {
-    const unsigned cur = tag[h];
-    if ((cur & STMASK) == (unsigned)st) return (int)h;      // (an empty slot's low bits are no state id)
-    if (cur == HEMPTY) return -1;
+  for (int p = 0; p < HPROBE / 4; p++, b = (b + 4) & (HCAP - 1)) {
+    const u32x4_t t = *reinterpret_cast<const u32x4_t *>(tag + b);
+    if ((t.x & STMASK) == (unsigned)st) return (int)b;            // (an empty slot's low bits are no state id)
+    if ((t.y & STMASK) == (unsigned)st) return (int)b + 1;
+    if ((t.z & STMASK) == (unsigned)st) return (int)b + 2;
+    if ((t.w & STMASK) == (unsigned)st) return (int)b + 3;
+    if (t.x == HEMPTY || t.y == HEMPTY || t.z == HEMPTY || t.w == HEMPTY) return -1;
   }
   return -1;
 }
@@ -1017,15 +1024,21 @@ __device__ __forceinline__ void map_relax(Shared &sh, gp<Ent> ent, int dsraw, fl
   if (sh.use_lds_map) {
     unsigned *tag = map_tag(sh);
     const unsigned want = (unsigned)(dsraw & ~PLDST);
-    unsigned h = map_hash(ds);
+    unsigned b = map_hash(ds);
 #pragma unroll 1
-    for (int p = 0; p < HPROBE; p++, h = (h + 1) & (HCAP - 1)) {
-      unsigned cur = tag[h];
-      if (cur == HEMPTY) {
-        cur = atomicCAS(&tag[h], HEMPTY, want);
-        if (cur == HEMPTY) { create = true; slot = (int)h; break; }
+    for (int p = 0; p < HPROBE / 4 && slot < 0; p++, b = (b + 4) & (HCAP - 1)) {
+      const u32x4_t t = *reinterpret_cast<const u32x4_t *>(tag + b);
+      const unsigned tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (slot >= 0) break;
+        unsigned cur = tv[j];
+        if (cur == HEMPTY) {
+          cur = atomicCAS(&tag[b + j], HEMPTY, want);
+          if (cur == HEMPTY) { create = true; slot = (int)(b + j); break; }
+        }
+        if ((cur & STMASK) == (unsigned)ds) { slot = (int)(b + j); break; }
       }
-      if ((cur & STMASK) == (unsigned)ds) { slot = (int)h; break; }
     }
   }
   if (slot >= 0) {
@@ -1082,6 +1095,7 @@ __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, in
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   gp<Ent> ent = uptr(s.ent);
   gp<i32x4> wt = uptr(s.w_tok);
+  gp<const i32x4> gst = (gp<const i32x4>)g.st, garcs = (gp<const i32x4>)g.arcs;      // (global, not generic: no FLAT accesses)
   const int w_tok_cap = s.w_tok_cap, front_cap = s.front_cap;
   for (int iter = 0;; iter++) {
     const int ncur = sh.fcnt[cur] < FCAP + front_cap ? sh.fcnt[cur] : FCAP + front_cap;
@@ -1097,7 +1111,7 @@ __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, in
       const int i = base + lane;
       const bool have = lane < CH && i < ncur;
       const int st = have ? front_get(sh, fcur, cur, i) : 0;
-      const i32x4 sr = g.st[st];
+      const i32x4 sr = gst[st];
       const float c = have ? map_cost(sh, ent, map_find(sh, st), st) : 0.0f;
       const bool exp = have && !(c > cutoff);
       const int a0 = sr.x, cnt = exp ? sr.y : 0;
@@ -1107,7 +1121,7 @@ __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, in
         bool create = false, push = false;
         int dsraw = 0, ds = 0, slot = -1;
         if (valid) {
-          const i32x4 arc = g.arcs[a];
+          const i32x4 arc = garcs[a];
           const float tot = cc + asf(arc.y);
           if (tot < cutoff) {
             dsraw = arc.x; ds = dsraw & STMASK;
@@ -1223,14 +1237,14 @@ __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, in
           else { const i32x4 rec = wt[e]; st = rec.x & STMASK; c = asf(rec.y); src = e; }
         }
         int a0 = 0, cnt = 0;
-        if (have) { const i32x4 sr = g.st[st]; a0 = sr.x; cnt = sr.y; }
+        if (have) { const i32x4 sr = gst[st]; a0 = sr.x; cnt = sr.y; }
         wave_expand(cnt, [&](bool valid, int owner, int j) {
           const int a = __shfl(a0, owner, 64) + j;
           const float cc = __shfl(c, owner, 64);
           const int so = __shfl(src, owner, 64);
           bool mk = false; int dtok = 0; i32x4 arc; float tot = 0.0f;
           if (valid) {
-            arc = g.arcs[a];
+            arc = garcs[a];
             tot = cc + asf(arc.y);
             if (tot < cutoff) {
               mk = true;
@@ -1323,6 +1337,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
   __syncthreads();
   const Slot &s = s_slot;
   const Pool &pool = s_pool;
+  gp<const i32x4> gst = (gp<const i32x4>)g.st, garcs = (gp<const i32x4>)g.arcs;      // (global, not generic: no FLAT accesses)
   const float INF = INFINITY;
   int par = 0, pp = 0;
 
@@ -1384,7 +1399,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
     {
       const unsigned ep = (unsigned)(0xFFFFFFFFu - (unsigned)(epoch_base + 0));
       if (tid == 0) {
-        const i32x4 sr = g.st[g.start];
+        const i32x4 sr = gst[g.start];
         int slot; bool create, improved;
         const int sraw = g.start | (sr.y > 0 ? EPSBIT : 0);
         map_relax(sh, gptr(s.ent), sraw, 0.0f, ep, slot, create, improved);
@@ -1538,7 +1553,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
           if (b < n) { const i32x4 t_ = tok[(lane < CH && i_ < n) ? i_ : 0]; if (lane < CH && i_ < n) { r_.x = t_.x; r_.y = t_.y; } }
           return r_;
         };
-        auto ld_st = [&](const i32x2 &r_) -> i32x4 { return g.st[(asf(r_.y) <= cur_cutoff) ? (r_.x & STMASK) : 0]; };
+        auto ld_st = [&](const i32x2 &r_) -> i32x4 { return gst[(asf(r_.y) <= cur_cutoff) ? (r_.x & STMASK) : 0]; };
         const int b0 = wave * CH;
         i32x2 recC = ld_tok(b0), recB = ld_tok(b0 + RS);
         i32x4 srC = ld_st(recC);
@@ -1564,7 +1579,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
               cc[u] = __shfl(c, owner[u], 64);
             }
 #pragma unroll
-            for (int u = 0; u < UA; u++) arc[u] = g.arcs[valid[u] ? a[u] : 0];
+            for (int u = 0; u < UA; u++) arc[u] = garcs[valid[u] ? a[u] : 0];
             P1STAMP(2)
 #pragma unroll
             for (int u = 0; u < UA; u++) sc[u] = cfg.acwt * llrow[valid[u] ? arc[u].z : 0];
@@ -1712,7 +1727,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       float bc = INF, bwf = INF; unsigned long long anyfinal = 0;
       for (int t = tb + tid; t < te; t += NT) {
         const i32x4 r = tok[t];
-        const float fc = asf(g.st[r.x & STMASK].w), c = asf(r.y);
+        const float fc = asf(gst[r.x & STMASK].w), c = asf(r.y);
         bc = fminf(bc, c); bwf = fminf(bwf, c + fc);
         anyfinal += fc != INF;
       }
@@ -1726,7 +1741,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       for (int iter = 0; iter < MAX_EPS_ITERS; iter++) {
         for (int t = tb + tid; t < te; t += NT) {
           const i32x4 r = tok[t];
-          const float fc = final_empty ? 0.0f : asf(g.st[r.x & STMASK].w);
+          const float fc = final_empty ? 0.0f : asf(gst[r.x & STMASK].w);
           const float x = asf(r.y) + fc - final_best;    // >= 0 by construction
           ((gp<int>)&tok[t])[3] = asi(x);
         }
@@ -1834,7 +1849,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
               const int st = r.x & STMASK;
               pool.tok_frame[o] = f; pool.tok_state[o] = st; pool.tok_cost[o] = asf(r.y); pool.tok_extra[o] = asf(r.z);
               float fin = INF;
-              if (f == F) fin = final_empty ? 0.0f : asf(g.st[st].w);
+              if (f == F) fin = final_empty ? 0.0f : asf(gst[st].w);
               pool.tok_final[o] = fin;
             }
           }
@@ -1853,9 +1868,9 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
               const int d = wave_alloc(&sh.flag, w);
               if (w) {
                 const long long o = loff + d;
-                const int il = g.arc_il[arc_id];
+                const int il = ((gp<const int>)g.arc_il)[arc_id];
                 pool.link_src[o] = a; pool.link_dst[o] = b;
-                pool.link_il[o] = il; pool.link_ol[o] = g.arcs[arc_id].w; pool.link_gr[o] = asf(L2.x);
+                pool.link_il[o] = il; pool.link_ol[o] = garcs[arc_id].w; pool.link_gr[o] = asf(L2.x);
                 pool.link_ac[o] = il != 0 ? asf(L2.y) - coff : asf(L2.y);
               }
             }
