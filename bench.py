@@ -193,10 +193,20 @@ def speech_model(args, lex, mf, post, ctx, device):
 
 
 def synth_lda(args):
-    """a 40 x 117 LDA+MLLT-like matrix (final.mat): orthonormal rows from a seeded Gaussian"""
-    rng = np.random.default_rng(77)
-    q, _ = np.linalg.qr(rng.standard_normal((117, 40)))
-    return np.ascontiguousarray(q.T, np.float32)
+    """a 40 x 117 LDA+MLLT-like matrix (final.mat) over 9 spliced frames of 13 cepstra.  Not a random projection (that throws
+    away two thirds of the information and the recogniser with it: WER 27 % against 5.5 %): the rows compute what a
+    discriminant projection of spliced frames mostly amounts to -- the centre frame, its first and second regression
+    derivatives (the delta windows of K/feat/feature-functions.cc:54-110 written as one linear map) -- plus the mean of C0
+    over the splice, so the recogniser works as well as with deltas and the kernels do the 117 -> 40 contraction."""
+    m = np.zeros((40, 9, 13), np.float32)
+    d1 = np.array([-2.0, -1.0, 0.0, 1.0, 2.0]) / 10.0
+    d2 = np.convolve(d1, d1)                      # 9 taps: offsets -4..4
+    for c in range(13):
+        m[c, 4, c] = 1.0
+        m[13 + c, 2:7, c] = d1
+        m[26 + c, :, c] = d2
+    m[39, :, 0] = 1.0 / 9.0
+    return np.ascontiguousarray(m.reshape(40, 117))
 
 
 def feature_space_model(args, sample_feats):
@@ -465,7 +475,9 @@ def determinize_measurement(args, dec, n_utt, T):
             "det_states_per_utt": out[3] / n_utt, "det_arcs_per_utt": out[4] / n_utt, "stopped_before_beam": int(out[5])}
 
 
-F64_MFMA_PEAK_TFLOPS = 78.6      # vendor figure for MI355X FP64 matrix (the micro-architecture guide lists no f64 row)
+F64_MFMA_PEAK_TFLOPS = 78.6      # vendor figure for MI355X FP64 matrix (the micro-architecture guide lists no f64 row): UNVERIFIED --
+F64_MFMA_MEASURED_TFLOPS = 47.6  # what tools/micro/mfma_f64_peak.hip sustains on the box (profiles/r02_mfma_f64_peak.json: independent
+                                 # v_mfma_f64_16x16x4_f64 chains on every SIMD)
 
 
 def ondemand_gmm_measurement(args, ctx, gmm, model, feats, T):
@@ -518,6 +530,8 @@ def fmllr_measurement(args, ctx, gmm, feats, foff, utt2spk, n_spk, T):
     gmm.lib.vbh_fmllr_work(gmm.dim, int(T), C.byref(b), C.byref(f))
     return {"kernel": "fmllr_accumulate_kernel", "bound": "mfma (f64)", "achieved": f.value / (best * 1e-3) / 1e12, "peak": F64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": f.value / (best * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, "kernel_ms": best, "algorithmic_flops": f.value,
+            "peak_note": "unverified vendor figure; measured with independent MFMA chains on every SIMD: %.1f TFLOP/s (profiles/r02_mfma_f64_peak.json)" % F64_MFMA_MEASURED_TFLOPS,
+            "frac_of_measured_peak": f.value / (best * 1e-3) / 1e12 / F64_MFMA_MEASURED_TFLOPS,
             "algorithmic_bytes": b.value, "speakers": int(n_spk), "frames": int(T), "count_check": float(beta.sum()),
             "note": "per-speaker G_d = sum_t b_t[d] x+ x+^T (lower-triangle tiles), K, beta for the whole batch; flops count the padded 48-row tiles issued"}
 
