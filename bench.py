@@ -67,10 +67,17 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=2,
                     help="search grids in flight: n contexts/streams whose decoders share one pool of search workspaces; the grid of one "
                          "batch drains while the next ones' workgroups fill the freed slots; 1 = one batch at a time")
+    ap.add_argument("--fe-cus", type=int, default=-1,
+                    help="confine the front end (MFCC, post, GMM) to this many CUs, the ones the searches do not use (-1: all the CUs the search mask leaves "
+                         "when batches overlap; 0: not confined, round 1's behaviour).  Unconfined, the GMM grid of the batch after next takes every CU a "
+                         "draining search grid frees -- short workgroups, three per CU, that keep coming -- and the next search's workgroups, which need a CU "
+                         "to themselves, start only when the GMM grid is through: consecutive searches did not overlap (r02 device timeline)")
     ap.add_argument("--search-cus", type=int, default=-1,
-                    help="confine the search contexts to this many CUs (0 = all, -1 = 7/8 of the device when batches are "
-                         "pipelined): the rest stays free for the front end of the batches ahead, which otherwise only "
-                         "runs while a search grid drains -- a persistent search workgroup owns its CU's whole LDS")
+                    help="confine the search contexts to this many CUs with a CU-masked stream (0 or -1 = not confined, the default since r02). "
+                         "Round 1 kept 1/8 of the CUs free for the front end of the batches ahead, which otherwise only runs while a search grid "
+                         "drains (a persistent search workgroup owns its CU's whole LDS); that paid when utterance times spread 1:5.  With the speech "
+                         "workload's even utterance times the drain is short, the front end (90 ms of full-chip work per batch) fits into it, and a "
+                         "mask of 224 CUs turned out to give the searches ~200 (device timeline): 2.50 M frames/s unmasked against 2.25 M masked")
     ap.add_argument("--no-determinize", action="store_true",
                     help="skip the second timed region, in which the host stage that follows every search in the reference's gmm-latgen-faster "
                          "(lattice determinization) is part of the step: a pool of host threads determinizes the lattices of batch k while the GPU "
@@ -576,7 +583,14 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from voicebridge_amd import api
-    ctx = api.Context(local_rank)
+    depth_ = max(1, args.pipeline) if not args.no_decode else 1
+    ncu_ = torch.cuda.get_device_properties(local_rank).multi_processor_count
+    if args.search_cus < 0:
+        args.search_cus = 0          # (r02: not masked; round 1 masked the searches to 7/8 of the CUs, see --search-cus)
+    if args.fe_cus < 0:
+        args.fe_cus = 0
+    ctx_full = api.Context(local_rank)                 # set-up and the kernels timed alone on the chip
+    ctx = api.Context(local_rank, cus=args.fe_cus, first_cu=args.search_cus) if args.fe_cus > 0 else ctx_full      # the front end of the step
     dev = ctx.device
     cdev = torch.device("cpu") if backend == "gloo" else dev        # where the tensors of the collectives live
 
@@ -774,9 +788,6 @@ def main():
     class Lane:
         pass
     depth = max(1, args.pipeline) if dec is not None else 1
-    if args.search_cus < 0:
-        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
-        args.search_cus = (ncu * 7 // 8) if depth > 1 else 0
     # ---- slices of a step: contiguous ranges of whole speakers
     S = max(1, args.sub_batches)
     if args.batch % (S * UTT_PER_SPK) != 0:
@@ -888,6 +899,8 @@ def main():
     det_pool = DetPool(args) if (dec_enabled and not args.no_determinize) else None
     det_on = [False]         # the headline region times the GPU path (SURVEY.md 8 a-e); a second region adds the host lattice stage
 
+    tl_dump = []
+
     def finish(L):
         """complete the lane's search in flight: lattices on the host, times collected"""
         if L.pending:
@@ -906,6 +919,8 @@ def main():
                     col_tl[sl_.a + u] = L.dec.timeline(u)
                 for k_, v_ in L.dec.batch_stats().items():
                     col_stats[k_] += v_
+            if L.timed and os.environ.get("VBH_BENCH_TIMELINE"):      # diagnostic: device timestamps of every utterance of every timed batch
+                tl_dump.append(np.array([L.dec.timeline(u) for u in range(per)], np.int64))
             if L.timed:
                 tm = L.dec.times()      # HIP events around the search kernel on its stream + host clocks
                 dec_ms.append(tm["total_ms"]); dec_k_ms.append(tm["kernel_ms"])
@@ -989,22 +1004,28 @@ def main():
     # after the timed region: the GMM kernel alone on the whole chip (in the pipeline it shares the
     # CUs with the search grids, so its in-pipeline duration says little about the kernel itself)
     n_rows0 = slices[0].r1 - slices[0].r0
+    # (with the front end's context confined to a few CUs these measurements get objects of their own on an unconfined context)
+    ctx.sync()
+    if ctx_full is not ctx:
+        gmm_m, mf_m = api.DiagGmm(ctx_full, *model), api.Mfcc(ctx_full)
+    else:
+        gmm_m, mf_m = gmm, mf
     gmm_alone_ms = None
     for _ in range(3):
-        ctx.timer_start(0)
-        gmm.loglikes(ring[0][1][:n_rows0], out=ring[0][2][:n_rows0])
-        ctx.timer_stop(0)
-        ctx.sync()
-        t_ = ctx.timer_ms(0) * (T / float(n_rows0))          # (scaled to the step's frame count when the step runs in slices)
+        ctx_full.timer_start(0)
+        gmm_m.loglikes(ring[0][1][:n_rows0], out=ring[0][2][:n_rows0])
+        ctx_full.timer_stop(0)
+        ctx_full.sync()
+        t_ = ctx_full.timer_ms(0) * (T / float(n_rows0))          # (scaled to the step's frame count when the step runs in slices)
         gmm_alone_ms = t_ if gmm_alone_ms is None else min(gmm_alone_ms, t_)
     # the MFCC kernel alone on the whole chip, the same way (its share of the pipelined step says little about the kernel)
     mfcc_alone_ms = None
     for _ in range(3):
-        ctx.timer_start(0)
-        mf.compute_packed(slices[0].wave, slices[0].woff, is_i16, out=ring[0][0][:n_rows0])
-        ctx.timer_stop(0)
-        ctx.sync()
-        t_ = ctx.timer_ms(0) * (T / float(n_rows0))
+        ctx_full.timer_start(0)
+        mf_m.compute_packed(slices[0].wave, slices[0].woff, is_i16, out=ring[0][0][:n_rows0])
+        ctx_full.timer_stop(0)
+        ctx_full.sync()
+        t_ = ctx_full.timer_ms(0) * (T / float(n_rows0))
         mfcc_alone_ms = t_ if mfcc_alone_ms is None else min(mfcc_alone_ms, t_)
     if dec_enabled:
         dec = lanes[(S - 1) % depth].dec                 # holds the lattices of the collection step's last slice
@@ -1115,11 +1136,11 @@ def main():
                     "copy_out_seconds_on_the_step_thread": det_pool.submit_s, "raw_arcs_per_utt": float(tt[2]) / max(nb, 1),
                     "det_arcs_per_utt": float(tt[4]) / max(nb, 1), "stopped_before_beam": int(tt[5])}
             try:
-                extra["gmm_on_demand"] = ondemand_gmm_measurement(args, ctx, gmm, model, ring[0][1][:n_rows0], n_rows0)
+                extra["gmm_on_demand"] = ondemand_gmm_measurement(args, ctx_full, gmm_m, model, ring[0][1][:n_rows0], n_rows0)
             except Exception as e:
                 extra["gmm_on_demand"] = {"error": str(e)}
             try:
-                extra["roofline_fmllr_stats"] = fmllr_measurement(args, ctx, gmm, ring[0][1][:n_rows0], slices[0].foff, slices[0].u2s,
+                extra["roofline_fmllr_stats"] = fmllr_measurement(args, ctx_full, gmm_m, ring[0][1][:n_rows0], slices[0].foff, slices[0].u2s,
                                                                   int(slices[0].u2s.max()) + 1, n_rows0)
             except Exception as e:        # a measurement beside the step, never a reason to lose the bench line
                 extra["roofline_fmllr_stats"] = {"error": str(e)}
@@ -1142,7 +1163,7 @@ def main():
                                     % (args.beam, args.lattice_beam, args.max_active, graph.num_states, graph.num_arcs)),
                        "utterances_per_step_per_gpu": args.batch, "utterance_seconds": args.seconds,
                        "frames_per_step_per_gpu": T, "pdfs": gmm.num_pdfs, "gaussians": gmm.num_gauss, "dim": gmm.dim, "features": args.feat,
-                       "batches_in_flight": depth, "slices_per_step": S, "search_cus": args.search_cus,
+                       "batches_in_flight": depth, "slices_per_step": S, "search_cus": args.search_cus, "front_end_cus": args.fe_cus,
                        "lattices": "raw (state level) in the headline region; determinized on the host in the second region (lattice_stage_in_step)",
                        "sharding": "utterances over ranks, no data-path collective"},
             "roofline": roof, "stage_ms": stage_ms,
@@ -1202,6 +1223,8 @@ def main():
                     wg_ = vdist.score([truth[u] for u in us_], [col_words[u] for u in us_])
                     out["parity_wer_on_the_cpu_sample"] = {"reference_percent": 100.0 * wr_[0] / max(wr_[1], 1), "gpu_percent": 100.0 * wg_[0] / max(wg_[1], 1),
                                                            "words": int(wr_[1]), "utterances": len(us_)}
+    if tl_dump and os.environ.get("VBH_BENCH_TIMELINE"):
+        np.save(os.environ["VBH_BENCH_TIMELINE"], np.stack(tl_dump))
     if det_pool is not None:
         det_pool.close()
     # tear down in order: decoders before their contexts (and before the interpreter's own finalisation)
