@@ -1060,7 +1060,7 @@ def main():
         value = total_frames / dt
         b, f = gmm.work(T)
         g_ms = float(np.mean(gmm_ms))
-        gmm_roof = {"kernel": "gmm_loglikes_kernel", "bound": "mfma", "achieved": f / (g_ms * 1e-3) / 1e12,
+        gmm_roof = {"kernel": "gmm_rows_kernel", "bound": "mfma", "achieved": f / (g_ms * 1e-3) / 1e12,
                     "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f / (g_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                     "traffic": None, "kernel_ms": g_ms, "algorithmic_flops": f, "algorithmic_bytes": b,
                     "hbm_GBs": b / (g_ms * 1e-3) / 1e9, "hbm_frac": b / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
