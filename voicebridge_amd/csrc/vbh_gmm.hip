@@ -28,6 +28,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstring>
+#include <mutex>
 
 namespace {
 
@@ -454,6 +456,12 @@ struct vbh_gmm {
   // plain row-major copies for the kernels that walk single pdfs (fMLLR statistics, vbh_fmllr.hip)
   DevBuf<float> d_miv, d_iv, d_gconsts;   // [G x D], [G x D], [G]
   DevBuf<int> d_pdf_offs;                 // [P+1]
+  // work buffers of vbh_gmm_loglikes_pairs, kept across calls (they only grow): a call is one pinned-staged upload of the pair lists,
+  // the kernel, one download -- no allocation once the largest job has been seen
+  DevBuf<long long> pr_off; DevBuf<int> pr_pdf; DevBuf<float> pr_out;
+  char *pr_pin = nullptr; size_t pr_pin_bytes = 0;
+  std::mutex pr_mu;
+  ~vbh_gmm() { if (pr_pin) (void)hipHostFree(pr_pin); }
 };
 
 void vbh_gmm_view_get(const vbh_gmm *g, vbh_gmm_view *v) {
@@ -633,16 +641,32 @@ int vbh_gmm_loglikes_pairs(vbh_gmm *g, const float *d_feats, int64_t T, const in
   for (long long q = 0; q < n; q++) VBH_CHECK(h_pair_pdf[q] >= 0 && h_pair_pdf[q] < g->P, "vbh_gmm_loglikes_pairs: pdf-id out of range");
   if (vbh_use_device(g->ctx)) return -1;
   hipStream_t st = g->ctx->stream;
-  DevBuf<long long> d_off; DevBuf<int> d_pdf; DevBuf<float> d_out;
   static_assert(sizeof(long long) == sizeof(int64_t), "int64");
-  if (d_off.upload(reinterpret_cast<const long long *>(h_pair_offsets), (size_t)T + 1, st) || d_pdf.upload(h_pair_pdf, (size_t)n, st) || d_out.alloc((size_t)n)) return -1;
+  std::lock_guard<std::mutex> lk(g->pr_mu);
+  // device buffers and the pinned staging area grow to the largest call seen and stay
+  if (g->pr_off.n < (size_t)T + 1 && g->pr_off.alloc(((size_t)T + 1) * 5 / 4 + 16)) return -1;
+  if (g->pr_pdf.n < (size_t)n && g->pr_pdf.alloc((size_t)n * 5 / 4 + 16)) return -1;
+  if (g->pr_out.n < (size_t)n && g->pr_out.alloc((size_t)n * 5 / 4 + 16)) return -1;
+  const size_t off_b = sizeof(long long) * ((size_t)T + 1), pdf_b = sizeof(int) * (size_t)n, out_b = sizeof(float) * (size_t)n;
+  const size_t need = off_b + pdf_b + out_b;
+  if (g->pr_pin_bytes < need) {
+    if (g->pr_pin) (void)hipHostFree(g->pr_pin);
+    g->pr_pin = nullptr; g->pr_pin_bytes = 0;
+    VBH_HIP(hipHostMalloc(reinterpret_cast<void **>(&g->pr_pin), need * 5 / 4 + 4096, hipHostMallocDefault));
+    g->pr_pin_bytes = need * 5 / 4 + 4096;
+  }
+  memcpy(g->pr_pin, h_pair_offsets, off_b);
+  memcpy(g->pr_pin + off_b, h_pair_pdf, pdf_b);
+  VBH_HIP(hipMemcpyAsync(g->pr_off.p, g->pr_pin, off_b, hipMemcpyHostToDevice, st));
+  VBH_HIP(hipMemcpyAsync(g->pr_pdf.p, g->pr_pin + off_b, pdf_b, hipMemcpyHostToDevice, st));
   const long long blocks = (T + 3) / 4;
   VBH_CHECK(blocks < 2147483647LL, "vbh_gmm_loglikes_pairs: T too large");
-  hipLaunchKernelGGL(gmm_loglikes_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_feats, (long long)T, g->D, d_off.p, d_pdf.p, g->d_pdf_offs.p,
-                     g->d_gconsts.p, g->d_miv.p, g->d_iv.p, d_out.p);
+  hipLaunchKernelGGL(gmm_loglikes_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_feats, (long long)T, g->D, g->pr_off.p, g->pr_pdf.p, g->d_pdf_offs.p,
+                     g->d_gconsts.p, g->d_miv.p, g->d_iv.p, g->pr_out.p);
   VBH_HIP(hipGetLastError());
-  VBH_HIP(hipMemcpyAsync(h_out, d_out.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, st));
-  VBH_HIP(hipStreamSynchronize(st));
+  VBH_HIP(hipMemcpyAsync(g->pr_pin + off_b + pdf_b, g->pr_out.p, out_b, hipMemcpyDeviceToHost, st));
+  VBH_HIP(hipStreamSynchronize(st));      // (the scores are the call's result: the one synchronisation it needs)
+  memcpy(h_out, g->pr_pin + off_b + pdf_b, out_b);
   return 0;
 }
 
