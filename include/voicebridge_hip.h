@@ -315,6 +315,11 @@ typedef struct vbh_best_path {    /* GetBestPath + GetLinearSymbolSequence (fast
   int32_t num_words; const int32_t *words;
   float best_graph, best_acoustic;           /* LatticeWeight of the path (acoustic still scaled) */
   int64_t n_tokens;                          /* tokens created (diagnostic) */
+  /* the path arc by arc, as GetBestPath builds its linear lattice before RemoveEpsLocal (faster-decoder.cc:113-141): labels of the
+   * graph arc, graph cost = its weight, acoustic cost = (float)(token cost - previous token's cost) - graph cost (still scaled);
+   * final_graph: the final cost of the last state when the path ends in a final state (reached_final), else 0 */
+  int32_t num_arcs; const int32_t *arc_ilabel; const int32_t *arc_olabel; const float *arc_graph; const float *arc_acoustic;
+  float final_graph;
 } vbh_best_path;
 /* pointers stay valid until the next vbh_faster_decode_batch / destroy on this decoder */
 int vbh_faster_decoder_result(vbh_faster_decoder *d, int32_t utt, vbh_best_path *out);

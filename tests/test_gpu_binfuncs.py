@@ -188,15 +188,28 @@ def test_gmm_decode_faster_vs_reference_program(host, tmp_path):
                                         "ark,t:%s" % (d / "words.txt"), "ark,t:%s" % (d / "ali.txt")], log)
     assert rc == 0, open(log).read()
     assert "Overall log-likelihood per frame" in open(log).read()
-    # the linear-lattice output is not part of this build: refused loudly
-    assert call(host.vb_GmmDecodeFaster, ["gmm-decode-faster", str(d / "final.mdl"), str(d / "HCLG.fst"), "ark:%s" % (d / "feats.ark"),
-                                          "ark,t:%s" % (d / "w2.txt"), "ark,t:%s" % (d / "a2.txt"), "ark:%s" % (d / "lat.ark")], log) == -1
+    # the 6th argument: the best path as a CompactLattice (GetBestPath's linear lattice after RemoveEpsLocal, acoustic costs un-scaled)
+    assert call(host.vb_GmmDecodeFaster, ["gmm-decode-faster"] + opts + [str(d / "final.mdl"), str(d / "HCLG.fst"), "ark:%s" % (d / "feats.ark"),
+                                          "ark,t:%s" % (d / "w2.txt"), "ark,t:%s" % (d / "a2.txt"), "ark:%s" % (d / "lat.ark")], log) == 0, open(log).read()
     mine_w, mine_a = (d / "words.txt").read_text(), (d / "ali.txt").read_text()
+    assert (d / "w2.txt").read_text() == mine_w and (d / "a2.txt").read_text() == mine_a
+    from tests import util
+    lats = util.read_lattice_ark(str(d / "lat.ark"))
+    ali_of = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in mine_a.splitlines()}
+    words_of = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in mine_w.splitlines()}
+    for k, (_typ, _start, states) in lats.items():
+        # a linear chain whose arcs spell the words and whose strings concatenate to the alignment
+        labels = [a[0] for st in states for a in st[1] if a[0] != 0]
+        tids = [t for st in states for a in st[1] for t in a[3]] + [t for st in states for t in st[0][2]]
+        assert labels == words_of[k] and tids == ali_of[k], k
+        assert all(len(st[1]) <= 1 for st in states)
     if have_ref("gmm-decode-faster"):
         ref("gmm-decode-faster", *opts, str(d / "final.mdl"), str(d / "HCLG.fst"), "ark:%s" % (d / "feats.ark"),
-            "ark,t:%s" % (d / "r_words.txt"), "ark,t:%s" % (d / "r_ali.txt"))
+            "ark,t:%s" % (d / "r_words.txt"), "ark,t:%s" % (d / "r_ali.txt"), "ark:%s" % (d / "r_lat.ark"))
         assert mine_w.split() == (d / "r_words.txt").read_text().split()
         assert mine_a.split() == (d / "r_ali.txt").read_text().split()
+        from tests.test_host_lattice import assert_same_archives
+        assert_same_archives(str(d / "lat.ark"), str(d / "r_lat.ark"), rtol=2e-4, atol=2e-2)
     else:
         assert "uttA" in mine_w and "uttA" in mine_a
 

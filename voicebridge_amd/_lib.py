@@ -65,7 +65,9 @@ class FasterCfg(C.Structure):
 class BestPath(C.Structure):
     _fields_ = [("ok", C.c_int32), ("reached_final", C.c_int32), ("num_frames", C.c_int32),
                 ("num_ali", C.c_int32), ("ali", C.POINTER(C.c_int32)), ("num_words", C.c_int32), ("words", C.POINTER(C.c_int32)),
-                ("best_graph", C.c_float), ("best_acoustic", C.c_float), ("n_tokens", C.c_int64)]
+                ("best_graph", C.c_float), ("best_acoustic", C.c_float), ("n_tokens", C.c_int64),
+                ("num_arcs", C.c_int32), ("arc_ilabel", C.POINTER(C.c_int32)), ("arc_olabel", C.POINTER(C.c_int32)),
+                ("arc_graph", C.POINTER(C.c_float)), ("arc_acoustic", C.POINTER(C.c_float)), ("final_graph", C.c_float)]
 
 
 class Lattice(C.Structure):

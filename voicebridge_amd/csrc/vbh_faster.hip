@@ -791,7 +791,7 @@ struct vbh_faster_decoder {
   std::vector<FSlot> h_slots;
   DevBuf<FSlot> d_slots;
   std::vector<void *> allocs;
-  struct Out { std::vector<int32_t> ali, words; vbh_best_path view; };
+  struct Out { std::vector<int32_t> ali, words, arc_il, arc_ol; std::vector<float> arc_gr, arc_ac; vbh_best_path view; };
   std::vector<Out> results;
 };
 
@@ -936,6 +936,8 @@ static int faster_decode_batch_impl(vbh_faster_decoder *d, const float *d_loglik
     vbh_faster_decoder::Out &o = d->results[u];
     // GetBestPath (:87-147): arcs from the start, (graph, acoustic) = (weight, tot - weight) summed in path order
     float t1 = 0.0f, t2 = 0.0f;
+    o.ali.clear(); o.words.clear();        // (a decoder is used for batch after batch)
+    o.arc_il.clear(); o.arc_ol.clear(); o.arc_gr.clear(); o.arc_ac.clear();
     for (int i = res[u].path_len - 1; i >= 0; i--) {
       const i32x4 a = paths[u][i];
       const int gb = a.z, tb = a.w;
@@ -945,6 +947,7 @@ static int faster_decode_batch_impl(vbh_faster_decoder *d, const float *d_loglik
       t1 = graph_cost + t1; t2 = ac_cost + t2;
       if (a.x != 0) o.ali.push_back(a.x);
       if (a.y != 0) o.words.push_back(a.y);
+      o.arc_il.push_back(a.x); o.arc_ol.push_back(a.y); o.arc_gr.push_back(graph_cost); o.arc_ac.push_back(ac_cost);
     }
     if (res[u].ok && res[u].reached_final) t1 = res[u].final_cost + t1;
     vbh_best_path &v = o.view;
@@ -953,6 +956,9 @@ static int faster_decode_batch_impl(vbh_faster_decoder *d, const float *d_loglik
     v.num_ali = (int)o.ali.size(); v.ali = o.ali.data(); v.num_words = (int)o.words.size(); v.words = o.words.data();
     v.best_graph = res[u].ok ? t1 : 0.0f; v.best_acoustic = res[u].ok ? t2 : 0.0f;
     v.n_tokens = res[u].n_tokens;
+    v.num_arcs = (int)o.arc_il.size(); v.arc_ilabel = o.arc_il.data(); v.arc_olabel = o.arc_ol.data();
+    v.arc_graph = o.arc_gr.data(); v.arc_acoustic = o.arc_ac.data();
+    v.final_graph = (res[u].ok && res[u].reached_final) ? res[u].final_cost : 0.0f;
   }
   return 0;
 }

@@ -918,7 +918,41 @@ int CopyFeats(int argc, char *argv[], std::ofstream &file_log) {
 // gmm-decode-faster (K/gmmbin/gmm-decode-faster.cc:67-211; the VoiceBridge DLL does not wrap this
 // program, so the upstream argv grammar and return convention are kept as they are):
 //   gmm-decode-faster [options] model-in fst-in features-rspecifier words-wspecifier [alignments-wspecifier [lattice-wspecifier]]
-// The linear-lattice output (6th argument) is not written by this build.
+// The 6th argument: the best path as a CompactLattice, built as the program builds it (:174-181): GetBestPath's linear lattice after
+// RemoveEpsLocal (K/decoder/faster-decoder.cc:113-146, K/fstext/remove-eps-local-inl.h), acoustic costs un-scaled, ConvertLattice.
+namespace {
+// RemoveEpsLocal on a linear chain: every interior state has one arc in and one out, so only the reference's "pattern 2" applies
+// (remove-eps-local-inl.h:229-283) and, visiting the states in order, it merges an arc with the arcs behind it for as long as the
+// labels do not clash (CanCombineArcs :60-68: not two non-zero ilabels, not two non-zero olabels; the weights multiply, left to
+// right); a trailing arc without labels folds into the final weight (CanCombineFinal :70-76).
+vblat::Lattice LinearBestPathLattice(const vbh_best_path &bp) {
+  std::vector<vblat::Arc> groups;
+  int i = 0;
+  while (i < bp.num_arcs) {
+    vblat::Arc cur{bp.arc_ilabel[i], bp.arc_olabel[i], vblat::Weight{bp.arc_graph[i], bp.arc_acoustic[i]}, 0};
+    i++;
+    while (i < bp.num_arcs && !(cur.ilabel != 0 && bp.arc_ilabel[i] != 0) && !(cur.olabel != 0 && bp.arc_olabel[i] != 0)) {
+      cur.w = vblat::Times(cur.w, vblat::Weight{bp.arc_graph[i], bp.arc_acoustic[i]});
+      if (cur.ilabel == 0) cur.ilabel = bp.arc_ilabel[i];
+      if (cur.olabel == 0) cur.olabel = bp.arc_olabel[i];
+      i++;
+    }
+    groups.push_back(cur);
+  }
+  vblat::Weight fin = bp.reached_final ? vblat::Weight{bp.final_graph, 0.0f} : vblat::One();
+  if (!groups.empty() && groups.back().ilabel == 0 && groups.back().olabel == 0) {      // (a path without a single label)
+    fin = vblat::Times(groups.back().w, fin);
+    groups.pop_back();
+  }
+  vblat::Lattice lat;
+  lat.start = 0;
+  lat.st.resize(groups.size() + 1);
+  for (size_t k = 0; k < groups.size(); k++) { groups[k].next = (int32_t)k + 1; lat.st[k].arcs.push_back(groups[k]); }
+  lat.st.back().final = fin;
+  return lat;
+}
+}  // namespace
+
 int GmmDecodeFaster(int argc, char *argv[], std::ofstream &file_log) {
   return Guard("gmm-decode-faster", &file_log, [&](Log &log) -> int {
     Options po;
@@ -926,8 +960,6 @@ int GmmDecodeFaster(int argc, char *argv[], std::ofstream &file_log) {
              "allow-partial", "decode-batch"});
     po.Parse(argc, argv);
     if (po.args.size() < 4 || po.args.size() > 6) throw ApiError("wrong arguments.");
-    if (po.args.size() == 6 && !po.args[5].empty())
-      throw ApiError("the linear-lattice output of gmm-decode-faster is not part of this build (use gmm-latgen-faster)");
     vbh_faster_cfg cfg;
     vbh_faster_cfg_default(&cfg);
     // FasterDecoderOptions defaults (K/decoder/faster-decoder.h:38-43), program default acoustic scale 0.1 (:79)
@@ -985,6 +1017,8 @@ int GmmDecodeFaster(int argc, char *argv[], std::ofstream &file_log) {
                            reinterpret_cast<const vbh_arc *>(graph.arcs.data()), &g), "vbh_graph_create");
     vbio::IntVectorWriter words_writer(po.args[3]), ali_writer;
     if (po.args.size() >= 5 && !po.args[4].empty()) ali_writer.Open(po.args[4]);
+    vbio::CompactLatticeWriter clat_writer;
+    if (po.args.size() == 6 && !po.args[5].empty()) clat_writer.Open(po.args[5]);
     const int batch_utts = (int)po.Num("decode-batch", 256);
     vbio::MatrixReader reader(po.args[2]);
     double tot_like = 0.0;
@@ -1062,6 +1096,13 @@ int GmmDecodeFaster(int argc, char *argv[], std::ofstream &file_log) {
           frame_count += nrows;
           words_writer.Write(utt, std::vector<int32_t>(bp.words, bp.words + bp.num_words));
           if (ali_writer.IsOpen()) ali_writer.Write(utt, std::vector<int32_t>(bp.ali, bp.ali + bp.num_ali));
+          if (clat_writer.IsOpen()) {          // "We'll write the lattice without acoustic scaling." (:175-181)
+            vblat::Lattice lat = LinearBestPathLattice(bp);
+            if (cfg.acoustic_scale != 0.0f) vblat::ScaleLattice(1.0, 0.0, 0.0, 1.0 / (double)cfg.acoustic_scale, &lat);
+            vblat::CompactLattice clat;
+            vblat::ConvertLattice(lat, &clat);
+            clat_writer.Write(utt, clat);
+          }
           const double like = -(double)bp.best_graph - (double)bp.best_acoustic;
           tot_like += like;
           log.os() << "LOG (gmm-decode-faster) Log-like per frame for utterance " << utt << " is " << (like / nrows) << " over " << nrows << " frames.\n";
