@@ -244,3 +244,34 @@ def test_score_kaldi_wer_on_golden_lattices(host, tmp_path):
     # a missing lattice file is an error
     os.remove(dec / "lat.1")
     assert host.vb_ScoreKaldiWER(str(data).encode(), str(graph).encode(), str(dec).encode(), 2, b"0.0", 8, 8) == -1
+
+
+def test_text_mode_lattice_archives(host, tmp_path):
+    """"ark,t:" lattice tables (K/lat/kaldi-lattice.cc:62-90,94-262,388-415): what this build writes is what the reference's lattice-copy
+    writes, byte for byte, and both read each other's text the same way -- CompactLattice and state-level Lattice entries"""
+    have = all(os.access(os.path.join(REFBIN, b), os.X_OK) for b in ("lattice-copy", "lattice-determinize-pruned"))
+    if not have:
+        pytest.skip("oracle/_ref/bin not built here")
+    d = tmp_path
+    o = unpack_golden(d)
+    p = lambda n: str(d / n)
+    log = p("log.txt")
+
+    def ref(*a):
+        r = subprocess.run([os.path.join(REFBIN, a[0])] + list(a[1:]), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-400:]
+    # ---- CompactLattice: write
+    assert call(host.vb_LatticeScale, ["lattice-scale", "--inv-acoustic-scale=1", "ark:" + p("det_pp.ark"), "ark,t:" + p("m_c.txt")], log) == 0, open(log).read()
+    ref("lattice-copy", "ark:" + p("det_pp.ark"), "ark,t:" + p("r_c.txt"))
+    assert open(p("m_c.txt")).read() == open(p("r_c.txt")).read()
+    assert "\t" in open(p("m_c.txt")).read() and "_" in open(p("m_c.txt")).read()
+    # ---- CompactLattice: read (the text has 6 significant digits, so compare reader with reader)
+    assert call(host.vb_LatticeScale, ["lattice-scale", "--inv-acoustic-scale=1", "ark,t:" + p("r_c.txt"), "ark:" + p("m_c.ark")], log) == 0, open(log).read()
+    ref("lattice-copy", "ark,t:" + p("r_c.txt"), "ark:" + p("r_c.ark"))
+    assert_same_archives(p("m_c.ark"), p("r_c.ark"))
+    # ---- state-level Lattice entries: read (lattice-determinize-pruned takes either kind) and write
+    ref("lattice-copy", "--write-compact=false", "ark:" + p("raw.ark"), "ark,t:" + p("r_l.txt"))
+    acwt, beam = "--acoustic-scale=%s" % o["acwt"], "--beam=%s" % o["beam"]
+    assert call(host.vb_LatticeDeterminizePruned, ["lattice-determinize-pruned", acwt, beam, "ark,t:" + p("r_l.txt"), "ark:" + p("m_l.ark")], log) == 0, open(log).read()
+    ref("lattice-determinize-pruned", acwt, beam, "ark,t:" + p("r_l.txt"), "ark:" + p("r_l.ark"))
+    assert_same_archives(p("m_l.ark"), p("r_l.ark"))

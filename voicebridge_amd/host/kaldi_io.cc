@@ -793,7 +793,6 @@ void ReadFst(const std::string &path, Graph *g) {
 
 void LatticeWriter::Open(const std::string &wspecifier) {
   spec_ = ParseWspecifier(wspecifier);
-  if (spec_.text) Fail("text-mode lattice output is not supported");
   ark_.open(spec_.ark_path, std::ios::binary);
   if (!ark_) Fail("cannot open " + spec_.ark_path + " for writing");
   open_ = true;
@@ -855,9 +854,74 @@ void SerializeLattice(const vblat::CompactLattice &clat, std::string *b) {
   }
 }
 
+// Text form of a lattice entry ("ark,t:"), as the reference prints it (K/lat/kaldi-lattice.cc:62-90,388-415: a newline after the key,
+// OpenFst's FstPrinter -- the start state first, then the others in order; per arc "state next ilabel [olabel] [weight]" with tabs, the
+// weight left out when it is One; per final state (or state without arcs) "state [weight]" -- and an empty line at the end).  Weights:
+// "graph,acoustic" resp. "graph,acoustic,tid_tid_..." with the stream's default float format (%g, 6 digits; K/fstext/lattice-weight.h).
+namespace {
+void PutTextFloat(std::string *t, float f) {
+  if (f == std::numeric_limits<float>::infinity()) { *t += "Infinity"; return; }
+  if (f == -std::numeric_limits<float>::infinity()) { *t += "-Infinity"; return; }
+  if (f != f) { *t += "BadNumber"; return; }
+  char b[48];
+  snprintf(b, sizeof(b), "%g", (double)f);
+  *t += b;
+}
+void PutTextWeight(std::string *t, const vblat::Weight &w) { PutTextFloat(t, w.v1); *t += ','; PutTextFloat(t, w.v2); }
+void PutTextCWeight(std::string *t, const vblat::CWeight &w) {
+  PutTextWeight(t, w.w);
+  *t += ',';
+  for (size_t i = 0; i < w.str.size(); i++) { if (i) *t += '_'; *t += std::to_string(w.str[i]); }
+}
+bool TxtIsOne(const vblat::Weight &w) { return w.v1 == 0.0f && w.v2 == 0.0f; }
+bool TxtIsZero(const vblat::Weight &w) { return w.v1 == std::numeric_limits<float>::infinity() && w.v2 == std::numeric_limits<float>::infinity(); }
+}  // namespace
+std::string LatticeObjectToText(const std::string &object) {
+  vblat::Lattice lat; vblat::CompactLattice clat; bool compact = false;
+  ParseLatticeBytes(object.data(), object.size(), &lat, &clat, &compact);
+  std::string t = "\n";
+  const int32_t start = compact ? clat.start : lat.start;
+  const int32_t ns = (int32_t)(compact ? clat.st.size() : lat.st.size());
+  auto print_state = [&](int32_t s) {
+    bool output = false;
+    if (!compact) {
+      const vblat::State &st = lat.st[s];
+      for (const vblat::Arc &a : st.arcs) {
+        t += std::to_string(s); t += '\t'; t += std::to_string(a.next); t += '\t'; t += std::to_string(a.ilabel); t += '\t'; t += std::to_string(a.olabel);
+        if (!TxtIsOne(a.w)) { t += '\t'; PutTextWeight(&t, a.w); }
+        t += '\n'; output = true;
+      }
+      if (!TxtIsZero(st.final) || !output) {
+        t += std::to_string(s);
+        if (!TxtIsOne(st.final)) { t += '\t'; PutTextWeight(&t, st.final); }
+        t += '\n';
+      }
+    } else {
+      const vblat::CState &st = clat.st[s];
+      for (const vblat::CArc &a : st.arcs) {
+        t += std::to_string(s); t += '\t'; t += std::to_string(a.next); t += '\t'; t += std::to_string(a.label);
+        if (!(TxtIsOne(a.w.w) && a.w.str.empty())) { t += '\t'; PutTextCWeight(&t, a.w); }
+        t += '\n'; output = true;
+      }
+      if (!TxtIsZero(st.final.w) || !output) {
+        t += std::to_string(s);
+        if (!(TxtIsOne(st.final.w) && st.final.str.empty())) { t += '\t'; PutTextCWeight(&t, st.final); }
+        t += '\n';
+      }
+    }
+  };
+  if (start >= 0 && start < ns) {
+    print_state(start);
+    for (int32_t s = 0; s < ns; s++) if (s != start) print_state(s);
+  }
+  t += '\n';
+  return t;
+}
+
 void LatticeWriter::WriteSerialized(const std::string &key, const std::string &object) {
   ark_ << key << ' ';
-  ark_.write(object.data(), (std::streamsize)object.size());
+  if (spec_.text) { const std::string t = LatticeObjectToText(object); ark_.write(t.data(), (std::streamsize)t.size()); }
+  else ark_.write(object.data(), (std::streamsize)object.size());
   if (ark_.fail()) Fail("write failure on " + spec_.ark_path);
 }
 void LatticeWriter::Write(const std::string &key, const LatticeOut &lat) {
@@ -869,14 +933,14 @@ void LatticeWriter::Write(const std::string &key, const vblat::Lattice &lat) {
 
 void CompactLatticeWriter::Open(const std::string &wspecifier) {
   spec_ = ParseWspecifier(wspecifier);
-  if (spec_.text) Fail("text-mode lattice output is not supported");
   ark_.open(spec_.ark_path, std::ios::binary);
   if (!ark_) Fail("cannot open " + spec_.ark_path + " for writing");
   open_ = true;
 }
 void CompactLatticeWriter::WriteSerialized(const std::string &key, const std::string &object) {
   ark_ << key << ' ';
-  ark_.write(object.data(), (std::streamsize)object.size());
+  if (spec_.text) { const std::string t = LatticeObjectToText(object); ark_.write(t.data(), (std::streamsize)t.size()); }
+  else ark_.write(object.data(), (std::streamsize)object.size());
   if (ark_.fail()) Fail("write failure on " + spec_.ark_path);
 }
 void CompactLatticeWriter::Write(const std::string &key, const vblat::CompactLattice &clat) {
@@ -898,6 +962,123 @@ struct MemIn {               // cursor over an archive mapped into memory
   int Peek() { return p < end ? (unsigned char)*p : EOF; }
   size_t Left() const { return (size_t)(end - p); }
 };
+// one line of a text-mode entry (without its end-of-line); false at the end of the input
+bool GetTextLine(StreamIn &in, std::string *line) { return (bool)std::getline(in.is, *line); }
+bool GetTextLine(MemIn &in, std::string *line) {
+  if (in.p >= in.end) return false;
+  const char *e = static_cast<const char *>(memchr(in.p, '\n', (size_t)(in.end - in.p)));
+  if (!e) { line->assign(in.p, in.end); in.p = in.end; return true; }
+  line->assign(in.p, e);
+  in.p = e + 1;
+  return true;
+}
+bool TextFloat(const char **p, float *f) {
+  const char *q = *p;
+  if (!strncmp(q, "Infinity", 8)) { *f = std::numeric_limits<float>::infinity(); *p = q + 8; return true; }
+  if (!strncmp(q, "-Infinity", 9)) { *f = -std::numeric_limits<float>::infinity(); *p = q + 9; return true; }
+  char *e = nullptr;
+  *f = strtof(q, &e);
+  if (e == q) return false;
+  *p = e;
+  return true;
+}
+bool TextWeight(const std::string &s, vblat::Weight *w) {      // "graph,acoustic"
+  const char *p = s.c_str();
+  if (!TextFloat(&p, &w->v1) || *p != ',') return false;
+  p++;
+  return TextFloat(&p, &w->v2) && *p == '\0';
+}
+bool TextCWeight(const std::string &s, vblat::CWeight *w) {    // "graph,acoustic,tid_tid_..." (the string may be empty)
+  const char *p = s.c_str();
+  if (!TextFloat(&p, &w->w.v1) || *p != ',') return false;
+  p++;
+  if (!TextFloat(&p, &w->w.v2) || *p != ',') return false;
+  p++;
+  w->str.clear();
+  while (*p) {
+    char *e = nullptr;
+    const long v = strtol(p, &e, 10);
+    if (e == p || v <= 0) return false;
+    w->str.push_back((int32_t)v);
+    p = e;
+    if (*p == '_') p++; else if (*p) return false;
+  }
+  return true;
+}
+bool TextInt(const std::string &s, int32_t *v) {
+  char *e = nullptr;
+  const long x = strtol(s.c_str(), &e, 10);
+  if (s.empty() || *e != '\0' || x < 0 || x > 2147483647L) return false;
+  *v = (int32_t)x;
+  return true;
+}
+// K/lat/kaldi-lattice.cc:94-262 (LatticeReader::ReadText): the entry is read as a Lattice and as a CompactLattice at the same time until a
+// line rules one of them out (4 columns can be either: an arc without weight of the one, an arc with weight of the other)
+template <class In>
+void ReadLatticeText(In &in, vblat::Lattice *lat, vblat::CompactLattice *clat, bool *is_compact) {
+  bool lat_ok = true, clat_ok = true;
+  lat->st.clear(); clat->st.clear(); lat->start = -1; clat->start = -1;
+  std::string line;
+  size_t nline = 0;
+  auto grow = [&](int32_t s) {
+    if (lat_ok && (size_t)s >= lat->st.size()) lat->st.resize((size_t)s + 1);
+    if (clat_ok && (size_t)s >= clat->st.size()) clat->st.resize((size_t)s + 1);
+  };
+  while (GetTextLine(in, &line)) {
+    std::vector<std::string> col;
+    size_t i = 0;
+    while (i < line.size()) {
+      while (i < line.size() && strchr("\t \r\n", line[i])) i++;
+      size_t j = i;
+      while (j < line.size() && !strchr("\t \r\n", line[j])) j++;
+      if (j > i) col.push_back(line.substr(i, j - i));
+      i = j;
+    }
+    if (nline == 0 && col.empty() && line.empty()) { nline = 0; continue; }     // the newline that follows the key
+    if (col.empty()) break;                                                       // the empty line that ends the entry
+    nline++;
+    int32_t s = 0, d = 0, il = 0, ol = 0;
+    if (col.size() > 5 || !TextInt(col[0], &s)) Fail("lattice (text): bad line: " + line);
+    grow(s);
+    if (nline == 1) { lat->start = s; clat->start = s; }
+    if (lat_ok) {
+      vblat::Weight w = vblat::One();
+      switch (col.size()) {
+        case 1: lat->st[s].final = vblat::One(); break;
+        case 2: if (TextWeight(col[1], &w)) lat->st[s].final = w; else lat_ok = false; break;
+        case 4: case 5:
+          if (TextInt(col[1], &d) && TextInt(col[2], &il) && TextInt(col[3], &ol) && (col.size() == 4 || (TextWeight(col[4], &w) &&
+              !(w.v1 == std::numeric_limits<float>::infinity() && w.v2 == std::numeric_limits<float>::infinity())))) {
+            grow(d);
+            lat->st[s].arcs.push_back(vblat::Arc{il, ol, w, d});
+          } else lat_ok = false;
+          break;
+        default: lat_ok = false;
+      }
+    }
+    if (clat_ok) {
+      vblat::CWeight w; w.w = vblat::One();
+      switch (col.size()) {
+        case 1: clat->st[s].final = w; break;
+        case 2: if (TextCWeight(col[1], &w)) clat->st[s].final = w; else clat_ok = false; break;
+        case 3: case 4:
+          if (TextInt(col[1], &d) && TextInt(col[2], &il) && (col.size() == 3 || (TextCWeight(col[3], &w) &&
+              !(w.w.v1 == std::numeric_limits<float>::infinity() && w.w.v2 == std::numeric_limits<float>::infinity())))) {
+            if ((size_t)d >= clat->st.size()) clat->st.resize((size_t)d + 1);
+            if (lat_ok && (size_t)d >= lat->st.size()) lat->st.resize((size_t)d + 1);
+            clat->st[s].arcs.push_back(vblat::CArc{il, w, d});
+          } else clat_ok = false;
+          break;
+        default: clat_ok = false;
+      }
+    }
+    if (!lat_ok && !clat_ok) Fail("lattice (text): bad line: " + line);
+  }
+  // (a state that only appears as a destination was added with the default weight, Zero: not final)
+  *is_compact = clat_ok && (!lat_ok || clat->NumArcs() > 0 || lat->NumArcs() == 0);
+  if (*is_compact) { lat->st.clear(); lat->start = -1; } else { clat->st.clear(); clat->start = -1; }
+}
+
 template <class In> std::string GetFstString(In &in) {
   const int32_t n = in.template Get<int32_t>();
   if (n < 0 || n > 4096) Fail("fst: bad string length in header");
@@ -909,7 +1090,7 @@ template <class In>
 void ReadLatticeBody(In &in, vblat::Lattice *lat, vblat::CompactLattice *clat, bool *is_compact) {
   const int c = in.Peek();
   if (c == EOF) Fail("lattice: unexpected end of file");
-  if (isspace(c)) Fail("text-mode lattices are not supported");
+  if (isspace(c)) { ReadLatticeText(in, lat, clat, is_compact); return; }
   if (in.template Get<int32_t>() != kFstMagic) Fail("lattice: bad magic number");
   const std::string fsttype = GetFstString(in), arctype = GetFstString(in);
   in.template Get<int32_t>();                       // version
@@ -968,7 +1149,16 @@ void SkimLatticeBody(MemIn &in) {
   auto skip = [&](size_t n) { if (in.Left() < n) Fail("lattice: truncated"); in.p += n; };
   const int c = in.Peek();
   if (c == EOF) Fail("lattice: unexpected end of file");
-  if (isspace(c)) Fail("text-mode lattices are not supported");
+  if (isspace(c)) {        // text entry: the newline after the key, lines, an empty line
+    std::string line;
+    bool first = true;
+    while (GetTextLine(in, &line)) {
+      const bool blank = line.find_first_not_of("\t \r") == std::string::npos;
+      if (blank && !first) break;
+      first = false;
+    }
+    return;
+  }
   if (in.Get<int32_t>() != kFstMagic) Fail("lattice: bad magic number");
   const std::string fsttype = GetFstString(in), arctype = GetFstString(in);
   skip(4 + 4 + 8 + 8);

@@ -213,6 +213,7 @@ class LatticeReader {
 };
 void ParseLatticeBytes(const char *p, size_t n, vblat::Lattice *lat, vblat::CompactLattice *clat, bool *is_compact);
 void ParseLatticeBytes(const char *p, size_t n, vblat::Lattice *lat);     // a compact entry is converted (LatticeHolder::Read)
+std::string LatticeObjectToText(const std::string &object);                // a serialised entry in the text form of "ark,t:" archives
 
 // Posterior / GaussPost tables (K/hmm/posterior.cc:32-62,127-215), binary archives
 typedef vblat::Posterior Posterior;
