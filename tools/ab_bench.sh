@@ -1,3 +1,5 @@
+# Same-box A/B of library variants built by tools/variants.py (under gpurun): bash tools/ab_bench.sh product <name> <name> ...
+# Each runs the default bench for 4 steps; prints value, search kernel time and per-utterance search time.
 cd $GRAFT_REPO_ROOT
 for v in "$@"; do
   if [ "$v" = product ]; then unset VBH_LIB_PATH; else export VBH_LIB_PATH=$GRAFT_REPO_ROOT/voicebridge_amd/lib/variants/libvoicebridge_hip_$v.so; fi
