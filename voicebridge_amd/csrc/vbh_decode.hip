@@ -185,10 +185,13 @@ struct FrameRec {
 // per-slot workspace (device pointers)
 struct Slot {
   Ent *ent;                                // [S]
-  i32x4 *w_tok; int *w_remap; i32x4 *wl; i32x2 *wl2;    // raw window: tokens, remap scratch, links {src, dst, tot, arc}, {graph, acoustic}
-  i32x4 *h_tok; int *h_remap; i32x4 *hl; i32x2 *hl2;    // history
+  // raw window: tokens, remap scratch, links {src, dst, tot, arc}.  A link's graph and acoustic cost are not stored: the graph cost is
+  // the arc's weight and the acoustic cost is recomputed from the frame's cost offset and the score matrix, with the expression that
+  // made it, for the few links that reach the output (the scores of a batch stay resident until its lattices are out)
+  i32x4 *w_tok; int *w_remap; i32x4 *wl;
+  i32x4 *h_tok; int *h_remap; i32x4 *hl;                // history
   FrameRec *fr;                            // [max_frames + 2]
-  i32x4 *cand; i32x2 *cand2;               // candidates of the current frame: {tot, ac, arc, src}, {dst|EPSBIT, weight}
+  i32x4 *cand;                             // candidates of the current frame: {tot, arc, source token, next state | EPSBIT}
   int *front[3];                           // epsilon work lists (state ids), rotated
   int *state;                              // persistent: [0] epoch base
   int w_tok_cap, w_link_cap, h_tok_cap, h_link_cap, front_cap, cand_cap;
@@ -780,17 +783,15 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
   __syncthreads();
   if (nseg > 0) {
     gp<const i32x4> src_lk = uptr(FROM_W ? s.wl : s.hl);
-    gp<const i32x2> src_l2 = uptr(FROM_W ? s.wl2 : s.hl2);
-    gp<i32x4> hl = uptr(s.hl); gp<i32x2> hl2 = uptr(s.hl2);
+    gp<i32x4> hl = uptr(s.hl);
     const int l0 = J.sbeg[0], l1 = J.sbeg[nseg];
     for (int base = l0; base < l1; base += NT * UM) {
-      i32x4 L[UM]; i32x2 A[UM]; bool ok[UM];
+      i32x4 L[UM]; bool ok[UM];
 #pragma unroll
       for (int u = 0; u < UM; u++) {
         const int l = base + u * NT + tid;
         ok[u] = l < l1;
         L[u] = src_lk[ok[u] ? l : l0];
-        A[u] = src_l2[ok[u] ? l : l0];
         ok[u] = ok[u] && L[u].x >= 0;
       }
       // end points: window ids and ids of the block being re-compacted go through the remap
@@ -816,7 +817,7 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
         if (c < J.sup[j]) {
           const int nid = J.sbase[j] + c + stage_l;
           i32x4 r = L[u]; r.x = ns; r.y = nd;
-          hl[nid] = r; hl2[nid] = A[u];
+          hl[nid] = r;
         } else sh.error = ERR_H_LINK;
       }
     }
@@ -919,7 +920,7 @@ __device__ bool recompact_tail(const Slot &s, Shared &sh) {
   if (sh.error != ERR_NONE) return false;
   // ---- staging -> final position (the two regions never overlap: staging starts at the old end)
   {
-    gp<i32x4> ht = uptr(s.h_tok), hl = uptr(s.hl); gp<i32x2> hl2 = uptr(s.hl2);
+    gp<i32x4> ht = uptr(s.h_tok), hl = uptr(s.hl);
     for (int base = tail_tb; base < new_nt; base += NT * U) {
       i32x4 R[U];
 #pragma unroll
@@ -928,11 +929,11 @@ __device__ bool recompact_tail(const Slot &s, Shared &sh) {
       for (int u = 0; u < U; u++) { const int i = base + u * NT + tid; if (i < new_nt) ht[i] = R[u]; }
     }
     for (int base = tail_lb; base < new_nl; base += NT * U) {
-      i32x4 R[U]; i32x2 A[U];
+      i32x4 R[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) { const int i = base + u * NT + tid; const int q = (i < new_nl ? i : tail_lb) + stage_l; R[u] = hl[q]; A[u] = hl2[q]; }
+      for (int u = 0; u < U; u++) { const int i = base + u * NT + tid; const int q = (i < new_nl ? i : tail_lb) + stage_l; R[u] = hl[q]; }
 #pragma unroll
-      for (int u = 0; u < U; u++) { const int i = base + u * NT + tid; if (i < new_nl) { hl[i] = R[u]; hl2[i] = A[u]; } }
+      for (int u = 0; u < U; u++) { const int i = base + u * NT + tid; if (i < new_nl) hl[i] = R[u]; }
     }
   }
   job_publish(s, sh);
@@ -1209,7 +1210,7 @@ __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, in
   const int lb = sh.w_nlink;
   if (sh.error != ERR_NONE) return lb;
   __syncthreads();        // (everybody has read w_nlink before the links below move it)
-  gp<i32x4> wl = uptr(s.wl); gp<i32x2> wl2 = uptr(s.wl2);
+  gp<i32x4> wl = uptr(s.wl);
   // ---- the emitting links' destinations
   for (int l = el_b + tid; l < el_e; l += NT) {
     gp<int> py = (gp<int>)&wl[l] + 1;
@@ -1257,8 +1258,7 @@ __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, in
           if (mk) {
             if (l < w_link_cap) {
               i32x4 r; r.x = so | WBIT; r.y = dtok | WBIT; r.z = asi(tot); r.w = a;
-              i32x2 r2; r2.x = arc.y; r2.y = 0;
-              wl[l] = r; wl2[l] = r2;
+              wl[l] = r;
               (void)__hip_atomic_fetch_or((gp<int>)&wt[dtok], PLDST, __ATOMIC_RELAXED, VBH_RMW_SCOPE);
             } else sh.error = ERR_W_LINK;
           }
@@ -1465,7 +1465,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       }
       const int tb = cur_b, n = cur_e - cur_b;
       gp<const i32x4> tok = uptr(cur_w ? s.w_tok : s.h_tok) + tb;
-      gp<i32x4> cand = uptr(s.cand); gp<i32x2> cand2 = uptr(s.cand2);
+      gp<i32x4> cand = uptr(s.cand);
       const int cand_cap = s.cand_cap;
       const int enc = cur_w ? WBIT : 0;
       const float *llrow = loglikes + (ud.row0 + frame) * (long long)P;
@@ -1602,9 +1602,8 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
             for (int u = 0; u < UA; u++) {
               if (valid[u]) {
                 if (q[u] < cand_cap) {
-                  i32x4 ca; ca.x = asi(tot[u]); ca.y = asi(ac[u]); ca.z = a[u]; ca.w = base + owner[u];
-                  i32x2 cb; cb.x = arc[u].x; cb.y = arc[u].y;
-                  cand[q[u]] = ca; cand2[q[u]] = cb;
+                  i32x4 ca; ca.x = asi(tot[u]); ca.y = a[u]; ca.z = base + owner[u]; ca.w = arc[u].x;
+                  cand[q[u]] = ca;
                 } else sh.error = ERR_CAND;
               }
             }
@@ -1628,15 +1627,15 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         gp<Ent> ent = uptr(s.ent);
         gp<i32x4> wt = uptr(s.w_tok);
         gp<int> front0 = uptr(s.front[0]);
-        gp<i32x4> wl = uptr(s.wl); gp<i32x2> wl2 = uptr(s.wl2);
+        gp<i32x4> wl = uptr(s.wl);
         const int w_tok_cap = s.w_tok_cap, front_cap = s.front_cap, w_link_cap = s.w_link_cap;
         for (int base = 0; base < ncand; base += NT * UC) {
-          i32x4 CA[UC]; i32x2 CB[UC]; bool adm[UC];
+          i32x4 CA[UC]; bool adm[UC];         // {tot, arc, source token, next state | EPSBIT}
 #pragma unroll
           for (int u = 0; u < UC; u++) {
             const int q = base + u * NT + tid;
             const bool ok = q < ncand;
-            CA[u] = cand[ok ? q : 0]; CB[u] = cand2[ok ? q : 0];
+            CA[u] = cand[ok ? q : 0];
             adm[u] = ok && !(asf(CA[u].x) > next_cutoff);
           }
           int slot[UC]; bool create[UC], mk2[UC]; int nid[UC];
@@ -1644,7 +1643,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
           for (int u = 0; u < UC; u++) {
             bool improved;
             slot[u] = -1; create[u] = false;
-            if (adm[u]) map_relax(sh, ent, CB[u].x, asf(CA[u].x), ep, slot[u], create[u], improved);
+            if (adm[u]) map_relax(sh, ent, CA[u].w, asf(CA[u].x), ep, slot[u], create[u], improved);
             mk2[u] = create[u] && slot[u] < 0;
             DIAG_ADD(0, adm[u] && slot[u] < 0)
             DIAG_ADD(1, adm[u])
@@ -1653,12 +1652,12 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
           bool pushf[UC]; int fq[UC], lq[UC];
 #pragma unroll
           for (int u = 0; u < UC; u++) {
-            pushf[u] = create[u] && CB[u].x < 0;
+            pushf[u] = create[u] && CA[u].w < 0;
             if (mk2[u]) {       // second-level state: its token is made now
               if (nid[u] < w_tok_cap) {
-                i32x4 r; r.x = CB[u].x & ~PLDST; r.y = 0; r.z = 0; r.w = (int)INF_BITS;
+                i32x4 r; r.x = CA[u].w & ~PLDST; r.y = 0; r.z = 0; r.w = (int)INF_BITS;
                 wt[nid[u]] = r;
-                st_i32(&ent[CB[u].x & STMASK].tokid, nid[u]);
+                st_i32(&ent[CA[u].w & STMASK].tokid, nid[u]);
               } else { sh.error = ERR_W_TOK; pushf[u] = false; }
             }
           }
@@ -1666,12 +1665,11 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
           wave_alloc_n<UC>(&sh.w_nlink, adm, lq);
 #pragma unroll
           for (int u = 0; u < UC; u++) {
-            if (pushf[u]) front_push(sh, front0, front_cap, 0, fq[u], CB[u].x & STMASK);
+            if (pushf[u]) front_push(sh, front0, front_cap, 0, fq[u], CA[u].w & STMASK);
             if (adm[u]) {
               if (lq[u] < w_link_cap) {
-                i32x4 r; r.x = (tb + CA[u].w) | enc; r.y = slot[u] >= 0 ? slot[u] : -1 - (CB[u].x & STMASK); r.z = CA[u].x; r.w = CA[u].z;
-                i32x2 r2; r2.x = CB[u].y; r2.y = CA[u].y;
-                wl[lq[u]] = r; wl2[lq[u]] = r2;
+                i32x4 r; r.x = (tb + CA[u].z) | enc; r.y = slot[u] >= 0 ? slot[u] : -1 - (CA[u].w & STMASK); r.z = CA[u].x; r.w = CA[u].y;
+                wl[lq[u]] = r;
               } else sh.error = ERR_W_LINK;
             }
           }
@@ -1789,7 +1787,6 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
     if (search_ok && sh.error == ERR_NONE) {
       const int F = T;
       gp<const i32x4> ht = uptr(s.h_tok), hl = uptr(s.hl);
-      gp<const i32x2> hl2 = uptr(s.hl2);
       gp<int> h_remap = uptr(s.h_remap);
       if (tid == 0) sh.flag = 0;
       __syncthreads();
@@ -1860,7 +1857,6 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
               const int l = b0 + lane;
               const bool in = l < le_;
               const i32x4 L = hl[in ? l : lb];
-              const i32x2 L2 = hl2[in ? l : lb];
               const int arc_id = in ? L.w : 0;
               const bool live = in && L.x >= 0;
               const int a = h_remap[live ? L.x : 0], b = h_remap[live ? L.y : 0];
@@ -1869,9 +1865,13 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
               if (w) {
                 const long long o = loff + d;
                 const int il = ((gp<const int>)g.arc_il)[arc_id];
+                const i32x4 arc = garcs[arc_id];
                 pool.link_src[o] = a; pool.link_dst[o] = b;
-                pool.link_il[o] = il; pool.link_ol[o] = garcs[arc_id].w; pool.link_gr[o] = asf(L2.x);
-                pool.link_ac[o] = il != 0 ? asf(L2.y) - coff : asf(L2.y);
+                pool.link_il[o] = il; pool.link_ol[o] = arc.w; pool.link_gr[o] = asf(arc.y);
+                // the acoustic cost as pass 1 computed it (cost_offset - acwt * score), then the offset taken out again (:148-152)
+                float acst = 0.0f;
+                if (il != 0) { acst = coff - cfg.acwt * loglikes[(ud.row0 + f) * (long long)P + arc.z]; acst = acst - coff; }
+                pool.link_ac[o] = acst;
               }
             }
           }
@@ -2130,10 +2130,10 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
     for (size_t i = 0; i < ns; i++) set->h[i].field = base + i * (size_t)(count);                    \
   }
   A_(ent, Ent, S, 0xFF)
-  A_(w_tok, i32x4, p.w_tok_cap, -2) A_(w_remap, int, p.w_tok_cap, 0) A_(wl, i32x4, p.w_link_cap, -2) A_(wl2, i32x2, p.w_link_cap, -2)
-  A_(h_tok, i32x4, p.h_tok_cap, -2) A_(h_remap, int, p.h_tok_cap, 0) A_(hl, i32x4, p.h_link_cap, -2) A_(hl2, i32x2, p.h_link_cap, -2)
+  A_(w_tok, i32x4, p.w_tok_cap, -2) A_(w_remap, int, p.w_tok_cap, 0) A_(wl, i32x4, p.w_link_cap, -2)
+  A_(h_tok, i32x4, p.h_tok_cap, -2) A_(h_remap, int, p.h_tok_cap, 0) A_(hl, i32x4, p.h_link_cap, -2)
   A_(fr, FrameRec, F, 0)
-  A_(cand, i32x4, p.cand_cap, -2) A_(cand2, i32x2, p.cand_cap, -2)
+  A_(cand, i32x4, p.cand_cap, -2)
   A_(front[0], int, p.front_cap, -2) A_(front[1], int, p.front_cap, -2) A_(front[2], int, p.front_cap, -2)
   A_(state, int, 4, 0)
 #undef A_
