@@ -95,13 +95,13 @@ constexpr int STMASK = 0x3FFFFFFF;
 #endif
 constexpr int U = VBH_U;                    // independent items per lane in the streaming passes
 #ifndef VBH_UC
-#define VBH_UC 2
+#define VBH_UC 4
 #endif
 #ifndef VBH_UM
 #define VBH_UM 4
 #endif
 #ifndef VBH_UA
-#define VBH_UA 2
+#define VBH_UA 4
 #endif
 constexpr int UA = VBH_UA;                  // x 64 arcs a wave has in flight in pass 1
 constexpr int UM = VBH_UM;                  // ... in the compaction moves
