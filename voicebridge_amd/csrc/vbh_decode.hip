@@ -387,6 +387,7 @@ struct Shared {
   unsigned hist[256];
   int w_ntok, w_nlink, h_ntok, h_nlink;
   int n_cand;
+  unsigned cand_bound;             // order-preserving key of the smallest tot + adaptive_beam seen so far in pass 1 (>= the final next_cutoff)
   int fcnt[3];                     // epsilon work-list fill counts, rotated with Slot::front
   int changed2[2];                 // "something changed" flags, alternated per use (see prune_frame)
   int cnt_tok[2], cnt_el[2], cnt_pl[2];   // survivors seen by a pruning sweep, alternated the same way
@@ -417,7 +418,7 @@ struct Shared {
   // The arena.  While a frame is built (pass 2 to the end of the frame): the state map, tags [0, HCAP) and cost keys
   // [HCAP, 2 HCAP) (see map_relax).  In the cutoff phase: the frame's token costs (lds_cost).  During pruning: the link
   // minima per token (prune_frame).  During compaction: FrameRec staging and the job arrays (struct Job).
-  unsigned arena[2 * HCAP];
+  alignas(16) unsigned arena[2 * HCAP];
 #ifdef VBH_LDS_CANARY
   unsigned canary_hi[4];
 #endif
@@ -1380,7 +1381,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
     if (tid == 0) {
       for (int i = 0; i < 12; i++) sh.tph[i] = 0;
       sh.w_ntok = 0; sh.w_nlink = 0; sh.h_ntok = 0; sh.h_nlink = 0; sh.error = ERR_NONE;
-      sh.n_max_bound = 0; sh.n_min_bound = 0; sh.n_cand = 0; sh.n_visited = 0;
+      sh.n_max_bound = 0; sh.n_min_bound = 0; sh.n_cand = 0; sh.cand_bound = 0xFFFFFFFFu; sh.n_visited = 0;
       sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0;
       sh.changed2[0] = 0; sh.changed2[1] = 0;
       sh.cnt_tok[0] = 0; sh.cnt_tok[1] = 0; sh.cnt_el[0] = 0; sh.cnt_el[1] = 0; sh.cnt_pl[0] = 0; sh.cnt_pl[1] = 0;
@@ -1595,12 +1596,28 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
                 c_arc_exp++;
               }
             }
+            // An arc whose tot already exceeds a bound on next_cutoff -- the smallest tot + adaptive_beam anybody in the workgroup has
+            // seen so far, kept in LDS -- cannot be admitted (the final next_cutoff is the minimum over all arcs, so it is no larger):
+            // it is not written to the candidate list.  (What the reference does one arc at a time, :758-760, as a filter only:
+            // the admitted set is still exactly {tot <= final next_cutoff}.)
+            bool keep[UA];
+            {
+              float it_min = INF;
+#pragma unroll
+              for (int u = 0; u < UA; u++) if (valid[u]) it_min = fminf(it_min, tot[u] + adaptive_beam);
+#pragma unroll
+              for (int o = 32; o > 0; o >>= 1) it_min = fminf(it_min, __shfl_xor(it_min, o, 64));
+              if (lane == 0) atomicMin(&sh.cand_bound, f2o(it_min));
+              const float bnd = o2f(sh.cand_bound);
+#pragma unroll
+              for (int u = 0; u < UA; u++) keep[u] = valid[u] && !(tot[u] > bnd);
+            }
             int q[UA];
-            wave_alloc_n<UA>(&sh.n_cand, valid, q);
+            wave_alloc_n<UA>(&sh.n_cand, keep, q);
             P1STAMP(4)
 #pragma unroll
             for (int u = 0; u < UA; u++) {
-              if (valid[u]) {
+              if (keep[u]) {
                 if (q[u] < cand_cap) {
                   i32x4 ca; ca.x = asi(tot[u]); ca.y = a[u]; ca.z = base + owner[u]; ca.w = arc[u].x;
                   cand[q[u]] = ca;
@@ -1691,7 +1708,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         r.tok_b = cur_b; r.tok_e = cur_e; r.el_b = 0; r.el_e = 0; r.pl_b = plb; r.pl_e = pl_end;
         r.flags = 1 | 4; r.cost_offset = 0.0f; r.a_tok = cur_e - cur_b; r.a_el = 0; r.a_pl = pl_end - plb; r.pad = 0;
         st_frame(s.fr + (frame + 1), r);
-        sh.n_cand = 0; sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0;
+        sh.n_cand = 0; sh.cand_bound = 0xFFFFFFFFu; sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0;
       }
 #ifdef VBH_DIAG
       if (tid == 0) {
