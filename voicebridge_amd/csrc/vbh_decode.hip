@@ -88,10 +88,10 @@ constexpr int EPSBIT = (int)0x80000000;     // on an arc's next state / a token'
 constexpr int PLDST = 0x40000000;           // on a token's state: the token is the destination of an epsilon link of its frame
 constexpr int STMASK = 0x3FFFFFFF;
 #ifndef VBH_U
-#define VBH_U 4
+#define VBH_U 2
 #endif
 #ifndef VBH_UL
-#define VBH_UL 2                // (r02, 768 threads: 4 costs 35 more spilled registers in the pruning sweep and 5 % of the search rate)
+#define VBH_UL 4                // (with VBH_U = 2: r02 same-box A/B, 248 against 251 ms per utterance; 2 spilled registers)
 #endif
 constexpr int U = VBH_U;                    // independent items per lane in the streaming passes
 #ifndef VBH_UC
