@@ -2079,12 +2079,13 @@ static int slot_alloc(vbh_decoder *d, SlotSet *set, size_t bytes, void **p, int 
 static const char *err_name(int e);
 
 // Frames between two intermediate prunings.  The final lattice does not depend on this schedule
-// (see the header), so the kernel prunes no more often than every 100 frames even when
+// (see the header), so the kernel prunes no more often than every 180 frames even when
 // cfg.prune_interval asks for less: every visit of a frame costs the same handful of dependent
-// passes however few links it holds, re-visits per frame fall with the interval, and HBM has room
-// for the longer raw window.  VBH_PRUNE_EVERY overrides (tuning, and tests of the pruning paths).
+// passes however few links it holds, re-visits per frame fall with the interval (r02, same box: 251 / 247 / 244 ms per
+// utterance at 100 / 140 / 180), and HBM has room for the longer raw window (~70 MB per search workspace).
+// VBH_PRUNE_EVERY overrides (tuning, and tests of the pruning paths).
 static int effective_prune_interval(const vbh_decode_cfg *cfg) {
-  int v = std::max(cfg->prune_interval, 100);
+  int v = std::max(cfg->prune_interval, 180);
   if (const char *e = getenv("VBH_PRUNE_EVERY")) { const int x = atoi(e); if (x > 0) v = x; }
   return std::min(v, MAX_WIN_FRAMES - 2);
 }
