@@ -83,7 +83,7 @@ constexpr int WG_PER_CU = ((1024 / NT) * VBH_WAVES_PER_EU) / 4 > 0 ? ((1024 / NT
 constexpr int WBIT = 0x40000000;            // token id lives in the raw window
 constexpr unsigned INF_BITS = 0x7F800000u;  // +inf as float bits
 constexpr int MAX_EPS_ITERS = 4096;
-constexpr int MAX_WIN_FRAMES = NT / 4;      // frames between two compactions (prune_interval + 1 <= this)
+constexpr int MAX_WIN_FRAMES = 512;         // frames between two compactions (prune_interval + 1 <= this); the job arrays live in the arena
 constexpr int EPSBIT = (int)0x80000000;     // on an arc's next state / a token's state: that state has epsilon arcs
 constexpr int PLDST = 0x40000000;           // on a token's state: the token is the destination of an epsilon link of its frame
 constexpr int STMASK = 0x3FFFFFFF;
@@ -2079,13 +2079,13 @@ static int slot_alloc(vbh_decoder *d, SlotSet *set, size_t bytes, void **p, int 
 static const char *err_name(int e);
 
 // Frames between two intermediate prunings.  The final lattice does not depend on this schedule
-// (see the header), so the kernel prunes no more often than every 180 frames even when
+// (see the header), so the kernel prunes no more often than every 300 frames even when
 // cfg.prune_interval asks for less: every visit of a frame costs the same handful of dependent
-// passes however few links it holds, re-visits per frame fall with the interval (r02, same box: 251 / 247 / 244 ms per
-// utterance at 100 / 140 / 180), and HBM has room for the longer raw window (~70 MB per search workspace).
+// passes however few links it holds, re-visits per frame fall with the interval (r02, same box: 251 / 247 / 244 / 241 / 243 ms per
+// utterance at 100 / 140 / 180 / 300 / 450), and HBM has room for the longer raw window (~115 MB per search workspace).
 // VBH_PRUNE_EVERY overrides (tuning, and tests of the pruning paths).
 static int effective_prune_interval(const vbh_decode_cfg *cfg) {
-  int v = std::max(cfg->prune_interval, 180);
+  int v = std::max(cfg->prune_interval, 300);
   if (const char *e = getenv("VBH_PRUNE_EVERY")) { const int x = atoi(e); if (x > 0) v = x; }
   return std::min(v, MAX_WIN_FRAMES - 2);
 }
