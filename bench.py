@@ -774,7 +774,7 @@ def main():
             elif any(dg[8:]):
                 tot += dg[8] + dg[9]
                 print("   VBH_DIAG: admit %.1f%% links %.1f%% cutoff-up-to-first-reduction %.1f%% rest-of-cutoff %.1f%%; admissions/frame %.0f, to the HBM map %.1f%%; "
-                      "frames creating > 3/4 of the LDS map %d, frames with > 2 candidates per slot %d"
+                      "frames creating > 3/4 of the LDS map %d, sweeps of the pruning passes %d"
                       % (100.0 * dg[8] / tot, 100.0 * dg[2] / tot, 100.0 * dg[9] / tot, 100.0 * dg[0] / tot, dg[11] / nf, 100.0 * dg[10] / max(dg[11], 1), dg[12], dg[13]))
                 print("   frames by tokens at their start (< 512, < 2048, < 6144, more): frames %s, kilocycles per frame %s"
                       % ([(dg[15] >> (16 * i)) & 0xFFFF for i in range(4)], [(dg[14] >> (16 * i)) & 0xFFFF for i in range(4)]))

@@ -697,6 +697,9 @@ __device__ int prune_frame(const Slot &s, int f, float lattice_beam, float delta
     }
     pp ^= 1;
     result |= any;
+#ifdef VBH_DIAG
+    if (tid == 0) sh.diag[4]++;        // sweeps (a frame with epsilon links is swept until its destinations stop moving: 1.9 per visit)
+#endif
     if (last) break;
   }
   if (tid == 0) { set_dirty(sh, f, false); if (result & 2) set_dirty(sh, f - 1, true); }
@@ -1919,6 +1922,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
 #ifdef VBH_DIAG
         r->t_phase[8] = sh.tph[8]; r->t_phase[9] = sh.tph[9];
         for (int i = 0; i < 4; i++) r->t_phase[10 + i] = sh.diag[i];
+        r->t_phase[13] = sh.diag[4];      // (replaces the candidates-per-slot counter: sweeps of the pruning passes)
         // [14], [15]: cycles and frames of the four frame classes, 16 bits of kilocycles-per-frame / frames each
         r->t_phase[14] = 0; r->t_phase[15] = 0;
         // heavy frames' phase cycles replace [0..6], [8], [9] when VBH_DIAG_HEAVY is defined
