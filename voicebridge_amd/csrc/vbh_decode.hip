@@ -67,12 +67,12 @@ namespace {
 
 // Threads per utterance.  One utterance per CU (the workgroup's ~150 KB of LDS leave room for no other workgroup), so the
 // thread count decides how many registers a thread gets: 1024 threads = 4 waves per SIMD = 128 VGPRs, 768 = 3 waves = 168
-// VGPRs, 512 = 2 waves = 256 VGPRs.  The frame loop wants about 250; at 128 it spills ~230 registers to scratch and the
-// spill code sits in the hot loops (small edits moved the kernel's speed by 20 % either way, r01/r02).  Measured on the
-// bench's speech workload (r02, one box, per-utterance search time): 1024 threads 376 ms, 768 threads 301 ms (58 spills),
-// 512 threads 330 ms (no spills, but only 8 waves to hide latency with).
+// VGPRs, 512 = 2 waves = 256 VGPRs.  Which one wins depends on how much the frame loop spills at 128 (r02, same-box A/B, per-
+// utterance search time on the bench's speech workload): while it spilled ~230 registers, 1024 / 768 / 512 threads took
+// 376 / 301 / 330 ms (and the 1024-thread build moved by 20 % from one compile to the next); with the leaner passes of the end
+// of r02 (16-byte links and candidates, tokens made once by the slot scan: 44 spilled registers at 128) 229 / 243 / 284 ms.
 #ifndef VBH_DECODE_NT
-#define VBH_DECODE_NT 768
+#define VBH_DECODE_NT 1024
 #endif
 constexpr int NT = VBH_DECODE_NT;    // threads per workgroup = per utterance; 1024/NT workgroups share a CU
 constexpr int NW = NT / 64;
@@ -91,7 +91,7 @@ constexpr int STMASK = 0x3FFFFFFF;
 #define VBH_U 2
 #endif
 #ifndef VBH_UL
-#define VBH_UL 4                // (with VBH_U = 2: r02 same-box A/B, 248 against 251 ms per utterance; 2 spilled registers)
+#define VBH_UL 1                // (r02 same-box A/B at 1024 threads: 1 / 2 / 4 links per lane in flight in the pruning sweep: 226-229 / 229 / 236 ms per utterance)
 #endif
 constexpr int U = VBH_U;                    // independent items per lane in the streaming passes
 #ifndef VBH_UC
