@@ -26,10 +26,19 @@
 namespace {
 
 thread_local std::string g_err;
-thread_local int g_step_depth = 0;     // > 0 while a step runs inside another (DecodeFmllr -> Decode): the outermost one frees the device cache
+thread_local int g_step_depth = 0;     // > 0 while a step runs inside another (DecodeFmllr -> Decode)
+// Model, graph and search workspace stay on the device from one step to the next (an application calls Decode, then DecodeFmllr,
+// then the next data set: re-creating a 30 GB workspace after it has been freed cost 2.3 s of DecodeFmllr's 7.9 s on 1024 utterances,
+// r02).  vb_release_device_cache() frees them; vb_set_release_device_cache(1) / VB_RELEASE_DEVICE_CACHE=1: every outermost step does.
+std::atomic<int> g_release_at_step_end{-1};
+bool ReleaseAtStepEnd() {
+  int v = g_release_at_step_end.load();
+  if (v < 0) { const char *e = getenv("VB_RELEASE_DEVICE_CACHE"); v = (e && *e && *e != '0') ? 1 : 0; g_release_at_step_end.store(v); }
+  return v != 0;
+}
 struct StepScope {
   StepScope() { g_step_depth++; }
-  ~StepScope() { if (--g_step_depth == 0) vb_release_device_cache(); }
+  ~StepScope() { if (--g_step_depth == 0 && ReleaseAtStepEnd()) vb_release_device_cache(); }
 };
 
 struct StepError : public std::runtime_error {
@@ -681,6 +690,7 @@ int vb_ScoreKaldiWER(const char *data, const char *lang_or_graph, const char *di
   UMAPSS a, b;
   return ScoreKaldiWER(data, lang_or_graph, dir, a, b, nj, 0, false, true, 6.0, word_ins_penalty ? word_ins_penalty : "0.0,0.5,1.0", min_lmwt, max_lmwt);
 }
+int vb_set_release_device_cache(int on) { g_release_at_step_end.store(on ? 1 : 0); return 0; }
 const char *vb_steps_last_error(void) { return g_err.c_str(); }
 int vb_set_step_devices(const int *devices, int n) {
   g_step_devices.clear();

@@ -81,6 +81,7 @@ int vb_DecodeFmllr(const char *graphdir, const char *data, const char *dir, int 
 int vb_ScoreKaldiWER(const char *data, const char *lang_or_graph, const char *dir, int nj, const char *word_ins_penalty, int min_lmwt,
                      int max_lmwt);
 const char *vb_steps_last_error(void);
+int vb_set_release_device_cache(int on);               // 1: every outermost step frees model, graph and search workspace when it returns (default 0: they stay for the next step; vb_release_device_cache() frees them)
 int vb_set_step_devices(const int *devices, int n);    // GPUs the jobs of the steps are spread over (n = 0: the calling thread's device only)
 }
 
