@@ -98,7 +98,7 @@ def parse():
                          "then exit.  RTF as a function of search difficulty")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-api", action="store_true", help="skip the step-API measurement (MakeMfcc / Decode / DecodeFmllr on a data directory, in a child process)")
-    ap.add_argument("--step-api-utts", type=int, default=256)
+    ap.add_argument("--step-api-utts", type=int, default=1024)
     ap.add_argument("--step-api-threads", type=int, default=1)
     ap.add_argument("--cpu-sample-seconds", type=float, default=120.0,
                     help="audio seconds one process of the CPU baseline decodes (whole speakers; the default is one speaker of four 30 s utterances, "
