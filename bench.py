@@ -99,7 +99,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-api", action="store_true", help="skip the step-API measurement (MakeMfcc / Decode / DecodeFmllr on a data directory, in a child process)")
     ap.add_argument("--step-api-utts", type=int, default=1024)
-    ap.add_argument("--step-api-threads", type=int, default=1)
+    ap.add_argument("--step-api-threads", type=int, default=4, help="host threads the nj = 4 jobs of a step run on, all on the one GPU (VB_STEP_DEVICES=0,0,..; the reference runs its jobs side by side)")
     ap.add_argument("--cpu-sample-seconds", type=float, default=120.0,
                     help="audio seconds one process of the CPU baseline decodes (whole speakers; the default is one speaker of four 30 s utterances, "
                          "about 10-30 s of one core depending on how hard the search is)")
@@ -1253,7 +1253,7 @@ def main():
                 k_fm = [k_ for k_ in st_ if k_.startswith("DecodeFmllr_s")][0]
                 out["step_api"] = {"what": "tools/bench_steps.py: %d utterances of 30 s in a data directory, nj = 4 jobs on %d host thread(s), one GPU; seconds per step "
                                            "of the reference's API and frames/s of the two decoding steps" % (args.step_api_utts, args.step_api_threads),
-                                   "MakeMfcc_s": st_["MakeMfcc_s"], "ComputeCmvnStats_s": st_["ComputeCmvnStats_s"], "Decode_s": st_[k_dec],
+                                   "job_threads": args.step_api_threads, "MakeMfcc_s": st_["MakeMfcc_s"], "ComputeCmvnStats_s": st_["ComputeCmvnStats_s"], "Decode_s": st_[k_dec],
                                    "DecodeFmllr_s": st_[k_fm], "Decode_step_frames_per_s": fr_ / st_[k_dec], "DecodeFmllr_step_frames_per_s": fr_ / st_[k_fm],
                                    "Decode_best_wer": st_.get("Decode_best_wer"), "DecodeFmllr_best_wer": st_.get("DecodeFmllr_best_wer")}
             except Exception as e:

@@ -339,3 +339,49 @@ def test_decode_lda_mllt_sat_model_against_the_reference_chain(host, tmp_path):
             rw = {l.split()[0]: l.split()[1:] for l in (d / "r_w.txt").read_text().split("\n") if l.strip()}
             for u in rw:
                 assert rw[u] == words[u], u
+
+
+def test_job_threads_leave_the_same_files(host, tmp_path):
+    """vb_set_step_devices: the jobs of a step on host threads of their own (here three threads sharing the one GPU and ONE
+    pool of search workspaces between their decoders), as VB/scr/steps/decode_gmm.cpp:300-324 runs its nj jobs side by side.
+    Same files, byte for byte, as the jobs one after the other; a second round on the same (persistent) job threads too."""
+    from tests import util
+    from voicebridge_amd import synth
+    H, n_cd, n_words = 3, 10, 30
+    P = n_cd * H
+    g, _ = synth.lexicon_graph(n_words, P, seed=3, n_phones=n_cd)
+    offs, w, means, iv = synth.gmm_model(P, P * 3, 39, seed=4, mean_scale=1.5, var_spread=0.3)
+    host.vb_set_step_devices.argtypes = [C.POINTER(C.c_int), C.c_int]
+    out = {}
+    try:
+        for tag, devs in (("serial", []), ("threads", [0, 0, 0]), ("threads_again", [0, 0, 0])):
+            d = tmp_path / tag
+            d.mkdir()
+            data, conf, utts = make_datadir(d, n_utt=6, n_spk=3, seconds=4.5)
+            assert host.vb_set_step_devices((C.c_int * max(len(devs), 1))(*devs), len(devs)) == 0
+            assert host.vb_MakeMfcc(str(data).encode(), str(conf).encode(), 3, 1, 0) == 0, host.vb_steps_last_error()
+            assert host.vb_ComputeCmvnStatsDir(str(data).encode()) == 0
+            exp = d / "exp" / "tri3"
+            graph = exp / "graph"
+            (graph / "phones").mkdir(parents=True)
+            util.write_mdl(str(exp / "final.mdl"), n_cd, H, offs, w, (means * iv).astype(np.float32), iv)
+            util.write_vector_fst(str(graph / "HCLG.fst"), g["final"], g["arc_offset"], g["arcs"])
+            (graph / "words.txt").write_text("<eps> 0\n" + "".join("w%d %d\n" % (i, i) for i in range(1, n_words + 2)))
+            (graph / "phones" / "silence.csl").write_text("1:2\n")
+            dec = exp / "decode_test"
+            assert host.vb_DecodeFmllr(str(graph).encode(), str(data).encode(), str(dec).encode(), 3, 0.083333, 7000, 13.0, 6.0, 0.01, b"",
+                                       1, b"0.0", 9, 9) == 0, host.vb_steps_last_error()
+            files = {}
+            for j in (1, 2, 3):
+                for n in ("lat.%d", "trans.%d", "w.%d"):
+                    files[n % j] = (dec / (n % j)).read_bytes()
+                files["si_lat.%d" % j] = (exp / "decode_test.si" / ("lat.%d" % j)).read_bytes()
+                files["mfcc.%d" % j] = (data / "mfcc" / ("raw_mfcc_test.%d.ark" % j)).read_bytes()
+            assert all(len(v) > 0 for v in files.values())
+            out[tag] = files
+    finally:
+        host.vb_set_step_devices((C.c_int * 1)(), 0)
+    for tag in ("threads", "threads_again"):
+        assert sorted(out[tag]) == sorted(out["serial"])
+        for n, v in out["serial"].items():
+            assert out[tag][n] == v, (tag, n)

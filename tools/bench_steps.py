@@ -130,7 +130,14 @@ def main():
                                             C.c_int, C.c_char_p, C.c_int, C.c_int]
             dec2 = os.path.join(exp, "decode_fmllr")
             t0 = time.perf_counter()
-            assert host.vb_DecodeFmllr(graph.encode(), data.encode(), dec2.encode(), a.nj, 0.083333, 7000, 13.0, 6.0, 0.01, b"", 0, b"0.0,0.5,1.0", 7, 17) == 0, host.vb_steps_last_error()
+            rc = host.vb_DecodeFmllr(graph.encode(), data.encode(), dec2.encode(), a.nj, 0.083333, 7000, 13.0, 6.0, 0.01, b"", 0, b"0.0,0.5,1.0", 7, 17)
+            if rc != 0:         # show what the jobs logged before the directory goes away
+                for root, _dirs, files in os.walk(dec2):
+                    for fn in sorted(files):
+                        if fn.endswith(".log"):
+                            txt = open(os.path.join(root, fn), errors="replace").read()
+                            sys.stderr.write("---- %s\n%s\n" % (os.path.join(root, fn), txt[-1500:]))
+            assert rc == 0, host.vb_steps_last_error()
             out["DecodeFmllr_s (SI pass + 2 fMLLR estimates + main search + rescoring + determinization + scoring)"] = time.perf_counter() - t0
             bw = os.path.join(dec2, "scoring_kaldi", "best_wer")
             if os.path.exists(bw):

@@ -2071,6 +2071,7 @@ struct vbh_decoder {
 
 // the pools of this process (weak: a pool lives as long as a decoder uses it), see vbh_decoder_create_shared
 static std::mutex g_pool_mu;
+static std::mutex g_pool_create_mu;
 static std::vector<std::weak_ptr<SlotSet>> g_pools;
 
 static int slot_alloc(vbh_decoder *d, SlotSet *set, size_t bytes, void **p, int memset_val = -2) {
@@ -2257,7 +2258,11 @@ int vbh_decoder_create_shared(vbh_ctx *ctx, const vbh_graph *graph, const vbh_de
   // Decoders of one process share the device's pool whenever an existing one fits (same graph size, capacities that cover
   // this configuration, at least as many slots): the jobs of a step running on several host threads, or a caller's decoders
   // on several streams, then hold ONE set of workspaces between them.  VBH_PRIVATE_SLOTS=1: every decoder its own.
+  // Looking for a pool and creating one is one critical section: job threads that start together must end up with one pool
+  // between them, not one each (four of ~20 GB each, twice per DecodeFmllr, did not fit the device).
+  std::unique_lock<std::mutex> create_lk(g_pool_create_mu, std::defer_lock);
   if (!getenv("VBH_PRIVATE_SLOTS")) {
+    create_lk.lock();
     int dev_cus0 = ctx->num_cus;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) dev_cus0 = prop.multiProcessorCount; }
     const int want_n = (std::min<int>(max_batch, WG_PER_CU * dev_cus0) + 7) & ~7;

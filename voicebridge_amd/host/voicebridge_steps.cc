@@ -17,6 +17,9 @@
 #include <sstream>
 #include <stdexcept>
 #include <thread>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <vector>
 
 #include "kaldi_io.h"
@@ -58,27 +61,74 @@ std::vector<int> StepDevices() {
   }
   return d;
 }
+// The job threads live as long as the device list does: a job thread's caches (model, graph, feature table, search workspace:
+// thread-local in voicebridge_api.cc) then persist from step to step exactly as the calling thread's do.  Threads started per
+// step re-created a 20 GB workspace per thread and step (and never freed the old one).  The object is never destroyed: at
+// process end the idle threads simply go away with the process.
+class JobWorkers {
+ public:
+  explicit JobWorkers(const std::vector<int> &devs) : devs_(devs), w_(devs.size()) {
+    for (size_t t = 0; t < w_.size(); t++) w_[t].th = std::thread([this, t]() { Loop((int)t); });
+  }
+  ~JobWorkers() {
+    for (Worker &w : w_) { { std::lock_guard<std::mutex> lk(w.mu); w.quit = true; } w.cv.notify_all(); }
+    for (Worker &w : w_) if (w.th.joinable()) w.th.join();
+  }
+  const std::vector<int> &devices() const { return devs_; }
+  // fn(t) on worker t for t < nt, all at once; returns when every one has finished
+  void Run(int nt, const std::function<void(int)> &fn) {
+    for (int t = 0; t < nt; t++) { { std::lock_guard<std::mutex> lk(w_[t].mu); w_[t].task = &fn; w_[t].done = false; } w_[t].cv.notify_all(); }
+    for (int t = 0; t < nt; t++) { std::unique_lock<std::mutex> lk(w_[t].mu); w_[t].cv.wait(lk, [&] { return w_[t].done; }); }
+  }
+ private:
+  struct Worker { std::thread th; std::mutex mu; std::condition_variable cv; const std::function<void(int)> *task = nullptr; bool done = true, quit = false; };
+  void Loop(int t) {
+    Worker &w = w_[t];
+    vb_set_device(devs_[t]);
+    for (;;) {
+      const std::function<void(int)> *task;
+      {
+        std::unique_lock<std::mutex> lk(w.mu);
+        w.cv.wait(lk, [&] { return w.quit || w.task; });
+        if (!w.task) break;
+        task = w.task;
+      }
+      (*task)(t);          // (catches its own exceptions)
+      { std::lock_guard<std::mutex> lk(w.mu); w.task = nullptr; w.done = true; }
+      w.cv.notify_all();
+    }
+    vb_release_device_cache();      // the device list changed: this thread's device memory goes with it
+  }
+  std::vector<int> devs_;
+  std::vector<Worker> w_;
+};
+std::mutex g_workers_mu;            // one step at a time uses the workers
+JobWorkers *g_workers = nullptr;
+thread_local bool g_on_job_thread = false;
+
 // fn(j) for j = 1..nj; an exception of any job is rethrown (the first one) after all threads have finished
 template <class F>
 void ForEachJob(int nj, F fn) {
   const std::vector<int> devs = StepDevices();
-  if (devs.size() <= 1 || nj <= 1) {
-    if (devs.size() == 1) vb_set_device(devs[0]);
+  if (devs.size() <= 1 || nj <= 1 || g_on_job_thread) {
+    if (devs.size() == 1 && !g_on_job_thread) vb_set_device(devs[0]);
     for (int j = 1; j <= nj; j++) fn(j);
     return;
   }
+  std::lock_guard<std::mutex> lk(g_workers_mu);
+  if (g_workers && g_workers->devices() != devs) { delete g_workers; g_workers = nullptr; }
+  if (!g_workers) g_workers = new JobWorkers(devs);
   const int nt = (int)std::min<size_t>(devs.size(), (size_t)nj);
   std::vector<std::string> errs(nt);
-  std::vector<std::thread> th;
-  for (int t = 0; t < nt; t++)
-    th.emplace_back([&, t]() {
-      try {
-        vb_set_device(devs[t]);
-        StepScope scope;                     // the thread's device cache is released when its last job is done
-        for (int j = 1 + t; j <= nj; j += nt) fn(j);
-      } catch (const std::exception &e) { errs[t] = e.what(); if (errs[t].empty()) errs[t] = "error"; }
-    });
-  for (auto &x : th) x.join();
+  const std::function<void(int)> body = [&](int t) {
+    g_on_job_thread = true;
+    try {
+      StepScope scope;                     // (VB_RELEASE_DEVICE_CACHE=1: the thread's device cache is released when its last job is done)
+      for (int j = 1 + t; j <= nj; j += nt) fn(j);
+    } catch (const std::exception &e) { errs[t] = e.what(); if (errs[t].empty()) errs[t] = "error"; }
+    catch (...) { errs[t] = "error"; }
+  };
+  g_workers->Run(nt, body);
   for (const auto &e : errs) if (!e.empty()) throw StepError(e);
 }
 

@@ -14,7 +14,10 @@
 // The nj jobs of a step are batches for a GPU here, not processes.  By default they run one after the other on the calling
 // thread's GPU (vb_set_device); vb_set_step_devices (or VB_STEP_DEVICES=0,1,...) names the GPUs of the node to use: the jobs
 // are then dealt round-robin to them, one host thread per device -- the reference's nj concurrent job threads
-// (scr/steps/decode_gmm.cpp:300-324), with a device behind each.  The per-job file layout (JOB-numbered archives, logs,
+// (scr/steps/decode_gmm.cpp:300-324), with a device behind each.  A device may be named more than once ("0,0,0,0"): that many
+// job threads share it, one job's host work (archives, determinization, fMLLR updates) overlapping the others' kernels, their
+// decoders drawing on ONE pool of search workspaces.  The job threads persist (and keep their model / graph / workspace
+// caches) until the device list changes.  The per-job file layout (JOB-numbered archives, logs,
 // split directories) is the reference's, so whatever consumes those directories keeps working.
 //
 //   scr/kaldi_scr.h:167-183  int ScoreKaldiWER(data, lang_or_graph, dir, wer filters, nj, stage, decode_mbr, stats, beam,
