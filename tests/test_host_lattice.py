@@ -232,6 +232,8 @@ def test_score_kaldi_wer_on_golden_lattices(host, tmp_path):
     data = d / "data"
     data.mkdir()
     (data / "text").write_text((d / "ref_text.txt").read_text())
+    utts = [l.split()[0] for l in (d / "ref_text.txt").read_text().split("\n") if l.strip()]
+    (data / "utt2spk").write_text("".join("%s spk%d\n" % (u, i % 2) for i, u in enumerate(utts)))
     host.vb_steps_last_error.restype = C.c_char_p
     rc = host.vb_ScoreKaldiWER(str(data).encode(), str(graph).encode(), str(dec).encode(), 2, b"0.0, 0.5", 8, 10)
     assert rc == 0, host.vb_steps_last_error()
@@ -240,7 +242,20 @@ def test_score_kaldi_wer_on_golden_lattices(host, tmp_path):
     # "%WER 50.00 [ 3 / 6, 1 ins, 2 del, 0 sub ]", "%SER 66.67 [ 2 / 3 ]" in the reference's one-line form
     assert (dec / "wer_9_0.5").read_text().split() == ["50.00", "3", "6", "1", "2", "0", "66.67", "2", "3"]
     assert len(list(dec.glob("wer_*"))) == 6
-    assert (dec / "scoring_kaldi" / "wer_details" / "wip").read_text().strip() in ("0.0", "0.5")
+    det = dec / "scoring_kaldi" / "wer_details"
+    assert det.joinpath("wip").read_text().strip() in ("0.0", "0.5")
+    # the statistics of the best combination (score_kaldi_wer.cpp:165-236): per utterance, per speaker, per word pair, bootstrap
+    # interval; their totals are those of the best WER file
+    best = (dec / "scoring_kaldi" / "best_wer").read_text().split()
+    csid = [list(map(int, l.split()[2:])) for l in det.joinpath("per_utt").read_text().split("\n") if " #csid " in l]
+    assert len(csid) == int(best[8]) and sum(c[2] for c in csid) == int(best[3]) and sum(c[3] for c in csid) == int(best[4]) and sum(c[1] for c in csid) == int(best[5])
+    rows = [l.split() for l in det.joinpath("per_spk").read_text().strip().split("\n")]
+    assert rows[-2][:2] == ["SUM", "raw"] and int(rows[-2][3]) == int(best[2]) and int(rows[-2][8]) == int(best[1]) and rows[-1][8] == best[0]
+    assert [r[0] for r in rows[1:-2:2]] == ["spk0", "spk1"]
+    ops = [l.split() for l in det.joinpath("ops").read_text().strip().split("\n")]
+    assert sum(int(o[3]) for o in ops if o[0] != "insertion") == int(best[2]) and sum(int(o[3]) for o in ops if o[0] == "insertion") == int(best[3])
+    assert all(o[1] == "'***'" for o in ops if o[0] == "insertion") and [o[0] for o in ops] == sorted(o[0] for o in ops)
+    assert det.joinpath("wer_bootci").read_bytes().startswith(b"Set1: WER ") and not list((dec / "scoring_kaldi").glob("penalty_*/*.at"))
     # a missing lattice file is an error
     os.remove(dec / "lat.1")
     assert host.vb_ScoreKaldiWER(str(data).encode(), str(graph).encode(), str(dec).encode(), 2, b"0.0", 8, 8) == -1

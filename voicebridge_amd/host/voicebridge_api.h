@@ -28,6 +28,7 @@
 #define VOICEBRIDGE_API_H_
 
 #include <fstream>
+#include <string>
 
 int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log);
 int ComputeCmvnStats(int argc, char *argv[], std::ofstream &file_log);
@@ -63,6 +64,18 @@ int GmmEstFmllr(int argc, char *argv[], std::ofstream &file_log);
 int ComposeTransforms(int argc, char *argv[], std::ofstream &file_log);
 int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log);
 
+// ---- the per-utterance statistics of ScoreKaldiWER (`stats`); host code in voicebridge_scoring.cc
+//   src/kaldi_src.h:75   int AlignText(int argc, char *argv[]);                     (K/bin/align-text.cc)
+//   src/kaldi_src.h:63   int ComputeWerBootci(int argc, char *argv[], fs::ofstream &file_log);   (K/bin/compute-wer-bootci.cc + output file)
+//   scr/kaldi_scr.h:204-224  WerPerUttDetails / WerPerSpkDetails / WerOpsDetails    (scr/utils/scoring/wer_*_details.cpp)
+int AlignText(int argc, char *argv[]);
+int AlignTextLogged(int argc, char *argv[], std::ofstream &file_log);       // the same with its messages in a log file
+int ComputeWerBootci(int argc, char *argv[], std::ofstream &file_log);
+int WerPerUttDetails(const std::string &in, const std::string &out, const std::string &special_symbol = "<eps>", const std::string &separator = ";",
+                     bool output_hyp = true, bool output_ref = true, bool output_ops = true, bool output_csid = true);
+int WerPerSpkDetails(const std::string &in, const std::string &utt2spk, const std::string &out, int WIDTH = 10, int SPK_WIDTH = 15);
+int WerOpsDetails(const std::string &in, const std::string &out, const std::string &special_symbol = "<eps>");
+
 // plain-C shims of the above for hosts without C++ streams (ctypes, cgo ...): log_path may be NULL
 extern "C" {
 int vb_ComputeMFCCFeats(int argc, char *argv[], const char *log_path);
@@ -87,6 +100,11 @@ int vb_GmmEstFmllrGpost(int argc, char *argv[], const char *log_path);
 int vb_GmmEstFmllr(int argc, char *argv[], const char *log_path);
 int vb_ComposeTransforms(int argc, char *argv[], const char *log_path);
 int vb_GmmRescoreLattice(int argc, char *argv[], const char *log_path);
+int vb_AlignText(int argc, char *argv[]);
+int vb_ComputeWerBootci(int argc, char *argv[], const char *log_path);
+int vb_WerPerUttDetails(const char *in, const char *out, const char *special_symbol);
+int vb_WerPerSpkDetails(const char *in, const char *utt2spk, const char *out);
+int vb_WerOpsDetails(const char *in, const char *out, const char *special_symbol);
 void vb_ComputeWerCounts(long long *out8);   // {word_errs, num_words, ins, del, sub, num_sent, sent_errs, absent} of the last ComputeWer
 int vb_set_workspace_max_active(int max_active);   // search workspaces of the thread's following gmm-latgen-faster calls cover this max_active too (0: off)
 int vb_set_device(int device_id);   // GPU used by the calling thread's subsequent calls (default 0)

@@ -706,7 +706,25 @@ int ScoreKaldiWER(const std::string &data, const std::string &lang_or_graph, con
         MakeDir(Join(sk, "wer_details"));
         WriteLines(Join(Join(sk, "wer_details"), "lmwt"), {std::to_string(best_lmwt)});
         WriteLines(Join(Join(sk, "wer_details"), "wip"), {best_wip});
-        slog << "WARNING per-utterance alignment statistics (wer_details/per_utt, per_spk, ops, wer_bootci) are not produced by this build\n";
+        // the hypotheses of the best combination aligned with the transcripts, then counted per utterance, per speaker and per
+        // word pair, and the bootstrap interval of the WER (score_kaldi_wer.cpp:180-236; the special symbol is passed with its
+        // quotes there, no shell strips them, so the files carry '***')
+        const std::string details = Join(sk, "wer_details"), pen = Join(sk, "penalty_" + best_wip), at = Join(pen, std::to_string(best_lmwt) + ".at");
+        const std::string eps = "'***'";
+        {
+          Argv a({"align-text", "--special-symbol=" + eps, "ark:" + Join(sk, "test_filt.txt"), "ark:" + Join(pen, std::to_string(best_lmwt) + ".txt"), "ark,t:" + at});
+          std::ofstream alog(Join(Join(sk, "log"), "align_text.log"), std::ios::binary);
+          if (AlignTextLogged(a.argc(), a.argv(), alog) < 0) throw StepError("align-text failed, see " + Join(Join(sk, "log"), "align_text.log"));
+        }
+        if (WerPerUttDetails(at, Join(details, "per_utt"), eps) < 0) throw StepError("wer_per_utt_details failed");
+        if (WerPerSpkDetails(Join(details, "per_utt"), Join(data, "utt2spk"), Join(details, "per_spk")) < 0) throw StepError("wer_per_spk_details failed");
+        if (WerOpsDetails(Join(details, "per_utt"), Join(details, "ops"), eps) < 0) throw StepError("wer_ops_details failed");
+        {
+          std::ofstream blog(Join(Join(sk, "log"), "wer_bootci.log"), std::ios::binary);
+          Argv a({"compute-wer-bootci", "--mode=present", "ark:" + Join(sk, "test_filt.txt"), "ark:" + Join(pen, std::to_string(best_lmwt) + ".txt"), Join(details, "wer_bootci")});
+          if (ComputeWerBootci(a.argc(), a.argv(), blog) < 0) throw StepError("compute-wer-bootci failed, see " + Join(Join(sk, "log"), "wer_bootci.log"));
+        }
+        unlink(at.c_str());
       }
     }
   });
