@@ -344,7 +344,7 @@ def test_decode_lda_mllt_sat_model_against_the_reference_chain(host, tmp_path):
 def test_job_threads_leave_the_same_files(host, tmp_path):
     """vb_set_step_devices: the jobs of a step on host threads of their own (here three threads sharing the one GPU and ONE
     pool of search workspaces between their decoders), as VB/scr/steps/decode_gmm.cpp:300-324 runs its nj jobs side by side.
-    Same files, byte for byte, as the jobs one after the other; a second round on the same (persistent) job threads too."""
+    Same files as the jobs one after the other; a second round on the same (persistent) job threads too."""
     from tests import util
     from voicebridge_amd import synth
     H, n_cd, n_words = 3, 10, 30
@@ -352,6 +352,11 @@ def test_job_threads_leave_the_same_files(host, tmp_path):
     g, _ = synth.lexicon_graph(n_words, P, seed=3, n_phones=n_cd)
     offs, w, means, iv = synth.gmm_model(P, P * 3, 39, seed=4, mean_scale=1.5, var_spread=0.3)
     host.vb_set_step_devices.argtypes = [C.POINTER(C.c_int), C.c_int]
+
+    def read_fm_bytes(b):
+        f = tmp_path / "m.ark"
+        f.write_bytes(b)
+        return read_fm_ark(str(f))
     out = {}
     try:
         for tag, devs in (("serial", []), ("threads", [0, 0, 0]), ("threads_again", [0, 0, 0])):
@@ -381,7 +386,26 @@ def test_job_threads_leave_the_same_files(host, tmp_path):
             out[tag] = files
     finally:
         host.vb_set_step_devices((C.c_int * 1)(), 0)
+    # The searches, the feature files and the words are the same byte for byte.  The fMLLR statistics are summed with f64 atomics
+    # (vbh_fmllr.hip), whose order depends on what else the device is running: transforms agree to rounding, and so do the costs
+    # of the final lattices, whose states, arcs and labels are the same.
+    def close_lattices(a, b):
+        la, lb = util.read_lattice_ark_bytes(a), util.read_lattice_ark_bytes(b)
+        assert sorted(la) == sorted(lb)
+        for k in la:
+            (ka, sa, sta), (kb, sb, stb) = la[k], lb[k]
+            assert ka == kb and sa == sb and len(sta) == len(stb)
+            for (fa, aa), (fb, ab) in zip(sta, stb):
+                assert fa[2:] == fb[2:] and np.allclose(fa[:2], fb[:2], rtol=1e-4, atol=2e-3) and len(aa) == len(ab)
+                for x, y in zip(aa, ab):
+                    assert (x[0], x[3], x[4]) == (y[0], y[3], y[4]) and np.allclose(x[1:3], y[1:3], rtol=1e-4, atol=2e-3)
     for tag in ("threads", "threads_again"):
         assert sorted(out[tag]) == sorted(out["serial"])
         for n, v in out["serial"].items():
-            assert out[tag][n] == v, (tag, n)
+            if n.startswith("trans."):
+                ta, tb = read_fm_bytes(out[tag][n]), read_fm_bytes(v)
+                assert sorted(ta) == sorted(tb) and all(np.allclose(ta[k], tb[k], rtol=1e-5, atol=1e-6) for k in ta), (tag, n)
+            elif n.startswith("lat."):
+                close_lattices(out[tag][n], v)
+            else:
+                assert out[tag][n] == v, (tag, n)

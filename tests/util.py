@@ -74,6 +74,15 @@ def read_wav_pcm16(path):
 from voicebridge_amd.refio import write_feats_ark, write_mdl, write_vector_fst, write_wav  # noqa: E402,F401
 
 
+def read_lattice_ark_bytes(raw):
+    """read_lattice_ark of an archive held in memory"""
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".ark") as f:
+        f.write(raw)
+        f.flush()
+        return read_lattice_ark(f.name)
+
+
 def read_lattice_ark(path):
     """Binary lattice archive -> {key: (kind, start, states)}; states = list of (final, arcs); for
     'lattice4' final = (graph, acoustic), arcs = (ilabel, olabel, graph, acoustic, next); for

@@ -398,76 +398,101 @@ std::vector<std::string> FrontEndOptions(const std::string &srcdir, const std::s
 }
 
 // ------------------------------------------------------------------------------------ Decode
+namespace {
+// What the nj jobs of one Decode share.  Decode = PrepareDecode + DecodeJob for every job + FinishDecode (+ scoring); DecodeFmllr
+// runs the jobs of its speaker-independent first pass inside its own per-job chains (no barrier between the passes: while one
+// job estimates its transforms on the host another is still searching).
+struct DecodeJobs {
+  std::string graph_dir, decode_dir, srcdir, sdata, model, trans_dir, trans_all, splice_opts, cmvn_opts, delta_opts;
+  bool use_trans = false, lda = false;
+  int nj = 1, max_active = 7000;
+  double beam = 13.0, lattice_beam = 6.0;
+  float acwt = 0.083333f;
+};
+
+DecodeJobs PrepareDecode(const std::string &graph_dir, const std::string &data_dir, const std::string &decode_dir, const std::string &model_in,
+                         const std::string &trans_dir, const std::string &iter, int nj, float acwt, int max_active, double beam, double lattice_beam,
+                         bool decode_mbr) {
+  if (decode_mbr) throw StepError("MBR decoding (decode_mbr) is not part of this build");
+  if (nj < 1) throw StepError("nj must be >= 1");
+  DecodeJobs c;
+  c.graph_dir = graph_dir; c.decode_dir = decode_dir; c.trans_dir = trans_dir; c.nj = nj; c.acwt = acwt; c.max_active = max_active; c.beam = beam;
+  c.lattice_beam = lattice_beam;
+  // fMLLR transforms of an earlier pass (decode_gmm.cpp:127-172): one archive per job when the job
+  // counts agree, otherwise all of them joined (binary archives concatenate)
+  c.use_trans = !trans_dir.empty() && Exists(trans_dir);
+  if (c.use_trans) {
+    if (!Exists(Join(trans_dir, "trans.1"))) throw StepError("Expected " + Join(trans_dir, "trans.1") + " to exist.");
+    const int nj_orig = atoi(FirstLine(Join(trans_dir, "num_jobs")).c_str());
+    if (nj_orig < 1) throw StepError("Could not read number of jobs from file " + Join(trans_dir, "num_jobs") + ".");
+    if (nj_orig != nj) {
+      MakeDirs(decode_dir);
+      c.trans_all = Join(decode_dir, "trans.ark");
+      std::ofstream out(c.trans_all, std::ios::binary);
+      if (!out) throw StepError("cannot write " + c.trans_all);
+      for (int n = 1; n <= nj_orig; n++) {
+        std::ifstream in(Join(trans_dir, "trans." + std::to_string(n)), std::ios::binary);
+        if (!in) throw StepError(Join(trans_dir, "trans." + std::to_string(n)) + " is required but can not be found.");
+        out << in.rdbuf();
+      }
+    }
+  }
+  c.srcdir = Parent(decode_dir);                  // the model directory (decode_gmm.cpp:80)
+  c.model = model_in;
+  if (c.model.empty()) c.model = Join(c.srcdir, (iter.empty() ? std::string("final") : iter) + ".mdl");
+  for (const std::string &f : {Join(data_dir, "feats.scp"), Join(data_dir, "cmvn.scp"), c.model, Join(graph_dir, "HCLG.fst")})
+    if (!Exists(f)) throw StepError(f + " is required but can not be found.");
+  c.lda = Exists(Join(c.srcdir, "final.mat"));
+  c.splice_opts = FirstLine(Join(c.srcdir, "splice_opts")); c.cmvn_opts = FirstLine(Join(c.srcdir, "cmvn_opts")); c.delta_opts = FirstLine(Join(c.srcdir, "delta_opts"));
+  MakeDirs(decode_dir); MakeDir(Join(decode_dir, "log"));
+  WriteLines(Join(decode_dir, "num_jobs"), {std::to_string(nj)});
+  if (SplitData(data_dir, nj, false) < 0) throw StepError("SplitData failed: " + g_err);
+  c.sdata = Join(data_dir, "split" + std::to_string(nj));
+  return c;
+}
+
+void DecodeJob(const DecodeJobs &c, int j) {
+  const std::string J = std::to_string(j), dsn = Join(c.sdata, J);
+  unlink(Join(c.decode_dir, "lat." + J).c_str());
+  std::ofstream log(Join(Join(c.decode_dir, "log"), "decode." + J + ".log"), std::ios::binary);
+  if (ReadLines(Join(dsn, "feats.scp"), false).empty()) return;
+  // The reference chains apply-cmvn | add-deltas (or splice-feats | transform-feats final.mat) [| transform-feats trans.JOB] |
+  // gmm-latgen-faster through temporary archives (decode_gmm.cpp:201-293).  Here the chain runs on the device in front of the
+  // scoring (GmmLatgenFaster's --fe-* options): the raw features of feats.scp are the only thing read.
+  std::vector<std::string> g = {"gmm-latgen-faster", "--max-active=" + std::to_string(c.max_active), "--beam=" + std::to_string(c.beam),
+                                "--lattice-beam=" + std::to_string(c.lattice_beam), "--acoustic-scale=" + std::to_string(c.acwt),
+                                "--allow-partial=true"};
+  for (const auto &o : FrontEndOptions(c.srcdir, dsn, c.lda, c.cmvn_opts, c.delta_opts, c.splice_opts)) g.push_back(o);
+  if (c.use_trans) g.push_back("--fe-trans=ark:" + (c.trans_all.empty() ? Join(c.trans_dir, "trans." + J) : c.trans_all));
+  const std::string symtab = Join(c.graph_dir, "words.txt");
+  if (Exists(symtab)) g.push_back("--word-symbol-table=" + symtab);
+  g.push_back(c.model); g.push_back(Join(c.graph_dir, "HCLG.fst")); g.push_back("scp:" + Join(dsn, "feats.scp")); g.push_back("ark:" + Join(c.decode_dir, "lat." + J));
+  g.push_back("ark,t:" + Join(c.decode_dir, "w." + J));
+  Argv a4(g);
+  const int rc = GmmLatgenFaster(a4.argc(), a4.argv(), log);
+  if (rc < 0) throw StepError("gmm-latgen-faster failed for job " + J + ", see " + Join(c.decode_dir, "log"));
+  // transcriptionJOB.trn: the words of w.JOB through the symbol table (decode_gmm.cpp:356-376)
+  if (Exists(symtab)) {
+    const std::map<int, std::string> sym = ReadSymbolTable(symtab);
+    std::vector<std::string> out;
+    for (const auto &l : ReadLines(Join(c.decode_dir, "w." + J), false)) out.push_back(Int2SymLine(sym, l));
+    WriteLines(Join(c.decode_dir, "transcription" + J + ".trn"), out);
+  }
+}
+
+void FinishDecode(const DecodeJobs &c) { if (!c.trans_all.empty()) unlink(c.trans_all.c_str()); }
+}  // namespace
+
 int Decode(const std::string &graph_dir, const std::string &data_dir, const std::string &decode_dir, const std::string &model_in,
            const std::string &trans_dir, UMAPSS &wer_ref_filter, UMAPSS &wer_hyp_filter, const std::string &iter, int nj, float acwt,
            int stage, int max_active, double beam, double lattice_beam, bool skip_scoring, bool decode_mbr, bool stats,
            const std::string &word_ins_penalty, int min_lmwt, int max_lmwt) {
-  StepScope scope;          // model, graph and search workspace stay on the device across the nj jobs, and go when the step returns
+  StepScope scope;          // (VB_RELEASE_DEVICE_CACHE=1: model, graph and search workspace go when the outermost step returns)
+  (void)stage;
   const int rc_decode = Run([&] {
-    if (decode_mbr) throw StepError("MBR decoding (decode_mbr) is not part of this build");
-    if (nj < 1) throw StepError("nj must be >= 1");
-    // fMLLR transforms of an earlier pass (decode_gmm.cpp:127-172): one archive per job when the job
-    // counts agree, otherwise all of them joined (binary archives concatenate)
-    std::string trans_all;
-    const bool use_trans = !trans_dir.empty() && Exists(trans_dir);
-    if (use_trans) {
-      if (!Exists(Join(trans_dir, "trans.1"))) throw StepError("Expected " + Join(trans_dir, "trans.1") + " to exist.");
-      const int nj_orig = atoi(FirstLine(Join(trans_dir, "num_jobs")).c_str());
-      if (nj_orig < 1) throw StepError("Could not read number of jobs from file " + Join(trans_dir, "num_jobs") + ".");
-      if (nj_orig != nj) {
-        MakeDirs(decode_dir);
-        trans_all = Join(decode_dir, "trans.ark");
-        std::ofstream out(trans_all, std::ios::binary);
-        if (!out) throw StepError("cannot write " + trans_all);
-        for (int n = 1; n <= nj_orig; n++) {
-          std::ifstream in(Join(trans_dir, "trans." + std::to_string(n)), std::ios::binary);
-          if (!in) throw StepError(Join(trans_dir, "trans." + std::to_string(n)) + " is required but can not be found.");
-          out << in.rdbuf();
-        }
-      }
-    }
-    (void)stage;
-    const std::string srcdir = Parent(decode_dir);                  // the model directory (decode_gmm.cpp:80)
-    std::string model = model_in;
-    if (model.empty()) model = Join(srcdir, (iter.empty() ? std::string("final") : iter) + ".mdl");
-    for (const std::string &f : {Join(data_dir, "feats.scp"), Join(data_dir, "cmvn.scp"), model, Join(graph_dir, "HCLG.fst")})
-      if (!Exists(f)) throw StepError(f + " is required but can not be found.");
-    const bool lda = Exists(Join(srcdir, "final.mat"));
-    const std::string splice_opts = FirstLine(Join(srcdir, "splice_opts")), cmvn_opts = FirstLine(Join(srcdir, "cmvn_opts")),
-                      delta_opts = FirstLine(Join(srcdir, "delta_opts"));
-    MakeDirs(decode_dir); MakeDir(Join(decode_dir, "log"));
-    WriteLines(Join(decode_dir, "num_jobs"), {std::to_string(nj)});
-    if (SplitData(data_dir, nj, false) < 0) throw StepError("SplitData failed: " + g_err);
-    const std::string sdata = Join(data_dir, "split" + std::to_string(nj));
-    ForEachJob(nj, [&](int j) {
-      const std::string J = std::to_string(j), dsn = Join(sdata, J);
-      unlink(Join(decode_dir, "lat." + J).c_str());
-      std::ofstream log(Join(Join(decode_dir, "log"), "decode." + J + ".log"), std::ios::binary);
-      if (ReadLines(Join(dsn, "feats.scp"), false).empty()) return;
-      // The reference chains apply-cmvn | add-deltas (or splice-feats | transform-feats final.mat) [| transform-feats trans.JOB] |
-      // gmm-latgen-faster through temporary archives (decode_gmm.cpp:201-293).  Here the chain runs on the device in front of the
-      // scoring (GmmLatgenFaster's --fe-* options): the raw features of feats.scp are the only thing read.
-      std::vector<std::string> g = {"gmm-latgen-faster", "--max-active=" + std::to_string(max_active), "--beam=" + std::to_string(beam),
-                                    "--lattice-beam=" + std::to_string(lattice_beam), "--acoustic-scale=" + std::to_string(acwt),
-                                    "--allow-partial=true"};
-      for (const auto &o : FrontEndOptions(srcdir, dsn, lda, cmvn_opts, delta_opts, splice_opts)) g.push_back(o);
-      if (use_trans) g.push_back("--fe-trans=ark:" + (trans_all.empty() ? Join(trans_dir, "trans." + J) : trans_all));
-      const std::string symtab = Join(graph_dir, "words.txt");
-      if (Exists(symtab)) g.push_back("--word-symbol-table=" + symtab);
-      g.push_back(model); g.push_back(Join(graph_dir, "HCLG.fst")); g.push_back("scp:" + Join(dsn, "feats.scp")); g.push_back("ark:" + Join(decode_dir, "lat." + J));
-      g.push_back("ark,t:" + Join(decode_dir, "w." + J));
-      Argv a4(g);
-      const int rc = GmmLatgenFaster(a4.argc(), a4.argv(), log);
-      if (rc < 0) throw StepError("gmm-latgen-faster failed for job " + J + ", see " + Join(decode_dir, "log"));
-      // transcriptionJOB.trn: the words of w.JOB through the symbol table (decode_gmm.cpp:356-376)
-      if (Exists(symtab)) {
-        const std::map<int, std::string> sym = ReadSymbolTable(symtab);
-        std::vector<std::string> out;
-        for (const auto &l : ReadLines(Join(decode_dir, "w." + J), false)) out.push_back(Int2SymLine(sym, l));
-        WriteLines(Join(decode_dir, "transcription" + J + ".trn"), out);
-      }
-    });
-    if (!trans_all.empty()) unlink(trans_all.c_str());
+    const DecodeJobs c = PrepareDecode(graph_dir, data_dir, decode_dir, model_in, trans_dir, iter, nj, acwt, max_active, beam, lattice_beam, decode_mbr);
+    ForEachJob(nj, [&](int j) { DecodeJob(c, j); });
+    FinishDecode(c);
   });
   if (rc_decode != 0 || skip_scoring) return rc_decode;
   if (!Exists(Join(data_dir, "text"))) { g_err = "Not scoring because " + Join(data_dir, "text") + " is missing"; return -1; }
@@ -489,6 +514,8 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
     if (decode_mbr) throw StepError("MBR decoding (decode_mbr) is not part of this build");
     if (nj < 1) throw StepError("nj must be >= 1");
     const double first_beam = 10.0; const int first_max_active = 2000;      // decode_fmllr.cpp:116-117
+    DecodeJobs si_jobs;
+    bool run_si = false;
     const std::string srcdir = Parent(dir), sdata = Join(data, "split" + std::to_string(nj));
     MakeDirs(Join(dir, "log"));
     if (SplitData(data, nj, false) < 0) throw StepError("SplitData failed: " + g_err);
@@ -510,18 +537,19 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
       while (si_dir.size() > 1 && si_dir.back() == '/') si_dir.pop_back();
       si_dir += ".si";
       if (stage <= 0) {
-        UMAPSS f1, f2;
-        // the first pass searches with max-active 2000, the main pass below with max_active: one set of search workspaces for both
+        // the speaker-independent first pass (decode_fmllr.cpp:215-259 calls Decode): its jobs run at the head of the per-job chains
+        // below.  It searches with max-active 2000, the main pass with max_active: one set of search workspaces for both
         vb_set_workspace_max_active(std::max(first_max_active, max_active));
-        if (Decode(graphdir, data, si_dir, alignment_model, "", f1, f2, "", nj, acwt, 0, first_max_active, first_beam, 6.0, skip_scoring, decode_mbr, stats,
-                   word_ins_penalty, min_lmwt, max_lmwt) < 0)
-          throw StepError("First pass speaker-independent decoding failed: " + g_err);
+        if (!skip_scoring && !Exists(Join(data, "text")))
+          throw StepError("First pass speaker-independent decoding failed: Not scoring because " + Join(data, "text") + " is missing");
+        si_jobs = PrepareDecode(graphdir, data, si_dir, alignment_model, "", "", nj, acwt, first_max_active, first_beam, 6.0, decode_mbr);
+        run_si = true;
       }
     }
     if (atoi(FirstLine(Join(si_dir, "num_jobs")).c_str()) != nj) throw StepError("Mismatch in number of jobs with si-dir.");
     const std::string adapt_model = (adapt_model_in.empty() || !Exists(adapt_model_in)) ? Join(srcdir, "final.mdl") : adapt_model_in;
     const std::string final_model = (final_model_in.empty() || !Exists(final_model_in)) ? Join(srcdir, "final.mdl") : final_model_in;
-    for (const std::string &f : {Join(si_dir, "lat.1"), adapt_model, final_model}) if (!Exists(f)) throw StepError("Failed to find " + f);
+    for (const std::string &f : {Join(si_dir, "lat.1"), adapt_model, final_model}) if (!Exists(f) && !(run_si && f == Join(si_dir, "lat.1"))) throw StepError("Failed to find " + f);
     const bool lda = Exists(Join(srcdir, "final.mat"));
     const std::string acw = "--acoustic-scale=" + std::to_string(acwt), symtab = Join(graphdir, "words.txt");
     const bool laps = getenv("VBH_DEBUG_TIMES") != nullptr;
@@ -534,6 +562,10 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
     };
     ForEachJob(nj, [&](int j) {
       const std::string J = std::to_string(j), dsn = Join(sdata, J);
+      if (run_si) {
+        try { DecodeJob(si_jobs, j); }
+        catch (const std::exception &e) { throw StepError(std::string("First pass speaker-independent decoding failed: ") + e.what()); }
+      }
       if (ReadLines(Join(dsn, "feats.scp"), false).empty()) return;
       std::ofstream log(Join(Join(dir, "log"), "fmllr." + J + ".log"), std::ios::binary);
       // ---- the features of every program below: the job's raw feats.scp behind the fused front end (the reference writes
@@ -583,7 +615,14 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
         unlink(t_grl.c_str()); unlink(lat_tmp.c_str());
       }
     });
-
+    if (run_si) {
+      FinishDecode(si_jobs);
+      if (!skip_scoring) {        // (what Decode does for the first pass when it runs as a step of its own)
+        UMAPSS f1, f2;
+        if (ScoreKaldiWER(data, graphdir, si_dir, f1, f2, nj, 0, decode_mbr, stats, 6.0, word_ins_penalty, min_lmwt, max_lmwt, "final") < 0)
+          throw StepError("First pass speaker-independent decoding failed: " + g_err);
+      }
+    }
   });
   if (rc != 0) return rc;
   if (!skip_scoring) {
@@ -592,9 +631,9 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
   }
   return Run([&] {       // words and transcripts of the final lattices (:642-745)
     const std::string symtab = Join(graphdir, "words.txt");
-    for (int j = 1; j <= nj; j++) {
+    ForEachJob(nj, [&](int j) {
       const std::string J = std::to_string(j);
-      if (!Exists(Join(dir, "lat." + J))) continue;
+      if (!Exists(Join(dir, "lat." + J))) return;
       std::ofstream log(Join(Join(dir, "log"), "decode." + J + ".log"), std::ios::binary);
       Argv a({"lattice-best-path", "ark:" + Join(dir, "lat." + J), "ark,t:" + Join(dir, "w." + J)});
       if (LatticeBestPath(a.argc(), a.argv(), log) < 0) throw StepError("lattice-best-path failed for job " + J);
@@ -605,7 +644,7 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
         WriteLines(Join(dir, "transcription" + J + ".trn"), out);
       }
       unlink(Join(dir, "trans_tmp." + J).c_str()); unlink(Join(dir, "pre_trans." + J).c_str());
-    }
+    });
   });
 }
 
