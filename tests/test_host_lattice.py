@@ -213,6 +213,14 @@ def test_fresh_cases_vs_reference_programs(host, tmp_path, seed, n_words, n_cd, 
         assert_same_archives(str(d / ("m_" + fn)), str(d / fn))
     assert (d / "m_best_words.txt").read_text().split() == (d / "best_words.txt").read_text().split()
     assert (d / "m_best_ali.txt").read_text().split() == (d / "best_ali.txt").read_text().split()
+    # and with --minimize=true, at a wider beam (more to merge)
+    p = lambda n: str(d / n)
+    for prog, fn, extra in (("lattice-determinize-pruned", host.vb_LatticeDeterminizePruned, []),
+                            ("lattice-determinize-phone-pruned", host.vb_LatticeDeterminizePhonePruned, [p("final.mdl")])):
+        a = ["--acoustic-scale=0.083333", "--beam=%s" % (float(beam) + 3.0), "--minimize=true"] + extra + ["ark:" + p("raw.ark")]
+        gg.ref(prog, *a, "ark:" + p("r_min.ark"))
+        assert call(fn, [prog] + a + ["ark:" + p("m_min.ark")], p("m_log.txt")) == 0
+        assert_same_archives(p("m_min.ark"), p("r_min.ark"))
 
 
 def test_score_kaldi_wer_on_golden_lattices(host, tmp_path):
@@ -290,3 +298,28 @@ def test_text_mode_lattice_archives(host, tmp_path):
     assert call(host.vb_LatticeDeterminizePruned, ["lattice-determinize-pruned", acwt, beam, "ark,t:" + p("r_l.txt"), "ark:" + p("m_l.ark")], log) == 0, open(log).read()
     ref("lattice-determinize-pruned", acwt, beam, "ark,t:" + p("r_l.txt"), "ark:" + p("r_l.ark"))
     assert_same_archives(p("m_l.ark"), p("r_l.ark"))
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_minimize_equals_the_reference_programs(host, tmp_path, case):
+    """--minimize=true (K/lat/push-lattice.cc, K/lat/minimize-lattice.cc behind K/latbin/lattice-determinize-pruned.cc:111-115 and
+    K/lat/determinize-lattice-pruned.cc:1460-1466): transition-id strings and weights pushed towards the start, equivalent states
+    merged.  Expected: the archives the reference's own programs wrote (tests/golden/lattices_min.npz, oracle/gen_golden_lat_min.py),
+    bit for bit; cases a and c lose a quarter / half of their states to the merge."""
+    g = util.load("lattices_min")
+    p = lambda n: str(tmp_path / n)
+    (tmp_path / "raw.ark").write_bytes(g[case + "_raw"].tobytes())
+    (tmp_path / "final.mdl").write_bytes(g[case + "_mdl"].tobytes())
+    acwt, beam = "--acoustic-scale=%s" % str(g["acwt"]), "--beam=%s" % str(g[case + "_beam"])
+    for fn, tag, extra in ((host.vb_LatticeDeterminizePruned, "p", []), (host.vb_LatticeDeterminizePhonePruned, "pp", [p("final.mdl")])):
+        (tmp_path / ("ref_%s.ark" % tag)).write_bytes(g["%s_det_%s_min" % (case, tag)].tobytes())
+        assert call(fn, ["prog", acwt, beam, "--minimize=true"] + extra + ["ark:" + p("raw.ark"), "ark:" + p("min_%s.ark" % tag)], p("log")) == 0, open(p("log")).read()
+        assert_same_archives(p("min_%s.ark" % tag), p("ref_%s.ark" % tag))
+        assert call(fn, ["prog", acwt, beam] + extra + ["ark:" + p("raw.ark"), "ark:" + p("det_%s.ark" % tag)], p("log")) == 0
+        n_det = sum(len(v[2]) for v in util.read_lattice_ark(p("det_%s.ark" % tag)).values())
+        n_min = sum(len(v[2]) for v in util.read_lattice_ark(p("min_%s.ark" % tag)).values())
+        assert [n_det, n_min] == g["%s_states_%s" % (case, tag)].tolist()
+        # the best path is what it was
+        for a in ("det", "min"):
+            assert call(host.vb_LatticeBestPath, ["lattice-best-path", acwt, "ark:" + p("%s_%s.ark" % (a, tag)), "ark,t:" + p("w_" + a), "ark,t:" + p("ali_" + a)], p("log")) == 0
+        assert open(p("w_det")).read() == open(p("w_min")).read() and open(p("ali_det")).read() == open(p("ali_min")).read()

@@ -796,9 +796,166 @@ bool DeterminizeLatticePhonePrunedWrapper(const TransInfo &tm, Lattice *ifst, do
       throw std::runtime_error("lattice determinization: --word-determinize=false is not supported");
   }
   ans = DeterminizeLatticePruned(*ifst, beam, ofst, det) && ans;
-  if (opts.minimize) throw std::runtime_error("lattice determinization: --minimize is not supported");
+  if (opts.minimize) {
+    ans = PushCompactLatticeStrings(ofst) && ans;
+    ans = PushCompactLatticeWeights(ofst) && ans;
+    ans = MinimizeCompactLattice(ofst, kDelta) && ans;
+  }
   Connect(ofst);
   return ans;
+}
+
+// ---- push and minimize (what --minimize adds after determinization: K/lat/determinize-lattice-pruned.cc:1460-1466,
+//      K/latbin/lattice-determinize-pruned.cc:111-115)
+static bool IsZeroC(const CWeight &w) { return IsZero(w.w) && w.str.empty(); }
+static bool SortedOrSort(CompactLattice *clat) { return IsTopSorted(*clat) || TopSort(clat); }
+
+namespace {
+// The first `len` transition-ids met from `state` on: along arc `arc_idx`, or (arc_idx < 0) along "any" path, which is the
+// state's final string when it is final and its first arc otherwise (CompactLatticePusher::GetString, K/lat/push-lattice.cc:53-86)
+void StringFrom(const CompactLattice &clat, int32_t state, int arc_idx, int32_t *out, size_t len) {
+  while (len != 0) {
+    const CState &st = clat.st[state];
+    if (arc_idx < 0 && !IsZeroC(st.final)) {
+      if (st.final.str.size() < len) throw std::runtime_error("push: paths in the lattice have inconsistent lengths");
+      std::copy(st.final.str.begin(), st.final.str.begin() + len, out);
+      return;
+    }
+    const size_t a = arc_idx < 0 ? 0 : (size_t)arc_idx;
+    if (a >= st.arcs.size()) throw std::runtime_error("push: paths in the lattice are inconsistent in length");
+    const std::vector<int32_t> &str = st.arcs[a].w.str;
+    if (str.size() >= len) { std::copy(str.begin(), str.begin() + len, out); return; }
+    std::copy(str.begin(), str.end(), out);
+    out += str.size(); len -= str.size();
+    state = st.arcs[a].next; arc_idx = -1;
+  }
+}
+}  // namespace
+
+// K/lat/push-lattice.cc:30-228: every state hands back to its incoming arcs the transition-ids that all of its continuations
+// start with (the longest common prefix, found from the last state to the first), so that equal futures look equal
+bool PushCompactLatticeStrings(CompactLattice *clat) {
+  if (!SortedOrSort(clat)) return false;
+  const int32_t n = (int32_t)clat->st.size();
+  std::vector<int32_t> shift(n, 0);
+  std::vector<int32_t> a, b;
+  for (int32_t s = n - 1; s > clat->start; s--) {
+    const CState &st = clat->st[s];
+    if (st.arcs.empty()) { shift[s] = (int32_t)st.final.str.size(); continue; }
+    const bool is_final = !IsZeroC(st.final);
+    int32_t sh = std::numeric_limits<int32_t>::max();
+    if (is_final) sh = std::min(sh, (int32_t)st.final.str.size());
+    for (const CArc &arc : st.arcs) sh = std::min(sh, shift[arc.next] + (int32_t)arc.w.str.size());
+    if (st.arcs.size() + (is_final ? 1 : 0) > 1 && sh > 0) {      // CheckForConflict (:88-131)
+      a.assign(sh, 0); b.assign(sh, 0);
+      size_t arc;
+      if (is_final) { std::copy(st.final.str.begin(), st.final.str.begin() + sh, a.begin()); arc = 0; }
+      else { StringFrom(*clat, s, 0, a.data(), a.size()); arc = 1; }
+      for (; arc < st.arcs.size(); arc++) {
+        StringFrom(*clat, s, (int)arc, b.data(), b.size());
+        const size_t same = std::mismatch(a.begin(), a.end(), b.begin()).first - a.begin();
+        if (same != a.size()) { sh = (int32_t)same; a.resize(same); b.resize(same); }
+      }
+    }
+    shift[s] = sh;
+  }
+  std::vector<int32_t> str;
+  for (int32_t s = 0; s < n; s++) {        // ApplyShifts (:170-201)
+    const int32_t sh = shift[s];
+    CState &st = clat->st[s];
+    for (CArc &arc : st.arcs) {
+      if (arc.next <= s) throw std::runtime_error("push: cyclic lattice");
+      str = arc.w.str;
+      const size_t orig = str.size(), more = (size_t)shift[arc.next];
+      str.resize(orig + more);
+      StringFrom(*clat, arc.next, -1, str.data() + orig, more);
+      arc.w.str.assign(str.begin() + sh, str.end());
+    }
+    if (!IsZeroC(st.final)) st.final.str.erase(st.final.str.begin(), st.final.str.begin() + sh);
+  }
+  return true;
+}
+
+// K/lat/push-lattice.cc:239-289: weights pushed towards the start (each state's best cost to the end becomes zero)
+bool PushCompactLatticeWeights(CompactLattice *clat) {
+  if (!SortedOrSort(clat)) return false;
+  const int32_t n = (int32_t)clat->st.size();
+  if (n == 0) return true;
+  std::vector<Weight> to_end(n);
+  for (int32_t s = n - 1; s >= 0; s--) {
+    Weight w = clat->st[s].final.w;
+    for (const CArc &arc : clat->st[s].arcs) {
+      if (arc.next <= s) throw std::runtime_error("push: cyclic lattices not allowed");
+      w = Plus(w, Times(arc.w.w, to_end[arc.next]));
+    }
+    to_end[s] = w;
+  }
+  to_end[0] = One();       // the leftover stays on the start state
+  for (int32_t s = 0; s < n; s++) {
+    const Weight here = to_end[s];
+    if (IsZero(here)) continue;
+    for (CArc &arc : clat->st[s].arcs)
+      if (!IsZero(to_end[arc.next])) arc.w.w = Times(arc.w.w, Divide(to_end[arc.next], here));
+    if (!IsZeroC(clat->st[s].final)) clat->st[s].final.w = Divide(clat->st[s].final.w, here);
+  }
+  return true;
+}
+
+// K/lat/minimize-lattice.cc:38-270: from the last state to the first, a state joins the first later state (among those with
+// the same hash of final string, labels, strings and successor classes) that has approximately the same final weight and, arc
+// by arc in label order, the same label, string, successor class and approximately the same weight.  The hash only narrows the
+// search -- which states merge does not depend on it -- so it need not be the reference's.
+bool MinimizeCompactLattice(CompactLattice *clat, float delta) {
+  if (!SortedOrSort(clat)) return false;
+  const int32_t n = (int32_t)clat->st.size();
+  auto hash_str = [](const std::vector<int32_t> &v) { uint64_t h = 1469598103934665603ull; for (int32_t x : v) h = (h ^ (uint32_t)x) * 1099511628211ull; return h | 1ull; };
+  std::vector<uint64_t> hash(n);
+  for (int32_t s = n - 1; s >= 0; s--) {
+    const CState &st = clat->st[s];
+    uint64_t h = IsZeroC(st.final) ? 33317ull : 607ull * hash_str(st.final.str);
+    for (const CArc &arc : st.arcs)        // (a sum: the order of the arcs must not matter)
+      h += 1447ull * (uint64_t)(arc.label == 0 ? 51907 : arc.label) * (1ull + hash_str(arc.w.str) * (arc.next > s ? hash[arc.next] : 1ull));
+    hash[s] = h;
+  }
+  std::unordered_map<uint64_t, std::vector<int32_t>> groups;
+  for (int32_t s = 0; s < n; s++) groups[hash[s]].push_back(s);
+  std::vector<int32_t> map(n);
+  for (int32_t s = 0; s < n; s++) map[s] = s;
+  struct Key { int32_t label, next; const CArc *arc; };
+  auto sorted_arcs = [&](int32_t state, std::vector<Key> *out) {
+    out->clear();
+    for (const CArc &arc : clat->st[state].arcs) {
+      if (arc.next == state) continue;                  // (self-loops are left out of the comparison, :163-167)
+      if (arc.next < state) throw std::runtime_error("minimize: lattice not topologically sorted");
+      out->push_back(Key{arc.label, map[arc.next], &arc});
+    }
+    std::sort(out->begin(), out->end(), [](const Key &x, const Key &y) { return x.label != y.label ? x.label < y.label : x.next < y.next; });
+  };
+  std::vector<Key> ka, kb;
+  auto equivalent = [&](int32_t s, int32_t t) {
+    const CState &a = clat->st[s], &b = clat->st[t];
+    if (!(ApproxEqual(a.final.w, b.final.w, delta) && a.final.str == b.final.str)) return false;
+    if (a.arcs.size() != b.arcs.size()) return false;
+    sorted_arcs(s, &ka); sorted_arcs(t, &kb);
+    if (ka.size() != kb.size()) throw std::runtime_error("minimize: self-loops in the lattice");
+    for (size_t i = 0; i < ka.size(); i++) {
+      if (ka[i].next != kb[i].next || ka[i].label != kb[i].label) return false;
+      if (!(ApproxEqual(ka[i].arc->w.w, kb[i].arc->w.w) && ka[i].arc->w.str == kb[i].arc->w.str)) return false;
+    }
+    return true;
+  };
+  int32_t removed = 0;
+  for (int32_t s = n - 1; s >= 0; s--)
+    for (int32_t t : groups[hash[s]])
+      if (t > s && map[t] == t && equivalent(s, t)) { map[s] = t; removed++; break; }
+  if (removed == 0) return true;
+  if (clat->start >= 0) clat->start = map[clat->start];
+  for (int32_t s = 0; s < n; s++) {
+    if (map[s] != s) continue;
+    for (CArc &arc : clat->st[s].arcs) arc.next = map[arc.next];
+  }
+  Connect(clat);
+  return true;
 }
 
 bool PruneLattice(float beam, Lattice *lat) {

@@ -96,6 +96,11 @@ bool DeterminizeLatticePruned(const Lattice &ifst, double beam, Lattice *ofst, D
 bool DeterminizeLatticePhonePrunedWrapper(const TransInfo &tm, Lattice *ifst, double beam, CompactLattice *ofst,
                                           PhoneDetOptions opts = PhoneDetOptions());
 bool PruneLattice(float beam, Lattice *lat);
+// --minimize: transition-id strings and weights pushed towards the start, then equivalent states merged
+// (kaldi-master/src/lat/push-lattice.cc, minimize-lattice.cc); false when the lattice cannot be sorted topologically
+bool PushCompactLatticeStrings(CompactLattice *clat);
+bool PushCompactLatticeWeights(CompactLattice *clat);
+bool MinimizeCompactLattice(CompactLattice *clat, float delta = kDelta);
 
 // ---- what scoring uses
 void ScaleLattice(double s00, double s01, double s10, double s11, Lattice *lat);

@@ -68,7 +68,7 @@ int LatticeDeterminizePruned(int argc, char *argv[], std::ofstream &file_log) {
     po.Parse(argc, argv);
     if (po.args.size() != 2) throw ApiError("Wrong arguments.");
     const float acoustic_scale = (float)po.Num("acoustic-scale", 1.0), beam = (float)po.Num("beam", 10.0);
-    if (po.Bool("minimize", false)) throw ApiError("--minimize=true is not supported");
+    const bool minimize = po.Bool("minimize", false);
     const vblat::DetOptions opts = ReadDetOptions(po, 50000000, 0);
     if (acoustic_scale == 0.0f) throw ApiError("Do not use a zero acoustic scale (cannot be inverted)");
     vbio::LatticeReader reader(po.args[0]);
@@ -95,6 +95,11 @@ int LatticeDeterminizePruned(int argc, char *argv[], std::ofstream &file_log) {
             it.ok = vblat::DeterminizeLatticePruned(it.lat, beam, &it.det, opts);
             vblat::Connect(&it.det);
             it.empty = it.det.st.empty();
+            if (minimize) {             // K/latbin/lattice-determinize-pruned.cc:111-115
+              vblat::PushCompactLatticeStrings(&it.det);
+              vblat::PushCompactLatticeWeights(&it.det);
+              vblat::MinimizeCompactLattice(&it.det);
+            }
             TopSortCompactIfNeeded(&it.det);
             it.depth = CompactLatticeDepth(it.det, &it.t);
             it.in_states = it.lat.st.size();
