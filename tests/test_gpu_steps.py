@@ -409,3 +409,24 @@ def test_job_threads_leave_the_same_files(host, tmp_path):
                 close_lattices(out[tag][n], v)
             else:
                 assert out[tag][n] == v, (tag, n)
+
+
+def test_make_mfcc_with_speaker_warp_factors(host, tmp_path):
+    """MakeMfcc on a data directory with spk2warp (VB/scr/steps/make_mfcc.cpp:63-76: --vtln-map=ark:spk2warp --utt2spk=ark:utt2spk):
+    the archives hold what compute-mfcc-feats computes with each speaker's warp factor"""
+    from oracle import vbo
+    data, conf, utts = make_datadir(tmp_path, n_utt=4, n_spk=2, seconds=0.8)
+    (data / "spk2warp").write_text("spk0 0.92\nspk1 1.08\n")
+    assert host.vb_MakeMfcc(str(data).encode(), str(conf).encode(), 2, 0, 0) == 0, host.vb_steps_last_error()
+    feats = {}
+    for j in (1, 2):
+        feats.update(read_fm_ark(str(data / "mfcc" / ("raw_mfcc_test.%d.ark" % j))))
+    assert sorted(feats) == utts
+    import wave as wavmod
+    o = vbo.mfcc_opts()
+    o.use_energy = 0
+    for i, u in enumerate(utts):
+        with wavmod.open(str(data / (u + ".wav")), "rb") as f:
+            x = np.frombuffer(f.readframes(f.getnframes()), "<i2").astype(np.float32)
+        np.testing.assert_allclose(feats[u], vbo.mfcc(x, o, vtln_warp=0.92 if i < 2 else 1.08), atol=2e-3, rtol=1e-5)
+    assert np.abs(feats[utts[0]] - vbo.mfcc(np.frombuffer(wavmod.open(str(data / (utts[0] + ".wav")), "rb").readframes(10 ** 7), "<i2").astype(np.float32), o)).max() > 0.05

@@ -1421,6 +1421,33 @@ std::vector<std::pair<std::string, std::vector<int32_t>>> ReadIntVectorTable(con
   return out;
 }
 
+std::map<std::string, float> ReadFloatTable(const std::string &rspecifier) {
+  const Rspec spec = ParseRspecifier(rspecifier);
+  if (spec.is_scp) Fail("scp: is not supported for float tables");
+  std::ifstream is(spec.path, std::ios::binary);
+  if (!is) Fail("cannot open " + spec.path);
+  std::map<std::string, float> out;
+  for (;;) {
+    const std::string key = ReadArkKey(is);
+    if (key.empty()) break;
+    float v = 0.0f;
+    if (is.peek() == '\0') {                 // "\0B", then the size byte and the value (WriteBasicType)
+      ReadBinaryHeader(is);
+      const int sz = is.get();
+      if (sz != 4) Fail("float table " + spec.path + ": expected a 4-byte float at key " + key);
+      is.read(reinterpret_cast<char *>(&v), 4);
+      if (!is) Fail("float table " + spec.path + " is truncated at key " + key);
+    } else {
+      std::string line;
+      std::getline(is, line);
+      std::istringstream ls(line);
+      if (!(ls >> v)) Fail("bad value in float table " + spec.path + " at key " + key);
+    }
+    out[key] = v;
+  }
+  return out;
+}
+
 std::vector<std::pair<std::string, std::vector<std::string>>> ReadTokenTable(const std::string &rspecifier) {
   const Rspec spec = ParseRspecifier(rspecifier);
   if (spec.is_scp) Fail("scp: is not supported for token tables");

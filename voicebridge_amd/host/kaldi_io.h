@@ -230,6 +230,8 @@ void WriteFloat(std::ostream &os, bool binary, float v);
 
 // Int32Vector tables in text or binary form (words, alignments): key -> ints
 std::vector<std::pair<std::string, std::vector<int32_t>>> ReadIntVectorTable(const std::string &rspecifier);
+// BaseFloat tables (one float per key, text "key 0.95" or binary): VTLN warp factors per speaker / utterance
+std::map<std::string, float> ReadFloatTable(const std::string &rspecifier);
 // token tables ("key tok tok ..." text lines): reference transcripts for compute-wer
 std::vector<std::pair<std::string, std::vector<std::string>>> ReadTokenTable(const std::string &rspecifier);
 

@@ -265,7 +265,17 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
     o.energy_floor = (float)po.Num("energy-floor", 0.0); o.raw_energy = po.Bool("raw-energy", true);
     o.cepstral_lifter = (float)po.Num("cepstral-lifter", 22.0); o.htk_compat = po.Bool("htk-compat", false);
     if (po.Str("output-format", "kaldi") != "kaldi") throw ApiError("Invalid output_format string " + po.Str("output-format", ""));
-    if (po.Has("vtln-map") || po.Has("utt2spk")) throw ApiError("--vtln-map / --utt2spk are not supported");
+    // --vtln-map=<rspecifier> [--utt2spk=<rspecifier>]: a warp factor per utterance, or per speaker (K/featbin/compute-mfcc-feats.cc:82-86,
+    // 127-137).  A warp factor is a set of mel-bank tables (vbh_mfcc_create); consecutive utterances with the same factor -- a speaker's,
+    // in a sorted table -- go to the device in one call.
+    const bool use_vtln_map = po.Has("vtln-map");
+    if (po.Has("utt2spk") && !use_vtln_map) throw ApiError("the utt2spk option is only needed if the vtln-map option is used.");
+    std::map<std::string, float> vtln_map;
+    std::map<std::string, std::string> vtln_utt2spk;
+    if (use_vtln_map) {
+      vtln_map = vbio::ReadFloatTable(po.Str("vtln-map", ""));
+      if (po.Has("utt2spk")) for (auto &kv : vbio::ReadTokenTable(po.Str("utt2spk", ""))) if (!kv.second.empty()) vtln_utt2spk[kv.first] = kv.second[0];
+    }
     if (po.Bool("allow-downsample", false)) throw ApiError("--allow-downsample is not supported");
     const bool subtract_mean = po.Bool("subtract-mean", false);
     const float vtln_warp = (float)po.Num("vtln-warp", 1.0);
@@ -320,8 +330,21 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
       if (!num_frames_out) throw ApiError("cannot open " + ws.ark_path);
     }
     vbh_ctx *ctx = Ctx();
-    vbh_mfcc *mf = nullptr;
-    Check(vbh_mfcc_create(ctx, &o, vtln_warp, &mf), "vbh_mfcc_create");
+    // one front end per warp factor in use (the mel banks are host-built tables on the device); all destroyed at the end
+    struct Banks {
+      vbh_ctx *ctx; const vbh_mfcc_opts *o; std::map<uint32_t, vbh_mfcc *> by_warp;
+      vbh_mfcc *Get(float warp) {
+        uint32_t bits; memcpy(&bits, &warp, 4);
+        auto it = by_warp.find(bits);
+        if (it != by_warp.end()) return it->second;
+        vbh_mfcc *m = nullptr;
+        Check(vbh_mfcc_create(ctx, o, warp, &m), "vbh_mfcc_create");
+        by_warp[bits] = m;
+        return m;
+      }
+      ~Banks() { for (auto &kv : by_warp) vbh_mfcc_destroy(kv.second); }
+    } banks{ctx, &o, {}};
+    if (!use_vtln_map) banks.Get(vtln_warp);       // (option errors surface before any file is read)
     int num_utts = 0, num_success = 0;
     size_t num_success_batches_base = 0;      // utterances handed to the device so far: the dither stream's utterance index
     // utterances are packed into batches of ~64 M samples per device pass
@@ -332,7 +355,7 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
     else for (size_t k = 0; k < scp.size(); k++) units.push_back(Unit{scp[k].key, k, -1});
     size_t i = 0;
     while (i < units.size()) {
-      std::vector<std::string> keys; std::vector<int64_t> woff(1, 0); std::vector<float> samples;
+      std::vector<std::string> keys; std::vector<int64_t> woff(1, 0); std::vector<float> samples; std::vector<float> warps;
       // the files of a batch are read and parsed on several host threads (a 30 s utterance is 1 MB of PCM), then taken in table order;
       // a recording that several segments of the batch cut from is read once
       const size_t i0 = i;
@@ -404,6 +427,15 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
           } else if (ch >= w.channels) { log.os() << "WARNING (compute-mfcc-feats) File with id " << un.key << " has " << w.channels << " channels but you specified channel " << channel << ", producing no output.\n"; continue; }
         }
         if (w.samp_freq != o.samp_freq) { log.os() << "WARNING (compute-mfcc-feats) Failed to compute features for utterance " << un.key << ": sample frequency mismatch " << w.samp_freq << " vs " << o.samp_freq << "\n"; continue; }
+        float warp_local = vtln_warp;
+        if (use_vtln_map) {
+          std::string mk = un.key;
+          if (!vtln_utt2spk.empty() || po.Has("utt2spk")) { const auto iu = vtln_utt2spk.find(un.key); mk = iu == vtln_utt2spk.end() ? std::string() : iu->second; }
+          const auto iw = mk.empty() ? vtln_map.end() : vtln_map.find(mk);
+          if (iw == vtln_map.end()) { log.os() << "WARNING (compute-mfcc-feats) No vtln-map entry for utterance-id (or speaker-id) " << un.key << "\n"; continue; }
+          warp_local = iw->second;
+        }
+        warps.push_back(warp_local);
         keys.push_back(un.key);
         samples.insert(samples.end(), w.data[ch].begin() + (std::ptrdiff_t)s0, w.data[ch].begin() + (std::ptrdiff_t)s1);
         woff.push_back((int64_t)samples.size());
@@ -414,11 +446,19 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
       for (size_t u = 0; u < keys.size(); u++) total += vbh_mfcc_num_frames(&o, woff[u + 1] - woff[u]);
       DevMem d_wave(ctx, sizeof(float) * samples.size()), d_feats(ctx, sizeof(float) * (size_t)total * o.num_ceps);
       Check(vbh_copy_h2d(ctx, d_wave.p, samples.data(), sizeof(float) * samples.size()), "vbh_copy_h2d");
-      std::vector<int64_t> foff(keys.size() + 1);
-      if (o.dither != 0.0f)
-        Check(vbh_mfcc_set_dither_stream(mf, dither_seed ? dither_seed : 0x4F6CDD1D2545F491ull, (int64_t)num_success_batches_base), "vbh_mfcc_set_dither_stream");
+      std::vector<int64_t> foff(keys.size() + 1, 0);
+      for (size_t g0 = 0; g0 < keys.size();) {        // runs of utterances with one warp factor
+        size_t g1 = g0 + 1;
+        while (g1 < keys.size() && warps[g1] == warps[g0]) g1++;
+        vbh_mfcc *mf = banks.Get(warps[g0]);
+        if (o.dither != 0.0f)
+          Check(vbh_mfcc_set_dither_stream(mf, dither_seed ? dither_seed : 0x4F6CDD1D2545F491ull, (int64_t)(num_success_batches_base + g0)), "vbh_mfcc_set_dither_stream");
+        std::vector<int64_t> fo(g1 - g0 + 1);
+        Check(vbh_mfcc_compute(mf, d_wave.p, 0, woff.data() + g0, (int32_t)(g1 - g0), (float *)d_feats.p + foff[g0] * o.num_ceps, fo.data()), "vbh_mfcc_compute");
+        for (size_t u = g0; u < g1; u++) foff[u + 1] = foff[g0] + fo[u - g0 + 1];
+        g0 = g1;
+      }
       num_success_batches_base += keys.size();
-      Check(vbh_mfcc_compute(mf, d_wave.p, 0, woff.data(), (int32_t)keys.size(), (float *)d_feats.p, foff.data()), "vbh_mfcc_compute");
       std::vector<float> feats((size_t)total * o.num_ceps);
       Check(vbh_copy_d2h(ctx, feats.data(), d_feats.p, sizeof(float) * feats.size()), "vbh_copy_d2h");
       // the utterances are encoded (compressed archives: a sort per column) on several threads, written in table order
@@ -454,7 +494,6 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
         num_success++;
       }
     }
-    vbh_mfcc_destroy(mf);
     writer.Close();
     log.os() << "LOG (compute-mfcc-feats)  Done " << num_success << " out of " << num_utts << " utterances.\n";
     return num_success != 0 ? 0 : 1;

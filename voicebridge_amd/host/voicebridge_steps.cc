@@ -252,7 +252,10 @@ int MakeMfcc(const std::string &datadir, const std::string &mfcc_config, int nj,
     // extract-segments; here compute-mfcc-feats takes the job's share of the segments file itself, --segments)
     const bool use_segments = Exists(Join(datadir, "segments"));
     const std::vector<std::string> seg_lines = use_segments ? ReadLines(Join(datadir, "segments")) : std::vector<std::string>();
-    if (Exists(Join(datadir, "spk2warp")) || Exists(Join(datadir, "utt2warp"))) throw StepError("VTLN warp maps are not part of this build");
+    // VTLN warp factors per speaker or per utterance (make_mfcc.cpp:63-76)
+    std::vector<std::string> vtln_opts;
+    if (Exists(Join(datadir, "spk2warp"))) vtln_opts = {"--vtln-map=ark:" + Join(datadir, "spk2warp"), "--utt2spk=ark:" + Join(datadir, "utt2spk")};
+    else if (Exists(Join(datadir, "utt2warp"))) vtln_opts = {"--vtln-map=ark:" + Join(datadir, "utt2warp")};
     const auto pieces = SplitLines(use_segments ? seg_lines : wav, nj);
     ForEachJob(nj, [&](int j) {
       const std::string J = std::to_string(j);
@@ -265,6 +268,7 @@ int MakeMfcc(const std::string &datadir, const std::string &mfcc_config, int nj,
       (void)temp;
       std::vector<std::string> c = {"compute-mfcc-feats", "--config=" + mfcc_config, std::string("--compress=") + (compress ? "true" : "false")};
       if (write_utt2num_frames) c.push_back("--write-num-frames=ark,t:" + Join(logdir, "utt2num_frames." + J));
+      for (const auto &o : vtln_opts) c.push_back(o);
       if (use_segments) { c.push_back("--segments=" + piece); c.push_back("scp,p:" + scp); }
       else c.push_back("scp,p:" + piece);
       c.push_back("ark,scp:" + Join(mfccdir, "raw_mfcc_" + name + "." + J + ".ark") + "," + Join(mfccdir, "raw_mfcc_" + name + "." + J + ".scp"));
