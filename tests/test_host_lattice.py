@@ -221,6 +221,12 @@ def test_fresh_cases_vs_reference_programs(host, tmp_path, seed, n_words, n_cd, 
         gg.ref(prog, *a, "ark:" + p("r_min.ark"))
         assert call(fn, [prog] + a + ["ark:" + p("m_min.ark")], p("m_log.txt")) == 0
         assert_same_archives(p("m_min.ark"), p("r_min.ark"))
+    # the phone-level pass alone, and no determinization at all (K/lat/determinize-lattice-pruned.cc:1423-1429,1445-1450)
+    for flags in (["--word-determinize=false"], ["--phone-determinize=false", "--word-determinize=false"]):
+        a = ["--acoustic-scale=0.083333", "--beam=%s" % beam] + flags + [p("final.mdl"), "ark:" + p("raw.ark")]
+        gg.ref("lattice-determinize-phone-pruned", *a, "ark:" + p("r_part.ark"))
+        assert call(host.vb_LatticeDeterminizePhonePruned, ["lattice-determinize-phone-pruned"] + a + ["ark:" + p("m_part.ark")], p("m_log.txt")) == 0
+        assert_same_archives(p("m_part.ark"), p("r_part.ark"))
 
 
 def test_score_kaldi_wer_on_golden_lattices(host, tmp_path):

@@ -755,8 +755,10 @@ bool DeterminizeLatticePhonePrunedWrapper(const TransInfo &tm, Lattice *ifst, do
       throw std::runtime_error("Topological sorting of state-level lattice failed (probably your lexicon has empty words or your LM has epsilon cycles).");
   }
   ArcSortILabel(ifst);
-  if (!opts.phone_determinize && !opts.word_determinize)
-    throw std::runtime_error("lattice determinization: --phone-determinize and --word-determinize both false is not supported");
+  // words are on the input side here; the conversion to a compact lattice wants the transition-ids there (ConvertLattice with
+  // invert = false inverts a copy, K/fstext/lattice-utils-inl.h:41-49)
+  auto convert_as_is = [&]() { Lattice back = *ifst; Invert(&back); ConvertLattice(back, ofst); Connect(ofst); };
+  if (!opts.phone_determinize && !opts.word_determinize) { convert_as_is(); return ans; }      // (:1423-1429: copied without determinization)
   DetOptions det;
   det.delta = opts.delta;
   det.max_mem = opts.max_mem;
@@ -792,8 +794,7 @@ bool DeterminizeLatticePhonePrunedWrapper(const TransInfo &tm, Lattice *ifst, do
     ans = DeterminizeLatticePruned(*ifst, beam, ifst, det) && ans;
     for (State &s : ifst->st) for (Arc &a : s.arcs) if (a.ilabel >= first_phone_label) a.ilabel = 0;
     TopSort(ifst);
-    if (!opts.word_determinize)
-      throw std::runtime_error("lattice determinization: --word-determinize=false is not supported");
+    if (!opts.word_determinize) { convert_as_is(); return ans; }        // (:1445-1450)
   }
   ans = DeterminizeLatticePruned(*ifst, beam, ofst, det) && ans;
   if (opts.minimize) {
