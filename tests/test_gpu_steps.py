@@ -430,3 +430,20 @@ def test_make_mfcc_with_speaker_warp_factors(host, tmp_path):
             x = np.frombuffer(f.readframes(f.getnframes()), "<i2").astype(np.float32)
         np.testing.assert_allclose(feats[u], vbo.mfcc(x, o, vtln_warp=0.92 if i < 2 else 1.08), atol=2e-3, rtol=1e-5)
     assert np.abs(feats[utts[0]] - vbo.mfcc(np.frombuffer(wavmod.open(str(data / (utts[0] + ".wav")), "rb").readframes(10 ** 7), "<i2").astype(np.float32), o)).max() > 0.05
+
+
+def test_job_threads_report_a_failing_job_and_go_on(host, tmp_path):
+    """a job that fails on its thread fails the step with its message (the first one), the other jobs finish, and the job threads
+    serve the next step"""
+    host.vb_set_step_devices.argtypes = [C.POINTER(C.c_int), C.c_int]
+    data, conf, utts = make_datadir(tmp_path, n_utt=4, n_spk=2, seconds=0.6)
+    try:
+        assert host.vb_set_step_devices((C.c_int * 2)(0, 0), 2) == 0
+        bad = tmp_path / "bad.conf"
+        bad.write_text("--use-energy=false\n--dither=0\n--no-such-option=1\n")
+        assert host.vb_MakeMfcc(str(data).encode(), str(bad).encode(), 2, 1, 0) == -1
+        assert b"compute-mfcc-feats failed for job" in host.vb_steps_last_error()
+        assert host.vb_MakeMfcc(str(data).encode(), str(conf).encode(), 2, 1, 0) == 0, host.vb_steps_last_error()
+        assert len((data / "feats.scp").read_text().strip().split("\n")) == len(utts)
+    finally:
+        host.vb_set_step_devices((C.c_int * 1)(), 0)
