@@ -359,7 +359,7 @@ def test_job_threads_leave_the_same_files(host, tmp_path):
         return read_fm_ark(str(f))
     out = {}
     try:
-        for tag, devs in (("serial", []), ("threads", [0, 0, 0]), ("threads_again", [0, 0, 0])):
+        for tag, devs in (("serial", [0]), ("threads", [0, 0, 0]), ("threads_again", [])):      # ([]: the default, four job threads on device 0)
             d = tmp_path / tag
             d.mkdir()
             data, conf, utts = make_datadir(d, n_utt=6, n_spk=3, seconds=4.5)

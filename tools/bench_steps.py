@@ -27,11 +27,10 @@ def main():
     ap.add_argument("--train-utts", type=int, default=128)
     ap.add_argument("--pdfs", type=int, default=2499)
     ap.add_argument("--gauss", type=int, default=15000)
-    ap.add_argument("--job-threads", type=int, default=1, help="host threads the jobs of a step run on, all on GPU 0 (VB_STEP_DEVICES=0,0,...)")
+    ap.add_argument("--job-threads", type=int, default=4, help="host threads the jobs of a step run on, all on GPU 0 (VB_STEP_DEVICES=0,0,...)")
     ap.add_argument("--fmllr", action="store_true", help="also time DecodeFmllr (SI pass, two fMLLR estimates, main search, rescoring, determinization)")
     a = ap.parse_args()
-    if a.job_threads > 1:
-        os.environ["VB_STEP_DEVICES"] = ",".join(["0"] * a.job_threads)
+    os.environ["VB_STEP_DEVICES"] = ",".join(["0"] * max(a.job_threads, 1))      # (one entry: the jobs one after the other)
     import torch        # before the product's libraries: torch brings its own HIP runtime, and the one loaded first serves the process
     host = C.CDLL(build.HOST_LIB)
     host.vb_steps_last_error.restype = C.c_char_p

@@ -1353,6 +1353,7 @@ void vb_det_pool_destroy(void *pool) {
 // the calling thread's following gmm-latgen-faster calls make their search workspaces large enough for this max_active as well
 int vb_set_workspace_max_active(int max_active) { g_workspace_max_active.store(max_active > 0 ? max_active : 0); return 0; }
 int vb_set_device(int device_id) { if (device_id != g_device) g_latgen.Release(); g_device = device_id; return 0; }
+int vb_get_device(void) { return g_device; }
 // frees the model, graph and search workspace the calling thread's last gmm-latgen-faster call left on the device
 void vb_release_device_cache(void) { g_latgen.Release(); ReleaseRawTableCache(); }
 int vb_ComputeMFCCFeats(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return ComputeMFCCFeats(argc, argv, l); }); }

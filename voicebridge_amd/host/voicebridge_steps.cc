@@ -48,9 +48,10 @@ struct StepError : public std::runtime_error {
   explicit StepError(const std::string &m) : std::runtime_error(m) {}
 };
 
-// Devices the jobs of a step are spread over (vb_set_step_devices / VB_STEP_DEVICES, default: the calling thread's device
-// only).  The reference starts its nj jobs as nj threads (VB/scr/steps/decode_gmm.cpp:300-324); here a job is a batch for a
-// GPU, so the jobs are dealt round-robin to the listed devices, one host thread per device, each running its jobs in order.
+// Devices the jobs of a step are spread over (vb_set_step_devices / VB_STEP_DEVICES; default: the calling thread's device named
+// four times).  The reference starts its nj jobs as nj threads (VB/scr/steps/decode_gmm.cpp:300-324); here a job is a batch for a
+// GPU, so the jobs are dealt round-robin to the entries of the list, one host thread per entry, each running its jobs in order: a
+// device named several times is shared by that many job threads (one job's host work overlaps the others' kernels).
 std::vector<int> g_step_devices;
 std::vector<int> StepDevices() {
   if (!g_step_devices.empty()) return g_step_devices;
@@ -58,6 +59,11 @@ std::vector<int> StepDevices() {
   if (const char *e = getenv("VB_STEP_DEVICES")) {
     std::string w; std::istringstream is(e);
     while (std::getline(is, w, ',')) if (!w.empty()) d.push_back(atoi(w.c_str()));
+  }
+  if (d.empty()) {        // default: the calling thread's device, its jobs on up to four host threads (VB_STEP_JOB_THREADS; 1 = one after the other)
+    int n = 4;
+    if (const char *e = getenv("VB_STEP_JOB_THREADS")) n = std::max(1, std::min(64, atoi(e)));
+    d.assign((size_t)n, vb_get_device());
   }
   return d;
 }

@@ -11,9 +11,10 @@
 //                                                        nj, acwt, stage, max_active, beam, lattice_beam, skip_scoring, ...)
 //                                                                                             scr/steps/decode_gmm.cpp:60-390
 // Same names, argument order and meaning, return 0 / -1; std::string stands in for boost::filesystem::path.
-// The nj jobs of a step are batches for a GPU here, not processes.  By default they run one after the other on the calling
-// thread's GPU (vb_set_device); vb_set_step_devices (or VB_STEP_DEVICES=0,1,...) names the GPUs of the node to use: the jobs
-// are then dealt round-robin to them, one host thread per device -- the reference's nj concurrent job threads
+// The nj jobs of a step are batches for a GPU here, not processes.  By default they run on up to four host threads that share the
+// calling thread's GPU (vb_set_device; VB_STEP_JOB_THREADS=1 or a one-entry device list: one after the other on the calling thread);
+// vb_set_step_devices (or VB_STEP_DEVICES=0,1,...) names the GPUs of the node to use: the jobs
+// are then dealt round-robin to them, one host thread per entry -- the reference's nj concurrent job threads
 // (scr/steps/decode_gmm.cpp:300-324), with a device behind each.  A device may be named more than once ("0,0,0,0"): that many
 // job threads share it, one job's host work (archives, determinization, fMLLR updates) overlapping the others' kernels, their
 // decoders drawing on ONE pool of search workspaces.  The job threads persist (and keep their model / graph / workspace
@@ -85,7 +86,7 @@ int vb_ScoreKaldiWER(const char *data, const char *lang_or_graph, const char *di
                      int max_lmwt);
 const char *vb_steps_last_error(void);
 int vb_set_release_device_cache(int on);               // 1: every outermost step frees model, graph and search workspace when it returns (default 0: they stay for the next step; vb_release_device_cache() frees them)
-int vb_set_step_devices(const int *devices, int n);    // GPUs the jobs of the steps are spread over (n = 0: the calling thread's device only)
+int vb_set_step_devices(const int *devices, int n);    // GPUs the jobs of the steps are spread over (n = 0: back to the default, four job threads on the calling thread's device)
 }
 
 #endif
