@@ -103,6 +103,62 @@ def test_fmllr_chain_matches_golden(host, tmp_path):
     compare_chain(d)
 
 
+def test_text_mode_posterior_tables(host, tmp_path):
+    """"ark,t:" posterior tables (K/hmm/posterior.cc:32-125): what lattice-to-post and weight-silence-post write in text mode is
+    what the reference's programs write, and what they read back gives the binary chain's result to the six digits text keeps"""
+    d = tmp_path
+    g = util.load("fmllr")
+    for k in g.files:
+        if k.startswith("file_"):
+            name = k[5:].rsplit("_", 1)
+            (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
+    p = lambda n: str(d / n)
+    run = mine_runner(host, d)
+    run("lattice-to-post", "--acoustic-scale=0.083333", "ark:" + p("ldp.ark"), "ark,t:" + p("post.txt"))
+    run("weight-silence-post", "0.01", "1:2", p("final.mdl"), "ark,t:" + p("post.txt"), "ark,t:" + p("wsp.txt"))
+    run("weight-silence-post", "1.0", "1:2", p("final.mdl"), "ark,t:" + p("wsp.txt"), "ark:" + p("wsp_bin.ark"))       # text in, binary out, unchanged weights
+
+    def read_post(path):
+        raw = open(path, "rb").read()
+        pos, out = 0, {}
+        while pos < len(raw):
+            sp = raw.index(b" ", pos)
+            key = raw[pos:sp].decode()
+            assert raw[sp + 1:sp + 3] == b"\0B"
+            pos = sp + 3
+            def i32():
+                nonlocal pos
+                assert raw[pos] == 4
+                v = int(np.frombuffer(raw, "<i4", 1, pos + 1)[0]); pos += 5
+                return v
+            frames = []
+            for _ in range(i32()):
+                fr = []
+                for _ in range(i32()):
+                    tid = i32()
+                    assert raw[pos] == 4
+                    fr.append((tid, float(np.frombuffer(raw, "<f4", 1, pos + 1)[0]))); pos += 5
+                frames.append(fr)
+            out[key] = frames
+        return out
+    want, got = read_post(p("wsp.ark")), read_post(p("wsp_bin.ark"))
+    assert list(want) == list(got)
+    for k in want:
+        assert len(want[k]) == len(got[k])
+        for fa, fb in zip(want[k], got[k]):
+            assert [x[0] for x in fa] == [x[0] for x in fb]
+            np.testing.assert_allclose([x[1] for x in fb], [x[1] for x in fa], rtol=2e-5, atol=1e-9)
+    first = open(p("post.txt")).readline().split()
+    assert first[1] == "[" and first[-1] == "]"
+    if all(os.access(os.path.join(REFBIN, b), os.X_OK) for b in ("lattice-to-post", "weight-silence-post")):
+        import subprocess
+        env = dict(os.environ, OPENBLAS_NUM_THREADS="1")
+        subprocess.run([os.path.join(REFBIN, "lattice-to-post"), "--acoustic-scale=0.083333", "ark:" + p("ldp.ark"), "ark,t:" + p("r_post.txt")], check=True, capture_output=True, env=env)
+        subprocess.run([os.path.join(REFBIN, "weight-silence-post"), "0.01", "1:2", p("final.mdl"), "ark,t:" + p("r_post.txt"), "ark,t:" + p("r_wsp.txt")], check=True, capture_output=True, env=env)
+        assert open(p("post.txt")).read() == open(p("r_post.txt")).read()
+        assert open(p("wsp.txt")).read() == open(p("r_wsp.txt")).read()
+
+
 @pytest.mark.skipif(not all(os.access(os.path.join(REFBIN, b), os.X_OK) for b in NEEDED), reason="oracle/_ref/bin not built")
 def test_fresh_case_vs_reference_programs(host, tmp_path):
     import sys

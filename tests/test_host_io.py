@@ -114,6 +114,25 @@ def test_model_reader(host, files):
     np.testing.assert_array_equal(iv, g["mdl_iv"])
 
 
+def test_text_mode_model(host, files, tmp_path):
+    """the same model in text form, as the reference's gmm-copy --binary=false wrote it (tests/golden/model_text.npz): the topology in
+    its own grammar (K/hmm/hmm-topology.cc:41-127), tuples, matrices in brackets; numbers as printed, i.e. to six digits"""
+    d, g = files
+    (tmp_path / "final_text.mdl").write_bytes(load("model_text")["file_final_text_mdl"].tobytes())
+    np_, dim, nt, ng = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    assert host.vbio_model_load(str(tmp_path / "final_text.mdl").encode(), C.byref(np_), C.byref(dim), C.byref(nt), C.byref(ng)) == 0, host.vbio_last_error()
+    assert [np_.value, dim.value] == g["mdl_meta"].tolist() and nt.value == len(g["tid2pdf"]) - 1 and ng.value == len(g["mdl_weights"])
+    t2p = np.zeros(nt.value + 1, np.int32); offs = np.zeros(np_.value + 1, np.int32)
+    w = np.zeros(ng.value, np.float32); miv = np.zeros(ng.value * dim.value, np.float32); iv = np.zeros_like(miv)
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    host.vbio_model_get(P(t2p, C.c_int), P(offs, C.c_int), P(w, C.c_float), P(miv, C.c_float), P(iv, C.c_float))
+    np.testing.assert_array_equal(t2p[1:], g["tid2pdf"][1:])
+    np.testing.assert_array_equal(offs, g["mdl_offs"])
+    np.testing.assert_allclose(w, g["mdl_weights"], rtol=2e-5)
+    np.testing.assert_allclose(miv, g["mdl_miv"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(iv, g["mdl_iv"], rtol=2e-5)
+
+
 def test_fst_reader(host, files):
     d, g = files
     ns, na, st = C.c_int(), C.c_longlong(), C.c_int()

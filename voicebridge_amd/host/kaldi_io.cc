@@ -638,17 +638,69 @@ void ReadModel(const std::string &path, Model *m) {
   std::ifstream is(path, std::ios::binary);
   if (!is) Fail("cannot open model " + path);
   const bool binary = ReadBinaryHeader(is);
-  if (!binary) Fail("text-mode .mdl is not supported: " + path);
   // ---- TransitionModel (transition-model.cc:383-409)
   ExpectToken(is, binary, "<TransitionModel>");
   ExpectToken(is, binary, "<Topology>");
   std::vector<int32_t> phones, phone2idx;
-  ReadIntVector(is, binary, &phones);
-  ReadIntVector(is, binary, &phone2idx);
-  int32_t sz = ReadInt32(is, binary);
+  std::vector<std::vector<HmmState>> entries;
+  if (!binary) {
+    // the text form of a topology is its own little language (hmm-topology.cc:41-127): <TopologyEntry> <ForPhones> p p .. </ForPhones>
+    // <State> i [<PdfClass> c | <ForwardPdfClass> c <SelfLoopPdfClass> c] {<Transition> dst prob} </State> ... </TopologyEntry>
+    for (;;) {
+      std::string tok = ReadToken(is, false);
+      if (tok == "</Topology>") break;
+      if (tok != "<TopologyEntry>") Fail("model: expected </Topology> or <TopologyEntry>, got " + tok);
+      ExpectToken(is, false, "<ForPhones>");
+      std::vector<int32_t> ph;
+      for (;;) {
+        const std::string w = ReadToken(is, false);
+        if (w == "</ForPhones>") break;
+        char *end = nullptr;
+        const long v = strtol(w.c_str(), &end, 10);
+        if (end == w.c_str() || *end || v <= 0) Fail("model: expected a phone, got " + w);
+        ph.push_back((int32_t)v);
+      }
+      std::vector<HmmState> entry;
+      tok = ReadToken(is, false);
+      while (tok != "</TopologyEntry>") {
+        if (tok != "<State>") Fail("model: expected </TopologyEntry> or <State>, got " + tok);
+        if (ReadInt32(is, false) != (int32_t)entry.size()) Fail("model: topology states are expected in order from zero");
+        HmmState st; st.fwd = -1; st.self = -1;
+        tok = ReadToken(is, false);
+        if (tok == "<PdfClass>") { st.fwd = st.self = ReadInt32(is, false); tok = ReadToken(is, false); }
+        else if (tok == "<ForwardPdfClass>") {
+          st.fwd = ReadInt32(is, false);
+          ExpectToken(is, false, "<SelfLoopPdfClass>");
+          st.self = ReadInt32(is, false);
+          tok = ReadToken(is, false);
+        }
+        while (tok == "<Transition>") {
+          const int32_t dst = ReadInt32(is, false);
+          st.trans.emplace_back(dst, ReadFloat(is, false));
+          tok = ReadToken(is, false);
+        }
+        if (tok != "</State>") Fail("model: unexpected token in the topology: " + tok);
+        entry.push_back(std::move(st));
+        tok = ReadToken(is, false);
+      }
+      for (int32_t p : ph) {
+        if ((int32_t)phone2idx.size() <= p) phone2idx.resize(p + 1, -1);
+        if (phone2idx[p] != -1) Fail("model: phone " + std::to_string(p) + " appears in several topology entries");
+        phone2idx[p] = (int32_t)entries.size();
+        phones.push_back(p);
+      }
+      entries.push_back(std::move(entry));
+    }
+  }
+  int32_t sz = 0;
   bool is_hmm = true;
-  if (sz == -1) { is_hmm = false; sz = ReadInt32(is, binary); }
-  std::vector<std::vector<HmmState>> entries(sz);
+  if (binary) {
+    ReadIntVector(is, binary, &phones);
+    ReadIntVector(is, binary, &phone2idx);
+    sz = ReadInt32(is, binary);
+    if (sz == -1) { is_hmm = false; sz = ReadInt32(is, binary); }
+    entries.resize(sz);
+  }
   for (int32_t i = 0; i < sz; i++) {
     const int32_t n = ReadInt32(is, binary);
     entries[i].resize(n);
@@ -663,7 +715,7 @@ void ReadModel(const std::string &path, Model *m) {
       }
     }
   }
-  ExpectToken(is, binary, "</Topology>");
+  if (binary) ExpectToken(is, binary, "</Topology>");
   const std::string tok = ReadToken(is, binary);
   if (tok != "<Triples>" && tok != "<Tuples>") Fail("model: expected <Triples> or <Tuples>, got " + tok);
   const int32_t ntup = ReadInt32(is, binary);
@@ -1280,16 +1332,27 @@ void WriteFloat(std::ostream &os, bool binary, float v) {
   if (binary) { os.put(4); os.write(reinterpret_cast<const char *>(&v), 4); } else os << v << ' ';
 }
 
-std::ofstream OpenArkForWriting(const std::string &wspecifier) {
+std::ofstream OpenArkForWriting(const std::string &wspecifier, bool *text) {
   const Wspec spec = ParseWspecifier(wspecifier);
-  if (!spec.has_ark || spec.has_scp || spec.text) Fail("expected a binary ark: wspecifier, got " + wspecifier);
+  if (text) *text = spec.text;
+  if (!spec.has_ark || spec.has_scp || (spec.text && !text)) Fail("expected a binary ark: wspecifier, got " + wspecifier);
   std::ofstream f(spec.ark_path, std::ios::binary);
   if (!f) Fail("cannot open " + spec.ark_path + " for writing");
   return f;
 }
 
 // One buffer per entry, one stream call (a job's table has a few million 5-byte fields)
-void SerializePosterior(const Posterior &post, std::string *b) {
+void SerializePosterior(const Posterior &post, std::string *b, bool text) {
+  if (text) {       // posterior.cc:45-55: "[ tid weight tid weight ] [ ... ] \n", numbers as operator<< prints them at the precision 7 Kaldi gives its text streams (InitKaldiOutputStream)
+    char num[48];
+    for (const auto &fr : post) {
+      b->append("[ ");
+      for (const auto &pr : fr) { snprintf(num, sizeof(num), "%d %.7g ", pr.first, (double)pr.second); b->append(num); }
+      b->append("] ");
+    }
+    b->push_back('\n');
+    return;
+  }
   size_t n = 0;
   for (const auto &fr : post) n += fr.size();
   b->reserve(b->size() + 7 + 5 * post.size() + 10 * n);
@@ -1301,9 +1364,9 @@ void SerializePosterior(const Posterior &post, std::string *b) {
     for (const auto &pr : fr) { put_i32(pr.first); b->push_back(4); b->append(reinterpret_cast<const char *>(&pr.second), 4); }
   }
 }
-void WritePosteriorEntry(std::ostream &os, const std::string &key, const Posterior &post) {
+void WritePosteriorEntry(std::ostream &os, const std::string &key, const Posterior &post, bool text) {
   std::string b;
-  SerializePosterior(post, &b);
+  SerializePosterior(post, &b, text);
   os << key << ' ';
   os.write(b.data(), (std::streamsize)b.size());
 }
@@ -1348,7 +1411,29 @@ std::vector<std::pair<std::string, Posterior>> ReadPosteriorTable(const std::str
     const std::string key(k, p);
     need(3);
     p++;
-    if (p[0] != '\0' || p[1] != 'B') Fail("text-mode posteriors are not supported: " + spec.path);
+    if (p[0] != '\0' || p[1] != 'B') {       // text: the rest of the line, "[ tid weight ... ] [ ... ]" (posterior.cc:80-125)
+      const char *eol = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+      if (!eol) eol = end;
+      std::istringstream ls(std::string(p, eol));
+      Posterior post;
+      std::string t;
+      while (ls >> t) {
+        if (t != "[") Fail("posterior: expected [ in the text entry of " + key + " in " + spec.path);
+        post.emplace_back();
+        for (;;) {
+          if (!(ls >> t)) Fail("posterior: unterminated frame in the text entry of " + key);
+          if (t == "]") break;
+          char *e1 = nullptr;
+          const long tid = strtol(t.c_str(), &e1, 10);
+          float w;
+          if (e1 == t.c_str() || *e1 || !(ls >> w)) Fail("posterior: bad pair in the text entry of " + key);
+          post.back().emplace_back((int32_t)tid, w);
+        }
+      }
+      out.emplace_back(key, std::move(post));
+      p = eol;
+      continue;
+    }
     p += 2;
     const int32_t sz = get_i32();
     if (sz < 0 || (size_t)sz > (size_t)(end - p) / 5) Fail("posterior: bad size");

@@ -218,12 +218,12 @@ std::string LatticeObjectToText(const std::string &object);                // a 
 // Posterior / GaussPost tables (K/hmm/posterior.cc:32-62,127-215), binary archives
 typedef vblat::Posterior Posterior;
 typedef std::vector<std::vector<std::pair<int32_t, std::vector<float>>>> GaussPost;    // per frame: (pdf-id, per-Gaussian posteriors)
-void WritePosteriorEntry(std::ostream &os, const std::string &key, const Posterior &post);
-void SerializePosterior(const Posterior &post, std::string *b);      // the entry's bytes after "key "
+void WritePosteriorEntry(std::ostream &os, const std::string &key, const Posterior &post, bool text = false);
+void SerializePosterior(const Posterior &post, std::string *b, bool text = false);      // the entry's bytes after "key " (text: the "ark,t:" form)
 void WriteGaussPostEntry(std::ostream &os, const std::string &key, const GaussPost &gpost);
 std::vector<std::pair<std::string, Posterior>> ReadPosteriorTable(const std::string &rspecifier);
 std::vector<std::pair<std::string, GaussPost>> ReadGaussPostTable(const std::string &rspecifier);
-std::ofstream OpenArkForWriting(const std::string &wspecifier);      // "ark:" only, binary
+std::ofstream OpenArkForWriting(const std::string &wspecifier, bool *text = nullptr);      // "ark:" (binary); "ark,t:" when the caller takes the flag
 // spk2utt: speaker -> utterances, in file order
 std::vector<std::pair<std::string, std::vector<std::string>>> ReadSpk2Utt(const std::string &rspecifier);
 void WriteFloat(std::ostream &os, bool binary, float v);

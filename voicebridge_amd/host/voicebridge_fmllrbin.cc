@@ -98,7 +98,8 @@ int LatticeToPost(int argc, char *argv[], std::ofstream &file_log) {
     const float acoustic_scale = (float)po.Num("acoustic-scale", 1.0), lm_scale = (float)po.Num("lm-scale", 1.0);
     if (acoustic_scale == 0.0f) throw ApiError("Do not use a zero acoustic scale (cannot be inverted)");
     vbio::LatticeReader reader(po.args[0]);
-    std::ofstream out = vbio::OpenArkForWriting(po.args[1]);
+    bool text_out = false;
+    std::ofstream out = vbio::OpenArkForWriting(po.args[1], &text_out);
     int n_done = 0;
     double total_like = 0.0, total_ac = 0.0, total_time = 0.0;
     // the lattices of the table are independent: parsed, scaled, forward-backward and the entry's bytes on the host's threads;
@@ -119,7 +120,7 @@ int LatticeToPost(int argc, char *argv[], std::ofstream &file_log) {
             vblat::Posterior post;
             it.like = vblat::LatticeForwardBackward(lat, &post, &it.ac);
             it.frames = post.size();
-            vbio::SerializePosterior(post, &it.entry);
+            vbio::SerializePosterior(post, &it.entry, text_out);
           } catch (const std::exception &e) { it.err = e.what(); if (it.err.empty()) it.err = "error"; }
         }
       };
@@ -160,7 +161,8 @@ int WeightSilencePost(int argc, char *argv[], std::ofstream &file_log) {
     { std::string tok; std::istringstream is(po.args[1]); while (std::getline(is, tok, ':')) { if (tok.empty()) throw ApiError("Invalid silence-phones string " + po.args[1]); sil.insert(atoi(tok.c_str())); } }
     vbio::Model model;
     vbio::ReadModel(po.args[2], &model);
-    std::ofstream out = vbio::OpenArkForWriting(po.args[4]);
+    bool text_out = false;
+    std::ofstream out = vbio::OpenArkForWriting(po.args[4], &text_out);
     int n = 0;
     for (auto &kv : vbio::ReadPosteriorTable(po.args[3])) {
       for (auto &fr : kv.second) {
@@ -173,7 +175,7 @@ int WeightSilencePost(int argc, char *argv[], std::ofstream &file_log) {
         }
         fr.swap(keep);
       }
-      vbio::WritePosteriorEntry(out, kv.first, kv.second);
+      vbio::WritePosteriorEntry(out, kv.first, kv.second, text_out);
       n++;
     }
     log.os() << "LOG (weight-silence-post) Done " << n << " posteriors.\n";
