@@ -319,6 +319,21 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
   return v;
 }
+// reductions over the wave on the VALU, result in every lane (same DPP ladder as the scan; lanes a step does not reach keep the identity)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  const int id = -1;      // 0xFFFFFFFF
+#define VBH_DPP_MIN(ctrl, rows) { const unsigned o_ = (unsigned)__builtin_amdgcn_update_dpp(id, (int)v, ctrl, rows, 0xf, false); v = o_ < v ? o_ : v; }
+  VBH_DPP_MIN(0x111, 0xf) VBH_DPP_MIN(0x112, 0xf) VBH_DPP_MIN(0x114, 0xf) VBH_DPP_MIN(0x118, 0xf) VBH_DPP_MIN(0x142, 0xa) VBH_DPP_MIN(0x143, 0xc)
+#undef VBH_DPP_MIN
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readlane(wave_incl_scan((int)v), 63); }
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+  const unsigned mh = wave_min_u32(hi);
+  const unsigned ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+  return ((unsigned long long)mh << 32) | ml;
+}
 __device__ __forceinline__ long long clk() { return (long long)__builtin_amdgcn_s_memtime(); }
 
 // Load-balanced expansion inside a wave.  Every lane brings one item with `cnt` sub-items
@@ -443,11 +458,7 @@ __device__ __forceinline__ const unsigned *map_key(const Shared &sh) { return sh
 
 // block reductions with ONE barrier each: partials go to red[par], par flips on every call
 __device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v, Shared &sh, int &par) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    unsigned long long w = __shfl_xor(v, o, 64);
-    v = w < v ? w : v;
-  }
+  v = wave_min_u64(v);
   if ((threadIdx.x & 63) == 0) sh.red[par][threadIdx.x >> 6] = v;
   __syncthreads();
   unsigned long long r = sh.red[par][0];
@@ -457,8 +468,7 @@ __device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v
   return r;
 }
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, Shared &sh, int &par) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v = ((unsigned long long)wave_sum_u32((unsigned)(v >> 32)) << 32) | wave_sum_u32((unsigned)v);      // (both halves stay below 2^32: counts of a frame's tokens)
   if ((threadIdx.x & 63) == 0) sh.red[par][threadIdx.x >> 6] = v;
   __syncthreads();
   unsigned long long r = 0;
@@ -1608,9 +1618,8 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
               float it_min = INF;
 #pragma unroll
               for (int u = 0; u < UA; u++) if (valid[u]) it_min = fminf(it_min, tot[u] + adaptive_beam);
-#pragma unroll
-              for (int o = 32; o > 0; o >>= 1) it_min = fminf(it_min, __shfl_xor(it_min, o, 64));
-              if (lane == 0) atomicMin(&sh.cand_bound, f2o(it_min));
+              const unsigned it_key = wave_min_u32(f2o(it_min));      // (the order-preserving key: min of keys = key of the min)
+              if (lane == 0) atomicMin(&sh.cand_bound, it_key);
               const float bnd = o2f(sh.cand_bound);
 #pragma unroll
               for (int u = 0; u < UA; u++) keep[u] = valid[u] && !(tot[u] > bnd);
