@@ -104,6 +104,7 @@ constexpr int U = VBH_U;                    // independent items per lane in the
 #define VBH_UA 4
 #endif
 constexpr int UA = VBH_UA;                  // x 64 arcs a wave has in flight in pass 1
+static_assert(UA >= 1 && UA <= 4, "Shared::wx holds 64 x 4 marker bytes per wave");
 constexpr int UM = VBH_UM;                  // ... in the compaction moves
 constexpr int UC = VBH_UC;                  // ... in the candidate passes (LDS-bound: more only costs registers)
 constexpr int UL = VBH_UL;                  // ... in the pruning sweeps over links
@@ -340,51 +341,73 @@ __device__ __forceinline__ long long clk() { return (long long)__builtin_amdgcn_
 // (0 = none); body(valid, owner, j) is then called wave-uniformly with the sub-items dealt
 // out 64 at a time: lane handles sub-item j of the item that lane `owner` brought.  All 64
 // lanes must call this together.
-template <class F>
-__device__ __forceinline__ void wave_expand(int cnt, F body) {
+// Who owns sub-item k: the last lane whose item starts at or before k.  Found without a search: every lane whose item starts
+// inside the round's window of 64 x UA sub-items leaves its number at that position in a per-wave strip of LDS bytes (`mk`,
+// 64 x UA of them), every lane reads the positions it will handle, and a running maximum over the window (DPP scan, plus what
+// is carried in from before the window) is the owner; the same scan over the marked positions gives the item's first
+// sub-item.  (The binary search over the prefix sums it replaces was seven dependent LDS shuffles per sub-item: 12 k cycles
+// of a frame's 43 k in pass 1, r02.)
+__device__ __forceinline__ int wave_max_scan(int v) {      // inclusive running maximum over the lanes, values >= 0
+#define VBH_DPP_MAX(ctrl, rows) { const int o_ = __builtin_amdgcn_update_dpp(0, v, ctrl, rows, 0xf, false); v = o_ > v ? o_ : v; }
+  VBH_DPP_MAX(0x111, 0xf) VBH_DPP_MAX(0x112, 0xf) VBH_DPP_MAX(0x114, 0xf) VBH_DPP_MAX(0x118, 0xf) VBH_DPP_MAX(0x142, 0xa) VBH_DPP_MAX(0x143, 0xc)
+#undef VBH_DPP_MAX
+  return v;
+}
+template <int UA>
+__device__ __forceinline__ void wave_owners(unsigned char *mk, int cnt, int excl, int k0, int total, bool (&valid)[UA], int (&owner)[UA], int (&j)[UA]) {
   const int lane = threadIdx.x & 63;
+  if (lane < 16 * UA) reinterpret_cast<unsigned *>(mk)[lane] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const bool has = cnt > 0;
+  if (has && excl >= k0 && excl < k0 + 64 * UA) mk[excl - k0] = (unsigned char)(lane + 1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // carried in: the last item that starts before the window (owner + 1, first sub-item + 1; 0 = none)
+  const unsigned long long before = __ballot(has && excl < k0);
+  int c_own = 0, c_start = 0;
+  if (before) {
+    const int l = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)before));
+    c_own = l + 1;
+    c_start = __builtin_amdgcn_readlane(excl, l) + 1;
+  }
+  int m[UA];
+#pragma unroll
+  for (int u = 0; u < UA; u++) m[u] = (k0 + u * 64 < total) ? (int)mk[u * 64 + lane] : 0;
+#pragma unroll
+  for (int u = 0; u < UA; u++) {
+    valid[u] = false; owner[u] = 0; j[u] = 0;
+    if (k0 + u * 64 < total) {      // (uniform)
+      const int k = k0 + u * 64 + lane;
+      int so = wave_max_scan(m[u]), ss = wave_max_scan(m[u] ? k + 1 : 0);
+      so = so > c_own ? so : c_own; ss = ss > c_start ? ss : c_start;
+      valid[u] = k < total;
+      owner[u] = valid[u] ? so - 1 : 0;
+      j[u] = k - (ss - 1);
+      c_own = __builtin_amdgcn_readlane(so, 63); c_start = __builtin_amdgcn_readlane(ss, 63);
+    }
+  }
+}
+template <class F>
+__device__ __forceinline__ void wave_expand(unsigned char *mk, int cnt, F body) {
   const int incl = wave_incl_scan(cnt);
   const int total = __builtin_amdgcn_readlane(incl, 63);
   const int excl = incl - cnt;
   for (int k0 = 0; k0 < total; k0 += 64) {
-    const int k = k0 + lane;
-    int lo = 0;     // number of lanes whose inclusive sum is <= k  ==  the owner of sub-item k
-#pragma unroll
-    for (int step = 32; step > 0; step >>= 1) {
-      const int v = __shfl(incl, lo + step - 1, 64);
-      if (v <= k) lo += step;
-    }
-    const bool valid = k < total;
-    const int owner = valid ? lo : 0;
-    const int j = k - __shfl(excl, owner, 64);
-    body(valid, owner, j);
+    bool valid[1]; int owner[1], j[1];
+    wave_owners<1>(mk, cnt, excl, k0, total, valid, owner, j);
+    body(valid[0], owner[0], j[0]);
   }
 }
 // the same, UA x 64 sub-items per round: body(valid[UA], owner[UA], j[UA]) can issue the loads of all of them before it uses any
 template <int UA, class F>
-__device__ __forceinline__ void wave_expand_n(int cnt, F body) {
-  const int lane = threadIdx.x & 63;
+__device__ __forceinline__ void wave_expand_n(unsigned char *mk, int cnt, F body) {
   const int incl = wave_incl_scan(cnt);
   const int total = __builtin_amdgcn_readlane(incl, 63);
   const int excl = incl - cnt;
   for (int k0 = 0; k0 < total; k0 += 64 * UA) {
     bool valid[UA]; int owner[UA], j[UA];
-#pragma unroll
-    for (int u = 0; u < UA; u++) {
-      valid[u] = false; owner[u] = 0; j[u] = 0;
-      if (k0 + u * 64 < total) {      // (uniform)
-        const int k = k0 + u * 64 + lane;
-        int lo = 0;
-#pragma unroll
-        for (int step = 32; step > 0; step >>= 1) {
-          const int v = __shfl(incl, lo + step - 1, 64);
-          if (v <= k) lo += step;
-        }
-        valid[u] = k < total;
-        owner[u] = valid[u] ? lo : 0;
-        j[u] = k - __shfl(excl, owner[u], 64);
-      }
-    }
+    wave_owners<UA>(mk, cnt, excl, k0, total, valid, owner, j);
     body(valid, owner, j);
   }
 }
@@ -424,6 +447,7 @@ struct Shared {
   unsigned dirty[DIRTY_FRAMES / 32];   // see frame_dirty()
   int use_lds_map;
   int scan_part[NW], scan_base;    // slot scan: occupied slots per wave, first token index it hands out
+  alignas(4) unsigned char wx[NW][64 * 4];   // wave_owners: a strip of 64 x UA marker bytes per wave (UA <= 4)
   int chk[4];                      // first failed consistency check: {where, frame, value, bound}
   float ll[LLCAP];                 // the frame's acoustic scores (VBH_LL_LDS)
   int j_ntf, j_nseg, j_tf0, j_tdst, j_ldst;   // compaction job (its arrays: struct Job, in the arena)
@@ -1130,7 +1154,7 @@ __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, in
       const float c = have ? map_cost(sh, ent, map_find(sh, st), st) : 0.0f;
       const bool exp = have && !(c > cutoff);
       const int a0 = sr.x, cnt = exp ? sr.y : 0;
-      wave_expand(cnt, [&](bool valid, int owner, int j) {
+      wave_expand(sh.wx[threadIdx.x >> 6], cnt, [&](bool valid, int owner, int j) {
         const int a = __shfl(a0, owner, 64) + j;
         const float cc = __shfl(c, owner, 64);
         bool create = false, push = false;
@@ -1253,7 +1277,7 @@ __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, in
         }
         int a0 = 0, cnt = 0;
         if (have) { const i32x4 sr = gst[st]; a0 = sr.x; cnt = sr.y; }
-        wave_expand(cnt, [&](bool valid, int owner, int j) {
+        wave_expand(sh.wx[threadIdx.x >> 6], cnt, [&](bool valid, int owner, int j) {
           const int a = __shfl(a0, owner, 64) + j;
           const float cc = __shfl(c, owner, 64);
           const int so = __shfl(src, owner, 64);
@@ -1583,7 +1607,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
           // (the sign bit of the first-arc index marks the frame's best token)
           const int a0 = (sr.x + sr.y) | ((exp && (rec.x & STMASK) == best_state) ? EPSBIT : 0), cnt = exp ? sr.z - sr.y : 0;
           c_tok_exp += exp;
-          wave_expand_n<UA>(cnt, [&](const bool (&valid)[UA], const int (&owner)[UA], const int (&j)[UA]) {
+          wave_expand_n<UA>(sh.wx[wave], cnt, [&](const bool (&valid)[UA], const int (&owner)[UA], const int (&j)[UA]) {
             P1STAMP(1)
             int a[UA]; float cc[UA]; bool isb[UA]; i32x4 arc[UA]; float sc[UA];
 #pragma unroll
