@@ -1173,7 +1173,7 @@ def main():
         # HBM traffic of the dominant kernels from the committed rocprofv3 --pmc passes of this
         # same command (profiles/): only attached when the batch size matches that run
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_g_pmc_traffic.json")))
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_h_pmc_traffic.json")))
             if tr.get("batch") == args.batch and world == 1:
                 for ro in [out["roofline"]] + [out[k] for k in ("roofline_gmm", "roofline_decode") if k in out]:
                     b_ = tr["bytes_per_launch"].get(ro["kernel"])

@@ -520,9 +520,23 @@ __device__ VBH_WARM float select_kth(gp<const i32x4> tok, int n, int k, Shared &
     for (int i = tid; i < 256; i += NT) sh.hist[i] = 0;
     __syncthreads();
     const unsigned prefix = sh.sel_prefix, mask = sh.sel_mask;
-    for (int i = tid; i < n; i += NT) {
-      const unsigned key = f2o(frame_cost(sh, tok, i));
-      if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
+    // four costs per thread and LDS read (the cost list is contiguous in the arena), their histogram adds in flight together
+    {
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const int nl = n < COST_CAP ? n : COST_CAP, n4 = nl & ~3;
+      const f32x4 *c4 = reinterpret_cast<const f32x4 *>(lds_cost(sh));
+      for (int i = tid * 4; i < n4; i += NT * 4) {
+        const f32x4 c = c4[i >> 2];
+        const unsigned k0 = f2o(c.x), k1 = f2o(c.y), k2 = f2o(c.z), k3 = f2o(c.w);
+        if ((k0 & mask) == prefix) atomicAdd(&sh.hist[(k0 >> shift) & 255u], 1u);
+        if ((k1 & mask) == prefix) atomicAdd(&sh.hist[(k1 >> shift) & 255u], 1u);
+        if ((k2 & mask) == prefix) atomicAdd(&sh.hist[(k2 >> shift) & 255u], 1u);
+        if ((k3 & mask) == prefix) atomicAdd(&sh.hist[(k3 >> shift) & 255u], 1u);
+      }
+      for (int i = n4 + tid; i < n; i += NT) {
+        const unsigned key = f2o(frame_cost(sh, tok, i));
+        if ((key & mask) == prefix) atomicAdd(&sh.hist[(key >> shift) & 255u], 1u);
+      }
     }
     __syncthreads();
     if (tid < 64) {     // wave 0: 4 bins per lane, prefix over lanes, then the bin inside the lane
@@ -1541,9 +1555,19 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         const float beam_cutoff = best + cfg.beam;
         float mac = INF, mic = INF;
         unsigned long long cnt = 0;   // (#cost < beam_cutoff) << 32 | (#cost <= beam_cutoff)
-        for (int i = tid; i < n; i += NT) {
-          const float c = frame_cost(sh, tok, i);
-          cnt += ((unsigned long long)(c < beam_cutoff) << 32) | (unsigned long long)(c <= beam_cutoff);
+        {     // (four costs per LDS read, as in select_kth)
+          typedef float f32x4 __attribute__((ext_vector_type(4)));
+          const int nl = n < COST_CAP ? n : COST_CAP, n4 = nl & ~3;
+          const f32x4 *c4 = reinterpret_cast<const f32x4 *>(lds_cost(sh));
+          for (int i = tid * 4; i < n4; i += NT * 4) {
+            const f32x4 c = c4[i >> 2];
+            cnt += ((unsigned long long)((int)(c.x < beam_cutoff) + (int)(c.y < beam_cutoff) + (int)(c.z < beam_cutoff) + (int)(c.w < beam_cutoff)) << 32) |
+                   (unsigned long long)((int)(c.x <= beam_cutoff) + (int)(c.y <= beam_cutoff) + (int)(c.z <= beam_cutoff) + (int)(c.w <= beam_cutoff));
+          }
+          for (int i = n4 + tid; i < n; i += NT) {
+            const float c = frame_cost(sh, tok, i);
+            cnt += ((unsigned long long)(c < beam_cutoff) << 32) | (unsigned long long)(c <= beam_cutoff);
+          }
         }
         cnt = block_sum_u64(cnt, sh, par);
         const int cnt_lt = (int)(cnt >> 32), cnt_le = (int)(unsigned)cnt;
