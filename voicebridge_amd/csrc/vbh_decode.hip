@@ -1534,11 +1534,19 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         for (int u = 0; u < (LLCAP + NT - 1) / NT; u++) { const int i = u * NT + tid; llr[u] = i < P ? llrow[i] : 0.0f; }
       }
       unsigned long long bk = ~0ull;
-      for (int i = tid; i < n; i += NT) {
-        const i32x4 r = tok[i];
-        if (i < COST_CAP) lds_cost(sh)[i] = asf(r.y);
-        const unsigned long long k = ((unsigned long long)f2o(asf(r.y)) << 32) | (unsigned)(r.x & STMASK);
-        bk = k < bk ? k : bk;
+      for (int i0 = 0; i0 < n; i0 += NT * 4) {          // (four records per thread in flight; only {state, cost} of each is read)
+        i32x2 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = i0 + u * NT + tid; r[u] = *reinterpret_cast<gp<const i32x2>>(tok + (i < n ? i : 0)); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + u * NT + tid;
+          if (i < n) {
+            if (i < COST_CAP) lds_cost(sh)[i] = asf(r[u].y);
+            const unsigned long long k = ((unsigned long long)f2o(asf(r[u].y)) << 32) | (unsigned)(r[u].x & STMASK);
+            bk = k < bk ? k : bk;
+          }
+        }
       }
       if (ll_lds) {      // (its readers come after the reduction barrier below; its last readers were pass 1 of the previous frame)
 #pragma unroll
