@@ -101,24 +101,58 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
   return v;
 }
-// see vbh_decode.hip: sub-items of up to 64 items dealt out evenly over the lanes of a wave
+// reductions and a running maximum over the wave on the VALU (the DPP ladder of the scan above), see vbh_decode.hip
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  const int id = -1;
+#define VBH_DPP_MIN(ctrl, rows) { const unsigned o_ = (unsigned)__builtin_amdgcn_update_dpp(id, (int)v, ctrl, rows, 0xf, false); v = o_ < v ? o_ : v; }
+  VBH_DPP_MIN(0x111, 0xf) VBH_DPP_MIN(0x112, 0xf) VBH_DPP_MIN(0x114, 0xf) VBH_DPP_MIN(0x118, 0xf) VBH_DPP_MIN(0x142, 0xa) VBH_DPP_MIN(0x143, 0xc)
+#undef VBH_DPP_MIN
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readlane(wave_incl_scan((int)v), 63); }
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+  const unsigned mh = wave_min_u32(hi);
+  const unsigned ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+  return ((unsigned long long)mh << 32) | ml;
+}
+__device__ __forceinline__ int wave_max_scan(int v) {      // inclusive running maximum over the lanes, values >= 0
+#define VBH_DPP_MAX(ctrl, rows) { const int o_ = __builtin_amdgcn_update_dpp(0, v, ctrl, rows, 0xf, false); v = o_ > v ? o_ : v; }
+  VBH_DPP_MAX(0x111, 0xf) VBH_DPP_MAX(0x112, 0xf) VBH_DPP_MAX(0x114, 0xf) VBH_DPP_MAX(0x118, 0xf) VBH_DPP_MAX(0x142, 0xa) VBH_DPP_MAX(0x143, 0xc)
+#undef VBH_DPP_MAX
+  return v;
+}
+// see vbh_decode.hip: sub-items of up to 64 items dealt out evenly over the lanes of a wave.  The owner of sub-item k is the last
+// lane whose item starts at or before k: every such lane leaves its number at that position in the wave's strip of 64 LDS bytes
+// (`mk`), and a running maximum over the window, plus what is carried in from before it, is the owner (no search by shuffles).
 template <class F>
-__device__ __forceinline__ void wave_expand(int cnt, F body) {
+__device__ __forceinline__ void wave_expand(unsigned char *mk, int cnt, F body) {
   const int lane = threadIdx.x & 63;
   const int incl = wave_incl_scan(cnt);
   const int total = __builtin_amdgcn_readlane(incl, 63);
   const int excl = incl - cnt;
+  const bool has = cnt > 0;
   for (int k0 = 0; k0 < total; k0 += 64) {
-    const int k = k0 + lane;
-    int lo = 0;
-#pragma unroll
-    for (int step = 32; step > 0; step >>= 1) {
-      const int v = __shfl(incl, lo + step - 1, 64);
-      if (v <= k) lo += step;
+    if (lane < 16) reinterpret_cast<unsigned *>(mk)[lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (has && excl >= k0 && excl < k0 + 64) mk[excl - k0] = (unsigned char)(lane + 1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long before = __ballot(has && excl < k0);
+    int c_own = 0, c_start = 0;
+    if (before) {
+      const int l = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)before));
+      c_own = l + 1;
+      c_start = __builtin_amdgcn_readlane(excl, l) + 1;
     }
+    const int k = k0 + lane;
+    const int m = (int)mk[lane];
+    int so = wave_max_scan(m), ss = wave_max_scan(m ? k + 1 : 0);
+    so = so > c_own ? so : c_own; ss = ss > c_start ? ss : c_start;
     const bool valid = k < total;
-    const int owner = valid ? lo : 0;
-    const int j = k - __shfl(excl, owner, 64);
+    const int owner = valid ? so - 1 : 0;
+    const int j = k - (ss - 1);
     body(valid, owner, j);
   }
 }
@@ -130,6 +164,7 @@ __device__ __forceinline__ int wave_chunk(int n) {
 struct Shared {
   unsigned long long red[2][NW];
   unsigned hist[256];
+  alignas(4) unsigned char wx[NW][64];   // wave_expand: a strip of 64 marker bytes per wave
   unsigned hs[HCAP];               // state map of the frame being built: tag,
   unsigned long long hc[HCAP];     // best cost (order-preserving key),
   int ht[HCAP];                    // index of the state's token within the frame
@@ -149,8 +184,7 @@ struct Shared {
 #endif
 
 __device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v, Shared &sh, int &par) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { const unsigned long long w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
+  v = wave_min_u64(v);
   if ((threadIdx.x & 63) == 0) sh.red[par][threadIdx.x >> 6] = v;
   __syncthreads();
   unsigned long long r = sh.red[par][0];
@@ -160,8 +194,7 @@ __device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v
   return r;
 }
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, Shared &sh, int &par) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v = ((unsigned long long)wave_sum_u32((unsigned)(v >> 32)) << 32) | wave_sum_u32((unsigned)v);      // (both halves are counts of a frame's tokens)
   if ((threadIdx.x & 63) == 0) sh.red[par][threadIdx.x >> 6] = v;
   __syncthreads();
   unsigned long long r = 0;
@@ -316,7 +349,7 @@ __device__ void epsilon_closure(const FGraph &g, const FSlot &s, double cutoff, 
       const double c = slot != -1 ? o2d(map_key(sh, m2, slot)) : 0.0;
       const bool exp = have && slot != -1 && !(c > cutoff);
       const int a0 = sr.x, cnt = exp ? sr.y : 0;
-      wave_expand(cnt, [&](bool valid, int owner, int j) {
+      wave_expand(sh.wx[threadIdx.x >> 6], cnt, [&](bool valid, int owner, int j) {
         const int a = __shfl(a0, owner, 64) + j;
         const double cc = __shfl(c, owner, 64);
         bool create = false, push = false, eps = false; int ds = 0, nslot = -1;   // (-1: none / no room)
@@ -383,7 +416,7 @@ __device__ void epsilon_winners(const FGraph &g, const FSlot &s, double cutoff, 
     const bool exp = have && slot != -1 && !(c > cutoff);
     const int a0 = sr.x, cnt = exp ? sr.y : 0;
     const int my_tok = exp ? tok_base + map_idx(sh, m2, slot) : 0;
-    wave_expand(cnt, [&](bool valid, int owner, int j) {
+    wave_expand(sh.wx[threadIdx.x >> 6], cnt, [&](bool valid, int owner, int j) {
       const int a = __shfl(a0, owner, 64) + j;
       const double cc = __shfl(c, owner, 64);
       const int src_tok = __shfl(my_tok, owner, 64);
@@ -616,7 +649,7 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
           const bool exp = have && c < weight_cutoff;
           const i32x4 sr = uptr(g.st)[exp ? (rec.z & STMASK) : 0];
           const int a0 = sr.x + sr.y, cnt = exp ? sr.z - sr.y : 0;
-          wave_expand(cnt, [&](bool valid, int owner, int j) {
+          wave_expand(sh.wx[threadIdx.x >> 6], cnt, [&](bool valid, int owner, int j) {
             const int a = __shfl(a0, owner, 64) + j;
             const double cc = __shfl(c, owner, 64);
             i32x4 arc; double nw = 0.0;
