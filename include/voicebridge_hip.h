@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define VBH_ABI_VERSION 1
+/* 2 (r03): vbh_best_path has six more fields than in version 1 and vbh_mfcc_opts.dither is applied (version 1 required 0) */
+#define VBH_ABI_VERSION 2
 
 /* ------------------------------------------------------------------ context / memory */
 typedef struct vbh_ctx vbh_ctx;
@@ -160,6 +161,16 @@ void vbh_gmm_destroy(vbh_gmm *g);
 int32_t vbh_gmm_num_pdfs(const vbh_gmm *g);
 int32_t vbh_gmm_dim(const vbh_gmm *g);
 int vbh_gmm_get_gconsts(const vbh_gmm *g, float *h_gconsts);   /* [G] as computed at create */
+/* How the LogSumExp over a pdf's Gaussians is evaluated (K/matrix/kaldi-vector.cc:757-775: the maximum, then the sum of
+ * exp(x - max) over the terms not below max + log(FLT_EPSILON), accumulated in double, max + log(sum)):
+ *   VBH_LSE_FAST   (default) the same two passes and cutoff, f32 sum, hardware exp2/log2: within 1e-5 of STRICT;
+ *   VBH_LSE_STRICT the reference's arithmetic: expf of the f32 difference, f64 sum, max + log(sum) in f64, rounded once;
+ *   VBH_LSE_ONLINE round 2's single pass (running maximum + rescaled sum, no cutoff): measurement only.
+ * The environment variable VBH_GMM_LSE=strict|fast|online sets the mode of models created afterwards. */
+#define VBH_LSE_FAST 0
+#define VBH_LSE_STRICT 1
+#define VBH_LSE_ONLINE 2
+int vbh_gmm_set_lse_mode(vbh_gmm *g, int32_t mode);
 /* d_feats [T x dim] -> d_loglikes [T x num_pdfs] (unscaled log-likelihoods) */
 int vbh_gmm_loglikes(vbh_gmm *g, const float *d_feats, int64_t T, float *d_loglikes);
 /* The on-demand form (the reference's semantics, K/gmm/decodable-am-diag-gmm.cc:28-72: a pdf is evaluated when the search or a

@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""tests/golden/speech_e2e.npz: the REFERENCE's own programs end to end, from PCM to words, on the bench's speech workload
+(the regime the headline is measured in).  Run in the build container only:
+
+    make -C oracle ref && python oracle/gen_golden_e2e.py
+
+N_UTT utterances of 30 s (16 speakers x 4; the test set of gen_golden_speech.py continued: same ids, same speakers, the same
+acoustic model -- per-pdf mean / variance taken from tests/golden/speech_refpaths.npz) go through the chain the reference's
+Decode() builds (VB/scr/steps/decode_gmm.cpp:201-293; program sources under VB/src/featbin, VB/src/gmmbin):
+
+    compute-mfcc-feats --dither=0 | compute-cmvn-stats --spk2utt | apply-cmvn --utt2spk | add-deltas | transform-feats --utt2spk
+    | gmm-latgen-faster --beam=13 --lattice-beam=6 --max-active=7000 --acoustic-scale=0.083333 --determinize-lattice=false
+      (VoiceBridge/VoiceBridge/kaldi-win/src/gmmbin/gmm-latgen-faster.cpp:103-170)
+
+What is stored:
+  * per utterance: the words of the reference's best path and its "log-like per frame" (gmm-latgen-faster's own log line);
+  * for the first N_STAGE utterances the reference's intermediate results, so that a test can swap stages between the two
+    implementations: its MFCCs [T x 13], its final features [T x 39], and every ROW_STEP-th row of its [T x P] score matrix
+    (gmm-compute-likes: DecodableAmDiagGmmUnmapped::LogLikelihoodZeroBased for every pdf) -- whole matrices would be 30 MB each;
+    the oracle's all-pdf scoring is pinned to those rows here and recomputes the rest in the test;
+  * WER counters of the reference's words against the transcripts (voicebridge_amd.dist.score) and the bootstrap interval the
+    reference's compute-wer-bootci gives for them;
+  * which stage moves the words, measured HERE with the oracle (plain C restatement, oracle/vb_oracle_*.c) in place of the
+    GPU: oracle chain from PCM, from the reference's MFCCs, from the reference's features (see `oracle_words_*`).
+The test regenerates waveforms and transcripts from seeds (numpy) -- nothing of the reference travels.
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import vbo  # noqa: E402
+from oracle import gen_golden_speech as gs  # noqa: E402
+from voicebridge_amd import dist as vdist  # noqa: E402
+from voicebridge_amd import refio, synth, synth_speech as ss  # noqa: E402
+
+B = os.path.join(HERE, "_ref", "bin")
+GOLD = os.path.join(ROOT, "tests", "golden")
+N_UTT, N_STAGE, ROW_STEP, N_JOBS = 64, 4, 47, 8
+P, G, D, WORDS = gs.P, gs.G, gs.D, gs.WORDS
+CFG = gs.CFG
+
+
+def test_set(lex, n_utt=N_UTT):
+    """waveforms (int16), speakers, hop labels and transcripts of utterances 0 .. n_utt-1 (utterances 0-7 are the test set of
+    gen_golden_speech.py)"""
+    ids = np.arange(n_utt)
+    spk = ids // 4
+    waves, hop, truth = gs.utterances(lex, ids, spk, False)
+    return ids, spk, waves, hop, truth
+
+
+def model():
+    fx = np.load(os.path.join(GOLD, "speech_refpaths.npz"))
+    return ss.mixture_from_stats(fx["mu"], fx["var"], G)
+
+
+def utt_name(spk, u):
+    return "s%04d-u%05d" % (spk, u)
+
+
+def read_ark_f32(path):
+    """{key: matrix} of a binary float-matrix archive (FM)"""
+    out = {}
+    blob = open(path, "rb").read()
+    i = 0
+    while i < len(blob):
+        j = blob.index(b" ", i)
+        key = blob[i:j].decode()
+        assert blob[j + 1:j + 3] == b"\0B" and blob[j + 3:j + 6] == b"FM ", (key, blob[j + 1:j + 8])
+        k = j + 6
+        assert blob[k] == 4
+        r = int(np.frombuffer(blob, "<i4", 1, k + 1)[0])
+        assert blob[k + 5] == 4
+        c = int(np.frombuffer(blob, "<i4", 1, k + 6)[0])
+        k += 10
+        out[key] = np.frombuffer(blob, "<f4", r * c, k).reshape(r, c).copy()
+        i = k + 4 * r * c
+    return out
+
+
+def main():
+    t00 = time.time()
+    g, t2p, lex = synth.lexicon_graph(WORDS, P, seed=11, return_lexicon=True)
+    print("graph: %d states / %d arcs, %.0f s" % (len(g["final"]), len(g["arcs"]), time.time() - t00), flush=True)
+    offs, w, miv, iv = model()
+    ids, spk, waves, hop, truth = test_set(lex)
+    xforms = {int(s): synth.affine(D, seed=int(s), scale=gs.XFORM_SCALE) for s in np.unique(spk)}
+    d = tempfile.mkdtemp(prefix="vb_e2e_")
+    env = dict(os.environ, OPENBLAS_NUM_THREADS="1", OMP_NUM_THREADS="1")
+    p = lambda n: os.path.join(d, n)
+    out = dict(n_utt=N_UTT, n_stage=N_STAGE, row_step=ROW_STEP, words_in_graph=WORDS, depth=gs.DEPTH,
+               cfg=np.array(["%s=%r" % kv for kv in sorted(CFG.items())]))
+    try:
+        refio.write_mdl(p("final.mdl"), P // 3, 3, offs, w, miv, iv)
+        refio.write_vector_fst(p("HCLG.fst"), g["final"], g["arc_offset"], g["arcs"], g["start"])
+        spks = sorted(xforms)
+        per = -(-len(spks) // N_JOBS)
+        jobs = [spks[j * per:(j + 1) * per] for j in range(N_JOBS) if spks[j * per:(j + 1) * per]]
+        for j, js in enumerate(jobs):
+            with open(p("wav.%d.scp" % j), "w") as f, open(p("utt2spk.%d" % j), "w") as fu, open(p("spk2utt.%d" % j), "w") as fs:
+                for s_ in js:
+                    us = [int(u) for u in ids if spk[u] == s_]
+                    for u in us:
+                        refio.write_wav(p("u%05d.wav" % u), waves[u])
+                        f.write("%s %s\n" % (utt_name(s_, u), p("u%05d.wav" % u)))
+                        fu.write("%s s%04d\n" % (utt_name(s_, u), s_))
+                    fs.write("s%04d %s\n" % (s_, " ".join(utt_name(s_, u) for u in us)))
+            refio.write_feats_ark(p("trans.%d.ark" % j), {"s%04d" % s_: xforms[s_] for s_ in js})
+
+        def run(name, *a):
+            r = subprocess.run([os.path.join(B, name)] + list(a), env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(name + ": " + r.stderr[-400:])
+            return r.stderr
+
+        def job(j):
+            q = lambda n: p("%s.%d" % (n, j))
+            run("compute-mfcc-feats", "--dither=0", "scp:" + p("wav.%d.scp" % j), "ark:" + q("mfcc"))
+            run("compute-cmvn-stats", "--spk2utt=ark:" + p("spk2utt.%d" % j), "ark:" + q("mfcc"), "ark:" + q("cmvn"))
+            run("apply-cmvn", "--utt2spk=ark:" + p("utt2spk.%d" % j), "ark:" + q("cmvn"), "ark:" + q("mfcc"), "ark:" + q("cm"))
+            run("add-deltas", "ark:" + q("cm"), "ark:" + q("dl"))
+            run("transform-feats", "--utt2spk=ark:" + p("utt2spk.%d" % j), "ark:" + p("trans.%d.ark" % j), "ark:" + q("dl"), "ark:" + q("feats"))
+            log = run("gmm-latgen-faster", "--beam=%g" % CFG["beam"], "--lattice-beam=%g" % CFG["lattice_beam"], "--max-active=%d" % CFG["max_active"],
+                      "--min-active=%d" % CFG["min_active"], "--acoustic-scale=%g" % CFG["acwt"], "--allow-partial=true", "--determinize-lattice=false",
+                      p("final.mdl"), p("HCLG.fst"), "ark:" + q("feats"), "ark:" + q("lat"), "ark,t:" + q("words"))
+            words, like = {}, {}
+            for line in open(q("words")):
+                f_ = line.split()
+                if f_:
+                    words[int(f_[0].split("-u")[1])] = np.array([int(x) for x in f_[1:]], np.int32)
+            for m_ in re.finditer(r"Log-like per frame for utterance \S+-u(\d+) is (\S+) over", log):
+                like[int(m_.group(1))] = float(m_.group(2))
+            print("job %d done: %d utterances  [%.0f s]" % (j, len(words), time.time() - t00), flush=True)
+            return words, like
+
+        with ThreadPoolExecutor(len(jobs)) as ex:
+            res = list(ex.map(job, range(len(jobs))))
+        ref_words, ref_like = {}, {}
+        for wd, lk in res:
+            ref_words.update(wd); ref_like.update(lk)
+        assert sorted(ref_words) == list(range(N_UTT)), sorted(ref_words)
+        for u in range(N_UTT):
+            out["ref_words_%d" % u] = ref_words[u]
+        out["ref_like_per_frame"] = np.array([ref_like[u] for u in range(N_UTT)], np.float64)
+        # ---- the reference's intermediate results of the first N_STAGE utterances (job 0 holds speakers 0 .. per-1)
+        mf = read_ark_f32(p("mfcc.0")); ft = read_ark_f32(p("feats.0"))
+        with open(p("stage.scp"), "w") as f:
+            pass
+        # scores: gmm-compute-likes on the reference's own features of those utterances
+        sel = {}
+        for u in range(N_STAGE):
+            sel[utt_name(int(spk[u]), u)] = ft[utt_name(int(spk[u]), u)]
+        refio.write_feats_ark(p("stage_feats.ark"), sel)
+        run("gmm-compute-likes", p("final.mdl"), "ark:" + p("stage_feats.ark"), "ark:" + p("stage_likes.ark"))
+        lk = read_ark_f32(p("stage_likes.ark"))
+        gc = vbo.gmm_gconsts(w, miv, iv)
+        for u in range(N_STAGE):
+            k = utt_name(int(spk[u]), u)
+            out["ref_mfcc_%d" % u] = mf[k].astype(np.float32)
+            out["ref_feats_%d" % u] = ft[k].astype(np.float32)
+            out["ref_scores_rows_%d" % u] = lk[k][::ROW_STEP].astype(np.float32)
+            # the oracle's scoring is the checker's stand-in for the rest of the rows: pin it to the reference's here
+            o_ll = vbo.gmm_loglikes(offs, gc, miv, iv, ft[k])[:, :lk[k].shape[1]]     # (the .mdl holds the 3 x (P // 3) pdfs the graph uses)
+            err = np.abs(o_ll - lk[k]).max() / np.abs(lk[k]).max()
+            print("utt %d: oracle scores on the reference's features vs gmm-compute-likes: max rel %.2e" % (u, err), flush=True)
+            assert err < 2e-5
+        # ---- WER of the reference against the transcripts, with the interval of ITS compute-wer-bootci
+        with open(p("ref.txt"), "w") as fr, open(p("hyp.txt"), "w") as fh:
+            for u in range(N_UTT):
+                fr.write("%s %s\n" % (utt_name(int(spk[u]), u), " ".join(str(int(x)) for x in truth[u])))
+                fh.write("%s %s\n" % (utt_name(int(spk[u]), u), " ".join(str(int(x)) for x in ref_words[u])))
+        r = subprocess.run([os.path.join(B, "compute-wer-bootci"), "--mode=present", "ark:" + p("ref.txt"), "ark:" + p("hyp.txt")], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        print(r.stdout.strip(), flush=True)
+        m = re.search(r"%WER ([0-9.]+) 95% Conf Interval \[ ([0-9.]+), ([0-9.]+) \]", r.stdout)
+        out["ref_wer_bootci"] = np.array([float(m.group(1)), float(m.group(2)), float(m.group(3))])      # mean, 95 % interval
+        cr = vdist.score(truth, [ref_words[u] for u in range(N_UTT)])
+        out["wer_counters_reference"] = cr
+        print("reference WER %.2f %% (%d errors / %d words)" % (100.0 * cr[0] / cr[1], cr[0], cr[1]), flush=True)
+        # ---- which stage moves the words: the oracle (reference-order admission, exact_cutoff=0) in place of the reference,
+        #      entering the chain at PCM / at the reference's MFCCs / at the reference's features, on the staged utterances
+        fst = vbo.make_fst(g["final"], g["arc_offset"], g["arcs"], g["start"])
+        o = vbo.mfcc_opts()
+        raws = {u: vbo.mfcc(waves[u].astype(np.float32), o) for u in range(N_UTT) if spk[u] in set(spk[:N_STAGE])}
+        mfcc_err = max(float(np.abs(raws[u] - out["ref_mfcc_%d" % u]).max()) for u in range(N_STAGE))
+        print("oracle MFCC vs the reference's: max abs %.3g" % mfcc_err, flush=True)
+        out["oracle_mfcc_max_abs_err"] = mfcc_err
+
+        def chain(raw_of):
+            st = {}
+            for u in raw_of:
+                s_ = int(spk[u]); st[s_] = st.get(s_, 0) + vbo.acc_cmvn_stats(raw_of[u])
+            return {u: vbo.transform_feats(vbo.add_deltas(vbo.apply_cmvn(raw_of[u], st[int(spk[u])])), xforms[int(spk[u])]) for u in range(N_STAGE)}
+        all_ref_mf = {u: mf[utt_name(int(spk[u]), u)] for u in raws}
+        entries = dict(pcm=chain(raws), ref_mfcc=chain(all_ref_mf), ref_feats={u: out["ref_feats_%d" % u] for u in range(N_STAGE)})
+        for name, feats in entries.items():
+            same = 0
+            for u in range(N_STAGE):
+                ll = vbo.gmm_loglikes(offs, gc, miv, iv, feats[u])
+                r_ = vbo.decode_lattice_faster(fst, ll, t2p, exact_cutoff=False, **CFG)
+                out["oracle_words_%s_%d" % (name, u)] = np.asarray(r_["words"], np.int32)
+                same += int(np.array_equal(r_["words"], ref_words[u]))
+            print("oracle entering at %-9s: words equal to the reference's on %d / %d  [%.0f s]" % (name, same, N_STAGE, time.time() - t00), flush=True)
+            out["oracle_same_%s" % name] = same
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    path = os.path.join(GOLD, "speech_e2e.npz")
+    np.savez_compressed(path, **out)
+    print("%s  %.1f KB  (%.0f s)" % (path, os.path.getsize(path) / 1024.0, time.time() - t00))
+
+
+if __name__ == "__main__":
+    main()

@@ -208,7 +208,9 @@ class FeaturePipeline:
 class DiagGmm:
     """AmDiagGmm scored for every pdf of every frame (vbh_gmm_*)."""
 
-    def __init__(self, ctx, pdf_offsets, weights, means_invvars, inv_vars):
+    LSE_MODES = {"fast": 0, "strict": 1, "online": 2}      # VBH_LSE_* of include/voicebridge_hip.h
+
+    def __init__(self, ctx, pdf_offsets, weights, means_invvars, inv_vars, lse=None):
         self.ctx, self.lib = ctx, ctx.lib
         offs = np.ascontiguousarray(pdf_offsets, np.int32)
         w = np.ascontiguousarray(weights, np.float32)
@@ -219,6 +221,12 @@ class DiagGmm:
         check(self.lib.vbh_gmm_create(ctx.h, self.dim, self.num_pdfs, _i32p(offs), _f32p(w), _f32p(miv), _f32p(iv), C.byref(h)),
               "vbh_gmm_create")
         self.h = h
+        if lse is not None:
+            self.set_lse_mode(lse)
+
+    def set_lse_mode(self, mode):
+        """'fast' (default), 'strict' (the reference's LogSumExp arithmetic: f64 sum, expf, log) or 'online' (round 2's form)"""
+        check(self.lib.vbh_gmm_set_lse_mode(self.h, self.LSE_MODES[mode]), "vbh_gmm_set_lse_mode")
 
     def gconsts(self):
         out = np.zeros(self.num_gauss, np.float32)

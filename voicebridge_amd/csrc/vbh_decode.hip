@@ -2035,7 +2035,9 @@ __global__ void fill_arc_pdf_kernel(i32x4 *__restrict__ arcs, const int *__restr
 
 // ============================================================================ host side
 struct vbh_graph {
-  vbh_ctx *ctx;
+  // Only the device is remembered, not the creating context: a graph is shared by the threads of a process (the jobs of a
+  // step), and the context of the thread that happened to build it may be gone by the time the last user lets go of it
+  int device;
   int S, start; long long A; int max_ilabel, max_degree;
   DevBuf<i32x4> st, arcs;      // device records (see DevGraph); arcs are stored epsilon-first within a state
   DevBuf<int> arc_il;
@@ -2141,6 +2143,7 @@ static std::vector<std::weak_ptr<SlotSet>> g_pools;
 
 static int slot_alloc(vbh_decoder *d, SlotSet *set, size_t bytes, void **p, int memset_val = -2) {
   VBH_HIP(hipMalloc(p, bytes ? bytes : 8));
+  if (getenv("VBH_DEBUG_ALLOC")) fprintf(stderr, "[vbh alloc] slot array [%p, %p) %zu B\n", *p, (void *)((char *)*p + bytes), bytes);
   set->allocs.push_back(*p);
   if (memset_val != -2) VBH_HIP(hipMemsetAsync(*p, memset_val, bytes, d->ctx->stream));
   return 0;
@@ -2284,7 +2287,7 @@ int vbh_graph_create(vbh_ctx *ctx, int32_t num_states, int32_t start, const floa
     }
   }
   vbh_graph *g = new vbh_graph();
-  g->ctx = ctx; g->S = num_states; g->start = start; g->A = A; g->max_ilabel = max_il; g->max_degree = max_deg;
+  g->device = ctx->device; g->S = num_states; g->start = start; g->A = A; g->max_ilabel = max_il; g->max_degree = max_deg;
   g->h_final.assign(h_final, h_final + num_states);
   hipStream_t st = ctx->stream;
   if (g->st.upload(h_st.data(), h_st.size(), st) || g->arcs.upload(h_ar.data(), h_ar.size(), st) ||
@@ -2296,8 +2299,10 @@ int vbh_graph_create(vbh_ctx *ctx, int32_t num_states, int32_t start, const floa
 
 void vbh_graph_destroy(vbh_graph *g) {
   if (!g) return;
-  (void)hipSetDevice(g->ctx->device);
-  (void)hipStreamSynchronize(g->ctx->stream);
+  // (no context to drain: whoever still searches this graph holds a decoder on it, and decoders are destroyed first; the
+  // device-wide wait covers streams of contexts that are gone)
+  (void)hipSetDevice(g->device);
+  (void)hipDeviceSynchronize();
   delete g;
 }
 

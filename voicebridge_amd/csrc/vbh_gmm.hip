@@ -30,6 +30,7 @@
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 
 namespace {
 
@@ -232,7 +233,12 @@ __global__ __launch_bounds__(256, 2) void gmm_loglikes_kernel(
 struct RbMeta { unsigned mask; int p0; int np; int pad; };
 constexpr int LDP = 17;       // padded row of a wave's staging area: [64 frames][<= 16 pdfs]
 
-template <int NC>             // NC = Kpad / 8: a lane's strip of a row-block is NC float4 (4 k-steps each)
+// LSE: how the LogSumExp over a pdf's Gaussians is evaluated (kaldi-vector.cc:757-775; vbh_gmm_set_lse_mode)
+//   VBH_LSE_FAST (default): the reference's two passes -- the pdf's maximum, then the sum of exp(x - max) over the terms not below
+//     max + log(FLT_EPSILON) -- with the sum in f32 and the hardware's exp2 / log2 (__expf, __logf): one exp per Gaussian;
+//   VBH_LSE_STRICT: the reference's arithmetic: expf of the f32 difference, the sum in f64, max + log(sum) in f64, rounded once;
+//   VBH_LSE_ONLINE: round 2's single pass (running maximum + rescaled sum, no cutoff, two exps per Gaussian), kept for A/B runs.
+template <int NC, int LSE>    // NC = Kpad / 8: a lane's strip of a row-block is NC float4 (4 k-steps each)
 __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
     const float *__restrict__ feats, long long T, int D, int P,
     const f32x4 *__restrict__ Mp,            // [n_rb][NC][64 lanes]: Mp[(rb*NC + c)*64 + lane][j] = row (lane & 31), k = 2(4c + j) + (lane >> 5)
@@ -308,15 +314,16 @@ __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
       const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[i]), __float_as_uint(acc1[i]), false, false);
       v0[i] = __uint_as_float(r[0]); v1[i] = __uint_as_float(r[1]);
     }
-    // ---- LogSumExp per pdf (kaldi-vector.cc:757-775), online: m = running maximum, s = sum of exp(x - m).  The terms the
-    //      reference drops (below max + log FLT_EPSILON) are below 1.2e-7 of the sum each: inside the stated tolerance.
-    {
+    // ---- LogSumExp per pdf (kaldi-vector.cc:757-775).  The pdf boundaries are wave-uniform (mask), so both passes are straight
+    //      register loops with scalar branches; the maxima wait in the lane's own row of the staging area (one LDS word per pdf).
+#define VBH_ROW(r) ((((r) >> 2) & 1) ? v1[((r) & 3) + 4 * ((r) >> 3)] : v0[((r) & 3) + 4 * ((r) >> 3)])
+    if (LSE == VBH_LSE_ONLINE) {
       float m = -3.0e38f, sum = 0.0f;
       float *so = stage + lane * LDP;
       int q = 0;
 #pragma unroll
       for (int r = 0; r < 32; r++) {
-        const float x = ((r >> 2) & 1) ? v1[(r & 3) + 4 * (r >> 3)] : v0[(r & 3) + 4 * (r >> 3)];
+        const float x = VBH_ROW(r);
         if (r > 0 && ((mask >> r) & 1u)) {      // (wave-uniform) row r starts the next pdf
           so[q] = sum > 0.0f ? m + __logf(sum) : -INFINITY;
           q++;
@@ -327,7 +334,42 @@ __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
         m = m2;
       }
       so[q] = sum > 0.0f ? m + __logf(sum) : -INFINITY;
+    } else {
+      const float kMinLogDiff = -15.9423847198486328125f;   // logf(FLT_EPSILON)
+      float *so = stage + lane * LDP;
+      {
+        float m = -INFINITY;
+        int q = 0;
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+          const float x = VBH_ROW(r);
+          if (r > 0 && ((mask >> r) & 1u)) { so[q] = m; q++; m = x; }
+          else m = fmaxf(m, x);
+        }
+        so[q] = m;
+      }
+      typedef typename std::conditional<LSE == VBH_LSE_STRICT, double, float>::type sum_t;
+      auto finish = [](float m, sum_t sum) -> float {
+        if (!(m > -INFINITY)) return -INFINITY;                  // a pdf of gap rows only (gconst = -inf)
+        if (LSE == VBH_LSE_STRICT) return (float)((double)m + log((double)sum));
+        return m + __logf((float)sum);
+      };
+      int q = 0;
+      float m = so[0], cutoff = m + kMinLogDiff;
+      sum_t sum = 0;
+#pragma unroll
+      for (int r = 0; r < 32; r++) {
+        const float x = VBH_ROW(r);
+        if (r > 0 && ((mask >> r) & 1u)) {
+          so[q] = finish(m, sum);
+          q++;
+          m = so[q]; cutoff = m + kMinLogDiff; sum = 0;
+        }
+        if (x >= cutoff) sum += LSE == VBH_LSE_STRICT ? (sum_t)expf(x - m) : (sum_t)__expf(x - m);
+      }
+      so[q] = finish(m, sum);
     }
+#undef VBH_ROW
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- out: runs of np pdfs per frame, lanes along (frame, pdf)
@@ -352,7 +394,7 @@ __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
 __global__ __launch_bounds__(256) void gmm_fold_parts_kernel(
     const float *__restrict__ parts, long long T, int n_parts, int P,
     const int *__restrict__ pdf_parts,     // [P+1] first part of every pdf
-    float *__restrict__ out) {
+    float *__restrict__ out, int strict) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= T * P) return;
   const long long t = idx / P;
@@ -364,9 +406,15 @@ __global__ __launch_bounds__(256) void gmm_fold_parts_kernel(
   float res = m;
   if (b - a > 1 && m > -INFINITY) {
     const float cutoff = m + -15.9423847198486328125f;
-    float sum = 0.f;
-    for (int i = a; i < b; i++) { const float v = row[i]; if (v >= cutoff) sum += __expf(v - m); }
-    res = m + __logf(sum);
+    if (strict) {
+      double sum = 0.0;
+      for (int i = a; i < b; i++) { const float v = row[i]; if (v >= cutoff) sum += (double)expf(v - m); }
+      res = (float)((double)m + log(sum));
+    } else {
+      float sum = 0.f;
+      for (int i = a; i < b; i++) { const float v = row[i]; if (v >= cutoff) sum += __expf(v - m); }
+      res = m + __logf(sum);
+    }
   }
   out[idx] = res;
 }
@@ -453,6 +501,7 @@ struct vbh_gmm {
   DevBuf<f32x4> Mp; DevBuf<RbMeta> rb_meta;
   DevBuf<int> d_pdf_parts2; DevBuf<float> part_scratch2; long long part_chunk2 = 0;
   size_t lds_bytes2 = 0;
+  int lse_mode = VBH_LSE_FAST;            // vbh_gmm_set_lse_mode
   // plain row-major copies for the kernels that walk single pdfs (fMLLR statistics, vbh_fmllr.hip)
   DevBuf<float> d_miv, d_iv, d_gconsts;   // [G x D], [G x D], [G]
   DevBuf<int> d_pdf_offs;                 // [P+1]
@@ -610,6 +659,10 @@ int vbh_gmm_create(vbh_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h
     g->lds_bytes2 = sizeof(float) * ((size_t)g->Kpad * LDA + ((4 - (g->Kpad * LDA) % 4) % 4) + 4 * (size_t)TM * LDP);
     if (const char *e = getenv("VBH_GMM_LDS_PAD")) g->lds_bytes2 += (size_t)atoi(e) * 1024;       // diagnostic: keeps the kernel off CUs whose LDS is mostly taken
   }
+  if (const char *e = getenv("VBH_GMM_LSE")) {
+    if (g->rows && !strcmp(e, "strict")) g->lse_mode = VBH_LSE_STRICT;
+    else if (g->rows && !strcmp(e, "online")) g->lse_mode = VBH_LSE_ONLINE;
+  }
   VBH_HIP(hipStreamSynchronize(s));
   const size_t a_floats = (size_t)g->Kpad * LDA + ((4 - (g->Kpad * LDA) % 4) % 4);
   const size_t bc_floats = std::max((size_t)g->Kpad * TN, (size_t)TM * LDC);
@@ -623,6 +676,13 @@ void vbh_gmm_destroy(vbh_gmm *g) {
   (void)hipSetDevice(g->ctx->device);
   (void)hipStreamSynchronize(g->ctx->stream);
   delete g;
+}
+int vbh_gmm_set_lse_mode(vbh_gmm *g, int32_t mode) {
+  VBH_CHECK(g, "vbh_gmm_set_lse_mode: NULL model");
+  VBH_CHECK(mode == VBH_LSE_FAST || mode == VBH_LSE_STRICT || mode == VBH_LSE_ONLINE, "vbh_gmm_set_lse_mode: unknown mode %d", mode);
+  VBH_CHECK(g->rows || mode == VBH_LSE_FAST, "vbh_gmm_set_lse_mode: the tile kernel (VBH_GMM_V1) has the default mode only");
+  g->lse_mode = mode;
+  return 0;
 }
 int32_t vbh_gmm_num_pdfs(const vbh_gmm *g) { return g->P; }
 int32_t vbh_gmm_dim(const vbh_gmm *g) { return g->D; }
@@ -693,7 +753,7 @@ int vbh_gmm_loglikes(vbh_gmm *g, const float *d_feats, int64_t T, float *d_logli
       const long long blocks = (n * g->P + 255) / 256;
       VBH_CHECK(blocks < 2147483647LL, "vbh_gmm_loglikes: chunk too large");
       hipLaunchKernelGGL(gmm_fold_parts_kernel, dim3((unsigned)blocks), dim3(256), 0, g->ctx->stream,
-                         g->part_scratch2.p, n, g->n_parts2, g->P, g->d_pdf_parts2.p, d_loglikes + t0 * g->P);
+                         g->part_scratch2.p, n, g->n_parts2, g->P, g->d_pdf_parts2.p, d_loglikes + t0 * g->P, (int)(g->lse_mode == VBH_LSE_STRICT));
       VBH_HIP(hipGetLastError());
     }
     return 0;
@@ -706,7 +766,7 @@ int vbh_gmm_loglikes(vbh_gmm *g, const float *d_feats, int64_t T, float *d_logli
     const long long blocks = (n * g->P + 255) / 256;
     VBH_CHECK(blocks < 2147483647LL, "vbh_gmm_loglikes: chunk too large");
     hipLaunchKernelGGL(gmm_fold_parts_kernel, dim3((unsigned)blocks), dim3(256), 0, g->ctx->stream,
-                       g->part_scratch.p, n, g->n_parts, g->P, g->d_pdf_parts.p, d_loglikes + t0 * g->P);
+                       g->part_scratch.p, n, g->n_parts, g->P, g->d_pdf_parts.p, d_loglikes + t0 * g->P, 0);
     VBH_HIP(hipGetLastError());
   }
   return 0;
@@ -758,13 +818,19 @@ static int gmm_launch_rows(vbh_gmm *g, const float *d_feats, long long T, int n_
   int per = (g->n_rb + groups - 1) / groups;
   per = (per + 3) & ~3;
   groups = (g->n_rb + per - 1) / per;
+#define VBH_GMM_LAUNCH_M(N, M)                                                                         \
+    {                                                                                                  \
+      VBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gmm_rows_kernel<N, M>),              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds_bytes2));    \
+      hipLaunchKernelGGL((gmm_rows_kernel<N, M>), dim3((unsigned)ftiles, groups), dim3(256), g->lds_bytes2, \
+                         g->ctx->stream, d_feats, (long long)T, g->D, n_cols, g->Mp.p, g->rb_meta.p,    \
+                         g->n_rb, per, d_out);                                                         \
+    }
 #define VBH_GMM_LAUNCH(N)                                                                              \
   case N:                                                                                              \
-    VBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gmm_rows_kernel<N>),                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds_bytes2));      \
-    hipLaunchKernelGGL(gmm_rows_kernel<N>, dim3((unsigned)ftiles, groups), dim3(256), g->lds_bytes2,   \
-                       g->ctx->stream, d_feats, (long long)T, g->D, n_cols, g->Mp.p, g->rb_meta.p,      \
-                       g->n_rb, per, d_out);                                                           \
+    if (g->lse_mode == VBH_LSE_STRICT) VBH_GMM_LAUNCH_M(N, VBH_LSE_STRICT)                             \
+    else if (g->lse_mode == VBH_LSE_ONLINE) VBH_GMM_LAUNCH_M(N, VBH_LSE_ONLINE)                        \
+    else VBH_GMM_LAUNCH_M(N, VBH_LSE_FAST)                                                             \
     break;
   switch (g->Kpad / 8) {
     VBH_GMM_LAUNCH(1) VBH_GMM_LAUNCH(2) VBH_GMM_LAUNCH(3) VBH_GMM_LAUNCH(4) VBH_GMM_LAUNCH(5) VBH_GMM_LAUNCH(6)
@@ -773,6 +839,7 @@ static int gmm_launch_rows(vbh_gmm *g, const float *d_feats, long long T, int n_
     default: vbh_set_error("vbh_gmm_loglikes: unsupported K %d", g->Kpad); return -1;
   }
 #undef VBH_GMM_LAUNCH
+#undef VBH_GMM_LAUNCH_M
   VBH_HIP(hipGetLastError());
   return 0;
 }

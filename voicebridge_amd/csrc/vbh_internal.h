@@ -86,6 +86,7 @@ struct DevBuf {
     n = count;
     if (count == 0) return 0;
     VBH_HIP(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+    if (getenv("VBH_DEBUG_ALLOC")) fprintf(stderr, "[vbh alloc] DevBuf [%p, %p) %zu B\n", (void *)p, (void *)((char *)p + count * sizeof(T)), count * sizeof(T));
     return 0;
   }
   int upload(const T *h, size_t count, hipStream_t s) {

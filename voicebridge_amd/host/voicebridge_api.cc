@@ -1352,10 +1352,16 @@ void vb_det_pool_destroy(void *pool) {
 }
 // the calling thread's following gmm-latgen-faster calls make their search workspaces large enough for this max_active as well
 int vb_set_workspace_max_active(int max_active) { g_workspace_max_active.store(max_active > 0 ? max_active : 0); return 0; }
+int vb_get_workspace_max_active(void) { return g_workspace_max_active.load(); }
 int vb_set_device(int device_id) { if (device_id != g_device) g_latgen.Release(); g_device = device_id; return 0; }
 int vb_get_device(void) { return g_device; }
 // frees the model, graph and search workspace the calling thread's last gmm-latgen-faster call left on the device
 void vb_release_device_cache(void) { g_latgen.Release(); ReleaseRawTableCache(); }
+// ... and the thread's GPU context itself (stream, staging arenas): for a thread that is about to end
+void vb_release_thread_context(void) {
+  vb_release_device_cache();
+  if (g_ctx) { vbh_ctx_destroy(g_ctx); g_ctx = nullptr; g_ctx_device = -1; }
+}
 int vb_ComputeMFCCFeats(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return ComputeMFCCFeats(argc, argv, l); }); }
 int vb_ComputeCmvnStats(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return ComputeCmvnStats(argc, argv, l); }); }
 int vb_ApplyCmvn(int argc, char *argv[], const char *lp) { return WithLog(lp, [&](std::ofstream &l) { return ApplyCmvn(argc, argv, l); }); }

@@ -106,12 +106,17 @@ int vb_WerPerUttDetails(const char *in, const char *out, const char *special_sym
 int vb_WerPerSpkDetails(const char *in, const char *utt2spk, const char *out);
 int vb_WerOpsDetails(const char *in, const char *out, const char *special_symbol);
 void vb_ComputeWerCounts(long long *out8);   // {word_errs, num_words, ins, del, sub, num_sent, sent_errs, absent} of the last ComputeWer
-int vb_set_workspace_max_active(int max_active);   // search workspaces of the thread's following gmm-latgen-faster calls cover this max_active too (0: off)
+// search workspaces of following gmm-latgen-faster calls cover this max_active too (0: off).  PROCESS-WIDE (the jobs of a step run on
+// threads of their own): a caller sets it for the duration of a step and puts the old value back (vb_get_workspace_max_active)
+int vb_set_workspace_max_active(int max_active);
+int vb_get_workspace_max_active(void);
 int vb_set_device(int device_id);   // GPU used by the calling thread's subsequent calls (default 0)
 int vb_get_device(void);
 // GmmLatgenFaster keeps the model, the graph and the search workspace of its last call on the device (the nj jobs of a step name the
 // same files again); this frees them
 void vb_release_device_cache(void);
+// the same, and the calling thread's GPU context (stream, staging arenas) with it: call on a thread that is about to end
+void vb_release_thread_context(void);
 }
 
 #endif

@@ -53,8 +53,12 @@ struct StepError : public std::runtime_error {
 // GPU, so the jobs are dealt round-robin to the entries of the list, one host thread per entry, each running its jobs in order: a
 // device named several times is shared by that many job threads (one job's host work overlaps the others' kernels).
 std::vector<int> g_step_devices;
+std::mutex g_step_devices_mu;
 std::vector<int> StepDevices() {
-  if (!g_step_devices.empty()) return g_step_devices;
+  {
+    std::lock_guard<std::mutex> lk(g_step_devices_mu);
+    if (!g_step_devices.empty()) return g_step_devices;
+  }
   std::vector<int> d;
   if (const char *e = getenv("VB_STEP_DEVICES")) {
     std::string w; std::istringstream is(e);
@@ -103,7 +107,7 @@ class JobWorkers {
       { std::lock_guard<std::mutex> lk(w.mu); w.task = nullptr; w.done = true; }
       w.cv.notify_all();
     }
-    vb_release_device_cache();      // the device list changed: this thread's device memory goes with it
+    vb_release_thread_context();    // the device list changed: this thread's device memory and its GPU context go with it
   }
   std::vector<int> devs_;
   std::vector<Worker> w_;
@@ -520,6 +524,8 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
                 bool decode_mbr, bool stats, const std::string &word_ins_penalty, int min_lmwt, int max_lmwt) {
   StepScope scope;
   std::string si_dir = si_dir_in;
+  // the workspace size both passes share is a process-wide setting (the jobs run on threads of their own): put back on the way out
+  struct WorkspaceGuard { int old = vb_get_workspace_max_active(); ~WorkspaceGuard() { vb_set_workspace_max_active(old); } } workspace_guard;
   const int rc = Run([&] {
     if (decode_mbr) throw StepError("MBR decoding (decode_mbr) is not part of this build");
     if (nj < 1) throw StepError("nj must be >= 1");
@@ -810,6 +816,7 @@ int vb_ScoreKaldiWER(const char *data, const char *lang_or_graph, const char *di
 int vb_set_release_device_cache(int on) { g_release_at_step_end.store(on ? 1 : 0); return 0; }
 const char *vb_steps_last_error(void) { return g_err.c_str(); }
 int vb_set_step_devices(const int *devices, int n) {
+  std::lock_guard<std::mutex> lk(g_step_devices_mu);
   g_step_devices.clear();
   for (int i = 0; i < n; i++) { if (devices[i] < 0) return -1; g_step_devices.push_back(devices[i]); }
   return 0;
