@@ -13,9 +13,11 @@ independent, so ranks share nothing on the data path (weak scaling) and a single
 collects the per-rank max time and frame counts at the end.
 
 Prints ONE JSON line (rank 0).  `value` is whole-job frames/s (100 frames = 1 s of audio, so
-RTF = 100 / value).  `roofline` prices the dominant kernel from HIP-event device time
-measured here; `cpu_baseline` times the oracle (oracle/, the parity checker) on a bounded
-sample of the same workload on this host's cores -- a reported baseline, not the target.
+RTF = 100 / value), the host lattice stage of gmm-latgen-faster (determinization) inside the
+timed step.  `roofline` prices the dominant kernel from HIP-event device time measured here;
+`cpu_baseline` times the REFERENCE's own programs (oracle/_ref/bin, compiled from its sources;
+kind "reference") on a bounded sample of the same workload on this host's cores, or, where
+they are not there, the oracle's restatement (kind "port") -- a reported baseline, not the target.
 """
 import argparse
 import json
@@ -63,6 +65,9 @@ def parse():
     ap.add_argument("--sub-batches", type=int, default=1,
                     help="a step's utterances go through the pipeline as this many slices of whole speakers (front end and search per slice): more, "
                          "smaller persistent search grids in flight, whose drains overlap; the step stays --batch utterances")
+    ap.add_argument("--batch-sets", type=int, default=4,
+                    help="distinct batches (other speakers, other utterances) that rotate through the timed steps, so that no step re-searches what the "
+                         "previous one left in the caches; 1 = the same batch every step (rounds 1-2)")
     ap.add_argument("--ahead", type=int, default=1, help="items the front end runs ahead of the search that is enqueued next (ring of pipeline + ahead score buffers)")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="search grids in flight: n contexts/streams whose decoders share one pool of search workspaces; the grid of one "
@@ -100,9 +105,12 @@ def parse():
     ap.add_argument("--no-step-api", action="store_true", help="skip the step-API measurement (MakeMfcc / Decode / DecodeFmllr on a data directory, in a child process)")
     ap.add_argument("--step-api-utts", type=int, default=1024)
     ap.add_argument("--step-api-threads", type=int, default=4, help="host threads the nj = 4 jobs of a step run on, all on the one GPU (VB_STEP_DEVICES=0,0,..; the reference runs its jobs side by side)")
-    ap.add_argument("--cpu-sample-seconds", type=float, default=120.0,
-                    help="audio seconds one process of the CPU baseline decodes (whole speakers; the default is one speaker of four 30 s utterances, "
-                         "about 10-30 s of one core depending on how hard the search is)")
+    ap.add_argument("--cpu-sample-seconds", type=float, default=240.0,
+                    help="audio seconds one process of the CPU baseline decodes (whole speakers; the default is two speakers of four 30 s utterances, "
+                         "about 20-30 s of one core depending on how hard the search is)")
+    ap.add_argument("--cpu-jobs", type=int, default=8,
+                    help="processes of the CPU baseline run side by side, one job of whole speakers each (the reference runs its nj jobs side by side; "
+                         "8 x 8 utterances = the 64-utterance sample; `cores` in the bench line says how many were used)")
     return ap.parse_args()
 
 
@@ -117,7 +125,7 @@ UTT_PER_SPK = 4
 SPEECH_XFORM_SCALE = 0.005
 
 
-def build_workload(args, rank, world, device, lex=None):
+def build_workload(args, rank, world, device, lex=None, set_index=0):
     """The job = world x batch utterances of world x batch/4 speakers (speakers of 4 utterances),
     sharded by speaker over the ranks as voicebridge_amd/dist.py does for a data directory (longest-processing-time
     assignment; all utterances have the same length here, so every rank gets batch/4 speakers).  Every utterance of the
@@ -132,6 +140,7 @@ def build_workload(args, rank, world, device, lex=None):
     rank_of = vdist.shard_speakers(np.full(world * n_spk, upk * frames_per_utt, np.int64), world)
     my_spk = np.flatnonzero(rank_of == rank)
     assert len(my_spk) == n_spk
+    my_spk = my_spk + set_index * world * n_spk        # (further batches of the job: other speakers, other utterances)
     utt2spk = (np.arange(args.batch, dtype=np.int32) // upk).astype(np.int32)      # rank-local speaker index: a speaker's utterances are adjacent
     gid = my_spk[utt2spk] * upk + np.arange(args.batch) % upk             # job-wide utterance id
     n = int(round(args.seconds * 16000))
@@ -235,7 +244,7 @@ def cpu_sample(args, utt2spk, n_spk):
     per = max(1, int(round(args.cpu_sample_seconds / args.seconds)))          # utterances one process decodes (about 10-20 s of one core)
     upk = max(1, int(np.sum(np.asarray(utt2spk) == 0)))
     spk_per_job = max(1, per // upk)
-    n_jobs = max(1, min(4, n_spk // spk_per_job))
+    n_jobs = max(1, min(max(1, args.cpu_jobs), n_spk // spk_per_job))
     jobs = []
     for j in range(n_jobs):
         spk = list(range(j * spk_per_job, (j + 1) * spk_per_job))
@@ -724,6 +733,26 @@ def main():
         fd.close()
     if args.probe and dec is not None:
         gmm.loglikes(feats, out=ll)
+        if os.environ.get("VBH_PROBE_REPEAT"):
+            # determinism: the same batch searched n times must give the same retries, counters and lattices every time
+            first, diffs = None, 0
+            for rep_ in range(int(os.environ["VBH_PROBE_REPEAT"])):
+                dec.decode(ll, foff, t2p)
+                sig = []
+                for u in range(args.batch):
+                    r = dec.result(u)
+                    sig.append((r["n_tokens_expanded"], r["n_arcs_expanded"], r["n_tokens_created"], r["n_links_created"], r["n_frames_maxactive_bound"],
+                                r["n_frames_minactive_bound"], r["num_toks"], r["num_links"],
+                                hash(r["tok_state"].tobytes() + r["tok_cost"].tobytes() + r["tok_extra"].tobytes() + r["link_src"].tobytes() + r["link_dst"].tobytes() +
+                                     r["link_graph"].tobytes() + r["link_acoustic"].tobytes() + np.asarray(r["words"]).tobytes())))
+                st_ = dec.batch_stats()
+                if first is None:
+                    first = (sig, st_)
+                else:
+                    bad = [u for u in range(args.batch) if sig[u] != first[0][u]]
+                    diffs += len(bad) + int(st_ != first[1])
+                    print("repeat %d: %d utterances differ from the first run%s; batch stats %s (first run %s)" % (rep_, len(bad), (" (first: %d)" % bad[0]) if bad else "", st_, first[1]), flush=True)
+            print("determinism: %d differences over %s repeats of %d utterances" % (diffs, os.environ["VBH_PROBE_REPEAT"], args.batch), flush=True)
         t0 = time.perf_counter()
         dec.decode(ll, foff, t2p)
         dt = time.perf_counter() - t0
@@ -796,18 +825,34 @@ def main():
 
     class Slice:
         pass
-    slices = []
-    for k in range(S):
+    # further batch sets (--batch-sets): waveforms, CMVN statistics and transforms of their own; set 0 is the batch built above
+    n_sets = max(1, args.batch_sets) if (dec is not None and args.workload == "speech" and not args.load_waves) else 1
+    sets = [(d_wave, woff, foff, utt2spk, stats, xforms)]
+    for k_ in range(1, n_sets):
+        w_, wo_, u2s_, nspk_, xf_, _gid, _truth = build_workload(args, rank, world, dev, lex, set_index=k_)
+        ctx.torch_sync()
+        raw_k, foff_k = mf.compute_packed(w_, wo_, is_i16, out=raw)        # (raw is scratch here: the pipeline recomputes it per item)
+        ctx.sync()
+        st_ = post.cmvn_stats(raw_k, foff_k, u2s_, nspk_)
+        sets.append((w_, wo_, foff_k, u2s_, st_, xf_))
+    slices = []        # [set * S + slice]
+    for (dw_, wo_, fo_, u2s_, st_, xf_) in sets:
+      for k in range(S):
         sl = Slice()
         sl.a, sl.b = k * per, (k + 1) * per
-        sl.wave = d_wave[int(woff[sl.a]):int(woff[sl.b])]
-        sl.woff = np.ascontiguousarray(woff[sl.a:sl.b + 1] - woff[sl.a])
-        sl.r0, sl.r1 = int(foff[sl.a]), int(foff[sl.b])
-        sl.foff = np.ascontiguousarray(foff[sl.a:sl.b + 1] - foff[sl.a])
-        s0, s1 = int(utt2spk[sl.a]), int(utt2spk[sl.b - 1]) + 1
-        sl.u2s = np.ascontiguousarray(utt2spk[sl.a:sl.b] - s0)
-        sl.stats, sl.xforms = np.ascontiguousarray(stats[s0:s1]), np.ascontiguousarray(xforms[s0:s1])
+        sl.wave = dw_[int(wo_[sl.a]):int(wo_[sl.b])]
+        sl.woff = np.ascontiguousarray(wo_[sl.a:sl.b + 1] - wo_[sl.a])
+        sl.r0, sl.r1 = int(fo_[sl.a]), int(fo_[sl.b])
+        sl.foff = np.ascontiguousarray(fo_[sl.a:sl.b + 1] - fo_[sl.a])
+        s0, s1 = int(u2s_[sl.a]), int(u2s_[sl.b - 1]) + 1
+        sl.u2s = np.ascontiguousarray(u2s_[sl.a:sl.b] - s0)
+        sl.stats, sl.xforms = np.ascontiguousarray(st_[s0:s1]), np.ascontiguousarray(xf_[s0:s1])
         slices.append(sl)
+    item0 = [0]          # items run so far: the batch sets rotate across the timed regions
+
+    def slice_of(i):
+        """slice of pipeline item i of the current run_steps call: set ((item0 + i) // S) % n_sets, part i % S"""
+        return (((item0[0] + i) // S) % n_sets) * S + (i % S)
     Ts = max(sl.r1 - sl.r0 for sl in slices)
     ahead = max(1, args.ahead) if depth > 1 else 1
     n_ring = depth + ahead if depth > 1 else 1
@@ -851,7 +896,7 @@ def main():
 
     def front_end(i, timed):
         """MFCC -> post -> GMM of item i (slice i % S of a step) into ring[i % n_ring], on the front-end stream"""
-        sl_ = slices[i % S]
+        sl_ = slices[slice_of(i)]
         r_, f_, l_ = ring[i % n_ring]
         n_rows = sl_.r1 - sl_.r0
         tsl = 1 + 2 * (i % 7)                # timer slots rotate: several items may be in flight
@@ -938,10 +983,11 @@ def main():
                 front_end(i, timed)
                 if L.dec is not None:
                     L.timed = timed
-                    L.slice = i % S
-                    L.dec.decode_begin(ring[0][2], slices[i % S].foff, t2p)
+                    L.slice = slice_of(i)
+                    L.dec.decode_begin(ring[0][2], slices[slice_of(i)].foff, t2p)
                     L.pending = True
                     finish(L)
+            item0[0] += items
             return
         # the front end runs `ahead` items in front of the search enqueued next; a search waits (on the device) for the front
         # end of its own item only: an event recorded on the front-end stream right after that item's scores
@@ -955,11 +1001,12 @@ def main():
                 n_fe += 1
             L.ctx.wait_mark(ctx, i % n_ring)
             L.timed = timed
-            L.slice = i % S
-            L.dec.decode_begin(ring[i % n_ring][2], slices[i % S].foff, t2p)
+            L.slice = slice_of(i)
+            L.dec.decode_begin(ring[i % n_ring][2], slices[slice_of(i)].foff, t2p)
             L.pending = True
         for L in lanes:
             finish(L)
+        item0[0] += items
 
     def barrier():
         for L in lanes:
@@ -972,32 +1019,40 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # headline region: the step INCLUDES the host stage the reference's gmm-latgen-faster applies to every utterance (Connect, phone- and
+    # word-level pruned determinization, un-scaling): a pool of host threads determinizes the lattices of batch k while the GPU searches
+    # batch k+1, and the region ends when the last batch is determinized (rounds 1-2 timed the raw-lattice path here)
+    det_in_headline = det_pool is not None
+    det_on[0] = det_in_headline
     run_steps(args.warmup, False)
     barrier()
+    if det_pool is not None:
+        det_pool.reset()
     t0 = time.perf_counter()
     run_steps(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
+    det_totals = det_pool.totals.copy() if det_pool is not None else None
+    det_submit_s = det_pool.submit_s if det_pool is not None else 0.0
+    det_on[0] = False
     for o_ in fe_timed:
         feat_ms.append(ctx.timer_ms(o_)); gmm_ms.append(ctx.timer_ms(o_ + 1))
     del fe_timed[:]
-    # second timed region: the same steps with the lattice stage of the reference's Decode inside them
-    det_dt = None
+    # second timed region: the GPU path alone (raw state-level lattices delivered to the host, no determinization)
+    raw_dt = None
     if det_pool is not None and args.det_steps > 0:
         n_dec_timed = len(dec_ms)
-        det_on[0] = True
         run_steps(1, False)
         barrier()
-        det_pool.reset()
         t0 = time.perf_counter()
         run_steps(args.det_steps, False)
         barrier()
-        det_dt = time.perf_counter() - t0
-        det_on[0] = False
+        raw_dt = time.perf_counter() - t0
         del dec_ms[n_dec_timed:], dec_k_ms[n_dec_timed:], dec_h_ms[n_dec_timed:]
     # one more (untimed) step through the same pipeline to gather every utterance's words, counters and timeline
     if dec_enabled:
         collect[0] = True
+        item0[0] = 0           # (the collection step searches batch set 0: its transcripts and ids are the ones scored and gathered)
         run_steps(1, False)
         barrier()
         collect[0] = False
@@ -1125,16 +1180,21 @@ def main():
                                "lattice_tokens_per_frame": c["lat_tok"] / T, "lattice_arcs_per_frame": c["lat_link"] / T,
                                "arc_expansions_per_s": c["arc"] / S / (k_ms * 1e-3)}
             extra["lattice_stage_host"] = determinize_measurement(args, dec, per, slices[(S - 1) % S].r1 - slices[(S - 1) % S].r0)
-            if det_pool is not None and det_dt is not None:
-                nb = args.det_steps * args.batch
-                tt = det_pool.totals
+            if det_pool is not None and det_totals is not None:
+                nb = args.steps * args.batch
+                tt = det_totals
                 extra["lattice_stage_in_step"] = {
-                    "value": T * args.det_steps / det_dt, "unit": "frames/s", "steps": args.det_steps, "ms_per_step": 1e3 * det_dt / args.det_steps,
-                    "what": "every timed batch's lattices determinized (Connect, phone-level + word-level pruned determinization, un-scaling) by a pool "
-                            "of host threads while the GPU searches the next batch; the timed region ends when the last batch is determinized",
+                    "what": "the headline `value` includes it: every timed batch's lattices determinized (Connect, phone-level + word-level pruned "
+                            "determinization, un-scaling: what gmm-latgen-faster does to every utterance) by a pool of host threads while the GPU "
+                            "searches the next batch; the timed region ends when the last batch is determinized",
                     "threads": det_pool.threads, "utterances": nb, "worker_seconds": float(tt[0]), "worker_ms_per_utterance": 1e3 * float(tt[0]) / max(nb, 1),
-                    "copy_out_seconds_on_the_step_thread": det_pool.submit_s, "raw_arcs_per_utt": float(tt[2]) / max(nb, 1),
+                    "copy_out_seconds_on_the_step_thread": det_submit_s, "raw_arcs_per_utt": float(tt[2]) / max(nb, 1),
                     "det_arcs_per_utt": float(tt[4]) / max(nb, 1), "stopped_before_beam": int(tt[5])}
+                if raw_dt is not None:
+                    extra["raw_lattice_rate"] = {"value": T * args.det_steps / raw_dt, "unit": "frames/s", "steps": args.det_steps,
+                                                 "ms_per_step": 1e3 * raw_dt / args.det_steps,
+                                                 "what": "a second timed region without the host lattice stage: the GPU path alone, raw state-level "
+                                                         "lattices delivered to the host (what rounds 1-2 reported as `value`)"}
             try:
                 extra["gmm_on_demand"] = ondemand_gmm_measurement(args, ctx_full, gmm_m, model, ring[0][1][:n_rows0], n_rows0)
             except Exception as e:
@@ -1164,7 +1224,8 @@ def main():
                        "utterances_per_step_per_gpu": args.batch, "utterance_seconds": args.seconds,
                        "frames_per_step_per_gpu": T, "pdfs": gmm.num_pdfs, "gaussians": gmm.num_gauss, "dim": gmm.dim, "features": args.feat,
                        "batches_in_flight": depth, "slices_per_step": S, "search_cus": args.search_cus, "front_end_cus": args.fe_cus,
-                       "lattices": "raw (state level) in the headline region; determinized on the host in the second region (lattice_stage_in_step)",
+                       "lattices": "determinized on the host inside the timed step (lattice_stage_in_step), as gmm-latgen-faster writes them; raw_lattice_rate: the GPU path alone",
+                       "batch_sets": n_sets,
                        "sharding": "utterances over ranks, no data-path collective"},
             "roofline": roof, "stage_ms": stage_ms,
         }

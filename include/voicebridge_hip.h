@@ -313,11 +313,21 @@ void vbh_faster_cfg_default(vbh_faster_cfg *cfg);
 typedef struct vbh_faster_decoder vbh_faster_decoder;
 int vbh_faster_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_faster_cfg *cfg, int32_t max_batch,
                               int32_t max_frames, vbh_faster_decoder **out);
+/* The same for alignment (AlignUtteranceWrapper, K/decoder/decoder-wrappers.cc:424-516: one small graph per utterance): `graph`
+ * is the disjoint union of the utterances' graphs and max_states_per_utt the largest of them, which sizes the per-frame
+ * workspaces (0: sized for the whole graph) */
+int vbh_faster_decoder_create_ex(vbh_ctx *ctx, const vbh_graph *graph, const vbh_faster_cfg *cfg, int32_t max_batch,
+                                 int32_t max_frames, int32_t max_states_per_utt, vbh_faster_decoder **out);
 void vbh_faster_decoder_destroy(vbh_faster_decoder *d);
 /* decodes n_utt utterances (rows h_frame_offsets[u]..[u+1] of d_loglikes [T x num_pdfs]); blocks */
 int vbh_faster_decode_batch(vbh_faster_decoder *d, const float *d_loglikes, int32_t num_pdfs,
                             const int64_t *h_frame_offsets, int32_t n_utt, const int32_t *h_tid2pdf,
                             int32_t num_tids);
+/* ... with a start state per utterance (h_start_states, NULL or -1 entries: the graph's own) and, when beam > 0, that beam instead
+ * of the configured one (the retry_beam second attempt of AlignUtteranceWrapper, decoder-wrappers.cc:466-473) */
+int vbh_faster_decode_batch_ex(vbh_faster_decoder *d, const float *d_loglikes, int32_t num_pdfs,
+                               const int64_t *h_frame_offsets, int32_t n_utt, const int32_t *h_tid2pdf,
+                               int32_t num_tids, const int32_t *h_start_states, float beam);
 typedef struct vbh_best_path {    /* GetBestPath + GetLinearSymbolSequence (faster-decoder.cc:87-147) */
   int32_t ok;                     /* a token survived the last frame (Decode's return value) */
   int32_t reached_final;          /* ReachedFinal() */

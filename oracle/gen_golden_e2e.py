@@ -46,6 +46,7 @@ from voicebridge_amd import refio, synth, synth_speech as ss  # noqa: E402
 B = os.path.join(HERE, "_ref", "bin")
 GOLD = os.path.join(ROOT, "tests", "golden")
 N_UTT, N_STAGE, ROW_STEP, N_JOBS = 64, 4, 47, 8
+HASH_RATIOS = (1.0, 3.0)
 P, G, D, WORDS = gs.P, gs.G, gs.D, gs.WORDS
 CFG = gs.CFG
 
@@ -133,21 +134,43 @@ def main():
             log = run("gmm-latgen-faster", "--beam=%g" % CFG["beam"], "--lattice-beam=%g" % CFG["lattice_beam"], "--max-active=%d" % CFG["max_active"],
                       "--min-active=%d" % CFG["min_active"], "--acoustic-scale=%g" % CFG["acwt"], "--allow-partial=true", "--determinize-lattice=false",
                       p("final.mdl"), p("HCLG.fst"), "ark:" + q("feats"), "ark:" + q("lat"), "ark,t:" + q("words"))
-            words, like = {}, {}
-            for line in open(q("words")):
-                f_ = line.split()
-                if f_:
-                    words[int(f_[0].split("-u")[1])] = np.array([int(x) for x in f_[1:]], np.int32)
+            def read_words(path):
+                w_ = {}
+                for line in open(path):
+                    f_ = line.split()
+                    if f_:
+                        w_[int(f_[0].split("-u")[1])] = np.array([int(x) for x in f_[1:]], np.int32)
+                return w_
+            words, like = read_words(q("words")), {}
             for m_ in re.finditer(r"Log-like per frame for utterance \S+-u(\d+) is (\S+) over", log):
                 like[int(m_.group(1))] = float(m_.group(2))
+            # the reference against itself: the same program, same inputs, another --hash-ratio (LatticeFasterDecoderConfig::hash_ratio,
+            # default 2.0: the size of the token hash, i.e. the ORDER in which ProcessEmitting visits the tokens while it tightens
+            # next_cutoff, lattice-faster-decoder.cc:743-775).  How many utterances change their words is the reference's own
+            # sensitivity to its visiting order in this regime -- the yardstick for an order-independent search
+            alt = {}
+            for hr in HASH_RATIOS:
+                run("gmm-latgen-faster", "--beam=%g" % CFG["beam"], "--lattice-beam=%g" % CFG["lattice_beam"], "--max-active=%d" % CFG["max_active"],
+                    "--min-active=%d" % CFG["min_active"], "--acoustic-scale=%g" % CFG["acwt"], "--allow-partial=true", "--determinize-lattice=false",
+                    "--hash-ratio=%g" % hr, p("final.mdl"), p("HCLG.fst"), "ark:" + q("feats"), "ark:" + q("lat"), "ark,t:" + q("words_hr"))
+                alt[hr] = read_words(q("words_hr"))
             print("job %d done: %d utterances  [%.0f s]" % (j, len(words), time.time() - t00), flush=True)
-            return words, like
+            return words, like, alt
 
         with ThreadPoolExecutor(len(jobs)) as ex:
             res = list(ex.map(job, range(len(jobs))))
         ref_words, ref_like = {}, {}
-        for wd, lk in res:
+        alt_words = {hr: {} for hr in HASH_RATIOS}
+        for wd, lk, alt in res:
             ref_words.update(wd); ref_like.update(lk)
+            for hr in HASH_RATIOS:
+                alt_words[hr].update(alt[hr])
+        for hr in HASH_RATIOS:
+            same = [bool(np.array_equal(alt_words[hr][u], ref_words[u])) for u in range(N_UTT)]
+            c_ = vdist.score(truth, [alt_words[hr][u] for u in range(N_UTT)])
+            print("the reference with --hash-ratio=%g: words equal to its default run on %d / %d utterances, WER %.2f %%" % (hr, sum(same), N_UTT, 100.0 * c_[0] / c_[1]), flush=True)
+            out["ref_same_words_hash_ratio_%g" % hr] = np.array(same)
+            out["ref_wer_counters_hash_ratio_%g" % hr] = c_
         assert sorted(ref_words) == list(range(N_UTT)), sorted(ref_words)
         for u in range(N_UTT):
             out["ref_words_%d" % u] = ref_words[u]

@@ -366,6 +366,10 @@ static float process_emitting(ldec *d) {
   if (frame + 1 > d->ncost) { d->cost_offsets = (float *)realloc(d->cost_offsets, sizeof(float) * (frame + 1)); d->ncost = frame + 1; }
   d->cost_offsets[frame] = cost_offset;
 
+  /* exact_cutoff == 2: the admission bound is the reference's INITIAL next_cutoff (from the best token's arcs, :712-724) and stays
+   * there: every arc the reference can admit in any visiting order is admitted (its running bound only falls from this value);
+   * the value handed to ProcessNonemitting is the final one, as in the other modes */
+  const float admit_cutoff = next_cutoff;
   if (c->exact_cutoff) {
     /* order-independent variant: next_cutoff takes its final value before any admission */
     for (int32_t i = 0; i < n; i++) {
@@ -390,7 +394,8 @@ static float process_emitting(ldec *d) {
           float ac_cost = cost_offset - dec_loglike(d, frame, arc->ilabel),
                 graph_cost = arc->weight, cur_cost = d->toks[tok].tot_cost,
                 tot_cost = cur_cost + ac_cost + graph_cost;
-          if (tot_cost > next_cutoff) continue;
+          if (c->exact_cutoff == 2) { if (tot_cost > admit_cutoff) continue; }
+          else if (tot_cost > next_cutoff) continue;
           else if (tot_cost + adaptive_beam < next_cutoff) next_cutoff = tot_cost + adaptive_beam;
           int32_t nt = find_or_add_token(d, arc->nextstate, frame + 1, tot_cost, NULL);
           d->toks[tok].links = new_link(d, nt, arc->ilabel, arc->olabel, graph_cost, ac_cost, d->toks[tok].links);

@@ -122,12 +122,19 @@ def test_words_from_pcm_against_the_reference_programs(chain, tmp_path):
           "|log-like per frame| differs by <= %.2e (equal-word utterances: %.2e); bootstrap: reference %.2f [%.2f, %.2f], GPU %.2f [%.2f, %.2f], "
           "P(GPU improves on reference) = %.2f" % ((sum(same), s["n"], wer_ref, wer_gpu, int(c_ref[1]), dlike.max(), dlike[np.array(same)].max()) + ci))
     assert all(r["ok"] == 1 for r in res)
-    # two float pipelines: an utterance in which a hypothesis is marginal at a frame where max-active decides the cutoff may keep it
-    # on one side only; what is required: most utterances word-identical, and no WER bias -- each side's WER inside
-    # the other's 95 % bootstrap interval, and the bootstrap cannot tell which one is better
-    assert sum(same) >= (s["n"] * 7) // 8
+    # What can be asked of an order-independent search here.  The reference itself is order dependent in this regime: the same
+    # program on the same inputs with --hash-ratio=1 / 3 instead of 2 (another visiting order in ProcessEmitting) changes the words
+    # of 1 / 2 of these 64 utterances (fixture: ref_same_words_hash_ratio_*).  The oracle says where the GPU's differences come
+    # from (tools/r3_admission_words.py): in reference order it reproduces the programs' words on 63 / 64 from PCM, in
+    # the order-independent mode -- what the GPU computes bit for bit -- on 60: three utterances lose their best path to the
+    # admission rule (max-active binds, adaptive_beam < beam, and the reference lets through arcs above the final next_cutoff
+    # that it happens to visit early), one differs within the float tolerance of the front end.
+    self_same = min(int(fx["ref_same_words_hash_ratio_1"].sum()), int(fx["ref_same_words_hash_ratio_3"].sum()))
+    assert sum(same) >= self_same - 4 and sum(same) >= (s["n"] * 7) // 8
+    # no WER bias beyond the resolution of the sample: each side's WER inside the other's 95 % bootstrap interval, and the
+    # difference below a quarter of the interval's width
     assert ci[1] <= wer_gpu <= ci[2] and ci[4] <= wer_ref <= ci[5]
-    assert 5.0 < ci[6] < 95.0          # (per cent)
+    assert abs(wer_gpu - wer_ref) < 0.25 * (ci[2] - ci[1])
     # where the words agree the path is the same and its score differs by the float tolerance of the chain only
     assert dlike[np.array(same)].max() < 2e-3
 
@@ -211,3 +218,20 @@ def test_stage_swaps_attribute_word_differences(chain):
     # agree bit for bit on identical scores; the oracle's scores are within one ulp of gmm-compute-likes)
     assert rows["reference features -> oracle scores"] == k
     assert rows["reference features -> GPU scores (strict)"] == k
+
+
+def test_search_is_deterministic(chain):
+    """identical input must give identical retries, counters and lattices, run after run (the order of a
+    frame's tokens inside the workspace may differ between runs -- atomics decide it -- the delivered lattice may not)"""
+    s = chain
+    ll = s["gmm"].loglikes(s["feats"])
+    first = None
+    for rep in range(4):
+        res = s["search"](ll, s["foff"])
+        sig = [tuple(int(r[k]) for k in ("n_tokens_expanded", "n_arcs_expanded", "n_tokens_created", "n_links_created", "n_frames_maxactive_bound",
+                                          "n_frames_minactive_bound", "num_toks", "num_links")) + (tuple(int(x) for x in r["words"]), float(r["best_graph"]), float(r["best_acoustic"]))
+               for r in res]
+        if first is None:
+            first = sig
+        else:
+            assert sig == first, "run %d differs from run 0" % rep

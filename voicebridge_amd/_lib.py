@@ -21,7 +21,7 @@ SYMBOLS = [
     "vbh_graph_create", "vbh_graph_destroy", "vbh_decode_cfg_default", "vbh_decoder_create", "vbh_decoder_create_shared", "vbh_decoder_set_cfg",
     "vbh_decoder_destroy", "vbh_decode_batch", "vbh_decode_batch_begin", "vbh_decode_batch_end", "vbh_decoder_result", "vbh_decoder_phase_cycles", "vbh_decoder_diag",
     "vbh_decoder_times", "vbh_decoder_utt_timeline", "vbh_decoder_batch_stats",
-    "vbh_faster_cfg_default", "vbh_faster_decoder_create", "vbh_faster_decoder_destroy", "vbh_faster_decode_batch",
+    "vbh_faster_cfg_default", "vbh_faster_decoder_create", "vbh_faster_decoder_create_ex", "vbh_faster_decoder_destroy", "vbh_faster_decode_batch", "vbh_faster_decode_batch_ex",
     "vbh_faster_decoder_result",
     "vbh_fmllr_accumulate", "vbh_fmllr_accumulate_gpost", "vbh_fmllr_work",
 ]

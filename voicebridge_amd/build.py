@@ -59,7 +59,7 @@ def build(force=False, verbose=True):
 
 
 HOST_LIB = os.path.join(LIBDIR, "libvoicebridge_host.so")
-HOST_SOURCES = ["kaldi_io.cc", "lattice.cc", "device_feats.cc", "voicebridge_api.cc", "voicebridge_latbin.cc", "voicebridge_fmllrbin.cc", "voicebridge_scoring.cc", "fmllr.cc", "voicebridge_steps.cc", "host_capi.cc"]
+HOST_SOURCES = ["kaldi_io.cc", "lattice.cc", "device_feats.cc", "voicebridge_api.cc", "voicebridge_latbin.cc", "voicebridge_fmllrbin.cc", "voicebridge_alignbin.cc", "voicebridge_scoring.cc", "fmllr.cc", "voicebridge_steps.cc", "host_capi.cc"]
 
 
 def build_host(force=False, verbose=True):

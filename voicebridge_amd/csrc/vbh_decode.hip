@@ -1143,8 +1143,16 @@ __device__ __forceinline__ void map_clear(Shared &sh) {
 //   3. emitting links get their destination token; the epsilon links are regenerated from the final costs (:824-845) and
 //      the tokens they point to tagged (PLDST).
 // Returns the first link index of the frame's epsilon links; on return a barrier has made all writes visible.
+// VBH_EARLY_EXCISE: a forward link whose cost exceeds the best cost of its destination by more than the lattice beam can never
+// survive PruneForwardLinks (:331-347: link_extra_cost = next_tok->extra_cost + (tot - next_tok->tot_cost) with extra_cost >= 0, and
+// float addition is monotone), whatever the later frames bring.  It is excised the moment the destination's final cost is known --
+// emitting links at their fix-up, epsilon links are not even written -- instead of in the first backward sweep: the sweeps gather no
+// destination for it.  The lattice is the same bit for bit.
+#ifndef VBH_EARLY_EXCISE
+#define VBH_EARLY_EXCISE 1
+#endif
 __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, int nb, float cutoff, unsigned ep,
-                                   int cur, Shared &sh, int el_b, int el_e) {
+                                   int cur, Shared &sh, int el_b, int el_e, float lattice_beam) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   gp<Ent> ent = uptr(s.ent);
   gp<i32x4> wt = uptr(s.w_tok);
@@ -1266,7 +1274,14 @@ __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, in
   // ---- the emitting links' destinations
   for (int l = el_b + tid; l < el_e; l += NT) {
     gp<int> py = (gp<int>)&wl[l] + 1;
+#if VBH_EARLY_EXCISE
+    const i32x2 yz = *(gp<i32x2>)py;
+    const int y = yz.x;
+    const float dcost = y >= 0 ? o2f(map_key(sh)[y]) : o2f((unsigned)ld_u64(&ent[-1 - y].key));
+    if (asf(yz.y) - dcost > lattice_beam) { py[-1] = -1; continue; }
+#else
     const int y = *py;
+#endif
     const int d = y >= 0 ? map_tok(sh, ent, y, 0, nb) : ld_i32(&ent[-1 - y].tokid);
     (void)VBH_CHK(sh, 30, d - nb, ne_all - nb);
     *py = d | WBIT;
@@ -1302,8 +1317,12 @@ __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, in
             if (tot < cutoff) {
               mk = true;
               const int ds = arc.x & STMASK;
-              dtok = map_tok(sh, ent, map_find(sh, ds), ds, nb);
+              const int dslot = map_find(sh, ds);
+              dtok = map_tok(sh, ent, dslot, ds, nb);
               mk = VBH_CHK(sh, 31, dtok - nb, ne_all - nb) && VBH_CHK(sh, 32, so - nb, ne_all - nb);
+#if VBH_EARLY_EXCISE
+              if (tot - map_cost(sh, ent, dslot, ds) > lattice_beam) mk = false;
+#endif
             }
           }
           const int l = wave_alloc(&sh.w_nlink, mk);
@@ -1465,7 +1484,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       }
       __threadfence_block();
       __syncthreads();
-      const int plb = process_nonemitting(g, s, 0, cfg.beam, ep, 0, sh, 0, 0);
+      const int plb = process_nonemitting(g, s, 0, cfg.beam, ep, 0, sh, 0, 0, cfg.lattice_beam);
       cur_b = 0; cur_e = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap;
       if (tid == 0) {
         FrameRec r;
@@ -1766,7 +1785,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       if (sh.error != ERR_NONE) break;
       PHASE(2)
       // ---- ProcessNonemitting(next_cutoff)
-      const int plb = process_nonemitting(g, s, nb, next_cutoff, ep, 0, sh, lb, le_emit);
+      const int plb = process_nonemitting(g, s, nb, next_cutoff, ep, 0, sh, lb, le_emit, cfg.lattice_beam);
       cur_b = nb; cur_e = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap; cur_w = true;
       const int pl_end = sh.w_nlink < s.w_link_cap ? sh.w_nlink : s.w_link_cap;
       if (tid == 0) {

@@ -61,7 +61,7 @@ struct FSlot {
   int tok_cap, frame_cap, cand_cap, front_cap, g_cap, stage_cap;
 };
 
-struct FUtt { long long row0; int T; int pad; };
+struct FUtt { long long row0; int T; int start; };      // start: the utterance's own start state (alignment: one graph per utterance inside a union graph), -1: the graph's
 struct FResult { int ok, error, reached_final, num_frames, path_len, final_state; float final_cost; int pad; long long n_tokens; };
 
 // (FERR_TOK: even after garbage collection the history does not fit)
@@ -568,9 +568,10 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
     // ---- InitDecoding (:36-45): the start token, then the epsilon closure with cutoff FLT_MAX
     if (tid == 0) {
       int slot; bool create, improved;
-      map_relax(sh, m2, g.start, 0.0, slot, create, improved);
+      const int start = ud.start >= 0 ? ud.start : g.start;
+      map_relax(sh, m2, start, 0.0, slot, create, improved);
       map_set_idx(sh, m2, slot, 0); uptr(s.win)[0] = ~0ull; sh.n_new = 1;
-      if (uptr(g.st)[g.start].y > 0) { uptr(s.front[0])[0] = g.start; sh.fcnt[0] = 1; uptr(s.elist)[0] = g.start; sh.n_eps = 1; }
+      if (uptr(g.st)[start].y > 0) { uptr(s.front[0])[0] = start; sh.fcnt[0] = 1; uptr(s.elist)[0] = start; sh.n_eps = 1; }
     }
     __syncthreads();
     epsilon_closure(g, s, (double)FLT_MAX, sh);
@@ -850,6 +851,11 @@ void vbh_faster_cfg_default(vbh_faster_cfg *c) {
 
 int vbh_faster_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_faster_cfg *cfg, int32_t max_batch,
                               int32_t max_frames, vbh_faster_decoder **out) {
+  return vbh_faster_decoder_create_ex(ctx, graph, cfg, max_batch, max_frames, 0, out);
+}
+
+int vbh_faster_decoder_create_ex(vbh_ctx *ctx, const vbh_graph *graph, const vbh_faster_cfg *cfg, int32_t max_batch,
+                                 int32_t max_frames, int32_t max_states_per_utt, vbh_faster_decoder **out) {
   VBH_CHECK(ctx && graph && cfg && out, "vbh_faster_decoder_create: NULL argument");
   VBH_CHECK(cfg->beam > 0.0f && cfg->max_active > 1 && cfg->min_active >= 0 && cfg->min_active < cfg->max_active && cfg->beam_delta > 0.0f,
             "vbh_faster_decoder_create: invalid config (FasterDecoderOptions::Check)");
@@ -864,6 +870,8 @@ int vbh_faster_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_fa
   const long long ma = std::min<long long>(cfg->max_active, gv.S);
   // (a frame early in an utterance can admit every arc leaving its tokens: all costs are still close)
   p.frame_cap = (int)std::min<long long>(std::max<long long>(gv.S, 1), std::max<long long>(16 * HCAP, std::min<long long>(16 * ma, 1 << 21)));
+  // (alignment: the graph is the union of the utterances' own graphs and a search never leaves its utterance's part)
+  if (max_states_per_utt > 0) p.frame_cap = std::min(p.frame_cap, std::max(max_states_per_utt, 64));
   if (const char *e = getenv("VBH_FASTER_FRAME_CAP")) { const int x = atoi(e); if (x > 0) p.frame_cap = std::min(p.frame_cap, x); }   // tests
   p.g_cap = 1;
   while (p.g_cap < 2 * p.frame_cap) p.g_cap <<= 1;
@@ -914,7 +922,7 @@ void vbh_faster_decoder_destroy(vbh_faster_decoder *d) {
 }
 
 static int faster_decode_batch_impl(vbh_faster_decoder *d, const float *d_loglikes, int32_t num_pdfs, const int64_t *h_frame_offsets,
-                                    int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids, bool *holds_pdf) {
+                                    int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids, const int32_t *h_start_states, float beam, bool *holds_pdf) {
   VBH_CHECK(d && h_frame_offsets && h_tid2pdf, "vbh_faster_decode_batch: NULL argument");
   VBH_CHECK(n_utt >= 0 && num_pdfs > 0 && num_tids >= 0, "vbh_faster_decode_batch: bad sizes");
   if (vbh_use_device(d->ctx)) return -1;
@@ -929,7 +937,8 @@ static int faster_decode_batch_impl(vbh_faster_decoder *d, const float *d_loglik
   for (int u = 0; u < n_utt; u++) {
     const long long T = h_frame_offsets[u + 1] - h_frame_offsets[u];
     VBH_CHECK(T >= 0 && T <= d->max_frames, "vbh_faster_decode_batch: utterance %d has %lld frames (decoder built for %d)", u, T, d->max_frames);
-    utts[u] = FUtt{h_frame_offsets[u], (int)T, 0};
+    if (h_start_states) VBH_CHECK(h_start_states[u] >= -1 && h_start_states[u] < gv.S, "vbh_faster_decode_batch: start state %d of utterance %d is not in the graph", h_start_states[u], u);
+    utts[u] = FUtt{h_frame_offsets[u], (int)T, h_start_states ? h_start_states[u] : -1};
     total += T;
   }
   VBH_CHECK(total == 0 || d_loglikes, "vbh_faster_decode_batch: NULL loglikes");
@@ -937,7 +946,7 @@ static int faster_decode_batch_impl(vbh_faster_decoder *d, const float *d_loglik
   if (vbh_graph_fill_pdf(d->graph, st, h_tid2pdf, num_tids)) return -1;
   *holds_pdf = true;
   FGraph fg{gv.S, gv.start, static_cast<const i32x4 *>(gv.st), static_cast<const i32x4 *>(gv.arcs), gv.arc_il};
-  FCfg fc{d->cfg.beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active};
+  FCfg fc{beam > 0.0f ? beam : d->cfg.beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active};
   std::vector<FResult> res(n_utt);
   d->results.resize(n_utt);
   const int path_cap = 4 * (d->max_frames + 2) + 64;
@@ -998,8 +1007,13 @@ static int faster_decode_batch_impl(vbh_faster_decoder *d, const float *d_loglik
 
 int vbh_faster_decode_batch(vbh_faster_decoder *d, const float *d_loglikes, int32_t num_pdfs, const int64_t *h_frame_offsets,
                             int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids) {
+  return vbh_faster_decode_batch_ex(d, d_loglikes, num_pdfs, h_frame_offsets, n_utt, h_tid2pdf, num_tids, nullptr, 0.0f);
+}
+
+int vbh_faster_decode_batch_ex(vbh_faster_decoder *d, const float *d_loglikes, int32_t num_pdfs, const int64_t *h_frame_offsets,
+                               int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids, const int32_t *h_start_states, float beam) {
   bool holds_pdf = false;
-  const int rc = faster_decode_batch_impl(d, d_loglikes, num_pdfs, h_frame_offsets, n_utt, h_tid2pdf, num_tids, &holds_pdf);
+  const int rc = faster_decode_batch_impl(d, d_loglikes, num_pdfs, h_frame_offsets, n_utt, h_tid2pdf, num_tids, h_start_states, beam, &holds_pdf);
   if (holds_pdf) vbh_graph_release_pdf(d->graph);
   return rc;
 }

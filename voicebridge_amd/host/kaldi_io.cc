@@ -733,7 +733,10 @@ void ReadModel(const std::string &path, Model *m) {
   // transition of the tuple's HMM state; a self-loop uses the self-loop pdf
   m->tid2pdf.assign(1, -1);
   m->trans.phone.assign(1, 0); m->trans.hmm_state.assign(1, 0); m->trans.self_loop.assign(1, 0);
+  m->tid2tstate.assign(1, 0);
+  int32_t tstate = 0;
   for (const Tuple &t : tuples) {
+    tstate++;
     if (t.phone < 0 || t.phone >= (int32_t)phone2idx.size() || phone2idx[t.phone] < 0) Fail("model: tuple phone without topology");
     const std::vector<HmmState> &e = entries[phone2idx[t.phone]];
     if (t.hmm_state < 0 || t.hmm_state >= (int32_t)e.size()) Fail("model: bad hmm state in tuple");
@@ -742,12 +745,24 @@ void ReadModel(const std::string &path, Model *m) {
       m->trans.phone.push_back(t.phone);
       m->trans.hmm_state.push_back(t.hmm_state);
       m->trans.self_loop.push_back(tr.first == t.hmm_state ? 1 : 0);
+      m->tid2tstate.push_back(tstate);
     }
   }
   ExpectToken(is, binary, "<LogProbs>");
   std::vector<float> logprobs;
   ReadVector(is, binary, &logprobs);
   ExpectToken(is, binary, "</LogProbs>");
+  if (logprobs.size() != m->tid2pdf.size()) Fail("model: <LogProbs> has " + std::to_string(logprobs.size()) + " entries for " + std::to_string(m->tid2pdf.size() - 1) + " transition-ids");
+  m->log_probs = logprobs;
+  // ComputeDerivedOfProbs (transition-model.cc:364-381): log(1 - self-loop probability) per transition-state, 0 without a self-loop
+  m->non_self_loop_log_probs.assign((size_t)tstate + 1, 0.0f);
+  for (size_t tid = 1; tid < m->tid2pdf.size(); tid++) {
+    if (!m->trans.self_loop[tid]) continue;
+    const float self_loop_prob = expf(m->log_probs[tid]);
+    float non_self_loop_prob = 1.0 - self_loop_prob;
+    if (non_self_loop_prob <= 0.0) non_self_loop_prob = 1.0e-10;
+    m->non_self_loop_log_probs[m->tid2tstate[tid]] = logf(non_self_loop_prob);
+  }
   ExpectToken(is, binary, "</TransitionModel>");
   // ---- AmDiagGmm (am-diag-gmm.cc:147-161)
   ExpectToken(is, binary, "<DIMENSION>");
@@ -779,6 +794,14 @@ void ReadModel(const std::string &path, Model *m) {
   }
 }
 
+float ScaledTransitionLogProb(const Model &m, int32_t tid, float transition_scale, float self_loop_scale) {
+  if (transition_scale == self_loop_scale) return m.log_probs[tid] * transition_scale;
+  if (m.trans.self_loop[tid]) return self_loop_scale * m.log_probs[tid];
+  const float nsl = m.non_self_loop_log_probs[m.tid2tstate[tid]];
+  // GetTransitionLogProbIgnoringSelfLoops (:457-461) = log_probs_(tid) - non-self-loop log prob of its transition-state
+  return self_loop_scale * nsl + transition_scale * (m.log_probs[tid] - nsl);
+}
+
 // ------------------------------------------------------------------ OpenFst binary
 namespace {
 std::string ReadFstString(std::istream &is) {
@@ -795,6 +818,61 @@ constexpr int32_t kFstMagic = 2125659606;
 void ReadFst(const std::string &path, Graph *g) {
   std::ifstream is(path, std::ios::binary);
   if (!is) Fail("cannot open fst " + path);
+  ReadFstStream(is, g, path);
+}
+
+FstTableReader::FstTableReader(const std::string &rspecifier) : spec_(ParseRspecifier(rspecifier)) {
+  if (spec_.is_scp) Fail("graph tables are read from archives (ark:), not from " + rspecifier);
+  ark_.open(spec_.path, std::ios::binary);
+  if (!ark_) Fail("cannot open " + spec_.path);
+}
+bool FstTableReader::Next(std::string *key, Graph *g) {
+  while (ark_.peek() == '\n' || ark_.peek() == ' ') ark_.get();
+  if (ark_.peek() == EOF) return false;
+  key->clear();
+  int c;
+  while ((c = ark_.get()) != EOF && c != ' ') key->push_back((char)c);
+  if (c == EOF) Fail("graph table: truncated entry for key " + *key);
+  if (isspace(ark_.peek())) Fail("graph table: text-form FSTs are not supported (key " + *key + "): write the table with ark:, not ark,t:");
+  ReadFstStream(ark_, g, "graph of " + *key);
+  return true;
+}
+
+void FloatWriter::Open(const std::string &wspecifier) {
+  spec_ = ParseWspecifier(wspecifier);
+  ark_.open(spec_.ark_path, std::ios::binary);
+  if (!ark_) Fail("cannot open " + spec_.ark_path + " for writing");
+  open_ = true;
+}
+void FloatWriter::Write(const std::string &key, float v) {
+  ark_ << key << ' ';
+  if (spec_.text) { if (ark_.precision() < 7) ark_.precision(7); ark_ << v << " \n"; }      // (WriteBasicType + BasicHolder: value, space, newline)
+  else { ark_.put('\0'); ark_.put('B'); ark_.put(4); ark_.write(reinterpret_cast<const char *>(&v), 4); }
+}
+void FloatVectorWriter::Open(const std::string &wspecifier) {
+  spec_ = ParseWspecifier(wspecifier);
+  ark_.open(spec_.ark_path, std::ios::binary);
+  if (!ark_) Fail("cannot open " + spec_.ark_path + " for writing");
+  open_ = true;
+}
+void FloatVectorWriter::Write(const std::string &key, const std::vector<float> &v) {
+  ark_ << key << ' ';
+  if (spec_.text) {
+    if (ark_.precision() < 7) ark_.precision(7);
+    ark_ << " [ ";
+    for (float x : v) ark_ << x << ' ';
+    ark_ << "]\n";
+  } else {
+    ark_.put('\0'); ark_.put('B');
+    ark_.write("FV ", 3);
+    ark_.put(4);
+    const int32_t n = (int32_t)v.size();
+    ark_.write(reinterpret_cast<const char *>(&n), 4);
+    if (n) ark_.write(reinterpret_cast<const char *>(v.data()), 4 * (size_t)n);
+  }
+}
+
+void ReadFstStream(std::istream &is, Graph *g, const std::string &path) {
   int32_t magic = 0;
   is.read(reinterpret_cast<char *>(&magic), 4);
   if (magic != kFstMagic) Fail("fst: bad magic number in " + path);

@@ -132,8 +132,15 @@ struct Model {
   // per transition-id (index 0 unused): TransitionIdToPhone / TransitionIdToHmmState / IsSelfLoop
   // (K/hmm/transition-model.h:160-175, .cc:144-177) -- what lattice determinization asks of the model
   vblat::TransInfo trans;
+  // transition probabilities (K/hmm/transition-model.h:148-158,.cc:364-381): log_probs_ per transition-id (index 0 unused), the
+  // transition-state of every transition-id, and per transition-state (index 0 unused) the log of 1 - its self-loop probability
+  std::vector<float> log_probs;
+  std::vector<int32_t> tid2tstate;
+  std::vector<float> non_self_loop_log_probs;
 };
 void ReadModel(const std::string &path, Model *m);
+// GetScaledTransitionLogProb (K/hmm/hmm-utils.cc:1019-1038): what AddTransitionProbs adds (negated) to the arc of a transition-id
+float ScaledTransitionLogProb(const Model &m, int32_t tid, float transition_scale, float self_loop_scale);
 
 // ---- graphs
 struct Arc { int32_t ilabel, olabel; float weight; int32_t nextstate; };
@@ -144,6 +151,36 @@ struct Graph {
   std::vector<Arc> arcs;
 };
 void ReadFst(const std::string &path, Graph *g);   // "const" or "vector", arc type "standard"
+void ReadFstStream(std::istream &is, Graph *g, const std::string &what);   // the same from an open stream (leaves it behind the FST)
+// sequential reader over a table of graphs ("ark:file", binary VectorFst<StdArc> entries as compile-train-graphs writes them:
+// VectorFstTplHolder, K/fstext/kaldi-fst-io-inl.h:170-207)
+class FstTableReader {
+ public:
+  explicit FstTableReader(const std::string &rspecifier);
+  bool Next(std::string *key, Graph *g);    // false at end
+ private:
+  Rspec spec_;
+  std::ifstream ark_;
+};
+// BaseFloatWriter / BaseFloatVectorWriter (K/util/kaldi-holder-inl.h BasicHolder<float>, KaldiObjectHolder<Vector<float>>)
+class FloatWriter {
+ public:
+  FloatWriter() {}
+  void Open(const std::string &wspecifier);
+  bool IsOpen() const { return open_; }
+  void Write(const std::string &key, float v);
+ private:
+  Wspec spec_; bool open_ = false; std::ofstream ark_;
+};
+class FloatVectorWriter {
+ public:
+  FloatVectorWriter() {}
+  void Open(const std::string &wspecifier);
+  bool IsOpen() const { return open_; }
+  void Write(const std::string &key, const std::vector<float> &v);
+ private:
+  Wspec spec_; bool open_ = false; std::ofstream ark_;
+};
 
 // raw lattice: one state per token, as GetRawLattice builds it
 struct LatticeArcOut { int32_t ilabel, olabel; float graph, acoustic; int32_t nextstate; };

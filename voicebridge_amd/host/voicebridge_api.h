@@ -40,6 +40,11 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log);
 int CopyFeats(int argc, char *argv[], std::ofstream &file_log);          // VB/src/kaldi_src.h:20
 // not wrapped by the reference DLL; upstream program K/gmmbin/gmm-decode-faster.cc with the same conventions
 int GmmDecodeFaster(int argc, char *argv[], std::ofstream &file_log);
+// gmm-align-compiled (VB/src/gmmbin/gmm-align-compiled.cpp:24-160 over AlignUtteranceWrapper, K/decoder/decoder-wrappers.cc:424-516):
+// <model> <graphs-rspecifier> <feature-rspecifier> <alignments-wspecifier> [scores-wspecifier]; --beam, --retry-beam,
+// --transition-scale, --acoustic-scale, --self-loop-scale, --write-per-frame-acoustic-loglikes as the reference's; --careful=true is
+// refused; --decode-batch=N utterances per launch of the batched FasterDecoder (extension).  voicebridge_alignbin.cc
+int GmmAlignCompiled(int argc, char *argv[], std::ofstream &file_log);
 
 // ---- lattices after the search; host code in voicebridge_latbin.cc
 //   src/kaldi_src.h:94   int LatticeDeterminizePruned(int argc, char *argv[], fs::ofstream &file_log);
@@ -86,6 +91,7 @@ int vb_SpliceFeats(int argc, char *argv[]);
 int vb_TransformFeats(int argc, char *argv[], const char *log_path);
 int vb_GmmLatgenFaster(int argc, char *argv[], const char *log_path);
 int vb_GmmDecodeFaster(int argc, char *argv[], const char *log_path);
+int vb_GmmAlignCompiled(int argc, char *argv[], const char *log_path);
 int vb_CopyFeats(int argc, char *argv[], const char *log_path);
 int vb_LatticeDeterminizePruned(int argc, char *argv[], const char *log_path);
 int vb_LatticeDeterminizePhonePruned(int argc, char *argv[], const char *log_path);

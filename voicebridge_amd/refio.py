@@ -72,6 +72,19 @@ def write_mdl(path, n_cd, hmm_states, offs, weights, miv, iv, self_p=0.6):
 
 def write_vector_fst(path, final, arc_offset, arcs, start=0):
     """OpenFst VectorFst<StdArc> binary file from the graph arrays of synth.*_graph() (vectorised: millions of states)."""
+    with open(path, "wb") as f:
+        f.write(vector_fst_bytes(final, arc_offset, arcs, start))
+
+
+def write_fst_table(path, graphs):
+    """Binary archive of VectorFst<StdArc> (what compile-train-graphs writes and gmm-align-compiled reads: key, space, the FST
+    as OpenFst writes it -- VectorFstTplHolder, K/fstext/kaldi-fst-io-inl.h:170-207).  graphs: {key: (final, arc_offset, arcs, start)}."""
+    with open(path, "wb") as f:
+        for k, (final, arc_offset, arcs, start) in graphs.items():
+            f.write(k.encode() + b" " + vector_fst_bytes(final, arc_offset, arcs, start))
+
+
+def vector_fst_bytes(final, arc_offset, arcs, start=0):
     S = len(final)
     a = np.ascontiguousarray(arcs)
     A = len(a)
@@ -94,9 +107,7 @@ def write_vector_fst(path, final, arc_offset, arcs, start=0):
         apos = 12 * (state_of_arc + 1) + 16 * np.arange(A, dtype=np.int64)
         ab = a.view(np.uint8).reshape(A, 16)
         body[apos[:, None] + np.arange(16)[None, :]] = ab
-    with open(path, "wb") as f:
-        f.write(hdr)
-        f.write(body.tobytes())
+    return hdr + body.tobytes()
 
 
 def write_feats_ark(path, feats):
