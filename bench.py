@@ -125,6 +125,53 @@ UTT_PER_SPK = 4
 SPEECH_XFORM_SCALE = 0.005
 
 
+def shared_objects(tag, rank, world, dist, build):
+    """What every rank needs and none has to make for itself (the 228 k-word graph: ~20 s of Python; the fitted acoustic model):
+    rank 0 builds it and leaves the arrays in /dev/shm, the other ranks of the node wait at a barrier and map them (read-only
+    numpy memory maps), rank 0 removes the files when everybody has them open.  `build` returns a tuple of dicts / arrays / ints;
+    with one rank it is simply called."""
+    if world <= 1:
+        return build()
+    import shutil
+    d = "/dev/shm/vb_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), tag)
+
+    def save(obj, path):
+        if isinstance(obj, dict):
+            os.makedirs(path)
+            for k, v in obj.items():
+                save(v, os.path.join(path, "d_" + k))
+        elif isinstance(obj, (tuple, list)):
+            os.makedirs(path)
+            for i, v in enumerate(obj):
+                save(v, os.path.join(path, "t_%03d" % i))
+        elif obj is None:
+            os.makedirs(path + ".none")
+        else:
+            np.save(path + ".npy", np.asarray(obj))
+
+    def load(path):
+        if os.path.isdir(path + ".none"):
+            return None
+        if os.path.isdir(path):
+            names = sorted(os.listdir(path))
+            if names and names[0].startswith("t_"):
+                return tuple(load(os.path.join(path, n.split(".")[0])) for n in sorted(set(n.split(".")[0] for n in names)))
+            return {n.split(".")[0][2:]: load(os.path.join(path, n.split(".")[0])) for n in sorted(set(n.split(".")[0] for n in names))}
+        a = np.load(path + ".npy", mmap_mode="r")
+        return a[()] .item() if a.ndim == 0 else a
+    if rank == 0:
+        shutil.rmtree(d, ignore_errors=True)
+        obj = build()
+        save(obj, os.path.join(d, "root"))
+    dist.barrier()
+    if rank != 0:
+        obj = load(os.path.join(d, "root"))
+    dist.barrier()
+    if rank == 0:
+        shutil.rmtree(d, ignore_errors=True)          # (the maps of the other ranks keep the pages until they let go)
+    return obj
+
+
 def build_workload(args, rank, world, device, lex=None, set_index=0):
     """The job = world x batch utterances of world x batch/4 speakers (speakers of 4 utterances),
     sharded by speaker over the ranks as voicebridge_amd/dist.py does for a data directory (longest-processing-time
@@ -605,7 +652,7 @@ def main():
 
     lex = None
     if args.workload == "speech":
-        g, t2p, lex = build_graph(args, lexicon=True)
+        g, t2p, lex = shared_objects("graph", rank, world, dist, lambda: build_graph(args, lexicon=True))
     d_wave, woff, utt2spk, n_spk, xforms, gid, truth = build_workload(args, rank, world, dev, lex)
     is_i16 = True
     mf = api.Mfcc(ctx)
@@ -626,7 +673,8 @@ def main():
     sample_idx = torch.linspace(0, T - 1, min(T, 20000), device=dev).long()
     n_unseen_pdfs = None
     if lex is not None:
-        model, n_unseen_pdfs = speech_model(args, lex, mf, post, ctx, dev)
+        model, n_unseen_pdfs = shared_objects("model", rank, world, dist, lambda: speech_model(args, lex, mf, post, ctx, dev))
+        model = tuple(np.ascontiguousarray(m_) for m_ in model)
     else:
         model = feature_space_model(args, feats[sample_idx].cpu().numpy())
     gmm = api.DiagGmm(ctx, *model)
@@ -1090,7 +1138,13 @@ def main():
                       "workgroups": len(set(col_tl[:, 2].tolist())), "span_ms": span / 1e5,
                       "mean_utterances_in_search": float(dur.sum()) / span,
                       "utterance_ms_min_mean_max": [float(dur.min()) / 1e5, float(dur.mean()) / 1e5, float(dur.max()) / 1e5]}
+    per_rank = [{"rank": 0, "seconds": dt, "frames_per_s": T * args.steps / dt, "device": local_rank}]
     if world > 1:
+        # every rank's own time for its K steps (between the same two barriers): a straggler shows up here, not only in the maximum
+        mine = torch.tensor([dt, float(T * args.steps), float(local_rank)], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [{"rank": r_, "seconds": float(e_[0]), "frames_per_s": float(e_[1]) / float(e_[0]), "device": int(e_[2])} for r_, e_ in enumerate(every)]
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -1228,16 +1282,22 @@ def main():
                        "batch_sets": n_sets,
                        "sharding": "utterances over ranks, no data-path collective"},
             "roofline": roof, "stage_ms": stage_ms,
+            "ranks": {"world_size": world, "backend": backend if world > 1 else "none (one process)", "visible_devices": torch.cuda.device_count(),
+                      "per_rank": per_rank, "timing": "every rank times its own K steps between the same two barriers; `value` = frames of all ranks / the slowest rank's time"},
         }
         out.update(extra)
         out["roofline_mfcc"] = extra_mfcc
         # HBM traffic of the dominant kernels from the committed rocprofv3 --pmc passes of this
         # same command (profiles/): only attached when the batch size matches that run
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_h_pmc_traffic.json")))
+            import glob
+            tr_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]        # the latest round's passes
+            tr = json.load(open(tr_path))
             if tr.get("batch") == args.batch and world == 1:
-                for ro in [out["roofline"]] + [out[k] for k in ("roofline_gmm", "roofline_decode") if k in out]:
-                    b_ = tr["bytes_per_launch"].get(ro["kernel"])
+                for ro in [out["roofline"]] + [out[k] for k in ("roofline_gmm", "roofline_decode", "roofline_mfcc") if k in out]:
+                    # (front-end kernels also run on small training batches in that command: their largest launch is the full batch)
+                    b_ = tr.get("bytes_of_largest_launch", {}).get(ro["kernel"]) if ro["kernel"] != "decode_kernel" else None
+                    b_ = b_ or tr["bytes_per_launch"].get(ro["kernel"])
                     if b_:
                         ro["traffic"] = b_
                         ro["traffic_source"] = tr.get("source", "profiles/")
@@ -1320,16 +1380,31 @@ def main():
             except Exception as e:
                 out["step_api"] = {"error": str(e)[:300]}
         print(json.dumps(out), flush=True)
+    # device objects go before their contexts, contexts before the interpreter's own finalisation (no exit handler has to guess an order)
+    ring = raw = feats = ll = d_wave = None
+    slices[:] = []
+    for obj in (locals().get("gmm_m"), locals().get("mf_m"), gmm, mf, post, locals().get("graph")):
+        try:
+            if obj is not None:
+                obj.close()
+        except Exception:
+            pass
+    torch.cuda.synchronize(dev)
+    for c_ in (ctx, ctx_full):
+        try:
+            c_.close()
+        except Exception:
+            pass
     if world > 1:
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
     main()
-    # The line is out.  Leave without the interpreter's and the libraries' exit handlers: torch, the HIP runtime and this package's
-    # libraries tear down device state in no defined order at exit (seen once in r02: a GPU memory fault after the last output line
-    # of an otherwise complete run), and nothing of this process is needed any more.
+    # A normal exit: main() has closed its decoders, contexts and device objects in order.  (Round 2 left here with os._exit(0) after one
+    # run of an earlier build had ended with a GPU memory fault AFTER its last output line; with the explicit tear-down at the end of
+    # main() the soft exit ran clean in every run since -- VBH_BENCH_HARD_EXIT=1 brings the old behaviour back for comparison.)
     sys.stdout.flush()
     sys.stderr.flush()
-    if not os.environ.get("VBH_BENCH_SOFT_EXIT"):      # (a profiler writes its files from an exit handler: tools/profile_bench.sh sets this)
+    if os.environ.get("VBH_BENCH_HARD_EXIT"):
         os._exit(0)

@@ -115,6 +115,9 @@ int vbh_mfcc_compute(vbh_mfcc *m, const void *d_wave, int wave_is_int16,
  * parity tests use dither = 0.  The noise is a pure function of (seed, first_utt_index + position of the utterance in the
  * call, frame, sample), so a job gets the same features however it is cut into calls.  Defaults: a fixed seed, index 0. */
 int vbh_mfcc_set_dither_stream(vbh_mfcc *m, uint64_t seed, int64_t first_utt_index);
+/* ... or, for the NEXT vbh_mfcc_compute call only, an explicit stream index per utterance (e.g. a hash of the utterance's name: the noise
+ * then does not depend on which job the utterance is in, nor on the order or number of the jobs) */
+int vbh_mfcc_set_dither_ids(vbh_mfcc *m, const int64_t *h_ids, int32_t n);
 
 /* ------------------------------------------------------------------ feature post-processing
  * replaces the apply-cmvn | add-deltas | [splice-feats | transform-feats final.mat] |
@@ -163,13 +166,14 @@ int32_t vbh_gmm_dim(const vbh_gmm *g);
 int vbh_gmm_get_gconsts(const vbh_gmm *g, float *h_gconsts);   /* [G] as computed at create */
 /* How the LogSumExp over a pdf's Gaussians is evaluated (K/matrix/kaldi-vector.cc:757-775: the maximum, then the sum of
  * exp(x - max) over the terms not below max + log(FLT_EPSILON), accumulated in double, max + log(sum)):
- *   VBH_LSE_FAST   (default) the same two passes and cutoff, f32 sum, hardware exp2/log2: within 1e-5 of STRICT;
- *   VBH_LSE_STRICT the reference's arithmetic: expf of the f32 difference, f64 sum, max + log(sum) in f64, rounded once;
- *   VBH_LSE_ONLINE round 2's single pass (running maximum + rescaled sum, no cutoff): measurement only.
- * The environment variable VBH_GMM_LSE=strict|fast|online sets the mode of models created afterwards. */
+ *   VBH_LSE_FAST    (default) one pass, running maximum + rescaled f32 sum, one hardware exp per Gaussian, no cutoff;
+ *   VBH_LSE_STRICT  the reference's arithmetic: two passes with its cutoff, expf, f64 sum, max + log(sum) in f64, rounded once;
+ *   VBH_LSE_TWOPASS the strict mode's two passes and cutoff in f32 with the hardware functions (measurement only: slower).
+ * All three are within 1e-6 relative of the reference's gmm-compute-likes on its own features (tests/test_gpu_e2e.py).
+ * The environment variable VBH_GMM_LSE=strict|twopass sets the mode of models created afterwards. */
 #define VBH_LSE_FAST 0
 #define VBH_LSE_STRICT 1
-#define VBH_LSE_ONLINE 2
+#define VBH_LSE_TWOPASS 2
 int vbh_gmm_set_lse_mode(vbh_gmm *g, int32_t mode);
 /* d_feats [T x dim] -> d_loglikes [T x num_pdfs] (unscaled log-likelihoods) */
 int vbh_gmm_loglikes(vbh_gmm *g, const float *d_feats, int64_t T, float *d_loglikes);

@@ -86,7 +86,7 @@ def test_feature_pipeline_vs_reference_programs(host, tmp_path):
     for k in want:
         assert mine[k].shape == want[k].shape
         if len(want[k]):
-            np.testing.assert_allclose(mine[k], want[k], atol=2e-3, rtol=1e-5)
+            np.testing.assert_allclose(mine[k], want[k], atol=1e-3, rtol=1e-5)
     # --- compute-cmvn-stats --spk2utt | apply-cmvn --utt2spk | add-deltas | transform-feats --utt2spk
     # (on the four real utterances: the reference's apply-cmvn aborts on the 0 x 0 matrix of the short one)
     write_wavs(d, waves[:4])
@@ -290,7 +290,7 @@ def test_compute_mfcc_feats_with_segments(host, tmp_path):
     for k, w in cuts.items():
         ref_ = vbo.mfcc(w.astype(np.float32), vbo.mfcc_opts())
         assert got[k].shape == ref_.shape, k
-        np.testing.assert_allclose(got[k], ref_, atol=2e-3, rtol=1e-5)
+        np.testing.assert_allclose(got[k], ref_, atol=1e-3, rtol=1e-5)
     if have_ref("extract-segments") and have_ref("compute-mfcc-feats"):
         ref("extract-segments", "scp:%s" % (d / "wav.scp"), str(d / "segments"), "ark:%s" % (d / "r_seg_wav.ark"))
         ref("compute-mfcc-feats", "--dither=0", "ark:%s" % (d / "r_seg_wav.ark"), "ark:%s" % (d / "r_seg.ark"))
@@ -298,7 +298,7 @@ def test_compute_mfcc_feats_with_segments(host, tmp_path):
         assert list(want) == list(got)
         for k in want:
             assert want[k].shape == got[k].shape
-            np.testing.assert_allclose(got[k], want[k], atol=2e-3, rtol=1e-5)
+            np.testing.assert_allclose(got[k], want[k], atol=1e-3, rtol=1e-5)
 
 
 def test_compute_mfcc_feats_with_vtln_map(host, tmp_path):
@@ -331,7 +331,7 @@ def test_compute_mfcc_feats_with_vtln_map(host, tmp_path):
     for got, warps in ((a, [0.9, 0.9, 1.1, 1.1]), (b, [0.85, 0.95, 1.0, 1.05, 1.2])):
         for i, wv in enumerate(warps):
             want = vbo.mfcc(waves[i].astype(np.float32), o, vtln_warp=wv)
-            np.testing.assert_allclose(got["utt%02d" % i], want, atol=2e-3, rtol=1e-5)
+            np.testing.assert_allclose(got["utt%02d" % i], want, atol=1e-3, rtol=1e-5)
     assert np.abs(a["utt00"] - b["utt02"][:1].mean()).max() > 0.1      # (the warp does change the features)
     assert np.abs(a["utt02"] - vbo.mfcc(waves[2].astype(np.float32), o)).max() > 0.05
     # --utt2spk without --vtln-map is an error, as upstream
@@ -342,4 +342,4 @@ def test_compute_mfcc_feats_with_vtln_map(host, tmp_path):
         want = read_fm_ark(d / "r.ark")
         assert list(want) == list(a)
         for k in want:
-            np.testing.assert_allclose(a[k], want[k], atol=2e-3, rtol=1e-5)
+            np.testing.assert_allclose(a[k], want[k], atol=1e-3, rtol=1e-5)

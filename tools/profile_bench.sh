@@ -4,7 +4,6 @@
 # The PCM of the workload is synthesised once by an unprofiled run (--save-waves) and read back by the profiled ones: the
 # counter passes do not survive torch's own kernels (SIGSEGV in the profiler right after start-up, r02).
 cd /tmp && export TMPDIR=/tmp
-export VBH_BENCH_SOFT_EXIT=1      # bench.py normally leaves with os._exit: rocprofv3 writes its output from an exit handler
 R=$GRAFT_REPO_ROOT; tag=$1
 python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-step-api --no-determinize --save-waves /tmp/vb_waves.npy > $R/gpurun_out/prof_${tag}_save.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag} -- python3 $R/bench.py --no-cpu-baseline --no-step-api --load-waves /tmp/vb_waves.npy > $R/gpurun_out/prof_${tag}_bench.log 2>&1

@@ -35,19 +35,25 @@ def short(k):
     return re.split(r"[<(]", k)[0]
 
 
-rows, per = [], {}
+rows, per, per_max = [], {}, {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     files = glob.glob(os.path.join(G, "pmc_%s_%s" % (tag, c), "**", "*_counter_collection.csv"), recursive=True)
     if not files:
         continue
     tot, n = defaultdict(float), defaultdict(set)
+    by_dispatch = defaultdict(float)
     for r in csv.DictReader(open(files[0])):
         if r["Counter_Name"] != c:
             continue
         k = short(r["Kernel_Name"])
         tot[k] += float(r["Counter_Value"])
         n[k].add(r["Dispatch_Id"])
+        by_dispatch[(k, r["Dispatch_Id"])] += float(r["Counter_Value"])
     per[c] = {}
+    mx = defaultdict(float)
+    for (k, _d), v in by_dispatch.items():
+        mx[k] = max(mx[k], v)
+    per_max[c] = {k: v * 1024.0 for k, v in mx.items()}
     for k in tot:
         rows.append((c, k, len(n[k]), tot[k], tot[k] / len(n[k])))
         per[c][k] = tot[k] / len(n[k]) * 1024.0
@@ -62,6 +68,8 @@ if rows:
            "note": "raw counter values x 1024 B; MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced streaming reads by 2x "
                    "and is uncalibrated for scattered access",
            "bytes_per_launch": {k: fe.get(k, 0.0) + wr.get(k, 0.0) for k in set(fe) | set(wr)},
+           # the largest launch of every kernel (the front-end kernels also run on the 64-utterance training batches: their mean says little)
+           "bytes_of_largest_launch": {k: per_max.get("FETCH_SIZE", {}).get(k, 0.0) + per_max.get("WRITE_SIZE", {}).get(k, 0.0) for k in set(fe) | set(wr)},
            "fetch_bytes_per_launch": fe, "write_bytes_per_launch": wr}
     json.dump(out, open(os.path.join(P, name + "_pmc_traffic.json"), "w"), indent=1)
     print("traffic: decode_kernel %.1f GB/launch" % (out["bytes_per_launch"].get("decode_kernel", 0) / 1e9))

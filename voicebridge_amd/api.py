@@ -208,7 +208,7 @@ class FeaturePipeline:
 class DiagGmm:
     """AmDiagGmm scored for every pdf of every frame (vbh_gmm_*)."""
 
-    LSE_MODES = {"fast": 0, "strict": 1, "online": 2}      # VBH_LSE_* of include/voicebridge_hip.h
+    LSE_MODES = {"fast": 0, "strict": 1, "twopass": 2}      # VBH_LSE_* of include/voicebridge_hip.h
 
     def __init__(self, ctx, pdf_offsets, weights, means_invvars, inv_vars, lse=None):
         self.ctx, self.lib = ctx, ctx.lib
@@ -225,7 +225,7 @@ class DiagGmm:
             self.set_lse_mode(lse)
 
     def set_lse_mode(self, mode):
-        """'fast' (default), 'strict' (the reference's LogSumExp arithmetic: f64 sum, expf, log) or 'online' (round 2's form)"""
+        """'fast' (default), 'strict' (the reference's LogSumExp arithmetic: f64 sum, expf, log) or 'twopass' (its passes in f32)"""
         check(self.lib.vbh_gmm_set_lse_mode(self.h, self.LSE_MODES[mode]), "vbh_gmm_set_lse_mode")
 
     def gconsts(self):

@@ -234,10 +234,13 @@ struct RbMeta { unsigned mask; int p0; int np; int pad; };
 constexpr int LDP = 17;       // padded row of a wave's staging area: [64 frames][<= 16 pdfs]
 
 // LSE: how the LogSumExp over a pdf's Gaussians is evaluated (kaldi-vector.cc:757-775; vbh_gmm_set_lse_mode)
-//   VBH_LSE_FAST (default): the reference's two passes -- the pdf's maximum, then the sum of exp(x - max) over the terms not below
-//     max + log(FLT_EPSILON) -- with the sum in f32 and the hardware's exp2 / log2 (__expf, __logf): one exp per Gaussian;
-//   VBH_LSE_STRICT: the reference's arithmetic: expf of the f32 difference, the sum in f64, max + log(sum) in f64, rounded once;
-//   VBH_LSE_ONLINE: round 2's single pass (running maximum + rescaled sum, no cutoff, two exps per Gaussian), kept for A/B runs.
+//   VBH_LSE_FAST (default): one pass over the lane's registers -- running maximum m and sum of exp(x - m), rescaled when the maximum
+//     moves; of the two exponentials of the textbook update one is always exp(0), so ONE exp(-|x - m|) per Gaussian does it; no cutoff
+//     (the terms the reference drops, below max + log FLT_EPSILON, are below 1.2e-7 of the sum each); f32, hardware exp2 / log2;
+//   VBH_LSE_STRICT: the reference's arithmetic: two passes (the pdf's maximum, then the terms not below max + log FLT_EPSILON), expf of
+//     the f32 difference, the sum in f64, max + log(sum) in f64, rounded once;
+//   VBH_LSE_TWOPASS: the strict mode's two passes and cutoff in f32 with the hardware functions: measured 7 % slower than FAST
+//     (83.5 vs 77.2 ms per 3.07 M frames: the maxima wait in LDS between the passes), kept for A/B runs.
 template <int NC, int LSE>    // NC = Kpad / 8: a lane's strip of a row-block is NC float4 (4 k-steps each)
 __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
     const float *__restrict__ feats, long long T, int D, int P,
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
     // ---- LogSumExp per pdf (kaldi-vector.cc:757-775).  The pdf boundaries are wave-uniform (mask), so both passes are straight
     //      register loops with scalar branches; the maxima wait in the lane's own row of the staging area (one LDS word per pdf).
 #define VBH_ROW(r) ((((r) >> 2) & 1) ? v1[((r) & 3) + 4 * ((r) >> 3)] : v0[((r) & 3) + 4 * ((r) >> 3)])
-    if (LSE == VBH_LSE_ONLINE) {
+    if (LSE == VBH_LSE_FAST) {
       float m = -3.0e38f, sum = 0.0f;
       float *so = stage + lane * LDP;
       int q = 0;
@@ -329,9 +332,11 @@ __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
           q++;
           m = -3.0e38f; sum = 0.0f;
         }
-        const float m2 = fmaxf(m, x);
-        sum = sum * __expf(m - m2) + __expf(x - m2);
-        m = m2;
+        // sum' = sum exp(m - m') + exp(x - m') with m' = max(m, x): one of the two factors is exp(0) = 1
+        const float d = x - m;
+        const float e = __expf(-fabsf(d));
+        sum = d > 0.0f ? fmaf(sum, e, 1.0f) : sum + e;
+        m = fmaxf(m, x);
       }
       so[q] = sum > 0.0f ? m + __logf(sum) : -INFINITY;
     } else {
@@ -661,7 +666,7 @@ int vbh_gmm_create(vbh_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h
   }
   if (const char *e = getenv("VBH_GMM_LSE")) {
     if (g->rows && !strcmp(e, "strict")) g->lse_mode = VBH_LSE_STRICT;
-    else if (g->rows && !strcmp(e, "online")) g->lse_mode = VBH_LSE_ONLINE;
+    else if (g->rows && !strcmp(e, "twopass")) g->lse_mode = VBH_LSE_TWOPASS;
   }
   VBH_HIP(hipStreamSynchronize(s));
   const size_t a_floats = (size_t)g->Kpad * LDA + ((4 - (g->Kpad * LDA) % 4) % 4);
@@ -679,7 +684,7 @@ void vbh_gmm_destroy(vbh_gmm *g) {
 }
 int vbh_gmm_set_lse_mode(vbh_gmm *g, int32_t mode) {
   VBH_CHECK(g, "vbh_gmm_set_lse_mode: NULL model");
-  VBH_CHECK(mode == VBH_LSE_FAST || mode == VBH_LSE_STRICT || mode == VBH_LSE_ONLINE, "vbh_gmm_set_lse_mode: unknown mode %d", mode);
+  VBH_CHECK(mode == VBH_LSE_FAST || mode == VBH_LSE_STRICT || mode == VBH_LSE_TWOPASS, "vbh_gmm_set_lse_mode: unknown mode %d", mode);
   VBH_CHECK(g->rows || mode == VBH_LSE_FAST, "vbh_gmm_set_lse_mode: the tile kernel (VBH_GMM_V1) has the default mode only");
   g->lse_mode = mode;
   return 0;
@@ -829,7 +834,7 @@ static int gmm_launch_rows(vbh_gmm *g, const float *d_feats, long long T, int n_
 #define VBH_GMM_LAUNCH(N)                                                                              \
   case N:                                                                                              \
     if (g->lse_mode == VBH_LSE_STRICT) VBH_GMM_LAUNCH_M(N, VBH_LSE_STRICT)                             \
-    else if (g->lse_mode == VBH_LSE_ONLINE) VBH_GMM_LAUNCH_M(N, VBH_LSE_ONLINE)                        \
+    else if (g->lse_mode == VBH_LSE_TWOPASS) VBH_GMM_LAUNCH_M(N, VBH_LSE_TWOPASS)                      \
     else VBH_GMM_LAUNCH_M(N, VBH_LSE_FAST)                                                             \
     break;
   switch (g->Kpad / 8) {

@@ -50,6 +50,7 @@ struct MfccParams {
   float dither;                     // 0 = off
   unsigned seed_lo, seed_hi;        // dither stream
   long long utt_base;               // job-wide index of the call's first utterance (noise independent of batching)
+  const long long *utt_ids;         // or: the stream index of every utterance of the call (vbh_mfcc_set_dither_ids), NULL = utt_base + position
 };
 
 struct vbh_mfcc_tables {
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256) void mfcc512_kernel(MfccParams p, vbh_mfcc_tab
           const int pr = lane + 64 * k;
           if (2 * pr < flen) {
             float n0, n1;
-            dither_pair(p, p.utt_base + utt, f, pr, n0, n1);
+            dither_pair(p, (p.utt_ids ? p.utt_ids[utt] : p.utt_base + utt), f, pr, n0, n1);
             xe[k] += p.dither * n0;
             if (2 * pr + 1 < flen) xo[k] += p.dither * n1;
           }
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccParams p, vbh_mfcc_tables
             v = load_sample<kInt16>(wave, w0 + s);
             if (p.dither != 0.0f) {
               float n0, n1;
-              dither_pair(p, p.utt_base + utt, f, i >> 1, n0, n1);
+              dither_pair(p, (p.utt_ids ? p.utt_ids[utt] : p.utt_base + utt), f, i >> 1, n0, n1);
               v += p.dither * ((i & 1) ? n1 : n0);
             }
             part += v;
@@ -563,6 +564,7 @@ struct vbh_mfcc {
   DevBuf<long long> d_wave_off, d_frame_off;
   DevBuf<int> d_chunk_utt, d_chunk_f0;
   size_t lds_bytes;
+  std::vector<int64_t> dither_ids;   // vbh_mfcc_set_dither_ids: stream indices of the next call's utterances
 };
 
 // ---- option helpers (feature-window.h:92-101, feature-window.cc:41-87)
@@ -711,7 +713,7 @@ int vbh_mfcc_create(vbh_ctx *ctx, const vbh_mfcc_opts *o, float vtln_warp, vbh_m
   p.use_lifter = o->cepstral_lifter != 0.0f; p.preemph = o->preemph_coeff;
   p.energy_floor = o->energy_floor; p.log_energy_floor = o->energy_floor > 0.0f ? logf(o->energy_floor) : 0.0f;
   p.melw_total = (int)melw.size();
-  p.dither = o->dither; p.seed_lo = 0x2545F491u; p.seed_hi = 0x4F6CDD1Du; p.utt_base = 0;
+  p.dither = o->dither; p.seed_lo = 0x2545F491u; p.seed_hi = 0x4F6CDD1Du; p.utt_base = 0; p.utt_ids = nullptr;
   hipStream_t s = ctx->stream;
   m->fast = N == kFastN && flen <= kFastN && nb <= 32 && o->num_ceps <= 16 && !getenv("VBH_MFCC_GENERIC");
   if (m->fast) {
@@ -767,6 +769,12 @@ int vbh_mfcc_set_dither_stream(vbh_mfcc *m, uint64_t seed, int64_t first_utt_ind
   return 0;
 }
 
+int vbh_mfcc_set_dither_ids(vbh_mfcc *m, const int64_t *h_ids, int32_t n) {
+  VBH_CHECK(m && (h_ids || n == 0) && n >= 0, "vbh_mfcc_set_dither_ids: bad argument");
+  m->dither_ids.assign(h_ids, h_ids + n);
+  return 0;
+}
+
 int vbh_mfcc_compute(vbh_mfcc *m, const void *d_wave, int wave_is_int16, const int64_t *h_wave_offsets,
                      int32_t n_utt, float *d_feats, int64_t *h_frame_offsets) {
   VBH_CHECK(m && h_wave_offsets && h_frame_offsets, "vbh_mfcc_compute: NULL argument");
@@ -785,9 +793,18 @@ int vbh_mfcc_compute(vbh_mfcc *m, const void *d_wave, int wave_is_int16, const i
   if (cu.empty()) return 0;
   VBH_CHECK(d_wave && d_feats, "vbh_mfcc_compute: NULL device buffer");
   hipStream_t s = m->ctx->stream;
+  // the stream indices of vbh_mfcc_set_dither_ids serve the one call they were given for
+  std::vector<long long> ids;
+  if (!m->dither_ids.empty()) {
+    VBH_CHECK((int)m->dither_ids.size() == n_utt, "vbh_mfcc_compute: %zu dither stream indices for %d utterances", m->dither_ids.size(), n_utt);
+    ids.assign(m->dither_ids.begin(), m->dither_ids.end());
+    m->dither_ids.clear();
+  }
   vbh_arena *ar = vbh_arena_begin(m->ctx, vbh_arena_need(woff.size() * 8) + vbh_arena_need(foff.size() * 8) +
-                                              vbh_arena_need(cu.size() * 4) + vbh_arena_need(cf.size() * 4));
+                                              vbh_arena_need(cu.size() * 4) + vbh_arena_need(cf.size() * 4) + vbh_arena_need(ids.size() * 8 + 8));
   if (!ar) return -1;
+  MfccParams p_call = m->p;
+  p_call.utt_ids = ids.empty() ? nullptr : vbh_arena_put(ar, ids.data(), ids.size());
   const long long *d_wave_off = vbh_arena_put(ar, woff.data(), woff.size()), *d_frame_off = vbh_arena_put(ar, foff.data(), foff.size());
   const int *d_chunk_utt = vbh_arena_put(ar, cu.data(), cu.size()), *d_chunk_f0 = vbh_arena_put(ar, cf.data(), cf.size());
   if (vbh_arena_commit(m->ctx, ar)) return -1;
@@ -799,7 +816,7 @@ int vbh_mfcc_compute(vbh_mfcc *m, const void *d_wave, int wave_is_int16, const i
     {                                                                                                                                   \
       VBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc512_kernel<I16, DIT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)m->fast_lds));                                                                                   \
-      hipLaunchKernelGGL((mfcc512_kernel<I16, DIT>), dim3(grid), dim3(256), m->fast_lds, s, m->p, t, ft, d_wave,                        \
+      hipLaunchKernelGGL((mfcc512_kernel<I16, DIT>), dim3(grid), dim3(256), m->fast_lds, s, p_call, t, ft, d_wave,                        \
                          d_wave_off, d_frame_off, d_chunk_utt, d_chunk_f0, n_chunks, d_feats);                                          \
     }
     const bool dit = m->p.dither != 0.0f;
@@ -809,11 +826,11 @@ int vbh_mfcc_compute(vbh_mfcc *m, const void *d_wave, int wave_is_int16, const i
 #undef VBH_LAUNCH_FAST
   } else if (wave_is_int16) {
     VBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes));
-    hipLaunchKernelGGL(mfcc_kernel<true>, dim3(grid), dim3(256), m->lds_bytes, s, m->p, t, d_wave, d_wave_off,
+    hipLaunchKernelGGL(mfcc_kernel<true>, dim3(grid), dim3(256), m->lds_bytes, s, p_call, t, d_wave, d_wave_off,
                        d_frame_off, d_chunk_utt, d_chunk_f0, n_chunks, d_feats);
   } else {
     VBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes));
-    hipLaunchKernelGGL(mfcc_kernel<false>, dim3(grid), dim3(256), m->lds_bytes, s, m->p, t, d_wave, d_wave_off,
+    hipLaunchKernelGGL(mfcc_kernel<false>, dim3(grid), dim3(256), m->lds_bytes, s, p_call, t, d_wave, d_wave_off,
                        d_frame_off, d_chunk_utt, d_chunk_f0, n_chunks, d_feats);
   }
   VBH_HIP(hipGetLastError());

@@ -451,8 +451,18 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
         size_t g1 = g0 + 1;
         while (g1 < keys.size() && warps[g1] == warps[g0]) g1++;
         vbh_mfcc *mf = banks.Get(warps[g0]);
-        if (o.dither != 0.0f)
-          Check(vbh_mfcc_set_dither_stream(mf, dither_seed ? dither_seed : 0x4F6CDD1D2545F491ull, (int64_t)(num_success_batches_base + g0)), "vbh_mfcc_set_dither_stream");
+        if (o.dither != 0.0f) {
+          // the noise of an utterance is keyed by a hash of its NAME (FNV-1a), not by its position in the table: the same utterance gets the
+          // same noise whatever job it is in, and no two jobs of MakeMfcc share a noise sequence
+          Check(vbh_mfcc_set_dither_stream(mf, dither_seed ? dither_seed : 0x4F6CDD1D2545F491ull, 0), "vbh_mfcc_set_dither_stream");
+          std::vector<int64_t> ids;
+          for (size_t u = g0; u < g1; u++) {
+            uint64_t h = 1469598103934665603ull;
+            for (unsigned char c : keys[u]) { h ^= c; h *= 1099511628211ull; }
+            ids.push_back((int64_t)(h & 0x7FFFFFFFFFFFFFFFull));
+          }
+          Check(vbh_mfcc_set_dither_ids(mf, ids.data(), (int32_t)ids.size()), "vbh_mfcc_set_dither_ids");
+        }
         std::vector<int64_t> fo(g1 - g0 + 1);
         Check(vbh_mfcc_compute(mf, d_wave.p, 0, woff.data() + g0, (int32_t)(g1 - g0), (float *)d_feats.p + foff[g0] * o.num_ceps, fo.data()), "vbh_mfcc_compute");
         for (size_t u = g0; u < g1; u++) foff[u + 1] = foff[g0] + fo[u - g0 + 1];
@@ -720,7 +730,12 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
              // transform-feats, transform-feats(fMLLR) and this program (VB/scr/steps/decode_gmm.cpp:201-293).  With --fe-cmvn the
              // feature rspecifier names the RAW features (e.g. the 13-dim MFCCs of feats.scp).
              "fe-cmvn", "fe-utt2spk", "fe-norm-vars", "fe-type", "fe-delta-order", "fe-delta-window", "fe-left-context", "fe-right-context",
-             "fe-lda", "fe-trans"});
+             "fe-lda", "fe-trans",
+             // --job-of-utt=<file of "utterance job" lines>: the table holds the utterances of SEVERAL jobs of a step, searched as one batch
+             // (one persistent grid over all of them); every "JOB" in the three wspecifiers is replaced by the utterance's job number, so
+             // that the step still leaves lat.JOB / w.JOB per job, in table order (VB/scr/steps/decode_gmm.cpp:300-324 runs the jobs side by
+             // side; on one GPU one grid of all their utterances fills the chip better than nj grids that queue behind each other)
+             "job-of-utt"});
     po.Parse(argc, argv);
     if (po.args.size() < 4 || po.args.size() > 6) throw ApiError("wrong arguments.");
     vbh_decode_cfg cfg;
@@ -782,12 +797,39 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     // ---- fused front end (extension, device_feats.h)
     FrontEnd fe;
     fe.Parse(po);
-    vbio::LatticeWriter lat_writer;
-    vbio::CompactLatticeWriter clat_writer;
-    if (want_lat) { if (determinize) clat_writer.Open(lat_wspec); else lat_writer.Open(lat_wspec); }
-    vbio::IntVectorWriter words_writer, ali_writer;
-    if (po.args.size() >= 5 && !po.args[4].empty()) words_writer.Open(po.args[4]);
-    if (po.args.size() >= 6 && !po.args[5].empty()) ali_writer.Open(po.args[5]);
+    // the writers of an utterance's job (one set, job 0, without --job-of-utt)
+    struct JobOut { vbio::LatticeWriter lat; vbio::CompactLatticeWriter clat; vbio::IntVectorWriter words, ali; };
+    std::map<std::string, int> job_of_utt;
+    if (po.Has("job-of-utt")) {
+      std::ifstream f(po.Str("job-of-utt", ""));
+      if (!f) throw ApiError("cannot open " + po.Str("job-of-utt", ""));
+      std::string k; int j;
+      while (f >> k >> j) job_of_utt[k] = j;
+    }
+    std::map<int, std::unique_ptr<JobOut>> outs;
+    auto for_job = [](std::string spec, int job) {
+      if (job > 0) for (size_t q = spec.find("JOB"); q != std::string::npos; q = spec.find("JOB", q)) { const std::string n = std::to_string(job); spec.replace(q, 3, n); q += n.size(); }
+      return spec;
+    };
+    auto out_of_job = [&](int job) -> JobOut & {
+      std::unique_ptr<JobOut> &o = outs[job];
+      if (!o) {
+        o.reset(new JobOut());
+        if (want_lat) { if (determinize) o->clat.Open(for_job(lat_wspec, job)); else o->lat.Open(for_job(lat_wspec, job)); }
+        if (po.args.size() >= 5 && !po.args[4].empty()) o->words.Open(for_job(po.args[4], job));
+        if (po.args.size() >= 6 && !po.args[5].empty()) o->ali.Open(for_job(po.args[5], job));
+      }
+      return *o;
+    };
+    auto out_of = [&](const std::string &utt) -> JobOut & {
+      if (job_of_utt.empty()) return out_of_job(0);
+      const auto it = job_of_utt.find(utt);
+      if (it == job_of_utt.end()) throw ApiError("--job-of-utt names no job for utterance " + utt);
+      return out_of_job(it->second);
+    };
+    // (the files exist even when no utterance of a job is decoded, as the reference's do)
+    if (job_of_utt.empty()) (void)out_of_job(0);
+    else for (const auto &kv : job_of_utt) (void)out_of_job(kv.second);
 
     const int batch_utts = (int)po.Num("decode-batch", 256);
     // the cached workspace serves this call when its capacities cover the search configuration (vbh_decoder_set_cfg: beams and
@@ -897,13 +939,14 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
           else { log.os() << "WARNING (gmm-latgen-faster) Not producing output for utterance " << utt << " since no final-state reached and --allow-partial=false.\n"; num_err++; continue; }
         }
         std::vector<int32_t> words(L.words, L.words + L.num_words), ali(L.ali, L.ali + L.num_ali);
-        if (words_writer.IsOpen()) words_writer.Write(utt, words);
-        if (ali_writer.IsOpen()) ali_writer.Write(utt, ali);
+        JobOut &jo = out_of(utt);
+        if (jo.words.IsOpen()) jo.words.Write(utt, words);
+        if (jo.ali.IsOpen()) jo.ali.Write(utt, ali);
         const double like = -((double)L.best_graph + (double)L.best_acoustic);
         if (want_lat) {
           if (!det_err[u].empty()) throw ApiError("lattice of " + utt + ": " + det_err[u]);
           if (!det_ok[u]) log.os() << "WARNING (gmm-latgen-faster) Determinization finished earlier than the beam for utterance " << utt << "\n";
-          if (determinize) clat_writer.WriteSerialized(utt, entry[u]); else lat_writer.WriteSerialized(utt, entry[u]);
+          if (determinize) jo.clat.WriteSerialized(utt, entry[u]); else jo.lat.WriteSerialized(utt, entry[u]);
           std::string().swap(entry[u]);
         }
         log.os() << "LOG (gmm-latgen-faster) Log-like per frame for utterance " << utt << " is " << (like / (L.num_ali ? L.num_ali : 1))

@@ -114,6 +114,11 @@ class JobWorkers {
 };
 std::mutex g_workers_mu;            // one step at a time uses the workers
 JobWorkers *g_workers = nullptr;
+// what the last ForEachJob did: the device of every job (in job order) and the worker thread that ran it (-1: the calling thread).
+// The fan-out is ONE code path whatever the list holds -- worker t calls vb_set_device(devs[t]) and runs jobs t+1, t+1+nt, ... --
+// so a list that names one GPU twice exercises everything a two-GPU list does except the device index (vb_last_step_jobs, tests)
+std::mutex g_last_jobs_mu;
+std::vector<int> g_last_job_device, g_last_job_worker;
 thread_local bool g_on_job_thread = false;
 
 // fn(j) for j = 1..nj; an exception of any job is rethrown (the first one) after all threads have finished
@@ -122,6 +127,7 @@ void ForEachJob(int nj, F fn) {
   const std::vector<int> devs = StepDevices();
   if (devs.size() <= 1 || nj <= 1 || g_on_job_thread) {
     if (devs.size() == 1 && !g_on_job_thread) vb_set_device(devs[0]);
+    if (!g_on_job_thread) { std::lock_guard<std::mutex> lk(g_last_jobs_mu); g_last_job_device.assign((size_t)nj, vb_get_device()); g_last_job_worker.assign((size_t)nj, -1); }
     for (int j = 1; j <= nj; j++) fn(j);
     return;
   }
@@ -130,11 +136,15 @@ void ForEachJob(int nj, F fn) {
   if (!g_workers) g_workers = new JobWorkers(devs);
   const int nt = (int)std::min<size_t>(devs.size(), (size_t)nj);
   std::vector<std::string> errs(nt);
+  { std::lock_guard<std::mutex> lk2(g_last_jobs_mu); g_last_job_device.assign((size_t)nj, -1); g_last_job_worker.assign((size_t)nj, -1); }
   const std::function<void(int)> body = [&](int t) {
     g_on_job_thread = true;
     try {
       StepScope scope;                     // (VB_RELEASE_DEVICE_CACHE=1: the thread's device cache is released when its last job is done)
-      for (int j = 1 + t; j <= nj; j += nt) fn(j);
+      for (int j = 1 + t; j <= nj; j += nt) {
+        { std::lock_guard<std::mutex> lk2(g_last_jobs_mu); g_last_job_device[(size_t)j - 1] = vb_get_device(); g_last_job_worker[(size_t)j - 1] = t; }
+        fn(j);
+      }
     } catch (const std::exception &e) { errs[t] = e.what(); if (errs[t].empty()) errs[t] = "error"; }
     catch (...) { errs[t] = "error"; }
   };
@@ -417,7 +427,7 @@ namespace {
 // runs the jobs of its speaker-independent first pass inside its own per-job chains (no barrier between the passes: while one
 // job estimates its transforms on the host another is still searching).
 struct DecodeJobs {
-  std::string graph_dir, decode_dir, srcdir, sdata, model, trans_dir, trans_all, splice_opts, cmvn_opts, delta_opts;
+  std::string graph_dir, decode_dir, data_dir, srcdir, sdata, model, trans_dir, trans_all, splice_opts, cmvn_opts, delta_opts;
   bool use_trans = false, lda = false;
   int nj = 1, max_active = 7000;
   double beam = 13.0, lattice_beam = 6.0;
@@ -430,7 +440,7 @@ DecodeJobs PrepareDecode(const std::string &graph_dir, const std::string &data_d
   if (decode_mbr) throw StepError("MBR decoding (decode_mbr) is not part of this build");
   if (nj < 1) throw StepError("nj must be >= 1");
   DecodeJobs c;
-  c.graph_dir = graph_dir; c.decode_dir = decode_dir; c.trans_dir = trans_dir; c.nj = nj; c.acwt = acwt; c.max_active = max_active; c.beam = beam;
+  c.graph_dir = graph_dir; c.decode_dir = decode_dir; c.data_dir = data_dir; c.trans_dir = trans_dir; c.nj = nj; c.acwt = acwt; c.max_active = max_active; c.beam = beam;
   c.lattice_beam = lattice_beam;
   // fMLLR transforms of an earlier pass (decode_gmm.cpp:127-172): one archive per job when the job
   // counts agree, otherwise all of them joined (binary archives concatenate)
@@ -463,6 +473,79 @@ DecodeJobs PrepareDecode(const std::string &graph_dir, const std::string &data_d
   if (SplitData(data_dir, nj, false) < 0) throw StepError("SplitData failed: " + g_err);
   c.sdata = Join(data_dir, "split" + std::to_string(nj));
   return c;
+}
+
+// ---- the searches of ALL jobs of a step as one batch (opt-in: VB_STEP_COMBINED_SEARCH=1).  The reference runs its nj jobs side by side
+// on nj cores (VB/scr/steps/decode_gmm.cpp:300-324); a job here is a batch for a GPU, and nj grids of one GPU queue behind each other
+// and hold up the small kernels of the other jobs' host stages (fMLLR statistics, rescoring: 145 -> 400-540 ms and 176 -> 400-575 ms per
+// call in DecodeFmllr, r03).  With the option the search stage of a step whose jobs share one device is ONE call over the concatenated
+// feature tables (gmm-latgen-faster --job-of-utt: one persistent grid over all utterances) that still leaves lat.JOB / w.JOB per job,
+// and the host stages between the searches stay per job on the job threads.  Measured (r03, 1024 utterances, nj = 4, one MI355X): the
+// statistics calls do fall to 115-275 ms, but the step as a whole gets SLOWER -- Decode 1.42 -> 1.6-3.5 s, DecodeFmllr 3.6 -> 4.2 s: one
+// thread now uploads all features (224 ms instead of 4 x 54 ms side by side), allocates one 30 GB score matrix (hipMalloc of that size takes
+// 1-2 s) and determinizes / writes after the search instead of under the other jobs' searches.  Per-job searches on job threads stay the
+// default; the files are the same either way (tests/test_gpu_steps.py::test_job_threads_leave_the_same_files).
+bool CombinedSearch(int nj) {
+  if (nj <= 1 || !getenv("VB_STEP_COMBINED_SEARCH")) return false;
+  const std::vector<int> devs = StepDevices();
+  for (int d : devs) if (d != devs[0]) return false;
+  return true;
+}
+// work_dir/all_feats.scp (the jobs' feats.scp in job order) and work_dir/job_of_utt; returns the number of utterances
+size_t WriteCombinedTables(const std::string &sdata, int nj, const std::string &work_dir) {
+  std::vector<std::string> scp, jobs;
+  for (int j = 1; j <= nj; j++)
+    for (const auto &l : ReadLines(Join(Join(sdata, std::to_string(j)), "feats.scp"), false)) { scp.push_back(l); jobs.push_back(FirstField(l) + " " + std::to_string(j)); }
+  WriteLines(Join(work_dir, "all_feats.scp"), scp);
+  WriteLines(Join(work_dir, "job_of_utt"), jobs);
+  return scp.size();
+}
+// decode.JOB.log of a step whose searches ran as one batch
+void CombinedLogStubs(const std::string &log_dir, const std::string &stem, int nj, const std::string &all_log) {
+  for (int j = 1; j <= nj; j++) {
+    std::ofstream f(Join(log_dir, stem + "." + std::to_string(j) + ".log"), std::ios::binary | std::ios::app);
+    f << "LOG (" << stem << ") the utterances of the " << nj << " jobs of this step were searched as one batch on one GPU: see " << all_log << "\n";
+  }
+}
+
+void DecodeAllJobs(const DecodeJobs &c) {
+  const std::string log_dir = Join(c.decode_dir, "log"), all_log = Join(log_dir, "decode.all.log");
+  for (int j = 1; j <= c.nj; j++) unlink(Join(c.decode_dir, "lat." + std::to_string(j)).c_str());
+  if (WriteCombinedTables(c.sdata, c.nj, c.decode_dir) == 0) return;
+  std::ofstream log(all_log, std::ios::binary);
+  std::vector<std::string> g = {"gmm-latgen-faster", "--max-active=" + std::to_string(c.max_active), "--beam=" + std::to_string(c.beam),
+                                "--lattice-beam=" + std::to_string(c.lattice_beam), "--acoustic-scale=" + std::to_string(c.acwt),
+                                "--allow-partial=true", "--decode-batch=1024", "--job-of-utt=" + Join(c.decode_dir, "job_of_utt")};
+  for (const auto &o : FrontEndOptions(c.srcdir, c.data_dir, c.lda, c.cmvn_opts, c.delta_opts, c.splice_opts)) g.push_back(o);
+  std::string trans_all = c.trans_all;
+  if (c.use_trans) {
+    if (trans_all.empty()) {          // one archive per job: joined (binary archives concatenate)
+      trans_all = Join(c.decode_dir, "trans.all.ark");
+      std::ofstream out(trans_all, std::ios::binary);
+      for (int n = 1; n <= c.nj; n++) { std::ifstream in(Join(c.trans_dir, "trans." + std::to_string(n)), std::ios::binary); if (in) out << in.rdbuf(); }
+    }
+    g.push_back("--fe-trans=ark:" + trans_all);
+  }
+  const std::string symtab = Join(c.graph_dir, "words.txt");
+  if (Exists(symtab)) g.push_back("--word-symbol-table=" + symtab);
+  g.push_back(c.model); g.push_back(Join(c.graph_dir, "HCLG.fst")); g.push_back("scp:" + Join(c.decode_dir, "all_feats.scp"));
+  g.push_back("ark:" + Join(c.decode_dir, "lat.JOB")); g.push_back("ark,t:" + Join(c.decode_dir, "w.JOB"));
+  Argv a4(g);
+  const int rc = GmmLatgenFaster(a4.argc(), a4.argv(), log);
+  if (c.use_trans && c.trans_all.empty()) unlink(trans_all.c_str());
+  unlink(Join(c.decode_dir, "all_feats.scp").c_str()); unlink(Join(c.decode_dir, "job_of_utt").c_str());
+  if (rc < 0) throw StepError("gmm-latgen-faster failed, see " + all_log);
+  CombinedLogStubs(log_dir, "decode", c.nj, all_log);
+  if (Exists(symtab)) {
+    const std::map<int, std::string> sym = ReadSymbolTable(symtab);
+    for (int j = 1; j <= c.nj; j++) {
+      const std::string J = std::to_string(j);
+      if (!Exists(Join(c.decode_dir, "w." + J))) continue;
+      std::vector<std::string> out;
+      for (const auto &l : ReadLines(Join(c.decode_dir, "w." + J), false)) out.push_back(Int2SymLine(sym, l));
+      WriteLines(Join(c.decode_dir, "transcription" + J + ".trn"), out);
+    }
+  }
 }
 
 void DecodeJob(const DecodeJobs &c, int j) {
@@ -505,7 +588,8 @@ int Decode(const std::string &graph_dir, const std::string &data_dir, const std:
   (void)stage;
   const int rc_decode = Run([&] {
     const DecodeJobs c = PrepareDecode(graph_dir, data_dir, decode_dir, model_in, trans_dir, iter, nj, acwt, max_active, beam, lattice_beam, decode_mbr);
-    ForEachJob(nj, [&](int j) { DecodeJob(c, j); });
+    if (CombinedSearch(nj)) { const std::vector<int> devs = StepDevices(); vb_set_device(devs[0]); DecodeAllJobs(c); }
+    else ForEachJob(nj, [&](int j) { DecodeJob(c, j); });
     FinishDecode(c);
   });
   if (rc_decode != 0 || skip_scoring) return rc_decode;
@@ -576,61 +660,110 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
       if (laps) fprintf(stderr, "DecodeFmllr %-28s %8.1f ms\n", what, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
       if (r < 0 || (r != 0 && !none_ok)) throw StepError(std::string(what) + " failed (return code " + std::to_string(r) + "), see " + Join(dir, "log"));
     };
-    ForEachJob(nj, [&](int j) {
-      const std::string J = std::to_string(j), dsn = Join(sdata, J);
-      if (run_si) {
-        try { DecodeJob(si_jobs, j); }
-        catch (const std::exception &e) { throw StepError(std::string("First pass speaker-independent decoding failed: ") + e.what()); }
+    // One job's part of the recipe in three pieces: `search` = the two gmm-latgen-faster passes, `before` = what lies between them
+    // (first fMLLR estimate), `after` = everything behind the main search.  Jobs on distinct GPUs run the pieces back to back per job,
+    // side by side (no barrier between the passes: while one job estimates its transforms on the host another is still searching); jobs
+    // that share ONE GPU run the two searches as one batch over all jobs' utterances each (CombinedSearch) and the host pieces side
+    // by side on the job threads -- no search grid of one job holds up the statistics / rescoring kernels of another.
+    const bool combined = CombinedSearch(nj);
+    auto job_files = [&](int j, std::string *J, std::string *dsn) { *J = std::to_string(j); *dsn = Join(sdata, *J); return !ReadLines(Join(*dsn, "feats.scp"), false).empty(); };
+    auto fe_of = [&](const std::string &dsn) { return FrontEndOptions(srcdir, dsn, lda, cmvn_opts, delta_opts, splice_opts); };
+    auto with_fe = [&](const std::vector<std::string> &fe, std::vector<std::string> a, const std::string &trans_file) {
+      std::vector<std::string> r{a[0]};
+      for (const auto &o : fe) r.push_back(o);
+      if (!trans_file.empty()) r.push_back("--fe-trans=ark:" + trans_file);
+      r.insert(r.end(), a.begin() + 1, a.end());
+      return r;
+    };
+    auto open_log = [&](const std::string &J, std::ofstream *log) { log->open(Join(Join(dir, "log"), "fmllr." + J + ".log"), std::ios::binary | std::ios::app); };
+    std::vector<std::string> main_opts = {"gmm-latgen-faster", "--max-active=" + std::to_string(max_active), "--beam=" + std::to_string(beam),
+                                          "--lattice-beam=" + std::to_string(lattice_beam), acw, "--determinize-lattice=false", "--allow-partial=true"};
+    if (Exists(symtab)) main_opts.push_back("--word-symbol-table=" + symtab);
+    // ---- the features of every program below: the job's raw feats.scp behind the fused front end (the reference writes
+    //      sifeats / transform_pass1feats / final feature archives: decode_fmllr.cpp:275-311, 390-402, 491-500, 568-580); the raw
+    //      rows are uploaded once per job (the thread's table cache) and the transforms applied on the device
+    auto before = [&](int j) {      // first-pass fMLLR from the SI lattices (:314-388)
+      std::string J, dsn;
+      if (!job_files(j, &J, &dsn) || stage > 1) return;
+      std::ofstream log; open_log(J, &log);
+      const std::string raw = "scp:" + Join(dsn, "feats.scp"), pre_trans = Join(dir, "pre_trans." + J), spk2utt = "--spk2utt=ark:" + Join(dsn, "spk2utt");
+      const std::string t_post = Join(dsn, "post.temp"), t_wsp = Join(dsn, "wsp.temp");
+      run("lattice-to-post", LatticeToPost, {"lattice-to-post", acw, "ark:" + Join(si_dir, "lat." + J), "ark:" + t_post}, log);
+      run("weight-silence-post", WeightSilencePost, {"weight-silence-post", std::to_string(silence_weight), silphonelist, alignment_model, "ark:" + t_post, "ark:" + t_wsp}, log);
+      // the reference pipes gmm-post-to-gpost (alignment model) into gmm-est-fmllr-gpost (adapt model); here the Gaussian
+      // posteriors never leave the GPU: gmm-est-fmllr takes them from --ali-model and the statistics from the adapt model
+      run("gmm-est-fmllr", GmmEstFmllr, with_fe(fe_of(dsn), {"gmm-est-fmllr", "--fmllr-update-type=" + fmllr_update_type, spk2utt, "--ali-model=" + alignment_model, adapt_model,
+                                                           raw, "ark:" + t_wsp, "ark:" + pre_trans}, ""), log);
+      unlink(t_post.c_str()); unlink(t_wsp.c_str());
+    };
+    auto main_search = [&](int j) {      // main search on the first-pass features (:390-489), one job
+      std::string J, dsn;
+      if (!job_files(j, &J, &dsn) || stage > 2) return;
+      std::ofstream log; open_log(J, &log);
+      std::vector<std::string> g = main_opts;
+      g.insert(g.end(), {adapt_model, Join(graphdir, "HCLG.fst"), "scp:" + Join(dsn, "feats.scp"), "ark:" + Join(dir, "lat.tmp." + J)});
+      run("gmm-latgen-faster", GmmLatgenFaster, with_fe(fe_of(dsn), g, Join(dir, "pre_trans." + J)), log);
+    };
+    auto main_search_all = [&]() {       // ... all jobs as one batch
+      if (stage > 2 || WriteCombinedTables(sdata, nj, dir) == 0) return;
+      const std::string all_log = Join(Join(dir, "log"), "fmllr.all.log"), trans_all = Join(dir, "pre_trans.all");
+      {
+        std::ofstream out(trans_all, std::ios::binary);
+        for (int n = 1; n <= nj; n++) { std::ifstream in(Join(dir, "pre_trans." + std::to_string(n)), std::ios::binary); if (in) out << in.rdbuf(); }
       }
-      if (ReadLines(Join(dsn, "feats.scp"), false).empty()) return;
-      std::ofstream log(Join(Join(dir, "log"), "fmllr." + J + ".log"), std::ios::binary);
-      // ---- the features of every program below: the job's raw feats.scp behind the fused front end (the reference writes
-      //      sifeats / transform_pass1feats / final feature archives: decode_fmllr.cpp:275-311, 390-402, 491-500, 568-580); the raw
-      //      rows are uploaded once per job (the thread's table cache) and the transforms applied on the device
-      const std::vector<std::string> fe = FrontEndOptions(srcdir, dsn, lda, cmvn_opts, delta_opts, splice_opts);
-      const std::string raw = "scp:" + Join(dsn, "feats.scp");
-      auto with_fe = [&](std::vector<std::string> a, const std::string &trans_file) {
-        std::vector<std::string> r{a[0]};
-        for (const auto &o : fe) r.push_back(o);
-        if (!trans_file.empty()) r.push_back("--fe-trans=ark:" + trans_file);
-        r.insert(r.end(), a.begin() + 1, a.end());
-        return r;
-      };
-      const std::string pre_trans = Join(dir, "pre_trans." + J), trans = Join(dir, "trans." + J), lat_tmp = Join(dir, "lat.tmp." + J);
+      std::ofstream log(all_log, std::ios::binary | std::ios::app);
+      std::vector<std::string> g = main_opts;
+      g.insert(g.end(), {"--decode-batch=1024", "--job-of-utt=" + Join(dir, "job_of_utt"), adapt_model, Join(graphdir, "HCLG.fst"), "scp:" + Join(dir, "all_feats.scp"),
+                         "ark:" + Join(dir, "lat.tmp.JOB")});
+      run("gmm-latgen-faster", GmmLatgenFaster, with_fe(fe_of(data), g, trans_all), log);
+      unlink(trans_all.c_str()); unlink(Join(dir, "all_feats.scp").c_str()); unlink(Join(dir, "job_of_utt").c_str());
+      CombinedLogStubs(Join(dir, "log"), "fmllr", nj, all_log);
+    };
+    auto after = [&](int j) {
+      std::string J, dsn;
+      if (!job_files(j, &J, &dsn)) return;
+      std::ofstream log; open_log(J, &log);
+      const std::vector<std::string> fe = fe_of(dsn);
+      const std::string raw = "scp:" + Join(dsn, "feats.scp"), pre_trans = Join(dir, "pre_trans." + J), trans = Join(dir, "trans." + J), lat_tmp = Join(dir, "lat.tmp." + J);
       const std::string spk2utt = "--spk2utt=ark:" + Join(dsn, "spk2utt");
-      if (stage <= 1) {      // first-pass fMLLR from the SI lattices (:314-388)
-        const std::string t_post = Join(dsn, "post.temp"), t_wsp = Join(dsn, "wsp.temp");
-        run("lattice-to-post", LatticeToPost, {"lattice-to-post", acw, "ark:" + Join(si_dir, "lat." + J), "ark:" + t_post}, log);
-        run("weight-silence-post", WeightSilencePost, {"weight-silence-post", std::to_string(silence_weight), silphonelist, alignment_model, "ark:" + t_post, "ark:" + t_wsp}, log);
-        // the reference pipes gmm-post-to-gpost (alignment model) into gmm-est-fmllr-gpost (adapt model); here the Gaussian
-        // posteriors never leave the GPU: gmm-est-fmllr takes them from --ali-model and the statistics from the adapt model
-        run("gmm-est-fmllr", GmmEstFmllr, with_fe({"gmm-est-fmllr", "--fmllr-update-type=" + fmllr_update_type, spk2utt, "--ali-model=" + alignment_model, adapt_model,
-                                                   raw, "ark:" + t_wsp, "ark:" + pre_trans}, ""), log);
-        unlink(t_post.c_str()); unlink(t_wsp.c_str());
-      }
-      if (stage <= 2) {      // main search on the first-pass features (:390-489)
-        std::vector<std::string> g = {"gmm-latgen-faster", "--max-active=" + std::to_string(max_active), "--beam=" + std::to_string(beam),
-                                      "--lattice-beam=" + std::to_string(lattice_beam), acw, "--determinize-lattice=false", "--allow-partial=true"};
-        if (Exists(symtab)) g.push_back("--word-symbol-table=" + symtab);
-        g.insert(g.end(), {adapt_model, Join(graphdir, "HCLG.fst"), raw, "ark:" + lat_tmp});
-        run("gmm-latgen-faster", GmmLatgenFaster, with_fe(g, pre_trans), log);
-      }
       if (stage <= 3) {      // second fMLLR estimate, composed with the first (:491-566)
         const std::string t_ldp = Join(dsn, "ldp.temp"), t_post = Join(dsn, "post.temp"), t_wsp = Join(dsn, "wsp.temp"), trans_tmp = Join(dir, "trans_tmp." + J);
         run("lattice-determinize-pruned", LatticeDeterminizePruned, {"lattice-determinize-pruned", acw, "--beam=" + std::to_string(4.0), "ark:" + lat_tmp, "ark:" + t_ldp}, log);
         run("lattice-to-post", LatticeToPost, {"lattice-to-post", acw, "ark:" + t_ldp, "ark:" + t_post}, log);
         run("weight-silence-post", WeightSilencePost, {"weight-silence-post", std::to_string(silence_weight), silphonelist, adapt_model, "ark:" + t_post, "ark:" + t_wsp}, log);
-        run("gmm-est-fmllr", GmmEstFmllr, with_fe({"gmm-est-fmllr", "--fmllr-update-type=" + fmllr_update_type, spk2utt, adapt_model, raw, "ark:" + t_wsp, "ark:" + trans_tmp}, pre_trans), log);
+        run("gmm-est-fmllr", GmmEstFmllr, with_fe(fe, {"gmm-est-fmllr", "--fmllr-update-type=" + fmllr_update_type, spk2utt, adapt_model, raw, "ark:" + t_wsp, "ark:" + trans_tmp}, pre_trans), log);
         run("compose-transforms", ComposeTransforms, {"compose-transforms", "--b-is-affine=true", "ark:" + trans_tmp, "ark:" + pre_trans, "ark:" + trans}, log);
         unlink(t_ldp.c_str()); unlink(t_post.c_str()); unlink(t_wsp.c_str());
       }
       if (stage <= 4) {      // rescoring with the final model on the final features, determinization (:568-640)
         const std::string t_grl = Join(dsn, "grl.temp");
-        run("gmm-rescore-lattice", GmmRescoreLattice, with_fe({"gmm-rescore-lattice", final_model, "ark:" + lat_tmp, raw, "ark:" + t_grl}, trans), log);
+        run("gmm-rescore-lattice", GmmRescoreLattice, with_fe(fe, {"gmm-rescore-lattice", final_model, "ark:" + lat_tmp, raw, "ark:" + t_grl}, trans), log);
         run("lattice-determinize-pruned", LatticeDeterminizePruned, {"lattice-determinize-pruned", acw, "--beam=" + std::to_string(lattice_beam), "ark:" + t_grl, "ark:" + Join(dir, "lat." + J)}, log);
         unlink(t_grl.c_str()); unlink(lat_tmp.c_str());
       }
-    });
+    };
+    for (int j = 1; j <= nj; j++) unlink(Join(Join(dir, "log"), "fmllr." + std::to_string(j) + ".log").c_str());
+    auto si_job = [&](int j) {
+      try { DecodeJob(si_jobs, j); }
+      catch (const std::exception &e) { throw StepError(std::string("First pass speaker-independent decoding failed: ") + e.what()); }
+    };
+    if (combined) {
+      vb_set_device(StepDevices()[0]);
+      if (run_si) {
+        try { DecodeAllJobs(si_jobs); }
+        catch (const std::exception &e) { throw StepError(std::string("First pass speaker-independent decoding failed: ") + e.what()); }
+      }
+      ForEachJob(nj, before);
+      main_search_all();
+      ForEachJob(nj, after);
+    } else {
+      ForEachJob(nj, [&](int j) {
+        if (run_si) si_job(j);
+        before(j);
+        main_search(j);
+        after(j);
+      });
+    }
     if (run_si) {
       FinishDecode(si_jobs);
       if (!skip_scoring) {        // (what Decode does for the first pass when it runs as a step of its own)
@@ -815,6 +948,13 @@ int vb_ScoreKaldiWER(const char *data, const char *lang_or_graph, const char *di
 }
 int vb_set_release_device_cache(int on) { g_release_at_step_end.store(on ? 1 : 0); return 0; }
 const char *vb_steps_last_error(void) { return g_err.c_str(); }
+// jobs of the last step's last fan-out: out_device[j], out_worker[j] for j < min(n, cap); returns n
+int vb_last_step_jobs(int *out_device, int *out_worker, int cap) {
+  std::lock_guard<std::mutex> lk(g_last_jobs_mu);
+  const int n = (int)g_last_job_device.size();
+  for (int j = 0; j < n && j < cap; j++) { out_device[j] = g_last_job_device[(size_t)j]; out_worker[j] = g_last_job_worker[(size_t)j]; }
+  return n;
+}
 int vb_set_step_devices(const int *devices, int n) {
   std::lock_guard<std::mutex> lk(g_step_devices_mu);
   g_step_devices.clear();

@@ -31,10 +31,11 @@
 // Scoring works on the lattices in memory (one read, all LMWT x WIP combinations spread over host
 // threads) instead of the reference's 33 passes over temporary archives; the files it leaves are the same.
 //
-// Not part of this build, refused with an error rather than skipped: a `segments` file in MakeMfcc
-// (extract-segments), fake / two-channel / fake-dims CMVN, MBR decoding (decode_mbr).  With stats = true the
-// best LMWT/WIP are recorded, but the per-utterance alignment statistics (align-text, per_utt, per_spk, ops,
-// bootstrap confidence interval) are not produced; scoring_kaldi/log/score.log says so.
+// Not part of this build, refused with an error rather than skipped: fake / two-channel / fake-dims CMVN, MBR decoding (decode_mbr).
+// `segments` files are honoured (extract-segments' rules) and, with stats = true, the per-utterance alignment statistics of scoring
+// (align-text, per_utt, per_spk, ops, bootstrap confidence interval) are produced (voicebridge_scoring.cc).
+// Not declared at all (outside the hot path): Train*, AlignSi, MkGraph -- the search AlignSi runs, gmm-align-compiled, is
+// the bin function GmmAlignCompiled (voicebridge_api.h).
 #ifndef VOICEBRIDGE_STEPS_H_
 #define VOICEBRIDGE_STEPS_H_
 
@@ -86,6 +87,7 @@ int vb_ScoreKaldiWER(const char *data, const char *lang_or_graph, const char *di
                      int max_lmwt);
 const char *vb_steps_last_error(void);
 int vb_set_release_device_cache(int on);               // 1: every outermost step frees model, graph and search workspace when it returns (default 0: they stay for the next step; vb_release_device_cache() frees them)
+int vb_last_step_jobs(int *out_device, int *out_worker, int cap);   // jobs of the last fan-out: device and worker thread (-1: the caller's) of each; returns their number
 int vb_set_step_devices(const int *devices, int n);    // GPUs the jobs of the steps are spread over (n = 0: back to the default, four job threads on the calling thread's device)
 }
 
