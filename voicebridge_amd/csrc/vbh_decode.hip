@@ -1623,6 +1623,14 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       // ---- the state map is emptied for the frame about to be built (the costs the cutoff phase kept in its memory were last
       //      read before that phase's last reduction barrier; the map's first writers come after pass 1's reduction barrier)
       map_clear(sh);
+      // The ends of the token and link windows, i.e. where frame + 1 will start.  Read HERE, not behind pass 1's reduction barrier where
+      // they are first used: pass 2 moves both counters (second-level tokens, every admitted link), and a wave that left that barrier
+      // late -- its SIMD busy with another workgroup's waves -- read them after a faster wave's first allocation: two waves of one
+      // frame then disagreed on the frame's first token / link.  With one workgroup per CU the window is a few instructions against a
+      // global round trip and was never seen hit; with two workgroups per CU (NT = 512) five utterances in a thousand came out different
+      // from run to run, some with cyclic lattices (r03).  Nothing moves the counters between here and pass 2.
+      const int nb = __builtin_amdgcn_readfirstlane(sh.w_ntok);     // first token of frame+1
+      const int lb = __builtin_amdgcn_readfirstlane(sh.w_nlink);
       // ---- pass 1 (arc-parallel): every candidate arc -> scratch list; min of tot + adaptive_beam
 #ifdef VBH_DIAG_P1
 #define P1STAMP(i) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (tid == 0) { const long long now_ = clk(); sh.hph[i] += now_ - p1_t; p1_t = now_; } }
@@ -1719,14 +1727,12 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       mymin = block_min_f(mymin, sh, par);
       P1STAMP(7)
       const float next_cutoff = mymin;
-      const int ncand = sh.n_cand < cand_cap ? sh.n_cand : cand_cap;
-      const int nb = sh.w_ntok;     // first token of frame+1
+      const int ncand = sh.n_cand < cand_cap ? sh.n_cand : cand_cap;      // (pass 2 does not move n_cand)
       PHASE(1)
       // ---- pass 2 (candidate-parallel): admit tot <= next_cutoff: the state's cost in the map is lowered (the thread whose
       //      compare-and-swap claims a first-level slot, or that meets a stale epoch in the second level, is the first to reach
       //      the state), and the forward link (:765-767) is written with a provisional destination -- map slot, or -1 - state
       //      for a second-level state -- that process_nonemitting replaces by the token once tokens are numbered
-      const int lb = sh.w_nlink;
       {
         gp<Ent> ent = uptr(s.ent);
         gp<i32x4> wt = uptr(s.w_tok);
