@@ -1,0 +1,38 @@
+"""The two-workgroups-per-CU build of the search kernel (voicebridge_amd/build.py STRESS_LIB: 512 threads per utterance, an
+8192-slot state map) as a race detector.  With another workgroup's waves on their SIMDs the waves of a workgroup
+skew by hundreds of cycles; round 2 saw memory faults in this configuration and round 3 run-to-run differences (5 utterances in
+1000, some with cyclic lattices) until the cause was found: the ends of the token / link windows were read behind pass 1's reduction
+barrier, where a late wave could see a faster wave's first allocation of pass 2 (csrc/vbh_decode.hip).  The variant is
+loaded in a child process (the library is chosen at import: VBH_LIB_PATH)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env():
+    from voicebridge_amd import build
+    if not os.path.exists(build.STRESS_LIB):
+        pytest.fail("the stress variant %s is not built (python -m voicebridge_amd.build)" % build.STRESS_LIB)
+    return dict(os.environ, VBH_LIB_PATH=build.STRESS_LIB)
+
+
+def test_parity_at_bench_scale_with_two_workgroups_per_cu():
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_config3.py", "tests/test_gpu_decode.py", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout.splitlines()[-1]
+
+
+def test_determinism_with_two_workgroups_per_cu():
+    """1024 utterances of the bench's speech workload searched three times: identical counters and lattices (before the fix: ~5 differed)"""
+    env = dict(_env(), VBH_PROBE_REPEAT="3")
+    r = subprocess.run([sys.executable, "bench.py", "--probe", "--batch", "1024", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    out = r.stdout + r.stderr
+    assert "determinism: 0 differences over 3 repeats of 1024 utterances" in out, out[-3000:]
+    assert "512 workgroups" in out          # two per CU really were resident

@@ -130,6 +130,12 @@ constexpr int DIRTY_FRAMES = 1 << 13;       // frames covered by the dirty bitma
 
 // The pruning and compaction passes run once per pruning interval; as functions of their own they get their own register
 // allocation instead of competing with the per-frame passes for the kernel's 128 VGPRs (VBH_OUTLINE=0: inlined, as before)
+// VBH_SURVIVOR_BITS: the pruning sweeps leave one bit per window token / link (alive after the sweep), and the compaction gathers the
+// records of the set bits instead of streaming the whole raw window (300 frames x 7 k records x 16 B = 34 MB per compaction, to move
+// a few hundred survivors) through the CU a second time
+#ifndef VBH_SURVIVOR_BITS
+#define VBH_SURVIVOR_BITS 1
+#endif
 #ifndef VBH_OUTLINE
 #define VBH_OUTLINE 0          // measured (r02, tools/variants.py): 1 and 2 are 15 % slower -- the call sites cost the hot loop more registers than the callees free
 #endif
@@ -190,6 +196,10 @@ struct Slot {
   // the arc's weight and the acoustic cost is recomputed from the frame's cost offset and the score matrix, with the expression that
   // made it, for the few links that reach the output (the scores of a batch stay resident until its lattices are out)
   i32x4 *w_tok; int *w_remap; i32x4 *wl;
+  // survivor bitmaps of the raw window, one bit per token / link, written by the last pruning sweep over a frame (a wave's 64 items
+  // are one word: every frame's token and link ranges start on a multiple of 64 in W): the compaction walks these words instead of
+  // reading the window's 16-byte records again (VBH_SURVIVOR_BITS)
+  unsigned long long *w_tok_alive, *w_lk_alive;
   i32x4 *h_tok; int *h_remap; i32x4 *hl;                // history
   FrameRec *fr;                            // [max_frames + 2]
   i32x4 *cand;                             // candidates of the current frame: {tot, arc, source token, next state | EPSBIT}
@@ -587,7 +597,8 @@ __device__ __forceinline__ bool chk_tok_id(Shared &sh, const Slot &s, int where,
 // Returns (valid on lane 0 of each wave) the links this wave kept: epsilon << 32 | emitting.
 template <bool LDS_TMP>
 __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, int le_, int split, gp<i32x4> wt, gp<i32x4> ht,
-                                                         float lattice_beam, unsigned *lds_tmp, int tb, Shared &sh, const Slot &s) {
+                                                         float lattice_beam, unsigned *lds_tmp, int tb, Shared &sh, const Slot &s,
+                                                         gp<unsigned long long> alive_bits = nullptr) {
   unsigned long long kept = 0;
   for (int base = lb; base < le_; base += NT * UL) {
     i32x4 L[UL]; bool ok[UL];
@@ -623,6 +634,9 @@ __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, i
       const unsigned long long m = __ballot(keep);
       // a wave's 64 links are consecutive, so the split falls on a lane boundary
       const int first = base + u * NT + ((int)threadIdx.x & ~63);
+#if VBH_SURVIVOR_BITS
+      if (alive_bits && ((int)threadIdx.x & 63) == 0 && first < le_) alive_bits[first >> 6] = m;      // (lb is a multiple of 64 in W)
+#endif
       const int ne = split - first;   // lanes [0, ne) hold epsilon links
       const unsigned long long em = ne <= 0 ? 0ull : (ne >= 64 ? ~0ull : ((1ull << ne) - 1ull));
       kept += ((unsigned long long)__popcll(m & em) << 32) | (unsigned long long)__popcll(m & ~em);
@@ -672,6 +686,13 @@ __device__ int prune_frame(const Slot &s, int f, float lattice_beam, float delta
   const bool lds_tmp = te - tb <= COST_CAP;
   unsigned *ltmp = sh.arena;
   int result = 0;
+#if VBH_SURVIVOR_BITS
+  // (window ranges start on multiples of 64; a frame whose links lie in two arrays has its emitting links at the start of W)
+  gp<unsigned long long> tbits = (flags & 1) ? uptr(s.w_tok_alive) : nullptr;
+  gp<unsigned long long> ebits = (flags & 2) ? uptr(s.w_lk_alive) : nullptr, pbits = (flags & 4) ? uptr(s.w_lk_alive) : nullptr;
+#else
+  gp<unsigned long long> tbits = nullptr, ebits = nullptr, pbits = nullptr;
+#endif
   for (int iter = 0; iter < MAX_EPS_ITERS; iter++) {
     i32x4 R0[U];            // first round of the token pass, prefetched
     if (lds_tmp) {
@@ -680,16 +701,16 @@ __device__ int prune_frame(const Slot &s, int f, float lattice_beam, float delta
     }
     unsigned long long kept;
     if (lds_tmp) {
-      if (one_range) kept = eval_links<true>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s);
+      if (one_range) kept = eval_links<true>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits);
       else {
-        kept = eval_links<true>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb, sh, s);
-        kept += eval_links<true>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s);
+        kept = eval_links<true>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, pbits);
+        kept += eval_links<true>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits);
       }
     } else {
-      if (one_range) kept = eval_links<false>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s);
+      if (one_range) kept = eval_links<false>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits);
       else {
-        kept = eval_links<false>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb, sh, s);
-        kept += eval_links<false>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s);
+        kept = eval_links<false>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, pbits);
+        kept += eval_links<false>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits);
       }
     }
     if ((tid & 63) == 0) {
@@ -730,7 +751,11 @@ __device__ int prune_frame(const Slot &s, int f, float lattice_beam, float delta
           // "changed" as the reference counts it (:358): |new - old| > delta; inf vs inf is no change
           if (fabsf(__uint_as_float(v) - __uint_as_float(o)) > delta) ch |= 1;
         }
-        alive += __popcll(__ballot(ok[u] && v != INF_BITS));
+        const unsigned long long am = __ballot(ok[u] && v != INF_BITS);
+        alive += __popcll(am);
+#if VBH_SURVIVOR_BITS
+        { const int first = base + u * NT + (tid & ~63); if (tbits && (tid & 63) == 0 && first < te) tbits[first >> 6] = am; }      // (tb is a multiple of 64 in W)
+#endif
       }
     }
     if (ch) atomicOr(&sh.changed2[pp], ch);
@@ -796,7 +821,7 @@ __device__ __forceinline__ int seg_find(const int *beg, int n, int x) {
 // >= remap_lo are translated through h_remap.  Flat over all frames: a survivor finds its
 // frame by binary search in LDS.
 template <bool FROM_W>
-__device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l, int remap_lo) {
+__device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l, int remap_lo, int dense_tok = 0, int dense_link = 0) {
   const int tid = threadIdx.x;
   gp<i32x4> wt = uptr(s.w_tok), ht = uptr(s.h_tok);
   gp<int> w_remap = uptr(s.w_remap), h_remap = uptr(s.h_remap);
@@ -804,8 +829,37 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
   gp<int> remap = FROM_W ? w_remap : h_remap;
   const int ntf = sh.j_ntf, nseg = sh.j_nseg;
   Job &J = job_of(sh);
+  // With survivor bitmaps (FROM_W only): the window's tokens below dense_tok and links below dense_link belong to frames the pruning
+  // pass has swept, and the bits of their last sweep say which are alive; the frontier frame's tokens and epsilon links (never
+  // swept) follow, one contiguous range each, and are read as before.
+  const bool bits = FROM_W && VBH_SURVIVOR_BITS;
+  auto move_tok = [&](int t, const i32x4 Rt) {
+    int nid = -1;
+    if ((unsigned)Rt.z != INF_BITS) {
+      const int j = seg_find(J.tbeg, ntf, t);
+      const int c = atomicAdd(&J.tcnt[j], 1);
+      if (c < J.tup[j]) {
+        nid = J.tbase[j] + c;
+        i32x4 r = Rt; r.w = (int)INF_BITS;
+        ht[nid + stage_t] = r;
+      } else sh.error = ERR_H_TOK;     // more survivors than the sweep counted: never expected
+    }
+    remap[t] = nid;
+  };
   if (ntf > 0) {
-    const int t0 = J.tbeg[0], t1 = J.tbeg[ntf];
+    const int t1 = J.tbeg[ntf];
+    int t0 = J.tbeg[0];
+    if (bits) {
+      gp<const unsigned long long> tb_ = uptr(s.w_tok_alive);
+      const int tend = dense_tok < t1 ? dense_tok : t1;
+      for (int w = (t0 >> 6) + tid; w < ((tend + 63) >> 6); w += NT) {
+        for (unsigned long long m = tb_[w]; m; m &= m - 1) {
+          const int t = (w << 6) + (__ffsll((long long)m) - 1);
+          if (t >= t0 && t < tend) { const i32x4 rec_ = src_tok[t]; move_tok(t, rec_); }
+        }
+      }
+      t0 = t0 > tend ? t0 : tend;
+    }
     for (int base = t0; base < t1; base += NT * UM) {
       i32x4 R[UM]; bool ok[UM];
 #pragma unroll
@@ -817,18 +871,7 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
 #pragma unroll
       for (int u = 0; u < UM; u++) {
         const int t = base + u * NT + tid;
-        if (!ok[u]) continue;
-        int nid = -1;
-        if ((unsigned)R[u].z != INF_BITS) {
-          const int j = seg_find(J.tbeg, ntf, t);
-          const int c = atomicAdd(&J.tcnt[j], 1);
-          if (c < J.tup[j]) {
-            nid = J.tbase[j] + c;
-            i32x4 r = R[u]; r.w = (int)INF_BITS;
-            ht[nid + stage_t] = r;
-          } else sh.error = ERR_H_TOK;     // more survivors than the sweep counted: never expected
-        }
-        remap[t] = nid;
+        if (ok[u]) move_tok(t, R[u]);
       }
     }
   }
@@ -836,7 +879,41 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
   if (nseg > 0) {
     gp<const i32x4> src_lk = uptr(FROM_W ? s.wl : s.hl);
     gp<i32x4> hl = uptr(s.hl);
-    const int l0 = J.sbeg[0], l1 = J.sbeg[nseg];
+    gp<const unsigned long long> tb_ = uptr(s.w_tok_alive);
+    // is window token i alive (swept frames: the bit of the last sweep; frontier frame: its remap entry, written above)?
+    auto w_alive = [&](int i) -> bool { return !bits || i >= dense_tok || ((tb_[i >> 6] >> (i & 63)) & 1ull); };
+    auto move_link = [&](int l, const i32x4 Lk) {
+      const int a = Lk.x, b2 = Lk.y;
+      if (a < 0) return;
+      int ns, nd;
+      if (a & WBIT) ns = w_alive(a ^ WBIT) ? w_remap[a ^ WBIT] : -1;
+      else if (a >= remap_lo) ns = h_remap[a];
+      else ns = (unsigned)((gp<const int>)(ht + a))[2] != INF_BITS ? a : -1;
+      if (b2 & WBIT) nd = w_alive(b2 ^ WBIT) ? w_remap[b2 ^ WBIT] : -1;
+      else if (b2 >= remap_lo) nd = h_remap[b2];
+      else nd = (unsigned)((gp<const int>)(ht + b2))[2] != INF_BITS ? b2 : -1;
+      if (ns < 0 || nd < 0) return;
+      const int j = seg_find(J.sbeg, nseg, l);
+      const int c = atomicAdd(&J.scnt[j], 1);
+      if (c < J.sup[j]) {
+        const int nid = J.sbase[j] + c + stage_l;
+        i32x4 r = Lk; r.x = ns; r.y = nd;
+        hl[nid] = r;
+      } else sh.error = ERR_H_LINK;
+    };
+    const int l1 = J.sbeg[nseg];
+    int l0 = J.sbeg[0];
+    if (bits) {
+      gp<const unsigned long long> lb_ = uptr(s.w_lk_alive);
+      const int lend = dense_link < l1 ? dense_link : l1;
+      for (int w = (l0 >> 6) + tid; w < ((lend + 63) >> 6); w += NT) {
+        for (unsigned long long m = lb_[w]; m; m &= m - 1) {
+          const int l = (w << 6) + (__ffsll((long long)m) - 1);
+          if (l >= l0 && l < lend) { const i32x4 rec_ = src_lk[l]; move_link(l, rec_); }
+        }
+      }
+      l0 = l0 > lend ? l0 : lend;
+    }
     for (int base = l0; base < l1; base += NT * UM) {
       i32x4 L[UM]; bool ok[UM];
 #pragma unroll
@@ -852,9 +929,12 @@ __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l
 #pragma unroll
       for (int u = 0; u < UM; u++) {
         const int a = L[u].x, b = L[u].y;
-        gp<const int> pa = !ok[u] ? h_remap : (a & WBIT) ? w_remap + (a ^ WBIT) : (a >= remap_lo) ? h_remap + a : (gp<const int>)(ht + a) + 2;
-        gp<const int> pb = !ok[u] ? h_remap : (b & WBIT) ? w_remap + (b ^ WBIT) : (b >= remap_lo) ? h_remap + b : (gp<const int>)(ht + b) + 2;
+        const bool wa = ok[u] && (a & WBIT) && !w_alive(a ^ WBIT), wb = ok[u] && (b & WBIT) && !w_alive(b ^ WBIT);      // (a window token a swept frame lost)
+        gp<const int> pa = (!ok[u] || wa) ? h_remap : (a & WBIT) ? w_remap + (a ^ WBIT) : (a >= remap_lo) ? h_remap + a : (gp<const int>)(ht + a) + 2;
+        gp<const int> pb = (!ok[u] || wb) ? h_remap : (b & WBIT) ? w_remap + (b ^ WBIT) : (b >= remap_lo) ? h_remap + b : (gp<const int>)(ht + b) + 2;
         vs[u] = *pa; vd[u] = *pb;
+        if (wa) vs[u] = -1;
+        if (wb) vd[u] = -1;
       }
 #pragma unroll
       for (int u = 0; u < UM; u++) {
@@ -1019,7 +1099,9 @@ __device__ VBH_COLD bool compact_window(const Slot &s, int prev_front, int front
   __syncthreads();
   if (sh.error != ERR_NONE) return false;
   const int blk_tb = sh.h_ntok, blk_lb = sh.h_nlink;
-  compact_move<true>(s, sh, 0, 0, had_tail ? old_tail_tb : INT_MAX);
+  // the frontier frame (the job's last) has not been swept: its tokens and epsilon links are read densely, the rest through the bitmaps
+  const int dense_tok = (lf[nf - 1].flags & 1) ? lf[nf - 1].tok_b : INT_MAX, dense_link = (lf[nf - 1].flags & 4) ? lf[nf - 1].pl_b : INT_MAX;
+  compact_move<true>(s, sh, 0, 0, had_tail ? old_tail_tb : INT_MAX, dense_tok, dense_link);
   __syncthreads();
   if (sh.error != ERR_NONE) return false;
   job_publish(s, sh);
@@ -1265,7 +1347,12 @@ __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, in
       if (want) front_push(sh, uptr(s.front[1]), front_cap, 1, q, t);
     }
   }
-  if (tid == 0) sh.w_ntok = ne_all < w_tok_cap ? ne_all : w_tok_cap;
+  if (tid == 0) {
+    sh.w_ntok = ne_all < w_tok_cap ? ne_all : w_tok_cap;
+#if VBH_SURVIVOR_BITS
+    sh.w_nlink = (sh.w_nlink + 63) & ~63;      // a frame's links (its epsilon links, then its emitting links) start a 64-bit word of the survivor bitmap
+#endif
+  }
   __syncthreads();
   const int lb = sh.w_nlink;
   if (sh.error != ERR_NONE) return lb;
@@ -1534,6 +1621,11 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         cur_w = false;
         PHASE(5)
       }
+#if VBH_SURVIVOR_BITS
+      // the tokens of frame + 1 start a word of the survivor bitmap (nobody reads the counter between the barrier that ended the
+      // previous frame and the one inside the cutoff phase below)
+      if (tid == 0) sh.w_ntok = (sh.w_ntok + 63) & ~63;
+#endif
       const int tb = cur_b, n = cur_e - cur_b;
       gp<const i32x4> tok = uptr(cur_w ? s.w_tok : s.h_tok) + tb;
       gp<i32x4> cand = uptr(s.cand);
@@ -2039,7 +2131,10 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
 #undef PHASE_D
 #undef DIAG_ADD
   if (spool.flags) {
-    __syncthreads();               // every wave's stores have left for L2
+    // every wave waits for its OWN stores (and writes back its XCD's L2) before the barrier: a workgroup barrier orders the waves of a CU
+    // through the in-order L1 path, which says nothing to the next owner of the slot on another CU
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
     if (tid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __hip_atomic_store(spool.flags + my_slot, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -2247,6 +2342,7 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
   }
   A_(ent, Ent, S, 0xFF)
   A_(w_tok, i32x4, p.w_tok_cap, -2) A_(w_remap, int, p.w_tok_cap, 0) A_(wl, i32x4, p.w_link_cap, -2)
+  A_(w_tok_alive, unsigned long long, p.w_tok_cap / 64 + 2, 0) A_(w_lk_alive, unsigned long long, p.w_link_cap / 64 + 2, 0)
   A_(h_tok, i32x4, p.h_tok_cap, -2) A_(h_remap, int, p.h_tok_cap, 0) A_(hl, i32x4, p.h_link_cap, -2)
   A_(fr, FrameRec, F, 0)
   A_(cand, i32x4, p.cand_cap, -2)
