@@ -36,11 +36,13 @@ def test_gmm_golden(ctx, name):
 
 
 @pytest.mark.parametrize("P,G,D,T", [(50, 300, 39, 200), (7, 7, 13, 65), (300, 1800, 40, 130), (3, 240, 39, 5),
-                                     (3, 700, 39, 70), (2, 2100, 20, 130), (40, 6000, 39, 200)])
+                                     (3, 700, 39, 70), (2, 2100, 20, 130), (40, 6000, 39, 200), (120, 120, 13, 70), (90, 150, 39, 64),
+                                     (1, 1, 5, 3), (1, 333, 39, 64), (500, 9000, 39, 100)])
 def test_gmm_vs_oracle(ctx, P, G, D, T):
     """ragged frame counts (not multiples of the 64-frame tile), 1-Gaussian pdfs, pdfs with
     ~100 Gaussians, tiles split over blockIdx.y, pdfs with more Gaussians than one 128-column tile
-    (scored in parts and folded)"""
+    (scored in parts and folded); in the dense packing of the default LogSumExp: pdfs that run from one 32-row block into the next
+    (their sum is carried on), more than 16 one-Gaussian pdfs in a row (the 16-ends-per-block rule), one pdf that is the whole model"""
     import torch
     from oracle import vbo
     from voicebridge_amd import api, synth
@@ -54,6 +56,24 @@ def test_gmm_vs_oracle(ctx, P, G, D, T):
     ref = vbo.gmm_loglikes(offs, vbo.gmm_gconsts(w, miv, iv), miv, iv, feats)
     np.testing.assert_allclose(ll.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
     m.close()
+
+
+@pytest.mark.parametrize("P,G,D,T", [(50, 300, 39, 200), (3, 700, 39, 70), (120, 120, 13, 70)])
+def test_gmm_strict_and_twopass_vs_oracle(ctx, P, G, D, T):
+    """the block-local packing (pdfs never straddle a row-block, large pdfs in parts) behind the two-pass modes"""
+    import torch
+    from oracle import vbo
+    from voicebridge_amd import api, synth
+    offs, w, means, iv = synth.gmm_model(P, G, D, seed=P + G)
+    miv = (means * iv).astype(np.float32)
+    feats = (np.random.default_rng(T).standard_normal((T, D)) * 1.3).astype(np.float32)
+    ref = vbo.gmm_loglikes(offs, vbo.gmm_gconsts(w, miv, iv), miv, iv, feats)
+    for mode in ("strict", "twopass"):
+        m = api.DiagGmm(ctx, offs, w, miv, iv, lse=mode)
+        ll = m.loglikes(torch.from_numpy(feats).to(ctx.device))
+        ctx.sync()
+        np.testing.assert_allclose(ll.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+        m.close()
 
 
 def test_gmm_reference_sizes_property(ctx):

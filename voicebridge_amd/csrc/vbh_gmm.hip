@@ -227,11 +227,20 @@ __global__ __launch_bounds__(256, 2) void gmm_loglikes_kernel(
 //     (L2/MALL resident) into registers, one row-block ahead; LDS holds only the 64 frames (read-only after the first
 //     barrier) and a small per-wave staging area for the output runs;
 //   * the four waves of a workgroup work on different row-blocks and never meet: NO barrier in the block loop.
-// The model is packed once (vbh_gmm_create): pdfs never straddle a 32-row block (the gap rows are Gaussians with
-// gconst = -inf, which add exp(-inf) = 0), a block holds at most 16 pdfs, a pdf with more than 32 Gaussians is scored in
-// parts of <= 32 that gmm_fold_parts_kernel combines.  Per block: {bit r set = row r starts a pdf, first pdf, #pdfs}.
+// The model is packed once (vbh_gmm_create) into row-blocks of 32 Gaussians, the row-blocks into SUPERBLOCKS (runs of consecutive
+// row-blocks, sbs[] = first row-block of each); wave w of a workgroup takes the superblocks w, w + 4, ... of its group and walks
+// the row-blocks of a superblock in order.  Two packings:
+//   * dense (the default LogSumExp, VBH_LSE_FAST): the Gaussians one after the other, a pdf may run over the end of a row-block into
+//     the next one of the same superblock -- the online LogSumExp just carries its (maximum, sum) pair on in the lane -- so only the
+//     last row-block of a superblock has unused rows (gap rows: Gaussians with gconst = -inf, which add exp(-inf) = 0); the
+//     superblocks are ~8 row-blocks, near-equal, their number a multiple of 4 (the four waves get the same work).  Per block:
+//     {bit r set = row r is the LAST Gaussian of a pdf, first pdf that ends in the block, number that end there (<= 16)};
+//   * block-local (VBH_LSE_STRICT / _TWOPASS, whose two passes need all of a pdf at once): pdfs never straddle a row-block, a pdf
+//     with more than 32 Gaussians is scored in parts of <= 32 that gmm_fold_parts_kernel combines; every superblock is one
+//     row-block.  Per block: {bit r set = row r STARTS a pdf, first pdf, number of pdfs (<= 16)}.
 struct RbMeta { unsigned mask; int p0; int np; int pad; };
-constexpr int LDP = 17;       // padded row of a wave's staging area: [64 frames][<= 16 pdfs]
+struct __attribute__((packed, aligned(4))) f32x4u { float x, y, z, w; };      // four floats at a 4-byte-aligned address (one 16-byte store)
+constexpr int LDP = 31;       // row of a wave's staging area: [64 frames][<= 15 pdfs waiting + <= 16 of the current block]
 
 // LSE: how the LogSumExp over a pdf's Gaussians is evaluated (kaldi-vector.cc:757-775; vbh_gmm_set_lse_mode)
 //   VBH_LSE_FAST (default): one pass over the lane's registers -- running maximum m and sum of exp(x - m), rescaled when the maximum
@@ -245,17 +254,17 @@ template <int NC, int LSE>    // NC = Kpad / 8: a lane's strip of a row-block is
 __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
     const float *__restrict__ feats, long long T, int D, int P,
     const f32x4 *__restrict__ Mp,            // [n_rb][NC][64 lanes]: Mp[(rb*NC + c)*64 + lane][j] = row (lane & 31), k = 2(4c + j) + (lane >> 5)
-    const RbMeta *__restrict__ meta, int n_rb, int rb_per_group,
+    const RbMeta *__restrict__ meta, const int *__restrict__ sbs, int n_sb, int sb_per_group,
     float *__restrict__ out) {
   extern __shared__ __align__(16) float lds[];
   constexpr int Kpad = NC * 8;
   float *sA = lds;                                   // [Kpad][LDA]: [x, x^2, 1, 0..] of 64 frames, k-major
   float *sStage = sA + Kpad * LDA + ((4 - (Kpad * LDA) % 4) % 4);
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long t0 = (long long)blockIdx.x * TM;
-  const int j_begin = blockIdx.y * rb_per_group;
-  int j_end = j_begin + rb_per_group;
-  if (j_end > n_rb) j_end = n_rb;
+  const int sb_begin = blockIdx.y * sb_per_group;
+  int sb_end = sb_begin + sb_per_group;
+  if (sb_end > n_sb) sb_end = n_sb;
   for (int idx = tid; idx < TM * D; idx += 256) {
     const int t = idx / D, d = idx - t * D;
     float x = 0.f;
@@ -268,20 +277,31 @@ __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
     sA[k * LDA + t] = (k == 2 * D) ? 1.0f : 0.0f;
   }
   __syncthreads();
+  int sb = sb_begin + wid;
+  if (sb >= sb_end) return;                         // (no barrier below)
   const int khalf = lane >> 5, l31 = lane & 31;
   float *stage = sStage + wid * (TM * LDP);
   const float *pb = sA + khalf * LDA + l31;
-  int rb = j_begin + wid;
-  f32x4 cur[NC];
-  if (rb < j_end) {
+  int rb = sbs[sb], rb_end = sbs[sb + 1];
+  // where this wave's output runs go: out + (t0 P + p0) is wave-uniform, the rest fits 32 bits
+  const int fmax = T - t0 < TM ? (int)(T - t0) : TM;
+  float *const out0 = out + t0 * P;
+  int pend = 0, pend_p0 = 0;              // VBH_LSE_FAST: finished pdfs waiting in the staging area, the first one's index
+  f32x4 sa[NC], sb2[NC];
 #pragma unroll
-    for (int c = 0; c < NC; c++) cur[c] = Mp[((size_t)rb * NC + c) * 64 + lane];
-  }
-  for (; rb < j_end; rb += 4) {
-    // next row-block's strip: in flight under this block's MFMAs
-    f32x4 nxt[NC];
+  for (int c = 0; c < NC; c++) sa[c] = Mp[((size_t)rb * NC + c) * 64 + lane];
+  float cm = -3.0e38f, csum = 0.0f;       // VBH_LSE_FAST: the open pdf's running maximum and sum, carried from row-block to row-block
+  // one row-block with its strip in `cur`; the next one's strip goes to `nxt` meanwhile (the caller swaps the two: no register copies)
+  auto do_block = [&](f32x4 (&cur)[NC], f32x4 (&nxt)[NC]) __attribute__((always_inline)) -> bool {
+    // the row-block after this one: the next of the superblock, or the first of the wave's next superblock
+    int nrb = rb + 1, nsb = sb, nend = rb_end;
+    if (nrb == rb_end) {
+      nsb = sb + 4;
+      if (nsb < sb_end) { nrb = sbs[nsb]; nend = sbs[nsb + 1]; } else nrb = -1;
+    }
+    // its strip: in flight under this block's MFMAs
     {
-      const int rbn = rb + 4 < j_end ? rb + 4 : rb;
+      const int rbn = nrb >= 0 ? nrb : rb;
 #pragma unroll
       for (int c = 0; c < NC; c++) nxt[c] = Mp[((size_t)rbn * NC + c) * 64 + lane];
     }
@@ -317,28 +337,70 @@ __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
       const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[i]), __float_as_uint(acc1[i]), false, false);
       v0[i] = __uint_as_float(r[0]); v1[i] = __uint_as_float(r[1]);
     }
-    // ---- LogSumExp per pdf (kaldi-vector.cc:757-775).  The pdf boundaries are wave-uniform (mask), so both passes are straight
-    //      register loops with scalar branches; the maxima wait in the lane's own row of the staging area (one LDS word per pdf).
+    // ---- LogSumExp per pdf (kaldi-vector.cc:757-775).  The pdf boundaries are wave-uniform (mask), so the passes are straight
+    //      register loops with scalar branches; a finished pdf's value goes to the lane's own row of the staging area.
 #define VBH_ROW(r) ((((r) >> 2) & 1) ? v1[((r) & 3) + 4 * ((r) >> 3)] : v0[((r) & 3) + 4 * ((r) >> 3)])
     if (LSE == VBH_LSE_FAST) {
-      float m = -3.0e38f, sum = 0.0f;
+      // (the raw hardware exp2 / log2: the library forms of __expf / __logf add a range fix for denormal results -- a compare, a select
+      // and an ldexp per call -- that a term of a sum whose largest term is 1 does not need; the maximum rides on the compare the sum needs)
+      const float kLog2e = 1.44269504088896340736f, kLn2 = 0.69314718055994530942f;
+      float m = cm, sum = csum;
       float *so = stage + lane * LDP;
-      int q = 0;
+      if (pend == 0) pend_p0 = p0;
+      int q = pend;
 #pragma unroll
       for (int r = 0; r < 32; r++) {
         const float x = VBH_ROW(r);
-        if (r > 0 && ((mask >> r) & 1u)) {      // (wave-uniform) row r starts the next pdf
-          so[q] = sum > 0.0f ? m + __logf(sum) : -INFINITY;
+        // sum' = sum exp(m - m') + exp(x - m') with m' = max(m, x): one of the two factors is exp(0) = 1
+        const float d = x - m;
+        const float e = __builtin_amdgcn_exp2f(-fabsf(d) * kLog2e);
+        const bool up = d > 0.0f;
+        sum = up ? fmaf(sum, e, 1.0f) : sum + e;
+        m = up ? x : m;
+        if ((mask >> r) & 1u) {      // (wave-uniform) row r is the last Gaussian of a pdf
+          so[q] = sum > 0.0f ? fmaf(__builtin_amdgcn_logf(sum), kLn2, m) : -INFINITY;
           q++;
           m = -3.0e38f; sum = 0.0f;
         }
-        // sum' = sum exp(m - m') + exp(x - m') with m' = max(m, x): one of the two factors is exp(0) = 1
-        const float d = x - m;
-        const float e = __expf(-fabsf(d));
-        sum = d > 0.0f ? fmaf(sum, e, 1.0f) : sum + e;
-        m = fmaxf(m, x);
       }
-      so[q] = sum > 0.0f ? m + __logf(sum) : -INFINITY;
+      cm = m; csum = sum;
+      pend = q;
+      // ---- out: the finished pdfs wait in the staging area until a frame's run is 16 of them or more (or the superblock ends: the
+      //      wave's next one is elsewhere in the model): runs of 64+ bytes per frame, lanes along (frame, pdf) -- scattered 4-byte
+      //      stores, one per pdf and lane, were measured to cost twice what the whole LogSumExp does
+      if (pend >= 16 || nsb != sb) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // whole groups of four pdfs: lanes along (frame, group), 16 bytes each; what is left over (< 4 pdfs) waits for the next run,
+        // or, at the end of a superblock, leaves from the lane that made it (lane = frame)
+        const int n4 = pend & ~3, nch = pend >> 2, rem = pend - n4;
+        if (nch > 0) {
+          const unsigned inv = (65536u + (unsigned)nch - 1u) / (unsigned)nch;
+          const int total = TM * nch;
+          float *const ob = out0 + pend_p0;
+          for (int idx = lane; idx < total; idx += 64) {
+            const int f = (int)(((unsigned)idx * inv) >> 16), c = idx - f * nch;
+            if (f < fmax) {
+              const float *src = stage + f * LDP + 4 * c;
+              f32x4u v; v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
+              *reinterpret_cast<f32x4u *>(ob + f * P + 4 * c) = v;
+            }
+          }
+        }
+        if (nsb != sb) {
+          if (lane < fmax)
+            for (int j = 0; j < rem; j++) out0[lane * P + pend_p0 + n4 + j] = so[n4 + j];
+          pend = 0;
+        } else {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          for (int j = 0; j < rem; j++) so[j] = so[n4 + j];
+          pend_p0 += n4;
+          pend = rem;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
     } else {
       const float kMinLogDiff = -15.9423847198486328125f;   // logf(FLT_EPSILON)
       float *so = stage + lane * LDP;
@@ -375,22 +437,25 @@ __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
       so[q] = finish(m, sum);
     }
 #undef VBH_ROW
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ---- out: runs of np pdfs per frame, lanes along (frame, pdf)
-    {
+    if (LSE != VBH_LSE_FAST) {
+      // ---- out: runs of np pdfs per frame from the staging area, lanes along (frame, pdf)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       const unsigned inv = (65536u + (unsigned)np - 1u) / (unsigned)np;
       const int total = TM * np;
+      float *const ob = out0 + p0;
       for (int idx = lane; idx < total; idx += 64) {
         const int f = (int)(((unsigned)idx * inv) >> 16), q = idx - f * np;
-        if (t0 + f < T) out[(t0 + f) * P + p0 + q] = stage[f * LDP + q];
+        if (f < fmax) ob[f * P + q] = stage[f * LDP + q];
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int c = 0; c < NC; c++) cur[c] = nxt[c];
-  }
+    if (nrb < 0) return false;
+    rb = nrb; sb = nsb; rb_end = nend;
+    return true;
+  };
+  while (do_block(sa, sb2) && do_block(sb2, sa)) {}
 }
 
 // A pdf with more than TN Gaussians is scored as several parts of <= TN columns (each part is a
@@ -502,8 +567,9 @@ struct vbh_gmm {
   long long part_chunk;
   // gmm_rows_kernel's form of the model (row-blocks of 32 Gaussians, see there); its own parts (a pdf of more than 32 Gaussians)
   bool rows = false;
-  int n_rb = 0, n_parts2 = 0;
-  DevBuf<f32x4> Mp; DevBuf<RbMeta> rb_meta;
+  int n_parts2 = 0;
+  struct RowsPack { DevBuf<f32x4> Mp; DevBuf<RbMeta> meta; DevBuf<int> sbs; int n_rb = 0, n_sb = 0; };
+  RowsPack pack_dense, pack_local;        // the two packings of gmm_rows_kernel (see there)
   DevBuf<int> d_pdf_parts2; DevBuf<float> part_scratch2; long long part_chunk2 = 0;
   size_t lds_bytes2 = 0;
   int lse_mode = VBH_LSE_FAST;            // vbh_gmm_set_lse_mode
@@ -530,7 +596,7 @@ int vbh_gmm_create(vbh_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h
                    const float *h_weights, const float *h_miv, const float *h_iv, vbh_gmm **out) {
   VBH_CHECK(ctx && h_pdf_offsets && h_weights && h_miv && h_iv && out, "vbh_gmm_create: NULL argument");
   VBH_CHECK(dim >= 1 && dim <= 63, "vbh_gmm_create: dim %d out of range [1,63]", dim);
-  VBH_CHECK(num_pdfs >= 1, "vbh_gmm_create: num_pdfs < 1");
+  VBH_CHECK(num_pdfs >= 1 && num_pdfs < (1 << 24), "vbh_gmm_create: num_pdfs %d out of range [1, 2^24)", num_pdfs);
   VBH_CHECK(h_pdf_offsets[0] == 0, "vbh_gmm_create: pdf_offsets[0] != 0");
   if (vbh_use_device(ctx)) return -1;
   const int D = dim, P = num_pdfs, G = h_pdf_offsets[P];
@@ -608,9 +674,76 @@ int vbh_gmm_create(vbh_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h
     if (g->d_pdf_parts.upload(pdf_parts.data(), pdf_parts.size(), s) ||
         g->part_scratch.alloc((size_t)chunk * NP)) { delete g; return -1; }
   }
-  // ---- gmm_rows_kernel: parts of <= 32 Gaussians, row-blocks of whole parts (<= 16 of them), gap rows with gconst = -inf
+  // ---- gmm_rows_kernel's two packings of the model
   g->rows = !getenv("VBH_GMM_V1");
   if (g->rows) {
+    const int NC = g->Kpad / 8;
+    // rows (row_gauss[i] = Gaussian of packed row i, -1 = gap row) -> the MFMA A-operand strips, with the block table
+    auto upload_pack = [&](vbh_gmm::RowsPack &pk, const std::vector<int> &row_gauss, const std::vector<RbMeta> &meta, const std::vector<int> &sbs) -> int {
+      pk.n_rb = (int)meta.size();
+      pk.n_sb = (int)sbs.size() - 1;
+      std::vector<f32x4> Mp((size_t)pk.n_rb * NC * 64);
+      for (int rb = 0; rb < pk.n_rb; rb++)
+        for (int c = 0; c < NC; c++)
+          for (int lane = 0; lane < 64; lane++) {
+            const int gi = row_gauss[(size_t)rb * 32 + (lane & 31)];
+            f32x4 v;
+            for (int j = 0; j < 4; j++) {
+              const int k = 2 * (4 * c + j) + (lane >> 5);
+              float x = 0.0f;
+              if (gi < 0) x = k == 2 * D ? -INFINITY : 0.0f;
+              else if (k < D) x = h_miv[(size_t)gi * D + k];
+              else if (k < 2 * D) x = -0.5f * h_iv[(size_t)gi * D + (k - D)];
+              else if (k == 2 * D) x = g->gconsts[gi];
+              v[j] = x;
+            }
+            Mp[((size_t)rb * NC + c) * 64 + lane] = v;
+          }
+      return pk.Mp.upload(Mp.data(), Mp.size(), s) || pk.meta.upload(meta.data(), meta.size(), s) || pk.sbs.upload(sbs.data(), sbs.size(), s);
+    };
+    {
+      // dense: the Gaussians in order; a superblock closes at the first pdf end at or past its share of the rows (near-equal superblocks of
+      // ~8 row-blocks, their number a multiple of 4 where the model is large enough), its last row-block is filled up with gap rows;
+      // a row-block in which 16 pdfs end already takes no further pdf end (the staging area's row): gap rows to its end
+      std::vector<RbMeta> meta;
+      std::vector<int> row_gauss, sbs(1, 0);
+      int want_sb = 4 * (int)((G + 4 * 256 / 2) / (4 * 256));
+      if (want_sb < 4) want_sb = 4;
+      if (want_sb > P) want_sb = P;
+      auto close_block_rows = [&]() { while (row_gauss.size() % 32) row_gauss.push_back(-1); };
+      auto block_of = [&](size_t row) { return row / 32; };
+      std::vector<int> ends;             // pdf ends per row-block so far
+      std::vector<unsigned> endmask;
+      std::vector<int> first_end;
+      auto note_end = [&](size_t row, int pdf) {
+        const size_t b = block_of(row);
+        if (ends.size() <= b) { ends.resize(b + 1, 0); endmask.resize(b + 1, 0u); first_end.resize(b + 1, 0); }
+        if (ends[b] == 0) first_end[b] = pdf;
+        ends[b]++;
+        endmask[b] |= 1u << (row % 32);
+      };
+      int sb_i = 0;
+      for (int p = 0; p < P; p++) {
+        const int n = h_pdf_offsets[p + 1] - h_pdf_offsets[p];
+        const size_t last = row_gauss.size() + n - 1;
+        if (block_of(last) < ends.size() && ends[block_of(last)] >= 16) close_block_rows();
+        for (int gi = h_pdf_offsets[p]; gi < h_pdf_offsets[p + 1]; gi++) row_gauss.push_back(gi);
+        note_end(row_gauss.size() - 1, p);
+        // this superblock's share of the Gaussians is used up (the last one takes what is left)
+        if (sb_i + 1 < want_sb && (long long)h_pdf_offsets[p + 1] * want_sb >= (long long)G * (sb_i + 1) && p + 1 < P) {
+          close_block_rows();
+          sbs.push_back((int)(row_gauss.size() / 32));
+          while ((long long)h_pdf_offsets[p + 1] * want_sb >= (long long)G * (sb_i + 1)) sb_i++;      // (a pdf larger than a share uses up several)
+        }
+      }
+      close_block_rows();
+      sbs.push_back((int)(row_gauss.size() / 32));
+      const int n_rb = (int)(row_gauss.size() / 32);
+      ends.resize(n_rb, 0); endmask.resize(n_rb, 0u); first_end.resize(n_rb, 0);
+      for (int b = 0; b < n_rb; b++) meta.push_back(RbMeta{endmask[b], first_end[b], ends[b], 0});
+      if (upload_pack(g->pack_dense, row_gauss, meta, sbs)) { delete g; return -1; }
+    }
+    // block-local: parts of <= 32 Gaussians, row-blocks of whole parts (<= 16 of them)
     std::vector<int> part2(1, 0), pdf_parts2(P + 1, 0);
     for (int p = 0; p < P; p++) {
       const int n = h_pdf_offsets[p + 1] - h_pdf_offsets[p], k = (n + 31) / 32;
@@ -619,40 +752,24 @@ int vbh_gmm_create(vbh_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h
     }
     const int NP2 = pdf_parts2[P];
     g->n_parts2 = NP2;
-    std::vector<RbMeta> meta;
-    std::vector<int> row_gauss;       // Gaussian of every packed row (-1 = gap)
-    for (int p = 0; p < NP2;) {
-      RbMeta m{0u, p, 0, 0};
-      int rows_used = 0;
-      while (p < NP2 && m.np < 16 && rows_used + (part2[p + 1] - part2[p]) <= 32) {
-        m.mask |= 1u << rows_used;
-        for (int gi = part2[p]; gi < part2[p + 1]; gi++) row_gauss.push_back(gi);
-        rows_used += part2[p + 1] - part2[p];
-        m.np++; p++;
-      }
-      for (; rows_used < 32; rows_used++) row_gauss.push_back(-1);
-      meta.push_back(m);
-    }
-    g->n_rb = (int)meta.size();
-    const int NC = g->Kpad / 8;
-    std::vector<f32x4> Mp((size_t)g->n_rb * NC * 64);
-    for (int rb = 0; rb < g->n_rb; rb++)
-      for (int c = 0; c < NC; c++)
-        for (int lane = 0; lane < 64; lane++) {
-          const int gi = row_gauss[(size_t)rb * 32 + (lane & 31)];
-          f32x4 v;
-          for (int j = 0; j < 4; j++) {
-            const int k = 2 * (4 * c + j) + (lane >> 5);
-            float x = 0.0f;
-            if (gi < 0) x = k == 2 * D ? -INFINITY : 0.0f;
-            else if (k < D) x = h_miv[(size_t)gi * D + k];
-            else if (k < 2 * D) x = -0.5f * h_iv[(size_t)gi * D + (k - D)];
-            else if (k == 2 * D) x = g->gconsts[gi];
-            v[j] = x;
-          }
-          Mp[((size_t)rb * NC + c) * 64 + lane] = v;
+    {
+      std::vector<RbMeta> meta;
+      std::vector<int> row_gauss, sbs;
+      for (int p = 0; p < NP2;) {
+        RbMeta m{0u, p, 0, 0};
+        int rows_used = 0;
+        while (p < NP2 && m.np < 16 && rows_used + (part2[p + 1] - part2[p]) <= 32) {
+          m.mask |= 1u << rows_used;
+          for (int gi = part2[p]; gi < part2[p + 1]; gi++) row_gauss.push_back(gi);
+          rows_used += part2[p + 1] - part2[p];
+          m.np++; p++;
         }
-    if (g->Mp.upload(Mp.data(), Mp.size(), s) || g->rb_meta.upload(meta.data(), meta.size(), s)) { delete g; return -1; }
+        for (; rows_used < 32; rows_used++) row_gauss.push_back(-1);
+        meta.push_back(m);
+      }
+      for (int i = 0; i <= (int)meta.size(); i++) sbs.push_back(i);
+      if (upload_pack(g->pack_local, row_gauss, meta, sbs)) { delete g; return -1; }
+    }
     if (NP2 > P) {
       long long chunk = (256LL << 20) / (4LL * NP2);
       chunk = chunk / TM * TM;
@@ -751,7 +868,7 @@ int vbh_gmm_loglikes(vbh_gmm *g, const float *d_feats, int64_t T, float *d_logli
   VBH_CHECK(T > 0 && d_feats && d_loglikes, "vbh_gmm_loglikes: bad arguments");
   if (vbh_use_device(g->ctx)) return -1;
   if (g->rows) {
-    if (g->n_parts2 == g->P) return gmm_launch_rows(g, d_feats, T, g->P, d_loglikes);
+    if (g->lse_mode == VBH_LSE_FAST || g->n_parts2 == g->P) return gmm_launch_rows(g, d_feats, T, g->P, d_loglikes);
     for (long long t0 = 0; t0 < T; t0 += g->part_chunk2) {
       const long long n = std::min<long long>(g->part_chunk2, T - t0);
       if (gmm_launch_rows(g, d_feats + t0 * g->D, n, g->n_parts2, g->part_scratch2.p)) return -1;
@@ -813,23 +930,24 @@ static int gmm_launch_tiles(vbh_gmm *g, const float *d_feats, long long T, int n
 static int gmm_launch_rows(vbh_gmm *g, const float *d_feats, long long T, int n_cols, float *d_out) {
   const long long ftiles = (T + TM - 1) / TM;
   VBH_CHECK(ftiles < 2147483647LL, "vbh_gmm_loglikes: T too large");
-  // split the row-blocks over blockIdx.y only when there are too few frame tiles to fill the chip
+  const vbh_gmm::RowsPack &pk = g->lse_mode == VBH_LSE_FAST ? g->pack_dense : g->pack_local;
+  // split the superblocks over blockIdx.y only when there are too few frame tiles to fill the chip
   int groups = 1;
   const long long want = 6LL * g->ctx->num_cus;
   if (ftiles < want) {
     groups = (int)((want + ftiles - 1) / ftiles);
-    if (groups > (g->n_rb + 3) / 4) groups = (g->n_rb + 3) / 4;
+    if (groups > (pk.n_sb + 3) / 4) groups = (pk.n_sb + 3) / 4;
   }
-  int per = (g->n_rb + groups - 1) / groups;
+  int per = (pk.n_sb + groups - 1) / groups;
   per = (per + 3) & ~3;
-  groups = (g->n_rb + per - 1) / per;
+  groups = (pk.n_sb + per - 1) / per;
 #define VBH_GMM_LAUNCH_M(N, M)                                                                         \
     {                                                                                                  \
       VBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gmm_rows_kernel<N, M>),              \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds_bytes2));    \
       hipLaunchKernelGGL((gmm_rows_kernel<N, M>), dim3((unsigned)ftiles, groups), dim3(256), g->lds_bytes2, \
-                         g->ctx->stream, d_feats, (long long)T, g->D, n_cols, g->Mp.p, g->rb_meta.p,    \
-                         g->n_rb, per, d_out);                                                         \
+                         g->ctx->stream, d_feats, (long long)T, g->D, n_cols, pk.Mp.p, pk.meta.p,      \
+                         pk.sbs.p, pk.n_sb, per, d_out);                                                \
     }
 #define VBH_GMM_LAUNCH(N)                                                                              \
   case N:                                                                                              \
