@@ -678,7 +678,10 @@ def main():
     else:
         model = feature_space_model(args, feats[sample_idx].cpu().numpy())
     gmm = api.DiagGmm(ctx, *model)
-    ll = torch.empty((T, gmm.num_pdfs), dtype=torch.float32, device=dev)
+    # score rows are padded to a multiple of 32 floats (128-byte lines: the GMM kernel's stores then cover whole sectors, vbh_gmm_loglikes_ld);
+    # the searches take the matrix as it is (their num_pdfs argument is the row length), the pad columns are never read
+    NPAD = gmm.padded_pdfs
+    ll = torch.empty((T, NPAD), dtype=torch.float32, device=dev)
     ctx.torch_sync()
 
     decode_setup = None
@@ -719,7 +722,7 @@ def main():
             lab = torch.as_tensor(np.concatenate([ss.frame_labels(hop_pdf[u:u + 1], int(foff[u + 1] - foff[u]))[0] for u in range(args.batch)]), device=dev).long()
             acc = 0
             for a_ in range(0, T, 1 << 18):
-                acc += int((ll[a_:a_ + (1 << 18)].argmax(1) == lab[a_:a_ + (1 << 18)]).sum())
+                acc += int((ll[a_:a_ + (1 << 18), :gmm.num_pdfs].argmax(1) == lab[a_:a_ + (1 << 18)]).sum())
             best = None
             for _ in range(2):
                 dec.decode(ll, foff, t2p)
@@ -815,6 +818,7 @@ def main():
         if os.environ.get("VBH_PROBE_PROXY"):
             # does a cheap statistic of the scores predict an utterance's search time?
             fo = torch.as_tensor(np.asarray(foff, np.int64), device=dev)
+            ll = ll[:, :gmm.num_pdfs]
             mx = ll.max(dim=1, keepdim=True).values
             for theta in (30.0, 60.0, 100.0, 156.0, 300.0):
                 cnt = torch.zeros(T, device=dev)
@@ -909,7 +913,7 @@ def main():
     else:
         del ll
         ring = [(torch.empty((Ts, raw.shape[1]), dtype=torch.float32, device=dev), torch.empty((Ts, feats.shape[1]), dtype=torch.float32, device=dev),
-                 torch.empty((Ts, gmm.num_pdfs), dtype=torch.float32, device=dev)) for _ in range(n_ring)]
+                 torch.empty((Ts, NPAD), dtype=torch.float32, device=dev)) for _ in range(n_ring)]
     lanes = []
     if dec is not None and (depth > 1 or S > 1):
         dec.close()          # the probe/setup decoder on the front-end context is not used by the pipeline
@@ -965,8 +969,9 @@ def main():
             ctx.sync(); print("item %d: gmm done" % i, file=sys.stderr, flush=True)
         if os.environ.get("VBH_BENCH_CHECK_LL"):     # diagnostic: are the scores sane while search grids are running beside the kernel?
             ctx.sync()
-            bad = int((~torch.isfinite(l_[:n_rows])).sum().item())
-            mn, mx = float(l_[:n_rows].min().item()), float(l_[:n_rows].max().item())
+            lv_ = l_[:n_rows, :gmm.num_pdfs]
+            bad = int((~torch.isfinite(lv_)).sum().item())
+            mn, mx = float(lv_.min().item()), float(lv_.max().item())
             print("item %d: scores non-finite %d, min %.1f max %.1f" % (i, bad, mn, mx), file=sys.stderr, flush=True)
             if check_gmm[0] is not None:
                 worst = 0.0
@@ -974,7 +979,7 @@ def main():
                     b_ = min(n_rows, a_ + (1 << 18))
                     ref_ = check_gmm[0].loglikes(f_[a_:b_])
                     ctx.sync()
-                    worst = max(worst, float((ref_ - l_[a_:b_]).abs().max().item()))
+                    worst = max(worst, float((ref_ - l_[a_:b_, :gmm.num_pdfs]).abs().max().item()))
                     del ref_
                 print("   vs the other GMM kernel: max abs diff %.3g" % worst, file=sys.stderr, flush=True)
         if timed:

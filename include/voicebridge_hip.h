@@ -177,6 +177,11 @@ int vbh_gmm_get_gconsts(const vbh_gmm *g, float *h_gconsts);   /* [G] as compute
 int vbh_gmm_set_lse_mode(vbh_gmm *g, int32_t mode);
 /* d_feats [T x dim] -> d_loglikes [T x num_pdfs] (unscaled log-likelihoods) */
 int vbh_gmm_loglikes(vbh_gmm *g, const float *d_feats, int64_t T, float *d_loglikes);
+/* The same with rows ld >= num_pdfs floats apart (columns num_pdfs..ld-1 are not written).  With ld = vbh_gmm_padded_pdfs()
+ * (num_pdfs rounded up to a multiple of 32: rows start on 128-byte lines) every store of the kernel covers whole 32-byte
+ * sectors; the search entry points take such a matrix as it is: their num_pdfs argument is the row length of d_loglikes. */
+int vbh_gmm_loglikes_ld(vbh_gmm *g, const float *d_feats, int64_t T, float *d_loglikes, int32_t ld);
+int32_t vbh_gmm_padded_pdfs(const vbh_gmm *g);
 /* The on-demand form (the reference's semantics, K/gmm/decodable-am-diag-gmm.cc:28-72: a pdf is evaluated when the search or a
  * lattice asks for it): log-likelihoods of the (frame, pdf) pairs [h_pair_offsets[t], h_pair_offsets[t+1]) of every frame t only;
  * h_out [h_pair_offsets[T]] on the host.  Used by gmm-rescore-lattice.  Synchronises. */
@@ -244,7 +249,8 @@ int vbh_decoder_set_cfg(vbh_decoder *d, const vbh_decode_cfg *cfg);
 void vbh_decoder_destroy(vbh_decoder *d);
 /* Replaces LatticeFasterDecoder::Decode + FinalizeDecoding for a batch of utterances
  * (DecodeUtteranceLatticeFaster, K/decoder/decoder-wrappers.cc:198-293).  d_loglikes
- * [total_frames x num_pdfs] unscaled; h_tid2pdf [num_tids+1] = TransitionModel::id2pdf_id_
+ * [total_frames x num_pdfs] unscaled (num_pdfs is the ROW LENGTH of the matrix: a matrix written by vbh_gmm_loglikes_ld is
+ * passed with its ld, the columns past the model's pdfs are never read); h_tid2pdf [num_tids+1] = TransitionModel::id2pdf_id_
  * (K/hmm/transition-model.h:324-328).  Synchronises; results are read with
  * vbh_decoder_result and stay valid until the next decode call. */
 int vbh_decode_batch(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs,

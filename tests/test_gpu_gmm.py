@@ -76,6 +76,42 @@ def test_gmm_strict_and_twopass_vs_oracle(ctx, P, G, D, T):
         m.close()
 
 
+def test_gmm_padded_rows_and_the_search_on_them(ctx):
+    """vbh_gmm_loglikes_ld: rows padded_pdfs floats apart hold the same scores bit for bit, the pad columns are left alone, and the
+    lattice search gives the same result on the padded matrix (its num_pdfs argument is the row length)"""
+    import torch
+    from voicebridge_amd import api, synth
+    P, G, D, T = 203, 1500, 39, 333
+    offs, w, means, iv = synth.gmm_model(P, G, D, seed=5)
+    miv = (means * iv).astype(np.float32)
+    feats = torch.from_numpy((np.random.default_rng(2).standard_normal((T, D)) * 1.2).astype(np.float32)).to(ctx.device)
+    for mode in ("fast", "strict"):
+        m = api.DiagGmm(ctx, offs, w, miv, iv, lse=mode)
+        assert m.padded_pdfs == 224
+        dense = m.loglikes(feats)
+        pad = torch.full((T, m.padded_pdfs), 7.0, dtype=torch.float32, device=ctx.device)
+        m.loglikes(feats, out=pad)
+        ctx.sync()
+        assert torch.equal(pad[:, :P], dense) and bool((pad[:, P:] == 7.0).all())
+        m.close()
+    # the lattice search on the padded matrix: same words, alignment and counters
+    ntid = 3 * P
+    g = synth.decoding_graph(3000, ntid, seed=9, eps_frac=0.3)
+    t2p = synth.tid2pdf(ntid, P, seed=9)
+    graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
+    foff = np.array([0, 100, 210, 333], np.int64)
+    dec = api.LatticeDecoder(ctx, graph, 3, 123, beam=11.0, max_active=3000, min_active=100, lattice_beam=5.0, acoustic_scale=0.1)
+    out = []
+    for mat in (dense, pad):
+        dec.decode(mat, foff, t2p)
+        out.append([dec.result(u) for u in range(3)])
+    for ra, rb in zip(*out):
+        np.testing.assert_array_equal(ra["words"], rb["words"])
+        np.testing.assert_array_equal(ra["ali"], rb["ali"])
+        assert ra["best_graph"] == rb["best_graph"] and ra["best_acoustic"] == rb["best_acoustic"]
+    dec.close(); graph.close()
+
+
 def test_gmm_reference_sizes_property(ctx):
     """BASELINE sizes (P=2500, G=15000, D=39): scoring a frame batch must equal scoring its
     rows one tile at a time in any order (each output depends on its own frame only), and a

@@ -1,0 +1,19 @@
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_gpu_gmm.py tests/test_gpu_e2e.py tests/test_gpu_binfuncs.py tests/test_gpu_align.py -m gpu -x -q > gpurun_out/r3_26_tests.log 2>&1 ; tail -5 gpurun_out/r3_26_tests.log
+VBH_DEBUG_GMM_PACK=1 timeout -k 10 150 python tools/gmm_time.py 2>gpurun_out/gmm_time.err || tail -5 gpurun_out/gmm_time.err; grep packing gpurun_out/gmm_time.err
+LD=2528 timeout -k 10 150 python tools/gmm_time.py 2>gpurun_out/gmm_time.err || tail -5 gpurun_out/gmm_time.err
+bash tools/pmc_gmm.sh r3i "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"
+cd $GRAFT_REPO_ROOT
+python - <<'PY' | tee gpurun_out/r3i_summary.txt
+import csv,glob,collections
+for d in sorted(glob.glob('gpurun_out/pmc_r3i_*')):
+    if not d[-1].isdigit(): continue
+    for f in glob.glob(d+'/**/*counter_collection.csv', recursive=True):
+        acc=collections.defaultdict(float); n=collections.Counter()
+        for r in csv.DictReader(open(f)):
+            for k in ('gmm_rows',):
+                if k in r['Kernel_Name']:
+                    acc[(k,r['Counter_Name'])]+=float(r['Counter_Value']); n[(k,r['Counter_Name'])]+=1
+        for k in acc: print(d, k, acc[k], n[k])
+PY
+rm -rf gpurun_out/pmc_r3i_*/

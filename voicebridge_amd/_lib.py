@@ -17,7 +17,7 @@ SYMBOLS = [
     "vbh_mfcc_opts_default", "vbh_mfcc_num_frames", "vbh_mfcc_create", "vbh_mfcc_destroy", "vbh_mfcc_compute", "vbh_mfcc_set_dither_stream", "vbh_mfcc_set_dither_ids",
     "vbh_featpost_out_dim", "vbh_featpost", "vbh_cmvn_stats",
     "vbh_gmm_create", "vbh_gmm_destroy", "vbh_gmm_num_pdfs", "vbh_gmm_dim", "vbh_gmm_get_gconsts",
-    "vbh_gmm_set_lse_mode", "vbh_gmm_loglikes", "vbh_gmm_loglikes_pairs", "vbh_gmm_work",
+    "vbh_gmm_set_lse_mode", "vbh_gmm_loglikes", "vbh_gmm_loglikes_ld", "vbh_gmm_padded_pdfs", "vbh_gmm_loglikes_pairs", "vbh_gmm_work",
     "vbh_graph_create", "vbh_graph_destroy", "vbh_decode_cfg_default", "vbh_decoder_create", "vbh_decoder_create_shared", "vbh_decoder_set_cfg",
     "vbh_decoder_destroy", "vbh_decode_batch", "vbh_decode_batch_begin", "vbh_decode_batch_end", "vbh_decoder_result", "vbh_decoder_phase_cycles", "vbh_decoder_diag",
     "vbh_decoder_times", "vbh_decoder_utt_timeline", "vbh_decoder_batch_stats",
@@ -119,6 +119,9 @@ def load():
     lib.vbh_gmm_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_float),
                                    C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_void_p)]
     lib.vbh_gmm_loglikes.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.vbh_gmm_loglikes_ld.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
+    lib.vbh_gmm_padded_pdfs.argtypes = [C.c_void_p]
+    lib.vbh_gmm_padded_pdfs.restype = C.c_int32
     lib.vbh_gmm_get_gconsts.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.vbh_gmm_work.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.vbh_gmm_set_lse_mode.argtypes = [C.c_void_p, C.c_int32]

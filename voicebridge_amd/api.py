@@ -233,13 +233,23 @@ class DiagGmm:
         check(self.lib.vbh_gmm_get_gconsts(self.h, _f32p(out)), "vbh_gmm_get_gconsts")
         return out
 
-    def loglikes(self, d_feats, out=None):
+    @property
+    def padded_pdfs(self):
+        """num_pdfs rounded up to a multiple of 32: the row length at which the kernel's stores cover whole sectors (vbh_gmm_padded_pdfs)"""
+        return int(self.lib.vbh_gmm_padded_pdfs(self.h))
+
+    def loglikes(self, d_feats, out=None, padded=False):
+        """[T x num_pdfs] scores; `out` may have longer rows (out.stride(0) >= num_pdfs, e.g. [T x padded_pdfs]: the decoders take
+        such a matrix as it is, its extra columns are never read); padded=True allocates that form"""
         T = d_feats.shape[0]
         fresh = out is None
         if fresh:
-            out = torch.empty((T, self.num_pdfs), dtype=torch.float32, device=self.ctx.device)
+            out = torch.empty((T, self.padded_pdfs if padded else self.num_pdfs), dtype=torch.float32, device=self.ctx.device)
             self.ctx.torch_sync()
-        check(self.lib.vbh_gmm_loglikes(self.h, d_feats.data_ptr(), T, out.data_ptr()), "vbh_gmm_loglikes")
+        if T > 0:
+            assert out.stride(1) == 1 and out.shape[0] >= T
+            check(self.lib.vbh_gmm_loglikes_ld(self.h, d_feats.data_ptr(), T, out.data_ptr(), int(out.stride(0)) if T > 1 or out.shape[0] > 1 else int(out.shape[1])),
+                  "vbh_gmm_loglikes_ld")
         if fresh:
             self.ctx.sync()
         return out

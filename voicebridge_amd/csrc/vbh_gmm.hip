@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void gmm_loglikes_kernel(
 //     barrier) and a small per-wave staging area for the output runs;
 //   * the four waves of a workgroup work on different row-blocks and never meet: NO barrier in the block loop.
 // The model is packed once (vbh_gmm_create) into row-blocks of 32 Gaussians, the row-blocks into SUPERBLOCKS (runs of consecutive
-// row-blocks, sbs[] = first row-block of each); wave w of a workgroup takes the superblocks w, w + 4, ... of its group and walks
+// row-blocks, sbs[] = {first, end} row-block of each); wave w of a workgroup takes the superblocks w, w + 4, ... of its group and walks
 // the row-blocks of a superblock in order.  Two packings:
 //   * dense (the default LogSumExp, VBH_LSE_FAST): the Gaussians one after the other, a pdf may run over the end of a row-block into
 //     the next one of the same superblock -- the online LogSumExp just carries its (maximum, sum) pair on in the lane -- so only the
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
     const float *__restrict__ feats, long long T, int D, int P,
     const f32x4 *__restrict__ Mp,            // [n_rb][NC][64 lanes]: Mp[(rb*NC + c)*64 + lane][j] = row (lane & 31), k = 2(4c + j) + (lane >> 5)
     const RbMeta *__restrict__ meta, const int *__restrict__ sbs, int n_sb, int sb_per_group,
-    float *__restrict__ out) {
+    float *__restrict__ out, int ld) {                 // out rows are ld floats apart (ld >= P)
   extern __shared__ __align__(16) float lds[];
   constexpr int Kpad = NC * 8;
   float *sA = lds;                                   // [Kpad][LDA]: [x, x^2, 1, 0..] of 64 frames, k-major
@@ -282,11 +282,12 @@ __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
   const int khalf = lane >> 5, l31 = lane & 31;
   float *stage = sStage + wid * (TM * LDP);
   const float *pb = sA + khalf * LDA + l31;
-  int rb = sbs[sb], rb_end = sbs[sb + 1];
-  // where this wave's output runs go: out + (t0 P + p0) is wave-uniform, the rest fits 32 bits
+  int rb = sbs[2 * sb], rb_end = sbs[2 * sb + 1];
+  // where this wave's output runs go: out + (t0 ld + p0) is wave-uniform, the rest fits 32 bits
   const int fmax = T - t0 < TM ? (int)(T - t0) : TM;
-  float *const out0 = out + t0 * P;
+  float *const out0 = out + t0 * ld;
   int pend = 0, pend_p0 = 0;              // VBH_LSE_FAST: finished pdfs waiting in the staging area, the first one's index
+  const bool lines = (ld & 15) == 0 && (reinterpret_cast<size_t>(out) & 63) == 0;     // rows start on 64-byte boundaries
   f32x4 sa[NC], sb2[NC];
 #pragma unroll
   for (int c = 0; c < NC; c++) sa[c] = Mp[((size_t)rb * NC + c) * 64 + lane];
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
     int nrb = rb + 1, nsb = sb, nend = rb_end;
     if (nrb == rb_end) {
       nsb = sb + 4;
-      if (nsb < sb_end) { nrb = sbs[nsb]; nend = sbs[nsb + 1]; } else nrb = -1;
+      if (nsb < sb_end) { nrb = sbs[2 * nsb]; nend = sbs[2 * nsb + 1]; } else nrb = -1;
     }
     // its strip: in flight under this block's MFMAs
     {
@@ -371,9 +372,14 @@ __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
       if (pend >= 16 || nsb != sb) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // whole groups of four pdfs: lanes along (frame, group), 16 bytes each; what is left over (< 4 pdfs) waits for the next run,
-        // or, at the end of a superblock, leaves from the lane that made it (lane = frame)
-        const int n4 = pend & ~3, nch = pend >> 2, rem = pend - n4;
+        // groups of four pdfs, lanes along (frame, group), 16 bytes each.  Inside a superblock the run goes up to the last 64-byte
+        // boundary of the row, the pdfs behind it wait for the next run; superblocks start at pdfs that are multiples of 8: with ld a
+        // multiple of 16 a run is whole 32-byte sectors and, but for a superblock's first and last, whole 64-byte halves of a line
+        // (L2 writes back dirty 64-byte halves: one that two runs share is written twice).  At the end of a superblock the whole
+        // run leaves, what does not fill a group of four from the lane that made it (lane = frame).
+        const bool last = nsb != sb;
+        const int n_out = last ? pend : (((pend_p0 + pend) & ~15) - pend_p0) & ~3;
+        const int nch = n_out >> 2, n4 = nch << 2;
         if (nch > 0) {
           const unsigned inv = (65536u + (unsigned)nch - 1u) / (unsigned)nch;
           const int total = TM * nch;
@@ -382,21 +388,26 @@ __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
             const int f = (int)(((unsigned)idx * inv) >> 16), c = idx - f * nch;
             if (f < fmax) {
               const float *src = stage + f * LDP + 4 * c;
-              f32x4u v; v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
-              *reinterpret_cast<f32x4u *>(ob + f * P + 4 * c) = v;
+              if (lines) {      // whole 64-byte halves of lines, nothing of them to come later: streamed past the L2's allocation
+                f32x4 v = {src[0], src[1], src[2], src[3]};
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(ob + f * ld + 4 * c));
+              } else {
+                f32x4u v; v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
+                *reinterpret_cast<f32x4u *>(ob + f * ld + 4 * c) = v;
+              }
             }
           }
         }
-        if (nsb != sb) {
+        if (last) {
           if (lane < fmax)
-            for (int j = 0; j < rem; j++) out0[lane * P + pend_p0 + n4 + j] = so[n4 + j];
+            for (int j = n4; j < pend; j++) out0[lane * ld + pend_p0 + j] = so[j];
           pend = 0;
         } else {
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          for (int j = 0; j < rem; j++) so[j] = so[n4 + j];
+          for (int j = n4; j < pend; j++) so[j - n4] = so[j];
           pend_p0 += n4;
-          pend = rem;
+          pend -= n4;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -446,7 +457,7 @@ __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
       float *const ob = out0 + p0;
       for (int idx = lane; idx < total; idx += 64) {
         const int f = (int)(((unsigned)idx * inv) >> 16), q = idx - f * np;
-        if (f < fmax) ob[f * P + q] = stage[f * LDP + q];
+        if (f < fmax) ob[f * ld + q] = stage[f * LDP + q];
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -464,7 +475,7 @@ __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
 __global__ __launch_bounds__(256) void gmm_fold_parts_kernel(
     const float *__restrict__ parts, long long T, int n_parts, int P,
     const int *__restrict__ pdf_parts,     // [P+1] first part of every pdf
-    float *__restrict__ out, int strict) {
+    float *__restrict__ out, int ld, int strict) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= T * P) return;
   const long long t = idx / P;
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(256) void gmm_fold_parts_kernel(
       res = m + __logf(sum);
     }
   }
-  out[idx] = res;
+  out[t * ld + p] = res;
 }
 
 // On-demand form (DecodableAmDiagGmmUnmapped::LogLikelihoodZeroBased, K/gmm/decodable-am-diag-gmm.cc:28-72): only the
@@ -681,7 +692,7 @@ int vbh_gmm_create(vbh_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h
     // rows (row_gauss[i] = Gaussian of packed row i, -1 = gap row) -> the MFMA A-operand strips, with the block table
     auto upload_pack = [&](vbh_gmm::RowsPack &pk, const std::vector<int> &row_gauss, const std::vector<RbMeta> &meta, const std::vector<int> &sbs) -> int {
       pk.n_rb = (int)meta.size();
-      pk.n_sb = (int)sbs.size() - 1;
+      pk.n_sb = (int)sbs.size() / 2;
       std::vector<f32x4> Mp((size_t)pk.n_rb * NC * 64);
       for (int rb = 0; rb < pk.n_rb; rb++)
         for (int c = 0; c < NC; c++)
@@ -702,45 +713,80 @@ int vbh_gmm_create(vbh_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h
       return pk.Mp.upload(Mp.data(), Mp.size(), s) || pk.meta.upload(meta.data(), meta.size(), s) || pk.sbs.upload(sbs.data(), sbs.size(), s);
     };
     {
-      // dense: the Gaussians in order; a superblock closes at the first pdf end at or past its share of the rows (near-equal superblocks of
-      // ~8 row-blocks, their number a multiple of 4 where the model is large enough), its last row-block is filled up with gap rows;
-      // a row-block in which 16 pdfs end already takes no further pdf end (the staging area's row): gap rows to its end
+      // dense: the Gaussians in order, cut into ~G/256 superblocks (a multiple of 4) at pdfs whose index is a multiple of 16 (the output
+      // runs of a superblock then start on a 64-byte boundary of the row); of the multiples of 16 near a superblock's share of the rows
+      // the cut is the one that leaves the fewest unused rows in its last row-block; a row-block in which 16 pdfs end already takes no
+      // further pdf end (the staging area's row): gap rows to its end.  The superblocks are then dealt to the four waves longest first,
+      // each to the wave with the least so far, so that the waves of a workgroup get the same number of row-blocks (table entry i
+      // belongs to wave i % 4).
       std::vector<RbMeta> meta;
-      std::vector<int> row_gauss, sbs(1, 0);
+      std::vector<int> row_gauss;
       int want_sb = 4 * (int)((G + 4 * 256 / 2) / (4 * 256));
       if (want_sb < 4) want_sb = 4;
       if (want_sb > P) want_sb = P;
-      auto close_block_rows = [&]() { while (row_gauss.size() % 32) row_gauss.push_back(-1); };
-      auto block_of = [&](size_t row) { return row / 32; };
+      int step = P >= 32 * want_sb ? 16 : P >= 16 * want_sb ? 8 : 1;
+      if (const char *e = getenv("VBH_GMM_CUT_STEP")) step = std::max(1, atoi(e));
+      std::vector<int> cut(1, 0);            // first pdf of every superblock
+      for (int i = 1; i < want_sb; i++) {
+        const long long target = (long long)G * i / want_sb;
+        const int pt = (int)(std::lower_bound(h_pdf_offsets, h_pdf_offsets + P + 1, (int)target) - h_pdf_offsets);
+        const int base = (pt + step / 2) / step * step;
+        int best = -1, best_pad = 0; long long best_dist = 0;
+        for (int k = -2; k <= 2; k++) {
+          const int c = base + k * step;
+          if (c <= cut.back() || c >= P) continue;
+          const int rows = h_pdf_offsets[c] - h_pdf_offsets[cut.back()], pad = (32 - rows % 32) % 32;
+          const long long dist = std::llabs((long long)h_pdf_offsets[c] - target);
+          if (best < 0 || pad < best_pad || (pad == best_pad && dist < best_dist)) { best = c; best_pad = pad; best_dist = dist; }
+        }
+        if (best > 0) cut.push_back(best);
+      }
+      cut.push_back(P);
+      const int n_sb = (int)cut.size() - 1;
+      std::vector<int> sb_first(n_sb), sb_end(n_sb);
       std::vector<int> ends;             // pdf ends per row-block so far
       std::vector<unsigned> endmask;
       std::vector<int> first_end;
-      auto note_end = [&](size_t row, int pdf) {
-        const size_t b = block_of(row);
-        if (ends.size() <= b) { ends.resize(b + 1, 0); endmask.resize(b + 1, 0u); first_end.resize(b + 1, 0); }
-        if (ends[b] == 0) first_end[b] = pdf;
-        ends[b]++;
-        endmask[b] |= 1u << (row % 32);
-      };
-      int sb_i = 0;
-      for (int p = 0; p < P; p++) {
-        const int n = h_pdf_offsets[p + 1] - h_pdf_offsets[p];
-        const size_t last = row_gauss.size() + n - 1;
-        if (block_of(last) < ends.size() && ends[block_of(last)] >= 16) close_block_rows();
-        for (int gi = h_pdf_offsets[p]; gi < h_pdf_offsets[p + 1]; gi++) row_gauss.push_back(gi);
-        note_end(row_gauss.size() - 1, p);
-        // this superblock's share of the Gaussians is used up (the last one takes what is left)
-        if (sb_i + 1 < want_sb && (long long)h_pdf_offsets[p + 1] * want_sb >= (long long)G * (sb_i + 1) && p + 1 < P) {
-          close_block_rows();
-          sbs.push_back((int)(row_gauss.size() / 32));
-          while ((long long)h_pdf_offsets[p + 1] * want_sb >= (long long)G * (sb_i + 1)) sb_i++;      // (a pdf larger than a share uses up several)
+      for (int i = 0; i < n_sb; i++) {
+        sb_first[i] = (int)(row_gauss.size() / 32);
+        for (int p = cut[i]; p < cut[i + 1]; p++) {
+          const int n = h_pdf_offsets[p + 1] - h_pdf_offsets[p];
+          const size_t last = row_gauss.size() + n - 1;
+          if (last / 32 < ends.size() && ends[last / 32] >= 16) while (row_gauss.size() % 32) row_gauss.push_back(-1);
+          for (int gi = h_pdf_offsets[p]; gi < h_pdf_offsets[p + 1]; gi++) row_gauss.push_back(gi);
+          const size_t row = row_gauss.size() - 1, b = row / 32;
+          if (ends.size() <= b) { ends.resize(b + 1, 0); endmask.resize(b + 1, 0u); first_end.resize(b + 1, 0); }
+          if (ends[b] == 0) first_end[b] = p;
+          ends[b]++;
+          endmask[b] |= 1u << (row % 32);
         }
+        while (row_gauss.size() % 32) row_gauss.push_back(-1);
+        sb_end[i] = (int)(row_gauss.size() / 32);
       }
-      close_block_rows();
-      sbs.push_back((int)(row_gauss.size() / 32));
       const int n_rb = (int)(row_gauss.size() / 32);
       ends.resize(n_rb, 0); endmask.resize(n_rb, 0u); first_end.resize(n_rb, 0);
       for (int b = 0; b < n_rb; b++) meta.push_back(RbMeta{endmask[b], first_end[b], ends[b], 0});
+      std::vector<int> order(n_sb), sbs(2 * (size_t)n_sb);
+      for (int i = 0; i < n_sb; i++) order[i] = i;
+      if (n_sb % 4 == 0) {
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sb_end[a] - sb_first[a] > sb_end[b] - sb_first[b]; });
+        std::vector<int> dealt(n_sb);
+        int load[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
+        for (int i = 0; i < n_sb; i++) {          // longest first, each to the wave with the least so far (of those not yet full)
+          int w = -1;
+          for (int k = 0; k < 4; k++) if (cnt[k] < n_sb / 4 && (w < 0 || load[k] < load[w])) w = k;
+          dealt[4 * cnt[w] + w] = order[i];
+          cnt[w]++; load[w] += sb_end[order[i]] - sb_first[order[i]];
+        }
+        order = dealt;
+      }
+      for (int i = 0; i < n_sb; i++) { sbs[2 * i] = sb_first[order[i]]; sbs[2 * i + 1] = sb_end[order[i]]; }
+      if (getenv("VBH_DEBUG_GMM_PACK")) {
+        int per_wave[4] = {0, 0, 0, 0};
+        for (int i = 0; i < n_sb; i++) per_wave[i % 4] += sbs[2 * i + 1] - sbs[2 * i];
+        fprintf(stderr, "vbh_gmm dense packing: %d Gaussians in %d row-blocks (%.1f %% unused rows), %d superblocks, row-blocks per wave %d %d %d %d\n",
+                G, n_rb, 100.0 * (32.0 * n_rb - G) / (32.0 * n_rb), n_sb, per_wave[0], per_wave[1], per_wave[2], per_wave[3]);
+      }
       if (upload_pack(g->pack_dense, row_gauss, meta, sbs)) { delete g; return -1; }
     }
     // block-local: parts of <= 32 Gaussians, row-blocks of whole parts (<= 16 of them)
@@ -767,7 +813,7 @@ int vbh_gmm_create(vbh_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h
         for (; rows_used < 32; rows_used++) row_gauss.push_back(-1);
         meta.push_back(m);
       }
-      for (int i = 0; i <= (int)meta.size(); i++) sbs.push_back(i);
+      for (int i = 0; i < (int)meta.size(); i++) { sbs.push_back(i); sbs.push_back(i + 1); }
       if (upload_pack(g->pack_local, row_gauss, meta, sbs)) { delete g; return -1; }
     }
     if (NP2 > P) {
@@ -860,26 +906,35 @@ int vbh_gmm_work(const vbh_gmm *g, int64_t T, double *bytes, double *flops) {
 }
 
 static int gmm_launch_tiles(vbh_gmm *g, const float *d_feats, long long T, int n_cols, float *d_out);
-static int gmm_launch_rows(vbh_gmm *g, const float *d_feats, long long T, int n_cols, float *d_out);
+static int gmm_launch_rows(vbh_gmm *g, const float *d_feats, long long T, int n_cols, float *d_out, int ld);
 
 int vbh_gmm_loglikes(vbh_gmm *g, const float *d_feats, int64_t T, float *d_loglikes) {
   VBH_CHECK(g, "vbh_gmm_loglikes: NULL model");
+  return vbh_gmm_loglikes_ld(g, d_feats, T, d_loglikes, g->P);
+}
+
+int32_t vbh_gmm_padded_pdfs(const vbh_gmm *g) { return (g->P + 31) & ~31; }
+
+int vbh_gmm_loglikes_ld(vbh_gmm *g, const float *d_feats, int64_t T, float *d_loglikes, int32_t ld) {
+  VBH_CHECK(g, "vbh_gmm_loglikes: NULL model");
+  VBH_CHECK(ld >= g->P && ld < (1 << 24), "vbh_gmm_loglikes: row length %d for %d pdfs", ld, g->P);
   if (T == 0) return 0;
   VBH_CHECK(T > 0 && d_feats && d_loglikes, "vbh_gmm_loglikes: bad arguments");
   if (vbh_use_device(g->ctx)) return -1;
   if (g->rows) {
-    if (g->lse_mode == VBH_LSE_FAST || g->n_parts2 == g->P) return gmm_launch_rows(g, d_feats, T, g->P, d_loglikes);
+    if (g->lse_mode == VBH_LSE_FAST || g->n_parts2 == g->P) return gmm_launch_rows(g, d_feats, T, g->P, d_loglikes, ld);
     for (long long t0 = 0; t0 < T; t0 += g->part_chunk2) {
       const long long n = std::min<long long>(g->part_chunk2, T - t0);
-      if (gmm_launch_rows(g, d_feats + t0 * g->D, n, g->n_parts2, g->part_scratch2.p)) return -1;
+      if (gmm_launch_rows(g, d_feats + t0 * g->D, n, g->n_parts2, g->part_scratch2.p, g->n_parts2)) return -1;
       const long long blocks = (n * g->P + 255) / 256;
       VBH_CHECK(blocks < 2147483647LL, "vbh_gmm_loglikes: chunk too large");
       hipLaunchKernelGGL(gmm_fold_parts_kernel, dim3((unsigned)blocks), dim3(256), 0, g->ctx->stream,
-                         g->part_scratch2.p, n, g->n_parts2, g->P, g->d_pdf_parts2.p, d_loglikes + t0 * g->P, (int)(g->lse_mode == VBH_LSE_STRICT));
+                         g->part_scratch2.p, n, g->n_parts2, g->P, g->d_pdf_parts2.p, d_loglikes + t0 * ld, (int)ld, (int)(g->lse_mode == VBH_LSE_STRICT));
       VBH_HIP(hipGetLastError());
     }
     return 0;
   }
+  VBH_CHECK(ld == g->P, "vbh_gmm_loglikes: the tile kernel (VBH_GMM_V1) writes dense rows only");
   if (g->n_parts == g->P) return gmm_launch_tiles(g, d_feats, T, g->P, d_loglikes);
   // some pdf spans several column groups: score the parts of a chunk of frames, fold them
   for (long long t0 = 0; t0 < T; t0 += g->part_chunk) {
@@ -888,7 +943,7 @@ int vbh_gmm_loglikes(vbh_gmm *g, const float *d_feats, int64_t T, float *d_logli
     const long long blocks = (n * g->P + 255) / 256;
     VBH_CHECK(blocks < 2147483647LL, "vbh_gmm_loglikes: chunk too large");
     hipLaunchKernelGGL(gmm_fold_parts_kernel, dim3((unsigned)blocks), dim3(256), 0, g->ctx->stream,
-                       g->part_scratch.p, n, g->n_parts, g->P, g->d_pdf_parts.p, d_loglikes + t0 * g->P, 0);
+                       g->part_scratch.p, n, g->n_parts, g->P, g->d_pdf_parts.p, d_loglikes + t0 * g->P, g->P, 0);
     VBH_HIP(hipGetLastError());
   }
   return 0;
@@ -927,7 +982,7 @@ static int gmm_launch_tiles(vbh_gmm *g, const float *d_feats, long long T, int n
   return 0;
 }
 
-static int gmm_launch_rows(vbh_gmm *g, const float *d_feats, long long T, int n_cols, float *d_out) {
+static int gmm_launch_rows(vbh_gmm *g, const float *d_feats, long long T, int n_cols, float *d_out, int ld) {
   const long long ftiles = (T + TM - 1) / TM;
   VBH_CHECK(ftiles < 2147483647LL, "vbh_gmm_loglikes: T too large");
   const vbh_gmm::RowsPack &pk = g->lse_mode == VBH_LSE_FAST ? g->pack_dense : g->pack_local;
@@ -947,7 +1002,7 @@ static int gmm_launch_rows(vbh_gmm *g, const float *d_feats, long long T, int n_
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds_bytes2));    \
       hipLaunchKernelGGL((gmm_rows_kernel<N, M>), dim3((unsigned)ftiles, groups), dim3(256), g->lds_bytes2, \
                          g->ctx->stream, d_feats, (long long)T, g->D, n_cols, pk.Mp.p, pk.meta.p,      \
-                         pk.sbs.p, pk.n_sb, per, d_out);                                                \
+                         pk.sbs.p, pk.n_sb, per, d_out, ld);                                            \
     }
 #define VBH_GMM_LAUNCH(N)                                                                              \
   case N:                                                                                              \

@@ -78,9 +78,10 @@ void AlignBatch(vbh_ctx *ctx, vbh_gmm *gmm, const vbio::Model &model, const std:
     max_T = std::max(max_T, m.rows);
   }
   const int64_t T = foff.back();
-  DevMem d_in(ctx, sizeof(float) * data.size()), d_ll(ctx, sizeof(float) * (size_t)T * model.num_pdfs);
+  const int32_t ld = vbh_gmm_padded_pdfs(gmm);       // score rows on 128-byte lines; the search takes ld as its row length
+  DevMem d_in(ctx, sizeof(float) * data.size()), d_ll(ctx, sizeof(float) * (size_t)T * ld);
   Check(vbh_copy_h2d(ctx, d_in.p, data.data(), sizeof(float) * data.size()), "vbh_copy_h2d");
-  Check(vbh_gmm_loglikes(gmm, (const float *)d_in.p, T, (float *)d_ll.p), "vbh_gmm_loglikes");
+  Check(vbh_gmm_loglikes_ld(gmm, (const float *)d_in.p, T, (float *)d_ll.p, ld), "vbh_gmm_loglikes");
   vbh_graph *g = nullptr;
   Check(vbh_graph_create(ctx, (int32_t)fin.size(), starts[0], fin.data(), aoff.data(), arcs.data(), &g), "vbh_graph_create");
   vbh_faster_cfg cfg;
@@ -91,7 +92,7 @@ void AlignBatch(vbh_ctx *ctx, vbh_gmm *gmm, const vbio::Model &model, const std:
   if (vbh_faster_decoder_create_ex(ctx, g, &cfg, (int32_t)utts.size(), max_T, max_states, &dec) != 0) {
     const std::string e = vbh_last_error(); vbh_graph_destroy(g); throw ApiError("vbh_faster_decoder_create: " + e);
   }
-  const int rc = vbh_faster_decode_batch_ex(dec, (const float *)d_ll.p, model.num_pdfs, foff.data(), (int32_t)utts.size(), model.tid2pdf.data(),
+  const int rc = vbh_faster_decode_batch_ex(dec, (const float *)d_ll.p, ld, foff.data(), (int32_t)utts.size(), model.tid2pdf.data(),
                                             (int32_t)model.tid2pdf.size() - 1, starts.data(), 0.0f);
   if (rc != 0) { const std::string e = vbh_last_error(); vbh_faster_decoder_destroy(dec); vbh_graph_destroy(g); throw ApiError("vbh_faster_decode_batch: " + e); }
   for (size_t i = 0; i < utts.size(); i++) {

@@ -868,8 +868,9 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
       if (fdim != model.dim)
         throw ApiError(fe.fused ? "Dim mismatch: front end gives dim " + std::to_string(fdim) + " vs. model dim = " + std::to_string(model.dim)
                                 : "Dim mismatch: data dim = " + std::to_string(fdim) + " vs. model dim = " + std::to_string(model.dim));
-      struct { void *p; } d_ll{g_latgen.Scores(ctx, sizeof(float) * (size_t)T * model.num_pdfs)};
-      Check(vbh_gmm_loglikes(gmm, d_feats_p, T, (float *)d_ll.p), "vbh_gmm_loglikes");
+      const int32_t ld = vbh_gmm_padded_pdfs(gmm);      // score rows on 128-byte lines (vbh_gmm_loglikes_ld); the search takes ld as its row length
+      struct { void *p; } d_ll{g_latgen.Scores(ctx, sizeof(float) * (size_t)T * ld)};
+      Check(vbh_gmm_loglikes_ld(gmm, d_feats_p, T, (float *)d_ll.p, ld), "vbh_gmm_loglikes");
       // the decoder (tens of GB of search workspace at the reference's batch sizes) is kept across the batches of the table
       // and only rebuilt when a batch needs more utterances or longer ones than it was made for
       if (dec == nullptr || (int)b.keys.size() > dec_batch || max_T > dec_T) {
@@ -880,7 +881,7 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
         if (ws_cfg.max_active != cfg.max_active) Check(vbh_decoder_set_cfg(dec, &cfg), "vbh_decoder_set_cfg");
         lap("front end + decoder create");
       }
-      const int rc = vbh_decode_batch(dec, (const float *)d_ll.p, model.num_pdfs, b.offs.data(), (int32_t)b.keys.size(),
+      const int rc = vbh_decode_batch(dec, (const float *)d_ll.p, ld, b.offs.data(), (int32_t)b.keys.size(),
                                       model.tid2pdf.data(), (int32_t)model.tid2pdf.size() - 1);
       if (rc != 0) throw ApiError(std::string("vbh_decode_batch: ") + vbh_last_error());
       lap("scores + search");
@@ -1121,7 +1122,8 @@ int GmmDecodeFaster(int argc, char *argv[], std::ofstream &file_log) {
       if (b.keys.empty()) break;
       lap("read features of a batch");
       const int64_t T = b.frames();
-      DevMem d_in(ctx, sizeof(float) * b.data.size()), d_ll(ctx, sizeof(float) * (size_t)T * model.num_pdfs);
+      const int32_t ld = vbh_gmm_padded_pdfs(gmm);
+      DevMem d_in(ctx, sizeof(float) * b.data.size()), d_ll(ctx, sizeof(float) * (size_t)T * ld);
       Check(vbh_copy_h2d(ctx, d_in.p, b.data.data(), sizeof(float) * b.data.size()), "vbh_copy_h2d");
       std::unique_ptr<DevMem> d_fe;
       const float *d_feats_p = (const float *)d_in.p;
@@ -1160,10 +1162,10 @@ int GmmDecodeFaster(int argc, char *argv[], std::ofstream &file_log) {
                            fe_lda.data.empty() ? nullptr : fe_lda.data.data(), xf.empty() ? nullptr : xf.data(), (float *)d_fe->p), "vbh_featpost");
         d_feats_p = (const float *)d_fe->p;
       }
-      Check(vbh_gmm_loglikes(gmm, d_feats_p, T, (float *)d_ll.p), "vbh_gmm_loglikes");
+      Check(vbh_gmm_loglikes_ld(gmm, d_feats_p, T, (float *)d_ll.p, ld), "vbh_gmm_loglikes");
       vbh_faster_decoder *dec = nullptr;
       Check(vbh_faster_decoder_create(ctx, g, &cfg, (int32_t)b.keys.size(), max_T, &dec), "vbh_faster_decoder_create");
-      const int rc = vbh_faster_decode_batch(dec, (const float *)d_ll.p, model.num_pdfs, b.offs.data(), (int32_t)b.keys.size(),
+      const int rc = vbh_faster_decode_batch(dec, (const float *)d_ll.p, ld, b.offs.data(), (int32_t)b.keys.size(),
                                              model.tid2pdf.data(), (int32_t)model.tid2pdf.size() - 1);
       if (rc != 0) { const std::string e = vbh_last_error(); vbh_faster_decoder_destroy(dec); throw ApiError("vbh_faster_decode_batch: " + e); }
       for (size_t u = 0; u < b.keys.size(); u++) {
