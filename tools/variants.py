@@ -1,4 +1,4 @@
-"""Experiment helper: build variants of the decode kernel into voicebridge_amd/lib/variants/ and
+"""Experiment helper: build variants of one kernel source (vbh_decode.hip unless SRC is another of the library's sources) into voicebridge_amd/lib/variants/ and
 (on the GPU box) time each with `bench.py --probe`.
 
   python tools/variants.py build NAME=SRC[:FLAG[:FLAG...]] ...   (here; SRC may live outside the repo)
@@ -32,7 +32,8 @@ def build(specs):
     for name, obj, p in procs:
         if p.wait() != 0:
             raise SystemExit("build failed: " + name)
-        objs = [os.path.join(B.LIBDIR, "obj", s.replace(".hip", ".o")) for s in B.HIP_SOURCES if s != "vbh_decode.hip"] + [obj]
+        replaced = os.path.basename(src) if os.path.basename(src) in B.HIP_SOURCES else "vbh_decode.hip"      # (the product object the variant stands in for)
+        objs = [os.path.join(B.LIBDIR, "obj", s.replace(".hip", ".o")) for s in B.HIP_SOURCES if s != replaced] + [obj]
         lib = os.path.join(VDIR, "libvoicebridge_hip_%s.so" % name)
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
         os.remove(obj)

@@ -403,9 +403,9 @@ class Determinizer {
   struct TaskWorse { bool operator()(const Task *a, const Task *b) const { return a->priority_cost > b->priority_cost; } };
   struct SubsetKey {   // states and strings only; weights are compared with a tolerance (:428-441)
     size_t operator()(const std::vector<Element> *s) const {
-      size_t hash = 0, factor = 1;
-      for (const Element &e : *s) { hash *= factor; hash += (size_t)e.state + 103333u * (size_t)e.string; factor *= 23531; }
-      return hash;
+      uint64_t h = 0x9E3779B97F4A7C15ull;        // (order-dependent mix of the (state, string) pairs; any hash would do: equality decides)
+      for (const Element &e : *s) { h ^= (uint64_t)(uint32_t)e.state | ((uint64_t)(uint32_t)e.string << 32); h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 31; }
+      return (size_t)h;
     }
   };
   struct SubsetEqual {
@@ -913,9 +913,10 @@ bool MinimizeCompactLattice(CompactLattice *clat, float delta) {
   std::vector<uint64_t> hash(n);
   for (int32_t s = n - 1; s >= 0; s--) {
     const CState &st = clat->st[s];
-    uint64_t h = IsZeroC(st.final) ? 33317ull : 607ull * hash_str(st.final.str);
-    for (const CArc &arc : st.arcs)        // (a sum: the order of the arcs must not matter)
-      h += 1447ull * (uint64_t)(arc.label == 0 ? 51907 : arc.label) * (1ull + hash_str(arc.w.str) * (arc.next > s ? hash[arc.next] : 1ull));
+    // (mixing: splitmix64's multipliers; a sum over the arcs, so that their order does not matter)
+    uint64_t h = IsZeroC(st.final) ? 0x632BE59BD9B4E019ull : 0xBF58476D1CE4E5B9ull * hash_str(st.final.str);
+    for (const CArc &arc : st.arcs)
+      h += 0x94D049BB133111EBull * ((uint64_t)(uint32_t)arc.label + 0x9E3779B9ull) * (1ull + hash_str(arc.w.str) * (arc.next > s ? hash[arc.next] : 1ull));
     hash[s] = h;
   }
   std::unordered_map<uint64_t, std::vector<int32_t>> groups;
