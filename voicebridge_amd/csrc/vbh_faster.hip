@@ -50,12 +50,14 @@ struct FCfg { float beam, beam_delta, acwt; int max_active, min_active; };
 struct FSlot {
   i32x4 *tok;              // [tok_cap] {prev token, arc (-1: start), state | EPSBIT, 0}
   double *cost;            // [tok_cap]
-  unsigned long long *win; // [frame_cap] winner key (arc << 32 | source token) per token of the frame being built
+  unsigned long long *win; // [HCAP + g_cap] winner key (arc << 32 | source token) per state of the frame being built, by map slot (LDS slots, then
+                           // the second level's); ~0 = none: make_tokens leaves every entry it read that way
   double *c_w;             // [cand_cap] candidate new_weight
   i32x4 *c_r;              // [cand_cap] {arc, source token, next state | EPSBIT, 0}
   int *front[3];           // epsilon work lists (states), rotated
   int *elist;              // [frame_cap] the frame's states that have epsilon arcs, each once (pushed by its creator)
   unsigned *g_hs; unsigned long long *g_hc; int *g_ht;   // second level of the state map, [g_cap] (power of two)
+  int *g_list;             // [frame_cap] the second-level slots the frame being built has claimed (what is walked, numbered and cleared)
   int *remap;              // [tok_cap] garbage collection: mark, then new index
   i32x4 *stage_tok; double *stage_cost;   // [stage_cap] survivors on their way down
   int tok_cap, frame_cap, cand_cap, front_cap, g_cap, stage_cap;
@@ -170,7 +172,9 @@ struct Shared {
   int ht[HCAP];                    // index of the state's token within the frame
   int n_new, n_cand, fcnt[3], error, utt;
   int n_eps;                       // fill of FSlot::elist
+  int grp[(HCAP / NT) * NW + 1];   // number_tokens: occupied slots per group of 64 map slots, then their exclusive prefix
   int g_used;                      // the second level holds entries of the frame being built
+  int n_g;                         // ... how many (fill of FSlot::g_list); -1: unknown, the whole table is cleared
   unsigned long long sel_prefix, sel_mask; int sel_k;
   unsigned long long u0;
 #ifdef VBH_FASTER_PROF      // build-time diagnostic: shader-clock cycles per phase, printed by thread 0 for the first utterances
@@ -245,8 +249,8 @@ __device__ double select_kth(gp<const double> cost, int n, int k, Shared &sh) {
 // second level, the same table in HBM (g_cap slots, cleared only after frames that used it); slots
 // are never freed within a frame, so a state always resolves to the same level.  A slot handle is
 // >= 0 for LDS, <= -2 for HBM slot -(handle + 2), -1 for "no room".
-struct Map2 { gp<unsigned> gs; gp<unsigned long long> gc; gp<int> gt; int gmask; };
-__device__ __forceinline__ Map2 map2_of(const FSlot &s) { Map2 m; m.gs = uptr(s.g_hs); m.gc = uptr(s.g_hc); m.gt = uptr(s.g_ht); m.gmask = s.g_cap - 1; return m; }
+struct Map2 { gp<unsigned> gs; gp<unsigned long long> gc; gp<int> gt; gp<int> gl; int gmask, gl_cap; };
+__device__ __forceinline__ Map2 map2_of(const FSlot &s) { Map2 m; m.gs = uptr(s.g_hs); m.gc = uptr(s.g_hc); m.gt = uptr(s.g_ht); m.gl = uptr(s.g_list); m.gmask = s.g_cap - 1; m.gl_cap = s.frame_cap; return m; }
 __device__ __forceinline__ unsigned map_hash(int st) { return ((unsigned)st * 2654435761u) >> (32 - HBITS); }
 __device__ __forceinline__ unsigned map_hash2(int st, int gmask) { return (((unsigned)st * 2246822519u) >> 7) & (unsigned)gmask; }
 __device__ __forceinline__ int map_find(const Shared &sh, const Map2 &m, int st) {
@@ -303,7 +307,10 @@ __device__ __forceinline__ void map_relax(Shared &sh, const Map2 &m, int ds, dou
     if (cur == HEMPTY) {
       unsigned expect = HEMPTY;
       if (__hip_atomic_compare_exchange_strong(&m.gs[h], &expect, (unsigned)ds, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-        create = true; slot = -(int)h - 2; break;
+        create = true; slot = -(int)h - 2;
+        const int q = atomicAdd(&sh.n_g, 1);
+        if (q < m.gl_cap) m.gl[q] = (int)h; else sh.error = FERR_FRAME;
+        break;
       }
       cur = expect;
     }
@@ -313,20 +320,62 @@ __device__ __forceinline__ void map_relax(Shared &sh, const Map2 &m, int ds, dou
   const unsigned long long oc = __hip_atomic_fetch_min(&m.gc[-slot - 2], ck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   improved = ck < oc;
 }
-// empty map for the next frame (all threads; followed by a barrier at the caller)
+// empty map for the next frame (all threads; followed by a barrier at the caller, who then sets g_used = n_g = 0)
 __device__ __forceinline__ void map_clear(Shared &sh, const FSlot &s) {
   for (int i = threadIdx.x; i < HCAP; i += NT) { sh.hs[i] = HEMPTY; sh.hc[i] = ~0ull; }
   if (sh.g_used) {
     gp<unsigned> gs = uptr(s.g_hs); gp<unsigned long long> gc = uptr(s.g_hc);
-    for (int i = threadIdx.x; i < s.g_cap; i += NT) { gs[i] = HEMPTY; gc[i] = ~0ull; }
+    const int ng = sh.n_g;
+    if (ng < 0 || ng > s.frame_cap) { for (int i = threadIdx.x; i < s.g_cap; i += NT) { gs[i] = HEMPTY; gc[i] = ~0ull; } }
+    else {
+      gp<const int> gl = uptr((const int *)s.g_list);
+      for (int i = threadIdx.x; i < ng; i += NT) { const int h = gl[i]; gs[h] = HEMPTY; gc[h] = ~0ull; }
+    }
   }
+}
+
+// where a state's winner key lives
+__device__ __forceinline__ int widx(int slot) { return slot >= 0 ? slot : HCAP + (-slot - 2); }
+
+// The frame's tokens are numbered when all its states are known (after the epsilon closure): a state's token index within the frame
+// is the number of occupied map slots before its own, in slot order -- so that make_tokens, which walks the slots in that order,
+// writes runs of consecutive tokens (one 16-byte and one 8-byte record per lane, neighbouring lanes neighbouring tokens) -- then
+// the second level's states in the order they are met.  Sets sh.n_new.  All threads; ends with a barrier.
+__device__ void number_tokens(const FSlot &s, Shared &sh) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int PER = HCAP / NT, NG = PER * NW;
+  unsigned long long occ[PER];
+#pragma unroll
+  for (int u = 0; u < PER; u++) {
+    occ[u] = __ballot(sh.hs[u * NT + tid] != HEMPTY);
+    if (lane == 0) sh.grp[u * NW + wave] = __popcll(occ[u]);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    static_assert(NG == 128, "two groups per lane");
+    const int a = sh.grp[2 * lane], b = sh.grp[2 * lane + 1];
+    const int incl = wave_incl_scan(a + b);
+    sh.grp[2 * lane] = incl - a - b; sh.grp[2 * lane + 1] = incl - b;
+    if (lane == 63) sh.grp[NG] = incl;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < PER; u++)
+    if ((occ[u] >> lane) & 1ull) sh.ht[u * NT + tid] = sh.grp[u * NW + wave] + __popcll(occ[u] & ((1ull << lane) - 1ull));
+  const int n_lds = sh.grp[NG];
+  const int ng = sh.g_used ? (sh.n_g < s.frame_cap ? sh.n_g : s.frame_cap) : 0;
+  if (ng > 0) {       // the second level's states: in the order of the frame's list of them
+    gp<const int> gl = uptr((const int *)s.g_list); gp<int> gt = uptr(s.g_ht);
+    for (int i = tid; i < ng; i += NT) gt[gl[i]] = n_lds + i;
+  }
+  if (tid == 0) sh.n_new = n_lds + ng;
+  __syncthreads();
 }
 
 // ProcessNonemitting (faster-decoder.cc:306-346) to the fixed point: work lists hold states; a
 // state whose cost exceeds the cutoff is not expanded, an arc that would is dropped.
 __device__ void epsilon_closure(const FGraph &g, const FSlot &s, double cutoff, Shared &sh) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  gp<unsigned long long> win = uptr(s.win);
   gp<int> elist = uptr(s.elist);
   const Map2 m2 = map2_of(s);
   const int frame_cap = s.frame_cap, front_cap = s.front_cap;
@@ -365,13 +414,8 @@ __device__ void epsilon_closure(const FGraph &g, const FSlot &s, double cutoff, 
             eps = create && arc.x < 0;
           }
         }
-        const int li = wave_alloc(&sh.n_new, create);
-        if (create) {
-          if (li < frame_cap) { map_set_idx(sh, m2, nslot, li); win[li] = ~0ull; }
-          else sh.error = FERR_FRAME;
-        }
         const int qe = wave_alloc(&sh.n_eps, eps);
-        if (eps && qe < frame_cap) elist[qe] = ds;      // (qe >= frame_cap implies li >= frame_cap: already an error)
+        if (eps) { if (qe < frame_cap) elist[qe] = ds; else sh.error = FERR_FRAME; }
         const int q = wave_alloc(&sh.fcnt[nxt], push);
         if (push) { if (q < front_cap) fnext[q] = ds; else sh.error = FERR_FRONT; }
       });
@@ -426,7 +470,7 @@ __device__ void epsilon_winners(const FGraph &g, const FSlot &s, double cutoff, 
         if (!(nc > cutoff)) {
           const int ds_slot = map_find(sh, m2, arc.x & STMASK);
           if (ds_slot != -1 && d2o(nc) == map_key(sh, m2, ds_slot))
-            (void)__hip_atomic_fetch_min(&win[map_idx(sh, m2, ds_slot)], ((unsigned long long)(unsigned)a << 32) | (unsigned)src_tok,
+            (void)__hip_atomic_fetch_min(&win[widx(ds_slot)], ((unsigned long long)(unsigned)a << 32) | (unsigned)src_tok,
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
@@ -434,11 +478,12 @@ __device__ void epsilon_winners(const FGraph &g, const FSlot &s, double cutoff, 
   }
 }
 
-// one token per map entry, appended to the utterance's history at tok_base.  The LDS level is
-// walked HCAP / NT entries per thread with every winner fetched before the first is used.
+// one token per map entry, appended to the utterance's history at tok_base (numbered by number_tokens: a wave writes runs of
+// consecutive tokens).  The LDS level is walked HCAP / NT entries per thread with every winner fetched before the first is used;
+// the winner entries that were read are left empty for the next frame.
 __device__ void make_tokens(const FSlot &s, int tok_base, Shared &sh) {
   gp<i32x4> tok = uptr(s.tok); gp<double> cost = uptr(s.cost);
-  gp<const unsigned long long> win = uptr(s.win);
+  gp<unsigned long long> win = uptr(s.win);
   const Map2 m2 = map2_of(s);
   constexpr int PER = HCAP / NT;
   int st[PER], li[PER]; unsigned long long key[PER], w[PER]; bool have[PER];
@@ -450,7 +495,7 @@ __device__ void make_tokens(const FSlot &s, int tok_base, Shared &sh) {
     st[u] = (int)tag; key[u] = sh.hc[e]; li[u] = have[u] ? sh.ht[e] : 0;
   }
 #pragma unroll
-  for (int u = 0; u < PER; u++) { w[u] = ~0ull; if (have[u]) w[u] = win[li[u]]; }
+  for (int u = 0; u < PER; u++) { w[u] = ~0ull; if (have[u]) w[u] = win[u * NT + threadIdx.x]; }
 #ifdef VBH_FASTER_PROF
   { unsigned long long x = 0;
 #pragma unroll
@@ -463,16 +508,20 @@ __device__ void make_tokens(const FSlot &s, int tok_base, Shared &sh) {
     if (!have[u]) continue;
     i32x4 r; r.x = (int)(unsigned)w[u]; r.y = (int)(unsigned)(w[u] >> 32); r.z = st[u]; r.w = 0;
     if (w[u] == ~0ull) { r.x = -1; r.y = -1; }      // the start token
+    else win[u * NT + threadIdx.x] = ~0ull;
     tok[tok_base + li[u]] = r;
     cost[tok_base + li[u]] = o2d(key[u]);
   }
   if (sh.g_used) {
-    for (int e = HCAP + threadIdx.x; e < HCAP + s.g_cap; e += NT) {
+    const int ng = sh.n_g < s.frame_cap ? sh.n_g : s.frame_cap;
+    for (int i = threadIdx.x; i < ng; i += NT) {
+      const int e = HCAP + m2.gl[i];
       int st1, li1; unsigned long long key1;
       if (!map_entry(sh, m2, e, st1, key1, li1)) continue;
-      const unsigned long long w1 = win[li1];
+      const unsigned long long w1 = win[e];
       i32x4 r; r.x = (int)(unsigned)w1; r.y = (int)(unsigned)(w1 >> 32); r.z = st1; r.w = 0;
       if (w1 == ~0ull) { r.x = -1; r.y = -1; }
+      else win[e] = ~0ull;
       tok[tok_base + li1] = r;
       cost[tok_base + li1] = o2d(key1);
     }
@@ -559,22 +608,24 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
     gp<unsigned long long> win = uptr(s.win);
     gp<double> c_w = uptr(s.c_w); gp<i32x4> c_r = uptr(s.c_r);
     const Map2 m2 = map2_of(s);
-    if (tid == 0) sh.g_used = 1;       // a previous utterance may have left entries in the second level
+    if (tid == 0) { sh.g_used = 1; sh.n_g = -1; }      // a previous utterance may have left entries in the second level
     __syncthreads();
     map_clear(sh, s);
+    for (int i = tid; i < HCAP + s.g_cap; i += NT) win[i] = ~0ull;      // (an utterance that ended in an error leaves winner keys behind)
     __syncthreads();
-    if (tid == 0) { sh.n_new = 0; sh.n_cand = 0; sh.n_eps = 0; sh.fcnt[0] = sh.fcnt[1] = sh.fcnt[2] = 0; sh.error = FERR_NONE; sh.g_used = 0; }
+    if (tid == 0) { sh.n_new = 0; sh.n_cand = 0; sh.n_eps = 0; sh.fcnt[0] = sh.fcnt[1] = sh.fcnt[2] = 0; sh.error = FERR_NONE; sh.g_used = 0; sh.n_g = 0; }
     __syncthreads();
     // ---- InitDecoding (:36-45): the start token, then the epsilon closure with cutoff FLT_MAX
     if (tid == 0) {
       int slot; bool create, improved;
       const int start = ud.start >= 0 ? ud.start : g.start;
       map_relax(sh, m2, start, 0.0, slot, create, improved);
-      map_set_idx(sh, m2, slot, 0); uptr(s.win)[0] = ~0ull; sh.n_new = 1;
       if (uptr(g.st)[start].y > 0) { uptr(s.front[0])[0] = start; sh.fcnt[0] = 1; uptr(s.elist)[0] = start; sh.n_eps = 1; }
     }
     __syncthreads();
     epsilon_closure(g, s, (double)FLT_MAX, sh);
+    number_tokens(s, sh);
+    if (tid == 0 && sh.n_new > s.frame_cap) sh.error = FERR_FRAME;
     int cur_b = 0, cur_n = sh.n_new < s.frame_cap ? sh.n_new : s.frame_cap;
     if (cur_n > s.tok_cap && tid == 0) sh.error = FERR_TOK;
     __syncthreads();
@@ -634,7 +685,7 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
       // the map of the frame about to be built
       map_clear(sh, s);
       __syncthreads();
-      if (tid == 0) { sh.n_new = 0; sh.n_cand = 0; sh.n_eps = 0; sh.fcnt[0] = sh.fcnt[1] = sh.fcnt[2] = 0; sh.g_used = 0; }
+      if (tid == 0) { sh.n_new = 0; sh.n_cand = 0; sh.n_eps = 0; sh.fcnt[0] = sh.fcnt[1] = sh.fcnt[2] = 0; sh.g_used = 0; sh.n_g = 0; }
       __syncthreads();
       // ---- pass 1 (:224-303, arc-parallel): candidates + min of new_weight + adaptive_beam
       FPHASE(2)
@@ -688,16 +739,11 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
           const bool adm = ok && nw < next_cutoff;
           int slot = -1; bool create = false, improved;
           if (adm) { map_relax(sh, m2, r.z & STMASK, nw, slot, create, improved); if (slot == -1) sh.error = FERR_MAP; }
-          const int li = wave_alloc(&sh.n_new, create);
-          bool pushf = false;
-          if (create) {
-            if (li < frame_cap) { map_set_idx(sh, m2, slot, li); win[li] = ~0ull; pushf = r.z < 0; }
-            else sh.error = FERR_FRAME;
-          }
+          const bool pushf = create && r.z < 0;
           const int f = wave_alloc(&sh.fcnt[0], pushf);
           if (pushf) {      // (a created state with epsilon arcs: also the head of the frame's epsilon-state list)
             if (f < front_cap) front0[f] = r.z & STMASK; else sh.error = FERR_FRONT;
-            if (f < frame_cap) elist0[f] = r.z & STMASK;
+            if (f < frame_cap) elist0[f] = r.z & STMASK; else sh.error = FERR_FRAME;
           }
         }
       }
@@ -713,8 +759,10 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
       epsilon_closure(g, s, next_cutoff, sh);
       FPHASE(5)
       if (sh.error != FERR_NONE) break;
+      number_tokens(s, sh);
+      if (sh.n_new > s.frame_cap) { if (tid == 0) sh.error = FERR_FRAME; __syncthreads(); break; }
       const int nb = cur_b + cur_n;
-      const int n_new = sh.n_new < s.frame_cap ? sh.n_new : s.frame_cap;
+      const int n_new = sh.n_new;
 #ifdef VBH_FASTER_DEBUG
       if (tid == 0 && utt == 0 && frame < 12) printf("frame %d: n=%d ncand=%d n_new=%d g_used=%d next_cutoff=%f weight_cutoff=%f best=%f\n", frame, n, ncand, sh.n_new, sh.g_used, next_cutoff, weight_cutoff, best);
 #endif
@@ -728,7 +776,7 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
         if (ok && nw < next_cutoff) {
           const int slot = map_find(sh, m2, r.z & STMASK);
           if (slot != -1 && d2o(nw) == map_key(sh, m2, slot))
-            (void)__hip_atomic_fetch_min(&win[map_idx(sh, m2, slot)], ((unsigned long long)(unsigned)r.x << 32) | (unsigned)r.y,
+            (void)__hip_atomic_fetch_min(&win[widx(slot)], ((unsigned long long)(unsigned)r.x << 32) | (unsigned)r.y,
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
@@ -900,11 +948,11 @@ int vbh_faster_decoder_create_ex(vbh_ctx *ctx, const vbh_graph *graph, const vbh
     d->allocs.push_back(base);                                                                      \
     for (size_t i = 0; i < ns; i++) d->h_slots[i].field = base + i * (size_t)(count);               \
   }
-  A_(tok, i32x4, p.tok_cap) A_(cost, double, p.tok_cap) A_(win, unsigned long long, p.frame_cap)
+  A_(tok, i32x4, p.tok_cap) A_(cost, double, p.tok_cap) A_(win, unsigned long long, HCAP + p.g_cap)
   A_(c_w, double, p.cand_cap) A_(c_r, i32x4, p.cand_cap)
   A_(front[0], int, p.front_cap) A_(front[1], int, p.front_cap) A_(front[2], int, p.front_cap)
   A_(elist, int, p.frame_cap)
-  A_(g_hs, unsigned, p.g_cap) A_(g_hc, unsigned long long, p.g_cap) A_(g_ht, int, p.g_cap)
+  A_(g_hs, unsigned, p.g_cap) A_(g_hc, unsigned long long, p.g_cap) A_(g_ht, int, p.g_cap) A_(g_list, int, p.frame_cap)
   A_(remap, int, p.tok_cap) A_(stage_tok, i32x4, p.stage_cap) A_(stage_cost, double, p.stage_cap)
 #undef A_
   if (d->d_slots.upload(d->h_slots.data(), d->h_slots.size(), ctx->stream)) { vbh_faster_decoder_destroy(d); return -1; }
