@@ -164,21 +164,26 @@ __device__ __forceinline__ int wave_chunk(int n) {
 }
 
 struct Shared {
-  unsigned long long red[2][NW];
+  unsigned long long red[2][NW], red2[2][NW];
   unsigned hist[256];
+  unsigned vhist[1024];            // get_cutoff: the frame's costs by value, 1024 equal steps from the smallest to the largest
+  unsigned long long vlist[2][64]; // ... the costs of the step an order statistic falls in ([which]: the max-active, the min-active one --
+  int vb[2], vr[2], vn[2];         //     a slow wave may still be reading the first one's when the second one starts), that step, the
+                                   //     statistic's rank within it, the fill of vlist
   alignas(4) unsigned char wx[NW][64];   // wave_expand: a strip of 64 marker bytes per wave
   unsigned hs[HCAP];               // state map of the frame being built: tag,
   unsigned long long hc[HCAP];     // best cost (order-preserving key),
   int ht[HCAP];                    // index of the state's token within the frame
   int n_new, n_cand, fcnt[3], error, utt;
+  unsigned long long cand_bound;   // pass 1: key of the smallest new_weight + adaptive_beam seen so far (>= the final next_cutoff)
   int n_eps;                       // fill of FSlot::elist
   int grp[(HCAP / NT) * NW + 1];   // number_tokens: occupied slots per group of 64 map slots, then their exclusive prefix
   int g_used;                      // the second level holds entries of the frame being built
   int n_g;                         // ... how many (fill of FSlot::g_list); -1: unknown, the whole table is cleared
-  unsigned long long sel_prefix, sel_mask; int sel_k;
+  unsigned long long sel_prefix, sel_mask; int sel_k, sel_single;
   unsigned long long u0;
 #ifdef VBH_FASTER_PROF      // build-time diagnostic: shader-clock cycles per phase, printed by thread 0 for the first utterances
-  long long tph[12], t_last;
+  long long tph[16], t_last;
 #endif
 };
 #ifdef VBH_FASTER_PROF
@@ -197,6 +202,16 @@ __device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v
   par ^= 1;
   return r;
 }
+// smallest and largest of the threads' (lo, hi) in one barrier
+__device__ __forceinline__ void block_minmax_u64(unsigned long long &lo, unsigned long long &hi, Shared &sh, int &par) {
+  lo = wave_min_u64(lo); hi = ~wave_min_u64(~hi);
+  if ((threadIdx.x & 63) == 0) { sh.red[par][threadIdx.x >> 6] = lo; sh.red2[par][threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  lo = sh.red[par][0]; hi = sh.red2[par][0];
+#pragma unroll
+  for (int i = 1; i < NW; i++) { lo = sh.red[par][i] < lo ? sh.red[par][i] : lo; hi = sh.red2[par][i] > hi ? sh.red2[par][i] : hi; }
+  par ^= 1;
+}
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, Shared &sh, int &par) {
   v = ((unsigned long long)wave_sum_u32((unsigned)(v >> 32)) << 32) | wave_sum_u32((unsigned)v);      // (both halves are counts of a frame's tokens)
   if ((threadIdx.x & 63) == 0) sh.red[par][threadIdx.x >> 6] = v;
@@ -208,20 +223,33 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
   return r;
 }
 
-// k-th smallest (0-based) of cost[0..n): radix select over the 64-bit order-preserving keys
-// (the std::nth_element value in GetCutoff, faster-decoder.cc:171-196)
-__device__ double select_kth(gp<const double> cost, int n, int k, Shared &sh) {
+// the step of a cost in the frame's histogram by value (monotone in c; c >= best)
+__device__ __forceinline__ int step_of(double c, double best, double scale) {
+  const double x = (c - best) * scale;
+  return x >= 1023.0 ? 1023 : (int)x;      // (also the costs at infinity; a NaN goes to step 0 like the comparison says)
+}
+
+// k-th smallest (0-based) of a frame's costs: radix select over the 64-bit order-preserving keys (the std::nth_element value in
+// GetCutoff, faster-decoder.cc:171-196).  each(f) calls f(key) for the calling thread's share of the keys.  The keys of a frame
+// agree in their leading bytes (sign, exponent, the top of the mantissa: they lie within a beam of each other): lo and hi, the
+// smallest and the largest key, say in how many, and the select starts below them.
+template <class Each>
+__device__ double select_kth(Each each, unsigned long long lo, unsigned long long hi, int k, Shared &sh) {
   const int tid = threadIdx.x;
+  int shift0 = 56;
+  while (shift0 > 0 && (lo >> shift0) == (hi >> shift0)) shift0 -= 8;
   __syncthreads();
-  if (tid == 0) { sh.sel_prefix = 0; sh.sel_mask = 0; sh.sel_k = k; }
-  for (int shift = 56; shift >= 0; shift -= 8) {
+  if (tid == 0) {
+    const unsigned long long m0 = shift0 == 56 ? 0ull : ~0ull << (shift0 + 8);
+    sh.sel_prefix = lo & m0; sh.sel_mask = m0; sh.sel_k = k;
+  }
+  for (int shift = shift0; shift >= 0; shift -= 8) {
     for (int i = tid; i < 256; i += NT) sh.hist[i] = 0;
     __syncthreads();
     const unsigned long long prefix = sh.sel_prefix, mask = sh.sel_mask;
-    for (int i = tid; i < n; i += NT) {
-      const unsigned long long key = d2o(cost[i]);
+    each([&](unsigned long long key) {
       if ((key & mask) == prefix) atomicAdd(&sh.hist[(unsigned)(key >> shift) & 255u], 1u);
-    }
+    });
     __syncthreads();
     if (tid < 64) {
       const int kk = sh.sel_k;
@@ -231,16 +259,103 @@ __device__ double select_kth(gp<const double> cost, int n, int k, Shared &sh) {
       const unsigned long long m = __ballot(incl > kk);
       const int owner = m ? __ffsll((long long)m) - 1 : 63;
       if (tid == owner) {
-        int r = kk - (incl - mine), b = 0;
-        if (r >= h0) { r -= h0; b = 1; if (r >= h1) { r -= h1; b = 2; if (r >= h2) { r -= h2; b = 3; } } }
+        int r = kk - (incl - mine), b = 0, hb = h0;
+        if (r >= h0) { r -= h0; b = 1; hb = h1; if (r >= h1) { r -= h1; b = 2; hb = h2; if (r >= h2) { r -= h2; b = 3; hb = h3; } } }
         sh.sel_k = r;
         sh.sel_prefix = prefix | ((unsigned long long)(4 * tid + b) << shift);
         sh.sel_mask = mask | (255ull << shift);
+        sh.sel_single = hb == 1;      // one key left under the prefix: it is the answer, whatever its remaining bytes
       }
     }
     __syncthreads();
+    if (sh.sel_single && shift > 0) {
+      const unsigned long long prefix1 = sh.sel_prefix, mask1 = sh.sel_mask;
+      __syncthreads();
+      each([&](unsigned long long key) { if ((key & mask1) == prefix1) sh.sel_prefix = key; });
+      __syncthreads();
+      break;
+    }
   }
   return o2d(sh.sel_prefix);
+}
+
+// The k-th smallest cost of a frame (0-based), given its histogram by value (vhist: step = (int)((cost - best) * scale), a
+// monotone function of the cost, so the steps are ordered like the costs): the step the statistic falls in, then the few costs of
+// that step ranked against each other by every wave for itself.  Two barriers; more than 64 costs in the step (many equal ones, a
+// degenerate range): the radix select.
+template <class Each>
+__device__ double select_by_value(Each each, double best, double scale, unsigned long long lo, unsigned long long hi, int k, int which, Shared &sh) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid < 64) {
+    int c[16], mine = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { c[i] = (int)sh.vhist[16 * tid + i]; mine += c[i]; }
+    const int incl = wave_incl_scan(mine);
+    const unsigned long long m = __ballot(incl > k);
+    const int owner = m ? __ffsll((long long)m) - 1 : 63;
+    if (tid == owner) {
+      int r = k - (incl - mine), bb = 0;
+#pragma unroll
+      for (int i = 0; i < 15; i++) if (bb == i && r >= c[i]) { r -= c[i]; bb = i + 1; }
+      sh.vb[which] = 16 * tid + bb; sh.vr[which] = r; sh.vn[which] = 0;
+    }
+  }
+  __syncthreads();
+  const int vb = sh.vb[which], vr = sh.vr[which];
+  each([&](unsigned long long key) {
+    if (step_of(o2d(key), best, scale) == vb) { const int q = atomicAdd(&sh.vn[which], 1); if (q < 64) sh.vlist[which][q] = key; }
+  });
+  __syncthreads();
+  const int vn = sh.vn[which];
+  if (vn > 64) return select_kth(each, lo, hi, k, sh);
+  const unsigned long long mykey = lane < vn ? sh.vlist[which][lane] : ~0ull;
+  int rank = 0;
+  for (int j = 0; j < vn; j++) { const unsigned long long o = sh.vlist[which][j]; rank += (o < mykey) || (o == mykey && j < lane); }
+  const unsigned long long hit = __ballot(lane < vn && rank == vr);
+  const int src = hit ? __ffsll((long long)hit) - 1 : 0;
+  const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mykey, src), khi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mykey >> 32), src);
+  return o2d(((unsigned long long)khi << 32) | klo);
+}
+
+// GetCutoff (faster-decoder.cc:151-213), in double, for the frame whose n costs each() enumerates: the cutoff on the tokens
+// (weight_cutoff) and the beam for the arcs leaving them (adaptive_beam).  Two barriers (smallest + largest cost; the counts on
+// either side of the beam + the histogram by value), two more per order statistic that decides.
+template <class Each>
+__device__ void get_cutoff(Each each, int n, const FCfg &cfg, Shared &sh, int &par, double &weight_cutoff, float &adaptive_beam) {
+  unsigned long long bk = ~0ull, wk = 0ull;
+  FPHASE(11)
+  each([&](unsigned long long k) { bk = k < bk ? k : bk; wk = k > wk ? k : wk; });
+  sh.vhist[threadIdx.x] = 0;
+  static_assert(NT == 1024, "one histogram step per thread");
+  block_minmax_u64(bk, wk, sh, par);
+  FPHASE(12)
+  const double best = n > 0 ? o2d(bk) : (double)INFINITY;
+  if (cfg.max_active == INT_MAX && cfg.min_active == 0) { adaptive_beam = cfg.beam; weight_cutoff = best + cfg.beam; return; }
+  const double beam_cutoff = best + cfg.beam;
+  double mac = (double)INFINITY, mic = (double)INFINITY;
+  // the order statistics are only computed when they decide the comparisons below:
+  // tmp[max_active] < beam_cutoff  <=>  more than max_active costs lie below beam_cutoff;
+  // tmp[min_active] > beam_cutoff  <=>  at most min_active costs are <= beam_cutoff
+  const double range = n > 0 ? o2d(wk) - best : 0.0;
+  const double scale = range > 0.0 && range < (double)INFINITY ? 1023.0 / range : 0.0;
+  unsigned long long cnt = 0;   // (#cost < beam_cutoff) << 32 | (#cost <= beam_cutoff)
+  each([&](unsigned long long k) {
+    const double c = o2d(k);
+    cnt += ((unsigned long long)(c < beam_cutoff) << 32) | (unsigned long long)(c <= beam_cutoff);
+    atomicAdd(&sh.vhist[step_of(c, best, scale)], 1u);
+  });
+  cnt = block_sum_u64(cnt, sh, par);
+  FPHASE(13)
+  const int cnt_lt = (int)(cnt >> 32), cnt_le = (int)(unsigned)cnt;
+  if (n > cfg.max_active && cnt_lt > cfg.max_active) mac = select_by_value(each, best, scale, bk, wk, cfg.max_active, 0, sh);
+  if (mac < beam_cutoff) { adaptive_beam = (float)(mac - best + cfg.beam_delta); weight_cutoff = mac; return; }
+  if (n > cfg.min_active) {
+    if (cfg.min_active == 0) mic = best;
+    else if (cnt_le <= cfg.min_active) mic = select_by_value(each, best, scale, bk, wk, cfg.min_active, 1, sh);
+    else mic = beam_cutoff;     // some value <= beam_cutoff: the comparison below is false
+  }
+  if (mic > beam_cutoff) { adaptive_beam = (float)(mic - best + cfg.beam_delta); weight_cutoff = mic; }
+  else { adaptive_beam = cfg.beam; weight_cutoff = beam_cutoff; }
 }
 
 // ---- state map of the frame being built: state -> (best cost, index of its token in the frame).
@@ -479,9 +594,9 @@ __device__ void epsilon_winners(const FGraph &g, const FSlot &s, double cutoff, 
 }
 
 // one token per map entry, appended to the utterance's history at tok_base (numbered by number_tokens: a wave writes runs of
-// consecutive tokens).  The LDS level is walked HCAP / NT entries per thread with every winner fetched before the first is used;
+// consecutive tokens); then GetCutoff for the frame's turn as the current frame, from the cost keys while they are in registers.  The LDS level is walked HCAP / NT entries per thread with every winner fetched before the first is used;
 // the winner entries that were read are left empty for the next frame.
-__device__ void make_tokens(const FSlot &s, int tok_base, Shared &sh) {
+__device__ void make_tokens(const FSlot &s, int tok_base, const FCfg &cfg, Shared &sh, int &par, double &weight_cutoff, float &adaptive_beam) {
   gp<i32x4> tok = uptr(s.tok); gp<double> cost = uptr(s.cost);
   gp<unsigned long long> win = uptr(s.win);
   const Map2 m2 = map2_of(s);
@@ -526,6 +641,14 @@ __device__ void make_tokens(const FSlot &s, int tok_base, Shared &sh) {
       cost[tok_base + li1] = o2d(key1);
     }
   }
+  // GetCutoff of the frame just made, for its turn as the current frame: its costs are the keys at hand (the second level's, if any,
+  // from its table, which stays until the next map is started)
+  const int ng = sh.g_used ? (sh.n_g < s.frame_cap ? sh.n_g : s.frame_cap) : 0;
+  get_cutoff([&](auto f) {
+#pragma unroll
+    for (int u = 0; u < PER; u++) if (have[u]) f(key[u]);
+    for (int i = threadIdx.x; i < ng; i += NT) f(m2.gc[m2.gl[i]]);
+  }, sh.n_new, cfg, sh, par, weight_cutoff, adaptive_beam);
 }
 
 // Tokens no current token can reach through back pointers will never be part of a best path (the
@@ -594,7 +717,7 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
   int par = 0;
 #ifdef VBH_FASTER_PROF
   long long *tph = sh.tph;
-  if (tid == 0) { for (int i = 0; i < 12; i++) sh.tph[i] = 0; sh.t_last = (long long)__builtin_amdgcn_s_memtime(); }
+  if (tid == 0) { for (int i = 0; i < 16; i++) sh.tph[i] = 0; sh.t_last = (long long)__builtin_amdgcn_s_memtime(); }
 #endif
   while (true) {
     __syncthreads();
@@ -623,6 +746,7 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
       if (uptr(g.st)[start].y > 0) { uptr(s.front[0])[0] = start; sh.fcnt[0] = 1; uptr(s.elist)[0] = start; sh.n_eps = 1; }
     }
     __syncthreads();
+    double weight_cutoff = (double)INFINITY; float adaptive_beam = cfg.beam;      // of the current frame (make_tokens)
     epsilon_closure(g, s, (double)FLT_MAX, sh);
     number_tokens(s, sh);
     if (tid == 0 && sh.n_new > s.frame_cap) sh.error = FERR_FRAME;
@@ -632,7 +756,7 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
     if (sh.error == FERR_NONE) {
       epsilon_winners(g, s, (double)FLT_MAX, 0, sh);
       __syncthreads();
-      make_tokens(s, 0, sh);
+      make_tokens(s, 0, cfg, sh, par, weight_cutoff, adaptive_beam);
     }
     __syncthreads();
     int frames_done = 0;
@@ -649,43 +773,12 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
       gp<const double> ccost = cost + cur_b;
       gp<const i32x4> ctok = tok + cur_b;
       const int n = cur_n;
-      // ---- GetCutoff (:151-213), in double
-      unsigned long long bk = ~0ull;
-      for (int i = tid; i < n; i += NT) { const unsigned long long k = d2o(ccost[i]); bk = k < bk ? k : bk; }
-      bk = block_min_u64(bk, sh, par);
-      const double best = n > 0 ? o2d(bk) : (double)INFINITY;
-      double weight_cutoff; float adaptive_beam;
-      if (cfg.max_active == INT_MAX && cfg.min_active == 0) { adaptive_beam = cfg.beam; weight_cutoff = best + cfg.beam; }
-      else {
-        const double beam_cutoff = best + cfg.beam;
-        double mac = (double)INFINITY, mic = (double)INFINITY;
-        // the order statistics are only computed when they decide the comparisons below:
-        // tmp[max_active] < beam_cutoff  <=>  more than max_active costs lie below beam_cutoff;
-        // tmp[min_active] > beam_cutoff  <=>  at most min_active costs are <= beam_cutoff
-        unsigned long long cnt = 0;   // (#cost < beam_cutoff) << 32 | (#cost <= beam_cutoff)
-        for (int i = tid; i < n; i += NT) {
-          const double c = ccost[i];
-          cnt += ((unsigned long long)(c < beam_cutoff) << 32) | (unsigned long long)(c <= beam_cutoff);
-        }
-        cnt = block_sum_u64(cnt, sh, par);
-        const int cnt_lt = (int)(cnt >> 32), cnt_le = (int)(unsigned)cnt;
-        if (n > cfg.max_active && cnt_lt > cfg.max_active) mac = select_kth(ccost, n, cfg.max_active, sh);
-        if (mac < beam_cutoff) { adaptive_beam = (float)(mac - best + cfg.beam_delta); weight_cutoff = mac; }
-        else {
-          if (n > cfg.min_active) {
-            if (cfg.min_active == 0) mic = best;
-            else if (cnt_le <= cfg.min_active) mic = select_kth(ccost, n, cfg.min_active, sh);
-            else mic = beam_cutoff;     // some value <= beam_cutoff: the comparison below is false
-          }
-          if (mic > beam_cutoff) { adaptive_beam = (float)(mic - best + cfg.beam_delta); weight_cutoff = mic; }
-          else { adaptive_beam = cfg.beam; weight_cutoff = beam_cutoff; }
-        }
-      }
+      // (GetCutoff, :151-213: weight_cutoff and adaptive_beam of this frame were computed when its tokens were made)
       FPHASE(1)
       // the map of the frame about to be built
       map_clear(sh, s);
       __syncthreads();
-      if (tid == 0) { sh.n_new = 0; sh.n_cand = 0; sh.n_eps = 0; sh.fcnt[0] = sh.fcnt[1] = sh.fcnt[2] = 0; sh.g_used = 0; sh.n_g = 0; }
+      if (tid == 0) { sh.n_new = 0; sh.n_cand = 0; sh.n_eps = 0; sh.fcnt[0] = sh.fcnt[1] = sh.fcnt[2] = 0; sh.g_used = 0; sh.n_g = 0; sh.cand_bound = ~0ull; }
       __syncthreads();
       // ---- pass 1 (:224-303, arc-parallel): candidates + min of new_weight + adaptive_beam
       FPHASE(2)
@@ -705,15 +798,22 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
             const int a = __shfl(a0, owner, 64) + j;
             const double cc = __shfl(c, owner, 64);
             i32x4 arc; double nw = 0.0;
+            unsigned long long kk = ~0ull;
             if (valid) {
               arc = uptr(g.arcs)[a];
               const float ac_cost = -(cfg.acwt * llrow[arc.z]);
               nw = ((double)asf(arc.y) + cc) + (double)ac_cost;    // arc.weight + tok->cost + ac_cost
-              const unsigned long long k = d2o(nw + (double)adaptive_beam);
-              mymin = k < mymin ? k : mymin;
+              kk = d2o(nw + (double)adaptive_beam);
+              mymin = kk < mymin ? kk : mymin;
             }
-            const int q = wave_alloc(&sh.n_cand, valid);
-            if (valid) {
+            // An arc whose new_weight has already reached a bound on next_cutoff -- the smallest new_weight + adaptive_beam anybody in
+            // the workgroup has seen so far, kept in LDS -- cannot be admitted (the final next_cutoff is the minimum over all arcs, so
+            // it is no larger): it is not written to the candidate list.  The admitted set is still {new_weight < final next_cutoff}.
+            const unsigned long long wk = wave_min_u64(kk);
+            if (lane == 0 && wk != ~0ull) atomicMin(&sh.cand_bound, wk);
+            const bool keep = valid && nw < o2d(sh.cand_bound);
+            const int q = wave_alloc(&sh.n_cand, keep);
+            if (keep) {
               if (q < cand_cap) {
                 c_w[q] = nw;
                 i32x4 r; r.x = a; r.y = cur_b + base + owner; r.z = arc.x; r.w = 0;
@@ -731,19 +831,27 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
       {
         gp<int> front0 = uptr(s.front[0]); gp<int> elist0 = uptr(s.elist);
         const int frame_cap = s.frame_cap, front_cap = s.front_cap;
-        for (int base = 0; base < ncand; base += NT) {
-          const int q = base + tid;
-          const bool ok = q < ncand;
-          const double nw = c_w[ok ? q : 0];
-          const i32x4 r = c_r[ok ? q : 0];
-          const bool adm = ok && nw < next_cutoff;
-          int slot = -1; bool create = false, improved;
-          if (adm) { map_relax(sh, m2, r.z & STMASK, nw, slot, create, improved); if (slot == -1) sh.error = FERR_MAP; }
-          const bool pushf = create && r.z < 0;
-          const int f = wave_alloc(&sh.fcnt[0], pushf);
-          if (pushf) {      // (a created state with epsilon arcs: also the head of the frame's epsilon-state list)
-            if (f < front_cap) front0[f] = r.z & STMASK; else sh.error = FERR_FRONT;
-            if (f < frame_cap) elist0[f] = r.z & STMASK; else sh.error = FERR_FRAME;
+        constexpr int UC = 2;        // candidates a thread has in flight
+        for (int base = 0; base < ncand; base += NT * UC) {
+          double nw[UC]; i32x4 r[UC]; bool ok[UC];
+#pragma unroll
+          for (int u = 0; u < UC; u++) {
+            const int q = base + u * NT + tid;
+            ok[u] = q < ncand;
+            nw[u] = c_w[ok[u] ? q : 0];
+            r[u] = c_r[ok[u] ? q : 0];
+          }
+#pragma unroll
+          for (int u = 0; u < UC; u++) {
+            const bool adm = ok[u] && nw[u] < next_cutoff;
+            int slot = -1; bool create = false, improved;
+            if (adm) { map_relax(sh, m2, r[u].z & STMASK, nw[u], slot, create, improved); if (slot == -1) sh.error = FERR_MAP; }
+            const bool pushf = create && r[u].z < 0;
+            const int f = wave_alloc(&sh.fcnt[0], pushf);
+            if (pushf) {      // (a created state with epsilon arcs: also the head of the frame's epsilon-state list)
+              if (f < front_cap) front0[f] = r[u].z & STMASK; else sh.error = FERR_FRONT;
+              if (f < frame_cap) elist0[f] = r[u].z & STMASK; else sh.error = FERR_FRAME;
+            }
           }
         }
       }
@@ -764,28 +872,35 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
       const int nb = cur_b + cur_n;
       const int n_new = sh.n_new;
 #ifdef VBH_FASTER_DEBUG
-      if (tid == 0 && utt == 0 && frame < 12) printf("frame %d: n=%d ncand=%d n_new=%d g_used=%d next_cutoff=%f weight_cutoff=%f best=%f\n", frame, n, ncand, sh.n_new, sh.g_used, next_cutoff, weight_cutoff, best);
+      if (tid == 0 && utt == 0 && frame < 12) printf("frame %d: n=%d ncand=%d n_new=%d g_used=%d next_cutoff=%f\n", frame, n, ncand, sh.n_new, sh.g_used, next_cutoff);
 #endif
       if (nb + n_new > s.tok_cap) { if (tid == 0) sh.error = FERR_TOK; __syncthreads(); break; }
       // ---- winners: the emitting candidates and the epsilon arcs that reproduce a state's final cost
-      for (int base = 0; base < ncand; base += NT) {
-        const int q = base + tid;
-        const bool ok = q < ncand;
-        const double nw = c_w[ok ? q : 0];
-        const i32x4 r = c_r[ok ? q : 0];
-        if (ok && nw < next_cutoff) {
-          const int slot = map_find(sh, m2, r.z & STMASK);
-          if (slot != -1 && d2o(nw) == map_key(sh, m2, slot))
-            (void)__hip_atomic_fetch_min(&win[widx(slot)], ((unsigned long long)(unsigned)r.x << 32) | (unsigned)r.y,
-                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (int base = 0; base < ncand; base += NT * 2) {
+        double nw[2]; i32x4 r[2]; bool ok[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int q = base + u * NT + tid;
+          ok[u] = q < ncand;
+          nw[u] = c_w[ok[u] ? q : 0];
+          r[u] = c_r[ok[u] ? q : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          if (ok[u] && nw[u] < next_cutoff) {
+            const int slot = map_find(sh, m2, r[u].z & STMASK);
+            if (slot != -1 && d2o(nw[u]) == map_key(sh, m2, slot))
+              (void)__hip_atomic_fetch_min(&win[widx(slot)], ((unsigned long long)(unsigned)r[u].x << 32) | (unsigned)r[u].y,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
         }
       }
       FPHASE(6)
       epsilon_winners(g, s, next_cutoff, nb, sh);
       __syncthreads();
       FPHASE(7)
-      make_tokens(s, nb, sh);
-      FPHASE(11)
+      make_tokens(s, nb, cfg, sh, par, weight_cutoff, adaptive_beam);
+      FPHASE(14)
       __syncthreads();
       FPHASE(8)
       cur_b = nb; cur_n = n_new;
@@ -849,10 +964,10 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
     FPHASE(9)
 #ifdef VBH_FASTER_PROF
     if (tid == 0 && utt < 4) {
-      printf("faster utt %d (%d frames, %lld tokens): cycles/frame gc %lld cutoff %lld clear %lld pass1 %lld pass2 %lld closure %lld winners %lld eps-winners %lld make: loads %lld stores %lld barrier %lld; outside the frame loop %lld total\n",
-             utt, T, (long long)(cur_b + cur_n), tph[0] / T, tph[1] / T, tph[2] / T, tph[3] / T, tph[4] / T, tph[5] / T, tph[6] / T, tph[7] / T, tph[10] / T, tph[11] / T, tph[8] / T, tph[9]);
+      printf("faster utt %d (%d frames, %lld tokens): cycles/frame gc %lld cutoff %lld clear %lld pass1 %lld pass2 %lld closure %lld winners %lld eps-winners %lld make: loads %lld stores %lld min %lld count %lld selects %lld barrier %lld; outside the frame loop %lld total\n",
+             utt, T, (long long)(cur_b + cur_n), tph[0] / T, tph[1] / T, tph[2] / T, tph[3] / T, tph[4] / T, tph[5] / T, tph[6] / T, tph[7] / T, tph[10] / T, tph[11] / T, tph[12] / T, tph[13] / T, tph[14] / T, tph[8] / T, tph[9]);
     }
-    if (tid == 0) for (int i = 0; i < 12; i++) tph[i] = 0;
+    if (tid == 0) for (int i = 0; i < 16; i++) tph[i] = 0;
 #endif
     if (tid == 0) {
       FResult *r = &results[utt];
