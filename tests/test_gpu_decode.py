@@ -177,3 +177,50 @@ def test_decode_begin_end_two_contexts(ctx):
     for d in decs:
         d.close()
     graph.close(); ctx2.close()
+
+
+def test_small_shared_pool_under_concurrent_decoders(ctx):
+    """decoders made for small batches share one pool of slots that is smaller than the number of workgroups the device can hold:
+    three host threads decoding at once make their grids wait for slots (claim_slot) -- same lattices as alone, nobody falls to the
+    host's retry path"""
+    import threading
+    import torch
+    from voicebridge_amd import api
+    cfg = dict(beam=11.0, max_active=3000, min_active=100, lattice_beam=5.0)
+    S, P, T, seed, NU = 20000, 64, 150, 21, 8
+    g, t2p, ll = make_case(S, P, T, seed, eps_frac=0.3, spread=30.0)
+    foff = np.arange(NU + 1, dtype=np.int64) * T
+    graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
+    rng = np.random.default_rng(5)
+    mats = [np.concatenate([ll[rng.permutation(T)] for _ in range(NU)]) for _ in range(3)]
+    ref = []
+    dec0 = api.LatticeDecoder(ctx, graph, NU, T, **cfg)
+    for m in mats:
+        d = torch.from_numpy(m).to(ctx.device); ctx.torch_sync()
+        dec0.decode(d, foff, t2p)
+        ref.append([dec0.result(u) for u in range(NU)])
+    out, stats, errs = [None] * 3, [None] * 3, []
+
+    def work(i):
+        try:
+            c = api.Context(0)
+            dec = api.LatticeDecoder(c, graph, NU, T, **cfg)       # (finds dec0's pool: 8 slots)
+            d = torch.from_numpy(mats[i]).to(c.device); c.torch_sync()
+            for _ in range(3):
+                dec.decode(d, foff, t2p)
+            out[i] = [dec.result(u) for u in range(NU)]
+            stats[i] = dec.batch_stats()
+            dec.close(); c.close()
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    for i in range(3):
+        assert stats[i]["retried_in_big_slot"] == 0 and stats[i]["failed"] == 0, stats[i]
+        for a, b in zip(out[i], ref[i]):
+            np.testing.assert_array_equal(a["words"], b["words"])
+            np.testing.assert_array_equal(a["ali"], b["ali"])
+            assert a["num_toks"] == b["num_toks"] and a["num_links"] == b["num_links"]
+    dec0.close(); graph.close()

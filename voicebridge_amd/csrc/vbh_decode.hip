@@ -1431,8 +1431,11 @@ __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, in
 // Search workspaces ("slots") of one device are a pool shared by every decoder created on it with
 // vbh_decoder_create_shared: the persistent grids of several batches are resident at the same time (the grid of batch k
 // drains while those of batches k+1, k+2 fill the freed CUs), so a workgroup cannot own slot blockIdx.x; it claims a free
-// slot when it starts and gives it back when it leaves.  At most WG_PER_CU workgroups per CU are resident, the pool holds
-// that many slots, so a resident workgroup always finds one.  The pool is partitioned by XCD (HW_REG_XCC_ID) and a
+// slot when it starts and gives it back when it leaves.  At most WG_PER_CU workgroups per CU are resident; a pool made for full
+// batches holds that many slots, so a resident workgroup finds one at once.  A pool made for small batches (--decode-batch below
+// the CU count) that several decoders share holds fewer: a workgroup then waits for a slot -- the holders are resident and
+// finish on their own, so the wait ends; it is bounded all the same (a few seconds), after which the workgroup leaves and its
+// grid's utterances fall to the grid's other workgroups, or are searched again by the host (ERR_NOT_RUN).  The pool is partitioned by XCD (HW_REG_XCC_ID) and a
 // workgroup looks in its own XCD's partition first: the slot's working set then stays in that XCD's L2.  That is a speed
 // matter only -- hand-over is an agent-scope release by the leaving workgroup and an agent-scope acquire by the claiming
 // one, and the only data a new owner reads before writing it are the epoch-stamped state-map entries (older versions carry
@@ -1444,7 +1447,7 @@ __device__ __forceinline__ int claim_slot(const SlotPoolDev &sp) {
   int x = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF);     // HW_REG_XCC_ID[3:0]
   if (x >= nx) x %= nx;
   const int start = (int)((blockIdx.x / 8u) % (unsigned)n);
-  for (int round = 0; round < 4096; round++) {
+  for (int round = 0; round < (1 << 20); round++) {
     // own partition first, then the others
     for (int dx = 0; dx < (round == 0 ? 1 : nx); dx++) {
       const int part = (x + dx) % nx;
@@ -1456,9 +1459,9 @@ __device__ __forceinline__ int claim_slot(const SlotPoolDev &sp) {
         if (__hip_atomic_compare_exchange_strong(f, &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return part * n + i;
       }
     }
-    __builtin_amdgcn_s_sleep(64);
+    if (round < 64) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(127);
   }
-  return -1;      // never expected (the pool holds a slot for every resident workgroup): the utterances are taken by the others
+  return -1;      // (seconds without a free slot: see above)
 }
 
 __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g, DecCfg cfg, const Slot *slots, SlotPoolDev spool,
