@@ -450,7 +450,9 @@ def host_threads(args):
         n = len(os.sched_getaffinity(0))
     except Exception:
         n = os.cpu_count() or 16
-    return max(1, min(16, n))
+    # (the ranks of a node share its cores: a rank takes its share, 16 at most)
+    ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    return max(1, min(16, n // ranks_here))
 
 
 def trans_info(args):

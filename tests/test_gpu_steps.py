@@ -220,7 +220,7 @@ def test_decode_fmllr_end_to_end(host, tmp_path):
     graph = exp / "graph"
     (graph / "phones").mkdir(parents=True)
     util.write_mdl(str(exp / "final.mdl"), n_cd, H, offs, w, (means * iv).astype(np.float32), iv)
-    util.write_vector_fst(str(graph / "HCLG.fst"), g["final"], g["arc_offset"], g["arcs"])
+    util.write_const_fst(str(graph / "HCLG.fst"), g["final"], g["arc_offset"], g["arcs"])      # (a ConstFst, as the reference's mkgraph writes HCLG: the mapped reader)
     (graph / "words.txt").write_text("<eps> 0\n" + "".join("w%d %d\n" % (i, i) for i in range(1, n_words + 2)))
     (graph / "phones" / "silence.csl").write_text("1:2\n")
     dec = exp / "decode_test"

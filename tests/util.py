@@ -71,7 +71,7 @@ def read_wav_pcm16(path):
 
 
 # ---------------------------------------------------------------- files for the lattice tests
-from voicebridge_amd.refio import write_feats_ark, write_mdl, write_vector_fst, write_wav  # noqa: E402,F401
+from voicebridge_amd.refio import write_const_fst, write_feats_ark, write_mdl, write_vector_fst, write_wav  # noqa: E402,F401
 
 
 def read_lattice_ark_bytes(raw):

@@ -99,7 +99,7 @@ def main():
         refio.write_mdl(os.path.join(exp, "final.mdl"), n_cd, H, offs, w, miv, iv)
         del mf, post, fit, gains
         torch.cuda.empty_cache()
-        refio.write_vector_fst(os.path.join(graph, "HCLG.fst"), g["final"], g["arc_offset"], g["arcs"], g["start"])
+        refio.write_const_fst(os.path.join(graph, "HCLG.fst"), g["final"], g["arc_offset"], g["arcs"], g["start"])      # (a ConstFst, as the reference's mkgraph leaves it)
         with open(os.path.join(graph, "words.txt"), "w") as f:
             f.write("<eps> 0\n" + "".join("w%d %d\n" % (i, i) for i in range(1, a.words + 2)))
         t_setup = time.perf_counter() - t0

@@ -2378,44 +2378,71 @@ int vbh_graph_create(vbh_ctx *ctx, int32_t num_states, int32_t start, const floa
   VBH_CHECK(h_arc_offsets[0] == 0 && A >= 0 && A < 2147483647LL, "vbh_graph_create: bad arc offsets");
   VBH_CHECK(A == 0 || h_arcs, "vbh_graph_create: arcs missing");
   if (vbh_use_device(ctx)) return -1;
+  // (the two passes over the arcs run on a few host threads: a decoding graph has millions of them, and every job of a step waits
+  // for this call)
+  const int n_thr = (int)std::max(1u, std::min(8u, std::min(std::thread::hardware_concurrency(), (unsigned)(A / 200000 + 1))));
+  auto parallel_states = [&](auto body) {        // body(thread index, first state, end state)
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_thr; t++)
+      th.emplace_back([&, t]() { body(t, (int)((long long)num_states * t / n_thr), (int)((long long)num_states * (t + 1) / n_thr)); });
+    body(0, 0, (int)((long long)num_states / n_thr));
+    for (auto &x : th) x.join();
+  };
   std::vector<int> off(num_states + 1), nieps(num_states, 0);
-  int max_il = 0, max_deg = 0;
   for (int s = 0; s <= num_states; s++) {
     VBH_CHECK(s == 0 || h_arc_offsets[s] >= h_arc_offsets[s - 1], "vbh_graph_create: arc offsets not monotone at state %d", s);
     off[s] = (int)h_arc_offsets[s];
   }
-  for (int s = 0; s < num_states; s++) {
-    if (off[s + 1] - off[s] > max_deg) max_deg = off[s + 1] - off[s];
-    for (int a = off[s]; a < off[s + 1]; a++) {
-      VBH_CHECK(h_arcs[a].nextstate >= 0 && h_arcs[a].nextstate < num_states, "vbh_graph_create: arc %d leaves the graph", a);
-      VBH_CHECK(h_arcs[a].ilabel >= 0, "vbh_graph_create: negative ilabel on arc %d", a);
-      nieps[s] += h_arcs[a].ilabel == 0;
-      if (h_arcs[a].ilabel > max_il) max_il = h_arcs[a].ilabel;
+  std::vector<int> t_max_il(n_thr, 0), t_max_deg(n_thr, 0), t_bad_arc(n_thr, -1), t_bad_kind(n_thr, 0);
+  parallel_states([&](int t, int s0, int s1) {
+    int mi = 0, md = 0;
+    for (int s = s0; s < s1; s++) {
+      if (off[s + 1] - off[s] > md) md = off[s + 1] - off[s];
+      int ne = 0;
+      for (int a = off[s]; a < off[s + 1]; a++) {
+        if (h_arcs[a].nextstate < 0 || h_arcs[a].nextstate >= num_states) { if (t_bad_arc[t] < 0) { t_bad_arc[t] = a; t_bad_kind[t] = 1; } continue; }
+        if (h_arcs[a].ilabel < 0) { if (t_bad_arc[t] < 0) { t_bad_arc[t] = a; t_bad_kind[t] = 2; } continue; }
+        ne += h_arcs[a].ilabel == 0;
+        if (h_arcs[a].ilabel > mi) mi = h_arcs[a].ilabel;
+      }
+      nieps[s] = ne;
     }
+    t_max_il[t] = mi; t_max_deg[t] = md;
+  });
+  int max_il = 0, max_deg = 0;
+  for (int t = 0; t < n_thr; t++) {
+    VBH_CHECK(t_bad_kind[t] != 1, "vbh_graph_create: arc %d leaves the graph", t_bad_arc[t]);
+    VBH_CHECK(t_bad_kind[t] != 2, "vbh_graph_create: negative ilabel on arc %d", t_bad_arc[t]);
+    max_il = std::max(max_il, t_max_il[t]); max_deg = std::max(max_deg, t_max_deg[t]);
   }
   // device records: per state {first arc, #epsilon arcs, #arcs, final cost}; arcs re-ordered
   // epsilon-first within a state (stable), next state tagged when it has epsilon arcs itself
-  std::vector<i32x4> h_st(num_states), h_ar((size_t)std::max<long long>(A, 1));
-  std::vector<int> h_il((size_t)std::max<long long>(A, 1), 0);
-  for (int s = 0; s < num_states; s++) {
-    int fb; memcpy(&fb, &h_final[s], 4);
-    i32x4 r; r.x = off[s]; r.y = nieps[s]; r.z = off[s + 1] - off[s]; r.w = fb;
-    h_st[s] = r;
-    int pe = off[s], pn = off[s] + nieps[s];
-    for (int a = off[s]; a < off[s + 1]; a++) {
-      const int p = h_arcs[a].ilabel == 0 ? pe++ : pn++;
-      i32x4 x; x.x = h_arcs[a].nextstate | (nieps[h_arcs[a].nextstate] > 0 ? EPSBIT : 0);
-      int wb; memcpy(&wb, &h_arcs[a].weight, 4);
-      x.y = wb; x.z = -1; x.w = h_arcs[a].olabel;
-      h_ar[p] = x; h_il[p] = h_arcs[a].ilabel;
+  const size_t An = (size_t)std::max<long long>(A, 1);
+  std::vector<i32x4> h_st(num_states);
+  std::unique_ptr<i32x4[]> h_ar(new i32x4[An]);       // (every element is written below: no zero-fill of ~100 MB first)
+  std::unique_ptr<int[]> h_il(new int[An]);
+  if (A == 0) { h_ar[0] = i32x4{0, 0, 0, 0}; h_il[0] = 0; }
+  parallel_states([&](int, int s0, int s1) {
+    for (int s = s0; s < s1; s++) {
+      int fb; memcpy(&fb, &h_final[s], 4);
+      i32x4 r; r.x = off[s]; r.y = nieps[s]; r.z = off[s + 1] - off[s]; r.w = fb;
+      h_st[s] = r;
+      int pe = off[s], pn = off[s] + nieps[s];
+      for (int a = off[s]; a < off[s + 1]; a++) {
+        const int p = h_arcs[a].ilabel == 0 ? pe++ : pn++;
+        i32x4 x; x.x = h_arcs[a].nextstate | (nieps[h_arcs[a].nextstate] > 0 ? EPSBIT : 0);
+        int wb; memcpy(&wb, &h_arcs[a].weight, 4);
+        x.y = wb; x.z = -1; x.w = h_arcs[a].olabel;
+        h_ar[p] = x; h_il[p] = h_arcs[a].ilabel;
+      }
     }
-  }
+  });
   vbh_graph *g = new vbh_graph();
   g->device = ctx->device; g->S = num_states; g->start = start; g->A = A; g->max_ilabel = max_il; g->max_degree = max_deg;
   g->h_final.assign(h_final, h_final + num_states);
   hipStream_t st = ctx->stream;
-  if (g->st.upload(h_st.data(), h_st.size(), st) || g->arcs.upload(h_ar.data(), h_ar.size(), st) ||
-      g->arc_il.upload(h_il.data(), h_il.size(), st)) { delete g; return -1; }
+  if (g->st.upload(h_st.data(), h_st.size(), st) || g->arcs.upload(h_ar.get(), An, st) ||
+      g->arc_il.upload(h_il.get(), An, st)) { delete g; return -1; }
   VBH_HIP(hipStreamSynchronize(st));
   *out = g;
   return 0;

@@ -815,7 +815,51 @@ std::string ReadFstString(std::istream &is) {
 constexpr int32_t kFstMagic = 2125659606;
 }  // namespace
 
+// A decoding graph is tens to hundreds of megabytes of fixed-size records: a const FST in a file is mapped and its arc array copied
+// out in one piece (no zero-filled vector first, no stream buffering); everything else goes through the stream reader.
+static bool ReadConstFstMapped(const std::string &path, Graph *g) {
+  const int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) return false;
+  struct stat sb;
+  if (fstat(fd, &sb) != 0 || sb.st_size < 64) { close(fd); return false; }
+  const size_t len = (size_t)sb.st_size;
+  void *mp = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (mp == MAP_FAILED) return false;
+  const char *b = static_cast<const char *>(mp);
+  size_t pos = 0;
+  bool ok = false;
+  auto rd = [&](void *dst, size_t n) -> bool { if (pos + n > len) return false; memcpy(dst, b + pos, n); pos += n; return true; };
+  auto rd_str = [&](std::string *o) -> bool { int32_t n; if (!rd(&n, 4) || n < 0 || pos + (size_t)n > len) return false; o->assign(b + pos, (size_t)n); pos += (size_t)n; return true; };
+  do {
+    int32_t magic, version, flags; uint64_t props; int64_t start, nstates, narcs;
+    std::string fsttype, arctype;
+    if (!rd(&magic, 4) || magic != kFstMagic || !rd_str(&fsttype) || !rd_str(&arctype)) break;
+    if (fsttype != "const" || arctype != "standard") break;
+    if (!rd(&version, 4) || !rd(&flags, 4) || !rd(&props, 8) || !rd(&start, 8) || !rd(&nstates, 8) || !rd(&narcs, 8)) break;
+    if ((flags & 3) || nstates < 0 || narcs < 0) break;
+    const bool aligned = (flags & 4) || version == 1;
+    if (aligned) pos = (pos + 15) & ~(size_t)15;
+    struct ConstState { float final; uint32_t pos, narcs, niepsilons, noepsilons; };
+    if (pos + sizeof(ConstState) * (size_t)nstates > len) break;
+    const ConstState *st = reinterpret_cast<const ConstState *>(b + pos);      // (20-byte records at a 4-byte-aligned offset)
+    pos += sizeof(ConstState) * (size_t)nstates;
+    if (aligned) pos = (pos + 15) & ~(size_t)15;
+    if (pos + sizeof(Arc) * (size_t)narcs > len) break;
+    const Arc *arcs = reinterpret_cast<const Arc *>(b + pos);
+    g->start = (int32_t)start;
+    g->arcs.assign(arcs, arcs + narcs);
+    g->final_cost.resize(nstates); g->arc_offset.resize(nstates + 1);
+    for (int64_t s = 0; s < nstates; s++) { g->final_cost[s] = st[s].final; g->arc_offset[s] = st[s].pos; }
+    g->arc_offset[nstates] = narcs;
+    ok = true;
+  } while (false);
+  munmap(mp, len);
+  return ok;
+}
+
 void ReadFst(const std::string &path, Graph *g) {
+  if (ReadConstFstMapped(path, g)) return;      // (anything else -- vector FSTs, unsupported or damaged files -- gets the stream reader and its messages)
   std::ifstream is(path, std::ios::binary);
   if (!is) Fail("cannot open fst " + path);
   ReadFstStream(is, g, path);

@@ -76,6 +76,30 @@ def write_vector_fst(path, final, arc_offset, arcs, start=0):
         f.write(vector_fst_bytes(final, arc_offset, arcs, start))
 
 
+def write_const_fst(path, final, arc_offset, arcs, start=0):
+    """OpenFst ConstFst<StdArc> binary file (what the reference's mkgraph leaves as HCLG.fst: `fstconvert(..., "const")`,
+    VB/scr/utils/mkgraph.cpp:309; openfst const-fst.h: file version 2, unaligned): header, the states
+    {final f32, first arc u32, #arcs u32, #input-epsilons u32, #output-epsilons u32}, the arcs."""
+    S = len(final)
+    a = np.ascontiguousarray(arcs)
+    A = len(a)
+    off = np.asarray(arc_offset, np.int64)
+    narcs = np.diff(off)
+
+    def s_(x):
+        return np.int32(len(x)).tobytes() + x
+    hdr = (np.int32(2125659606).tobytes() + s_(b"const") + s_(b"standard") + np.int32(2).tobytes() + np.int32(0).tobytes() +
+           np.uint64(3).tobytes() + np.int64(start).tobytes() + np.int64(S).tobytes() + np.int64(A).tobytes())
+    st = np.zeros(S, np.dtype([("final", "<f4"), ("pos", "<u4"), ("narcs", "<u4"), ("nie", "<u4"), ("noe", "<u4")]))
+    st["final"] = np.asarray(final, "<f4"); st["pos"] = off[:-1]; st["narcs"] = narcs
+    if A:
+        state_of_arc = np.repeat(np.arange(S, dtype=np.int64), narcs)
+        st["nie"] = np.bincount(state_of_arc, weights=(a["ilabel"] == 0), minlength=S).astype(np.uint32)
+        st["noe"] = np.bincount(state_of_arc, weights=(a["olabel"] == 0), minlength=S).astype(np.uint32)
+    with open(path, "wb") as f:
+        f.write(hdr); f.write(st.tobytes()); f.write(a.tobytes())
+
+
 def write_fst_table(path, graphs):
     """Binary archive of VectorFst<StdArc> (what compile-train-graphs writes and gmm-align-compiled reads: key, space, the FST
     as OpenFst writes it -- VectorFstTplHolder, K/fstext/kaldi-fst-io-inl.h:170-207).  graphs: {key: (final, arc_offset, arcs, start)}."""
