@@ -20,6 +20,7 @@
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <future>
 #include <thread>
 #include <vector>
 
@@ -768,6 +769,16 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     };
     vbh_ctx *ctx = Ctx();
     LatgenCache &cache = g_latgen;
+    std::future<std::shared_ptr<GraphHolder>> graph_loading;
+    // (the helper must not outlive this call: an exception on the way out waits for it first)
+    struct JoinOnExit { std::future<std::shared_ptr<GraphHolder>> &f; ~JoinOnExit() { if (f.valid()) f.wait(); } } join_graph{graph_loading};
+    auto need_graph = [&]() {
+      if (!graph_loading.valid()) return;
+      cache.gh = graph_loading.get();
+      cache.graph_start = cache.gh->start;
+      cache.ctx = ctx; cache.graph_path = po.args[1]; cache.graph_sig = FileSig(po.args[1]);
+      lap("graph (loaded meanwhile)");
+    };
     {
       const long long ms = FileSig(po.args[0]), gs = FileSig(po.args[1]);
       if (cache.ctx != ctx) cache.Release();
@@ -776,9 +787,11 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
       if (!cache.gh || cache.graph_path != po.args[1] || cache.graph_sig != gs || gs < 0) {
         if (cache.dec) { vbh_decoder_destroy(cache.dec); cache.dec = nullptr; cache.dec_batch = cache.dec_T = 0; }
         cache.gh.reset();
-        cache.gh = SharedGraph(ctx, g_device, po.args[1], gs, lap);
-        cache.graph_start = cache.gh->start;
-        cache.ctx = ctx; cache.graph_path = po.args[1]; cache.graph_sig = gs;
+        // The graph (file -> host -> device form: the longest piece of a cold start) is fetched by a helper thread while this one
+        // reads the model and the features and scores the first batch; it is waited for where the search workspace is made.
+        const int device = g_device;
+        const std::string gpath = po.args[1];
+        graph_loading = std::async(std::launch::async, [ctx, device, gpath, gs]() { return SharedGraph(ctx, device, gpath, gs, [](const char *) {}); });
       }
       if (cache.gmm == nullptr || cache.model_path != po.args[0] || cache.model_sig != ms || ms < 0) {
         if (cache.gmm) { vbh_gmm_destroy(cache.gmm); cache.gmm = nullptr; }
@@ -791,9 +804,7 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
       }
     }
     const vbio::Model &model = cache.model;
-    struct { int32_t start; } graph{cache.graph_start};
     vbh_gmm *gmm = cache.gmm;
-    vbh_graph *g = cache.gh->g;
     // ---- fused front end (extension, device_feats.h)
     FrontEnd fe;
     fe.Parse(po);
@@ -873,6 +884,9 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
       Check(vbh_gmm_loglikes_ld(gmm, d_feats_p, T, (float *)d_ll.p, ld), "vbh_gmm_loglikes");
       // the decoder (tens of GB of search workspace at the reference's batch sizes) is kept across the batches of the table
       // and only rebuilt when a batch needs more utterances or longer ones than it was made for
+      need_graph();
+      vbh_graph *g = cache.gh->g;
+      struct { int32_t start; } graph{cache.graph_start};
       if (dec == nullptr || (int)b.keys.size() > dec_batch || max_T > dec_T) {
         if (dec) vbh_decoder_destroy(dec);
         dec = nullptr;
