@@ -60,19 +60,24 @@ const RawTable &CachedRawTable(const std::string &rspecifier) {
   RawTable &t = g_table;
   if (t.ctx == ctx && t.rspec == rspecifier && t.sig == sig && sig >= 0 && t.d_raw) return t;
   t = RawTable();
-  vbio::MatrixReader reader(rspecifier);
-  std::vector<float> data;
-  std::string key; vbio::Matrix m;
-  while (reader.Next(&key, &m)) {
+  // (four host threads read and decode the entries: the job has nothing else to do until its features are on the device)
+  std::vector<std::string> keys; std::vector<vbio::Matrix> mats;
+  vbio::ReadMatricesInOrder(rspecifier, 4, &keys, &mats);
+  for (size_t i = 0; i < keys.size(); i++) {
+    const vbio::Matrix &m = mats[i];
     if (m.rows > 0) {
       if (t.dim == 0) t.dim = m.cols;
-      if (m.cols != t.dim) throw ApiError("feature table " + rspecifier + ": " + key + " has dimension " + std::to_string(m.cols) + ", the entries before it " + std::to_string(t.dim));
-      data.insert(data.end(), m.data.begin(), m.data.end());
+      if (m.cols != t.dim) throw ApiError("feature table " + rspecifier + ": " + keys[i] + " has dimension " + std::to_string(m.cols) + ", the entries before it " + std::to_string(t.dim));
     }
-    t.index[key] = (int)t.keys.size();
-    t.keys.push_back(key);
+    t.index[keys[i]] = (int)t.keys.size();
+    t.keys.push_back(keys[i]);
     t.offs.push_back(t.offs.back() + (m.rows > 0 ? m.rows : 0));
   }
+  const size_t total = (size_t)t.offs.back() * (size_t)t.dim;
+  std::unique_ptr<float[]> data_p(new float[std::max<size_t>(total, 1)]);
+  struct { float *p; size_t n; float *data() { return p; } size_t size() const { return n; } bool empty() const { return n == 0; } } data{data_p.get(), total};
+  for (size_t i = 0; i < mats.size(); i++)
+    if (mats[i].rows > 0) memcpy(data.p + (size_t)t.offs[i] * (size_t)t.dim, mats[i].data.data(), sizeof(float) * mats[i].data.size());
   t.d_raw.reset(new DevBuffer(ctx, sizeof(float) * data.size()));
   if (!data.empty()) Check(vbh_copy_h2d(ctx, t.d_raw->p, data.data(), sizeof(float) * data.size()), "vbh_copy_h2d");
   Check(vbh_ctx_sync(ctx), "vbh_ctx_sync");      // `data` goes out of scope

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <limits>
 #include <sstream>
+#include <thread>
 
 namespace vbio {
 
@@ -465,6 +466,46 @@ bool MatrixReader::Next(std::string *key, Matrix *m) {
   const bool binary = ReadBinaryHeader(ark_);
   ReadMatrix(ark_, binary, m);
   return true;
+}
+
+void ReadMatricesInOrder(const std::string &rspecifier, int threads, std::vector<std::string> *keys, std::vector<Matrix> *mats) {
+  keys->clear(); mats->clear();
+  const Rspec spec = ParseRspecifier(rspecifier);
+  if (!spec.is_scp || threads <= 1) {
+    MatrixReader r(rspecifier);
+    std::string k; Matrix m;
+    while (r.Next(&k, &m)) { keys->push_back(k); mats->push_back(std::move(m)); m = Matrix(); }
+    return;
+  }
+  const std::vector<ScpEntry> scp = ReadScp(spec.path);
+  const size_t n = scp.size();
+  keys->resize(n); mats->resize(n);
+  const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n / 8 + 1));
+  std::vector<std::string> err((size_t)nt);
+  auto work = [&](int t) {
+    try {
+      std::ifstream f; std::string open_path;
+      for (size_t i = n * (size_t)t / (size_t)nt; i < n * (size_t)(t + 1) / (size_t)nt; i++) {
+        const ScpEntry &e = scp[i];
+        if (!f.is_open() || open_path != e.path) {       // (the entries of a job usually sit in one archive)
+          f.close(); f.clear();
+          f.open(e.path, std::ios::binary);
+          if (!f) Fail("cannot open " + e.path);
+          open_path = e.path;
+        }
+        f.clear();
+        f.seekg(e.offset >= 0 ? e.offset : 0);
+        const bool binary = ReadBinaryHeader(f);
+        ReadMatrix(f, binary, &(*mats)[i]);
+        (*keys)[i] = e.key;
+      }
+    } catch (const std::exception &ex) { err[(size_t)t] = ex.what(); if (err[(size_t)t].empty()) err[(size_t)t] = "error"; }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+  work(0);
+  for (std::thread &x : th) x.join();
+  for (const std::string &e : err) if (!e.empty()) Fail(e);
 }
 
 std::map<std::string, Matrix> ReadMatrixTable(const std::string &rspecifier) {

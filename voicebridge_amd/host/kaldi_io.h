@@ -79,6 +79,9 @@ class MatrixReader {
   std::vector<ScpEntry> scp_;
   size_t pos_ = 0;
 };
+// all entries of a table, in table order; the entries of an scp table (a file position each) are read and decoded on up to
+// `threads` host threads -- a job's feature table is hundreds of compressed matrices, and everything the job does waits for it
+void ReadMatricesInOrder(const std::string &rspecifier, int threads, std::vector<std::string> *keys, std::vector<Matrix> *mats);
 // all entries of a table of matrices keyed by utterance/speaker (transforms, cmvn stats)
 std::map<std::string, Matrix> ReadMatrixTable(const std::string &rspecifier);
 std::map<std::string, MatrixD> ReadMatrixDTable(const std::string &rspecifier);
