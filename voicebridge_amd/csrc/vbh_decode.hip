@@ -573,6 +573,9 @@ __device__ __forceinline__ gp<i32x4> tokp(gp<i32x4> wt, gp<i32x4> ht, int id) { 
 
 // Consistency checks on indices that are about to address memory: a violation is recorded (first one wins), the utterance
 // fails with ERR_INTERNAL instead of the device faulting.
+#ifndef VBH_SWEEP_BITS
+#define VBH_SWEEP_BITS VBH_SURVIVOR_BITS      // the pruning sweeps record excised window links in the survivor bitmap only (eval_links)
+#endif
 #ifndef VBH_CHECKS
 #define VBH_CHECKS 0           // (diagnostic builds: -DVBH_CHECKS=1; measured r02: 20 % slower, the compares cost registers the frame loop does not have)
 #endif
@@ -598,7 +601,14 @@ __device__ __forceinline__ bool chk_tok_id(Shared &sh, const Slot &s, int where,
 template <bool LDS_TMP>
 __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, int le_, int split, gp<i32x4> wt, gp<i32x4> ht,
                                                          float lattice_beam, unsigned *lds_tmp, int tb, Shared &sh, const Slot &s,
-                                                         gp<unsigned long long> alive_bits = nullptr) {
+                                                         gp<unsigned long long> alive_bits = nullptr, bool bits_valid = false,
+                                                         int lds_off = 0, int lds_cap = 128) {
+  // With a survivor bitmap (links of the raw window; VBH_SWEEP_BITS): the bitmap IS the record of which links are excised -- nothing is
+  // written into the link records (a scattered 4-byte store per excised link: whole 64-byte half-lines written back for it), and from
+  // the second sweep of a visit on (bits_valid) the links the bitmap says are gone are not read again.  The words of the frame being
+  // swept are kept in LDS (sh.hist, 128 words = 8192 links; beyond that from the bitmap in HBM) between the sweeps of a visit.
+  const bool use_bits = VBH_SWEEP_BITS && alive_bits != nullptr;
+  unsigned long long *lbits = reinterpret_cast<unsigned long long *>(sh.hist) + lds_off;      // (a frame with its links in two ranges: half of the words each)
   unsigned long long kept = 0;
   for (int base = lb; base < le_; base += NT * UL) {
     i32x4 L[UL]; bool ok[UL];
@@ -606,6 +616,11 @@ __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, i
     for (int u = 0; u < UL; u++) {
       const int l = base + u * NT + (int)threadIdx.x;
       ok[u] = l < le_;
+      if (use_bits && bits_valid) {
+        const int wfirst = base + u * NT + ((int)threadIdx.x & ~63), wi = (wfirst - lb) >> 6;
+        const unsigned long long word = wfirst < le_ ? (wi < lds_cap ? lbits[wi] : alive_bits[wfirst >> 6]) : 0ull;
+        ok[u] = ok[u] && ((word >> ((int)threadIdx.x & 63)) & 1ull);
+      }
       L[u] = lk[ok[u] ? l : lb];
       ok[u] = ok[u] && L[u].x >= 0;   // negative source: already excised
       if (ok[u]) {
@@ -625,7 +640,7 @@ __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, i
       // next_tok->extra_cost + ((tok->tot_cost + link->acoustic_cost + link->graph_cost) - next_tok->tot_cost)
       float le = asf(D[u].z) + (asf(L[u].z) - asf(D[u].y));
       const bool keep = ok[u] && !(le > lattice_beam);
-      if (ok[u] && !keep) ((gp<int>)&lk[l])[0] = -1;
+      if (ok[u] && !keep && !use_bits) ((gp<int>)&lk[l])[0] = -1;
       if (keep) {
         if (le < 0.0f) le = 0.0f;
         if (LDS_TMP) atomicMin(&lds_tmp[(L[u].x & ~WBIT) - tb], __float_as_uint(le));
@@ -635,7 +650,10 @@ __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, i
       // a wave's 64 links are consecutive, so the split falls on a lane boundary
       const int first = base + u * NT + ((int)threadIdx.x & ~63);
 #if VBH_SURVIVOR_BITS
-      if (alive_bits && ((int)threadIdx.x & 63) == 0 && first < le_) alive_bits[first >> 6] = m;      // (lb is a multiple of 64 in W)
+      if (alive_bits && ((int)threadIdx.x & 63) == 0 && first < le_) {      // (lb is a multiple of 64 in W)
+        alive_bits[first >> 6] = m;
+        if (use_bits && ((first - lb) >> 6) < lds_cap) lbits[(first - lb) >> 6] = m;
+      }
 #endif
       const int ne = split - first;   // lanes [0, ne) hold epsilon links
       const unsigned long long em = ne <= 0 ? 0ull : (ne >= 64 ? ~0ull : ((1ull << ne) - 1ull));
@@ -701,16 +719,16 @@ __device__ int prune_frame(const Slot &s, int f, float lattice_beam, float delta
     }
     unsigned long long kept;
     if (lds_tmp) {
-      if (one_range) kept = eval_links<true>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits);
+      if (one_range) kept = eval_links<true>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0);
       else {
-        kept = eval_links<true>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, pbits);
-        kept += eval_links<true>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits);
+        kept = eval_links<true>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, pbits, iter > 0, 0, 64);
+        kept += eval_links<true>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 64, 64);
       }
     } else {
-      if (one_range) kept = eval_links<false>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits);
+      if (one_range) kept = eval_links<false>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0);
       else {
-        kept = eval_links<false>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, pbits);
-        kept += eval_links<false>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits);
+        kept = eval_links<false>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, pbits, iter > 0, 0, 64);
+        kept += eval_links<false>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 64, 64);
       }
     }
     if ((tid & 63) == 0) {
