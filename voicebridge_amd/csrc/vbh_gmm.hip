@@ -8,16 +8,17 @@
 //   gmm/diag-gmm.cc:114-152              ComputeGconsts (host, at create)
 //   matrix/kaldi-vector.cc:757-775       LogSumExp with the max + log(FLT_EPSILON) cutoff
 //
-// Formulation.  For a tile of 64 frames and up to 128 Gaussians the per-Gaussian
-// log-likelihoods are one exact-f32 MFMA contraction  C[t][g] = sum_k A[t][k] B[k][g]  with
-//   A[t] = [ x_0..x_{D-1}, x_0^2..x_{D-1}^2, 1, 0.. ]           (K = 2D+1, padded to 8)
-//   B[:,g] = [ miv_g, -0.5 iv_g, gconst_g, 0.. ]
-// (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, bit-identical to VALU f32), followed by
-// a log-sum-exp over each pdf's own Gaussians.  The model is packed once, tile-major, so a
-// workgroup streams B tiles with 16-byte coalesced loads (L2/MALL resident: 4.7 MB at
-// G = 15000, D = 39) while its 64 frames of A stay in LDS.  The accumulator tile is spilled to
-// the LDS space of the B tile it came from, and the epilogue threads walk pdfs.  A pdf with more
-// than 128 Gaussians is scored as several column groups that gmm_fold_parts_kernel combines.
+// Formulation.  The per-Gaussian log-likelihoods of a tile of 64 frames are an exact-f32 MFMA contraction
+//   C[g][t] = sum_k M[g][k] X[k][t],   M[g] = [ miv_g, -0.5 iv_g, gconst_g, 0.. ],   X[:,t] = [ x, x^2, 1, 0.. ]   (K = 2D+1, padded to 8)
+// (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, bit-identical to VALU f32), followed by a log-sum-exp over each pdf's own
+// Gaussians.  Two kernels:
+//   * gmm_rows_kernel (the product): the MODEL is the MFMA's A operand (row-blocks of 32 Gaussians straight from global memory, L2/MALL
+//     resident: 4.8 MB at G = 15000, D = 39), the frames its B operand (in LDS); the accumulator layout then gives every lane the 32
+//     Gaussians of ONE frame, the LogSumExp is a register loop, and a pdf may run from one row-block into the next (dense packing).
+//     See the comment above the kernel;
+//   * gmm_loglikes_kernel (round 1's form, behind VBH_GMM_V1): frames as the A operand, Gaussian tiles of 128 columns as B, the
+//     accumulator tile spilled to LDS for the epilogue; a pdf with more than 128 Gaussians in column groups that gmm_fold_parts_kernel
+//     combines.
 //
 // Roofline: per T frames  bytes = 4(2GD+G) + 4TD + 4TP,
 // flops = TG(4D+2) + TG + TP.  At the reference sizes this is fp32-matrix bound (AI ~ 200
