@@ -164,16 +164,19 @@ int WeightSilencePost(int argc, char *argv[], std::ofstream &file_log) {
     bool text_out = false;
     std::ofstream out = vbio::OpenArkForWriting(po.args[4], &text_out);
     int n = 0;
+    // (per transition-id: is its phone a silence phone?  The frames are filtered in place: a table holds a vector per frame)
+    std::vector<char> tid_sil(model.trans.phone.size(), 0);
+    for (size_t t = 1; t < model.trans.phone.size(); t++) tid_sil[t] = sil.count(model.trans.phone[t]) ? 1 : 0;
     for (auto &kv : vbio::ReadPosteriorTable(po.args[3])) {
       for (auto &fr : kv.second) {
-        std::vector<std::pair<int32_t, float>> keep;
-        keep.reserve(fr.size());
-        for (const auto &pr : fr) {
-          if (pr.first <= 0 || pr.first >= (int32_t)model.trans.phone.size()) throw ApiError("posterior: transition-id out of the model's range");
-          if (sil.count(model.trans.phone[pr.first])) { if (w != 0.0f) keep.emplace_back(pr.first, pr.second * w); }
-          else keep.push_back(pr);
+        size_t o = 0;
+        for (size_t i = 0; i < fr.size(); i++) {
+          const std::pair<int32_t, float> pr = fr[i];
+          if (pr.first <= 0 || pr.first >= (int32_t)tid_sil.size()) throw ApiError("posterior: transition-id out of the model's range");
+          if (tid_sil[pr.first]) { if (w != 0.0f) fr[o++] = std::make_pair(pr.first, pr.second * w); }
+          else fr[o++] = pr;
         }
-        fr.swap(keep);
+        fr.resize(o);
       }
       vbio::WritePosteriorEntry(out, kv.first, kv.second, text_out);
       n++;
