@@ -86,6 +86,34 @@ def test_faster_batch_vs_oracle(ctx, S, P, T, seed, cfg):
     dec.close(); graph.close()
 
 
+@pytest.mark.parametrize("S,P,T,seed,spread,cfg", [
+    # every state of a 60000-state graph alive in a frame: far more than the 8192 slots of the LDS map -- the second map level, its
+    # list of slots, the numbering and the winners of second-level states
+    (60000, 64, 40, 7, 30.0, dict(beam=60.0, max_active=2147483647, min_active=0)),
+    # all scores equal: masses of equal costs -- the order statistics' by-value histogram has one full step and falls back to the
+    # radix select, with max-active binding in every frame
+    (20000, 16, 50, 8, 0.0, dict(beam=13.0, max_active=300, min_active=20)),
+    # min-active binds in most frames (a narrow beam under widely spread scores)
+    (30000, 64, 80, 9, 40.0, dict(beam=2.0, max_active=5000, min_active=150)),
+])
+def test_faster_map_spill_ties_and_min_active(ctx, S, P, T, seed, spread, cfg):
+    import torch
+    from oracle import vbo
+    from voicebridge_amd import api
+    g, t2p, ll = make_case(S, P, T, seed, eps_frac=0.3, spread=spread)
+    graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
+    dec = api.FasterDecoder(ctx, graph, 2, T, **cfg)
+    foff = np.array([0, T, T + T // 2], np.int64)
+    d = torch.from_numpy(np.ascontiguousarray(np.concatenate([ll, ll[:T // 2]]))).to(ctx.device)
+    ctx.torch_sync()
+    dec.decode(d, foff, t2p)
+    fst = vbo.make_fst(g["final"], g["arc_offset"], g["arcs"], 0)
+    for u, n in enumerate((T, T // 2)):
+        ref = vbo.decode_faster(fst, ll[:n], t2p, exact_cutoff=True, **cfg)
+        assert_same_path(dec.result(u), ref)
+    dec.close(); graph.close()
+
+
 def test_faster_garbage_collection(ctx, monkeypatch):
     """a history far too small for the utterance: unreachable tokens are collected on the way and the
     best path must not change"""

@@ -37,7 +37,8 @@ def test_gmm_golden(ctx, name):
 
 @pytest.mark.parametrize("P,G,D,T", [(50, 300, 39, 200), (7, 7, 13, 65), (300, 1800, 40, 130), (3, 240, 39, 5),
                                      (3, 700, 39, 70), (2, 2100, 20, 130), (40, 6000, 39, 200), (120, 120, 13, 70), (90, 150, 39, 64),
-                                     (1, 1, 5, 3), (1, 333, 39, 64), (500, 9000, 39, 100)])
+                                     (1, 1, 5, 3), (1, 333, 39, 64), (500, 9000, 39, 100), (4000, 16000, 39, 70), (64, 8192, 39, 66),
+                                     (1000, 1000, 20, 65), (700, 2100, 60, 64), (33, 5000, 39, 64)])
 def test_gmm_vs_oracle(ctx, P, G, D, T):
     """ragged frame counts (not multiples of the 64-frame tile), 1-Gaussian pdfs, pdfs with
     ~100 Gaussians, tiles split over blockIdx.y, pdfs with more Gaussians than one 128-column tile
