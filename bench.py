@@ -1312,7 +1312,7 @@ def main():
             pass
         if gathered is not None:
             out["gather"] = gathered
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # (the reported CPU baseline belongs to the one-GPU line; the N > 1 runs do not repeat it)
             jobs = cpu_sample(args, utt2spk, n_spk)
             n_smp = int(round(args.seconds * 16000))
             waves = {u: d_wave[u * n_smp:(u + 1) * n_smp].cpu().numpy() for j_ in jobs for u in j_}
