@@ -619,6 +619,8 @@ def launch_ranks(args):
 
 def main():
     args = parse()
+    # (multi-process GPU work on this driver stack needs dmabuf IPC: RCCL's handle exchange fails with the legacy mode)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
