@@ -59,6 +59,41 @@ def test_gmm_vs_oracle(ctx, P, G, D, T):
     m.close()
 
 
+@pytest.mark.parametrize("cut_step", [None, "1", "3"])
+@pytest.mark.parametrize("sizes", [[130] * 29 + [1] * 64 + [130] * 30, [100] * 13 + [1] * 48 + [7, 1, 1, 90] * 20, [1] * 37 + [200] * 9 + [1] * 51])
+def test_gmm_mixed_model_staging_rows(ctx, sizes, cut_step, monkeypatch):
+    """many 100+-Gaussian pdfs around runs of one-Gaussian pdfs.  With superblocks cut at arbitrary pdfs (VBH_GMM_CUT_STEP=1 / 3)
+    a run of finished pdfs starts at a pdf that is no multiple of 4, the aligned flush can leave 16-18 waiting, and the next block's ends
+    used to run over the lane's staging row (LDP): the flush now empties the row then, and the default packing cuts at multiples of 4."""
+    import torch
+    from oracle import vbo
+    from voicebridge_amd import api
+    if cut_step is not None:
+        monkeypatch.setenv("VBH_GMM_CUT_STEP", cut_step)
+    D, T = 39, 130
+    rng = np.random.default_rng(len(sizes))
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    G = int(offs[-1])
+    w = np.concatenate([rng.dirichlet(np.ones(n)) for n in sizes]).astype(np.float32)
+    means = rng.standard_normal((G, D)).astype(np.float32)
+    iv = (1.0 / rng.uniform(0.5, 2.0, (G, D))).astype(np.float32)
+    miv = (means * iv).astype(np.float32)
+    feats = (rng.standard_normal((T, D)) * 1.3).astype(np.float32)
+    ref = vbo.gmm_loglikes(offs, vbo.gmm_gconsts(w, miv, iv), miv, iv, feats)
+    for padded in (False, True):
+        m = api.DiagGmm(ctx, offs, w, miv, iv)
+        d = torch.from_numpy(feats).to(ctx.device)
+        if padded:
+            out = torch.zeros((T, m.padded_pdfs), dtype=torch.float32, device=ctx.device)
+            m.loglikes(d, out=out)
+            ll = out[:, :len(sizes)]
+        else:
+            ll = m.loglikes(d)
+        ctx.sync()
+        np.testing.assert_allclose(ll.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+        m.close()
+
+
 @pytest.mark.parametrize("P,G,D,T", [(50, 300, 39, 200), (3, 700, 39, 70), (120, 120, 13, 70)])
 def test_gmm_strict_and_twopass_vs_oracle(ctx, P, G, D, T):
     """the block-local packing (pdfs never straddle a row-block, large pdfs in parts) behind the two-pass modes"""

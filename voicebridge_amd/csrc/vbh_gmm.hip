@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void gmm_loglikes_kernel(
 //     row-block.  Per block: {bit r set = row r STARTS a pdf, first pdf, number of pdfs (<= 16)}.
 struct RbMeta { unsigned mask; int p0; int np; int pad; };
 struct __attribute__((packed, aligned(4))) f32x4u { float x, y, z, w; };      // four floats at a 4-byte-aligned address (one 16-byte store)
-constexpr int LDP = 31;       // row of a wave's staging area: [64 frames][<= 15 pdfs waiting + <= 16 of the current block]
+constexpr int LDP = 31;       // row of a wave's staging area: [64 frames][<= 15 pdfs waiting + <= 16 of the current block] (the flush keeps <= LDP - 16 waiting)
 
 // LSE: how the LogSumExp over a pdf's Gaussians is evaluated (kaldi-vector.cc:757-775; vbh_gmm_set_lse_mode)
 //   VBH_LSE_FAST (default): one pass over the lane's registers -- running maximum m and sum of exp(x - m), rescaled when the maximum
@@ -379,7 +379,10 @@ __global__ __launch_bounds__(256, 3) void gmm_rows_kernel(
         // (L2 writes back dirty 64-byte halves: one that two runs share is written twice).  At the end of a superblock the whole
         // run leaves, what does not fill a group of four from the lane that made it (lane = frame).
         const bool last = nsb != sb;
-        const int n_out = last ? pend : (((pend_p0 + pend) & ~15) - pend_p0) & ~3;
+        // (a run that starts at a pdf that is no multiple of 4 -- VBH_GMM_CUT_STEP only: the packing cuts at multiples of 4 -- could
+        // leave more than 15 pdfs waiting, and the next block's 16 would overrun the lane's row: then everything leaves, unaligned)
+        int n_out = last ? pend : (((pend_p0 + pend) & ~15) - pend_p0) & ~3;
+        if (pend - n_out > LDP - 16) n_out = pend & ~3;
         const int nch = n_out >> 2, n4 = nch << 2;
         if (nch > 0) {
           const unsigned inv = (65536u + (unsigned)nch - 1u) / (unsigned)nch;
@@ -725,7 +728,8 @@ int vbh_gmm_create(vbh_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h
       int want_sb = 4 * (int)((G + 4 * 256 / 2) / (4 * 256));
       if (want_sb < 4) want_sb = 4;
       if (want_sb > P) want_sb = P;
-      int step = P >= 32 * want_sb ? 16 : P >= 16 * want_sb ? 8 : 1;
+      // (never at a pdf that is no multiple of 4: the staging row, LDP, holds 15 waiting pdfs + a block's 16 only if a run's first pdf is)
+      int step = P >= 32 * want_sb ? 16 : P >= 16 * want_sb ? 8 : 4;
       if (const char *e = getenv("VBH_GMM_CUT_STEP")) step = std::max(1, atoi(e));
       std::vector<int> cut(1, 0);            // first pdf of every superblock
       for (int i = 1; i < want_sb; i++) {

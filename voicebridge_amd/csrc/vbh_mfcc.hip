@@ -779,6 +779,11 @@ int vbh_mfcc_compute(vbh_mfcc *m, const void *d_wave, int wave_is_int16, const i
                      int32_t n_utt, float *d_feats, int64_t *h_frame_offsets) {
   VBH_CHECK(m && h_wave_offsets && h_frame_offsets, "vbh_mfcc_compute: NULL argument");
   VBH_CHECK(n_utt >= 0, "vbh_mfcc_compute: n_utt < 0");
+  // the stream indices of vbh_mfcc_set_dither_ids serve the one call they were given for: taken (and dropped) before any
+  // early return, so that a call that launches nothing cannot leave them to the next one
+  std::vector<long long> ids(m->dither_ids.begin(), m->dither_ids.end());
+  m->dither_ids.clear();
+  VBH_CHECK(ids.empty() || (int)ids.size() == n_utt, "vbh_mfcc_compute: %zu dither stream indices for %d utterances", ids.size(), n_utt);
   if (vbh_use_device(m->ctx)) return -1;
   std::vector<long long> woff(n_utt + 1), foff(n_utt + 1);
   std::vector<int> cu, cf;
@@ -793,13 +798,6 @@ int vbh_mfcc_compute(vbh_mfcc *m, const void *d_wave, int wave_is_int16, const i
   if (cu.empty()) return 0;
   VBH_CHECK(d_wave && d_feats, "vbh_mfcc_compute: NULL device buffer");
   hipStream_t s = m->ctx->stream;
-  // the stream indices of vbh_mfcc_set_dither_ids serve the one call they were given for
-  std::vector<long long> ids;
-  if (!m->dither_ids.empty()) {
-    VBH_CHECK((int)m->dither_ids.size() == n_utt, "vbh_mfcc_compute: %zu dither stream indices for %d utterances", m->dither_ids.size(), n_utt);
-    ids.assign(m->dither_ids.begin(), m->dither_ids.end());
-    m->dither_ids.clear();
-  }
   vbh_arena *ar = vbh_arena_begin(m->ctx, vbh_arena_need(woff.size() * 8) + vbh_arena_need(foff.size() * 8) +
                                               vbh_arena_need(cu.size() * 4) + vbh_arena_need(cf.size() * 4) + vbh_arena_need(ids.size() * 8 + 8));
   if (!ar) return -1;

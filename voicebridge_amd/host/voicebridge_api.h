@@ -16,14 +16,19 @@
 // caller holding an fs::ofstream passes it unchanged).  Log text goes to file_log when it is
 // open, else to stderr.
 //
-// Differences that a caller must know (all reported as errors, never silently ignored):
-//   * compute-mfcc-feats: --dither must be 0 (the reference default 1.0 draws from libc rand());
-//     --output-format=htk, --vtln-map, --min-duration, wav.scp pipes are not supported.
-//   * gmm-latgen-faster: --determinize-lattice=true (the default) writes CompactLattices determinized
-//     by the reference's two-pass (phone level, then word level) pruned algorithm, restated in
-//     host/lattice.cc; --minimize=true is not supported.  --word-symbol-table is accepted and
-//     ignored (it only echoes words to stderr in the reference).
-//   * lattice programs read and write binary archives only (text-mode lattices are refused).
+// Differences that a caller must know (all reported as errors or warnings, never silently ignored):
+//   * compute-mfcc-feats: --dither is honoured (default 1.0 as the reference; voicebridge_api.cc:246-252) from a counter-based
+//     generator, so dithered features equal the reference's statistically and bit for bit only with --dither=0 (the reference
+//     draws from libc rand()); --dither-seed (extension) selects the stream.  --vtln-map / --utt2spk, --min-duration, --segments
+//     are supported.  Refused: --output-format=htk, --allow-downsample; a wav.scp entry that is a pipe ("cmd |") is skipped with
+//     a warning, as an unreadable file is.
+//   * gmm-latgen-faster: --determinize-lattice=true (the default) writes CompactLattices determinized by the reference's
+//     two-pass (phone level, then word level) pruned algorithm, restated in host/lattice.cc; --minimize=true is supported
+//     (voicebridge_api.cc:761; bit-exact against the reference programs, tests/test_host_lattice.py).  --word-symbol-table is
+//     accepted and ignored (it only echoes words to stderr in the reference).
+//   * lattice, posterior and int-vector tables are read and written in binary and in text mode ("ark,t:"); models are read in both
+//     modes and written in binary only.
+//   * apply-cmvn: --norm-means=false / --skip-dims / --reverse are refused; compute-cmvn-stats: --weights is refused.
 #ifndef VOICEBRIDGE_API_H_
 #define VOICEBRIDGE_API_H_
 
