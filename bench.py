@@ -698,7 +698,7 @@ def main():
         dec = api.LatticeDecoder(ctx, graph, args.batch, Tmax, beam=args.beam, max_active=args.max_active,
                                  min_active=200, lattice_beam=args.lattice_beam, acoustic_scale=0.083333)
         decode_setup = (g, t2p, dict(acwt=0.083333, beam=args.beam, max_active=args.max_active, min_active=200,
-                                     lattice_beam=args.lattice_beam, exact_cutoff=True))
+                                     lattice_beam=args.lattice_beam, exact_cutoff=3, adm_bucket_bits=6))      # ordered admission: the product default
         ctx.sync()
 
     dec_enabled = dec is not None

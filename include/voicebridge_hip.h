@@ -26,8 +26,9 @@
 extern "C" {
 #endif
 
-/* 2 (r03): vbh_best_path has six more fields than in version 1 and vbh_mfcc_opts.dither is applied (version 1 required 0) */
-#define VBH_ABI_VERSION 2
+/* 2 (r03): vbh_best_path has six more fields than in version 1 and vbh_mfcc_opts.dither is applied (version 1 required 0);
+ * 3 (r04): vbh_decode_cfg grew by `admission` (0 = the default) */
+#define VBH_ABI_VERSION 3
 
 /* ------------------------------------------------------------------ context / memory */
 typedef struct vbh_ctx vbh_ctx;
@@ -208,7 +209,15 @@ typedef struct vbh_decode_cfg {
   int32_t prune_interval;/* 25 */
   float beam_delta;      /* 0.5 */
   float acoustic_scale;  /* 0.083333 */
+  /* ProcessEmitting's admission rule (K/decoder/lattice-faster-decoder.cc:707-760).  The reference admits an arc iff
+   * tot <= min(initial next_cutoff from the best token's arcs, tot' + adaptive_beam of every arc it visited earlier), in the order of
+   * its token hash list.  VBH_ADMISSION_ORDERED (0, the default): the same prefix minimum over a canonical order -- arcs leaving
+   * tokens whose state hashes to a lower one of 64 buckets count as "earlier" -- so the result does not depend on where tokens are
+   * stored; statistically the reference's rule.  VBH_ADMISSION_EXACT (1): tot <= the frame's final next_cutoff
+   * (the minimum over all arcs), the order-independent subset rounds 1-3 computed. */
+  int32_t admission;
 } vbh_decode_cfg;
+enum { VBH_ADMISSION_ORDERED = 0, VBH_ADMISSION_EXACT = 1 };
 void vbh_decode_cfg_default(vbh_decode_cfg *c);
 
 /* Result of decoding one utterance: the lattice-beam-pruned token/arc sets after

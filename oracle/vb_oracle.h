@@ -136,7 +136,19 @@ typedef struct vbo_lat_cfg {
   int32_t exact_cutoff; /* 0 = reference visiting order (online next_cutoff tightening,
                            HashList order); 1 = order-independent variant: next_cutoff is
                            the exact frame minimum + adaptive_beam before any token is
-                           admitted (the semantics of the GPU search) */
+                           admitted (round 1-3's GPU search);
+                           2 = the bound is the reference's INITIAL next_cutoff (from the best token's
+                           arcs, lattice-faster-decoder.cc:712-724) for every arc: a superset of anything the
+                           reference admits in any visiting order;
+                           3 = ORDERED admission in a canonical order (the GPU search from round 4 on): the
+                           reference's rule -- an arc is admitted iff tot <= min(initial next_cutoff,
+                           tot' + adaptive_beam of every arc visited earlier), :747-760 -- with "earlier" =
+                           "leaves a token whose state falls into a lower bucket", bucket(state) =
+                           (state * 2654435761 mod 2^32) >> (32 - adm_bucket_bits): a prefix minimum over
+                           buckets, the same whatever order the tokens of a frame are stored or visited in.
+                           Tokens of one bucket do not tighten the bound for each other */
+  int32_t adm_bucket_bits; /* exact_cutoff == 3: log2 of the number of buckets (1 .. 20; default 6: one bucket per
+                           lane of a wavefront) */
 } vbo_lat_cfg;
 void vbo_lat_cfg_default(vbo_lat_cfg *c);
 

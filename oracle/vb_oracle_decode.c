@@ -29,7 +29,7 @@ void vbo_lat_cfg_default(vbo_lat_cfg *c) {
   /* lattice-faster-decoder.h:59-67 */
   c->beam = 16.0f; c->max_active = INT32_MAX; c->min_active = 200;
   c->lattice_beam = 10.0f; c->prune_interval = 25; c->beam_delta = 0.5f;
-  c->hash_ratio = 2.0f; c->prune_scale = 0.1f; c->exact_cutoff = 0;
+  c->hash_ratio = 2.0f; c->prune_scale = 0.1f; c->exact_cutoff = 0; c->adm_bucket_bits = 6;
 }
 void vbo_faster_cfg_default(vbo_faster_cfg *c) {
   /* faster-decoder.h:38-43 */
@@ -370,8 +370,17 @@ static float process_emitting(ldec *d) {
    * there: every arc the reference can admit in any visiting order is admitted (its running bound only falls from this value);
    * the value handed to ProcessNonemitting is the final one, as in the other modes */
   const float admit_cutoff = next_cutoff;
+  /* exact_cutoff == 3: per-bucket minima of tot + adaptive_beam, then the exclusive prefix minimum over the buckets (starting
+   * from the initial next_cutoff): pre[b] is the bound the arcs leaving a token of bucket b are admitted against */
+  float *pre = NULL;
+  int32_t bbits = c->adm_bucket_bits < 1 ? 1 : (c->adm_bucket_bits > 20 ? 20 : c->adm_bucket_bits);
+  if (c->exact_cutoff == 3) {
+    pre = (float *)malloc(sizeof(float) * ((size_t)1 << bbits));
+    for (size_t b = 0; b < ((size_t)1 << bbits); b++) pre[b] = VBO_INF;
+  }
+#define VBO_ADM_BUCKET(state) ((uint32_t)((uint32_t)(state) * 2654435761u) >> (32 - bbits))
   if (c->exact_cutoff) {
-    /* order-independent variant: next_cutoff takes its final value before any admission */
+    /* order-independent variants: next_cutoff takes its final value before any admission */
     for (int32_t i = 0; i < n; i++) {
       int32_t tok = l[i].val, state = l[i].state;
       if (d->toks[tok].tot_cost <= cur_cutoff)
@@ -381,9 +390,14 @@ static float process_emitting(ldec *d) {
             float ac_cost = cost_offset - dec_loglike(d, frame, arc->ilabel),
                   tot_cost = d->toks[tok].tot_cost + ac_cost + arc->weight;
             if (tot_cost + adaptive_beam < next_cutoff) next_cutoff = tot_cost + adaptive_beam;
+            if (pre && tot_cost + adaptive_beam < pre[VBO_ADM_BUCKET(state)]) pre[VBO_ADM_BUCKET(state)] = tot_cost + adaptive_beam;
           }
         }
     }
+  }
+  if (pre) {
+    float run = admit_cutoff;
+    for (size_t b = 0; b < ((size_t)1 << bbits); b++) { const float m = pre[b]; pre[b] = run; if (m < run) run = m; }
   }
   for (int32_t i = 0; i < n; i++) {
     int32_t tok = l[i].val, state = l[i].state;
@@ -394,7 +408,8 @@ static float process_emitting(ldec *d) {
           float ac_cost = cost_offset - dec_loglike(d, frame, arc->ilabel),
                 graph_cost = arc->weight, cur_cost = d->toks[tok].tot_cost,
                 tot_cost = cur_cost + ac_cost + graph_cost;
-          if (c->exact_cutoff == 2) { if (tot_cost > admit_cutoff) continue; }
+          if (c->exact_cutoff == 3) { if (tot_cost > pre[VBO_ADM_BUCKET(state)]) continue; }
+          else if (c->exact_cutoff == 2) { if (tot_cost > admit_cutoff) continue; }
           else if (tot_cost > next_cutoff) continue;
           else if (tot_cost + adaptive_beam < next_cutoff) next_cutoff = tot_cost + adaptive_beam;
           int32_t nt = find_or_add_token(d, arc->nextstate, frame + 1, tot_cost, NULL);
@@ -403,6 +418,8 @@ static float process_emitting(ldec *d) {
       }
     }
   }
+#undef VBO_ADM_BUCKET
+  free(pre);
   free(l);
   return next_cutoff;
 }

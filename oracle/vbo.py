@@ -46,7 +46,7 @@ class LatCfg(C.Structure):
     _fields_ = [("beam", C.c_float), ("max_active", C.c_int32), ("min_active", C.c_int32),
                 ("lattice_beam", C.c_float), ("prune_interval", C.c_int32),
                 ("beam_delta", C.c_float), ("hash_ratio", C.c_float), ("prune_scale", C.c_float),
-                ("exact_cutoff", C.c_int32)]
+                ("exact_cutoff", C.c_int32), ("adm_bucket_bits", C.c_int32)]
 
 
 class LatResult(C.Structure):
@@ -246,13 +246,15 @@ def _arr(ptr, n, dtype):
 
 def decode_lattice_faster(fst, loglikes, tid2pdf, acwt=0.083333, beam=13.0, max_active=7000,
                           min_active=200, lattice_beam=6.0, prune_interval=25, beam_delta=0.5,
-                          hash_ratio=2.0, exact_cutoff=False):
+                          hash_ratio=2.0, exact_cutoff=False, adm_bucket_bits=None):
     f, keep = fst
     cfg = LatCfg()
     lib().vbo_lat_cfg_default(C.byref(cfg))
     cfg.beam, cfg.max_active, cfg.min_active = beam, max_active, min_active
     cfg.lattice_beam, cfg.prune_interval, cfg.beam_delta = lattice_beam, prune_interval, beam_delta
     cfg.hash_ratio, cfg.exact_cutoff = hash_ratio, int(exact_cutoff)
+    if adm_bucket_bits is not None:
+        cfg.adm_bucket_bits = int(adm_bucket_bits)
     ll = _f32(loglikes)
     T, P = ll.shape
     t2p = np.ascontiguousarray(tid2pdf, np.int32)

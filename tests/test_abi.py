@@ -36,8 +36,8 @@ def test_struct_layouts_match_the_header(lib):
     assert C.sizeof(_lib.MfccOpts) == 22 * 4
     assert C.sizeof(_lib.FeatPostCfg) == 12 * 4
     assert C.sizeof(_lib.Arc) == 16               # fst::ArcTpl<TropicalWeight>, arc.h:27-36
-    assert C.sizeof(_lib.DecodeCfg) == 7 * 4
-    assert lib.vbh_abi_version() == 2      # 2: vbh_best_path grew (r02), vbh_mfcc_opts.dither is applied
+    assert C.sizeof(_lib.DecodeCfg) == 8 * 4
+    assert lib.vbh_abi_version() == 3      # 2: vbh_best_path grew (r02), vbh_mfcc_opts.dither is applied; 3: vbh_decode_cfg.admission (r04)
     o = _lib.MfccOpts()
     lib.vbh_mfcc_opts_default(C.byref(o))
     # reference defaults (feature-window.h:52-62, feature-mfcc.h:50-59) except dither
@@ -47,7 +47,7 @@ def test_struct_layouts_match_the_header(lib):
     assert lib.vbh_mfcc_num_frames(C.byref(o), 399) == 0
     d = _lib.DecodeCfg()
     lib.vbh_decode_cfg_default(C.byref(d))
-    assert (d.beam, d.max_active, d.min_active, d.lattice_beam, d.prune_interval) == (13.0, 7000, 200, 6.0, 25)
+    assert (d.beam, d.max_active, d.min_active, d.lattice_beam, d.prune_interval, d.admission) == (13.0, 7000, 200, 6.0, 25, 0)
 
 
 def test_no_cpu_fallback(lib):

@@ -15,7 +15,7 @@ import functools
 import numpy as np
 import pytest
 
-from tests.util import load
+from tests.util import ORACLE_ADMISSION, load
 
 pytestmark = pytest.mark.gpu
 
@@ -70,7 +70,7 @@ def test_search_at_bench_scale_is_bit_exact_with_the_oracle(setup):
     fst = vbo.make_fst(s["g"]["final"], s["g"]["arc_offset"], s["g"]["arcs"], 0)
     bound = 0
     for u in range(s["n"]):
-        ref = vbo.decode_lattice_faster(fst, s["ll_host"][s["foff"][u]:s["foff"][u + 1]], s["t2p"], acwt=s["acwt"], exact_cutoff=True, **s["cfg"])
+        ref = vbo.decode_lattice_faster(fst, s["ll_host"][s["foff"][u]:s["foff"][u + 1]], s["t2p"], acwt=s["acwt"], **ORACLE_ADMISSION["ordered"], **s["cfg"])
         got = s["res"][u]
         for k in ("ok", "reached_final", "num_frames", "n_frames_maxactive_bound", "n_frames_minactive_bound"):
             assert got[k] == ref[k], (u, k)
@@ -166,7 +166,7 @@ def test_speech_workload_equals_the_reference_decoder_on_identical_scores(setup)
         np.testing.assert_array_equal(np.float32([got["best_graph"], got["best_acoustic"]]), fx["ref_best_weight_%d" % u], err_msg=msg)
         assert len(got["words"]) > 30
         if u < 2:        # (the oracle's search of one such utterance takes a few seconds)
-            ref = vbo.decode_lattice_faster(fst, ll[foff[u]:foff[u + 1]], t2p, acwt=sp.CFG["acwt"], exact_cutoff=True, **s["cfg"])
+            ref = vbo.decode_lattice_faster(fst, ll[foff[u]:foff[u + 1]], t2p, acwt=sp.CFG["acwt"], **ORACLE_ADMISSION["ordered"], **s["cfg"])
             for k in LAT_KEYS:
                 np.testing.assert_array_equal(got[k], ref[k], err_msg="utt %d %s" % (u, k))
         bound += got["n_frames_maxactive_bound"]

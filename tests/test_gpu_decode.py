@@ -1,4 +1,4 @@
-"""GPU parity: the lattice search vs the oracle's order-independent mode (bit-exact: token
+"""GPU parity: the lattice search vs the oracle in the same admission mode (bit-exact: token
 sets, float32 costs, every lattice arc, best path) and vs the reference's golden best paths."""
 import glob
 import os
@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.util import GOLD, load, parse_opts
+from tests.util import ADMISSIONS, GOLD, ORACLE_ADMISSION, load, parse_opts
 
 pytestmark = pytest.mark.gpu
 
@@ -45,8 +45,9 @@ def assert_same_lattice(got, ref):
     assert got["n_frames_minactive_bound"] == ref["n_frames_minactive_bound"]
 
 
+@pytest.mark.parametrize("adm", ADMISSIONS)
 @pytest.mark.parametrize("name", CASES)
-def test_decode_golden_cases(ctx, name):
+def test_decode_golden_cases(ctx, name, adm):
     import torch
     from oracle import vbo
     from voicebridge_amd import api
@@ -56,16 +57,21 @@ def test_decode_golden_cases(ctx, name):
     kw = dict(beam=o["beam"], max_active=int(o["max_active"]), min_active=int(o["min_active"]),
               lattice_beam=o["lattice_beam"], prune_interval=int(o["prune_interval"]))
     ref = vbo.decode_lattice_faster(vbo.make_fst(g["fst_final"], g["fst_off"], arcs, 0), g["loglikes"], g["tid2pdf"],
-                                    acwt=o["acwt"], exact_cutoff=True, **kw)
+                                    acwt=o["acwt"], **ORACLE_ADMISSION[adm], **kw)
     graph = api.Graph(ctx, g["fst_final"], g["fst_off"], arcs, 0)
     T = g["loglikes"].shape[0]
-    dec = api.LatticeDecoder(ctx, graph, 1, T, acoustic_scale=o["acwt"], **kw)
+    dec = api.LatticeDecoder(ctx, graph, 1, T, acoustic_scale=o["acwt"], admission=adm, **kw)
     ll = torch.from_numpy(g["loglikes"]).to(ctx.device)
     ctx.torch_sync()
     dec.decode(ll, [0, T], g["tid2pdf"])
     got = dec.result(0)
     assert_same_lattice(got, ref)
-    # and the reference's own best path (golden vectors from the reference build)
+    # and the reference's own best path (golden vectors from the reference build).  One random-graph case with max-active binding in
+    # every frame is decided by the visiting order itself: there the ordered rule's canonical order (and the superset rule, oracle
+    # exact_cutoff = 2) end on another path than the reference's HashList order; the oracle pins the ordered result bit for bit above
+    if adm == "ordered" and name == "decode_g1_maxact":
+        graph.close(); dec.close()
+        return
     np.testing.assert_array_equal(got["words"], g["ref_lat_words"])
     np.testing.assert_array_equal(got["ali"], g["ref_lat_ali"])
     np.testing.assert_array_equal(np.float32([got["best_graph"], got["best_acoustic"]]), g["ref_lat_best_weight"])
@@ -82,6 +88,7 @@ def make_case(S, P, T, seed, spread=30.0, **gkw):
     return g, t2p, ll
 
 
+@pytest.mark.parametrize("adm", ADMISSIONS)
 @pytest.mark.parametrize("S,P,T,seed,cfg", [
     (20000, 64, 120, 1, dict(beam=13.0, max_active=7000, min_active=200, lattice_beam=6.0)),
     (20000, 64, 90, 2, dict(beam=13.0, max_active=300, min_active=20, lattice_beam=6.0)),       # max-active binds
@@ -90,7 +97,7 @@ def make_case(S, P, T, seed, spread=30.0, **gkw):
     (5000, 32, 0, 5, dict(beam=13.0, max_active=7000, min_active=200, lattice_beam=6.0)),        # empty utterance
     (5000, 32, 1, 6, dict(beam=13.0, max_active=7000, min_active=200, lattice_beam=6.0)),
 ])
-def test_decode_batch_vs_oracle(ctx, S, P, T, seed, cfg):
+def test_decode_batch_vs_oracle(ctx, S, P, T, seed, cfg, adm):
     """larger graphs with epsilon chains; a ragged batch of three utterances through one call"""
     import torch
     from oracle import vbo
@@ -101,13 +108,13 @@ def test_decode_batch_vs_oracle(ctx, S, P, T, seed, cfg):
     foff[1:] = np.cumsum(lens)
     batch = np.concatenate([ll[:n] for n in lens]) if sum(lens) else np.zeros((0, P), np.float32)
     graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
-    dec = api.LatticeDecoder(ctx, graph, 3, max(lens), **cfg)
+    dec = api.LatticeDecoder(ctx, graph, 3, max(lens), admission=adm, **cfg)
     d = torch.from_numpy(np.ascontiguousarray(batch)).to(ctx.device) if len(batch) else torch.zeros((1, P), device=ctx.device)
     ctx.torch_sync()
     dec.decode(d, foff, t2p)
     fst = vbo.make_fst(g["final"], g["arc_offset"], g["arcs"], 0)
     for u, n in enumerate(lens):
-        ref = vbo.decode_lattice_faster(fst, ll[:n] if n else np.zeros((0, P), np.float32), t2p, exact_cutoff=True, **cfg)
+        ref = vbo.decode_lattice_faster(fst, ll[:n] if n else np.zeros((0, P), np.float32), t2p, **ORACLE_ADMISSION[adm], **cfg)
         assert_same_lattice(dec.result(u), ref)
     dec.close(); graph.close()
 
@@ -137,7 +144,7 @@ def test_decode_independent_of_pruning_schedule(ctx, monkeypatch, every, lds_map
     dec.decode(d, foff, t2p)
     fst = vbo.make_fst(g["final"], g["arc_offset"], g["arcs"], 0)
     for u, n in enumerate(lens):
-        ref = vbo.decode_lattice_faster(fst, ll[:n], t2p, exact_cutoff=True, **cfg)
+        ref = vbo.decode_lattice_faster(fst, ll[:n], t2p, **ORACLE_ADMISSION["ordered"], **cfg)
         assert_same_lattice(dec.result(u), ref)
     dec.close(); graph.close()
 
@@ -172,7 +179,7 @@ def test_decode_begin_end_two_contexts(ctx):
     fst = vbo.make_fst(g["final"], g["arc_offset"], g["arcs"], 0)
     for d, ln in zip(decs, lens):
         for u, n in enumerate(ln):
-            ref = vbo.decode_lattice_faster(fst, ll[:n], t2p, exact_cutoff=True, **cfg)
+            ref = vbo.decode_lattice_faster(fst, ll[:n], t2p, **ORACLE_ADMISSION["ordered"], **cfg)
             assert_same_lattice(d.result(u), ref)
     for d in decs:
         d.close()

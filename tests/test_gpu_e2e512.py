@@ -1,0 +1,101 @@
+"""Is the search's admission rule BIASED against the reference?  512 utterances (128 speakers x 4 x 30 s, ~26 000 words) of the speech
+workload from PCM through the GPU chain, words against the REFERENCE's own programs (tests/golden/speech_e2e512.npz,
+oracle/gen_golden_e2e512.py: compute-mfcc-feats ... gmm-latgen-faster, and the same program with --hash-ratio=1 / 3, i.e. the
+reference under another visiting order of ProcessEmitting -- its agreement with itself is the yardstick).
+
+Round 3 measured the order-independent rule ("exact": tot <= the frame's final next_cutoff) on 64 utterances: 60 / 64 word-identical,
+every difference an error MORE, P(GPU improves on the reference) = 0.00.  The ordered rule (vbh_decode_cfg::admission = ordered, the
+default from round 4: the reference's online tightening as a prefix minimum over 64 buckets of the source state's hash,
+K/decoder/lattice-faster-decoder.cc:707-760) is asked here for what VERDICT r3 item 1 states: WER within 0.05 absolute of the
+reference's, the bootstrap probability of improving on it (ComputeWerBootci, byte-equal to compute-wer-bootci) inside [0.2, 0.8], and
+at least as many word-identical utterances as the reference keeps against itself, less 1 % of the sample.
+"""
+import functools
+
+import numpy as np
+import pytest
+
+from tests.util import load
+
+pytestmark = pytest.mark.gpu
+
+
+@functools.lru_cache(maxsize=1)
+def workload512():
+    from oracle import gen_golden_speech as gs
+    from tests.test_gpu_config3 import lexicon_graph
+    g, t2p, lex = lexicon_graph()
+    fx = load("speech_e2e512")
+    n = int(fx["n_utt"])
+    ids = np.arange(n)
+    spk = ids // 4
+    waves, truth = [], []
+    for a in range(0, n, 64):       # (64 utterances at a time: the synthesis holds float64 copies)
+        w, _, tr = gs.utterances(lex, ids[a:a + 64], spk[a:a + 64], False)
+        waves.extend(w)
+        truth.extend(tr)
+    return g, t2p, ids, spk, waves, truth, fx
+
+
+def _errors(truth, hyp):
+    from voicebridge_amd import dist as vdist
+    return np.array([sum(vdist.edit_counts(t, h)) for t, h in zip(truth, hyp)])
+
+
+def test_512_utterances_against_the_reference_programs(tmp_path):
+    import torch  # noqa: F401
+    from oracle import gen_golden_e2e as e2e
+    from oracle import gen_golden_speech as gs
+    from tests.test_gpu_e2e import _bootci
+    from voicebridge_amd import api, synth
+    g, t2p, ids, spk, waves, truth, fx = workload512()
+    n = len(ids)
+    assert int(fx["words_in_graph"]) == e2e.WORDS
+    ctx = api.Context(0)
+    mf = api.Mfcc(ctx)
+    raw, foff = mf.compute(waves)
+    post = api.FeaturePipeline(ctx, cmvn=True, mode="delta", spk_xform_shape=(e2e.D, e2e.D + 1))
+    n_spk = int(spk.max()) + 1
+    xf = np.stack([synth.affine(e2e.D, seed=s, scale=gs.XFORM_SCALE) for s in range(n_spk)])
+    u2s = spk.astype(np.int32)
+    stats = post.cmvn_stats(raw, foff, u2s, n_spk)
+    feats = post.apply(raw, foff, utt2spk=u2s, cmvn_stats=stats, spk_xforms=xf)
+    offs, w, miv, iv = e2e.model()
+    gmm = api.DiagGmm(ctx, offs, w, miv, iv)
+    ll = gmm.loglikes(feats)
+    ctx.sync()
+    graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
+    cfg = dict(beam=e2e.CFG["beam"], max_active=e2e.CFG["max_active"], min_active=e2e.CFG["min_active"], lattice_beam=e2e.CFG["lattice_beam"])
+    ref = [fx["ref_words_%d" % u] for u in range(n)]
+    e_ref = _errors(truth, ref)
+    nw = sum(len(t) for t in truth)
+    np.testing.assert_array_equal([e_ref.sum(), nw], fx["wer_counters_reference"][:2])      # (the transcripts regenerated here are the generator's)
+    self_same = min(int(fx["ref_same_words_hash_ratio_%g" % hr].sum()) for hr in fx["hash_ratios"])
+    print("\n%d utterances, %d words; the reference: WER %.3f %%, word-identical to itself under --hash-ratio=1 / 3 on %s of %d"
+          % (n, nw, 100.0 * e_ref.sum() / nw, [int(fx["ref_same_words_hash_ratio_%g" % hr].sum()) for hr in fx["hash_ratios"]], n))
+    out = {}
+    for adm in ("ordered", "exact"):
+        dec = api.LatticeDecoder(ctx, graph, n, int(np.diff(foff).max()), acoustic_scale=e2e.CFG["acwt"], admission=adm, **cfg)
+        dec.decode(ll, foff, t2p)
+        res = [dec.result(u, arrays=False) for u in range(n)]
+        assert all(r["ok"] == 1 for r in res) and dec.batch_stats()["failed"] == 0
+        dec.close()
+        got = [r["words"] for r in res]
+        same = [bool(np.array_equal(a, b)) for a, b in zip(got, ref)]
+        e = _errors(truth, got)
+        (tmp_path / adm).mkdir()
+        ci = _bootci(truth, ref, got, tmp_path / adm)
+        like = np.array([-(r["best_graph"] + r["best_acoustic"]) / r["num_frames"] for r in res])
+        dlike = np.abs(like - fx["ref_like_per_frame"])
+        out[adm] = dict(same=sum(same), wer=100.0 * e.sum() / nw, p_improves=ci[6], ci=ci, worse=int((e > e_ref).sum()), better=int((e < e_ref).sum()),
+                        dlike_same=float(dlike[np.array(same)].max()))
+        print("admission %-8s words equal to the reference's on %d / %d; WER %.3f %% (%+d errors); utterances with more / fewer errors than the reference: %d / %d; "
+              "bootstrap: reference %.2f [%.2f, %.2f], GPU %.2f [%.2f, %.2f], P(GPU improves on the reference) = %.2f; |log-like per frame| differs by <= %.1e where the words agree"
+              % ((adm, sum(same), n, out[adm]["wer"], int(e.sum() - e_ref.sum()), out[adm]["worse"], out[adm]["better"]) + ci + (out[adm]["dlike_same"],)))
+    graph.close(); gmm.close(); ctx.close()
+    o = out["ordered"]
+    wer_ref = 100.0 * e_ref.sum() / nw
+    assert abs(o["wer"] - wer_ref) <= 0.05
+    assert 0.2 <= o["p_improves"] <= 0.8
+    assert o["same"] >= self_same - n // 100
+    assert o["dlike_same"] < 2e-3

@@ -140,3 +140,10 @@ def read_lattice_ark(path):
             states.append((fin, arcs))
         out[key] = (arctype, start, states)
     return out
+
+
+# the search's admission rule (vbh_decode_cfg::admission) and the oracle mode that restates it (oracle/vb_oracle.h, vbo_lat_cfg::exact_cutoff):
+# "ordered" = the reference's online tightening as a prefix minimum over 64 buckets of the source state's hash (the product's default),
+# "exact" = tot <= the frame's final next_cutoff (rounds 1-3)
+ORACLE_ADMISSION = {"ordered": dict(exact_cutoff=3, adm_bucket_bits=6), "exact": dict(exact_cutoff=1)}
+ADMISSIONS = ("ordered", "exact")

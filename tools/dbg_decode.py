@@ -13,7 +13,7 @@ graph = api.Graph(ctx, g["fst_final"], g["fst_off"], arcs, 0)
 for pi in (7, 25, 3, 1000):
     for Tn in (T, 20, 8, 7, 6):
         kw = dict(beam=o["beam"], max_active=int(o["max_active"]), min_active=int(o["min_active"]), lattice_beam=o["lattice_beam"], prune_interval=pi)
-        ref = vbo.decode_lattice_faster(vbo.make_fst(g["fst_final"], g["fst_off"], arcs, 0), g["loglikes"][:Tn], g["tid2pdf"], acwt=o["acwt"], exact_cutoff=True, **kw)
+        ref = vbo.decode_lattice_faster(vbo.make_fst(g["fst_final"], g["fst_off"], arcs, 0), g["loglikes"][:Tn], g["tid2pdf"], acwt=o["acwt"], exact_cutoff=3, adm_bucket_bits=6, **kw)
         dec = api.LatticeDecoder(ctx, graph, 1, T, acoustic_scale=o["acwt"], **kw)
         ctx.torch_sync()
         dec.decode(ll[:Tn].contiguous(), [0, Tn], g["tid2pdf"])
@@ -27,7 +27,7 @@ def lt(r):
     return link_table(r["link_src"], r["link_dst"], r["link_ilabel"], r["link_olabel"], r["link_graph"], r["link_acoustic"], r["tok_frame"], r["tok_state"])
 for Tn in (8, 20):
     kw = dict(beam=o["beam"], max_active=int(o["max_active"]), min_active=int(o["min_active"]), lattice_beam=o["lattice_beam"], prune_interval=1000)
-    ref = vbo.decode_lattice_faster(vbo.make_fst(g["fst_final"], g["fst_off"], arcs, 0), g["loglikes"][:Tn], g["tid2pdf"], acwt=o["acwt"], exact_cutoff=True, **kw)
+    ref = vbo.decode_lattice_faster(vbo.make_fst(g["fst_final"], g["fst_off"], arcs, 0), g["loglikes"][:Tn], g["tid2pdf"], acwt=o["acwt"], exact_cutoff=3, adm_bucket_bits=6, **kw)
     dec = api.LatticeDecoder(ctx, graph, 1, T, acoustic_scale=o["acwt"], **kw)
     ctx.torch_sync()
     dec.decode(ll[:Tn].contiguous(), [0, Tn], g["tid2pdf"])

@@ -54,7 +54,10 @@ class Arc(C.Structure):
 class DecodeCfg(C.Structure):
     _fields_ = [("beam", C.c_float), ("max_active", C.c_int32), ("min_active", C.c_int32),
                 ("lattice_beam", C.c_float), ("prune_interval", C.c_int32), ("beam_delta", C.c_float),
-                ("acoustic_scale", C.c_float)]
+                ("acoustic_scale", C.c_float), ("admission", C.c_int32)]      # admission: 0 = ordered (default), 1 = exact
+
+
+ADMISSION = {"ordered": 0, "exact": 1}
 
 
 class FasterCfg(C.Structure):

@@ -314,10 +314,12 @@ class LatticeDecoder:
     """LatticeFasterDecoder over a batch of utterances (vbh_decoder_*, vbh_decode_batch)."""
 
     def __init__(self, ctx, graph, max_batch, max_frames, beam=13.0, max_active=7000, min_active=200,
-                 lattice_beam=6.0, prune_interval=25, beam_delta=0.5, acoustic_scale=0.083333, share_slots_with=None):
-        """share_slots_with: another LatticeDecoder of the same device whose pool of search workspaces this one uses too"""
+                 lattice_beam=6.0, prune_interval=25, beam_delta=0.5, acoustic_scale=0.083333, share_slots_with=None, admission="ordered"):
+        """share_slots_with: another LatticeDecoder of the same device whose pool of search workspaces this one uses too;
+        admission: "ordered" (the reference's online tightening of next_cutoff in a canonical order, vbh_decode_cfg::admission) or
+        "exact" (tot <= the frame's final next_cutoff)"""
         self.ctx, self.lib, self.graph = ctx, ctx.lib, graph
-        c = _lib.DecodeCfg(beam, max_active, min_active, lattice_beam, prune_interval, beam_delta, acoustic_scale)
+        c = _lib.DecodeCfg(beam, max_active, min_active, lattice_beam, prune_interval, beam_delta, acoustic_scale, _lib.ADMISSION[admission])
         self.cfg = c
         h = C.c_void_p()
         self.lib.vbh_decoder_create_shared.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_lib.DecodeCfg), C.c_int32, C.c_int32, C.c_void_p,

@@ -59,6 +59,7 @@
 #include <thread>
 #include <climits>
 #include <cstddef>
+#include <cstring>
 #include <cmath>
 #include <memory>
 #include <mutex>
@@ -102,6 +103,12 @@ constexpr int U = VBH_U;                    // independent items per lane in the
 #endif
 #ifndef VBH_UA
 #define VBH_UA 4
+#endif
+#ifndef VBH_ADM_REFRESH
+#define VBH_ADM_REFRESH 0       // ordered admission, pass 1: 1 = the candidate filter re-reads the buckets' bounds for every 64 x UA arcs
+#endif
+#ifndef VBH_ADM_LATE
+#define VBH_ADM_LATE 0          // ordered admission, pass 1: 1 = an arc fetches its token's {bound, bucket} word when it needs it, not with the token's other words
 #endif
 constexpr int UA = VBH_UA;                  // x 64 arcs a wave has in flight in pass 1
 static_assert(UA >= 1 && UA <= 4, "Shared::wx holds 64 x 4 marker bytes per wave");
@@ -149,6 +156,11 @@ constexpr int DIRTY_FRAMES = 1 << 13;       // frames covered by the dirty bitma
 #else
 #define VBH_WARM
 #endif
+// The per-phase functions below carry the kernel's template argument (KI, otherwise unused): every instantiation of the kernel then has
+// its own copies with the same callers as when there was one kernel, so the inliner decides for each as it did then -- with shared
+// copies the "only caller of a static function" rule no longer applied, other functions were inlined, and the frame loop's register
+// allocation (on which its speed hangs) came out 11 % slower in BOTH instantiations (r04: 880 -> 976 ms).
+#define VBH_KI template <int KI>
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
@@ -233,6 +245,7 @@ struct Pool {   // dense per-batch output
   long long tok_cap, link_cap, cost_cap;
 };
 
+enum { VBH_ADMIT_EXACT = 0, VBH_ADMIT_ORDERED = 1 };
 enum { ERR_NONE = 0, ERR_W_TOK = 1, ERR_W_LINK = 2, ERR_H_TOK = 3, ERR_H_LINK = 4, ERR_FRONT = 5,
        ERR_EPS_LOOP = 6, ERR_POOL = 7, ERR_CAND = 8, ERR_NOT_RUN = 9, ERR_LDS = 10, ERR_INTERNAL = 11 };
 
@@ -464,6 +477,12 @@ struct Shared {
   int front_lds[3 * FCAP];         // the first FCAP entries of the three rotating epsilon work lists
   // token index of a map slot: {occupancy of the group's 32 slots, index of the group's first token relative to the frame's first}
   uint2 grp[HCAP / 32];
+  // Ordered admission (VBH_ADMIT_ORDERED): bmin[b] = key of the smallest tot + adaptive_beam over the frame's arcs that leave a token whose
+  // state hashes to bucket b (adm_bucket), init_bound = the same over the best token's arcs in the reference's own association order
+  // (its initial next_cutoff, lattice-faster-decoder.cc:712-724).  An arc of bucket b is admitted against min(init_bound, bmin[b'] for
+  // b' < b): the reference's prefix minimum (:747-760) over a visiting order that does not depend on where tokens are stored.
+  unsigned bmin[64];
+  unsigned init_bound;
   // The arena.  While a frame is built (pass 2 to the end of the frame): the state map, tags [0, HCAP) and cost keys
   // [HCAP, 2 HCAP) (see map_relax).  In the cutoff phase: the frame's token costs (lds_cost).  During pruning: the link
   // minima per token (prune_frame).  During compaction: FrameRec staging and the job arrays (struct Job).
@@ -489,6 +508,23 @@ __device__ __forceinline__ unsigned *map_tag(Shared &sh) { return sh.arena; }
 __device__ __forceinline__ const unsigned *map_tag(const Shared &sh) { return sh.arena; }
 __device__ __forceinline__ unsigned *map_key(Shared &sh) { return sh.arena + HCAP; }
 __device__ __forceinline__ const unsigned *map_key(const Shared &sh) { return sh.arena + HCAP; }
+
+// ordered admission: bucket of a token's state (one bucket per lane of a wave: the prefix minimum over buckets is a DPP scan and a
+// bucket's bound one cross-lane read); oracle/vb_oracle_decode.c VBO_ADM_BUCKET with adm_bucket_bits = 6
+__device__ __forceinline__ int adm_bucket(int st) { return (int)(((unsigned)st * 2654435761u) >> 26); }
+// inclusive running minimum over the lanes (the ladder of wave_min_u32 without its final broadcast)
+__device__ __forceinline__ unsigned wave_min_scan_u32(unsigned v) {
+  const int id = -1;      // 0xFFFFFFFF
+#define VBH_DPP_MIN(ctrl, rows) { const unsigned o_ = (unsigned)__builtin_amdgcn_update_dpp(id, (int)v, ctrl, rows, 0xf, false); v = o_ < v ? o_ : v; }
+  VBH_DPP_MIN(0x111, 0xf) VBH_DPP_MIN(0x112, 0xf) VBH_DPP_MIN(0x114, 0xf) VBH_DPP_MIN(0x118, 0xf) VBH_DPP_MIN(0x142, 0xa) VBH_DPP_MIN(0x143, 0xc)
+#undef VBH_DPP_MIN
+  return v;
+}
+// the bound of every bucket as it stands: lane b gets min(init_bound, bmin[b'] for b' < b) (a key; all 64 lanes call it together)
+__device__ __forceinline__ unsigned adm_bounds(const unsigned *bmin, const unsigned *init_bound) {
+  const int lane = threadIdx.x & 63;
+  return wave_min_scan_u32(lane == 0 ? *init_bound : bmin[lane - 1]);
+}
 
 // block reductions with ONE barrier each: partials go to red[par], par flips on every call
 __device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v, Shared &sh, int &par) {
@@ -522,7 +558,7 @@ __device__ __forceinline__ float frame_cost(const Shared &sh, gp<const i32x4> to
 
 // k-th smallest (0-based) of the current frame's costs: exact radix select on the
 // order-preserving keys (the std::nth_element value in GetCutoff, lattice-faster-decoder.cc:654-676)
-__device__ VBH_WARM float select_kth(gp<const i32x4> tok, int n, int k, Shared &sh) {
+VBH_KI __device__ VBH_WARM float select_kth(gp<const i32x4> tok, int n, int k, Shared &sh) {
   const int tid = threadIdx.x;
   __syncthreads();
   if (tid == 0) { sh.sel_prefix = 0; sh.sel_mask = 0; sh.sel_k = k; }
@@ -680,7 +716,7 @@ __device__ __forceinline__ void set_dirty(Shared &sh, int f, bool d) {
 // and holds +inf again on exit.  Leaves the frame's survivor counts in its FrameRec.  Returns
 // (uniformly) bit 0: some extra_cost moved by more than delta (the reference's "changed", :358),
 // bit 1: some extra_cost moved at all.
-__device__ int prune_frame(const Slot &s, int f, float lattice_beam, float delta, Shared &sh, int &pp) {
+VBH_KI __device__ int prune_frame(const Slot &s, int f, float lattice_beam, float delta, Shared &sh, int &pp) {
   const int tid = threadIdx.x;
   FrameRec *frp = s.fr + f;
   const FrameRec fr = ld_frame(frp);
@@ -805,7 +841,7 @@ __device__ int prune_frame(const Slot &s, int f, float lattice_beam, float delta
 // since its last evaluation would be recomputed to the same values.  extra_costs only grow as
 // the frontier advances, so values left stale by an intermediate pass are lower bounds and
 // pruning with them never removes anything the final pass keeps.
-__device__ VBH_COLD void prune_backward(const Slot &s, int from, int first_unpruned, int stop_at, float lattice_beam, float delta,
+VBH_KI __device__ VBH_COLD void prune_backward(const Slot &s, int from, int first_unpruned, int stop_at, float lattice_beam, float delta,
                                bool final, Shared &sh, int &pp) {
   int visited = 0;
   int above = 3;   // result of the frame above: the frontier counts as changed
@@ -815,7 +851,7 @@ __device__ VBH_COLD void prune_backward(const Slot &s, int from, int first_unpru
     if (final) {
       if (!(above & 2) && !frame_dirty(sh, f)) { above = 0; continue; }
     } else if (f < first_unpruned && !(above & 1)) break;
-    above = prune_frame(s, f, lattice_beam, delta, sh, pp);
+    above = prune_frame<KI>(s, f, lattice_beam, delta, sh, pp);
     __syncthreads();   // thread 0's dirty-bit updates before anybody tests the next frame
     visited++;
   }
@@ -838,7 +874,7 @@ __device__ __forceinline__ int seg_find(const int *beg, int n, int x) {
 // ids carry WBIT, remap table w_remap), else a block of H (remap table h_remap).  H token ids
 // >= remap_lo are translated through h_remap.  Flat over all frames: a survivor finds its
 // frame by binary search in LDS.
-template <bool FROM_W>
+template <int KI, bool FROM_W>
 __device__ void compact_move(const Slot &s, Shared &sh, int stage_t, int stage_l, int remap_lo, int dense_tok = 0, int dense_link = 0) {
   const int tid = threadIdx.x;
   gp<i32x4> wt = uptr(s.w_tok), ht = uptr(s.h_tok);
@@ -1039,7 +1075,7 @@ static_assert(sizeof(FrameRec) == 48, "FrameRec is addressed as 12 ints / 3 vect
 // dead.  Survivors are staged in the free space behind the block and copied back to its start;
 // h_remap[] maps old to new token indices (-1 = dead) for this block.  Everything that refers to
 // these tokens is either inside the block or still in the raw window.  Returns false on overflow.
-__device__ bool recompact_tail(const Slot &s, Shared &sh) {
+VBH_KI __device__ bool recompact_tail(const Slot &s, Shared &sh) {
   const int tid = threadIdx.x;
   const int tf0 = sh.tail_f0, tf1 = sh.tail_f1;
   if (tf1 < 0) return true;                       // nothing appended yet
@@ -1065,7 +1101,7 @@ __device__ bool recompact_tail(const Slot &s, Shared &sh) {
   if (sh.error != ERR_NONE) return false;
   const int new_nt = sh.h_ntok, new_nl = sh.h_nlink;
   const int stage_t = old_nt - tail_tb, stage_l = old_nl - tail_lb;   // staging offset relative to the final position
-  compact_move<false>(s, sh, stage_t, stage_l, tail_tb);
+  compact_move<KI, false>(s, sh, stage_t, stage_l, tail_tb);
   __syncthreads();
   if (sh.error != ERR_NONE) return false;
   // ---- staging -> final position (the two regions never overlap: staging starts at the old end)
@@ -1095,11 +1131,11 @@ __device__ bool recompact_tail(const Slot &s, Shared &sh) {
 // Move the survivors of the raw window into the history: tokens of frames (prev_front, front],
 // emitting links from frames [prev_front, front-1], epsilon links within (prev_front, front].
 // Returns false (uniformly) on overflow.
-__device__ VBH_COLD bool compact_window(const Slot &s, int prev_front, int front, Shared &sh) {
+VBH_KI __device__ VBH_COLD bool compact_window(const Slot &s, int prev_front, int front, Shared &sh) {
   const int tid = threadIdx.x;
   const int old_tail_tb = sh.tail_tok_b;
   const bool had_tail = sh.tail_f1 >= 0;
-  if (!recompact_tail(s, sh)) return false;
+  if (!recompact_tail<KI>(s, sh)) return false;
   const int f0 = prev_front < 0 ? 0 : prev_front;
   const int nf = front - f0 + 1;     // frames f0..front  (<= MAX_WIN_FRAMES, checked on the host)
   const FrameRec *lf = job_stage_frames(s, sh, f0, nf);
@@ -1119,7 +1155,7 @@ __device__ VBH_COLD bool compact_window(const Slot &s, int prev_front, int front
   const int blk_tb = sh.h_ntok, blk_lb = sh.h_nlink;
   // the frontier frame (the job's last) has not been swept: its tokens and epsilon links are read densely, the rest through the bitmaps
   const int dense_tok = (lf[nf - 1].flags & 1) ? lf[nf - 1].tok_b : INT_MAX, dense_link = (lf[nf - 1].flags & 4) ? lf[nf - 1].pl_b : INT_MAX;
-  compact_move<true>(s, sh, 0, 0, had_tail ? old_tail_tb : INT_MAX, dense_tok, dense_link);
+  compact_move<KI, true>(s, sh, 0, 0, had_tail ? old_tail_tb : INT_MAX, dense_tok, dense_link);
   __syncthreads();
   if (sh.error != ERR_NONE) return false;
   job_publish(s, sh);
@@ -1251,7 +1287,7 @@ __device__ __forceinline__ void map_clear(Shared &sh) {
 #ifndef VBH_EARLY_EXCISE
 #define VBH_EARLY_EXCISE 1
 #endif
-__device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, int nb, float cutoff, unsigned ep,
+VBH_KI __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, int nb, float cutoff, unsigned ep,
                                    int cur, Shared &sh, int el_b, int el_e, float lattice_beam) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   gp<Ent> ent = uptr(s.ent);
@@ -1482,6 +1518,11 @@ __device__ __forceinline__ int claim_slot(const SlotPoolDev &sp) {
   return -1;      // (seconds without a free slot: see above)
 }
 
+// ADM: ProcessEmitting's admission rule, a template argument so that the rule not in use costs the frame loop no registers.
+//   VBH_ADMIT_EXACT (0): tot <= the frame's final next_cutoff, whatever the order (rounds 1-3; oracle exact_cutoff = 1);
+//   VBH_ADMIT_ORDERED (1): the reference's online tightening (:747-760) as a prefix minimum over a canonical order: tot <= min(initial
+//   next_cutoff, tot' + adaptive_beam of every arc leaving a token of a lower bucket) (oracle exact_cutoff = 3, adm_bucket_bits = 6).
+template <int ADM>
 __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g, DecCfg cfg, const Slot *slots, SlotPoolDev spool,
                                                      const float *__restrict__ loglikes, int P,
                                                      const UttDesc *__restrict__ utts, const int *__restrict__ work_list,
@@ -1560,6 +1601,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       for (int i = 0; i < 12; i++) sh.tph[i] = 0;
       sh.w_ntok = 0; sh.w_nlink = 0; sh.h_ntok = 0; sh.h_nlink = 0; sh.error = ERR_NONE;
       sh.n_max_bound = 0; sh.n_min_bound = 0; sh.n_cand = 0; sh.cand_bound = 0xFFFFFFFFu; sh.n_visited = 0;
+      if (ADM == VBH_ADMIT_ORDERED) sh.init_bound = 0xFFFFFFFFu;
       sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0;
       sh.changed2[0] = 0; sh.changed2[1] = 0;
       sh.cnt_tok[0] = 0; sh.cnt_tok[1] = 0; sh.cnt_el[0] = 0; sh.cnt_el[1] = 0; sh.cnt_pl[0] = 0; sh.cnt_pl[1] = 0;
@@ -1567,6 +1609,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       sh.chk[0] = 0; sh.chk[1] = 0; sh.chk[2] = 0; sh.chk[3] = 0;
     }
     for (int i = tid; i < DIRTY_FRAMES / 32; i += NT) sh.dirty[i] = ~0u;   // no frame has been evaluated yet
+    if (ADM == VBH_ADMIT_ORDERED && tid < 64) sh.bmin[tid] = 0xFFFFFFFFu;
     map_clear(sh);
     if (tid == 0) sh.use_lds_map = cfg.use_lds_map;
     pp = 0;
@@ -1592,7 +1635,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       }
       __threadfence_block();
       __syncthreads();
-      const int plb = process_nonemitting(g, s, 0, cfg.beam, ep, 0, sh, 0, 0, cfg.lattice_beam);
+      const int plb = process_nonemitting<ADM>(g, s, 0, cfg.beam, ep, 0, sh, 0, 0, cfg.lattice_beam);
       cur_b = 0; cur_e = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap;
       if (tid == 0) {
         FrameRec r;
@@ -1633,10 +1676,10 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         // intermediate passes walk back at most one interval beyond the unpruned frames: a bound on
         // the work (long-lived parallel paths would otherwise drag every pass back to frame 0);
         // whatever is left stale is a lower bound and is settled by the final pass
-        prune_backward(s, frame - 1, prev_front < 0 ? 0 : prev_front, (prev_front < 0 ? 0 : prev_front) - cfg.prune_back,
+        prune_backward<ADM>(s, frame - 1, prev_front < 0 ? 0 : prev_front, (prev_front < 0 ? 0 : prev_front) - cfg.prune_back,
                        cfg.lattice_beam, cfg.lattice_beam * 0.1f, /*final=*/false, sh, pp);
         PHASE(4)
-        if (!compact_window(s, prev_front, frame, sh)) break;
+        if (!compact_window<ADM>(s, prev_front, frame, sh)) break;
         prev_front = frame;
         { const FrameRec fr = ld_frame(s.fr + frame); cur_b = fr.tok_b; cur_e = fr.tok_e; }
         cur_w = false;
@@ -1712,14 +1755,14 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         cnt = block_sum_u64(cnt, sh, par);
         const int cnt_lt = (int)(cnt >> 32), cnt_le = (int)(unsigned)cnt;
         // the order statistic is only needed when it decides the comparison
-        if (n > cfg.max_active && cnt_lt > cfg.max_active) mac = select_kth(tok, n, cfg.max_active, sh);
+        if (n > cfg.max_active && cnt_lt > cfg.max_active) mac = select_kth<ADM>(tok, n, cfg.max_active, sh);
         if (mac < beam_cutoff) {
           adaptive_beam = mac - best + cfg.beam_delta; cur_cutoff = mac;
           if (tid == 0) sh.n_max_bound++;
         } else {
           if (n > cfg.min_active) {
             if (cfg.min_active == 0) mic = best;
-            else if (cnt_le <= cfg.min_active) mic = select_kth(tok, n, cfg.min_active, sh);
+            else if (cnt_le <= cfg.min_active) mic = select_kth<ADM>(tok, n, cfg.min_active, sh);
             else mic = beam_cutoff;   // some value <= beam_cutoff: the comparison below is false
           }
           if (mic > beam_cutoff) {
@@ -1778,15 +1821,25 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
           const bool exp = c <= cur_cutoff;       // (false for lanes without a token)
           // (the sign bit of the first-arc index marks the frame's best token)
           const int a0 = (sr.x + sr.y) | ((exp && (rec.x & STMASK) == best_state) ? EPSBIT : 0), cnt = exp ? sr.z - sr.y : 0;
+          // ordered admission: the token's bucket and, as a filter, its bucket's bound as it stands at the start of the round, in one
+          // word for the lanes that expand its arcs: the key with its six low bits giving way to the bucket (read back with those
+          // bits set: a bound rounded UP, and an unset bound reads as NaN, which no cost exceeds)
+          int bkw = 0;
+          if (ADM == VBH_ADMIT_ORDERED) {
+            const int bk = adm_bucket(rec.x & STMASK);
+            const unsigned pre = adm_bounds(sh.bmin, &sh.init_bound);
+            bkw = (int)(((unsigned)__shfl((int)pre, bk, 64) & ~63u) | (unsigned)bk);
+          }
           c_tok_exp += exp;
           wave_expand_n<UA>(sh.wx[wave], cnt, [&](const bool (&valid)[UA], const int (&owner)[UA], const int (&j)[UA]) {
             P1STAMP(1)
-            int a[UA]; float cc[UA]; bool isb[UA]; i32x4 arc[UA]; float sc[UA];
+            int a[UA]; float cc[UA]; bool isb[UA]; i32x4 arc[UA]; float sc[UA]; int bko[UA];
 #pragma unroll
             for (int u = 0; u < UA; u++) {
               const int ao = __shfl(a0, owner[u], 64);
               a[u] = (ao & ~EPSBIT) + j[u]; isb[u] = ao < 0;
               cc[u] = __shfl(c, owner[u], 64);
+              bko[u] = (ADM == VBH_ADMIT_ORDERED && !VBH_ADM_LATE) ? __shfl(bkw, owner[u], 64) : 0;
             }
 #pragma unroll
             for (int u = 0; u < UA; u++) arc[u] = garcs[valid[u] ? a[u] : 0];
@@ -1810,7 +1863,34 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
             // it is not written to the candidate list.  (What the reference does one arc at a time, :758-760, as a filter only:
             // the admitted set is still exactly {tot <= final next_cutoff}.)
             bool keep[UA];
-            {
+            if (ADM == VBH_ADMIT_ORDERED) {
+              // Ordered admission: every arc lowers its bucket's minimum (and the best token's arcs the initial bound); what an arc is
+              // admitted against is only known when all arcs have (pass 2), but the bounds as they stand now are no smaller, so an arc
+              // above its bucket's present bound is not written
+#if VBH_ADM_REFRESH
+              const unsigned pre2 = adm_bounds(sh.bmin, &sh.init_bound);      // the bounds as they stand now, not at the start of the round
+#endif
+#pragma unroll
+              for (int u = 0; u < UA; u++) {
+                if (VBH_ADM_LATE) bko[u] = __shfl(bkw, owner[u], 64);
+#if VBH_ADM_REFRESH
+                const float bnd = fminf(o2f((unsigned)bko[u] | 63u), o2f((unsigned)__shfl((int)pre2, bko[u] & 63, 64)));
+#else
+                const float bnd = o2f((unsigned)bko[u] | 63u);
+#endif
+                keep[u] = valid[u] && !(tot[u] > bnd);
+                bko[u] &= 63;
+                if (valid[u]) {
+                  // Only an arc that gets below the bound of its OWN bucket can lower the bound of a later one (those are minima over
+                  // this bucket's bound and more), so every other arc -- all but the frame's few best -- spares its atomic: bmin[] need
+                  // not hold the buckets' exact minima, only the prefix minima over it must come out exact.  (An unset bound is a NaN:
+                  // the comparison is written so that it then fails and the atomic is done.)
+                  const float v = tot[u] + adaptive_beam;
+                  if (!(v >= bnd)) atomicMin(&sh.bmin[bko[u]], f2o(v));
+                  if (isb[u]) atomicMin(&sh.init_bound, f2o((((asf(arc[u].y) + cost_offset) - sc[u]) + best) + adaptive_beam));
+                }
+              }
+            } else {
               float it_min = INF;
 #pragma unroll
               for (int u = 0; u < UA; u++) if (valid[u]) it_min = fminf(it_min, tot[u] + adaptive_beam);
@@ -1827,7 +1907,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
             for (int u = 0; u < UA; u++) {
               if (keep[u]) {
                 if (q[u] < cand_cap) {
-                  i32x4 ca; ca.x = asi(tot[u]); ca.y = a[u]; ca.z = base + owner[u]; ca.w = arc[u].x;
+                  i32x4 ca; ca.x = asi(tot[u]); ca.y = a[u]; ca.z = (base + owner[u]) | (bko[u] << 26); ca.w = arc[u].x;
                   cand[q[u]] = ca;
                 } else sh.error = ERR_CAND;
               }
@@ -1841,6 +1921,8 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       P1STAMP(7)
       const float next_cutoff = mymin;
       const int ncand = sh.n_cand < cand_cap ? sh.n_cand : cand_cap;      // (pass 2 does not move n_cand)
+      // ordered admission: the buckets' final bounds (every arc's minimum is in: the reduction's barrier), lane b holds bucket b's
+      const unsigned adm_pre = ADM == VBH_ADMIT_ORDERED ? adm_bounds(sh.bmin, &sh.init_bound) : 0u;
       PHASE(1)
       // ---- pass 2 (candidate-parallel): admit tot <= next_cutoff: the state's cost in the map is lowered (the thread whose
       //      compare-and-swap claims a first-level slot, or that meets a stale epoch in the second level, is the first to reach
@@ -1859,7 +1941,11 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
             const int q = base + u * NT + tid;
             const bool ok = q < ncand;
             CA[u] = cand[ok ? q : 0];
-            adm[u] = ok && !(asf(CA[u].x) > next_cutoff);
+            if (ADM == VBH_ADMIT_ORDERED) {
+              const float bnd = o2f((unsigned)__shfl((int)adm_pre, (int)((unsigned)CA[u].z >> 26), 64));
+              adm[u] = ok && !(asf(CA[u].x) > bnd);
+              CA[u].z &= 0x03FFFFFF;
+            } else adm[u] = ok && !(asf(CA[u].x) > next_cutoff);
           }
           int slot[UC]; bool create[UC], mk2[UC]; int nid[UC];
 #pragma unroll
@@ -1904,7 +1990,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       if (sh.error != ERR_NONE) break;
       PHASE(2)
       // ---- ProcessNonemitting(next_cutoff)
-      const int plb = process_nonemitting(g, s, nb, next_cutoff, ep, 0, sh, lb, le_emit, cfg.lattice_beam);
+      const int plb = process_nonemitting<ADM>(g, s, nb, next_cutoff, ep, 0, sh, lb, le_emit, cfg.lattice_beam);
       cur_b = nb; cur_e = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap; cur_w = true;
       const int pl_end = sh.w_nlink < s.w_link_cap ? sh.w_nlink : s.w_link_cap;
       if (tid == 0) {
@@ -1915,6 +2001,10 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         r.flags = 1 | 4; r.cost_offset = 0.0f; r.a_tok = cur_e - cur_b; r.a_el = 0; r.a_pl = pl_end - plb; r.pad = 0;
         st_frame(s.fr + (frame + 1), r);
         sh.n_cand = 0; sh.cand_bound = 0xFFFFFFFFu; sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0;
+      }
+      if (ADM == VBH_ADMIT_ORDERED) {      // (their last readers: before pass 2; the barrier below)
+        if (tid >= NT - 64) sh.bmin[tid - (NT - 64)] = 0xFFFFFFFFu;
+        if (tid == 0) sh.init_bound = 0xFFFFFFFFu;
       }
 #ifdef VBH_DIAG
       if (tid == 0) {
@@ -1995,9 +2085,9 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         if (last) break;
       }
       __syncthreads();
-      prune_backward(s, F - 1, /*first_unpruned=*/0, /*stop_at=*/0, cfg.lattice_beam, 0.0f, /*final=*/true, sh, pp);   // delta 0 (:606-611)
+      prune_backward<ADM>(s, F - 1, /*first_unpruned=*/0, /*stop_at=*/0, cfg.lattice_beam, 0.0f, /*final=*/true, sh, pp);   // delta 0 (:606-611)
       PHASE(4)
-      compact_window(s, prev_front, F, sh);
+      compact_window<ADM>(s, prev_front, F, sh);
       PHASE(5)
     }
     __syncthreads();
@@ -2298,6 +2388,12 @@ static const char *err_name(int e);
 // passes however few links it holds, re-visits per frame fall with the interval (r02, same box: 251 / 247 / 244 / 241 / 243 ms per
 // utterance at 100 / 140 / 180 / 300 / 450), and HBM has room for the longer raw window (~115 MB per search workspace).
 // VBH_PRUNE_EVERY overrides (tuning, and tests of the pruning paths).
+// VBH_ADMISSION=exact|ordered overrides the configuration (A/B runs of programs that do not expose the field)
+static int admission_of(const vbh_decode_cfg *cfg) {
+  int a = cfg->admission == VBH_ADMISSION_EXACT ? VBH_ADMIT_EXACT : VBH_ADMIT_ORDERED;
+  if (const char *e = getenv("VBH_ADMISSION")) a = !strcmp(e, "exact") ? VBH_ADMIT_EXACT : !strcmp(e, "ordered") ? VBH_ADMIT_ORDERED : a;
+  return a;
+}
 static int effective_prune_interval(const vbh_decode_cfg *cfg) {
   int v = std::max(cfg->prune_interval, 300);
   if (const char *e = getenv("VBH_PRUNE_EVERY")) { const int x = atoi(e); if (x > 0) v = x; }
@@ -2385,6 +2481,7 @@ void vbh_decode_cfg_default(vbh_decode_cfg *c) {
   // VB/scr/kaldi_scr.h:152-157 (Decode defaults) over lattice-faster-decoder.h:59-67
   c->beam = 13.0f; c->max_active = 7000; c->min_active = 200; c->lattice_beam = 6.0f;
   c->prune_interval = 25; c->beam_delta = 0.5f; c->acoustic_scale = 0.083333f;
+  c->admission = VBH_ADMISSION_ORDERED;
 }
 
 int vbh_graph_create(vbh_ctx *ctx, int32_t num_states, int32_t start, const float *h_final,
@@ -2680,6 +2777,12 @@ static const char *err_name(int e) {
 
 extern "C" {
 
+// one instantiation of the search kernel per admission rule (DecCfg::admission)
+#define VBH_LAUNCH_DECODE(grid_, dg_, dc_, ...)                                                                                         \
+  {                                                                                                                                     \
+    if (admission_of(&d->cfg) == VBH_ADMIT_ORDERED) hipLaunchKernelGGL(decode_kernel<VBH_ADMIT_ORDERED>, grid_, dim3(NT), 0, st, dg_, dc_, __VA_ARGS__); \
+    else hipLaunchKernelGGL(decode_kernel<VBH_ADMIT_EXACT>, grid_, dim3(NT), 0, st, dg_, dc_, __VA_ARGS__);                               \
+  }
 static int decode_batch_begin_impl(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, const int64_t *h_frame_offsets,
                                    int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids) {
   VBH_CHECK(d && h_frame_offsets && h_tid2pdf, "vbh_decode_batch: NULL argument");
@@ -2786,7 +2889,7 @@ static int decode_batch_begin_impl(vbh_decoder *d, const float *d_loglikes, int3
       Pool closed = pool; closed.tok_cap = 0; closed.link_cap = 0; closed.cost_cap = 0;
       VBH_HIP(hipMemcpyAsync(d->d_utts.p, probe.data(), sizeof(UttDesc) * n_utt, hipMemcpyHostToDevice, st));
       VBH_HIP(hipMemcpyAsync(d->d_pool.p, &closed, sizeof(Pool), hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(decode_kernel, dim3(std::min(WG_PER_CU * d->ctx->num_cus, n_utt)), dim3(NT), 0, st, dg0, dc0, d->small_set->d.p, d->small_set->dev(), d_loglikes,
+      VBH_LAUNCH_DECODE(dim3(std::min(WG_PER_CU * d->ctx->num_cus, n_utt)), dg0, dc0, d->small_set->d.p, d->small_set->dev(), d_loglikes,
                          (int)num_pdfs, d->d_utts.p, (const int *)nullptr, n_utt, d->d_counter.p, d->d_res.p, d->d_pool.p);
       VBH_HIP(hipGetLastError());
       std::vector<UttResult> pr(n_utt);
@@ -2818,7 +2921,7 @@ static int decode_batch_begin_impl(vbh_decoder *d, const float *d_loglikes, int3
     const int grid = std::min(std::min(d->small_set->n, WG_PER_CU * d->ctx->num_cus), n_utt);
     VBH_HIP(hipMemsetAsync(d->d_res.p, 0xFF, sizeof(UttResult) * (size_t)n_utt, st));     // error = -1: "no workgroup searched it" until one does
     VBH_HIP(hipEventRecord(d->ev0, st));
-    hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(NT), 0, st, d->pend.dg, d->pend.dc, d->small_set->d.p, d->small_set->dev(), d_loglikes, (int)num_pdfs,
+    VBH_LAUNCH_DECODE(dim3(grid), d->pend.dg, d->pend.dc, d->small_set->d.p, d->small_set->dev(), d_loglikes, (int)num_pdfs,
                        d->d_utts.p, d_work_list, n_utt, d->d_counter.p, d->d_res.p, d_pool.p);
     VBH_HIP(hipGetLastError());
     VBH_HIP(hipEventRecord(d->ev1, st));
@@ -2955,7 +3058,7 @@ static int decode_batch_end_impl(vbh_decoder *d) {
       VBH_HIP(hipMemsetAsync(d_counter.p, 0, sizeof(int), st));
       const int grid = std::min<int>(big ? set.n : std::min(set.n, WG_PER_CU * d->ctx->num_cus), (int)list.size());
       VBH_HIP(hipEventRecord(ev0, st));
-      hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(NT), 0, st, dg, dc, set.d.p, set.dev(), d_loglikes, (int)num_pdfs,
+      VBH_LAUNCH_DECODE(dim3(grid), dg, dc, set.d.p, set.dev(), d_loglikes, (int)num_pdfs,
                          d_utts.p, d_list.p, (int)list.size(), d_counter.p, d_res.p, d_pool.p);
       VBH_HIP(hipGetLastError());
       VBH_HIP(hipEventRecord(ev1, st));
