@@ -133,11 +133,16 @@ def test_output_pool_grows_instead_of_failing_the_batch(setup, monkeypatch):
     dec.close()
 
 
-def test_speech_workload_equals_the_reference_decoder_on_identical_scores(setup):
+@pytest.mark.parametrize("adm", ["ordered", "exact"])
+def test_speech_workload_equals_the_reference_decoder_on_identical_scores(setup, adm):
     """The regime the bench's headline is measured in (synth_speech: ~50 words per 30 s utterance, max-active deciding the cutoff in
-    every sixth frame, WER about 1 % with this graph): the GPU search on the ORACLE's scores must give the best paths the REFERENCE's
-    own LatticeFasterDecoder gave on the same scores (oracle/gen_golden_speech.py ran it in the build container) -- words, alignment
-    and float32 weights, bit for bit -- and the lattice the oracle's order-independent mode gives."""
+    every sixth frame, WER about 1 % with this graph): the GPU search on the ORACLE's scores against the best paths the REFERENCE's
+    own LatticeFasterDecoder gave on the same scores (oracle/gen_golden_speech.py ran it in the build container).  Which arcs above the
+    final next_cutoff get through depends on the visiting order (the reference's: its hash list), and in this regime that decides the
+    best path of about one utterance in a hundred (tests/golden/speech_e2e512.npz: the reference against itself under another
+    --hash-ratio).  With admission = "exact" (none of those arcs) all eight come out as the reference's -- words, alignment and float32
+    weights bit for bit; with "ordered" (the reference's rule in a canonical order: the product's default) seven or eight do.  In
+    both modes the lattice is the oracle's in the same mode, bit for bit."""
     from oracle import gen_golden_speech as sp
     from oracle import vbo
     from voicebridge_amd import api, synth_speech as ss
@@ -154,22 +159,26 @@ def test_speech_workload_equals_the_reference_decoder_on_identical_scores(setup)
     ll = np.concatenate([vbo.gmm_loglikes(offs, gc, miv, iv, F[u]) for u in range(sp.N_UTT)])
     foff = np.zeros(sp.N_UTT + 1, np.int64)
     foff[1:] = np.cumsum([f.shape[0] for f in F])
-    dec = api.LatticeDecoder(s["ctx"], s["graph"], sp.N_UTT, int(np.diff(foff).max()), acoustic_scale=sp.CFG["acwt"], **s["cfg"])
+    dec = api.LatticeDecoder(s["ctx"], s["graph"], sp.N_UTT, int(np.diff(foff).max()), acoustic_scale=sp.CFG["acwt"], admission=adm, **s["cfg"])
     dec.decode(s["torch"].from_numpy(ll).to(s["ctx"].device), foff, t2p)
     fst = vbo.make_fst(g["final"], g["arc_offset"], g["arcs"], 0)
-    bound = 0
+    bound, same = 0, 0
     for u in range(sp.N_UTT):
         got = dec.result(u)
         msg = "utt %d (regenerated waveforms %s the fixture's)" % (u, "equal" if same_waves else "DIFFER from")
-        np.testing.assert_array_equal(got["words"], fx["ref_words_%d" % u], err_msg=msg)
-        np.testing.assert_array_equal(got["ali"], fx["ref_ali_%d" % u], err_msg=msg)
-        np.testing.assert_array_equal(np.float32([got["best_graph"], got["best_acoustic"]]), fx["ref_best_weight_%d" % u], err_msg=msg)
+        eq = (np.array_equal(got["words"], fx["ref_words_%d" % u]) and np.array_equal(got["ali"], fx["ref_ali_%d" % u]) and
+              np.array_equal(np.float32([got["best_graph"], got["best_acoustic"]]), fx["ref_best_weight_%d" % u]))
+        same += int(eq)
+        if adm == "exact":
+            assert eq, msg
         assert len(got["words"]) > 30
-        if u < 2:        # (the oracle's search of one such utterance takes a few seconds)
-            ref = vbo.decode_lattice_faster(fst, ll[foff[u]:foff[u + 1]], t2p, acwt=sp.CFG["acwt"], **ORACLE_ADMISSION["ordered"], **s["cfg"])
+        if u < 2 or not eq:        # (the oracle's search of one such utterance takes a few seconds)
+            ref = vbo.decode_lattice_faster(fst, ll[foff[u]:foff[u + 1]], t2p, acwt=sp.CFG["acwt"], **ORACLE_ADMISSION[adm], **s["cfg"])
             for k in LAT_KEYS:
                 np.testing.assert_array_equal(got[k], ref[k], err_msg="utt %d %s" % (u, k))
         bound += got["n_frames_maxactive_bound"]
+    print("\nadmission %s: best path (words, alignment, weights) bit-identical to the reference decoder's on %d / %d utterances" % (adm, same, sp.N_UTT))
+    assert same >= sp.N_UTT - 1
     assert bound > 8 * 300
     assert dec.batch_stats()["failed"] == 0
     dec.close()

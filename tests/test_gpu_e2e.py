@@ -122,19 +122,19 @@ def test_words_from_pcm_against_the_reference_programs(chain, tmp_path):
           "|log-like per frame| differs by <= %.2e (equal-word utterances: %.2e); bootstrap: reference %.2f [%.2f, %.2f], GPU %.2f [%.2f, %.2f], "
           "P(GPU improves on reference) = %.2f" % ((sum(same), s["n"], wer_ref, wer_gpu, int(c_ref[1]), dlike.max(), dlike[np.array(same)].max()) + ci))
     assert all(r["ok"] == 1 for r in res)
-    # What can be asked of an order-independent search here.  The reference itself is order dependent in this regime: the same
-    # program on the same inputs with --hash-ratio=1 / 3 instead of 2 (another visiting order in ProcessEmitting) changes the words
-    # of 1 / 2 of these 64 utterances (fixture: ref_same_words_hash_ratio_*).  The oracle says where the GPU's differences come
-    # from (tools/r3_admission_words.py): in reference order it reproduces the programs' words on 63 / 64 from PCM, in
-    # the order-independent mode -- what the GPU computes bit for bit -- on 60: three utterances lose their best path to the
-    # admission rule (max-active binds, adaptive_beam < beam, and the reference lets through arcs above the final next_cutoff
-    # that it happens to visit early), one differs within the float tolerance of the front end.
+    # What can be asked here.  The reference is order dependent in this regime: the same program on the same inputs with --hash-ratio=1 / 3
+    # instead of 2 (another visiting order in ProcessEmitting, so other arcs above the final next_cutoff get through) changes the words
+    # of 1 / 2 of these 64 utterances (fixture: ref_same_words_hash_ratio_*).  The GPU search applies the reference's rule in a canonical
+    # order (admission = ordered), so it differs from the reference's default run the way the reference's other runs do, plus the float
+    # tolerance of the front end: 60 / 64 here, errors on both sides.  The statistical statement -- no bias against the reference -- is
+    # made on 512 utterances (tests/test_gpu_e2e512.py); this sample is too small for more than: nine in ten utterances word-identical,
+    # each side's WER inside the other's 95 % bootstrap interval, and the GPU not on the losing side of every resampling (round 3's
+    # order-independent rule was: P(GPU improves) = 0.00 on this sample -- and 0.98 on the 512).
     self_same = min(int(fx["ref_same_words_hash_ratio_1"].sum()), int(fx["ref_same_words_hash_ratio_3"].sum()))
-    assert sum(same) >= self_same - 4 and sum(same) >= (s["n"] * 7) // 8
-    # no WER bias beyond the resolution of the sample: each side's WER inside the other's 95 % bootstrap interval, and the
-    # difference below a quarter of the interval's width
+    assert sum(same) >= self_same - 4 and sum(same) >= (s["n"] * 9) // 10
     assert ci[1] <= wer_gpu <= ci[2] and ci[4] <= wer_ref <= ci[5]
     assert abs(wer_gpu - wer_ref) < 0.25 * (ci[2] - ci[1])
+    assert ci[6] >= 5.0          # (ComputeWerBootci prints the probability in per cent)
     # where the words agree the path is the same and its score differs by the float tolerance of the chain only
     assert dlike[np.array(same)].max() < 2e-3
 

@@ -87,10 +87,10 @@ def test_512_utterances_against_the_reference_programs(tmp_path):
         ci = _bootci(truth, ref, got, tmp_path / adm)
         like = np.array([-(r["best_graph"] + r["best_acoustic"]) / r["num_frames"] for r in res])
         dlike = np.abs(like - fx["ref_like_per_frame"])
-        out[adm] = dict(same=sum(same), wer=100.0 * e.sum() / nw, p_improves=ci[6], ci=ci, worse=int((e > e_ref).sum()), better=int((e < e_ref).sum()),
+        out[adm] = dict(same=sum(same), wer=100.0 * e.sum() / nw, p_improves=ci[6] / 100.0, ci=ci, worse=int((e > e_ref).sum()), better=int((e < e_ref).sum()),
                         dlike_same=float(dlike[np.array(same)].max()))
         print("admission %-8s words equal to the reference's on %d / %d; WER %.3f %% (%+d errors); utterances with more / fewer errors than the reference: %d / %d; "
-              "bootstrap: reference %.2f [%.2f, %.2f], GPU %.2f [%.2f, %.2f], P(GPU improves on the reference) = %.2f; |log-like per frame| differs by <= %.1e where the words agree"
+              "bootstrap: reference %.2f [%.2f, %.2f], GPU %.2f [%.2f, %.2f], P(GPU improves on the reference) = %.1f %%; |log-like per frame| differs by <= %.1e where the words agree"
               % ((adm, sum(same), n, out[adm]["wer"], int(e.sum() - e_ref.sum()), out[adm]["worse"], out[adm]["better"]) + ci + (out[adm]["dlike_same"],)))
     graph.close(); gmm.close(); ctx.close()
     o = out["ordered"]
