@@ -1163,6 +1163,17 @@ def main():
         ctx_full.sync()
         t_ = ctx_full.timer_ms(0) * (T / float(n_rows0))
         mfcc_alone_ms = t_ if mfcc_alone_ms is None else min(mfcc_alone_ms, t_)
+    # ... and the post-processing kernel (CMVN + deltas / splice + transforms), the same way
+    featpost_alone_ms = None
+    post_m = post if ctx_full is ctx else (api.FeaturePipeline(ctx_full, cmvn=True, mode="splice", splice_left=4, splice_right=4, lda=lda, spk_xform_shape=(40, 41))
+                                           if args.feat == "lda" else api.FeaturePipeline(ctx_full, cmvn=True, mode="delta", spk_xform_shape=(39, 40)))
+    for _ in range(3):
+        ctx_full.timer_start(0)
+        post_m.apply(ring[0][0][:n_rows0], slices[0].foff, utt2spk=slices[0].u2s, cmvn_stats=slices[0].stats, spk_xforms=slices[0].xforms, out=ring[0][1][:n_rows0])
+        ctx_full.timer_stop(0)
+        ctx_full.sync()
+        t_ = ctx_full.timer_ms(0) * (T / float(n_rows0))
+        featpost_alone_ms = t_ if featpost_alone_ms is None else min(featpost_alone_ms, t_)
     if dec_enabled:
         dec = lanes[(S - 1) % depth].dec                 # holds the lattices of the collection step's last slice
         dur = (col_tl[:, 1] - col_tl[:, 0]).astype(np.float64)
@@ -1216,15 +1227,37 @@ def main():
                 gmm_roof[k_] = v_
             gmm_roof["frac"] = gmm_roof["achieved"] / F32_MFMA_PEAK_TFLOPS
             gmm_roof["hbm_frac"] = gmm_roof["hbm_GBs"] / HBM_PEAK_GBS
-        # MFCC: SURVEY.md 8d: 160 new int16 samples in + 13 floats out = 372 B and ~15 kflop per frame
+        # MFCC: SURVEY.md 8d: 160 new int16 samples in + 13 floats out = 372 B and ~15 kflop per frame.  What binds it is the LDS pipe (the
+        # radix-4 exchanges of the FFT, the mel accumulation and the DCT all go through LDS): the counters of profiles/r04_frontend_counters.json
+        # (rocprofv3 --pmc, this command with --no-decode) say the LDS arrays are busy 75 % of the CU-cycles and the waves wait for LDS 62 %
+        # of theirs, VALU issue 17 %.  So the kernel is priced against the LDS pipe, with the fraction of the HBM roof beside it for the record.
         m_bytes, m_flops = 372.0 * T, 15.0e3 * T
-        extra_mfcc = {"kernel": "mfcc512_kernel", "bound": "hbm", "achieved": m_bytes / (mfcc_alone_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                      "unit": "GB/s", "frac": m_bytes / (mfcc_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": mfcc_alone_ms,
+        fe_cnt = {}
+        try:
+            fe_cnt = json.load(open(os.path.join(ROOT, "profiles", "r04_frontend_counters.json")))
+        except Exception:
+            pass
+        mc = fe_cnt.get("mfcc512_kernel", {})
+        extra_mfcc = {"kernel": "mfcc512_kernel", "bound": "lds", "achieved": mc.get("lds_busy_cycles_per_frame"), "unit": "LDS-array busy cycles per frame (all CUs)",
+                      "peak": (mfcc_alone_ms * 1e-3 * mc["clock_hz"] * mc["cus"] / T) if mc else None,
+                      "frac": (mc["lds_busy_cycles_per_frame"] / (mfcc_alone_ms * 1e-3 * mc["clock_hz"] * mc["cus"] / T)) if mc else None,
+                      "traffic": None, "kernel_ms": mfcc_alone_ms,
+                      "hbm_GBs": m_bytes / (mfcc_alone_ms * 1e-3) / 1e9, "hbm_frac": m_bytes / (mfcc_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       "algorithmic_bytes": m_bytes, "algorithmic_flops": m_flops, "gflops": m_flops / (mfcc_alone_ms * 1e-3) / 1e9,
-                      "frames_per_s": T / (mfcc_alone_ms * 1e-3),
-                      "note": "kernel alone on the chip, HIP events on its stream, best of 3 after the timed region; HBM-bound by its arithmetic intensity "
-                              "(40 flop/B) only in principle: a frame is a 512-point FFT plus three small dot-product stages through LDS, so the kernel "
-                              "is bound by LDS/VALU issue, and the fraction of the HBM roof is small by construction"}
+                      "frames_per_s": T / (mfcc_alone_ms * 1e-3), "counters": mc or None,
+                      "note": "kernel alone on the chip, HIP events on its stream, best of 3 after the timed region.  frac = the share of this launch's CU-cycles "
+                              "(its duration x 2.4 GHz x 256 CUs: a lower bound, the chip clocks lower under load) during which the LDS arrays are busy, from SQ_LDS_IDX_ACTIVE per frame of the committed "
+                              "counter pass; by arithmetic intensity (40 flop/B) the kernel would be HBM-bound, but a frame is a 512-point FFT plus three small "
+                              "dot-product stages through LDS, so hbm_frac is small by construction"}
+        # post-processing: 4 (13 + D) bytes per frame in and out, HBM-bound
+        fp_bytes = 4.0 * (13 + args.feat_dim) * T
+        extra_featpost = {"kernel": "featpost_kernel", "bound": "hbm", "achieved": fp_bytes / (featpost_alone_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": fp_bytes / (featpost_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": featpost_alone_ms,
+                          "algorithmic_bytes": fp_bytes, "frames_per_s": T / (featpost_alone_ms * 1e-3), "counters": fe_cnt.get("featpost_kernel"),
+                          "note": "kernel alone on the chip, best of 3 after the timed region: CMVN + deltas (or splice + LDA) + the speaker's transform, 64 frames "
+                                  "(+ halo) per workgroup; 1 %% of the step.  Far from the HBM roof: a workgroup's 64 frames are 3 KB in and 10 KB out between two "
+                                  "barriers, and the waves spend their time waiting for those few loads (VALU issue 17 % of the wave-cycles, "
+                                  "profiles/r04_frontend_counters.json)"}
         stage_ms = {"mfcc+featpost": float(np.mean(feat_ms)), "gmm": g_ms}
         roof = gmm_roof
         extra = {}
@@ -1329,6 +1362,7 @@ def main():
         }
         out.update(extra)
         out["roofline_mfcc"] = extra_mfcc
+        out["roofline_featpost"] = extra_featpost
         # HBM traffic of the dominant kernels from the committed rocprofv3 --pmc passes of this
         # same command (profiles/): only attached when the batch size matches that run
         try:

@@ -2432,8 +2432,10 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
   const int pi = effective_prune_interval(cfg);
   const int win = pi + 1;
   Slot p{};
-  p.w_tok_cap = (int)std::min<long long>(per_frame_tok_s * win, 1LL << 28);
-  p.w_link_cap = (int)std::min<long long>((per_frame_link + per_frame_tok_s) * win, 1LL << 28);
+  // (every frame's tokens and links start a 64-bit word of the survivor bitmaps, VBH_SURVIVOR_BITS: a frame takes whole words, which
+  // for a graph of a dozen states -- config 1's monophone loop -- is several times what its tokens need; tests/test_gpu_config1.py)
+  p.w_tok_cap = (int)std::min<long long>((((per_frame_tok_s + 63) & ~63LL) + 64) * win, 1LL << 28);
+  p.w_link_cap = (int)std::min<long long>((((per_frame_link + per_frame_tok_s + 63) & ~63LL) + 64) * win, 1LL << 28);
   // history: one unpruned frontier frame per interval plus the survivors
   const long long n_int = max_frames / pi + 2;
   const long long front_avg = big ? per_frame_tok : per_frame_tok / 2;

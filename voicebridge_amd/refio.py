@@ -35,31 +35,35 @@ def _fmat(m):
 
 def write_mdl(path, n_cd, hmm_states, offs, weights, miv, iv, self_p=0.6):
     """Binary .mdl: `n_cd` phones, each a left-to-right HMM of `hmm_states` emitting states (self-loop then forward
-    transition) with pdf = phone_index * hmm_states + state, i.e. the transition-ids synth.lexicon_graph() uses (pdf p:
-    self-loop 2p+1, forward 2p+2); then the diagonal GMMs of the first n_cd * hmm_states pdfs.  Readable by the reference
-    (TransitionModel::Read, AmDiagGmm::Read) and by vbio::ReadModel."""
-    H = hmm_states
+    transition; an int, or a list with one count per phone: one topology entry per distinct count) with the pdfs numbered
+    phone by phone, state by state, i.e. the transition-ids synth.lexicon_graph() uses (pdf p: self-loop 2p+1, forward 2p+2);
+    then the diagonal GMMs of those pdfs.  Readable by the reference (TransitionModel::Read, AmDiagGmm::Read) and by
+    vbio::ReadModel."""
+    Hs = [int(hmm_states)] * n_cd if np.isscalar(hmm_states) else [int(h) for h in hmm_states]
+    assert len(Hs) == n_cd
+    kinds = sorted(set(Hs))
     parts = [b"\0B" + _tok("<TransitionModel>") + _tok("<Topology>")]
     phones = list(range(1, n_cd + 1))
-    parts.append(_ivec(phones) + _ivec([-1] + [0] * n_cd))
-    parts.append(_i32(1))                      # one topology entry shared by all phones
-    parts.append(_i32(H + 1))
-    for k in range(H):
-        parts.append(_i32(k) + _i32(2) + _i32(k) + _f32(self_p) + _i32(k + 1) + _f32(1.0 - self_p))
-    parts.append(_i32(-1) + _i32(0))           # final non-emitting state
-    parts.append(_tok("</Topology>") + _tok("<Triples>") + _i32(n_cd * H))
-    trip = np.zeros((n_cd * H, 3), "<i4")
-    trip[:, 0] = np.repeat(np.arange(1, n_cd + 1), H)
-    trip[:, 1] = np.tile(np.arange(H), n_cd)
-    trip[:, 2] = np.arange(n_cd * H)
-    rec = np.zeros((n_cd * H, 3), dtype=[("s", "u1"), ("v", "<i4")])
+    parts.append(_ivec(phones) + _ivec([-1] + [kinds.index(h) for h in Hs]))
+    parts.append(_i32(len(kinds)))             # one topology entry per distinct state count
+    for H in kinds:
+        parts.append(_i32(H + 1))
+        for k in range(H):
+            parts.append(_i32(k) + _i32(2) + _i32(k) + _f32(self_p) + _i32(k + 1) + _f32(1.0 - self_p))
+        parts.append(_i32(-1) + _i32(0))       # final non-emitting state
+    P = int(sum(Hs))
+    parts.append(_tok("</Topology>") + _tok("<Triples>") + _i32(P))
+    trip = np.zeros((P, 3), "<i4")
+    trip[:, 0] = np.repeat(np.arange(1, n_cd + 1), Hs)
+    trip[:, 1] = np.concatenate([np.arange(h) for h in Hs])
+    trip[:, 2] = np.arange(P)
+    rec = np.zeros((P, 3), dtype=[("s", "u1"), ("v", "<i4")])
     rec["s"] = 4
     rec["v"] = trip
     parts.append(rec.tobytes())
     parts.append(_tok("</Triples>") + _tok("<LogProbs>"))
-    lp = [0.0] + [np.log(self_p), np.log(1.0 - self_p)] * (n_cd * H)
+    lp = [0.0] + [np.log(self_p), np.log(1.0 - self_p)] * P
     parts.append(_fvec(lp) + _tok("</LogProbs>") + _tok("</TransitionModel>"))
-    P = n_cd * H
     D = miv.shape[1]
     parts.append(_tok("<DIMENSION>") + _i32(D) + _tok("<NUMPDFS>") + _i32(P))
     for p in range(P):
