@@ -52,11 +52,13 @@ def test_header_stands_alone(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.access(BIN, os.X_OK), reason="oracle/_ref/vb_ref_decodable not built (make -C oracle ref in the build container)")
-def test_reference_decoder_runs_on_gpu_scores(tmp_path):
+@pytest.mark.parametrize("seconds,P,G,n_words", [(2.5, 600, 2400, 3000), (30.0, 2000, 10000, 20000)])
+def test_reference_decoder_runs_on_gpu_scores(tmp_path, seconds, P, G, n_words):
+    """the second case is BASELINE config 2 at tri1 sizes: P = 2000 pdfs, G = 10 000 Gaussians, one 30 s utterance"""
     from oracle import vbo
     from voicebridge_amd import api, synth
     ctx = api.Context(0)
-    waves = [synth.wave(3, 2.5)]
+    waves = [synth.wave(3, seconds)]
     mf = api.Mfcc(ctx)
     raw, foff = mf.compute(waves)
     post = api.FeaturePipeline(ctx, cmvn=True, mode="delta", spk_xform_shape=(39, 40))
@@ -64,11 +66,10 @@ def test_reference_decoder_runs_on_gpu_scores(tmp_path):
     feats = post.apply(raw, foff, utt2spk=[0], cmvn_stats=stats, spk_xforms=synth.affine(39, seed=1)[None])
     ctx.sync()
     f_host = feats.cpu().numpy()
-    P, G = 600, 2400
     offs, w, means, iv = synth.gmm_model(P, G, 39, seed=5, mean_scale=1.5, dim_scale=f_host.std(0) + 1e-3, var_spread=0.2)
     means = means + f_host.mean(0)
     miv = (means * iv).astype(np.float32)
-    g, t2p = synth.lexicon_graph(3000, P, seed=6)
+    g, t2p = synth.lexicon_graph(n_words, P, seed=6)
     cfg = dict(beam=13.0, max_active=7000, min_active=200, lattice_beam=6.0)
     d = tmp_path
     ai = np.stack([g["arcs"]["ilabel"], g["arcs"]["olabel"], g["arcs"]["nextstate"]], 1).astype(np.int32)
@@ -95,7 +96,17 @@ def test_reference_decoder_runs_on_gpu_scores(tmp_path):
     dec = api.LatticeDecoder(ctx, graph, 1, len(f_host), acoustic_scale=0.083333, **cfg)
     dec.decode(ll, foff, t2p)
     got = dec.result(0)
-    np.testing.assert_array_equal(got["words"], words)
-    np.testing.assert_array_equal(got["ali"], ali)
-    np.testing.assert_array_equal(np.float32([got["best_graph"], got["best_acoustic"]]), bw)
+    assert got["ok"] == 1 and got["num_frames"] == len(f_host)
+    if seconds < 10:
+        np.testing.assert_array_equal(got["words"], words)
+        np.testing.assert_array_equal(got["ali"], ali)
+        np.testing.assert_array_equal(np.float32([got["best_graph"], got["best_acoustic"]]), bw)
+    else:
+        # (3000 frames: the two searches visit the tokens in different orders, tests/test_gpu_e2e512.py: the best path's score may
+        # differ by what one admitted arc more or less is worth)
+        same = np.array_equal(got["words"], words)
+        cost_ref, cost_gpu = float(bw[0] + bw[1]), float(got["best_graph"] + got["best_acoustic"])
+        print("\ntri1 sizes: P %d G %d T %d, graph %d states: the reference decoder on GPU scores and the GPU search: same words %s, path cost %.3f vs %.3f"
+              % (P, G, len(f_host), len(g["final"]), same, cost_ref, cost_gpu))
+        assert abs(cost_ref - cost_gpu) <= 2e-3 * abs(cost_ref)
     dec.close(); graph.close(); gmm.close(); ctx.close()
