@@ -101,6 +101,9 @@ constexpr int STMASK = 0x3FFFFFFF;
 #define VBH_UL 1                // (r02 same-box A/B at 1024 threads: 1 / 2 / 4 links per lane in flight in the pruning sweep: 226-229 / 229 / 236 ms per utterance)
 #endif
 constexpr int U = VBH_U;                    // independent items per lane in the streaming passes
+#ifndef VBH_LINK_PF
+#define VBH_LINK_PF 0           // pruning sweeps: the next round's link records are fetched before this round's are worked on
+#endif
 #ifndef VBH_UC
 #define VBH_UC 4
 #endif
@@ -149,6 +152,10 @@ constexpr int DIRTY_FRAMES = 1 << 13;       // frames covered by the dirty bitma
 #ifndef VBH_SURVIVOR_BITS
 #define VBH_SURVIVOR_BITS 1
 #endif
+#ifndef VBH_DST_BITS
+#define VBH_DST_BITS VBH_SURVIVOR_BITS
+#endif
+constexpr int DSTBITS_WORDS = VBH_DST_BITS ? 256 : 1;      // x 64 tokens of a frame (the links to tokens beyond them gather their destination as before)
 #ifndef VBH_OUTLINE
 #define VBH_OUTLINE 0          // measured (r02, tools/variants.py): 1 and 2 are 15 % slower -- the call sites cost the hot loop more registers than the callees free
 #endif
@@ -474,6 +481,11 @@ struct Shared {
   long long hph[12];               // phase cycles of the frames of the last class alone
 #endif
   unsigned dirty[DIRTY_FRAMES / 32];   // see frame_dirty()
+  // VBH_DST_BITS: the survivor bitmap of the tokens of the frame swept last (what its final sweep wrote to Slot::w_tok_alive), for the sweep
+  // over the frame below it: an emitting link whose destination the bitmap says is dead is excised without gathering the destination's
+  // record -- all but a per cent of a frame's links (dst_frame: whose tokens these are, -1: nobody's; dst_tb: their first window index)
+  unsigned long long dstbits[2][DSTBITS_WORDS];      // [frame & 1]: the sweeps over frame f read f + 1's bits while they write f's
+  int dst_frame, dst_tb, dst_n;
   int use_lds_map;
   int scan_part[NW], scan_base;    // slot scan: occupied slots per wave, first token index it hands out
   alignas(4) unsigned char wx[NW][64 * 4];   // wave_owners: a strip of 64 x UA marker bytes per wave (UA <= 4)
@@ -644,7 +656,7 @@ template <bool LDS_TMP>
 __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, int le_, int split, gp<i32x4> wt, gp<i32x4> ht,
                                                          float lattice_beam, unsigned *lds_tmp, int tb, Shared &sh, const Slot &s,
                                                          gp<unsigned long long> alive_bits = nullptr, bool bits_valid = false,
-                                                         int lds_off = 0, int lds_cap = 128) {
+                                                         int lds_off = 0, int lds_cap = 128, const unsigned long long *dst_bits = nullptr, int dst_tb = 0, int dst_n = 0) {
   // With a survivor bitmap (links of the raw window; VBH_SWEEP_BITS): the bitmap IS the record of which links are excised -- nothing is
   // written into the link records (a scattered 4-byte store per excised link: whole 64-byte half-lines written back for it), and from
   // the second sweep of a visit on (bits_valid) the links the bitmap says are gone are not read again.  The words of the frame being
@@ -652,29 +664,56 @@ __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, i
   const bool use_bits = VBH_SWEEP_BITS && alive_bits != nullptr;
   unsigned long long *lbits = reinterpret_cast<unsigned long long *>(sh.hist) + lds_off;      // (a frame with its links in two ranges: half of the words each)
   unsigned long long kept = 0;
-  for (int base = lb; base < le_; base += NT * UL) {
-    i32x4 L[UL]; bool ok[UL];
+  // the records of one round: is the link there (and, from a visit's second sweep on, alive by the bitmap), its record
+  auto fetch = [&](int base, i32x4 (&Lx)[UL], bool (&okx)[UL]) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < UL; u++) {
       const int l = base + u * NT + (int)threadIdx.x;
-      ok[u] = l < le_;
+      okx[u] = l < le_;
       if (use_bits && bits_valid) {
         const int wfirst = base + u * NT + ((int)threadIdx.x & ~63), wi = (wfirst - lb) >> 6;
         const unsigned long long word = wfirst < le_ ? (wi < lds_cap ? lbits[wi] : alive_bits[wfirst >> 6]) : 0ull;
-        ok[u] = ok[u] && ((word >> ((int)threadIdx.x & 63)) & 1ull);
+        okx[u] = okx[u] && ((word >> ((int)threadIdx.x & 63)) & 1ull);
       }
-      L[u] = lk[ok[u] ? l : lb];
+      Lx[u] = lk[okx[u] ? l : lb];
+    }
+  };
+#if VBH_LINK_PF
+  i32x4 Lp[UL]; bool okp[UL];       // the next round's records: in flight while this round's are worked on
+  if (lb < le_) fetch(lb, Lp, okp);
+#endif
+  for (int base = lb; base < le_; base += NT * UL) {
+    i32x4 L[UL]; bool ok[UL];
+#if VBH_LINK_PF
+#pragma unroll
+    for (int u = 0; u < UL; u++) { L[u] = Lp[u]; ok[u] = okp[u]; }
+    if (base + NT * UL < le_) fetch(base + NT * UL, Lp, okp);
+#else
+    fetch(base, L, ok);
+#endif
+#pragma unroll
+    for (int u = 0; u < UL; u++) {
       ok[u] = ok[u] && L[u].x >= 0;   // negative source: already excised
       if (ok[u]) {
         ok[u] = chk_tok_id(sh, s, 10, L[u].y) && chk_tok_id(sh, s, 12, L[u].x);
         if (LDS_TMP && ok[u]) ok[u] = VBH_CHK(sh, 14, (L[u].x & ~WBIT) - tb, COST_CAP);
       }
     }
+    // (dst_bits: the emitting links' destinations are the window tokens [dst_tb, dst_tb + dst_n) of the frame above, whose survivor bits are
+    // in sh.dstbits: a link to a dead token has link_extra_cost = +inf (:338) and goes without its destination's record being read)
+    if (VBH_DST_BITS && dst_bits) {
+#pragma unroll
+      for (int u = 0; u < UL; u++) {
+        const int l = base + u * NT + (int)threadIdx.x;
+        const unsigned di = (unsigned)((L[u].y ^ WBIT) - dst_tb);
+        if (ok[u] && l >= split && di < (unsigned)dst_n) ok[u] = (dst_bits[di >> 6] >> (di & 63)) & 1ull;
+      }
+    }
     i32x4 D[UL];
 #pragma unroll
     for (int u = 0; u < UL; u++) {
-      gp<const i32x4> dp = ok[u] ? tokp(wt, ht, L[u].y) : ht;
-      D[u] = *dp;
+      if (VBH_DST_BITS) { D[u].x = 0; D[u].y = 0; D[u].z = 0; D[u].w = 0; if (ok[u]) D[u] = *tokp(wt, ht, L[u].y); }
+      else { gp<const i32x4> dp = ok[u] ? tokp(wt, ht, L[u].y) : ht; D[u] = *dp; }
     }
 #pragma unroll
     for (int u = 0; u < UL; u++) {
@@ -753,6 +792,11 @@ VBH_KI __device__ int prune_frame(const Slot &s, int f, float lattice_beam, floa
 #else
   gp<unsigned long long> tbits = nullptr, ebits = nullptr, pbits = nullptr;
 #endif
+  // the survivor bits of the tokens the emitting links point to (frame f + 1, swept just before this one), if they are in LDS (VBH_DST_BITS)
+  const bool d_ok = VBH_DST_BITS && ebits != nullptr && sh.dst_frame == f + 1;
+  const unsigned long long *dbits = d_ok ? sh.dstbits[(f + 1) & 1] : nullptr;
+  const int d_tb = sh.dst_tb, d_n = sh.dst_n;
+  unsigned long long *mybits = sh.dstbits[f & 1];
   for (int iter = 0; iter < MAX_EPS_ITERS; iter++) {
     i32x4 R0[U];            // first round of the token pass, prefetched
     if (lds_tmp) {
@@ -761,16 +805,16 @@ VBH_KI __device__ int prune_frame(const Slot &s, int f, float lattice_beam, floa
     }
     unsigned long long kept;
     if (lds_tmp) {
-      if (one_range) kept = eval_links<true>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0);
+      if (one_range) kept = eval_links<true>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 0, 128, dbits, d_tb, d_n);
       else {
         kept = eval_links<true>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, pbits, iter > 0, 0, 64);
-        kept += eval_links<true>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 64, 64);
+        kept += eval_links<true>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 64, 64, dbits, d_tb, d_n);
       }
     } else {
-      if (one_range) kept = eval_links<false>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0);
+      if (one_range) kept = eval_links<false>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 0, 128, dbits, d_tb, d_n);
       else {
         kept = eval_links<false>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, pbits, iter > 0, 0, 64);
-        kept += eval_links<false>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 64, 64);
+        kept += eval_links<false>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 64, 64, dbits, d_tb, d_n);
       }
     }
     if ((tid & 63) == 0) {
@@ -814,7 +858,8 @@ VBH_KI __device__ int prune_frame(const Slot &s, int f, float lattice_beam, floa
         const unsigned long long am = __ballot(ok[u] && v != INF_BITS);
         alive += __popcll(am);
 #if VBH_SURVIVOR_BITS
-        { const int first = base + u * NT + (tid & ~63); if (tbits && (tid & 63) == 0 && first < te) tbits[first >> 6] = am; }      // (tb is a multiple of 64 in W)
+        { const int first = base + u * NT + (tid & ~63);      // (tb is a multiple of 64 in W)
+          if (tbits && (tid & 63) == 0 && first < te) { tbits[first >> 6] = am; if (VBH_DST_BITS && ((first - tb) >> 6) < DSTBITS_WORDS) mybits[(first - tb) >> 6] = am; } }
 #endif
       }
     }
@@ -835,7 +880,11 @@ VBH_KI __device__ int prune_frame(const Slot &s, int f, float lattice_beam, floa
 #endif
     if (last) break;
   }
-  if (tid == 0) { set_dirty(sh, f, false); if (result & 2) set_dirty(sh, f - 1, true); }
+  if (tid == 0) {
+    set_dirty(sh, f, false); if (result & 2) set_dirty(sh, f - 1, true);
+    // whose survivor bits sh.dstbits[f & 1] now holds (window tokens only: the bitmap is the window's)
+    if (VBH_DST_BITS) { sh.dst_frame = tbits ? f : -1; sh.dst_tb = tb; sh.dst_n = (te - tb) < 64 * DSTBITS_WORDS ? (te - tb) : 64 * DSTBITS_WORDS; }
+  }
   return result;
 }
 
@@ -852,6 +901,7 @@ VBH_KI __device__ VBH_COLD void prune_backward(const Slot &s, int from, int firs
   int visited = 0;
   int above = 3;   // result of the frame above: the frontier counts as changed
   for (int i = threadIdx.x; i < COST_CAP; i += NT) sh.arena[i] = INF_BITS;   // see prune_frame
+  if (VBH_DST_BITS && threadIdx.x == 0) sh.dst_frame = -1;                   // (no frame's survivor bits are in LDS yet)
   __syncthreads();
   for (int f = from; f >= 0 && f >= stop_at; f--) {
     if (final) {
@@ -2926,7 +2976,12 @@ static int decode_batch_begin_impl(vbh_decoder *d, const float *d_loglikes, int3
   d->pend.d_loglikes = d_loglikes; d->pend.num_pdfs = num_pdfs; d->pend.tok_cap = tok_cap; d->pend.link_cap = link_cap;
   {
     // one workgroup per slot the context's CUs can hold (a CU-masked context counts its own CUs), never more than the pool has
-    const int grid = std::min(std::min(d->small_set->n, WG_PER_CU * d->ctx->num_cus), n_utt);
+    int grid = std::min(std::min(d->small_set->n, WG_PER_CU * d->ctx->num_cus), n_utt);
+    // VBH_SEARCH_MAX_WGS (diagnostic): a search grid smaller than the device.  A persistent search workgroup holds its CU until the grid has no
+    // utterance left, so this keeps CUs free for the kernels other job threads issue beside a search (statistics, rescoring, the next job's
+    // scoring).  Measured r04 on DecodeFmllr, 4 jobs of 256 utterances on one GPU: 3.56 s uncapped, 4.00 / 4.27 / 4.24 s at 224 / 192 / 160
+    // workgroups -- a job is one utterance per CU, and the utterances that do not fit the grid double the job's search time.  Not a default.
+    if (const char *e = getenv("VBH_SEARCH_MAX_WGS")) { const int cap_wgs = atoi(e); if (cap_wgs > 0) grid = std::max(1, std::min(grid, cap_wgs)); }
     VBH_HIP(hipMemsetAsync(d->d_res.p, 0xFF, sizeof(UttResult) * (size_t)n_utt, st));     // error = -1: "no workgroup searched it" until one does
     VBH_HIP(hipEventRecord(d->ev0, st));
     VBH_LAUNCH_DECODE(dim3(grid), d->pend.dg, d->pend.dc, d->small_set->d.p, d->small_set->dev(), d_loglikes, (int)num_pdfs,
