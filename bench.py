@@ -1321,6 +1321,44 @@ def main():
                                                  "ms_per_step": 1e3 * raw_dt / args.det_steps,
                                                  "what": "a second timed region without the host lattice stage: the GPU path alone, raw state-level "
                                                          "lattices delivered to the host (what rounds 1-2 reported as `value`)"}
+            # beside the step, on the scores of one batch: the 1-best search (FasterDecoder: gmm-decode-faster, and gmm-align-compiled's search;
+            # K/gmmbin/gmm-decode-faster.cc:131-166) and the lattice search under the other admission rule (vbh_decode_cfg::admission)
+            try:
+                sl0 = slices[0]
+                ll0 = ring[0][2][:n_rows0]
+                fd = api.FasterDecoder(ctx_full, graph, per, Tmax, beam=args.beam, max_active=args.max_active, min_active=20, acoustic_scale=0.083333)
+                best_f = None
+                for _ in range(3):
+                    t0_ = time.perf_counter()
+                    fd.decode(ll0, sl0.foff, t2p)
+                    dtf = time.perf_counter() - t0_
+                    best_f = dtf if best_f is None else min(best_f, dtf)
+                r0_ = fd.result(0)
+                fd.close()
+                extra["faster_rate"] = {"value": n_rows0 / best_f, "unit": "frames/s", "utterances": per, "seconds_per_call": best_f,
+                                        "what": "vbh_faster_decode_batch on one batch's scores (the same utterances, graph, beam and max-active as the lattice "
+                                                "search; min-active 20): kernel + back traces + results on the host, best of 3 calls",
+                                        "words_utt0": len(r0_["words"]), "reached_final_utt0": int(r0_["reached_final"])}
+            except Exception as e:
+                extra["faster_rate"] = {"error": str(e)}
+            try:
+                dx = api.LatticeDecoder(ctx_full, graph, per, Tmax, beam=args.beam, max_active=args.max_active, min_active=200, lattice_beam=args.lattice_beam,
+                                        acoustic_scale=0.083333, share_slots_with=dec, admission="exact")
+                kx = None
+                for _ in range(2):
+                    dx.decode(ring[0][2][:n_rows0], slices[0].foff, t2p)
+                    kx = dx.times()["kernel_ms"] if kx is None else min(kx, dx.times()["kernel_ms"])
+                cx = np.zeros(4)
+                for u in range(per):
+                    r_ = dx.result(u, arrays=False)
+                    cx += [r_["n_tokens_expanded"], r_["n_arcs_expanded"], r_["n_tokens_created"], r_["n_links_created"]]
+                dx.close()
+                extra["search_exact_admission"] = {"kernel_ms": kx, "frames_per_s_search_only": n_rows0 / (kx * 1e-3), "tokens_created_per_frame": cx[2] / n_rows0,
+                                                   "links_per_frame": cx[3] / n_rows0,
+                                                   "what": "the search kernel alone on one batch with admission = exact (tot <= the frame's final next_cutoff, rounds 1-3): "
+                                                           "fewer tokens than the reference's rule admits; the step runs admission = ordered (DESIGN.md 5)"}
+            except Exception as e:
+                extra["search_exact_admission"] = {"error": str(e)}
             try:
                 extra["gmm_on_demand"] = ondemand_gmm_measurement(args, ctx_full, gmm_m, model, ring[0][1][:n_rows0], n_rows0)
             except Exception as e:
