@@ -32,6 +32,10 @@ if os.path.exists(log):
 def short(k):
     k = re.sub(r"\(anonymous namespace\)::", "", k)
     k = re.sub(r"^void ", "", k)
+    # the search kernel has one instantiation per admission rule: <1> = ordered (the product's default) keeps the plain name, <0> = exact
+    m = re.match(r"decode_kernel<(\d)>", k)
+    if m:
+        return "decode_kernel" if m.group(1) == "1" else "decode_kernel<exact admission>"
     return re.split(r"[<(]", k)[0]
 
 

@@ -105,8 +105,8 @@ constexpr int U = VBH_U;                    // independent items per lane in the
 #define VBH_LINK_PF 0           // pruning sweeps: the next round's link records are fetched before this round's are worked on
 #endif
 #ifndef VBH_UC
-#define VBH_UC 4
-#endif
+#define VBH_UC 1                // (r04, same-box A/B of the ordered kernel: 4 / 3 / 2 / 1 candidates per lane in pass 2: 930 / 914 / 898 / 877-880 ms per 1024 x 30 s;
+#endif                          //  exact kernel 858 / - / 855 / 848: what more candidates in flight overlap costs the frame loop more in spilled registers elsewhere)
 #ifndef VBH_UM
 #define VBH_UM 4
 #endif
