@@ -104,6 +104,12 @@ constexpr int U = VBH_U;                    // independent items per lane in the
 #ifndef VBH_LINK_PF
 #define VBH_LINK_PF 0           // pruning sweeps: the next round's link records are fetched before this round's are worked on
 #endif
+#ifndef VBH_X1
+#define VBH_X1 1                // 32-bit per-thread work counters (two registers fewer alive across the frame loop)
+#endif
+#ifndef VBH_X2
+#define VBH_X2 1                // the phase timer's last stamp stays wave-uniform (scalar registers); r04: 882.7 -> 876.7 ms with both
+#endif
 #ifndef VBH_UC
 #define VBH_UC 1                // (r04, same-box A/B of the ordered kernel: 4 / 3 / 2 / 1 candidates per lane in pass 2: 930 / 914 / 898 / 877-880 ms per 1024 x 30 s;
 #endif                          //  exact kernel 858 / - / 855 / 848: what more candidates in flight overlap costs the frame loop more in spilled registers elsewhere)
@@ -155,7 +161,9 @@ constexpr int DIRTY_FRAMES = 1 << 13;       // frames covered by the dirty bitma
 #ifndef VBH_DST_BITS
 #define VBH_DST_BITS VBH_SURVIVOR_BITS
 #endif
-constexpr int DSTBITS_WORDS = VBH_DST_BITS ? 256 : 1;      // x 64 tokens of a frame (the links to tokens beyond them gather their destination as before)
+// x 64 tokens of a frame (the links to tokens beyond them gather their destination as before); half as many in the builds with two
+// workgroups per CU, whose LDS must stay under 80 KB (the stress variant of voicebridge_amd/build.py)
+constexpr int DSTBITS_WORDS = VBH_DST_BITS ? (VBH_DECODE_NT >= 1024 ? 256 : 128) : 1;
 #ifndef VBH_OUTLINE
 #define VBH_OUTLINE 0          // measured (r02, tools/variants.py): 1 and 2 are 15 % slower -- the call sites cost the hot loop more registers than the callees free
 #endif
@@ -1631,7 +1639,11 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
     __syncthreads();
     const int epoch_base = sh.flag + 1;
     __syncthreads();
+#if VBH_X1
+    int c_tok_exp = 0, c_arc_exp = 0;              // per-thread counters, reduced at the end (32 bits: an utterance's totals are tens of millions)
+#else
     long long c_tok_exp = 0, c_arc_exp = 0;        // per-thread counters, reduced at the end
+#endif
     long long t_last = clk();
     const long long rt_start = (long long)__builtin_amdgcn_s_memrealtime();
 #ifdef VBH_DIAG
@@ -1642,7 +1654,11 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
 #define PHASE(i) { if (tid == 0) { const long long now_ = clk(); sh.tph[i] += now_ - t_last; if (f_heavy) sh.hph[i] += now_ - t_last; t_last = now_; } }
 #endif
 #else
+#if VBH_X2
+#define PHASE(i) { const long long now_ = clk(); if (tid == 0) sh.tph[i] += now_ - t_last; t_last = now_; }      // (t_last stays wave-uniform: scalar registers)
+#else
 #define PHASE(i) { if (tid == 0) { const long long now_ = clk(); sh.tph[i] += now_ - t_last; t_last = now_; } }
+#endif
 #endif
 #ifdef VBH_DIAG
 #define PHASE_D(i) PHASE(i)
@@ -2254,8 +2270,8 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
     }
     PHASE(6)
     {
-      const unsigned long long te_ = block_sum_u64((unsigned long long)c_tok_exp, sh, par);
-      const unsigned long long ae_ = block_sum_u64((unsigned long long)c_arc_exp, sh, par);
+      const unsigned long long te_ = block_sum_u64((unsigned long long)(unsigned)c_tok_exp, sh, par);
+      const unsigned long long ae_ = block_sum_u64((unsigned long long)(unsigned)c_arc_exp, sh, par);
       if (tid == 0) {
         UttResult *r = &results[utt];
         r->ok = r_ok; r->error = r_error; r->reached_final = r_reached_final; r->num_frames = frames_done;
