@@ -57,6 +57,11 @@ int vbh_ctx_mark(vbh_ctx *ctx, int slot);
 int vbh_ctx_wait_mark(vbh_ctx *ctx, vbh_ctx *other, int slot);
 void *vbh_ctx_stream(vbh_ctx *ctx);               /* hipStream_t all work is enqueued on */
 int vbh_ctx_device(vbh_ctx *ctx);
+/* Scratch device memory of a context: slot's buffer (slots 0 .. 11), at least `bytes` long, grown when a call asks for more and otherwise
+ * handed out again -- for a host's per-call work buffers.  No counterpart in the reference (its programs allocate on the host heap); on the
+ * device a free waits for every stream of the device, which a host that runs several contexts side by side (the step API's job threads)
+ * cannot afford per call.  The buffer belongs to the context: contents do not survive growth, the memory goes with vbh_ctx_destroy. */
+int vbh_ctx_scratch(vbh_ctx *ctx, int32_t slot, size_t bytes, void **d_ptr);
 int vbh_dev_alloc(vbh_ctx *ctx, size_t bytes, void **d_ptr);
 int vbh_dev_free(vbh_ctx *ctx, void *d_ptr);
 int vbh_copy_h2d(vbh_ctx *ctx, void *d_dst, const void *h_src, size_t bytes); /* async on the stream */

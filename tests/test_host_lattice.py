@@ -105,6 +105,30 @@ def test_chain_matches_golden(host, tmp_path):
     assert "[PARTIAL]" in open(log).read()
 
 
+def test_in_memory_tables_between_programs(host, tmp_path):
+    """"ark:mem:NAME": a table handed from one bin function to the next without a file (what DecodeFmllr does with its 100 MB temporaries,
+    voicebridge_steps.cc): the chain through memory ends in the same bytes as the chain through files; a table that was never
+    written, and one that was dropped, are errors like a missing file"""
+    d = tmp_path
+    o = unpack_golden(d)
+    p = lambda n: str(d / n)
+    log = p("log.txt")
+    acwt, beam = "--acoustic-scale=%s" % o["acwt"], "--beam=%s" % o["beam"]
+    assert call(host.vb_LatticeDeterminizePhonePruned, ["lattice-determinize-phone-pruned", acwt, beam, p("final.mdl"), "ark:" + p("raw.ark"), "ark:mem:" + p("det_pp")], log) == 0
+    assert not os.path.exists(p("det_pp")) and not os.path.exists("mem:" + p("det_pp"))
+    assert call(host.vb_LatticeScale, ["lattice-scale", "--inv-acoustic-scale=%s" % o["lmwt"], "ark:mem:" + p("det_pp"), "ark:mem:" + p("scaled")], log) == 0
+    assert call(host.vb_LatticeAddPenalty, ["lattice-add-penalty", "--word-ins-penalty=%s" % o["wip"], "ark:mem:" + p("scaled"), "ark:" + p("m_pen.ark")], log) == 0
+    assert_same_archives(p("m_pen.ark"), p("pen.ark"))
+    # a raw (state-level) table through memory into the word-level determinization
+    assert call(host.vb_LatticeDeterminizePruned, ["lattice-determinize-pruned", acwt, beam, "ark:" + p("raw.ark"), "ark:mem:" + p("det_p")], log) == 0
+    assert call(host.vb_LatticeScale, ["lattice-scale", "--inv-acoustic-scale=1", "ark:mem:" + p("det_p"), "ark:" + p("m_det_p.ark")], log) == 0
+    assert_same_archives(p("m_det_p.ark"), p("det_p.ark"))
+    assert call(host.vb_LatticeScale, ["lattice-scale", "ark:mem:" + p("never_written"), "ark:" + p("x.ark")], log) == -1
+    host.vbio_mem_unlink(("mem:" + p("scaled")).encode())
+    assert call(host.vb_LatticeAddPenalty, ["lattice-add-penalty", "ark:mem:" + p("scaled"), "ark:" + p("y.ark")], log) == -1
+    assert call(host.vb_LatticeScale, ["lattice-scale", "ark:" + p("raw.ark"), "ark,t:mem:" + p("text")], log) == -1      # no text-mode tables in memory
+
+
 def test_determinized_lattice_properties(host, tmp_path):
     """size-independent properties: the output is deterministic on word labels, its best path has
     the cost of the raw lattice's best path, and every path's alignment has one transition-id per frame"""

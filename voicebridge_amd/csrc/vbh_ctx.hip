@@ -43,6 +43,22 @@ int vbh_arena_commit(vbh_ctx *ctx, vbh_arena *a) {
 }
 
 
+void *vbh_scratch(vbh_ctx *c, int slot, size_t bytes) {
+  if (!c || slot < 0 || slot >= VBH_SCRATCH_SLOTS) { vbh_set_error("vbh_scratch: bad slot %d", slot); return nullptr; }
+  if (c->scratch[slot].cap >= bytes && c->scratch[slot].p) return c->scratch[slot].p;
+  if (hipSetDevice(c->device) != hipSuccess) { vbh_set_error("vbh_scratch: hipSetDevice failed"); return nullptr; }
+  if (c->scratch[slot].p) {
+    (void)hipStreamSynchronize(c->stream);      // (whoever used the old buffer on this stream is done; other streams never see it)
+    (void)hipFree(c->scratch[slot].p);
+    c->scratch[slot].p = nullptr; c->scratch[slot].cap = 0;
+  }
+  const size_t want = bytes + bytes / 4 + 256;      // room to grow: a job's batches differ by a few per cent
+  const hipError_t e = hipMalloc(&c->scratch[slot].p, want);
+  if (e != hipSuccess) { c->scratch[slot].p = nullptr; vbh_set_error("vbh_scratch: hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return nullptr; }
+  c->scratch[slot].cap = want;
+  return c->scratch[slot].p;
+}
+
 extern "C" {
 
 int vbh_abi_version(void) { return VBH_ABI_VERSION; }
@@ -108,6 +124,7 @@ void vbh_ctx_destroy(vbh_ctx *c) {
     if (c->arena[i].d) (void)hipFree(c->arena[i].d);
     if (c->arena[i].done) (void)hipEventDestroy(c->arena[i].done);
   }
+  for (int i = 0; i < VBH_SCRATCH_SLOTS; i++) if (c->scratch[i].p) (void)hipFree(c->scratch[i].p);
   for (int i = 0; i < VBH_MAX_TIMERS; i++) {
     if (c->marks[i]) (void)hipEventDestroy(c->marks[i]);
     (void)hipEventDestroy(c->ev_start[i]);
@@ -153,6 +170,12 @@ int vbh_ctx_wait_mark(vbh_ctx *c, vbh_ctx *other, int slot) {
 }
 void *vbh_ctx_stream(vbh_ctx *c) { return reinterpret_cast<void *>(c->stream); }
 int vbh_ctx_device(vbh_ctx *c) { return c->device; }
+
+int vbh_ctx_scratch(vbh_ctx *c, int32_t slot, size_t bytes, void **d_ptr) {
+  VBH_CHECK(c && d_ptr && slot >= 0 && VBH_SCR_USER + slot < VBH_SCRATCH_SLOTS, "vbh_ctx_scratch: bad argument (slots 0 .. %d)", VBH_SCRATCH_SLOTS - VBH_SCR_USER - 1);
+  *d_ptr = vbh_scratch(c, VBH_SCR_USER + slot, bytes ? bytes : 1);
+  return *d_ptr ? 0 : -1;
+}
 
 int vbh_dev_alloc(vbh_ctx *c, size_t bytes, void **d_ptr) {
   if (vbh_use_device(c)) return -1;

@@ -104,6 +104,9 @@ constexpr int U = VBH_U;                    // independent items per lane in the
 #ifndef VBH_LINK_PF
 #define VBH_LINK_PF 0           // pruning sweeps: the next round's link records are fetched before this round's are worked on
 #endif
+#ifndef VBH_FX
+#define VBH_FX 1                // emitting links per thread in flight when their destinations are filled in
+#endif
 #ifndef VBH_X1
 #define VBH_X1 1                // 32-bit per-thread work counters (two registers fewer alive across the frame loop)
 #endif
@@ -135,7 +138,10 @@ constexpr int UL = VBH_UL;                  // ... in the pruning sweeps over li
 #endif
 constexpr int HBITS = VBH_HBITS;
 constexpr int HCAP = 1 << HBITS;            // slots of the per-frame state map in LDS
-constexpr int HPROBE = 24;                  // probes before a state is sent to the table in HBM
+#ifndef VBH_HPROBE
+#define VBH_HPROBE 24
+#endif
+constexpr int HPROBE = VBH_HPROBE;          // probes before a state is sent to the table in HBM
 constexpr unsigned HEMPTY = 0xFFFFFFFFu;
 constexpr int SPT = 32;                     // slots a thread numbers in the slot scan: one group (threads 0 .. HCAP / 32 - 1 take part)
 constexpr int COST_CAP = 2 * HCAP;          // token costs of the current frame cached in LDS (the map's memory, idle at that time)
@@ -483,6 +489,9 @@ struct Shared {
   // re-compacted in place at the next one, once those frames have been pruned with look-ahead
   int tail_tok_b, tail_link_b, tail_f0, tail_f1;
   long long tph[12];               // phase cycle counters (thread 0)
+#ifdef VBH_DIAG_EPS
+  long long ept[12], ep_last;      // process_nonemitting by part (thread 0's clock): closure, scan + token records, second-level tokens, link fix-up, epsilon links
+#endif
 #ifdef VBH_DIAG
   int diag[8];
   long long fcl[8];                // cycles / frames by class of frame (tokens at its start: < 512, < 2048, < 6144, more)
@@ -1351,9 +1360,17 @@ __device__ __forceinline__ void map_clear(Shared &sh) {
 #ifndef VBH_EARLY_EXCISE
 #define VBH_EARLY_EXCISE 1
 #endif
+#ifdef VBH_DIAG_EPS
+#define EPSTAMP(i) { if (threadIdx.x == 0) { const long long now_ = clk(); sh.ept[i] += now_ - sh.ep_last; sh.ep_last = now_; } }
+#else
+#define EPSTAMP(i)
+#endif
 VBH_KI __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, int nb, float cutoff, unsigned ep,
                                    int cur, Shared &sh, int el_b, int el_e, float lattice_beam) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef VBH_DIAG_EPS
+  if (tid == 0) sh.ep_last = clk();
+#endif
   gp<Ent> ent = uptr(s.ent);
   gp<i32x4> wt = uptr(s.w_tok);
   gp<const i32x4> gst = (gp<const i32x4>)g.st, garcs = (gp<const i32x4>)g.arcs;      // (global, not generic: no FLAT accesses)
@@ -1409,6 +1426,7 @@ VBH_KI __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot
     cur = nxt;
   }
   __syncthreads();
+  EPSTAMP(0)
   // ---- slot scan: thread t numbers the occupied ones of slots [t SPT, (t+1) SPT)
   const int n2 = sh.w_ntok < w_tok_cap ? sh.w_ntok : w_tok_cap;      // second-level tokens: [nb, n2)
   unsigned occ = 0;
@@ -1452,6 +1470,7 @@ VBH_KI __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot
       const int q = wave_alloc(&sh.fcnt[0], want);
       if (want) front_push(sh, uptr(s.front[0]), front_cap, 0, q, slot);
     }
+    EPSTAMP(1)
     // second-level tokens: final cost; the ones to expand go on work list 1 (as token indices)
     for (int t0 = nb + wave * 64; t0 < n2; t0 += NT) {
       const int t = t0 + lane;
@@ -1472,25 +1491,37 @@ VBH_KI __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot
 #endif
   }
   __syncthreads();
+  EPSTAMP(2)
   const int lb = sh.w_nlink;
   if (sh.error != ERR_NONE) return lb;
   __syncthreads();        // (everybody has read w_nlink before the links below move it)
   gp<i32x4> wl = uptr(s.wl);
-  // ---- the emitting links' destinations
-  for (int l = el_b + tid; l < el_e; l += NT) {
-    gp<int> py = (gp<int>)&wl[l] + 1;
+  // ---- the emitting links' destinations (VBH_FX links per thread in flight: the pass is a chain of one load per round otherwise)
+  for (int l0 = el_b + tid; l0 < el_e; l0 += NT * VBH_FX) {
+    i32x2 yz[VBH_FX];
+#pragma unroll
+    for (int u = 0; u < VBH_FX; u++) { const int l = l0 + u * NT; yz[u] = *(gp<i32x2>)((gp<int>)&wl[l < el_e ? l : el_b] + 1); }
+#pragma unroll
+    for (int u = 0; u < VBH_FX; u++) {
+      const int l = l0 + u * NT;
+      if (l >= el_e) continue;
+      gp<int> py = (gp<int>)&wl[l] + 1;
+      const int y = yz[u].x;
 #if VBH_EARLY_EXCISE
-    const i32x2 yz = *(gp<i32x2>)py;
-    const int y = yz.x;
-    const float dcost = y >= 0 ? o2f(map_key(sh)[y]) : o2f((unsigned)ld_u64(&ent[-1 - y].key));
-    if (asf(yz.y) - dcost > lattice_beam) { py[-1] = -1; continue; }
-#else
-    const int y = *py;
+      const float dcost = y >= 0 ? o2f(map_key(sh)[y]) : o2f((unsigned)ld_u64(&ent[-1 - y].key));
+      if (asf(yz[u].y) - dcost > lattice_beam) {
+#ifdef VBH_DIAG_EPS
+        atomicAdd((unsigned long long *)&sh.ept[6], 1ull);
 #endif
-    const int d = y >= 0 ? map_tok(sh, ent, y, 0, nb) : ld_i32(&ent[-1 - y].tokid);
-    (void)VBH_CHK(sh, 30, d - nb, ne_all - nb);
-    *py = d | WBIT;
+        py[-1] = -1; continue;
+      }
+#endif
+      const int d = y >= 0 ? map_tok(sh, ent, y, 0, nb) : ld_i32(&ent[-1 - y].tokid);
+      (void)VBH_CHK(sh, 30, d - nb, ne_all - nb);
+      *py = d | WBIT;
+    }
   }
+  EPSTAMP(3)
   // ---- epsilon links regenerated from the final costs; what they point to is tagged
   {
     const int w_link_cap = s.w_link_cap;
@@ -1542,7 +1573,9 @@ VBH_KI __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot
       }
     }
   }
+  EPSTAMP(4)
   __syncthreads();
+  EPSTAMP(5)
   return lb;
 }
 
@@ -1680,6 +1713,9 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       sh.tail_tok_b = 0; sh.tail_link_b = 0; sh.tail_f0 = -1; sh.tail_f1 = -2;
       sh.chk[0] = 0; sh.chk[1] = 0; sh.chk[2] = 0; sh.chk[3] = 0;
     }
+#ifdef VBH_DIAG_EPS
+    if (tid < 12) sh.ept[tid] = 0;
+#endif
     for (int i = tid; i < DIRTY_FRAMES / 32; i += NT) sh.dirty[i] = ~0u;   // no frame has been evaluated yet
     if (ADM == VBH_ADMIT_ORDERED && tid < 64) sh.bmin[tid] = 0xFFFFFFFFu;
     map_clear(sh);
@@ -2269,6 +2305,11 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       } else r_error = ERR_POOL;
     }
     PHASE(6)
+#ifdef VBH_DIAG_EPS
+    if (tid == 0 && utt < 2)
+      printf("utt %d: process_nonemitting cycles/frame: closure %lld, scan + token records %lld, second-level tokens %lld, link fix-up %lld, epsilon links %lld, last barrier %lld; emitting links excised at the fix-up %lld per frame\n",
+             utt, sh.ept[0] / (T + 1), sh.ept[1] / (T + 1), sh.ept[2] / (T + 1), sh.ept[3] / (T + 1), sh.ept[4] / (T + 1), sh.ept[5] / (T + 1), sh.ept[6] / (T + 1));
+#endif
     {
       const unsigned long long te_ = block_sum_u64((unsigned long long)(unsigned)c_tok_exp, sh, par);
       const unsigned long long ae_ = block_sum_u64((unsigned long long)(unsigned)c_arc_exp, sh, par);

@@ -341,7 +341,7 @@ int vbh_cmvn_stats(vbh_ctx *ctx, const float *d_feats, int32_t dim, const int64_
   std::vector<int> u2s(h_utt2spk, h_utt2spk + n_utt);
   for (int u = 0; u < n_utt; u++) VBH_CHECK(u2s[u] >= 0 && u2s[u] < n_spk, "vbh_cmvn_stats: utt2spk[%d] out of range", u);
   hipStream_t s = ctx->stream;
-  DevBuf<long long> d_foff; DevBuf<int> d_u2s; DevBuf<double> d_stats;
+  ScratchBuf<long long> d_foff(ctx, VBH_SCR_CMVN + 0); ScratchBuf<int> d_u2s(ctx, VBH_SCR_CMVN + 1); ScratchBuf<double> d_stats(ctx, VBH_SCR_CMVN + 2);
   if (d_foff.upload(foff.data(), foff.size(), s) || d_u2s.upload(u2s.data(), u2s.size(), s) || d_stats.alloc(n)) return -1;
   VBH_HIP(hipMemsetAsync(d_stats.p, 0, n * sizeof(double), s));
   hipLaunchKernelGGL(cmvn_stats_kernel, dim3(n_utt), dim3(256), 0, s, d_feats, dim, d_foff.p, d_u2s.p, d_stats.p);

@@ -294,8 +294,11 @@ static int fmllr_run(vbh_ctx *ctx, const vbh_gmm_view &vm, const float *d_feats,
   }
   VBH_CHECK(!slices.empty(), "vbh_fmllr_accumulate: no frames assigned to a speaker");
   hipStream_t st = ctx->stream;
-  DevBuf<long long> d_poff; DevBuf<int> d_ppdf; DevBuf<float> d_a, d_b, d_cnt; DevBuf<Seg> d_segs; DevBuf<Slice> d_slices; DevBuf<ColTile> d_tiles;
-  DevBuf<double> d_beta, d_K, d_G;
+  // (work buffers from the context's scratch slots: no allocation or free per call, vbh_internal.h)
+  ScratchBuf<long long> d_poff(ctx, VBH_SCR_FMLLR + 0); ScratchBuf<int> d_ppdf(ctx, VBH_SCR_FMLLR + 1);
+  ScratchBuf<float> d_a(ctx, VBH_SCR_FMLLR + 2), d_b(ctx, VBH_SCR_FMLLR + 3), d_cnt(ctx, VBH_SCR_FMLLR + 4);
+  ScratchBuf<Seg> d_segs(ctx, VBH_SCR_FMLLR + 5); ScratchBuf<Slice> d_slices(ctx, VBH_SCR_FMLLR + 6); ScratchBuf<ColTile> d_tiles(ctx, VBH_SCR_FMLLR + 7);
+  ScratchBuf<double> d_beta(ctx, VBH_SCR_FMLLR + 8), d_K(ctx, VBH_SCR_FMLLR + 9), d_G(ctx, VBH_SCR_FMLLR + 10);
   static_assert(sizeof(long long) == sizeof(int64_t), "int64");
   if (d_poff.upload(reinterpret_cast<const long long *>(h_pair_offsets), (size_t)T + 1, st) || d_ppdf.upload(h_pair_pdf, (size_t)std::max<long long>(n_pairs, 1), st) ||
       d_a.alloc((size_t)T * D) || d_b.alloc((size_t)T * D) || d_cnt.alloc((size_t)T) ||
@@ -342,7 +345,7 @@ int vbh_fmllr_accumulate(vbh_ctx *ctx, const vbh_gmm *ali_gmm, const vbh_gmm *ad
   vbh_gmm_view_get(adapt_gmm, &vm);
   VBH_CHECK(va.D == vm.D && va.P == vm.P && va.G == vm.G, "vbh_fmllr_accumulate: the two models differ in shape");
   const int D = vm.D;
-  DevBuf<float> d_pw;
+  ScratchBuf<float> d_pw(ctx, VBH_SCR_FMLLR + 11);
   return fmllr_run(ctx, vm, d_feats, n_utt, h_frame_offsets, h_utt2spk, n_spk, h_pair_offsets, h_pair_pdf, h_beta, h_K, h_G, kernel_ms,
                    [&](hipStream_t st, unsigned fblocks, long long T, long long n_pairs, const long long *d_poff, const int *d_ppdf, float *d_a, float *d_b, float *d_cnt) -> int {
                      if (d_pw.upload(h_pair_weight, (size_t)std::max<long long>(n_pairs, 1), st)) return -1;
@@ -369,7 +372,7 @@ int vbh_fmllr_accumulate_gpost(vbh_ctx *ctx, const vbh_gmm *adapt_gmm, const flo
       VBH_CHECK(h_gpost_offsets[q + 1] - h_gpost_offsets[q] == h_pdf_num_gauss[h_pair_pdf[q]], "vbh_fmllr_accumulate_gpost: posterior vector does not match the pdf");
     }
   }
-  DevBuf<long long> d_goff; DevBuf<float> d_gp;
+  ScratchBuf<long long> d_goff(ctx, VBH_SCR_FMLLR + 12); ScratchBuf<float> d_gp(ctx, VBH_SCR_FMLLR + 13);
   return fmllr_run(ctx, vm, d_feats, n_utt, h_frame_offsets, h_utt2spk, n_spk, h_pair_offsets, h_pair_pdf, h_beta, h_K, h_G, kernel_ms,
                    [&](hipStream_t st, unsigned fblocks, long long T, long long n_pairs, const long long *d_poff, const int *d_ppdf, float *d_a, float *d_b, float *d_cnt) -> int {
                      const long long n_g = h_gpost_offsets[n_pairs];

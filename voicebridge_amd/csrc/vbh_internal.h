@@ -29,6 +29,13 @@ struct vbh_arena {
   bool pending = false;
 };
 
+// Scratch device memory of a context: per-call work buffers (statistics, posteriors, front-end output) come from a small table of
+// grow-only allocations instead of a hipMalloc / hipFree pair per call.  hipFree waits for the WHOLE device, i.e. for the persistent search
+// grids of every other context: with four job threads sharing a GPU a call that frees a dozen temporaries spent most of its time waiting
+// for other jobs' searches (r04: gmm-est-fmllr 134 ms alone, 400-650 ms beside searches).  A slot is reused by the next call
+// that asks for it (same stream: ordered); all of it is released with the context.
+#define VBH_SCRATCH_SLOTS 32
+enum { VBH_SCR_FMLLR = 0, VBH_SCR_CMVN = 16, VBH_SCR_USER = 20 };      // first slot of each user (vbh_ctx_scratch serves VBH_SCR_USER ...)
 struct vbh_ctx {
   int device;
   hipStream_t stream;
@@ -37,7 +44,10 @@ struct vbh_ctx {
   vbh_arena arena[VBH_ARENAS];
   int arena_next = 0;
   hipEvent_t marks[VBH_MAX_TIMERS] = {};      // vbh_ctx_mark / vbh_ctx_wait_mark
+  struct { void *p; size_t cap; } scratch[VBH_SCRATCH_SLOTS] = {};
 };
+// slot's buffer, at least `bytes` long (nullptr + error on failure); contents are not preserved when it grows
+void *vbh_scratch(vbh_ctx *ctx, int slot, size_t bytes);
 
 vbh_arena *vbh_arena_begin(vbh_ctx *ctx, size_t bytes);          // NULL on error
 int vbh_arena_commit(vbh_ctx *ctx, vbh_arena *a);                 // enqueue the copy on ctx->stream
@@ -100,6 +110,25 @@ struct DevBuf {
     n = 0;
   }
   ~DevBuf() { free(); }
+};
+
+// the same interface over a scratch slot of the context (nothing is freed when it goes out of scope)
+template <class T>
+struct ScratchBuf {
+  vbh_ctx *ctx; int slot;
+  T *p = nullptr;
+  size_t n = 0;
+  ScratchBuf(vbh_ctx *c, int s) : ctx(c), slot(s) {}
+  int alloc(size_t count) {
+    n = count;
+    p = static_cast<T *>(vbh_scratch(ctx, slot, (count ? count : 1) * sizeof(T)));
+    return p ? 0 : -1;
+  }
+  int upload(const T *h, size_t count, hipStream_t s) {
+    if (alloc(count)) return -1;
+    if (count) VBH_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
+    return 0;
+  }
 };
 
 // what another translation unit needs of a vbh_graph (defined in vbh_decode.hip): the device

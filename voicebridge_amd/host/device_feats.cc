@@ -124,12 +124,16 @@ const float *DeviceFeatures(const FrontEnd &fe, const RawTable &t, size_t u0, si
   offs.push_back(t.offs[u1] - t.offs[u0]);
   const int od = vbh_featpost_out_dim(&cfg);
   const int64_t T = t.offs[u1] - t.offs[u0];
-  hold->reset(new DevBuffer(ctx, sizeof(float) * (size_t)T * od));
+  // the output lives in scratch slot 0 of the thread's context: the programs of a job run one after the other on that context (stream
+  // order), and a buffer allocated and freed per call would make every call wait for the other jobs' searches (hipFree waits for the device)
+  (void)hold;
+  void *d_out = nullptr;
+  Check(vbh_ctx_scratch(ctx, 0, sizeof(float) * (size_t)std::max<int64_t>(T, 1) * od, &d_out), "vbh_ctx_scratch");
   if (T > 0)
     Check(vbh_featpost(ctx, &cfg, d_in, offs.data(), (int32_t)(u1 - u0), u2s.data(), (int)idx.size(), stats.data(),
-                       fe.lda.data.empty() ? nullptr : fe.lda.data.data(), xf.empty() ? nullptr : xf.data(), (float *)(*hold)->p), "vbh_featpost");
+                       fe.lda.data.empty() ? nullptr : fe.lda.data.data(), xf.empty() ? nullptr : xf.data(), (float *)d_out), "vbh_featpost");
   *dim = od;
-  return static_cast<const float *>((*hold)->p);
+  return static_cast<const float *>(d_out);
 }
 
 }  // namespace vbapi

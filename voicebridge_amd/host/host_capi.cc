@@ -83,4 +83,6 @@ int vb_fmllr_update(int dim, double beta, const double *K, const double *G, cons
   });
 }
 
+// drops an in-memory table ("mem:NAME", kaldi_io.h) as unlink() drops a file
+void vbio_mem_unlink(const char *path) { vbio::MemUnlink(path); }
 }  // extern "C"

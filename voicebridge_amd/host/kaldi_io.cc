@@ -10,6 +10,8 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <sstream>
 #include <thread>
 
@@ -1006,12 +1008,32 @@ void ReadFstStream(std::istream &is, Graph *g, const std::string &path) {
   } else Fail("fst: type " + fsttype + " not supported (need const or vector)");
 }
 
+namespace {
+std::mutex g_mem_mu;
+std::map<std::string, std::shared_ptr<MemTable>> g_mem_tables;
+}  // namespace
+bool IsMemPath(const std::string &path) { return path.compare(0, 4, "mem:") == 0; }
+void MemPublish(const std::string &path, std::shared_ptr<MemTable> t) { std::lock_guard<std::mutex> lk(g_mem_mu); g_mem_tables[path] = std::move(t); }
+std::shared_ptr<MemTable> MemLookup(const std::string &path) {
+  std::lock_guard<std::mutex> lk(g_mem_mu);
+  auto it = g_mem_tables.find(path);
+  return it == g_mem_tables.end() ? nullptr : it->second;
+}
+void MemUnlink(const std::string &path) { std::lock_guard<std::mutex> lk(g_mem_mu); g_mem_tables.erase(path); }
+
 void LatticeWriter::Open(const std::string &wspecifier) {
   spec_ = ParseWspecifier(wspecifier);
+  if (IsMemPath(spec_.ark_path)) {
+    if (spec_.text || spec_.has_scp) Fail("an in-memory table is binary and has no script file: " + wspecifier);
+    mem_ = std::make_shared<MemTable>();
+    open_ = true;
+    return;
+  }
   ark_.open(spec_.ark_path, std::ios::binary);
   if (!ark_) Fail("cannot open " + spec_.ark_path + " for writing");
   open_ = true;
 }
+LatticeWriter::~LatticeWriter() { if (mem_) MemPublish(spec_.ark_path, std::move(mem_)); }
 
 // Lattices are serialised into one buffer per entry and parsed from a mapping of the whole archive: an entry has millions of
 // 4-byte fields, and a stream call per field costs more than everything else the lattice programs do.
@@ -1133,7 +1155,12 @@ std::string LatticeObjectToText(const std::string &object) {
   return t;
 }
 
+void LatticeWriter::WriteSerialized(const std::string &key, std::string &&object) {
+  if (mem_) { mem_->emplace_back(key, std::move(object)); return; }
+  WriteSerialized(key, static_cast<const std::string &>(object));
+}
 void LatticeWriter::WriteSerialized(const std::string &key, const std::string &object) {
+  if (mem_) { mem_->emplace_back(key, object); return; }
   ark_ << key << ' ';
   if (spec_.text) { const std::string t = LatticeObjectToText(object); ark_.write(t.data(), (std::streamsize)t.size()); }
   else ark_.write(object.data(), (std::streamsize)object.size());
@@ -1148,11 +1175,23 @@ void LatticeWriter::Write(const std::string &key, const vblat::Lattice &lat) {
 
 void CompactLatticeWriter::Open(const std::string &wspecifier) {
   spec_ = ParseWspecifier(wspecifier);
+  if (IsMemPath(spec_.ark_path)) {
+    if (spec_.text || spec_.has_scp) Fail("an in-memory table is binary and has no script file: " + wspecifier);
+    mem_ = std::make_shared<MemTable>();
+    open_ = true;
+    return;
+  }
   ark_.open(spec_.ark_path, std::ios::binary);
   if (!ark_) Fail("cannot open " + spec_.ark_path + " for writing");
   open_ = true;
 }
+CompactLatticeWriter::~CompactLatticeWriter() { if (mem_) MemPublish(spec_.ark_path, std::move(mem_)); }
+void CompactLatticeWriter::WriteSerialized(const std::string &key, std::string &&object) {
+  if (mem_) { mem_->emplace_back(key, std::move(object)); return; }
+  WriteSerialized(key, static_cast<const std::string &>(object));
+}
 void CompactLatticeWriter::WriteSerialized(const std::string &key, const std::string &object) {
+  if (mem_) { mem_->emplace_back(key, object); return; }
   ark_ << key << ' ';
   if (spec_.text) { const std::string t = LatticeObjectToText(object); ark_.write(t.data(), (std::streamsize)t.size()); }
   else ark_.write(object.data(), (std::streamsize)object.size());
@@ -1416,6 +1455,11 @@ void ParseLatticeBytes(const char *p, size_t n, vblat::Lattice *lat) {
 
 LatticeReader::LatticeReader(const std::string &rspecifier) : spec_(ParseRspecifier(rspecifier)) {
   if (spec_.is_scp) { scp_ = ReadScp(spec_.path); return; }
+  if (IsMemPath(spec_.path)) {
+    mem_ = MemLookup(spec_.path);
+    if (!mem_) Fail("no in-memory table " + spec_.path);
+    return;
+  }
   const int fd = ::open(spec_.path.c_str(), O_RDONLY);
   if (fd < 0) Fail("cannot open archive " + spec_.path);
   struct stat sb;
@@ -1442,6 +1486,14 @@ bool LatticeReader::Next(std::string *key, vblat::Lattice *lat, vblat::CompactLa
     *key = e.key;
     return true;
   }
+  if (mem_) {
+    if (pos_ >= mem_->size()) return false;
+    const std::pair<std::string, std::string> &e = (*mem_)[pos_++];
+    *key = e.first;
+    MemIn in{e.second.data(), e.second.data() + e.second.size()};
+    ReadLatticeBody(in, lat, clat, is_compact);
+    return true;
+  }
   const char *p = map_ + pos_, *end = map_ + map_len_;
   while (p < end && isspace((unsigned char)*p)) p++;
   if (p == end) { pos_ = map_len_; return false; }
@@ -1462,6 +1514,12 @@ bool LatticeReader::NextBytes(std::string *key, const char **bytes, size_t *n) {
     held_.emplace_back();
     if (compact) SerializeLattice(clat, &held_.back()); else SerializeLattice(lat, &held_.back());
     *bytes = held_.back().data(); *n = held_.back().size();
+    return true;
+  }
+  if (mem_) {
+    if (pos_ >= mem_->size()) return false;
+    const std::pair<std::string, std::string> &e = (*mem_)[pos_++];
+    *key = e.first; *bytes = e.second.data(); *n = e.second.size();
     return true;
   }
   const char *p = map_ + pos_, *end = map_ + map_len_;

@@ -20,6 +20,7 @@
 #include <map>
 #include <ostream>
 #include <stdexcept>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -185,6 +186,17 @@ class FloatVectorWriter {
   Wspec spec_; bool open_ = false; std::ofstream ark_;
 };
 
+// In-memory lattice tables.  An archive path that starts with "mem:" ("ark:mem:NAME") names a table that never touches a file: the
+// writers keep every entry's bytes (moved in where the caller gives them up), publish the table under its name when they are destroyed,
+// and LatticeReader walks the entries in place.  For the temporary tables a step hands from one program to the next inside one process
+// -- DecodeFmllr's raw lattices are 100 MB per job, written once and read twice (VB/scr/steps/decode_fmllr.cpp:390-640 writes lat.tmp.JOB
+// and rescored lattices as files); MemUnlink drops a table as unlink() drops a file.
+typedef std::vector<std::pair<std::string, std::string>> MemTable;      // (key, serialised object)
+bool IsMemPath(const std::string &path);
+void MemPublish(const std::string &path, std::shared_ptr<MemTable> t);
+std::shared_ptr<MemTable> MemLookup(const std::string &path);           // nullptr: no such table
+void MemUnlink(const std::string &path);
+
 // raw lattice: one state per token, as GetRawLattice builds it
 struct LatticeArcOut { int32_t ilabel, olabel; float graph, acoustic; int32_t nextstate; };
 struct LatticeOut {
@@ -194,16 +206,19 @@ struct LatticeOut {
 class LatticeWriter {   // LatticeWriter ("Lattice" holder), binary archives
  public:
   LatticeWriter() {}
+  ~LatticeWriter();
   void Open(const std::string &wspecifier);
   bool IsOpen() const { return open_; }
   void Write(const std::string &key, const LatticeOut &lat);
   void Write(const std::string &key, const vblat::Lattice &lat);
   void WriteSerialized(const std::string &key, const std::string &object);   // object: what SerializeLattice made
+  void WriteSerialized(const std::string &key, std::string &&object);        // ... given up by the caller (an in-memory table takes it without a copy)
  private:
   Wspec spec_;
   bool open_ = false;
   std::ofstream ark_;
   std::string buf_;
+  std::shared_ptr<MemTable> mem_;
 };
 // the bytes of one archive entry (after the key); callers serialise on their own threads and hand the result to WriteSerialized
 void SerializeLattice(const LatticeOut &lat, std::string *b);
@@ -217,15 +232,18 @@ void SerializeLattice(const vblat::CompactLattice &clat, std::string *b);
 class CompactLatticeWriter {
  public:
   CompactLatticeWriter() {}
+  ~CompactLatticeWriter();
   void Open(const std::string &wspecifier);
   bool IsOpen() const { return open_; }
   void Write(const std::string &key, const vblat::CompactLattice &clat);
   void WriteSerialized(const std::string &key, const std::string &object);
+  void WriteSerialized(const std::string &key, std::string &&object);
  private:
   Wspec spec_;
   bool open_ = false;
   std::ofstream ark_;
   std::string buf_;
+  std::shared_ptr<MemTable> mem_;
 };
 
 // sequential reader over binary lattice archives ("ark:" or "scp:"); an entry is either a
@@ -250,6 +268,7 @@ class LatticeReader {
   std::vector<ScpEntry> scp_;
   size_t pos_ = 0;                 // scp: next line; ark: offset into the mapping
   std::deque<std::string> held_;   // scp: the entries NextBytes handed out
+  std::shared_ptr<MemTable> mem_;  // "ark:mem:NAME": the table, walked entry by entry (pos_ = next entry)
 };
 void ParseLatticeBytes(const char *p, size_t n, vblat::Lattice *lat, vblat::CompactLattice *clat, bool *is_compact);
 void ParseLatticeBytes(const char *p, size_t n, vblat::Lattice *lat);     // a compact entry is converted (LatticeHolder::Read)

@@ -35,11 +35,11 @@ void Check(int rc, const char *what) {
   if (rc != 0) throw ApiError(std::string(what) + ": " + vbh_last_error());
 }
 
-struct DevMem {
+struct DevMem {   // a per-call work buffer: scratch slot `slot` of the context (vbh_ctx_scratch: nothing is allocated or freed per call once it has its size)
   vbh_ctx *ctx; void *p = nullptr;
-  DevMem(vbh_ctx *c, size_t bytes) : ctx(c) { Check(vbh_dev_alloc(c, bytes, &p), "vbh_dev_alloc"); }
-  ~DevMem() { if (p) vbh_dev_free(ctx, p); }
+  DevMem(vbh_ctx *c, size_t bytes, int slot) : ctx(c) { Check(vbh_ctx_scratch(c, slot, bytes, &p), "vbh_ctx_scratch"); }
   DevMem(const DevMem &) = delete;
+  DevMem &operator=(const DevMem &) = delete;
 };
 
 struct AlignUtt {
@@ -79,7 +79,7 @@ void AlignBatch(vbh_ctx *ctx, vbh_gmm *gmm, const vbio::Model &model, const std:
   }
   const int64_t T = foff.back();
   const int32_t ld = vbh_gmm_padded_pdfs(gmm);       // score rows on 128-byte lines; the search takes ld as its row length
-  DevMem d_in(ctx, sizeof(float) * data.size()), d_ll(ctx, sizeof(float) * (size_t)T * ld);
+  DevMem d_in(ctx, sizeof(float) * data.size(), 1), d_ll(ctx, sizeof(float) * (size_t)T * ld, 5);
   Check(vbh_copy_h2d(ctx, d_in.p, data.data(), sizeof(float) * data.size()), "vbh_copy_h2d");
   Check(vbh_gmm_loglikes_ld(gmm, (const float *)d_in.p, T, (float *)d_ll.p, ld), "vbh_gmm_loglikes");
   vbh_graph *g = nullptr;

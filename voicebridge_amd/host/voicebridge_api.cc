@@ -50,11 +50,11 @@ vbh_ctx *Ctx() {
   return g_ctx;
 }
 
-struct DevMem {   // RAII device buffer through the ABI
+struct DevMem {   // a per-call work buffer: scratch slot `slot` of the context (vbh_ctx_scratch: nothing is allocated or freed per call once it has its size)
   vbh_ctx *ctx; void *p = nullptr;
-  DevMem(vbh_ctx *c, size_t bytes) : ctx(c) { Check(vbh_dev_alloc(c, bytes, &p), "vbh_dev_alloc"); }
-  ~DevMem() { if (p) vbh_dev_free(ctx, p); }
+  DevMem(vbh_ctx *c, size_t bytes, int slot) : ctx(c) { Check(vbh_ctx_scratch(c, slot, bytes, &p), "vbh_ctx_scratch"); }
   DevMem(const DevMem &) = delete;
+  DevMem &operator=(const DevMem &) = delete;
 };
 
 struct Batch {   // utterances of a feature table packed row-wise
@@ -114,7 +114,7 @@ void RunFeatpost(const vbh_featpost_cfg &cfg, const Batch &b, const std::vector<
   vbh_ctx *ctx = Ctx();
   *out_dim = vbh_featpost_out_dim(&cfg);
   const int64_t T = b.frames();
-  DevMem d_in(ctx, sizeof(float) * b.data.size()), d_out(ctx, sizeof(float) * (size_t)T * *out_dim);
+  DevMem d_in(ctx, sizeof(float) * b.data.size(), 1), d_out(ctx, sizeof(float) * (size_t)T * *out_dim, 2);
   Check(vbh_copy_h2d(ctx, d_in.p, b.data.data(), sizeof(float) * b.data.size()), "vbh_copy_h2d");
   Check(vbh_featpost(ctx, &cfg, (const float *)d_in.p, b.offs.data(), (int32_t)b.keys.size(),
                      utt2spk.empty() ? nullptr : utt2spk.data(), n_spk, stats, lda, spk, (float *)d_out.p), "vbh_featpost");
@@ -445,7 +445,7 @@ int ComputeMFCCFeats(int argc, char *argv[], std::ofstream &file_log) {
       if (keys.empty()) continue;
       int64_t total = 0;
       for (size_t u = 0; u < keys.size(); u++) total += vbh_mfcc_num_frames(&o, woff[u + 1] - woff[u]);
-      DevMem d_wave(ctx, sizeof(float) * samples.size()), d_feats(ctx, sizeof(float) * (size_t)total * o.num_ceps);
+      DevMem d_wave(ctx, sizeof(float) * samples.size(), 3), d_feats(ctx, sizeof(float) * (size_t)total * o.num_ceps, 4);
       Check(vbh_copy_h2d(ctx, d_wave.p, samples.data(), sizeof(float) * samples.size()), "vbh_copy_h2d");
       std::vector<int64_t> foff(keys.size() + 1, 0);
       for (size_t g0 = 0; g0 < keys.size();) {        // runs of utterances with one warp factor
@@ -556,7 +556,7 @@ int ComputeCmvnStats(int argc, char *argv[], std::ofstream &file_log) {
     if (b.keys.empty()) { log.os() << "LOG (compute-cmvn-stats) no features\n"; return 1; }
     vbh_ctx *ctx = Ctx();
     const int n_spk = (int)spk_index.size(), D = b.dim;
-    DevMem d_in(ctx, sizeof(float) * b.data.size());
+    DevMem d_in(ctx, sizeof(float) * b.data.size(), 1);
     Check(vbh_copy_h2d(ctx, d_in.p, b.data.data(), sizeof(float) * b.data.size()), "vbh_copy_h2d");
     std::vector<double> stats((size_t)n_spk * 2 * (D + 1));
     Check(vbh_cmvn_stats(ctx, (const float *)d_in.p, D, b.offs.data(), (int32_t)b.keys.size(), u2s.data(), n_spk, stats.data()), "vbh_cmvn_stats");
@@ -961,7 +961,7 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
         if (want_lat) {
           if (!det_err[u].empty()) throw ApiError("lattice of " + utt + ": " + det_err[u]);
           if (!det_ok[u]) log.os() << "WARNING (gmm-latgen-faster) Determinization finished earlier than the beam for utterance " << utt << "\n";
-          if (determinize) jo.clat.WriteSerialized(utt, entry[u]); else jo.lat.WriteSerialized(utt, entry[u]);
+          if (determinize) jo.clat.WriteSerialized(utt, std::move(entry[u])); else jo.lat.WriteSerialized(utt, std::move(entry[u]));
           std::string().swap(entry[u]);
         }
         log.os() << "LOG (gmm-latgen-faster) Log-like per frame for utterance " << utt << " is " << (like / (L.num_ali ? L.num_ali : 1))
@@ -970,8 +970,9 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
         frame_count += L.num_frames;
         num_done++;
       }
+      lap("write results");
     }
-    lap("write results");
+    lap("end of the table");
     log.os() << "LOG (gmm-latgen-faster) Done " << num_done << " utterances, failed for " << num_err << "\n";
     log.os() << "LOG (gmm-latgen-faster) Overall log-likelihood per frame is " << (frame_count ? tot_like / frame_count : 0.0)
              << " over " << frame_count << " frames.\n";
@@ -1137,7 +1138,7 @@ int GmmDecodeFaster(int argc, char *argv[], std::ofstream &file_log) {
       lap("read features of a batch");
       const int64_t T = b.frames();
       const int32_t ld = vbh_gmm_padded_pdfs(gmm);
-      DevMem d_in(ctx, sizeof(float) * b.data.size()), d_ll(ctx, sizeof(float) * (size_t)T * ld);
+      DevMem d_in(ctx, sizeof(float) * b.data.size(), 1), d_ll(ctx, sizeof(float) * (size_t)T * ld, 5);
       Check(vbh_copy_h2d(ctx, d_in.p, b.data.data(), sizeof(float) * b.data.size()), "vbh_copy_h2d");
       std::unique_ptr<DevMem> d_fe;
       const float *d_feats_p = (const float *)d_in.p;
@@ -1171,7 +1172,7 @@ int GmmDecodeFaster(int argc, char *argv[], std::ofstream &file_log) {
         if (!fe_trans.empty() && !idx.empty()) { cfg.spk_rows = fe_trans.begin()->second.rows; cfg.spk_cols = fe_trans.begin()->second.cols; }
         const int od = vbh_featpost_out_dim(&cfg);
         if (od != model.dim) throw ApiError("Dim mismatch: front end gives dim " + std::to_string(od) + " vs. model dim = " + std::to_string(model.dim));
-        d_fe.reset(new DevMem(ctx, sizeof(float) * (size_t)T * od));
+        d_fe.reset(new DevMem(ctx, sizeof(float) * (size_t)T * od, 6));
         Check(vbh_featpost(ctx, &cfg, (const float *)d_in.p, b.offs.data(), (int32_t)b.keys.size(), u2s.data(), (int)idx.size(), stats.data(),
                            fe_lda.data.empty() ? nullptr : fe_lda.data.data(), xf.empty() ? nullptr : xf.data(), (float *)d_fe->p), "vbh_featpost");
         d_feats_p = (const float *)d_fe->p;

@@ -572,7 +572,7 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
     for (Item &it : items) {
       if (!it.err.empty()) throw ApiError(it.err);
       if (!it.warn.empty()) { log.os() << "WARNING (gmm-rescore-lattice) " << it.warn << "\n"; num_err++; continue; }
-      writer.WriteSerialized(it.key, it.entry);
+      writer.WriteSerialized(it.key, std::move(it.entry));
       num_done++; num_frames += it.rows;
       std::string().swap(it.entry);
     }

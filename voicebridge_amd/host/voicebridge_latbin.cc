@@ -122,7 +122,7 @@ int LatticeDeterminizePruned(int argc, char *argv[], std::ofstream &file_log) {
       if (!it.ok) { log.os() << "WARNING (lattice-determinize-pruned) For key " << it.key << ", determinization did not succeed(partial output will be pruned tighter than the specified beam.)\n"; n_warn++; }
       if (it.empty) { log.os() << "WARNING (lattice-determinize-pruned) For key " << it.key << ", determinized and trimmed lattice was empty.\n"; n_warn++; }
       sum_depth_in += (double)it.in_states; sum_depth_out += it.depth * it.t; sum_t += it.t;
-      writer.WriteSerialized(it.key, it.entry);
+      writer.WriteSerialized(it.key, std::move(it.entry));
       std::string().swap(it.entry);
       n_done++;
     }

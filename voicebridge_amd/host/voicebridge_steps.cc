@@ -665,6 +665,13 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
     // side by side (no barrier between the passes: while one job estimates its transforms on the host another is still searching); jobs
     // that share ONE GPU run the two searches as one batch over all jobs' utterances each (CombinedSearch) and the host pieces side
     // by side on the job threads -- no search grid of one job holds up the statistics / rescoring kernels of another.
+    // The two big temporary tables of a job -- the main pass's raw lattices (lat.tmp.JOB, ~100 MB per 256 utterances, written once and read
+    // by the determinization for the second estimate and by the rescoring) and the rescored lattices -- are handed from program to program
+    // in memory (vbio "mem:" tables) when all of them run in this call; a run that resumes behind the main search (stage > 2) finds
+    // lat.tmp.JOB as files, as the reference leaves them.  VB_STEP_FILE_TEMPS=1: files always.
+    const bool mem_tmp = stage <= 2 && !getenv("VB_STEP_FILE_TEMPS");
+    const std::string tmp_prefix = mem_tmp ? "mem:" : "";
+    auto drop_tmp = [&](const std::string &path) { if (vbio::IsMemPath(path)) vbio::MemUnlink(path); else unlink(path.c_str()); };
     const bool combined = CombinedSearch(nj);
     auto job_files = [&](int j, std::string *J, std::string *dsn) { *J = std::to_string(j); *dsn = Join(sdata, *J); return !ReadLines(Join(*dsn, "feats.scp"), false).empty(); };
     auto fe_of = [&](const std::string &dsn) { return FrontEndOptions(srcdir, dsn, lda, cmvn_opts, delta_opts, splice_opts); };
@@ -701,7 +708,7 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
       if (!job_files(j, &J, &dsn) || stage > 2) return;
       std::ofstream log; open_log(J, &log);
       std::vector<std::string> g = main_opts;
-      g.insert(g.end(), {adapt_model, Join(graphdir, "HCLG.fst"), "scp:" + Join(dsn, "feats.scp"), "ark:" + Join(dir, "lat.tmp." + J)});
+      g.insert(g.end(), {adapt_model, Join(graphdir, "HCLG.fst"), "scp:" + Join(dsn, "feats.scp"), "ark:" + tmp_prefix + Join(dir, "lat.tmp." + J)});
       run("gmm-latgen-faster", GmmLatgenFaster, with_fe(fe_of(dsn), g, Join(dir, "pre_trans." + J)), log);
     };
     auto main_search_all = [&]() {       // ... all jobs as one batch
@@ -714,7 +721,7 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
       std::ofstream log(all_log, std::ios::binary | std::ios::app);
       std::vector<std::string> g = main_opts;
       g.insert(g.end(), {"--decode-batch=1024", "--job-of-utt=" + Join(dir, "job_of_utt"), adapt_model, Join(graphdir, "HCLG.fst"), "scp:" + Join(dir, "all_feats.scp"),
-                         "ark:" + Join(dir, "lat.tmp.JOB")});
+                         "ark:" + tmp_prefix + Join(dir, "lat.tmp.JOB")});
       run("gmm-latgen-faster", GmmLatgenFaster, with_fe(fe_of(data), g, trans_all), log);
       unlink(trans_all.c_str()); unlink(Join(dir, "all_feats.scp").c_str()); unlink(Join(dir, "job_of_utt").c_str());
       CombinedLogStubs(Join(dir, "log"), "fmllr", nj, all_log);
@@ -724,7 +731,7 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
       if (!job_files(j, &J, &dsn)) return;
       std::ofstream log; open_log(J, &log);
       const std::vector<std::string> fe = fe_of(dsn);
-      const std::string raw = "scp:" + Join(dsn, "feats.scp"), pre_trans = Join(dir, "pre_trans." + J), trans = Join(dir, "trans." + J), lat_tmp = Join(dir, "lat.tmp." + J);
+      const std::string raw = "scp:" + Join(dsn, "feats.scp"), pre_trans = Join(dir, "pre_trans." + J), trans = Join(dir, "trans." + J), lat_tmp = tmp_prefix + Join(dir, "lat.tmp." + J);
       const std::string spk2utt = "--spk2utt=ark:" + Join(dsn, "spk2utt");
       if (stage <= 3) {      // second fMLLR estimate, composed with the first (:491-566)
         const std::string t_ldp = Join(dsn, "ldp.temp"), t_post = Join(dsn, "post.temp"), t_wsp = Join(dsn, "wsp.temp"), trans_tmp = Join(dir, "trans_tmp." + J);
@@ -736,10 +743,10 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
         unlink(t_ldp.c_str()); unlink(t_post.c_str()); unlink(t_wsp.c_str());
       }
       if (stage <= 4) {      // rescoring with the final model on the final features, determinization (:568-640)
-        const std::string t_grl = Join(dsn, "grl.temp");
+        const std::string t_grl = (getenv("VB_STEP_FILE_TEMPS") ? "" : "mem:") + Join(dsn, "grl.temp");
         run("gmm-rescore-lattice", GmmRescoreLattice, with_fe(fe, {"gmm-rescore-lattice", final_model, "ark:" + lat_tmp, raw, "ark:" + t_grl}, trans), log);
         run("lattice-determinize-pruned", LatticeDeterminizePruned, {"lattice-determinize-pruned", acw, "--beam=" + std::to_string(lattice_beam), "ark:" + t_grl, "ark:" + Join(dir, "lat." + J)}, log);
-        unlink(t_grl.c_str()); unlink(lat_tmp.c_str());
+        drop_tmp(t_grl); drop_tmp(lat_tmp);
       }
     };
     for (int j = 1; j <= nj; j++) unlink(Join(Join(dir, "log"), "fmllr." + std::to_string(j) + ".log").c_str());
