@@ -143,10 +143,13 @@ constexpr int HCAP = 1 << HBITS;            // slots of the per-frame state map 
 #endif
 constexpr int HPROBE = VBH_HPROBE;          // probes before a state is sent to the table in HBM
 constexpr unsigned HEMPTY = 0xFFFFFFFFu;
-constexpr int SPT = 32;                     // slots a thread numbers in the slot scan: one group (threads 0 .. HCAP / 32 - 1 take part)
+#ifndef VBH_SPT
+#define VBH_SPT 32              // (r04: 16 -- all 1024 threads number and write tokens, half as many rounds -- 877 -> 1000 ms: the frame loop's register allocation again)
+#endif
+constexpr int SPT = VBH_SPT;                // slots a thread numbers in the slot scan: 32 = one group of Shared::grp (threads 0 .. HCAP / 32 - 1 take part), 16 = half a group
 constexpr int COST_CAP = 2 * HCAP;          // token costs of the current frame cached in LDS (the map's memory, idle at that time)
 constexpr int FCAP = NT >= 1024 ? 1024 : 512;   // entries of each epsilon work list kept in LDS
-static_assert(HCAP / SPT <= NT, "slot scan: one thread per 32-slot group");
+static_assert(HCAP / SPT <= NT && (SPT == 32 || SPT == 16), "slot scan: one thread per group of 32 slots, or per half group");
 // VBH_LL_LDS: the frame's row of acoustic scores (P floats, fetched coalesced at the start of the frame) is kept in LDS, so
 // that the per-arc score lookup of pass 1 is an LDS read instead of a third dependent global access (token -> state -> arc
 // -> score); models of more than LLCAP pdfs read the row from global memory as before
@@ -1451,7 +1454,15 @@ VBH_KI __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot
   const int ne_all = sh.scan_base + total;
   if (ne_all > w_tok_cap) { if (tid == 0) sh.error = ERR_W_TOK; }
   else {
-    if (scans) { uint2 gq; gq.x = occ; gq.y = (unsigned)first; sh.grp[tid] = gq; }
+    if (scans) {
+      // {occupancy of the group's 32 slots, index of the group's first token}: with half a group per thread the lower half's thread writes
+      // the index, both their halves of the mask (16-bit stores into the same word)
+      if (SPT == 32) { uint2 gq; gq.x = occ; gq.y = (unsigned)first; sh.grp[tid] = gq; }
+      else {
+        reinterpret_cast<unsigned short *>(&sh.grp[tid >> 1].x)[tid & 1] = (unsigned short)occ;
+        if (!(tid & 1)) sh.grp[tid >> 1].y = (unsigned)first;
+      }
+    }
     // token records of the first-level states, final cost included; those with epsilon arcs and a cost within the cutoff go
     // on work list 0 (as slots) for the regeneration of the epsilon links
     const unsigned *tag = map_tag(sh);
