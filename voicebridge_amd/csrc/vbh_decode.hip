@@ -2558,7 +2558,9 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
   Slot p{};
   // (every frame's tokens and links start a 64-bit word of the survivor bitmaps, VBH_SURVIVOR_BITS: a frame takes whole words, which
   // for a graph of a dozen states -- config 1's monophone loop -- is several times what its tokens need; tests/test_gpu_config1.py)
-  p.w_tok_cap = (int)std::min<long long>((((per_frame_tok_s + 63) & ~63LL) + 64) * win, 1LL << 28);
+  // (at most 2^26 - 64 tokens in the window, hence in a frame: a candidate's source token shares its word with the six bits of the
+  // token's admission bucket, decode_kernel pass 1)
+  p.w_tok_cap = (int)std::min<long long>((((per_frame_tok_s + 63) & ~63LL) + 64) * win, (1LL << 26) - 64);
   p.w_link_cap = (int)std::min<long long>((((per_frame_link + per_frame_tok_s + 63) & ~63LL) + 64) * win, 1LL << 28);
   // history: one unpruned frontier frame per interval plus the survivors
   const long long n_int = max_frames / pi + 2;
