@@ -672,6 +672,17 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
     const bool mem_tmp = stage <= 2 && !getenv("VB_STEP_FILE_TEMPS");
     const std::string tmp_prefix = mem_tmp ? "mem:" : "";
     auto drop_tmp = [&](const std::string &path) { if (vbio::IsMemPath(path)) vbio::MemUnlink(path); else unlink(path.c_str()); };
+    // (whatever way this call ends, no in-memory table of it stays behind: an exception between a table's writer and its last reader would
+    // otherwise leave a job's hundred megabytes in the registry)
+    struct MemTempGuard {
+      std::vector<std::string> names;
+      ~MemTempGuard() { for (const std::string &n : names) vbio::MemUnlink(n); }
+    } mem_guard;
+    for (int j = 1; j <= nj; j++) {
+      const std::string J = std::to_string(j);
+      if (mem_tmp) mem_guard.names.push_back("mem:" + Join(dir, "lat.tmp." + J));
+      if (!getenv("VB_STEP_FILE_TEMPS")) mem_guard.names.push_back("mem:" + Join(Join(sdata, J), "grl.temp"));
+    }
     const bool combined = CombinedSearch(nj);
     auto job_files = [&](int j, std::string *J, std::string *dsn) { *J = std::to_string(j); *dsn = Join(sdata, *J); return !ReadLines(Join(*dsn, "feats.scp"), false).empty(); };
     auto fe_of = [&](const std::string &dsn) { return FrontEndOptions(srcdir, dsn, lda, cmvn_opts, delta_opts, splice_opts); };
