@@ -8,9 +8,13 @@ Two modes of the restatement are checked:
     (frame, HCLG state) tokens, their tot_cost / extra_cost, every lattice arc, the best
     path and its weight -- in beam-limited, max-active-limited, min-active-limited and
     no-final-state cases alike;
-  * exact_cutoff=True is the order-independent variant the GPU search implements.  Its
+  * exact_cutoff=True is the order-independent variant (the GPU search's admission = exact).  Its
     lattice must be a sub-lattice of the reference's with identical costs, and its best
-    path must be the reference's best path.
+    path must be the reference's best path;
+  * exact_cutoff=3 is the reference's admission rule in a canonical order (the GPU search's default,
+    admission = ordered): between the other two in the work it does, the reference's best path
+    wherever the visiting order does not decide it, and independent of the number of buckets where
+    nothing binds.
 """
 import glob
 import os
@@ -145,3 +149,33 @@ def test_reference_lattice_depends_on_hash_size_but_exact_variant_does_not():
         assert r["n_frames_maxactive_bound"] == 0
         r2 = vbo.decode_lattice_faster(f, g["loglikes"], g["tid2pdf"], exact_cutoff=True, hash_ratio=hr, **o)
         assert set(our_links(r2)) == ex
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_ordered_admission_mode(name):
+    """exact_cutoff=3 (vb_oracle.h): the reference's prefix-minimum admission over buckets of the source state's hash.  It admits at
+    least what the order-independent rule admits and at most what the superset rule (mode 2: the initial next_cutoff for every arc)
+    admits, frame by frame on equal tokens -- over a whole utterance that shows as tokens created; its best path is the reference's in
+    every golden case but the one whose path the visiting order itself decides (a random graph with max-active binding in every frame,
+    where the superset rule ends elsewhere too); runs are deterministic."""
+    g = load(name)
+    o = parse_opts(g["opts"])
+    fst, cfg = fst_from(g), cfg_from(o)
+    r1 = vbo.decode_lattice_faster(fst, g["loglikes"], g["tid2pdf"], exact_cutoff=1, **cfg)
+    r2 = vbo.decode_lattice_faster(fst, g["loglikes"], g["tid2pdf"], exact_cutoff=2, **cfg)
+    r3 = vbo.decode_lattice_faster(fst, g["loglikes"], g["tid2pdf"], exact_cutoff=3, adm_bucket_bits=6, **cfg)
+    r3b = vbo.decode_lattice_faster(fst, g["loglikes"], g["tid2pdf"], exact_cutoff=3, adm_bucket_bits=6, **cfg)
+    for k in ("tok_frame", "tok_state", "tok_cost", "tok_extra", "link_src", "link_dst", "link_graph", "link_acoustic", "words", "ali"):
+        np.testing.assert_array_equal(r3[k], r3b[k], err_msg=k)
+    assert r3["ok"] == 1 and r3["num_frames"] == g["loglikes"].shape[0]
+    assert r1["n_tok_created"] <= r3["n_tok_created"] <= r2["n_tok_created"]
+    if name != "decode_g1_maxact":
+        np.testing.assert_array_equal(r3["words"], g["ref_lat_words"])
+        np.testing.assert_array_equal(r3["ali"], g["ref_lat_ali"])
+        np.testing.assert_array_equal(np.float32([r3["best_graph"], r3["best_acoustic"]]), g["ref_lat_best_weight"])
+    else:
+        assert not np.array_equal(r2["words"], g["ref_lat_words"]) or not np.array_equal(r2["ali"], g["ref_lat_ali"])
+    # with one bucket (bits = 1 is the fewest: two) the rule comes close to the superset rule, with 2^20 to one arc order per state
+    for bits in (1, 12, 20):
+        rb = vbo.decode_lattice_faster(fst, g["loglikes"], g["tid2pdf"], exact_cutoff=3, adm_bucket_bits=bits, **cfg)
+        assert rb["ok"] == 1 and r1["n_tok_created"] <= rb["n_tok_created"] <= r2["n_tok_created"]
