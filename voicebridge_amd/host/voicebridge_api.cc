@@ -842,7 +842,8 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     if (job_of_utt.empty()) (void)out_of_job(0);
     else for (const auto &kv : job_of_utt) (void)out_of_job(kv.second);
 
-    const int batch_utts = (int)po.Num("decode-batch", 256);
+    int batch_utts = (int)po.Num("decode-batch", 256);
+    if (!po.Has("decode-batch")) if (const char *e = getenv("VB_DECODE_BATCH")) { const int x = atoi(e); if (x > 0) batch_utts = x; }      // (tuning: utterances per search grid)
     // the cached workspace serves this call when its capacities cover the search configuration (vbh_decoder_set_cfg: beams and
     // scales are free, max_active up to what the workspaces were made for); --workspace-max-active (extension) asks for workspaces
     // that also cover a later call with a larger max_active (DecodeFmllr: first pass 2000, main pass 7000)
