@@ -13,8 +13,9 @@
  * a bucket in insertion order.  This file reproduces that order with its own data
  * structure (an insertion stamp per element and an occupation stamp per bucket, sorted when
  * the list is needed), so that cfg.exact_cutoff == 0 gives the reference's token sets in
- * every regime.  cfg.exact_cutoff == 1 is the order-independent variant used by the GPU
- * search (see vb_oracle.h).
+ * every regime.  cfg.exact_cutoff == 1 is the order-independent variant (the GPU search's
+ * admission = exact, and the 1-best search), == 3 the reference's admission rule in a canonical
+ * order (the GPU lattice search's default, admission = ordered); see vb_oracle.h.
  */
 #include "vb_oracle.h"
 

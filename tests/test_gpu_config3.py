@@ -2,7 +2,7 @@
 180 k-word lexicon graph (~2 M states), P = 2500 / G = 15000 / D = 39, beam 13, lattice-beam 6, max-active 7000 -- the whole
 GPU path from PCM to lattices, checked
 
-  * against the oracle's order-independent mode on the GPU's own scores: bit-exact token sets, float32 costs, every arc,
+  * against the oracle in the GPU's admission mode (ordered, the default: exact_cutoff = 3) on the GPU's own scores: bit-exact token sets, float32 costs, every arc,
     best path (what only exists at this size is exercised here: ~30 compactions per utterance, the dirty-frame bitmap, the
     HBM level of the state map, frames bound by max-active and by min-active);
   * against tests/golden/config3_refpaths.npz: words, alignment and weights the REFERENCE's own programs decode for the same
