@@ -104,6 +104,14 @@ constexpr int U = VBH_U;                    // independent items per lane in the
 #ifndef VBH_LINK_PF
 #define VBH_LINK_PF 0           // pruning sweeps: the next round's link records are fetched before this round's are worked on
 #endif
+// VBH_LAZY_DST: an emitting link keeps the provisional destination pass 2 gives it -- the destination state's slot in the frame's LDS map
+// -- instead of being read and patched once the frame's tokens are numbered (a pass over every link of the frame: 9 k cycles, and every
+// link's line written a second time).  The slot -> token table of a frame (Shared::grp, 4 KB) goes to a ring in the slot's memory; a pruning
+// sweep loads the table of the frame above and translates on the fly; a link that SURVIVES a sweep (a handful per frame) gets its
+// destination written then.  Links to second-level states (a few per cent) are listed by pass 2 and resolved as before.
+#ifndef VBH_LAZY_DST
+#define VBH_LAZY_DST 1
+#endif
 #ifndef VBH_FX
 #define VBH_FX 1                // emitting links per thread in flight when their destinations are filled in
 #endif
@@ -157,6 +165,7 @@ static_assert(HCAP / SPT <= NT && (SPT == 32 || SPT == 16), "slot scan: one thre
 #define VBH_LL_LDS 0           // measured (r02): 1 is 15 % slower at 1024 threads -- see DESIGN.md (register allocation of the frame loop)
 #endif
 constexpr int LLCAP = VBH_LL_LDS ? 2560 : 1;
+constexpr int GRP_RING = MAX_WIN_FRAMES + 2; // frames whose slot -> token tables are kept (VBH_LAZY_DST): every frame with links in the raw window
 constexpr int DIRTY_FRAMES = 1 << 13;       // frames covered by the dirty bitmap (1 KB of LDS); later frames count as dirty
 
 // The pruning and compaction passes run once per pruning interval; as functions of their own they get their own register
@@ -172,7 +181,7 @@ constexpr int DIRTY_FRAMES = 1 << 13;       // frames covered by the dirty bitma
 #endif
 // x 64 tokens of a frame (the links to tokens beyond them gather their destination as before); half as many in the builds with two
 // workgroups per CU, whose LDS must stay under 80 KB (the stress variant of voicebridge_amd/build.py)
-constexpr int DSTBITS_WORDS = VBH_DST_BITS ? (VBH_DECODE_NT >= 1024 ? 256 : 128) : 1;
+constexpr int DSTBITS_WORDS = VBH_DST_BITS ? (VBH_DECODE_NT >= 1024 ? 256 : 64) : 1;
 #ifndef VBH_OUTLINE
 #define VBH_OUTLINE 0          // measured (r02, tools/variants.py): 1 and 2 are 15 % slower -- the call sites cost the hot loop more registers than the callees free
 #endif
@@ -242,6 +251,7 @@ struct Slot {
   // are one word: every frame's token and link ranges start on a multiple of 64 in W): the compaction walks these words instead of
   // reading the window's 16-byte records again (VBH_SURVIVOR_BITS)
   unsigned long long *w_tok_alive, *w_lk_alive;
+  unsigned long long *w_grp;               // [GRP_RING][HCAP / 32] first token << 32 | occupancy of the map's 32-slot groups, per frame (VBH_LAZY_DST)
   i32x4 *h_tok; int *h_remap; i32x4 *hl;                // history
   FrameRec *fr;                            // [max_frames + 2]
   i32x4 *cand;                             // candidates of the current frame: {tot, arc, source token, next state | EPSBIT}
@@ -504,6 +514,9 @@ struct Shared {
   // VBH_DST_BITS: the survivor bitmap of the tokens of the frame swept last (what its final sweep wrote to Slot::w_tok_alive), for the sweep
   // over the frame below it: an emitting link whose destination the bitmap says is dead is excised without gathering the destination's
   // record -- all but a per cent of a frame's links (dst_frame: whose tokens these are, -1: nobody's; dst_tb: their first window index)
+  uint2 grp2[VBH_LAZY_DST ? HCAP / 32 : 1];  // VBH_LAZY_DST: the slot -> token table of frame grp2_frame (tokens from grp2_tb on), for the sweep over the frame below it
+  int grp2_frame, grp2_tb;
+  int n_l2;                                  // ... emitting links of the frame being built whose destination is a second-level state (listed in hist)
   unsigned long long dstbits[2][DSTBITS_WORDS];      // [frame & 1]: the sweeps over frame f read f + 1's bits while they write f's
   int dst_frame, dst_tb, dst_n;
   int use_lds_map;
@@ -676,7 +689,8 @@ template <bool LDS_TMP>
 __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, int le_, int split, gp<i32x4> wt, gp<i32x4> ht,
                                                          float lattice_beam, unsigned *lds_tmp, int tb, Shared &sh, const Slot &s,
                                                          gp<unsigned long long> alive_bits = nullptr, bool bits_valid = false,
-                                                         int lds_off = 0, int lds_cap = 128, const unsigned long long *dst_bits = nullptr, int dst_tb = 0, int dst_n = 0) {
+                                                         int lds_off = 0, int lds_cap = 128, const unsigned long long *dst_bits = nullptr, int dst_tb = 0, int dst_n = 0,
+                                                         const uint2 *grp2 = nullptr, int grp_tb = 0) {
   // With a survivor bitmap (links of the raw window; VBH_SWEEP_BITS): the bitmap IS the record of which links are excised -- nothing is
   // written into the link records (a scattered 4-byte store per excised link: whole 64-byte half-lines written back for it), and from
   // the second sweep of a visit on (bits_valid) the links the bitmap says are gone are not read again.  The words of the frame being
@@ -711,9 +725,16 @@ __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, i
 #else
     fetch(base, L, ok);
 #endif
+    bool prov[UL];       // VBH_LAZY_DST: the link still carries its destination's map slot (grp2: the slot -> token table of the frame above)
 #pragma unroll
     for (int u = 0; u < UL; u++) {
       ok[u] = ok[u] && L[u].x >= 0;   // negative source: already excised
+      prov[u] = false;
+      if (VBH_LAZY_DST && grp2 != nullptr) {
+        const int l = base + u * NT + (int)threadIdx.x, y = L[u].y;
+        prov[u] = ok[u] && l >= split && y >= 0 && !(y & WBIT);
+        if (prov[u]) { const uint2 gq = grp2[y >> 5]; L[u].y = (grp_tb + (int)gq.y + __popc(gq.x & ((1u << (y & 31)) - 1u))) | WBIT; }
+      }
       if (ok[u]) {
         ok[u] = chk_tok_id(sh, s, 10, L[u].y) && chk_tok_id(sh, s, 12, L[u].x);
         if (LDS_TMP && ok[u]) ok[u] = VBH_CHK(sh, 14, (L[u].x & ~WBIT) - tb, COST_CAP);
@@ -742,6 +763,7 @@ __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, i
       float le = asf(D[u].z) + (asf(L[u].z) - asf(D[u].y));
       const bool keep = ok[u] && !(le > lattice_beam);
       if (ok[u] && !keep && !use_bits) ((gp<int>)&lk[l])[0] = -1;
+      if (VBH_LAZY_DST && keep && prov[u]) ((gp<int>)&lk[l])[1] = L[u].y;       // a survivor: from now on the link names its destination token
       if (keep) {
         if (le < 0.0f) le = 0.0f;
         if (LDS_TMP) atomicMin(&lds_tmp[(L[u].x & ~WBIT) - tb], __float_as_uint(le));
@@ -812,6 +834,29 @@ VBH_KI __device__ int prune_frame(const Slot &s, int f, float lattice_beam, floa
 #else
   gp<unsigned long long> tbits = nullptr, ebits = nullptr, pbits = nullptr;
 #endif
+  // VBH_LAZY_DST: the slot -> token table of frame f + 1, for this frame's emitting links while they are in the raw window.  It is in LDS
+  // already when frame f + 1 was the last one swept (it left its table there on its way out) or this is the first frame of the pass
+  // (prune_backward); otherwise it is fetched now
+  const uint2 *g2 = nullptr;
+  int g2_tb = 0;
+  if (VBH_LAZY_DST && (flags & 2) && sh.use_lds_map) {
+    // (uniform: everybody reads the word its last writer left behind a barrier -- and thread 0 must not write it again before everybody
+    // HAS read it: without the first barrier a late wave saw the new value, skipped the block and its barrier, and translated slots with a
+    // table that was not there yet; found by the two-workgroups-per-CU build, tests/test_gpu_variant.py, as a memory fault)
+    const bool fetch = sh.grp2_frame != f + 1;
+    if (fetch) {
+      __syncthreads();
+      gp<const unsigned long long> src = uptr(s.w_grp) + (size_t)((f + 1) % GRP_RING) * (HCAP / 32);
+      if (tid < HCAP / 32) { const unsigned long long w_ = src[tid]; uint2 gq; gq.x = (unsigned)w_; gq.y = (unsigned)(w_ >> 32); sh.grp2[tid] = gq; }
+      if (tid == 0) { sh.grp2_frame = f + 1; sh.grp2_tb = ((gp<const int>)(s.fr + f + 1))[0]; }
+      __syncthreads();
+    }
+    g2 = sh.grp2; g2_tb = sh.grp2_tb;
+  }
+  // ... and this frame's own table, for the sweep over frame f - 1: fetched now, put into LDS on the way out (when nobody reads f + 1's any more)
+  unsigned long long own_g = 0;
+  const bool leave_table = VBH_LAZY_DST && (flags & 1) && sh.use_lds_map;
+  if (leave_table && tid < HCAP / 32) own_g = (uptr(s.w_grp) + (size_t)(f % GRP_RING) * (HCAP / 32))[tid];
   // the survivor bits of the tokens the emitting links point to (frame f + 1, swept just before this one), if they are in LDS (VBH_DST_BITS)
   const bool d_ok = VBH_DST_BITS && ebits != nullptr && sh.dst_frame == f + 1;
   const unsigned long long *dbits = d_ok ? sh.dstbits[(f + 1) & 1] : nullptr;
@@ -825,16 +870,16 @@ VBH_KI __device__ int prune_frame(const Slot &s, int f, float lattice_beam, floa
     }
     unsigned long long kept;
     if (lds_tmp) {
-      if (one_range) kept = eval_links<true>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 0, 128, dbits, d_tb, d_n);
+      if (one_range) kept = eval_links<true>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 0, 128, dbits, d_tb, d_n, g2, g2_tb);
       else {
         kept = eval_links<true>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, pbits, iter > 0, 0, 64);
-        kept += eval_links<true>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 64, 64, dbits, d_tb, d_n);
+        kept += eval_links<true>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 64, 64, dbits, d_tb, d_n, g2, g2_tb);
       }
     } else {
-      if (one_range) kept = eval_links<false>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 0, 128, dbits, d_tb, d_n);
+      if (one_range) kept = eval_links<false>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 0, 128, dbits, d_tb, d_n, g2, g2_tb);
       else {
         kept = eval_links<false>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, pbits, iter > 0, 0, 64);
-        kept += eval_links<false>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 64, 64, dbits, d_tb, d_n);
+        kept += eval_links<false>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 64, 64, dbits, d_tb, d_n, g2, g2_tb);
       }
     }
     if ((tid & 63) == 0) {
@@ -900,7 +945,9 @@ VBH_KI __device__ int prune_frame(const Slot &s, int f, float lattice_beam, floa
 #endif
     if (last) break;
   }
+  if (leave_table && tid < HCAP / 32) { uint2 gq; gq.x = (unsigned)own_g; gq.y = (unsigned)(own_g >> 32); sh.grp2[tid] = gq; }      // (everybody is past the last sweep's link pass: the barrier behind it)
   if (tid == 0) {
+    if (VBH_LAZY_DST) { sh.grp2_frame = leave_table ? f : -1; sh.grp2_tb = tb; }
     set_dirty(sh, f, false); if (result & 2) set_dirty(sh, f - 1, true);
     // whose survivor bits sh.dstbits[f & 1] now holds (window tokens only: the bitmap is the window's)
     if (VBH_DST_BITS) { sh.dst_frame = tbits ? f : -1; sh.dst_tb = tb; sh.dst_n = (te - tb) < 64 * DSTBITS_WORDS ? (te - tb) : 64 * DSTBITS_WORDS; }
@@ -922,6 +969,7 @@ VBH_KI __device__ VBH_COLD void prune_backward(const Slot &s, int from, int firs
   int above = 3;   // result of the frame above: the frontier counts as changed
   for (int i = threadIdx.x; i < COST_CAP; i += NT) sh.arena[i] = INF_BITS;   // see prune_frame
   if (VBH_DST_BITS && threadIdx.x == 0) sh.dst_frame = -1;                   // (no frame's survivor bits are in LDS yet)
+  if (VBH_LAZY_DST && threadIdx.x == 0) sh.grp2_frame = -1;                  // (... nor any frame's slot -> token table)
   __syncthreads();
   for (int f = from; f >= 0 && f >= stop_at; f--) {
     if (final) {
@@ -1369,7 +1417,7 @@ __device__ __forceinline__ void map_clear(Shared &sh) {
 #define EPSTAMP(i)
 #endif
 VBH_KI __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, int nb, float cutoff, unsigned ep,
-                                   int cur, Shared &sh, int el_b, int el_e, float lattice_beam) {
+                                   int cur, Shared &sh, int el_b, int el_e, float lattice_beam, int fpo) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef VBH_DIAG_EPS
   if (tid == 0) sh.ep_last = clk();
@@ -1457,7 +1505,10 @@ VBH_KI __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot
     if (scans) {
       // {occupancy of the group's 32 slots, index of the group's first token}: with half a group per thread the lower half's thread writes
       // the index, both their halves of the mask (16-bit stores into the same word)
-      if (SPT == 32) { uint2 gq; gq.x = occ; gq.y = (unsigned)first; sh.grp[tid] = gq; }
+      if (SPT == 32) {
+        uint2 gq; gq.x = occ; gq.y = (unsigned)first; sh.grp[tid] = gq;
+        if (VBH_LAZY_DST) (uptr(s.w_grp) + (size_t)(fpo % GRP_RING) * (HCAP / 32))[tid] = ((unsigned long long)gq.y << 32) | gq.x;      // the frame's slot -> token table, for the pruning sweeps
+      }
       else {
         reinterpret_cast<unsigned short *>(&sh.grp[tid >> 1].x)[tid & 1] = (unsigned short)occ;
         if (!(tid & 1)) sh.grp[tid >> 1].y = (unsigned)first;
@@ -1507,6 +1558,27 @@ VBH_KI __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot
   if (sh.error != ERR_NONE) return lb;
   __syncthreads();        // (everybody has read w_nlink before the links below move it)
   gp<i32x4> wl = uptr(s.wl);
+#if VBH_LAZY_DST
+  // ---- the emitting links' destinations: a link to a first-level state keeps the slot pass 2 gave it (the pruning sweeps translate it,
+  //      eval_links); those to second-level states -- listed by pass 2 in sh.hist, 256 of them; more: every link is looked at -- get
+  //      their tokens from the states' entries now
+  {
+    static_assert(SPT == 32, "the slot -> token table is written by the one-group-per-thread scan");
+    const int n_l2 = sh.n_l2;
+    if (n_l2 <= 256) {
+      for (int i = tid; i < n_l2; i += NT) {
+        gp<int> py = (gp<int>)&wl[sh.hist[i]] + 1;
+        *py = ld_i32(&ent[-1 - *py].tokid) | WBIT;
+      }
+    } else {
+      for (int l = el_b + tid; l < el_e; l += NT) {
+        gp<int> py = (gp<int>)&wl[l] + 1;
+        const int y = *py;
+        if (y < 0) *py = ld_i32(&ent[-1 - y].tokid) | WBIT;
+      }
+    }
+  }
+#else
   // ---- the emitting links' destinations (VBH_FX links per thread in flight: the pass is a chain of one load per round otherwise)
   for (int l0 = el_b + tid; l0 < el_e; l0 += NT * VBH_FX) {
     i32x2 yz[VBH_FX];
@@ -1532,6 +1604,7 @@ VBH_KI __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot
       *py = d | WBIT;
     }
   }
+#endif
   EPSTAMP(3)
   // ---- epsilon links regenerated from the final costs; what they point to is tagged
   {
@@ -1716,7 +1789,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
     if (tid == 0) {
       for (int i = 0; i < 12; i++) sh.tph[i] = 0;
       sh.w_ntok = 0; sh.w_nlink = 0; sh.h_ntok = 0; sh.h_nlink = 0; sh.error = ERR_NONE;
-      sh.n_max_bound = 0; sh.n_min_bound = 0; sh.n_cand = 0; sh.cand_bound = 0xFFFFFFFFu; sh.n_visited = 0;
+      sh.n_max_bound = 0; sh.n_min_bound = 0; sh.n_cand = 0; sh.cand_bound = 0xFFFFFFFFu; sh.n_visited = 0; sh.n_l2 = 0; sh.grp2_frame = -1;
       if (ADM == VBH_ADMIT_ORDERED) sh.init_bound = 0xFFFFFFFFu;
       sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0;
       sh.changed2[0] = 0; sh.changed2[1] = 0;
@@ -1754,7 +1827,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       }
       __threadfence_block();
       __syncthreads();
-      const int plb = process_nonemitting<ADM>(g, s, 0, cfg.beam, ep, 0, sh, 0, 0, cfg.lattice_beam);
+      const int plb = process_nonemitting<ADM>(g, s, 0, cfg.beam, ep, 0, sh, 0, 0, cfg.lattice_beam, 0);
       cur_b = 0; cur_e = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap;
       if (tid == 0) {
         FrameRec r;
@@ -2091,6 +2164,16 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
           }
           wave_alloc_n<UC>(&sh.fcnt[0], pushf, fq);
           wave_alloc_n<UC>(&sh.w_nlink, adm, lq);
+#if VBH_LAZY_DST
+          {     // the links whose destination is a second-level state: listed for process_nonemitting (the others keep their slot)
+            bool l2[UC]; int q2[UC];
+#pragma unroll
+            for (int u = 0; u < UC; u++) l2[u] = adm[u] && slot[u] < 0;
+            wave_alloc_n<UC>(&sh.n_l2, l2, q2);
+#pragma unroll
+            for (int u = 0; u < UC; u++) if (l2[u] && q2[u] < 256) sh.hist[q2[u]] = (unsigned)lq[u];
+          }
+#endif
 #pragma unroll
           for (int u = 0; u < UC; u++) {
             if (pushf[u]) front_push(sh, front0, front_cap, 0, fq[u], CA[u].w & STMASK);
@@ -2109,7 +2192,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       if (sh.error != ERR_NONE) break;
       PHASE(2)
       // ---- ProcessNonemitting(next_cutoff)
-      const int plb = process_nonemitting<ADM>(g, s, nb, next_cutoff, ep, 0, sh, lb, le_emit, cfg.lattice_beam);
+      const int plb = process_nonemitting<ADM>(g, s, nb, next_cutoff, ep, 0, sh, lb, le_emit, cfg.lattice_beam, frame + 1);
       cur_b = nb; cur_e = sh.w_ntok < s.w_tok_cap ? sh.w_ntok : s.w_tok_cap; cur_w = true;
       const int pl_end = sh.w_nlink < s.w_link_cap ? sh.w_nlink : s.w_link_cap;
       if (tid == 0) {
@@ -2119,7 +2202,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         r.tok_b = cur_b; r.tok_e = cur_e; r.el_b = 0; r.el_e = 0; r.pl_b = plb; r.pl_e = pl_end;
         r.flags = 1 | 4; r.cost_offset = 0.0f; r.a_tok = cur_e - cur_b; r.a_el = 0; r.a_pl = pl_end - plb; r.pad = 0;
         st_frame(s.fr + (frame + 1), r);
-        sh.n_cand = 0; sh.cand_bound = 0xFFFFFFFFu; sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0;
+        sh.n_cand = 0; sh.cand_bound = 0xFFFFFFFFu; sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0; sh.n_l2 = 0;
       }
       if (ADM == VBH_ADMIT_ORDERED) {      // (their last readers: before pass 2; the barrier below)
         if (tid >= NT - 64) sh.bmin[tid - (NT - 64)] = 0xFFFFFFFFu;
@@ -2588,6 +2671,7 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
   A_(ent, Ent, S, 0xFF)
   A_(w_tok, i32x4, p.w_tok_cap, -2) A_(w_remap, int, p.w_tok_cap, 0) A_(wl, i32x4, p.w_link_cap, -2)
   A_(w_tok_alive, unsigned long long, p.w_tok_cap / 64 + 2, 0) A_(w_lk_alive, unsigned long long, p.w_link_cap / 64 + 2, 0)
+  A_(w_grp, unsigned long long, (size_t)GRP_RING * (HCAP / 32), 0)
   A_(h_tok, i32x4, p.h_tok_cap, -2) A_(h_remap, int, p.h_tok_cap, 0) A_(hl, i32x4, p.h_link_cap, -2)
   A_(fr, FrameRec, F, 0)
   A_(cand, i32x4, p.cand_cap, -2)
