@@ -660,6 +660,11 @@ __device__ __forceinline__ gp<i32x4> tokp(gp<i32x4> wt, gp<i32x4> ht, int id) { 
 
 // Consistency checks on indices that are about to address memory: a violation is recorded (first one wins), the utterance
 // fails with ERR_INTERNAL instead of the device faulting.
+#ifndef VBH_EPS_RELAX
+#define VBH_EPS_RELAX 2        // the epsilon links of a frame relaxed on their own instead of sweeping the frame once per level (prune_frame): 1 = any number of them,
+                               // 2 = up to 64 (one wave, no barriers; more: the sweeps).  r04 same-box A/B, ms per 1024 x 30 s: 0: 850.2, 1: 1172 (the frame loop's
+                               // register allocation: 125 spills) / 838.5 as a function call, 2: 814.2 / 820.6 as a function call
+#endif
 #ifndef VBH_SWEEP_BITS
 #define VBH_SWEEP_BITS VBH_SURVIVOR_BITS      // the pruning sweeps record excised window links in the survivor bitmap only (eval_links)
 #endif
@@ -690,7 +695,7 @@ __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, i
                                                          float lattice_beam, unsigned *lds_tmp, int tb, Shared &sh, const Slot &s,
                                                          gp<unsigned long long> alive_bits = nullptr, bool bits_valid = false,
                                                          int lds_off = 0, int lds_cap = 128, const unsigned long long *dst_bits = nullptr, int dst_tb = 0, int dst_n = 0,
-                                                         const uint2 *grp2 = nullptr, int grp_tb = 0) {
+                                                         const uint2 *grp2 = nullptr, int grp_tb = 0, bool eps_skip = false) {
   // With a survivor bitmap (links of the raw window; VBH_SWEEP_BITS): the bitmap IS the record of which links are excised -- nothing is
   // written into the link records (a scattered 4-byte store per excised link: whole 64-byte half-lines written back for it), and from
   // the second sweep of a visit on (bits_valid) the links the bitmap says are gone are not read again.  The words of the frame being
@@ -703,7 +708,7 @@ __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, i
 #pragma unroll
     for (int u = 0; u < UL; u++) {
       const int l = base + u * NT + (int)threadIdx.x;
-      okx[u] = l < le_;
+      okx[u] = l < le_ && !(eps_skip && l < split);      // (eps_skip: the epsilon links are left to relax_eps_links; their bitmap bits are written as 0 here)
       if (use_bits && bits_valid) {
         const int wfirst = base + u * NT + ((int)threadIdx.x & ~63), wi = (wfirst - lb) >> 6;
         const unsigned long long word = wfirst < le_ ? (wi < lds_cap ? lbits[wi] : alive_bits[wfirst >> 6]) : 0ull;
@@ -786,6 +791,91 @@ __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, i
   return kept;
 }
 
+// The epsilon links [pb, pe) of a frame whose tokens' emitting-link minima are in lds_tmp (all of them, behind a barrier): relax them to
+// the fixed point (see prune_frame), then record which of them survive -- in the bitmap (window links; eval_links left their bits 0) or
+// in the records (history links) -- and add their number to *cnt.  Source and destination both belong to the frame [tb, te).
+#ifndef VBH_RELAX_ATTR
+#define VBH_RELAX_ATTR __forceinline__
+#endif
+__device__ VBH_RELAX_ATTR void relax_eps_links(gp<i32x4> plk, int pb, int pe, gp<i32x4> wt, gp<i32x4> ht, float lattice_beam, unsigned *lds_tmp,
+                                                int tb, int te, Shared &sh, const Slot &s, gp<unsigned long long> pbits, int *cnt) {
+  const int tid = threadIdx.x, ne = pe - pb;
+  // "did anybody's link move a token" across the workgroup with one barrier per round: three flags in rotation (round k sets and reads
+  // flag k % 3 around its barrier and clears flag (k + 2) % 3, which nobody touches before the barrier of round k + 1); all three are 0 on
+  // entry (prune_frame) and on exit.  (select_kth's words, idle during pruning: __syncthreads_or would take LDS of its own, which the
+  // two-workgroups-per-CU build does not have)
+  int *flag3 = reinterpret_cast<int *>(&sh.sel_prefix);
+  int round = 0;
+  auto block_or = [&](bool ch) -> bool {
+    if (ch) flag3[round] = 1;
+    __syncthreads();
+    const bool any = flag3[round] != 0;
+    if (tid == 0) flag3[round >= 1 ? round - 1 : 2] = 0;
+    round = round == 2 ? 0 : round + 1;
+    return any;
+  };
+  // one link: its record, the cost of its destination; a = (tok->tot_cost + acoustic + graph) - next_tok->tot_cost (:337)
+  auto load = [&](int l, bool mine, int &si, int &di, float &a) -> bool {
+    const i32x4 L = plk[mine ? l : pb];
+    bool ok = mine && L.x >= 0;
+    if (ok) ok = chk_tok_id(sh, s, 16, L.y) && chk_tok_id(sh, s, 18, L.x);
+    si = (L.x & ~WBIT) - tb; di = (L.y & ~WBIT) - tb;
+    if (ok) ok = VBH_CHK(sh, 22, si, te - tb) && VBH_CHK(sh, 23, di, te - tb);
+    gp<const i32x4> dp = ok ? tokp(wt, ht, L.y) : ht;
+    a = asf(L.z) - asf(((gp<const int>)dp)[1]);
+    return ok;
+  };
+  auto step = [&](bool ok, int si, int di, float a, bool &keep) -> bool {
+    float le = asf((int)lds_tmp[ok ? di : 0]) + a;       // next_tok->extra_cost as it stands + a
+    keep = ok && !(le > lattice_beam);
+    if (!keep) return false;
+    if (le < 0.0f) le = 0.0f;
+    const unsigned v = __float_as_uint(le);
+    return atomicMin(&lds_tmp[si], v) > v;
+  };
+  auto record = [&](int l, bool ok, bool keep) {
+    if (pbits) { if (keep) (void)__hip_atomic_fetch_or(pbits + (l >> 6), 1ull << (l & 63), __ATOMIC_RELAXED, VBH_RMW_SCOPE); }
+    else if (ok && !keep) ((gp<int>)&plk[l])[0] = -1;
+    const unsigned long long m = __ballot(keep);
+    if ((tid & 63) == 0 && m) atomicAdd(cnt, __popcll(m));
+  };
+#if VBH_EPS_RELAX == 2
+  if (tid < 64) {       // (ne <= 64: prune_frame)
+    int si, di; float a; bool keep;
+    const bool ok = load(pb + tid, tid < ne, si, di, a);
+    while (__ballot(step(ok, si, di, a, keep)) != 0ull) {}
+    record(pb + tid, ok, keep);
+  }
+  return;
+#endif
+  if (ne <= NT) {
+    // a link per thread, held in registers; up to 64 links: wave 0 alone, without barriers
+    if (ne > 64 || tid < 64) {
+      int si, di; float a; bool keep;
+      const bool ok = load(pb + tid, tid < ne, si, di, a);
+      for (;;) {
+        const bool ch = step(ok, si, di, a, keep);
+        const bool any = ne <= 64 ? __ballot(ch) != 0ull : block_or(ch);
+        if (!any) break;
+      }
+      record(pb + tid, ok, keep);
+    }
+  } else {
+    for (;;) {
+      bool ch = false;
+      for (int l = pb + tid; l < pe; l += NT) { int si, di; float a; bool keep; const bool ok = load(l, true, si, di, a); ch |= step(ok, si, di, a, keep); }
+      if (!block_or(ch)) break;
+    }
+    for (int base = pb; base < pe; base += NT) {
+      const int l = base + tid;
+      int si, di; float a; bool keep;
+      const bool ok = load(l, l < pe, si, di, a);
+      (void)step(ok, si, di, a, keep);      // (at the fixed point: changes nothing)
+      record(l, ok, keep);
+    }
+  }
+}
+
 // frames whose links must be re-evaluated because the tokens of the next frame changed since
 // they were last evaluated (or they never were).  One bit per frame in LDS; frames beyond the
 // bitmap always count as dirty.  Thread 0 writes, everybody reads after a barrier.
@@ -862,7 +952,15 @@ VBH_KI __device__ int prune_frame(const Slot &s, int f, float lattice_beam, floa
   const unsigned long long *dbits = d_ok ? sh.dstbits[(f + 1) & 1] : nullptr;
   const int d_tb = sh.dst_tb, d_n = sh.dst_n;
   unsigned long long *mybits = sh.dstbits[f & 1];
-  for (int iter = 0; iter < MAX_EPS_ITERS; iter++) {
+  // VBH_EPS_RELAX (frames with their link minima in LDS): ONE sweep per visit.  The emitting links (their destinations, frame f + 1, do not
+  // move during the visit) leave E(t) = the minimum over a token's emitting links in ltmp; the frame's epsilon links -- a handful per frame
+  // in an HCLG -- are then relaxed on top of that, ltmp[src] = min(ltmp[src], ltmp[dst] + (tot - cost[dst])), until nothing moves: the
+  // same fixed point as sweeping the whole frame again for every level of epsilon links (:300-371 iterates the frame; 1.7 sweeps per visit
+  // measured, each with the latency of a full link pass), reached from above, so every step is an atomicMin.
+  const bool relax = VBH_EPS_RELAX && lds_tmp && (VBH_EPS_RELAX != 2 || pe - pb <= 64);
+  const int iters_max = relax ? 1 : MAX_EPS_ITERS;
+  if (relax && pe - pb > 64 && tid == 0) { sh.sel_prefix = 0; sh.sel_mask = 0; sh.sel_k = 0; }      // relax_eps_links' flags (ordered by the barrier behind the link pass)
+  for (int iter = 0; iter < iters_max; iter++) {
     i32x4 R0[U];            // first round of the token pass, prefetched
     if (lds_tmp) {
 #pragma unroll
@@ -870,9 +968,9 @@ VBH_KI __device__ int prune_frame(const Slot &s, int f, float lattice_beam, floa
     }
     unsigned long long kept;
     if (lds_tmp) {
-      if (one_range) kept = eval_links<true>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 0, 128, dbits, d_tb, d_n, g2, g2_tb);
+      if (one_range) kept = eval_links<true>(elk, pb, ee, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 0, 128, dbits, d_tb, d_n, g2, g2_tb, relax);
       else {
-        kept = eval_links<true>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, pbits, iter > 0, 0, 64);
+        kept = (relax && !pbits) ? 0ull : eval_links<true>(plk, pb, pe, pe, wt, ht, lattice_beam, ltmp, tb, sh, s, pbits, iter > 0, 0, 64, nullptr, 0, 0, nullptr, 0, relax);
         kept += eval_links<true>(elk, eb, ee, eb, wt, ht, lattice_beam, ltmp, tb, sh, s, ebits, iter > 0, 64, 64, dbits, d_tb, d_n, g2, g2_tb);
       }
     } else {
@@ -891,6 +989,10 @@ VBH_KI __device__ int prune_frame(const Slot &s, int f, float lattice_beam, floa
     // entries (read by their consumers before they arrived at the barrier above) are cleared for
     // the following use
     if (tid == 0) { sh.changed2[pp ^ 1] = 0; sh.cnt_tok[pp ^ 1] = 0; sh.cnt_el[pp ^ 1] = 0; sh.cnt_pl[pp ^ 1] = 0; }
+    if (relax && pe > pb) {      // (uniform)
+      relax_eps_links(plk, pb, pe, wt, ht, lattice_beam, ltmp, tb, te, sh, s, pbits, &sh.cnt_pl[pp]);
+      __syncthreads();
+    }
     int ch = 0, alive = 0;
     for (int base = tb; base < te; base += NT * U) {
       i32x4 R[U]; bool ok[U];
@@ -933,7 +1035,7 @@ VBH_KI __device__ int prune_frame(const Slot &s, int f, float lattice_beam, floa
     __syncthreads();
     const int any = sh.changed2[pp];
     // another sweep can only differ if a token that some epsilon link of this frame points to moved
-    const bool last = !(any & 4) || pe == pb;
+    const bool last = relax || !(any & 4) || pe == pb;
     if (last && tid == 0) {
       i32x4 c; c.x = sh.cnt_tok[pp]; c.y = sh.cnt_el[pp]; c.z = sh.cnt_pl[pp]; c.w = 0;
       ((gp<i32x4>)frp)[2] = c;
