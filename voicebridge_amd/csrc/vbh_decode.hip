@@ -185,15 +185,36 @@ constexpr int DSTBITS_WORDS = VBH_DST_BITS ? (VBH_DECODE_NT >= 1024 ? 256 : 64) 
 #ifndef VBH_OUTLINE
 #define VBH_OUTLINE 0          // measured (r02, tools/variants.py): 1 and 2 are 15 % slower -- the call sites cost the hot loop more registers than the callees free
 #endif
+// Which phase functions are functions of their own is NOT left to the inliner (r04).  prune_backward (two call sites, just under the
+// inliner's size threshold) must be part of the kernel: whenever an edit pushed it over the threshold and it became a call, the frame
+// loop's state had to live in the callee-saved registers across it and pass 1's inner loop got the spill code -- the "register
+// lottery" of rounds 2-4 (+35-60 % kernel time from edits that had nothing to do with pass 1; spill instructions by source line:
+// llvm-objdump -l of a -gline-tables-only build).  compact_window and process_nonemitting (two call sites each, far over the
+// threshold) are calls: inlined as well (VBH_INLINE_ALL=3) the kernel is 110 KB and 1 % slower.  Same-box A/B, ms per 1024 x 30 s:
+// this 817-819; everything inlined 826-828; prune_backward and compact_window inlined 831; process_nonemitting inlined and
+// prune_backward a call 1119.
+#ifndef VBH_INLINE_ALL
+#define VBH_INLINE_ALL 0
+#endif
 #if VBH_OUTLINE
 #define VBH_COLD __attribute__((noinline))
+#define VBH_PRUNE_ATTR __attribute__((noinline))
+#elif VBH_INLINE_ALL & 1
+#define VBH_COLD __attribute__((always_inline))
+#define VBH_PRUNE_ATTR __attribute__((always_inline))
 #else
-#define VBH_COLD
+#define VBH_COLD __attribute__((noinline))
+#define VBH_PRUNE_ATTR __attribute__((always_inline))
 #endif
 #if VBH_OUTLINE >= 2
 #define VBH_WARM __attribute__((noinline))
+#define VBH_NONEMIT_ATTR __attribute__((noinline))
+#elif VBH_INLINE_ALL & 2
+#define VBH_WARM __attribute__((always_inline))
+#define VBH_NONEMIT_ATTR __attribute__((always_inline))
 #else
 #define VBH_WARM
+#define VBH_NONEMIT_ATTR __attribute__((noinline))
 #endif
 // The per-phase functions below carry the kernel's template argument (KI, otherwise unused): every instantiation of the kernel then has
 // its own copies with the same callers as when there was one kernel, so the inliner decides for each as it did then -- with shared
@@ -1065,7 +1086,7 @@ VBH_KI __device__ int prune_frame(const Slot &s, int f, float lattice_beam, floa
 // since its last evaluation would be recomputed to the same values.  extra_costs only grow as
 // the frontier advances, so values left stale by an intermediate pass are lower bounds and
 // pruning with them never removes anything the final pass keeps.
-VBH_KI __device__ VBH_COLD void prune_backward(const Slot &s, int from, int first_unpruned, int stop_at, float lattice_beam, float delta,
+VBH_KI __device__ VBH_PRUNE_ATTR void prune_backward(const Slot &s, int from, int first_unpruned, int stop_at, float lattice_beam, float delta,
                                bool final, Shared &sh, int &pp) {
   int visited = 0;
   int above = 3;   // result of the frame above: the frontier counts as changed
@@ -1518,7 +1539,7 @@ __device__ __forceinline__ void map_clear(Shared &sh) {
 #else
 #define EPSTAMP(i)
 #endif
-VBH_KI __device__ VBH_WARM int process_nonemitting(const DevGraph &g, const Slot &s, int nb, float cutoff, unsigned ep,
+VBH_KI __device__ VBH_NONEMIT_ATTR int process_nonemitting(const DevGraph &g, const Slot &s, int nb, float cutoff, unsigned ep,
                                    int cur, Shared &sh, int el_b, int el_e, float lattice_beam, int fpo) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef VBH_DIAG_EPS
