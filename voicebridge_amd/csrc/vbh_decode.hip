@@ -235,11 +235,18 @@ template <class T> using gp = VBH_GLOBAL T *;
 __device__ __forceinline__ float asf(int x) { return __int_as_float(x); }
 __device__ __forceinline__ int asi(float x) { return __float_as_int(x); }
 
+// The graph as the lattice search reads it (VBH_PACKED_GRAPH; built by vbh_graph_create next to the plain arrays the other consumers keep):
+// ONE array of 16-byte records in which a state's record sits directly in front of its arcs, and a state's id IS the index of its record
+// -- st and arcs both point to that array.  Expanding a token then touches one random 64-byte line (record + arcs: a state of this graph
+// has 2 arcs on average; blocks of up to four records never straddle a line, larger ones start one) where the two arrays cost two or three:
+// the search is bound by cache lines in flight per CU, and the graph's gathers were half of its L2 reads.  The ids are
+// monotone in the graph's own, so every tie broken by state id falls as before; the graph's own id rides in the record (ordered admission
+// hashes it, the lattice reports it).
 struct DevGraph {
-  int S, start;
-  const i32x4 *st;      // [S] {first arc, #epsilon arcs, #arcs, final cost bits}
-  const i32x4 *arcs;    // [A] {nextstate | EPSBIT, weight bits, pdf (filled per batch), olabel}; epsilon arcs first
-  const int *arc_il;    // [A] ilabel
+  int S, start;         // records in the array, the start state's
+  const i32x4 *st;      // [S] a state's record: {the graph's own state id, #epsilon arcs, #arcs, final cost bits}; its arcs follow it
+  const i32x4 *arcs;    // [S] an arc: {next state's record | EPSBIT, weight bits, pdf (filled per batch), olabel}; epsilon arcs first
+  const int *arc_il;    // [S] ilabel (-1: not an arc)
 };
 
 struct DecCfg {
@@ -1566,7 +1573,7 @@ VBH_KI __device__ VBH_NONEMIT_ATTR int process_nonemitting(const DevGraph &g, co
       const i32x4 sr = gst[st];
       const float c = have ? map_cost(sh, ent, map_find(sh, st), st) : 0.0f;
       const bool exp = have && !(c > cutoff);
-      const int a0 = sr.x, cnt = exp ? sr.y : 0;
+      const int a0 = st + 1, cnt = exp ? sr.y : 0;      // (a state's arcs follow its record)
       wave_expand(sh.wx[threadIdx.x >> 6], cnt, [&](bool valid, int owner, int j) {
         const int a = __shfl(a0, owner, 64) + j;
         const float cc = __shfl(c, owner, 64);
@@ -1748,7 +1755,7 @@ VBH_KI __device__ VBH_NONEMIT_ATTR int process_nonemitting(const DevGraph &g, co
           else { const i32x4 rec = wt[e]; st = rec.x & STMASK; c = asf(rec.y); src = e; }
         }
         int a0 = 0, cnt = 0;
-        if (have) { const i32x4 sr = gst[st]; a0 = sr.x; cnt = sr.y; }
+        if (have) { const i32x4 sr = gst[st]; a0 = st + 1; cnt = sr.y; }
         wave_expand(sh.wx[threadIdx.x >> 6], cnt, [&](bool valid, int owner, int j) {
           const int a = __shfl(a0, owner, 64) + j;
           const float cc = __shfl(c, owner, 64);
@@ -2135,13 +2142,13 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
           const float c = asf(rec.y);
           const bool exp = c <= cur_cutoff;       // (false for lanes without a token)
           // (the sign bit of the first-arc index marks the frame's best token)
-          const int a0 = (sr.x + sr.y) | ((exp && (rec.x & STMASK) == best_state) ? EPSBIT : 0), cnt = exp ? sr.z - sr.y : 0;
+          const int a0 = ((rec.x & STMASK) + 1 + sr.y) | ((exp && (rec.x & STMASK) == best_state) ? EPSBIT : 0), cnt = exp ? sr.z - sr.y : 0;
           // ordered admission: the token's bucket and, as a filter, its bucket's bound as it stands at the start of the round, in one
           // word for the lanes that expand its arcs: the key with its six low bits giving way to the bucket (read back with those
           // bits set: a bound rounded UP, and an unset bound reads as NaN, which no cost exceeds)
           int bkw = 0;
           if (ADM == VBH_ADMIT_ORDERED) {
-            const int bk = adm_bucket(rec.x & STMASK);
+            const int bk = adm_bucket(sr.x & STMASK);      // (of the graph's own state id: oracle/vb_oracle_decode.c VBO_ADM_BUCKET)
             const unsigned pre = adm_bounds(sh.bmin, &sh.init_bound);
             bkw = (int)(((unsigned)__shfl((int)pre, bk, 64) & ~63u) | (unsigned)bk);
           }
@@ -2482,9 +2489,10 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
             if (in && d >= 0) {
               const long long o = toff + d;
               const int st = r.x & STMASK;
-              pool.tok_frame[o] = f; pool.tok_state[o] = st; pool.tok_cost[o] = asf(r.y); pool.tok_extra[o] = asf(r.z);
+              const i32x4 sr = gst[st];
+              pool.tok_frame[o] = f; pool.tok_state[o] = sr.x; pool.tok_cost[o] = asf(r.y); pool.tok_extra[o] = asf(r.z);      // (the graph's own state id)
               float fin = INF;
-              if (f == F) fin = final_empty ? 0.0f : asf(gst[st].w);
+              if (f == F) fin = final_empty ? 0.0f : asf(sr.w);
               pool.tok_final[o] = fin;
             }
           }
@@ -2588,7 +2596,7 @@ __global__ void fill_arc_pdf_kernel(i32x4 *__restrict__ arcs, const int *__restr
                                     const int *__restrict__ tid2pdf) {
   for (long long a = blockIdx.x * (long long)blockDim.x + threadIdx.x; a < A; a += (long long)gridDim.x * blockDim.x) {
     const int il = arc_il[a];
-    reinterpret_cast<int *>(&arcs[a])[2] = il == 0 ? -1 : tid2pdf[il];
+    if (il >= 0) reinterpret_cast<int *>(&arcs[a])[2] = il == 0 ? -1 : tid2pdf[il];      // (-1: a state's record or padding of the packed array)
   }
 }
 
@@ -2600,8 +2608,11 @@ struct vbh_graph {
   // step), and the context of the thread that happened to build it may be gone by the time the last user lets go of it
   int device;
   int S, start; long long A; int max_ilabel, max_degree;
-  DevBuf<i32x4> st, arcs;      // device records (see DevGraph); arcs are stored epsilon-first within a state
-  DevBuf<int> arc_il;
+  DevBuf<i32x4> st, arcs;      // plain device records ({first arc, #epsilon arcs, #arcs, final cost}, {next state | EPSBIT, weight, pdf, olabel});
+  DevBuf<int> arc_il;          // arcs are stored epsilon-first within a state: what vbh_graph_view shows (the 1-best search, alignment, the decodable seam)
+  DevBuf<i32x4> pk;            // the packed array of the lattice search (DevGraph)
+  DevBuf<int> pk_il;
+  long long PKN = 0; int start_pk = 0;
   // tid2pdf table the arcs' pdf fields currently hold (empty: none) and the searches in flight that read them: decoders on
   // several host threads / streams may share a graph as long as they use the same transition model at the same time
   mutable std::vector<int> filled_t2p;
@@ -2627,6 +2638,7 @@ int vbh_graph_fill_pdf(const vbh_graph *g, hipStream_t st, const int32_t *h_t2p,
   DevBuf<int> d_t2p;
   if (d_t2p.upload(t2p.data(), t2p.size(), st)) return -1;
   hipLaunchKernelGGL(fill_arc_pdf_kernel, dim3(1024), dim3(256), 0, st, g->arcs.p, g->arc_il.p, g->A, d_t2p.p);
+  hipLaunchKernelGGL(fill_arc_pdf_kernel, dim3(1024), dim3(256), 0, st, g->pk.p, g->pk_il.p, g->PKN, d_t2p.p);
   VBH_HIP(hipGetLastError());
   VBH_HIP(hipStreamSynchronize(st));
   g->filled_t2p = t2p;
@@ -2791,7 +2803,7 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
     if (slot_alloc(d, set, sizeof(type) * (size_t)(count) * ns, reinterpret_cast<void **>(&base), ms)) return -1; \
     for (size_t i = 0; i < ns; i++) set->h[i].field = base + i * (size_t)(count);                    \
   }
-  A_(ent, Ent, S, 0xFF)
+  A_(ent, Ent, graph->PKN, 0xFF)      // (indexed by the search's state ids: records of the packed graph)
   A_(w_tok, i32x4, p.w_tok_cap, -2) A_(w_remap, int, p.w_tok_cap, 0) A_(wl, i32x4, p.w_link_cap, -2)
   A_(w_tok_alive, unsigned long long, p.w_tok_cap / 64 + 2, 0) A_(w_lk_alive, unsigned long long, p.w_link_cap / 64 + 2, 0)
   A_(w_grp, unsigned long long, (size_t)GRP_RING * (HCAP / 32), 0)
@@ -2887,12 +2899,41 @@ int vbh_graph_create(vbh_ctx *ctx, int32_t num_states, int32_t start, const floa
       }
     }
   });
+  // the packed array (DevGraph): where every state's record goes -- a block of a record and its arcs that fits a 64-byte line (four
+  // records) does not straddle one, a larger block starts one
+  std::vector<int> pos(num_states);
+  long long pkn = 0;
+  for (int s = 0; s < num_states; s++) {
+    const int k = 1 + (off[s + 1] - off[s]);
+    if ((pkn & 3) + k > 4 && (pkn & 3) != 0) pkn = (pkn + 3) & ~3LL;
+    VBH_CHECK(pkn + k <= (long long)STMASK, "vbh_graph_create: %d states and %lld arcs do not fit the %d records the lattice search's packed graph can address",
+              num_states, A, STMASK);
+    pos[s] = (int)pkn;
+    pkn += k;
+  }
+  std::unique_ptr<i32x4[]> h_pk(new i32x4[(size_t)pkn]);
+  std::unique_ptr<int[]> h_pil(new int[(size_t)pkn]);
+  parallel_states([&](int, int s0, int s1) {
+    for (int s = s0; s < s1; s++) {
+      const int p0 = pos[s], k = off[s + 1] - off[s];
+      i32x4 r = h_st[s]; r.x = s;
+      h_pk[p0] = r; h_pil[p0] = -1;
+      for (int j = 0; j < k; j++) {
+        i32x4 x = h_ar[off[s] + j];      // (already epsilon-first)
+        x.x = pos[x.x & STMASK] | (x.x & EPSBIT);
+        h_pk[p0 + 1 + j] = x; h_pil[p0 + 1 + j] = h_il[off[s] + j];
+      }
+      const long long end = s + 1 < num_states ? pos[s + 1] : pkn;
+      for (long long q = (long long)p0 + 1 + k; q < end; q++) { h_pk[q] = i32x4{0, 0, 0, 0}; h_pil[q] = -1; }      // padding: never addressed
+    }
+  });
   vbh_graph *g = new vbh_graph();
   g->device = ctx->device; g->S = num_states; g->start = start; g->A = A; g->max_ilabel = max_il; g->max_degree = max_deg;
+  g->PKN = pkn; g->start_pk = pos[start];
   g->h_final.assign(h_final, h_final + num_states);
   hipStream_t st = ctx->stream;
   if (g->st.upload(h_st.data(), h_st.size(), st) || g->arcs.upload(h_ar.get(), An, st) ||
-      g->arc_il.upload(h_il.get(), An, st)) { delete g; return -1; }
+      g->arc_il.upload(h_il.get(), An, st) || g->pk.upload(h_pk.get(), (size_t)pkn, st) || g->pk_il.upload(h_pil.get(), (size_t)pkn, st)) { delete g; return -1; }
   VBH_HIP(hipStreamSynchronize(st));
   *out = g;
   return 0;
@@ -3200,7 +3241,7 @@ static int decode_batch_begin_impl(vbh_decoder *d, const float *d_loglikes, int3
   d->pend.holds_pdf = true;
   DevBuf<Pool> &d_pool = d->d_pool;
   if (!d_pool.p && d_pool.alloc(1)) return -1;
-  const DevGraph dg0{g->S, g->start, g->st.p, g->arcs.p, g->arc_il.p};
+  const DevGraph dg0{(int)g->PKN, g->start_pk, g->pk.p, g->pk.p, g->pk_il.p};
   const DecCfg dc0{d->cfg.beam, d->cfg.lattice_beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active, effective_prune_interval(&d->cfg), getenv("VBH_NO_LDS_MAP") ? 0 : 1,
                       getenv("VBH_PRUNE_BACK") ? std::max(0, atoi(getenv("VBH_PRUNE_BACK"))) : effective_prune_interval(&d->cfg)};
   // Optional longest-first order for the persistent grid (VBH_LPT_PROBE_FRAMES=n, off by default).
