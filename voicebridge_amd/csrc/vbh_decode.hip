@@ -234,6 +234,19 @@ template <class T> using gp = VBH_GLOBAL T *;
 
 __device__ __forceinline__ float asf(int x) { return __int_as_float(x); }
 __device__ __forceinline__ int asi(float x) { return __float_as_int(x); }
+// Cache policy (VBH_NT_GRAPH / VBH_NT_LINKS): a record of the graph is read once per expansion out of hundreds of megabytes, a link is written
+// once and read a pruning interval later -- neither should push the frame's candidates and tokens, read back within the frame, out of L2
+#ifndef VBH_NT_GRAPH
+#define VBH_NT_GRAPH 0
+#endif
+#ifndef VBH_NT_LINKS
+#define VBH_NT_LINKS 1
+#endif
+#ifndef VBH_NT_PRUNE
+#define VBH_NT_PRUNE 0
+#endif
+__device__ __forceinline__ i32x4 ld_graph(gp<const i32x4> p) { return VBH_NT_GRAPH ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void st_link(gp<i32x4> p, i32x4 v) { if (VBH_NT_LINKS) __builtin_nontemporal_store(v, p); else *p = v; }
 
 // The graph as the lattice search reads it (VBH_PACKED_GRAPH; built by vbh_graph_create next to the plain arrays the other consumers keep):
 // ONE array of 16-byte records in which a state's record sits directly in front of its arcs, and a state's id IS the index of its record
@@ -742,7 +755,7 @@ __device__ __forceinline__ unsigned long long eval_links(gp<i32x4> lk, int lb, i
         const unsigned long long word = wfirst < le_ ? (wi < lds_cap ? lbits[wi] : alive_bits[wfirst >> 6]) : 0ull;
         okx[u] = okx[u] && ((word >> ((int)threadIdx.x & 63)) & 1ull);
       }
-      Lx[u] = lk[okx[u] ? l : lb];
+      Lx[u] = VBH_NT_PRUNE ? __builtin_nontemporal_load(lk + (okx[u] ? l : lb)) : lk[okx[u] ? l : lb];
     }
   };
 #if VBH_LINK_PF
@@ -2128,7 +2141,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
           if (b < n) { const i32x4 t_ = tok[(lane < CH && i_ < n) ? i_ : 0]; if (lane < CH && i_ < n) { r_.x = t_.x; r_.y = t_.y; } }
           return r_;
         };
-        auto ld_st = [&](const i32x2 &r_) -> i32x4 { return gst[(asf(r_.y) <= cur_cutoff) ? (r_.x & STMASK) : 0]; };
+        auto ld_st = [&](const i32x2 &r_) -> i32x4 { return ld_graph(gst + ((asf(r_.y) <= cur_cutoff) ? (r_.x & STMASK) : 0)); };
         const int b0 = wave * CH;
         i32x2 recC = ld_tok(b0), recB = ld_tok(b0 + RS);
         i32x4 srC = ld_st(recC);
@@ -2164,7 +2177,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
               bko[u] = (ADM == VBH_ADMIT_ORDERED && !VBH_ADM_LATE) ? __shfl(bkw, owner[u], 64) : 0;
             }
 #pragma unroll
-            for (int u = 0; u < UA; u++) arc[u] = garcs[valid[u] ? a[u] : 0];
+            for (int u = 0; u < UA; u++) arc[u] = ld_graph(garcs + (valid[u] ? a[u] : 0));
             P1STAMP(2)
 #pragma unroll
             for (int u = 0; u < UA; u++) sc[u] = cfg.acwt * llrow[valid[u] ? arc[u].z : 0];
@@ -2310,7 +2323,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
             if (adm[u]) {
               if (lq[u] < w_link_cap) {
                 i32x4 r; r.x = (tb + CA[u].z) | enc; r.y = slot[u] >= 0 ? slot[u] : -1 - (CA[u].w & STMASK); r.z = CA[u].x; r.w = CA[u].y;
-                wl[lq[u]] = r;
+                st_link(wl + lq[u], r);
               } else sh.error = ERR_W_LINK;
             }
           }
