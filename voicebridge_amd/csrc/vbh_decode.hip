@@ -24,7 +24,7 @@
 //   * streaming passes (candidates, links, tokens, compaction) are unrolled U times with all
 //     loads issued before the first use.
 // Per workgroup ("slot") HBM holds
-//   * ent[S] = {key, tokid}: key = (epoch | order-preserving bits of the best cost reaching
+//   * ent[records of the packed graph, DevGraph] = {key, tokid}: key = (epoch | order-preserving bits of the best cost reaching
 //     the state this frame), updated with one 64-bit atomicMin whose return value tells the
 //     thread whether it is the first to reach the state (then it creates the token).  The
 //     epoch (frame counter) in the high word makes entries of older frames lose every
@@ -269,7 +269,7 @@ struct DecCfg {
   int prune_back;       // frames an intermediate pruning pass may walk back beyond the unpruned window
 };
 
-struct Ent { unsigned long long key; int tokid; int pad; };   // per graph state
+struct Ent { unsigned long long key; int tokid; int pad; };   // per record of the packed graph (indexed by the search's state ids)
 
 struct FrameRec {
   int tok_b, tok_e;     // tokens of this frame (frame_plus_one index)
@@ -2805,7 +2805,7 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
                                         std::min<long long>((ma + 256) * std::max(graph->max_degree, 1),
                                                             big ? (1LL << 24) : (long long)((1LL << 21) * std::min(1.0, slot_scale))));
   set->proto = p; set->n = n;
-  set->device = d->ctx->device; set->max_frames = max_frames; set->graph_states = graph->S; set->cfg = *cfg;
+  set->device = d->ctx->device; set->max_frames = max_frames; set->graph_states = (int)graph->PKN; set->cfg = *cfg;      // (what the slots' second-level maps are sized by: records of the packed graph)
   set->h.assign(n, p);
   const size_t F = (size_t)max_frames + 2;
   // one allocation per field, covering all slots (slot i owns [i*count, (i+1)*count))
@@ -2973,7 +2973,7 @@ int vbh_decoder_create_shared(vbh_ctx *ctx, const vbh_graph *graph, const vbh_de
   d->ctx = ctx; d->graph = graph; d->cfg = *cfg; d->max_frames = max_frames;
   if (share_slots_with) {
     const SlotSet *o = share_slots_with->small_set.get();
-    const bool ok = o && o->device == ctx->device && o->graph_states == graph->S && o->max_frames >= max_frames &&
+    const bool ok = o && o->device == ctx->device && o->graph_states == (int)graph->PKN && o->max_frames >= max_frames &&
                     o->cfg.max_active >= cfg->max_active && effective_prune_interval(&o->cfg) == effective_prune_interval(cfg);
     if (!ok) { delete d; vbh_set_error("vbh_decoder_create_shared: the other decoder's search slots do not fit (device, graph size, max_frames, max_active or pruning interval differ)"); return -1; }
     d->small_set = share_slots_with->small_set;
@@ -2995,7 +2995,7 @@ int vbh_decoder_create_shared(vbh_ctx *ctx, const vbh_graph *graph, const vbh_de
     for (auto it = g_pools.begin(); it != g_pools.end();) {
       std::shared_ptr<SlotSet> o = it->lock();
       if (!o) { it = g_pools.erase(it); continue; }
-      if (o->device == ctx->device && o->graph_states == graph->S && o->max_frames >= max_frames && o->cfg.max_active >= cfg->max_active &&
+      if (o->device == ctx->device && o->graph_states == (int)graph->PKN && o->max_frames >= max_frames && o->cfg.max_active >= cfg->max_active &&
           effective_prune_interval(&o->cfg) == effective_prune_interval(cfg) && o->n >= want_n) {
         d->small_set = o;
         *out = d;
