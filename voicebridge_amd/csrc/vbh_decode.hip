@@ -24,7 +24,7 @@
 //   * streaming passes (candidates, links, tokens, compaction) are unrolled U times with all
 //     loads issued before the first use.
 // Per workgroup ("slot") HBM holds
-//   * ent[records of the packed graph, DevGraph] = {key, tokid}: key = (epoch | order-preserving bits of the best cost reaching
+//   * ent[records of the packed graph / 2] = {key, tokid} (EntMap): key = (epoch | order-preserving bits of the best cost reaching
 //     the state this frame), updated with one 64-bit atomicMin whose return value tells the
 //     thread whether it is the first to reach the state (then it creates the token).  The
 //     epoch (frame counter) in the high word makes entries of older frames lose every
@@ -269,7 +269,16 @@ struct DecCfg {
   int prune_back;       // frames an intermediate pruning pass may walk back beyond the unpruned window
 };
 
-struct Ent { unsigned long long key; int tokid; int pad; };   // per record of the packed graph (indexed by the search's state ids)
+struct Ent { unsigned long long key; int tokid; int pad; };   // per graph state
+// The second level of the state map.  The search's state ids are record indices of the packed graph (DevGraph), in which every state
+// takes at least two records (vbh_graph_create pads a state without arcs): id >> 1 is unique per state, and the map has half as many
+// entries as the graph has records -- about twice the number of states, where one per record would be four times.  (Found through the
+// state's record instead, which carries the graph's own id: one entry per state, and 1.4 % of the kernel for the gather's place in pass 2
+// -- 807 against 794-797 ms -- although only states that found no room in the LDS map take that path.)
+struct EntMap {
+  gp<Ent> e;
+  __device__ __forceinline__ VBH_GLOBAL Ent &operator[](int id) const { return e[id >> 1]; }
+};
 
 struct FrameRec {
   int tok_b, tok_e;     // tokens of this frame (frame_plus_one index)
@@ -1472,7 +1481,7 @@ __device__ __forceinline__ int map_find(const Shared &sh, int st) {     // slot,
 }
 // lower the cost of the state dsraw & STMASK to tot (dsraw: the arc's next-state field, EPSBIT included).  slot: first-level
 // slot or -1; create: this thread is the first to reach the state in this frame; improved: the cost went down.
-__device__ __forceinline__ void map_relax(Shared &sh, gp<Ent> ent, int dsraw, float tot, unsigned ep, int &slot, bool &create,
+__device__ __forceinline__ void map_relax(Shared &sh, const EntMap &ent, int dsraw, float tot, unsigned ep, int &slot, bool &create,
                                           bool &improved) {
   const unsigned ck = f2o(tot);
   const int ds = dsraw & STMASK;
@@ -1507,11 +1516,11 @@ __device__ __forceinline__ void map_relax(Shared &sh, gp<Ent> ent, int dsraw, fl
     improved = create || nk < old;
   }
 }
-__device__ __forceinline__ float map_cost(const Shared &sh, gp<const Ent> ent, int slot, int st) {
+__device__ __forceinline__ float map_cost(const Shared &sh, const EntMap &ent, int slot, int st) {
   return slot >= 0 ? o2f(map_key(sh)[slot]) : o2f((unsigned)ld_u64(&ent[st].key));
 }
 // token of a state, frame-relative for first-level states (valid after slot_scan), absolute window index for second-level ones
-__device__ __forceinline__ int map_tok(const Shared &sh, gp<const Ent> ent, int slot, int st, int nb) {
+__device__ __forceinline__ int map_tok(const Shared &sh, const EntMap &ent, int slot, int st, int nb) {
   if (slot < 0) return ld_i32(&ent[st].tokid);
   const uint2 gq = sh.grp[slot >> 5];
   return nb + (int)gq.y + __popc(gq.x & ((1u << (slot & 31)) - 1u));
@@ -1565,9 +1574,9 @@ VBH_KI __device__ VBH_NONEMIT_ATTR int process_nonemitting(const DevGraph &g, co
 #ifdef VBH_DIAG_EPS
   if (tid == 0) sh.ep_last = clk();
 #endif
-  gp<Ent> ent = uptr(s.ent);
   gp<i32x4> wt = uptr(s.w_tok);
   gp<const i32x4> gst = (gp<const i32x4>)g.st, garcs = (gp<const i32x4>)g.arcs;      // (global, not generic: no FLAT accesses)
+  const EntMap ent{uptr(s.ent)};
   const int w_tok_cap = s.w_tok_cap, front_cap = s.front_cap;
   for (int iter = 0;; iter++) {
     const int ncur = sh.fcnt[cur] < FCAP + front_cap ? sh.fcnt[cur] : FCAP + front_cap;
@@ -1959,11 +1968,12 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         const i32x4 sr = gst[g.start];
         int slot; bool create, improved;
         const int sraw = g.start | (sr.y > 0 ? EPSBIT : 0);
-        map_relax(sh, gptr(s.ent), sraw, 0.0f, ep, slot, create, improved);
+        const EntMap ent0{gptr(s.ent)};
+        map_relax(sh, ent0, sraw, 0.0f, ep, slot, create, improved);
         if (slot < 0) {        // second-level state: its token is made here (first-level ones by the slot scan)
           i32x4 r; r.x = sraw; r.y = 0; r.z = 0; r.w = (int)INF_BITS;
           gptr(s.w_tok)[0] = r;
-          st_i32(&gptr(s.ent)[g.start].tokid, 0);
+          st_i32(&ent0[g.start].tokid, 0);
           sh.w_ntok = 1;
         }
         if (sr.y > 0) { front_push(sh, gptr(s.front[0]), s.front_cap, 0, 0, g.start); sh.fcnt[0] = 1; }
@@ -2264,7 +2274,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       //      the state), and the forward link (:765-767) is written with a provisional destination -- map slot, or -1 - state
       //      for a second-level state -- that process_nonemitting replaces by the token once tokens are numbered
       {
-        gp<Ent> ent = uptr(s.ent);
+        const EntMap ent{uptr(s.ent)};
         gp<i32x4> wt = uptr(s.w_tok);
         gp<int> front0 = uptr(s.front[0]);
         gp<i32x4> wl = uptr(s.wl);
@@ -2805,7 +2815,7 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
                                         std::min<long long>((ma + 256) * std::max(graph->max_degree, 1),
                                                             big ? (1LL << 24) : (long long)((1LL << 21) * std::min(1.0, slot_scale))));
   set->proto = p; set->n = n;
-  set->device = d->ctx->device; set->max_frames = max_frames; set->graph_states = (int)graph->PKN; set->cfg = *cfg;      // (what the slots' second-level maps are sized by: records of the packed graph)
+  set->device = d->ctx->device; set->max_frames = max_frames; set->graph_states = (int)(graph->PKN / 2 + 1); set->cfg = *cfg;      // (what the slots' second-level maps are sized by)
   set->h.assign(n, p);
   const size_t F = (size_t)max_frames + 2;
   // one allocation per field, covering all slots (slot i owns [i*count, (i+1)*count))
@@ -2816,7 +2826,7 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
     if (slot_alloc(d, set, sizeof(type) * (size_t)(count) * ns, reinterpret_cast<void **>(&base), ms)) return -1; \
     for (size_t i = 0; i < ns; i++) set->h[i].field = base + i * (size_t)(count);                    \
   }
-  A_(ent, Ent, graph->PKN, 0xFF)      // (indexed by the search's state ids: records of the packed graph)
+  A_(ent, Ent, graph->PKN / 2 + 1, 0xFF)      // (EntMap)
   A_(w_tok, i32x4, p.w_tok_cap, -2) A_(w_remap, int, p.w_tok_cap, 0) A_(wl, i32x4, p.w_link_cap, -2)
   A_(w_tok_alive, unsigned long long, p.w_tok_cap / 64 + 2, 0) A_(w_lk_alive, unsigned long long, p.w_link_cap / 64 + 2, 0)
   A_(w_grp, unsigned long long, (size_t)GRP_RING * (HCAP / 32), 0)
@@ -2917,7 +2927,7 @@ int vbh_graph_create(vbh_ctx *ctx, int32_t num_states, int32_t start, const floa
   std::vector<int> pos(num_states);
   long long pkn = 0;
   for (int s = 0; s < num_states; s++) {
-    const int k = 1 + (off[s + 1] - off[s]);
+    const int k = std::max(2, 1 + (off[s + 1] - off[s]));      // (at least two records: EntMap)
     if ((pkn & 3) + k > 4 && (pkn & 3) != 0) pkn = (pkn + 3) & ~3LL;
     VBH_CHECK(pkn + k <= (long long)STMASK, "vbh_graph_create: %d states and %lld arcs do not fit the %d records the lattice search's packed graph can address",
               num_states, A, STMASK);
@@ -2973,7 +2983,7 @@ int vbh_decoder_create_shared(vbh_ctx *ctx, const vbh_graph *graph, const vbh_de
   d->ctx = ctx; d->graph = graph; d->cfg = *cfg; d->max_frames = max_frames;
   if (share_slots_with) {
     const SlotSet *o = share_slots_with->small_set.get();
-    const bool ok = o && o->device == ctx->device && o->graph_states == (int)graph->PKN && o->max_frames >= max_frames &&
+    const bool ok = o && o->device == ctx->device && o->graph_states == (int)(graph->PKN / 2 + 1) && o->max_frames >= max_frames &&
                     o->cfg.max_active >= cfg->max_active && effective_prune_interval(&o->cfg) == effective_prune_interval(cfg);
     if (!ok) { delete d; vbh_set_error("vbh_decoder_create_shared: the other decoder's search slots do not fit (device, graph size, max_frames, max_active or pruning interval differ)"); return -1; }
     d->small_set = share_slots_with->small_set;
@@ -2995,7 +3005,7 @@ int vbh_decoder_create_shared(vbh_ctx *ctx, const vbh_graph *graph, const vbh_de
     for (auto it = g_pools.begin(); it != g_pools.end();) {
       std::shared_ptr<SlotSet> o = it->lock();
       if (!o) { it = g_pools.erase(it); continue; }
-      if (o->device == ctx->device && o->graph_states == (int)graph->PKN && o->max_frames >= max_frames && o->cfg.max_active >= cfg->max_active &&
+      if (o->device == ctx->device && o->graph_states == (int)(graph->PKN / 2 + 1) && o->max_frames >= max_frames && o->cfg.max_active >= cfg->max_active &&
           effective_prune_interval(&o->cfg) == effective_prune_interval(cfg) && o->n >= want_n) {
         d->small_set = o;
         *out = d;
