@@ -119,6 +119,73 @@ def test_decode_batch_vs_oracle(ctx, S, P, T, seed, cfg, adm):
     dec.close(); graph.close()
 
 
+def irregular_graph(seed):
+    """a synthetic graph bent into the shapes its generator does not make (out-degrees 2-5, start 0): states WITHOUT arcs (final sinks),
+    chains of one-arc states, a hub with 45 arcs, and a start state that is not state 0"""
+    from voicebridge_amd import synth
+    S, ntid = 3000, 3 * 48
+    g = synth.decoding_graph(S, ntid, seed=seed, num_words=120, eps_frac=0.25)
+    rng = np.random.default_rng(seed)
+    off, arcs, final = g["arc_offset"], g["arcs"], g["final"].copy()
+    lists = [list(arcs[off[s]:off[s + 1]]) for s in range(S)]
+    sinks = rng.choice(np.arange(50, S), 150, replace=False)
+    for s in sinks:
+        lists[s] = []
+        final[s] = np.float32(rng.uniform(0.0, 2.0))
+    for s in rng.choice(np.setdiff1d(np.arange(50, S), sinks), 300, replace=False):
+        lists[s] = lists[s][:1]
+    hub = 17
+    extra = np.zeros(45, arcs.dtype)
+    extra["ilabel"] = rng.integers(1, ntid + 1, 45); extra["olabel"] = rng.integers(0, 120, 45)
+    extra["weight"] = rng.uniform(0.1, 3.0, 45).astype(np.float32); extra["nextstate"] = rng.integers(0, S, 45)
+    lists[hub] = list(extra)
+    for k in range(6):      # the first states lead to the hub, so that it is reached
+        a = lists[k][0].copy(); a["nextstate"] = hub; lists[k][0] = a
+    # the start state becomes state 1234: states 0 and 1234 trade numbers
+    perm = np.arange(S); perm[0], perm[1234] = 1234, 0
+    new_lists = [None] * S
+    for s in range(S):
+        out = []
+        for a in lists[s]:
+            b = a.copy(); b["nextstate"] = perm[a["nextstate"]]; out.append(b)
+        new_lists[perm[s]] = out
+    new_final = np.empty_like(final); new_final[perm] = final
+    new_off = np.zeros(S + 1, np.int64); new_off[1:] = np.cumsum([len(l) for l in new_lists])
+    new_arcs = np.array([a for l in new_lists for a in l], dtype=arcs.dtype)
+    return dict(final=new_final, arc_offset=new_off, arcs=new_arcs, start=1234), synth.tid2pdf(ntid, 48, seed=seed)
+
+
+@pytest.mark.parametrize("adm", ADMISSIONS)
+@pytest.mark.parametrize("lds_map", [True, False])
+def test_irregular_graph_shapes(ctx, monkeypatch, adm, lds_map):
+    """the packed graph of the lattice search (a state's record in front of its arcs, ids = record indices, blocks that do not straddle
+    lines, at least two records per state): states without arcs, one-arc chains, a 45-arc hub, a start state other than 0 -- and the
+    states the lattice reports are the graph's own"""
+    import torch
+    from oracle import vbo
+    from voicebridge_amd import api
+    if not lds_map:
+        monkeypatch.setenv("VBH_NO_LDS_MAP", "1")
+    g, t2p = irregular_graph(7)
+    deg = np.diff(g["arc_offset"])
+    assert (deg == 0).sum() >= 100 and (deg == 1).sum() >= 100 and deg.max() == 45 and g["start"] != 0
+    rng = np.random.default_rng(11)
+    T, P = 80, 48
+    ll = (rng.standard_normal((T, P)) * 20.0 - 60.0).astype(np.float32)
+    cfg = dict(beam=12.0, max_active=1500, min_active=100, lattice_beam=6.0, prune_interval=9)
+    graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], g["start"])
+    dec = api.LatticeDecoder(ctx, graph, 1, T, admission=adm, **cfg)
+    d = torch.from_numpy(ll).to(ctx.device)
+    ctx.torch_sync()
+    dec.decode(d, [0, T], t2p)
+    got = dec.result(0)
+    fst = vbo.make_fst(g["final"], g["arc_offset"], g["arcs"], g["start"])
+    ref = vbo.decode_lattice_faster(fst, ll, t2p, **ORACLE_ADMISSION[adm], **cfg)
+    assert_same_lattice(got, ref)
+    assert got["tok_state"].max() < len(g["final"]) and len(got["tok_state"]) > T
+    dec.close(); graph.close()
+
+
 @pytest.mark.parametrize("every", [3, 7, 25])
 @pytest.mark.parametrize("lds_map", [True, False])
 def test_decode_independent_of_pruning_schedule(ctx, monkeypatch, every, lds_map):
