@@ -248,7 +248,7 @@ __device__ __forceinline__ int asi(float x) { return __float_as_int(x); }
 __device__ __forceinline__ i32x4 ld_graph(gp<const i32x4> p) { return VBH_NT_GRAPH ? __builtin_nontemporal_load(p) : *p; }
 __device__ __forceinline__ void st_link(gp<i32x4> p, i32x4 v) { if (VBH_NT_LINKS) __builtin_nontemporal_store(v, p); else *p = v; }
 
-// The graph as the lattice search reads it (VBH_PACKED_GRAPH; built by vbh_graph_create next to the plain arrays the other consumers keep):
+// The graph as the searches read it (built by vbh_graph_create; the 1-best search, vbh_faster.hip, reads the same arrays):
 // ONE array of 16-byte records in which a state's record sits directly in front of its arcs, and a state's id IS the index of its record
 // -- st and arcs both point to that array.  Expanding a token then touches one random 64-byte line (record + arcs: a state of this graph
 // has 2 arcs on average; blocks of up to four records never straddle a line, larger ones start one) where the two arrays cost two or three:
@@ -2631,11 +2631,10 @@ struct vbh_graph {
   // step), and the context of the thread that happened to build it may be gone by the time the last user lets go of it
   int device;
   int S, start; long long A; int max_ilabel, max_degree;
-  DevBuf<i32x4> st, arcs;      // plain device records ({first arc, #epsilon arcs, #arcs, final cost}, {next state | EPSBIT, weight, pdf, olabel});
-  DevBuf<int> arc_il;          // arcs are stored epsilon-first within a state: what vbh_graph_view shows (the 1-best search, alignment, the decodable seam)
-  DevBuf<i32x4> pk;            // the packed array of the lattice search (DevGraph)
-  DevBuf<int> pk_il;
+  DevBuf<i32x4> pk;            // the packed array (DevGraph): what both searches read
+  DevBuf<int> pk_il;           // an arc's ilabel (-1: a state's record or padding)
   long long PKN = 0; int start_pk = 0;
+  std::vector<int> h_pos;      // [S] a state's record in the packed array (per-utterance start states of the 1-best search are translated on the host)
   // tid2pdf table the arcs' pdf fields currently hold (empty: none) and the searches in flight that read them: decoders on
   // several host threads / streams may share a graph as long as they use the same transition model at the same time
   mutable std::vector<int> filled_t2p;
@@ -2646,7 +2645,7 @@ struct vbh_graph {
 
 void vbh_graph_view_get(const vbh_graph *g, vbh_graph_view *v) {
   v->S = g->S; v->start = g->start; v->A = g->A; v->max_ilabel = g->max_ilabel; v->max_degree = g->max_degree;
-  v->st = g->st.p; v->arcs = g->arcs.p; v->arc_il = g->arc_il.p;
+  v->PKN = g->PKN; v->start_pk = g->start_pk; v->pk = g->pk.p; v->pk_il = g->pk_il.p; v->h_pos = g->h_pos.data();
 }
 
 // The arcs' pdf fields depend on tid2pdf only: refill when the table changes.  A search that reads them holds a use count
@@ -2660,7 +2659,6 @@ int vbh_graph_fill_pdf(const vbh_graph *g, hipStream_t st, const int32_t *h_t2p,
                                "vbh_graph must use one table at a time");
   DevBuf<int> d_t2p;
   if (d_t2p.upload(t2p.data(), t2p.size(), st)) return -1;
-  hipLaunchKernelGGL(fill_arc_pdf_kernel, dim3(1024), dim3(256), 0, st, g->arcs.p, g->arc_il.p, g->A, d_t2p.p);
   hipLaunchKernelGGL(fill_arc_pdf_kernel, dim3(1024), dim3(256), 0, st, g->pk.p, g->pk_il.p, g->PKN, d_t2p.p);
   VBH_HIP(hipGetLastError());
   VBH_HIP(hipStreamSynchronize(st));
@@ -2952,11 +2950,10 @@ int vbh_graph_create(vbh_ctx *ctx, int32_t num_states, int32_t start, const floa
   });
   vbh_graph *g = new vbh_graph();
   g->device = ctx->device; g->S = num_states; g->start = start; g->A = A; g->max_ilabel = max_il; g->max_degree = max_deg;
-  g->PKN = pkn; g->start_pk = pos[start];
+  g->PKN = pkn; g->start_pk = pos[start]; g->h_pos = pos;
   g->h_final.assign(h_final, h_final + num_states);
   hipStream_t st = ctx->stream;
-  if (g->st.upload(h_st.data(), h_st.size(), st) || g->arcs.upload(h_ar.get(), An, st) ||
-      g->arc_il.upload(h_il.get(), An, st) || g->pk.upload(h_pk.get(), (size_t)pkn, st) || g->pk_il.upload(h_pil.get(), (size_t)pkn, st)) { delete g; return -1; }
+  if (g->pk.upload(h_pk.get(), (size_t)pkn, st) || g->pk_il.upload(h_pil.get(), (size_t)pkn, st)) { delete g; return -1; }
   VBH_HIP(hipStreamSynchronize(st));
   *out = g;
   return 0;

@@ -44,6 +44,9 @@ template <class T> using gp = VBH_GLOBAL T *;
 
 __device__ __forceinline__ float asf(int x) { return __int_as_float(x); }
 
+// The packed graph of vbh_decode.hip (DevGraph): st and arcs are ONE array of 16-byte records, a state's record {the graph's own state id,
+// #epsilon arcs, #arcs, final cost} directly in front of its arcs (epsilon arcs first), a state's id = the index of its record, an arc's
+// next state = that state's record.  Ids are monotone in the graph's own, arc positions in the plain arc numbering: ties fall as before.
 struct FGraph { int S, start; const i32x4 *st; const i32x4 *arcs; const int *arc_il; };
 struct FCfg { float beam, beam_delta, acwt; int max_active, min_active; };
 
@@ -512,7 +515,7 @@ __device__ void epsilon_closure(const FGraph &g, const FSlot &s, double cutoff, 
       const int slot = have ? map_find(sh, m2, st) : -1;
       const double c = slot != -1 ? o2d(map_key(sh, m2, slot)) : 0.0;
       const bool exp = have && slot != -1 && !(c > cutoff);
-      const int a0 = sr.x, cnt = exp ? sr.y : 0;
+      const int a0 = st + 1, cnt = exp ? sr.y : 0;      // (a state's arcs follow its record)
       wave_expand(sh.wx[threadIdx.x >> 6], cnt, [&](bool valid, int owner, int j) {
         const int a = __shfl(a0, owner, 64) + j;
         const double cc = __shfl(c, owner, 64);
@@ -573,7 +576,7 @@ __device__ void epsilon_winners(const FGraph &g, const FSlot &s, double cutoff, 
     const int slot = have ? map_find(sh, m2, st) : -1;
     const double c = slot != -1 ? o2d(map_key(sh, m2, slot)) : 0.0;
     const bool exp = have && slot != -1 && !(c > cutoff);
-    const int a0 = sr.x, cnt = exp ? sr.y : 0;
+    const int a0 = st + 1, cnt = exp ? sr.y : 0;
     const int my_tok = exp ? tok_base + map_idx(sh, m2, slot) : 0;
     wave_expand(sh.wx[threadIdx.x >> 6], cnt, [&](bool valid, int owner, int j) {
       const int a = __shfl(a0, owner, 64) + j;
@@ -793,7 +796,7 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
           const double c = ccost[have ? i : 0];
           const bool exp = have && c < weight_cutoff;
           const i32x4 sr = uptr(g.st)[exp ? (rec.z & STMASK) : 0];
-          const int a0 = sr.x + sr.y, cnt = exp ? sr.z - sr.y : 0;
+          const int a0 = (rec.z & STMASK) + 1 + sr.y, cnt = exp ? sr.z - sr.y : 0;
           wave_expand(sh.wx[threadIdx.x >> 6], cnt, [&](bool valid, int owner, int j) {
             const int a = __shfl(a0, owner, 64) + j;
             const double cc = __shfl(c, owner, 64);
@@ -972,7 +975,8 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
     if (tid == 0) {
       FResult *r = &results[utt];
       r->ok = r_ok; r->error = sh.error; r->reached_final = r_final; r->num_frames = frames_done; r->path_len = r_len;
-      r->final_state = r_state; r->final_cost = r_fc; r->pad = 0; r->n_tokens = cur_b + cur_n;
+      r->final_state = r_state >= 0 ? (uptr(g.st)[r_state].x & STMASK) : r_state;      // (the graph's own state id)
+      r->final_cost = r_fc; r->pad = 0; r->n_tokens = cur_b + cur_n;
     }
     __syncthreads();
   }
@@ -1101,14 +1105,14 @@ static int faster_decode_batch_impl(vbh_faster_decoder *d, const float *d_loglik
     const long long T = h_frame_offsets[u + 1] - h_frame_offsets[u];
     VBH_CHECK(T >= 0 && T <= d->max_frames, "vbh_faster_decode_batch: utterance %d has %lld frames (decoder built for %d)", u, T, d->max_frames);
     if (h_start_states) VBH_CHECK(h_start_states[u] >= -1 && h_start_states[u] < gv.S, "vbh_faster_decode_batch: start state %d of utterance %d is not in the graph", h_start_states[u], u);
-    utts[u] = FUtt{h_frame_offsets[u], (int)T, h_start_states ? h_start_states[u] : -1};
+    utts[u] = FUtt{h_frame_offsets[u], (int)T, (h_start_states && h_start_states[u] >= 0) ? gv.h_pos[h_start_states[u]] : -1};
     total += T;
   }
   VBH_CHECK(total == 0 || d_loglikes, "vbh_faster_decode_batch: NULL loglikes");
   hipStream_t st = d->ctx->stream;
   if (vbh_graph_fill_pdf(d->graph, st, h_tid2pdf, num_tids)) return -1;
   *holds_pdf = true;
-  FGraph fg{gv.S, gv.start, static_cast<const i32x4 *>(gv.st), static_cast<const i32x4 *>(gv.arcs), gv.arc_il};
+  FGraph fg{(int)gv.PKN, gv.start_pk, static_cast<const i32x4 *>(gv.pk), static_cast<const i32x4 *>(gv.pk), gv.pk_il};
   FCfg fc{beam > 0.0f ? beam : d->cfg.beam, d->cfg.beam_delta, d->cfg.acoustic_scale, d->cfg.max_active, d->cfg.min_active};
   std::vector<FResult> res(n_utt);
   d->results.resize(n_utt);

@@ -136,7 +136,10 @@ struct ScratchBuf {
 // weight, pdf, olabel}, eps arcs first within a state) and the ilabels
 struct vbh_graph_view {
   int S, start; long long A; int max_ilabel, max_degree;
-  const void *st; const void *arcs; const int *arc_il;
+  // the device graph (vbh_decode.hip, DevGraph): one array of 16-byte records, a state's record {the graph's own id, #epsilon arcs,
+  // #arcs, final cost} directly in front of its arcs, a state's id = the index of its record; pk_il: an arc's ilabel (-1: not an
+  // arc); h_pos[s] (host) = state s's record
+  long long PKN; int start_pk; const void *pk; const int *pk_il; const int *h_pos;
 };
 void vbh_graph_view_get(const vbh_graph *g, vbh_graph_view *v);
 // make the arcs' pdf fields hold h_t2p[ilabel] (no-op when they already do); h_t2p[0] is ignored
