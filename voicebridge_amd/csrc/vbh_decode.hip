@@ -243,8 +243,9 @@ __device__ __forceinline__ int asi(float x) { return __float_as_int(x); }
 #define VBH_NT_LINKS 1
 #endif
 #ifndef VBH_NT_PRUNE
-#define VBH_NT_PRUNE 0
+#define VBH_NT_PRUNE 1         // the pruning sweep's link loads as well (r04, ms per 1024 x 30 s: 790.2-793.2 against 795.2-796.5; profiles/README.md)
 #endif
+
 __device__ __forceinline__ i32x4 ld_graph(gp<const i32x4> p) { return VBH_NT_GRAPH ? __builtin_nontemporal_load(p) : *p; }
 __device__ __forceinline__ void st_link(gp<i32x4> p, i32x4 v) { if (VBH_NT_LINKS) __builtin_nontemporal_store(v, p); else *p = v; }
 
