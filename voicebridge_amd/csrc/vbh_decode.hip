@@ -242,6 +242,12 @@ __device__ __forceinline__ int asi(float x) { return __float_as_int(x); }
 #ifndef VBH_NT_LINKS
 #define VBH_NT_LINKS 1
 #endif
+#ifndef VBH_NT_EPSLINKS
+#define VBH_NT_EPSLINKS 1      // the epsilon links' stores too, and ...
+#endif
+#ifndef VBH_NT_P1TOK
+#define VBH_NT_P1TOK 1         // ... pass 1's token loads (their last reader until a pruning pass); r04, same box, three alternations: 788.0 / 791.4 / 788.4 against 798.4 / 793.7 / 796.4 ms
+#endif
 #ifndef VBH_NT_PRUNE
 #define VBH_NT_PRUNE 1         // the pruning sweep's link loads as well (r04, ms per 1024 x 30 s: 790.2-793.2 against 795.2-796.5; profiles/README.md)
 #endif
@@ -1802,7 +1808,7 @@ VBH_KI __device__ VBH_NONEMIT_ATTR int process_nonemitting(const DevGraph &g, co
           if (mk) {
             if (l < w_link_cap) {
               i32x4 r; r.x = so | WBIT; r.y = dtok | WBIT; r.z = asi(tot); r.w = a;
-              wl[l] = r;
+              if (VBH_NT_EPSLINKS) st_link(wl + l, r); else wl[l] = r;
               (void)__hip_atomic_fetch_or((gp<int>)&wt[dtok], PLDST, __ATOMIC_RELAXED, VBH_RMW_SCOPE);
             } else sh.error = ERR_W_LINK;
           }
@@ -2149,7 +2155,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         auto ld_tok = [&](int b) -> i32x2 {      // {state | flags, cost} of this lane's token of the round starting at b
           const int i_ = b + lane;
           i32x2 r_; r_.x = 0; r_.y = 0x7FC00000;      // (no token: a NaN cost fails every comparison)
-          if (b < n) { const i32x4 t_ = tok[(lane < CH && i_ < n) ? i_ : 0]; if (lane < CH && i_ < n) { r_.x = t_.x; r_.y = t_.y; } }
+          if (b < n) { const i32x4 t_ = VBH_NT_P1TOK ? __builtin_nontemporal_load(tok + ((lane < CH && i_ < n) ? i_ : 0)) : tok[(lane < CH && i_ < n) ? i_ : 0]; if (lane < CH && i_ < n) { r_.x = t_.x; r_.y = t_.y; } }
           return r_;
         };
         auto ld_st = [&](const i32x2 &r_) -> i32x4 { return ld_graph(gst + ((asf(r_.y) <= cur_cutoff) ? (r_.x & STMASK) : 0)); };
