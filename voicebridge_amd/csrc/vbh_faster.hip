@@ -438,9 +438,11 @@ __device__ __forceinline__ void map_relax(Shared &sh, const Map2 &m, int ds, dou
   const unsigned long long oc = __hip_atomic_fetch_min(&m.gc[-slot - 2], ck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   improved = ck < oc;
 }
-// empty map for the next frame (all threads; followed by a barrier at the caller, who then sets g_used = n_g = 0)
-__device__ __forceinline__ void map_clear(Shared &sh, const FSlot &s) {
-  for (int i = threadIdx.x; i < HCAP; i += NT) { sh.hs[i] = HEMPTY; sh.hc[i] = ~0ull; }
+// empty map for the next frame (all threads; followed by a barrier at the caller, who then sets g_used = n_g = 0).  lds_level = false:
+// the second level only -- inside the frame loop make_tokens, the map's last reader, which walks every LDS slot anyway, has left the
+// occupied ones empty (a frame of this search fills 570 of the 8192 slots: writing all of them again was 4 % of a frame)
+__device__ __forceinline__ void map_clear(Shared &sh, const FSlot &s, bool lds_level = true) {
+  if (lds_level) for (int i = threadIdx.x; i < HCAP; i += NT) { sh.hs[i] = HEMPTY; sh.hc[i] = ~0ull; }
   if (sh.g_used) {
     gp<unsigned> gs = uptr(s.g_hs); gp<unsigned long long> gc = uptr(s.g_hc);
     const int ng = sh.n_g;
@@ -611,6 +613,7 @@ __device__ void make_tokens(const FSlot &s, int tok_base, const FCfg &cfg, Share
     const unsigned tag = sh.hs[e];
     have[u] = tag != HEMPTY;
     st[u] = (int)tag; key[u] = sh.hc[e]; li[u] = have[u] ? sh.ht[e] : 0;
+    if (have[u]) { sh.hs[e] = HEMPTY; sh.hc[e] = ~0ull; }      // (this thread was the slot's last reader: map_clear)
   }
 #pragma unroll
   for (int u = 0; u < PER; u++) { w[u] = ~0ull; if (have[u]) w[u] = win[u * NT + threadIdx.x]; }
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
       // (GetCutoff, :151-213: weight_cutoff and adaptive_beam of this frame were computed when its tokens were made)
       FPHASE(1)
       // the map of the frame about to be built
-      map_clear(sh, s);
+      map_clear(sh, s, /*lds_level=*/false);
       __syncthreads();
       if (tid == 0) { sh.n_new = 0; sh.n_cand = 0; sh.n_eps = 0; sh.fcnt[0] = sh.fcnt[1] = sh.fcnt[2] = 0; sh.g_used = 0; sh.n_g = 0; sh.cand_bound = ~0ull; }
       __syncthreads();
