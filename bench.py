@@ -880,7 +880,9 @@ def main():
             if os.environ.get("VBH_PROBE_P1"):
                 print("   pass 1 of wave 0, kilocycles per frame: round top (token/state wait) %.1f, owner search %.1f, arc wait %.1f, score wait %.1f, "
                       "compute + alloc %.1f, stores %.1f, loop exit %.1f, reduction barrier %.1f" % tuple(x / nf / 1e3 for x in dg[:8]))
-            elif any(dg[8:]):
+            elif not (dg[8] or dg[9]):      # (not a -DVBH_DIAG build: [12] = candidates pass 1 wrote)
+                print("   candidates/frame=%.0f (of %.0f arcs expanded; %.0f admitted)" % (dg[12] / nf, r["n_arcs_expanded"] / nf, r["n_links_created"] / nf))
+            else:
                 tot += dg[8] + dg[9]
                 print("   VBH_DIAG: admit %.1f%% links %.1f%% cutoff-up-to-first-reduction %.1f%% rest-of-cutoff %.1f%%; admissions/frame %.0f, to the HBM map %.1f%%; "
                       "frames creating > 3/4 of the LDS map %d, sweeps of the pruning passes %d"

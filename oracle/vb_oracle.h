@@ -197,8 +197,12 @@ typedef struct vbo_faster_cfg {
    * semantics a parallel search implements: next_cutoff takes its final value before anything is
    * admitted; per state the cheapest incoming arc wins, ties go to the smaller arc index; the
    * epsilon closure is taken to its fixed point before tokens are made; ties between final tokens
-   * go to the smaller state id */
+   * go to the smaller state id; 3: the same, but arcs are admitted by the reference's own rule (faster-decoder.cc:266-273: strictly
+   * below the running next_weight_cutoff, which every admitted arc tightens) applied in a canonical order -- arcs leaving tokens of
+   * a lower one of 2^adm_bucket_bits state-hash buckets first, starting from the bound of the best token's arcs (:241-255) -- the
+   * lattice search's mode 3 for this decoder (the GPU's VBH_ADMISSION_ORDERED) */
   int32_t exact_cutoff;
+  int32_t adm_bucket_bits;
 } vbo_faster_cfg;
 void vbo_faster_cfg_default(vbo_faster_cfg *c);
 typedef struct vbo_faster_result {

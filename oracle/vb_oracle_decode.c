@@ -35,7 +35,7 @@ void vbo_lat_cfg_default(vbo_lat_cfg *c) {
 void vbo_faster_cfg_default(vbo_faster_cfg *c) {
   /* faster-decoder.h:38-43 */
   c->beam = 16.0f; c->max_active = INT32_MAX; c->min_active = 20;
-  c->beam_delta = 0.5f; c->hash_ratio = 2.0f; c->exact_cutoff = 0;
+  c->beam_delta = 0.5f; c->hash_ratio = 2.0f; c->exact_cutoff = 0; c->adm_bucket_bits = 6;
 }
 
 /* ------------------------------------------------------------------------------------
@@ -985,8 +985,41 @@ static double fx_process_emitting(fdec *d, fentries *f, int32_t frame) {
   float adaptive_beam; int32_t best_idx;
   const double weight_cutoff = f_get_cutoff(d, l, n, &adaptive_beam, &best_idx);
   double next_cutoff = INFINITY;
+  /* exact_cutoff == 3 (ordered admission, the lattice search's mode 3 for this decoder): the reference's online tightening of
+   * next_weight_cutoff (faster-decoder.cc:266-273) as a prefix minimum over a canonical visiting order -- arcs leaving tokens whose
+   * state falls into a lower one of 2^adm_bucket_bits buckets count as visited earlier -- starting from the bound the best token's
+   * arcs give (:241-255).  pre[b]: what the arcs leaving a token of bucket b are admitted against (strictly below, :266). */
+  const int ordered = d->cfg->exact_cutoff == 3;
+  const int32_t bbits = d->cfg->adm_bucket_bits < 1 ? 1 : (d->cfg->adm_bucket_bits > 20 ? 20 : d->cfg->adm_bucket_bits);
+#define VBO_FADM_BUCKET(state) ((uint32_t)((uint32_t)(state) * 2654435761u) >> (32 - bbits))
+  double *pre = NULL, init_bound = INFINITY;
+  if (ordered) {
+    pre = (double *)malloc(sizeof(double) * ((size_t)1 << bbits));
+    for (size_t b = 0; b < ((size_t)1 << bbits); b++) pre[b] = INFINITY;
+    if (best_idx >= 0) {
+      /* among equal-cost best tokens the smallest state id (the reference: the first in HashList order, :161-166) */
+      const double bw = d->toks[l[best_idx].val].cost;
+      for (int32_t i = 0; i < n; i++)
+        if (d->toks[l[i].val].cost == bw && l[i].state < l[best_idx].state) best_idx = i;
+      const int32_t state = l[best_idx].state, tok = l[best_idx].val;
+      for (int64_t a = fst->arc_offset[state]; a < fst->arc_offset[state + 1]; a++) {
+        const vbo_arc *arc = &fst->arcs[a];
+        if (arc->ilabel == 0) continue;
+        const float ac_cost = -(d->acwt * d->loglikes[(size_t)frame * d->P + d->tid2pdf[arc->ilabel]]);
+        const double new_weight = arc->weight + d->toks[tok].cost + ac_cost;
+        if (new_weight + adaptive_beam < init_bound) init_bound = new_weight + adaptive_beam;
+      }
+    }
+    next_cutoff = init_bound;
+  }
   for (int pass = 0; pass < 2; pass++) {
-    if (pass == 1) fe_clear(f);
+    if (pass == 1) {
+      fe_clear(f);
+      if (ordered) {      /* exclusive prefix minimum over the buckets, from the initial bound */
+        double run = init_bound;
+        for (size_t b = 0; b < ((size_t)1 << bbits); b++) { const double m = pre[b]; pre[b] = run; if (m < run) run = m; }
+      }
+    }
     for (int32_t i = 0; i < n; i++) {
       const int32_t state = l[i].state, tok = l[i].val;
       if (!(d->toks[tok].cost < weight_cutoff)) continue;
@@ -995,11 +1028,16 @@ static double fx_process_emitting(fdec *d, fentries *f, int32_t frame) {
         if (arc->ilabel == 0) continue;
         const float ac_cost = -(d->acwt * d->loglikes[(size_t)frame * d->P + d->tid2pdf[arc->ilabel]]);
         const double new_weight = arc->weight + d->toks[tok].cost + ac_cost;
-        if (pass == 0) { if (new_weight + adaptive_beam < next_cutoff) next_cutoff = new_weight + adaptive_beam; }
-        else if (new_weight < next_cutoff) fe_relax(f, arc->nextstate, new_weight, a, tok, -1);
+        if (pass == 0) {
+          if (new_weight + adaptive_beam < next_cutoff) next_cutoff = new_weight + adaptive_beam;
+          if (ordered && new_weight + adaptive_beam < pre[VBO_FADM_BUCKET(state)]) pre[VBO_FADM_BUCKET(state)] = new_weight + adaptive_beam;
+        }
+        else if (ordered ? new_weight < pre[VBO_FADM_BUCKET(state)] : new_weight < next_cutoff) fe_relax(f, arc->nextstate, new_weight, a, tok, -1);
       }
     }
   }
+#undef VBO_FADM_BUCKET
+  free(pre);
   free(l);
   return next_cutoff;
 }

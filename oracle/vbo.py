@@ -70,7 +70,7 @@ class LatResult(C.Structure):
 
 class FasterCfg(C.Structure):
     _fields_ = [("beam", C.c_float), ("max_active", C.c_int32), ("min_active", C.c_int32),
-                ("beam_delta", C.c_float), ("hash_ratio", C.c_float), ("exact_cutoff", C.c_int32)]
+                ("beam_delta", C.c_float), ("hash_ratio", C.c_float), ("exact_cutoff", C.c_int32), ("adm_bucket_bits", C.c_int32)]
 
 
 class FasterResult(C.Structure):
@@ -283,9 +283,10 @@ def decode_lattice_faster(fst, loglikes, tid2pdf, acwt=0.083333, beam=13.0, max_
 
 
 def decode_faster(fst, loglikes, tid2pdf, acwt=0.083333, beam=13.0, max_active=7000, min_active=20,
-                  beam_delta=0.5, hash_ratio=2.0, exact_cutoff=False):
+                  beam_delta=0.5, hash_ratio=2.0, exact_cutoff=False, adm_bucket_bits=6):
+    """exact_cutoff: False / 0 = the reference's HashList order; True / 1 = order-independent admission; 3 = ordered admission"""
     f, keep = fst
-    cfg = FasterCfg(beam, max_active, min_active, beam_delta, hash_ratio, int(bool(exact_cutoff)))
+    cfg = FasterCfg(beam, max_active, min_active, beam_delta, hash_ratio, int(exact_cutoff), adm_bucket_bits)
     ll = _f32(loglikes)
     T, P = ll.shape
     t2p = np.ascontiguousarray(tid2pdf, np.int32)

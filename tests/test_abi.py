@@ -37,7 +37,7 @@ def test_struct_layouts_match_the_header(lib):
     assert C.sizeof(_lib.FeatPostCfg) == 12 * 4
     assert C.sizeof(_lib.Arc) == 16               # fst::ArcTpl<TropicalWeight>, arc.h:27-36
     assert C.sizeof(_lib.DecodeCfg) == 8 * 4
-    assert lib.vbh_abi_version() == 3      # 2: vbh_best_path grew (r02), vbh_mfcc_opts.dither is applied; 3: vbh_decode_cfg.admission (r04)
+    assert lib.vbh_abi_version() == 4      # 2: vbh_best_path grew (r02), vbh_mfcc_opts.dither is applied; 3: vbh_decode_cfg.admission (r04); 4: vbh_faster_cfg.admission (r05)
     o = _lib.MfccOpts()
     lib.vbh_mfcc_opts_default(C.byref(o))
     # reference defaults (feature-window.h:52-62, feature-mfcc.h:50-59) except dither

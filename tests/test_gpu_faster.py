@@ -1,5 +1,6 @@
-"""GPU parity: FasterDecoder vs the oracle's order-independent mode (bit-exact best path: words,
-alignment, float32 weights) and vs the reference's golden best paths."""
+"""GPU parity: FasterDecoder vs the oracle in the same admission mode -- ordered (the default: the reference's rule in a canonical order,
+oracle exact_cutoff = 3) and exact (the order-independent subset, exact_cutoff = 1) -- bit-exact best path (words, alignment, float32
+weights), and vs the reference's golden best paths."""
 import glob
 import os
 
@@ -12,6 +13,8 @@ from tests.test_gpu_decode import arcs_of, make_case
 pytestmark = pytest.mark.gpu
 
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "decode_*.npz")))
+ORACLE_MODE = {"ordered": 3, "exact": 1}
+ADMS = ("ordered", "exact")
 
 
 @pytest.fixture(scope="module")
@@ -31,8 +34,9 @@ def assert_same_path(got, ref):
     assert np.float32(got["best_acoustic"]) == np.float32(ref["best_acoustic"])
 
 
+@pytest.mark.parametrize("adm", ADMS)
 @pytest.mark.parametrize("name", CASES)
-def test_faster_golden_cases(ctx, name):
+def test_faster_golden_cases(ctx, name, adm):
     import torch
     from oracle import vbo
     from voicebridge_amd import api
@@ -41,20 +45,24 @@ def test_faster_golden_cases(ctx, name):
     arcs = arcs_of(g)
     kw = dict(beam=o["beam"], max_active=int(o["max_active"]), min_active=20)
     ref = vbo.decode_faster(vbo.make_fst(g["fst_final"], g["fst_off"], arcs, 0), g["loglikes"], g["tid2pdf"],
-                            acwt=o["acwt"], exact_cutoff=True, **kw)
+                            acwt=o["acwt"], exact_cutoff=ORACLE_MODE[adm], **kw)
     graph = api.Graph(ctx, g["fst_final"], g["fst_off"], arcs, 0)
     T = g["loglikes"].shape[0]
-    dec = api.FasterDecoder(ctx, graph, 1, T, acoustic_scale=o["acwt"], **kw)
+    dec = api.FasterDecoder(ctx, graph, 1, T, acoustic_scale=o["acwt"], admission=adm, **kw)
     ll = torch.from_numpy(g["loglikes"]).to(ctx.device)
     ctx.torch_sync()
     dec.decode(ll, [0, T], g["tid2pdf"])
     got = dec.result(0)
     assert_same_path(got, ref)
-    # and the reference's own best path (golden vectors from the reference build)
+    dec.close(); graph.close()
+    # and the reference's own best path (golden vectors from the reference build): hard for every case and mode but the one the visiting
+    # order itself decides (tests/test_gpu_decode.py ORDER_DECIDES), where the search must NOT come out as the reference's
+    if (name, adm) == ("decode_g1_maxact", "ordered"):
+        assert not np.array_equal(got["ali"], g["ref_fast_ali"])
+        return
     np.testing.assert_array_equal(got["words"], g["ref_fast_words"])
     np.testing.assert_array_equal(got["ali"], g["ref_fast_ali"])
     np.testing.assert_allclose([got["best_graph"], got["best_acoustic"]], g["ref_fast_best_weight"], rtol=2e-6)
-    dec.close(); graph.close()
 
 
 @pytest.mark.parametrize("S,P,T,seed,cfg", [
@@ -65,7 +73,8 @@ def test_faster_golden_cases(ctx, name):
     (5000, 32, 0, 5, dict(beam=16.0, max_active=7000, min_active=20)),              # empty utterance
     (5000, 32, 1, 6, dict(beam=16.0, max_active=7000, min_active=20)),
 ])
-def test_faster_batch_vs_oracle(ctx, S, P, T, seed, cfg):
+@pytest.mark.parametrize("adm", ADMS)
+def test_faster_batch_vs_oracle(ctx, S, P, T, seed, cfg, adm):
     import torch
     from oracle import vbo
     from voicebridge_amd import api
@@ -75,13 +84,13 @@ def test_faster_batch_vs_oracle(ctx, S, P, T, seed, cfg):
     foff[1:] = np.cumsum(lens)
     batch = np.concatenate([ll[:n] for n in lens]) if sum(lens) else np.zeros((0, P), np.float32)
     graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
-    dec = api.FasterDecoder(ctx, graph, 3, max(lens), **cfg)
+    dec = api.FasterDecoder(ctx, graph, 3, max(lens), admission=adm, **cfg)
     d = torch.from_numpy(np.ascontiguousarray(batch)).to(ctx.device) if len(batch) else torch.zeros((1, P), device=ctx.device)
     ctx.torch_sync()
     dec.decode(d, foff, t2p)
     fst = vbo.make_fst(g["final"], g["arc_offset"], g["arcs"], 0)
     for u, n in enumerate(lens):
-        ref = vbo.decode_faster(fst, ll[:n] if n else np.zeros((0, P), np.float32), t2p, exact_cutoff=True, **cfg)
+        ref = vbo.decode_faster(fst, ll[:n] if n else np.zeros((0, P), np.float32), t2p, exact_cutoff=ORACLE_MODE[adm], **cfg)
         assert_same_path(dec.result(u), ref)
     dec.close(); graph.close()
 
@@ -96,20 +105,21 @@ def test_faster_batch_vs_oracle(ctx, S, P, T, seed, cfg):
     # min-active binds in most frames (a narrow beam under widely spread scores)
     (30000, 64, 80, 9, 40.0, dict(beam=2.0, max_active=5000, min_active=150)),
 ])
-def test_faster_map_spill_ties_and_min_active(ctx, S, P, T, seed, spread, cfg):
+@pytest.mark.parametrize("adm", ADMS)
+def test_faster_map_spill_ties_and_min_active(ctx, S, P, T, seed, spread, cfg, adm):
     import torch
     from oracle import vbo
     from voicebridge_amd import api
     g, t2p, ll = make_case(S, P, T, seed, eps_frac=0.3, spread=spread)
     graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
-    dec = api.FasterDecoder(ctx, graph, 2, T, **cfg)
+    dec = api.FasterDecoder(ctx, graph, 2, T, admission=adm, **cfg)
     foff = np.array([0, T, T + T // 2], np.int64)
     d = torch.from_numpy(np.ascontiguousarray(np.concatenate([ll, ll[:T // 2]]))).to(ctx.device)
     ctx.torch_sync()
     dec.decode(d, foff, t2p)
     fst = vbo.make_fst(g["final"], g["arc_offset"], g["arcs"], 0)
     for u, n in enumerate((T, T // 2)):
-        ref = vbo.decode_faster(fst, ll[:n], t2p, exact_cutoff=True, **cfg)
+        ref = vbo.decode_faster(fst, ll[:n], t2p, exact_cutoff=ORACLE_MODE[adm], **cfg)
         assert_same_path(dec.result(u), ref)
     dec.close(); graph.close()
 
@@ -124,7 +134,7 @@ def test_faster_garbage_collection(ctx, monkeypatch):
     S, P, T, seed = 60000, 96, 160, 31
     g, t2p, ll = make_case(S, P, T, seed, eps_frac=0.3, spread=25.0)
     fst = vbo.make_fst(g["final"], g["arc_offset"], g["arcs"], 0)
-    ref = vbo.decode_faster(fst, ll, t2p, exact_cutoff=True, **cfg)
+    ref = vbo.decode_faster(fst, ll, t2p, exact_cutoff=3, **cfg)      # (the default admission: ordered)
     graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
     d = torch.from_numpy(ll).to(ctx.device)
     ctx.torch_sync()

@@ -62,7 +62,7 @@ ADMISSION = {"ordered": 0, "exact": 1}
 
 class FasterCfg(C.Structure):
     _fields_ = [("beam", C.c_float), ("max_active", C.c_int32), ("min_active", C.c_int32), ("beam_delta", C.c_float),
-                ("acoustic_scale", C.c_float)]
+                ("acoustic_scale", C.c_float), ("admission", C.c_int32)]      # admission: 0 = ordered (default), 1 = exact
 
 
 class BestPath(C.Structure):

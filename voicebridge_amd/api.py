@@ -410,9 +410,9 @@ class FasterDecoder:
     """FasterDecoder (1-best Viterbi beam search) over a Graph (vbh_faster_*)."""
 
     def __init__(self, ctx, graph, max_batch, max_frames, beam=16.0, max_active=2147483647, min_active=20, beam_delta=0.5,
-                 acoustic_scale=0.083333):
+                 acoustic_scale=0.083333, admission="ordered"):
         self.ctx, self.lib, self.graph = ctx, ctx.lib, graph
-        cfg = _lib.FasterCfg(beam, int(max_active), int(min_active), beam_delta, acoustic_scale)
+        cfg = _lib.FasterCfg(beam, int(max_active), int(min_active), beam_delta, acoustic_scale, _lib.ADMISSION[admission])
         h = C.c_void_p()
         check(self.lib.vbh_faster_decoder_create(ctx.h, graph.h, C.byref(cfg), int(max_batch), int(max_frames), C.byref(h)),
               "vbh_faster_decoder_create")

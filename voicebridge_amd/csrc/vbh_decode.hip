@@ -725,6 +725,17 @@ __device__ __forceinline__ gp<i32x4> tokp(gp<i32x4> wt, gp<i32x4> ht, int id) { 
 #ifndef VBH_SWEEP_BITS
 #define VBH_SWEEP_BITS VBH_SURVIVOR_BITS      // the pruning sweeps record excised window links in the survivor bitmap only (eval_links)
 #endif
+// VBH_SPARSE_TOK (r05): the token pass of a pruning sweep over a frame of the raw window touches the records of the SURVIVORS only.  A window
+// frame is swept exactly once while it is in the window (the pass that ends with its compaction visits every window frame once, top down),
+// so every token's old extra_cost is the 0 it was created with and need not be read; and a token that dies -- all but a handful per frame
+// -- is recorded in the survivor bitmap alone: its readers are the sweep over the frame below (sh.dstbits) and the compaction
+// (Slot::w_tok_alive), both of which consult the bitmap before the record.  Before: 16 bytes read and a 4-byte store into every token
+// record of the frame, i.e. every line of the frame's tokens fetched and written back once more, 300 frames after the search had left them
+// (a sixth of the kernel's memory traffic).  Frames the bitmap in LDS does not cover entirely, or whose epsilon links are swept the old
+// way, keep the old pass (their records stay exact).
+#ifndef VBH_SPARSE_TOK
+#define VBH_SPARSE_TOK 1
+#endif
 #ifndef VBH_CHECKS
 #define VBH_CHECKS 0           // (diagnostic builds: -DVBH_CHECKS=1; measured r02: 20 % slower, the compares cost registers the frame loop does not have)
 #endif
@@ -1016,10 +1027,12 @@ VBH_KI __device__ int prune_frame(const Slot &s, int f, float lattice_beam, floa
   // measured, each with the latency of a full link pass), reached from above, so every step is an atomicMin.
   const bool relax = VBH_EPS_RELAX && lds_tmp && (VBH_EPS_RELAX != 2 || pe - pb <= 64);
   const int iters_max = relax ? 1 : MAX_EPS_ITERS;
+  // VBH_SPARSE_TOK: a window frame swept in one sweep, all of whose tokens the bitmap in LDS covers
+  const bool sparse = VBH_SPARSE_TOK && VBH_DST_BITS && tbits != nullptr && relax && (te - tb) <= 64 * DSTBITS_WORDS;
   if (relax && pe - pb > 64 && tid == 0) { sh.sel_prefix = 0; sh.sel_mask = 0; sh.sel_k = 0; }      // relax_eps_links' flags (ordered by the barrier behind the link pass)
   for (int iter = 0; iter < iters_max; iter++) {
     i32x4 R0[U];            // first round of the token pass, prefetched
-    if (lds_tmp) {
+    if (lds_tmp && !sparse) {
 #pragma unroll
       for (int u = 0; u < U; u++) { const int t = tb + u * NT + tid; R0[u] = tok[t < te ? t : tb]; }
     }
@@ -1057,7 +1070,8 @@ VBH_KI __device__ int prune_frame(const Slot &s, int f, float lattice_beam, floa
       for (int u = 0; u < U; u++) {
         const int t = base + u * NT + tid;
         ok[u] = t < te;
-        if (lds_tmp && base == tb) R[u] = R0[u];
+        if (sparse) { R[u].x = 0; R[u].y = 0; R[u].z = 0; R[u].w = 0; }      // (old extra_cost: what the token was created with; the record is not read)
+        else if (lds_tmp && base == tb) R[u] = R0[u];
         else R[u] = tok[ok[u] ? t : tb];
       }
 #pragma unroll
@@ -1068,7 +1082,7 @@ VBH_KI __device__ int prune_frame(const Slot &s, int f, float lattice_beam, floa
         if (lds_tmp) {
           v = INF_BITS;
           if (ok[u]) { v = ltmp[t - tb]; if (v != INF_BITS) ltmp[t - tb] = INF_BITS; }
-          if (ok[u] && v != o) ((gp<int>)&tok[t])[2] = (int)v;
+          if (ok[u] && v != o && !(sparse && v == INF_BITS)) ((gp<int>)&tok[t])[2] = (int)v;      // (sparse: a dead token's record is left alone)
         } else if (ok[u] && (v != o || v != INF_BITS)) {
           i32x2 nv; nv.x = (int)v; nv.y = (int)INF_BITS;
           *(gp<i32x2>)((gp<int>)&tok[t] + 2) = nv;
@@ -2362,6 +2376,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         r.tok_b = cur_b; r.tok_e = cur_e; r.el_b = 0; r.el_e = 0; r.pl_b = plb; r.pl_e = pl_end;
         r.flags = 1 | 4; r.cost_offset = 0.0f; r.a_tok = cur_e - cur_b; r.a_el = 0; r.a_pl = pl_end - plb; r.pad = 0;
         st_frame(s.fr + (frame + 1), r);
+        sh.tph[11] += sh.n_cand;      // candidates pass 1 wrote, over the utterance (reported in UttResult::t_phase[12]; no room for a word of its own: the two-workgroups-per-CU build's LDS ends 16 bytes under 80 KB)
         sh.n_cand = 0; sh.cand_bound = 0xFFFFFFFFu; sh.fcnt[0] = 0; sh.fcnt[1] = 0; sh.fcnt[2] = 0; sh.n_l2 = 0;
       }
       if (ADM == VBH_ADMIT_ORDERED) {      // (their last readers: before pass 2; the barrier below)
@@ -2579,6 +2594,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         for (int i = 0; i < 7; i++) r->t_phase[i] = sh.tph[i];
         r->t_phase[7] = sh.n_visited;   // slot 7: frames visited by pruning (not a time)
         for (int i = 8; i < 16; i++) r->t_phase[i] = 0;
+        r->t_phase[12] = sh.tph[11];
         if (r_error == ERR_INTERNAL) { r->t_phase[8] = sh.chk[0]; r->t_phase[9] = sh.chk[1]; r->t_phase[10] = sh.chk[2]; r->t_phase[11] = sh.chk[3]; }
 #ifdef VBH_DIAG
         r->t_phase[8] = sh.tph[8]; r->t_phase[9] = sh.tph[9];

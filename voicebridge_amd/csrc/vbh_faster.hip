@@ -12,19 +12,24 @@
 // links, pruning passes or compaction: a token is {previous token, arc, state} + a double cost,
 // kept for the whole utterance for the back trace.
 //
-// Semantics = oracle/vb_oracle_decode.c with exact_cutoff = 1 (bit-exact, tests/test_gpu_faster.py;
-// that mode reproduces the reference's best paths on all its golden cases,
-// tests/test_oracle_decode.py): next_cutoff takes its final value (min over all candidate arcs of
-// new_weight + adaptive_beam) before anything is admitted; per state the cheapest incoming arc
-// wins and ties go to the smaller arc index; the epsilon closure runs to its fixed point before
-// tokens are made; ties between final tokens go to the smaller state id.  The reference's own
-// choices in those three places follow its hash-list order.
+// Semantics = oracle/vb_oracle_decode.c's order-independent FasterDecoder (bit-exact, tests/test_gpu_faster.py; both modes reproduce
+// the reference's best paths on all its golden cases, tests/test_oracle_decode.py): per state the cheapest incoming arc wins and ties go
+// to the smaller arc index; the epsilon closure runs to its fixed point before tokens are made; ties between final tokens go to the
+// smaller state id (the reference's own choices in those three places follow its hash-list order).  ADMISSION of emitting arcs
+// (vbh_faster_cfg::admission; the kernel is a template over it, as decode_kernel is):
+//   FADM_ORDERED (the default; oracle exact_cutoff = 3): the reference's rule -- an arc is admitted iff new_weight < next_weight_cutoff
+//     as it stands when the arc is visited, every admitted arc tightening it (faster-decoder.cc:266-273), from the bound the best token's
+//     arcs give (:241-255) -- applied in a canonical order: arcs leaving tokens whose state hashes to a lower one of 64 buckets count as
+//     visited earlier (the prefix minimum of vbh_decode.hip's ordered admission, here on 64-bit keys);
+//   FADM_EXACT (rounds 1-4; oracle exact_cutoff = 1): next_cutoff takes its final value (min over all candidate arcs of new_weight +
+//     adaptive_beam) before anything is admitted -- the order-independent subset of what the reference admits.
 #include "vbh_internal.h"
 
 #include <algorithm>
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <cstring>
 
 namespace {
 
@@ -121,6 +126,24 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
   const unsigned ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
   return ((unsigned long long)mh << 32) | ml;
 }
+// inclusive running minimum of 64-bit keys over the lanes (the DPP ladder of wave_min_u32 on both halves; lanes a step does not reach
+// keep their value: the identity is all ones)
+__device__ __forceinline__ unsigned long long wave_min_scan_u64(unsigned long long v) {
+  unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+  const int id = -1;
+#define VBH_DPP_MIN64(ctrl, rows) { const unsigned oh_ = (unsigned)__builtin_amdgcn_update_dpp(id, (int)hi, ctrl, rows, 0xf, false), \
+                                                   ol_ = (unsigned)__builtin_amdgcn_update_dpp(id, (int)lo, ctrl, rows, 0xf, false); \
+                                    const bool lt_ = oh_ < hi || (oh_ == hi && ol_ < lo); hi = lt_ ? oh_ : hi; lo = lt_ ? ol_ : lo; }
+  VBH_DPP_MIN64(0x111, 0xf) VBH_DPP_MIN64(0x112, 0xf) VBH_DPP_MIN64(0x114, 0xf) VBH_DPP_MIN64(0x118, 0xf) VBH_DPP_MIN64(0x142, 0xa) VBH_DPP_MIN64(0x143, 0xc)
+#undef VBH_DPP_MIN64
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
+  return ((unsigned long long)(unsigned)__shfl((int)(unsigned)(v >> 32), src, 64) << 32) | (unsigned)__shfl((int)(unsigned)v, src, 64);
+}
+enum { FADM_ORDERED = 0, FADM_EXACT = 1 };
+// ordered admission: bucket of a token's state, from the graph's own state id (oracle/vb_oracle_decode.c VBO_FADM_BUCKET, adm_bucket_bits = 6)
+__device__ __forceinline__ int adm_bucket(int st) { return (int)(((unsigned)st * 2654435761u) >> 26); }
 __device__ __forceinline__ int wave_max_scan(int v) {      // inclusive running maximum over the lanes, values >= 0
 #define VBH_DPP_MAX(ctrl, rows) { const int o_ = __builtin_amdgcn_update_dpp(0, v, ctrl, rows, 0xf, false); v = o_ > v ? o_ : v; }
   VBH_DPP_MAX(0x111, 0xf) VBH_DPP_MAX(0x112, 0xf) VBH_DPP_MAX(0x114, 0xf) VBH_DPP_MAX(0x118, 0xf) VBH_DPP_MAX(0x142, 0xa) VBH_DPP_MAX(0x143, 0xc)
@@ -168,6 +191,10 @@ __device__ __forceinline__ int wave_chunk(int n) {
 
 struct Shared {
   unsigned long long red[2][NW], red2[2][NW];
+  unsigned red3[2][NW];            // get_cutoff: the state of a wave's cheapest token
+  // ordered admission (FADM_ORDERED): bmin[b] = key of the smallest new_weight + adaptive_beam over the frame's arcs that leave a token of
+  // bucket b and got below b's own bound (others cannot change a later bucket's), init_bound = the same over the best token's arcs
+  unsigned long long bmin[64], init_bound;
   unsigned hist[256];
   unsigned vhist[1024];            // get_cutoff: the frame's costs by value, 1024 equal steps from the smallest to the largest
   unsigned long long vlist[2][64]; // ... the costs of the step an order statistic falls in ([which]: the max-active, the min-active one --
@@ -205,14 +232,21 @@ __device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v
   par ^= 1;
   return r;
 }
-// smallest and largest of the threads' (lo, hi) in one barrier
-__device__ __forceinline__ void block_minmax_u64(unsigned long long &lo, unsigned long long &hi, Shared &sh, int &par) {
+// smallest and largest of the threads' (lo, hi) in one barrier; st: the thread's state at its lo -> the smallest state among the
+// tokens at the overall lo (GetCutoff's best_elem, faster-decoder.cc:161-166, with ties to the smaller state id instead of list order)
+__device__ __forceinline__ void block_minmax_u64(unsigned long long &lo, unsigned long long &hi, unsigned &st, Shared &sh, int &par) {
+  const unsigned long long mylo = lo;
   lo = wave_min_u64(lo); hi = ~wave_min_u64(~hi);
-  if ((threadIdx.x & 63) == 0) { sh.red[par][threadIdx.x >> 6] = lo; sh.red2[par][threadIdx.x >> 6] = hi; }
+  st = wave_min_u32(mylo == lo ? st : 0xFFFFFFFFu);
+  if ((threadIdx.x & 63) == 0) { sh.red[par][threadIdx.x >> 6] = lo; sh.red2[par][threadIdx.x >> 6] = hi; sh.red3[par][threadIdx.x >> 6] = st; }
   __syncthreads();
-  lo = sh.red[par][0]; hi = sh.red2[par][0];
+  lo = sh.red[par][0]; hi = sh.red2[par][0]; st = sh.red3[par][0];
 #pragma unroll
-  for (int i = 1; i < NW; i++) { lo = sh.red[par][i] < lo ? sh.red[par][i] : lo; hi = sh.red2[par][i] > hi ? sh.red2[par][i] : hi; }
+  for (int i = 1; i < NW; i++) {
+    const unsigned long long l_ = sh.red[par][i]; const unsigned s_ = sh.red3[par][i];
+    if (l_ < lo || (l_ == lo && s_ < st)) { lo = l_; st = s_; }
+    hi = sh.red2[par][i] > hi ? sh.red2[par][i] : hi;
+  }
   par ^= 1;
 }
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, Shared &sh, int &par) {
@@ -323,14 +357,16 @@ __device__ double select_by_value(Each each, double best, double scale, unsigned
 // GetCutoff (faster-decoder.cc:151-213), in double, for the frame whose n costs each() enumerates: the cutoff on the tokens
 // (weight_cutoff) and the beam for the arcs leaving them (adaptive_beam).  Two barriers (smallest + largest cost; the counts on
 // either side of the beam + the histogram by value), two more per order statistic that decides.
-template <class Each>
-__device__ void get_cutoff(Each each, int n, const FCfg &cfg, Shared &sh, int &par, double &weight_cutoff, float &adaptive_beam) {
+template <class EachS, class Each>
+__device__ void get_cutoff(EachS each_s, Each each, int n, const FCfg &cfg, Shared &sh, int &par, double &weight_cutoff, float &adaptive_beam, int &best_state) {
   unsigned long long bk = ~0ull, wk = 0ull;
+  unsigned bs = 0xFFFFFFFFu;
   FPHASE(11)
-  each([&](unsigned long long k) { bk = k < bk ? k : bk; wk = k > wk ? k : wk; });
+  each_s([&](unsigned long long k, unsigned st) { if (k < bk || (k == bk && st < bs)) { bk = k; bs = st; } wk = k > wk ? k : wk; });
   sh.vhist[threadIdx.x] = 0;
   static_assert(NT == 1024, "one histogram step per thread");
-  block_minmax_u64(bk, wk, sh, par);
+  block_minmax_u64(bk, wk, bs, sh, par);
+  best_state = (int)bs;
   FPHASE(12)
   const double best = n > 0 ? o2d(bk) : (double)INFINITY;
   if (cfg.max_active == INT_MAX && cfg.min_active == 0) { adaptive_beam = cfg.beam; weight_cutoff = best + cfg.beam; return; }
@@ -601,7 +637,7 @@ __device__ void epsilon_winners(const FGraph &g, const FSlot &s, double cutoff, 
 // one token per map entry, appended to the utterance's history at tok_base (numbered by number_tokens: a wave writes runs of
 // consecutive tokens); then GetCutoff for the frame's turn as the current frame, from the cost keys while they are in registers.  The LDS level is walked HCAP / NT entries per thread with every winner fetched before the first is used;
 // the winner entries that were read are left empty for the next frame.
-__device__ void make_tokens(const FSlot &s, int tok_base, const FCfg &cfg, Shared &sh, int &par, double &weight_cutoff, float &adaptive_beam) {
+__device__ void make_tokens(const FSlot &s, int tok_base, const FCfg &cfg, Shared &sh, int &par, double &weight_cutoff, float &adaptive_beam, int &best_state) {
   gp<i32x4> tok = uptr(s.tok); gp<double> cost = uptr(s.cost);
   gp<unsigned long long> win = uptr(s.win);
   const Map2 m2 = map2_of(s);
@@ -652,9 +688,13 @@ __device__ void make_tokens(const FSlot &s, int tok_base, const FCfg &cfg, Share
   const int ng = sh.g_used ? (sh.n_g < s.frame_cap ? sh.n_g : s.frame_cap) : 0;
   get_cutoff([&](auto f) {
 #pragma unroll
+    for (int u = 0; u < PER; u++) if (have[u]) f(key[u], (unsigned)(st[u] & STMASK));
+    for (int i = threadIdx.x; i < ng; i += NT) f(m2.gc[m2.gl[i]], m2.gs[m2.gl[i]] & (unsigned)STMASK);
+  }, [&](auto f) {
+#pragma unroll
     for (int u = 0; u < PER; u++) if (have[u]) f(key[u]);
     for (int i = threadIdx.x; i < ng; i += NT) f(m2.gc[m2.gl[i]]);
-  }, sh.n_new, cfg, sh, par, weight_cutoff, adaptive_beam);
+  }, sh.n_new, cfg, sh, par, weight_cutoff, adaptive_beam, best_state);
 }
 
 // Tokens no current token can reach through back pointers will never be part of a best path (the
@@ -707,6 +747,7 @@ __device__ int collect_garbage(const FSlot &s, int gc_base, int cur_b, int cur_n
   return gc_base + total - cur_n;
 }
 
+template <int ADM>
 __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const FSlot *slots, const float *__restrict__ loglikes, int P,
                                                        const FUtt *__restrict__ utts, int n_work, int *work_counter, FResult *results,
                                                        i32x4 *paths, int path_cap) {   // best path per utterance, last arc first: {ilabel, olabel, weight, tot_cost}
@@ -753,6 +794,8 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
     }
     __syncthreads();
     double weight_cutoff = (double)INFINITY; float adaptive_beam = cfg.beam;      // of the current frame (make_tokens)
+    int best_state = -1;                                                          // ... and its cheapest token's state (ties: the smallest)
+    if (ADM == FADM_ORDERED) { if (tid < 64) sh.bmin[tid] = ~0ull; if (tid == 0) sh.init_bound = ~0ull; }
     epsilon_closure(g, s, (double)FLT_MAX, sh);
     number_tokens(s, sh);
     if (tid == 0 && sh.n_new > s.frame_cap) sh.error = FERR_FRAME;
@@ -762,7 +805,7 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
     if (sh.error == FERR_NONE) {
       epsilon_winners(g, s, (double)FLT_MAX, 0, sh);
       __syncthreads();
-      make_tokens(s, 0, cfg, sh, par, weight_cutoff, adaptive_beam);
+      make_tokens(s, 0, cfg, sh, par, weight_cutoff, adaptive_beam, best_state);
     }
     __syncthreads();
     int frames_done = 0;
@@ -799,9 +842,19 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
           const double c = ccost[have ? i : 0];
           const bool exp = have && c < weight_cutoff;
           const i32x4 sr = uptr(g.st)[exp ? (rec.z & STMASK) : 0];
-          const int a0 = (rec.z & STMASK) + 1 + sr.y, cnt = exp ? sr.z - sr.y : 0;
+          // (the sign bit of the first-arc index marks the frame's best token: its arcs give the initial bound, faster-decoder.cc:241-255)
+          const int a0 = ((rec.z & STMASK) + 1 + sr.y) | ((ADM == FADM_ORDERED && exp && (rec.z & STMASK) == best_state) ? EPSBIT : 0), cnt = exp ? sr.z - sr.y : 0;
+          // ordered admission: the token's bucket, and its bucket's bound as it stands at the start of the round (lane b of the scan
+          // holds bucket b's: min(init_bound, bmin of the buckets below b)) -- a filter here, the final bounds decide in pass 2
+          int bkt = 0; unsigned long long bnd_t = ~0ull;
+          if (ADM == FADM_ORDERED) {
+            bkt = adm_bucket(sr.x & STMASK);
+            const unsigned long long pre = wave_min_scan_u64(lane == 0 ? sh.init_bound : sh.bmin[lane - 1]);
+            bnd_t = shfl_u64(pre, bkt);
+          }
           wave_expand(sh.wx[threadIdx.x >> 6], cnt, [&](bool valid, int owner, int j) {
-            const int a = __shfl(a0, owner, 64) + j;
+            const int ao = __shfl(a0, owner, 64);
+            const int a = (ao & ~EPSBIT) + j;
             const double cc = __shfl(c, owner, 64);
             i32x4 arc; double nw = 0.0;
             unsigned long long kk = ~0ull;
@@ -812,17 +865,32 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
               kk = d2o(nw + (double)adaptive_beam);
               mymin = kk < mymin ? kk : mymin;
             }
-            // An arc whose new_weight has already reached a bound on next_cutoff -- the smallest new_weight + adaptive_beam anybody in
-            // the workgroup has seen so far, kept in LDS -- cannot be admitted (the final next_cutoff is the minimum over all arcs, so
-            // it is no larger): it is not written to the candidate list.  The admitted set is still {new_weight < final next_cutoff}.
-            const unsigned long long wk = wave_min_u64(kk);
-            if (lane == 0 && wk != ~0ull) atomicMin(&sh.cand_bound, wk);
-            const bool keep = valid && nw < o2d(sh.cand_bound);
+            bool keep; int bko = 0;
+            if (ADM == FADM_ORDERED) {
+              // Every arc may lower its bucket's minimum, the best token's arcs the initial bound -- but only an arc that gets below the
+              // bound of its OWN bucket can change the bound of a later one (those are minima over this bucket's bound and more), so all
+              // but the frame's few best arcs spare the atomic.  An arc at or above its bucket's present bound is not written (:266: the
+              // final bound is no larger).
+              bko = __shfl(bkt, owner, 64);
+              const unsigned long long bnd = shfl_u64(bnd_t, owner);
+              keep = valid && d2o(nw) < bnd;
+              if (valid) {
+                if (kk < bnd) atomicMin(&sh.bmin[bko], kk);
+                if (ao < 0) atomicMin(&sh.init_bound, kk);
+              }
+            } else {
+              // An arc whose new_weight has already reached a bound on next_cutoff -- the smallest new_weight + adaptive_beam anybody in
+              // the workgroup has seen so far, kept in LDS -- cannot be admitted (the final next_cutoff is the minimum over all arcs, so
+              // it is no larger): it is not written to the candidate list.  The admitted set is still {new_weight < final next_cutoff}.
+              const unsigned long long wk = wave_min_u64(kk);
+              if (lane == 0 && wk != ~0ull) atomicMin(&sh.cand_bound, wk);
+              keep = valid && nw < o2d(sh.cand_bound);
+            }
             const int q = wave_alloc(&sh.n_cand, keep);
             if (keep) {
               if (q < cand_cap) {
                 c_w[q] = nw;
-                i32x4 r; r.x = a; r.y = cur_b + base + owner; r.z = arc.x; r.w = 0;
+                i32x4 r; r.x = a; r.y = cur_b + base + owner; r.z = arc.x; r.w = bko;
                 c_r[q] = r;
               } else sh.error = FERR_CAND;
             }
@@ -832,6 +900,13 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
       mymin = block_min_u64(mymin, sh, par);
       const double next_cutoff = mymin == ~0ull ? (double)INFINITY : o2d(mymin);
       const int ncand = sh.n_cand < s.cand_cap ? sh.n_cand : s.cand_cap;
+      // ordered admission: the buckets' FINAL bounds (every arc's atomic is in: the reduction's barrier), lane b holds bucket b's key; a
+      // candidate is admitted iff its new_weight lies strictly below its bucket's (d2o is monotone: the comparison of the keys)
+      const unsigned long long adm_pre = ADM == FADM_ORDERED ? wave_min_scan_u64(lane == 0 ? sh.init_bound : sh.bmin[lane - 1]) : 0ull;
+      auto admitted = [&](double nw_, int bucket_) -> bool {
+        if (ADM == FADM_ORDERED) return d2o(nw_) < shfl_u64(adm_pre, bucket_);
+        return nw_ < next_cutoff;
+      };
       FPHASE(3)
       // ---- pass 2: admit new_weight < next_cutoff; cheapest per state
       {
@@ -849,7 +924,7 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
           }
 #pragma unroll
           for (int u = 0; u < UC; u++) {
-            const bool adm = ok[u] && nw[u] < next_cutoff;
+            const bool adm = admitted(nw[u], r[u].w & 63) && ok[u];      // (all 64 lanes take part in the bound's shuffle)
             int slot = -1; bool create = false, improved;
             if (adm) { map_relax(sh, m2, r[u].z & STMASK, nw[u], slot, create, improved); if (slot == -1) sh.error = FERR_MAP; }
             const bool pushf = create && r[u].z < 0;
@@ -893,7 +968,8 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
         }
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-          if (ok[u] && nw[u] < next_cutoff) {
+          const bool adm = admitted(nw[u], r[u].w & 63) && ok[u];
+          if (adm) {
             const int slot = map_find(sh, m2, r[u].z & STMASK);
             if (slot != -1 && d2o(nw[u]) == map_key(sh, m2, slot))
               (void)__hip_atomic_fetch_min(&win[widx(slot)], ((unsigned long long)(unsigned)r[u].x << 32) | (unsigned)r[u].y,
@@ -902,10 +978,14 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
         }
       }
       FPHASE(6)
+      if (ADM == FADM_ORDERED) {      // (the bounds' last readers took them into registers before pass 2; two barriers lie between here and pass 1 of the next frame)
+        if (tid >= NT - 64) sh.bmin[tid - (NT - 64)] = ~0ull;
+        if (tid == 0) sh.init_bound = ~0ull;
+      }
       epsilon_winners(g, s, next_cutoff, nb, sh);
       __syncthreads();
       FPHASE(7)
-      make_tokens(s, nb, cfg, sh, par, weight_cutoff, adaptive_beam);
+      make_tokens(s, nb, cfg, sh, par, weight_cutoff, adaptive_beam, best_state);
       FPHASE(14)
       __syncthreads();
       FPHASE(8)
@@ -1017,6 +1097,7 @@ extern "C" {
 void vbh_faster_cfg_default(vbh_faster_cfg *c) {
   // faster-decoder.h:38-43 (FasterDecoderOptions), acoustic scale as in VB/scr/kaldi_scr.h:152-157
   c->beam = 16.0f; c->max_active = INT_MAX; c->min_active = 20; c->beam_delta = 0.5f; c->acoustic_scale = 0.083333f;
+  c->admission = VBH_ADMISSION_ORDERED;
 }
 
 int vbh_faster_decoder_create(vbh_ctx *ctx, const vbh_graph *graph, const vbh_faster_cfg *cfg, int32_t max_batch,
@@ -1123,8 +1204,14 @@ static int faster_decode_batch_impl(vbh_faster_decoder *d, const float *d_loglik
   DevBuf<FUtt> d_utts; DevBuf<int> d_counter; DevBuf<FResult> d_res; DevBuf<i32x4> d_paths;
   if (d_utts.upload(utts.data(), utts.size(), st) || d_counter.alloc(1) || d_res.alloc(n_utt) || d_paths.alloc((size_t)n_utt * path_cap)) return -1;
   VBH_HIP(hipMemsetAsync(d_counter.p, 0, sizeof(int), st));
-  hipLaunchKernelGGL(faster_kernel, dim3(std::min(d->n_slots, n_utt)), dim3(NT), 0, st, fg, fc, d->d_slots.p, d_loglikes, (int)num_pdfs,
-                     d_utts.p, n_utt, d_counter.p, d_res.p, d_paths.p, path_cap);
+  int adm = d->cfg.admission == VBH_ADMISSION_EXACT ? FADM_EXACT : FADM_ORDERED;
+  if (const char *e = getenv("VBH_FASTER_ADMISSION")) adm = !strcmp(e, "exact") ? FADM_EXACT : !strcmp(e, "ordered") ? FADM_ORDERED : adm;      // (tests, A/B)
+  if (adm == FADM_ORDERED)
+    hipLaunchKernelGGL(faster_kernel<FADM_ORDERED>, dim3(std::min(d->n_slots, n_utt)), dim3(NT), 0, st, fg, fc, d->d_slots.p, d_loglikes, (int)num_pdfs,
+                       d_utts.p, n_utt, d_counter.p, d_res.p, d_paths.p, path_cap);
+  else
+    hipLaunchKernelGGL(faster_kernel<FADM_EXACT>, dim3(std::min(d->n_slots, n_utt)), dim3(NT), 0, st, fg, fc, d->d_slots.p, d_loglikes, (int)num_pdfs,
+                       d_utts.p, n_utt, d_counter.p, d_res.p, d_paths.p, path_cap);
   VBH_HIP(hipGetLastError());
   VBH_HIP(hipMemcpyAsync(res.data(), d_res.p, sizeof(FResult) * n_utt, hipMemcpyDeviceToHost, st));
   VBH_HIP(hipStreamSynchronize(st));

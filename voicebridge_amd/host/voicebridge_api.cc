@@ -736,11 +736,20 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
              // (one persistent grid over all of them); every "JOB" in the three wspecifiers is replaced by the utterance's job number, so
              // that the step still leaves lat.JOB / w.JOB per job, in table order (VB/scr/steps/decode_gmm.cpp:300-324 runs the jobs side by
              // side; on one GPU one grid of all their utterances fills the chip better than nj grids that queue behind each other)
-             "job-of-utt"});
+             "job-of-utt",
+             // --admission=ordered|exact (vbh_decode_cfg::admission; default ordered = the reference's rule in a canonical visiting order,
+             // exact = the order-independent subset: 3 % fewer tokens, ~5 % faster, not the reference's amount of search)
+             "admission"});
     po.Parse(argc, argv);
     if (po.args.size() < 4 || po.args.size() > 6) throw ApiError("wrong arguments.");
     vbh_decode_cfg cfg;
     vbh_decode_cfg_default(&cfg);
+    {
+      const std::string adm = po.Str("admission", "ordered");
+      if (adm == "exact") cfg.admission = VBH_ADMISSION_EXACT;
+      else if (adm == "ordered") cfg.admission = VBH_ADMISSION_ORDERED;
+      else throw ApiError("--admission must be ordered or exact, not " + adm);
+    }
     // LatticeFasterDecoderConfig defaults (K/decoder/lattice-faster-decoder.h:59-67), not Decode()'s
     cfg.beam = (float)po.Num("beam", 16.0);
     cfg.max_active = (int)po.Num("max-active", (double)std::numeric_limits<int32_t>::max());
@@ -1056,11 +1065,17 @@ int GmmDecodeFaster(int argc, char *argv[], std::ofstream &file_log) {
   return Guard("gmm-decode-faster", &file_log, [&](Log &log) -> int {
     Options po;
     po.Know({"beam", "max-active", "min-active", "beam-delta", "hash-ratio", "acoustic-scale", "word-symbol-table",
-             "allow-partial", "decode-batch"});
+             "allow-partial", "decode-batch", "admission"});      // (--admission=ordered|exact: an extension, as in gmm-latgen-faster above)
     po.Parse(argc, argv);
     if (po.args.size() < 4 || po.args.size() > 6) throw ApiError("wrong arguments.");
     vbh_faster_cfg cfg;
     vbh_faster_cfg_default(&cfg);
+    {
+      const std::string adm = po.Str("admission", "ordered");
+      if (adm == "exact") cfg.admission = VBH_ADMISSION_EXACT;
+      else if (adm == "ordered") cfg.admission = VBH_ADMISSION_ORDERED;
+      else throw ApiError("--admission must be ordered or exact, not " + adm);
+    }
     // FasterDecoderOptions defaults (K/decoder/faster-decoder.h:38-43), program default acoustic scale 0.1 (:79)
     cfg.beam = (float)po.Num("beam", 16.0);
     cfg.max_active = (int)po.Num("max-active", (double)std::numeric_limits<int32_t>::max());
