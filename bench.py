@@ -265,20 +265,8 @@ def speech_model(args, lex, mf, post, ctx, device):
 
 
 def synth_lda(args):
-    """a 40 x 117 LDA+MLLT-like matrix (final.mat) over 9 spliced frames of 13 cepstra.  Not a random projection (that throws
-    away two thirds of the information and the recogniser with it: WER 27 % against 5.5 %): the rows compute what a
-    discriminant projection of spliced frames mostly amounts to -- the centre frame, its first and second regression
-    derivatives (the delta windows of K/feat/feature-functions.cc:54-110 written as one linear map) -- plus the mean of C0
-    over the splice, so the recogniser works as well as with deltas and the kernels do the 117 -> 40 contraction."""
-    m = np.zeros((40, 9, 13), np.float32)
-    d1 = np.array([-2.0, -1.0, 0.0, 1.0, 2.0]) / 10.0
-    d2 = np.convolve(d1, d1)                      # 9 taps: offsets -4..4
-    for c in range(13):
-        m[c, 4, c] = 1.0
-        m[13 + c, 2:7, c] = d1
-        m[26 + c, :, c] = d2
-    m[39, :, 0] = 1.0 / 9.0
-    return np.ascontiguousarray(m.reshape(40, 117))
+    from voicebridge_amd import synth
+    return synth.lda_matrix()
 
 
 def feature_space_model(args, sample_feats):
@@ -909,6 +897,10 @@ def main():
         pass
     # further batch sets (--batch-sets): waveforms, CMVN statistics and transforms of their own; set 0 is the batch built above
     n_sets = max(1, args.batch_sets) if (dec is not None and args.workload == "speech" and not args.load_waves) else 1
+    if args.scaling == "strong" and n_sets < args.sets_per_step:
+        # (the step would otherwise walk the SAME batch sets_per_step times and still call it a corpus of N distinct utterances)
+        sys.exit("bench.py: --scaling strong needs the speech workload with its own synthesis (no --load-waves, no --no-decode): a step is one pass over "
+                 "%d DISTINCT batches per rank, and this configuration holds %d" % (args.sets_per_step, n_sets))
     sets = [(d_wave, woff, foff, utt2spk, stats, xforms)]
     for k_ in range(1, n_sets):
         w_, wo_, u2s_, nspk_, xf_, _gid, _truth = build_workload(args, rank, world, dev, lex, set_index=k_)
@@ -1240,9 +1232,10 @@ def main():
         except Exception:
             pass
         mc = fe_cnt.get("mfcc512_kernel", {})
+        mc_ok = all(mc.get(k_) for k_ in ("clock_hz", "cus", "lds_busy_cycles_per_frame"))      # (a counters file without them must not raise)
         extra_mfcc = {"kernel": "mfcc512_kernel", "bound": "lds", "achieved": mc.get("lds_busy_cycles_per_frame"), "unit": "LDS-array busy cycles per frame (all CUs)",
-                      "peak": (mfcc_alone_ms * 1e-3 * mc["clock_hz"] * mc["cus"] / T) if mc else None,
-                      "frac": (mc["lds_busy_cycles_per_frame"] / (mfcc_alone_ms * 1e-3 * mc["clock_hz"] * mc["cus"] / T)) if mc else None,
+                      "peak": (mfcc_alone_ms * 1e-3 * mc["clock_hz"] * mc["cus"] / T) if mc_ok else None,
+                      "frac": (mc["lds_busy_cycles_per_frame"] / (mfcc_alone_ms * 1e-3 * mc["clock_hz"] * mc["cus"] / T)) if mc_ok else None,
                       "traffic": None, "kernel_ms": mfcc_alone_ms,
                       "hbm_GBs": m_bytes / (mfcc_alone_ms * 1e-3) / 1e9, "hbm_frac": m_bytes / (mfcc_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       "algorithmic_bytes": m_bytes, "algorithmic_flops": m_flops, "gflops": m_flops / (mfcc_alone_ms * 1e-3) / 1e9,
@@ -1257,7 +1250,7 @@ def main():
                           "frac": fp_bytes / (featpost_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": featpost_alone_ms,
                           "algorithmic_bytes": fp_bytes, "frames_per_s": T / (featpost_alone_ms * 1e-3), "counters": fe_cnt.get("featpost_kernel"),
                           "note": "kernel alone on the chip, best of 3 after the timed region: CMVN + deltas (or splice + LDA) + the speaker's transform, 64 frames "
-                                  "(+ halo) per workgroup; 1 %% of the step.  Far from the HBM roof: a workgroup's 64 frames are 3 KB in and 10 KB out between two "
+                                  "(+ halo) per workgroup; 1 % of the step.  Far from the HBM roof: a workgroup's 64 frames are 3 KB in and 10 KB out between two "
                                   "barriers, and the waves spend their time waiting for those few loads (VALU issue 17 % of the wave-cycles, "
                                   "profiles/r04_frontend_counters.json)"}
         stage_ms = {"mfcc+featpost": float(np.mean(feat_ms)), "gmm": g_ms}
@@ -1447,22 +1440,41 @@ def main():
                         for u, w_ in cpu_words.items() if list(col_words[u]) != list(w_)]
                 if diff:
                     out["parity_words_differ"] = [{k_: (v_ if "words" not in k_ else "%d words" % len(v_)) for k_, v_ in d_.items()} for d_ in diff]
+                # which of the differing utterances the GPU's own best path scores better / worse on (like_per_frame: the path's own score)
+                gb_ = sum(1 for d_ in diff if d_["reference_like_per_frame"] is not None and d_["gpu_like_per_frame"] > d_["reference_like_per_frame"])
+                gw_ = sum(1 for d_ in diff if d_["reference_like_per_frame"] is not None and d_["gpu_like_per_frame"] < d_["reference_like_per_frame"])
+                out["parity_paths_where_words_differ"] = {"gpu_path_scores_better": gb_, "gpu_path_scores_worse": gw_, "utterances": len(diff)}
                 out["parity_note"] = ("best-path words of the GPU step against the %s's for the utterances of the CPU sample (same waveforms, model, graph, "
                                       "transforms).  A search with max-active deciding the cutoff in every sixth frame is sensitive to WHICH arcs above the "
                                       "final next_cutoff ProcessEmitting lets through, i.e. to its visiting order: the reference against itself under another "
                                       "--hash-ratio changes the words of 6-7 of 512 such utterances (tests/golden/speech_e2e512.npz).  The GPU search applies the "
                                       "reference's rule in a canonical order (vbh_decode_cfg::admission = ordered), so single utterances differ at about that rate "
-                                      "plus the front end's float tolerance (MFCC 1e-3 abs, scores 1e-4 rel), in either direction; measured on 512 utterances "
-                                      "(tests/test_gpu_e2e512.py, DESIGN.md 5): WER within 0.03 abs of the reference's, bootstrap P(GPU improves on the "
-                                      "reference) 0.34.  like_per_frame is the best path's own score: the higher one found the better path"
+                                      "plus the front end's float tolerance (MFCC 1e-3 abs, scores 1e-4 rel).  What THIS sample shows is in "
+                                      "parity_wer_on_the_cpu_sample (error counts of both against the transcripts, utterances with more / fewer errors than the "
+                                      "reference, the bootstrap probability that the GPU improves on the reference computed on these utterances) and "
+                                      "parity_paths_where_words_differ (whose best path scores higher where the words differ: a lower GPU score is a search error "
+                                      "of the GPU's); the 512-utterance measurement (tests/test_gpu_e2e512.py, DESIGN.md 5): WER within 0.03 abs of the "
+                                      "reference's, bootstrap P(GPU improves on the reference) 0.34"
                                       % ("reference programs" if ref_cb is not None else "oracle"))
                 if truth is not None:
                     from voicebridge_amd import dist as vdist
                     us_ = sorted(cpu_words)
                     wr_ = vdist.score([truth[u] for u in us_], [cpu_words[u] for u in us_])
                     wg_ = vdist.score([truth[u] for u in us_], [col_words[u] for u in us_])
+                    # per-utterance errors and the two-system bootstrap of compute-wer-bootci (K/bin/compute-wer-bootci.cc:137-155: utterances
+                    # resampled with replacement, "improves" = strictly fewer errors in the resample), on THIS sample
+                    er_ = np.array([sum(vdist.edit_counts(truth[u], cpu_words[u])) for u in us_], np.int64)
+                    eg_ = np.array([sum(vdist.edit_counts(truth[u], col_words[u])) for u in us_], np.int64)
+                    rng_ = np.random.default_rng(0)
+                    ix_ = rng_.integers(0, len(us_), (10000, len(us_)))
+                    dd_ = (er_ - eg_)[ix_].sum(1)
                     out["parity_wer_on_the_cpu_sample"] = {"reference_percent": 100.0 * wr_[0] / max(wr_[1], 1), "gpu_percent": 100.0 * wg_[0] / max(wg_[1], 1),
-                                                           "words": int(wr_[1]), "utterances": len(us_)}
+                                                           "words": int(wr_[1]), "utterances": len(us_),
+                                                           "reference_errors": int(er_.sum()), "gpu_errors": int(eg_.sum()),
+                                                           "utterances_gpu_more_errors": int((eg_ > er_).sum()), "utterances_gpu_fewer_errors": int((eg_ < er_).sum()),
+                                                           "bootstrap_p_gpu_improves_on_reference": float((dd_ > 0).mean()),
+                                                           "bootstrap_p_reference_improves_on_gpu": float((dd_ < 0).mean()),
+                                                           "bootstrap": "10000 resamples of the sample's utterances, strictly fewer word errors (compute-wer-bootci's two-system comparison)"}
     if tl_dump and os.environ.get("VBH_BENCH_TIMELINE"):
         np.save(os.environ["VBH_BENCH_TIMELINE"], np.stack(tl_dump))
     if det_pool is not None:

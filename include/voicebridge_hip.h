@@ -63,6 +63,8 @@ int vbh_ctx_device(vbh_ctx *ctx);
  * device a free waits for every stream of the device, which a host that runs several contexts side by side (the step API's job threads)
  * cannot afford per call.  The buffer belongs to the context: contents do not survive growth, the memory goes with vbh_ctx_destroy. */
 int vbh_ctx_scratch(vbh_ctx *ctx, int32_t slot, size_t bytes, void **d_ptr);
+/* gives the slot's memory back now (slot < 0: every slot's); the next vbh_ctx_scratch allocates again.  Waits for the context's stream. */
+int vbh_ctx_scratch_release(vbh_ctx *ctx, int32_t slot);
 int vbh_dev_alloc(vbh_ctx *ctx, size_t bytes, void **d_ptr);
 int vbh_dev_free(vbh_ctx *ctx, void *d_ptr);
 int vbh_copy_h2d(vbh_ctx *ctx, void *d_dst, const void *h_src, size_t bytes); /* async on the stream */

@@ -388,6 +388,32 @@ static int CmdDecode(const std::string &dir) {
     fo.hash_ratio = OptD(o, "hash_ratio", 2.0);
     FasterDecoder dec(*g, fo);
     MatrixDecodable decodable(ll, tid2pdf, acwt);
+    if (OptD(o, "faster_dump_frames", 0) != 0) {
+      // Decode() unrolled (faster-decoder.cc:47-54) so that the per-frame state can be dumped: tokens alive after every frame's
+      // ProcessNonemitting, the cutoff ProcessEmitting returned
+      std::vector<int32> ntok; std::vector<float> cut;
+      dec.InitDecoding();
+      while (!decodable.IsLastFrame(dec.num_frames_decoded_ - 1)) {
+        { const int32 df = OptD(o, "faster_dump_tokens_at", -1);
+          if (df >= 0 && dec.num_frames_decoded_ == df) {
+            size_t cnt; BaseFloat ab; FasterDecoder::Elem *be = NULL;
+            double wc0 = dec.GetCutoff(const_cast<FasterDecoder::Elem *>(dec.toks_.GetList()), &cnt, &ab, &be);
+            int32 below = 0, eq = 0;
+            for (const FasterDecoder::Elem *e = dec.toks_.GetList(); e != NULL; e = e->tail) { below += e->val->cost_ < wc0; eq += e->val->cost_ == wc0; }
+            fprintf(stderr, "G frame %d: GetCutoff -> %.9f adaptive_beam %.9f, %d tokens, %d strictly below, %d equal; min_active %d max_active %d beam %.3f\n",
+                    dec.num_frames_decoded_, wc0, ab, (int)cnt, below, eq, dec.config_.min_active, dec.config_.max_active, dec.config_.beam);
+          } }
+        double weight_cutoff = dec.ProcessEmitting(&decodable);
+        dec.ProcessNonemitting(weight_cutoff);
+        int32 c = 0; double best = std::numeric_limits<double>::infinity();
+        for (const FasterDecoder::Elem *e = dec.toks_.GetList(); e != NULL; e = e->tail) { c++; if (e->val->cost_ < best) best = e->val->cost_; }
+        ntok.push_back(c); cut.push_back(static_cast<float>(weight_cutoff - best)); cut.push_back(static_cast<float>(best));
+        { const int32 df = OptD(o, "faster_dump_tokens_at", -1);
+          if (df >= 0 && (dec.num_frames_decoded_ == df || dec.num_frames_decoded_ == df + 1))
+            for (const FasterDecoder::Elem *e = dec.toks_.GetList(); e != NULL; e = e->tail) fprintf(stderr, "T %d %d %.6f\n", dec.num_frames_decoded_, e->key, e->val->cost_); }
+      }
+      WriteVecI(dir + "/out_fast_ntok.npy", ntok); WriteVecF(dir + "/out_fast_cutoff_minus_best.npy", cut);
+    } else
     dec.Decode(&decodable);
     std::vector<int32> ali, words; std::vector<float> bw(2, std::numeric_limits<float>::infinity());
     std::vector<int32> meta; meta.push_back(0); meta.push_back(dec.ReachedFinal()); meta.push_back(dec.NumFramesDecoded());

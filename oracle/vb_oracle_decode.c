@@ -837,8 +837,14 @@ static double f_get_cutoff(fdec *d, const olist_item *l, int32_t n, float *adapt
   }
   if (c->max_active == INT32_MAX && c->min_active == 0) { *adaptive_beam = c->beam; return best + c->beam; }
   double beam_cutoff = best + c->beam, min_active_cutoff = INFINITY, max_active_cutoff = INFINITY;
+  /* faster-decoder.h:174: tmp_array_ is a std::vector<BaseFloat> -- the costs, doubles in the tokens, are NARROWED TO FLOAT when GetCutoff
+   * collects them (:171), so both order statistics are float32-rounded costs (promoted back to double, :183, :196), while best_cost and
+   * beam_cutoff stay exact doubles.  Where a cutoff falls among (nearly) equal costs -- the fan-out of a word end over the phone-start
+   * states by weight-0 epsilon arcs leaves dozens of exactly equal costs, and min-active = 20 puts the cutoff right there -- the rounding
+   * decides whether `cost < cutoff` (:262) expands all of them or none: found in round 5 by the 512-utterance gmm-decode-faster fixture
+   * (tests/golden/speech_faster512.npz), where a search with exact-double statistics loses the path on most utterances. */
   double *tmp = (double *)malloc(sizeof(double) * (n > 0 ? n : 1));
-  for (int32_t i = 0; i < n; i++) tmp[i] = d->toks[l[i].val].cost;
+  for (int32_t i = 0; i < n; i++) tmp[i] = (double)(float)d->toks[l[i].val].cost;
   int sorted = 0; double ret;
   if ((size_t)n > (size_t)c->max_active) { qsort(tmp, n, sizeof(double), cmp_f64); sorted = 1; max_active_cutoff = tmp[c->max_active]; }
   if (max_active_cutoff < beam_cutoff) {

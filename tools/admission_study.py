@@ -12,6 +12,9 @@ improves on the reference (compute-wer-bootci's two-system comparison, kaldi-mas
 resampled utterances, strictly fewer errors), tokens created.  CPU only.
 
     python tools/admission_study.py [--utts 512] [--jobs 8] [--modes 0,1,2,3:6,3:10,3:16]
+
+--decoder faster (round 5): the same study for the 1-best search, FasterDecoder (oracle modes 0, 1, 3 of vbo_decode_faster), against
+tests/golden/speech_faster512.npz (the reference's gmm-decode-faster, min-active 20: oracle/gen_golden_faster512.py).
 """
 import argparse
 import os
@@ -37,7 +40,7 @@ def parse_modes(s):
 
 
 def work(args):
-    spks, modes = args
+    spks, modes, decoder = args
     from oracle import vbo, gen_golden_e2e as e2e, gen_golden_speech as gs
     from voicebridge_amd import synth
     g, t2p, lex = synth.lexicon_graph(e2e.WORDS, e2e.P, seed=11, return_lexicon=True)
@@ -57,8 +60,17 @@ def work(args):
             ll = vbo.gmm_loglikes(offs, gc, miv, iv, f)
             rec = dict(truth=np.asarray(truth[k], np.int32))
             for (m, bits) in modes:
-                r = vbo.decode_lattice_faster(fst, ll, t2p, exact_cutoff=m, adm_bucket_bits=bits, **e2e.CFG)
                 key = "%d_%d" % (m, bits)
+                if decoder == "faster":
+                    from oracle import gen_golden_faster512 as f512
+                    C_ = f512.CFG
+                    r = vbo.decode_faster(fst, ll, t2p, acwt=C_["acwt"], beam=C_["beam"], max_active=C_["max_active"], min_active=C_["min_active"],
+                                          beam_delta=C_["beam_delta"], exact_cutoff=m, adm_bucket_bits=bits)
+                    rec["words_" + key] = np.asarray(r["words"], np.int32)
+                    rec["cost_" + key] = float(r["best_graph"] + r["best_acoustic"])
+                    rec["toks_" + key] = 1; rec["links_" + key] = 0; rec["maxbound_" + key] = 0
+                    continue
+                r = vbo.decode_lattice_faster(fst, ll, t2p, exact_cutoff=m, adm_bucket_bits=bits, **e2e.CFG)
                 rec["words_" + key] = np.asarray(r["words"], np.int32)
                 rec["cost_" + key] = float(r["best_graph"] + r["best_acoustic"])
                 rec["toks_" + key] = int(r["n_tok_created"])
@@ -85,16 +97,17 @@ def main():
     ap.add_argument("--modes", default="0,1,2,3:6,3:10,3:16")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "admission_study.npz"))
     ap.add_argument("--analyse-only", action="store_true")
+    ap.add_argument("--decoder", choices=("lattice", "faster"), default="lattice")
     a = ap.parse_args()
     modes = parse_modes(a.modes)
     t0 = time.time()
     from voicebridge_amd import dist as vdist
-    fx = np.load(os.path.join(ROOT, "tests", "golden", "speech_e2e512.npz"))
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "speech_faster512.npz" if a.decoder == "faster" else "speech_e2e512.npz"))
     if not a.analyse_only:
         n_spk = a.utts // 4
         chunks = [list(range(j, n_spk, a.jobs)) for j in range(a.jobs)]
         with ProcessPoolExecutor(a.jobs) as ex:
-            parts = list(ex.map(work, [(c, modes) for c in chunks if c]))
+            parts = list(ex.map(work, [(c, modes, a.decoder) for c in chunks if c]))
         res = {}
         for p in parts:
             res.update(p)

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("VBH_LIB_PATH") or os.path.join(HERE, "lib", "libvoice
 
 # every symbol include/voicebridge_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "vbh_abi_version", "vbh_last_error", "vbh_device_count", "vbh_ctx_create", "vbh_ctx_create_with_priority", "vbh_ctx_create_on_cus", "vbh_ctx_destroy", "vbh_ctx_scratch",
+    "vbh_abi_version", "vbh_last_error", "vbh_device_count", "vbh_ctx_create", "vbh_ctx_create_with_priority", "vbh_ctx_create_on_cus", "vbh_ctx_destroy", "vbh_ctx_scratch", "vbh_ctx_scratch_release",
     "vbh_ctx_sync", "vbh_ctx_wait_for", "vbh_ctx_mark", "vbh_ctx_wait_mark", "vbh_ctx_stream", "vbh_ctx_device", "vbh_dev_alloc", "vbh_dev_free", "vbh_copy_h2d",
     "vbh_copy_d2h", "vbh_memset", "vbh_timer_start", "vbh_timer_stop", "vbh_timer_elapsed_ms",
     "vbh_mfcc_opts_default", "vbh_mfcc_num_frames", "vbh_mfcc_create", "vbh_mfcc_destroy", "vbh_mfcc_compute", "vbh_mfcc_set_dither_stream", "vbh_mfcc_set_dither_ids",

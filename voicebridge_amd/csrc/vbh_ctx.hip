@@ -177,6 +177,23 @@ int vbh_ctx_scratch(vbh_ctx *c, int32_t slot, size_t bytes, void **d_ptr) {
   return *d_ptr ? 0 : -1;
 }
 
+// Gives a scratch slot's memory back (slot < 0: every user slot's).  The slots only grow otherwise, and a host that put a job's score matrix
+// in one keeps gigabytes pinned per thread for the life of its context: the host layer calls this when it lets go of its device
+// cache (vb_release_device_cache), i.e. at the end of a step when asked to, or when the thread's device changes.  Waits for the context's stream.
+int vbh_ctx_scratch_release(vbh_ctx *c, int32_t slot) {
+  VBH_CHECK(c && VBH_SCR_USER + slot < VBH_SCRATCH_SLOTS, "vbh_ctx_scratch_release: bad argument (slots 0 .. %d, or < 0 for all)", VBH_SCRATCH_SLOTS - VBH_SCR_USER - 1);
+  if (vbh_use_device(c)) return -1;
+  bool synced = false;
+  for (int i = VBH_SCR_USER; i < VBH_SCRATCH_SLOTS; i++) {
+    if (slot >= 0 && i != VBH_SCR_USER + slot) continue;
+    if (!c->scratch[i].p) continue;
+    if (!synced) { VBH_HIP(hipStreamSynchronize(c->stream)); synced = true; }
+    (void)hipFree(c->scratch[i].p);
+    c->scratch[i].p = nullptr; c->scratch[i].cap = 0;
+  }
+  return 0;
+}
+
 int vbh_dev_alloc(vbh_ctx *c, size_t bytes, void **d_ptr) {
   if (vbh_use_device(c)) return -1;
   VBH_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));

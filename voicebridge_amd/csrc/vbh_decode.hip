@@ -1741,13 +1741,15 @@ VBH_KI __device__ VBH_NONEMIT_ATTR int process_nonemitting(const DevGraph &g, co
     if (n_l2 <= 256) {
       for (int i = tid; i < n_l2; i += NT) {
         gp<int> py = (gp<int>)&wl[sh.hist[i]] + 1;
-        *py = ld_i32(&ent[-1 - *py].tokid) | WBIT;
+        const int d_ = ld_i32(&ent[-1 - *py].tokid);
+        (void)VBH_CHK(sh, 30, d_ - nb, ne_all - nb);
+        *py = d_ | WBIT;
       }
     } else {
       for (int l = el_b + tid; l < el_e; l += NT) {
         gp<int> py = (gp<int>)&wl[l] + 1;
         const int y = *py;
-        if (y < 0) *py = ld_i32(&ent[-1 - y].tokid) | WBIT;
+        if (y < 0) { const int d_ = ld_i32(&ent[-1 - y].tokid); (void)VBH_CHK(sh, 30, d_ - nb, ne_all - nb); *py = d_ | WBIT; }
       }
     }
   }
@@ -2057,6 +2059,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
       if (tid == 0) sh.w_ntok = (sh.w_ntok + 63) & ~63;
 #endif
       const int tb = cur_b, n = cur_e - cur_b;
+      if (n >= (1 << 26)) { if (tid == 0) sh.error = ERR_W_TOK; __syncthreads(); break; }      // (uniform; see w_tok_cap: the candidates' source-token word)
       gp<const i32x4> tok = uptr(cur_w ? s.w_tok : s.h_tok) + tb;
       gp<i32x4> cand = uptr(s.cand);
       const int cand_cap = s.cand_cap;
@@ -2273,7 +2276,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
             for (int u = 0; u < UA; u++) {
               if (keep[u]) {
                 if (q[u] < cand_cap) {
-                  i32x4 ca; ca.x = asi(tot[u]); ca.y = a[u]; ca.z = (base + owner[u]) | (bko[u] << 26); ca.w = arc[u].x;
+                  i32x4 ca; ca.x = asi(tot[u]); ca.y = a[u]; ca.z = (int)((unsigned)(base + owner[u]) | ((unsigned)bko[u] << 26)); ca.w = arc[u].x;
                   cand[q[u]] = ca;
                 } else sh.error = ERR_CAND;
               }
@@ -2820,9 +2823,9 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
   Slot p{};
   // (every frame's tokens and links start a 64-bit word of the survivor bitmaps, VBH_SURVIVOR_BITS: a frame takes whole words, which
   // for a graph of a dozen states -- config 1's monophone loop -- is several times what its tokens need; tests/test_gpu_config1.py)
-  // (at most 2^26 - 64 tokens in the window, hence in a frame: a candidate's source token shares its word with the six bits of the
-  // token's admission bucket, decode_kernel pass 1)
-  p.w_tok_cap = (int)std::min<long long>((((per_frame_tok_s + 63) & ~63LL) + 64) * win, (1LL << 26) - 64);
+  // (a FRAME holds fewer than 2^26 tokens -- a candidate's source token, an index within its frame, shares its word with the six bits of
+  // the token's admission bucket, decode_kernel pass 1: checked per frame in the kernel -- the window as many as its indices allow)
+  p.w_tok_cap = (int)std::min<long long>((((per_frame_tok_s + 63) & ~63LL) + 64) * win, 1LL << 28);
   p.w_link_cap = (int)std::min<long long>((((per_frame_link + per_frame_tok_s + 63) & ~63LL) + 64) * win, 1LL << 28);
   // history: one unpruned frontier frame per interval plus the survivors
   const long long n_int = max_frames / pi + 2;

@@ -377,20 +377,28 @@ __device__ void get_cutoff(EachS each_s, Each each, int n, const FCfg &cfg, Shar
   // tmp[min_active] > beam_cutoff  <=>  at most min_active costs are <= beam_cutoff
   const double range = n > 0 ? o2d(wk) - best : 0.0;
   const double scale = range > 0.0 && range < (double)INFINITY ? 1023.0 / range : 0.0;
-  unsigned long long cnt = 0;   // (#cost < beam_cutoff) << 32 | (#cost <= beam_cutoff)
+  // The reference collects the costs in a std::vector<BaseFloat> (faster-decoder.h:174, faster-decoder.cc:171): both order statistics are
+  // FLOAT32-ROUNDED costs, compared with the exact double beam_cutoff and handed back as the cutoff (:183, :196).  Rounding is monotone, so
+  // the k-th smallest rounded cost is the rounded k-th smallest cost -- the selects below run on the exact keys and their result is rounded
+  // -- and the counts that decide whether a statistic matters are taken over the rounded costs.  (Where the cutoff falls among equal costs
+  // -- a word end's fan-out over the phone-start states leaves dozens, and min-active = 20 puts the cutoff there -- the rounding decides
+  // whether `cost < cutoff` expands all of them or none; with exact doubles the search lost the path on most of the 512 utterances of
+  // tests/golden/speech_faster512.npz: round 5.)
+  unsigned long long cnt = 0;   // (#rounded cost < beam_cutoff) << 32 | (#rounded cost <= beam_cutoff)
   each([&](unsigned long long k) {
     const double c = o2d(k);
-    cnt += ((unsigned long long)(c < beam_cutoff) << 32) | (unsigned long long)(c <= beam_cutoff);
+    const double cr = (double)(float)c;
+    cnt += ((unsigned long long)(cr < beam_cutoff) << 32) | (unsigned long long)(cr <= beam_cutoff);
     atomicAdd(&sh.vhist[step_of(c, best, scale)], 1u);
   });
   cnt = block_sum_u64(cnt, sh, par);
   FPHASE(13)
   const int cnt_lt = (int)(cnt >> 32), cnt_le = (int)(unsigned)cnt;
-  if (n > cfg.max_active && cnt_lt > cfg.max_active) mac = select_by_value(each, best, scale, bk, wk, cfg.max_active, 0, sh);
+  if (n > cfg.max_active && cnt_lt > cfg.max_active) mac = (double)(float)select_by_value(each, best, scale, bk, wk, cfg.max_active, 0, sh);
   if (mac < beam_cutoff) { adaptive_beam = (float)(mac - best + cfg.beam_delta); weight_cutoff = mac; return; }
   if (n > cfg.min_active) {
     if (cfg.min_active == 0) mic = best;
-    else if (cnt_le <= cfg.min_active) mic = select_by_value(each, best, scale, bk, wk, cfg.min_active, 1, sh);
+    else if (cnt_le <= cfg.min_active) mic = (double)(float)select_by_value(each, best, scale, bk, wk, cfg.min_active, 1, sh);
     else mic = beam_cutoff;     // some value <= beam_cutoff: the comparison below is false
   }
   if (mic > beam_cutoff) { adaptive_beam = (float)(mic - best + cfg.beam_delta); weight_cutoff = mic; }

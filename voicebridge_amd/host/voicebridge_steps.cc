@@ -667,8 +667,9 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
     // by side on the job threads -- no search grid of one job holds up the statistics / rescoring kernels of another.
     // The two big temporary tables of a job -- the main pass's raw lattices (lat.tmp.JOB, ~100 MB per 256 utterances, written once and read
     // by the determinization for the second estimate and by the rescoring) and the rescored lattices -- are handed from program to program
-    // in memory (vbio "mem:" tables) when all of them run in this call; a run that resumes behind the main search (stage > 2) finds
-    // lat.tmp.JOB as files, as the reference leaves them.  VB_STEP_FILE_TEMPS=1: files always.
+    // in memory (vbio "mem:" tables) when all of them run in this call, and dropped however the call ends.  A run that resumes behind the main
+    // search (stage > 2) reads lat.tmp.JOB as files, which only a run with VB_STEP_FILE_TEMPS=1 (files always, as the reference leaves them)
+    // has written: without them the resume fails with a message that says so (below).
     const bool mem_tmp = stage <= 2 && !getenv("VB_STEP_FILE_TEMPS");
     const std::string tmp_prefix = mem_tmp ? "mem:" : "";
     auto drop_tmp = [&](const std::string &path) { if (vbio::IsMemPath(path)) vbio::MemUnlink(path); else unlink(path.c_str()); };
@@ -744,6 +745,12 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
       const std::vector<std::string> fe = fe_of(dsn);
       const std::string raw = "scp:" + Join(dsn, "feats.scp"), pre_trans = Join(dir, "pre_trans." + J), trans = Join(dir, "trans." + J), lat_tmp = tmp_prefix + Join(dir, "lat.tmp." + J);
       const std::string spk2utt = "--spk2utt=ark:" + Join(dsn, "spk2utt");
+      // A run that resumes behind the main search reads lat.tmp.JOB from disk -- which only a run with file temporaries left there (the
+      // default keeps them in process memory and drops them however the call ends): say so instead of failing inside a program
+      if (stage > 2 && stage <= 4 && !Exists(lat_tmp))
+        throw StepError(lat_tmp + " is required to resume DecodeFmllr at stage " + std::to_string(stage) + " but can not be found: a run keeps the main pass's raw "
+                        "lattices in memory unless VB_STEP_FILE_TEMPS=1 is set (then they are the reference's files and survive a failed run); "
+                        "resume at stage <= 2, or run the earlier stages again with VB_STEP_FILE_TEMPS=1");
       if (stage <= 3) {      // second fMLLR estimate, composed with the first (:491-566)
         const std::string t_ldp = Join(dsn, "ldp.temp"), t_post = Join(dsn, "post.temp"), t_wsp = Join(dsn, "wsp.temp"), trans_tmp = Join(dir, "trans_tmp." + J);
         run("lattice-determinize-pruned", LatticeDeterminizePruned, {"lattice-determinize-pruned", acw, "--beam=" + std::to_string(4.0), "ark:" + lat_tmp, "ark:" + t_ldp}, log);

@@ -59,8 +59,9 @@ int Decode(const std::string &graph_dir, const std::string &data_dir, const std:
 // Speaker-adapted decoding: a speaker-independent pass (Decode with beam 10 / max-active 2000 into <dir>.si) -> fMLLR from its lattice
 // posteriors (pre_trans.JOB) -> main search on the transformed features (raw lattices lat.tmp.JOB) -> a second fMLLR estimate from the
 // pruned-determinized lattices, composed with the first (trans.JOB) -> acoustic rescoring with the final model on the final features ->
-// determinization (lat.JOB) -> best path (w.JOB, transcriptionJOB.trn) -> scoring.  The two searches and the feature pipeline run on
-// the GPU; posteriors, the fMLLR statistics/update, rescoring and determinization are host code this round.
+// determinization (lat.JOB) -> best path (w.JOB, transcriptionJOB.trn) -> scoring.  On the GPU: the feature pipeline, both searches,
+// the fMLLR sufficient statistics (vbh_fmllr_accumulate) and the scores the rescoring adds (vbh_gmm_loglikes_pairs); on the host: the
+// lattice forward-backward and silence weighting, the row-by-row fMLLR update, determinization, scoring.
 int DecodeFmllr(const std::string &graphdir, const std::string &data, const std::string &dir, const std::string &alignment_model = "",
                 const std::string &adapt_model = "", const std::string &final_model = "", int nj = 4, float acwt = 0.083333f, int stage = 0,
                 int max_active = 7000, double beam = 13.0, double lattice_beam = 6.0, double silence_weight = 0.01, const std::string &si_dir = "",
