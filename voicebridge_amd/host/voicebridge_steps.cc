@@ -657,7 +657,13 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
       Argv av(std::move(a));
       const auto t0 = std::chrono::steady_clock::now();
       const int r = fn(av.argc(), av.argv(), log);
-      if (laps) fprintf(stderr, "DecodeFmllr %-28s %8.1f ms\n", what, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+      if (laps) {
+        static const auto t_proc = std::chrono::steady_clock::now();      // (diagnostic timeline: start / end relative to the first call of the process)
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "DecodeFmllr %-28s %8.1f ms   [%8.1f .. %8.1f] thread %zx\n", what, 1e3 * std::chrono::duration<double>(t1 - t0).count(),
+                1e3 * std::chrono::duration<double>(t0 - t_proc).count(), 1e3 * std::chrono::duration<double>(t1 - t_proc).count(),
+                std::hash<std::thread::id>()(std::this_thread::get_id()) & 0xFFFF);
+      }
       if (r < 0 || (r != 0 && !none_ok)) throw StepError(std::string(what) + " failed (return code " + std::to_string(r) + "), see " + Join(dir, "log"));
     };
     // One job's part of the recipe in three pieces: `search` = the two gmm-latgen-faster passes, `before` = what lies between them
@@ -772,18 +778,39 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
       try { DecodeJob(si_jobs, j); }
       catch (const std::exception &e) { throw StepError(std::string("First pass speaker-independent decoding failed: ") + e.what()); }
     };
+    // The first pass is scored as Decode scores it when it runs as a step of its own (decode_fmllr.cpp:215-259) -- 33 LM-weight x penalty
+    // combinations over its lattices, a quarter of a second of host threads that nothing later depends on.  It starts when the last job's
+    // first-pass lattices are written and runs beside the main searches (the host waits for the GPU then), not behind the whole recipe
+    // (round 5; VB_STEP_SI_SCORING_LAST=1: as before).
+    std::atomic<int> si_done{0};
+    std::thread si_scorer;
+    std::string si_score_err;
+    struct SiJoin { std::thread &t; ~SiJoin() { if (t.joinable()) t.join(); } } si_join{si_scorer};
+    const bool si_score_early = run_si && !skip_scoring && !getenv("VB_STEP_SI_SCORING_LAST");
+    auto score_si = [&]() {
+      UMAPSS f1, f2;
+      if (ScoreKaldiWER(data, graphdir, si_dir, f1, f2, nj, 0, decode_mbr, stats, 6.0, word_ins_penalty, min_lmwt, max_lmwt, "final") < 0)
+        si_score_err = "First pass speaker-independent decoding failed: " + g_err;
+    };
+    auto si_job_done = [&]() {
+      if (++si_done == nj && si_score_early) {
+        static std::mutex mu; std::lock_guard<std::mutex> lk(mu);
+        if (!si_scorer.joinable()) si_scorer = std::thread(score_si);
+      }
+    };
     if (combined) {
       vb_set_device(StepDevices()[0]);
       if (run_si) {
         try { DecodeAllJobs(si_jobs); }
         catch (const std::exception &e) { throw StepError(std::string("First pass speaker-independent decoding failed: ") + e.what()); }
+        for (int j = 0; j < nj; j++) si_job_done();
       }
       ForEachJob(nj, before);
       main_search_all();
       ForEachJob(nj, after);
     } else {
       ForEachJob(nj, [&](int j) {
-        if (run_si) si_job(j);
+        if (run_si) { si_job(j); si_job_done(); }
         before(j);
         main_search(j);
         after(j);
@@ -791,11 +818,10 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
     }
     if (run_si) {
       FinishDecode(si_jobs);
-      if (!skip_scoring) {        // (what Decode does for the first pass when it runs as a step of its own)
-        UMAPSS f1, f2;
-        if (ScoreKaldiWER(data, graphdir, si_dir, f1, f2, nj, 0, decode_mbr, stats, 6.0, word_ins_penalty, min_lmwt, max_lmwt, "final") < 0)
-          throw StepError("First pass speaker-independent decoding failed: " + g_err);
-      }
+      if (si_scorer.joinable()) si_scorer.join();
+      if (!si_score_err.empty()) throw StepError(si_score_err);
+      if (!skip_scoring && !si_score_early) score_si();
+      if (!si_score_err.empty()) throw StepError(si_score_err);
     }
   });
   if (rc != 0) return rc;
