@@ -1410,6 +1410,25 @@ def main():
                     if b_:
                         ro["traffic"] = b_
                         ro["traffic_source"] = tr.get("source", "profiles/")
+                    if b_ and ro["kernel"] == "decode_kernel":
+                        # A roof that fits a search made of 16-byte records gathered at random (VERDICT r4 "next" 2a): what the chip delivers to a kernel
+                        # that does nothing else -- tools/micro/gather16_peak.hip, 256 workgroups x 16 waves on a table of the packed graph's size:
+                        # 57 G random 64-byte lines per second chip-wide whatever the loads in flight per lane (223 M per CU; a CU alone reaches 850 M: the
+                        # limit is the fabric's, not the CU's), i.e. 0.91 TB/s of useful 16-byte records = 11 % of the 8 TB/s this kernel's `frac` is
+                        # priced against.  gather_frac = the 64-byte lines the kernel moves through the fabric per second (counted traffic / 64 B over its
+                        # live duration) over that ceiling: an UPPER bound on how close to the random-access roof it runs, since half of its traffic
+                        # (tokens, links, candidates) streams, which the fabric serves at up to 98 G lines/s (6.29 TB/s measured copy)
+                        try:
+                            gl_ = [json.loads(x) for x in open(os.path.join(ROOT, "profiles", "r05_gather16_126mb.jsonl")) if x.startswith("{")]
+                            ceil_ = max(g_["records_per_s"] for g_ in gl_ if g_["what"].startswith("independent") and g_.get("cus", 256) >= 256 and " 1 lanes per" in g_["what"])
+                            lines_ = b_ / 64.0 / (ro["kernel_ms"] * 1e-3)
+                            ro["gather_frac"] = lines_ / ceil_
+                            ro["gather"] = {"lines64_per_s": lines_, "ceiling_lines64_per_s": ceil_, "ceiling_useful_GBs_of_16_byte_records": ceil_ * 16.0 / 1e9,
+                                            "ceiling_source": "profiles/r05_gather16_126mb.jsonl (tools/micro/gather16_peak.hip: independent random 16-byte loads, 126 MB table, all CUs)",
+                                            "streaming_ceiling_lines64_per_s": 6.29e12 / 64.0,
+                                            "note": "counted FETCH_SIZE + WRITE_SIZE of the committed profile of this command / 64 B, over this run's kernel time"}
+                        except Exception:
+                            pass
         except Exception:
             pass
         if gathered is not None:
