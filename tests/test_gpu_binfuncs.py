@@ -199,6 +199,15 @@ def test_gmm_decode_faster_vs_reference_program(host, tmp_path):
                                           "ark,t:%s" % (d / "w2.txt"), "ark,t:%s" % (d / "a2.txt"), "ark:%s" % (d / "lat.ark")], log) == 0, open(log).read()
     mine_w, mine_a = (d / "words.txt").read_text(), (d / "ali.txt").read_text()
     assert (d / "w2.txt").read_text() == mine_w and (d / "a2.txt").read_text() == mine_a
+    # --admission=ordered|exact (an extension: vbh_faster_cfg::admission); anything else is an error, as a bad option is in the reference
+    for adm in ("ordered", "exact"):
+        assert call(host.vb_GmmDecodeFaster, ["gmm-decode-faster", "--admission=" + adm] + opts + [str(d / "final.mdl"), str(d / "HCLG.fst"), "ark:%s" % (d / "feats.ark"),
+                                              "ark,t:%s" % (d / "w3.txt"), "ark,t:%s" % (d / "a3.txt")], log) == 0, open(log).read()
+        assert (d / "w3.txt").read_text() == mine_w and (d / "a3.txt").read_text() == mine_a      # (beam-limited toy case: the rule does not decide)
+    assert call(host.vb_GmmDecodeFaster, ["gmm-decode-faster", "--admission=sometimes"] + opts + [str(d / "final.mdl"), str(d / "HCLG.fst"), "ark:%s" % (d / "feats.ark"),
+                                          "ark,t:%s" % (d / "w3.txt")], log) == -1
+    assert call(host.vb_GmmLatgenFaster, ["gmm-latgen-faster", "--admission=sometimes"] + opts + [str(d / "final.mdl"), str(d / "HCLG.fst"), "ark:%s" % (d / "feats.ark"),
+                                          "ark:%s" % (d / "l3.ark")], log) == -1
     from tests import util
     lats = util.read_lattice_ark(str(d / "lat.ark"))
     ali_of = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in mine_a.splitlines()}

@@ -87,6 +87,35 @@ const RawTable &CachedRawTable(const std::string &rspecifier) {
 
 void ReleaseRawTableCache() { g_table = RawTable(); }
 
+namespace {
+struct GmmCache {
+  vbh_ctx *ctx = nullptr;
+  std::map<std::string, vbh_gmm *> models;
+  void Clear() { for (auto &kv : models) vbh_gmm_destroy(kv.second); models.clear(); ctx = nullptr; }
+};
+thread_local GmmCache g_gmms;
+long long ModelSig(const std::string &path) {
+  struct stat st;
+  if (stat(path.c_str(), &st) != 0) return -1;
+  return (long long)st.st_size * 1000003LL + (long long)st.st_mtime * 7919LL + (long long)st.st_mtim.tv_nsec;
+}
+}  // namespace
+vbh_gmm *CachedDeviceGmm(const std::string &path, const vbio::Model &model) {
+  vbh_ctx *ctx = SharedCtx();
+  if (g_gmms.ctx != ctx) g_gmms.Clear();      // (the thread's context was replaced: its device changed)
+  g_gmms.ctx = ctx;
+  const std::string key = std::to_string(ModelSig(path)) + "|" + path;
+  auto it = g_gmms.models.find(key);
+  if (it != g_gmms.models.end()) return it->second;
+  if (g_gmms.models.size() >= 8) g_gmms.Clear(), g_gmms.ctx = ctx;      // (a step names two or three models)
+  vbh_gmm *g = nullptr;
+  if (vbh_gmm_create(ctx, model.dim, model.num_pdfs, model.pdf_offsets.data(), model.weights.data(), model.means_invvars.data(), model.inv_vars.data(), &g) != 0)
+    throw ApiError(std::string("vbh_gmm_create: ") + vbh_last_error());
+  g_gmms.models[key] = g;
+  return g;
+}
+void ReleaseDeviceGmmCache() { g_gmms.Clear(); }
+
 const float *DeviceFeatures(const FrontEnd &fe, const RawTable &t, size_t u0, size_t u1, int *dim, std::unique_ptr<DevBuffer> *hold) {
   const float *d_in = static_cast<const float *>(t.d_raw->p) + t.offs[u0] * (int64_t)t.dim;
   if (!fe.fused) { *dim = t.dim; return d_in; }

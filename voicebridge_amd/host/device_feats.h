@@ -58,6 +58,14 @@ struct RawTable {        // the rows of every utterance of a feature table, in t
 const RawTable &CachedRawTable(const std::string &rspecifier);
 void ReleaseRawTableCache();              // (vb_release_device_cache)
 
+// A model's device form (vbh_gmm) of the calling thread, kept from program to program: gmm-est-fmllr and gmm-rescore-lattice name the
+// same two or three model files job after job, and creating and destroying the device model per call is a dozen hipMalloc / hipFree --
+// every hipFree waits for ALL work of the device, i.e. for the other jobs' persistent search grids: the second fMLLR estimate of a job
+// whose search had ended early took 745 ms for 143 ms of work (round 5).  Keyed by path and file signature; a thread's models are
+// never shared (a vbh_gmm holds per-call buffers); released by vb_release_device_cache.
+vbh_gmm *CachedDeviceGmm(const std::string &path, const vbio::Model &model);
+void ReleaseDeviceGmmCache();
+
 // Features of utterances [u0, u1) of the table behind the front end -- or the table's own rows when no --fe-* options were
 // given -- as a device matrix [rows x *dim]; the returned pointer is into *hold (front end) or into the table (plain).
 const float *DeviceFeatures(const FrontEnd &fe, const RawTable &t, size_t u0, size_t u1, int *dim, std::unique_ptr<DevBuffer> *hold);

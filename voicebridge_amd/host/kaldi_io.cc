@@ -1078,17 +1078,32 @@ void SerializeLattice(const vblat::Lattice &lat, std::string *b) {
   }
 }
 void SerializeLattice(const vblat::CompactLattice &clat, std::string *b) {
-  PutFstHeader(b, "compactlattice44", clat.start, (int64_t)clat.st.size(), (int64_t)clat.NumArcs());
+  // One allocation and plain stores: an entry of a rescored raw lattice is half a megabyte of 4-byte fields, and sixteen threads growing
+  // strings field by field meet in the allocator (round 5: 1.0 -> 0.3 ms per entry)
+  size_t na = 0, nstr = 0;
+  for (const vblat::CState &s : clat.st) { na += s.arcs.size(); nstr += s.final.str.size(); for (const vblat::CArc &a : s.arcs) nstr += a.w.str.size(); }
+  const size_t head0 = b->size();
+  PutFstHeader(b, "compactlattice44", clat.start, (int64_t)clat.st.size(), (int64_t)na);
+  const size_t body0 = b->size();
+  // per state: final weight (2 floats + int32 length + string) + int64 arc count; per arc: 2 labels + weight (2 floats + length + string) + next state
+  const size_t body = clat.st.size() * (12 + 8) + na * (8 + 12 + 4) + 4 * nstr;
+  b->resize(body0 + body);
+  char *p = &(*b)[body0];
+  auto put = [&](const void *src, size_t n) { memcpy(p, src, n); p += n; };
   auto put_w = [&](const vblat::CWeight &w) {
-    Put(b, w.w.v1); Put(b, w.w.v2);
-    Put<int32_t>(b, (int32_t)w.str.size());
-    if (!w.str.empty()) b->append(reinterpret_cast<const char *>(w.str.data()), 4 * w.str.size());
+    put(&w.w.v1, 4); put(&w.w.v2, 4);
+    const int32_t len = (int32_t)w.str.size();
+    put(&len, 4);
+    if (len) put(w.str.data(), 4 * (size_t)len);
   };
   for (const vblat::CState &s : clat.st) {
     put_w(s.final);
-    Put<int64_t>(b, (int64_t)s.arcs.size());
-    for (const vblat::CArc &a : s.arcs) { Put(b, a.label); Put(b, a.label); put_w(a.w); Put(b, a.next); }
+    const int64_t n = (int64_t)s.arcs.size();
+    put(&n, 8);
+    for (const vblat::CArc &a : s.arcs) { put(&a.label, 4); put(&a.label, 4); put_w(a.w); put(&a.next, 4); }
   }
+  if ((size_t)(p - &(*b)[0]) != body0 + body) Fail("internal: compact lattice entry size");
+  (void)head0;
 }
 
 // Text form of a lattice entry ("ark,t:"), as the reference prints it (K/lat/kaldi-lattice.cc:62-90,388-415: a newline after the key,

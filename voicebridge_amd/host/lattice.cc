@@ -1095,10 +1095,12 @@ void ConvertLattice(const Lattice &lat, CompactLattice *clat) {
   for (int32_t s = 0; s < n; s++) remove[s] = props[s] == (kArcsIn | kArcsOut) || props[s] == (kArcsIn | kArcsOut | kIlabelsOut);
   std::vector<int32_t> mapping(n, -1);
   CompactLattice f;     // arcs carry their strings directly (the symbol table of Factor is only an indirection)
+  { size_t keep = 0; for (int32_t s = 0; s < n; s++) keep += !remove[s]; f.st.reserve(keep); }      // (no regrowth: a state moves its arcs' strings along)
   auto state_of = [&](int32_t s) { if (mapping[s] < 0) { mapping[s] = (int32_t)f.st.size(); f.st.emplace_back(); } return mapping[s]; };
   for (int32_t s : order) {
     if (remove[s]) continue;
     const int32_t ns = state_of(s);
+    f.st[ns].arcs.reserve(lat.st[s].arcs.size());
     for (const Arc &a0 : lat.st[s].arcs) {
       Arc arc = a0;
       CArc out;
@@ -1219,28 +1221,25 @@ bool RescoreCompactLattice(const std::function<float(int32_t, int32_t)> &loglike
   if (!IsTopSorted(*clat) && !TopSort(clat)) return false;
   std::vector<int32_t> times;
   const int32_t utt_len = CompactLatticeStateTimes(*clat, &times);
-  struct Tup { int32_t state, arc, tid; };
-  std::vector<std::vector<Tup>> tts(utt_len);
+  // The reference buckets (state, arc, transition-id) by time and walks the times in order (lattice-functions.cc:1236-1300); a weight
+  // receives its transition-ids' scores in increasing time, i.e. in the order of its own string, and no two weights share a sum: walking
+  // the weights and their strings directly adds the same floats in the same order -- without three thousand vectors per utterance.
+  // First the checks the bucketed walk would have failed on (nothing is modified when it returns false)
+  if (utt_len > num_frames) return false;          // features are too short for the lattice
   for (int32_t s = 0; s < (int32_t)clat->st.size(); s++) {
     const int32_t t = times[s];
-    for (int32_t ai = 0; ai < (int32_t)clat->st[s].arcs.size(); ai++) {
-      const std::vector<int32_t> &str = clat->st[s].arcs[ai].w.str;
-      for (size_t off = 0; off < str.size(); off++) {
-        if (t < utt_len) tts[t + off].push_back(Tup{s, ai, str[off]});
-        else if (t != utt_len) return false;
-      }
-    }
-    const CWeight &f = clat->st[s].final;
-    if (!(IsZero(f.w) && f.str.empty()))
-      for (size_t off = 0; off < f.str.size(); off++) tts[t + off].push_back(Tup{s, -1, f.str[off]});
+    for (const CArc &a : clat->st[s].arcs)
+      if (!a.w.str.empty() && t >= utt_len && t != utt_len) return false;
   }
-  for (int32_t t = 0; t < utt_len; t++) {
-    if (t >= num_frames) return false;          // features are too short for the lattice
-    for (const Tup &x : tts[t]) {
-      const float ll = loglike(t, x.tid);
-      Weight &w = x.arc < 0 ? clat->st[x.state].final.w : clat->st[x.state].arcs[x.arc].w.w;
-      w.v2 = -ll + w.v2;
+  for (int32_t s = 0; s < (int32_t)clat->st.size(); s++) {
+    const int32_t t = times[s];
+    for (CArc &a : clat->st[s].arcs) {
+      if (t >= utt_len) continue;                  // (t == utt_len: the reference adds nothing for such a string either)
+      for (size_t off = 0; off < a.w.str.size(); off++) a.w.w.v2 = -loglike(t + (int32_t)off, a.w.str[off]) + a.w.w.v2;
     }
+    CWeight &f = clat->st[s].final;
+    if (!(IsZero(f.w) && f.str.empty()))
+      for (size_t off = 0; off < f.str.size(); off++) f.w.v2 = -loglike(t + (int32_t)off, f.str[off]) + f.w.v2;
   }
   return true;
 }

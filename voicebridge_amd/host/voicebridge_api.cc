@@ -1433,7 +1433,7 @@ int vb_set_device(int device_id) { if (device_id != g_device) g_latgen.Release()
 int vb_get_device(void) { return g_device; }
 // frees the model, graph and search workspace the calling thread's last gmm-latgen-faster call left on the device
 // (and the context's scratch buffers -- a job's score matrix and feature output among them, gigabytes per job thread: ADVICE r4)
-void vb_release_device_cache(void) { g_latgen.Release(); ReleaseRawTableCache(); if (g_ctx) (void)vbh_ctx_scratch_release(g_ctx, -1); }
+void vb_release_device_cache(void) { g_latgen.Release(); ReleaseRawTableCache(); ReleaseDeviceGmmCache(); if (g_ctx) (void)vbh_ctx_scratch_release(g_ctx, -1); }
 // ... and the thread's GPU context itself (stream, staging arenas): for a thread that is about to end
 void vb_release_thread_context(void) {
   vb_release_device_cache();

@@ -6,6 +6,7 @@
 // GPU (DESIGN.md "next").
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <functional>
 #include <map>
@@ -30,7 +31,8 @@ namespace {
 struct Gmm {       // the acoustic model as the host sees it: gconsts recomputed as DiagGmm::Read does (K/gmm/diag-gmm.cc:114-152)
   vbio::Model m;
   std::vector<float> gconsts;
-  explicit Gmm(const std::string &path) {
+  std::string path;      // the file it was read from (key of the thread's cached device form, CachedDeviceGmm)
+  explicit Gmm(const std::string &path_in) : path(path_in) {
     vbio::ReadModel(path, &m);
     const int D = m.dim, G = m.pdf_offsets.back();
     gconsts.resize(G);
@@ -261,19 +263,26 @@ static int EstimateOnGpu(const char *prog, bool use_gpost, const Options &po, co
   if (po.Has("spk2utt")) units = vbio::ReadSpk2Utt(po.Str("spk2utt", ""));
   else for (const std::string &k : tab.keys) units.emplace_back(k, std::vector<std::string>{k});
   vbh_ctx *ctx = SharedCtx();
-  vbh_gmm *dgmm = nullptr;
-  if (vbh_gmm_create(ctx, D, gmm.m.num_pdfs, gmm.m.pdf_offsets.data(), gmm.m.weights.data(), gmm.m.means_invvars.data(), gmm.m.inv_vars.data(), &dgmm) != 0)
-    throw ApiError(std::string("vbh_gmm_create: ") + vbh_last_error());
-  struct GmmGuard { vbh_gmm *g; ~GmmGuard() { if (g) vbh_gmm_destroy(g); } } guard{dgmm}, ali_guard{nullptr};
+  // (the device forms of the models are the thread's cached ones: no device allocation, hence no device-wide wait, per call)
+  vbh_gmm *dgmm = gmm.path.empty() ? nullptr : CachedDeviceGmm(gmm.path, gmm.m);
+  struct GmmGuard { vbh_gmm *g; ~GmmGuard() { if (g) vbh_gmm_destroy(g); } } guard{nullptr}, ali_guard{nullptr};
+  if (!dgmm) {
+    if (vbh_gmm_create(ctx, D, gmm.m.num_pdfs, gmm.m.pdf_offsets.data(), gmm.m.weights.data(), gmm.m.means_invvars.data(), gmm.m.inv_vars.data(), &dgmm) != 0)
+      throw ApiError(std::string("vbh_gmm_create: ") + vbh_last_error());
+    guard.g = dgmm;
+  }
   // --ali-model (extension): the Gaussian posteriors come from that model, the statistics from `gmm` -- what the reference gets
   // by piping gmm-post-to-gpost into gmm-est-fmllr-gpost (VB/scr/steps/decode_fmllr.cpp first pass), without the gpost table
   vbh_gmm *dali = dgmm;
   if (ali_gmm) {
     if (ali_gmm->m.dim != D || ali_gmm->m.pdf_offsets != gmm.m.pdf_offsets || ali_gmm->m.tid2pdf != gmm.m.tid2pdf) throw ApiError("--ali-model: the alignment model's Gaussians do not match the model's");
-    if (vbh_gmm_create(ctx, D, ali_gmm->m.num_pdfs, ali_gmm->m.pdf_offsets.data(), ali_gmm->m.weights.data(), ali_gmm->m.means_invvars.data(),
-                       ali_gmm->m.inv_vars.data(), &ali_guard.g) != 0)
-      throw ApiError(std::string("vbh_gmm_create: ") + vbh_last_error());
-    dali = ali_guard.g;
+    if (!ali_gmm->path.empty()) dali = CachedDeviceGmm(ali_gmm->path, ali_gmm->m);
+    else {
+      if (vbh_gmm_create(ctx, D, ali_gmm->m.num_pdfs, ali_gmm->m.pdf_offsets.data(), ali_gmm->m.weights.data(), ali_gmm->m.means_invvars.data(),
+                         ali_gmm->m.inv_vars.data(), &ali_guard.g) != 0)
+        throw ApiError(std::string("vbh_gmm_create: ") + vbh_last_error());
+      dali = ali_guard.g;
+    }
   }
   std::vector<int32_t> num_gauss(gmm.m.num_pdfs);
   for (int p = 0; p < gmm.m.num_pdfs; p++) num_gauss[p] = gmm.m.pdf_offsets[p + 1] - gmm.m.pdf_offsets[p];
@@ -449,6 +458,14 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
     FrontEnd::Know(&po);
     po.Parse(argc, argv);
     if (po.args.size() != 4) throw ApiError("Wrong arguments.");
+    const bool laps = getenv("VBH_DEBUG_TIMES") != nullptr;      // diagnostic: where the time of a call goes
+    auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+      if (!laps) return;
+      const auto now = std::chrono::steady_clock::now();
+      fprintf(stderr, "gmm-rescore-lattice lap %-30s %8.1f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_lap).count());
+      t_lap = now;
+    };
     const float old_acoustic_scale = (float)po.Num("old-acoustic-scale", 0.0);
     vbio::Model model;
     vbio::ReadModel(po.args[0], &model);
@@ -457,10 +474,9 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
     fe.Parse(po);
     const RawTable &tab = CachedRawTable(po.args[2]);
     vbh_ctx *ctx = SharedCtx();
-    vbh_gmm *dgmm = nullptr;
-    if (vbh_gmm_create(ctx, D, model.num_pdfs, model.pdf_offsets.data(), model.weights.data(), model.means_invvars.data(), model.inv_vars.data(), &dgmm) != 0)
-      throw ApiError(std::string("vbh_gmm_create: ") + vbh_last_error());
-    struct GmmGuard { vbh_gmm *g; ~GmmGuard() { vbh_gmm_destroy(g); } } guard{dgmm};
+    (void)ctx;
+    vbh_gmm *dgmm = CachedDeviceGmm(po.args[0], model);      // (the thread's cached device form: no device allocation per call)
+    lap("model + table + device model");
     vbio::LatticeReader reader(po.args[1]);
     vbio::CompactLatticeWriter writer;
     writer.Open(po.args[3]);
@@ -476,6 +492,7 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
     };
     std::vector<Item> items;
     { Item it; while (reader.NextBytes(&it.key, &it.bytes, &it.nbytes)) { items.push_back(std::move(it)); it = Item(); } }
+    lap("lattice table read");
     auto parallel_for = [&](size_t n, const std::function<void(size_t)> &fn) {
       std::atomic<size_t> next{0};
       auto work = [&]() { for (size_t i = next++; i < n; i = next++) fn(i); };
@@ -503,13 +520,16 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
         std::vector<int32_t> times;
         const int32_t utt_len = vblat::CompactLatticeStateTimes(it.clat, &times);
         if (utt_len > it.rows) { it.warn = "Features are too short for lattice: utt-len is " + std::to_string(utt_len) + " for utterance " + it.key; return; }
-        std::vector<std::vector<int32_t>> pdfs(it.rows);
+        // (flat: (frame << 32 | pdf) keys of every transition-id, sorted and made unique -- a vector per frame was three thousand
+        // allocations per utterance on sixteen threads at once)
+        std::vector<uint64_t> keys;
+        keys.reserve(2 * it.clat.NumArcs() + 16);
         bool ok = true;
         auto add = [&](int32_t t0, const std::vector<int32_t> &str) {
           for (size_t o = 0; o < str.size(); o++) {
             if (str[o] <= 0 || str[o] >= (int32_t)model.tid2pdf.size()) throw ApiError("lattice: transition-id out of the model's range");
             if (t0 + (int32_t)o >= it.rows) { ok = false; return; }
-            pdfs[t0 + o].push_back(model.tid2pdf[str[o]]);
+            keys.push_back(((uint64_t)(uint32_t)(t0 + (int32_t)o) << 32) | (uint32_t)model.tid2pdf[str[o]]);
           }
         };
         for (size_t s = 0; s < it.clat.st.size() && ok; s++) {
@@ -517,19 +537,17 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
           add(times[s], it.clat.st[s].final.str);
         }
         if (!ok) { it.warn = "lattice/feature mismatch for utterance " + it.key; return; }
-        it.off.reserve(it.rows + 1);
-        for (int t = 0; t < it.rows; t++) {
-          std::vector<int32_t> &v = pdfs[t];
-          std::sort(v.begin(), v.end());
-          v.erase(std::unique(v.begin(), v.end()), v.end());
-          it.off.push_back((int64_t)it.pdfs.size());
-          it.pdfs.insert(it.pdfs.end(), v.begin(), v.end());
-        }
-        it.off.push_back((int64_t)it.pdfs.size());
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        it.off.assign((size_t)it.rows + 1, 0);
+        it.pdfs.resize(keys.size());
+        for (size_t k = 0; k < keys.size(); k++) { it.pdfs[k] = (int32_t)(uint32_t)keys[k]; it.off[(size_t)(keys[k] >> 32) + 1]++; }
+        for (int t = 0; t < it.rows; t++) it.off[(size_t)t + 1] += it.off[(size_t)t];
         it.ok = true;
       } catch (const std::exception &e) { it.err = e.what(); if (it.err.empty()) it.err = "error"; }
     });
     for (const Item &it : items) if (!it.err.empty()) throw ApiError(it.err);
+    lap("parse + convert + pdf lists");
     // ---- the pairs of every frame of the table, in table order (frames of utterances without a usable lattice: none)
     std::vector<int> item_of(tab.keys.size(), -1);
     for (size_t i = 0; i < items.size(); i++) if (items[i].ok && item_of[(size_t)items[i].utt] < 0) item_of[(size_t)items[i].utt] = (int)i;
@@ -544,6 +562,7 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
       ppdf.insert(ppdf.end(), it.pdfs.begin(), it.pdfs.end());
     }
     std::vector<float> scores(ppdf.size());
+    lap("pair table");
     if (!ppdf.empty()) {
       int fdim = 0;
       std::unique_ptr<DevBuffer> hold;
@@ -552,6 +571,7 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
       if (vbh_gmm_loglikes_pairs(dgmm, d_feats, tab.frames(), poff.data(), ppdf.data(), scores.data()) != 0)
         throw ApiError(std::string("vbh_gmm_loglikes_pairs: ") + vbh_last_error());
     }
+    lap("features + scores on the device");
     parallel_for(items.size(), [&](size_t k) {
       Item &it = items[k];
       if (!it.ok) return;
@@ -569,6 +589,7 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
         vblat::CompactLattice().st.swap(it.clat.st);
       } catch (const std::exception &e) { it.err = e.what(); }
     });
+    lap("rescore + serialize");
     for (Item &it : items) {
       if (!it.err.empty()) throw ApiError(it.err);
       if (!it.warn.empty()) { log.os() << "WARNING (gmm-rescore-lattice) " << it.warn << "\n"; num_err++; continue; }
@@ -576,6 +597,7 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
       num_done++; num_frames += it.rows;
       std::string().swap(it.entry);
     }
+    lap("write");
     log.os() << "LOG (gmm-rescore-lattice) Done " << num_done << " lattices with errors on " << num_err << ", #frames is " << num_frames << "\n";
     return num_done != 0 ? 0 : 1;
   });
