@@ -141,6 +141,12 @@ static_assert(UA >= 1 && UA <= 4, "Shared::wx holds 64 x 4 marker bytes per wave
 constexpr int UM = VBH_UM;                  // ... in the compaction moves
 constexpr int UC = VBH_UC;                  // ... in the candidate passes (LDS-bound: more only costs registers)
 constexpr int UL = VBH_UL;                  // ... in the pruning sweeps over links
+#ifndef VBH_CAND_PF
+#define VBH_CAND_PF 0          // pass 2: the next round's candidates in flight while this round's are admitted
+#endif
+#ifndef VBH_SEL_SKIP
+#define VBH_SEL_SKIP 1         // GetCutoff's radix select starts below the key bytes all of a frame's costs share (select_kth)
+#endif
 #ifndef VBH_HBITS
 #define VBH_HBITS (VBH_DECODE_NT >= 512 ? 14 : 11)
 #endif
@@ -666,11 +672,20 @@ __device__ __forceinline__ float frame_cost(const Shared &sh, gp<const i32x4> to
 
 // k-th smallest (0-based) of the current frame's costs: exact radix select on the
 // order-preserving keys (the std::nth_element value in GetCutoff, lattice-faster-decoder.cc:654-676)
-VBH_KI __device__ VBH_WARM float select_kth(gp<const i32x4> tok, int n, int k, Shared &sh) {
+// lo, hi: the smallest and the largest key of the frame (VBH_SEL_SKIP).  A frame's costs lie within a few beams of each other far from zero,
+// so their keys agree in the leading byte or two (sign, exponent, the top of the mantissa): the digits all keys share are the
+// statistic's as well, and the select starts below them -- two of its four passes (three barriers and a sweep over the costs each) in a
+// typical frame.  Exact: only passes whose histogram would have had a single occupied bin are left out.
+VBH_KI __device__ VBH_WARM float select_kth(gp<const i32x4> tok, int n, int k, Shared &sh, unsigned lo, unsigned hi) {
   const int tid = threadIdx.x;
+  int shift0 = 24;
+  if (VBH_SEL_SKIP) while (shift0 > 0 && (lo >> shift0) == (hi >> shift0)) shift0 -= 8;
   __syncthreads();
-  if (tid == 0) { sh.sel_prefix = 0; sh.sel_mask = 0; sh.sel_k = k; }
-  for (int shift = 24; shift >= 0; shift -= 8) {
+  if (tid == 0) {
+    const unsigned m0 = shift0 == 24 ? 0u : ~0u << (shift0 + 8);
+    sh.sel_prefix = lo & m0; sh.sel_mask = m0; sh.sel_k = k;
+  }
+  for (int shift = shift0; shift >= 0; shift -= 8) {
     for (int i = tid; i < 256; i += NT) sh.hist[i] = 0;
     __syncthreads();
     const unsigned prefix = sh.sel_prefix, mask = sh.sel_mask;
@@ -2078,6 +2093,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         for (int u = 0; u < (LLCAP + NT - 1) / NT; u++) { const int i = u * NT + tid; llr[u] = i < P ? llrow[i] : 0.0f; }
       }
       unsigned long long bk = ~0ull;
+      unsigned wk = 0u;                                 // the largest cost key (VBH_SEL_SKIP)
       for (int i0 = 0; i0 < n; i0 += NT * 4) {          // (four records per thread in flight; only {state, cost} of each is read)
         i32x2 r[4];
 #pragma unroll
@@ -2089,6 +2105,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
             if (i < COST_CAP) lds_cost(sh)[i] = asf(r[u].y);
             const unsigned long long k = ((unsigned long long)f2o(asf(r[u].y)) << 32) | (unsigned)(r[u].x & STMASK);
             bk = k < bk ? k : bk;
+            if (VBH_SEL_SKIP) wk = (unsigned)(k >> 32) > wk ? (unsigned)(k >> 32) : wk;
           }
         }
       }
@@ -2096,7 +2113,19 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
 #pragma unroll
         for (int u = 0; u < (LLCAP + NT - 1) / NT; u++) { const int i = u * NT + tid; if (i < P) sh.ll[i] = llr[u]; }
       }
+      if (VBH_SEL_SKIP) {
+        // (the maximum rides on the minimum's barrier: its partials in sh.hist, idle between the previous frame's second-level link list
+        // and the select, which empties it behind a barrier of its own)
+        const unsigned wmax = ~wave_min_u32(~wk);
+        if (lane == 0) sh.hist[par * NW + wave] = wmax;
+      }
+      const int par_cut = par;
       bk = block_min_u64(bk, sh, par);
+      if (VBH_SEL_SKIP) {
+        wk = sh.hist[par_cut * NW];
+#pragma unroll
+        for (int i = 1; i < NW; i++) wk = sh.hist[par_cut * NW + i] > wk ? sh.hist[par_cut * NW + i] : wk;
+      }
       PHASE_D(9)
       const float best = n > 0 ? o2f((unsigned)(bk >> 32)) : INF;
       const int best_state = (int)(unsigned)bk;
@@ -2124,14 +2153,14 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         cnt = block_sum_u64(cnt, sh, par);
         const int cnt_lt = (int)(cnt >> 32), cnt_le = (int)(unsigned)cnt;
         // the order statistic is only needed when it decides the comparison
-        if (n > cfg.max_active && cnt_lt > cfg.max_active) mac = select_kth<ADM>(tok, n, cfg.max_active, sh);
+        if (n > cfg.max_active && cnt_lt > cfg.max_active) mac = select_kth<ADM>(tok, n, cfg.max_active, sh, (unsigned)(bk >> 32), wk);
         if (mac < beam_cutoff) {
           adaptive_beam = mac - best + cfg.beam_delta; cur_cutoff = mac;
           if (tid == 0) sh.n_max_bound++;
         } else {
           if (n > cfg.min_active) {
             if (cfg.min_active == 0) mic = best;
-            else if (cnt_le <= cfg.min_active) mic = select_kth<ADM>(tok, n, cfg.min_active, sh);
+            else if (cnt_le <= cfg.min_active) mic = select_kth<ADM>(tok, n, cfg.min_active, sh, (unsigned)(bk >> 32), wk);
             else mic = beam_cutoff;   // some value <= beam_cutoff: the comparison below is false
           }
           if (mic > beam_cutoff) {
@@ -2303,13 +2332,30 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
         gp<int> front0 = uptr(s.front[0]);
         gp<i32x4> wl = uptr(s.wl);
         const int w_tok_cap = s.w_tok_cap, front_cap = s.front_cap, w_link_cap = s.w_link_cap;
+#if VBH_CAND_PF
+        // (the next round's candidate records are fetched before this round's are worked on: a round is otherwise a load the whole wave
+        // waits for, then a stretch of LDS atomics during which nothing is in flight)
+        i32x4 CAn[UC];
+#pragma unroll
+        for (int u = 0; u < UC; u++) { const int q = u * NT + tid; CAn[u] = cand[q < ncand ? q : 0]; }
+#endif
         for (int base = 0; base < ncand; base += NT * UC) {
           i32x4 CA[UC]; bool adm[UC];         // {tot, arc, source token, next state | EPSBIT}
+#if VBH_CAND_PF
+#pragma unroll
+          for (int u = 0; u < UC; u++) CA[u] = CAn[u];
+          if (base + NT * UC < ncand) {
+#pragma unroll
+            for (int u = 0; u < UC; u++) { const int q = base + NT * UC + u * NT + tid; CAn[u] = cand[q < ncand ? q : 0]; }
+          }
+#endif
 #pragma unroll
           for (int u = 0; u < UC; u++) {
             const int q = base + u * NT + tid;
             const bool ok = q < ncand;
+#if !VBH_CAND_PF
             CA[u] = cand[ok ? q : 0];
+#endif
             if (ADM == VBH_ADMIT_ORDERED) {
               const float bnd = o2f((unsigned)__shfl((int)adm_pre, (int)((unsigned)CA[u].z >> 26), 64));
               adm[u] = ok && !(asf(CA[u].x) > bnd);

@@ -228,6 +228,7 @@ struct Shared {
   unsigned long long u0;
 #ifdef VBH_FASTER_PROF      // build-time diagnostic: shader-clock cycles per phase, printed by thread 0 for the first utterances
   long long tph[16], t_last;
+  int n_sel, n_sel_over, n_sel_radix;
 #endif
 };
 #ifdef VBH_FASTER_PROF
@@ -362,6 +363,9 @@ __device__ double select_by_value(Each each, double best, double scale, unsigned
   });
   __syncthreads();
   const int vn = sh.vn[which];
+#ifdef VBH_FASTER_PROF
+  if (threadIdx.x == 0) { sh.n_sel++; if (vn > 64) sh.n_sel_over++; }
+#endif
   if (vn > 64) {
     // More costs in the step than the list holds.  The common reason (round 5): dozens of EXACTLY equal costs -- a word end's fan-out over
     // the phone-start states by weight-0 epsilon arcs -- right where min-active puts the cutoff.  If the step's costs are all one value,
@@ -371,6 +375,9 @@ __device__ double select_by_value(Each each, double best, double scale, unsigned
     __syncthreads();      // (everybody has read the range before the next use of the slot resets it)
     if (threadIdx.x == 0) { sh.vmin[which] = ~0ull; sh.vmax[which] = 0ull; }
     if (smin == smax) return o2d(smin);
+#ifdef VBH_FASTER_PROF
+    if (threadIdx.x == 0) sh.n_sel_radix++;
+#endif
     return select_kth(each, lo, hi, k, sh);
   }
   const unsigned long long mykey = lane < vn ? sh.vlist[which][lane] : ~0ull;
@@ -869,7 +876,7 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
   int par = 0;
 #ifdef VBH_FASTER_PROF
   long long *tph = sh.tph;
-  if (tid == 0) { for (int i = 0; i < 16; i++) sh.tph[i] = 0; sh.t_last = (long long)__builtin_amdgcn_s_memtime(); }
+  if (tid == 0) { for (int i = 0; i < 16; i++) sh.tph[i] = 0; sh.t_last = (long long)__builtin_amdgcn_s_memtime(); sh.n_sel = sh.n_sel_over = sh.n_sel_radix = 0; }
 #endif
   while (true) {
     __syncthreads();
@@ -1182,10 +1189,10 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
     FPHASE(9)
 #ifdef VBH_FASTER_PROF
     if (tid == 0 && utt < 4) {
-      printf("faster utt %d (%d frames, %lld tokens, %d frames on the slow winner path [tie %d bad %d]): cycles/frame gc %lld cutoff %lld clear %lld pass1 %lld pass2 %lld closure %lld winners %lld eps-winners %lld make: loads %lld stores %lld min %lld count %lld selects %lld barrier %lld; outside the frame loop %lld total\n",
-             utt, T, (long long)(cur_b + cur_n), sh.n_slow, sh.u_tie, sh.u_bad, tph[0] / T, tph[1] / T, tph[2] / T, tph[3] / T, tph[4] / T, tph[5] / T, tph[6] / T, tph[7] / T, tph[10] / T, tph[11] / T, tph[12] / T, tph[13] / T, tph[14] / T, tph[8] / T, tph[9]);
+      printf("faster utt %d (%d frames, %lld tokens, %d frames on the slow winner path [tie %d bad %d]; order statistics %d, over 64 in the step %d, radix select %d): cycles/frame gc %lld cutoff %lld clear %lld pass1 %lld pass2 %lld closure %lld winners %lld eps-winners %lld make: loads %lld stores %lld min %lld count %lld selects %lld barrier %lld; outside the frame loop %lld total\n",
+             utt, T, (long long)(cur_b + cur_n), sh.n_slow, sh.u_tie, sh.u_bad, sh.n_sel, sh.n_sel_over, sh.n_sel_radix, tph[0] / T, tph[1] / T, tph[2] / T, tph[3] / T, tph[4] / T, tph[5] / T, tph[6] / T, tph[7] / T, tph[10] / T, tph[11] / T, tph[12] / T, tph[13] / T, tph[14] / T, tph[8] / T, tph[9]);
     }
-    if (tid == 0) for (int i = 0; i < 16; i++) tph[i] = 0;
+    if (tid == 0) { for (int i = 0; i < 16; i++) tph[i] = 0; sh.n_sel = sh.n_sel_over = sh.n_sel_radix = 0; }
 #endif
     if (tid == 0) {
       FResult *r = &results[utt];
