@@ -39,7 +39,10 @@ constexpr int EPSBIT = (int)0x80000000;     // on an arc's next state: that stat
 constexpr int STMASK = 0x3FFFFFFF;
 constexpr int HBITS = 13;
 constexpr int HCAP = 1 << HBITS;            // states per frame the LDS map can hold
-constexpr int HPROBE = 64;
+#ifndef VBH_FASTER_HPROBE
+#define VBH_FASTER_HPROBE 16      // (round 5, same box: 64 / 32 / 16 / 8 probes: 2.06 / 1.99 / 1.97 / 2.00 s per 1024 x 30 s: a full map is given up on sooner)
+#endif
+constexpr int HPROBE = VBH_FASTER_HPROBE;
 constexpr unsigned HEMPTY = 0xFFFFFFFFu;
 constexpr int MAX_EPS_ITERS = 4096;
 #ifndef VBH_FASTER_SLOW
@@ -229,6 +232,7 @@ struct Shared {
 #ifdef VBH_FASTER_PROF      // build-time diagnostic: shader-clock cycles per phase, printed by thread 0 for the first utterances
   long long tph[16], t_last;
   int n_sel, n_sel_over, n_sel_radix;
+  long long s_cand, s_new, s_g, s_tok; int s_gframes;
 #endif
 };
 #ifdef VBH_FASTER_PROF
@@ -876,7 +880,7 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
   int par = 0;
 #ifdef VBH_FASTER_PROF
   long long *tph = sh.tph;
-  if (tid == 0) { for (int i = 0; i < 16; i++) sh.tph[i] = 0; sh.t_last = (long long)__builtin_amdgcn_s_memtime(); sh.n_sel = sh.n_sel_over = sh.n_sel_radix = 0; }
+  if (tid == 0) { for (int i = 0; i < 16; i++) sh.tph[i] = 0; sh.t_last = (long long)__builtin_amdgcn_s_memtime(); sh.n_sel = sh.n_sel_over = sh.n_sel_radix = 0; sh.s_cand = sh.s_new = sh.s_g = sh.s_tok = 0; sh.s_gframes = 0; }
 #endif
   while (true) {
     __syncthreads();
@@ -1083,6 +1087,9 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
       if (sh.n_new > s.frame_cap) { if (tid == 0) sh.error = FERR_FRAME; __syncthreads(); break; }
       const int nb = cur_b + cur_n;
       const int n_new = sh.n_new;
+#ifdef VBH_FASTER_PROF
+      if (tid == 0) { sh.s_cand += ncand; sh.s_new += n_new; sh.s_tok += n; if (sh.g_used) { sh.s_g += sh.n_g; sh.s_gframes++; } }
+#endif
 #ifdef VBH_FASTER_DEBUG
       if (tid == 0 && utt == 0 && frame < 12) printf("frame %d: n=%d ncand=%d n_new=%d g_used=%d next_cutoff=%f\n", frame, n, ncand, sh.n_new, sh.g_used, next_cutoff);
 #endif
@@ -1189,10 +1196,10 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
     FPHASE(9)
 #ifdef VBH_FASTER_PROF
     if (tid == 0 && utt < 4) {
-      printf("faster utt %d (%d frames, %lld tokens, %d frames on the slow winner path [tie %d bad %d]; order statistics %d, over 64 in the step %d, radix select %d): cycles/frame gc %lld cutoff %lld clear %lld pass1 %lld pass2 %lld closure %lld winners %lld eps-winners %lld make: loads %lld stores %lld min %lld count %lld selects %lld barrier %lld; outside the frame loop %lld total\n",
-             utt, T, (long long)(cur_b + cur_n), sh.n_slow, sh.u_tie, sh.u_bad, sh.n_sel, sh.n_sel_over, sh.n_sel_radix, tph[0] / T, tph[1] / T, tph[2] / T, tph[3] / T, tph[4] / T, tph[5] / T, tph[6] / T, tph[7] / T, tph[10] / T, tph[11] / T, tph[12] / T, tph[13] / T, tph[14] / T, tph[8] / T, tph[9]);
+      printf("faster utt %d (%d frames, %lld tokens, %d frames on the slow winner path [tie %d bad %d]; order statistics %d, over 64 in the step %d, radix select %d; per frame: tokens %lld, candidates %lld, new states %lld; second map level in %d frames, %lld states each): cycles/frame gc %lld cutoff %lld clear %lld pass1 %lld pass2 %lld closure %lld winners %lld eps-winners %lld make: loads %lld stores %lld min %lld count %lld selects %lld barrier %lld; outside the frame loop %lld total\n",
+             utt, T, (long long)(cur_b + cur_n), sh.n_slow, sh.u_tie, sh.u_bad, sh.n_sel, sh.n_sel_over, sh.n_sel_radix, sh.s_tok / T, sh.s_cand / T, sh.s_new / T, sh.s_gframes, sh.s_g / (sh.s_gframes ? sh.s_gframes : 1), tph[0] / T, tph[1] / T, tph[2] / T, tph[3] / T, tph[4] / T, tph[5] / T, tph[6] / T, tph[7] / T, tph[10] / T, tph[11] / T, tph[12] / T, tph[13] / T, tph[14] / T, tph[8] / T, tph[9]);
     }
-    if (tid == 0) { for (int i = 0; i < 16; i++) tph[i] = 0; sh.n_sel = sh.n_sel_over = sh.n_sel_radix = 0; }
+    if (tid == 0) { for (int i = 0; i < 16; i++) tph[i] = 0; sh.n_sel = sh.n_sel_over = sh.n_sel_radix = 0; sh.s_cand = sh.s_new = sh.s_g = sh.s_tok = 0; sh.s_gframes = 0; }
 #endif
     if (tid == 0) {
       FResult *r = &results[utt];
