@@ -959,14 +959,29 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
       unsigned long long mymin = ~0ull;
       {
         const int cand_cap = s.cand_cap;
-        const int CH = wave_chunk(n);
-        for (int base = wave * CH; base < n; base += NW * CH) {
-          const int i = base + lane;
-          const bool have = lane < CH && i < n;
-          const i32x4 rec = ctok[have ? i : 0];
-          const double c = ccost[have ? i : 0];
-          const bool exp = have && c < weight_cutoff;
-          const i32x4 sr = uptr(g.st)[exp ? (rec.z & STMASK) : 0];
+        // Rounds of <= 64 tokens per wave, software-pipelined as decode_kernel's pass 1 (round 5): while the arcs of round r are expanded, the
+        // state records of round r + 1 and the token records of round r + 2 are on their way (a round is otherwise a chain of four
+        // dependent loads: token, state, arc, score)
+        const int CH = wave_chunk(n), RS = NW * CH;
+        struct TokIn { int z; double c; };
+        auto ld_tok = [&](int b) -> TokIn {       // {state, cost} of this lane's token of the round starting at b (no token: a cost no cutoff admits)
+          const int i_ = b + lane;
+          TokIn t_; t_.z = 0; t_.c = (double)INFINITY;
+          if (b < n) { const bool have_ = lane < CH && i_ < n; const int z_ = ctok[have_ ? i_ : 0].z; const double c_ = ccost[have_ ? i_ : 0]; if (have_) { t_.z = z_; t_.c = c_; } }
+          return t_;
+        };
+        auto ld_st = [&](const TokIn &t_) -> i32x4 { return uptr(g.st)[(t_.c < weight_cutoff) ? (t_.z & STMASK) : 0]; };
+        const int b0 = wave * CH;
+        TokIn recC = ld_tok(b0), recB = ld_tok(b0 + RS);
+        i32x4 srC = ld_st(recC);
+        for (int base = b0; base < n; base += RS) {
+          const i32x4 srB = ld_st(recB);
+          const TokIn recA = ld_tok(base + 2 * RS);
+          i32x4 rec; rec.x = 0; rec.y = 0; rec.z = recC.z; rec.w = 0;
+          const double c = recC.c;
+          const i32x4 sr = srC;
+          recC = recB; srC = srB; recB = recA;
+          const bool exp = c < weight_cutoff;       // (false for lanes without a token)
           // (the sign bit of the first-arc index marks the frame's best token: its arcs give the initial bound, faster-decoder.cc:241-255)
           const int a0 = ((rec.z & STMASK) + 1 + sr.y) | ((ADM == FADM_ORDERED && exp && (rec.z & STMASK) == best_state) ? EPSBIT : 0), cnt = exp ? sr.z - sr.y : 0;
           // ordered admission: the token's bucket, and its bucket's bound as it stands at the start of the round (lane b of the scan
