@@ -3,7 +3,10 @@
 #ifndef VOICEBRIDGE_API_COMMON_H_
 #define VOICEBRIDGE_API_COMMON_H_
 
+#include <chrono>
+#include <sys/resource.h>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <initializer_list>
@@ -27,6 +30,22 @@ struct Log {
 
 // ---- Kaldi command-line grammar (K/util/parse-options.cc:341-352,477-508): --name=value,
 // --flag (boolean true), --config=file with one option per line, "--" ends the options
+// diagnostic (VBH_DEBUG_TIMES=1): where the host time of a program goes, lap by lap on stderr
+struct Laps {
+  const char *prog; bool on; std::chrono::steady_clock::time_point t; struct rusage r;
+  explicit Laps(const char *p) : prog(p), on(getenv("VBH_DEBUG_TIMES") != nullptr), t(std::chrono::steady_clock::now()) { if (on) getrusage(RUSAGE_SELF, &r); }
+  void operator()(const char *what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    struct rusage q; getrusage(RUSAGE_SELF, &q);      // (of the whole process: every thread that ran during the lap)
+    auto ms = [](const timeval &a, const timeval &b) { return (a.tv_sec - b.tv_sec) * 1e3 + (a.tv_usec - b.tv_usec) / 1e3; };
+    fprintf(stderr, "%s lap %-34s %8.1f ms   (process: user %.0f ms, system %.0f ms, page faults %ld, context switches %ld + %ld)\n", prog, what,
+            1e3 * std::chrono::duration<double>(now - t).count(), ms(q.ru_utime, r.ru_utime), ms(q.ru_stime, r.ru_stime), q.ru_minflt - r.ru_minflt,
+            q.ru_nvcsw - r.ru_nvcsw, q.ru_nivcsw - r.ru_nivcsw);
+    t = now; r = q;
+  }
+};
+
 struct Options {
   std::map<std::string, std::string> kv;
   std::vector<std::string> args;

@@ -1011,6 +1011,7 @@ void ReadFstStream(std::istream &is, Graph *g, const std::string &path) {
 namespace {
 std::mutex g_mem_mu;
 std::map<std::string, std::shared_ptr<MemTable>> g_mem_tables;
+std::map<std::string, std::shared_ptr<const FlatPostTable>> g_mem_posts;      // posterior tables published as objects
 }  // namespace
 bool IsMemPath(const std::string &path) { return path.compare(0, 4, "mem:") == 0; }
 void MemPublish(const std::string &path, std::shared_ptr<MemTable> t) { std::lock_guard<std::mutex> lk(g_mem_mu); g_mem_tables[path] = std::move(t); }
@@ -1019,7 +1020,7 @@ std::shared_ptr<MemTable> MemLookup(const std::string &path) {
   auto it = g_mem_tables.find(path);
   return it == g_mem_tables.end() ? nullptr : it->second;
 }
-void MemUnlink(const std::string &path) { std::lock_guard<std::mutex> lk(g_mem_mu); g_mem_tables.erase(path); }
+void MemUnlink(const std::string &path) { std::lock_guard<std::mutex> lk(g_mem_mu); g_mem_tables.erase(path); g_mem_posts.erase(path); }
 
 void LatticeWriter::Open(const std::string &wspecifier) {
   spec_ = ParseWspecifier(wspecifier);
@@ -1622,9 +1623,154 @@ void WriteGaussPostEntry(std::ostream &os, const std::string &key, const GaussPo
   }
 }
 
+namespace {
+std::shared_ptr<const FlatPostTable> MemLookupPost(const std::string &path) {
+  std::lock_guard<std::mutex> lk(g_mem_mu);
+  auto it = g_mem_posts.find(path);
+  return it == g_mem_posts.end() ? nullptr : it->second;
+}
+// one entry's bytes after "key " as SerializePosterior makes them, from the flat form
+void SerializeFlatPost(const FlatPost &post, std::string *b, bool text) {
+  const size_t T = post.frames();
+  if (text) {
+    char num[48];
+    for (size_t t = 0; t < T; t++) {
+      b->append("[ ");
+      for (int32_t i = post.off[t]; i < post.off[t + 1]; i++) { snprintf(num, sizeof(num), "%d %.7g ", post.e[(size_t)i].first, (double)post.e[(size_t)i].second); b->append(num); }
+      b->append("] ");
+    }
+    b->push_back('\n');
+    return;
+  }
+  b->reserve(b->size() + 7 + 5 * T + 10 * post.e.size());
+  auto put_i32 = [&](int32_t v) { b->push_back(4); b->append(reinterpret_cast<const char *>(&v), 4); };
+  b->push_back('\0'); b->push_back('B');
+  put_i32((int32_t)T);
+  for (size_t t = 0; t < T; t++) {
+    put_i32(post.off[t + 1] - post.off[t]);
+    for (int32_t i = post.off[t]; i < post.off[t + 1]; i++) { put_i32(post.e[(size_t)i].first); b->push_back(4); b->append(reinterpret_cast<const char *>(&post.e[(size_t)i].second), 4); }
+  }
+}
+}  // namespace
+
+void FlattenPosterior(const Posterior &post, FlatPost *flat) {
+  size_t n = 0;
+  for (const auto &fr : post) n += fr.size();
+  flat->off.clear(); flat->off.reserve(post.size() + 1); flat->off.push_back(0);
+  flat->e.clear(); flat->e.reserve(n);
+  for (const auto &fr : post) { flat->e.insert(flat->e.end(), fr.begin(), fr.end()); flat->EndFrame(); }
+}
+
+void WritePosteriorTableFlat(const std::string &wspecifier, std::shared_ptr<FlatPostTable> table) {
+  const Wspec spec = ParseWspecifier(wspecifier);
+  if (!spec.has_ark || spec.has_scp) Fail("expected an ark: wspecifier, got " + wspecifier);
+  if (IsMemPath(spec.ark_path)) {
+    if (spec.text) Fail("an in-memory table is binary: " + wspecifier);
+    std::lock_guard<std::mutex> lk(g_mem_mu);
+    g_mem_posts[spec.ark_path] = std::move(table);
+    return;
+  }
+  std::ofstream f(spec.ark_path, std::ios::binary);
+  if (!f) Fail("cannot open " + spec.ark_path + " for writing");
+  std::string b;
+  for (const auto &kv : *table) {
+    b.clear();
+    b.append(kv.first); b.push_back(' ');
+    SerializeFlatPost(kv.second, &b, spec.text);
+    f.write(b.data(), (std::streamsize)b.size());
+  }
+  if (f.fail()) Fail("write failure on " + spec.ark_path);
+}
+
+std::shared_ptr<const FlatPostTable> ReadPosteriorTableFlat(const std::string &rspecifier) {
+  const Rspec spec = ParseRspecifier(rspecifier);
+  if (spec.is_scp) Fail("scp: is not supported for posterior tables");
+  if (IsMemPath(spec.path)) {
+    std::shared_ptr<const FlatPostTable> t = MemLookupPost(spec.path);
+    if (!t) Fail("cannot open " + spec.path + " (no such in-memory posterior table)");
+    return t;
+  }
+  std::string buf;
+  {
+    std::ifstream is(spec.path, std::ios::binary | std::ios::ate);
+    if (!is) Fail("cannot open " + spec.path);
+    const std::streamoff n = is.tellg();
+    is.seekg(0);
+    buf.resize((size_t)std::max<std::streamoff>(n, 0));
+    if (n > 0) is.read(&buf[0], n);
+    if (is.fail()) Fail("read failure on " + spec.path);
+  }
+  const char *p = buf.data(), *end = p + buf.size();
+  auto need = [&](size_t n) { if ((size_t)(end - p) < n) Fail("posterior: truncated table " + spec.path); };
+  auto get_i32 = [&]() { need(5); if (*p != 4) Fail("posterior: expected a 4-byte integer in " + spec.path); int32_t v; memcpy(&v, p + 1, 4); p += 5; return v; };
+  auto out = std::make_shared<FlatPostTable>();
+  for (;;) {
+    while (p < end && isspace((unsigned char)*p)) p++;
+    if (p == end) break;
+    const char *k = p;
+    while (p < end && !isspace((unsigned char)*p)) p++;
+    const std::string key(k, p);
+    need(3);
+    p++;
+    FlatPost post;
+    if (p[0] != '\0' || p[1] != 'B') {       // text: the rest of the line, "[ tid weight ... ] [ ... ]" (posterior.cc:80-125)
+      const char *eol = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+      if (!eol) eol = end;
+      std::istringstream ls(std::string(p, eol));
+      std::string t;
+      while (ls >> t) {
+        if (t != "[") Fail("posterior: expected [ in the text entry of " + key + " in " + spec.path);
+        for (;;) {
+          if (!(ls >> t)) Fail("posterior: unterminated frame in the text entry of " + key);
+          if (t == "]") break;
+          char *e1 = nullptr;
+          const long tid = strtol(t.c_str(), &e1, 10);
+          float w;
+          if (e1 == t.c_str() || *e1 || !(ls >> w)) Fail("posterior: bad pair in the text entry of " + key);
+          post.e.emplace_back((int32_t)tid, w);
+        }
+        post.EndFrame();
+      }
+      out->emplace_back(key, std::move(post));
+      p = eol;
+      continue;
+    }
+    p += 2;
+    const int32_t sz = get_i32();
+    if (sz < 0 || (size_t)sz > (size_t)(end - p) / 5) Fail("posterior: bad size");
+    post.off.reserve((size_t)sz + 1);
+    post.e.reserve((size_t)sz + (size_t)sz / 2);
+    for (int32_t t = 0; t < sz; t++) {
+      const int32_t n = get_i32();
+      if (n < 0 || (size_t)n > (size_t)(end - p) / 10) Fail("posterior: bad size");
+      for (int32_t i = 0; i < n; i++) {
+        if (p[0] != 4 || p[5] != 4) Fail("posterior: bad field size in " + spec.path);
+        std::pair<int32_t, float> pr;
+        memcpy(&pr.first, p + 1, 4); memcpy(&pr.second, p + 6, 4);
+        post.e.push_back(pr);
+        p += 10;
+      }
+      post.EndFrame();
+    }
+    out->emplace_back(key, std::move(post));
+  }
+  return out;
+}
+
 std::vector<std::pair<std::string, Posterior>> ReadPosteriorTable(const std::string &rspecifier) {
   const Rspec spec = ParseRspecifier(rspecifier);
   if (spec.is_scp) Fail("scp: is not supported for posterior tables");
+  if (IsMemPath(spec.path)) {       // a table published as an object: frame vectors made from the flat form
+    std::shared_ptr<const FlatPostTable> t = MemLookupPost(spec.path);
+    if (!t) Fail("cannot open " + spec.path + " (no such in-memory posterior table)");
+    std::vector<std::pair<std::string, Posterior>> out;
+    for (const auto &kv : *t) {
+      Posterior post(kv.second.frames());
+      for (size_t f = 0; f < post.size(); f++) post[f].assign(kv.second.e.begin() + kv.second.off[f], kv.second.e.begin() + kv.second.off[f + 1]);
+      out.emplace_back(kv.first, std::move(post));
+    }
+    return out;
+  }
   std::string buf;
   {
     std::ifstream is(spec.path, std::ios::binary | std::ios::ate);

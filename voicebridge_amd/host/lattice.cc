@@ -345,9 +345,10 @@ class Determinizer {
     if (n == 0) return;
     ofst->st.resize(n);
     ofst->start = 0;
+    std::vector<int32_t> seq_;
     for (int s = 0; s < n; s++) {
       for (const TempArc &t : out_[s]->arcs) {
-        CWeight w; w.w = t.weight; repo_.ToVector(t.string, &w.str);
+        CWeight w; w.w = t.weight; repo_.ToVector(t.string, &seq_); w.str.assign(seq_.begin(), seq_.end());
         if (t.next < 0) ofst->st[s].final = std::move(w);
         else ofst->st[s].arcs.push_back(CArc{t.ilabel, std::move(w), t.next});
       }
@@ -824,7 +825,7 @@ void StringFrom(const CompactLattice &clat, int32_t state, int arc_idx, int32_t 
     }
     const size_t a = arc_idx < 0 ? 0 : (size_t)arc_idx;
     if (a >= st.arcs.size()) throw std::runtime_error("push: paths in the lattice are inconsistent in length");
-    const std::vector<int32_t> &str = st.arcs[a].w.str;
+    const LabelStr &str = st.arcs[a].w.str;
     if (str.size() >= len) { std::copy(str.begin(), str.begin() + len, out); return; }
     std::copy(str.begin(), str.end(), out);
     out += str.size(); len -= str.size();
@@ -866,7 +867,7 @@ bool PushCompactLatticeStrings(CompactLattice *clat) {
     CState &st = clat->st[s];
     for (CArc &arc : st.arcs) {
       if (arc.next <= s) throw std::runtime_error("push: cyclic lattice");
-      str = arc.w.str;
+      str.assign(arc.w.str.begin(), arc.w.str.end());
       const size_t orig = str.size(), more = (size_t)shift[arc.next];
       str.resize(orig + more);
       StringFrom(*clat, arc.next, -1, str.data() + orig, more);
@@ -909,7 +910,7 @@ bool PushCompactLatticeWeights(CompactLattice *clat) {
 bool MinimizeCompactLattice(CompactLattice *clat, float delta) {
   if (!SortedOrSort(clat)) return false;
   const int32_t n = (int32_t)clat->st.size();
-  auto hash_str = [](const std::vector<int32_t> &v) { uint64_t h = 1469598103934665603ull; for (int32_t x : v) h = (h ^ (uint32_t)x) * 1099511628211ull; return h | 1ull; };
+  auto hash_str = [](const LabelStr &v) { uint64_t h = 1469598103934665603ull; for (int32_t x : v) h = (h ^ (uint32_t)x) * 1099511628211ull; return h | 1ull; };
   std::vector<uint64_t> hash(n);
   for (int32_t s = n - 1; s >= 0; s--) {
     const CState &st = clat->st[s];

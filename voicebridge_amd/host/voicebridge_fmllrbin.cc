@@ -100,15 +100,15 @@ int LatticeToPost(int argc, char *argv[], std::ofstream &file_log) {
     const float acoustic_scale = (float)po.Num("acoustic-scale", 1.0), lm_scale = (float)po.Num("lm-scale", 1.0);
     if (acoustic_scale == 0.0f) throw ApiError("Do not use a zero acoustic scale (cannot be inverted)");
     vbio::LatticeReader reader(po.args[0]);
-    bool text_out = false;
-    std::ofstream out = vbio::OpenArkForWriting(po.args[1], &text_out);
     int n_done = 0;
     double total_like = 0.0, total_ac = 0.0, total_time = 0.0;
-    // the lattices of the table are independent: parsed, scaled, forward-backward and the entry's bytes on the host's threads;
-    // written (and the totals added up) in table order
-    struct Item { std::string key; const char *bytes = nullptr; size_t nbytes = 0; std::string entry, err; double like = 0, ac = 0; size_t frames = 0; };
+    // the lattices of the table are independent: parsed, scaled, forward-backward on the host's threads; the table is written (a file),
+    // or handed on as it is ("ark:mem:"), in table order
+    struct Item { std::string key; const char *bytes = nullptr; size_t nbytes = 0; vbio::FlatPost post; std::string err; double like = 0, ac = 0; };
     std::vector<Item> items;
+    Laps lap("lattice-to-post");
     { Item it; while (reader.NextBytes(&it.key, &it.bytes, &it.nbytes)) { items.push_back(std::move(it)); it = Item(); } }
+    lap("table read");
     {
       std::atomic<size_t> next{0};
       auto work = [&]() {
@@ -121,8 +121,7 @@ int LatticeToPost(int argc, char *argv[], std::ofstream &file_log) {
             if (!vblat::IsTopSorted(lat) && !vblat::TopSort(&lat)) throw ApiError("Cycles detected in lattice.");
             vblat::Posterior post;
             it.like = vblat::LatticeForwardBackward(lat, &post, &it.ac);
-            it.frames = post.size();
-            vbio::SerializePosterior(post, &it.entry, text_out);
+            vbio::FlattenPosterior(post, &it.post);
           } catch (const std::exception &e) { it.err = e.what(); if (it.err.empty()) it.err = "error"; }
         }
       };
@@ -132,15 +131,17 @@ int LatticeToPost(int argc, char *argv[], std::ofstream &file_log) {
       work();
       for (std::thread &t : pool) t.join();
     }
+    lap("parse + forward-backward");
+    auto table = std::make_shared<vbio::FlatPostTable>();
+    table->reserve(items.size());
     for (Item &it : items) {
       if (!it.err.empty()) throw ApiError(it.err);
-      total_like += it.like; total_time += (double)it.frames; total_ac += it.ac;
-      out << it.key << ' ';
-      out.write(it.entry.data(), (std::streamsize)it.entry.size());
-      std::string().swap(it.entry);
+      total_like += it.like; total_time += (double)it.post.frames(); total_ac += it.ac;
+      table->emplace_back(std::move(it.key), std::move(it.post));
       n_done++;
     }
-    if (out.fail()) throw ApiError("write failure on " + po.args[1]);
+    vbio::WritePosteriorTableFlat(po.args[1], std::move(table));
+    lap("write");
     log.os() << "LOG (lattice-to-post) Overall average log-like/frame is " << (total_like / total_time) << " over " << total_time
              << " frames.  Average acoustic like/frame is " << (total_ac / total_time) << "\n";
     log.os() << "LOG (lattice-to-post) Done " << n_done << " lattices.\n";
@@ -163,26 +164,33 @@ int WeightSilencePost(int argc, char *argv[], std::ofstream &file_log) {
     { std::string tok; std::istringstream is(po.args[1]); while (std::getline(is, tok, ':')) { if (tok.empty()) throw ApiError("Invalid silence-phones string " + po.args[1]); sil.insert(atoi(tok.c_str())); } }
     vbio::Model model;
     vbio::ReadModel(po.args[2], &model);
-    bool text_out = false;
-    std::ofstream out = vbio::OpenArkForWriting(po.args[4], &text_out);
     int n = 0;
-    // (per transition-id: is its phone a silence phone?  The frames are filtered in place: a table holds a vector per frame)
+    // (per transition-id: is its phone a silence phone?)
     std::vector<char> tid_sil(model.trans.phone.size(), 0);
     for (size_t t = 1; t < model.trans.phone.size(); t++) tid_sil[t] = sil.count(model.trans.phone[t]) ? 1 : 0;
-    for (auto &kv : vbio::ReadPosteriorTable(po.args[3])) {
-      for (auto &fr : kv.second) {
-        size_t o = 0;
-        for (size_t i = 0; i < fr.size(); i++) {
-          const std::pair<int32_t, float> pr = fr[i];
+    Laps lap("weight-silence-post");
+    const std::shared_ptr<const vbio::FlatPostTable> in = vbio::ReadPosteriorTableFlat(po.args[3]);
+    lap("model + table read");
+    auto out = std::make_shared<vbio::FlatPostTable>();
+    out->reserve(in->size());
+    for (const auto &kv : *in) {
+      const vbio::FlatPost &src = kv.second;
+      vbio::FlatPost dst;
+      dst.off.reserve(src.off.size()); dst.e.reserve(src.e.size());
+      for (size_t t = 0; t < src.frames(); t++) {
+        for (int32_t i = src.off[t]; i < src.off[t + 1]; i++) {
+          const std::pair<int32_t, float> pr = src.e[(size_t)i];
           if (pr.first <= 0 || pr.first >= (int32_t)tid_sil.size()) throw ApiError("posterior: transition-id out of the model's range");
-          if (tid_sil[pr.first]) { if (w != 0.0f) fr[o++] = std::make_pair(pr.first, pr.second * w); }
-          else fr[o++] = pr;
+          if (tid_sil[pr.first]) { if (w != 0.0f) dst.e.emplace_back(pr.first, pr.second * w); }
+          else dst.e.push_back(pr);
         }
-        fr.resize(o);
+        dst.EndFrame();
       }
-      vbio::WritePosteriorEntry(out, kv.first, kv.second, text_out);
+      out->emplace_back(kv.first, std::move(dst));
       n++;
     }
+    vbio::WritePosteriorTableFlat(po.args[4], std::move(out));
+    lap("weight + write");
     log.os() << "LOG (weight-silence-post) Done " << n << " posteriors.\n";
     return n != 0 ? 0 : 1;
   });
@@ -252,6 +260,7 @@ static int EstimateOnGpu(const char *prog, bool use_gpost, const Options &po, co
                          const std::string &trans_wspec, Log &log, AddUtt add_utt) {
   const vbfmllr::FmllrOptions opts = ReadFmllrOptions(po);
   const int D = gmm.m.dim, n1 = D + 1;
+  Laps lap(prog);
   // ---- the features: the table on the device (the thread's cached copy when this job's previous program read it), behind
   //      the fused front end when --fe-* options are given
   FrontEnd fe;
@@ -284,6 +293,7 @@ static int EstimateOnGpu(const char *prog, bool use_gpost, const Options &po, co
       dali = ali_guard.g;
     }
   }
+  lap("feature table + device models");
   std::vector<int32_t> num_gauss(gmm.m.num_pdfs);
   for (int p = 0; p < gmm.m.num_pdfs; p++) num_gauss[p] = gmm.m.pdf_offsets[p + 1] - gmm.m.pdf_offsets[p];
   std::vector<vbfmllr::FmllrAccs> accs(units.size(), vbfmllr::FmllrAccs(D));
@@ -309,10 +319,12 @@ static int EstimateOnGpu(const char *prog, bool use_gpost, const Options &po, co
     }
     for (int t = 0; t < rows; t++) sink.EndFrame();      // an utterance without statistics: frames without pairs
   }
+  lap("posterior pairs");
   if (num_done > 0) {
     int fdim = 0;
     std::unique_ptr<DevBuffer> hold;
     const float *d_feats = DeviceFeatures(fe, tab, 0, NU, &fdim, &hold);
+    lap("features on the device");
     if (fdim != D) throw ApiError("Dim mismatch: data dim = " + std::to_string(fdim) + " vs. model dim = " + std::to_string(D));
     const int S = (int)units.size();
     std::vector<double> beta(S), K((size_t)S * D * n1), G((size_t)S * D * n1 * n1);
@@ -322,7 +334,9 @@ static int EstimateOnGpu(const char *prog, bool use_gpost, const Options &po, co
         : vbh_fmllr_accumulate(ctx, dali, dgmm, d_feats, (int32_t)NU, tab.offs.data(), u2s.data(), S, sink.poff.data(), sink.ppdf.data(),
                                sink.pw.data(), beta.data(), K.data(), G.data(), nullptr);
     if (rc != 0) throw ApiError(std::string("vbh_fmllr_accumulate: ") + vbh_last_error());
+    lap("statistics on the device");
     for (int s_ = 0; s_ < S; s_++) if (beta[s_] != 0.0) accs[s_].AddStats(beta[s_], &K[(size_t)s_ * D * n1], &G[(size_t)s_ * D * n1 * n1]);
+    lap("statistics added");
   }
   // ---- per unit: update from the unit transform (40 row-by-row iterations, a 39 x 39 inverse per row: 0.1 s of one core per
   //      speaker, independent per speaker -> spread over the host's threads), then written in table order
@@ -346,6 +360,7 @@ static int EstimateOnGpu(const char *prog, bool use_gpost, const Options &po, co
     work();
     for (std::thread &t : pool) t.join();
   }
+  lap("row updates");
   vbio::MatrixWriter writer(trans_wspec);
   double tot_impr = 0.0, tot_t = 0.0;
   for (size_t s = 0; s < units.size(); s++) {
@@ -403,15 +418,34 @@ int GmmEstFmllr(int argc, char *argv[], std::ofstream &file_log) {
     const Gmm gmm(po.args[0]);
     std::unique_ptr<Gmm> ali;
     if (po.Has("ali-model")) ali.reset(new Gmm(po.Str("ali-model", "")));
-    std::map<std::string, vbio::Posterior> posts;
-    for (auto &kv : vbio::ReadPosteriorTable(po.args[2])) posts.emplace(kv.first, std::move(kv.second));
+    Laps lap("gmm-est-fmllr");
+    const std::shared_ptr<const vbio::FlatPostTable> table = vbio::ReadPosteriorTableFlat(po.args[2]);
+    std::unordered_map<std::string, const vbio::FlatPost *> posts;
+    posts.reserve(table->size() * 2);
+    for (const auto &kv : *table) posts.emplace(kv.first, &kv.second);       // (a key met twice: the first entry, as std::map::emplace kept it)
+    lap("models + posterior table read");
+    std::vector<std::pair<int32_t, float>> fr;
     return EstimateOnGpu("gmm-est-fmllr", false, po, gmm, ali.get(), po.args[1], po.args[3], log, [&](const std::string &utt, int feat_rows, PairSink *sink) {
       auto pi = posts.find(utt);
       if (pi == posts.end()) { log.os() << "WARNING (gmm-est-fmllr) Did not find posteriors for utterance " << utt << "\n"; return false; }
-      if ((int)pi->second.size() != feat_rows) { log.os() << "WARNING (gmm-est-fmllr) Posterior vector has wrong size " << pi->second.size() << " vs. " << feat_rows << "\n"; return false; }
-      vbio::Posterior pdf_post;
-      PosteriorToPdfs(gmm.m.tid2pdf, pi->second, &pdf_post);
-      for (const auto &fr : pdf_post) { for (const auto &pr : fr) { sink->ppdf.push_back(pr.first); sink->pw.push_back(pr.second); } sink->EndFrame(); }
+      const vbio::FlatPost &post = *pi->second;
+      if ((int)post.frames() != feat_rows) { log.os() << "WARNING (gmm-est-fmllr) Posterior vector has wrong size " << post.frames() << " vs. " << feat_rows << "\n"; return false; }
+      // ConvertPosteriorToPdfs (K/hmm/posterior.cc:322-346) frame by frame: the weights of a frame's transition-ids that share a pdf added
+      // in their order of appearance, pdfs in increasing order, zero totals dropped
+      for (int32_t i = 0; i < (int32_t)post.e.size(); i++)
+        if (post.e[(size_t)i].first <= 0 || post.e[(size_t)i].first >= (int32_t)gmm.m.tid2pdf.size()) throw ApiError("posterior: transition-id out of the model's range");
+      for (size_t t = 0; t < post.frames(); t++) {
+        fr.clear();
+        for (int32_t i = post.off[t]; i < post.off[t + 1]; i++) {
+          const int32_t pdf = gmm.m.tid2pdf[post.e[(size_t)i].first];
+          size_t k = 0;
+          while (k < fr.size() && fr[k].first < pdf) k++;
+          if (k < fr.size() && fr[k].first == pdf) fr[k].second += post.e[(size_t)i].second;
+          else fr.insert(fr.begin() + (std::ptrdiff_t)k, std::make_pair(pdf, 0.0f + post.e[(size_t)i].second));
+        }
+        for (const auto &pr : fr) if (pr.second != 0.0f) { sink->ppdf.push_back(pr.first); sink->pw.push_back(pr.second); }
+        sink->EndFrame();
+      }
       return true;
     });
   });
@@ -458,14 +492,7 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
     FrontEnd::Know(&po);
     po.Parse(argc, argv);
     if (po.args.size() != 4) throw ApiError("Wrong arguments.");
-    const bool laps = getenv("VBH_DEBUG_TIMES") != nullptr;      // diagnostic: where the time of a call goes
-    auto t_lap = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-      if (!laps) return;
-      const auto now = std::chrono::steady_clock::now();
-      fprintf(stderr, "gmm-rescore-lattice lap %-30s %8.1f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_lap).count());
-      t_lap = now;
-    };
+    Laps lap("gmm-rescore-lattice");
     const float old_acoustic_scale = (float)po.Num("old-acoustic-scale", 0.0);
     vbio::Model model;
     vbio::ReadModel(po.args[0], &model);
@@ -486,7 +513,7 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
     // the on-demand kernel for the (frame, pdf) pairs of all lattices over the table's features on the device; then the scores are
     // added (host threads) and the lattices written in table order.
     struct Item {
-      std::string key; const char *bytes = nullptr; size_t nbytes = 0; vblat::CompactLattice clat; std::string entry; int utt = -1, rows = 0;
+      std::string key; const char *bytes = nullptr; size_t nbytes = 0; std::string entry; int utt = -1, rows = 0;
       std::vector<int64_t> off; std::vector<int32_t> pdfs;      // per frame [off[t], off[t+1]) into pdfs (sorted, unique)
       int64_t base = 0; std::string warn, err; bool ok = false;
     };
@@ -502,40 +529,58 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
       work();
       for (std::thread &t : pool) t.join();
     };
+    // ---- pass 1 (host threads): which (frame, pdf) pairs a lattice holds.  For the state-level lattices DecodeFmllr hands over (the main
+    //      search's raw lattices: 9 k states / 15 k arcs per 30 s) these are read off the arcs as parsed -- an arc's transition-id at its
+    //      source state's time -- the same set the compact form's strings give (RescoreCompactLattice's time_to_state walk,
+    //      lattice-functions.cc:1236-1270); nothing of the lattice is kept: pass 2 parses the entry again (0.2 ms) and converts it there.
+    //      Keeping a thousand converted lattices alive between the passes grew sixteen threads' heaps page by page at once: 3.4 s of
+    //      system time in 0.3 s of wall clock, ten times what the conversion itself takes (round 5, VBH_DEBUG_TIMES laps).
     parallel_for(items.size(), [&](size_t i) {
       Item &it = items[i];
       try {
         auto fi = tab.index.find(it.key);
         if (fi == tab.index.end() || tab.rows((size_t)fi->second) == 0) { it.warn = "No feature found for utterance " + it.key + ". Skipping"; return; }
         it.utt = fi->second; it.rows = tab.rows((size_t)it.utt);
-        {
-          vblat::Lattice lat; bool compact = false;
-          vbio::ParseLatticeBytes(it.bytes, it.nbytes, &lat, &it.clat, &compact);
-          if (!compact) vblat::ConvertLattice(lat, &it.clat);      // CompactLatticeHolder::Read of a state-level lattice
-        }
-        if (old_acoustic_scale != 1.0f) vblat::ScaleLattice(1.0, 0.0, 0.0, (double)old_acoustic_scale, &it.clat);
-        if (it.clat.st.empty()) { it.warn = "Rescoring empty lattice for utterance " + it.key; return; }
-        if (!vblat::TopSort(&it.clat)) { it.warn = "Cycles detected in lattice " + it.key; return; }
-        // the pdfs the lattice holds at every frame (the same walk as RescoreCompactLattice's time_to_state, lattice-functions.cc:1236-1270)
-        std::vector<int32_t> times;
-        const int32_t utt_len = vblat::CompactLatticeStateTimes(it.clat, &times);
-        if (utt_len > it.rows) { it.warn = "Features are too short for lattice: utt-len is " + std::to_string(utt_len) + " for utterance " + it.key; return; }
-        // (flat: (frame << 32 | pdf) keys of every transition-id, sorted and made unique -- a vector per frame was three thousand
-        // allocations per utterance on sixteen threads at once)
-        std::vector<uint64_t> keys;
-        keys.reserve(2 * it.clat.NumArcs() + 16);
+        std::vector<uint64_t> keys;      // (frame << 32 | pdf) of every transition-id, then sorted and made unique
         bool ok = true;
-        auto add = [&](int32_t t0, const std::vector<int32_t> &str) {
-          for (size_t o = 0; o < str.size(); o++) {
-            if (str[o] <= 0 || str[o] >= (int32_t)model.tid2pdf.size()) throw ApiError("lattice: transition-id out of the model's range");
-            if (t0 + (int32_t)o >= it.rows) { ok = false; return; }
-            keys.push_back(((uint64_t)(uint32_t)(t0 + (int32_t)o) << 32) | (uint32_t)model.tid2pdf[str[o]]);
-          }
+        auto add1 = [&](int32_t t, int32_t tid) {
+          if (tid <= 0 || tid >= (int32_t)model.tid2pdf.size()) throw ApiError("lattice: transition-id out of the model's range");
+          if (t >= it.rows) { ok = false; return; }
+          keys.push_back(((uint64_t)(uint32_t)t << 32) | (uint32_t)model.tid2pdf[tid]);
         };
-        for (size_t s = 0; s < it.clat.st.size() && ok; s++) {
-          for (const vblat::CArc &a : it.clat.st[s].arcs) add(times[s], a.w.str);
-          add(times[s], it.clat.st[s].final.str);
+        int32_t utt_len = 0;
+        vblat::Lattice lat; vblat::CompactLattice clat; bool compact = false;
+        vbio::ParseLatticeBytes(it.bytes, it.nbytes, &lat, &clat, &compact);
+        if (!compact) {
+          if (lat.start < 0 || lat.st.empty()) { it.warn = "Rescoring empty lattice for utterance " + it.key; return; }
+          // state times by a walk from the start state (every path to a state holds the same number of transition-ids)
+          const int32_t n = (int32_t)lat.st.size();
+          std::vector<int32_t> times((size_t)n, -1), stack(1, lat.start);
+          times[(size_t)lat.start] = 0;
+          keys.reserve(lat.NumArcs() + 16);
+          while (!stack.empty()) {
+            const int32_t s = stack.back(); stack.pop_back();
+            const int32_t t = times[(size_t)s];
+            for (const vblat::Arc &a : lat.st[(size_t)s].arcs) {
+              if (a.ilabel != 0) add1(t, a.ilabel);
+              if (times[(size_t)a.next] < 0) { times[(size_t)a.next] = t + (a.ilabel != 0 ? 1 : 0); stack.push_back(a.next); }
+            }
+            if (!vblat::IsZero(lat.st[(size_t)s].final)) utt_len = std::max(utt_len, t);
+            if (!ok) break;
+          }
+        } else {
+          if (clat.st.empty()) { it.warn = "Rescoring empty lattice for utterance " + it.key; return; }
+          if (!vblat::TopSort(&clat)) { it.warn = "Cycles detected in lattice " + it.key; return; }
+          std::vector<int32_t> times;
+          utt_len = vblat::CompactLatticeStateTimes(clat, &times);
+          keys.reserve(2 * clat.NumArcs() + 16);
+          auto add = [&](int32_t t0, const vblat::LabelStr &str) { for (size_t o = 0; o < str.size() && ok; o++) add1(t0 + (int32_t)o, str[o]); };
+          for (size_t s = 0; s < clat.st.size() && ok; s++) {
+            for (const vblat::CArc &a : clat.st[s].arcs) add(times[s], a.w.str);
+            add(times[s], clat.st[s].final.str);
+          }
         }
+        if (utt_len > it.rows) { it.warn = "Features are too short for lattice: utt-len is " + std::to_string(utt_len) + " for utterance " + it.key; return; }
         if (!ok) { it.warn = "lattice/feature mismatch for utterance " + it.key; return; }
         std::sort(keys.begin(), keys.end());
         keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
@@ -547,7 +592,7 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
       } catch (const std::exception &e) { it.err = e.what(); if (it.err.empty()) it.err = "error"; }
     });
     for (const Item &it : items) if (!it.err.empty()) throw ApiError(it.err);
-    lap("parse + convert + pdf lists");
+    lap("pass 1: parse + pdf lists");
     // ---- the pairs of every frame of the table, in table order (frames of utterances without a usable lattice: none)
     std::vector<int> item_of(tab.keys.size(), -1);
     for (size_t i = 0; i < items.size(); i++) if (items[i].ok && item_of[(size_t)items[i].utt] < 0) item_of[(size_t)items[i].utt] = (int)i;
@@ -572,6 +617,8 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
         throw ApiError(std::string("vbh_gmm_loglikes_pairs: ") + vbh_last_error());
     }
     lap("features + scores on the device");
+    // ---- pass 2 (host threads): the entry parsed again, converted to the compact form (CompactLatticeHolder::Read of a state-level
+    //      lattice), old scores scaled, sorted, rescored, serialised -- every temporary freed before the thread's next lattice
     parallel_for(items.size(), [&](size_t k) {
       Item &it = items[k];
       if (!it.ok) return;
@@ -584,12 +631,20 @@ int GmmRescoreLattice(int argc, char *argv[], std::ofstream &file_log) {
         return scores[src.base + (f - src.pdfs.data())];
       };
       try {
-        if (!vblat::RescoreCompactLattice(loglike, it.rows, &it.clat)) { it.ok = false; it.warn = "lattice/feature mismatch for utterance " + it.key; return; }
-        vbio::SerializeLattice(it.clat, &it.entry);
-        vblat::CompactLattice().st.swap(it.clat.st);
+        vblat::CompactLattice clat;
+        {
+          vblat::Lattice lat; bool compact = false;
+          vbio::ParseLatticeBytes(it.bytes, it.nbytes, &lat, &clat, &compact);
+          if (!compact) vblat::ConvertLattice(lat, &clat);
+        }
+        if (old_acoustic_scale != 1.0f) vblat::ScaleLattice(1.0, 0.0, 0.0, (double)old_acoustic_scale, &clat);
+        if (clat.st.empty()) { it.ok = false; it.warn = "Rescoring empty lattice for utterance " + it.key; return; }
+        if (!vblat::TopSort(&clat)) { it.ok = false; it.warn = "Cycles detected in lattice " + it.key; return; }
+        if (!vblat::RescoreCompactLattice(loglike, it.rows, &clat)) { it.ok = false; it.warn = "lattice/feature mismatch for utterance " + it.key; return; }
+        vbio::SerializeLattice(clat, &it.entry);
       } catch (const std::exception &e) { it.err = e.what(); }
     });
-    lap("rescore + serialize");
+    lap("pass 2: parse + convert + rescore + serialize");
     for (Item &it : items) {
       if (!it.err.empty()) throw ApiError(it.err);
       if (!it.warn.empty()) { log.os() << "WARNING (gmm-rescore-lattice) " << it.warn << "\n"; num_err++; continue; }

@@ -80,7 +80,9 @@ int LatticeDeterminizePruned(int argc, char *argv[], std::ofstream &file_log) {
     struct Item { std::string key; const char *bytes = nullptr; size_t nbytes = 0; vblat::Lattice lat; vblat::CompactLattice det; std::string entry;
                   bool ok = true, empty = false, unsorted = false; double depth = 0; int32_t t = 0; size_t in_states = 0; std::string err; };
     std::vector<Item> items;
+    Laps lap("lattice-determinize-pruned");
     { Item it; while (reader.NextBytes(&it.key, &it.bytes, &it.nbytes)) { items.push_back(std::move(it)); it = Item(); } }
+    lap("table read");
     {
       std::atomic<size_t> next{0};
       auto work = [&]() {
@@ -116,6 +118,7 @@ int LatticeDeterminizePruned(int argc, char *argv[], std::ofstream &file_log) {
       work();
       for (std::thread &t : pool) t.join();
     }
+    lap("parse + determinize + serialize");
     for (Item &it : items) {
       if (!it.err.empty()) throw ApiError("key " + it.key + ": " + it.err);
       if (it.unsorted) log.os() << "WARNING (lattice-determinize-pruned) Could not topologically sort lattice: this probably means it has bad properties e.g. epsilon cycles.\n";

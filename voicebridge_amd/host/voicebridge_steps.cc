@@ -677,7 +677,7 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
     // search (stage > 2) reads lat.tmp.JOB as files, which only a run with VB_STEP_FILE_TEMPS=1 (files always, as the reference leaves them)
     // has written: without them the resume fails with a message that says so (below).
     const bool mem_tmp = stage <= 2 && !getenv("VB_STEP_FILE_TEMPS");
-    const std::string tmp_prefix = mem_tmp ? "mem:" : "";
+    const std::string tmp_prefix = mem_tmp ? "mem:" : "", small_tmp = getenv("VB_STEP_FILE_TEMPS") ? "" : "mem:";
     auto drop_tmp = [&](const std::string &path) { if (vbio::IsMemPath(path)) vbio::MemUnlink(path); else unlink(path.c_str()); };
     // (whatever way this call ends, no in-memory table of it stays behind: an exception between a table's writer and its last reader would
     // otherwise leave a job's hundred megabytes in the registry)
@@ -688,7 +688,7 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
     for (int j = 1; j <= nj; j++) {
       const std::string J = std::to_string(j);
       if (mem_tmp) mem_guard.names.push_back("mem:" + Join(dir, "lat.tmp." + J));
-      if (!getenv("VB_STEP_FILE_TEMPS")) mem_guard.names.push_back("mem:" + Join(Join(sdata, J), "grl.temp"));
+      if (!getenv("VB_STEP_FILE_TEMPS")) for (const char *t : {"grl.temp", "post.temp", "wsp.temp", "ldp.temp"}) mem_guard.names.push_back("mem:" + Join(Join(sdata, J), t));
     }
     const bool combined = CombinedSearch(nj);
     auto job_files = [&](int j, std::string *J, std::string *dsn) { *J = std::to_string(j); *dsn = Join(sdata, *J); return !ReadLines(Join(*dsn, "feats.scp"), false).empty(); };
@@ -712,14 +712,16 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
       if (!job_files(j, &J, &dsn) || stage > 1) return;
       std::ofstream log; open_log(J, &log);
       const std::string raw = "scp:" + Join(dsn, "feats.scp"), pre_trans = Join(dir, "pre_trans." + J), spk2utt = "--spk2utt=ark:" + Join(dsn, "spk2utt");
-      const std::string t_post = Join(dsn, "post.temp"), t_wsp = Join(dsn, "wsp.temp");
+      // (the small temporaries between the programs -- posteriors, determinized lattices -- are in-memory tables too; the posteriors as
+      // objects, kaldi_io.h FlatPostTable; VB_STEP_FILE_TEMPS=1: files, as the reference leaves them)
+      const std::string t_post = small_tmp + Join(dsn, "post.temp"), t_wsp = small_tmp + Join(dsn, "wsp.temp");
       run("lattice-to-post", LatticeToPost, {"lattice-to-post", acw, "ark:" + Join(si_dir, "lat." + J), "ark:" + t_post}, log);
       run("weight-silence-post", WeightSilencePost, {"weight-silence-post", std::to_string(silence_weight), silphonelist, alignment_model, "ark:" + t_post, "ark:" + t_wsp}, log);
       // the reference pipes gmm-post-to-gpost (alignment model) into gmm-est-fmllr-gpost (adapt model); here the Gaussian
       // posteriors never leave the GPU: gmm-est-fmllr takes them from --ali-model and the statistics from the adapt model
       run("gmm-est-fmllr", GmmEstFmllr, with_fe(fe_of(dsn), {"gmm-est-fmllr", "--fmllr-update-type=" + fmllr_update_type, spk2utt, "--ali-model=" + alignment_model, adapt_model,
                                                            raw, "ark:" + t_wsp, "ark:" + pre_trans}, ""), log);
-      unlink(t_post.c_str()); unlink(t_wsp.c_str());
+      drop_tmp(t_post); drop_tmp(t_wsp);
     };
     auto main_search = [&](int j) {      // main search on the first-pass features (:390-489), one job
       std::string J, dsn;
@@ -758,13 +760,13 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
                         "lattices in memory unless VB_STEP_FILE_TEMPS=1 is set (then they are the reference's files and survive a failed run); "
                         "resume at stage <= 2, or run the earlier stages again with VB_STEP_FILE_TEMPS=1");
       if (stage <= 3) {      // second fMLLR estimate, composed with the first (:491-566)
-        const std::string t_ldp = Join(dsn, "ldp.temp"), t_post = Join(dsn, "post.temp"), t_wsp = Join(dsn, "wsp.temp"), trans_tmp = Join(dir, "trans_tmp." + J);
+        const std::string t_ldp = small_tmp + Join(dsn, "ldp.temp"), t_post = small_tmp + Join(dsn, "post.temp"), t_wsp = small_tmp + Join(dsn, "wsp.temp"), trans_tmp = Join(dir, "trans_tmp." + J);
         run("lattice-determinize-pruned", LatticeDeterminizePruned, {"lattice-determinize-pruned", acw, "--beam=" + std::to_string(4.0), "ark:" + lat_tmp, "ark:" + t_ldp}, log);
         run("lattice-to-post", LatticeToPost, {"lattice-to-post", acw, "ark:" + t_ldp, "ark:" + t_post}, log);
         run("weight-silence-post", WeightSilencePost, {"weight-silence-post", std::to_string(silence_weight), silphonelist, adapt_model, "ark:" + t_post, "ark:" + t_wsp}, log);
         run("gmm-est-fmllr", GmmEstFmllr, with_fe(fe, {"gmm-est-fmllr", "--fmllr-update-type=" + fmllr_update_type, spk2utt, adapt_model, raw, "ark:" + t_wsp, "ark:" + trans_tmp}, pre_trans), log);
         run("compose-transforms", ComposeTransforms, {"compose-transforms", "--b-is-affine=true", "ark:" + trans_tmp, "ark:" + pre_trans, "ark:" + trans}, log);
-        unlink(t_ldp.c_str()); unlink(t_post.c_str()); unlink(t_wsp.c_str());
+        drop_tmp(t_ldp); drop_tmp(t_post); drop_tmp(t_wsp);
       }
       if (stage <= 4) {      // rescoring with the final model on the final features, determinization (:568-640)
         const std::string t_grl = (getenv("VB_STEP_FILE_TEMPS") ? "" : "mem:") + Join(dsn, "grl.temp");
