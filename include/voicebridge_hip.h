@@ -269,6 +269,17 @@ int vbh_decoder_create_shared(vbh_ctx *ctx, const vbh_graph *graph, const vbh_de
  * decoder's workspaces were made for): DecodeFmllr's speaker-independent pass (beam 10, max-active 2000) and its main pass
  * (beam 13, max-active 7000) then share one decoder and one set of workspaces. */
 int vbh_decoder_set_cfg(vbh_decoder *d, const vbh_decode_cfg *cfg);
+/* The library holds the search kernel in two layouts and a decoder is made for one of them:
+ *   1 = one workgroup of 1024 threads per CU (an utterance has the CU to itself): heavy searches, the default;
+ *   2 = two workgroups of 512 threads per CU: light searches (max_active <= 3000, e.g. DecodeFmllr's first pass at beam 10 /
+ *       max-active 2000), whose frames are a chain of short dependent phases -- two utterances per CU fill each other's waits
+ *       (1.4 x the frames per second at those settings; 5 % slower than layout 1 at max-active 7000).
+ * Results do not depend on the layout (the same algorithm on a smaller first-level state map; tests/test_gpu_variant.py runs the
+ * parity tests in layout 2).  vbh_decode_layout_for() = the layout vbh_decoder_create picks for a configuration (environment
+ * VBH_DECODE_LAYOUT=1|2 overrides); vbh_decoder_set_cfg never changes a decoder's layout, so a caller that alternates between a
+ * light and a heavy configuration keeps one decoder per layout (voicebridge_amd/host/voicebridge_api.cc does). */
+int vbh_decode_layout_for(const vbh_decode_cfg *cfg);
+int vbh_decoder_layout(const vbh_decoder *d);
 void vbh_decoder_destroy(vbh_decoder *d);
 /* Replaces LatticeFasterDecoder::Decode + FinalizeDecoding for a batch of utterances
  * (DecodeUtteranceLatticeFaster, K/decoder/decoder-wrappers.cc:198-293).  d_loglikes

@@ -1,9 +1,10 @@
-"""The two-workgroups-per-CU build of the search kernel (voicebridge_amd/build.py STRESS_LIB: 512 threads per utterance, an
-8192-slot state map) as a race detector.  With another workgroup's waves on their SIMDs the waves of a workgroup
-skew by hundreds of cycles; round 2 saw memory faults in this configuration and round 3 run-to-run differences (5 utterances in
-1000, some with cyclic lattices) until the cause was found: the ends of the token / link windows were read behind pass 1's reduction
-barrier, where a late wave could see a faster wave's first allocation of pass 2 (csrc/vbh_decode.hip).  The variant is
-loaded in a child process (the library is chosen at import: VBH_LIB_PATH)."""
+"""Layout 2 of the search kernel (two workgroups of 512 threads per CU, an 8192-slot state map: csrc/vbh_decode.hip "the two builds of this
+file") forced on the heavy configurations it is not chosen for (VBH_DECODE_LAYOUT=2) -- as a race detector and as the
+parity check of the layout the library picks for light searches (max_active <= 3000).  With another workgroup's waves on their SIMDs the waves
+of a workgroup skew by hundreds of cycles; round 2 saw memory faults in this configuration and round 3 run-to-run differences (5 utterances
+in 1000, some with cyclic lattices) until the cause was found: the ends of the token / link windows were read behind pass 1's reduction
+barrier, where a late wave could see a faster wave's first allocation of pass 2.  Child processes: the layout is chosen when a
+decoder is made, from the environment."""
 import os
 import subprocess
 import sys
@@ -16,10 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _env():
-    from voicebridge_amd import build
-    if not os.path.exists(build.STRESS_LIB):
-        pytest.fail("the stress variant %s is not built (python -m voicebridge_amd.build)" % build.STRESS_LIB)
-    return dict(os.environ, VBH_LIB_PATH=build.STRESS_LIB)
+    return dict(os.environ, VBH_DECODE_LAYOUT="2")
 
 
 def test_parity_at_bench_scale_with_two_workgroups_per_cu():

@@ -33,7 +33,7 @@ def build(specs):
         if p.wait() != 0:
             raise SystemExit("build failed: " + name)
         replaced = os.path.basename(src) if os.path.basename(src) in B.HIP_SOURCES else "vbh_decode.hip"      # (the product object the variant stands in for)
-        objs = [os.path.join(B.LIBDIR, "obj", s.replace(".hip", ".o")) for s in B.HIP_SOURCES if s != replaced] + [obj]
+        objs = [os.path.join(B.LIBDIR, "obj", s.replace(".hip", ".o")) for s in B.HIP_SOURCES if s != replaced] + [obj, os.path.join(B.LIBDIR, "obj", "vbh_decode_l2.o")]
         lib = os.path.join(VDIR, "libvoicebridge_hip_%s.so" % name)
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
         os.remove(obj)

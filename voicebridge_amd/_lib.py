@@ -18,7 +18,7 @@ SYMBOLS = [
     "vbh_featpost_out_dim", "vbh_featpost", "vbh_cmvn_stats",
     "vbh_gmm_create", "vbh_gmm_destroy", "vbh_gmm_num_pdfs", "vbh_gmm_dim", "vbh_gmm_get_gconsts",
     "vbh_gmm_set_lse_mode", "vbh_gmm_loglikes", "vbh_gmm_loglikes_ld", "vbh_gmm_padded_pdfs", "vbh_gmm_loglikes_pairs", "vbh_gmm_work",
-    "vbh_graph_create", "vbh_graph_destroy", "vbh_decode_cfg_default", "vbh_decoder_create", "vbh_decoder_create_shared", "vbh_decoder_set_cfg",
+    "vbh_graph_create", "vbh_graph_destroy", "vbh_decode_cfg_default", "vbh_decoder_create", "vbh_decoder_create_shared", "vbh_decoder_set_cfg", "vbh_decode_layout_for", "vbh_decoder_layout",
     "vbh_decoder_destroy", "vbh_decode_batch", "vbh_decode_batch_begin", "vbh_decode_batch_end", "vbh_decoder_result", "vbh_decoder_phase_cycles", "vbh_decoder_diag",
     "vbh_decoder_times", "vbh_decoder_utt_timeline", "vbh_decoder_batch_stats",
     "vbh_faster_cfg_default", "vbh_faster_decoder_create", "vbh_faster_decoder_create_ex", "vbh_faster_decoder_destroy", "vbh_faster_decode_batch", "vbh_faster_decode_batch_ex",

@@ -14,6 +14,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvoicebridge_hip.so")
 HIP_SOURCES = ["vbh_ctx.hip", "vbh_mfcc.hip", "vbh_featpost.hip", "vbh_gmm.hip", "vbh_decode.hip", "vbh_faster.hip", "vbh_fmllr.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+LAYOUT2_FLAGS = ["-DVBH_LAYOUT2=1", "-DVBH_DECODE_NT=512", "-DVBH_WAVES_PER_EU=4", "-DVBH_HBITS=13"]
 
 
 def _newer(src, dst):
@@ -46,6 +47,16 @@ def build(force=False, verbose=True):
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd)))
+    # the search kernel's second layout (two 512-thread workgroups per CU, for light searches: csrc/vbh_decode.hip "the two builds of this
+    # file"): the same source again, device code + launcher only
+    src = os.path.join(CSRC, "vbh_decode.hip")
+    obj2 = os.path.join(objdir, "vbh_decode_l2.o")
+    objs.append(obj2)
+    if force or _newer(src, obj2) or any(_newer(d, obj2) for d in deps):
+        cmd = [hipcc] + FLAGS + ["-ffp-contract=off"] + LAYOUT2_FLAGS + ["-c", src, "-o", obj2]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append(("vbh_decode.hip (layout 2)", subprocess.Popen(cmd)))
     failed = [s for s, p in procs if p.wait() != 0]
     if failed:
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
@@ -54,38 +65,8 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    build_stress_variant(objs, deps, force=force, verbose=verbose)
     build_host(force=force, verbose=verbose)
     return LIB
-
-
-# The search kernel with two workgroups per CU (512 threads per utterance, 4 waves per SIMD, an 8192-slot state map): not a product
-# configuration (it is no faster) but a RACE DETECTOR -- the waves of a workgroup skew far more when another
-# workgroup's waves share their SIMDs, which is how round 3 found the counter read that two waves of a frame could see differently.
-# tests/test_gpu_variant.py runs the bench-scale parity tests and a determinism check on it.
-STRESS_LIB = os.path.join(LIBDIR, "variants", "libvoicebridge_hip_nt512.so")
-STRESS_FLAGS = ["-DVBH_DECODE_NT=512", "-DVBH_WAVES_PER_EU=4", "-DVBH_HBITS=13"]
-
-
-def build_stress_variant(objs, deps, force=False, verbose=True):
-    os.makedirs(os.path.dirname(STRESS_LIB), exist_ok=True)
-    src = os.path.join(CSRC, "vbh_decode.hip")
-    obj = os.path.join(LIBDIR, "obj", "vbh_decode_nt512.o")
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    rebuilt = False
-    if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
-        cmd = [hipcc] + FLAGS + ["-ffp-contract=off"] + STRESS_FLAGS + ["-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        rebuilt = True
-    others = [o for o in objs if not o.endswith("vbh_decode.o")]
-    if rebuilt or not os.path.exists(STRESS_LIB) or any(_newer(o, STRESS_LIB) for o in others):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", STRESS_LIB] + others + [obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-    return STRESS_LIB
 
 
 HOST_LIB = os.path.join(LIBDIR, "libvoicebridge_host.so")

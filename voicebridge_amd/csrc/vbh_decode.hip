@@ -2686,6 +2686,7 @@ __global__ __launch_bounds__(NT, VBH_WAVES_PER_EU) void decode_kernel(DevGraph g
   }
 }
 
+#if !VBH_LAYOUT2
 // per batch: pdf of every emitting arc (arc.z = tid2pdf[ilabel]; -1 for input-epsilon arcs)
 __global__ void fill_arc_pdf_kernel(i32x4 *__restrict__ arcs, const int *__restrict__ arc_il, long long A,
                                     const int *__restrict__ tid2pdf) {
@@ -2694,10 +2695,64 @@ __global__ void fill_arc_pdf_kernel(i32x4 *__restrict__ arcs, const int *__restr
     if (il >= 0) reinterpret_cast<int *>(&arcs[a])[2] = il == 0 ? -1 : tid2pdf[il];      // (-1: a state's record or padding of the packed array)
   }
 }
+#endif
+
+// ---- the two builds of this file.  The library holds the search kernel twice (voicebridge_amd/build.py):
+//   layout 1 = one workgroup of 1024 threads per CU, a 16384-slot state map: the default.  A heavy search (max-active 7000) is bound by
+//              what one CU's units get through, and an utterance wants all of them (two half-size workgroups per CU: 977 against 925 ms);
+//   layout 2 = two workgroups of 512 threads per CU, an 8192-slot map (this file with -DVBH_LAYOUT2 -DVBH_DECODE_NT=512
+//              -DVBH_WAVES_PER_EU=4 -DVBH_HBITS=13).  A LIGHT search -- DecodeFmllr's first pass at beam 10 / max-active 2000: 670
+//              tokens per frame -- is bound by the ~25 dependent phases of a frame, and two utterances per CU fill each other's waits:
+//              392 -> 279 ms per 1024 x 30 s, same box (round 5).  Until then this build was the race detector of tests/test_gpu_variant.py
+//              (waves skew far more beside another workgroup's); it still is, now inside the product.
+// The second build consists of the device code above and the two entry points below; the host side (first build only) picks a layout
+// per decoder (vbh_decode_layout_for: max_active <= 3000 -> 2; VBH_DECODE_LAYOUT=1|2 overrides) and sizes its slot pools by it.
+struct LaunchArgs {
+  int admission, grid; hipStream_t st;
+  DevGraph dg; DecCfg dc; const Slot *slots; SlotPoolDev spool; const float *loglikes; int P;
+  const UttDesc *utts; const int *work_list; int n_work; int *work_counter; UttResult *results; const Pool *pool;
+};
+void launch_decode(const LaunchArgs &a) {
+  if (a.admission == VBH_ADMIT_ORDERED)
+    hipLaunchKernelGGL(decode_kernel<VBH_ADMIT_ORDERED>, dim3(a.grid), dim3(NT), 0, a.st, a.dg, a.dc, a.slots, a.spool, a.loglikes, a.P, a.utts, a.work_list,
+                       a.n_work, a.work_counter, a.results, a.pool);
+  else
+    hipLaunchKernelGGL(decode_kernel<VBH_ADMIT_EXACT>, dim3(a.grid), dim3(NT), 0, a.st, a.dg, a.dc, a.slots, a.spool, a.loglikes, a.P, a.utts, a.work_list,
+                       a.n_work, a.work_counter, a.results, a.pool);
+}
 
 }  // namespace
 
+#if VBH_LAYOUT2
+extern "C" void vbh_decode_l2_launch(const void *args) { launch_decode(*static_cast<const LaunchArgs *>(args)); }
+extern "C" void vbh_decode_l2_info(int *out3) { out3[0] = NT; out3[1] = HCAP; out3[2] = WG_PER_CU; }
+#else
+extern "C" void vbh_decode_l2_launch(const void *args);
+extern "C" void vbh_decode_l2_info(int *out3);
+
 // ============================================================================ host side
+struct Layout { int id, nt, hcap, wg_per_cu; void (*launch)(const void *); };
+static void launch_l1(const void *args) { launch_decode(*static_cast<const LaunchArgs *>(args)); }
+static const Layout *layout_by_id(int id) {
+  static const Layout l1{1, NT, HCAP, WG_PER_CU, launch_l1};
+  static const Layout l2 = [] { int v[3]; vbh_decode_l2_info(v); return Layout{2, v[0], v[1], v[2], vbh_decode_l2_launch}; }();
+  return id == 2 ? &l2 : &l1;
+}
+#ifndef VBH_LIGHT_MAX_ACTIVE
+#define VBH_LIGHT_MAX_ACTIVE 3000
+#endif
+// Slots of a decoder's pool: one per workgroup that can be resident, or fewer for small batches.  A pool is shared by the decoders of a
+// process (vbh_decoder_create_shared), and in layout 2 a job of 256 utterances fills only half of the device: the pool is made for the
+// whole device from 128 utterances up, so that the grids of several job threads run side by side instead of spinning for a slot
+// (four jobs of 256 sharing 256 slots gained nothing over layout 1: DecodeFmllr's first pass, round 5).
+static int pool_slots(const Layout *lay, int max_batch, int dev_cus) {
+  const int cap = lay->wg_per_cu * dev_cus;
+  return (lay->id == 2 && max_batch >= 128) ? cap : std::min(max_batch, cap);
+}
+static int layout_for(const vbh_decode_cfg *cfg) {
+  if (const char *e = getenv("VBH_DECODE_LAYOUT")) { if (!strcmp(e, "1")) return 1; if (!strcmp(e, "2")) return 2; }
+  return cfg->max_active <= VBH_LIGHT_MAX_ACTIVE ? 2 : 1;
+}
 struct vbh_graph {
   // Only the device is remembered, not the creating context: a graph is shared by the threads of a process (the jobs of a
   // step), and the context of the thread that happened to build it may be gone by the time the last user lets go of it
@@ -2758,6 +2813,7 @@ struct SlotSet {          // workspaces of one size class
   DevBuf<int> flags;
   int n_per_xcd = 0, n_xcd = 1;
   int device = 0, max_frames = 0, graph_states = 0;
+  int layout = 1;           // the build of the kernel these slots were made for (their slot -> token tables hold its map size)
   vbh_decode_cfg cfg{};
   std::vector<void *> allocs;
   SlotPoolDev dev() const { return SlotPoolDev{flags.p, n_per_xcd, n_xcd}; }
@@ -2771,6 +2827,7 @@ struct SlotSet {          // workspaces of one size class
 
 struct vbh_decoder {
   vbh_ctx *ctx; const vbh_graph *graph; vbh_decode_cfg cfg;
+  const Layout *lay = nullptr;
   int max_frames;
   std::shared_ptr<SlotSet> small_set;   // the device's slot pool (shared by the decoders created with vbh_decoder_create_shared)
   SlotSet big_set;                      // generous capacities, private, allocated on first overflow
@@ -2885,6 +2942,7 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
                                         std::min<long long>((ma + 256) * std::max(graph->max_degree, 1),
                                                             big ? (1LL << 24) : (long long)((1LL << 21) * std::min(1.0, slot_scale))));
   set->proto = p; set->n = n;
+  set->layout = d->lay->id;
   set->device = d->ctx->device; set->max_frames = max_frames; set->graph_states = (int)(graph->PKN / 2 + 1); set->cfg = *cfg;      // (what the slots' second-level maps are sized by)
   set->h.assign(n, p);
   const size_t F = (size_t)max_frames + 2;
@@ -2899,7 +2957,7 @@ static int alloc_slot_set(vbh_decoder *d, SlotSet *set, int n, bool big) {
   A_(ent, Ent, graph->PKN / 2 + 1, 0xFF)      // (EntMap)
   A_(w_tok, i32x4, p.w_tok_cap, -2) A_(w_remap, int, p.w_tok_cap, 0) A_(wl, i32x4, p.w_link_cap, -2)
   A_(w_tok_alive, unsigned long long, p.w_tok_cap / 64 + 2, 0) A_(w_lk_alive, unsigned long long, p.w_link_cap / 64 + 2, 0)
-  A_(w_grp, unsigned long long, (size_t)GRP_RING * (HCAP / 32), 0)
+  A_(w_grp, unsigned long long, (size_t)GRP_RING * (size_t)(d->lay->hcap / 32), 0)
   A_(h_tok, i32x4, p.h_tok_cap, -2) A_(h_remap, int, p.h_tok_cap, 0) A_(hl, i32x4, p.h_link_cap, -2)
   A_(fr, FrameRec, F, 0)
   A_(cand, i32x4, p.cand_cap, -2)
@@ -3050,6 +3108,7 @@ int vbh_decoder_create_shared(vbh_ctx *ctx, const vbh_graph *graph, const vbh_de
   if (vbh_use_device(ctx)) return -1;
   vbh_decoder *d = new vbh_decoder();
   d->ctx = ctx; d->graph = graph; d->cfg = *cfg; d->max_frames = max_frames;
+  d->lay = share_slots_with ? share_slots_with->lay : layout_by_id(layout_for(cfg));
   if (share_slots_with) {
     const SlotSet *o = share_slots_with->small_set.get();
     const bool ok = o && o->device == ctx->device && o->graph_states == (int)(graph->PKN / 2 + 1) && o->max_frames >= max_frames &&
@@ -3069,12 +3128,12 @@ int vbh_decoder_create_shared(vbh_ctx *ctx, const vbh_graph *graph, const vbh_de
     create_lk.lock();
     int dev_cus0 = ctx->num_cus;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) dev_cus0 = prop.multiProcessorCount; }
-    const int want_n = (std::min<int>(max_batch, WG_PER_CU * dev_cus0) + 7) & ~7;
+    const int want_n = (pool_slots(d->lay, max_batch, dev_cus0) + 7) & ~7;
     std::lock_guard<std::mutex> lk(g_pool_mu);
     for (auto it = g_pools.begin(); it != g_pools.end();) {
       std::shared_ptr<SlotSet> o = it->lock();
       if (!o) { it = g_pools.erase(it); continue; }
-      if (o->device == ctx->device && o->graph_states == (int)(graph->PKN / 2 + 1) && o->max_frames >= max_frames && o->cfg.max_active >= cfg->max_active &&
+      if (o->layout == d->lay->id && o->device == ctx->device && o->graph_states == (int)(graph->PKN / 2 + 1) && o->max_frames >= max_frames && o->cfg.max_active >= cfg->max_active &&
           effective_prune_interval(&o->cfg) == effective_prune_interval(cfg) && o->n >= want_n) {
         d->small_set = o;
         *out = d;
@@ -3089,7 +3148,7 @@ int vbh_decoder_create_shared(vbh_ctx *ctx, const vbh_graph *graph, const vbh_de
   // so capacity never truncates a result.
   int dev_cus = ctx->num_cus;
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) dev_cus = prop.multiProcessorCount; }
-  int n = std::min<int>(max_batch, WG_PER_CU * dev_cus);
+  int n = pool_slots(d->lay, max_batch, dev_cus);
   n = (n + 7) & ~7;
   d->small_set = std::make_shared<SlotSet>();
   if (alloc_slot_set(d, d->small_set.get(), n, /*big=*/false)) { vbh_decoder_destroy(d); return -1; }
@@ -3245,11 +3304,11 @@ static const char *err_name(int e) {
 
 extern "C" {
 
-// one instantiation of the search kernel per admission rule (DecCfg::admission)
-#define VBH_LAUNCH_DECODE(grid_, dg_, dc_, ...)                                                                                         \
+// the search kernel of the decoder's layout, one instantiation per admission rule (DecCfg::admission)
+#define VBH_LAUNCH_DECODE(grid_, dg_, dc_, slots_, spool_, ll_, P_, utts_, list_, n_work_, counter_, res_, pool_)                          \
   {                                                                                                                                     \
-    if (admission_of(&d->cfg) == VBH_ADMIT_ORDERED) hipLaunchKernelGGL(decode_kernel<VBH_ADMIT_ORDERED>, grid_, dim3(NT), 0, st, dg_, dc_, __VA_ARGS__); \
-    else hipLaunchKernelGGL(decode_kernel<VBH_ADMIT_EXACT>, grid_, dim3(NT), 0, st, dg_, dc_, __VA_ARGS__);                               \
+    const LaunchArgs a_{admission_of(&d->cfg), (int)(grid_), st, dg_, dc_, slots_, spool_, ll_, P_, utts_, list_, n_work_, counter_, res_, pool_}; \
+    d->lay->launch(&a_);                                                                                                                \
   }
 static int decode_batch_begin_impl(vbh_decoder *d, const float *d_loglikes, int32_t num_pdfs, const int64_t *h_frame_offsets,
                                    int32_t n_utt, const int32_t *h_tid2pdf, int32_t num_tids) {
@@ -3357,7 +3416,7 @@ static int decode_batch_begin_impl(vbh_decoder *d, const float *d_loglikes, int3
       Pool closed = pool; closed.tok_cap = 0; closed.link_cap = 0; closed.cost_cap = 0;
       VBH_HIP(hipMemcpyAsync(d->d_utts.p, probe.data(), sizeof(UttDesc) * n_utt, hipMemcpyHostToDevice, st));
       VBH_HIP(hipMemcpyAsync(d->d_pool.p, &closed, sizeof(Pool), hipMemcpyHostToDevice, st));
-      VBH_LAUNCH_DECODE(dim3(std::min(WG_PER_CU * d->ctx->num_cus, n_utt)), dg0, dc0, d->small_set->d.p, d->small_set->dev(), d_loglikes,
+      VBH_LAUNCH_DECODE(std::min(d->lay->wg_per_cu * d->ctx->num_cus, n_utt), dg0, dc0, d->small_set->d.p, d->small_set->dev(), d_loglikes,
                          (int)num_pdfs, d->d_utts.p, (const int *)nullptr, n_utt, d->d_counter.p, d->d_res.p, d->d_pool.p);
       VBH_HIP(hipGetLastError());
       std::vector<UttResult> pr(n_utt);
@@ -3386,7 +3445,7 @@ static int decode_batch_begin_impl(vbh_decoder *d, const float *d_loglikes, int3
   d->pend.d_loglikes = d_loglikes; d->pend.num_pdfs = num_pdfs; d->pend.tok_cap = tok_cap; d->pend.link_cap = link_cap;
   {
     // one workgroup per slot the context's CUs can hold (a CU-masked context counts its own CUs), never more than the pool has
-    int grid = std::min(std::min(d->small_set->n, WG_PER_CU * d->ctx->num_cus), n_utt);
+    int grid = std::min(std::min(d->small_set->n, d->lay->wg_per_cu * d->ctx->num_cus), n_utt);
     // VBH_SEARCH_MAX_WGS (diagnostic): a search grid smaller than the device.  A persistent search workgroup holds its CU until the grid has no
     // utterance left, so this keeps CUs free for the kernels other job threads issue beside a search (statistics, rescoring, the next job's
     // scoring).  Measured r04 on DecodeFmllr, 4 jobs of 256 utterances on one GPU: 3.56 s uncapped, 4.00 / 4.27 / 4.24 s at 224 / 192 / 160
@@ -3394,7 +3453,7 @@ static int decode_batch_begin_impl(vbh_decoder *d, const float *d_loglikes, int3
     if (const char *e = getenv("VBH_SEARCH_MAX_WGS")) { const int cap_wgs = atoi(e); if (cap_wgs > 0) grid = std::max(1, std::min(grid, cap_wgs)); }
     VBH_HIP(hipMemsetAsync(d->d_res.p, 0xFF, sizeof(UttResult) * (size_t)n_utt, st));     // error = -1: "no workgroup searched it" until one does
     VBH_HIP(hipEventRecord(d->ev0, st));
-    VBH_LAUNCH_DECODE(dim3(grid), d->pend.dg, d->pend.dc, d->small_set->d.p, d->small_set->dev(), d_loglikes, (int)num_pdfs,
+    VBH_LAUNCH_DECODE(grid, d->pend.dg, d->pend.dc, d->small_set->d.p, d->small_set->dev(), d_loglikes, (int)num_pdfs,
                        d->d_utts.p, d_work_list, n_utt, d->d_counter.p, d->d_res.p, d_pool.p);
     VBH_HIP(hipGetLastError());
     VBH_HIP(hipEventRecord(d->ev1, st));
@@ -3529,9 +3588,9 @@ static int decode_batch_end_impl(vbh_decoder *d) {
       DevBuf<int> d_list;
       if (d_list.upload(list.data(), list.size(), st)) return -1;
       VBH_HIP(hipMemsetAsync(d_counter.p, 0, sizeof(int), st));
-      const int grid = std::min<int>(big ? set.n : std::min(set.n, WG_PER_CU * d->ctx->num_cus), (int)list.size());
+      const int grid = std::min<int>(big ? set.n : std::min(set.n, d->lay->wg_per_cu * d->ctx->num_cus), (int)list.size());
       VBH_HIP(hipEventRecord(ev0, st));
-      VBH_LAUNCH_DECODE(dim3(grid), dg, dc, set.d.p, set.dev(), d_loglikes, (int)num_pdfs,
+      VBH_LAUNCH_DECODE(grid, dg, dc, set.d.p, set.dev(), d_loglikes, (int)num_pdfs,
                          d_utts.p, d_list.p, (int)list.size(), d_counter.p, d_res.p, d_pool.p);
       VBH_HIP(hipGetLastError());
       VBH_HIP(hipEventRecord(ev1, st));
@@ -3668,4 +3727,8 @@ int vbh_decoder_result(vbh_decoder *d, int32_t utt, vbh_lattice *out) {
   return 0;
 }
 
+int vbh_decode_layout_for(const vbh_decode_cfg *cfg) { return cfg ? layout_for(cfg) : 1; }
+int vbh_decoder_layout(const vbh_decoder *d) { return d && d->lay ? d->lay->id : 0; }
+
 }  // extern "C"
+#endif  // !VBH_LAYOUT2

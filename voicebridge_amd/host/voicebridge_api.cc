@@ -163,9 +163,10 @@ struct LatgenCache {
   int32_t graph_start = 0;
   vbh_gmm *gmm = nullptr;
   std::shared_ptr<GraphHolder> gh;
-  vbh_decoder *dec = nullptr;
-  vbh_decode_cfg dec_cfg{};
-  int dec_batch = 0, dec_T = 0;
+  // one search workspace per layout of the search kernel (voicebridge_hip.h vbh_decode_layout_for): DecodeFmllr alternates between a
+  // light first pass (max-active 2000: two utterances per CU) and the heavy main pass; [layout - 1]
+  struct Dec { vbh_decoder *dec = nullptr; vbh_decode_cfg cfg{}; int batch = 0, T = 0; } decs[2];
+  void DropDecoders() { for (Dec &d : decs) { if (d.dec) vbh_decoder_destroy(d.dec); d = Dec(); } }
   void *d_ll = nullptr;            // the batch's scores [frames x pdfs]: gigabytes per job, kept (grow-only) like the search workspace
   size_t d_ll_bytes = 0;
   void *Scores(vbh_ctx *c, size_t bytes) {
@@ -180,10 +181,10 @@ struct LatgenCache {
   void Release() {
     if (d_ll && ctx) vbh_dev_free(ctx, d_ll);
     d_ll = nullptr; d_ll_bytes = 0;
-    if (dec) vbh_decoder_destroy(dec);
+    DropDecoders();
     gh.reset();
     if (gmm) vbh_gmm_destroy(gmm);
-    dec = nullptr; gmm = nullptr; dec_batch = dec_T = 0; model_path.clear(); graph_path.clear(); ctx = nullptr;
+    gmm = nullptr; model_path.clear(); graph_path.clear(); ctx = nullptr;
   }
   ~LatgenCache() { /* the process is ending or the thread is: the runtime reclaims device memory */ }
 };
@@ -794,7 +795,7 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
       // the graph (and with it the search workspace) and the model are kept independently: DecodeFmllr's passes use two or
       // three models over one graph
       if (!cache.gh || cache.graph_path != po.args[1] || cache.graph_sig != gs || gs < 0) {
-        if (cache.dec) { vbh_decoder_destroy(cache.dec); cache.dec = nullptr; cache.dec_batch = cache.dec_T = 0; }
+        cache.DropDecoders();
         cache.gh.reset();
         // The graph (file -> host -> device form: the longest piece of a cold start) is fetched by a helper thread while this one
         // reads the model and the features and scores the first batch; it is waited for where the search workspace is made.
@@ -856,15 +857,20 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     // the cached workspace serves this call when its capacities cover the search configuration (vbh_decoder_set_cfg: beams and
     // scales are free, max_active up to what the workspaces were made for); --workspace-max-active (extension) asks for workspaces
     // that also cover a later call with a larger max_active (DecodeFmllr: first pass 2000, main pass 7000)
+    // A light configuration (layout 2) gets workspaces of its own, sized for itself; the workspace-wide max_active applies to the heavy layout
+    const int layout = vbh_decode_layout_for(&cfg);
+    LatgenCache::Dec &cd = cache.decs[layout == 2 ? 1 : 0];
     vbh_decode_cfg ws_cfg = cfg;
-    ws_cfg.max_active = std::max(cfg.max_active, (int)po.Num("workspace-max-active", 0.0));
-    if (g_workspace_max_active.load() > ws_cfg.max_active) ws_cfg.max_active = g_workspace_max_active.load();
-    if (cache.dec && memcmp(&cache.dec_cfg, &cfg, sizeof(cfg)) != 0 && vbh_decoder_set_cfg(cache.dec, &cfg) != 0) {
-      vbh_decoder_destroy(cache.dec); cache.dec = nullptr; cache.dec_batch = cache.dec_T = 0;
+    if (layout != 2) {
+      ws_cfg.max_active = std::max(cfg.max_active, (int)po.Num("workspace-max-active", 0.0));
+      if (g_workspace_max_active.load() > ws_cfg.max_active) ws_cfg.max_active = g_workspace_max_active.load();
     }
-    cache.dec_cfg = cfg;
-    vbh_decoder *&dec = cache.dec;
-    int &dec_batch = cache.dec_batch, &dec_T = cache.dec_T;
+    if (cd.dec && memcmp(&cd.cfg, &cfg, sizeof(cfg)) != 0 && vbh_decoder_set_cfg(cd.dec, &cfg) != 0) {
+      vbh_decoder_destroy(cd.dec); cd = LatgenCache::Dec();
+    }
+    cd.cfg = cfg;
+    vbh_decoder *&dec = cd.dec;
+    int &dec_batch = cd.batch, &dec_T = cd.T;
     // the feature table on the device: read and uploaded once per job (the thread's cached copy serves the job's other programs)
     const RawTable &tab = CachedRawTable(po.args[2]);
     lap("features to the device");

@@ -22,6 +22,7 @@
 #include <mutex>
 #include <vector>
 
+#include "api_common.h"
 #include "kaldi_io.h"
 #include "lattice.h"
 #include "voicebridge_api.h"
@@ -653,17 +654,19 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
     const bool lda = Exists(Join(srcdir, "final.mat"));
     const std::string acw = "--acoustic-scale=" + std::to_string(acwt), symtab = Join(graphdir, "words.txt");
     const bool laps = getenv("VBH_DEBUG_TIMES") != nullptr;
+    const auto t_proc = std::chrono::steady_clock::now();      // (diagnostic timeline, VBH_DEBUG_TIMES=1: start / end of every program relative to the step's start)
+    auto timeline = [&](const char *what, std::chrono::steady_clock::time_point t0) {
+      if (!laps) return;
+      const auto t1 = std::chrono::steady_clock::now();
+      fprintf(stderr, "DecodeFmllr %-28s %8.1f ms   [%8.1f .. %8.1f] thread %zx\n", what, 1e3 * std::chrono::duration<double>(t1 - t0).count(),
+              1e3 * std::chrono::duration<double>(t0 - t_proc).count(), 1e3 * std::chrono::duration<double>(t1 - t_proc).count(),
+              std::hash<std::thread::id>()(std::this_thread::get_id()) & 0xFFFF);
+    };
     auto run = [&](const char *what, int (*fn)(int, char **, std::ofstream &), std::vector<std::string> a, std::ofstream &log, bool none_ok = false) {
       Argv av(std::move(a));
       const auto t0 = std::chrono::steady_clock::now();
       const int r = fn(av.argc(), av.argv(), log);
-      if (laps) {
-        static const auto t_proc = std::chrono::steady_clock::now();      // (diagnostic timeline: start / end relative to the first call of the process)
-        const auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "DecodeFmllr %-28s %8.1f ms   [%8.1f .. %8.1f] thread %zx\n", what, 1e3 * std::chrono::duration<double>(t1 - t0).count(),
-                1e3 * std::chrono::duration<double>(t0 - t_proc).count(), 1e3 * std::chrono::duration<double>(t1 - t_proc).count(),
-                std::hash<std::thread::id>()(std::this_thread::get_id()) & 0xFFFF);
-      }
+      timeline(what, t0);
       if (r < 0 || (r != 0 && !none_ok)) throw StepError(std::string(what) + " failed (return code " + std::to_string(r) + "), see " + Join(dir, "log"));
     };
     // One job's part of the recipe in three pieces: `search` = the two gmm-latgen-faster passes, `before` = what lies between them
@@ -777,6 +780,8 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
     };
     for (int j = 1; j <= nj; j++) unlink(Join(Join(dir, "log"), "fmllr." + std::to_string(j) + ".log").c_str());
     auto si_job = [&](int j) {
+      const auto t0 = std::chrono::steady_clock::now();
+      struct Tl { decltype(timeline) &f; std::chrono::steady_clock::time_point t0; ~Tl() { f("first pass (Decode job)", t0); } } tl{timeline, t0};
       try { DecodeJob(si_jobs, j); }
       catch (const std::exception &e) { throw StepError(std::string("First pass speaker-independent decoding failed: ") + e.what()); }
     };
@@ -875,6 +880,7 @@ int ScoreKaldiWER(const std::string &data, const std::string &lang_or_graph, con
     std::vector<std::string> wips;
     { std::string w; std::istringstream is(word_ins_penalty); while (std::getline(is, w, ',')) { w.erase(0, w.find_first_not_of(" \t")); w.erase(w.find_last_not_of(" \t") + 1); if (!w.empty()) wips.push_back(w); } }
     if (wips.empty()) throw StepError("no word insertion penalty given");
+    vbapi::Laps lap("ScoreKaldiWER");
     if (stage <= 0) {
       // all lat.* of the directory, in job order
       const int njobs = std::max(1, atoi(FirstLine(Join(dir, "num_jobs")).c_str()));
@@ -887,7 +893,9 @@ int ScoreKaldiWER(const std::string &data, const std::string &lang_or_graph, con
         while (reader.NextCompact(&key, &clat)) lats.emplace_back(key, std::move(clat));
       }
       if (lats.empty()) throw StepError("Could not find lat.* in " + dir);
+      lap("lattices read");
       const std::map<int, std::string> sym = ReadSymbolTable(symtab);
+      lap("symbol table read");
       struct Job { std::string wip; int lmwt; std::string err; };
       std::vector<Job> jobs;
       for (const auto &w : wips) { MakeDirs(Join(Join(sk, "penalty_" + w), "log")); for (int l = min_lmwt; l <= max_lmwt; l++) jobs.push_back(Job{w, l, ""}); }
@@ -928,6 +936,7 @@ int ScoreKaldiWER(const std::string &data, const std::string &lang_or_graph, con
       work();
       for (std::thread &t : pool) t.join();
       for (const Job &jb : jobs) if (!jb.err.empty()) throw StepError("scoring LMWT " + std::to_string(jb.lmwt) + " penalty " + jb.wip + ": " + jb.err);
+      lap("best paths + compute-wer of every combination");
     }
     if (stage <= 1) {
       // BestWer (VB/scr/utils/best_wer.cpp:25-71): smallest %SER, then smallest %WER, in the order wip-major / LMWT-minor
@@ -967,6 +976,7 @@ int ScoreKaldiWER(const std::string &data, const std::string &lang_or_graph, con
         }
         unlink(at.c_str());
       }
+      lap("best combination + details");
     }
   });
 }
