@@ -21,6 +21,9 @@
 #include <functional>
 #include <mutex>
 #include <vector>
+#include <cctype>
+#include <cstring>
+#include <memory>
 
 #include "api_common.h"
 #include "kaldi_io.h"
@@ -222,21 +225,64 @@ std::vector<std::vector<std::string>> SplitLines(const std::vector<std::string> 
 }
 
 // words.txt: "symbol id" per line
-std::map<int, std::string> ReadSymbolTable(const std::string &path) {
-  std::map<int, std::string> m;
-  for (const auto &l : ReadLines(path)) { std::istringstream is(l); std::string w; int id; if (is >> w >> id) m[id] = w; }
-  return m;
+// words.txt: "word id" lines.  A lexicon of a quarter of a million words takes 40 ms to read into a map, and a step reads it once per job and
+// once per scoring run: the table is parsed once per (file, size, mtime) and kept for the process (ids are dense: a vector).
+struct SymTab {
+  std::vector<std::string> w; std::vector<char> has;
+  const std::string *Find(long id) const { return id >= 0 && (size_t)id < w.size() && has[(size_t)id] ? &w[(size_t)id] : nullptr; }
+};
+std::shared_ptr<const SymTab> ReadSymbolTable(const std::string &path) {
+  static std::mutex mu;
+  static std::map<std::string, std::shared_ptr<const SymTab>> cache;
+  struct stat st;
+  if (stat(path.c_str(), &st) != 0) throw StepError("cannot open " + path);
+  const std::string key = path + "|" + std::to_string((long long)st.st_size) + "|" + std::to_string((long long)st.st_mtim.tv_sec) + "." + std::to_string((long long)st.st_mtim.tv_nsec);
+  std::lock_guard<std::mutex> lk(mu);       // (a second thread asking for the same table waits for the first one's parse)
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  std::string buf;
+  {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw StepError("cannot open " + path);
+    buf.resize((size_t)st.st_size);
+    f.read(&buf[0], (std::streamsize)buf.size());
+    buf.resize((size_t)f.gcount());
+  }
+  auto t = std::make_shared<SymTab>();
+  const char *p = buf.data(), *end = p + buf.size();
+  while (p < end) {
+    const char *eol = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+    if (!eol) eol = end;
+    const char *a = p;
+    while (a < eol && isspace((unsigned char)*a)) a++;
+    const char *b = a;
+    while (b < eol && !isspace((unsigned char)*b)) b++;
+    const char *c = b;
+    while (c < eol && isspace((unsigned char)*c)) c++;
+    if (b > a && c < eol && (isdigit((unsigned char)*c) || *c == '-' || *c == '+')) {      // (`is >> w >> id`: lines without both fields are skipped)
+      char *e = nullptr;
+      const long id = strtol(c, &e, 10);
+      if (e != c && id >= 0 && id < (1L << 28)) {
+        if ((size_t)id >= t->w.size()) { t->w.resize((size_t)id + 1); t->has.resize((size_t)id + 1, 0); }
+        t->w[(size_t)id].assign(a, b); t->has[(size_t)id] = 1;
+      }
+    }
+    p = eol + 1;
+  }
+  for (auto i = cache.begin(); i != cache.end();) i = (i->first.compare(0, path.size() + 1, path + "|") == 0) ? cache.erase(i) : std::next(i);      // (an older version of the file)
+  cache[key] = t;
+  return t;
 }
 // int2sym.pl -f 2-: every field after the key through the table (VB/scr/utils/int2sym.cpp)
-std::string Int2SymLine(const std::map<int, std::string> &sym, const std::string &line) {
+std::string Int2SymLine(const SymTab &sym, const std::string &line) {
   std::istringstream is(line);
   std::string key, tok, out;
   is >> key;
   out = key;
   while (is >> tok) {
-    const auto it = sym.find(atoi(tok.c_str()));
-    if (it == sym.end()) throw StepError("Word-id " + tok + " not in symbol table.");
-    out += " " + it->second;
+    const std::string *w = sym.Find(atoi(tok.c_str()));
+    if (!w) throw StepError("Word-id " + tok + " not in symbol table.");
+    out += " " + *w;
   }
   return out;
 }
@@ -538,7 +584,7 @@ void DecodeAllJobs(const DecodeJobs &c) {
   if (rc < 0) throw StepError("gmm-latgen-faster failed, see " + all_log);
   CombinedLogStubs(log_dir, "decode", c.nj, all_log);
   if (Exists(symtab)) {
-    const std::map<int, std::string> sym = ReadSymbolTable(symtab);
+    const std::shared_ptr<const SymTab> symp = ReadSymbolTable(symtab); const SymTab &sym = *symp;
     for (int j = 1; j <= c.nj; j++) {
       const std::string J = std::to_string(j);
       if (!Exists(Join(c.decode_dir, "w." + J))) continue;
@@ -571,7 +617,7 @@ void DecodeJob(const DecodeJobs &c, int j) {
   if (rc < 0) throw StepError("gmm-latgen-faster failed for job " + J + ", see " + Join(c.decode_dir, "log"));
   // transcriptionJOB.trn: the words of w.JOB through the symbol table (decode_gmm.cpp:356-376)
   if (Exists(symtab)) {
-    const std::map<int, std::string> sym = ReadSymbolTable(symtab);
+    const std::shared_ptr<const SymTab> symp = ReadSymbolTable(symtab); const SymTab &sym = *symp;
     std::vector<std::string> out;
     for (const auto &l : ReadLines(Join(c.decode_dir, "w." + J), false)) out.push_back(Int2SymLine(sym, l));
     WriteLines(Join(c.decode_dir, "transcription" + J + ".trn"), out);
@@ -845,7 +891,7 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
       Argv a({"lattice-best-path", "ark:" + Join(dir, "lat." + J), "ark,t:" + Join(dir, "w." + J)});
       if (LatticeBestPath(a.argc(), a.argv(), log) < 0) throw StepError("lattice-best-path failed for job " + J);
       if (Exists(symtab)) {
-        const std::map<int, std::string> sym = ReadSymbolTable(symtab);
+        const std::shared_ptr<const SymTab> symp = ReadSymbolTable(symtab); const SymTab &sym = *symp;
         std::vector<std::string> out;
         for (const auto &l : ReadLines(Join(dir, "w." + J), false)) out.push_back(Int2SymLine(sym, l));
         WriteLines(Join(dir, "transcription" + J + ".trn"), out);
@@ -894,48 +940,73 @@ int ScoreKaldiWER(const std::string &data, const std::string &lang_or_graph, con
       }
       if (lats.empty()) throw StepError("Could not find lat.* in " + dir);
       lap("lattices read");
-      const std::map<int, std::string> sym = ReadSymbolTable(symtab);
+      const std::shared_ptr<const SymTab> symp = ReadSymbolTable(symtab); const SymTab &sym = *symp;
       lap("symbol table read");
-      struct Job { std::string wip; int lmwt; std::string err; };
-      std::vector<Job> jobs;
-      for (const auto &w : wips) { MakeDirs(Join(Join(sk, "penalty_" + w), "log")); for (int l = min_lmwt; l <= max_lmwt; l++) jobs.push_back(Job{w, l, ""}); }
+      // 33 combinations x a thousand lattices: the work items are (combination, block of 128 utterances), so that sixteen threads stay busy
+      // to the end (whole combinations as items: 33 on 16 threads = three rounds, the last one of a single item); the thread that finishes
+      // a combination's last block writes its log and hypotheses and runs compute-wer
+      struct Job {
+        std::string wip; int lmwt = 0; std::string err; std::mutex mu;
+        std::vector<std::string> hyp, logl; std::vector<char> has; int blocks_left = 0;
+      };
+      const size_t NL = lats.size(), BLK = 128, nblk = (NL + BLK - 1) / BLK;
+      std::vector<std::unique_ptr<Job>> jobs;
+      for (const auto &w : wips) {
+        MakeDirs(Join(Join(sk, "penalty_" + w), "log"));
+        for (int l = min_lmwt; l <= max_lmwt; l++) {
+          jobs.emplace_back(new Job());
+          Job &jb = *jobs.back();
+          jb.wip = w; jb.lmwt = l; jb.hyp.resize(NL); jb.logl.resize(NL); jb.has.assign(NL, 0); jb.blocks_left = (int)nblk;
+        }
+      }
       std::atomic<size_t> next{0};
       auto work = [&]() {
-        for (size_t i = next++; i < jobs.size(); i = next++) {
-          Job &jb = jobs[i];
+        char num[96];
+        for (size_t i = next++; i < jobs.size() * nblk; i = next++) {
+          Job &jb = *jobs[i / nblk];
+          const size_t u0 = (i % nblk) * BLK, u1 = std::min(NL, u0 + BLK);
           try {
             const float inv_acoustic_scale = (float)jb.lmwt, acoustic_scale = (float)(1.0 / inv_acoustic_scale);     // lattice-scale.cc:70-80
             const float pen = (float)atof(jb.wip.c_str());
-            std::vector<std::string> hyp;
-            std::ofstream jlog(Join(Join(Join(sk, "penalty_" + jb.wip), "log"), "LMWT." + std::to_string(jb.lmwt) + ".log"), std::ios::binary);
-            for (const auto &kv : lats) {
+            for (size_t u = u0; u < u1; u++) {
+              const auto &kv = lats[u];
               vblat::CompactLattice c = kv.second;
               vblat::ScaleLattice(1.0, 0.0, 0.0, (double)acoustic_scale, &c);
               vblat::AddWordInsPen(pen, &c);
               vblat::CompactLattice best;
               vblat::CompactLatticeShortestPath(c, &best);
-              if (best.start < 0) { jlog << "WARNING (lattice-best-path) Best-path failed for key " << kv.first << "\n"; continue; }
+              if (best.start < 0) { jb.logl[u] = "WARNING (lattice-best-path) Best-path failed for key " + kv.first + "\n"; continue; }
               std::vector<int32_t> words; vblat::Weight w;
               if (!vblat::GetLinearSymbolSequence(best, nullptr, &words, &w)) throw StepError("best path of " + kv.first + " is not linear");
-              jlog << "LOG (lattice-best-path) For utterance " << kv.first << ", best cost " << w.v1 << " + " << w.v2 << " = " << (w.v1 + w.v2) << "\n";
+              { std::ostringstream o; o << "LOG (lattice-best-path) For utterance " << kv.first << ", best cost " << w.v1 << " + " << w.v2 << " = " << (w.v1 + w.v2) << "\n"; jb.logl[u] = o.str(); }
               std::string line = kv.first;
-              for (int32_t x : words) line += " " + std::to_string(x);
-              hyp.push_back(FilterLine(Int2SymLine(sym, line), wer_hyp_filter));
+              for (int32_t x : words) { snprintf(num, sizeof(num), " %d", x); line += num; }
+              jb.hyp[u] = FilterLine(Int2SymLine(sym, line), wer_hyp_filter);
+              jb.has[u] = 1;
             }
+          } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(jb.mu); jb.err = e.what(); }
+          bool last;
+          { std::lock_guard<std::mutex> lk(jb.mu); last = --jb.blocks_left == 0; }
+          if (!last || !jb.err.empty()) continue;
+          try {
+            std::ofstream jlog(Join(Join(Join(sk, "penalty_" + jb.wip), "log"), "LMWT." + std::to_string(jb.lmwt) + ".log"), std::ios::binary);
+            std::vector<std::string> hyp;
+            for (size_t u = 0; u < NL; u++) { jlog << jb.logl[u]; if (jb.has[u]) hyp.push_back(std::move(jb.hyp[u])); }
             const std::string hyp_file = Join(Join(sk, "penalty_" + jb.wip), std::to_string(jb.lmwt) + ".txt");
             WriteLines(hyp_file, hyp);
             Argv a({"compute-wer", "--mode=present", "ark:" + Join(sk, "test_filt.txt"), "ark,p:" + hyp_file,
                     Join(dir, "wer_" + std::to_string(jb.lmwt) + "_" + jb.wip)});
             if (ComputeWer(a.argc(), a.argv(), jlog) < 0) throw StepError("compute-wer failed, see " + Join(Join(sk, "penalty_" + jb.wip), "log"));
-          } catch (const std::exception &e) { jb.err = e.what(); }
+            std::vector<std::string>().swap(jb.hyp); std::vector<std::string>().swap(jb.logl);
+          } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(jb.mu); jb.err = e.what(); }
         }
       };
-      const unsigned nt = std::max(1u, std::min((unsigned)jobs.size(), std::min((unsigned)std::max(nj, 1) * 4u, std::max(1u, std::thread::hardware_concurrency()))));
+      const unsigned nt = std::max(1u, std::min((unsigned)(jobs.size() * nblk), std::min((unsigned)std::max(nj, 1) * 4u, std::max(1u, std::thread::hardware_concurrency()))));
       std::vector<std::thread> pool;
       for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
       work();
       for (std::thread &t : pool) t.join();
-      for (const Job &jb : jobs) if (!jb.err.empty()) throw StepError("scoring LMWT " + std::to_string(jb.lmwt) + " penalty " + jb.wip + ": " + jb.err);
+      for (const auto &jb : jobs) if (!jb->err.empty()) throw StepError("scoring LMWT " + std::to_string(jb->lmwt) + " penalty " + jb->wip + ": " + jb->err);
       lap("best paths + compute-wer of every combination");
     }
     if (stage <= 1) {
@@ -961,6 +1032,16 @@ int ScoreKaldiWER(const std::string &data, const std::string &lang_or_graph, con
         // quotes there, no shell strips them, so the files carry '***')
         const std::string details = Join(sk, "wer_details"), pen = Join(sk, "penalty_" + best_wip), at = Join(pen, std::to_string(best_lmwt) + ".at");
         const std::string eps = "'***'";
+        // (the bootstrap interval needs the hypotheses only: it runs beside the alignment and the three tables made from it)
+        std::string boot_err;
+        std::thread boot([&]() {
+          try {
+            std::ofstream blog(Join(Join(sk, "log"), "wer_bootci.log"), std::ios::binary);
+            Argv a({"compute-wer-bootci", "--mode=present", "ark:" + Join(sk, "test_filt.txt"), "ark:" + Join(pen, std::to_string(best_lmwt) + ".txt"), Join(details, "wer_bootci")});
+            if (ComputeWerBootci(a.argc(), a.argv(), blog) < 0) boot_err = "compute-wer-bootci failed, see " + Join(Join(sk, "log"), "wer_bootci.log");
+          } catch (const std::exception &e) { boot_err = e.what(); if (boot_err.empty()) boot_err = "compute-wer-bootci failed"; }
+        });
+        struct JoinBoot { std::thread &t; ~JoinBoot() { if (t.joinable()) t.join(); } } join_boot{boot};
         {
           Argv a({"align-text", "--special-symbol=" + eps, "ark:" + Join(sk, "test_filt.txt"), "ark:" + Join(pen, std::to_string(best_lmwt) + ".txt"), "ark,t:" + at});
           std::ofstream alog(Join(Join(sk, "log"), "align_text.log"), std::ios::binary);
@@ -969,11 +1050,8 @@ int ScoreKaldiWER(const std::string &data, const std::string &lang_or_graph, con
         if (WerPerUttDetails(at, Join(details, "per_utt"), eps) < 0) throw StepError("wer_per_utt_details failed");
         if (WerPerSpkDetails(Join(details, "per_utt"), Join(data, "utt2spk"), Join(details, "per_spk")) < 0) throw StepError("wer_per_spk_details failed");
         if (WerOpsDetails(Join(details, "per_utt"), Join(details, "ops"), eps) < 0) throw StepError("wer_ops_details failed");
-        {
-          std::ofstream blog(Join(Join(sk, "log"), "wer_bootci.log"), std::ios::binary);
-          Argv a({"compute-wer-bootci", "--mode=present", "ark:" + Join(sk, "test_filt.txt"), "ark:" + Join(pen, std::to_string(best_lmwt) + ".txt"), Join(details, "wer_bootci")});
-          if (ComputeWerBootci(a.argc(), a.argv(), blog) < 0) throw StepError("compute-wer-bootci failed, see " + Join(Join(sk, "log"), "wer_bootci.log"));
-        }
+        boot.join();
+        if (!boot_err.empty()) throw StepError(boot_err);
         unlink(at.c_str());
       }
       lap("best combination + details");
