@@ -328,7 +328,8 @@ int vbh_decoder_times(vbh_decoder *d, float *out4);
  * alignment model and the adaptation model for the gmm-post-to-gpost | gmm-est-fmllr-gpost pair of
  * DecodeFmllr's first pass); the two models must have the same Gaussians per pdf.  h_utt2spk[u] in
  * [0, n_spk) or -1 (utterance skipped).  Outputs on the host, double: h_beta [n_spk],
- * h_K [n_spk][dim][dim+1], h_G [n_spk][dim][dim+1][dim+1] (full symmetric).  kernel_ms (optional):
+ * h_K [n_spk][dim][dim+1], h_G [n_spk][dim][dim+1][dim+1] (full symmetric); h_K and h_G may both be NULL (the statistics stay on the
+ * device for vbh_fmllr_update_full).  kernel_ms (optional):
  * HIP-event duration of the accumulation kernel on the context's stream.  Synchronises. */
 int vbh_fmllr_accumulate(vbh_ctx *ctx, const vbh_gmm *ali_gmm, const vbh_gmm *adapt_gmm, const float *d_feats, int32_t n_utt,
                          const int64_t *h_frame_offsets, const int32_t *h_utt2spk, int32_t n_spk, const int64_t *h_pair_offsets,
@@ -340,6 +341,14 @@ int vbh_fmllr_accumulate_gpost(vbh_ctx *ctx, const vbh_gmm *adapt_gmm, const flo
                                const int32_t *h_utt2spk, int32_t n_spk, const int64_t *h_pair_offsets, const int32_t *h_pair_pdf,
                                const int64_t *h_gpost_offsets, const float *h_gpost, const int32_t *h_pdf_num_gauss, double *h_beta, double *h_K,
                                double *h_G, float *kernel_ms);
+/* The row-by-row update on the device (ComputeFmllrMatrixDiagGmmFull / FmllrInnerUpdate / FmllrAuxFuncDiagGmm,
+ * K/transform/fmllr-diag-gmm.cc:195-273, 496-508; update type "full") from the statistics the context's LAST vbh_fmllr_accumulate* call
+ * left on the device -- pass h_K = h_G = NULL there and the 128 MB of a 256-speaker batch never cross the bus.  One wave per speaker,
+ * double throughout.  h_xform [n_spk][dim][dim+1] float: in = the initial transform (the unit transform for gmm-est-fmllr), out = the
+ * estimate (unchanged where beta <= min_count or the objective did not increase); h_impr [n_spk] = the objective's improvement (0 there).
+ * A singular statistic fails the call ("fMLLR: singular matrix").  Synchronises. */
+int vbh_fmllr_update_full(vbh_ctx *ctx, int32_t dim, int32_t n_spk, float min_count, int32_t num_iters, float *h_xform, float *h_impr,
+                          float *kernel_ms);
 /* algorithmic work of the accumulation kernel for T frames: bytes read, f64 flops issued */
 int vbh_fmllr_work(int32_t dim, int64_t T, double *bytes, double *flops);
 

@@ -87,6 +87,56 @@ def test_fmllr_stats_vs_numpy(ctx, D, n_utt, n_spk, two_models):
         ali.close()
 
 
+@pytest.mark.parametrize("D,n_spk", [(39, 5), (40, 3), (13, 2)])
+def test_fmllr_update_on_the_device_vs_host(ctx, D, n_spk):
+    """vbh_fmllr_update_full (one wave per speaker, from the statistics where vbh_fmllr_accumulate left them) against the host's
+    FmllrAccs::Update on the same statistics (host/fmllr.cc, itself pinned to the reference's gmm-est-fmllr by the golden tests below):
+    the same algorithm in double, so the transforms agree far inside the 5e-6 the reference comparison allows; a speaker below min-count
+    keeps its initial transform; a non-unit initial transform is taken up"""
+    import ctypes as C
+    import torch
+    from voicebridge_amd import api, synth
+    from voicebridge_amd import build
+    rng = np.random.default_rng(100 + D)
+    P = 40
+    offs, w, means, iv = synth.gmm_model(P, 200, D, seed=D + 1)
+    miv = (means * iv).astype(np.float32)
+    gmm = api.DiagGmm(ctx, offs, w, miv, iv)
+    lens = rng.integers(400, 900, 2 * n_spk)
+    lens[-1] = 30                                    # the last speaker's second utterance: tiny
+    foff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    T = int(foff[-1])
+    feats = (rng.standard_normal((T, D)) * 1.1 + 0.3).astype(np.float32)
+    utt2spk = (np.arange(2 * n_spk) % n_spk).astype(np.int32)
+    utt2spk[n_spk - 1] = -1                          # ... and its first one skipped: that speaker stays below min-count
+    poff = np.arange(T + 1, dtype=np.int64)
+    ppdf = rng.integers(0, P, T).astype(np.int32)
+    pw = np.ones(T, np.float32)
+    beta, K, G, _ = gmm.fmllr_stats(torch.from_numpy(feats).to(ctx.device), foff, utt2spk, n_spk, poff, ppdf, pw)
+    assert beta[n_spk - 1] < 100 < beta[0]
+    host = C.CDLL(build.HOST_LIB)
+    host.vb_fmllr_update.restype = C.c_int
+    host.vb_fmllr_update.argtypes = [C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_char_p, C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+    for init in ("unit", "other"):
+        x0 = np.tile(np.hstack([np.eye(D, dtype=np.float32), np.zeros((D, 1), np.float32)]), (n_spk, 1, 1))
+        if init == "other":
+            x0 = (x0 + 0.02 * rng.standard_normal(x0.shape)).astype(np.float32)
+        xd, impr_d, ms = gmm.fmllr_update_full(n_spk, xform=x0, min_count=100.0, num_iters=40)
+        for s in range(n_spk):
+            xh = x0[s].copy()
+            impr_h = C.c_float()
+            assert host.vb_fmllr_update(D, float(beta[s]), np.ascontiguousarray(K[s]).ctypes.data, np.ascontiguousarray(G[s]).ctypes.data, b"full", 100.0, 40,
+                                        xh.ctypes.data, C.byref(impr_h)) == 0
+            np.testing.assert_allclose(xd[s], xh, rtol=0, atol=2e-6 * max(1.0, np.abs(xh).max()))
+            assert abs(impr_d[s] - impr_h.value) <= 1e-4 * max(1.0, abs(impr_h.value))
+            if s == n_spk - 1:
+                assert np.array_equal(xd[s], x0[s]) and impr_d[s] == 0.0      # below min-count: untouched
+            else:
+                assert impr_d[s] > 0.0 and not np.array_equal(xd[s], x0[s])
+        print("D = %d, %d speakers, initial transform %s: device update %.2f ms" % (D, n_spk, init, ms))
+    gmm.close()
+
+
 def test_gmm_est_fmllr_bin_function_vs_golden(tmp_path):
     """GmmEstFmllr and the gmm-post-to-gpost | gmm-est-fmllr-gpost pair, both fed by the kernel: the transforms of the
     reference's programs on the golden case"""

@@ -23,7 +23,7 @@ SYMBOLS = [
     "vbh_decoder_times", "vbh_decoder_utt_timeline", "vbh_decoder_batch_stats",
     "vbh_faster_cfg_default", "vbh_faster_decoder_create", "vbh_faster_decoder_create_ex", "vbh_faster_decoder_destroy", "vbh_faster_decode_batch", "vbh_faster_decode_batch_ex",
     "vbh_faster_decoder_result",
-    "vbh_fmllr_accumulate", "vbh_fmllr_accumulate_gpost", "vbh_fmllr_work",
+    "vbh_fmllr_accumulate", "vbh_fmllr_accumulate_gpost", "vbh_fmllr_work", "vbh_fmllr_update_full",
 ]
 
 

@@ -277,6 +277,20 @@ class DiagGmm:
               "vbh_fmllr_accumulate")
         return beta, K, G, ms.value
 
+    def fmllr_update_full(self, n_spk, xform=None, min_count=500.0, num_iters=40):
+        """the row-by-row fMLLR update on the device (vbh_fmllr_update_full) from the statistics the context's last fmllr_stats call left
+        there: returns (transforms [S, D, D+1] float32, objective improvements [S] float32, kernel ms); xform: the initial transforms
+        (default: unit)"""
+        D = self.dim
+        x = np.tile(np.hstack([np.eye(D, dtype=np.float32), np.zeros((D, 1), np.float32)]), (n_spk, 1, 1)) if xform is None else np.array(xform, np.float32)
+        x = np.ascontiguousarray(x.reshape(n_spk, D, D + 1))
+        impr = np.zeros(n_spk, np.float32)
+        ms = C.c_float()
+        fn = self.lib.vbh_fmllr_update_full
+        fn.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+        check(fn(self.ctx.h, D, int(n_spk), float(min_count), int(num_iters), x.ctypes.data, impr.ctypes.data, C.byref(ms)), "vbh_fmllr_update_full")
+        return x, impr, ms.value
+
     def close(self):
         if self.h:
             self.lib.vbh_gmm_destroy(self.h)

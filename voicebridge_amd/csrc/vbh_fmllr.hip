@@ -7,7 +7,16 @@
 //   transform/fmllr-diag-gmm.cc:562-596   CommitSingleFrameStats: beta += count, K += a x+^T, G_d += b[d] x+ x+^T (double)
 //   gmmbin/gmm-est-fmllr.cc:36-52         AccumulateForUtterance (posteriors on transition-ids summed per pdf)
 //
-// Two kernels.
+//   transform/fmllr-diag-gmm.cc:195-273   ComputeFmllrMatrixDiagGmmFull / FmllrInnerUpdate: the row-by-row update (fmllr_update_kernel below)
+//   transform/fmllr-diag-gmm.cc:496-508   FmllrAuxFuncDiagGmm
+//
+// Three kernels.
+//   fmllr_update_kernel: one wave per speaker, everything in double.  The 39 inverses of the 40 x 40 G_d (Gauss-Jordan with partial
+//     pivoting in LDS, lane = column), then 40 iterations of: inverse(A) from scratch, and per row d the two 40 x 40 matrix-vector
+//     products with inverse(G_d), the quadratic in alpha, and the rank-one (Sherman-Morrison) change of inverse(A) -- host/fmllr.cc's
+//     Update(), operation for operation.  Sequential by nature (a row needs the rows before it): ~6 M cycles = 2.5 ms whatever
+//     the number of speakers up to one per CU, against 4-5 ms of a host core PER SPEAKER; and the 128 MB of statistics of a
+//     256-speaker batch never leave the device.
 //   fmllr_frame_stats_kernel: one wave per frame, lane = feature dimension; the frame's (pdf, weight) pairs are
 //     walked, per-Gaussian log-likelihoods are wave reductions, a/b/count leave as [T x D] / [T] float arrays.
 //     Bytes per frame: 4D in + 8D + 4 out + the touched Gaussians (2 x 4D each, L2-resident model); HBM-bound, tiny.
@@ -230,6 +239,193 @@ __global__ __launch_bounds__(NWAVE * 64) void fmllr_accumulate_kernel(
   }
 }
 
+
+// ---- the row-by-row update (host/fmllr.cc FmllrAccs::Update, "full"), one wave per speaker
+constexpr int ULD = 49;          // padded row of the work matrices in LDS (n <= 48)
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// in-place inverse of the n x n matrix m (LDS, row stride ULD) by Gauss-Jordan elimination with partial pivoting, lane = column;
+// returns log|det| (every lane), sets *singular.  The pivot of a column is the FIRST row of the largest magnitude, as the host's loop finds it.
+__device__ double invert_lds(double *m, int n, int lane, int *perm, bool *singular) {
+  double logdet = 0.0;
+  for (int c = 0; c < n; c++) {
+    // pivot: rows c..n-1 of column c, one per lane
+    const double mag = (lane >= c && lane < n) ? fabs(m[lane * ULD + c]) : -1.0;
+    double best = mag;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) best = fmax(best, __shfl_xor(best, o));
+    const unsigned long long at = __ballot(mag == best && lane >= c && lane < n);
+    const int piv = at ? __ffsll((long long)at) - 1 : c;
+    if (!(best > 0.0)) { *singular = true; return 0.0; }
+    if (lane == 0) perm[c] = piv;
+    if (piv != c && lane < n) { const double a = m[c * ULD + lane], b = m[piv * ULD + lane]; m[c * ULD + lane] = b; m[piv * ULD + lane] = a; }
+    __syncthreads();
+    const double d = m[c * ULD + c];
+    logdet += log(fabs(d));
+    const double inv = 1.0 / d;
+    __syncthreads();
+    if (lane < n) m[c * ULD + lane] = (lane == c ? 1.0 : m[c * ULD + lane]) * inv;
+    __syncthreads();
+    const double pc = lane < n ? m[c * ULD + lane] : 0.0;
+#pragma unroll 4
+    for (int r = 0; r < n; r++) {
+      if (r == c) continue;
+      const double f = m[r * ULD + c];           // (every lane reads it before lane c overwrites it: one wave, its LDS operations in program order)
+      if (lane < n) m[r * ULD + lane] = (lane == c ? 0.0 : m[r * ULD + lane]) - f * pc;
+    }
+    __syncthreads();
+  }
+  for (int c = n - 1; c >= 0; c--) {
+    const int p = perm[c];
+    if (p != c) {
+      for (int r = 0; r < n; r++) {
+        double v = 0.0;
+        if (lane == c) v = m[r * ULD + p]; else if (lane == p) v = m[r * ULD + c];
+        __syncthreads();
+        if (lane == c || lane == p) m[r * ULD + lane] = v;
+      }
+      __syncthreads();
+    }
+  }
+  return logdet;
+}
+
+// G of (speaker, d): the accumulation kernel fills the lower triangle
+__device__ __forceinline__ double g_at(const double *__restrict__ g, int n1, int i, int j) { return i >= j ? g[i * n1 + j] : g[j * n1 + i]; }
+
+// FmllrAuxFuncDiagGmm (fmllr-diag-gmm.cc:496-508) of W (LDS, row stride ULD): beta log|det A| + sum W.K - 1/2 sum_d w_d^T G_d w_d
+__device__ double aux_func(const double *W, double *work, int *perm, int D, double beta, const double *__restrict__ K, const double *__restrict__ G, int lane, bool *singular) {
+  const int n1 = D + 1;
+  for (int r = 0; r < D; r++) if (lane < D) work[r * ULD + lane] = W[r * ULD + lane];
+  __syncthreads();
+  double obj = beta * invert_lds(work, D, lane, perm, singular);
+  if (*singular) return 0.0;
+  double wk = 0.0;
+  for (int r = 0; r < D; r++) if (lane < n1) wk += W[r * ULD + lane] * K[r * n1 + lane];
+  obj += wave_sum_d(wk);
+  for (int d = 0; d < D; d++) {
+    const double *g = G + (size_t)d * n1 * n1;
+    double s = 0.0;
+    if (lane < n1) { for (int j = 0; j < n1; j++) s += g_at(g, n1, lane, j) * W[d * ULD + j]; s *= W[d * ULD + lane]; }
+    obj -= 0.5 * wave_sum_d(s);
+  }
+  return obj;
+}
+
+__global__ __launch_bounds__(64) void fmllr_update_kernel(int D, int num_iters, float min_count, const double *__restrict__ beta_all, const double *__restrict__ K_all,
+                                                         const double *__restrict__ G_all, double *__restrict__ invG_all, float *__restrict__ xform_all,
+                                                         float *__restrict__ impr_all, int *__restrict__ status_all) {
+  __shared__ double Wm[48 * ULD], Mm[48 * ULD], work[48 * ULD];      // (work doubles as the row's inverse(G_d) during the iterations)
+  __shared__ double row[64], rinv[64], delta[64], uvec[64], vvec[64];
+  __shared__ int perm[64];
+  const int s = blockIdx.x, lane = threadIdx.x, n1 = D + 1;
+  const double beta = beta_all[s];
+  float *xform = xform_all + (size_t)s * D * n1;
+  if (lane == 0) { impr_all[s] = 0.0f; status_all[s] = 0; }
+  if (!(beta > (double)min_count)) return;          // "Not updating fMLLR since below min-count"
+  const double *K = K_all + (size_t)s * D * n1, *G = G_all + (size_t)s * D * n1 * n1;
+  double *invG = invG_all + (size_t)s * D * n1 * n1;
+  bool singular = false;
+  // ---- inverse(G_d), stored TRANSPOSED (T[j][i] = inverse[i][j]) so that a lane's row of it is read across lanes in one line
+  for (int d = 0; d < D; d++) {
+    const double *g = G + (size_t)d * n1 * n1;
+    for (int r = 0; r < n1; r++) if (lane < n1) work[r * ULD + lane] = g_at(g, n1, r, lane);
+    __syncthreads();
+    (void)invert_lds(work, n1, lane, perm, &singular);
+    if (singular) { if (lane == 0) status_all[s] = 1; return; }
+    double *t = invG + (size_t)d * n1 * n1;
+    for (int j = 0; j < n1; j++) if (lane < n1) t[j * n1 + lane] = work[lane * ULD + j];
+    __syncthreads();
+  }
+  __threadfence_block();
+  for (int r = 0; r < D; r++) if (lane < n1) Wm[r * ULD + lane] = (double)xform[r * n1 + lane];
+  __syncthreads();
+  const float old_objf = (float)aux_func(Wm, work, perm, D, beta, K, G, lane, &singular);
+  if (singular) { if (lane == 0) status_all[s] = 1; return; }
+  // inverse(G_d) of the row being updated lives in LDS (`work`); the next row's is fetched into registers while this row is worked on
+  // (read straight from memory in the matrix-vector loops, each row was eighty dependent global round trips of a lone wave: 30 ms per
+  // call; staged at the top of the row: 20 ms; fetched one row ahead: see tests/test_gpu_fmllr.py's print)
+  constexpr int NPF = (48 * 48 + 63) / 64;
+  const int nn = n1 * n1;
+  double nxt[NPF];
+  auto fetch = [&](int d_) {
+    const double *t_ = invG + (size_t)d_ * nn;
+#pragma unroll
+    for (int u = 0; u < NPF; u++) { const int e = u * 64 + lane; nxt[u] = e < nn ? t_[e] : 0.0; }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int u = 0; u < NPF; u++) { const int e = u * 64 + lane; if (e < nn) work[(e / n1) * ULD + (e % n1)] = nxt[u]; }
+  };
+  if (num_iters > 0) { fetch(0); __syncthreads(); stage(); __syncthreads(); }
+  for (int iter = 0; iter < num_iters; iter++) {
+    for (int r = 0; r < D; r++) if (lane < D) Mm[r * ULD + lane] = Wm[r * ULD + lane];
+    __syncthreads();
+    (void)invert_lds(Mm, D, lane, perm, &singular);
+    if (singular) { if (lane == 0) status_all[s] = 1; return; }
+    for (int d = 0; d < D; d++) {
+      const double *k = K + (size_t)d * n1;          // (work[j * ULD + i] = inverse(G_d)[i][j])
+      fetch(d + 1 < D ? d + 1 : 0);
+      const double rw = lane < D ? Mm[lane * ULD + d] : 0.0;          // row[c] = inverse(A)[c][d]; row[D] = 0
+      row[lane] = rw;
+      __syncthreads();
+      double ri = 0.0;
+      if (lane < n1) {
+#pragma unroll 8
+        for (int j = 0; j < n1; j++) ri += work[j * ULD + lane] * row[j];
+      }
+      const double kl = lane < n1 ? k[lane] : 0.0;
+      const double e1 = wave_sum_d(lane < n1 ? ri * rw : 0.0), e2 = wave_sum_d(lane < n1 ? ri * kl : 0.0);
+      const double discr = sqrt(e2 * e2 + 4 * e1 * beta);
+      const double alpha1 = (-e2 + discr) / (2 * e1), alpha2 = (-e2 - discr) / (2 * e1);
+      const double auxf1 = beta * log(fabs(alpha1 * e1 + e2)) - 0.5 * alpha1 * alpha1 * e1;
+      const double auxf2 = beta * log(fabs(alpha2 * e1 + e2)) - 0.5 * alpha2 * alpha2 * e1;
+      const double alpha = auxf1 > auxf2 ? alpha1 : alpha2;
+      __syncthreads();
+      row[lane] = rw * alpha + kl;
+      __syncthreads();
+      double nw = 0.0;
+      if (lane < n1) {
+#pragma unroll 8
+        for (int j = 0; j < n1; j++) nw += work[j * ULD + lane] * row[j];
+      }
+      const double dl = lane < D ? nw - Wm[d * ULD + lane] : 0.0;
+      if (lane < n1) Wm[d * ULD + lane] = nw;
+      delta[lane] = dl;
+      // A' = A + e_d delta^T  ->  inverse(A') = M - (M e_d)(delta^T M) / (1 + delta^T M e_d)
+      const double ul = lane < D ? Mm[lane * ULD + d] : 0.0;
+      uvec[lane] = ul;
+      const double denom = 1.0 + wave_sum_d(dl * ul);
+      if (denom == 0.0 || !isfinite(denom)) { if (lane == 0) status_all[s] = 1; return; }
+      __syncthreads();
+      double sv = 0.0;
+      if (lane < D) {
+#pragma unroll 8
+        for (int r = 0; r < D; r++) sv += delta[r] * Mm[r * ULD + lane];
+      }
+      sv /= denom;
+      if (lane < D) {
+#pragma unroll 8
+        for (int r = 0; r < D; r++) Mm[r * ULD + lane] -= uvec[r] * sv;
+      }
+      __syncthreads();
+      stage();
+      __syncthreads();
+    }
+  }
+  const float new_objf = (float)aux_func(Wm, work, perm, D, beta, K, G, lane, &singular);
+  if (singular) { if (lane == 0) status_all[s] = 1; return; }
+  const float impr = new_objf - old_objf;
+  // "No applying fMLLR transform change because objective function did not increase."
+  if (impr < 0.0f && !(fabsf(new_objf - old_objf) <= 0.001f * (fabsf(new_objf) + fabsf(old_objf)))) return;
+  for (int r = 0; r < D; r++) if (lane < n1) xform[r * n1 + lane] = (float)Wm[r * ULD + lane];
+  if (lane == 0) impr_all[s] = impr;
+}
+
 }  // namespace
 
 extern "C" {
@@ -318,13 +514,14 @@ static int fmllr_run(vbh_ctx *ctx, const vbh_gmm_view &vm, const float *d_feats,
                      d_tiles.p, d_beta.p, d_K.p, d_G.p);
   VBH_HIP(hipGetLastError());
   if (kernel_ms) VBH_HIP(hipEventRecord(e1, st));
+  ctx->fmllr_dim = D; ctx->fmllr_nspk = n_spk;       // (the statistics stay in the scratch slots: vbh_fmllr_update_full)
   VBH_HIP(hipMemcpyAsync(h_beta, d_beta.p, sizeof(double) * n_spk, hipMemcpyDeviceToHost, st));
-  VBH_HIP(hipMemcpyAsync(h_K, d_K.p, sizeof(double) * (size_t)n_spk * D * n1, hipMemcpyDeviceToHost, st));
-  VBH_HIP(hipMemcpyAsync(h_G, d_G.p, sizeof(double) * (size_t)n_spk * D * n1 * n1, hipMemcpyDeviceToHost, st));
+  if (h_K) VBH_HIP(hipMemcpyAsync(h_K, d_K.p, sizeof(double) * (size_t)n_spk * D * n1, hipMemcpyDeviceToHost, st));
+  if (h_G) VBH_HIP(hipMemcpyAsync(h_G, d_G.p, sizeof(double) * (size_t)n_spk * D * n1 * n1, hipMemcpyDeviceToHost, st));
   VBH_HIP(hipStreamSynchronize(st));
   if (kernel_ms) { VBH_HIP(hipEventElapsedTime(kernel_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
   // the kernel fills the lower triangles (j <= i); mirror them
-  for (size_t m = 0; m < (size_t)n_spk * D; m++) {
+  if (h_G) for (size_t m = 0; m < (size_t)n_spk * D; m++) {
     double *g = h_G + m * n1 * n1;
     for (int i = 0; i < n1; i++) for (int j = i + 1; j < n1; j++) g[(size_t)i * n1 + j] = g[(size_t)j * n1 + i];
   }
@@ -337,7 +534,7 @@ int vbh_fmllr_accumulate(vbh_ctx *ctx, const vbh_gmm *ali_gmm, const vbh_gmm *ad
                          const int64_t *h_frame_offsets, const int32_t *h_utt2spk, int32_t n_spk, const int64_t *h_pair_offsets,
                          const int32_t *h_pair_pdf, const float *h_pair_weight, double *h_beta, double *h_K, double *h_G,
                          float *kernel_ms) {
-  VBH_CHECK(ctx && ali_gmm && adapt_gmm && d_feats && h_frame_offsets && h_utt2spk && h_pair_offsets && h_beta && h_K && h_G,
+  VBH_CHECK(ctx && ali_gmm && adapt_gmm && d_feats && h_frame_offsets && h_utt2spk && h_pair_offsets && h_beta && (h_K != nullptr) == (h_G != nullptr),
             "vbh_fmllr_accumulate: NULL argument");
   if (vbh_use_device(ctx)) return -1;
   vbh_gmm_view va, vm;
@@ -359,7 +556,7 @@ int vbh_fmllr_accumulate_gpost(vbh_ctx *ctx, const vbh_gmm *adapt_gmm, const flo
                                const int32_t *h_utt2spk, int32_t n_spk, const int64_t *h_pair_offsets, const int32_t *h_pair_pdf,
                                const int64_t *h_gpost_offsets, const float *h_gpost, const int32_t *h_pdf_num_gauss, double *h_beta, double *h_K,
                                double *h_G, float *kernel_ms) {
-  VBH_CHECK(ctx && adapt_gmm && d_feats && h_frame_offsets && h_utt2spk && h_pair_offsets && h_gpost_offsets && h_beta && h_K && h_G,
+  VBH_CHECK(ctx && adapt_gmm && d_feats && h_frame_offsets && h_utt2spk && h_pair_offsets && h_gpost_offsets && h_beta && (h_K != nullptr) == (h_G != nullptr),
             "vbh_fmllr_accumulate_gpost: NULL argument");
   if (vbh_use_device(ctx)) return -1;
   vbh_gmm_view vm;
@@ -382,6 +579,39 @@ int vbh_fmllr_accumulate_gpost(vbh_ctx *ctx, const vbh_gmm *adapt_gmm, const flo
                                         vm.iv, d_a, d_b, d_cnt);
                      return 0;
                    });
+}
+
+int vbh_fmllr_update_full(vbh_ctx *ctx, int32_t dim, int32_t n_spk, float min_count, int32_t num_iters, float *h_xform, float *h_impr,
+                          float *kernel_ms) {
+  VBH_CHECK(ctx && h_xform && h_impr, "vbh_fmllr_update_full: NULL argument");
+  VBH_CHECK(ctx->fmllr_dim == dim && ctx->fmllr_nspk == n_spk && dim >= 1 && n_spk >= 1,
+            "vbh_fmllr_update_full: the context holds no statistics of %d speakers in %d dimensions (the last vbh_fmllr_accumulate* call left %d / %d)", n_spk, dim,
+            ctx->fmllr_nspk, ctx->fmllr_dim);
+  VBH_CHECK(num_iters >= 0, "vbh_fmllr_update_full: num_iters < 0");
+  if (vbh_use_device(ctx)) return -1;
+  const int D = dim, n1 = D + 1;
+  hipStream_t st = ctx->stream;
+  ScratchBuf<double> d_beta(ctx, VBH_SCR_FMLLR + 8), d_K(ctx, VBH_SCR_FMLLR + 9), d_G(ctx, VBH_SCR_FMLLR + 10), d_invG(ctx, VBH_SCR_FMLLR + 14);
+  ScratchBuf<float> d_out(ctx, VBH_SCR_FMLLR + 15);
+  const size_t nx = (size_t)n_spk * D * n1;
+  // (the three statistics slots are re-opened at the sizes they were filled with: nothing moves)
+  if (d_beta.alloc(n_spk) || d_K.alloc(nx) || d_G.alloc(nx * n1) || d_invG.alloc(nx * n1) || d_out.alloc(nx + 2 * (size_t)n_spk)) return -1;
+  float *d_x = d_out.p, *d_impr = d_out.p + nx;
+  int *d_status = reinterpret_cast<int *>(d_out.p + nx + n_spk);
+  VBH_HIP(hipMemcpyAsync(d_x, h_xform, sizeof(float) * nx, hipMemcpyHostToDevice, st));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (kernel_ms) { VBH_HIP(hipEventCreate(&e0)); VBH_HIP(hipEventCreate(&e1)); VBH_HIP(hipEventRecord(e0, st)); }
+  hipLaunchKernelGGL(fmllr_update_kernel, dim3((unsigned)n_spk), dim3(64), 0, st, D, (int)num_iters, min_count, d_beta.p, d_K.p, d_G.p, d_invG.p, d_x, d_impr, d_status);
+  VBH_HIP(hipGetLastError());
+  if (kernel_ms) VBH_HIP(hipEventRecord(e1, st));
+  std::vector<int> status(n_spk);
+  VBH_HIP(hipMemcpyAsync(h_xform, d_x, sizeof(float) * nx, hipMemcpyDeviceToHost, st));
+  VBH_HIP(hipMemcpyAsync(h_impr, d_impr, sizeof(float) * n_spk, hipMemcpyDeviceToHost, st));
+  VBH_HIP(hipMemcpyAsync(status.data(), d_status, sizeof(int) * n_spk, hipMemcpyDeviceToHost, st));
+  VBH_HIP(hipStreamSynchronize(st));
+  if (kernel_ms) { VBH_HIP(hipEventElapsedTime(kernel_ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+  for (int s_ = 0; s_ < n_spk; s_++) VBH_CHECK(status[s_] == 0, "fMLLR: singular matrix (speaker %d)", s_);
+  return 0;
 }
 
 }  // extern "C"

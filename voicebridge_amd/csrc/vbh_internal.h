@@ -45,6 +45,7 @@ struct vbh_ctx {
   int arena_next = 0;
   hipEvent_t marks[VBH_MAX_TIMERS] = {};      // vbh_ctx_mark / vbh_ctx_wait_mark
   struct { void *p; size_t cap; } scratch[VBH_SCRATCH_SLOTS] = {};
+  int fmllr_dim = 0, fmllr_nspk = 0;       // the statistics the last vbh_fmllr_accumulate* left in the scratch slots (vbh_fmllr_update_full reads them there)
 };
 // slot's buffer, at least `bytes` long (nullptr + error on failure); contents are not preserved when it grows
 void *vbh_scratch(vbh_ctx *ctx, int slot, size_t bytes);

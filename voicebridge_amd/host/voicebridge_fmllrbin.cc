@@ -320,6 +320,19 @@ static int EstimateOnGpu(const char *prog, bool use_gpost, const Options &po, co
     for (int t = 0; t < rows; t++) sink.EndFrame();      // an utterance without statistics: frames without pairs
   }
   lap("posterior pairs");
+  // The "full" update (the default) runs on the device from the statistics where the accumulation left them (vbh_fmllr_update_full: one
+  // wave per unit; the 128 MB of a 256-speaker batch stay there); the closed-form update types read the statistics on the host.
+  const bool device_update = opts.update_type == "full" && !getenv("VB_FMLLR_HOST_UPDATE");
+  std::vector<vbio::Matrix> xf(units.size());
+  std::vector<float> imprs(units.size(), 0.0f), counts(units.size(), 0.0f);
+  std::vector<double> betas(units.size(), 0.0);
+  std::vector<std::string> uerr(units.size());
+  for (size_t s = 0; s < units.size(); s++) {
+    vbio::Matrix &t = xf[s];
+    t.rows = D; t.cols = n1; t.data.assign((size_t)D * n1, 0.0f);
+    for (int d = 0; d < D; d++) t.data[(size_t)d * n1 + d] = 1.0f;
+  }
+  bool updated_on_device = false;
   if (num_done > 0) {
     int fdim = 0;
     std::unique_ptr<DevBuffer> hold;
@@ -327,31 +340,39 @@ static int EstimateOnGpu(const char *prog, bool use_gpost, const Options &po, co
     lap("features on the device");
     if (fdim != D) throw ApiError("Dim mismatch: data dim = " + std::to_string(fdim) + " vs. model dim = " + std::to_string(D));
     const int S = (int)units.size();
-    std::vector<double> beta(S), K((size_t)S * D * n1), G((size_t)S * D * n1 * n1);
+    std::vector<double> beta(S), K, G;
+    if (!device_update) { K.resize((size_t)S * D * n1); G.resize((size_t)S * D * n1 * n1); }
+    double *pK = device_update ? nullptr : K.data(), *pG = device_update ? nullptr : G.data();
     const int rc = use_gpost
         ? vbh_fmllr_accumulate_gpost(ctx, dgmm, d_feats, (int32_t)NU, tab.offs.data(), u2s.data(), S, sink.poff.data(), sink.ppdf.data(),
-                                     sink.goff.data(), sink.gpost.data(), num_gauss.data(), beta.data(), K.data(), G.data(), nullptr)
+                                     sink.goff.data(), sink.gpost.data(), num_gauss.data(), beta.data(), pK, pG, nullptr)
         : vbh_fmllr_accumulate(ctx, dali, dgmm, d_feats, (int32_t)NU, tab.offs.data(), u2s.data(), S, sink.poff.data(), sink.ppdf.data(),
-                               sink.pw.data(), beta.data(), K.data(), G.data(), nullptr);
+                               sink.pw.data(), beta.data(), pK, pG, nullptr);
     if (rc != 0) throw ApiError(std::string("vbh_fmllr_accumulate: ") + vbh_last_error());
     lap("statistics on the device");
-    for (int s_ = 0; s_ < S; s_++) if (beta[s_] != 0.0) accs[s_].AddStats(beta[s_], &K[(size_t)s_ * D * n1], &G[(size_t)s_ * D * n1 * n1]);
-    lap("statistics added");
+    for (int s_ = 0; s_ < S; s_++) betas[(size_t)s_] = beta[(size_t)s_];
+    if (device_update) {
+      std::vector<float> x((size_t)S * D * n1), im((size_t)S, 0.0f);
+      for (int s_ = 0; s_ < S; s_++) memcpy(&x[(size_t)s_ * D * n1], xf[(size_t)s_].data.data(), sizeof(float) * (size_t)D * n1);
+      if (vbh_fmllr_update_full(ctx, D, S, opts.min_count, opts.num_iters, x.data(), im.data(), nullptr) != 0) throw ApiError(std::string("fMLLR update: ") + vbh_last_error());
+      for (int s_ = 0; s_ < S; s_++) {
+        memcpy(xf[(size_t)s_].data.data(), &x[(size_t)s_ * D * n1], sizeof(float) * (size_t)D * n1);
+        imprs[(size_t)s_] = im[(size_t)s_]; counts[(size_t)s_] = (float)beta[(size_t)s_];
+      }
+      updated_on_device = true;
+      lap("row updates on the device");
+    } else {
+      for (int s_ = 0; s_ < S; s_++) if (beta[s_] != 0.0) accs[s_].AddStats(beta[s_], &K[(size_t)s_ * D * n1], &G[(size_t)s_ * D * n1 * n1]);
+      lap("statistics added");
+    }
   }
-  // ---- per unit: update from the unit transform (40 row-by-row iterations, a 39 x 39 inverse per row: 0.1 s of one core per
-  //      speaker, independent per speaker -> spread over the host's threads), then written in table order
-  std::vector<vbio::Matrix> xf(units.size());
-  std::vector<float> imprs(units.size(), 0.0f), counts(units.size(), 0.0f);
-  std::vector<std::string> uerr(units.size());
-  {
+  // ---- the other update types (and units without statistics): from the unit transform on the host's threads, written in table order
+  if (!updated_on_device) {
     std::atomic<size_t> next{0};
     auto work = [&]() {
       for (size_t s = next++; s < units.size(); s = next++) {
         if (!po.Has("spk2utt") && !unit_has_utt[s]) continue;
-        vbio::Matrix &t = xf[s];
-        t.rows = D; t.cols = n1; t.data.assign((size_t)D * n1, 0.0f);
-        for (int d = 0; d < D; d++) t.data[(size_t)d * n1 + d] = 1.0f;
-        try { imprs[s] = accs[s].Update(opts, t.data.data(), &counts[s]); } catch (const std::exception &e) { uerr[s] = e.what(); }
+        try { imprs[s] = accs[s].Update(opts, xf[s].data.data(), &counts[s]); betas[s] = accs[s].beta(); } catch (const std::exception &e) { uerr[s] = e.what(); }
       }
     };
     const unsigned nt = std::max(1u, std::min<unsigned>(16, std::min<unsigned>((unsigned)units.size(), std::thread::hardware_concurrency())));
@@ -359,14 +380,14 @@ static int EstimateOnGpu(const char *prog, bool use_gpost, const Options &po, co
     for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
     work();
     for (std::thread &t : pool) t.join();
+    lap("row updates");
   }
-  lap("row updates");
   vbio::MatrixWriter writer(trans_wspec);
   double tot_impr = 0.0, tot_t = 0.0;
   for (size_t s = 0; s < units.size(); s++) {
     if (!po.Has("spk2utt") && !unit_has_utt[s]) continue;     // per-utterance mode writes nothing for skipped utterances
     if (!uerr[s].empty()) throw ApiError("fMLLR update for " + units[s].first + ": " + uerr[s]);
-    if (!(accs[s].beta() > opts.min_count)) log.os() << "WARNING (" << prog << ") Not updating fMLLR since below min-count: count is " << accs[s].beta() << "\n";
+    if (!(betas[s] > opts.min_count)) log.os() << "WARNING (" << prog << ") Not updating fMLLR since below min-count: count is " << betas[s] << "\n";
     writer.Write(units[s].first, xf[s]);
     log.os() << "LOG (" << prog << ") For " << (po.Has("spk2utt") ? "speaker " : "utterance ") << units[s].first << ", auxf-impr from fMLLR is " << (imprs[s] / counts[s])
              << ", over " << counts[s] << " frames.\n";
