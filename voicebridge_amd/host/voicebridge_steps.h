@@ -60,8 +60,10 @@ int Decode(const std::string &graph_dir, const std::string &data_dir, const std:
 // posteriors (pre_trans.JOB) -> main search on the transformed features (raw lattices lat.tmp.JOB) -> a second fMLLR estimate from the
 // pruned-determinized lattices, composed with the first (trans.JOB) -> acoustic rescoring with the final model on the final features ->
 // determinization (lat.JOB) -> best path (w.JOB, transcriptionJOB.trn) -> scoring.  On the GPU: the feature pipeline, both searches,
-// the fMLLR sufficient statistics (vbh_fmllr_accumulate) and the scores the rescoring adds (vbh_gmm_loglikes_pairs); on the host: the
-// lattice forward-backward and silence weighting, the row-by-row fMLLR update, determinization, scoring.
+// (the first one in the search kernel's light layout), the fMLLR sufficient statistics and the row-by-row update from them
+// (vbh_fmllr_accumulate, vbh_fmllr_update_full) and the scores the rescoring adds (vbh_gmm_loglikes_pairs); on the host: the lattice
+// forward-backward and silence weighting (on the determinized lattices: milliseconds), determinization, scoring.  The small temporaries
+// between the programs are in-memory tables (posteriors as objects) unless VB_STEP_FILE_TEMPS=1.
 int DecodeFmllr(const std::string &graphdir, const std::string &data, const std::string &dir, const std::string &alignment_model = "",
                 const std::string &adapt_model = "", const std::string &final_model = "", int nj = 4, float acwt = 0.083333f, int stage = 0,
                 int max_active = 7000, double beam = 13.0, double lattice_beam = 6.0, double silence_weight = 0.01, const std::string &si_dir = "",
