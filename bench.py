@@ -1523,9 +1523,10 @@ def main():
                 k_dec = [k_ for k_ in st_ if k_.startswith("Decode_s")][0]
                 k_fm = [k_ for k_ in st_ if k_.startswith("DecodeFmllr_s")][0]
                 out["step_api"] = {"what": "tools/bench_steps.py: %d utterances of 30 s in a data directory, nj = 4 jobs on %d host thread(s), one GPU; seconds per step "
-                                           "of the reference's API and frames/s of the two decoding steps" % (args.step_api_utts, args.step_api_threads),
+                                           "of the reference's API and frames/s of the two decoding steps; Decode_s / DecodeFmllr_s = the SECOND call of the step in the process (graph, models and "
+                                           "search workspaces exist: the rate of a process that decodes set after set), *_first_call_s = the first (loads the graph, makes the workspaces)" % (args.step_api_utts, args.step_api_threads),
                                    "job_threads": args.step_api_threads, "MakeMfcc_s": st_["MakeMfcc_s"], "ComputeCmvnStats_s": st_["ComputeCmvnStats_s"], "Decode_s": st_[k_dec],
-                                   "DecodeFmllr_s": st_[k_fm], "Decode_step_frames_per_s": fr_ / st_[k_dec], "DecodeFmllr_step_frames_per_s": fr_ / st_[k_fm],
+                                   "DecodeFmllr_s": st_[k_fm], "Decode_first_call_s": st_.get("Decode_first_call_s"), "DecodeFmllr_first_call_s": st_.get("DecodeFmllr_first_call_s"), "Decode_step_frames_per_s": fr_ / st_[k_dec], "DecodeFmllr_step_frames_per_s": fr_ / st_[k_fm],
                                    "Decode_best_wer": st_.get("Decode_best_wer"), "DecodeFmllr_best_wer": st_.get("DecodeFmllr_best_wer")}
             except Exception as e:
                 out["step_api"] = {"error": str(e)[:300]}
