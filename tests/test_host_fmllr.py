@@ -103,6 +103,46 @@ def test_fmllr_chain_matches_golden(host, tmp_path):
     compare_chain(d)
 
 
+def test_in_memory_posterior_tables(host, tmp_path):
+    """"ark:mem:NAME" posterior tables (kaldi_io.h FlatPostTable: the object itself is handed from program to program, as DecodeFmllr does
+    with post.temp / wsp.temp): the chain through memory writes the bytes the chain through files writes; weight-silence-post with weight 1
+    turns an in-memory table into a file unchanged; a reader of the frame-vector form (gmm-post-to-gpost's) takes an in-memory table too;
+    an unlinked table is gone"""
+    import ctypes as C
+    d = tmp_path
+    g = util.load("fmllr")
+    for k in g.files:
+        if k.startswith("file_"):
+            name = k[5:].rsplit("_", 1)
+            (d / (name[0] + "." + name[1])).write_bytes(g[k].tobytes())
+    p = lambda n: str(d / n)
+    run = mine_runner(host, d)
+    run("lattice-to-post", "--acoustic-scale=0.083333", "ark:" + p("ldp.ark"), "ark:" + p("f_post.ark"))
+    run("weight-silence-post", "0.01", "1:2", p("final.mdl"), "ark:" + p("f_post.ark"), "ark:" + p("f_wsp.ark"))
+    m_post, m_wsp = "mem:" + p("post.temp"), "mem:" + p("wsp.temp")
+    run("lattice-to-post", "--acoustic-scale=0.083333", "ark:" + p("ldp.ark"), "ark:" + m_post)
+    assert not os.path.exists(p("post.temp"))
+    run("weight-silence-post", "0.01", "1:2", p("final.mdl"), "ark:" + m_post, "ark:" + m_wsp)
+    run("weight-silence-post", "1.0", "1:2", p("final.mdl"), "ark:" + m_post, "ark:" + p("m_post.ark"))
+    run("weight-silence-post", "1.0", "1:2", p("final.mdl"), "ark:" + m_wsp, "ark:" + p("m_wsp.ark"))
+    assert open(p("m_post.ark"), "rb").read() == open(p("f_post.ark"), "rb").read() == open(p("post.ark"), "rb").read()
+    assert open(p("m_wsp.ark"), "rb").read() == open(p("f_wsp.ark"), "rb").read() == open(p("wsp.ark"), "rb").read()
+    run("weight-silence-post", "1.0", "1:2", p("final.mdl"), "ark:" + m_wsp, "ark,t:" + p("m_wsp.txt"))       # ... and as text
+    run("weight-silence-post", "1.0", "1:2", p("final.mdl"), "ark:" + p("f_wsp.ark"), "ark,t:" + p("f_wsp.txt"))
+    assert open(p("m_wsp.txt")).read() == open(p("f_wsp.txt")).read()
+    # the frame-vector reader (gmm-post-to-gpost) on the in-memory table: the same Gaussian posteriors as from the file
+    run("gmm-post-to-gpost", p("final.mdl"), "ark:" + p("feats.ark"), "ark:" + m_wsp, "ark:" + p("m_gpost.ark"))
+    run("gmm-post-to-gpost", p("final.mdl"), "ark:" + p("feats.ark"), "ark:" + p("f_wsp.ark"), "ark:" + p("f_gpost.ark"))
+    assert open(p("m_gpost.ark"), "rb").read() == open(p("f_gpost.ark"), "rb").read()
+    host.vbio_mem_unlink.argtypes = [C.c_char_p]
+    host.vbio_mem_unlink(m_post.encode()); host.vbio_mem_unlink(m_wsp.encode())
+    log = str(d / "gone.txt")
+    assert call(host.vb_WeightSilencePost, ["weight-silence-post", "1.0", "1:2", p("final.mdl"), "ark:" + m_wsp, "ark:" + p("gone.ark")], log) == -1
+    assert "no such in-memory posterior table" in open(log).read()
+    with pytest.raises(AssertionError):       # a text in-memory table makes no sense
+        run("lattice-to-post", "--acoustic-scale=0.083333", "ark:" + p("ldp.ark"), "ark,t:" + m_post)
+
+
 def test_text_mode_posterior_tables(host, tmp_path):
     """"ark,t:" posterior tables (K/hmm/posterior.cc:32-125): what lattice-to-post and weight-silence-post write in text mode is
     what the reference's programs write, and what they read back gives the binary chain's result to the six digits text keeps"""
