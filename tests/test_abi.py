@@ -71,3 +71,23 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dp, f), errors="ignore").read()
                 bad = re.search(r'#\s*include[^\n]*oracle|^\s*(from|import)\s+oracle|libvb_oracle|dlopen[^\n]*oracle', src, flags=re.M)
                 assert bad is None, (os.path.join(dp, f), bad.group(0))
+
+
+def test_search_layout_is_chosen_by_the_configuration(lib, monkeypatch):
+    """vbh_decode_layout_for (no GPU needed): light searches (max_active <= 3000) get the two-workgroups-per-CU layout, the
+    defaults the one-workgroup layout; VBH_DECODE_LAYOUT overrides either way"""
+    from voicebridge_amd import _lib
+    monkeypatch.delenv("VBH_DECODE_LAYOUT", raising=False)
+    cfg = _lib.DecodeCfg()
+    lib.vbh_decode_cfg_default(C.byref(cfg))
+    lib.vbh_decode_layout_for.argtypes = [C.POINTER(_lib.DecodeCfg)]
+    assert cfg.max_active == 7000 and lib.vbh_decode_layout_for(C.byref(cfg)) == 1
+    cfg.max_active = 2000; cfg.beam = 10.0           # DecodeFmllr's first pass
+    assert lib.vbh_decode_layout_for(C.byref(cfg)) == 2
+    cfg.max_active = 3001
+    assert lib.vbh_decode_layout_for(C.byref(cfg)) == 1
+    monkeypatch.setenv("VBH_DECODE_LAYOUT", "2")
+    assert lib.vbh_decode_layout_for(C.byref(cfg)) == 2
+    monkeypatch.setenv("VBH_DECODE_LAYOUT", "1")
+    cfg.max_active = 500
+    assert lib.vbh_decode_layout_for(C.byref(cfg)) == 1

@@ -115,6 +115,8 @@ def test_decode_batch_vs_oracle(ctx, S, P, T, seed, cfg, adm):
     batch = np.concatenate([ll[:n] for n in lens]) if sum(lens) else np.zeros((0, P), np.float32)
     graph = api.Graph(ctx, g["final"], g["arc_offset"], g["arcs"], 0)
     dec = api.LatticeDecoder(ctx, graph, 3, max(lens), admission=adm, **cfg)
+    if "VBH_DECODE_LAYOUT" not in os.environ:        # (both layouts of the kernel are met by these cases: light configurations get two workgroups per CU)
+        assert dec.layout == (2 if cfg["max_active"] <= 3000 else 1)
     d = torch.from_numpy(np.ascontiguousarray(batch)).to(ctx.device) if len(batch) else torch.zeros((1, P), device=ctx.device)
     ctx.torch_sync()
     dec.decode(d, foff, t2p)

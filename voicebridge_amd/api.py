@@ -344,6 +344,12 @@ class LatticeDecoder:
         self.h = h
         self.n_utt = 0
 
+    @property
+    def layout(self):
+        """1: one 1024-thread workgroup per CU; 2: two 512-thread workgroups per CU (light searches) -- vbh_decoder_layout"""
+        self.lib.vbh_decoder_layout.argtypes = [C.c_void_p]
+        return int(self.lib.vbh_decoder_layout(self.h))
+
     def decode(self, d_loglikes, frame_offsets, tid2pdf):
         fo = np.ascontiguousarray(frame_offsets, np.int64)
         t2p = np.ascontiguousarray(tid2pdf, np.int32)

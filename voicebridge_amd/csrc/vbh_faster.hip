@@ -62,8 +62,9 @@ struct FGraph { int S, start; const i32x4 *st; const i32x4 *arcs; const int *arc
 struct FCfg { float beam, beam_delta, acwt; int max_active, min_active; };
 
 struct FSlot {
-  i32x4 *tok;              // [tok_cap] {prev token, arc (-1: start), state | EPSBIT, 0}
-  double *cost;            // [tok_cap]
+  i32x4 *tok;              // [tok_cap] {prev token, arc (-1: start), state | EPSBIT, the arc's cost: float(cost - prev's cost)}
+  double *cost;            // [2 x frame_cap] the costs of the current frame's tokens and of the frame being made, in alternating halves
+                           //   (only those two frames' costs are ever read: the history keeps {previous token, arc, state} alone, round 5)
   unsigned long long *win; // [HCAP + g_cap] winner key (arc << 32 | source token) per state of the frame being built, by map slot (LDS slots, then
                            // the second level's); ~0 = none: make_tokens leaves every entry it read that way.  Used by the SLOW path only (below)
   // Round 5: the way into a state is recorded WHEN its cost is lowered.  Whoever lowers a state's cost (map_relax: improved) stores {its cost key,
@@ -81,7 +82,7 @@ struct FSlot {
   unsigned *g_hs; unsigned long long *g_hc; int *g_ht;   // second level of the state map, [g_cap] (power of two)
   int *g_list;             // [frame_cap] the second-level slots the frame being built has claimed (what is walked, numbered and cleared)
   int *remap;              // [tok_cap] garbage collection: mark, then new index
-  i32x4 *stage_tok; double *stage_cost;   // [stage_cap] survivors on their way down
+  i32x4 *stage_tok;        // [stage_cap] survivors on their way down
   int tok_cap, frame_cap, cand_cap, front_cap, g_cap, stage_cap;
 };
 
@@ -725,8 +726,9 @@ __device__ void epsilon_winners(const FGraph &g, const FSlot &s, double cutoff, 
 // the winner entries that were read are left empty for the next frame.
 // slow: the winners are in FSlot::win (winners / epsilon_winners ran); otherwise in FSlot::wrec (checked by number_tokens)
 template <bool slow>
-__device__ void make_tokens(const FSlot &s, int tok_base, const FCfg &cfg, Shared &sh, int &par, double &weight_cutoff, float &adaptive_beam, int &best_state) {
-  gp<i32x4> tok = uptr(s.tok); gp<double> cost = uptr(s.cost);
+__device__ void make_tokens(const FSlot &s, int tok_base, gp<double> cost_out, gp<const double> cost_cur, int cur_b, const FCfg &cfg, Shared &sh, int &par,
+                            double &weight_cutoff, float &adaptive_beam, int &best_state) {
+  gp<i32x4> tok = uptr(s.tok);
   gp<unsigned long long> win = uptr(s.win);
   gp<const i32x4> wrec = uptr((const i32x4 *)s.wrec);
   const Map2 m2 = map2_of(s);
@@ -746,25 +748,36 @@ __device__ void make_tokens(const FSlot &s, int tok_base, const FCfg &cfg, Share
     st[u] = (int)tag; key[u] = sh.hc[e]; li[u] = have[u] ? sh.ht[e] : 0;
     if (have[u]) { sh.hs[e] = HEMPTY; sh.hc[e] = ~0ull; }      // (this thread was the slot's last reader: map_clear)
   }
+  // ---- the frame's costs first (the half of FSlot::cost that is not the current frame's): a token's record carries the cost of the
+  //      arc that made it, cost - source's cost in double rounded to float -- what GetBestPath computes from the two tokens
+  //      (faster-decoder.cc:122-127) -- and the source may be a token of THIS frame (epsilon arcs).  The history keeps no costs.
+  const int ng_all = sh.g_used ? (sh.n_g < s.frame_cap ? sh.n_g : s.frame_cap) : 0;
+#pragma unroll
+  for (int u = 0; u < PER; u++) if (have[u]) cost_out[li[u]] = o2d(key[u]);
+  for (int i = threadIdx.x; i < ng_all; i += NT) {
+    const int h = m2.gl[i];
+    if (slow) { int st1, li1; unsigned long long key1; if (map_entry(sh, m2, HCAP + h, st1, key1, li1)) cost_out[li1] = o2d(key1); }
+    else cost_out[m2.gt[h]] = o2d(m2.gc[h]);
+  }
+  __syncthreads();
+  auto arc_cost = [&](double c, int src) -> int {       // src: absolute token index (-1: the start token, no arc)
+    if (src < 0) return 0;
+    const double pc = src >= tok_base ? cost_out[src - tok_base] : cost_cur[src - cur_b];
+    return __float_as_int((float)(c - pc));
+  };
   if (!slow) {
 #pragma unroll
     for (int u = 0; u < PER; u++) {
       if (!have[u]) continue;
       const i32x4 wr = wrec[u * NT + threadIdx.x];
-      i32x4 r; r.x = src_of(wr.w); r.y = wr.z; r.z = st[u]; r.w = 0;
+      i32x4 r; r.x = src_of(wr.w); r.y = wr.z; r.z = st[u]; r.w = arc_cost(o2d(key[u]), r.x);
       tok[tok_base + li[u]] = r;
-      cost[tok_base + li[u]] = o2d(key[u]);
     }
-    if (sh.g_used) {
-      const int ng = sh.n_g < s.frame_cap ? sh.n_g : s.frame_cap;
-      for (int i = threadIdx.x; i < ng; i += NT) {
-        const int h = m2.gl[i];
-        const i32x4 wr = wrec[HCAP + h];
-        i32x4 r; r.x = src_of(wr.w); r.y = wr.z; r.z = (int)m2.gs[h]; r.w = 0;
-        const int li1 = m2.gt[h];
-        tok[tok_base + li1] = r;
-        cost[tok_base + li1] = o2d(m2.gc[h]);
-      }
+    for (int i = threadIdx.x; i < ng_all; i += NT) {
+      const int h = m2.gl[i];
+      const i32x4 wr = wrec[HCAP + h];
+      i32x4 r; r.x = src_of(wr.w); r.y = wr.z; r.z = (int)m2.gs[h]; r.w = arc_cost(o2d(m2.gc[h]), r.x);
+      tok[tok_base + m2.gt[h]] = r;
     }
   }
 #pragma unroll
@@ -782,12 +795,11 @@ __device__ void make_tokens(const FSlot &s, int tok_base, const FCfg &cfg, Share
     i32x4 r; r.x = (int)(unsigned)w[u]; r.y = (int)(unsigned)(w[u] >> 32); r.z = st[u]; r.w = 0;
     if (w[u] == ~0ull) { r.x = -1; r.y = -1; }      // the start token
     else win[u * NT + threadIdx.x] = ~0ull;
+    r.w = arc_cost(o2d(key[u]), r.x);
     tok[tok_base + li[u]] = r;
-    cost[tok_base + li[u]] = o2d(key[u]);
   }
-  if (slow && sh.g_used) {
-    const int ng = sh.n_g < s.frame_cap ? sh.n_g : s.frame_cap;
-    for (int i = threadIdx.x; i < ng; i += NT) {
+  if (slow) {
+    for (int i = threadIdx.x; i < ng_all; i += NT) {
       const int e = HCAP + m2.gl[i];
       int st1, li1; unsigned long long key1;
       if (!map_entry(sh, m2, e, st1, key1, li1)) continue;
@@ -795,8 +807,8 @@ __device__ void make_tokens(const FSlot &s, int tok_base, const FCfg &cfg, Share
       i32x4 r; r.x = (int)(unsigned)w1; r.y = (int)(unsigned)(w1 >> 32); r.z = st1; r.w = 0;
       if (w1 == ~0ull) { r.x = -1; r.y = -1; }
       else win[e] = ~0ull;
+      r.w = arc_cost(o2d(key1), r.x);
       tok[tok_base + li1] = r;
-      cost[tok_base + li1] = o2d(key1);
     }
   }
   // GetCutoff of the frame just made, for its turn as the current frame: its costs are the keys at hand (the second level's, if any,
@@ -821,9 +833,9 @@ __device__ void make_tokens(const FSlot &s, int tok_base, const FCfg &cfg, Share
 // Returns the new position of the current frame; everything below it is then settled.
 __device__ int collect_garbage(const FSlot &s, int gc_base, int cur_b, int cur_n, Shared &sh) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  gp<i32x4> tok = uptr(s.tok); gp<double> cost = uptr(s.cost);
+  gp<i32x4> tok = uptr(s.tok);
   gp<int> remap = uptr(s.remap);
-  gp<i32x4> st_tok = uptr(s.stage_tok); gp<double> st_cost = uptr(s.stage_cost);
+  gp<i32x4> st_tok = uptr(s.stage_tok);      // (the current frame's tokens all survive, in their order: their costs stay where they are, FSlot::cost)
   const int end = cur_b + cur_n;
   for (int i = gc_base + tid; i < end; i += NT) remap[i] = 0;
   __syncthreads();
@@ -849,7 +861,7 @@ __device__ int collect_garbage(const FSlot &s, int gc_base, int cur_b, int cur_n
   if (total > s.stage_cap) { if (tid == 0) sh.error = FERR_TOK; __syncthreads(); return cur_b; }
   int idx = wbase + incl - c;
   for (int t = lo; t < hi; t++) {
-    if (remap[t]) { st_tok[idx] = tok[t]; st_cost[idx] = cost[t]; remap[t] = gc_base + idx; idx++; }
+    if (remap[t]) { st_tok[idx] = tok[t]; remap[t] = gc_base + idx; idx++; }
     else remap[t] = -1;
   }
   __syncthreads();
@@ -857,7 +869,6 @@ __device__ int collect_garbage(const FSlot &s, int gc_base, int cur_b, int cur_n
     i32x4 r = st_tok[j];
     if (r.x >= gc_base) r.x = remap[r.x];
     tok[gc_base + j] = r;
-    cost[gc_base + j] = st_cost[j];
   }
   __syncthreads();
   return gc_base + total - cur_n;
@@ -929,12 +940,13 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
         __syncthreads();
         if (tid == 0) sh.n_slow++;
       }
-      if (slow0) make_tokens<true>(s, 0, cfg, sh, par, weight_cutoff, adaptive_beam, best_state);
-      else make_tokens<false>(s, 0, cfg, sh, par, weight_cutoff, adaptive_beam, best_state);
+      if (slow0) make_tokens<true>(s, 0, cost, cost, 0, cfg, sh, par, weight_cutoff, adaptive_beam, best_state);
+      else make_tokens<false>(s, 0, cost, cost, 0, cfg, sh, par, weight_cutoff, adaptive_beam, best_state);
     }
     __syncthreads();
     int frames_done = 0;
     int gc_base = 0;
+    int chalf = 0;          // the half of FSlot::cost that holds the current frame's costs
     FPHASE(9)
     for (int frame = 0; frame < T && sh.error == FERR_NONE; frame++) {
       if (cur_b + cur_n + s.frame_cap > s.tok_cap) {      // make room for whatever this frame may create
@@ -944,7 +956,7 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
       }
       FPHASE(0)
       const float *llrow = loglikes + (ud.row0 + frame) * (long long)P;
-      gp<const double> ccost = cost + cur_b;
+      gp<const double> ccost = cost + (size_t)chalf * s.frame_cap;
       gp<const i32x4> ctok = tok + cur_b;
       const int n = cur_n;
       // (GetCutoff, :151-213: weight_cutoff and adaptive_beam of this frame were computed when its tokens were made)
@@ -1145,19 +1157,19 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
         if (tid == 0) { sh.n_slow++; sh.u_tie += sh.tie; sh.u_bad += sh.bad; }
       }
       FPHASE(7)
-      if (slow) make_tokens<true>(s, nb, cfg, sh, par, weight_cutoff, adaptive_beam, best_state);
-      else make_tokens<false>(s, nb, cfg, sh, par, weight_cutoff, adaptive_beam, best_state);
+      if (slow) make_tokens<true>(s, nb, cost + (size_t)(chalf ^ 1) * s.frame_cap, ccost, cur_b, cfg, sh, par, weight_cutoff, adaptive_beam, best_state);
+      else make_tokens<false>(s, nb, cost + (size_t)(chalf ^ 1) * s.frame_cap, ccost, cur_b, cfg, sh, par, weight_cutoff, adaptive_beam, best_state);
       FPHASE(14)
       __syncthreads();
       FPHASE(8)
-      cur_b = nb; cur_n = n_new;
+      cur_b = nb; cur_n = n_new; chalf ^= 1;
       frames_done = frame + 1;
     }
     __syncthreads();
     // ---- ReachedFinal / GetBestPath (:78-147)
     int r_ok = 0, r_final = 0, r_len = 0, r_state = -1; float r_fc = 0.0f;
     if (sh.error == FERR_NONE && frames_done == T) {
-      gp<const double> ccost = cost + cur_b;
+      gp<const double> ccost = cost + (size_t)chalf * s.frame_cap;
       gp<const i32x4> ctok = tok + cur_b;
       unsigned long long anyf = 0;
       for (int i = tid; i < cur_n; i += NT) {
@@ -1191,10 +1203,9 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
           while (true) {
             const i32x4 r = tok[t];
             if (r.x < 0) break;                     // the start token
-            const double c = cost[t], pc = cost[r.x];
             const i32x4 arc = uptr(g.arcs)[r.y];
             if (len < path_cap) {
-              i32x4 o; o.x = uptr(g.arc_il)[r.y]; o.y = arc.w; o.z = arc.y; o.w = __float_as_int((float)(c - pc));
+              i32x4 o; o.x = uptr(g.arc_il)[r.y]; o.y = arc.w; o.z = arc.y; o.w = r.w;      // (the arc's cost: made with the token, make_tokens)
               path[len] = o;
             } else err = 1;
             len++;
@@ -1292,12 +1303,14 @@ int vbh_faster_decoder_create_ex(vbh_ctx *ctx, const vbh_graph *graph, const vbh
   // (small graphs: every state every frame is the worst case and cheap to provide -- nothing to collect then)
   const long long worst = (long long)p.frame_cap * ((long long)max_frames + 2);
   const long long kept = 256LL * ((long long)max_frames + 2);
-  // Round 5: with the reference's cutoffs (float32-rounded order statistics) a 30 s utterance of the bench's workload makes ~1.1 M tokens;
-  // a collection costs ~12 ms (every current token walks its ancestors, then 2 M records move through the staging buffer), 12-15 % of
-  // an utterance at three or four collections.  The history is therefore sized so that an ordinary utterance needs none -- ~500 tokens
-  // per frame, 6 M tokens at least: 170 MB per slot, 43 GB for 256 slots of a device that has 288 -- and collection stays the answer to
-  // the extraordinary one (and to VBH_FASTER_HISTORY, the tests' way of forcing it).
-  p.tok_cap = (int)std::min<long long>(std::min<long long>(worst, std::max<long long>(std::max<long long>(kept, 500LL * ((long long)max_frames + 2)) + 4LL * p.frame_cap, 6LL << 20)), 1LL << 28);
+  // Round 5: with the reference's cutoffs (float32-rounded order statistics) a 30 s utterance of the bench's workload makes 7-9 M
+  // tokens (2300-3000 per frame), and a collection costs ~50 M cycles (every current token walks its ancestors -- the trunk of the
+  // history one dependent load at a time -- then the records move through the staging buffer): 9 % of an utterance's time at one or two
+  // collections (-DVBH_FASTER_PROF).  The history is therefore sized so that an ordinary utterance needs none -- 10 M tokens at least;
+  // it holds {previous token, arc, state} records and the collection's remap word only (the costs of the two frames that are ever read
+  // live in FSlot::cost): 20 bytes per token, 200 MB per slot, 51 GB for 256 slots of a device that has 288 -- and collection stays
+  // the answer to the extraordinary one (and to VBH_FASTER_HISTORY, the tests' way of forcing it).
+  p.tok_cap = (int)std::min<long long>(std::min<long long>(worst, std::max<long long>(std::max<long long>(kept, 500LL * ((long long)max_frames + 2)) + 4LL * p.frame_cap, 10LL << 20)), 1LL << 28);
   if (const char *e = getenv("VBH_FASTER_HISTORY")) {     // tests: a small history forces garbage collections
     const long long x = atoll(e);
     if (x > 0) p.tok_cap = (int)std::min<long long>(p.tok_cap, std::max<long long>(x, 2LL * p.frame_cap));
@@ -1317,12 +1330,12 @@ int vbh_faster_decoder_create_ex(vbh_ctx *ctx, const vbh_graph *graph, const vbh
     d->allocs.push_back(base);                                                                      \
     for (size_t i = 0; i < ns; i++) d->h_slots[i].field = base + i * (size_t)(count);               \
   }
-  A_(tok, i32x4, p.tok_cap) A_(cost, double, p.tok_cap) A_(win, unsigned long long, HCAP + p.g_cap) A_(wrec, i32x4, HCAP + p.g_cap)
+  A_(tok, i32x4, p.tok_cap) A_(cost, double, 2 * (size_t)p.frame_cap) A_(win, unsigned long long, HCAP + p.g_cap) A_(wrec, i32x4, HCAP + p.g_cap)
   A_(c_w, double, p.cand_cap) A_(c_r, i32x4, p.cand_cap)
   A_(front[0], int, p.front_cap) A_(front[1], int, p.front_cap) A_(front[2], int, p.front_cap)
   A_(elist, int, p.frame_cap)
   A_(g_hs, unsigned, p.g_cap) A_(g_hc, unsigned long long, p.g_cap) A_(g_ht, int, p.g_cap) A_(g_list, int, p.frame_cap)
-  A_(remap, int, p.tok_cap) A_(stage_tok, i32x4, p.stage_cap) A_(stage_cost, double, p.stage_cap)
+  A_(remap, int, p.tok_cap) A_(stage_tok, i32x4, p.stage_cap)
 #undef A_
   if (d->d_slots.upload(d->h_slots.data(), d->h_slots.size(), ctx->stream)) { vbh_faster_decoder_destroy(d); return -1; }
   VBH_HIP(hipStreamSynchronize(ctx->stream));
