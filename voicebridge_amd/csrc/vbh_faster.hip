@@ -45,6 +45,11 @@ constexpr int HCAP = 1 << HBITS;            // states per frame the LDS map can 
 constexpr int HPROBE = VBH_FASTER_HPROBE;
 constexpr unsigned HEMPTY = 0xFFFFFFFFu;
 constexpr int MAX_EPS_ITERS = 4096;
+#ifndef VBH_FASTER_UA
+#define VBH_FASTER_UA 4         // x 64 arcs a wave has in flight in pass 1 (round 5, same box, s per 1024 x 30 s: 1 / 2 / 4: 1.68 / 1.65 / 1.56)
+#endif
+constexpr int UA = VBH_FASTER_UA;
+static_assert(UA >= 1 && UA <= 4, "Shared::wx holds 64 x 4 marker bytes per wave");
 #ifndef VBH_FASTER_SLOW
 #define VBH_FASTER_SLOW 0      // 1: every frame takes the slow winner path (rounds 1-4's; A/B and tests)
 #endif
@@ -199,6 +204,64 @@ __device__ __forceinline__ void wave_expand(unsigned char *mk, int cnt, F body) 
     body(valid, owner, j);
   }
 }
+// the same UA x 64 sub-items per round (vbh_decode.hip wave_owners / wave_expand_n): body(valid[UA], owner[UA], j[UA]) issues the loads
+// of all of them before it uses any.  mk: 64 x UA marker bytes.
+template <int UA, class F>
+__device__ __forceinline__ void wave_expand_n(unsigned char *mk, int cnt, F body) {
+  const int lane = threadIdx.x & 63;
+  const int incl = wave_incl_scan(cnt);
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  const int excl = incl - cnt;
+  const bool has = cnt > 0;
+  for (int k0 = 0; k0 < total; k0 += 64 * UA) {
+    if (lane < 16 * UA) reinterpret_cast<unsigned *>(mk)[lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (has && excl >= k0 && excl < k0 + 64 * UA) mk[excl - k0] = (unsigned char)(lane + 1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long before = __ballot(has && excl < k0);
+    int c_own = 0, c_start = 0;
+    if (before) {
+      const int l = __builtin_amdgcn_readfirstlane(63 - __clzll((long long)before));
+      c_own = l + 1;
+      c_start = __builtin_amdgcn_readlane(excl, l) + 1;
+    }
+    bool valid[UA]; int owner[UA], j[UA], m[UA];
+#pragma unroll
+    for (int u = 0; u < UA; u++) m[u] = (k0 + u * 64 < total) ? (int)mk[u * 64 + lane] : 0;
+#pragma unroll
+    for (int u = 0; u < UA; u++) {
+      valid[u] = false; owner[u] = 0; j[u] = 0;
+      if (k0 + u * 64 < total) {      // (uniform)
+        const int k = k0 + u * 64 + lane;
+        int so = wave_max_scan(m[u]), ss = wave_max_scan(m[u] ? k + 1 : 0);
+        so = so > c_own ? so : c_own; ss = ss > c_start ? ss : c_start;
+        valid[u] = k < total;
+        owner[u] = valid[u] ? so - 1 : 0;
+        j[u] = k - (ss - 1);
+        c_own = __builtin_amdgcn_readlane(so, 63); c_start = __builtin_amdgcn_readlane(ss, 63);
+      }
+    }
+    body(valid, owner, j);
+  }
+}
+// N requests per lane with ONE LDS atomic; all 64 lanes must call it together
+template <int N>
+__device__ __forceinline__ void wave_alloc_n(int *counter, const bool (&want)[N], int (&idx)[N]) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  unsigned long long m[N]; int off[N]; int total = 0;
+#pragma unroll
+  for (int u = 0; u < N; u++) { m[u] = __ballot(want[u]); off[u] = total; total += __popcll(m[u]); }
+  int base = 0;
+  if (total) {
+    if (lane == 0) base = atomicAdd(counter, total);
+    base = __builtin_amdgcn_readfirstlane(base);
+  }
+#pragma unroll
+  for (int u = 0; u < N; u++) idx[u] = want[u] ? base + off[u] + __popcll(m[u] & lt) : -1;
+}
 __device__ __forceinline__ int wave_chunk(int n) {
   const int c = (n + NW - 1) / NW;
   return c < 1 ? 1 : (c > 64 ? 64 : c);
@@ -216,7 +279,7 @@ struct Shared {
   unsigned long long vmin[2], vmax[2];   // ... the range of the step's costs beyond the list's 64 (reset by their reader; ~0 / 0 between uses)
   int vb[2], vr[2], vn[2];         //     a slow wave may still be reading the first one's when the second one starts), that step, the
                                    //     statistic's rank within it, the fill of vlist
-  alignas(4) unsigned char wx[NW][64];   // wave_expand: a strip of 64 marker bytes per wave
+  alignas(4) unsigned char wx[NW][64 * 4];   // wave_expand / wave_expand_n: a strip of 64 x UA marker bytes per wave (UA <= 4)
   unsigned hs[HCAP];               // state map of the frame being built: tag,
   unsigned long long hc[HCAP];     // best cost (order-preserving key),
   int ht[HCAP];                    // index of the state's token within the frame
@@ -1004,47 +1067,68 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
             const unsigned long long pre = wave_min_scan_u64(lane == 0 ? sh.init_bound : sh.bmin[lane - 1]);
             bnd_t = shfl_u64(pre, bkt);
           }
-          wave_expand(sh.wx[threadIdx.x >> 6], cnt, [&](bool valid, int owner, int j) {
-            const int ao = __shfl(a0, owner, 64);
-            const int a = (ao & ~EPSBIT) + j;
-            const double cc = __shfl(c, owner, 64);
-            i32x4 arc; double nw = 0.0;
-            unsigned long long kk = ~0ull;
-            if (valid) {
-              arc = uptr(g.arcs)[a];
-              const float ac_cost = -(cfg.acwt * llrow[arc.z]);
-              nw = ((double)asf(arc.y) + cc) + (double)ac_cost;    // arc.weight + tok->cost + ac_cost
-              kk = d2o(nw + (double)adaptive_beam);
-              mymin = kk < mymin ? kk : mymin;
+          wave_expand_n<UA>(sh.wx[threadIdx.x >> 6], cnt, [&](const bool (&valid)[UA], const int (&owner)[UA], const int (&j)[UA]) {
+            int ao[UA], a[UA]; double cc[UA]; i32x4 arc[UA]; float sc[UA];
+#pragma unroll
+            for (int u = 0; u < UA; u++) {
+              ao[u] = __shfl(a0, owner[u], 64);
+              a[u] = (ao[u] & ~EPSBIT) + j[u];
+              cc[u] = __shfl(c, owner[u], 64);
             }
-            bool keep; int bko = 0;
+#pragma unroll
+            for (int u = 0; u < UA; u++) arc[u] = uptr(g.arcs)[valid[u] ? a[u] : 0];
+#pragma unroll
+            for (int u = 0; u < UA; u++) sc[u] = llrow[valid[u] ? arc[u].z : 0];
+            double nw[UA]; unsigned long long kk[UA]; bool keep[UA]; int bko[UA];
+#pragma unroll
+            for (int u = 0; u < UA; u++) {
+              nw[u] = 0.0; kk[u] = ~0ull;
+              if (valid[u]) {
+                const float ac_cost = -(cfg.acwt * sc[u]);
+                nw[u] = ((double)asf(arc[u].y) + cc[u]) + (double)ac_cost;    // arc.weight + tok->cost + ac_cost
+                kk[u] = d2o(nw[u] + (double)adaptive_beam);
+                mymin = kk[u] < mymin ? kk[u] : mymin;
+              }
+            }
             if (ADM == FADM_ORDERED) {
               // Every arc may lower its bucket's minimum, the best token's arcs the initial bound -- but only an arc that gets below the
               // bound of its OWN bucket can change the bound of a later one (those are minima over this bucket's bound and more), so all
               // but the frame's few best arcs spare the atomic.  An arc at or above its bucket's present bound is not written (:266: the
               // final bound is no larger).
-              bko = __shfl(bkt, owner, 64);
-              const unsigned long long bnd = shfl_u64(bnd_t, owner);
-              keep = valid && d2o(nw) < bnd;
-              if (valid) {
-                if (kk < bnd) atomicMin(&sh.bmin[bko], kk);
-                if (ao < 0) atomicMin(&sh.init_bound, kk);
+#pragma unroll
+              for (int u = 0; u < UA; u++) {
+                bko[u] = __shfl(bkt, owner[u], 64);
+                const unsigned long long bnd = shfl_u64(bnd_t, owner[u]);
+                keep[u] = valid[u] && d2o(nw[u]) < bnd;
+                if (valid[u]) {
+                  if (kk[u] < bnd) atomicMin(&sh.bmin[bko[u]], kk[u]);
+                  if (ao[u] < 0) atomicMin(&sh.init_bound, kk[u]);
+                }
               }
             } else {
               // An arc whose new_weight has already reached a bound on next_cutoff -- the smallest new_weight + adaptive_beam anybody in
               // the workgroup has seen so far, kept in LDS -- cannot be admitted (the final next_cutoff is the minimum over all arcs, so
               // it is no larger): it is not written to the candidate list.  The admitted set is still {new_weight < final next_cutoff}.
-              const unsigned long long wk = wave_min_u64(kk);
+              unsigned long long rk = ~0ull;
+#pragma unroll
+              for (int u = 0; u < UA; u++) { bko[u] = 0; rk = kk[u] < rk ? kk[u] : rk; }
+              const unsigned long long wk = wave_min_u64(rk);
               if (lane == 0 && wk != ~0ull) atomicMin(&sh.cand_bound, wk);
-              keep = valid && nw < o2d(sh.cand_bound);
+              const double bound = o2d(sh.cand_bound);
+#pragma unroll
+              for (int u = 0; u < UA; u++) keep[u] = valid[u] && nw[u] < bound;
             }
-            const int q = wave_alloc(&sh.n_cand, keep);
-            if (keep) {
-              if (q < cand_cap) {
-                c_w[q] = nw;
-                i32x4 r; r.x = a; r.y = cur_b + base + owner; r.z = arc.x; r.w = bko;
-                c_r[q] = r;
-              } else sh.error = FERR_CAND;
+            int q[UA];
+            wave_alloc_n<UA>(&sh.n_cand, keep, q);
+#pragma unroll
+            for (int u = 0; u < UA; u++) {
+              if (keep[u]) {
+                if (q[u] < cand_cap) {
+                  c_w[q[u]] = nw[u];
+                  i32x4 r; r.x = a[u]; r.y = cur_b + base + owner[u]; r.z = arc[u].x; r.w = bko[u];
+                  c_r[q[u]] = r;
+                } else sh.error = FERR_CAND;
+              }
             }
           });
         }
