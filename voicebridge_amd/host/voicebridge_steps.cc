@@ -156,6 +156,20 @@ void ForEachJob(int nj, F fn) {
   for (const auto &e : errs) if (!e.empty()) throw StepError(e);
 }
 
+// Utterances per search grid of a job's gmm-latgen-faster: 1024 shared out among the job threads that search side by side on one device
+// (four threads: 256 each, one utterance per CU and the other jobs' grids fill the drains; one thread: 1024 in one grid -- four grids of 256
+// in a row were 4 x 230 ms against 780, round 5), never fewer than 256.  VB_DECODE_BATCH overrides.
+std::string DecodeBatchOption(int nj) {
+  if (const char *e = getenv("VB_DECODE_BATCH")) if (atoi(e) > 0) return std::string("--decode-batch=") + std::to_string(atoi(e));
+  const std::vector<int> devs = StepDevices();
+  std::map<int, int> per_dev;
+  const int nt = (int)std::min<size_t>(std::max<size_t>(devs.size(), 1), (size_t)std::max(nj, 1));
+  for (int t = 0; t < nt; t++) per_dev[devs.empty() ? 0 : devs[(size_t)t]]++;
+  int most = 1;
+  for (const auto &kv : per_dev) most = std::max(most, kv.second);
+  return "--decode-batch=" + std::to_string(std::max(256, 1024 / most));
+}
+
 bool Exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
 bool IsDir(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
 void MakeDir(const std::string &p) {
@@ -605,7 +619,7 @@ void DecodeJob(const DecodeJobs &c, int j) {
   // scoring (GmmLatgenFaster's --fe-* options): the raw features of feats.scp are the only thing read.
   std::vector<std::string> g = {"gmm-latgen-faster", "--max-active=" + std::to_string(c.max_active), "--beam=" + std::to_string(c.beam),
                                 "--lattice-beam=" + std::to_string(c.lattice_beam), "--acoustic-scale=" + std::to_string(c.acwt),
-                                "--allow-partial=true"};
+                                "--allow-partial=true", DecodeBatchOption(c.nj)};
   for (const auto &o : FrontEndOptions(c.srcdir, dsn, c.lda, c.cmvn_opts, c.delta_opts, c.splice_opts)) g.push_back(o);
   if (c.use_trans) g.push_back("--fe-trans=ark:" + (c.trans_all.empty() ? Join(c.trans_dir, "trans." + J) : c.trans_all));
   const std::string symtab = Join(c.graph_dir, "words.txt");
@@ -751,7 +765,7 @@ int DecodeFmllr(const std::string &graphdir, const std::string &data, const std:
     };
     auto open_log = [&](const std::string &J, std::ofstream *log) { log->open(Join(Join(dir, "log"), "fmllr." + J + ".log"), std::ios::binary | std::ios::app); };
     std::vector<std::string> main_opts = {"gmm-latgen-faster", "--max-active=" + std::to_string(max_active), "--beam=" + std::to_string(beam),
-                                          "--lattice-beam=" + std::to_string(lattice_beam), acw, "--determinize-lattice=false", "--allow-partial=true"};
+                                          "--lattice-beam=" + std::to_string(lattice_beam), acw, "--determinize-lattice=false", "--allow-partial=true", DecodeBatchOption(nj)};
     if (Exists(symtab)) main_opts.push_back("--word-symbol-table=" + symtab);
     // ---- the features of every program below: the job's raw feats.scp behind the fused front end (the reference writes
     //      sifeats / transform_pass1feats / final feature archives: decode_fmllr.cpp:275-311, 390-402, 491-500, 568-580); the raw
