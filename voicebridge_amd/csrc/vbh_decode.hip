@@ -153,8 +153,8 @@ constexpr int UL = VBH_UL;                  // ... in the pruning sweeps over li
 constexpr int HBITS = VBH_HBITS;
 constexpr int HCAP = 1 << HBITS;            // slots of the per-frame state map in LDS
 #ifndef VBH_HPROBE
-#define VBH_HPROBE 24
-#endif
+#define VBH_HPROBE 16           // (round 5, same box, ms per 1024 x 30 s: 8 / 12 / 16 / 24 / 48 / 96 probes: 778-780 / 774-776 / 772 / 777-779 / 790-794 / 824: a crowded
+#endif                          //  neighbourhood is given up on sooner; the HBM level takes 3 % of the admissions either way)
 constexpr int HPROBE = VBH_HPROBE;          // probes before a state is sent to the table in HBM
 constexpr unsigned HEMPTY = 0xFFFFFFFFu;
 #ifndef VBH_SPT
