@@ -83,6 +83,12 @@ def test_make_mfcc_cmvn_and_decode_steps(host, tmp_path):
     parts = [(data / "split2" / str(j) / "utt2spk").read_text().split("\n")[:-1] for j in (1, 2)]
     assert sum(len(p) for p in parts) == len(utts) and all(parts)
     assert not ({l.split()[1] for l in parts[0]} & {l.split()[1] for l in parts[1]})
+    # ... and leaves an up-to-date split alone (split_data.cpp:64-82): the files keep their modification times; a newer source splits again
+    stamp = lambda: [os.stat(data / "split2" / str(j) / f).st_mtime_ns for j in (1, 2) for f in ("utt2spk", "feats.scp")]
+    before = stamp()
+    assert host.vb_SplitData(str(data).encode(), 2, 0) == 0 and stamp() == before
+    os.utime(data / "feats.scp", ns=(before[0] + 10**9, before[0] + 10**9))
+    assert host.vb_SplitData(str(data).encode(), 2, 0) == 0 and stamp() != before
     # ---- Decode: model directory exp/tri with final.mdl, graph directory with HCLG.fst
     g = load("files")
     exp = d / "exp" / "tri"

@@ -818,6 +818,7 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     // ---- fused front end (extension, device_feats.h)
     FrontEnd fe;
     fe.Parse(po);
+    lap("front-end options and tables");
     // the writers of an utterance's job (one set, job 0, without --job-of-utt)
     struct JobOut { vbio::LatticeWriter lat; vbio::CompactLatticeWriter clat; vbio::IntVectorWriter words, ali; };
     std::map<std::string, int> job_of_utt;
@@ -852,6 +853,7 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     if (job_of_utt.empty()) (void)out_of_job(0);
     else for (const auto &kv : job_of_utt) (void)out_of_job(kv.second);
 
+    lap("output tables opened");
     int batch_utts = (int)po.Num("decode-batch", 256);
     if (!po.Has("decode-batch")) if (const char *e = getenv("VB_DECODE_BATCH")) { const int x = atoi(e); if (x > 0) batch_utts = x; }      // (tuning: utterances per search grid)
     // the cached workspace serves this call when its capacities cover the search configuration (vbh_decoder_set_cfg: beams and
@@ -872,6 +874,7 @@ int GmmLatgenFaster(int argc, char *argv[], std::ofstream &file_log) {
     vbh_decoder *&dec = cd.dec;
     int &dec_batch = cd.batch, &dec_T = cd.T;
     // the feature table on the device: read and uploaded once per job (the thread's cached copy serves the job's other programs)
+    lap("search configuration");
     const RawTable &tab = CachedRawTable(po.args[2]);
     lap("features to the device");
     double tot_like = 0.0;
