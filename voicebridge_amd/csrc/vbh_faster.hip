@@ -882,9 +882,11 @@ __device__ void make_tokens(const FSlot &s, int tok_base, gp<double> cost_out, g
     for (int u = 0; u < PER; u++) if (have[u]) f(key[u], (unsigned)(st[u] & STMASK));
     for (int i = threadIdx.x; i < ng; i += NT) f(m2.gc[m2.gl[i]], m2.gs[m2.gl[i]] & (unsigned)STMASK);
   }, [&](auto f) {
-#pragma unroll
-    for (int u = 0; u < PER; u++) if (have[u]) f(key[u]);
-    for (int i = threadIdx.x; i < ng; i += NT) f(m2.gc[m2.gl[i]]);
+    // (the counts and the order statistics read the frame's costs where they were just written, token by token: three coalesced loads
+    // per thread and pass whatever the map looks like -- from the map, a thread's eight slots hold anything from none to eight entries,
+    // and every pass gathered the second level's keys through its list again)
+    const int nn = sh.n_new;
+    for (int i = threadIdx.x; i < nn; i += NT) f(d2o(cost_out[i]));
   }, sh.n_new, cfg, sh, par, weight_cutoff, adaptive_beam, best_state);
 }
 
