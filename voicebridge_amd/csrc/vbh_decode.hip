@@ -95,7 +95,7 @@ constexpr int EPSBIT = (int)0x80000000;     // on an arc's next state / a token'
 constexpr int PLDST = 0x40000000;           // on a token's state: the token is the destination of an epsilon link of its frame
 constexpr int STMASK = 0x3FFFFFFF;
 #ifndef VBH_U
-#define VBH_U 2
+#define VBH_U 1                 // (round 5, same box, ms per 1024 x 30 s: 1 / 2 / 3 items per lane in the streaming passes: 765-768 / 775-778 / 812; in round 4 it was 802 / 799 / -)
 #endif
 #ifndef VBH_UL
 #define VBH_UL 1                // (r02 same-box A/B at 1024 threads: 1 / 2 / 4 links per lane in flight in the pruning sweep: 226-229 / 229 / 236 ms per utterance)
@@ -128,7 +128,7 @@ constexpr int U = VBH_U;                    // independent items per lane in the
 #define VBH_UM 4
 #endif
 #ifndef VBH_UA
-#define VBH_UA 4
+#define VBH_UA 3                // (round 5, with VBH_U = 1, same box: 2 / 3 / 4 strips of 64 arcs in flight per wave in pass 1: 769-773 / 759-762 / 767-768 ms; with VBH_U = 2 it was 796 / 783 / 776)
 #endif
 #ifndef VBH_ADM_REFRESH
 #define VBH_ADM_REFRESH 0       // ordered admission, pass 1: 1 = the candidate filter re-reads the buckets' bounds for every 64 x UA arcs
