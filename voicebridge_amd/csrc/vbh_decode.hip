@@ -102,7 +102,7 @@ constexpr int STMASK = 0x3FFFFFFF;
 #endif
 constexpr int U = VBH_U;                    // independent items per lane in the streaming passes
 #ifndef VBH_LINK_PF
-#define VBH_LINK_PF 0           // pruning sweeps: the next round's link records are fetched before this round's are worked on
+#define VBH_LINK_PF 1           // (round 5, with VBH_U = 1 / VBH_UA = 3, same box: 755.2-755.5 against 760.5-760.8 ms; in round 4 it cost registers: 1216) pruning sweeps: the next round's link records are fetched before this round's are worked on
 #endif
 // VBH_LAZY_DST: an emitting link keeps the provisional destination pass 2 gives it -- the destination state's slot in the frame's LDS map
 // -- instead of being read and patched once the frame's tokens are numbered (a pass over every link of the frame: 9 k cycles, and every
@@ -131,7 +131,7 @@ constexpr int U = VBH_U;                    // independent items per lane in the
 #define VBH_UA 3                // (round 5, with VBH_U = 1, same box: 2 / 3 / 4 strips of 64 arcs in flight per wave in pass 1: 769-773 / 759-762 / 767-768 ms; with VBH_U = 2 it was 796 / 783 / 776)
 #endif
 #ifndef VBH_ADM_REFRESH
-#define VBH_ADM_REFRESH 0       // ordered admission, pass 1: 1 = the candidate filter re-reads the buckets' bounds for every 64 x UA arcs
+#define VBH_ADM_REFRESH 1       // (round 5: with the two prefetches 751.4-751.9 against 753.6-754.2 ms) ordered admission, pass 1: 1 = the candidate filter re-reads the buckets' bounds for every 64 x UA arcs
 #endif
 #ifndef VBH_ADM_LATE
 #define VBH_ADM_LATE 0          // ordered admission, pass 1: 1 = an arc fetches its token's {bound, bucket} word when it needs it, not with the token's other words
@@ -142,7 +142,7 @@ constexpr int UM = VBH_UM;                  // ... in the compaction moves
 constexpr int UC = VBH_UC;                  // ... in the candidate passes (LDS-bound: more only costs registers)
 constexpr int UL = VBH_UL;                  // ... in the pruning sweeps over links
 #ifndef VBH_CAND_PF
-#define VBH_CAND_PF 0          // pass 2: the next round's candidates in flight while this round's are admitted
+#define VBH_CAND_PF 1          // (round 5: with VBH_LINK_PF 753.6-754.2 against 755.2-755.5 ms) pass 2: the next round's candidates in flight while this round's are admitted
 #endif
 #ifndef VBH_SEL_SKIP
 #define VBH_SEL_SKIP 1         // GetCutoff's radix select starts below the key bytes all of a frame's costs share (select_kth)
