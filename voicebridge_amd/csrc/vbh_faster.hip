@@ -1151,7 +1151,10 @@ __global__ __launch_bounds__(NT, 4) void faster_kernel(FGraph g, FCfg cfg, const
         gp<int> front0 = uptr(s.front[0]); gp<int> elist0 = uptr(s.elist);
         gp<i32x4> wrec = uptr(s.wrec);
         const int frame_cap = s.frame_cap, front_cap = s.front_cap;
-        constexpr int UC = 2;        // candidates a thread has in flight
+#ifndef VBH_FASTER_UC
+#define VBH_FASTER_UC 2
+#endif
+        constexpr int UC = VBH_FASTER_UC;        // candidates a thread has in flight
         for (int base = 0; base < ncand; base += NT * UC) {
           double nw[UC]; i32x4 r[UC]; bool ok[UC];
 #pragma unroll
