@@ -137,6 +137,25 @@ def test_fmllr_update_on_the_device_vs_host(ctx, D, n_spk):
     gmm.close()
 
 
+def test_fmllr_update_on_the_device_refuses_singular_statistics(ctx):
+    """constant features make every G_d singular: the host's update throws "fMLLR: singular matrix", the device's fails the call with the
+    same words (and names the speaker); statistics of another shape than asked for are refused before anything runs"""
+    import torch
+    from voicebridge_amd import api, synth
+    D, P = 13, 8
+    offs, w, means, iv = synth.gmm_model(P, 16, D, seed=3)
+    gmm = api.DiagGmm(ctx, offs, w, (means * iv).astype(np.float32), iv)
+    T = 900
+    feats = np.zeros((T, D), np.float32)
+    foff = np.array([0, T], np.int64)
+    gmm.fmllr_stats(torch.from_numpy(feats).to(ctx.device), foff, np.zeros(1, np.int32), 1, np.arange(T + 1, dtype=np.int64), np.zeros(T, np.int32), np.ones(T, np.float32))
+    with pytest.raises(RuntimeError, match="singular matrix"):
+        gmm.fmllr_update_full(1, min_count=100.0)
+    with pytest.raises(RuntimeError, match="holds no statistics of 2 speakers"):
+        gmm.fmllr_update_full(2, min_count=100.0)
+    gmm.close()
+
+
 def test_gmm_est_fmllr_bin_function_vs_golden(tmp_path):
     """GmmEstFmllr and the gmm-post-to-gpost | gmm-est-fmllr-gpost pair, both fed by the kernel: the transforms of the
     reference's programs on the golden case"""
