@@ -366,10 +366,18 @@ def test_job_threads_leave_the_same_files(host, tmp_path):
     out = {}
     try:
         # (combined: VB_STEP_COMBINED_SEARCH=1, the searches of all jobs of a step as one batch -- same files)
-        for tag, devs in (("serial", [0]), ("threads", [0, 0, 0]), ("threads_again", []), ("combined", [0, 0, 0])):      # ([]: the default, four job threads on device 0)
-            os.environ.pop("VB_STEP_COMBINED_SEARCH", None)
+        # (file_temps: VB_STEP_FILE_TEMPS=1, the temporaries between the programs as the reference's files instead of in-memory tables --
+        #  posteriors as objects, lattices as bytes; host_update: VB_FMLLR_HOST_UPDATE=1, the fMLLR row update on the host's threads instead
+        #  of the device -- same files again)
+        for tag, devs in (("serial", [0]), ("threads", [0, 0, 0]), ("threads_again", []), ("combined", [0, 0, 0]), ("file_temps", [0, 0, 0]), ("host_update", [0, 0, 0])):      # ([]: the default, four job threads on device 0)
+            for k in ("VB_STEP_COMBINED_SEARCH", "VB_STEP_FILE_TEMPS", "VB_FMLLR_HOST_UPDATE"):
+                os.environ.pop(k, None)
             if tag == "combined":
                 os.environ["VB_STEP_COMBINED_SEARCH"] = "1"
+            if tag == "file_temps":
+                os.environ["VB_STEP_FILE_TEMPS"] = "1"
+            if tag == "host_update":
+                os.environ["VB_FMLLR_HOST_UPDATE"] = "1"
             d = tmp_path / tag
             d.mkdir()
             data, conf, utts = make_datadir(d, n_utt=6, n_spk=3, seconds=4.5)
@@ -404,7 +412,8 @@ def test_job_threads_leave_the_same_files(host, tmp_path):
             out[tag] = files
     finally:
         host.vb_set_step_devices((C.c_int * 1)(), 0)
-        os.environ.pop("VB_STEP_COMBINED_SEARCH", None)
+        for k in ("VB_STEP_COMBINED_SEARCH", "VB_STEP_FILE_TEMPS", "VB_FMLLR_HOST_UPDATE"):
+            os.environ.pop(k, None)
     # The searches, the feature files and the words are the same byte for byte.  The fMLLR statistics are summed with f64 atomics
     # (vbh_fmllr.hip), whose order depends on what else the device is running: transforms agree to rounding, and so do the costs
     # of the final lattices, whose states, arcs and labels are the same.
@@ -418,7 +427,7 @@ def test_job_threads_leave_the_same_files(host, tmp_path):
                 assert fa[2:] == fb[2:] and np.allclose(fa[:2], fb[:2], rtol=1e-4, atol=2e-3) and len(aa) == len(ab)
                 for x, y in zip(aa, ab):
                     assert (x[0], x[3], x[4]) == (y[0], y[3], y[4]) and np.allclose(x[1:3], y[1:3], rtol=1e-4, atol=2e-3)
-    for tag in ("threads", "threads_again", "combined"):
+    for tag in ("threads", "threads_again", "combined", "file_temps", "host_update"):
         assert sorted(out[tag]) == sorted(out["serial"])
         for n, v in out["serial"].items():
             if n.startswith("trans."):
