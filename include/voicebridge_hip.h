@@ -271,7 +271,7 @@ int vbh_decoder_create_shared(vbh_ctx *ctx, const vbh_graph *graph, const vbh_de
 int vbh_decoder_set_cfg(vbh_decoder *d, const vbh_decode_cfg *cfg);
 /* The library holds the search kernel in two layouts and a decoder is made for one of them:
  *   1 = one workgroup of 1024 threads per CU (an utterance has the CU to itself): heavy searches, the default;
- *   2 = two workgroups of 512 threads per CU: light searches (max_active <= 3000, e.g. DecodeFmllr's first pass at beam 10 /
+ *   2 = two workgroups of 512 threads per CU: light searches (max_active <= 4000, e.g. DecodeFmllr's first pass at beam 10 /
  *       max-active 2000), whose frames are a chain of short dependent phases -- two utterances per CU fill each other's waits
  *       (1.4 x the frames per second at those settings; 5 % slower than layout 1 at max-active 7000).
  * Results do not depend on the layout (the same algorithm on a smaller first-level state map; tests/test_gpu_variant.py runs the

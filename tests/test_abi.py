@@ -74,7 +74,7 @@ def test_product_never_imports_the_oracle():
 
 
 def test_search_layout_is_chosen_by_the_configuration(lib, monkeypatch):
-    """vbh_decode_layout_for (no GPU needed): light searches (max_active <= 3000) get the two-workgroups-per-CU layout, the
+    """vbh_decode_layout_for (no GPU needed): light searches (max_active <= 4000) get the two-workgroups-per-CU layout, the
     defaults the one-workgroup layout; VBH_DECODE_LAYOUT overrides either way"""
     from voicebridge_amd import _lib
     monkeypatch.delenv("VBH_DECODE_LAYOUT", raising=False)
@@ -84,7 +84,7 @@ def test_search_layout_is_chosen_by_the_configuration(lib, monkeypatch):
     assert cfg.max_active == 7000 and lib.vbh_decode_layout_for(C.byref(cfg)) == 1
     cfg.max_active = 2000; cfg.beam = 10.0           # DecodeFmllr's first pass
     assert lib.vbh_decode_layout_for(C.byref(cfg)) == 2
-    cfg.max_active = 3001
+    cfg.max_active = 4001
     assert lib.vbh_decode_layout_for(C.byref(cfg)) == 1
     monkeypatch.setenv("VBH_DECODE_LAYOUT", "2")
     assert lib.vbh_decode_layout_for(C.byref(cfg)) == 2

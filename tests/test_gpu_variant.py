@@ -1,6 +1,6 @@
 """Layout 2 of the search kernel (two workgroups of 512 threads per CU, an 8192-slot state map: csrc/vbh_decode.hip "the two builds of this
 file") forced on the heavy configurations it is not chosen for (VBH_DECODE_LAYOUT=2) -- as a race detector and as the
-parity check of the layout the library picks for light searches (max_active <= 3000).  With another workgroup's waves on their SIMDs the waves
+parity check of the layout the library picks for light searches (max_active <= 4000).  With another workgroup's waves on their SIMDs the waves
 of a workgroup skew by hundreds of cycles; round 2 saw memory faults in this configuration and round 3 run-to-run differences (5 utterances
 in 1000, some with cyclic lattices) until the cause was found: the ends of the token / link windows were read behind pass 1's reduction
 barrier, where a late wave could see a faster wave's first allocation of pass 2.  Child processes: the layout is chosen when a

@@ -2706,7 +2706,7 @@ __global__ void fill_arc_pdf_kernel(i32x4 *__restrict__ arcs, const int *__restr
 //              392 -> 279 ms per 1024 x 30 s, same box (round 5).  Until then this build was the race detector of tests/test_gpu_variant.py
 //              (waves skew far more beside another workgroup's); it still is, now inside the product.
 // The second build consists of the device code above and the two entry points below; the host side (first build only) picks a layout
-// per decoder (vbh_decode_layout_for: max_active <= 3000 -> 2; VBH_DECODE_LAYOUT=1|2 overrides) and sizes its slot pools by it.
+// per decoder (vbh_decode_layout_for: max_active <= 4000 -> 2; VBH_DECODE_LAYOUT=1|2 overrides) and sizes its slot pools by it.
 struct LaunchArgs {
   int admission, grid; hipStream_t st;
   DevGraph dg; DecCfg dc; const Slot *slots; SlotPoolDev spool; const float *loglikes; int P;
@@ -2739,7 +2739,7 @@ static const Layout *layout_by_id(int id) {
   return id == 2 ? &l2 : &l1;
 }
 #ifndef VBH_LIGHT_MAX_ACTIVE
-#define VBH_LIGHT_MAX_ACTIVE 3000
+#define VBH_LIGHT_MAX_ACTIVE 4000      // (round 5, beam 13, ms per 1024 x 30 s in layout 1 / 2: max-active 1000: 358 / 238; 3000: 492 / 409; 4000: 562 / 521; 5000: 624 / 636; 7000: 752 / 977)
 #endif
 // Slots of a decoder's pool: one per workgroup that can be resident, or fewer for small batches.  A pool is shared by the decoders of a
 // process (vbh_decoder_create_shared), and in layout 2 a job of 256 utterances fills only half of the device: the pool is made for the
